@@ -1,0 +1,80 @@
+"""ctypes binding of libcdsmvs_hip.so (the C ABI declared in include/cds_mvsnet_hip.h).
+
+The shared object is built in-tree by ``cds_mvsnet_amd/csrc/Makefile`` (``__graft_entry__.build()``)
+with hipcc for gfx950.  There is deliberately NO fallback: if the library is missing the import of
+the ops fails loudly — the product path never routes through PyTorch or CPU code.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_float, c_int, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcdsmvs_hip.so")
+
+# activation / flag codes (mirror include/cds_mvsnet_hip.h)
+ACT_NONE, ACT_RELU, ACT_LEAKY01, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3, 4
+AGG_ACCUMULATE, AGG_NORMALIZE = 1, 2
+MAX_VIEWS = 8
+EINVAL = -1000
+
+P = c_void_p
+I = c_int
+F = c_float
+
+# name -> argtypes; every function returns int
+SIGNATURES = {
+    "cds_version": [],
+    "cds_chw_to_hwc_f32": [P, P, I, I, I, P],
+    "cds_homo_warp_f32": [P, P, P, P, I, I, I, I, I, P],
+    "cds_warp_entropy_f32": [P, P, P, P, P, I, I, I, I, I, I, P],
+    "cds_warp_aggregate_f32": [P, P, P, P, P, P, P, I, I, I, I, I, I, I, P],
+    "cds_volume_normalize_f32": [P, P, I, I, I, P],
+    "cds_softargmin_conf_f32": [P, P, P, P, P, I, I, I, I, P],
+    "cds_depth_hypotheses_f32": [P, P, I, I, I, I, I, I, F, F, F, P],
+    "cds_depth_planes_f32": [P, I, I, I, F, F, P],
+    "cds_conv3d_k3_f32": [P, P, P, P, P, I, I, I, I, I, I, I, P],
+    "cds_deconv3d_k3s2_f32": [P, P, P, P, P, I, I, I, I, I, I, P],
+    "cds_conv2d_f32": [P, P, P, P, I, I, I, I, I, I, I, I, I, P],
+    "cds_dynconv_blend_f32": [P, P, P, P, F, F, F, P, P, I, I, I, I, P],
+    "cds_instnorm_act_f32": [P, P, P, I, I, I, I, I, P],
+}
+
+_lib = None
+
+
+class CdsLibraryError(RuntimeError):
+    pass
+
+
+def load() -> ctypes.CDLL:
+    """Load (once) and return the library; raises CdsLibraryError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise CdsLibraryError(
+            f"{LIB_PATH} not found: build it with `make -C {os.path.join(_HERE, 'csrc')}` "
+            "(or `python -c 'import __graft_entry__ as g; g.build()'`). "
+            "cds_mvsnet_amd has no CPU / PyTorch fallback.")
+    import torch  # noqa: F401  (ensures torch's libamdhip64.so.7 is the one the loader binds to)
+
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:  # pragma: no cover
+            raise CdsLibraryError(f"{LIB_PATH} does not export {name}") from e
+        fn.argtypes = argtypes
+        fn.restype = c_int
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc == 0:
+        return
+    if rc == EINVAL:
+        raise ValueError(f"{what}: invalid argument (CDS_EINVAL)")
+    raise RuntimeError(f"{what}: HIP error {-rc}")

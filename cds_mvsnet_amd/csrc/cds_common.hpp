@@ -1,0 +1,46 @@
+// Shared helpers for the gfx950 kernels of libcdsmvs_hip.so.
+// Built with -ffp-contract=off: every fused multiply-add in this library is an explicit fmaf(),
+// every separately rounded mul/add is written as such, so the fp32 operation order documented in
+// DESIGN.md is what the hardware executes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/cds_mvsnet_hip.h"
+
+#define CDS_WAVE 64
+
+static inline int cds_launch_status() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : -(int)e;
+}
+
+static inline int cds_ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// Bijective XCD-aware remap of a linear workgroup id (guide T1): the dispatcher places block b on
+// XCD b % 8, so consecutive logical tiles are handed to the same XCD to share its private L2.
+__device__ __forceinline__ int cds_xcd_remap(int bid, int nwg) {
+  const int nx = 8;
+  if (nwg < 2 * nx) return bid;
+  int q = nwg / nx, r = nwg % nx;
+  int xcd = bid % nx, idx = bid / nx;
+  int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + idx;
+}
+
+// lean epilogue activation for the conv kernels (none / ReLU / sigmoid)
+__device__ __forceinline__ float cds_act_conv(float v, int act) {
+  if (act == CDS_ACT_RELU) return fmaxf(v, 0.0f);
+  if (act == CDS_ACT_SIGMOID) return 1.0f / (1.0f + expf(-v));
+  return v;
+}
+
+__device__ __forceinline__ float cds_apply_act(float v, int act) {
+  switch (act) {
+    case CDS_ACT_RELU: return fmaxf(v, 0.0f);
+    case CDS_ACT_LEAKY01: return v > 0.0f ? v : v * 0.1f;
+    case CDS_ACT_SIGMOID: return 1.0f / (1.0f + expf(-v));
+    case CDS_ACT_TANH: return tanhf(v);
+    default: return v;
+  }
+}

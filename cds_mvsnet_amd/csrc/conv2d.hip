@@ -1,0 +1,292 @@
+// 2D feature path:
+//   cds_conv2d_f32         direct LDS-tiled k x k convolution (k in 1,3,5,7,11; stride 1|2)
+//                          models/module.py:28-71, models/dynamic_conv.py:86-87,112,116, model.py:14
+//   cds_dynconv_blend_f32  DynamicConv epilogue: epipolar curvature projection, 1x1 MLP,
+//                          softmax(./T), blend                       models/dynamic_conv.py:97-122
+//   cds_instnorm_act_f32   InstanceNorm2d (+LeakyReLU(0.1) | tanh)   models/module.py:53,66-69,223
+//
+// Convolution scheme (same as conv3d.hip): input tile + halo of CI_CHUNK channels in LDS, PX
+// x-adjacent outputs x 8 output channels of accumulators per thread, weights packed
+// [Cin][k*k][CoutP] (cout fastest, CoutP = Cout rounded up to 8, zero padded) and fetched as
+// wave-uniform scalar loads.
+#include "cds_common.hpp"
+
+namespace {
+
+constexpr int CO = 8;
+
+template <int K, int S, int PX, int CI_CHUNK>
+struct C2Cfg {
+  static constexpr int LX = 16, LY = 16;
+  static constexpr int TX = LX * PX, TY = LY;
+  static constexpr int IX = (TX - 1) * S + K, IY = (TY - 1) * S + K;
+  static constexpr int IXP = (IX + 3) & ~3;
+  static constexpr int TILE = IY * IXP;
+  static constexpr int NIN = (PX - 1) * S + K;
+};
+
+template <int K, int S, int PX, int CI_CHUNK>
+__global__ __launch_bounds__(256) void conv2d_kernel(const float* __restrict__ x, const float* __restrict__ wpk,
+                                                     const float* __restrict__ bias, float* __restrict__ out, int N,
+                                                     int Cin, int Cout, int CoutP, int H, int W, int Ho, int Wo, int pad,
+                                                     int act, int tiles_x, int tiles_y) {
+  using Cfg = C2Cfg<K, S, PX, CI_CHUNK>;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int co_blocks = CoutP / CO;
+  const int ntiles = tiles_x * tiles_y;
+  int lin = cds_xcd_remap(blockIdx.x, ntiles * co_blocks * N);
+  const int cob = lin % co_blocks;
+  lin /= co_blocks;
+  const int tile = lin % ntiles;
+  const int n = lin / ntiles;
+  const int tx_i = tile % tiles_x, ty_i = tile / tiles_x;
+  const int co0 = cob * CO;
+  const int tid = threadIdx.x;
+  const int lx = tid % Cfg::LX, ly = tid / Cfg::LX;
+  const int ox0 = tx_i * Cfg::TX, oy0 = ty_i * Cfg::TY;
+  const int gx0 = ox0 * S - pad, gy0 = oy0 * S - pad;
+  const size_t plane = (size_t)H * W;
+  const float* __restrict__ xn = x + (size_t)n * Cin * plane;
+
+  float acc[PX][CO];
+#pragma unroll
+  for (int p = 0; p < PX; ++p)
+#pragma unroll
+    for (int c = 0; c < CO; ++c) acc[p][c] = 0.f;
+
+  for (int ci0 = 0; ci0 < Cin; ci0 += CI_CHUNK) {
+    __syncthreads();
+    const int nrows = CI_CHUNK * Cfg::IY;
+    for (int row = tid / 64; row < nrows; row += 4) {
+      const int ci = row / Cfg::IY, ry = row % Cfg::IY;
+      const int gy = gy0 + ry;
+      const bool row_ok = (ci0 + ci < Cin) && gy >= 0 && gy < H;
+      const float* __restrict__ src = xn + (size_t)(ci0 + ci) * plane + (size_t)gy * W;
+      float* dst = lds + ci * Cfg::TILE + ry * Cfg::IXP;
+      for (int i = tid & 63; i < Cfg::IXP; i += 64) {
+        const int gx = gx0 + i;
+        float v = 0.f;
+        if (row_ok && gx >= 0 && gx < W && i < Cfg::IX) v = src[gx];
+        dst[i] = v;
+      }
+    }
+    __syncthreads();
+    const int cmax = min(CI_CHUNK, Cin - ci0);
+    for (int ci = 0; ci < cmax; ++ci) {
+      const float* __restrict__ wc = wpk + ((size_t)(ci0 + ci) * K * K) * CoutP + co0;
+      const float* tile_ci = lds + ci * Cfg::TILE;
+#pragma unroll
+      for (int ky = 0; ky < K; ++ky) {
+        const float* rowp = tile_ci + (ly * S + ky) * Cfg::IXP + lx * PX * S;
+        float in[Cfg::NIN];
+#pragma unroll
+        for (int i = 0; i < Cfg::NIN; ++i) in[i] = rowp[i];
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx) {
+#pragma unroll
+          for (int c = 0; c < CO; ++c) {
+            const float wv = wc[(ky * K + kx) * CoutP + c];
+#pragma unroll
+            for (int p = 0; p < PX; ++p) acc[p][c] = fmaf(in[p * S + kx], wv, acc[p][c]);
+          }
+        }
+      }
+    }
+  }
+
+  const int oy = oy0 + ly, oxb = ox0 + lx * PX;
+  if (oy >= Ho) return;
+  const size_t oplane = (size_t)Ho * Wo;
+#pragma unroll
+  for (int c = 0; c < CO; ++c) {
+    if (co0 + c < Cout) {
+      const float b = bias ? bias[co0 + c] : 0.f;
+      const size_t base = ((size_t)n * Cout + co0 + c) * oplane + (size_t)oy * Wo + oxb;
+#pragma unroll
+      for (int p = 0; p < PX; ++p)
+        if (oxb + p < Wo) out[base + p] = cds_act_conv(acc[p][c] + b, act);
+    }
+  }
+}
+
+template <int K, int S, int PX, int CI_CHUNK>
+int launch_conv2d(const float* x, const float* w, const float* b, float* out, int N, int Cin, int Cout, int H, int W,
+                  int pad, int act, hipStream_t st) {
+  using Cfg = C2Cfg<K, S, PX, CI_CHUNK>;
+  const int Ho = (H + 2 * pad - K) / S + 1, Wo = (W + 2 * pad - K) / S + 1;
+  const int CoutP = (Cout + CO - 1) / CO * CO;
+  const int tx = cds_ceil_div(Wo, Cfg::TX), ty = cds_ceil_div(Ho, Cfg::TY);
+  const size_t lds_bytes = (size_t)Cfg::TILE * CI_CHUNK * sizeof(float);
+  auto kern = conv2d_kernel<K, S, PX, CI_CHUNK>;
+  hipLaunchKernelGGL(kern, dim3(tx * ty * (CoutP / CO) * N), dim3(256), lds_bytes, st, x, w, b, out, N, Cin, Cout,
+                     CoutP, H, W, Ho, Wo, pad, act, tx, ty);
+  return cds_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------
+// DynamicConv epilogue.  `branch` holds, for each kernel size k, the Cout conv responses followed
+// by the 3 curvature responses: [K][Cout+3][H][W].
+// ---------------------------------------------------------------------------------------------
+template <int K>
+__global__ __launch_bounds__(256) void dynconv_blend_kernel(const float* __restrict__ branch,
+                                                            const float* __restrict__ w1, const float* __restrict__ b1,
+                                                            const float* __restrict__ w2, float epi_x, float epi_y,
+                                                            float temperature, float* __restrict__ out,
+                                                            float* __restrict__ norm_curv, int Cout, int H, int W) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  const int hw = H * W;
+  if (p >= hw) return;
+  const int y = p / W, x = p % W;
+  float u = (float)x - epi_x, v = (float)y - epi_y;
+  const float nrm = sqrtf(u * u + v * v);
+  u = u / (nrm + 1e-6f);
+  v = v / (nrm + 1e-6f);
+  const float b0 = u * u, b1v = 2.0f * u * v, b2 = v * v;
+  const size_t bstride = (size_t)(Cout + 3) * hw;
+  float curv[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const float* a = branch + k * bstride + (size_t)Cout * hw + p;
+    curv[k] = a[0] * b0 + a[hw] * b1v + a[2 * (size_t)hw] * b2;
+  }
+  float hid[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) s = fmaf(w1[j * K + k], curv[k], s);
+    hid[j] = fmaxf(s + b1[j], 0.f);
+  }
+  float logit[K], mx = -INFINITY;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s = fmaf(w2[k * 4 + j], hid[j], s);
+    logit[k] = s / temperature;
+    mx = fmaxf(mx, logit[k]);
+  }
+  float den = 0.f;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    logit[k] = expf(logit[k] - mx);
+    den += logit[k];
+  }
+  float nc = 0.f;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    logit[k] = logit[k] / den;
+    nc = nc + curv[k] * logit[k];
+  }
+  norm_curv[p] = nc;
+  for (int c = 0; c < Cout; ++c) {
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) s = s + branch[k * bstride + (size_t)c * hw + p] * logit[k];
+    out[(size_t)c * hw + p] = s;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// InstanceNorm: per-channel sum / sum of squares in fp64 (ATen's CPU kernel accumulates float
+// statistics in double), wave-shuffle + one atomic per block; then y = act(x*alpha + beta).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void instnorm_stats_kernel(const float* __restrict__ x, double* __restrict__ stats,
+                                                             int hw, int blocks_per_c) {
+  const int c = blockIdx.x / blocks_per_c, b = blockIdx.x % blocks_per_c;
+  const float* __restrict__ xc = x + (size_t)c * hw;
+  double s = 0.0, q = 0.0;
+  for (int i = b * 256 + threadIdx.x; i < hw; i += blocks_per_c * 256) {
+    double v = (double)xc[i];
+    s += v;
+    q += v * v;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    s += __shfl_xor(s, o);
+    q += __shfl_xor(q, o);
+  }
+  __shared__ double red[2][4];
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    red[0][wave] = s;
+    red[1][wave] = q;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(&stats[2 * c + 0], red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+    atomicAdd(&stats[2 * c + 1], red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+  }
+}
+
+__global__ __launch_bounds__(256) void instnorm_apply_kernel(const float* __restrict__ x,
+                                                             const double* __restrict__ stats, float* __restrict__ out,
+                                                             int C, int hw, int act, int out_hwc) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= hw) return;
+  for (int c = 0; c < C; ++c) {
+    const double mean = stats[2 * c] / hw;
+    double var = stats[2 * c + 1] / hw - mean * mean;
+    var = var < 0.0 ? 0.0 : var;
+    const float invstd = (float)(1.0 / sqrt(var + 1e-5));
+    const float alpha = invstd, beta = -(float)mean * invstd;
+    float v = cds_apply_act(x[(size_t)c * hw + p] * alpha + beta, act);
+    if (out_hwc)
+      out[(size_t)p * C + c] = v;
+    else
+      out[(size_t)c * hw + p] = v;
+  }
+}
+
+}  // namespace
+
+extern "C" int cds_conv2d_f32(const float* x, const float* weight, const float* bias, float* out, int N, int Cin,
+                              int Cout, int H, int W, int k, int stride, int pad, int act, void* stream) {
+  if (!x || !weight || !out || N < 1 || Cin < 1 || Cout < 1 || H < 1 || W < 1 || pad < 0) return CDS_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  if (stride == 1) {
+    switch (k) {
+      case 1: return launch_conv2d<1, 1, 4, 8>(x, weight, bias, out, N, Cin, Cout, H, W, pad, act, st);
+      case 3: return launch_conv2d<3, 1, 4, 4>(x, weight, bias, out, N, Cin, Cout, H, W, pad, act, st);
+      case 5: return launch_conv2d<5, 1, 4, 4>(x, weight, bias, out, N, Cin, Cout, H, W, pad, act, st);
+      case 7: return launch_conv2d<7, 1, 4, 4>(x, weight, bias, out, N, Cin, Cout, H, W, pad, act, st);
+      case 11: return launch_conv2d<11, 1, 4, 4>(x, weight, bias, out, N, Cin, Cout, H, W, pad, act, st);
+      default: return CDS_EINVAL;
+    }
+  }
+  if (stride == 2 && k == 3) return launch_conv2d<3, 2, 2, 4>(x, weight, bias, out, N, Cin, Cout, H, W, pad, act, st);
+  return CDS_EINVAL;
+}
+
+extern "C" int cds_dynconv_blend_f32(const float* branches, const float* w1, const float* b1, const float* w2,
+                                     float epi_x, float epi_y, float temperature, float* out, float* norm_curv, int K,
+                                     int Cout, int H, int W, void* stream) {
+  if (!branches || !w1 || !b1 || !w2 || !out || !norm_curv || Cout < 1 || H < 1 || W < 1) return CDS_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(cds_ceil_div(H * W, 256)), block(256);
+  if (K == 2)
+    hipLaunchKernelGGL(dynconv_blend_kernel<2>, grid, block, 0, st, branches, w1, b1, w2, epi_x, epi_y, temperature, out,
+                       norm_curv, Cout, H, W);
+  else if (K == 3)
+    hipLaunchKernelGGL(dynconv_blend_kernel<3>, grid, block, 0, st, branches, w1, b1, w2, epi_x, epi_y, temperature, out,
+                       norm_curv, Cout, H, W);
+  else
+    return CDS_EINVAL;
+  return cds_launch_status();
+}
+
+extern "C" int cds_instnorm_act_f32(const float* x, float* out, float* stats, int C, int H, int W, int act, int out_hwc,
+                                    void* stream) {
+  if (!x || !out || !stats || C < 1 || H < 1 || W < 1) return CDS_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int hw = H * W;
+  double* dstats = reinterpret_cast<double*>(stats);  // scratch: 2*C doubles = 4*C floats
+  hipError_t e = hipMemsetAsync(dstats, 0, sizeof(double) * 2 * C, st);
+  if (e != hipSuccess) return -(int)e;
+  int bpc = cds_ceil_div(hw, 256 * 16);
+  if (bpc < 1) bpc = 1;
+  hipLaunchKernelGGL(instnorm_stats_kernel, dim3(C * bpc), dim3(256), 0, st, x, dstats, hw, bpc);
+  hipLaunchKernelGGL(instnorm_apply_kernel, dim3(cds_ceil_div(hw, 256)), dim3(256), 0, st, x, dstats, out, C, hw, act,
+                     out_hwc);
+  return cds_launch_status();
+}

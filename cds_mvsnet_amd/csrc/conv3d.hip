@@ -1,0 +1,301 @@
+// K4: CostRegNet building blocks as direct LDS-tiled 3x3x3 kernels (no im2col).
+//   cds_conv3d_k3_f32      Conv3d k3 p1 stride 1|2 (+bias +ReLU +residual)   module.py:80-116
+//   cds_deconv3d_k3s2_f32  ConvTranspose3d k3 s2 p1 op1 (+bias +ReLU +residual) module.py:125-160
+//
+// Scheme: a workgroup owns an output tile and all of a block of CO output channels.  The input
+// tile (with halo) of CI_CHUNK input channels is staged in LDS; every thread keeps PX x-adjacent
+// voxels x CO channels of accumulators in registers.  Weights are pre-packed [Cin][27][Cout]
+// (cout fastest) so the 3*CO weights of one (cin,kz,ky) row are contiguous and wave-uniform: they
+// are fetched through the scalar cache into SGPRs and feed v_fmac directly (no LDS / VGPR cost).
+// fp32 accumulate with explicit fmaf, order: cin-major, then kz, ky, kx.
+#include "cds_common.hpp"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// forward conv, stride S in {1,2}
+// thread layout LX x LY x LZ (=256 threads), each thread PX outputs along x.
+// ---------------------------------------------------------------------------------------------
+template <int S, int LX, int LY, int LZ, int PX, int CO, int CI_CHUNK>
+struct ConvCfg {
+  static constexpr int TX = LX * PX, TY = LY, TZ = LZ;                    // output tile
+  static constexpr int IX = (TX - 1) * S + 3, IY = (TY - 1) * S + 3, IZ = (TZ - 1) * S + 3;  // input tile
+  static constexpr int IXP = (IX + 3) & ~3;                                // row stride (16-byte rows)
+  static constexpr int TILE = IZ * IY * IXP;
+  static constexpr int LDS_FLOATS = TILE * CI_CHUNK;
+  static constexpr int NIN = (PX - 1) * S + 3;                             // inputs per row per thread
+};
+
+template <int S, int LX, int LY, int LZ, int PX, int CO, int CI_CHUNK>
+__global__ __launch_bounds__(256) void conv3d_k3_kernel(const float* __restrict__ x, const float* __restrict__ wpk,
+                                                        const float* __restrict__ bias, const float* __restrict__ skip,
+                                                        float* __restrict__ out, int Cin, int Cout, int D, int H, int W,
+                                                        int Do, int Ho, int Wo, int act, int tiles_x, int tiles_y,
+                                                        int tiles_z, int ntiles) {
+  using Cfg = ConvCfg<S, LX, LY, LZ, PX, CO, CI_CHUNK>;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+
+  const int co_blocks = Cout / CO;  // host guarantees divisibility (or CO == Cout)
+  int lin = cds_xcd_remap(blockIdx.x, ntiles * co_blocks);
+  const int cob = lin % co_blocks;
+  int tile = lin / co_blocks;
+  const int tx_i = tile % tiles_x;
+  tile /= tiles_x;
+  const int ty_i = tile % tiles_y;
+  const int tz_i = tile / tiles_y;
+  const int co0 = cob * CO;
+
+  const int tid = threadIdx.x;
+  const int lx = tid % LX, ly = (tid / LX) % LY, lz = tid / (LX * LY);
+  const int ox0 = tx_i * Cfg::TX, oy0 = ty_i * Cfg::TY, oz0 = tz_i * Cfg::TZ;
+  // input-space origin of the tile (padding 1)
+  const int gx0 = ox0 * S - 1, gy0 = oy0 * S - 1, gz0 = oz0 * S - 1;
+
+  float acc[PX][CO];
+#pragma unroll
+  for (int p = 0; p < PX; ++p)
+#pragma unroll
+    for (int c = 0; c < CO; ++c) acc[p][c] = 0.f;
+
+  const size_t plane = (size_t)H * W, vol = (size_t)D * plane;
+
+  for (int ci0 = 0; ci0 < Cin; ci0 += CI_CHUNK) {
+    __syncthreads();
+    // ---- stage: rows of the input tile, one (ci,z,y) row at a time per LX*? threads ----
+    const int nrows = CI_CHUNK * Cfg::IZ * Cfg::IY;
+    for (int row = tid / 64; row < nrows; row += 4) {  // each wave stages whole rows
+      const int ci = row / (Cfg::IZ * Cfg::IY);
+      const int rz = (row / Cfg::IY) % Cfg::IZ;
+      const int ry = row % Cfg::IY;
+      const int gz = gz0 + rz, gy = gy0 + ry;
+      const bool row_ok = (ci0 + ci < Cin) && gz >= 0 && gz < D && gy >= 0 && gy < H;
+      const float* __restrict__ src = x + (size_t)(ci0 + ci) * vol + (size_t)gz * plane + (size_t)gy * W;
+      float* dst = lds + (size_t)ci * Cfg::TILE + (rz * Cfg::IY + ry) * Cfg::IXP;
+      for (int i = tid & 63; i < Cfg::IXP; i += 64) {
+        const int gx = gx0 + i;
+        float v = 0.f;
+        if (row_ok && gx >= 0 && gx < W && i < Cfg::IX) v = src[gx];
+        dst[i] = v;
+      }
+    }
+    __syncthreads();
+    // ---- compute ----
+    const int cmax = min(CI_CHUNK, Cin - ci0);
+    for (int ci = 0; ci < cmax; ++ci) {
+      const float* __restrict__ wc = wpk + ((size_t)(ci0 + ci) * 27) * Cout + co0;
+      const float* tile_ci = lds + (size_t)ci * Cfg::TILE;
+#pragma unroll
+      for (int kz = 0; kz < 3; ++kz) {
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+          const float* rowp = tile_ci + ((lz * S + kz) * Cfg::IY + (ly * S + ky)) * Cfg::IXP + lx * PX * S;
+          float in[Cfg::NIN];
+#pragma unroll
+          for (int i = 0; i < Cfg::NIN; ++i) in[i] = rowp[i];
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) {
+#pragma unroll
+            for (int c = 0; c < CO; ++c) {
+              const float wv = wc[((kz * 3 + ky) * 3 + kx) * Cout + c];
+#pragma unroll
+              for (int p = 0; p < PX; ++p) acc[p][c] = fmaf(in[p * S + kx], wv, acc[p][c]);
+            }
+          }
+        }
+      }
+    }
+  }
+
+  // ---- epilogue ----
+  const int oz = oz0 + lz, oy = oy0 + ly, oxb = ox0 + lx * PX;
+  if (oz >= Do || oy >= Ho) return;
+  const size_t oplane = (size_t)Ho * Wo, ovol = (size_t)Do * oplane;
+#pragma unroll
+  for (int c = 0; c < CO; ++c) {
+    const float b = bias ? bias[co0 + c] : 0.f;
+    const size_t base = (size_t)(co0 + c) * ovol + (size_t)oz * oplane + (size_t)oy * Wo + oxb;
+#pragma unroll
+    for (int p = 0; p < PX; ++p) {
+      if (oxb + p < Wo) {
+        float v = (act == CDS_ACT_RELU ? fmaxf(acc[p][c] + b, 0.f) : acc[p][c] + b);
+        if (skip) v = skip[base + p] + v;
+        out[base + p] = v;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// transposed conv k3 s2 p1 op1.  A thread owns one input-space cell a=(az,ay,ax) and produces the
+// 2x2x2 output voxels (2a+{0,1}) for CO channels.  Along one axis, output 2a uses (input a, tap 1)
+// and output 2a+1 uses (input a+1, tap 0) and (input a, tap 2).
+// wpk layout [Cin][27][Cout], tap index (kz*3+ky)*3+kx, taken from PyTorch's [Cin][Cout][3][3][3].
+// ---------------------------------------------------------------------------------------------
+template <int LX, int LY, int LZ, int CO, int CI_CHUNK>
+__global__ __launch_bounds__(256) void deconv3d_k3s2_kernel(const float* __restrict__ x, const float* __restrict__ wpk,
+                                                            const float* __restrict__ bias,
+                                                            const float* __restrict__ skip, float* __restrict__ out,
+                                                            int Cin, int Cout, int D, int H, int W, int act, int tiles_x,
+                                                            int tiles_y, int tiles_z, int ntiles) {
+  constexpr int IX = LX + 1, IY = LY + 1, IZ = LZ + 1;
+  constexpr int TILE = IZ * IY * IX;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+
+  const int co_blocks = Cout / CO;
+  int lin = cds_xcd_remap(blockIdx.x, ntiles * co_blocks);
+  const int cob = lin % co_blocks;
+  int tile = lin / co_blocks;
+  const int tx_i = tile % tiles_x;
+  tile /= tiles_x;
+  const int ty_i = tile % tiles_y;
+  const int tz_i = tile / tiles_y;
+  const int co0 = cob * CO;
+
+  const int tid = threadIdx.x;
+  const int lx = tid % LX, ly = (tid / LX) % LY, lz = tid / (LX * LY);
+  const int ax0 = tx_i * LX, ay0 = ty_i * LY, az0 = tz_i * LZ;
+
+  float acc[8][CO];
+#pragma unroll
+  for (int q = 0; q < 8; ++q)
+#pragma unroll
+    for (int c = 0; c < CO; ++c) acc[q][c] = 0.f;
+
+  const size_t plane = (size_t)H * W, vol = (size_t)D * plane;
+
+  for (int ci0 = 0; ci0 < Cin; ci0 += CI_CHUNK) {
+    __syncthreads();
+    for (int i = tid; i < TILE * CI_CHUNK; i += 256) {
+      const int ci = i / TILE;
+      int r = i % TILE;
+      const int rx = r % IX;
+      r /= IX;
+      const int ry = r % IY, rz = r / IY;
+      const int gz = az0 + rz, gy = ay0 + ry, gx = ax0 + rx;
+      float v = 0.f;
+      if (ci0 + ci < Cin && gz < D && gy < H && gx < W) v = x[(size_t)(ci0 + ci) * vol + (size_t)gz * plane + (size_t)gy * W + gx];
+      lds[i] = v;
+    }
+    __syncthreads();
+    const int cmax = min(CI_CHUNK, Cin - ci0);
+    for (int ci = 0; ci < cmax; ++ci) {
+      const float* __restrict__ wc = wpk + ((size_t)(ci0 + ci) * 27) * Cout + co0;
+      const float* t = lds + (size_t)ci * TILE + (lz * IY + ly) * IX + lx;
+      float in[2][2][2];
+#pragma unroll
+      for (int dz = 0; dz < 2; ++dz)
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+          for (int dx = 0; dx < 2; ++dx) in[dz][dy][dx] = t[(dz * IY + dy) * IX + dx];
+      // per axis: parity 0 -> {(in 0, tap 1)}; parity 1 -> {(in 1, tap 0), (in 0, tap 2)}
+#pragma unroll
+      for (int pz = 0; pz < 2; ++pz)
+#pragma unroll
+        for (int py = 0; py < 2; ++py)
+#pragma unroll
+          for (int px = 0; px < 2; ++px) {
+            const int q = (pz * 2 + py) * 2 + px;
+#pragma unroll
+            for (int sz = 0; sz <= pz; ++sz)
+#pragma unroll
+              for (int sy = 0; sy <= py; ++sy)
+#pragma unroll
+                for (int sx = 0; sx <= px; ++sx) {
+                  const int iz = pz ? 1 - sz : 0, kz = pz ? 2 * sz : 1;
+                  const int iy = py ? 1 - sy : 0, ky = py ? 2 * sy : 1;
+                  const int ix = px ? 1 - sx : 0, kx = px ? 2 * sx : 1;
+                  const float v = in[iz][iy][ix];
+#pragma unroll
+                  for (int c = 0; c < CO; ++c)
+                    acc[q][c] = fmaf(v, wc[((kz * 3 + ky) * 3 + kx) * Cout + c], acc[q][c]);
+                }
+          }
+    }
+  }
+
+  const int az = az0 + lz, ay = ay0 + ly, ax = ax0 + lx;
+  if (az >= D || ay >= H || ax >= W) return;
+  const int Do = 2 * D, Ho = 2 * H, Wo = 2 * W;
+  const size_t oplane = (size_t)Ho * Wo, ovol = (size_t)Do * oplane;
+#pragma unroll
+  for (int c = 0; c < CO; ++c) {
+    const float b = bias ? bias[co0 + c] : 0.f;
+#pragma unroll
+    for (int pz = 0; pz < 2; ++pz)
+#pragma unroll
+      for (int py = 0; py < 2; ++py) {
+        const size_t base = (size_t)(co0 + c) * ovol + (size_t)(2 * az + pz) * oplane + (size_t)(2 * ay + py) * Wo + 2 * ax;
+        float2 v;
+        v.x = acc[(pz * 2 + py) * 2 + 0][c] + b;
+        v.y = acc[(pz * 2 + py) * 2 + 1][c] + b;
+        if (act == CDS_ACT_RELU) {
+          v.x = fmaxf(v.x, 0.f);
+          v.y = fmaxf(v.y, 0.f);
+        }
+        if (skip) {
+          const float2 s = *reinterpret_cast<const float2*>(skip + base);
+          v.x = s.x + v.x;
+          v.y = s.y + v.y;
+        }
+        *reinterpret_cast<float2*>(out + base) = v;
+      }
+  }
+}
+
+template <int S, int LX, int LY, int LZ, int PX, int CO, int CI_CHUNK>
+int launch_conv(const float* x, const float* w, const float* b, const float* skip, float* out, int Cin, int Cout, int D,
+                int H, int W, int act, hipStream_t st) {
+  using Cfg = ConvCfg<S, LX, LY, LZ, PX, CO, CI_CHUNK>;
+  const int Do = (D - 1) / S + 1, Ho = (H - 1) / S + 1, Wo = (W - 1) / S + 1;
+  const int tx = cds_ceil_div(Wo, Cfg::TX), ty = cds_ceil_div(Ho, Cfg::TY), tz = cds_ceil_div(Do, Cfg::TZ);
+  const int ntiles = tx * ty * tz;
+  const size_t lds_bytes = (size_t)Cfg::LDS_FLOATS * sizeof(float);
+  auto kern = conv3d_k3_kernel<S, LX, LY, LZ, PX, CO, CI_CHUNK>;
+  hipLaunchKernelGGL(kern, dim3(ntiles * (Cout / CO)), dim3(256), lds_bytes, st, x, w, b, skip, out, Cin, Cout, D, H, W,
+                     Do, Ho, Wo, act, tx, ty, tz, ntiles);
+  return cds_launch_status();
+}
+
+template <int LX, int LY, int LZ, int CO, int CI_CHUNK>
+int launch_deconv(const float* x, const float* w, const float* b, const float* skip, float* out, int Cin, int Cout,
+                  int D, int H, int W, int act, hipStream_t st) {
+  const int tx = cds_ceil_div(W, LX), ty = cds_ceil_div(H, LY), tz = cds_ceil_div(D, LZ);
+  const int ntiles = tx * ty * tz;
+  const size_t lds_bytes = (size_t)(LX + 1) * (LY + 1) * (LZ + 1) * CI_CHUNK * sizeof(float);
+  auto kern = deconv3d_k3s2_kernel<LX, LY, LZ, CO, CI_CHUNK>;
+  hipLaunchKernelGGL(kern, dim3(ntiles * (Cout / CO)), dim3(256), lds_bytes, st, x, w, b, skip, out, Cin, Cout, D, H, W,
+                     act, tx, ty, tz, ntiles);
+  return cds_launch_status();
+}
+
+}  // namespace
+
+extern "C" int cds_conv3d_k3_f32(const float* x, const float* weight, const float* bias, const float* skip, float* out,
+                                 int Cin, int Cout, int D, int H, int W, int stride, int act, void* stream) {
+  if (!x || !weight || !out || Cin < 1 || Cout < 1 || D < 1 || H < 1 || W < 1 || (stride != 1 && stride != 2))
+    return CDS_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int Wo = (W - 1) / stride + 1;
+  const bool wide = Wo >= 48;
+  if (Cout == 1) {
+    if (stride != 1) return CDS_EINVAL;
+    return wide ? launch_conv<1, 16, 4, 4, 4, 1, 4>(x, weight, bias, skip, out, Cin, Cout, D, H, W, act, st)
+                : launch_conv<1, 4, 8, 8, 4, 1, 4>(x, weight, bias, skip, out, Cin, Cout, D, H, W, act, st);
+  }
+  if (Cout % 8) return CDS_EINVAL;
+  if (stride == 1) {
+    return wide ? launch_conv<1, 16, 4, 4, 4, 8, 4>(x, weight, bias, skip, out, Cin, Cout, D, H, W, act, st)
+                : launch_conv<1, 4, 8, 8, 4, 8, 4>(x, weight, bias, skip, out, Cin, Cout, D, H, W, act, st);
+  }
+  return wide ? launch_conv<2, 16, 4, 4, 2, 8, 2>(x, weight, bias, skip, out, Cin, Cout, D, H, W, act, st)
+              : launch_conv<2, 4, 8, 8, 2, 8, 2>(x, weight, bias, skip, out, Cin, Cout, D, H, W, act, st);
+}
+
+extern "C" int cds_deconv3d_k3s2_f32(const float* x, const float* weight, const float* bias, const float* skip,
+                                     float* out, int Cin, int Cout, int D, int H, int W, int act, void* stream) {
+  if (!x || !weight || !out || Cin < 1 || Cout < 1 || (Cout % 8) || D < 1 || H < 1 || W < 1) return CDS_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  return W >= 48 ? launch_deconv<64, 2, 2, 8, 8>(x, weight, bias, skip, out, Cin, Cout, D, H, W, act, st)
+                 : launch_deconv<16, 4, 4, 8, 8>(x, weight, bias, skip, out, Cin, Cout, D, H, W, act, st);
+}

@@ -1,0 +1,391 @@
+// Plane-sweep warp kernels: homography warp, K1 warp-correlate-entropy, K3 warp-aggregate.
+// Replaces models/utils/warping.py:69-104 + models/model.py:44-50,57-60,74 of the reference.
+//
+// fp32 operation order (pinned against ATen's CPU kernels, see oracle/cds_oracle.py):
+//   r   = fma(R2, 1, fma(R1, y, R0*x))            (sgemm with K=3)
+//   p   = r*d (rounded) + t (rounded)
+//   u   = p.x / (p.z + 1e-6)   v = p.y / (p.z + 1e-6)        true IEEE division
+//   ix  = ((u / ((w-1)/2) - 1) + 1) * ((w-1)/2)              normalise / un-normalise round trip
+//   val = fma(v_se, w_se, fma(v_sw, w_sw, fma(v_ne, w_ne, v_nw*w_nw)))
+//   in_prod = ref*val ; volume += in_prod*vis                (three separate roundings)
+#include "cds_common.hpp"
+
+struct WarpMats {
+  float m[CDS_MAX_VIEWS][12];
+};
+
+struct Taps {
+  int off[4];   // element offset of the texel (pixel index, not yet multiplied by C); -1 if outside
+  float wt[4];  // nw, ne, sw, se
+};
+
+__device__ __forceinline__ void cds_row_terms(const float* __restrict__ m, float x, float y, float r[3]) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    float a = m[3 * i + 0] * x;
+    a = fmaf(m[3 * i + 1], y, a);
+    a = fmaf(m[3 * i + 2], 1.0f, a);
+    r[i] = a;
+  }
+}
+
+__device__ __forceinline__ Taps cds_taps(const float r[3], const float* __restrict__ t, float d, int h,
+                                         int w, float half_w, float half_h) {
+  float px = r[0] * d + t[0];
+  float py = r[1] * d + t[1];
+  float pz = r[2] * d + t[2];
+  float z = pz + 1e-6f;
+  float u = px / z;
+  float v = py / z;
+  float gx = u / half_w - 1.0f;
+  float gy = v / half_h - 1.0f;
+  float ix = (gx + 1.0f) * half_w;
+  float iy = (gy + 1.0f) * half_h;
+  float x0f = floorf(ix), y0f = floorf(iy);
+  float wx = ix - x0f, ex = 1.0f - wx;
+  float ny = iy - y0f, sy = 1.0f - ny;
+  Taps tp;
+  tp.wt[0] = sy * ex;
+  tp.wt[1] = sy * wx;
+  tp.wt[2] = ny * ex;
+  tp.wt[3] = ny * wx;
+  // Range test in float first: NaN / inf / huge coordinates fail every comparison -> all taps "outside".
+  bool x0ok = (x0f >= 0.0f) && (x0f <= (float)(w - 1));
+  bool x1ok = (x0f >= -1.0f) && (x0f <= (float)(w - 2));
+  bool y0ok = (y0f >= 0.0f) && (y0f <= (float)(h - 1));
+  bool y1ok = (y0f >= -1.0f) && (y0f <= (float)(h - 2));
+  int x0 = (x0ok || x1ok) ? (int)x0f : 0;
+  int y0 = (y0ok || y1ok) ? (int)y0f : 0;
+  int base = y0 * w + x0;
+  tp.off[0] = (x0ok && y0ok) ? base : -1;
+  tp.off[1] = (x1ok && y0ok) ? base + 1 : -1;
+  tp.off[2] = (x0ok && y1ok) ? base + w : -1;
+  tp.off[3] = (x1ok && y1ok) ? base + w + 1 : -1;
+  return tp;
+}
+
+__device__ __forceinline__ float4 cds_ld4(const float* __restrict__ p, int off, int C, int c0) {
+  if (off < 0) return make_float4(0.f, 0.f, 0.f, 0.f);
+  return *reinterpret_cast<const float4*>(p + (size_t)off * C + c0);
+}
+
+__device__ __forceinline__ float cds_interp(float a, float b, float c, float d, const float wt[4]) {
+  float o = a * wt[0];
+  o = fmaf(b, wt[1], o);
+  o = fmaf(c, wt[2], o);
+  o = fmaf(d, wt[3], o);
+  return o;
+}
+
+#define CDS_TILE_X 64
+#define CDS_TILE_Y 4
+
+// ---------------------------------------------------------------------------------------------
+// plain warp  -> out [C][D][h][w]
+// ---------------------------------------------------------------------------------------------
+template <int C>
+__global__ __launch_bounds__(256) void warp_kernel(const float* __restrict__ src, WarpMats mats,
+                                                   const float* __restrict__ hyp, float* __restrict__ out,
+                                                   int D, int h, int w, int hyp_pp, int tiles_x,
+                                                   int ntiles) {
+  int tile = cds_xcd_remap(blockIdx.x, ntiles);
+  int tx = tile % tiles_x, ty = tile / tiles_x;
+  int x = tx * CDS_TILE_X + (threadIdx.x & 63);
+  int y = ty * CDS_TILE_Y + (threadIdx.x >> 6);
+  if (x >= w || y >= h) return;
+  const float half_w = (float)((w - 1) / 2.0), half_h = (float)((h - 1) / 2.0);
+  float r[3];
+  cds_row_terms(mats.m[0], (float)x, (float)y, r);
+  const size_t hw = (size_t)h * w;
+  const size_t pix = (size_t)y * w + x;
+  for (int d = 0; d < D; ++d) {
+    float dv = hyp_pp ? hyp[d * hw + pix] : hyp[d];
+    Taps tp = cds_taps(r, mats.m[0] + 9, dv, h, w, half_w, half_h);
+#pragma unroll
+    for (int c0 = 0; c0 < C; c0 += 4) {
+      float4 a = cds_ld4(src, tp.off[0], C, c0), b = cds_ld4(src, tp.off[1], C, c0);
+      float4 c = cds_ld4(src, tp.off[2], C, c0), e = cds_ld4(src, tp.off[3], C, c0);
+      out[((size_t)(c0 + 0) * D + d) * hw + pix] = cds_interp(a.x, b.x, c.x, e.x, tp.wt);
+      out[((size_t)(c0 + 1) * D + d) * hw + pix] = cds_interp(a.y, b.y, c.y, e.y, tp.wt);
+      out[((size_t)(c0 + 2) * D + d) * hw + pix] = cds_interp(a.z, b.z, c.z, e.z, tp.wt);
+      out[((size_t)(c0 + 3) * D + d) * hw + pix] = cds_interp(a.w, b.w, c.w, e.w, tp.wt);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1: entropy over D of softmax(sum_C ref*warp), one thread per (pixel, view).
+// Online softmax statistics: m (running max), Z = sum e^(s-m), T = sum (s-m) e^(s-m);
+// entropy = log Z - T/Z   (algebraically -sum p log p, finite where the textbook form is 0*log 0).
+// ---------------------------------------------------------------------------------------------
+template <int C>
+__global__ __launch_bounds__(256) void warp_entropy_kernel(const float* __restrict__ ref,
+                                                           const float* __restrict__ src, WarpMats mats,
+                                                           const float* __restrict__ hyp,
+                                                           float* __restrict__ entropy, int V, int D, int h,
+                                                           int w, int hyp_pp, int tiles_x, int ntiles) {
+  // view is the fastest-varying logical index so the V blocks of one pixel tile are co-scheduled
+  // and share the tile's hypotheses through L2.
+  int lin = cds_xcd_remap(blockIdx.x, ntiles * V);
+  int v = lin % V;
+  int tile = lin / V;
+  int tx = tile % tiles_x, ty = tile / tiles_x;
+  int x = tx * CDS_TILE_X + (threadIdx.x & 63);
+  int y = ty * CDS_TILE_Y + (threadIdx.x >> 6);
+  if (x >= w || y >= h) return;
+  const float half_w = (float)((w - 1) / 2.0), half_h = (float)((h - 1) / 2.0);
+  const size_t hw = (size_t)h * w;
+  const size_t pix = (size_t)y * w + x;
+  const float* __restrict__ srcv = src + (size_t)v * hw * C;
+  float rf[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) rf[c] = ref[((size_t)v * C + c) * hw + pix];
+  float r[3];
+  cds_row_terms(mats.m[v], (float)x, (float)y, r);
+  float m = -INFINITY, Z = 0.f, T = 0.f;
+  for (int d = 0; d < D; ++d) {
+    float dv = hyp_pp ? hyp[d * hw + pix] : hyp[d];
+    Taps tp = cds_taps(r, mats.m[v] + 9, dv, h, w, half_w, half_h);
+    float s = 0.f;
+    // ATen's outer-dim sum: sequential inside 16-row levels, then level sums added.
+#pragma unroll
+    for (int cb = 0; cb < C; cb += 16) {
+      float part = 0.f;
+#pragma unroll
+      for (int c0 = cb; c0 < cb + 16 && c0 < C; c0 += 4) {
+        float4 a = cds_ld4(srcv, tp.off[0], C, c0), b = cds_ld4(srcv, tp.off[1], C, c0);
+        float4 c = cds_ld4(srcv, tp.off[2], C, c0), e = cds_ld4(srcv, tp.off[3], C, c0);
+        part = part + rf[c0 + 0] * cds_interp(a.x, b.x, c.x, e.x, tp.wt);
+        part = part + rf[c0 + 1] * cds_interp(a.y, b.y, c.y, e.y, tp.wt);
+        part = part + rf[c0 + 2] * cds_interp(a.z, b.z, c.z, e.z, tp.wt);
+        part = part + rf[c0 + 3] * cds_interp(a.w, b.w, c.w, e.w, tp.wt);
+      }
+      s = s + part;
+    }
+    if (s > m) {  // also taken on the first plane (m = -inf)
+      float sc = expf(m - s);  // exp(-inf) = 0 on the first plane
+      // T' = sum (s_i - m') e_i' = sc*(T + (m - m')*Z);  guard 0*inf on the first plane
+      float shift = (Z == 0.f) ? 0.f : (m - s) * Z;
+      T = sc * (T + shift);
+      Z = Z * sc;
+      m = s;
+    }
+    float dlt = s - m;
+    float e = expf(dlt);
+    Z += e;
+    T = fmaf(dlt, e, T);
+  }
+  entropy[(size_t)v * hw + pix] = logf(Z) - T / Z;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K3: volume[c][d][p] = sum_v vis_v[p] * ref_v[c][p] * warp_v[c][d][p]  (/ (vis_sum+1e-6)).
+// One thread per (pixel, group of CG=8 channels); all views in the inner loop so every volume
+// element is produced in registers and stored exactly once.
+// ---------------------------------------------------------------------------------------------
+template <int VMAX>
+__global__ __launch_bounds__(256) void warp_aggregate_kernel(
+    const float* __restrict__ ref, const float* __restrict__ src, const float* __restrict__ vis, WarpMats mats,
+    const float* __restrict__ hyp, float* __restrict__ volume, const float* __restrict__ vis_sum, int V, int C,
+    int D, int h, int w, int hyp_pp, int flags, int tiles_x, int ntiles) {
+  constexpr int CG = 8;
+  const int ngroups = C / CG;
+  int lin = cds_xcd_remap(blockIdx.x, ntiles * ngroups);
+  int g = lin % ngroups;
+  int tile = lin / ngroups;
+  int tx = tile % tiles_x, ty = tile / tiles_x;
+  int x = tx * CDS_TILE_X + (threadIdx.x & 63);
+  int y = ty * CDS_TILE_Y + (threadIdx.x >> 6);
+  if (x >= w || y >= h) return;
+  const float half_w = (float)((w - 1) / 2.0), half_h = (float)((h - 1) / 2.0);
+  const size_t hw = (size_t)h * w;
+  const size_t pix = (size_t)y * w + x;
+  const int c_base = g * CG;
+
+  float rf[VMAX][CG];
+  float vw[VMAX];
+  float r[VMAX][3];
+#pragma unroll
+  for (int v = 0; v < VMAX; ++v) {
+    if (v < V) {
+      vw[v] = vis[(size_t)v * hw + pix];
+#pragma unroll
+      for (int c = 0; c < CG; ++c) rf[v][c] = ref[((size_t)v * C + c_base + c) * hw + pix];
+      cds_row_terms(mats.m[v], (float)x, (float)y, r[v]);
+    }
+  }
+  const bool accumulate = flags & CDS_AGG_ACCUMULATE;
+  const bool normalize = flags & CDS_AGG_NORMALIZE;
+  const float denom = (normalize ? vis_sum[pix] : 1.0f) + 1e-6f;  // vis_sum finalised by vis_sum_kernel
+
+  float dnext = hyp_pp ? hyp[pix] : hyp[0];
+  for (int d = 0; d < D; ++d) {
+    float dv = dnext;
+    if (d + 1 < D) dnext = hyp_pp ? hyp[(size_t)(d + 1) * hw + pix] : hyp[d + 1];
+    float acc[CG];
+#pragma unroll
+    for (int c = 0; c < CG; ++c) acc[c] = accumulate ? volume[((size_t)(c_base + c) * D + d) * hw + pix] : 0.f;
+#pragma unroll
+    for (int v = 0; v < VMAX; ++v) {
+      if (v < V) {
+        const float* __restrict__ srcv = src + (size_t)v * hw * C;
+        Taps tp = cds_taps(r[v], mats.m[v] + 9, dv, h, w, half_w, half_h);
+#pragma unroll
+        for (int c0 = 0; c0 < CG; c0 += 4) {
+          float4 a = cds_ld4(srcv, tp.off[0], C, c_base + c0), b = cds_ld4(srcv, tp.off[1], C, c_base + c0);
+          float4 c = cds_ld4(srcv, tp.off[2], C, c_base + c0), e = cds_ld4(srcv, tp.off[3], C, c_base + c0);
+          float w0 = cds_interp(a.x, b.x, c.x, e.x, tp.wt);
+          float w1 = cds_interp(a.y, b.y, c.y, e.y, tp.wt);
+          float w2 = cds_interp(a.z, b.z, c.z, e.z, tp.wt);
+          float w3 = cds_interp(a.w, b.w, c.w, e.w, tp.wt);
+          acc[c0 + 0] = acc[c0 + 0] + (rf[v][c0 + 0] * w0) * vw[v];
+          acc[c0 + 1] = acc[c0 + 1] + (rf[v][c0 + 1] * w1) * vw[v];
+          acc[c0 + 2] = acc[c0 + 2] + (rf[v][c0 + 2] * w2) * vw[v];
+          acc[c0 + 3] = acc[c0 + 3] + (rf[v][c0 + 3] * w3) * vw[v];
+        }
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < CG; ++c) {
+      float o = normalize ? acc[c] / denom : acc[c];
+      __builtin_nontemporal_store(o, &volume[((size_t)(c_base + c) * D + d) * hw + pix]);
+    }
+  }
+}
+
+// vis_sum[p] = (accumulate ? vis_sum[p] : 0) + vis_0[p] + vis_1[p] + ...   (view order, model.py:58)
+__global__ void vis_sum_kernel(const float* __restrict__ vis, float* __restrict__ vis_sum, int V, int hw,
+                               int accumulate) {
+  int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= hw) return;
+  float s = accumulate ? vis_sum[p] : 0.f;
+  for (int v = 0; v < V; ++v) s = s + vis[(size_t)v * hw + p];
+  vis_sum[p] = s;
+}
+
+__global__ void volume_normalize_kernel(float* __restrict__ vol, const float* __restrict__ vis_sum, size_t hw,
+                                        size_t planes) {
+  size_t n4 = (hw % 4 == 0) ? hw / 4 : 0;  // rows are 16-byte aligned only when hw % 4 == 0
+  for (size_t pl = blockIdx.y; pl < planes; pl += gridDim.y) {
+    float4* row = reinterpret_cast<float4*>(vol + pl * hw);
+    const float4* vs = reinterpret_cast<const float4*>(vis_sum);
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+      float4 a = row[i], s = vs[i];
+      a.x = a.x / (s.x + 1e-6f);
+      a.y = a.y / (s.y + 1e-6f);
+      a.z = a.z / (s.z + 1e-6f);
+      a.w = a.w / (s.w + 1e-6f);
+      row[i] = a;
+    }
+    if (blockIdx.x == 0) {
+      for (size_t i = n4 * 4 + threadIdx.x; i < hw; i += blockDim.x) vol[pl * hw + i] = vol[pl * hw + i] / (vis_sum[i] + 1e-6f);
+    }
+  }
+}
+
+__global__ void chw_to_hwc_kernel(const float* __restrict__ src, float* __restrict__ dst, int C, int hw) {
+  // one thread per (pixel, 4 channels): coalesced plane reads, 16-byte texel stores
+  int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= hw) return;
+  for (int c0 = 0; c0 < C; c0 += 4) {
+    float4 v;
+    v.x = src[(size_t)(c0 + 0) * hw + p];
+    v.y = src[(size_t)(c0 + 1) * hw + p];
+    v.z = src[(size_t)(c0 + 2) * hw + p];
+    v.w = src[(size_t)(c0 + 3) * hw + p];
+    *reinterpret_cast<float4*>(dst + (size_t)p * C + c0) = v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host entry points
+// ---------------------------------------------------------------------------------------------
+static bool cds_warp_args_ok(int V, int C, int D, int h, int w) {
+  return V >= 1 && V <= CDS_MAX_VIEWS && (C == 8 || C == 16 || C == 32) && D >= 1 && h >= 1 && w >= 1;
+}
+
+static void cds_fill_mats(WarpMats& wm, const float* mats_host, int V) {
+  for (int v = 0; v < CDS_MAX_VIEWS; ++v)
+    for (int i = 0; i < 12; ++i) wm.m[v][i] = v < V ? mats_host[v * 12 + i] : 0.f;
+}
+
+extern "C" int cds_chw_to_hwc_f32(const float* src_chw, float* dst_hwc, int C, int h, int w, void* stream) {
+  if (!src_chw || !dst_hwc || C < 4 || (C % 4) || h < 1 || w < 1) return CDS_EINVAL;
+  int hw = h * w;
+  hipLaunchKernelGGL(chw_to_hwc_kernel, dim3(cds_ceil_div(hw, 256)), dim3(256), 0, (hipStream_t)stream, src_chw,
+                     dst_hwc, C, hw);
+  return cds_launch_status();
+}
+
+extern "C" int cds_homo_warp_f32(const float* src_hwc, const float* mat_host, const float* hyp, float* out, int C,
+                                 int D, int h, int w, int hyp_per_pixel, void* stream) {
+  if (!src_hwc || !mat_host || !hyp || !out || !cds_warp_args_ok(1, C, D, h, w)) return CDS_EINVAL;
+  WarpMats wm;
+  cds_fill_mats(wm, mat_host, 1);
+  int tiles_x = cds_ceil_div(w, CDS_TILE_X), tiles_y = cds_ceil_div(h, CDS_TILE_Y);
+  int ntiles = tiles_x * tiles_y;
+  hipStream_t st = (hipStream_t)stream;
+#define LAUNCH(CC)                                                                                              \
+  hipLaunchKernelGGL(warp_kernel<CC>, dim3(ntiles), dim3(256), 0, st, src_hwc, wm, hyp, out, D, h, w, hyp_per_pixel, \
+                     tiles_x, ntiles)
+  if (C == 8) LAUNCH(8);
+  else if (C == 16) LAUNCH(16);
+  else LAUNCH(32);
+#undef LAUNCH
+  return cds_launch_status();
+}
+
+extern "C" int cds_warp_entropy_f32(const float* ref_chw, const float* src_hwc, const float* mats_host,
+                                    const float* hyp, float* entropy, int V, int C, int D, int h, int w,
+                                    int hyp_per_pixel, void* stream) {
+  if (!ref_chw || !src_hwc || !mats_host || !hyp || !entropy || !cds_warp_args_ok(V, C, D, h, w)) return CDS_EINVAL;
+  WarpMats wm;
+  cds_fill_mats(wm, mats_host, V);
+  int tiles_x = cds_ceil_div(w, CDS_TILE_X), tiles_y = cds_ceil_div(h, CDS_TILE_Y);
+  int ntiles = tiles_x * tiles_y;
+  hipStream_t st = (hipStream_t)stream;
+#define LAUNCH(CC)                                                                                          \
+  hipLaunchKernelGGL(warp_entropy_kernel<CC>, dim3(ntiles * V), dim3(256), 0, st, ref_chw, src_hwc, wm, hyp, \
+                     entropy, V, D, h, w, hyp_per_pixel, tiles_x, ntiles)
+  if (C == 8) LAUNCH(8);
+  else if (C == 16) LAUNCH(16);
+  else LAUNCH(32);
+#undef LAUNCH
+  return cds_launch_status();
+}
+
+extern "C" int cds_warp_aggregate_f32(const float* ref_chw, const float* src_hwc, const float* vis_w,
+                                      const float* mats_host, const float* hyp, float* volume, float* vis_sum, int V,
+                                      int C, int D, int h, int w, int hyp_per_pixel, int flags, void* stream) {
+  if (!ref_chw || !src_hwc || !vis_w || !mats_host || !hyp || !volume || !vis_sum || !cds_warp_args_ok(V, C, D, h, w))
+    return CDS_EINVAL;
+  WarpMats wm;
+  cds_fill_mats(wm, mats_host, V);
+  int tiles_x = cds_ceil_div(w, CDS_TILE_X), tiles_y = cds_ceil_div(h, CDS_TILE_Y);
+  int ntiles = tiles_x * tiles_y;
+  int ngroups = C / 8;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(vis_sum_kernel, dim3(cds_ceil_div(h * w, 256)), dim3(256), 0, st, vis_w, vis_sum, V, h * w,
+                     flags & CDS_AGG_ACCUMULATE);
+#define LAUNCH(VM)                                                                                                  \
+  hipLaunchKernelGGL(warp_aggregate_kernel<VM>, dim3(ntiles * ngroups), dim3(256), 0, st, ref_chw, src_hwc, vis_w, wm, \
+                     hyp, volume, vis_sum, V, C, D, h, w, hyp_per_pixel, flags, tiles_x, ntiles)
+  if (V <= 2) LAUNCH(2);
+  else if (V <= 4) LAUNCH(4);
+  else if (V <= 6) LAUNCH(6);
+  else LAUNCH(8);
+#undef LAUNCH
+  return cds_launch_status();
+}
+
+extern "C" int cds_volume_normalize_f32(float* volume, const float* vis_sum, int C, int D, int hw, void* stream) {
+  if (!volume || !vis_sum || C < 1 || D < 1 || hw < 1) return CDS_EINVAL;
+  size_t planes = (size_t)C * D;
+  int gx = cds_ceil_div(cds_ceil_div(hw, 4), 256);
+  if (gx > 64) gx = 64;
+  if (gx < 1) gx = 1;
+  int gy = planes > 4096 ? 4096 : (int)planes;
+  hipLaunchKernelGGL(volume_normalize_kernel, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, volume, vis_sum,
+                     (size_t)hw, planes);
+  return cds_launch_status();
+}

@@ -1,0 +1,48 @@
+"""Deterministic initialiser used where no checkpoint is available (benchmarks, fixtures).
+
+There is no network access on the build / GPU boxes and the reference ships no licence for its
+checkpoints, so synthetic weights are generated here.  The values are chosen so that every
+activation stays O(1) and BatchNorm running statistics are non-trivial (a fold bug would show).
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn as nn
+
+
+@torch.no_grad()
+def seeded_init_(module: nn.Module, seed: int = 0) -> nn.Module:
+    """Fill every parameter / buffer of ``module`` from a CPU generator seeded with ``seed``.
+
+    Works on any module tree that uses the reference's state-dict names (ours or the reference's
+    own classes), because it only looks at tensor names and shapes."""
+    g = torch.Generator().manual_seed(seed)
+    sd = module.state_dict()
+    for name in sorted(sd.keys()):
+        t = sd[name]
+        if name.endswith("num_batches_tracked"):
+            t.fill_(100)
+            continue
+        shape = tuple(t.shape)
+        if name.endswith("running_mean"):
+            v = 0.1 * torch.randn(shape, generator=g)
+        elif name.endswith("running_var"):
+            v = 0.5 + torch.rand(shape, generator=g)
+        elif name.endswith(".bn.weight") or (len(shape) == 1 and name.endswith(".weight")):
+            v = 0.75 + 0.5 * torch.rand(shape, generator=g)
+        elif name.endswith(".bias"):
+            v = 0.1 * torch.randn(shape, generator=g)
+        else:  # convolution kernels
+            if "att_convs" in name:
+                std = 0.1
+            else:
+                is_transposed = "conv7.conv" in name or "conv9.conv" in name or "conv11.conv" in name or ".deconv." in name
+                fan_in = (shape[0] if is_transposed else shape[1]) * math.prod(shape[2:])
+                if is_transposed:
+                    fan_in = fan_in / 8.0 if len(shape) == 5 else fan_in / 4.0  # stride-2: 1/2^d of taps hit
+                std = math.sqrt(2.0 / fan_in)
+            v = std * torch.randn(shape, generator=g)
+        t.copy_(v.to(t.dtype))
+    return module

@@ -1,0 +1,530 @@
+"""Drop-in ``CDSMVSNet`` for MI355X: same constructor, ``forward`` signature, output dict and
+state-dict keys as the reference's ``models.model.CDSMVSNet`` (models/model.py:97-223), with the
+plane-sweep hot path executed by hand-written gfx950 kernels (libcdsmvs_hip.so).
+
+The ``nn.Module`` tree below only *holds parameters* under the reference's names so that reference
+checkpoints load unchanged (387 entries, e.g. ``feature.conv00.conv.att_convs.0.weight``,
+``stage_net.vis.0.0.conv.weight``, ``cost_regularization.2.conv7.conv.weight``).  None of the holder
+``nn.Conv*`` modules is ever called on the hot path: weights are BN-folded and packed once
+(:class:`_Packed`) and handed to the C ABI through :mod:`cds_mvsnet_amd.ops`.
+
+Scope: inference (``model.eval()``).  Training-mode forward (``gt_depths`` /
+batch-statistics BatchNorm) is the next row of §8(f) and raises ``NotImplementedError``.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import geometry, ops
+from .ops import ACT_LEAKY01, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH
+
+Tensor = torch.Tensor
+BN_EPS = 1e-5
+
+
+# ------------------------------------------------------------------------------------------------
+# parameter holders (names fix the state-dict keys)
+# ------------------------------------------------------------------------------------------------
+class DynamicConv(nn.Module):
+    """Parameters of one dynamic-scale convolution (models/dynamic_conv.py:81-95)."""
+
+    def __init__(self, in_c: int, out_c: int, size_kernels: Sequence[int], bias: bool = True, hidden_dim: int = 4):
+        super().__init__()
+        self.size_kernels = tuple(size_kernels)
+        self.in_c, self.out_c = in_c, out_c
+        self.att_convs = nn.ModuleList([nn.Conv2d(in_c, 3, k, padding=(k - 1) // 2, bias=False) for k in size_kernels])
+        self.convs = nn.ModuleList([nn.Conv2d(in_c, out_c, k, padding=(k - 1) // 2, bias=bias) for k in size_kernels])
+        nk = len(size_kernels)
+        self.att_weights = nn.Sequential(nn.Conv2d(nk, hidden_dim, 1, bias=False), nn.BatchNorm2d(hidden_dim),
+                                         nn.ReLU(inplace=True), nn.Conv2d(hidden_dim, nk, 1, bias=False))
+        for p in self.att_convs.parameters():
+            nn.init.normal_(p, std=0.1)
+
+
+class ConvUnit(nn.Module):
+    """``conv`` = DynamicConv or plain Conv2d; followed by InstanceNorm + LeakyReLU(0.1) (module.py:28-71)."""
+
+    def __init__(self, in_c: int, out_c: int, kernel, stride: int = 1, dynamic: bool = False, padding: int = 0):
+        super().__init__()
+        self.dynamic, self.stride, self.padding = dynamic, stride, padding
+        if dynamic:
+            self.conv = DynamicConv(in_c, out_c, kernel, bias=False)
+        else:
+            self.conv = nn.Conv2d(in_c, out_c, kernel, stride=stride, padding=padding, bias=False)
+
+
+class FeatureNet(nn.Module):
+    """Parameter layout of the 3-level dynamic-conv pyramid (module.py:201-232)."""
+
+    def __init__(self, base_channels: int = 8):
+        super().__init__()
+        b = base_channels
+        self.conv00 = ConvUnit(3, b, (3, 7, 11), dynamic=True)
+        self.conv01 = ConvUnit(b, b, (3, 5, 7), dynamic=True)
+        self.downsample1 = ConvUnit(b, 2 * b, 3, stride=2, padding=1)
+        self.conv10 = ConvUnit(2 * b, 2 * b, (3, 5), dynamic=True)
+        self.conv11 = ConvUnit(2 * b, 2 * b, (3, 5), dynamic=True)
+        self.downsample2 = ConvUnit(2 * b, 4 * b, 3, stride=2, padding=1)
+        self.conv20 = ConvUnit(4 * b, 4 * b, (1, 3), dynamic=True)
+        self.conv21 = ConvUnit(4 * b, 4 * b, (1, 3), dynamic=True)
+        self.out1 = DynamicConv(4 * b, 4 * b, (1, 3))
+        self.inner1 = ConvUnit(6 * b, 2 * b, 1)
+        self.inner2 = ConvUnit(3 * b, b, 1)
+        self.out2 = DynamicConv(2 * b, 2 * b, (1, 3))
+        self.out3 = DynamicConv(b, b, (1, 3))
+        self.out_channels = [4 * b, 2 * b, b]
+
+
+class ConvBn2d(nn.Module):
+    def __init__(self, in_c: int, out_c: int):
+        super().__init__()
+        self.conv = nn.Conv2d(in_c, out_c, 3, padding=1, bias=False)
+        self.bn = nn.BatchNorm2d(out_c)
+
+
+class ConvBn3d(nn.Module):
+    def __init__(self, in_c: int, out_c: int, stride: int = 1, transposed: bool = False):
+        super().__init__()
+        self.stride, self.transposed = stride, transposed
+        if transposed:
+            self.conv = nn.ConvTranspose3d(in_c, out_c, 3, stride=2, padding=1, output_padding=1, bias=False)
+        else:
+            self.conv = nn.Conv3d(in_c, out_c, 3, stride=stride, padding=1, bias=False)
+        self.bn = nn.BatchNorm3d(out_c)
+
+
+class CostRegNet(nn.Module):
+    """3D U-Net regulariser (module.py:270-315); forward runs on the HIP conv kernels."""
+
+    def __init__(self, in_channels: int, base_channels: int):
+        super().__init__()
+        b = base_channels
+        self.conv0 = ConvBn3d(in_channels, b)
+        self.conv1 = ConvBn3d(b, 2 * b, stride=2)
+        self.conv2 = ConvBn3d(2 * b, 2 * b)
+        self.conv3 = ConvBn3d(2 * b, 4 * b, stride=2)
+        self.conv4 = ConvBn3d(4 * b, 4 * b)
+        self.conv5 = ConvBn3d(4 * b, 8 * b, stride=2)
+        self.conv6 = ConvBn3d(8 * b, 8 * b)
+        self.conv7 = ConvBn3d(8 * b, 4 * b, transposed=True)
+        self.conv9 = ConvBn3d(4 * b, 2 * b, transposed=True)
+        self.conv11 = ConvBn3d(2 * b, b, transposed=True)
+        self.prob = nn.Conv3d(b, 1, 3, stride=1, padding=1, bias=False)
+        self._packed = _Packed(self)
+
+    def _pack(self) -> Dict[str, Tensor]:
+        out: Dict[str, Tensor] = {}
+        for name in ("conv0", "conv1", "conv2", "conv3", "conv4", "conv5", "conv6", "conv7", "conv9", "conv11"):
+            unit: ConvBn3d = getattr(self, name)
+            scale, shift = _bn_fold(unit.bn)
+            w = unit.conv.weight.detach()
+            if unit.transposed:   # [Cin,Cout,3,3,3]
+                w = (w * scale.view(1, -1, 1, 1, 1)).permute(0, 2, 3, 4, 1)
+            else:                 # [Cout,Cin,3,3,3]
+                w = (w * scale.view(-1, 1, 1, 1, 1)).permute(1, 2, 3, 4, 0)
+            out[name + ".w"] = w.reshape(w.shape[0], 27, w.shape[-1]).contiguous()
+            out[name + ".b"] = shift.contiguous()
+        w = self.prob.weight.detach().permute(1, 2, 3, 4, 0)
+        out["prob.w"] = w.reshape(w.shape[0], 27, 1).contiguous()
+        return out
+
+    def forward(self, volume: Tensor) -> Tensor:
+        """volume [C,D,h,w] (one batch item) -> [D,h,w].  D, h, w must be multiples of 8."""
+        if self.training:
+            raise NotImplementedError("CostRegNet: training-mode BatchNorm is not built yet (SURVEY §8(f)-2)")
+        C, D, h, w = volume.shape
+        if D % 8 or h % 8 or w % 8:
+            raise ValueError(f"CostRegNet needs D,h,w divisible by 8, got {(D, h, w)}")
+        p = self._packed.get(self._pack)
+        c0 = ops.conv3d_k3(volume, p["conv0.w"], p["conv0.b"])
+        c1 = ops.conv3d_k3(c0, p["conv1.w"], p["conv1.b"], stride=2)
+        c2 = ops.conv3d_k3(c1, p["conv2.w"], p["conv2.b"])
+        del c1
+        c3 = ops.conv3d_k3(c2, p["conv3.w"], p["conv3.b"], stride=2)
+        c4 = ops.conv3d_k3(c3, p["conv4.w"], p["conv4.b"])
+        del c3
+        c5 = ops.conv3d_k3(c4, p["conv5.w"], p["conv5.b"], stride=2)
+        x = ops.conv3d_k3(c5, p["conv6.w"], p["conv6.b"])
+        del c5
+        x = ops.deconv3d_k3s2(x, p["conv7.w"], p["conv7.b"], skip=c4)
+        del c4
+        x = ops.deconv3d_k3s2(x, p["conv9.w"], p["conv9.b"], skip=c2)
+        del c2
+        x = ops.deconv3d_k3s2(x, p["conv11.w"], p["conv11.b"], skip=c0)
+        del c0
+        return ops.conv3d_k3(x, p["prob.w"], None, relu=False)[0]
+
+
+class Refinement(nn.Module):
+    """2x depth up-sampling with image guidance (module.py:318-370).  3.6 % of the reference's CPU time
+    and adjacent to — not on — the plane-sweep path: it stays on stock PyTorch-ROCm ops."""
+
+    def __init__(self):
+        super().__init__()
+        self.conv0 = ConvBn2d(3, 8)
+        self.conv1 = ConvBn2d(1, 8)
+        self.conv2 = ConvBn2d(8, 8)
+        self.deconv = nn.ConvTranspose2d(8, 8, 3, padding=1, output_padding=1, stride=2, bias=False)
+        self.bn = nn.BatchNorm2d(8)
+        self.conv3 = ConvBn2d(16, 8)
+        self.res = nn.Conv2d(8, 1, 3, padding=1, bias=False)
+
+    @staticmethod
+    def _cbr(unit: ConvBn2d, x: Tensor) -> Tensor:
+        return F.relu(unit.bn(unit.conv(x)))
+
+    def forward(self, img: Tensor, depth0: Tensor, dmin: Tensor, dmax: Tensor) -> Tensor:
+        B = dmin.shape[0]
+        lo, hi = dmin.view(B, 1, 1, 1), dmax.view(B, 1, 1, 1)
+        d = (depth0 - lo) / (hi - lo) * 10
+        f_img = self._cbr(self.conv0, img)
+        f_d = F.relu(self.bn(self.deconv(self._cbr(self.conv2, self._cbr(self.conv1, d)))))
+        res = self.res(self._cbr(self.conv3, torch.cat((f_d, f_img), dim=1)))
+        d = (F.interpolate(d, scale_factor=2, mode="bilinear", align_corners=True) + res) / 10
+        return d * (hi - lo) + lo
+
+
+# ------------------------------------------------------------------------------------------------
+# weight folding / packing
+# ------------------------------------------------------------------------------------------------
+def _bn_fold(bn: nn.Module) -> Tuple[Tensor, Tensor]:
+    """Eval-mode BatchNorm as y = x*scale + shift."""
+    scale = bn.weight.detach() / torch.sqrt(bn.running_var + bn.eps)
+    shift = bn.bias.detach() - bn.running_mean * scale
+    return scale, shift
+
+
+def _pack2d(w: Tensor) -> Tensor:
+    """[Cout,Cin,k,k] -> [Cin,k*k,CoutP] (cout fastest, zero padded to a multiple of 8)."""
+    cout, cin, k, _ = w.shape
+    p = w.permute(1, 2, 3, 0).reshape(cin, k * k, cout)
+    pad = (-cout) % 8
+    if pad:
+        p = F.pad(p, (0, pad))
+    return p.contiguous()
+
+
+class _Packed:
+    """Lazily built, version-checked cache of folded/packed weights for one holder module."""
+
+    def __init__(self, owner: nn.Module):
+        self._owner_ref = [owner]  # list: keep nn.Module from registering it as a sub-module
+        self._sig = None
+        self._data: Dict[str, Tensor] = {}
+
+    def _signature(self):
+        owner = self._owner_ref[0]
+        return tuple((t.data_ptr(), t._version) for t in list(owner.parameters()) + list(owner.buffers()))
+
+    def get(self, builder) -> Dict[str, Tensor]:
+        sig = self._signature()
+        if sig != self._sig:
+            with torch.no_grad():
+                self._data = builder()
+            self._sig = sig
+        return self._data
+
+
+# ------------------------------------------------------------------------------------------------
+# FeatureNet on the HIP kernels (module.py:234-267, dynamic_conv.py:97-122)
+# ------------------------------------------------------------------------------------------------
+class _FeatureRunner:
+    def __init__(self, net: FeatureNet):
+        self.net = net
+        self.packed = _Packed(net)
+
+    def _pack(self) -> Dict[str, Tensor]:
+        out: Dict[str, Tensor] = {}
+        net = self.net
+
+        def dyn(name: str, dc: DynamicConv):
+            dev = dc.att_convs[0].weight.device
+            for i, k in enumerate(dc.size_kernels):
+                w = torch.cat((dc.convs[i].weight.detach(), dc.att_convs[i].weight.detach()), dim=0)
+                out[f"{name}.w{i}"] = _pack2d(w)
+                if dc.convs[i].bias is not None:
+                    out[f"{name}.b{i}"] = torch.cat((dc.convs[i].bias.detach(), torch.zeros(3, device=dev))).contiguous()
+            scale, shift = _bn_fold(dc.att_weights[1])
+            nk = len(dc.size_kernels)
+            out[f"{name}.m1"] = (dc.att_weights[0].weight.detach().reshape(4, nk) * scale.view(4, 1)).contiguous()
+            out[f"{name}.mb"] = shift.contiguous()
+            out[f"{name}.m2"] = dc.att_weights[3].weight.detach().reshape(nk, 4).contiguous()
+
+        for name in ("conv00", "conv01", "conv10", "conv11", "conv20", "conv21"):
+            dyn(name, getattr(net, name).conv)
+        for name in ("out1", "out2", "out3"):
+            dyn(name, getattr(net, name))
+        for name in ("downsample1", "downsample2", "inner1", "inner2"):
+            out[f"{name}.w"] = _pack2d(getattr(net, name).conv.weight.detach())
+        return out
+
+    def _dynamic(self, p, name: str, dc: DynamicConv, x: Tensor, epi: Tuple[float, float], T: float):
+        Cin, H, W = x.shape
+        nk = len(dc.size_kernels)
+        branches = torch.empty((nk, dc.out_c + 3, H, W), dtype=torch.float32, device=x.device)
+        x4 = x.unsqueeze(0)
+        for i, k in enumerate(dc.size_kernels):
+            ops.conv2d(x4, p[f"{name}.w{i}"], p.get(f"{name}.b{i}"), dc.out_c + 3, k, 1, (k - 1) // 2, ACT_NONE,
+                       out=branches[i])
+        return ops.dynconv_blend(branches, p[f"{name}.m1"], p[f"{name}.mb"], p[f"{name}.m2"], epi, T)
+
+    def _dyn_unit(self, p, name, x, epi, T):
+        y, nc = self._dynamic(p, name, getattr(self.net, name).conv, x, epi, T)
+        return ops.instnorm_act(y, ACT_LEAKY01), nc
+
+    def _plain_unit(self, p, name, x):
+        unit: ConvUnit = getattr(self.net, name)
+        k = unit.conv.kernel_size[0]
+        y = ops.conv2d(x.unsqueeze(0), p[f"{name}.w"], None, unit.conv.out_channels, k, unit.stride, unit.padding)[0]
+        return ops.instnorm_act(y, ACT_LEAKY01)
+
+    def __call__(self, img: Tensor, epi: Tuple[float, float], T: float, hwc: bool):
+        """img [3,H,W] -> {'stageK': (feat [C,h,w] or [h,w,C] if hwc, nc_sum [h,w], |nc| [h,w])}."""
+        net = self.net
+        if net.training:
+            raise NotImplementedError("FeatureNet: training mode is not built yet (SURVEY §8(f)-2)")
+        p = self.packed.get(self._pack)
+        e0 = epi
+        e1 = (epi[0] / 2, epi[1] / 2)
+        e2 = (epi[0] / 4, epi[1] / 4)
+        c00, n00 = self._dyn_unit(p, "conv00", img, e0, T)
+        c01, n01 = self._dyn_unit(p, "conv01", c00, e0, T)
+        d0 = self._plain_unit(p, "downsample1", c01)
+        c10, n10 = self._dyn_unit(p, "conv10", d0, e1, T)
+        c11, n11 = self._dyn_unit(p, "conv11", c10, e1, T)
+        d1 = self._plain_unit(p, "downsample2", c11)
+        c20, n20 = self._dyn_unit(p, "conv20", d1, e2, T)
+        c21, n21 = self._dyn_unit(p, "conv21", c20, e2, T)
+
+        out = {}
+        o1, n22 = self._dynamic(p, "out1", net.out1, c21, e2, T)
+        out["stage1"] = (ops.instnorm_act(o1, ACT_TANH, out_hwc=hwc), (n20 ** 2 + n21 ** 2 + n22 ** 2) / 3, n22.abs())
+
+        x = torch.cat((_nearest2x(c21), c11), dim=0)
+        x = self._plain_unit(p, "inner1", x)
+        o2, n12 = self._dynamic(p, "out2", net.out2, x, e1, T)
+        o2n = ops.instnorm_act(o2, ACT_TANH)
+        out["stage2"] = (ops.chw_to_hwc(o2n) if hwc else o2n, (n10 ** 2 + n11 ** 2 + n12 ** 2) / 3, n12.abs())
+
+        x = torch.cat((_nearest2x(o2n), c01), dim=0)
+        x = self._plain_unit(p, "inner2", x)
+        o3, n02 = self._dynamic(p, "out3", net.out3, x, e0, T)
+        out["stage3"] = (ops.instnorm_act(o3, ACT_TANH, out_hwc=hwc), (n00 ** 2 + n01 ** 2 + n02 ** 2) / 3, n02.abs())
+        return out
+
+
+def _nearest2x(x: Tensor) -> Tensor:
+    """[C,h,w] -> [C,2h,2w] nearest-neighbour (pure data movement; module.py:253,260)."""
+    C, h, w = x.shape
+    return x.view(C, h, 1, w, 1).expand(C, h, 2, w, 2).reshape(C, 2 * h, 2 * w)
+
+
+# ------------------------------------------------------------------------------------------------
+# StageNet: one cost-volume stage (models/model.py:11-94)
+# ------------------------------------------------------------------------------------------------
+class StageNet(nn.Module):
+    def __init__(self, num_mvs_stages: int = 3):
+        super().__init__()
+        self.vis = nn.ModuleList([nn.Sequential(ConvBn2d(2, 16), ConvBn2d(16, 16), ConvBn2d(16, 16),
+                                                nn.Conv2d(16, 1, 1), nn.Sigmoid()) for _ in range(num_mvs_stages)])
+        self._packed = _Packed(self)
+
+    def _pack(self) -> Dict[str, Tensor]:
+        out: Dict[str, Tensor] = {}
+        for s, seq in enumerate(self.vis):
+            for i in range(3):
+                scale, shift = _bn_fold(seq[i].bn)
+                out[f"{s}.w{i}"] = _pack2d(seq[i].conv.weight.detach() * scale.view(-1, 1, 1, 1))
+                out[f"{s}.b{i}"] = shift.contiguous()
+            out[f"{s}.w3"] = _pack2d(seq[3].weight.detach())
+            out[f"{s}.b3"] = seq[3].bias.detach().contiguous()
+        return out
+
+    def visibility(self, entropy: Tensor, ref_nc: Tensor, stage_idx: int) -> Tensor:
+        """entropy, ref_nc [V,h,w] -> visibility weight [V,h,w]   (model.py:14,51)."""
+        p = self._packed.get(self._pack)
+        s = stage_idx
+        x = torch.stack((entropy, ref_nc), dim=1)
+        for i in range(3):
+            x = ops.conv2d(x, p[f"{s}.w{i}"], p[f"{s}.b{i}"], 16, 3, 1, 1, ACT_RELU)
+        return ops.conv2d(x, p[f"{s}.w3"], p[f"{s}.b3"], 1, 1, 1, 0, ACT_SIGMOID)[:, 0]
+
+    def aggregate(self, ref_chw: Tensor, src_hwc: Tensor, ref_nc: Tensor, mats: Tensor, hyp: Tensor, stage_idx: int,
+                  normalize: bool = True):
+        """K1 -> vis CNN -> K3 for the given source views.  Returns (volume, vis_sum, entropy, vis_w)."""
+        ent = ops.warp_entropy(ref_chw, src_hwc, mats, hyp)
+        vis = self.visibility(ent, ref_nc, stage_idx).contiguous()
+        volume, vis_sum = ops.warp_aggregate(ref_chw, src_hwc, vis, mats, hyp, normalize=normalize)
+        return volume, vis_sum, ent, vis
+
+    def run_single(self, ref_chw, src_hwc, ref_nc, nc_sums, mats, hyp, cost_regularization, stage_idx):
+        """One batch item.  ref_chw [V,C,h,w], src_hwc [V,h,w,C], ref_nc [V,h,w], nc_sums [V,h,w] (already
+        (ref+src)/2 per view), hyp [D,h,w]."""
+        volume, _, _, _ = self.aggregate(ref_chw, src_hwc, ref_nc, mats, hyp, stage_idx)
+        prob_pre = cost_regularization(volume)
+        del volume
+        depth, conf = ops.softargmin_conf(prob_pre, hyp)
+        nc_mean = nc_sums.sum(dim=0) / nc_sums.shape[0]
+        return depth, conf, nc_mean
+
+    def forward(self, features, proj_matrices, depth_values, num_depth, cost_regularization, prob_volume_init=None,
+                stage_idx=0, gt_depth=None):
+        """Reference signature (model.py:16).  features: list over source views of
+        {'ref': (fea [B,C,h,w], nc_sum [B,1,h,w], nc [B,1,h,w]), 'src': (fea, nc_sum, _)}; proj_matrices
+        [B,N,2,4,4]; depth_values [B,D,h,w]."""
+        if self.training or gt_depth is not None:
+            raise NotImplementedError("StageNet: the training branch (model.py:52-56,63-69) is not built yet")
+        if prob_volume_init is not None:
+            raise NotImplementedError("prob_volume_init is dead code in the reference (never passed)")
+        assert len(features) == proj_matrices.shape[1] - 1, "Different number of images and projection matrices"
+        assert depth_values.shape[1] == num_depth, f"depth_values.shape[1]:{depth_values.shape[1]}  num_depth:{num_depth}"
+        B = depth_values.shape[0]
+        cams = proj_matrices.detach().float().cpu()
+        depths, confs, ncs = [], [], []
+        for b in range(B):
+            ref = torch.stack([f["ref"][0][b] for f in features]).contiguous()
+            src = torch.stack([ops.chw_to_hwc(f["src"][0][b].contiguous()) for f in features])
+            ref_nc = torch.stack([f["ref"][2][b, 0] for f in features]).contiguous()
+            nc_sums = torch.stack([(f["ref"][1][b, 0] + f["src"][1][b, 0]) / 2 for f in features])
+            hyp = depth_values[b]
+            if hyp.dim() == 1:
+                h, w = ref.shape[-2:]
+                hyp = hyp.view(-1, 1, 1).expand(-1, h, w)
+            d, c, n = self.run_single(ref, src, ref_nc, nc_sums, geometry.warp_matrices(cams[b]), hyp.contiguous(),
+                                      cost_regularization, stage_idx)
+            depths.append(d)
+            confs.append(c)
+            ncs.append(n.unsqueeze(0))
+        return {"depth": torch.stack(depths), "photometric_confidence": torch.stack(confs),
+                "norm_curv": torch.stack(ncs)}
+
+
+# ------------------------------------------------------------------------------------------------
+# the model (models/model.py:97-223)
+# ------------------------------------------------------------------------------------------------
+class CDSMVSNet(nn.Module):
+    def __init__(self, refine=False, ndepths=(48, 32, 8), depth_interals_ratio=(4, 2, 1), share_cr=False,
+                 grad_method="detach", arch_mode="fpn", cr_base_chs=(8, 8, 8)):
+        super().__init__()
+        assert len(ndepths) == len(depth_interals_ratio)
+        if share_cr:
+            raise NotImplementedError("share_cr=True crashes in the reference too (model.py:129-130 passes a list)")
+        self.refine = refine
+        self.share_cr = share_cr
+        self.ndepths = tuple(ndepths)
+        self.depth_interals_ratio = tuple(depth_interals_ratio)
+        self.grad_method = grad_method
+        self.arch_mode = arch_mode
+        self.cr_base_chs = tuple(cr_base_chs)
+        self.num_stage = len(ndepths)
+        self.stage_infos = {"stage1": {"scale": 4.0}, "stage2": {"scale": 2.0}, "stage3": {"scale": 1.0}}
+
+        self.feature = FeatureNet(base_channels=8)
+        self.stage_net = StageNet(num_mvs_stages=self.num_stage)
+        self.cost_regularization = nn.ModuleList([CostRegNet(self.feature.out_channels[i], self.cr_base_chs[i])
+                                                  for i in range(self.num_stage)])
+        if self.refine:
+            self.refine_network = Refinement()
+        self._feature_runner = [_FeatureRunner(self.feature)]  # in a list: not a sub-module
+        # view-shard hook: set by cds_mvsnet_amd.distributed.shard_views(); None = all views on this GPU
+        self._view_shard = None
+
+    # -- helpers -----------------------------------------------------------------------------
+    def extract_pair_features(self, ref_img: Tensor, src_img: Tensor, cam_ref: Tensor, cam_src: Tensor, T: float):
+        """FeatureNet for one (reference, source) pair; reference features are pair specific because
+        DynamicConv is conditioned on the epipole (model.py:154-161)."""
+        e_ref, e_src = geometry.pair_epipoles(cam_ref, cam_src)
+        run = self._feature_runner[0]
+        return run(ref_img, e_ref, T, hwc=False), run(src_img, e_src, T, hwc=True)
+
+    def forward(self, imgs, proj_matrices, depth_values, gt_depths=None, temperature=0.001):
+        if self.training or gt_depths is not None:
+            raise NotImplementedError("CDSMVSNet: training forward (gt_depths / batch-stat BN) is SURVEY §8(f)-2; "
+                                      "call model.eval()")
+        if not imgs.is_cuda:
+            raise RuntimeError("cds_mvsnet_amd.CDSMVSNet runs on a ROCm device only (no CPU fallback); "
+                               "move the model and inputs with .cuda()")
+        B, N, _, Him, Wim = imgs.shape
+        H, W = (Him // 2, Wim // 2) if self.refine else (Him, Wim)
+        if H % 32 or W % 32:
+            raise ValueError("internal resolution must be a multiple of 32 (three stride-2 levels at 1/4 scale)")
+        T = float(temperature)
+        dv = depth_values.detach().float().cpu()
+        cams = {k: v.detach().float().cpu() for k, v in proj_matrices.items()}
+        imgs = imgs.float()
+
+        per_b: List[Dict[str, object]] = []
+        for b in range(B):
+            dmin, dmax = dv[b, 0], dv[b, -1]
+            dint = dv[b, 1] - dv[b, 0]
+            # ---- features, one FeatureNet pass per image of every (ref, src) pair ----
+            ref_img = _resize_nearest(imgs[b, 0], H, W)
+            views = self._my_views(N - 1)
+            pairs = []
+            for v in views:
+                src_img = _resize_nearest(imgs[b, v + 1], H, W)
+                pairs.append(self.extract_pair_features(ref_img, src_img, cams["stage3"][b, 0], cams["stage3"][b, v + 1], T))
+            out_b: Dict[str, object] = {}
+            depth = None
+            for s in range(self.num_stage):
+                name = f"stage{s + 1}"
+                scale = int(self.stage_infos[name]["scale"])
+                h, w = H // scale, W // scale
+                D = self.ndepths[s]
+                if depth is None:
+                    hyp = ops.depth_planes(D, h, w, float(dmin), float(dmax), imgs.device)
+                else:
+                    interval = float(self.depth_interals_ratio[s] * dint)
+                    hyp = ops.depth_hypotheses(depth, D, H, W, scale, interval, float(dmin), float(dmax))
+                ref = torch.stack([p[0][name][0] for p in pairs])
+                src = torch.stack([p[1][name][0] for p in pairs])
+                ref_nc = torch.stack([p[0][name][2] for p in pairs])
+                nc_sums = torch.stack([(p[0][name][1] + p[1][name][1]) / 2 for p in pairs])
+                all_mats = geometry.warp_matrices(cams[name][b])
+                mats = all_mats[views].contiguous()
+                depth, conf, nc = self._run_stage(ref, src, ref_nc, nc_sums, mats, hyp, s, N - 1)
+                out_b[name] = {"depth": depth, "photometric_confidence": conf, "norm_curv": nc.unsqueeze(0)}
+            per_b.append(out_b)
+
+        outputs: Dict[str, object] = {}
+        for s in range(self.num_stage):
+            name = f"stage{s + 1}"
+            st = {k: torch.stack([pb[name][k] for pb in per_b]) for k in ("depth", "photometric_confidence", "norm_curv")}
+            outputs[name] = st
+            outputs.update(st)
+        depth = outputs["depth"]
+        if self.refine:
+            dvd = depth_values.float()
+            dint = (dvd[:, 1] - dvd[:, 0]).view(B, 1, 1)
+            cur = depth / dint
+            refined = self.refine_network(imgs[:, 0], cur.unsqueeze(1), dvd[:, 0] / dint[:, 0, 0], dvd[:, -1] / dint[:, 0, 0])
+            outputs["refined_depth"] = refined.squeeze(1) * dint
+        else:
+            outputs["refined_depth"] = depth
+        return outputs
+
+    # -- view sharding --------------------------------------------------------
+    def _my_views(self, V: int) -> List[int]:
+        sh = self._view_shard
+        return list(range(V)) if sh is None else sh.local_views(V)
+
+    def _run_stage(self, ref, src, ref_nc, nc_sums, mats, hyp, s, V_total):
+        sh = self._view_shard
+        if sh is None:
+            return self.stage_net.run_single(ref, src, ref_nc, nc_sums, mats, hyp, self.cost_regularization[s], s)
+        return sh.run_stage(self, ref, src, ref_nc, nc_sums, mats, hyp, s, V_total)
+
+
+def _resize_nearest(img: Tensor, H: int, W: int) -> Tensor:
+    """F.interpolate(img, (H, W)) with the default nearest mode (model.py:159-160): identity when the size
+    already matches, plain subsampling for the refine=True half-resolution case."""
+    _, h, w = img.shape
+    if (h, w) == (H, W):
+        return img.contiguous()
+    if h == 2 * H and w == 2 * W:
+        return img[:, ::2, ::2].contiguous()
+    return F.interpolate(img.unsqueeze(0), (H, W))[0].contiguous()

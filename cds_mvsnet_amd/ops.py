@@ -1,0 +1,232 @@
+"""Tensor-level wrappers around the C ABI (include/cds_mvsnet_hip.h).
+
+PyTorch is used here only for device memory (allocation through the caching allocator) and for the
+current HIP stream; all arithmetic happens in libcdsmvs_hip.so.  Every function requires fp32,
+contiguous, ROCm-resident tensors and raises otherwise — there is no CPU path.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import (ACT_LEAKY01, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, AGG_ACCUMULATE, AGG_NORMALIZE,
+                   MAX_VIEWS, check)
+
+Tensor = torch.Tensor
+
+
+def _dev(t: Tensor, name: str) -> int:
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a tensor")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: cds_mvsnet_amd ops need a ROCm (cuda) tensor; there is no CPU fallback")
+    if t.dtype != torch.float32:
+        raise TypeError(f"{name}: expected float32, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: tensor must be contiguous")
+    return t.data_ptr()
+
+
+def _host(t: Tensor, name: str) -> int:
+    if t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous():
+        raise ValueError(f"{name}: expected a contiguous float32 CPU tensor")
+    return t.data_ptr()
+
+
+def _stream(t: Tensor) -> int:
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def version() -> int:
+    return _lib.load().cds_version()
+
+
+def chw_to_hwc(x: Tensor) -> Tensor:
+    C, h, w = x.shape
+    out = torch.empty((h, w, C), dtype=torch.float32, device=x.device)
+    check(_lib.load().cds_chw_to_hwc_f32(_dev(x, "x"), out.data_ptr(), C, h, w, _stream(x)), "cds_chw_to_hwc_f32")
+    return out
+
+
+def _hyp_args(hyp: Tensor, D_expected: Optional[int], h: int, w: int) -> Tuple[int, int]:
+    if hyp.dim() == 1:
+        return hyp.shape[0], 0
+    if hyp.dim() == 3 and hyp.shape[1] == h and hyp.shape[2] == w:
+        return hyp.shape[0], 1
+    raise ValueError(f"hypotheses must be [D] or [D,{h},{w}], got {tuple(hyp.shape)}")
+
+
+def homo_warp(src_hwc: Tensor, mat: Tensor, hyp: Tensor) -> Tensor:
+    """models/utils/warping.py:69-104 for one view.  src_hwc [h,w,C], mat CPU [12] -> [C,D,h,w]."""
+    h, w, C = src_hwc.shape
+    D, pp = _hyp_args(hyp, None, h, w)
+    out = torch.empty((C, D, h, w), dtype=torch.float32, device=src_hwc.device)
+    check(_lib.load().cds_homo_warp_f32(_dev(src_hwc, "src_hwc"), _host(mat, "mat"), _dev(hyp, "hyp"), out.data_ptr(),
+                                        C, D, h, w, pp, _stream(out)), "cds_homo_warp_f32")
+    return out
+
+
+def warp_entropy(ref_chw: Tensor, src_hwc: Tensor, mats: Tensor, hyp: Tensor) -> Tensor:
+    """K1.  ref_chw [V,C,h,w], src_hwc [V,h,w,C], mats CPU [V,12], hyp [D,h,w]|[D] -> entropy [V,h,w]."""
+    V, C, h, w = ref_chw.shape
+    if tuple(src_hwc.shape) != (V, h, w, C) or tuple(mats.shape) != (V, 12):
+        raise ValueError("warp_entropy: inconsistent shapes")
+    D, pp = _hyp_args(hyp, None, h, w)
+    ent = torch.empty((V, h, w), dtype=torch.float32, device=ref_chw.device)
+    lib = _lib.load()
+    for v0 in range(0, V, MAX_VIEWS):
+        v1 = min(V, v0 + MAX_VIEWS)
+        check(lib.cds_warp_entropy_f32(_dev(ref_chw[v0:v1], "ref"), _dev(src_hwc[v0:v1], "src"),
+                                       _host(mats[v0:v1], "mats"), _dev(hyp, "hyp"), ent[v0:v1].data_ptr(),
+                                       v1 - v0, C, D, h, w, pp, _stream(ent)), "cds_warp_entropy_f32")
+    return ent
+
+
+def warp_aggregate(ref_chw: Tensor, src_hwc: Tensor, vis_w: Tensor, mats: Tensor, hyp: Tensor,
+                   normalize: bool = True, volume: Optional[Tensor] = None, vis_sum: Optional[Tensor] = None,
+                   accumulate: bool = False) -> Tuple[Tensor, Tensor]:
+    """K3.  Returns (volume [C,D,h,w], vis_sum [h,w]).  With normalize=False the raw visibility-weighted
+    sums are returned (what a source-view shard contributes to the all-reduce)."""
+    V, C, h, w = ref_chw.shape
+    if tuple(src_hwc.shape) != (V, h, w, C) or tuple(mats.shape) != (V, 12) or tuple(vis_w.shape) != (V, h, w):
+        raise ValueError("warp_aggregate: inconsistent shapes")
+    D, pp = _hyp_args(hyp, None, h, w)
+    dev = ref_chw.device
+    if volume is None:
+        if accumulate:
+            raise ValueError("accumulate=True needs an existing volume")
+        volume = torch.empty((C, D, h, w), dtype=torch.float32, device=dev)
+        vis_sum = torch.empty((h, w), dtype=torch.float32, device=dev)
+    lib = _lib.load()
+    nchunks = (V + MAX_VIEWS - 1) // MAX_VIEWS
+    for i, v0 in enumerate(range(0, V, MAX_VIEWS)):
+        v1 = min(V, v0 + MAX_VIEWS)
+        flags = 0
+        if accumulate or i > 0:
+            flags |= AGG_ACCUMULATE
+        if normalize and i == nchunks - 1:
+            flags |= AGG_NORMALIZE
+        check(lib.cds_warp_aggregate_f32(_dev(ref_chw[v0:v1], "ref"), _dev(src_hwc[v0:v1], "src"),
+                                         _dev(vis_w[v0:v1], "vis"), _host(mats[v0:v1], "mats"), _dev(hyp, "hyp"),
+                                         _dev(volume, "volume"), _dev(vis_sum, "vis_sum"), v1 - v0, C, D, h, w, pp,
+                                         flags, _stream(volume)), "cds_warp_aggregate_f32")
+    return volume, vis_sum
+
+
+def volume_normalize_(volume: Tensor, vis_sum: Tensor) -> Tensor:
+    C, D, h, w = volume.shape
+    check(_lib.load().cds_volume_normalize_f32(_dev(volume, "volume"), _dev(vis_sum, "vis_sum"), C, D, h * w,
+                                               _stream(volume)), "cds_volume_normalize_f32")
+    return volume
+
+
+def softargmin_conf(prob_pre: Tensor, hyp: Tensor, want_prob: bool = False):
+    """K5.  prob_pre [D,h,w] -> depth [h,w], confidence [h,w] (and prob [D,h,w] if requested)."""
+    D, h, w = prob_pre.shape
+    D2, pp = _hyp_args(hyp, D, h, w)
+    if D2 != D:
+        raise ValueError("softargmin_conf: hypotheses / volume depth mismatch")
+    depth = torch.empty((h, w), dtype=torch.float32, device=prob_pre.device)
+    conf = torch.empty_like(depth)
+    prob = torch.empty_like(prob_pre) if want_prob else None
+    check(_lib.load().cds_softargmin_conf_f32(_dev(prob_pre, "prob_pre"), _dev(hyp, "hyp"), depth.data_ptr(),
+                                              conf.data_ptr(), prob.data_ptr() if want_prob else None, D, h, w, pp,
+                                              _stream(depth)), "cds_softargmin_conf_f32")
+    return (depth, conf, prob) if want_prob else (depth, conf)
+
+
+def depth_hypotheses(prev_depth: Tensor, D: int, H: int, W: int, scale: int, interval: float, dmin: float,
+                     dmax: float) -> Tensor:
+    """K6.  prev_depth [hp,wp] -> hypotheses [D,H/scale,W/scale]."""
+    hp, wp = prev_depth.shape
+    out = torch.empty((D, H // scale, W // scale), dtype=torch.float32, device=prev_depth.device)
+    check(_lib.load().cds_depth_hypotheses_f32(_dev(prev_depth, "prev_depth"), out.data_ptr(), D, hp, wp, H, W, scale,
+                                               float(interval), float(dmin), float(dmax), _stream(out)),
+          "cds_depth_hypotheses_f32")
+    return out
+
+
+def depth_planes(D: int, h: int, w: int, lo: float, hi: float, device) -> Tensor:
+    out = torch.empty((D, h, w), dtype=torch.float32, device=device)
+    check(_lib.load().cds_depth_planes_f32(out.data_ptr(), D, h, w, float(lo), float(hi), _stream(out)),
+          "cds_depth_planes_f32")
+    return out
+
+
+def conv3d_k3(x: Tensor, wpk: Tensor, bias: Optional[Tensor], stride: int = 1, relu: bool = True,
+              skip: Optional[Tensor] = None) -> Tensor:
+    """K4.  x [Cin,D,H,W], wpk packed [Cin,27,Cout] -> [Cout,Do,Ho,Wo]."""
+    Cin, D, H, W = x.shape
+    if wpk.shape[0] != Cin or wpk.shape[1] != 27:
+        raise ValueError("conv3d_k3: packed weight must be [Cin,27,Cout]")
+    Cout = wpk.shape[2]
+    Do, Ho, Wo = (D - 1) // stride + 1, (H - 1) // stride + 1, (W - 1) // stride + 1
+    out = torch.empty((Cout, Do, Ho, Wo), dtype=torch.float32, device=x.device)
+    if skip is not None and skip.shape != out.shape:
+        raise ValueError("conv3d_k3: residual shape mismatch")
+    check(_lib.load().cds_conv3d_k3_f32(_dev(x, "x"), _dev(wpk, "weight"), _dev(bias, "bias") if bias is not None else None,
+                                        _dev(skip, "skip") if skip is not None else None, out.data_ptr(), Cin, Cout, D, H,
+                                        W, stride, ACT_RELU if relu else ACT_NONE, _stream(x)), "cds_conv3d_k3_f32")
+    return out
+
+
+def deconv3d_k3s2(x: Tensor, wpk: Tensor, bias: Optional[Tensor], relu: bool = True,
+                  skip: Optional[Tensor] = None) -> Tensor:
+    """K4.  x [Cin,D,H,W], wpk packed [Cin,27,Cout] -> [Cout,2D,2H,2W]."""
+    Cin, D, H, W = x.shape
+    if wpk.shape[0] != Cin or wpk.shape[1] != 27:
+        raise ValueError("deconv3d_k3s2: packed weight must be [Cin,27,Cout]")
+    Cout = wpk.shape[2]
+    out = torch.empty((Cout, 2 * D, 2 * H, 2 * W), dtype=torch.float32, device=x.device)
+    if skip is not None and skip.shape != out.shape:
+        raise ValueError("deconv3d_k3s2: residual shape mismatch")
+    check(_lib.load().cds_deconv3d_k3s2_f32(_dev(x, "x"), _dev(wpk, "weight"),
+                                            _dev(bias, "bias") if bias is not None else None,
+                                            _dev(skip, "skip") if skip is not None else None, out.data_ptr(), Cin, Cout,
+                                            D, H, W, ACT_RELU if relu else ACT_NONE, _stream(x)),
+          "cds_deconv3d_k3s2_f32")
+    return out
+
+
+def conv2d(x: Tensor, wpk: Tensor, bias: Optional[Tensor], cout: int, k: int, stride: int = 1, pad: int = 0,
+           act: int = ACT_NONE, out: Optional[Tensor] = None) -> Tensor:
+    """x [N,Cin,H,W], wpk packed [Cin,k*k,CoutP] -> [N,cout,Ho,Wo] (written into `out` if given)."""
+    N, Cin, H, W = x.shape
+    coutp = (cout + 7) // 8 * 8
+    if tuple(wpk.shape) != (Cin, k * k, coutp):
+        raise ValueError(f"conv2d: packed weight must be [{Cin},{k * k},{coutp}], got {tuple(wpk.shape)}")
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    if out is None:
+        out = torch.empty((N, cout, Ho, Wo), dtype=torch.float32, device=x.device)
+    elif out.numel() != N * cout * Ho * Wo:
+        raise ValueError("conv2d: bad output buffer")
+    check(_lib.load().cds_conv2d_f32(_dev(x, "x"), _dev(wpk, "weight"), _dev(bias, "bias") if bias is not None else None,
+                                     _dev(out, "out"), N, Cin, cout, H, W, k, stride, pad, act, _stream(x)),
+          "cds_conv2d_f32")
+    return out
+
+
+def dynconv_blend(branches: Tensor, w1: Tensor, b1: Tensor, w2: Tensor, epipole_xy: Tuple[float, float],
+                  temperature: float) -> Tuple[Tensor, Tensor]:
+    """K7 epilogue.  branches [K,Cout+3,H,W] -> (out [Cout,H,W], norm_curv [H,W])."""
+    K, C3, H, W = branches.shape
+    cout = C3 - 3
+    out = torch.empty((cout, H, W), dtype=torch.float32, device=branches.device)
+    nc = torch.empty((H, W), dtype=torch.float32, device=branches.device)
+    check(_lib.load().cds_dynconv_blend_f32(_dev(branches, "branches"), _dev(w1, "w1"), _dev(b1, "b1"), _dev(w2, "w2"),
+                                            float(epipole_xy[0]), float(epipole_xy[1]), float(temperature),
+                                            out.data_ptr(), nc.data_ptr(), K, cout, H, W, _stream(out)),
+          "cds_dynconv_blend_f32")
+    return out, nc
+
+
+def instnorm_act(x: Tensor, act: int, out_hwc: bool = False) -> Tensor:
+    """K8.  x [C,H,W] -> InstanceNorm + activation; [H,W,C] if out_hwc."""
+    C, H, W = x.shape
+    out = torch.empty((H, W, C) if out_hwc else (C, H, W), dtype=torch.float32, device=x.device)
+    stats = torch.empty((2 * C,), dtype=torch.float64, device=x.device)
+    check(_lib.load().cds_instnorm_act_f32(_dev(x, "x"), out.data_ptr(), stats.data_ptr(), C, H, W, act,
+                                           1 if out_hwc else 0, _stream(x)), "cds_instnorm_act_f32")
+    return out

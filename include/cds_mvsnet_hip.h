@@ -1,0 +1,166 @@
+/*
+ * cds_mvsnet_hip.h — C ABI of libcdsmvs_hip.so, the MI355X (gfx950) implementation of the
+ * CDS-MVSNet plane-sweep hot path.
+ *
+ * The reference (TruongKhang/cds-mvsnet) is pure Python/PyTorch and has no FFI of its own; its
+ * boundary for this path is models.model.CDSMVSNet.forward (models/model.py:140).  Beneath that
+ * boundary this library replaces the PyTorch op sequences listed below.  Each entry point cites
+ * the reference lines it replaces.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to contiguous fp32 unless the name ends in _host;
+ *   - the caller owns all memory; nothing is allocated, freed or synchronised inside;
+ *   - `stream` is a hipStream_t (NULL = default stream); calls are re-entrant across streams;
+ *   - return value: 0 on success, a negative hipError_t on a launch failure,
+ *     CDS_EINVAL (-1000) for invalid arguments;
+ *   - batch: one call handles one batch item (the Python host loops over B).
+ *
+ * Layouts: feature maps NCHW without the N ([C][h][w]); channels-last copies [h][w][C] where
+ * stated; cost volumes [C][D][h][w]; per-pixel hypotheses [D][h][w].
+ */
+#ifndef CDS_MVSNET_HIP_H
+#define CDS_MVSNET_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CDS_EINVAL (-1000)
+#define CDS_MAX_VIEWS 8 /* source views per launch; more are handled by chunked calls */
+
+/* activation codes for the conv entry points */
+#define CDS_ACT_NONE 0
+#define CDS_ACT_RELU 1
+#define CDS_ACT_LEAKY01 2 /* LeakyReLU(0.1) */
+#define CDS_ACT_SIGMOID 3
+#define CDS_ACT_TANH 4
+
+/* flags of cds_warp_aggregate_f32 */
+#define CDS_AGG_ACCUMULATE 1 /* add onto the existing volume / vis_sum instead of overwriting */
+#define CDS_AGG_NORMALIZE 2  /* divide by (vis_sum + 1e-6) before the store (model.py:74) */
+
+/* Library version (major*10000 + minor*100 + patch). */
+int cds_version(void);
+
+/* [C][h][w] -> [h][w][C] re-layout of one feature map (source maps are gathered channels-last). */
+int cds_chw_to_hwc_f32(const float* src_chw, float* dst_hwc, int C, int h, int w, void* stream);
+
+/*
+ * homo_warping_3D (models/utils/warping.py:69-104): bilinear, zero padding, align_corners=True.
+ *   src_hwc   [h][w][C]   source feature map, channels-last
+ *   mat_host  12 floats   rows of (P_src * P_ref^-1)[:3,:3] then its [:3,3] (warping.py:80-82)
+ *   hyp       [D][h][w] if hyp_per_pixel else [D]
+ *   out       [C][D][h][w]
+ */
+int cds_homo_warp_f32(const float* src_hwc, const float* mat_host, const float* hyp, float* out,
+                      int C, int D, int h, int w, int hyp_per_pixel, void* stream);
+
+/*
+ * K1 "warp-correlate-entropy" (warping.py:79-102 + model.py:46-50): for every source view v and
+ * pixel, the entropy over D of softmax_D( sum_C ref_v * warp(src_v) ).  Never materialises the
+ * warped volume.
+ *   ref_chw   [V][C][h][w]  per-pair reference features
+ *   src_hwc   [V][h][w][C]  source features, channels-last
+ *   mats_host [V][12]
+ *   entropy   [V][h][w]
+ */
+int cds_warp_entropy_f32(const float* ref_chw, const float* src_hwc, const float* mats_host,
+                         const float* hyp, float* entropy, int V, int C, int D, int h, int w,
+                         int hyp_per_pixel, void* stream);
+
+/*
+ * K3 "warp-aggregate" (model.py:44-47,57-60,74): volume = sum_v vis_v * (ref_v (x) warp(src_v)),
+ * vis_sum = sum_v vis_v, optionally normalised by (vis_sum + 1e-6).  The volume is written once.
+ *   vis_w     [V][h][w]
+ *   volume    [C][D][h][w]
+ *   vis_sum   [h][w]
+ *   flags     CDS_AGG_*
+ * V <= CDS_MAX_VIEWS per call.
+ */
+int cds_warp_aggregate_f32(const float* ref_chw, const float* src_hwc, const float* vis_w,
+                           const float* mats_host, const float* hyp, float* volume, float* vis_sum,
+                           int V, int C, int D, int h, int w, int hyp_per_pixel, int flags,
+                           void* stream);
+
+/* volume[c][d][p] /= (vis_sum[p] + 1e-6)  (model.py:74) — the finalisation after a view-shard
+ * all-reduce of partial sums. */
+int cds_volume_normalize_f32(float* volume, const float* vis_sum, int C, int D, int hw, void* stream);
+
+/*
+ * K5 (model.py:90-92, module.py:373-391): softmax over D, depth = sum p*hyp, confidence =
+ * sum of p over [i-1,i+2] at i = clamp(trunc(sum p*index),0,D-1).  prob (may be NULL) receives
+ * the softmax volume [D][h][w].
+ */
+int cds_softargmin_conf_f32(const float* prob_pre, const float* hyp, float* depth, float* conf,
+                            float* prob, int D, int h, int w, int hyp_per_pixel, void* stream);
+
+/*
+ * K6 (module.py:394-439 + model.py:176-193): per-pixel hypotheses of a cascade stage.
+ *   prev_depth [hp][wp]  previous stage depth map; it is bilinearly (align_corners=False)
+ *                        upsampled to H x W, sampled at  up - ((D-1)/2)*interval + k*interval,
+ *                        clamped to [dmin,dmax] and resized trilinearly to [D][H/scale][W/scale].
+ *   out        [D][H/scale][W/scale]
+ */
+int cds_depth_hypotheses_f32(const float* prev_depth, float* out, int D, int hp, int wp, int H, int W,
+                             int scale, float interval, float dmin, float dmax, void* stream);
+
+/* First-stage planes: out[k][y][x] = lo + k*((hi-lo)/(D-1))  (module.py:425-433). */
+int cds_depth_planes_f32(float* out, int D, int h, int w, float lo, float hi, void* stream);
+
+/*
+ * K4 (module.py:80-116,270-315): 3x3x3 convolution, padding 1, stride 1 or 2, with fused
+ * per-channel bias (folded BatchNorm3d), optional ReLU and optional residual added AFTER the
+ * activation (module.py:311-313).
+ *   x [Cin][D][H][W]; bias [Cout] or NULL; skip like out or NULL
+ *   weight PACKED [Cin][27][Cout] (tap = (kz*3+ky)*3+kx, cout fastest) — i.e. PyTorch's
+ *          [Cout][Cin][3][3][3] permuted (1,2,3,4,0); Cout must be 1 or a multiple of 8
+ *   out [Cout][Do][Ho][Wo], Xo = (X-1)/stride+1
+ */
+int cds_conv3d_k3_f32(const float* x, const float* weight, const float* bias, const float* skip,
+                      float* out, int Cin, int Cout, int D, int H, int W, int stride, int act,
+                      void* stream);
+
+/*
+ * K4 (module.py:125-160): ConvTranspose3d k=3, stride 2, padding 1, output_padding 1 (doubles
+ * D,H,W) + bias + activation + residual.
+ *   weight PACKED [Cin][27][Cout] — PyTorch's transposed-conv layout [Cin][Cout][3][3][3]
+ *          permuted (0,2,3,4,1) (no flip: out[2*zi-1+kz] += x[zi]*w[kz]); Cout multiple of 8
+ *   x [Cin][D][H][W] -> out [Cout][2D][2H][2W]
+ */
+int cds_deconv3d_k3s2_f32(const float* x, const float* weight, const float* bias, const float* skip,
+                          float* out, int Cin, int Cout, int D, int H, int W, int act, void* stream);
+
+/*
+ * Direct 2D convolution (vis CNN model.py:14; FeatureNet branches dynamic_conv.py:112,116;
+ * module.py:28-71).  Square kernel k in {1,3,5,7,11} at stride 1, k = 3 at stride 2, zero padding.
+ *   x [N][Cin][H][W]; bias [Cout] or NULL; out [N][Cout][Ho][Wo]
+ *   weight PACKED [Cin][k*k][CoutP], CoutP = Cout rounded up to a multiple of 8 (zero padded),
+ *          cout fastest — PyTorch's [Cout][Cin][k][k] permuted (1,2,3,0)
+ */
+int cds_conv2d_f32(const float* x, const float* weight, const float* bias, float* out, int N, int Cin,
+                   int Cout, int H, int W, int k, int stride, int pad, int act, void* stream);
+
+/*
+ * K7 epilogue of DynamicConv (dynamic_conv.py:97-122): epipolar projection of the K 3-channel
+ * curvature responses, 1x1 MLP (K->4, folded BN, ReLU, 4->K), softmax(./temperature), blend.
+ *   branches [K][Cout+3][H][W]  per kernel size: the Cout responses of convs[k] followed by the
+ *                               3 responses of att_convs[k] (one fused cds_conv2d_f32 per size)
+ *   w1 [4][K], b1 [4] (BN folded), w2 [K][4]          (device pointers); K in {2,3}
+ *   out [Cout][H][W]; norm_curv [H][W]
+ */
+int cds_dynconv_blend_f32(const float* branches, const float* w1, const float* b1, const float* w2,
+                          float epi_x, float epi_y, float temperature, float* out, float* norm_curv,
+                          int K, int Cout, int H, int W, void* stream);
+
+/*
+ * K8 (module.py:53,66-69,223,230,232): InstanceNorm2d (no affine, eps 1e-5, biased variance)
+ * followed by LeakyReLU(0.1) or tanh.  x [C][H][W]; `stats` is a caller-provided, 8-byte aligned
+ * scratch of 4*C floats (per-channel fp64 sum and sum of squares).  If out_hwc is non-zero the result is written channels-last [H][W][C].
+ */
+int cds_instnorm_act_f32(const float* x, float* out, float* stats, int C, int H, int W, int act,
+                         int out_hwc, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CDS_MVSNET_HIP_H */

@@ -1,0 +1,219 @@
+"""Capture golden input/output vectors from the REFERENCE implementation (CPU, fp32).
+
+Run in the build container only (``/root/reference`` is not present on the GPU box):
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+The reference is imported read-only; weights come from this repo's own seeded initialiser
+(``cds_mvsnet_amd.seeded_init_``) and are loaded into the reference through the shared state-dict
+keys, so no reference weights or source text are vendored.  Only data (inputs + expected outputs) is
+written, as ``tests/golden/*.npz``.  Fixtures: G1 warp/aggregate, G2 CostRegNet,
+G3 regression, G4 hypotheses, G5 DynamicConv/FeatureNet/epipoles, G6 full forward.
+"""
+import os
+import sys
+import warnings
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root/reference")
+warnings.filterwarnings("ignore")
+torch.set_num_threads(8)
+
+from models.model import CDSMVSNet as RefNet  # noqa: E402  (reference)
+from models.module import CostRegNet as RefCostReg, FeatureNet as RefFeatureNet  # noqa: E402
+from models.module import conf_regression, depth_regression, get_depth_range_samples  # noqa: E402
+from models.dynamic_conv import DynamicConv as RefDynConv, compute_Fmatrix, compute_epipole  # noqa: E402
+from models.utils.warping import homo_warping_3D  # noqa: E402
+
+from cds_mvsnet_amd import seeded_init_, synth  # noqa: E402
+
+SEED = 7
+
+
+def save(name, **arrays):
+    out = {}
+    for k, v in arrays.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}: {os.path.getsize(path) / 1e6:.2f} MB", {k: v.shape for k, v in out.items()})
+
+
+def ref_model(refine):
+    m = RefNet(refine=refine, ndepths=(48, 32, 8), depth_interals_ratio=(4.0, 1.5, 0.75))
+    seeded_init_(m, SEED)
+    return m.eval()
+
+
+@torch.no_grad()
+def g1_warp_aggregate():
+    model = ref_model(False)
+    for tag, (h, w, D, C, N, stage) in {"a": (32, 40, 16, 8, 3, 2), "b": (16, 24, 48, 32, 3, 0),
+                                        "c": (24, 32, 16, 16, 4, 1)}.items():
+        feats = synth.make_pair_features(N - 1, C, h, w, seed=11 + stage, sharp=(tag != "a"))
+        cams = synth.stage_cameras(N, h, w, seed=3 + stage)
+        hyp = synth.make_hypotheses(D, h, w, seed=5 + stage)
+        captured = {}
+
+        def vis_hook(mod, inp, out, store=captured):
+            store.setdefault("vis_in", []).append(inp[0].clone())
+            store.setdefault("vis_out", []).append(out.clone())
+
+        def cr_hook(mod, inp, store=captured):
+            store["volume_mean"] = inp[0].clone()
+
+        h1 = model.stage_net.vis[stage].register_forward_hook(vis_hook)
+        h2 = model.cost_regularization[stage].register_forward_pre_hook(cr_hook)
+        out = model.stage_net(feats, cams, depth_values=hyp, num_depth=D,
+                              cost_regularization=model.cost_regularization[stage], stage_idx=stage)
+        h1.remove()
+        h2.remove()
+        # plain warp of view 0 + the matrices the reference derives (model.py:40-43, warping.py:80)
+        projs = []
+        for v in range(N):
+            P = cams[:, v, 0].clone()
+            P[:, :3, :4] = torch.matmul(cams[:, v, 1, :3, :3], cams[:, v, 0, :3, :4])
+            projs.append(P)
+        mats = []
+        for v in range(1, N):
+            M = torch.matmul(projs[v], torch.inverse(projs[0]))[0]
+            mats.append(torch.cat((M[:3, :3].reshape(9), M[:3, 3].reshape(3))))
+        warped0 = homo_warping_3D(feats[0]["src"][0], projs[1], projs[0], hyp)
+        save(f"g1_warp_aggregate_{tag}",
+             ref_fea=torch.cat([f["ref"][0] for f in feats]), src_fea=torch.cat([f["src"][0] for f in feats]),
+             ref_nc_sum=torch.cat([f["ref"][1] for f in feats]), src_nc_sum=torch.cat([f["src"][1] for f in feats]),
+             ref_nc=torch.cat([f["ref"][2] for f in feats]), cams=cams, hyp=hyp, mats=torch.stack(mats),
+             stage=np.int64(stage), warped0=warped0[0] if tag == "a" else np.zeros(1, np.float32),
+             entropy=torch.cat([x[:, 0] for x in captured["vis_in"]]), vis_w=torch.cat([x[:, 0] for x in captured["vis_out"]]),
+             volume_mean=captured["volume_mean"][0], depth=out["depth"], conf=out["photometric_confidence"],
+             norm_curv=out["norm_curv"])
+
+
+@torch.no_grad()
+def g2_costreg():
+    for tag, (C, D, h, w) in {"c8": (8, 8, 16, 24), "c16": (16, 16, 16, 24), "c32": (32, 8, 16, 24),
+                              "c8_wide": (8, 8, 8, 64)}.items():
+        net = RefCostReg(in_channels=C, base_channels=8)
+        seeded_init_(net, SEED + C)
+        net.eval()
+        g = torch.Generator().manual_seed(C)
+        vol = 0.3 * torch.randn(1, C, D, h, w, generator=g)
+        save(f"g2_costreg_{tag}", volume=vol[0], cost_reg=net(vol)[0, 0], seed=np.int64(SEED + C))
+
+
+@torch.no_grad()
+def g3_regress():
+    g = torch.Generator().manual_seed(3)
+    for tag, (D, h, w) in {"d48": (48, 16, 24), "d8": (8, 16, 24), "d192": (192, 8, 16)}.items():
+        pre = 2.0 * torch.randn(1, D, h, w, generator=g)
+        # edge cases: sharp peaks at the first / last plane and at an interior plane
+        pre[0, 0, 0, :8] += 30.0
+        pre[0, D - 1, 1, :8] += 30.0
+        pre[0, D // 2, 2, :8] += 30.0
+        pre[0, 1, 3, :8] += 12.0
+        pre[0, D - 2, 4, :8] += 12.0
+        hyp = synth.make_hypotheses(D, h, w, seed=D)
+        prob = F.softmax(pre, dim=1)
+        save(f"g3_regress_{tag}", prob_pre=pre[0], hyp=hyp[0], prob=prob[0], depth=depth_regression(prob, hyp)[0],
+             conf=conf_regression(prob)[0])
+
+
+@torch.no_grad()
+def g4_hypotheses():
+    g = torch.Generator().manual_seed(4)
+    H, W = 64, 96
+    dv = synth.make_depth_values()
+    dmin, dmax = dv[:, [0]].unsqueeze(-1).unsqueeze(-1), dv[:, [-1]].unsqueeze(-1).unsqueeze(-1)
+    dint = (dv[:, 1] - dv[:, 0]).unsqueeze(-1).unsqueeze(-1)
+    cases = {}
+    # first stage: global planes
+    full = get_depth_range_samples(cur_depth=dv, ndepth=48, depth_inteval_pixel=4.0 * dint, dtype=torch.float32,
+                                   device=torch.device("cpu"), shape=[1, H, W], max_depth=dmax, min_depth=dmin)
+    cases["s1"] = F.interpolate(full.unsqueeze(1), [48, H // 4, W // 4], mode="trilinear", align_corners=False).squeeze(1)
+    # later stages, previous depth spans beyond both clamps
+    for tag, (hp, wp, D, ratio, scale) in {"s2": (H // 4, W // 4, 32, 1.5, 2), "s3": (H // 2, W // 2, 8, 0.75, 1),
+                                           "s2x4": (H // 4, W // 4, 16, 4.0, 4)}.items():
+        prev = 415.0 + 500.0 * torch.rand(1, hp, wp, generator=g)
+        cur = F.interpolate(prev.unsqueeze(1), [H, W], mode="bilinear", align_corners=False).squeeze(1)
+        full = get_depth_range_samples(cur_depth=cur, ndepth=D, depth_inteval_pixel=ratio * dint, dtype=torch.float32,
+                                       device=torch.device("cpu"), shape=[1, H, W], max_depth=dmax, min_depth=dmin)
+        cases[tag] = F.interpolate(full.unsqueeze(1), [D, H // scale, W // scale], mode="trilinear",
+                                   align_corners=False).squeeze(1)
+        cases[tag + "_prev"] = prev
+        cases[tag + "_meta"] = np.array([D, ratio, scale], dtype=np.float64)
+    save("g4_hypotheses", depth_values=dv, H=np.int64(H), W=np.int64(W), **cases)
+
+
+@torch.no_grad()
+def g5_features():
+    H, W = 64, 96
+    cams = synth.make_cameras(3, H, W, refine=False, seed=5)["stage3"]
+    Fm = compute_Fmatrix(cams[:, 0], cams[:, 1])
+    e_ref, e_src = compute_epipole(Fm), compute_epipole(torch.transpose(Fm, 1, 2))
+    img = synth.make_images(1, H, W, seed=5)[:, 0]
+    # single DynamicConv (K = 3) with bias
+    dc = RefDynConv(3, 8, size_kernels=(3, 7, 11))
+    seeded_init_(dc, SEED)
+    dc.eval()
+    dyn = {}
+    for T in (1.0, 0.1, 0.01):
+        y, nc = dc(img, epipole=e_ref, temperature=T)
+        dyn[f"y_T{T}"] = y[0]
+        dyn[f"nc_T{T}"] = nc[0, 0]
+    save("g5_dynconv", img=img[0], cams=cams, fmatrix=Fm, epipole_ref=e_ref, epipole_src=e_src, **dyn)
+    net = RefFeatureNet(base_channels=8, arch_mode="fpn")
+    seeded_init_(net, SEED)
+    net.eval()
+    feats = {}
+    for T in (1.0, 0.01):
+        out = net(img, epipole=e_ref, temperature=T)
+        for s in ("stage1", "stage2", "stage3"):
+            feats[f"{s}_fea_T{T}"] = out[s][0][0]
+            feats[f"{s}_ncsum_T{T}"] = out[s][1][0, 0]
+            feats[f"{s}_nc_T{T}"] = out[s][2][0, 0]
+    save("g5_featurenet", img=img[0], epipole=e_ref, **feats)
+
+
+@torch.no_grad()
+def g6_forward():
+    for tag, (refine, H, W) in {"norefine": (False, 128, 160), "refine": (True, 128, 192)}.items():
+        model = ref_model(refine)
+        N = 3
+        imgs = synth.make_images(N, H, W, seed=6)
+        cams = synth.make_cameras(N, H, W, refine=refine, seed=6)
+        dv = synth.make_depth_values()
+        hyps = []
+
+        def pre_hook(mod, args, kwargs, store=hyps):
+            store.append(kwargs["depth_values"].clone())
+
+        hk = model.stage_net.register_forward_pre_hook(pre_hook, with_kwargs=True)
+        out = model(imgs, cams, dv, temperature=0.01)
+        hk.remove()
+        arrays = {"imgs": imgs, "depth_values": dv, "refined_depth": out["refined_depth"]}
+        for k, v in cams.items():
+            arrays["cam_" + k] = v
+        for s in range(3):
+            st = out[f"stage{s + 1}"]
+            arrays[f"stage{s + 1}_depth"] = st["depth"]
+            arrays[f"stage{s + 1}_conf"] = st["photometric_confidence"]
+            arrays[f"stage{s + 1}_norm_curv"] = st["norm_curv"]
+            arrays[f"stage{s + 1}_hyp"] = hyps[s][0, :, ::4, ::4]  # sub-sampled: pins the hypothesis generator
+        save(f"g6_forward_{tag}", **arrays)
+
+
+if __name__ == "__main__":
+    g1_warp_aggregate()
+    g2_costreg()
+    g3_regress()
+    g4_hypotheses()
+    g5_features()
+    g6_forward()

@@ -1,0 +1,301 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the golden vectors captured from the
+reference and against the CPU oracle on seeded inputs.  Run with ``pytest -m gpu`` on an MI355X.
+
+Tolerances (fp32): warped / aggregated volume <= 1e-5 abs (observed ~1e-7),
+entropy / visibility <= 2e-5, CostRegNet output <= 1e-4, features <= 5e-5, stage depth mean-L1 <= 1e-3
+(the reference is not bit-stable against itself below ~2e-4).
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from cds_mvsnet_amd import ops as o
+    assert o.version() >= 100
+    return o
+
+
+def _stage_inputs(g, dev, ops):
+    ref = g["ref_fea"].to(dev).contiguous()
+    src_hwc = torch.stack([ops.chw_to_hwc(s.contiguous()) for s in g["src_fea"].to(dev)])
+    return ref, src_hwc, g["mats"].contiguous(), g["hyp"][0].to(dev).contiguous()
+
+
+def test_chw_to_hwc(dev, ops):
+    x = torch.randn(16, 24, 40, device=dev)
+    assert torch.equal(ops.chw_to_hwc(x), x.permute(1, 2, 0).contiguous())
+
+
+def test_homo_warp_matches_reference_grid_sample(dev, ops):
+    g = load_golden("g1_warp_aggregate_a")
+    _, src_hwc, mats, hyp = _stage_inputs(g, dev, ops)
+    out = ops.homo_warp(src_hwc[0], mats[0], hyp).cpu()
+    diff = (out - g["warped0"]).abs()
+    assert diff.max() < 1e-6, diff.max()
+    assert (out != g["warped0"]).float().mean() < 1e-3  # op order is pinned: almost every voxel is bit-identical
+
+
+def test_homo_warp_plane_hypotheses(dev, ops):
+    """[D] (per-plane) hypotheses == the same planes broadcast per pixel (warping.py accepts both)."""
+    g = load_golden("g1_warp_aggregate_a")
+    _, src_hwc, mats, _ = _stage_inputs(g, dev, ops)
+    planes = torch.linspace(425, 900, 12, device=dev)
+    h, w, _ = src_hwc[0].shape
+    a = ops.homo_warp(src_hwc[0], mats[0], planes)
+    b = ops.homo_warp(src_hwc[0], mats[0], planes.view(-1, 1, 1).expand(-1, h, w).contiguous())
+    assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_warp_entropy(tag, dev, ops):
+    g = load_golden(f"g1_warp_aggregate_{tag}")
+    ref, src_hwc, mats, hyp = _stage_inputs(g, dev, ops)
+    ent = ops.warp_entropy(ref, src_hwc, mats, hyp).cpu()
+    assert (ent - g["entropy"]).abs().max() < 2e-5
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_visibility_cnn(tag, dev, seeded_state):
+    g = load_golden(f"g1_warp_aggregate_{tag}")
+    model = seeded_state(False).to(dev)
+    vis = model.stage_net.visibility(g["entropy"].to(dev), g["ref_nc"][:, 0].to(dev).contiguous(), int(g["stage"])).cpu()
+    assert (vis - g["vis_w"]).abs().max() < 1e-5
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_warp_aggregate(tag, dev, ops):
+    g = load_golden(f"g1_warp_aggregate_{tag}")
+    ref, src_hwc, mats, hyp = _stage_inputs(g, dev, ops)
+    vol, vis_sum = ops.warp_aggregate(ref, src_hwc, g["vis_w"].to(dev).contiguous(), mats, hyp)
+    diff = (vol.cpu() - g["volume_mean"]).abs()
+    assert diff.max() < 1e-5, diff.max()
+    assert (vis_sum.cpu() - g["vis_w"].sum(0)).abs().max() < 1e-6
+
+
+@pytest.mark.parametrize("tag", ["a", "c"])
+def test_view_shards_sum_to_unsharded(tag, dev, ops):
+    """partial volume sums over disjoint view subsets add up (fp32 re-association only)."""
+    g = load_golden(f"g1_warp_aggregate_{tag}")
+    ref, src_hwc, mats, hyp = _stage_inputs(g, dev, ops)
+    vis = g["vis_w"].to(dev).contiguous()
+    full, _ = ops.warp_aggregate(ref, src_hwc, vis, mats, hyp)
+    V = ref.shape[0]
+    parts = [ops.warp_aggregate(ref[v:v + 1], src_hwc[v:v + 1], vis[v:v + 1], mats[v:v + 1].contiguous(), hyp,
+                                normalize=False) for v in range(V)]
+    vol = sum(p[0] for p in parts)
+    vs = sum(p[1] for p in parts)
+    ops.volume_normalize_(vol, vs)
+    assert (vol - full).abs().max() < 1e-6
+    # accumulate flag: second call adds onto the first
+    v0, s0 = ops.warp_aggregate(ref[:1], src_hwc[:1], vis[:1], mats[:1].contiguous(), hyp, normalize=False)
+    v1, s1 = ops.warp_aggregate(ref[1:], src_hwc[1:], vis[1:], mats[1:].contiguous(), hyp, normalize=True, volume=v0,
+                                vis_sum=s0, accumulate=True)
+    assert (v1 - full).abs().max() < 1e-6
+
+
+@pytest.mark.parametrize("tag,C", [("c8", 8), ("c16", 16), ("c32", 32), ("c8_wide", 8)])
+def test_costreg(tag, C, dev):
+    from cds_mvsnet_amd import CostRegNet, seeded_init_
+    g = load_golden(f"g2_costreg_{tag}")
+    net = CostRegNet(C, 8)
+    seeded_init_(net, int(g["seed"]))
+    net = net.to(dev).eval()
+    out = net(g["volume"].to(dev).contiguous()).cpu()
+    err = (out - g["cost_reg"]).abs().max()
+    assert err < 1e-4, err
+
+
+def test_conv3d_layers_vs_torch(dev, ops):
+    """Every conv flavour of K4 against the plain fp32 torch op on the CPU (odd sizes exercise the tile edges)."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(0)
+    for (cin, cout, D, H, W, stride) in [(8, 8, 5, 9, 70, 1), (8, 16, 6, 10, 22, 2), (16, 16, 3, 7, 13, 1),
+                                          (32, 64, 4, 6, 10, 2), (8, 1, 4, 9, 50, 1), (64, 64, 1, 2, 3, 1)]:
+        x = torch.randn(cin, D, H, W, generator=g)
+        w = torch.randn(cout, cin, 3, 3, 3, generator=g) * 0.1
+        b = torch.randn(cout, generator=g)
+        ref = F.relu(F.conv3d(x[None], w, b, stride=stride, padding=1))[0]
+        skip = torch.randn(ref.shape, generator=g)
+        wpk = w.permute(1, 2, 3, 4, 0).reshape(cin, 27, cout).contiguous().to(dev)
+        out = ops.conv3d_k3(x.to(dev), wpk, b.to(dev), stride=stride, relu=True, skip=skip.to(dev)).cpu()
+        assert (out - (ref + skip)).abs().max() < 2e-5 * max(1.0, ref.abs().max().item()), (cin, cout, stride)
+    for (cin, cout, D, H, W) in [(16, 8, 3, 5, 50), (64, 32, 1, 2, 3), (32, 16, 2, 6, 9)]:
+        x = torch.randn(cin, D, H, W, generator=g)
+        w = torch.randn(cin, cout, 3, 3, 3, generator=g) * 0.1
+        b = torch.randn(cout, generator=g)
+        ref = F.relu(F.conv_transpose3d(x[None], w, b, stride=2, padding=1, output_padding=1))[0]
+        skip = torch.randn(ref.shape, generator=g)
+        wpk = w.permute(0, 2, 3, 4, 1).reshape(cin, 27, cout).contiguous().to(dev)
+        out = ops.deconv3d_k3s2(x.to(dev), wpk, b.to(dev), relu=True, skip=skip.to(dev)).cpu()
+        assert (out - (ref + skip)).abs().max() < 2e-5 * max(1.0, ref.abs().max().item()), (cin, cout)
+
+
+def test_conv2d_vs_torch(dev, ops):
+    import torch.nn.functional as F
+    from cds_mvsnet_amd.model import _pack2d
+    g = torch.Generator().manual_seed(1)
+    for (n, cin, cout, H, W, k, s) in [(1, 3, 11, 37, 70, 11, 1), (2, 8, 11, 20, 33, 7, 1), (1, 16, 19, 18, 30, 5, 1),
+                                       (3, 2, 16, 16, 24, 3, 1), (1, 8, 16, 21, 35, 3, 2), (1, 48, 16, 9, 14, 1, 1),
+                                       (2, 16, 1, 9, 14, 1, 1)]:
+        x = torch.randn(n, cin, H, W, generator=g)
+        w = torch.randn(cout, cin, k, k, generator=g) * 0.1
+        b = torch.randn(cout, generator=g)
+        pad = (k - 1) // 2
+        ref = F.conv2d(x, w, b, stride=s, padding=pad)
+        out = ops.conv2d(x.to(dev), _pack2d(w).to(dev), b.to(dev), cout, k, s, pad).cpu()
+        assert out.shape == ref.shape
+        assert (out - ref).abs().max() < 2e-5 * max(1.0, ref.abs().max().item()), (cin, cout, k, s)
+
+
+@pytest.mark.parametrize("tag", ["d48", "d8", "d192"])
+def test_softargmin_conf(tag, dev, ops):
+    g = load_golden(f"g3_regress_{tag}")
+    depth, conf, prob = ops.softargmin_conf(g["prob_pre"].to(dev), g["hyp"].to(dev), want_prob=True)
+    assert (prob.cpu() - g["prob"]).abs().max() < 1e-6
+    assert (depth.cpu() - g["depth"]).abs().max() < 5e-4
+    # the gathered window index is floor(sum p*idx): a 1-ulp difference can flip it for isolated pixels
+    bad = ((conf.cpu() - g["conf"]).abs() > 1e-5).float().mean()
+    assert bad <= 0.01, bad
+    # edge rows: peaks at d=0 / d=D-1 (window clipped by the zero padding) must match exactly enough
+    assert (conf.cpu()[:5, :8] - g["conf"][:5, :8]).abs().max() < 1e-5
+
+
+def test_depth_hypotheses(dev, ops):
+    g = load_golden("g4_hypotheses")
+    dv = g["depth_values"]
+    H, W = int(g["H"]), int(g["W"])
+    dmin, dmax, dint = float(dv[0, 0]), float(dv[0, -1]), dv[0, 1] - dv[0, 0]
+    s1 = ops.depth_planes(48, H // 4, W // 4, dmin, dmax, dev).cpu()
+    assert torch.equal(s1, g["s1"][0])
+    for tag in ("s2", "s3", "s2x4"):
+        D, ratio, scale = g[tag + "_meta"]
+        interval = float(float(ratio) * dint)
+        out = ops.depth_hypotheses(g[tag + "_prev"][0].to(dev).contiguous(), int(D), H, W, int(scale), interval, dmin,
+                                   dmax).cpu()
+        diff = (out - g[tag][0]).abs()
+        assert diff.max() < 1e-4, (tag, diff.max())
+        assert (out != g[tag][0]).float().mean() < 0.01, tag  # op order pinned: (nearly) bit-identical
+
+
+def test_dynconv_and_epipoles(dev, ops, seeded_state):
+    from cds_mvsnet_amd import geometry, seeded_init_
+    from cds_mvsnet_amd.model import DynamicConv, FeatureNet, _FeatureRunner
+    g = load_golden("g5_dynconv")
+    e_ref, e_src = geometry.pair_epipoles(g["cams"][0, 0], g["cams"][0, 1])
+    assert abs(e_ref[0] - float(g["epipole_ref"][0, 0])) <= 1e-3 * abs(e_ref[0]) + 1e-3
+    assert abs(e_src[1] - float(g["epipole_src"][0, 1])) <= 1e-3 * abs(e_src[1]) + 1e-3
+    # a single K=3 DynamicConv with bias through conv2d + blend
+    dc = DynamicConv(3, 8, (3, 7, 11))
+    seeded_init_(dc, 7)
+    dc = dc.to(dev).eval()
+
+    class _Holder(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.dc = dc
+    runner = _FeatureRunner.__new__(_FeatureRunner)
+    packed = {}
+    for i, k in enumerate(dc.size_kernels):
+        from cds_mvsnet_amd.model import _pack2d, _bn_fold
+        packed[f"dc.w{i}"] = _pack2d(torch.cat((dc.convs[i].weight.detach(), dc.att_convs[i].weight.detach()), 0))
+        packed[f"dc.b{i}"] = torch.cat((dc.convs[i].bias.detach(), torch.zeros(3, device=dev))).contiguous()
+    scale, shift = _bn_fold(dc.att_weights[1])
+    packed["dc.m1"] = (dc.att_weights[0].weight.detach().reshape(4, 3) * scale.view(4, 1)).contiguous()
+    packed["dc.mb"] = shift.contiguous()
+    packed["dc.m2"] = dc.att_weights[3].weight.detach().reshape(3, 4).contiguous()
+    epi = (float(g["epipole_ref"][0, 0]), float(g["epipole_ref"][0, 1]))
+    for T in (1.0, 0.1, 0.01):
+        y, nc = runner._dynamic(packed, "dc", dc, g["img"].to(dev).contiguous(), epi, T)
+        assert (y.cpu() - g[f"y_T{T}"]).abs().max() < 5e-5, T
+        assert (nc.cpu() - g[f"nc_T{T}"]).abs().max() < 5e-5, T
+
+
+def test_featurenet(dev, seeded_state):
+    from cds_mvsnet_amd import FeatureNet, seeded_init_
+    from cds_mvsnet_amd.model import _FeatureRunner
+    g = load_golden("g5_featurenet")
+    net = FeatureNet(8)
+    seeded_init_(net, 7)
+    net = net.to(dev).eval()
+    run = _FeatureRunner(net)
+    epi = (float(g["epipole"][0, 0]), float(g["epipole"][0, 1]))
+    for T in (1.0, 0.01):
+        out = run(g["img"].to(dev).contiguous(), epi, T, hwc=False)
+        out_hwc = run(g["img"].to(dev).contiguous(), epi, T, hwc=True)
+        for s in ("stage1", "stage2", "stage3"):
+            assert (out[s][0].cpu() - g[f"{s}_fea_T{T}"]).abs().max() < 5e-5, (s, T)
+            assert (out[s][1].cpu() - g[f"{s}_ncsum_T{T}"]).abs().max() < 5e-5, (s, T)
+            assert (out[s][2].cpu() - g[f"{s}_nc_T{T}"]).abs().max() < 5e-5, (s, T)
+            assert torch.equal(out_hwc[s][0].permute(2, 0, 1), out[s][0])
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_stage_net_reference_signature(tag, dev, seeded_state):
+    """StageNet.forward with the reference's own call signature (model.py:16) vs the reference output."""
+    g = load_golden(f"g1_warp_aggregate_{tag}")
+    model = seeded_state(False).to(dev)
+    stage = int(g["stage"])
+    V = g["ref_fea"].shape[0]
+    feats = [{"ref": (g["ref_fea"][v:v + 1].to(dev), g["ref_nc_sum"][v:v + 1].to(dev), g["ref_nc"][v:v + 1].to(dev)),
+              "src": (g["src_fea"][v:v + 1].to(dev), g["src_nc_sum"][v:v + 1].to(dev), None)} for v in range(V)]
+    hyp = g["hyp"].to(dev)
+    out = model.stage_net(feats, g["cams"].to(dev), depth_values=hyp, num_depth=hyp.shape[1],
+                          cost_regularization=model.cost_regularization[stage], stage_idx=stage)
+    assert (out["depth"].cpu() - g["depth"]).abs().mean() < 1e-3
+    assert (out["photometric_confidence"].cpu() - g["conf"]).abs().mean() < 1e-3
+    assert (out["norm_curv"].cpu() - g["norm_curv"]).abs().max() < 1e-6
+
+
+@pytest.mark.parametrize("tag,refine", [("norefine", False), ("refine", True)])
+def test_full_forward(tag, refine, dev, seeded_state):
+    g = load_golden(f"g6_forward_{tag}")
+    model = seeded_state(refine).to(dev)
+    cams = {k[4:]: v.to(dev) for k, v in g.items() if k.startswith("cam_")}
+    with torch.no_grad():
+        out = model(g["imgs"].to(dev), cams, g["depth_values"].to(dev), temperature=0.01)
+    assert set(out.keys()) >= {"stage1", "stage2", "stage3", "depth", "photometric_confidence", "norm_curv",
+                               "refined_depth"}
+    for s in (1, 2, 3):
+        st = out[f"stage{s}"]
+        l1 = (st["depth"].cpu() - g[f"stage{s}_depth"]).abs().mean().item()
+        assert l1 < 1e-3, (s, l1)
+        assert (st["photometric_confidence"].cpu() - g[f"stage{s}_conf"]).abs().mean() < 1e-3, s
+        assert (st["norm_curv"].cpu() - g[f"stage{s}_norm_curv"]).abs().max() < 1e-4, s
+    assert (out["refined_depth"].cpu() - g["refined_depth"]).abs().mean() < 1e-3
+    assert out["depth"].shape == g["stage3_depth"].shape
+
+
+def test_oracle_parity_midsize(dev, ops, seeded_state):
+    """Seeded 64x80, D=96, C=8, N=5 stage against the CPU oracle (sizes the goldens do not cover)."""
+    from cds_mvsnet_amd import synth
+    from oracle import cds_oracle as O
+    h, w, D, C, N = 64, 80, 96, 8, 5
+    model = seeded_state(False)
+    sd = model.state_dict()
+    feats = synth.make_pair_features(N - 1, C, h, w, seed=21, sharp=True)
+    cams = synth.stage_cameras(N, h, w, seed=22)
+    hyp = synth.make_hypotheses(D, h, w, seed=23)
+    ref_out = O.stage_forward(feats, cams, hyp, sd, 2, exact=False)
+    model = model.to(dev)
+    dfe = [{k: tuple(t.to(dev) if t is not None else None for t in f[k]) for k in ("ref", "src")} for f in feats]
+    out = model.stage_net(dfe, cams.to(dev), depth_values=hyp.to(dev), num_depth=D,
+                          cost_regularization=model.cost_regularization[2], stage_idx=2)
+    assert (out["depth"].cpu() - ref_out["depth"]).abs().mean() < 1e-3
+    assert (out["photometric_confidence"].cpu() - ref_out["photometric_confidence"]).abs().mean() < 1e-3
+
+
+def test_cpu_tensors_fail_loudly(ops):
+    with pytest.raises(RuntimeError):
+        ops.chw_to_hwc(torch.zeros(8, 4, 4))
