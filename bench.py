@@ -1,0 +1,221 @@
+#!/usr/bin/env python
+"""bench.py — depth-maps/sec of the CDS-MVSNet plane-sweep hot path on MI355X.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1], SURVEY §8(d) "M1"): one single-stage plane sweep per step — per-pair
+feature maps [C=8, 512, 640] for N=5 views, D=192 per-pixel hypotheses -> K1 warp-correlate-entropy, visibility
+CNN, K3 warp-aggregate (2.0 GB volume), CostRegNet (3D U-Net, 625 GFLOP fp32), soft-argmin depth + confidence.
+Inputs are synthetic (seeded), resident in HBM before the timed region; weights are seeded random (no network).
+
+Multi-GPU: default ``--parallelism replicas`` — every rank computes the depth map of its own reference view
+(the reference's only multi-GPU mode, nn.DataParallel batch scatter, as one process per GPU; no data-path
+collective; weak scaling).  ``--parallelism viewshard`` shards the source views of ONE depth map over the ranks
+with a single RCCL all-reduce of the partial volume (north_star; strong scaling).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (fused warp-aggregate kernel,
+HBM bound) and `cpu_baseline` (the CPU oracle timed on the host cores on a bounded sample) objects.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK = 8.0e12          # B/s, MI355X spec (MI355X_MICROARCH.md); 6.29e12 measured copy ceiling
+FP32_PEAK = 157.3e12       # FLOP/s vector / f32-MFMA
+
+WORKLOADS = {
+    # name: (h, w, D, C, n_views)
+    "M1": (512, 640, 192, 8, 5),
+    "M1b": (128, 160, 192, 32, 5),
+    "tiny": (64, 80, 48, 8, 3),
+}
+
+
+def algorithmic_bytes(h, w, D, C, n_views):
+    """volume write + hypotheses read + ref/src feature maps + per-view visibility maps, fp32."""
+    hw, V = h * w, n_views - 1
+    return 4 * (C * D * hw + D * hw + 2 * V * C * hw + V * hw)
+
+
+def costreg_flops(h, w, D, C):
+    """Multiply-adds x2 of the 11 3x3x3 (de)convolutions of CostRegNet (module.py:270-315), base 8."""
+    v = D * h * w
+    b = 8
+    f = 27 * C * b * v                                   # conv0
+    f += 27 * b * 2 * b * v / 8 + 27 * 2 * b * 2 * b * v / 8       # conv1, conv2
+    f += 27 * 2 * b * 4 * b * v / 64 + 27 * 4 * b * 4 * b * v / 64  # conv3, conv4
+    f += 27 * 4 * b * 8 * b * v / 512 + 27 * 8 * b * 8 * b * v / 512  # conv5, conv6
+    f += 27 * 8 * b * 4 * b * v / 512 + 27 * 4 * b * 2 * b * v / 64 + 27 * 2 * b * b * v / 8  # deconvs (per input voxel)
+    f += 27 * b * 1 * v                                  # prob
+    return 2.0 * f
+
+
+def make_workload(name, seed, device):
+    from cds_mvsnet_amd import synth
+    h, w, D, C, n_views = WORKLOADS[name]
+    feats = synth.make_pair_features(n_views - 1, C, h, w, seed=seed + 1)
+    cams = synth.stage_cameras(n_views, h, w, seed=seed)
+    hyp = synth.make_hypotheses(D, h, w, seed=seed + 1)
+    dfe = [{k: tuple(t.to(device) for t in f[k]) for k in ("ref", "src")} for f in feats]
+    return feats, cams, hyp, dfe
+
+
+def cpu_baseline(model_cpu, name, budget_frac):
+    """The CPU oracle (proved equal to the reference, tests/test_oracle_golden.py) on a window of the same
+    workload: top-left (h*f) x (w*f) pixels, all D planes, all views.  Returns the JSON object."""
+    from cds_mvsnet_amd import synth
+    from oracle import cds_oracle as O
+    h, w, D, C, n_views = WORKLOADS[name]
+    hs, ws = max(8, int(h * budget_frac) // 8 * 8), max(8, int(w * budget_frac) // 8 * 8)
+    cores = min(os.cpu_count() or 1, 64)
+    torch.set_num_threads(cores)
+    feats = synth.make_pair_features(n_views - 1, C, hs, ws, seed=2)
+    cams = synth.stage_cameras(n_views, hs, ws, seed=1)
+    hyp = synth.make_hypotheses(D, hs, ws, seed=2)
+    sd = model_cpu.state_dict()
+    stage = {8: 2, 16: 1, 32: 0}[C]
+    with torch.no_grad():
+        O.stage_forward(feats, cams, hyp[:, :8], sd, stage, exact=False)  # warm-up (thread pool, oneDNN primitives)
+        t0 = time.time()
+        O.stage_forward(feats, cams, hyp, sd, stage, exact=False)
+        dt = time.time() - t0
+    frac = (hs * ws) / float(h * w)
+    return {"value": frac / dt, "unit": "depth-maps/s", "cores": cores, "kind": "port",
+            "sample": f"{name} window {ws}x{hs} of {w}x{h} ({frac:.4f} of the pixels), D={D}, C={C}, N={n_views}, "
+                      f"1 run, {dt:.2f} s of torch-CPU oracle (F.grid_sample path)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="M1", choices=sorted(WORKLOADS))
+    ap.add_argument("--parallelism", default="replicas", choices=["replicas", "viewshard"])
+    ap.add_argument("--cpu-sample", type=float, default=0.25, help="linear window fraction for the CPU baseline (0 = skip)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if args.gpus != 1 or world != 1:
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from cds_mvsnet_amd import CDSMVSNet, ops, seeded_init_
+    h, w, D, C, n_views = WORKLOADS[args.workload]
+    stage = {8: 2, 16: 1, 32: 0}[C]
+    model_cpu = seeded_init_(CDSMVSNet(refine=False, ndepths=(48, 32, 8), depth_interals_ratio=(4.0, 1.5, 0.75)), 0).eval()
+    import copy
+    model = copy.deepcopy(model_cpu).to(dev)
+    # replicas: every rank owns a different reference view (different seed); viewshard: same depth map everywhere
+    seed = rank if args.parallelism == "replicas" else 0
+    _, cams, hyp, dfe = make_workload(args.workload, seed, dev)
+    cams_d, hyp_d = cams.to(dev), hyp.to(dev)
+    if world > 1 and args.parallelism == "viewshard":
+        from cds_mvsnet_amd import distributed as cdist
+        runner = cdist.ViewShardedStage(model, dist.group.WORLD)
+        def step():
+            return runner(dfe, cams_d, hyp_d, D, stage)
+    else:
+        def step():
+            return model.stage_net(dfe, cams_d, depth_values=hyp_d, num_depth=D,
+                                   cost_regularization=model.cost_regularization[stage], stage_idx=stage)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            out = step()
+        ops.PROFILE.clear()
+        ops.PROFILE_ON = True
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = step()
+        barrier()
+        dt = time.perf_counter() - t0
+        ops.PROFILE_ON = False
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / args.steps * 1e3
+    maps_per_step = world if args.parallelism == "replicas" else 1
+    value = maps_per_step * args.steps / dt
+    depth_mean = float(out["depth"].mean().item())
+
+    # per-kernel durations from the HIP events recorded inside the timed region (same stream as the launches)
+    kern = {k: sum(a.elapsed_time(b) for a, b in v) / len(v) for k, v in ops.PROFILE.items() if v}
+    b_alg = algorithmic_bytes(h, w, D, C, n_views)
+    roof = None
+    if "warp_aggregate" in kern:
+        t_k3 = kern["warp_aggregate"] * 1e-3
+        achieved = b_alg / t_k3
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get(args.workload, {}).get("warp_aggregate_hbm_bytes")
+            except Exception:
+                traffic = None
+        roof = {"kernel": "warp_aggregate_kernel (K3, fused homography warp + visibility-weighted aggregation)",
+                "bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK, "frac_of_measured_copy_ceiling": achieved / 6.29e12,
+                "algorithmic_bytes": b_alg, "kernel_ms": kern["warp_aggregate"], "traffic": traffic}
+        span = sum(kern.get(k, 0.0) for k in ("warp_entropy", "visibility_cnn", "warp_aggregate"))
+        roof["k1_vis_k3_span_ms"] = span
+        roof["k1_vis_k3_span_frac"] = b_alg / (span * 1e-3) / HBM_PEAK if span > 0 else None
+    extra = {}
+    if "costreg" in kern:
+        fl = costreg_flops(h, w, D, C)
+        extra["roofline_costreg"] = {"bound": "fp32", "achieved": fl / (kern["costreg"] * 1e-3) / 1e12,
+                                     "peak": FP32_PEAK / 1e12, "unit": "TFLOP/s",
+                                     "frac": fl / (kern["costreg"] * 1e-3) / FP32_PEAK, "kernel_ms": kern["costreg"],
+                                     "flops": fl}
+    extra["kernel_ms"] = {k: round(v, 4) for k, v in sorted(kern.items())}
+
+    if rank == 0:
+        cpu = None
+        if world == 1 and args.cpu_sample > 0:
+            cpu = cpu_baseline(model_cpu, args.workload, args.cpu_sample)
+        line = {
+            "metric": "depth-maps/sec per ref view at 640x512 N=5 D=192 (single-stage plane sweep incl. CostRegNet + regression)",
+            "value": value, "unit": "depth-maps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "weak" if args.parallelism == "replicas" else "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic (seeded features/cameras/hypotheses, seeded random weights)",
+            "config": {"workload": f"{args.workload}: single-stage StageNet volume {w}x{h}, D={D}, C={C}, N={n_views} views",
+                       "parallelism": args.parallelism if world > 1 else "single", "depth_mean": depth_mean},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        line.update(extra)
+        print(json.dumps(line))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

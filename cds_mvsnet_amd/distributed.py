@@ -1,0 +1,106 @@
+"""Source-view sharding across the GPUs of one node (north_star).
+
+``volume_sum = sum_v vis_v * (ref_v (x) warp_v)``, ``vis_sum = sum_v vis_v`` and ``nc_sum`` are plain sums
+over source views (models/model.py:57-60) and ``vis_v`` only depends on view v's own data
+(model.py:44-51).  One process per GPU; rank r owns the source views ``{v : v % world == r}``, runs
+FeatureNet for its pairs, K1, the visibility CNN and a partial K3 WITHOUT the final division, then ONE fp32
+SUM all-reduce (RCCL over xGMI on the compute stream; gloo in the CPU tests) of a single flat buffer
+``[C*D*h*w | h*w | h*w]`` = volume_sum ++ vis_sum ++ nc_sum, after which every rank normalises, runs
+CostRegNet + regression and holds the depth map that seeds the next stage.  The result differs from the
+unsharded sum only by fp32 re-association.
+
+xGMI is point-to-point (7 links per GPU): a ring all-reduce of the 0.5-2 GB volume is single-link bound, which
+at the single-stage M1 size costs more than the warp work it parallelises — this mode
+exists for the many-view / large-image configs; bench.py defaults to independent replicas.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+from . import geometry, ops
+
+Tensor = torch.Tensor
+
+
+class ViewShard:
+    def __init__(self, group: Optional["dist.ProcessGroup"] = None):
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+
+    # ---- bookkeeping (device independent) ----------------------------------------------------
+    def local_views(self, n_src: int) -> List[int]:
+        return [v for v in range(n_src) if v % self.world == self.rank]
+
+    @staticmethod
+    def flat_size(C: int, D: int, h: int, w: int) -> int:
+        return C * D * h * w + 2 * h * w
+
+    @staticmethod
+    def split_flat(flat: Tensor, C: int, D: int, h: int, w: int) -> Tuple[Tensor, Tensor, Tensor]:
+        n = C * D * h * w
+        return flat[:n].view(C, D, h, w), flat[n:n + h * w].view(h, w), flat[n + h * w:].view(h, w)
+
+    def all_reduce_partials(self, flat: Tensor) -> Tensor:
+        """The single exchange step: SUM over ranks of volume_sum ++ vis_sum ++ nc_sum."""
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        return flat
+
+    # ---- one stage on this rank's views (GPU) --------------------------------------------------
+    def run_stage(self, model, ref: Optional[Tensor], src: Optional[Tensor], ref_nc: Optional[Tensor],
+                  nc_sums: Optional[Tensor], mats: Optional[Tensor], hyp: Tensor, stage_idx: int, n_src_total: int,
+                  C: Optional[int] = None):
+        D, h, w = hyp.shape
+        if ref is not None:
+            C = ref.shape[1]
+        flat = torch.zeros(self.flat_size(C, D, h, w), dtype=torch.float32, device=hyp.device)
+        vol, vis_sum, nc_sum = self.split_flat(flat, C, D, h, w)
+        if ref is not None and ref.shape[0] > 0:
+            ent = ops.warp_entropy(ref, src, mats, hyp)
+            vis = model.stage_net.visibility(ent, ref_nc, stage_idx).contiguous()
+            ops.warp_aggregate(ref, src, vis, mats, hyp, normalize=False, volume=vol, vis_sum=vis_sum)
+            nc_sum.copy_(nc_sums.sum(dim=0))
+        with ops.prof("allreduce"):
+            self.all_reduce_partials(flat)
+        ops.volume_normalize_(vol, vis_sum)
+        prob_pre = model.cost_regularization[stage_idx](vol)
+        depth, conf = ops.softargmin_conf(prob_pre, hyp)
+        return depth, conf, nc_sum / n_src_total
+
+
+def shard_views(model, group: Optional["dist.ProcessGroup"] = None) -> ViewShard:
+    """Make ``model.forward`` shard the source views of every depth map over the ranks of ``group``."""
+    sh = ViewShard(group)
+    model._view_shard = sh
+    return sh
+
+
+class ViewShardedStage:
+    """Single-stage driver with the reference's StageNet argument layout (used by bench.py --parallelism
+    viewshard): every rank is handed all views and picks its own."""
+
+    def __init__(self, model, group=None):
+        self.model = model
+        self.shard = ViewShard(group)
+
+    def __call__(self, features, proj_matrices: Tensor, depth_values: Tensor, num_depth: int, stage_idx: int):
+        sh = self.shard
+        V = len(features)
+        mine = sh.local_views(V)
+        cams = proj_matrices.detach().float().cpu()
+        hyp = depth_values[0].contiguous()
+        C = features[0]["ref"][0].shape[1]
+        if mine:
+            ref = torch.stack([features[v]["ref"][0][0] for v in mine]).contiguous()
+            src = torch.stack([ops.chw_to_hwc(features[v]["src"][0][0].contiguous()) for v in mine])
+            ref_nc = torch.stack([features[v]["ref"][2][0, 0] for v in mine]).contiguous()
+            nc_sums = torch.stack([(features[v]["ref"][1][0, 0] + features[v]["src"][1][0, 0]) / 2 for v in mine])
+            mats = geometry.warp_matrices(cams[0])[mine].contiguous()
+        else:
+            ref = src = ref_nc = nc_sums = mats = None
+        depth, conf, nc = sh.run_stage(self.model, ref, src, ref_nc, nc_sums, mats, hyp, stage_idx, V, C=C)
+        return {"depth": depth.unsqueeze(0), "photometric_confidence": conf.unsqueeze(0),
+                "norm_curv": nc.view(1, 1, *nc.shape)}

@@ -140,6 +140,11 @@ class CostRegNet(nn.Module):
         if D % 8 or h % 8 or w % 8:
             raise ValueError(f"CostRegNet needs D,h,w divisible by 8, got {(D, h, w)}")
         p = self._packed.get(self._pack)
+        with ops.prof("costreg"):
+            return self._run(volume, p)
+
+    @staticmethod
+    def _run(volume: Tensor, p: Dict[str, Tensor]) -> Tensor:
         c0 = ops.conv3d_k3(volume, p["conv0.w"], p["conv0.b"])
         c1 = ops.conv3d_k3(c0, p["conv1.w"], p["conv1.b"], stride=2)
         c2 = ops.conv3d_k3(c1, p["conv2.w"], p["conv2.b"])
@@ -348,10 +353,11 @@ class StageNet(nn.Module):
         """entropy, ref_nc [V,h,w] -> visibility weight [V,h,w]   (model.py:14,51)."""
         p = self._packed.get(self._pack)
         s = stage_idx
-        x = torch.stack((entropy, ref_nc), dim=1)
-        for i in range(3):
-            x = ops.conv2d(x, p[f"{s}.w{i}"], p[f"{s}.b{i}"], 16, 3, 1, 1, ACT_RELU)
-        return ops.conv2d(x, p[f"{s}.w3"], p[f"{s}.b3"], 1, 1, 1, 0, ACT_SIGMOID)[:, 0]
+        with ops.prof("visibility_cnn"):
+            x = torch.stack((entropy, ref_nc), dim=1)
+            for i in range(3):
+                x = ops.conv2d(x, p[f"{s}.w{i}"], p[f"{s}.b{i}"], 16, 3, 1, 1, ACT_RELU)
+            return ops.conv2d(x, p[f"{s}.w3"], p[f"{s}.b3"], 1, 1, 1, 0, ACT_SIGMOID)[:, 0]
 
     def aggregate(self, ref_chw: Tensor, src_hwc: Tensor, ref_nc: Tensor, mats: Tensor, hyp: Tensor, stage_idx: int,
                   normalize: bool = True):
@@ -480,12 +486,14 @@ class CDSMVSNet(nn.Module):
                 else:
                     interval = float(self.depth_interals_ratio[s] * dint)
                     hyp = ops.depth_hypotheses(depth, D, H, W, scale, interval, float(dmin), float(dmax))
-                ref = torch.stack([p[0][name][0] for p in pairs])
-                src = torch.stack([p[1][name][0] for p in pairs])
-                ref_nc = torch.stack([p[0][name][2] for p in pairs])
-                nc_sums = torch.stack([(p[0][name][1] + p[1][name][1]) / 2 for p in pairs])
-                all_mats = geometry.warp_matrices(cams[name][b])
-                mats = all_mats[views].contiguous()
+                if pairs:
+                    ref = torch.stack([p[0][name][0] for p in pairs])
+                    src = torch.stack([p[1][name][0] for p in pairs])
+                    ref_nc = torch.stack([p[0][name][2] for p in pairs])
+                    nc_sums = torch.stack([(p[0][name][1] + p[1][name][1]) / 2 for p in pairs])
+                    mats = geometry.warp_matrices(cams[name][b])[views].contiguous()
+                else:  # a view-shard rank without a source view of its own (more GPUs than views)
+                    ref = src = ref_nc = nc_sums = mats = None
                 depth, conf, nc = self._run_stage(ref, src, ref_nc, nc_sums, mats, hyp, s, N - 1)
                 out_b[name] = {"depth": depth, "photometric_confidence": conf, "norm_curv": nc.unsqueeze(0)}
             per_b.append(out_b)
@@ -516,7 +524,7 @@ class CDSMVSNet(nn.Module):
         sh = self._view_shard
         if sh is None:
             return self.stage_net.run_single(ref, src, ref_nc, nc_sums, mats, hyp, self.cost_regularization[s], s)
-        return sh.run_stage(self, ref, src, ref_nc, nc_sums, mats, hyp, s, V_total)
+        return sh.run_stage(self, ref, src, ref_nc, nc_sums, mats, hyp, s, V_total, C=self.feature.out_channels[s])
 
 
 def _resize_nearest(img: Tensor, H: int, W: int) -> Tensor:

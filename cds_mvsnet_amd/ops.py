@@ -16,6 +16,32 @@ from ._lib import (ACT_LEAKY01, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, AGG_A
 
 Tensor = torch.Tensor
 
+# Optional per-op timing with HIP events on the launch stream (bench.py turns it on inside its timed region;
+# events are recorded asynchronously, nothing synchronises here).
+PROFILE_ON = False
+PROFILE: dict = {}
+
+
+class prof:
+    """``with prof("name"):`` brackets the enclosed launches with two events when PROFILE_ON."""
+
+    def __init__(self, name: str):
+        self.name = name
+        self.start = None
+
+    def __enter__(self):
+        if PROFILE_ON:
+            self.start = torch.cuda.Event(enable_timing=True)
+            self.start.record()
+        return self
+
+    def __exit__(self, *exc):
+        if self.start is not None:
+            end = torch.cuda.Event(enable_timing=True)
+            end.record()
+            PROFILE.setdefault(self.name, []).append((self.start, end))
+        return False
+
 
 def _dev(t: Tensor, name: str) -> int:
     if not isinstance(t, torch.Tensor):
@@ -76,11 +102,12 @@ def warp_entropy(ref_chw: Tensor, src_hwc: Tensor, mats: Tensor, hyp: Tensor) ->
     D, pp = _hyp_args(hyp, None, h, w)
     ent = torch.empty((V, h, w), dtype=torch.float32, device=ref_chw.device)
     lib = _lib.load()
-    for v0 in range(0, V, MAX_VIEWS):
-        v1 = min(V, v0 + MAX_VIEWS)
-        check(lib.cds_warp_entropy_f32(_dev(ref_chw[v0:v1], "ref"), _dev(src_hwc[v0:v1], "src"),
-                                       _host(mats[v0:v1], "mats"), _dev(hyp, "hyp"), ent[v0:v1].data_ptr(),
-                                       v1 - v0, C, D, h, w, pp, _stream(ent)), "cds_warp_entropy_f32")
+    with prof("warp_entropy"):
+        for v0 in range(0, V, MAX_VIEWS):
+            v1 = min(V, v0 + MAX_VIEWS)
+            check(lib.cds_warp_entropy_f32(_dev(ref_chw[v0:v1], "ref"), _dev(src_hwc[v0:v1], "src"),
+                                           _host(mats[v0:v1], "mats"), _dev(hyp, "hyp"), ent[v0:v1].data_ptr(),
+                                           v1 - v0, C, D, h, w, pp, _stream(ent)), "cds_warp_entropy_f32")
     return ent
 
 
@@ -98,20 +125,24 @@ def warp_aggregate(ref_chw: Tensor, src_hwc: Tensor, vis_w: Tensor, mats: Tensor
         if accumulate:
             raise ValueError("accumulate=True needs an existing volume")
         volume = torch.empty((C, D, h, w), dtype=torch.float32, device=dev)
+    if vis_sum is None:
         vis_sum = torch.empty((h, w), dtype=torch.float32, device=dev)
+    if tuple(volume.shape) != (C, D, h, w) or tuple(vis_sum.shape) != (h, w):
+        raise ValueError("warp_aggregate: bad output buffers")
     lib = _lib.load()
     nchunks = (V + MAX_VIEWS - 1) // MAX_VIEWS
-    for i, v0 in enumerate(range(0, V, MAX_VIEWS)):
-        v1 = min(V, v0 + MAX_VIEWS)
-        flags = 0
-        if accumulate or i > 0:
-            flags |= AGG_ACCUMULATE
-        if normalize and i == nchunks - 1:
-            flags |= AGG_NORMALIZE
-        check(lib.cds_warp_aggregate_f32(_dev(ref_chw[v0:v1], "ref"), _dev(src_hwc[v0:v1], "src"),
-                                         _dev(vis_w[v0:v1], "vis"), _host(mats[v0:v1], "mats"), _dev(hyp, "hyp"),
-                                         _dev(volume, "volume"), _dev(vis_sum, "vis_sum"), v1 - v0, C, D, h, w, pp,
-                                         flags, _stream(volume)), "cds_warp_aggregate_f32")
+    with prof("warp_aggregate"):
+        for i, v0 in enumerate(range(0, V, MAX_VIEWS)):
+            v1 = min(V, v0 + MAX_VIEWS)
+            flags = 0
+            if accumulate or i > 0:
+                flags |= AGG_ACCUMULATE
+            if normalize and i == nchunks - 1:
+                flags |= AGG_NORMALIZE
+            check(lib.cds_warp_aggregate_f32(_dev(ref_chw[v0:v1], "ref"), _dev(src_hwc[v0:v1], "src"),
+                                             _dev(vis_w[v0:v1], "vis"), _host(mats[v0:v1], "mats"), _dev(hyp, "hyp"),
+                                             _dev(volume, "volume"), _dev(vis_sum, "vis_sum"), v1 - v0, C, D, h, w, pp,
+                                             flags, _stream(volume)), "cds_warp_aggregate_f32")
     return volume, vis_sum
 
 
@@ -131,9 +162,10 @@ def softargmin_conf(prob_pre: Tensor, hyp: Tensor, want_prob: bool = False):
     depth = torch.empty((h, w), dtype=torch.float32, device=prob_pre.device)
     conf = torch.empty_like(depth)
     prob = torch.empty_like(prob_pre) if want_prob else None
-    check(_lib.load().cds_softargmin_conf_f32(_dev(prob_pre, "prob_pre"), _dev(hyp, "hyp"), depth.data_ptr(),
-                                              conf.data_ptr(), prob.data_ptr() if want_prob else None, D, h, w, pp,
-                                              _stream(depth)), "cds_softargmin_conf_f32")
+    with prof("softargmin_conf"):
+        check(_lib.load().cds_softargmin_conf_f32(_dev(prob_pre, "prob_pre"), _dev(hyp, "hyp"), depth.data_ptr(),
+                                                  conf.data_ptr(), prob.data_ptr() if want_prob else None, D, h, w, pp,
+                                                  _stream(depth)), "cds_softargmin_conf_f32")
     return (depth, conf, prob) if want_prob else (depth, conf)
 
 
