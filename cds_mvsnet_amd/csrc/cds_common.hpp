@@ -10,6 +10,9 @@
 
 #define CDS_WAVE 64
 
+// native 4-float vector (volatile-loadable, unlike HIP's float4 struct): pins a 16-byte LDS read
+using cds_f4 = float __attribute__((ext_vector_type(4)));
+
 static inline int cds_launch_status() {
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : -(int)e;

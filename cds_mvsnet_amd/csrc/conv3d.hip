@@ -81,6 +81,7 @@ __global__ __launch_bounds__(256) void conv3d_k3_kernel(const float* __restrict_
     __syncthreads();
     // ---- compute ----
     const int cmax = min(CI_CHUNK, Cin - ci0);
+#pragma unroll 1
     for (int ci = 0; ci < cmax; ++ci) {
       const float* __restrict__ wc = wpk + ((size_t)(ci0 + ci) * 27) * Cout + co0;
       const float* tile_ci = lds + (size_t)ci * Cfg::TILE;
@@ -178,6 +179,7 @@ __global__ __launch_bounds__(256) void deconv3d_k3s2_kernel(const float* __restr
     }
     __syncthreads();
     const int cmax = min(CI_CHUNK, Cin - ci0);
+#pragma unroll 1
     for (int ci = 0; ci < cmax; ++ci) {
       const float* __restrict__ wc = wpk + ((size_t)(ci0 + ci) * 27) * Cout + co0;
       const float* t = lds + (size_t)ci * TILE + (lz * IY + ly) * IX + lx;
@@ -269,6 +271,327 @@ int launch_deconv(const float* x, const float* w, const float* b, const float* s
   return cds_launch_status();
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// v2 "pipe" kernels (wide volumes, W % 4 == 0): the input tile starts at an x that is a multiple of 4
+// so it is staged with aligned 16-byte loads; every thread owns NSLOT float4 slots of the tile, the
+// loads of chunk k+1 are issued before the FMAs of chunk k and land in registers while the chunk is
+// computed (global latency hidden behind ~7k cycles of FMAs instead of being serialised per row).
+// ---------------------------------------------------------------------------------------------
+template <int S, int LX, int LY, int LZ, int PX, int CO, int CI_CHUNK>
+struct PipeCfg {
+  static constexpr int TX = LX * PX, TY = LY, TZ = LZ;
+  static constexpr int OFFX = 3;                                   // tile x origin = S*ox0 - 4, first needed col = 3
+  static constexpr int IY = (TY - 1) * S + 3, IZ = (TZ - 1) * S + 3;
+  static constexpr int IXP = ((TX - 1) * S + 6 + 3) & ~3;
+  static constexpr int Q = IXP / 4;                                // float4 per row
+  static constexpr int NS = IZ * IY * Q;                           // float4 per input channel
+  static constexpr int TILE = NS * 4;
+  static constexpr int NSLOT = (CI_CHUNK * NS + 255) / 256;
+  static constexpr int NIN = (PX - 1) * S + 3;
+};
+
+template <int S, int LX, int LY, int LZ, int PX, int CO, int CI_CHUNK>
+__global__ __launch_bounds__(256) void conv3d_k3_pipe_kernel(const float* __restrict__ x, const float* __restrict__ wpk,
+                                                             const float* __restrict__ bias,
+                                                             const float* __restrict__ skip, float* __restrict__ out,
+                                                             int Cin, int Cout, int D, int H, int W, int Do, int Ho,
+                                                             int Wo, int act, int tiles_x, int tiles_y, int tiles_z,
+                                                             int ntiles) {
+  using Cfg = PipeCfg<S, LX, LY, LZ, PX, CO, CI_CHUNK>;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int co_blocks = Cout / CO;
+  int lin = cds_xcd_remap(blockIdx.x, ntiles * co_blocks);
+  const int cob = lin % co_blocks;
+  int tile = lin / co_blocks;
+  const int tx_i = tile % tiles_x;
+  tile /= tiles_x;
+  const int ty_i = tile % tiles_y;
+  const int tz_i = tile / tiles_y;
+  const int co0 = cob * CO;
+  const int tid = threadIdx.x;
+  const int lx = tid % LX, ly = (tid / LX) % LY, lz = tid / (LX * LY);
+  const int ox0 = tx_i * Cfg::TX, oy0 = ty_i * Cfg::TY, oz0 = tz_i * Cfg::TZ;
+  const int gx0 = ox0 * S - 4, gy0 = oy0 * S - 1, gz0 = oz0 * S - 1;
+  const size_t plane = (size_t)H * W, vol = (size_t)D * plane;
+
+  // per-thread staging slots: global element offset (within channel ci0) or -1
+  int goff[Cfg::NSLOT];
+#pragma unroll
+  for (int j = 0; j < Cfg::NSLOT; ++j) {
+    const int s = tid + 256 * j;
+    const int ci = s / Cfg::NS;
+    int r = s - ci * Cfg::NS;
+    const int row = r / Cfg::Q, c4 = r - row * Cfg::Q;
+    const int rz = row / Cfg::IY, ry = row - rz * Cfg::IY;
+    const int gz = gz0 + rz, gy = gy0 + ry, gx = gx0 + 4 * c4;
+    const bool ok = (s < CI_CHUNK * Cfg::NS) && gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx + 3 < W;
+    goff[j] = ok ? (int)((size_t)ci * vol + (size_t)gz * plane + (size_t)gy * W + gx) : -1;
+  }
+  float4 pre[Cfg::NSLOT];
+  auto issue = [&](int ci0) {
+    const float* __restrict__ xb = x + (size_t)ci0 * vol;
+#pragma unroll
+    for (int j = 0; j < Cfg::NSLOT; ++j) {
+      const int s = tid + 256 * j;
+      const int ci = s / Cfg::NS;
+      // branch-free: always load (from element 0 when the slot is outside); masked when written to LDS
+      const bool ok = goff[j] >= 0 && ci0 + ci < Cin;
+      pre[j] = *reinterpret_cast<const float4*>(ok ? xb + goff[j] : x);
+    }
+  };
+
+  float acc[PX][CO];
+#pragma unroll
+  for (int p = 0; p < PX; ++p)
+#pragma unroll
+    for (int c = 0; c < CO; ++c) acc[p][c] = 0.f;
+
+  issue(0);
+  for (int ci0 = 0; ci0 < Cin; ci0 += CI_CHUNK) {
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < Cfg::NSLOT; ++j) {
+      const int s = tid + 256 * j;
+      const bool ok = goff[j] >= 0 && ci0 + s / Cfg::NS < Cin;
+      if (s < CI_CHUNK * Cfg::NS)
+        *reinterpret_cast<float4*>(lds + 4 * s) = ok ? pre[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
+    if (ci0 + CI_CHUNK < Cin) issue(ci0 + CI_CHUNK);
+    const int cmax = min(CI_CHUNK, Cin - ci0);
+#pragma unroll 1
+    for (int ci = 0; ci < cmax; ++ci) {
+      const float* __restrict__ wc = wpk + ((size_t)(ci0 + ci) * 27) * Cout + co0;
+      const float* tile_ci = lds + ci * Cfg::TILE;
+#pragma unroll 1
+      for (int kz = 0; kz < 3; ++kz) {
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+          const float* rowp = tile_ci + ((lz * S + kz) * Cfg::IY + (ly * S + ky)) * Cfg::IXP + lx * PX * S;
+          float in[Cfg::NIN];
+          if constexpr (S == 1 && PX == 4) {
+            // cols 4lx+3 .. 4lx+8: one aligned 16-byte read for the middle four, two dword reads for the ends
+            const cds_f4 b = *reinterpret_cast<const volatile cds_f4*>(rowp + 4);
+            in[0] = rowp[3]; in[1] = b.x; in[2] = b.y; in[3] = b.z; in[4] = b.w; in[5] = rowp[8];
+          } else if constexpr (S == 2 && PX == 2) {
+            const cds_f4 b = *reinterpret_cast<const volatile cds_f4*>(rowp + 4);
+            in[0] = rowp[3]; in[1] = b.x; in[2] = b.y; in[3] = b.z; in[4] = b.w;
+          } else {
+#pragma unroll
+            for (int i = 0; i < Cfg::NIN; ++i) in[i] = rowp[Cfg::OFFX + i];
+          }
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) {
+#pragma unroll
+            for (int c = 0; c < CO; ++c) {
+              const float wv = wc[((kz * 3 + ky) * 3 + kx) * Cout + c];
+#pragma unroll
+              for (int p = 0; p < PX; ++p) acc[p][c] = fmaf(in[p * S + kx], wv, acc[p][c]);
+            }
+          }
+        }
+      }
+    }
+  }
+
+  const int oz = oz0 + lz, oy = oy0 + ly, oxb = ox0 + lx * PX;
+  if (oz >= Do || oy >= Ho || oxb >= Wo) return;
+  const size_t oplane = (size_t)Ho * Wo, ovol = (size_t)Do * oplane;
+  const bool vec = (PX == 4) && ((Wo & 3) == 0);  // oxb is a multiple of 4 -> 16-byte aligned rows
+#pragma unroll
+  for (int c = 0; c < CO; ++c) {
+    const float b = bias ? bias[co0 + c] : 0.f;
+    const size_t base = (size_t)(co0 + c) * ovol + (size_t)oz * oplane + (size_t)oy * Wo + oxb;
+    float v[PX];
+#pragma unroll
+    for (int p = 0; p < PX; ++p) v[p] = (act == CDS_ACT_RELU) ? fmaxf(acc[p][c] + b, 0.f) : acc[p][c] + b;
+    if (vec) {
+      if constexpr (PX == 4) {
+        float4 o = make_float4(v[0], v[1], v[2], v[3]);
+        if (skip) {
+          const float4 s4 = *reinterpret_cast<const float4*>(skip + base);
+          o.x = s4.x + o.x; o.y = s4.y + o.y; o.z = s4.z + o.z; o.w = s4.w + o.w;
+        }
+        *reinterpret_cast<float4*>(out + base) = o;
+      }
+    } else {
+#pragma unroll
+      for (int p = 0; p < PX; ++p)
+        if (oxb + p < Wo) out[base + p] = skip ? skip[base + p] + v[p] : v[p];
+    }
+  }
+}
+
+template <int LX, int LY, int LZ, int CO, int CI_CHUNK>
+struct DPipeCfg {
+  static constexpr int IY = LY + 1, IZ = LZ + 1;
+  static constexpr int IXP = (LX + 1 + 3) & ~3;
+  static constexpr int Q = IXP / 4;
+  static constexpr int NS = IZ * IY * Q;
+  static constexpr int TILE = NS * 4;
+  static constexpr int NSLOT = (CI_CHUNK * NS + 255) / 256;
+};
+
+template <int LX, int LY, int LZ, int CO, int CI_CHUNK>
+__global__ __launch_bounds__(256) void deconv3d_k3s2_pipe_kernel(const float* __restrict__ x,
+                                                                 const float* __restrict__ wpk,
+                                                                 const float* __restrict__ bias,
+                                                                 const float* __restrict__ skip, float* __restrict__ out,
+                                                                 int Cin, int Cout, int D, int H, int W, int act,
+                                                                 int tiles_x, int tiles_y, int tiles_z, int ntiles) {
+  using Cfg = DPipeCfg<LX, LY, LZ, CO, CI_CHUNK>;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int co_blocks = Cout / CO;
+  int lin = cds_xcd_remap(blockIdx.x, ntiles * co_blocks);
+  const int cob = lin % co_blocks;
+  int tile = lin / co_blocks;
+  const int tx_i = tile % tiles_x;
+  tile /= tiles_x;
+  const int ty_i = tile % tiles_y;
+  const int tz_i = tile / tiles_y;
+  const int co0 = cob * CO;
+  const int tid = threadIdx.x;
+  const int lx = tid % LX, ly = (tid / LX) % LY, lz = tid / (LX * LY);
+  const int ax0 = tx_i * LX, ay0 = ty_i * LY, az0 = tz_i * LZ;
+  const size_t plane = (size_t)H * W, vol = (size_t)D * plane;
+
+  int goff[Cfg::NSLOT];
+#pragma unroll
+  for (int j = 0; j < Cfg::NSLOT; ++j) {
+    const int s = tid + 256 * j;
+    const int ci = s / Cfg::NS;
+    int r = s - ci * Cfg::NS;
+    const int row = r / Cfg::Q, c4 = r - row * Cfg::Q;
+    const int rz = row / Cfg::IY, ry = row - rz * Cfg::IY;
+    const int gz = az0 + rz, gy = ay0 + ry, gx = ax0 + 4 * c4;
+    const bool ok = (s < CI_CHUNK * Cfg::NS) && gz < D && gy < H && gx + 3 < W;
+    goff[j] = ok ? (int)((size_t)ci * vol + (size_t)gz * plane + (size_t)gy * W + gx) : -1;
+  }
+  float4 pre[Cfg::NSLOT];
+  auto issue = [&](int ci0) {
+    const float* __restrict__ xb = x + (size_t)ci0 * vol;
+#pragma unroll
+    for (int j = 0; j < Cfg::NSLOT; ++j) {
+      const int s = tid + 256 * j;
+      const int ci = s / Cfg::NS;
+      // branch-free: always load (from element 0 when the slot is outside); masked when written to LDS
+      const bool ok = goff[j] >= 0 && ci0 + ci < Cin;
+      pre[j] = *reinterpret_cast<const float4*>(ok ? xb + goff[j] : x);
+    }
+  };
+
+  float acc[8][CO];
+#pragma unroll
+  for (int q = 0; q < 8; ++q)
+#pragma unroll
+    for (int c = 0; c < CO; ++c) acc[q][c] = 0.f;
+
+  issue(0);
+  for (int ci0 = 0; ci0 < Cin; ci0 += CI_CHUNK) {
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < Cfg::NSLOT; ++j) {
+      const int s = tid + 256 * j;
+      const bool ok = goff[j] >= 0 && ci0 + s / Cfg::NS < Cin;
+      if (s < CI_CHUNK * Cfg::NS)
+        *reinterpret_cast<float4*>(lds + 4 * s) = ok ? pre[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
+    if (ci0 + CI_CHUNK < Cin) issue(ci0 + CI_CHUNK);
+    const int cmax = min(CI_CHUNK, Cin - ci0);
+#pragma unroll 1
+    for (int ci = 0; ci < cmax; ++ci) {
+      const float* __restrict__ wc = wpk + ((size_t)(ci0 + ci) * 27) * Cout + co0;
+      const float* t = lds + ci * Cfg::TILE + (lz * Cfg::IY + ly) * Cfg::IXP + lx;
+      float in[2][2][2];
+#pragma unroll
+      for (int dz = 0; dz < 2; ++dz)
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+          for (int dx = 0; dx < 2; ++dx) in[dz][dy][dx] = t[(dz * Cfg::IY + dy) * Cfg::IXP + dx];
+#pragma unroll
+      for (int pz = 0; pz < 2; ++pz)
+#pragma unroll
+        for (int py = 0; py < 2; ++py)
+#pragma unroll
+          for (int px = 0; px < 2; ++px) {
+            const int q = (pz * 2 + py) * 2 + px;
+#pragma unroll
+            for (int sz = 0; sz <= pz; ++sz)
+#pragma unroll
+              for (int sy = 0; sy <= py; ++sy)
+#pragma unroll
+                for (int sx = 0; sx <= px; ++sx) {
+                  const int iz = pz ? 1 - sz : 0, kz = pz ? 2 * sz : 1;
+                  const int iy = py ? 1 - sy : 0, ky = py ? 2 * sy : 1;
+                  const int ix = px ? 1 - sx : 0, kx = px ? 2 * sx : 1;
+                  const float v = in[iz][iy][ix];
+#pragma unroll
+                  for (int c = 0; c < CO; ++c)
+                    acc[q][c] = fmaf(v, wc[((kz * 3 + ky) * 3 + kx) * Cout + c], acc[q][c]);
+                }
+          }
+    }
+  }
+
+  const int az = az0 + lz, ay = ay0 + ly, ax = ax0 + lx;
+  if (az >= D || ay >= H || ax >= W) return;
+  const int Do = 2 * D, Ho = 2 * H, Wo = 2 * W;
+  const size_t oplane = (size_t)Ho * Wo, ovol = (size_t)Do * oplane;
+#pragma unroll
+  for (int c = 0; c < CO; ++c) {
+    const float b = bias ? bias[co0 + c] : 0.f;
+#pragma unroll
+    for (int pz = 0; pz < 2; ++pz)
+#pragma unroll
+      for (int py = 0; py < 2; ++py) {
+        const size_t base = (size_t)(co0 + c) * ovol + (size_t)(2 * az + pz) * oplane + (size_t)(2 * ay + py) * Wo + 2 * ax;
+        float2 v;
+        v.x = acc[(pz * 2 + py) * 2 + 0][c] + b;
+        v.y = acc[(pz * 2 + py) * 2 + 1][c] + b;
+        if (act == CDS_ACT_RELU) {
+          v.x = fmaxf(v.x, 0.f);
+          v.y = fmaxf(v.y, 0.f);
+        }
+        if (skip) {
+          const float2 s = *reinterpret_cast<const float2*>(skip + base);
+          v.x = s.x + v.x;
+          v.y = s.y + v.y;
+        }
+        *reinterpret_cast<float2*>(out + base) = v;
+      }
+  }
+}
+
+template <int S, int LX, int LY, int LZ, int PX, int CO, int CI_CHUNK>
+int launch_conv_pipe(const float* x, const float* w, const float* b, const float* skip, float* out, int Cin, int Cout,
+                     int D, int H, int W, int act, hipStream_t st) {
+  using Cfg = PipeCfg<S, LX, LY, LZ, PX, CO, CI_CHUNK>;
+  const int Do = (D - 1) / S + 1, Ho = (H - 1) / S + 1, Wo = (W - 1) / S + 1;
+  const int tx = cds_ceil_div(Wo, Cfg::TX), ty = cds_ceil_div(Ho, Cfg::TY), tz = cds_ceil_div(Do, Cfg::TZ);
+  const int ntiles = tx * ty * tz;
+  const size_t lds_bytes = (size_t)Cfg::TILE * CI_CHUNK * sizeof(float);
+  auto kern = conv3d_k3_pipe_kernel<S, LX, LY, LZ, PX, CO, CI_CHUNK>;
+  hipLaunchKernelGGL(kern, dim3(ntiles * (Cout / CO)), dim3(256), lds_bytes, st, x, w, b, skip, out, Cin, Cout, D, H, W,
+                     Do, Ho, Wo, act, tx, ty, tz, ntiles);
+  return cds_launch_status();
+}
+
+template <int LX, int LY, int LZ, int CO, int CI_CHUNK>
+int launch_deconv_pipe(const float* x, const float* w, const float* b, const float* skip, float* out, int Cin, int Cout,
+                       int D, int H, int W, int act, hipStream_t st) {
+  using Cfg = DPipeCfg<LX, LY, LZ, CO, CI_CHUNK>;
+  const int tx = cds_ceil_div(W, LX), ty = cds_ceil_div(H, LY), tz = cds_ceil_div(D, LZ);
+  const int ntiles = tx * ty * tz;
+  const size_t lds_bytes = (size_t)Cfg::TILE * CI_CHUNK * sizeof(float);
+  auto kern = deconv3d_k3s2_pipe_kernel<LX, LY, LZ, CO, CI_CHUNK>;
+  hipLaunchKernelGGL(kern, dim3(ntiles * (Cout / CO)), dim3(256), lds_bytes, st, x, w, b, skip, out, Cin, Cout, D, H, W,
+                     act, tx, ty, tz, ntiles);
+  return cds_launch_status();
+}
+
 }  // namespace
 
 extern "C" int cds_conv3d_k3_f32(const float* x, const float* weight, const float* bias, const float* skip, float* out,
@@ -278,6 +601,14 @@ extern "C" int cds_conv3d_k3_f32(const float* x, const float* weight, const floa
   hipStream_t st = (hipStream_t)stream;
   const int Wo = (W - 1) / stride + 1;
   const bool wide = Wo >= 48;
+  // total elements must fit the 32-bit staging offsets of the pipe kernels
+  const bool pipe_ok = (W % 4 == 0) && Wo >= 32 && ((size_t)Cin * D * H * W < (size_t)0x7fffffff);
+  if (pipe_ok && Cout % 8 == 0) {
+    if (stride == 1) return launch_conv_pipe<1, 16, 4, 4, 4, 8, 4>(x, weight, bias, skip, out, Cin, Cout, D, H, W, act, st);
+    return launch_conv_pipe<2, 16, 4, 4, 2, 8, 2>(x, weight, bias, skip, out, Cin, Cout, D, H, W, act, st);
+  }
+  if (pipe_ok && Cout == 1 && stride == 1)
+    return launch_conv_pipe<1, 16, 4, 4, 4, 1, 4>(x, weight, bias, skip, out, Cin, Cout, D, H, W, act, st);
   if (Cout == 1) {
     if (stride != 1) return CDS_EINVAL;
     return wide ? launch_conv<1, 16, 4, 4, 4, 1, 4>(x, weight, bias, skip, out, Cin, Cout, D, H, W, act, st)
@@ -296,6 +627,8 @@ extern "C" int cds_deconv3d_k3s2_f32(const float* x, const float* weight, const 
                                      float* out, int Cin, int Cout, int D, int H, int W, int act, void* stream) {
   if (!x || !weight || !out || Cin < 1 || Cout < 1 || (Cout % 8) || D < 1 || H < 1 || W < 1) return CDS_EINVAL;
   hipStream_t st = (hipStream_t)stream;
+  if ((W % 4 == 0) && W >= 32 && ((size_t)Cin * D * H * W < (size_t)0x7fffffff))
+    return launch_deconv_pipe<64, 2, 2, 8, 8>(x, weight, bias, skip, out, Cin, Cout, D, H, W, act, st);
   return W >= 48 ? launch_deconv<64, 2, 2, 8, 8>(x, weight, bias, skip, out, Cin, Cout, D, H, W, act, st)
                  : launch_deconv<16, 4, 4, 8, 8>(x, weight, bias, skip, out, Cin, Cout, D, H, W, act, st);
 }
