@@ -8,77 +8,9 @@
 //   ix  = ((u / ((w-1)/2) - 1) + 1) * ((w-1)/2)              normalise / un-normalise round trip
 //   val = fma(v_se, w_se, fma(v_sw, w_sw, fma(v_ne, w_ne, v_nw*w_nw)))
 //   in_prod = ref*val ; volume += in_prod*vis                (three separate roundings)
-#include "cds_common.hpp"
+#include <stdlib.h>
 
-struct WarpMats {
-  float m[CDS_MAX_VIEWS][12];
-};
-
-struct Taps {
-  int off[4];   // element offset of the texel (pixel index, not yet multiplied by C); -1 if outside
-  float wt[4];  // nw, ne, sw, se
-};
-
-__device__ __forceinline__ void cds_row_terms(const float* __restrict__ m, float x, float y, float r[3]) {
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    float a = m[3 * i + 0] * x;
-    a = fmaf(m[3 * i + 1], y, a);
-    a = fmaf(m[3 * i + 2], 1.0f, a);
-    r[i] = a;
-  }
-}
-
-__device__ __forceinline__ Taps cds_taps(const float r[3], const float* __restrict__ t, float d, int h,
-                                         int w, float half_w, float half_h) {
-  float px = r[0] * d + t[0];
-  float py = r[1] * d + t[1];
-  float pz = r[2] * d + t[2];
-  float z = pz + 1e-6f;
-  float u = px / z;
-  float v = py / z;
-  float gx = u / half_w - 1.0f;
-  float gy = v / half_h - 1.0f;
-  float ix = (gx + 1.0f) * half_w;
-  float iy = (gy + 1.0f) * half_h;
-  float x0f = floorf(ix), y0f = floorf(iy);
-  float wx = ix - x0f, ex = 1.0f - wx;
-  float ny = iy - y0f, sy = 1.0f - ny;
-  Taps tp;
-  tp.wt[0] = sy * ex;
-  tp.wt[1] = sy * wx;
-  tp.wt[2] = ny * ex;
-  tp.wt[3] = ny * wx;
-  // Range test in float first: NaN / inf / huge coordinates fail every comparison -> all taps "outside".
-  bool x0ok = (x0f >= 0.0f) && (x0f <= (float)(w - 1));
-  bool x1ok = (x0f >= -1.0f) && (x0f <= (float)(w - 2));
-  bool y0ok = (y0f >= 0.0f) && (y0f <= (float)(h - 1));
-  bool y1ok = (y0f >= -1.0f) && (y0f <= (float)(h - 2));
-  int x0 = (x0ok || x1ok) ? (int)x0f : 0;
-  int y0 = (y0ok || y1ok) ? (int)y0f : 0;
-  int base = y0 * w + x0;
-  tp.off[0] = (x0ok && y0ok) ? base : -1;
-  tp.off[1] = (x1ok && y0ok) ? base + 1 : -1;
-  tp.off[2] = (x0ok && y1ok) ? base + w : -1;
-  tp.off[3] = (x1ok && y1ok) ? base + w + 1 : -1;
-  return tp;
-}
-
-__device__ __forceinline__ float4 cds_ld4(const float* __restrict__ p, int off, int C, int c0) {
-  if (off < 0) return make_float4(0.f, 0.f, 0.f, 0.f);
-  return *reinterpret_cast<const float4*>(p + (size_t)off * C + c0);
-}
-
-__device__ __forceinline__ float cds_interp(float a, float b, float c, float d, const float wt[4]) {
-  float o = a * wt[0];
-  o = fmaf(b, wt[1], o);
-  o = fmaf(c, wt[2], o);
-  o = fmaf(d, wt[3], o);
-  return o;
-}
-
-#define CDS_TILE_X 64
-#define CDS_TILE_Y 4
+#include "warp_common.hpp"
 
 // ---------------------------------------------------------------------------------------------
 // plain warp  -> out [C][D][h][w]
@@ -300,6 +232,20 @@ __global__ void chw_to_hwc_kernel(const float* __restrict__ src, float* __restri
 // ---------------------------------------------------------------------------------------------
 // host entry points
 // ---------------------------------------------------------------------------------------------
+// LDS-staged fast paths (warp_lds.hip); return false when the shape is not covered.
+bool cds_warp_aggregate_lds_launch(const float* ref, const float* src, const float* vis, const WarpMats& wm,
+                                   const float* hyp, float* volume, const float* vis_sum, int V, int C, int D, int h,
+                                   int w, int hyp_pp, int flags, hipStream_t st);
+bool cds_warp_entropy_lds_launch(const float* ref, const float* src, const WarpMats& wm, const float* hyp,
+                                 float* entropy, int V, int C, int D, int h, int w, int hyp_pp, hipStream_t st);
+static bool cds_use_lds_path() {
+  static const bool on = []() {
+    const char* e = getenv("CDS_WARP_DIRECT");  // CDS_WARP_DIRECT=1 forces the direct (L1 gather) kernels
+    return !(e && e[0] == '1');
+  }();
+  return on;
+}
+
 static bool cds_warp_args_ok(int V, int C, int D, int h, int w) {
   return V >= 1 && V <= CDS_MAX_VIEWS && (C == 8 || C == 16 || C == 32) && D >= 1 && h >= 1 && w >= 1;
 }
@@ -344,6 +290,8 @@ extern "C" int cds_warp_entropy_f32(const float* ref_chw, const float* src_hwc, 
   int tiles_x = cds_ceil_div(w, CDS_TILE_X), tiles_y = cds_ceil_div(h, CDS_TILE_Y);
   int ntiles = tiles_x * tiles_y;
   hipStream_t st = (hipStream_t)stream;
+  if (cds_use_lds_path() && cds_warp_entropy_lds_launch(ref_chw, src_hwc, wm, hyp, entropy, V, C, D, h, w, hyp_per_pixel, st))
+    return cds_launch_status();
 #define LAUNCH(CC)                                                                                          \
   hipLaunchKernelGGL(warp_entropy_kernel<CC>, dim3(ntiles * V), dim3(256), 0, st, ref_chw, src_hwc, wm, hyp, \
                      entropy, V, D, h, w, hyp_per_pixel, tiles_x, ntiles)
@@ -367,6 +315,9 @@ extern "C" int cds_warp_aggregate_f32(const float* ref_chw, const float* src_hwc
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(vis_sum_kernel, dim3(cds_ceil_div(h * w, 256)), dim3(256), 0, st, vis_w, vis_sum, V, h * w,
                      flags & CDS_AGG_ACCUMULATE);
+  if (cds_use_lds_path() &&
+      cds_warp_aggregate_lds_launch(ref_chw, src_hwc, vis_w, wm, hyp, volume, vis_sum, V, C, D, h, w, hyp_per_pixel, flags, st))
+    return cds_launch_status();
 #define LAUNCH(VM)                                                                                                  \
   hipLaunchKernelGGL(warp_aggregate_kernel<VM>, dim3(ntiles * ngroups), dim3(256), 0, st, ref_chw, src_hwc, vis_w, wm, \
                      hyp, volume, vis_sum, V, C, D, h, w, hyp_per_pixel, flags, tiles_x, ntiles)
