@@ -120,78 +120,148 @@ __device__ __forceinline__ void stage_box(const float* __restrict__ srcv, int w,
   }
 }
 
-struct Tex {
-  float4 lo, hi;
-};
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ v2f splat2(float a) { return (v2f){a, a}; }
 
-// Taps with box-relative coordinates: same arithmetic as cds_taps, but keeps (x0,y0) instead of a linear offset.
-struct Taps2 {
-  int x0, y0;
-  bool ok[4];
-  float wt[4];
-};
-__device__ __forceinline__ Taps2 taps2(const float r[3], const float* __restrict__ t, float d, int h, int w, float half_w,
-                                       float half_h) {
-  float px = r[0] * d + t[0];
-  float py = r[1] * d + t[1];
-  float pz = r[2] * d + t[2];
-  float z = pz + 1e-6f;
-  float u = px / z;
-  float v = py / z;
-  float gx = u / half_w - 1.0f;
-  float gy = v / half_h - 1.0f;
-  float ix = (gx + 1.0f) * half_w;
-  float iy = (gy + 1.0f) * half_h;
-  float x0f = floorf(ix), y0f = floorf(iy);
-  float wx = ix - x0f, ex = 1.0f - wx;
-  float ny = iy - y0f, sy = 1.0f - ny;
-  Taps2 tp;
-  tp.wt[0] = sy * ex;
-  tp.wt[1] = sy * wx;
-  tp.wt[2] = ny * ex;
-  tp.wt[3] = ny * wx;
-  bool x0ok = (x0f >= 0.0f) && (x0f <= (float)(w - 1));
-  bool x1ok = (x0f >= -1.0f) && (x0f <= (float)(w - 2));
-  bool y0ok = (y0f >= 0.0f) && (y0f <= (float)(h - 1));
-  bool y1ok = (y0f >= -1.0f) && (y0f <= (float)(h - 2));
-  tp.x0 = (x0ok || x1ok) ? (int)x0f : 0;
-  tp.y0 = (y0ok || y1ok) ? (int)y0f : 0;
-  tp.ok[0] = x0ok && y0ok;
-  tp.ok[1] = x1ok && y0ok;
-  tp.ok[2] = x0ok && y1ok;
-  tp.ok[3] = x1ok && y1ok;
-  return tp;
+// a / b for two planes at once: v_rcp + one Newton step for the reciprocal, then two Markstein corrections of the
+// quotient (correctly rounded for operands in the normal range; the pole z -> 0 yields inf/NaN like IEEE division).
+__device__ __forceinline__ v2f div2_refine(v2f a, v2f b, v2f y) {
+  v2f q = a * y;
+  v2f r = fma2(-b, q, a);
+  q = fma2(r, y, q);
+  r = fma2(-b, q, a);
+  return fma2(r, y, q);
+}
+// a / c for a constant c with rc = RN(1/c): one correction gives the correctly rounded quotient.
+__device__ __forceinline__ v2f div2_const(v2f a, float c, float rc) {
+  v2f q = a * rc;
+  v2f r = fma2(splat2(-c), q, a);
+  return fma2(r, splat2(rc), q);
 }
 
-__device__ __forceinline__ Tex fetch2(int x, int y, bool ok, int w, const Box& b, const float4* __restrict__ lds,
-                                      const float* __restrict__ srcv) {
-  Tex t;
-  t.lo = make_float4(0.f, 0.f, 0.f, 0.f);
-  t.hi = t.lo;
-  if (ok) {
-    const int bx = x - b.x0, by = y - b.y0;
-    if ((unsigned)bx < (unsigned)b.bw && (unsigned)by < (unsigned)b.bh) {  // bw = bh = 0 when the box is not staged
-      const int ti = by * b.bw + bx;
-      t.lo = lds[ti];
-      t.hi = lds[BOX_CAP + ti];
-    } else {
-      const float4* g = reinterpret_cast<const float4*>(srcv + ((size_t)y * w + x) * C8);
-      t.lo = g[0];
-      t.hi = g[1];
-    }
+struct Geo {       // per launch constants
+  int h, w;
+  float half_w, half_h, rhw, rhh;
+};
+
+// Sample positions of two consecutive planes (same fp32 operation order as cds_taps).
+__device__ __forceinline__ void positions2(const float r[3], const float* __restrict__ t, v2f d, const Geo& g, v2f& ix,
+                                           v2f& iy) {
+  const v2f px = r[0] * d + t[0];
+  const v2f py = r[1] * d + t[1];
+  const v2f pz = r[2] * d + t[2];
+  const v2f z = pz + 1e-6f;
+  v2f y0;
+  y0.x = __builtin_amdgcn_rcpf(z.x);
+  y0.y = __builtin_amdgcn_rcpf(z.y);
+  const v2f e = fma2(-z, y0, splat2(1.0f));
+  const v2f y = fma2(e, y0, y0);
+  const v2f u = div2_refine(px, z, y);
+  const v2f v = div2_refine(py, z, y);
+  const v2f gx = div2_const(u, g.half_w, g.rhw) - 1.0f;
+  const v2f gy = div2_const(v, g.half_h, g.rhh) - 1.0f;
+  ix = (gx + 1.0f) * g.half_w;
+  iy = (gy + 1.0f) * g.half_h;
+}
+
+// clamp x into [lo, hi] (lowered to v_med3_i32 when lo <= hi)
+__device__ __forceinline__ int cds_clampi(int x, int lo, int hi) { return min(max(x, lo), hi); }
+
+struct Cell {  // one plane, one view: integer cell, zeroed-if-outside weights, LDS indices
+  int x0, y0;
+  float w00, w01, w10, w11;
+  int a00, a01, a10, a11;
+  bool miss;   // a tap that is inside the image is not inside the staged box
+};
+
+__device__ __forceinline__ Cell make_cell(float x0f, float y0f, float w00, float w01, float w10, float w11, const Geo& g,
+                                          const Box& b) {
+  Cell c;
+  c.x0 = (int)x0f;  // v_cvt_i32_f32 saturates; NaN -> 0 (then the NaN weights propagate like the reference)
+  c.y0 = (int)y0f;
+  const bool x0ok = (unsigned)c.x0 < (unsigned)g.w, x1ok = (unsigned)(c.x0 + 1) < (unsigned)g.w;
+  const bool y0ok = (unsigned)c.y0 < (unsigned)g.h, y1ok = (unsigned)(c.y0 + 1) < (unsigned)g.h;
+  c.w00 = (x0ok && y0ok) ? w00 : 0.f;
+  c.w01 = (x1ok && y0ok) ? w01 : 0.f;
+  c.w10 = (x0ok && y1ok) ? w10 : 0.f;
+  c.w11 = (x1ok && y1ok) ? w11 : 0.f;
+  const int bx1 = b.x0 + b.bw - 1, by1 = b.y0 + b.bh - 1;
+  const int xa = cds_clampi(c.x0, b.x0, bx1), xb = cds_clampi(c.x0 + 1, b.x0, bx1);
+  const int ya = cds_clampi(c.y0, b.y0, by1), yb = cds_clampi(c.y0 + 1, b.y0, by1);
+  c.miss = !b.staged || (x0ok && xa != c.x0) || (x1ok && xb != c.x0 + 1) || (y0ok && ya != c.y0) ||
+           (y1ok && yb != c.y0 + 1);
+  const int base = -(b.y0 * b.bw + b.x0);
+  const int ra = ya * b.bw + base, rb = yb * b.bw + base;
+  c.a00 = ra + xa;
+  c.a01 = ra + xb;
+  c.a10 = rb + xa;
+  c.a11 = rb + xb;
+  return c;
+}
+
+struct Tex8 {
+  cds_f4 lo, hi;
+};
+
+__device__ __forceinline__ void fetch_cell(const Cell& c, const Geo& g, const cds_f4* __restrict__ lds,
+                                           const float* __restrict__ srcv, Tex8 t[4]) {
+  if (__builtin_expect(c.miss, 0)) {
+    // slow path (box too large for LDS, or a tap outside the first/last-plane bounding box): global gathers from
+    // coordinates clamped into the image; taps outside the image already carry weight 0.
+    const int xa = min(max(c.x0, 0), g.w - 1), xb = min(max(c.x0 + 1, 0), g.w - 1);
+    const int ya = min(max(c.y0, 0), g.h - 1), yb = min(max(c.y0 + 1, 0), g.h - 1);
+    const cds_f4* p;
+    p = reinterpret_cast<const cds_f4*>(srcv + ((size_t)ya * g.w + xa) * C8); t[0].lo = p[0]; t[0].hi = p[1];
+    p = reinterpret_cast<const cds_f4*>(srcv + ((size_t)ya * g.w + xb) * C8); t[1].lo = p[0]; t[1].hi = p[1];
+    p = reinterpret_cast<const cds_f4*>(srcv + ((size_t)yb * g.w + xa) * C8); t[2].lo = p[0]; t[2].hi = p[1];
+    p = reinterpret_cast<const cds_f4*>(srcv + ((size_t)yb * g.w + xb) * C8); t[3].lo = p[0]; t[3].hi = p[1];
+  } else {
+    t[0].lo = lds[c.a00]; t[0].hi = lds[BOX_CAP + c.a00];
+    t[1].lo = lds[c.a01]; t[1].hi = lds[BOX_CAP + c.a01];
+    t[2].lo = lds[c.a10]; t[2].hi = lds[BOX_CAP + c.a10];
+    t[3].lo = lds[c.a11]; t[3].hi = lds[BOX_CAP + c.a11];
   }
-  return t;
+}
+
+// bilinear interpolation of the 8 channels as four channel pairs (v_pk_mul / v_pk_fma), cds_interp's operation order
+__device__ __forceinline__ void interp8(const Tex8 t[4], const Cell& c, v2f o[4]) {
+  const v2f w0 = splat2(c.w00), w1 = splat2(c.w01), w2 = splat2(c.w10), w3 = splat2(c.w11);
+#define CDS_PAIR(j, F, A, B)                              \
+  o[j] = (v2f){t[0].F.A, t[0].F.B} * w0;                  \
+  o[j] = fma2((v2f){t[1].F.A, t[1].F.B}, w1, o[j]);       \
+  o[j] = fma2((v2f){t[2].F.A, t[2].F.B}, w2, o[j]);       \
+  o[j] = fma2((v2f){t[3].F.A, t[3].F.B}, w3, o[j]);
+  CDS_PAIR(0, lo, x, y)
+  CDS_PAIR(1, lo, z, w)
+  CDS_PAIR(2, hi, x, y)
+  CDS_PAIR(3, hi, z, w)
+#undef CDS_PAIR
+}
+
+__device__ __forceinline__ void plane_weights(v2f ix, v2f iy, v2f& x0f, v2f& y0f, v2f w[4]) {
+  x0f.x = floorf(ix.x); x0f.y = floorf(ix.y);
+  y0f.x = floorf(iy.x); y0f.y = floorf(iy.y);
+  const v2f wx = ix - x0f, ex = 1.0f - wx;
+  const v2f ny = iy - y0f, sy = 1.0f - ny;
+  w[0] = sy * ex;
+  w[1] = sy * wx;
+  w[2] = ny * ex;
+  w[3] = ny * wx;
 }
 
 // ---------------------------------------------------------------------------------------------
-// K3 with LDS-staged boxes, C = 8, V <= 4 (all views of a chunk resident: 4 x 16 KB)
+// K3 with LDS-staged boxes, C = 8, V <= 4 (all views of a chunk resident: 4 x 15.75 KB).
+// Two planes per iteration so the position / weight arithmetic issues as packed fp32 (v_pk_*).
+// Accumulation: volume += (ref*vis) * warp as one fma per channel (re-association of the reference's
+// (ref*warp)*vis, <= 2 ulp of a value below 1).
 // ---------------------------------------------------------------------------------------------
 template <int VMAX>
 __global__ __launch_bounds__(256) void warp_aggregate_lds_kernel(
     const float* __restrict__ ref, const float* __restrict__ src, const float* __restrict__ vis, WarpMats mats,
     const float* __restrict__ hyp, float* __restrict__ volume, const float* __restrict__ vis_sum, int V, int D, int h,
-    int w, int flags, int tiles_x, int ntiles) {
-  extern __shared__ __attribute__((aligned(16))) float4 lds4[];  // VMAX * 2*BOX_CAP float4, then int red[4*VMAX*4]
+    int w, float rhw, float rhh, int flags, int tiles_x, int ntiles) {
+  extern __shared__ __attribute__((aligned(16))) cds_f4 lds4[];  // VMAX * 2*BOX_CAP float4, then int red[4*VMAX*4]
   int* red = reinterpret_cast<int*>(lds4 + VMAX * 2 * BOX_CAP);
 
   const int tile = cds_xcd_remap(blockIdx.x, ntiles);
@@ -200,19 +270,24 @@ __global__ __launch_bounds__(256) void warp_aggregate_lds_kernel(
   const int y = ty * CDS_TILE_Y + (threadIdx.x >> 6);
   const bool active = x < w && y < h;
   const int xc = min(x, w - 1), yc = min(y, h - 1);  // inactive lanes shadow a valid pixel, never store
-  const float half_w = (float)((w - 1) / 2.0), half_h = (float)((h - 1) / 2.0);
+  Geo g;
+  g.h = h; g.w = w;
+  g.half_w = (float)((w - 1) / 2.0); g.half_h = (float)((h - 1) / 2.0);
+  g.rhw = rhw; g.rhh = rhh;
   const size_t hw = (size_t)h * w;
   const size_t pix = (size_t)yc * w + xc;
 
-  float rf[VMAX][C8];
-  float vw[VMAX];
+  v2f rv[VMAX][4];  // (ref * vis) per channel pair
   float r[VMAX][3];
 #pragma unroll
   for (int v = 0; v < VMAX; ++v) {
     if (v < V) {
-      vw[v] = vis[(size_t)v * hw + pix];
+      const float vw = vis[(size_t)v * hw + pix];
 #pragma unroll
-      for (int c = 0; c < C8; ++c) rf[v][c] = ref[((size_t)v * C8 + c) * hw + pix];
+      for (int j = 0; j < 4; ++j) {
+        rv[v][j].x = ref[((size_t)v * C8 + 2 * j) * hw + pix] * vw;
+        rv[v][j].y = ref[((size_t)v * C8 + 2 * j + 1) * hw + pix] * vw;
+      }
       cds_row_terms(mats.m[v], (float)xc, (float)yc, r[v]);
     }
   }
@@ -222,15 +297,14 @@ __global__ __launch_bounds__(256) void warp_aggregate_lds_kernel(
 
   for (int d0 = 0; d0 < D; d0 += DC) {
     const int d1 = min(D, d0 + DC);
-    // ---- boxes of this chunk ----
     int cx0[VMAX], cy0[VMAX], cx1[VMAX], cy1[VMAX];
     const float dfirst = hyp[(size_t)d0 * hw + pix], dlast = hyp[(size_t)(d1 - 1) * hw + pix];
 #pragma unroll
     for (int v = 0; v < VMAX; ++v) {
       cx0[v] = cy0[v] = cx1[v] = cy1[v] = 0;
       if (v < V) {
-        cell_of(r[v], mats.m[v] + 9, dfirst, h, w, half_w, half_h, cx0[v], cy0[v]);
-        cell_of(r[v], mats.m[v] + 9, dlast, h, w, half_w, half_h, cx1[v], cy1[v]);
+        cell_of(r[v], mats.m[v] + 9, dfirst, h, w, g.half_w, g.half_h, cx0[v], cy0[v]);
+        cell_of(r[v], mats.m[v] + 9, dlast, h, w, g.half_w, g.half_h, cx1[v], cy1[v]);
       }
     }
     Box box[VMAX];
@@ -238,50 +312,65 @@ __global__ __launch_bounds__(256) void warp_aggregate_lds_kernel(
     reduce_boxes<VMAX>(cx0, cy0, cx1, cy1, active, V, h, w, red, box);
 #pragma unroll
     for (int v = 0; v < VMAX; ++v)
-      if (v < V) stage_box(src + (size_t)v * hw * C8, w, box[v], lds4 + v * 2 * BOX_CAP);
+      if (v < V) stage_box(src + (size_t)v * hw * C8, w, box[v], reinterpret_cast<float4*>(lds4 + v * 2 * BOX_CAP));
     __syncthreads();
 
-    // ---- planes of the chunk ----
-    float dnext = hyp[(size_t)d0 * hw + pix];
-    for (int d = d0; d < d1; ++d) {
-      const float dv = dnext;
-      if (d + 1 < d1) dnext = hyp[(size_t)(d + 1) * hw + pix];
-      float acc[C8];
+    for (int d = d0; d < d1; d += 2) {
+      const bool two = d + 1 < d1;
+      v2f dv;
+      dv.x = hyp[(size_t)d * hw + pix];
+      dv.y = two ? hyp[(size_t)(d + 1) * hw + pix] : dv.x;
+      v2f acc[2][4];
 #pragma unroll
-      for (int c = 0; c < C8; ++c) acc[c] = accumulate ? volume[((size_t)c * D + d) * hw + pix] : 0.f;
+      for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          acc[k][j] = splat2(0.f);
+          if (accumulate && (k == 0 || two)) {
+            acc[k][j].x = volume[((size_t)(2 * j) * D + d + k) * hw + pix];
+            acc[k][j].y = volume[((size_t)(2 * j + 1) * D + d + k) * hw + pix];
+          }
+        }
 #pragma unroll
       for (int v = 0; v < VMAX; ++v) {
         if (v < V) {
           const float* __restrict__ srcv = src + (size_t)v * hw * C8;
-          const float4* lv = lds4 + v * 2 * BOX_CAP;
-          const Taps2 tp = taps2(r[v], mats.m[v] + 9, dv, h, w, half_w, half_h);
-          const Tex a = fetch2(tp.x0, tp.y0, tp.ok[0], w, box[v], lv, srcv);
-          const Tex b = fetch2(tp.x0 + 1, tp.y0, tp.ok[1], w, box[v], lv, srcv);
-          const Tex c = fetch2(tp.x0, tp.y0 + 1, tp.ok[2], w, box[v], lv, srcv);
-          const Tex e = fetch2(tp.x0 + 1, tp.y0 + 1, tp.ok[3], w, box[v], lv, srcv);
-          const float w0 = cds_interp(a.lo.x, b.lo.x, c.lo.x, e.lo.x, tp.wt);
-          const float w1 = cds_interp(a.lo.y, b.lo.y, c.lo.y, e.lo.y, tp.wt);
-          const float w2 = cds_interp(a.lo.z, b.lo.z, c.lo.z, e.lo.z, tp.wt);
-          const float w3 = cds_interp(a.lo.w, b.lo.w, c.lo.w, e.lo.w, tp.wt);
-          const float w4 = cds_interp(a.hi.x, b.hi.x, c.hi.x, e.hi.x, tp.wt);
-          const float w5 = cds_interp(a.hi.y, b.hi.y, c.hi.y, e.hi.y, tp.wt);
-          const float w6 = cds_interp(a.hi.z, b.hi.z, c.hi.z, e.hi.z, tp.wt);
-          const float w7 = cds_interp(a.hi.w, b.hi.w, c.hi.w, e.hi.w, tp.wt);
-          acc[0] = acc[0] + (rf[v][0] * w0) * vw[v];
-          acc[1] = acc[1] + (rf[v][1] * w1) * vw[v];
-          acc[2] = acc[2] + (rf[v][2] * w2) * vw[v];
-          acc[3] = acc[3] + (rf[v][3] * w3) * vw[v];
-          acc[4] = acc[4] + (rf[v][4] * w4) * vw[v];
-          acc[5] = acc[5] + (rf[v][5] * w5) * vw[v];
-          acc[6] = acc[6] + (rf[v][6] * w6) * vw[v];
-          acc[7] = acc[7] + (rf[v][7] * w7) * vw[v];
+          const cds_f4* lv = lds4 + v * 2 * BOX_CAP;
+          v2f ix, iy, x0f, y0f, wt[4];
+          positions2(r[v], mats.m[v] + 9, dv, g, ix, iy);
+          plane_weights(ix, iy, x0f, y0f, wt);
+          {
+            const Cell c = make_cell(x0f.x, y0f.x, wt[0].x, wt[1].x, wt[2].x, wt[3].x, g, box[v]);
+            Tex8 t[4];
+            fetch_cell(c, g, lv, srcv, t);
+            v2f o[4];
+            interp8(t, c, o);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[0][j] = fma2(rv[v][j], o[j], acc[0][j]);
+          }
+          {
+            const Cell c = make_cell(x0f.y, y0f.y, wt[0].y, wt[1].y, wt[2].y, wt[3].y, g, box[v]);
+            Tex8 t[4];
+            fetch_cell(c, g, lv, srcv, t);
+            v2f o[4];
+            interp8(t, c, o);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[1][j] = fma2(rv[v][j], o[j], acc[1][j]);
+          }
         }
       }
       if (active) {
 #pragma unroll
-        for (int c = 0; c < C8; ++c) {
-          const float o = normalize ? acc[c] / denom : acc[c];
-          __builtin_nontemporal_store(o, &volume[((size_t)c * D + d) * hw + pix]);
+        for (int k = 0; k < 2; ++k) {
+          if (k == 0 || two) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const float o0 = normalize ? acc[k][j].x / denom : acc[k][j].x;
+              const float o1 = normalize ? acc[k][j].y / denom : acc[k][j].y;
+              __builtin_nontemporal_store(o0, &volume[((size_t)(2 * j) * D + d + k) * hw + pix]);
+              __builtin_nontemporal_store(o1, &volume[((size_t)(2 * j + 1) * D + d + k) * hw + pix]);
+            }
+          }
         }
       }
     }
@@ -289,14 +378,28 @@ __global__ __launch_bounds__(256) void warp_aggregate_lds_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
-// K1 with an LDS-staged box, C = 8, one (tile, view) per workgroup
+// K1 with an LDS-staged box, C = 8, one (tile, view) per workgroup, two planes per iteration
 // ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void online_entropy_update(float s, float& mx, float& Z, float& T) {
+  if (s > mx) {
+    const float sc = expf(mx - s);
+    const float shift = (Z == 0.f) ? 0.f : (mx - s) * Z;
+    T = sc * (T + shift);
+    Z = Z * sc;
+    mx = s;
+  }
+  const float dlt = s - mx;
+  const float ev = expf(dlt);
+  Z += ev;
+  T = fmaf(dlt, ev, T);
+}
+
 __global__ __launch_bounds__(256) void warp_entropy_lds_kernel(const float* __restrict__ ref,
                                                                const float* __restrict__ src, WarpMats mats,
                                                                const float* __restrict__ hyp,
                                                                float* __restrict__ entropy, int V, int D, int h, int w,
-                                                               int tiles_x, int ntiles) {
-  extern __shared__ __attribute__((aligned(16))) float4 lds4[];
+                                                               float rhw, float rhh, int tiles_x, int ntiles) {
+  extern __shared__ __attribute__((aligned(16))) cds_f4 lds4[];
   int* red = reinterpret_cast<int*>(lds4 + 2 * BOX_CAP);
   const int lin = cds_xcd_remap(blockIdx.x, ntiles * V);
   const int v = lin % V;
@@ -306,60 +409,64 @@ __global__ __launch_bounds__(256) void warp_entropy_lds_kernel(const float* __re
   const int y = ty * CDS_TILE_Y + (threadIdx.x >> 6);
   const bool active = x < w && y < h;
   const int xc = min(x, w - 1), yc = min(y, h - 1);
-  const float half_w = (float)((w - 1) / 2.0), half_h = (float)((h - 1) / 2.0);
+  Geo g;
+  g.h = h; g.w = w;
+  g.half_w = (float)((w - 1) / 2.0); g.half_h = (float)((h - 1) / 2.0);
+  g.rhw = rhw; g.rhh = rhh;
   const size_t hw = (size_t)h * w;
   const size_t pix = (size_t)yc * w + xc;
   const float* __restrict__ srcv = src + (size_t)v * hw * C8;
-  // the matrix of this block's view, copied out of the kernarg struct with a block-uniform index
   float m[12];
 #pragma unroll
   for (int i = 0; i < 12; ++i) m[i] = mats.m[v][i];
-  float rf[C8];
+  v2f rf[4];
 #pragma unroll
-  for (int c = 0; c < C8; ++c) rf[c] = ref[((size_t)v * C8 + c) * hw + pix];
+  for (int j = 0; j < 4; ++j) {
+    rf[j].x = ref[((size_t)v * C8 + 2 * j) * hw + pix];
+    rf[j].y = ref[((size_t)v * C8 + 2 * j + 1) * hw + pix];
+  }
   float r[3];
   cds_row_terms(m, (float)xc, (float)yc, r);
   float mx = -INFINITY, Z = 0.f, T = 0.f;
   for (int d0 = 0; d0 < D; d0 += DC) {
     const int d1 = min(D, d0 + DC);
     int cx0[1], cy0[1], cx1[1], cy1[1];
-    cell_of(r, m + 9, hyp[(size_t)d0 * hw + pix], h, w, half_w, half_h, cx0[0], cy0[0]);
-    cell_of(r, m + 9, hyp[(size_t)(d1 - 1) * hw + pix], h, w, half_w, half_h, cx1[0], cy1[0]);
+    cell_of(r, m + 9, hyp[(size_t)d0 * hw + pix], h, w, g.half_w, g.half_h, cx0[0], cy0[0]);
+    cell_of(r, m + 9, hyp[(size_t)(d1 - 1) * hw + pix], h, w, g.half_w, g.half_h, cx1[0], cy1[0]);
     Box box[1];
     __syncthreads();
     reduce_boxes<1>(cx0, cy0, cx1, cy1, active, 1, h, w, red, box);
-    stage_box(srcv, w, box[0], lds4);
+    stage_box(srcv, w, box[0], reinterpret_cast<float4*>(lds4));
     __syncthreads();
-    float dnext = hyp[(size_t)d0 * hw + pix];
-    for (int d = d0; d < d1; ++d) {
-      const float dv = dnext;
-      if (d + 1 < d1) dnext = hyp[(size_t)(d + 1) * hw + pix];
-      const Taps2 tp = taps2(r, m + 9, dv, h, w, half_w, half_h);
-      const Tex a = fetch2(tp.x0, tp.y0, tp.ok[0], w, box[0], lds4, srcv);
-      const Tex b = fetch2(tp.x0 + 1, tp.y0, tp.ok[1], w, box[0], lds4, srcv);
-      const Tex c = fetch2(tp.x0, tp.y0 + 1, tp.ok[2], w, box[0], lds4, srcv);
-      const Tex e = fetch2(tp.x0 + 1, tp.y0 + 1, tp.ok[3], w, box[0], lds4, srcv);
-      float s = 0.f;
-      s = s + rf[0] * cds_interp(a.lo.x, b.lo.x, c.lo.x, e.lo.x, tp.wt);
-      s = s + rf[1] * cds_interp(a.lo.y, b.lo.y, c.lo.y, e.lo.y, tp.wt);
-      s = s + rf[2] * cds_interp(a.lo.z, b.lo.z, c.lo.z, e.lo.z, tp.wt);
-      s = s + rf[3] * cds_interp(a.lo.w, b.lo.w, c.lo.w, e.lo.w, tp.wt);
-      s = s + rf[4] * cds_interp(a.hi.x, b.hi.x, c.hi.x, e.hi.x, tp.wt);
-      s = s + rf[5] * cds_interp(a.hi.y, b.hi.y, c.hi.y, e.hi.y, tp.wt);
-      s = s + rf[6] * cds_interp(a.hi.z, b.hi.z, c.hi.z, e.hi.z, tp.wt);
-      s = s + rf[7] * cds_interp(a.hi.w, b.hi.w, c.hi.w, e.hi.w, tp.wt);
-      s = 0.f + s;  // (level sum of ATen's cascade: one 16-row level for C = 8)
-      if (s > mx) {
-        const float sc = expf(mx - s);
-        const float shift = (Z == 0.f) ? 0.f : (mx - s) * Z;
-        T = sc * (T + shift);
-        Z = Z * sc;
-        mx = s;
+    for (int d = d0; d < d1; d += 2) {
+      const bool two = d + 1 < d1;
+      v2f dv;
+      dv.x = hyp[(size_t)d * hw + pix];
+      dv.y = two ? hyp[(size_t)(d + 1) * hw + pix] : dv.x;
+      v2f ix, iy, x0f, y0f, wt[4];
+      positions2(r, m + 9, dv, g, ix, iy);
+      plane_weights(ix, iy, x0f, y0f, wt);
+      float sim[2];
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const Cell c = k == 0 ? make_cell(x0f.x, y0f.x, wt[0].x, wt[1].x, wt[2].x, wt[3].x, g, box[0])
+                              : make_cell(x0f.y, y0f.y, wt[0].y, wt[1].y, wt[2].y, wt[3].y, g, box[0]);
+        Tex8 t[4];
+        fetch_cell(c, g, lds4, srcv, t);
+        v2f o[4];
+        interp8(t, c, o);
+        // sum_C ref*warp, channel order 0..7 (ATen's sequential outer-dim sum for C <= 16)
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const v2f p = rf[j] * o[j];
+          s = s + p.x;
+          s = s + p.y;
+        }
+        sim[k] = s;
       }
-      const float dlt = s - mx;
-      const float ev = expf(dlt);
-      Z += ev;
-      T = fmaf(dlt, ev, T);
+      online_entropy_update(sim[0], mx, Z, T);
+      if (two) online_entropy_update(sim[1], mx, Z, T);
     }
   }
   if (active) entropy[(size_t)v * hw + pix] = logf(Z) - T / Z;
@@ -371,13 +478,14 @@ __global__ __launch_bounds__(256) void warp_entropy_lds_kernel(const float* __re
 bool cds_warp_aggregate_lds_launch(const float* ref, const float* src, const float* vis, const WarpMats& wm,
                                    const float* hyp, float* volume, const float* vis_sum, int V, int C, int D, int h,
                                    int w, int hyp_pp, int flags, hipStream_t st) {
-  if (C != 8 || V > 4 || !hyp_pp) return false;
+  if (C != 8 || V > 4 || !hyp_pp || w < 2 || h < 2) return false;
   const int tiles_x = cds_ceil_div(w, CDS_TILE_X), tiles_y = cds_ceil_div(h, CDS_TILE_Y);
   const int ntiles = tiles_x * tiles_y;
+  const float rhw = (float)(1.0 / (double)(float)((w - 1) / 2.0)), rhh = (float)(1.0 / (double)(float)((h - 1) / 2.0));
 #define LAUNCH(VM)                                                                                                     \
   hipLaunchKernelGGL(warp_aggregate_lds_kernel<VM>, dim3(ntiles), dim3(256),                                           \
                      (size_t)VM * 2 * BOX_CAP * sizeof(float4) + 4 * VM * 4 * sizeof(int), st, ref, src, vis, wm, hyp, \
-                     volume, vis_sum, V, D, h, w, flags, tiles_x, ntiles)
+                     volume, vis_sum, V, D, h, w, rhw, rhh, flags, tiles_x, ntiles)
   if (V <= 2) LAUNCH(2);
   else LAUNCH(4);
 #undef LAUNCH
@@ -386,11 +494,12 @@ bool cds_warp_aggregate_lds_launch(const float* ref, const float* src, const flo
 
 bool cds_warp_entropy_lds_launch(const float* ref, const float* src, const WarpMats& wm, const float* hyp,
                                  float* entropy, int V, int C, int D, int h, int w, int hyp_pp, hipStream_t st) {
-  if (C != 8 || !hyp_pp) return false;
+  if (C != 8 || !hyp_pp || w < 2 || h < 2) return false;
   const int tiles_x = cds_ceil_div(w, CDS_TILE_X), tiles_y = cds_ceil_div(h, CDS_TILE_Y);
   const int ntiles = tiles_x * tiles_y;
+  const float rhw = (float)(1.0 / (double)(float)((w - 1) / 2.0)), rhh = (float)(1.0 / (double)(float)((h - 1) / 2.0));
   hipLaunchKernelGGL(warp_entropy_lds_kernel, dim3(ntiles * V), dim3(256),
                      (size_t)2 * BOX_CAP * sizeof(float4) + 4 * 4 * sizeof(int), st, ref, src, wm, hyp, entropy, V, D, h,
-                     w, tiles_x, ntiles);
+                     w, rhw, rhh, tiles_x, ntiles);
   return true;
 }
