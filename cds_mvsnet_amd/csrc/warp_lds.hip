@@ -13,6 +13,8 @@
 // falls outside it (non-monotone hypotheses, projective pole) and any box larger than the LDS budget take the
 // original global-memory path per lane / per block, so results never depend on the geometry assumptions.
 // Arithmetic and operation order are identical to warp.hip (same cds_taps / cds_interp).
+#include <stdlib.h>
+
 #include "warp_common.hpp"
 
 namespace {
@@ -37,7 +39,7 @@ __device__ __forceinline__ int wave_max(int v) {
   return v;
 }
 
-// integer cell (floor of the sample position) clamped to [-2, n+1]; NaN -> -2 (never in the image)
+// integer cell (floor of the sample position) clamped to [-2, n]; NaN -> -2 (never in the image)
 __device__ __forceinline__ void cell_of(const float r[3], const float* __restrict__ t, float d, int h, int w,
                                         float half_w, float half_h, int& cx, int& cy) {
   float px = r[0] * d + t[0];
@@ -49,8 +51,8 @@ __device__ __forceinline__ void cell_of(const float r[3], const float* __restric
   float fx = floorf(ix), fy = floorf(iy);
   fx = (fx >= -2.0f) ? fx : -2.0f;  // also catches NaN
   fy = (fy >= -2.0f) ? fy : -2.0f;
-  fx = fminf(fx, (float)(w + 1));
-  fy = fminf(fy, (float)(h + 1));
+  fx = fminf(fx, (float)w);
+  fy = fminf(fy, (float)h);
   cx = (int)fx;
   cy = (int)fy;
 }
@@ -91,30 +93,36 @@ __device__ __forceinline__ void reduce_boxes(const int cx0[NV], const int cy0[NV
       ymin = min(ymin, p[2]);
       ymax = max(ymax, p[3]);
     }
-    // taps touch cells [xmin, xmax+1] x [ymin, ymax+1]; clip to the image
-    int bx0 = max(xmin, 0), bx1 = min(xmax + 1, w - 1);
-    int by0 = max(ymin, 0), by1 = min(ymax + 1, h - 1);
-    int bw = bx1 - bx0 + 1, bh = by1 - by0 + 1;
-    bool ok = (v < nv) && bw > 0 && bh > 0 && bw * bh <= BOX_CAP;
-    box[v].x0 = __builtin_amdgcn_readfirstlane(bx0);
-    box[v].y0 = __builtin_amdgcn_readfirstlane(by0);
+    // taps touch cells [xmin, xmax+1] x [ymin, ymax+1] (cells are clamped to [-2, n], so the box reaches at most
+    // two texels outside the image; that border is staged as zeros = grid_sample's zero padding)
+    const int bw = xmax + 2 - xmin, bh = ymax + 2 - ymin;
+    const bool ok = (v < nv) && xmax >= xmin && ymax >= ymin && bw * bh <= BOX_CAP;
+    // not staged: origin far away and limits 0, so no cell ever passes the containment test
+    box[v].x0 = __builtin_amdgcn_readfirstlane(ok ? xmin : -0x40000000);
+    box[v].y0 = __builtin_amdgcn_readfirstlane(ok ? ymin : -0x40000000);
     box[v].bw = __builtin_amdgcn_readfirstlane(ok ? bw : 0);
     box[v].bh = __builtin_amdgcn_readfirstlane(ok ? bh : 0);
     box[v].staged = __builtin_amdgcn_readfirstlane((int)ok) != 0;
   }
 }
 
-// Cooperative copy of one box into its two LDS planes.  Each wave takes rows wave, wave+4, ...
-__device__ __forceinline__ void stage_box(const float* __restrict__ srcv, int w, const Box& b, float4* __restrict__ dst) {
+// Cooperative copy of one box into its two LDS planes, zero outside the image.  Each wave takes rows wave, wave+4, ...
+__device__ __forceinline__ void stage_box(const float* __restrict__ srcv, int h, int w, const Box& b,
+                                          float4* __restrict__ dst) {
   if (!b.staged) return;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int n4 = 2 * b.bw;  // float4 per row
   for (int row = wave; row < b.bh; row += 4) {
-    const float4* __restrict__ g = reinterpret_cast<const float4*>(srcv + ((size_t)(b.y0 + row) * w + b.x0) * C8);
+    const int gy = b.y0 + row;
+    const bool row_ok = (unsigned)gy < (unsigned)h;
+    const float4* __restrict__ g =
+        reinterpret_cast<const float4*>(srcv + ((ptrdiff_t)(row_ok ? gy : 0) * w + b.x0) * C8);
     float4* lo = dst + row * b.bw;
     float4* hi = dst + BOX_CAP + row * b.bw;
     for (int i = lane; i < n4; i += 64) {
-      const float4 v = g[i];
+      const bool ok = row_ok && (unsigned)(b.x0 + (i >> 1)) < (unsigned)w;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ok) v = g[i];
       ((i & 1) ? hi : lo)[i >> 1] = v;
     }
   }
@@ -165,68 +173,56 @@ __device__ __forceinline__ void positions2(const float r[3], const float* __rest
   iy = (gy + 1.0f) * g.half_h;
 }
 
-// clamp x into [lo, hi] (lowered to v_med3_i32 when lo <= hi)
-__device__ __forceinline__ int cds_clampi(int x, int lo, int hi) { return min(max(x, lo), hi); }
-
-struct Cell {  // one plane, one view: integer cell, zeroed-if-outside weights, LDS indices
-  int x0, y0;
-  float w00, w01, w10, w11;
-  int a00, a01, a10, a11;
-  bool miss;   // a tap that is inside the image is not inside the staged box
-};
-
-__device__ __forceinline__ Cell make_cell(float x0f, float y0f, float w00, float w01, float w10, float w11, const Geo& g,
-                                          const Box& b) {
-  Cell c;
-  c.x0 = (int)x0f;  // v_cvt_i32_f32 saturates; NaN -> 0 (then the NaN weights propagate like the reference)
-  c.y0 = (int)y0f;
-  const bool x0ok = (unsigned)c.x0 < (unsigned)g.w, x1ok = (unsigned)(c.x0 + 1) < (unsigned)g.w;
-  const bool y0ok = (unsigned)c.y0 < (unsigned)g.h, y1ok = (unsigned)(c.y0 + 1) < (unsigned)g.h;
-  c.w00 = (x0ok && y0ok) ? w00 : 0.f;
-  c.w01 = (x1ok && y0ok) ? w01 : 0.f;
-  c.w10 = (x0ok && y1ok) ? w10 : 0.f;
-  c.w11 = (x1ok && y1ok) ? w11 : 0.f;
-  const int bx1 = b.x0 + b.bw - 1, by1 = b.y0 + b.bh - 1;
-  const int xa = cds_clampi(c.x0, b.x0, bx1), xb = cds_clampi(c.x0 + 1, b.x0, bx1);
-  const int ya = cds_clampi(c.y0, b.y0, by1), yb = cds_clampi(c.y0 + 1, b.y0, by1);
-  c.miss = !b.staged || (x0ok && xa != c.x0) || (x1ok && xb != c.x0 + 1) || (y0ok && ya != c.y0) ||
-           (y1ok && yb != c.y0 + 1);
-  const int base = -(b.y0 * b.bw + b.x0);
-  const int ra = ya * b.bw + base, rb = yb * b.bw + base;
-  c.a00 = ra + xa;
-  c.a01 = ra + xb;
-  c.a10 = rb + xa;
-  c.a11 = rb + xb;
-  return c;
+// v_med3_i32 with an inline constant and one SGPR (constant-bus limit of gfx9 VOP3 = 1)
+__device__ __forceinline__ int clamp_m2(int x, int hi) {
+  int r;
+  asm("v_med3_i32 %0, %1, -2, %2" : "=v"(r) : "v"(x), "s"(hi));
+  return r;
 }
 
 struct Tex8 {
   cds_f4 lo, hi;
 };
 
-__device__ __forceinline__ void fetch_cell(const Cell& c, const Geo& g, const cds_f4* __restrict__ lds,
-                                           const float* __restrict__ srcv, Tex8 t[4]) {
-  if (__builtin_expect(c.miss, 0)) {
-    // slow path (box too large for LDS, or a tap outside the first/last-plane bounding box): global gathers from
-    // coordinates clamped into the image; taps outside the image already carry weight 0.
-    const int xa = min(max(c.x0, 0), g.w - 1), xb = min(max(c.x0 + 1, 0), g.w - 1);
-    const int ya = min(max(c.y0, 0), g.h - 1), yb = min(max(c.y0 + 1, 0), g.h - 1);
+// The 2x2 texel cell of one (plane, view).  Fast path: the cell, clamped to [-2, n] (everything further out is
+// zero padding anyway), lies inside the staged zero-bordered box -> four 32-byte texels from LDS, no per-tap
+// validity logic.  Slow path (box not staged, or a cell outside the first/last-plane bounding box): global gathers
+// with per-tap image tests.  Returns the weights to use (zeroed for out-of-image taps on the slow path).
+__device__ __forceinline__ void fetch_cell(float x0f, float y0f, const Geo& g, const Box& b,
+                                           const cds_f4* __restrict__ lds, const float* __restrict__ srcv, Tex8 t[4],
+                                           float wgt[4]) {
+  const int x0 = clamp_m2((int)x0f, g.w);  // v_cvt_i32_f32 saturates, NaN -> 0 (NaN weights then propagate)
+  const int y0 = clamp_m2((int)y0f, g.h);
+  const unsigned ux = (unsigned)(x0 - b.x0), uy = (unsigned)(y0 - b.y0);
+  const bool inside = (ux + 2u <= (unsigned)b.bw) && (uy + 2u <= (unsigned)b.bh);  // bw = bh = 0 when not staged
+  if (__builtin_expect(!inside, 0)) {
+    const bool x0ok = (unsigned)x0 < (unsigned)g.w, x1ok = (unsigned)(x0 + 1) < (unsigned)g.w;
+    const bool y0ok = (unsigned)y0 < (unsigned)g.h, y1ok = (unsigned)(y0 + 1) < (unsigned)g.h;
+    wgt[0] = (x0ok && y0ok) ? wgt[0] : 0.f;
+    wgt[1] = (x1ok && y0ok) ? wgt[1] : 0.f;
+    wgt[2] = (x0ok && y1ok) ? wgt[2] : 0.f;
+    wgt[3] = (x1ok && y1ok) ? wgt[3] : 0.f;
+    const int xa = min(max(x0, 0), g.w - 1), xb = min(max(x0 + 1, 0), g.w - 1);
+    const int ya = min(max(y0, 0), g.h - 1), yb = min(max(y0 + 1, 0), g.h - 1);
     const cds_f4* p;
     p = reinterpret_cast<const cds_f4*>(srcv + ((size_t)ya * g.w + xa) * C8); t[0].lo = p[0]; t[0].hi = p[1];
     p = reinterpret_cast<const cds_f4*>(srcv + ((size_t)ya * g.w + xb) * C8); t[1].lo = p[0]; t[1].hi = p[1];
     p = reinterpret_cast<const cds_f4*>(srcv + ((size_t)yb * g.w + xa) * C8); t[2].lo = p[0]; t[2].hi = p[1];
     p = reinterpret_cast<const cds_f4*>(srcv + ((size_t)yb * g.w + xb) * C8); t[3].lo = p[0]; t[3].hi = p[1];
   } else {
-    t[0].lo = lds[c.a00]; t[0].hi = lds[BOX_CAP + c.a00];
-    t[1].lo = lds[c.a01]; t[1].hi = lds[BOX_CAP + c.a01];
-    t[2].lo = lds[c.a10]; t[2].hi = lds[BOX_CAP + c.a10];
-    t[3].lo = lds[c.a11]; t[3].hi = lds[BOX_CAP + c.a11];
+    const unsigned i0 = __umul24(uy, (unsigned)b.bw) + ux;
+    const cds_f4* r0 = lds + i0;
+    const cds_f4* r1 = r0 + b.bw;
+    t[0].lo = r0[0]; t[0].hi = r0[BOX_CAP];
+    t[1].lo = r0[1]; t[1].hi = r0[BOX_CAP + 1];
+    t[2].lo = r1[0]; t[2].hi = r1[BOX_CAP];
+    t[3].lo = r1[1]; t[3].hi = r1[BOX_CAP + 1];
   }
 }
 
 // bilinear interpolation of the 8 channels as four channel pairs (v_pk_mul / v_pk_fma), cds_interp's operation order
-__device__ __forceinline__ void interp8(const Tex8 t[4], const Cell& c, v2f o[4]) {
-  const v2f w0 = splat2(c.w00), w1 = splat2(c.w01), w2 = splat2(c.w10), w3 = splat2(c.w11);
+__device__ __forceinline__ void interp8(const Tex8 t[4], const float wgt[4], v2f o[4]) {
+  const v2f w0 = splat2(wgt[0]), w1 = splat2(wgt[1]), w2 = splat2(wgt[2]), w3 = splat2(wgt[3]);
 #define CDS_PAIR(j, F, A, B)                              \
   o[j] = (v2f){t[0].F.A, t[0].F.B} * w0;                  \
   o[j] = fma2((v2f){t[1].F.A, t[1].F.B}, w1, o[j]);       \
@@ -254,17 +250,22 @@ __device__ __forceinline__ void plane_weights(v2f ix, v2f iy, v2f& x0f, v2f& y0f
 // K3 with LDS-staged boxes, C = 8, V <= 4 (all views of a chunk resident: 4 x 15.75 KB).
 // Two planes per iteration so the position / weight arithmetic issues as packed fp32 (v_pk_*).
 // Accumulation: volume += (ref*vis) * warp as one fma per channel (re-association of the reference's
-// (ref*warp)*vis, <= 2 ulp of a value below 1).
+// (ref*warp)*vis, <= 2 ulp of a value below 1).  Normalisation a/(vis_sum+1e-6): reciprocal refined once per
+// pixel, quotient corrected with two fmas (correctly rounded like the IEEE sequence, 3 instead of ~10 VALU ops).
+// Addressing: per-channel slab base (uniform) + one 32-bit byte offset per plane (slab = D*h*w*4 < 4 GB).
 // ---------------------------------------------------------------------------------------------
 template <int VMAX>
 __global__ __launch_bounds__(256) void warp_aggregate_lds_kernel(
     const float* __restrict__ ref, const float* __restrict__ src, const float* __restrict__ vis, WarpMats mats,
     const float* __restrict__ hyp, float* __restrict__ volume, const float* __restrict__ vis_sum, int V, int D, int h,
-    int w, float rhw, float rhh, int flags, int tiles_x, int ntiles) {
+    int w, float rhw, float rhh, int flags, int tiles_x, int ntiles, int nseg, int seg_planes) {
   extern __shared__ __attribute__((aligned(16))) cds_f4 lds4[];  // VMAX * 2*BOX_CAP float4, then int red[4*VMAX*4]
   int* red = reinterpret_cast<int*>(lds4 + VMAX * 2 * BOX_CAP);
 
-  const int tile = cds_xcd_remap(blockIdx.x, ntiles);
+  // depth segment is the fastest-varying index: the nseg blocks of a tile run together and share its features in L2
+  const int lin = cds_xcd_remap(blockIdx.x, ntiles * nseg);
+  const int seg = lin % nseg;
+  const int tile = lin / nseg;
   const int tx = tile % tiles_x, ty = tile / tiles_x;
   const int x = tx * CDS_TILE_X + (threadIdx.x & 63);
   const int y = ty * CDS_TILE_Y + (threadIdx.x >> 6);
@@ -274,8 +275,9 @@ __global__ __launch_bounds__(256) void warp_aggregate_lds_kernel(
   g.h = h; g.w = w;
   g.half_w = (float)((w - 1) / 2.0); g.half_h = (float)((h - 1) / 2.0);
   g.rhw = rhw; g.rhh = rhh;
-  const size_t hw = (size_t)h * w;
-  const size_t pix = (size_t)yc * w + xc;
+  const unsigned hw = (unsigned)h * (unsigned)w;
+  const unsigned pix = (unsigned)yc * (unsigned)w + (unsigned)xc;
+  const size_t slab = (size_t)D * hw;  // elements per channel of the volume
 
   v2f rv[VMAX][4];  // (ref * vis) per channel pair
   float r[VMAX][3];
@@ -294,9 +296,13 @@ __global__ __launch_bounds__(256) void warp_aggregate_lds_kernel(
   const bool accumulate = flags & CDS_AGG_ACCUMULATE;
   const bool normalize = flags & CDS_AGG_NORMALIZE;
   const float denom = (normalize ? vis_sum[pix] : 1.0f) + 1e-6f;
+  float yden = __builtin_amdgcn_rcpf(denom);
+  yden = fmaf(fmaf(-denom, yden, 1.0f), yden, yden);
+  const char* hyp_b = reinterpret_cast<const char*>(hyp);
 
-  for (int d0 = 0; d0 < D; d0 += DC) {
-    const int d1 = min(D, d0 + DC);
+  const int dseg0 = seg * seg_planes, dseg1 = min(D, dseg0 + seg_planes);
+  for (int d0 = dseg0; d0 < dseg1; d0 += DC) {
+    const int d1 = min(dseg1, d0 + DC);
     int cx0[VMAX], cy0[VMAX], cx1[VMAX], cy1[VMAX];
     const float dfirst = hyp[(size_t)d0 * hw + pix], dlast = hyp[(size_t)(d1 - 1) * hw + pix];
 #pragma unroll
@@ -312,14 +318,21 @@ __global__ __launch_bounds__(256) void warp_aggregate_lds_kernel(
     reduce_boxes<VMAX>(cx0, cy0, cx1, cy1, active, V, h, w, red, box);
 #pragma unroll
     for (int v = 0; v < VMAX; ++v)
-      if (v < V) stage_box(src + (size_t)v * hw * C8, w, box[v], reinterpret_cast<float4*>(lds4 + v * 2 * BOX_CAP));
+      if (v < V) stage_box(src + (size_t)v * hw * C8, h, w, box[v], reinterpret_cast<float4*>(lds4 + v * 2 * BOX_CAP));
     __syncthreads();
 
-    for (int d = d0; d < d1; d += 2) {
+    unsigned boff = ((unsigned)d0 * hw + pix) * 4u;  // byte offset of (plane d, pixel) inside a channel slab / hyp
+    const unsigned bstep = hw * 4u;
+    v2f dnext;  // hypotheses of the next plane pair, loaded one iteration ahead
+    dnext.x = *reinterpret_cast<const float*>(hyp_b + boff);
+    dnext.y = (d0 + 1 < d1) ? *reinterpret_cast<const float*>(hyp_b + boff + bstep) : dnext.x;
+    for (int d = d0; d < d1; d += 2, boff += 2u * bstep) {
       const bool two = d + 1 < d1;
-      v2f dv;
-      dv.x = hyp[(size_t)d * hw + pix];
-      dv.y = two ? hyp[(size_t)(d + 1) * hw + pix] : dv.x;
+      const v2f dv = dnext;
+      if (d + 2 < d1) {
+        dnext.x = *reinterpret_cast<const float*>(hyp_b + boff + 2u * bstep);
+        dnext.y = (d + 3 < d1) ? *reinterpret_cast<const float*>(hyp_b + boff + 3u * bstep) : dnext.x;
+      }
       v2f acc[2][4];
 #pragma unroll
       for (int k = 0; k < 2; ++k)
@@ -327,8 +340,8 @@ __global__ __launch_bounds__(256) void warp_aggregate_lds_kernel(
         for (int j = 0; j < 4; ++j) {
           acc[k][j] = splat2(0.f);
           if (accumulate && (k == 0 || two)) {
-            acc[k][j].x = volume[((size_t)(2 * j) * D + d + k) * hw + pix];
-            acc[k][j].y = volume[((size_t)(2 * j + 1) * D + d + k) * hw + pix];
+            acc[k][j].x = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(volume + (size_t)(2 * j) * slab) + boff + k * bstep);
+            acc[k][j].y = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(volume + (size_t)(2 * j + 1) * slab) + boff + k * bstep);
           }
         }
 #pragma unroll
@@ -339,23 +352,15 @@ __global__ __launch_bounds__(256) void warp_aggregate_lds_kernel(
           v2f ix, iy, x0f, y0f, wt[4];
           positions2(r[v], mats.m[v] + 9, dv, g, ix, iy);
           plane_weights(ix, iy, x0f, y0f, wt);
-          {
-            const Cell c = make_cell(x0f.x, y0f.x, wt[0].x, wt[1].x, wt[2].x, wt[3].x, g, box[v]);
-            Tex8 t[4];
-            fetch_cell(c, g, lv, srcv, t);
-            v2f o[4];
-            interp8(t, c, o);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[0][j] = fma2(rv[v][j], o[j], acc[0][j]);
-          }
-          {
-            const Cell c = make_cell(x0f.y, y0f.y, wt[0].y, wt[1].y, wt[2].y, wt[3].y, g, box[v]);
+          for (int k = 0; k < 2; ++k) {
+            float wgt[4] = {k ? wt[0].y : wt[0].x, k ? wt[1].y : wt[1].x, k ? wt[2].y : wt[2].x, k ? wt[3].y : wt[3].x};
             Tex8 t[4];
-            fetch_cell(c, g, lv, srcv, t);
+            fetch_cell(k ? x0f.y : x0f.x, k ? y0f.y : y0f.x, g, box[v], lv, srcv, t, wgt);
             v2f o[4];
-            interp8(t, c, o);
+            interp8(t, wgt, o);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[1][j] = fma2(rv[v][j], o[j], acc[1][j]);
+            for (int j = 0; j < 4; ++j) acc[k][j] = fma2(rv[v][j], o[j], acc[k][j]);
           }
         }
       }
@@ -365,10 +370,18 @@ __global__ __launch_bounds__(256) void warp_aggregate_lds_kernel(
           if (k == 0 || two) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-              const float o0 = normalize ? acc[k][j].x / denom : acc[k][j].x;
-              const float o1 = normalize ? acc[k][j].y / denom : acc[k][j].y;
-              __builtin_nontemporal_store(o0, &volume[((size_t)(2 * j) * D + d + k) * hw + pix]);
-              __builtin_nontemporal_store(o1, &volume[((size_t)(2 * j + 1) * D + d + k) * hw + pix]);
+              v2f o = acc[k][j];
+              if (normalize) {
+                v2f q = o * yden;
+                v2f rr = fma2(splat2(-denom), q, o);
+                q = fma2(rr, splat2(yden), q);
+                rr = fma2(splat2(-denom), q, o);
+                o = fma2(rr, splat2(yden), q);
+              }
+              float* p0 = reinterpret_cast<float*>(reinterpret_cast<char*>(volume + (size_t)(2 * j) * slab) + boff + k * bstep);
+              float* p1 = reinterpret_cast<float*>(reinterpret_cast<char*>(volume + (size_t)(2 * j + 1) * slab) + boff + k * bstep);
+              __builtin_nontemporal_store(o.x, p0);
+              __builtin_nontemporal_store(o.y, p1);
             }
           }
         }
@@ -380,16 +393,20 @@ __global__ __launch_bounds__(256) void warp_aggregate_lds_kernel(
 // ---------------------------------------------------------------------------------------------
 // K1 with an LDS-staged box, C = 8, one (tile, view) per workgroup, two planes per iteration
 // ---------------------------------------------------------------------------------------------
+// Softmax-entropy statistics with a lazily updated reference m: Z = sum e^(s-m), T = sum (s-m) e^(s-m).
+// m starts at the first plane's score and is only moved when a score exceeds it by more than 40 (e^40 is far from
+// fp32 overflow even summed over thousands of planes); with tanh-bounded features |s| <= C this never triggers.
 __device__ __forceinline__ void online_entropy_update(float s, float& mx, float& Z, float& T) {
-  if (s > mx) {
-    const float sc = expf(mx - s);
+  float dlt = s - mx;
+  if (__builtin_expect(dlt > 40.0f, 0)) {  // also taken on the first plane (mx = -inf)
+    const float sc = expf(mx - s);         // exp(-inf) = 0 on the first plane
     const float shift = (Z == 0.f) ? 0.f : (mx - s) * Z;
     T = sc * (T + shift);
     Z = Z * sc;
     mx = s;
+    dlt = 0.f;
   }
-  const float dlt = s - mx;
-  const float ev = expf(dlt);
+  const float ev = __builtin_amdgcn_exp2f(dlt * 1.44269504088896340736f);  // v_exp_f32, ~1 ulp
   Z += ev;
   T = fmaf(dlt, ev, T);
 }
@@ -413,8 +430,8 @@ __global__ __launch_bounds__(256) void warp_entropy_lds_kernel(const float* __re
   g.h = h; g.w = w;
   g.half_w = (float)((w - 1) / 2.0); g.half_h = (float)((h - 1) / 2.0);
   g.rhw = rhw; g.rhh = rhh;
-  const size_t hw = (size_t)h * w;
-  const size_t pix = (size_t)yc * w + xc;
+  const unsigned hw = (unsigned)h * (unsigned)w;
+  const unsigned pix = (unsigned)yc * (unsigned)w + (unsigned)xc;
   const float* __restrict__ srcv = src + (size_t)v * hw * C8;
   float m[12];
 #pragma unroll
@@ -427,6 +444,7 @@ __global__ __launch_bounds__(256) void warp_entropy_lds_kernel(const float* __re
   }
   float r[3];
   cds_row_terms(m, (float)xc, (float)yc, r);
+  const char* hyp_b = reinterpret_cast<const char*>(hyp);
   float mx = -INFINITY, Z = 0.f, T = 0.f;
   for (int d0 = 0; d0 < D; d0 += DC) {
     const int d1 = min(D, d0 + DC);
@@ -436,34 +454,40 @@ __global__ __launch_bounds__(256) void warp_entropy_lds_kernel(const float* __re
     Box box[1];
     __syncthreads();
     reduce_boxes<1>(cx0, cy0, cx1, cy1, active, 1, h, w, red, box);
-    stage_box(srcv, w, box[0], reinterpret_cast<float4*>(lds4));
+    stage_box(srcv, h, w, box[0], reinterpret_cast<float4*>(lds4));
     __syncthreads();
-    for (int d = d0; d < d1; d += 2) {
+    unsigned boff = ((unsigned)d0 * hw + pix) * 4u;
+    const unsigned bstep = hw * 4u;
+    v2f dnext;
+    dnext.x = *reinterpret_cast<const float*>(hyp_b + boff);
+    dnext.y = (d0 + 1 < d1) ? *reinterpret_cast<const float*>(hyp_b + boff + bstep) : dnext.x;
+    for (int d = d0; d < d1; d += 2, boff += 2u * bstep) {
       const bool two = d + 1 < d1;
-      v2f dv;
-      dv.x = hyp[(size_t)d * hw + pix];
-      dv.y = two ? hyp[(size_t)(d + 1) * hw + pix] : dv.x;
+      const v2f dv = dnext;
+      if (d + 2 < d1) {
+        dnext.x = *reinterpret_cast<const float*>(hyp_b + boff + 2u * bstep);
+        dnext.y = (d + 3 < d1) ? *reinterpret_cast<const float*>(hyp_b + boff + 3u * bstep) : dnext.x;
+      }
       v2f ix, iy, x0f, y0f, wt[4];
       positions2(r, m + 9, dv, g, ix, iy);
       plane_weights(ix, iy, x0f, y0f, wt);
       float sim[2];
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
-        const Cell c = k == 0 ? make_cell(x0f.x, y0f.x, wt[0].x, wt[1].x, wt[2].x, wt[3].x, g, box[0])
-                              : make_cell(x0f.y, y0f.y, wt[0].y, wt[1].y, wt[2].y, wt[3].y, g, box[0]);
+        float wgt[4] = {k ? wt[0].y : wt[0].x, k ? wt[1].y : wt[1].x, k ? wt[2].y : wt[2].x, k ? wt[3].y : wt[3].x};
         Tex8 t[4];
-        fetch_cell(c, g, lds4, srcv, t);
+        fetch_cell(k ? x0f.y : x0f.x, k ? y0f.y : y0f.x, g, box[0], lds4, srcv, t, wgt);
         v2f o[4];
-        interp8(t, c, o);
+        interp8(t, wgt, o);
         // sum_C ref*warp, channel order 0..7 (ATen's sequential outer-dim sum for C <= 16)
-        float s = 0.f;
+        float sacc = 0.f;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const v2f p = rf[j] * o[j];
-          s = s + p.x;
-          s = s + p.y;
+          sacc = sacc + p.x;
+          sacc = sacc + p.y;
         }
-        sim[k] = s;
+        sim[k] = sacc;
       }
       online_entropy_update(sim[0], mx, Z, T);
       if (two) online_entropy_update(sim[1], mx, Z, T);
@@ -478,14 +502,22 @@ __global__ __launch_bounds__(256) void warp_entropy_lds_kernel(const float* __re
 bool cds_warp_aggregate_lds_launch(const float* ref, const float* src, const float* vis, const WarpMats& wm,
                                    const float* hyp, float* volume, const float* vis_sum, int V, int C, int D, int h,
                                    int w, int hyp_pp, int flags, hipStream_t st) {
-  if (C != 8 || V > 4 || !hyp_pp || w < 2 || h < 2) return false;
+  if (C != 8 || V > 4 || !hyp_pp || w < 2 || h < 2 || (size_t)D * h * w * 4 >= ((size_t)1 << 32)) return false;
   const int tiles_x = cds_ceil_div(w, CDS_TILE_X), tiles_y = cds_ceil_div(h, CDS_TILE_Y);
   const int ntiles = tiles_x * tiles_y;
   const float rhw = (float)(1.0 / (double)(float)((w - 1) / 2.0)), rhh = (float)(1.0 / (double)(float)((h - 1) / 2.0));
+  // Depth segments: enough workgroups for ~10 waves per SIMD (2 are resident), each a whole number of DC chunks.
+  const int chunks = cds_ceil_div(D, DC);
+  int nseg = 1;
+  while (nseg < chunks && (size_t)ntiles * nseg * 4 < (size_t)10 * 1024) nseg *= 2;
+  if (nseg > chunks) nseg = chunks;
+  if (const char* e = getenv("CDS_K3_NSEG")) nseg = atoi(e) > 0 ? (atoi(e) < chunks ? atoi(e) : chunks) : nseg;  // tuning knob
+  const int seg_planes = cds_ceil_div(chunks, nseg) * DC;
+  nseg = cds_ceil_div(D, seg_planes);
 #define LAUNCH(VM)                                                                                                     \
-  hipLaunchKernelGGL(warp_aggregate_lds_kernel<VM>, dim3(ntiles), dim3(256),                                           \
+  hipLaunchKernelGGL(warp_aggregate_lds_kernel<VM>, dim3(ntiles * nseg), dim3(256),                                    \
                      (size_t)VM * 2 * BOX_CAP * sizeof(float4) + 4 * VM * 4 * sizeof(int), st, ref, src, vis, wm, hyp, \
-                     volume, vis_sum, V, D, h, w, rhw, rhh, flags, tiles_x, ntiles)
+                     volume, vis_sum, V, D, h, w, rhw, rhh, flags, tiles_x, ntiles, nseg, seg_planes)
   if (V <= 2) LAUNCH(2);
   else LAUNCH(4);
 #undef LAUNCH
@@ -494,7 +526,7 @@ bool cds_warp_aggregate_lds_launch(const float* ref, const float* src, const flo
 
 bool cds_warp_entropy_lds_launch(const float* ref, const float* src, const WarpMats& wm, const float* hyp,
                                  float* entropy, int V, int C, int D, int h, int w, int hyp_pp, hipStream_t st) {
-  if (C != 8 || !hyp_pp || w < 2 || h < 2) return false;
+  if (C != 8 || !hyp_pp || w < 2 || h < 2 || (size_t)D * h * w * 4 >= ((size_t)1 << 32)) return false;
   const int tiles_x = cds_ceil_div(w, CDS_TILE_X), tiles_y = cds_ceil_div(h, CDS_TILE_Y);
   const int ntiles = tiles_x * tiles_y;
   const float rhw = (float)(1.0 / (double)(float)((w - 1) / 2.0)), rhh = (float)(1.0 / (double)(float)((h - 1) / 2.0));
