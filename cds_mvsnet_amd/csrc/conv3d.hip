@@ -8,6 +8,8 @@
 // (cout fastest) so the 3*CO weights of one (cin,kz,ky) row are contiguous and wave-uniform: they
 // are fetched through the scalar cache into SGPRs and feed v_fmac directly (no LDS / VGPR cost).
 // fp32 accumulate with explicit fmaf, order: cin-major, then kz, ky, kx.
+#include <stdlib.h>
+
 #include "cds_common.hpp"
 
 namespace {
@@ -278,9 +280,9 @@ int launch_deconv(const float* x, const float* w, const float* b, const float* s
 // loads of chunk k+1 are issued before the FMAs of chunk k and land in registers while the chunk is
 // computed (global latency hidden behind ~7k cycles of FMAs instead of being serialised per row).
 // ---------------------------------------------------------------------------------------------
-template <int S, int LX, int LY, int LZ, int PX, int CO, int CI_CHUNK>
+template <int S, int LX, int LY, int LZ, int PX, int PZ, int CO, int CI_CHUNK>
 struct PipeCfg {
-  static constexpr int TX = LX * PX, TY = LY, TZ = LZ;
+  static constexpr int TX = LX * PX, TY = LY, TZ = LZ * PZ;
   static constexpr int OFFX = 3;                                   // tile x origin = S*ox0 - 4, first needed col = 3
   static constexpr int IY = (TY - 1) * S + 3, IZ = (TZ - 1) * S + 3;
   static constexpr int IXP = ((TX - 1) * S + 6 + 3) & ~3;
@@ -289,16 +291,18 @@ struct PipeCfg {
   static constexpr int TILE = NS * 4;
   static constexpr int NSLOT = (CI_CHUNK * NS + 255) / 256;
   static constexpr int NIN = (PX - 1) * S + 3;
+  static constexpr int NZ = (PZ - 1) * S + 3;                      // input rows along z per thread
 };
 
-template <int S, int LX, int LY, int LZ, int PX, int CO, int CI_CHUNK>
+// PZ = outputs per thread along z (register blocking: an input row read from LDS feeds up to 3 z-outputs).
+template <int S, int LX, int LY, int LZ, int PX, int PZ, int CO, int CI_CHUNK>
 __global__ __launch_bounds__(256) void conv3d_k3_pipe_kernel(const float* __restrict__ x, const float* __restrict__ wpk,
                                                              const float* __restrict__ bias,
                                                              const float* __restrict__ skip, float* __restrict__ out,
                                                              int Cin, int Cout, int D, int H, int W, int Do, int Ho,
                                                              int Wo, int act, int tiles_x, int tiles_y, int tiles_z,
                                                              int ntiles) {
-  using Cfg = PipeCfg<S, LX, LY, LZ, PX, CO, CI_CHUNK>;
+  using Cfg = PipeCfg<S, LX, LY, LZ, PX, PZ, CO, CI_CHUNK>;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int co_blocks = Cout / CO;
   int lin = cds_xcd_remap(blockIdx.x, ntiles * co_blocks);
@@ -341,11 +345,13 @@ __global__ __launch_bounds__(256) void conv3d_k3_pipe_kernel(const float* __rest
     }
   };
 
-  float acc[PX][CO];
+  float acc[PZ][PX][CO];
 #pragma unroll
-  for (int p = 0; p < PX; ++p)
+  for (int z = 0; z < PZ; ++z)
 #pragma unroll
-    for (int c = 0; c < CO; ++c) acc[p][c] = 0.f;
+    for (int p = 0; p < PX; ++p)
+#pragma unroll
+      for (int c = 0; c < CO; ++c) acc[z][p][c] = 0.f;
 
   issue(0);
   for (int ci0 = 0; ci0 < Cin; ci0 += CI_CHUNK) {
@@ -365,10 +371,10 @@ __global__ __launch_bounds__(256) void conv3d_k3_pipe_kernel(const float* __rest
       const float* __restrict__ wc = wpk + ((size_t)(ci0 + ci) * 27) * Cout + co0;
       const float* tile_ci = lds + ci * Cfg::TILE;
 #pragma unroll 1
-      for (int kz = 0; kz < 3; ++kz) {
+      for (int ky = 0; ky < 3; ++ky) {
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-          const float* rowp = tile_ci + ((lz * S + kz) * Cfg::IY + (ly * S + ky)) * Cfg::IXP + lx * PX * S;
+        for (int iz = 0; iz < Cfg::NZ; ++iz) {
+          const float* rowp = tile_ci + ((lz * PZ * S + iz) * Cfg::IY + (ly * S + ky)) * Cfg::IXP + lx * PX * S;
           float in[Cfg::NIN];
           if constexpr (S == 1 && PX == 4) {
             // cols 4lx+3 .. 4lx+8: one aligned 16-byte read for the middle four, two dword reads for the ends
@@ -382,12 +388,18 @@ __global__ __launch_bounds__(256) void conv3d_k3_pipe_kernel(const float* __rest
             for (int i = 0; i < Cfg::NIN; ++i) in[i] = rowp[Cfg::OFFX + i];
           }
 #pragma unroll
-          for (int kx = 0; kx < 3; ++kx) {
+          for (int z = 0; z < PZ; ++z) {
+            const int kz = iz - z * S;  // compile-time after unrolling
+            if (kz >= 0 && kz < 3) {
 #pragma unroll
-            for (int c = 0; c < CO; ++c) {
-              const float wv = wc[((kz * 3 + ky) * 3 + kx) * Cout + c];
+              for (int kx = 0; kx < 3; ++kx) {
 #pragma unroll
-              for (int p = 0; p < PX; ++p) acc[p][c] = fmaf(in[p * S + kx], wv, acc[p][c]);
+                for (int c = 0; c < CO; ++c) {
+                  const float wv = wc[((kz * 3 + ky) * 3 + kx) * Cout + c];
+#pragma unroll
+                  for (int p = 0; p < PX; ++p) acc[z][p][c] = fmaf(in[p * S + kx], wv, acc[z][p][c]);
+                }
+              }
             }
           }
         }
@@ -395,30 +407,35 @@ __global__ __launch_bounds__(256) void conv3d_k3_pipe_kernel(const float* __rest
     }
   }
 
-  const int oz = oz0 + lz, oy = oy0 + ly, oxb = ox0 + lx * PX;
-  if (oz >= Do || oy >= Ho || oxb >= Wo) return;
+  const int oy = oy0 + ly, oxb = ox0 + lx * PX;
+  if (oy >= Ho || oxb >= Wo) return;
   const size_t oplane = (size_t)Ho * Wo, ovol = (size_t)Do * oplane;
   const bool vec = (PX == 4) && ((Wo & 3) == 0);  // oxb is a multiple of 4 -> 16-byte aligned rows
 #pragma unroll
-  for (int c = 0; c < CO; ++c) {
-    const float b = bias ? bias[co0 + c] : 0.f;
-    const size_t base = (size_t)(co0 + c) * ovol + (size_t)oz * oplane + (size_t)oy * Wo + oxb;
-    float v[PX];
+  for (int z = 0; z < PZ; ++z) {
+    const int oz = oz0 + lz * PZ + z;
+    if (oz >= Do) break;
 #pragma unroll
-    for (int p = 0; p < PX; ++p) v[p] = (act == CDS_ACT_RELU) ? fmaxf(acc[p][c] + b, 0.f) : acc[p][c] + b;
-    if (vec) {
-      if constexpr (PX == 4) {
-        float4 o = make_float4(v[0], v[1], v[2], v[3]);
-        if (skip) {
-          const float4 s4 = *reinterpret_cast<const float4*>(skip + base);
-          o.x = s4.x + o.x; o.y = s4.y + o.y; o.z = s4.z + o.z; o.w = s4.w + o.w;
+    for (int c = 0; c < CO; ++c) {
+      const float b = bias ? bias[co0 + c] : 0.f;
+      const size_t base = (size_t)(co0 + c) * ovol + (size_t)oz * oplane + (size_t)oy * Wo + oxb;
+      float v[PX];
+#pragma unroll
+      for (int p = 0; p < PX; ++p) v[p] = (act == CDS_ACT_RELU) ? fmaxf(acc[z][p][c] + b, 0.f) : acc[z][p][c] + b;
+      if (vec) {
+        if constexpr (PX == 4) {
+          float4 o = make_float4(v[0], v[1], v[2], v[3]);
+          if (skip) {
+            const float4 s4 = *reinterpret_cast<const float4*>(skip + base);
+            o.x = s4.x + o.x; o.y = s4.y + o.y; o.z = s4.z + o.z; o.w = s4.w + o.w;
+          }
+          *reinterpret_cast<float4*>(out + base) = o;
         }
-        *reinterpret_cast<float4*>(out + base) = o;
-      }
-    } else {
+      } else {
 #pragma unroll
-      for (int p = 0; p < PX; ++p)
-        if (oxb + p < Wo) out[base + p] = skip ? skip[base + p] + v[p] : v[p];
+        for (int p = 0; p < PX; ++p)
+          if (oxb + p < Wo) out[base + p] = skip ? skip[base + p] + v[p] : v[p];
+      }
     }
   }
 }
@@ -565,15 +582,16 @@ __global__ __launch_bounds__(256) void deconv3d_k3s2_pipe_kernel(const float* __
   }
 }
 
-template <int S, int LX, int LY, int LZ, int PX, int CO, int CI_CHUNK>
+template <int S, int LX, int LY, int LZ, int PX, int PZ, int CO, int CI_CHUNK>
 int launch_conv_pipe(const float* x, const float* w, const float* b, const float* skip, float* out, int Cin, int Cout,
                      int D, int H, int W, int act, hipStream_t st) {
-  using Cfg = PipeCfg<S, LX, LY, LZ, PX, CO, CI_CHUNK>;
+  using Cfg = PipeCfg<S, LX, LY, LZ, PX, PZ, CO, CI_CHUNK>;
   const int Do = (D - 1) / S + 1, Ho = (H - 1) / S + 1, Wo = (W - 1) / S + 1;
   const int tx = cds_ceil_div(Wo, Cfg::TX), ty = cds_ceil_div(Ho, Cfg::TY), tz = cds_ceil_div(Do, Cfg::TZ);
   const int ntiles = tx * ty * tz;
   const size_t lds_bytes = (size_t)Cfg::TILE * CI_CHUNK * sizeof(float);
-  auto kern = conv3d_k3_pipe_kernel<S, LX, LY, LZ, PX, CO, CI_CHUNK>;
+  static_assert(Cfg::TILE * CI_CHUNK * sizeof(float) <= 65536, "dynamic LDS above 64 KB needs a function attribute");
+  auto kern = conv3d_k3_pipe_kernel<S, LX, LY, LZ, PX, PZ, CO, CI_CHUNK>;
   hipLaunchKernelGGL(kern, dim3(ntiles * (Cout / CO)), dim3(256), lds_bytes, st, x, w, b, skip, out, Cin, Cout, D, H, W,
                      Do, Ho, Wo, act, tx, ty, tz, ntiles);
   return cds_launch_status();
@@ -592,6 +610,161 @@ int launch_deconv_pipe(const float* x, const float* w, const float* b, const flo
   return cds_launch_status();
 }
 
+// ---------------------------------------------------------------------------------------------
+// transposed conv v2 (wide volumes): a workgroup owns 64x4x4 input cells and ONE (z,y) output parity class
+// (pz,py); a thread owns 4 x-adjacent cells and produces their 8 x-adjacent outputs (both x parities) x 8 channels
+// (64 accumulators).  Every weight fetched through the scalar cache is now used by 4 cells (the v1 kernel used each
+// weight once per thread and was bound by scalar-load issue: 4 packed FMAs per s_load instead of 16).
+// ---------------------------------------------------------------------------------------------
+template <int CO, int CI_CHUNK>
+struct D2Cfg {
+  static constexpr int LX = 16, LY = 4, LZ = 4, PC = 4;   // PC cells per thread
+  static constexpr int IY = LY + 1, IZ = LZ + 1;
+  static constexpr int IXP = (LX * PC + 1 + 3) & ~3;        // 68
+  static constexpr int Q = IXP / 4;
+  static constexpr int NS = IZ * IY * Q;
+  static constexpr int TILE = NS * 4;
+  static constexpr int NSLOT = (CI_CHUNK * NS + 255) / 256;
+};
+
+template <int CO, int CI_CHUNK>
+__global__ __launch_bounds__(256) void deconv3d_k3s2_v2_kernel(const float* __restrict__ x, const float* __restrict__ wpk,
+                                                               const float* __restrict__ bias,
+                                                               const float* __restrict__ skip, float* __restrict__ out,
+                                                               int Cin, int Cout, int D, int H, int W, int act,
+                                                               int tiles_x, int tiles_y, int tiles_z, int ntiles) {
+  using Cfg = D2Cfg<CO, CI_CHUNK>;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int co_blocks = Cout / CO;
+  int lin = cds_xcd_remap(blockIdx.x, ntiles * co_blocks * 4);
+  const int cls = lin & 3;          // parity class: the 4 classes of a tile run together (same input tile in L2)
+  lin >>= 2;
+  const int cob = lin % co_blocks;
+  int tile = lin / co_blocks;
+  const int tx_i = tile % tiles_x;
+  tile /= tiles_x;
+  const int ty_i = tile % tiles_y;
+  const int tz_i = tile / tiles_y;
+  const int co0 = cob * CO;
+  const int pz = cls >> 1, py = cls & 1;
+  const int tid = threadIdx.x;
+  const int lx = tid % Cfg::LX, ly = (tid / Cfg::LX) % Cfg::LY, lz = tid / (Cfg::LX * Cfg::LY);
+  const int ax0 = tx_i * Cfg::LX * Cfg::PC, ay0 = ty_i * Cfg::LY, az0 = tz_i * Cfg::LZ;
+  const size_t plane = (size_t)H * W, vol = (size_t)D * plane;
+
+  int goff[Cfg::NSLOT];
+#pragma unroll
+  for (int j = 0; j < Cfg::NSLOT; ++j) {
+    const int s = tid + 256 * j;
+    const int ci = s / Cfg::NS;
+    int r = s - ci * Cfg::NS;
+    const int row = r / Cfg::Q, c4 = r - row * Cfg::Q;
+    const int rz = row / Cfg::IY, ry = row - rz * Cfg::IY;
+    const int gz = az0 + rz, gy = ay0 + ry, gx = ax0 + 4 * c4;
+    const bool ok = (s < CI_CHUNK * Cfg::NS) && gz < D && gy < H && gx + 3 < W;
+    goff[j] = ok ? (int)((size_t)ci * vol + (size_t)gz * plane + (size_t)gy * W + gx) : -1;
+  }
+  float4 pre[Cfg::NSLOT];
+  auto issue = [&](int ci0) {
+    const float* __restrict__ xb = x + (size_t)ci0 * vol;
+#pragma unroll
+    for (int j = 0; j < Cfg::NSLOT; ++j) {
+      const int s = tid + 256 * j;
+      const int ci = s / Cfg::NS;
+      const bool ok = goff[j] >= 0 && ci0 + ci < Cin;
+      pre[j] = *reinterpret_cast<const float4*>(ok ? xb + goff[j] : x);
+    }
+  };
+
+  float acc[2 * Cfg::PC][CO];  // [output x: 2*cell + px][co]
+#pragma unroll
+  for (int q = 0; q < 2 * Cfg::PC; ++q)
+#pragma unroll
+    for (int c = 0; c < CO; ++c) acc[q][c] = 0.f;
+
+  issue(0);
+  for (int ci0 = 0; ci0 < Cin; ci0 += CI_CHUNK) {
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < Cfg::NSLOT; ++j) {
+      const int s = tid + 256 * j;
+      const bool ok = goff[j] >= 0 && ci0 + s / Cfg::NS < Cin;
+      if (s < CI_CHUNK * Cfg::NS)
+        *reinterpret_cast<float4*>(lds + 4 * s) = ok ? pre[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
+    if (ci0 + CI_CHUNK < Cin) issue(ci0 + CI_CHUNK);
+    const int cmax = min(CI_CHUNK, Cin - ci0);
+#pragma unroll 1
+    for (int ci = 0; ci < cmax; ++ci) {
+      const float* __restrict__ wc = wpk + ((size_t)(ci0 + ci) * 27) * Cout + co0;
+      const float* t = lds + ci * Cfg::TILE + (lz * Cfg::IY + ly) * Cfg::IXP + lx * Cfg::PC;
+      // along z (and y): parity 0 -> (input +0, tap 1); parity 1 -> (input +1, tap 0) and (input +0, tap 2)
+      for (int sz = 0; sz <= pz; ++sz) {
+        const int iz = pz ? 1 - sz : 0, kz = pz ? 2 * sz : 1;
+        for (int sy = 0; sy <= py; ++sy) {
+          const int iy = py ? 1 - sy : 0, ky = py ? 2 * sy : 1;
+          const float* rowp = t + (iz * Cfg::IY + iy) * Cfg::IXP;
+          const cds_f4 b = *reinterpret_cast<const volatile cds_f4*>(rowp);
+          const float in[5] = {b.x, b.y, b.z, b.w, rowp[4]};
+          const float* __restrict__ wrow = wc + ((kz * 3 + ky) * 3) * Cout;  // taps kx = 0,1,2 of this (kz,ky)
+#pragma unroll
+          for (int c = 0; c < CO; ++c) {
+            const float w0 = wrow[c], w1 = wrow[Cout + c], w2 = wrow[2 * Cout + c];
+#pragma unroll
+            for (int p = 0; p < Cfg::PC; ++p) {
+              acc[2 * p][c] = fmaf(in[p], w1, acc[2 * p][c]);              // x = 2a   : (input a,   tap 1)
+              acc[2 * p + 1][c] = fmaf(in[p + 1], w0, acc[2 * p + 1][c]);  // x = 2a+1 : (input a+1, tap 0)
+              acc[2 * p + 1][c] = fmaf(in[p], w2, acc[2 * p + 1][c]);      //            (input a,   tap 2)
+            }
+          }
+        }
+      }
+    }
+  }
+
+  const int az = az0 + lz, ay = ay0 + ly, ax = ax0 + lx * Cfg::PC;
+  if (az >= D || ay >= H || ax >= W) return;
+  const int Do = 2 * D, Ho = 2 * H, Wo = 2 * W;
+  const size_t oplane = (size_t)Ho * Wo, ovol = (size_t)Do * oplane;
+#pragma unroll
+  for (int c = 0; c < CO; ++c) {
+    const float b = bias ? bias[co0 + c] : 0.f;
+    const size_t base = (size_t)(co0 + c) * ovol + (size_t)(2 * az + pz) * oplane + (size_t)(2 * ay + py) * Wo + 2 * ax;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {  // W % 4 == 0 and ax % 4 == 0: both halves are fully inside or outside
+      if (ax + 2 * half < W) {
+        float4 o;
+        o.x = acc[4 * half + 0][c] + b;
+        o.y = acc[4 * half + 1][c] + b;
+        o.z = acc[4 * half + 2][c] + b;
+        o.w = acc[4 * half + 3][c] + b;
+        if (act == CDS_ACT_RELU) {
+          o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
+        }
+        if (skip) {
+          const float4 s4 = *reinterpret_cast<const float4*>(skip + base + 4 * half);
+          o.x = s4.x + o.x; o.y = s4.y + o.y; o.z = s4.z + o.z; o.w = s4.w + o.w;
+        }
+        *reinterpret_cast<float4*>(out + base + 4 * half) = o;
+      }
+    }
+  }
+}
+
+template <int CO, int CI_CHUNK>
+int launch_deconv_v2(const float* x, const float* w, const float* b, const float* skip, float* out, int Cin, int Cout,
+                     int D, int H, int W, int act, hipStream_t st) {
+  using Cfg = D2Cfg<CO, CI_CHUNK>;
+  const int tx = cds_ceil_div(W, Cfg::LX * Cfg::PC), ty = cds_ceil_div(H, Cfg::LY), tz = cds_ceil_div(D, Cfg::LZ);
+  const int ntiles = tx * ty * tz;
+  const size_t lds_bytes = (size_t)Cfg::TILE * CI_CHUNK * sizeof(float);
+  auto kern = deconv3d_k3s2_v2_kernel<CO, CI_CHUNK>;
+  hipLaunchKernelGGL(kern, dim3(ntiles * (Cout / CO) * 4), dim3(256), lds_bytes, st, x, w, b, skip, out, Cin, Cout, D, H,
+                     W, act, tx, ty, tz, ntiles);
+  return cds_launch_status();
+}
+
 }  // namespace
 
 extern "C" int cds_conv3d_k3_f32(const float* x, const float* weight, const float* bias, const float* skip, float* out,
@@ -603,12 +776,19 @@ extern "C" int cds_conv3d_k3_f32(const float* x, const float* weight, const floa
   const bool wide = Wo >= 48;
   // total elements must fit the 32-bit staging offsets of the pipe kernels
   const bool pipe_ok = (W % 4 == 0) && Wo >= 32 && ((size_t)Cin * D * H * W < (size_t)0x7fffffff);
+  static const int pz_knob = []() { const char* e = getenv("CDS_CONV_PZ"); return e ? atoi(e) : 0; }();  // A/B knob
   if (pipe_ok && Cout % 8 == 0) {
-    if (stride == 1) return launch_conv_pipe<1, 16, 4, 4, 4, 8, 4>(x, weight, bias, skip, out, Cin, Cout, D, H, W, act, st);
-    return launch_conv_pipe<2, 16, 4, 4, 2, 8, 2>(x, weight, bias, skip, out, Cin, Cout, D, H, W, act, st);
+    if (stride == 1) {
+      if (pz_knob == 2) return launch_conv_pipe<1, 16, 4, 4, 4, 2, 8, 2>(x, weight, bias, skip, out, Cin, Cout, D, H, W, act, st);
+      return launch_conv_pipe<1, 16, 4, 4, 4, 1, 8, 4>(x, weight, bias, skip, out, Cin, Cout, D, H, W, act, st);
+    }
+    return launch_conv_pipe<2, 16, 4, 4, 2, 1, 8, 2>(x, weight, bias, skip, out, Cin, Cout, D, H, W, act, st);
   }
-  if (pipe_ok && Cout == 1 && stride == 1)
-    return launch_conv_pipe<1, 16, 4, 4, 4, 1, 4>(x, weight, bias, skip, out, Cin, Cout, D, H, W, act, st);
+  if (pipe_ok && Cout == 1 && stride == 1) {
+    // Cout = 1 (prob): 4 z-outputs per thread so every LDS row read feeds up to 3 outputs (LDS-bound otherwise)
+    if (pz_knob == 1) return launch_conv_pipe<1, 16, 4, 4, 4, 1, 1, 4>(x, weight, bias, skip, out, Cin, Cout, D, H, W, act, st);
+    return launch_conv_pipe<1, 16, 4, 4, 4, 4, 1, 2>(x, weight, bias, skip, out, Cin, Cout, D, H, W, act, st);
+  }
   if (Cout == 1) {
     if (stride != 1) return CDS_EINVAL;
     return wide ? launch_conv<1, 16, 4, 4, 4, 1, 4>(x, weight, bias, skip, out, Cin, Cout, D, H, W, act, st)
@@ -627,8 +807,11 @@ extern "C" int cds_deconv3d_k3s2_f32(const float* x, const float* weight, const 
                                      float* out, int Cin, int Cout, int D, int H, int W, int act, void* stream) {
   if (!x || !weight || !out || Cin < 1 || Cout < 1 || (Cout % 8) || D < 1 || H < 1 || W < 1) return CDS_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  if ((W % 4 == 0) && W >= 32 && ((size_t)Cin * D * H * W < (size_t)0x7fffffff))
-    return launch_deconv_pipe<64, 2, 2, 8, 8>(x, weight, bias, skip, out, Cin, Cout, D, H, W, act, st);
+  if ((W % 4 == 0) && W >= 32 && ((size_t)Cin * D * H * W < (size_t)0x7fffffff)) {
+    static const bool v1 = []() { const char* e = getenv("CDS_DECONV_V1"); return e && e[0] == '1'; }();  // A/B knob
+    if (v1) return launch_deconv_pipe<64, 2, 2, 8, 8>(x, weight, bias, skip, out, Cin, Cout, D, H, W, act, st);
+    return launch_deconv_v2<8, 4>(x, weight, bias, skip, out, Cin, Cout, D, H, W, act, st);
+  }
   return W >= 48 ? launch_deconv<64, 2, 2, 8, 8>(x, weight, bias, skip, out, Cin, Cout, D, H, W, act, st)
                  : launch_deconv<16, 4, 4, 8, 8>(x, weight, bias, skip, out, Cin, Cout, D, H, W, act, st);
 }
