@@ -31,6 +31,15 @@ __device__ __forceinline__ int cds_xcd_remap(int bid, int nwg) {
   return base + idx;
 }
 
+// Tell the compiler a pointer is wave-uniform (it is derived from blockIdx / kernel arguments only): the loads
+// through it become scalar-cache loads with SALU address arithmetic instead of per-load v_readfirstlane pairs.
+__device__ __forceinline__ const float* cds_uniform_ptr(const float* p) {
+  const uint64_t u = reinterpret_cast<uint64_t>(p);
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u);
+  const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
+  return reinterpret_cast<const float*>(((uint64_t)hi << 32) | lo);
+}
+
 // lean epilogue activation for the conv kernels (none / ReLU / sigmoid)
 __device__ __forceinline__ float cds_act_conv(float v, int act) {
   if (act == CDS_ACT_RELU) return fmaxf(v, 0.0f);

@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256) void conv2d_kernel(const float* __restrict__ x
     __syncthreads();
     const int cmax = min(CI_CHUNK, Cin - ci0);
     for (int ci = 0; ci < cmax; ++ci) {
-      const float* __restrict__ wc = wpk + ((size_t)(ci0 + ci) * K * K) * CoutP + co0;
+      const float* __restrict__ wc = wpk + __builtin_amdgcn_readfirstlane(((ci0 + ci) * K * K) * CoutP + co0);
       const float* tile_ci = lds + ci * Cfg::TILE;
 #pragma unroll
       for (int ky = 0; ky < K; ++ky) {

@@ -368,7 +368,7 @@ __global__ __launch_bounds__(256) void conv3d_k3_pipe_kernel(const float* __rest
     const int cmax = min(CI_CHUNK, Cin - ci0);
 #pragma unroll 1
     for (int ci = 0; ci < cmax; ++ci) {
-      const float* __restrict__ wc = wpk + ((size_t)(ci0 + ci) * 27) * Cout + co0;
+      const float* __restrict__ wc = wpk + __builtin_amdgcn_readfirstlane(((ci0 + ci) * 27) * Cout + co0);
       const float* tile_ci = lds + ci * Cfg::TILE;
 #pragma unroll 1
       for (int ky = 0; ky < 3; ++ky) {
@@ -378,10 +378,10 @@ __global__ __launch_bounds__(256) void conv3d_k3_pipe_kernel(const float* __rest
           float in[Cfg::NIN];
           if constexpr (S == 1 && PX == 4) {
             // cols 4lx+3 .. 4lx+8: one aligned 16-byte read for the middle four, two dword reads for the ends
-            const cds_f4 b = *reinterpret_cast<const volatile cds_f4*>(rowp + 4);
+            const cds_f4 b = *reinterpret_cast<const cds_f4*>(rowp + 4);
             in[0] = rowp[3]; in[1] = b.x; in[2] = b.y; in[3] = b.z; in[4] = b.w; in[5] = rowp[8];
           } else if constexpr (S == 2 && PX == 2) {
-            const cds_f4 b = *reinterpret_cast<const volatile cds_f4*>(rowp + 4);
+            const cds_f4 b = *reinterpret_cast<const cds_f4*>(rowp + 4);
             in[0] = rowp[3]; in[1] = b.x; in[2] = b.y; in[3] = b.z; in[4] = b.w;
           } else {
 #pragma unroll
@@ -697,7 +697,7 @@ __global__ __launch_bounds__(256) void deconv3d_k3s2_v2_kernel(const float* __re
     const int cmax = min(CI_CHUNK, Cin - ci0);
 #pragma unroll 1
     for (int ci = 0; ci < cmax; ++ci) {
-      const float* __restrict__ wc = wpk + ((size_t)(ci0 + ci) * 27) * Cout + co0;
+      const float* __restrict__ wc = wpk + __builtin_amdgcn_readfirstlane(((ci0 + ci) * 27) * Cout + co0);
       const float* t = lds + ci * Cfg::TILE + (lz * Cfg::IY + ly) * Cfg::IXP + lx * Cfg::PC;
       // along z (and y): parity 0 -> (input +0, tap 1); parity 1 -> (input +1, tap 0) and (input +0, tap 2)
       for (int sz = 0; sz <= pz; ++sz) {
@@ -705,7 +705,7 @@ __global__ __launch_bounds__(256) void deconv3d_k3s2_v2_kernel(const float* __re
         for (int sy = 0; sy <= py; ++sy) {
           const int iy = py ? 1 - sy : 0, ky = py ? 2 * sy : 1;
           const float* rowp = t + (iz * Cfg::IY + iy) * Cfg::IXP;
-          const cds_f4 b = *reinterpret_cast<const volatile cds_f4*>(rowp);
+          const cds_f4 b = *reinterpret_cast<const cds_f4*>(rowp);
           const float in[5] = {b.x, b.y, b.z, b.w, rowp[4]};
           const float* __restrict__ wrow = wc + ((kz * 3 + ky) * 3) * Cout;  // taps kx = 0,1,2 of this (kz,ky)
 #pragma unroll
