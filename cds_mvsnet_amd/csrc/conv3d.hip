@@ -767,6 +767,12 @@ int launch_deconv_v2(const float* x, const float* w, const float* b, const float
 
 }  // namespace
 
+bool cds_conv3d_mfma_launch(const float* x, const float* w, const float* b, const float* skip, float* out, int Cin,
+                            int Cout, int D, int H, int W, int stride, int act, hipStream_t st, int* rc);
+
+bool cds_deconv3d_mfma_launch(const float* x, const float* w, const float* b, const float* skip, float* out, int Cin,
+                              int Cout, int D, int H, int W, int act, hipStream_t st, int* rc);
+
 extern "C" int cds_conv3d_k3_f32(const float* x, const float* weight, const float* bias, const float* skip, float* out,
                                  int Cin, int Cout, int D, int H, int W, int stride, int act, void* stream) {
   if (!x || !weight || !out || Cin < 1 || Cout < 1 || D < 1 || H < 1 || W < 1 || (stride != 1 && stride != 2))
@@ -777,6 +783,11 @@ extern "C" int cds_conv3d_k3_f32(const float* x, const float* weight, const floa
   // total elements must fit the 32-bit staging offsets of the pipe kernels
   const bool pipe_ok = (W % 4 == 0) && Wo >= 32 && ((size_t)Cin * D * H * W < (size_t)0x7fffffff);
   static const int pz_knob = []() { const char* e = getenv("CDS_CONV_PZ"); return e ? atoi(e) : 0; }();  // A/B knob
+  static const bool no_mfma = []() { const char* e = getenv("CDS_CONV_NO_MFMA"); return e && e[0] == '1'; }();
+  if (!no_mfma) {
+    int rc = 0;
+    if (cds_conv3d_mfma_launch(x, weight, bias, skip, out, Cin, Cout, D, H, W, stride, act, st, &rc)) return rc;
+  }
   if (pipe_ok && Cout % 8 == 0) {
     if (stride == 1) {
       if (pz_knob == 2) return launch_conv_pipe<1, 16, 4, 4, 4, 2, 8, 2>(x, weight, bias, skip, out, Cin, Cout, D, H, W, act, st);
@@ -807,6 +818,11 @@ extern "C" int cds_deconv3d_k3s2_f32(const float* x, const float* weight, const 
                                      float* out, int Cin, int Cout, int D, int H, int W, int act, void* stream) {
   if (!x || !weight || !out || Cin < 1 || Cout < 1 || (Cout % 8) || D < 1 || H < 1 || W < 1) return CDS_EINVAL;
   hipStream_t st = (hipStream_t)stream;
+  {
+    static const bool no_mfma = []() { const char* e = getenv("CDS_CONV_NO_MFMA"); return e && e[0] == '1'; }();
+    int rc = 0;
+    if (!no_mfma && cds_deconv3d_mfma_launch(x, weight, bias, skip, out, Cin, Cout, D, H, W, act, st, &rc)) return rc;
+  }
   if ((W % 4 == 0) && W >= 32 && ((size_t)Cin * D * H * W < (size_t)0x7fffffff)) {
     static const bool v1 = []() { const char* e = getenv("CDS_DECONV_V1"); return e && e[0] == '1'; }();  // A/B knob
     if (v1) return launch_deconv_pipe<64, 2, 2, 8, 8>(x, weight, bias, skip, out, Cin, Cout, D, H, W, act, st);

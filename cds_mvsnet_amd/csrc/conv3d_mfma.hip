@@ -1,0 +1,326 @@
+// K4 on the matrix cores: 3x3x3 convolution as an implicit GEMM on v_mfma_f32_16x16x4_f32 (fp32 in, fp32
+// accumulate, bit-exact fmaf chains, 157 TF peak = the packed-VALU peak but with 1 instruction per 2048 FLOP, so the
+// issue slots stay free for LDS reads / staging).  Used for the layers with Cout % 16 == 0 (N = 16 output channels
+// per MFMA); the Cout = 8 / 1 layers stay on the packed-VALU kernels of conv3d.hip (an N = 16 tile would idle half).
+//
+//   D[m = voxel][n = cout] += A[m][k] * B[k][n],  k = 4 consecutive input channels of ONE tap per MFMA
+//   A: lane l -> voxel (l & 15) of a 16-voxel x-run, input channel (l >> 4): one ds_read_b32 from the LDS tile
+//   B: lane l -> weight [ci0 + (l >> 4)][tap][co0 + (l & 15)]: one cached global load per (tap, chunk), reused by
+//      every M-tile of the wave
+//   C/D: lane l holds cout (l & 15), voxels (l >> 4) * 4 + 0..3 of the run -> one 16-byte store per M-tile
+#include "cds_common.hpp"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int S>
+struct MCfg {
+  static constexpr int TX = 64 / S, TY = 4, TZ = (S == 1 ? 4 : 2);           // output tile
+  static constexpr int XT = TX / 16;                                           // 16-voxel runs per row
+  static constexpr int NT = XT * TZ;                                          // M-tiles per wave (wave = one y row)
+  static constexpr int IY = (TY - 1) * S + 3, IZ = (TZ - 1) * S + 3;
+  static constexpr int IXP = ((TX - 1) * S + 6 + 3) & ~3;                     // tile x origin = S*ox0 - 4
+  static constexpr int Q = IXP / 4;
+  static constexpr int NS = IZ * IY * Q;                                      // float4 per channel
+  static constexpr int SLAB = NS * 4 + 16;                                    // +16 floats: channel k lands 16 banks apart
+  static constexpr int CI_CHUNK = 4;
+  static constexpr int NSLOT = (CI_CHUNK * NS + 255) / 256;
+};
+
+template <int S>
+__global__ __launch_bounds__(256) void conv3d_k3_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wpk,
+                                                             const float* __restrict__ bias,
+                                                             const float* __restrict__ skip, float* __restrict__ out,
+                                                             int Cin, int Cout, int D, int H, int W, int Do, int Ho,
+                                                             int Wo, int act, int tiles_x, int tiles_y, int tiles_z,
+                                                             int ntiles) {
+  using Cfg = MCfg<S>;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int co_blocks = Cout / 16;
+  int lin = cds_xcd_remap(blockIdx.x, ntiles * co_blocks);
+  const int cob = lin % co_blocks;
+  int tile = lin / co_blocks;
+  const int tx_i = tile % tiles_x;
+  tile /= tiles_x;
+  const int ty_i = tile % tiles_y;
+  const int tz_i = tile / tiles_y;
+  const int co0 = cob * 16;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // = output row y of this wave inside the tile
+  const int ox0 = tx_i * Cfg::TX, oy0 = ty_i * Cfg::TY, oz0 = tz_i * Cfg::TZ;
+  const int gx0 = ox0 * S - 4, gy0 = oy0 * S - 1, gz0 = oz0 * S - 1;
+  const size_t plane = (size_t)H * W, vol = (size_t)D * plane;
+
+  // ---- staging slots (same scheme as conv3d_k3_pipe_kernel: aligned float4, one chunk ahead) ----
+  int goff[Cfg::NSLOT];
+  int loff[Cfg::NSLOT];
+#pragma unroll
+  for (int j = 0; j < Cfg::NSLOT; ++j) {
+    const int s = tid + 256 * j;
+    const int ci = s / Cfg::NS;
+    int r = s - ci * Cfg::NS;
+    const int row = r / Cfg::Q, c4 = r - row * Cfg::Q;
+    const int rz = row / Cfg::IY, ry = row - rz * Cfg::IY;
+    const int gz = gz0 + rz, gy = gy0 + ry, gx = gx0 + 4 * c4;
+    const bool ok = (s < Cfg::CI_CHUNK * Cfg::NS) && gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx + 3 < W;
+    goff[j] = ok ? (int)((size_t)ci * vol + (size_t)gz * plane + (size_t)gy * W + gx) : -1;
+    loff[j] = ci * Cfg::SLAB + 4 * r;
+  }
+  float4 pre[Cfg::NSLOT];
+  auto issue = [&](int ci0) {
+    const float* __restrict__ xb = x + (size_t)ci0 * vol;
+#pragma unroll
+    for (int j = 0; j < Cfg::NSLOT; ++j) {
+      const bool ok = goff[j] >= 0;
+      pre[j] = *reinterpret_cast<const float4*>(ok ? xb + goff[j] : x);
+    }
+  };
+
+  f32x4 acc[Cfg::NT];
+#pragma unroll
+  for (int t = 0; t < Cfg::NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // lane-constant part of the A address: channel slab (l >> 4), voxel (l & 15) of the run, this wave's row
+  const float* a_base = lds + (lane >> 4) * Cfg::SLAB + (wave * S) * Cfg::IXP + (lane & 15) * S + 3;
+  // lane-constant part of the B address: [ci0 + (l >> 4)][tap][co0 + (l & 15)]
+  const float* __restrict__ b_base = wpk + (size_t)(lane >> 4) * 27 * Cout + co0 + (lane & 15);
+
+  issue(0);
+  for (int ci0 = 0; ci0 < Cin; ci0 += Cfg::CI_CHUNK) {   // host guarantees Cin % 4 == 0
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < Cfg::NSLOT; ++j) {
+      const int s = tid + 256 * j;
+      if (s < Cfg::CI_CHUNK * Cfg::NS)
+        *reinterpret_cast<float4*>(lds + loff[j]) = goff[j] >= 0 ? pre[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
+    if (ci0 + Cfg::CI_CHUNK < Cin) issue(ci0 + Cfg::CI_CHUNK);
+    const float* __restrict__ bw = b_base + (size_t)ci0 * 27 * Cout;
+#pragma unroll 1
+    for (int kz = 0; kz < 3; ++kz) {
+#pragma unroll 1
+      for (int ky = 0; ky < 3; ++ky) {
+        float bv[3];
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) bv[kx] = bw[((kz * 3 + ky) * 3 + kx) * Cout];
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+#pragma unroll
+          for (int t = 0; t < Cfg::NT; ++t) {
+            const int tz = t / Cfg::XT, txr = t % Cfg::XT;
+            const float a = a_base[((tz * S + kz) * Cfg::IY + ky) * Cfg::IXP + txr * 16 * S + kx];
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[kx], acc[t], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+
+  // ---- epilogue: lane -> cout (l & 15), voxels x = run*16 + (l >> 4)*4 + 0..3 ----
+  const int oy = oy0 + wave;
+  if (oy >= Ho) return;
+  const int co = co0 + (lane & 15);
+  const float b = bias ? bias[co] : 0.f;
+  const size_t oplane = (size_t)Ho * Wo, ovol = (size_t)Do * oplane;
+  const bool vec = (Wo & 3) == 0;
+#pragma unroll
+  for (int t = 0; t < Cfg::NT; ++t) {
+    const int tz = t / Cfg::XT, txr = t % Cfg::XT;
+    const int oz = oz0 + tz, oxb = ox0 + txr * 16 + (lane >> 4) * 4;
+    if (oz >= Do || oxb >= Wo) continue;
+    const size_t base = (size_t)co * ovol + (size_t)oz * oplane + (size_t)oy * Wo + oxb;
+    float v[4] = {acc[t].x + b, acc[t].y + b, acc[t].z + b, acc[t].w + b};
+    if (act == CDS_ACT_RELU) {
+#pragma unroll
+      for (int p = 0; p < 4; ++p) v[p] = fmaxf(v[p], 0.f);
+    }
+    if (vec) {
+      float4 o = make_float4(v[0], v[1], v[2], v[3]);
+      if (skip) {
+        const float4 s4 = *reinterpret_cast<const float4*>(skip + base);
+        o.x = s4.x + o.x; o.y = s4.y + o.y; o.z = s4.z + o.z; o.w = s4.w + o.w;
+      }
+      *reinterpret_cast<float4*>(out + base) = o;
+    } else {
+#pragma unroll
+      for (int p = 0; p < 4; ++p)
+        if (oxb + p < Wo) out[base + p] = skip ? skip[base + p] + v[p] : v[p];
+    }
+  }
+}
+
+template <int S>
+int launch_mfma(const float* x, const float* w, const float* b, const float* skip, float* out, int Cin, int Cout, int D,
+                int H, int W, int act, hipStream_t st) {
+  using Cfg = MCfg<S>;
+  const int Do = (D - 1) / S + 1, Ho = (H - 1) / S + 1, Wo = (W - 1) / S + 1;
+  const int tx = cds_ceil_div(Wo, Cfg::TX), ty = cds_ceil_div(Ho, Cfg::TY), tz = cds_ceil_div(Do, Cfg::TZ);
+  const int ntiles = tx * ty * tz;
+  const size_t lds_bytes = (size_t)Cfg::SLAB * Cfg::CI_CHUNK * sizeof(float);
+  static_assert(Cfg::SLAB * Cfg::CI_CHUNK * sizeof(float) <= 65536, "LDS tile above 64 KB");
+  hipLaunchKernelGGL(conv3d_k3_mfma_kernel<S>, dim3(ntiles * (Cout / 16)), dim3(256), lds_bytes, st, x, w, b, skip, out,
+                     Cin, Cout, D, H, W, Do, Ho, Wo, act, tx, ty, tz, ntiles);
+  return cds_launch_status();
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Transposed conv (k3, s2, p1, op1) on the matrix cores.  A workgroup owns 64x4x2 input cells and one (z,y) output
+// parity class; M = 16 x-consecutive cells, N = 16 couts, K = 4 input channels of one tap.  Both x parities are
+// accumulated in the same lane (acc0: x = 2a, acc1: x = 2a+1) so the epilogue stores 8 consecutive outputs.
+// ---------------------------------------------------------------------------------------------
+struct MDCfg {
+  static constexpr int CX = 64, CY = 4, CZ = 2;                // input cells per workgroup
+  static constexpr int XT = CX / 16, NT = XT * CZ;             // M-tiles per wave (wave = one y row of cells)
+  static constexpr int IY = CY + 1, IZ = CZ + 1;
+  static constexpr int IXP = (CX + 1 + 3) & ~3;                // 68
+  static constexpr int Q = IXP / 4;
+  static constexpr int NS = IZ * IY * Q;
+  static constexpr int SLAB = NS * 4 + 16;
+  static constexpr int CI_CHUNK = 4;
+  static constexpr int NSLOT = (CI_CHUNK * NS + 255) / 256;
+};
+
+__global__ __launch_bounds__(256) void deconv3d_k3s2_mfma_kernel(const float* __restrict__ x,
+                                                                 const float* __restrict__ wpk,
+                                                                 const float* __restrict__ bias,
+                                                                 const float* __restrict__ skip, float* __restrict__ out,
+                                                                 int Cin, int Cout, int D, int H, int W, int act,
+                                                                 int tiles_x, int tiles_y, int tiles_z, int ntiles) {
+  using Cfg = MDCfg;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int co_blocks = Cout / 16;
+  int lin = cds_xcd_remap(blockIdx.x, ntiles * co_blocks * 4);
+  const int cls = lin & 3;
+  lin >>= 2;
+  const int cob = lin % co_blocks;
+  int tile = lin / co_blocks;
+  const int tx_i = tile % tiles_x;
+  tile /= tiles_x;
+  const int ty_i = tile % tiles_y;
+  const int tz_i = tile / tiles_y;
+  const int co0 = cob * 16;
+  const int pz = cls >> 1, py = cls & 1;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ax0 = tx_i * Cfg::CX, ay0 = ty_i * Cfg::CY, az0 = tz_i * Cfg::CZ;
+  const size_t plane = (size_t)H * W, vol = (size_t)D * plane;
+
+  int goff[Cfg::NSLOT];
+  int loff[Cfg::NSLOT];
+#pragma unroll
+  for (int j = 0; j < Cfg::NSLOT; ++j) {
+    const int s = tid + 256 * j;
+    const int ci = s / Cfg::NS;
+    int r = s - ci * Cfg::NS;
+    const int row = r / Cfg::Q, c4 = r - row * Cfg::Q;
+    const int rz = row / Cfg::IY, ry = row - rz * Cfg::IY;
+    const int gz = az0 + rz, gy = ay0 + ry, gx = ax0 + 4 * c4;
+    const bool ok = (s < Cfg::CI_CHUNK * Cfg::NS) && gz < D && gy < H && gx + 3 < W;
+    goff[j] = ok ? (int)((size_t)ci * vol + (size_t)gz * plane + (size_t)gy * W + gx) : -1;
+    loff[j] = ci * Cfg::SLAB + 4 * r;
+  }
+  float4 pre[Cfg::NSLOT];
+  auto issue = [&](int ci0) {
+    const float* __restrict__ xb = x + (size_t)ci0 * vol;
+#pragma unroll
+    for (int j = 0; j < Cfg::NSLOT; ++j) pre[j] = *reinterpret_cast<const float4*>(goff[j] >= 0 ? xb + goff[j] : x);
+  };
+
+  f32x4 acc0[Cfg::NT], acc1[Cfg::NT];
+#pragma unroll
+  for (int t = 0; t < Cfg::NT; ++t) acc0[t] = acc1[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const float* a_base = lds + (lane >> 4) * Cfg::SLAB + wave * Cfg::IXP + (lane & 15);
+  const float* __restrict__ b_base = wpk + (size_t)(lane >> 4) * 27 * Cout + co0 + (lane & 15);
+
+  issue(0);
+  for (int ci0 = 0; ci0 < Cin; ci0 += Cfg::CI_CHUNK) {
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < Cfg::NSLOT; ++j) {
+      const int s = tid + 256 * j;
+      if (s < Cfg::CI_CHUNK * Cfg::NS)
+        *reinterpret_cast<float4*>(lds + loff[j]) = goff[j] >= 0 ? pre[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
+    if (ci0 + Cfg::CI_CHUNK < Cin) issue(ci0 + Cfg::CI_CHUNK);
+    const float* __restrict__ bw = b_base + (size_t)ci0 * 27 * Cout;
+    for (int sz = 0; sz <= pz; ++sz) {
+      const int iz = pz ? 1 - sz : 0, kz = pz ? 2 * sz : 1;
+      for (int sy = 0; sy <= py; ++sy) {
+        const int iy = py ? 1 - sy : 0, ky = py ? 2 * sy : 1;
+        const float* __restrict__ bt = bw + ((kz * 3 + ky) * 3) * Cout;
+        const float b0 = bt[0], b1 = bt[Cout], b2 = bt[2 * Cout];   // taps kx = 0, 1, 2
+        const float* arow = a_base + (iz * Cfg::IY + iy) * Cfg::IXP;
+#pragma unroll
+        for (int t = 0; t < Cfg::NT; ++t) {
+          const int tz = t / Cfg::XT, txr = t % Cfg::XT;
+          const float* ap = arow + (tz * Cfg::IY) * Cfg::IXP + txr * 16;
+          const float a0 = ap[0], a1 = ap[1];
+          acc0[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b1, acc0[t], 0, 0, 0);  // x = 2a   : (cell a,   tap 1)
+          acc1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b0, acc1[t], 0, 0, 0);  // x = 2a+1 : (cell a+1, tap 0)
+          acc1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b2, acc1[t], 0, 0, 0);  //            (cell a,   tap 2)
+        }
+      }
+    }
+  }
+
+  const int ay = ay0 + wave;
+  if (ay >= H) return;
+  const int co = co0 + (lane & 15);
+  const float b = bias ? bias[co] : 0.f;
+  const int Do = 2 * D, Ho = 2 * H, Wo = 2 * W;
+  const size_t oplane = (size_t)Ho * Wo, ovol = (size_t)Do * oplane;
+#pragma unroll
+  for (int t = 0; t < Cfg::NT; ++t) {
+    const int tz = t / Cfg::XT, txr = t % Cfg::XT;
+    const int az = az0 + tz, ax = ax0 + txr * 16 + (lane >> 4) * 4;   // first of this lane's 4 cells
+    if (az >= D || ax >= W) continue;                                  // W % 4 == 0: the 4 cells are all in or all out
+    const size_t base = (size_t)co * ovol + (size_t)(2 * az + pz) * oplane + (size_t)(2 * ay + py) * Wo + 2 * ax;
+    float v[8] = {acc0[t].x, acc1[t].x, acc0[t].y, acc1[t].y, acc0[t].z, acc1[t].z, acc0[t].w, acc1[t].w};
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      v[p] += b;
+      if (act == CDS_ACT_RELU) v[p] = fmaxf(v[p], 0.f);
+    }
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      float4 o = make_float4(v[4 * half], v[4 * half + 1], v[4 * half + 2], v[4 * half + 3]);
+      if (skip) {
+        const float4 s4 = *reinterpret_cast<const float4*>(skip + base + 4 * half);
+        o.x = s4.x + o.x; o.y = s4.y + o.y; o.z = s4.z + o.z; o.w = s4.w + o.w;
+      }
+      *reinterpret_cast<float4*>(out + base + 4 * half) = o;
+    }
+  }
+}
+
+}  // namespace
+
+// Returns false when the shape is not covered (caller falls back to the VALU kernels).
+bool cds_conv3d_mfma_launch(const float* x, const float* w, const float* b, const float* skip, float* out, int Cin,
+                            int Cout, int D, int H, int W, int stride, int act, hipStream_t st, int* rc) {
+  const int Wo = (W - 1) / stride + 1;
+  if ((Cout % 16) || (Cin % 4) || (W % 4) || Wo < 32 || (size_t)Cin * D * H * W >= (size_t)0x7fffffff) return false;
+  *rc = stride == 1 ? launch_mfma<1>(x, w, b, skip, out, Cin, Cout, D, H, W, act, st)
+                    : launch_mfma<2>(x, w, b, skip, out, Cin, Cout, D, H, W, act, st);
+  return true;
+}
+
+bool cds_deconv3d_mfma_launch(const float* x, const float* w, const float* b, const float* skip, float* out, int Cin,
+                              int Cout, int D, int H, int W, int act, hipStream_t st, int* rc) {
+  if ((Cout % 16) || (Cin % 4) || (W % 4) || W < 32 || (size_t)Cin * D * H * W >= (size_t)0x7fffffff) return false;
+  using Cfg = MDCfg;
+  const int tx = cds_ceil_div(W, Cfg::CX), ty = cds_ceil_div(H, Cfg::CY), tz = cds_ceil_div(D, Cfg::CZ);
+  const int ntiles = tx * ty * tz;
+  const size_t lds_bytes = (size_t)Cfg::SLAB * Cfg::CI_CHUNK * sizeof(float);
+  hipLaunchKernelGGL(deconv3d_k3s2_mfma_kernel, dim3(ntiles * (Cout / 16) * 4), dim3(256), lds_bytes, st, x, w, b, skip,
+                     out, Cin, Cout, D, H, W, act, tx, ty, tz, ntiles);
+  *rc = cds_launch_status();
+  return true;
+}
