@@ -103,6 +103,7 @@ def main():
     ap.add_argument("--workload", default="M1", choices=sorted(WORKLOADS))
     ap.add_argument("--parallelism", default="replicas", choices=["replicas", "viewshard"])
     ap.add_argument("--cpu-sample", type=float, default=0.25, help="linear window fraction for the CPU baseline (0 = skip)")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) in production; gloo only for single-GPU dry runs")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -112,13 +113,18 @@ def main():
         if args.gpus != 1 or world != 1:
             raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback)"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # CDS_BENCH_DEVICE pins every rank to one device (dry run of the N>1 control flow on a 1-GPU box, with gloo)
+    dev_index = int(os.environ.get("CDS_BENCH_DEVICE", local_rank))
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.dist_backend)
 
     from cds_mvsnet_amd import CDSMVSNet, ops, seeded_init_
     h, w, D, C, n_views = WORKLOADS[args.workload]
@@ -158,7 +164,7 @@ def main():
         dt = time.perf_counter() - t0
         ops.PROFILE_ON = False
     if dist is not None:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt], device=dev if args.dist_backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3
