@@ -19,9 +19,23 @@
 
 namespace {
 
+#ifndef CDS_K3_TW
+#define CDS_K3_TW 64
+#define CDS_K3_TH 4
+#define CDS_K3_BOX 504
+#define CDS_K3_DC 32
+#define CDS_K3_MINW 1
+#endif
 constexpr int C8 = 8;
-constexpr int BOX_CAP = 504;   // texels per view box (15.75 KB; 4 views + scratch stay below 64 KB)
-constexpr int DC = 32;         // depth planes per staged chunk
+constexpr int TW = CDS_K3_TW, TH = CDS_K3_TH;  // reference-pixel tile of a workgroup (TW*TH = 256)
+constexpr int BOX_CAP = CDS_K3_BOX;   // texels per view box (x 32 B; 4 views + scratch must fit the LDS budget)
+constexpr int DC = CDS_K3_DC;         // depth planes per staged chunk
+#ifndef CDS_K1_DC
+#define CDS_K1_DC 64
+#define CDS_K1_BOX 1016
+#endif
+constexpr int DC1 = CDS_K1_DC;        // K1 stages one view per workgroup: longer chunks, bigger box budget
+constexpr int BOX1 = CDS_K1_BOX;
 
 struct Box {
   int x0, y0, bw, bh;  // origin, width, height in texels (block-uniform)
@@ -59,7 +73,7 @@ __device__ __forceinline__ void cell_of(const float r[3], const float* __restric
 
 // Block-wide bounding boxes for NV views.  lo/hi: this thread's cells at the chunk's first and last plane.
 // red: LDS scratch int[4 waves][NV][4].
-template <int NV>
+template <int NV, int CAP>
 __device__ __forceinline__ void reduce_boxes(const int cx0[NV], const int cy0[NV], const int cx1[NV], const int cy1[NV],
                                              bool active, int nv, int h, int w, int* red, Box box[NV]) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -96,7 +110,7 @@ __device__ __forceinline__ void reduce_boxes(const int cx0[NV], const int cy0[NV
     // taps touch cells [xmin, xmax+1] x [ymin, ymax+1] (cells are clamped to [-2, n], so the box reaches at most
     // two texels outside the image; that border is staged as zeros = grid_sample's zero padding)
     const int bw = xmax + 2 - xmin, bh = ymax + 2 - ymin;
-    const bool ok = (v < nv) && xmax >= xmin && ymax >= ymin && bw * bh <= BOX_CAP;
+    const bool ok = (v < nv) && xmax >= xmin && ymax >= ymin && bw * bh <= CAP;
     // not staged: origin far away and limits 0, so no cell ever passes the containment test
     box[v].x0 = __builtin_amdgcn_readfirstlane(ok ? xmin : -0x40000000);
     box[v].y0 = __builtin_amdgcn_readfirstlane(ok ? ymin : -0x40000000);
@@ -107,6 +121,7 @@ __device__ __forceinline__ void reduce_boxes(const int cx0[NV], const int cy0[NV
 }
 
 // Cooperative copy of one box into its two LDS planes, zero outside the image.  Each wave takes rows wave, wave+4, ...
+template <int CAP>
 __device__ __forceinline__ void stage_box(const float* __restrict__ srcv, int h, int w, const Box& b,
                                           float4* __restrict__ dst) {
   if (!b.staged) return;
@@ -118,7 +133,7 @@ __device__ __forceinline__ void stage_box(const float* __restrict__ srcv, int h,
     const float4* __restrict__ g =
         reinterpret_cast<const float4*>(srcv + ((ptrdiff_t)(row_ok ? gy : 0) * w + b.x0) * C8);
     float4* lo = dst + row * b.bw;
-    float4* hi = dst + BOX_CAP + row * b.bw;
+    float4* hi = dst + CAP + row * b.bw;
     for (int i = lane; i < n4; i += 64) {
       const bool ok = row_ok && (unsigned)(b.x0 + (i >> 1)) < (unsigned)w;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -188,6 +203,7 @@ struct Tex8 {
 // zero padding anyway), lies inside the staged zero-bordered box -> four 32-byte texels from LDS, no per-tap
 // validity logic.  Slow path (box not staged, or a cell outside the first/last-plane bounding box): global gathers
 // with per-tap image tests.  Returns the weights to use (zeroed for out-of-image taps on the slow path).
+template <int CAP>
 __device__ __forceinline__ void fetch_cell(float x0f, float y0f, const Geo& g, const Box& b,
                                            const cds_f4* __restrict__ lds, const float* __restrict__ srcv, Tex8 t[4],
                                            float wgt[4]) {
@@ -213,10 +229,10 @@ __device__ __forceinline__ void fetch_cell(float x0f, float y0f, const Geo& g, c
     const unsigned i0 = __umul24(uy, (unsigned)b.bw) + ux;
     const cds_f4* r0 = lds + i0;
     const cds_f4* r1 = r0 + b.bw;
-    t[0].lo = r0[0]; t[0].hi = r0[BOX_CAP];
-    t[1].lo = r0[1]; t[1].hi = r0[BOX_CAP + 1];
-    t[2].lo = r1[0]; t[2].hi = r1[BOX_CAP];
-    t[3].lo = r1[1]; t[3].hi = r1[BOX_CAP + 1];
+    t[0].lo = r0[0]; t[0].hi = r0[CAP];
+    t[1].lo = r0[1]; t[1].hi = r0[CAP + 1];
+    t[2].lo = r1[0]; t[2].hi = r1[CAP];
+    t[3].lo = r1[1]; t[3].hi = r1[CAP + 1];
   }
 }
 
@@ -255,7 +271,7 @@ __device__ __forceinline__ void plane_weights(v2f ix, v2f iy, v2f& x0f, v2f& y0f
 // Addressing: per-channel slab base (uniform) + one 32-bit byte offset per plane (slab = D*h*w*4 < 4 GB).
 // ---------------------------------------------------------------------------------------------
 template <int VMAX>
-__global__ __launch_bounds__(256) void warp_aggregate_lds_kernel(
+__global__ __launch_bounds__(256, CDS_K3_MINW) void warp_aggregate_lds_kernel(
     const float* __restrict__ ref, const float* __restrict__ src, const float* __restrict__ vis, WarpMats mats,
     const float* __restrict__ hyp, float* __restrict__ volume, const float* __restrict__ vis_sum, int V, int D, int h,
     int w, float rhw, float rhh, int flags, int tiles_x, int ntiles, int nseg, int seg_planes) {
@@ -267,8 +283,8 @@ __global__ __launch_bounds__(256) void warp_aggregate_lds_kernel(
   const int seg = lin % nseg;
   const int tile = lin / nseg;
   const int tx = tile % tiles_x, ty = tile / tiles_x;
-  const int x = tx * CDS_TILE_X + (threadIdx.x & 63);
-  const int y = ty * CDS_TILE_Y + (threadIdx.x >> 6);
+  const int x = tx * TW + (threadIdx.x % TW);
+  const int y = ty * TH + (threadIdx.x / TW);
   const bool active = x < w && y < h;
   const int xc = min(x, w - 1), yc = min(y, h - 1);  // inactive lanes shadow a valid pixel, never store
   Geo g;
@@ -315,10 +331,10 @@ __global__ __launch_bounds__(256) void warp_aggregate_lds_kernel(
     }
     Box box[VMAX];
     __syncthreads();  // previous chunk's LDS reads are done (also protects `red`)
-    reduce_boxes<VMAX>(cx0, cy0, cx1, cy1, active, V, h, w, red, box);
+    reduce_boxes<VMAX, BOX_CAP>(cx0, cy0, cx1, cy1, active, V, h, w, red, box);
 #pragma unroll
     for (int v = 0; v < VMAX; ++v)
-      if (v < V) stage_box(src + (size_t)v * hw * C8, h, w, box[v], reinterpret_cast<float4*>(lds4 + v * 2 * BOX_CAP));
+      if (v < V) stage_box<BOX_CAP>(src + (size_t)v * hw * C8, h, w, box[v], reinterpret_cast<float4*>(lds4 + v * 2 * BOX_CAP));
     __syncthreads();
 
     unsigned boff = ((unsigned)d0 * hw + pix) * 4u;  // byte offset of (plane d, pixel) inside a channel slab / hyp
@@ -356,7 +372,7 @@ __global__ __launch_bounds__(256) void warp_aggregate_lds_kernel(
           for (int k = 0; k < 2; ++k) {
             float wgt[4] = {k ? wt[0].y : wt[0].x, k ? wt[1].y : wt[1].x, k ? wt[2].y : wt[2].x, k ? wt[3].y : wt[3].x};
             Tex8 t[4];
-            fetch_cell(k ? x0f.y : x0f.x, k ? y0f.y : y0f.x, g, box[v], lv, srcv, t, wgt);
+            fetch_cell<BOX_CAP>(k ? x0f.y : x0f.x, k ? y0f.y : y0f.x, g, box[v], lv, srcv, t, wgt);
             v2f o[4];
             interp8(t, wgt, o);
 #pragma unroll
@@ -417,13 +433,13 @@ __global__ __launch_bounds__(256) void warp_entropy_lds_kernel(const float* __re
                                                                float* __restrict__ entropy, int V, int D, int h, int w,
                                                                float rhw, float rhh, int tiles_x, int ntiles) {
   extern __shared__ __attribute__((aligned(16))) cds_f4 lds4[];
-  int* red = reinterpret_cast<int*>(lds4 + 2 * BOX_CAP);
+  int* red = reinterpret_cast<int*>(lds4 + 2 * BOX1);
   const int lin = cds_xcd_remap(blockIdx.x, ntiles * V);
   const int v = lin % V;
   const int tile = lin / V;
   const int tx = tile % tiles_x, ty = tile / tiles_x;
-  const int x = tx * CDS_TILE_X + (threadIdx.x & 63);
-  const int y = ty * CDS_TILE_Y + (threadIdx.x >> 6);
+  const int x = tx * TW + (threadIdx.x % TW);
+  const int y = ty * TH + (threadIdx.x / TW);
   const bool active = x < w && y < h;
   const int xc = min(x, w - 1), yc = min(y, h - 1);
   Geo g;
@@ -446,15 +462,15 @@ __global__ __launch_bounds__(256) void warp_entropy_lds_kernel(const float* __re
   cds_row_terms(m, (float)xc, (float)yc, r);
   const char* hyp_b = reinterpret_cast<const char*>(hyp);
   float mx = -INFINITY, Z = 0.f, T = 0.f;
-  for (int d0 = 0; d0 < D; d0 += DC) {
-    const int d1 = min(D, d0 + DC);
+  for (int d0 = 0; d0 < D; d0 += DC1) {
+    const int d1 = min(D, d0 + DC1);
     int cx0[1], cy0[1], cx1[1], cy1[1];
     cell_of(r, m + 9, hyp[(size_t)d0 * hw + pix], h, w, g.half_w, g.half_h, cx0[0], cy0[0]);
     cell_of(r, m + 9, hyp[(size_t)(d1 - 1) * hw + pix], h, w, g.half_w, g.half_h, cx1[0], cy1[0]);
     Box box[1];
     __syncthreads();
-    reduce_boxes<1>(cx0, cy0, cx1, cy1, active, 1, h, w, red, box);
-    stage_box(srcv, h, w, box[0], reinterpret_cast<float4*>(lds4));
+    reduce_boxes<1, BOX1>(cx0, cy0, cx1, cy1, active, 1, h, w, red, box);
+    stage_box<BOX1>(srcv, h, w, box[0], reinterpret_cast<float4*>(lds4));
     __syncthreads();
     unsigned boff = ((unsigned)d0 * hw + pix) * 4u;
     const unsigned bstep = hw * 4u;
@@ -476,7 +492,7 @@ __global__ __launch_bounds__(256) void warp_entropy_lds_kernel(const float* __re
       for (int k = 0; k < 2; ++k) {
         float wgt[4] = {k ? wt[0].y : wt[0].x, k ? wt[1].y : wt[1].x, k ? wt[2].y : wt[2].x, k ? wt[3].y : wt[3].x};
         Tex8 t[4];
-        fetch_cell(k ? x0f.y : x0f.x, k ? y0f.y : y0f.x, g, box[0], lds4, srcv, t, wgt);
+        fetch_cell<BOX1>(k ? x0f.y : x0f.x, k ? y0f.y : y0f.x, g, box[0], lds4, srcv, t, wgt);
         v2f o[4];
         interp8(t, wgt, o);
         // sum_C ref*warp, channel order 0..7 (ATen's sequential outer-dim sum for C <= 16)
@@ -503,7 +519,7 @@ bool cds_warp_aggregate_lds_launch(const float* ref, const float* src, const flo
                                    const float* hyp, float* volume, const float* vis_sum, int V, int C, int D, int h,
                                    int w, int hyp_pp, int flags, hipStream_t st) {
   if (C != 8 || V > 4 || !hyp_pp || w < 2 || h < 2 || (size_t)D * h * w * 4 >= ((size_t)1 << 32)) return false;
-  const int tiles_x = cds_ceil_div(w, CDS_TILE_X), tiles_y = cds_ceil_div(h, CDS_TILE_Y);
+  const int tiles_x = cds_ceil_div(w, TW), tiles_y = cds_ceil_div(h, TH);
   const int ntiles = tiles_x * tiles_y;
   const float rhw = (float)(1.0 / (double)(float)((w - 1) / 2.0)), rhh = (float)(1.0 / (double)(float)((h - 1) / 2.0));
   // Depth segments: enough workgroups for ~10 waves per SIMD (2 are resident), each a whole number of DC chunks.
@@ -527,11 +543,11 @@ bool cds_warp_aggregate_lds_launch(const float* ref, const float* src, const flo
 bool cds_warp_entropy_lds_launch(const float* ref, const float* src, const WarpMats& wm, const float* hyp,
                                  float* entropy, int V, int C, int D, int h, int w, int hyp_pp, hipStream_t st) {
   if (C != 8 || !hyp_pp || w < 2 || h < 2 || (size_t)D * h * w * 4 >= ((size_t)1 << 32)) return false;
-  const int tiles_x = cds_ceil_div(w, CDS_TILE_X), tiles_y = cds_ceil_div(h, CDS_TILE_Y);
+  const int tiles_x = cds_ceil_div(w, TW), tiles_y = cds_ceil_div(h, TH);
   const int ntiles = tiles_x * tiles_y;
   const float rhw = (float)(1.0 / (double)(float)((w - 1) / 2.0)), rhh = (float)(1.0 / (double)(float)((h - 1) / 2.0));
   hipLaunchKernelGGL(warp_entropy_lds_kernel, dim3(ntiles * V), dim3(256),
-                     (size_t)2 * BOX_CAP * sizeof(float4) + 4 * 4 * sizeof(int), st, ref, src, wm, hyp, entropy, V, D, h,
+                     (size_t)2 * BOX1 * sizeof(float4) + 4 * 4 * sizeof(int), st, ref, src, wm, hyp, entropy, V, D, h,
                      w, rhw, rhh, tiles_x, ntiles);
   return true;
 }
