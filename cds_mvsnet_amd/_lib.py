@@ -17,6 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libcdsmvs_hip.so")
 ACT_NONE, ACT_RELU, ACT_LEAKY01, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3, 4
 AGG_ACCUMULATE, AGG_NORMALIZE = 1, 2
 MAX_VIEWS = 8
+MAX_IMAGES = 16
 EINVAL = -1000
 
 P = c_void_p
@@ -37,8 +38,8 @@ SIGNATURES = {
     "cds_conv3d_k3_f32": [P, P, P, P, P, I, I, I, I, I, I, I, P],
     "cds_deconv3d_k3s2_f32": [P, P, P, P, P, I, I, I, I, I, I, P],
     "cds_conv2d_f32": [P, P, P, P, I, I, I, I, I, I, I, I, I, P],
-    "cds_dynconv_blend_f32": [P, P, P, P, F, F, F, P, P, I, I, I, I, P],
-    "cds_instnorm_act_f32": [P, P, P, I, I, I, I, I, P],
+    "cds_dynconv_blend_f32": [P, P, P, P, P, F, P, P, I, I, I, I, I, P],
+    "cds_instnorm_act_f32": [P, P, P, I, I, I, I, I, I, P],
 }
 
 _lib = None

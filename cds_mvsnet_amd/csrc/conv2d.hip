@@ -127,22 +127,32 @@ int launch_conv2d(const float* x, const float* w, const float* b, float* out, in
 // DynamicConv epilogue.  `branch` holds, for each kernel size k, the Cout conv responses followed
 // by the 3 curvature responses: [K][Cout+3][H][W].
 // ---------------------------------------------------------------------------------------------
+struct EpiBatch {
+  float x[CDS_MAX_IMAGES], y[CDS_MAX_IMAGES];
+};
+
+// branch: [K][N][Cout+3][H][W]; out: [N][Cout][H][W]; norm_curv: [N][H][W]; image n = blockIdx.y
 template <int K>
 __global__ __launch_bounds__(256) void dynconv_blend_kernel(const float* __restrict__ branch,
                                                             const float* __restrict__ w1, const float* __restrict__ b1,
-                                                            const float* __restrict__ w2, float epi_x, float epi_y,
-                                                            float temperature, float* __restrict__ out,
-                                                            float* __restrict__ norm_curv, int Cout, int H, int W) {
+                                                            const float* __restrict__ w2, EpiBatch epi, float temperature,
+                                                            float* __restrict__ out, float* __restrict__ norm_curv,
+                                                            int N, int Cout, int H, int W) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   const int hw = H * W;
   if (p >= hw) return;
+  const int n = blockIdx.y;
+  const float epi_x = epi.x[n], epi_y = epi.y[n];
+  branch += (size_t)n * (Cout + 3) * hw;
+  out += (size_t)n * Cout * hw;
+  norm_curv += (size_t)n * hw;
   const int y = p / W, x = p % W;
   float u = (float)x - epi_x, v = (float)y - epi_y;
   const float nrm = sqrtf(u * u + v * v);
   u = u / (nrm + 1e-6f);
   v = v / (nrm + 1e-6f);
   const float b0 = u * u, b1v = 2.0f * u * v, b2 = v * v;
-  const size_t bstride = (size_t)(Cout + 3) * hw;
+  const size_t bstride = (size_t)N * (Cout + 3) * hw;  // stride between kernel sizes
   float curv[K];
 #pragma unroll
   for (int k = 0; k < K; ++k) {
@@ -219,11 +229,16 @@ __global__ __launch_bounds__(256) void instnorm_stats_kernel(const float* __rest
   }
 }
 
+// x: [N][C][hw]; stats per (n,c); out: [N][C][hw] or channels-last [N][hw][C]; image n = blockIdx.y
 __global__ __launch_bounds__(256) void instnorm_apply_kernel(const float* __restrict__ x,
                                                              const double* __restrict__ stats, float* __restrict__ out,
                                                              int C, int hw, int act, int out_hwc) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= hw) return;
+  const int n = blockIdx.y;
+  x += (size_t)n * C * hw;
+  out += (size_t)n * C * hw;
+  stats += (size_t)n * 2 * C;
   for (int c = 0; c < C; ++c) {
     const double mean = stats[2 * c] / hw;
     double var = stats[2 * c + 1] / hw - mean * mean;
@@ -259,34 +274,41 @@ extern "C" int cds_conv2d_f32(const float* x, const float* weight, const float* 
 }
 
 extern "C" int cds_dynconv_blend_f32(const float* branches, const float* w1, const float* b1, const float* w2,
-                                     float epi_x, float epi_y, float temperature, float* out, float* norm_curv, int K,
-                                     int Cout, int H, int W, void* stream) {
-  if (!branches || !w1 || !b1 || !w2 || !out || !norm_curv || Cout < 1 || H < 1 || W < 1) return CDS_EINVAL;
+                                     const float* epipoles_host, float temperature, float* out, float* norm_curv, int N,
+                                     int K, int Cout, int H, int W, void* stream) {
+  if (!branches || !w1 || !b1 || !w2 || !epipoles_host || !out || !norm_curv || N < 1 || N > CDS_MAX_IMAGES ||
+      Cout < 1 || H < 1 || W < 1)
+    return CDS_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  dim3 grid(cds_ceil_div(H * W, 256)), block(256);
+  EpiBatch epi;
+  for (int n = 0; n < CDS_MAX_IMAGES; ++n) {
+    epi.x[n] = n < N ? epipoles_host[2 * n] : 0.f;
+    epi.y[n] = n < N ? epipoles_host[2 * n + 1] : 0.f;
+  }
+  dim3 grid(cds_ceil_div(H * W, 256), N), block(256);
   if (K == 2)
-    hipLaunchKernelGGL(dynconv_blend_kernel<2>, grid, block, 0, st, branches, w1, b1, w2, epi_x, epi_y, temperature, out,
-                       norm_curv, Cout, H, W);
+    hipLaunchKernelGGL(dynconv_blend_kernel<2>, grid, block, 0, st, branches, w1, b1, w2, epi, temperature, out,
+                       norm_curv, N, Cout, H, W);
   else if (K == 3)
-    hipLaunchKernelGGL(dynconv_blend_kernel<3>, grid, block, 0, st, branches, w1, b1, w2, epi_x, epi_y, temperature, out,
-                       norm_curv, Cout, H, W);
+    hipLaunchKernelGGL(dynconv_blend_kernel<3>, grid, block, 0, st, branches, w1, b1, w2, epi, temperature, out,
+                       norm_curv, N, Cout, H, W);
   else
     return CDS_EINVAL;
   return cds_launch_status();
 }
 
-extern "C" int cds_instnorm_act_f32(const float* x, float* out, float* stats, int C, int H, int W, int act, int out_hwc,
-                                    void* stream) {
-  if (!x || !out || !stats || C < 1 || H < 1 || W < 1) return CDS_EINVAL;
+extern "C" int cds_instnorm_act_f32(const float* x, float* out, float* stats, int N, int C, int H, int W, int act,
+                                    int out_hwc, void* stream) {
+  if (!x || !out || !stats || N < 1 || C < 1 || H < 1 || W < 1) return CDS_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const int hw = H * W;
-  double* dstats = reinterpret_cast<double*>(stats);  // scratch: 2*C doubles = 4*C floats
-  hipError_t e = hipMemsetAsync(dstats, 0, sizeof(double) * 2 * C, st);
+  double* dstats = reinterpret_cast<double*>(stats);  // scratch: 2*N*C doubles
+  hipError_t e = hipMemsetAsync(dstats, 0, sizeof(double) * 2 * N * C, st);
   if (e != hipSuccess) return -(int)e;
   int bpc = cds_ceil_div(hw, 256 * 16);
   if (bpc < 1) bpc = 1;
-  hipLaunchKernelGGL(instnorm_stats_kernel, dim3(C * bpc), dim3(256), 0, st, x, dstats, hw, bpc);
-  hipLaunchKernelGGL(instnorm_apply_kernel, dim3(cds_ceil_div(hw, 256)), dim3(256), 0, st, x, dstats, out, C, hw, act,
+  hipLaunchKernelGGL(instnorm_stats_kernel, dim3(N * C * bpc), dim3(256), 0, st, x, dstats, hw, bpc);
+  hipLaunchKernelGGL(instnorm_apply_kernel, dim3(cds_ceil_div(hw, 256), N), dim3(256), 0, st, x, dstats, out, C, hw, act,
                      out_hwc);
   return cds_launch_status();
 }

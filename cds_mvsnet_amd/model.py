@@ -267,13 +267,13 @@ class _FeatureRunner:
             out[f"{name}.w"] = _pack2d(getattr(net, name).conv.weight.detach())
         return out
 
-    def _dynamic(self, p, name: str, dc: DynamicConv, x: Tensor, epi: Tuple[float, float], T: float):
-        Cin, H, W = x.shape
+    def _dynamic(self, p, name: str, dc: DynamicConv, x: Tensor, epi: Tensor, T: float):
+        """x [N,Cin,H,W], epi CPU [N,2] (pixels at this resolution) -> (out [N,Cout,H,W], norm_curv [N,H,W])."""
+        N, Cin, H, W = x.shape
         nk = len(dc.size_kernels)
-        branches = torch.empty((nk, dc.out_c + 3, H, W), dtype=torch.float32, device=x.device)
-        x4 = x.unsqueeze(0)
+        branches = torch.empty((nk, N, dc.out_c + 3, H, W), dtype=torch.float32, device=x.device)
         for i, k in enumerate(dc.size_kernels):
-            ops.conv2d(x4, p[f"{name}.w{i}"], p.get(f"{name}.b{i}"), dc.out_c + 3, k, 1, (k - 1) // 2, ACT_NONE,
+            ops.conv2d(x, p[f"{name}.w{i}"], p.get(f"{name}.b{i}"), dc.out_c + 3, k, 1, (k - 1) // 2, ACT_NONE,
                        out=branches[i])
         return ops.dynconv_blend(branches, p[f"{name}.m1"], p[f"{name}.mb"], p[f"{name}.m2"], epi, T)
 
@@ -284,19 +284,34 @@ class _FeatureRunner:
     def _plain_unit(self, p, name, x):
         unit: ConvUnit = getattr(self.net, name)
         k = unit.conv.kernel_size[0]
-        y = ops.conv2d(x.unsqueeze(0), p[f"{name}.w"], None, unit.conv.out_channels, k, unit.stride, unit.padding)[0]
+        y = ops.conv2d(x, p[f"{name}.w"], None, unit.conv.out_channels, k, unit.stride, unit.padding)
         return ops.instnorm_act(y, ACT_LEAKY01)
 
-    def __call__(self, img: Tensor, epi: Tuple[float, float], T: float, hwc: bool):
-        """img [3,H,W] -> {'stageK': (feat [C,h,w] or [h,w,C] if hwc, nc_sum [h,w], |nc| [h,w])}."""
+    @staticmethod
+    def _final(o: Tensor, n_chw: int) -> Tuple[Tensor, Optional[Tensor]]:
+        """InstanceNorm + tanh of the stage output; the first n_chw images stay [C,h,w] (reference features), the
+        rest are emitted channels-last [h,w,C] (source features, gathered by K1/K3)."""
+        N = o.shape[0]
+        chw = ops.instnorm_act(o[:n_chw].contiguous(), ACT_TANH) if n_chw > 0 else None
+        hwc = ops.instnorm_act(o[n_chw:].contiguous(), ACT_TANH, out_hwc=True) if n_chw < N else None
+        return chw, hwc
+
+    def __call__(self, imgs: Tensor, epipoles: Tensor, T: float, n_chw: Optional[int] = None):
+        """imgs [N,3,H,W], epipoles CPU [N,2] (one epipole per image, full-resolution pixels).
+        Returns {'stageK': (fea_chw [n_chw,C,h,w] | None, fea_hwc [N-n_chw,h,w,C] | None, nc_sum [N,h,w], |nc| [N,h,w])}."""
         net = self.net
         if net.training:
             raise NotImplementedError("FeatureNet: training mode is not built yet (SURVEY §8(f)-2)")
+        N = imgs.shape[0]
+        if n_chw is None:
+            n_chw = N
+        if N > ops.MAX_IMAGES:
+            raise ValueError(f"at most {ops.MAX_IMAGES} images per FeatureNet batch")
         p = self.packed.get(self._pack)
-        e0 = epi
-        e1 = (epi[0] / 2, epi[1] / 2)
-        e2 = (epi[0] / 4, epi[1] / 4)
-        c00, n00 = self._dyn_unit(p, "conv00", img, e0, T)
+        e0 = epipoles.float().contiguous()
+        e1 = (e0 / 2).contiguous()
+        e2 = (e0 / 4).contiguous()
+        c00, n00 = self._dyn_unit(p, "conv00", imgs, e0, T)
         c01, n01 = self._dyn_unit(p, "conv01", c00, e0, T)
         d0 = self._plain_unit(p, "downsample1", c01)
         c10, n10 = self._dyn_unit(p, "conv10", d0, e1, T)
@@ -307,25 +322,26 @@ class _FeatureRunner:
 
         out = {}
         o1, n22 = self._dynamic(p, "out1", net.out1, c21, e2, T)
-        out["stage1"] = (ops.instnorm_act(o1, ACT_TANH, out_hwc=hwc), (n20 ** 2 + n21 ** 2 + n22 ** 2) / 3, n22.abs())
+        out["stage1"] = self._final(o1, n_chw) + ((n20 ** 2 + n21 ** 2 + n22 ** 2) / 3, n22.abs())
 
-        x = torch.cat((_nearest2x(c21), c11), dim=0)
+        x = torch.cat((_nearest2x(c21), c11), dim=1)
         x = self._plain_unit(p, "inner1", x)
         o2, n12 = self._dynamic(p, "out2", net.out2, x, e1, T)
         o2n = ops.instnorm_act(o2, ACT_TANH)
-        out["stage2"] = (ops.chw_to_hwc(o2n) if hwc else o2n, (n10 ** 2 + n11 ** 2 + n12 ** 2) / 3, n12.abs())
+        hwc2 = torch.stack([ops.chw_to_hwc(o2n[i]) for i in range(n_chw, N)]) if n_chw < N else None
+        out["stage2"] = (o2n[:n_chw] if n_chw > 0 else None, hwc2, (n10 ** 2 + n11 ** 2 + n12 ** 2) / 3, n12.abs())
 
-        x = torch.cat((_nearest2x(o2n), c01), dim=0)
+        x = torch.cat((_nearest2x(o2n), c01), dim=1)
         x = self._plain_unit(p, "inner2", x)
         o3, n02 = self._dynamic(p, "out3", net.out3, x, e0, T)
-        out["stage3"] = (ops.instnorm_act(o3, ACT_TANH, out_hwc=hwc), (n00 ** 2 + n01 ** 2 + n02 ** 2) / 3, n02.abs())
+        out["stage3"] = self._final(o3, n_chw) + ((n00 ** 2 + n01 ** 2 + n02 ** 2) / 3, n02.abs())
         return out
 
 
 def _nearest2x(x: Tensor) -> Tensor:
-    """[C,h,w] -> [C,2h,2w] nearest-neighbour (pure data movement; module.py:253,260)."""
-    C, h, w = x.shape
-    return x.view(C, h, 1, w, 1).expand(C, h, 2, w, 2).reshape(C, 2 * h, 2 * w)
+    """[N,C,h,w] -> [N,C,2h,2w] nearest-neighbour (pure data movement; module.py:253,260)."""
+    N, C, h, w = x.shape
+    return x.view(N, C, h, 1, w, 1).expand(N, C, h, 2, w, 2).reshape(N, C, 2 * h, 2 * w)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -440,12 +456,18 @@ class CDSMVSNet(nn.Module):
         self._view_shard = None
 
     # -- helpers -----------------------------------------------------------------------------
-    def extract_pair_features(self, ref_img: Tensor, src_img: Tensor, cam_ref: Tensor, cam_src: Tensor, T: float):
-        """FeatureNet for one (reference, source) pair; reference features are pair specific because
-        DynamicConv is conditioned on the epipole (model.py:154-161)."""
-        e_ref, e_src = geometry.pair_epipoles(cam_ref, cam_src)
-        run = self._feature_runner[0]
-        return run(ref_img, e_ref, T, hwc=False), run(src_img, e_src, T, hwc=True)
+    def extract_features(self, ref_img: Tensor, src_imgs: List[Tensor], cam_ref: Tensor, cam_srcs: List[Tensor], T: float):
+        """FeatureNet for every (reference, source) pair in ONE batched pass: V copies of the reference image (each
+        conditioned on its pair's epipole — DynamicConv makes reference features pair specific, model.py:154-161)
+        followed by the V source images.  Returns the runner's dict; rows [0,V) are the reference features (CHW), the
+        source features come back channels-last."""
+        V = len(src_imgs)
+        epi = []
+        for cam_src in cam_srcs:
+            epi.append(geometry.pair_epipoles(cam_ref, cam_src))
+        epipoles = torch.tensor([e[0] for e in epi] + [e[1] for e in epi], dtype=torch.float32)
+        batch = torch.stack([ref_img] * V + list(src_imgs))
+        return self._feature_runner[0](batch, epipoles, T, n_chw=V)
 
     def forward(self, imgs, proj_matrices, depth_values, gt_depths=None, temperature=0.001):
         if self.training or gt_depths is not None:
@@ -470,10 +492,11 @@ class CDSMVSNet(nn.Module):
             # ---- features, one FeatureNet pass per image of every (ref, src) pair ----
             ref_img = _resize_nearest(imgs[b, 0], H, W)
             views = self._my_views(N - 1)
-            pairs = []
-            for v in views:
-                src_img = _resize_nearest(imgs[b, v + 1], H, W)
-                pairs.append(self.extract_pair_features(ref_img, src_img, cams["stage3"][b, 0], cams["stage3"][b, v + 1], T))
+            V = len(views)
+            feats = None
+            if V:
+                feats = self.extract_features(ref_img, [_resize_nearest(imgs[b, v + 1], H, W) for v in views],
+                                              cams["stage3"][b, 0], [cams["stage3"][b, v + 1] for v in views], T)
             out_b: Dict[str, object] = {}
             depth = None
             for s in range(self.num_stage):
@@ -486,11 +509,10 @@ class CDSMVSNet(nn.Module):
                 else:
                     interval = float(self.depth_interals_ratio[s] * dint)
                     hyp = ops.depth_hypotheses(depth, D, H, W, scale, interval, float(dmin), float(dmax))
-                if pairs:
-                    ref = torch.stack([p[0][name][0] for p in pairs])
-                    src = torch.stack([p[1][name][0] for p in pairs])
-                    ref_nc = torch.stack([p[0][name][2] for p in pairs])
-                    nc_sums = torch.stack([(p[0][name][1] + p[1][name][1]) / 2 for p in pairs])
+                if V:
+                    ref, src, nc_sum, nc_abs = feats[name]
+                    ref_nc = nc_abs[:V].contiguous()
+                    nc_sums = (nc_sum[:V] + nc_sum[V:]) / 2
                     mats = geometry.warp_matrices(cams[name][b])[views].contiguous()
                 else:  # a view-shard rank without a source view of its own (more GPUs than views)
                     ref = src = ref_nc = nc_sums = mats = None

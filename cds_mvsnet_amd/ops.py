@@ -12,7 +12,7 @@ import torch
 
 from . import _lib
 from ._lib import (ACT_LEAKY01, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, AGG_ACCUMULATE, AGG_NORMALIZE,
-                   MAX_VIEWS, check)
+                   MAX_IMAGES, MAX_VIEWS, check)
 
 Tensor = torch.Tensor
 
@@ -240,25 +240,26 @@ def conv2d(x: Tensor, wpk: Tensor, bias: Optional[Tensor], cout: int, k: int, st
     return out
 
 
-def dynconv_blend(branches: Tensor, w1: Tensor, b1: Tensor, w2: Tensor, epipole_xy: Tuple[float, float],
+def dynconv_blend(branches: Tensor, w1: Tensor, b1: Tensor, w2: Tensor, epipoles: Tensor,
                   temperature: float) -> Tuple[Tensor, Tensor]:
-    """K7 epilogue.  branches [K,Cout+3,H,W] -> (out [Cout,H,W], norm_curv [H,W])."""
-    K, C3, H, W = branches.shape
+    """K7 epilogue.  branches [K,N,Cout+3,H,W], epipoles CPU [N,2] -> (out [N,Cout,H,W], norm_curv [N,H,W])."""
+    K, N, C3, H, W = branches.shape
     cout = C3 - 3
-    out = torch.empty((cout, H, W), dtype=torch.float32, device=branches.device)
-    nc = torch.empty((H, W), dtype=torch.float32, device=branches.device)
+    if tuple(epipoles.shape) != (N, 2):
+        raise ValueError("dynconv_blend: epipoles must be [N,2]")
+    out = torch.empty((N, cout, H, W), dtype=torch.float32, device=branches.device)
+    nc = torch.empty((N, H, W), dtype=torch.float32, device=branches.device)
     check(_lib.load().cds_dynconv_blend_f32(_dev(branches, "branches"), _dev(w1, "w1"), _dev(b1, "b1"), _dev(w2, "w2"),
-                                            float(epipole_xy[0]), float(epipole_xy[1]), float(temperature),
-                                            out.data_ptr(), nc.data_ptr(), K, cout, H, W, _stream(out)),
-          "cds_dynconv_blend_f32")
+                                            _host(epipoles, "epipoles"), float(temperature), out.data_ptr(),
+                                            nc.data_ptr(), N, K, cout, H, W, _stream(out)), "cds_dynconv_blend_f32")
     return out, nc
 
 
 def instnorm_act(x: Tensor, act: int, out_hwc: bool = False) -> Tensor:
-    """K8.  x [C,H,W] -> InstanceNorm + activation; [H,W,C] if out_hwc."""
-    C, H, W = x.shape
-    out = torch.empty((H, W, C) if out_hwc else (C, H, W), dtype=torch.float32, device=x.device)
-    stats = torch.empty((2 * C,), dtype=torch.float64, device=x.device)
-    check(_lib.load().cds_instnorm_act_f32(_dev(x, "x"), out.data_ptr(), stats.data_ptr(), C, H, W, act,
+    """K8.  x [N,C,H,W] -> InstanceNorm + activation; [N,H,W,C] if out_hwc."""
+    N, C, H, W = x.shape
+    out = torch.empty((N, H, W, C) if out_hwc else (N, C, H, W), dtype=torch.float32, device=x.device)
+    stats = torch.empty((2 * N * C,), dtype=torch.float64, device=x.device)
+    check(_lib.load().cds_instnorm_act_f32(_dev(x, "x"), out.data_ptr(), stats.data_ptr(), N, C, H, W, act,
                                            1 if out_hwc else 0, _stream(x)), "cds_instnorm_act_f32")
     return out

@@ -27,6 +27,7 @@ extern "C" {
 
 #define CDS_EINVAL (-1000)
 #define CDS_MAX_VIEWS 8 /* source views per launch; more are handled by chunked calls */
+#define CDS_MAX_IMAGES 16 /* images per batched FeatureNet launch */
 
 /* activation codes for the conv entry points */
 #define CDS_ACT_NONE 0
@@ -141,23 +142,26 @@ int cds_conv2d_f32(const float* x, const float* weight, const float* bias, float
                    int Cout, int H, int W, int k, int stride, int pad, int act, void* stream);
 
 /*
- * K7 epilogue of DynamicConv (dynamic_conv.py:97-122): epipolar projection of the K 3-channel
- * curvature responses, 1x1 MLP (K->4, folded BN, ReLU, 4->K), softmax(./temperature), blend.
- *   branches [K][Cout+3][H][W]  per kernel size: the Cout responses of convs[k] followed by the
- *                               3 responses of att_convs[k] (one fused cds_conv2d_f32 per size)
- *   w1 [4][K], b1 [4] (BN folded), w2 [K][4]          (device pointers); K in {2,3}
- *   out [Cout][H][W]; norm_curv [H][W]
+ * K7 epilogue of DynamicConv (dynamic_conv.py:97-122) for a batch of N images (each with its own epipole):
+ * epipolar projection of the K 3-channel curvature responses, 1x1 MLP (K->4, folded BN, ReLU, 4->K),
+ * softmax(./temperature), blend.
+ *   branches [K][N][Cout+3][H][W]  per kernel size: the Cout responses of convs[k] followed by the 3 responses of
+ *                                  att_convs[k] (one batched cds_conv2d_f32 per size)
+ *   w1 [4][K], b1 [4] (BN folded), w2 [K][4]   (device pointers); K in {2,3}
+ *   epipoles_host [N][2]           (x, y) in pixels of this resolution; N <= CDS_MAX_IMAGES
+ *   out [N][Cout][H][W]; norm_curv [N][H][W]
  */
 int cds_dynconv_blend_f32(const float* branches, const float* w1, const float* b1, const float* w2,
-                          float epi_x, float epi_y, float temperature, float* out, float* norm_curv,
-                          int K, int Cout, int H, int W, void* stream);
+                          const float* epipoles_host, float temperature, float* out, float* norm_curv,
+                          int N, int K, int Cout, int H, int W, void* stream);
 
 /*
- * K8 (module.py:53,66-69,223,230,232): InstanceNorm2d (no affine, eps 1e-5, biased variance)
- * followed by LeakyReLU(0.1) or tanh.  x [C][H][W]; `stats` is a caller-provided, 8-byte aligned
- * scratch of 4*C floats (per-channel fp64 sum and sum of squares).  If out_hwc is non-zero the result is written channels-last [H][W][C].
+ * K8 (module.py:53,66-69,223,230,232): InstanceNorm2d (no affine, eps 1e-5, biased variance) followed by
+ * LeakyReLU(0.1) or tanh, for N images.  x [N][C][H][W]; `stats` is a caller-provided, 8-byte aligned scratch of
+ * 4*N*C floats (per-(image,channel) fp64 sum and sum of squares).  If out_hwc is non-zero the result is written
+ * channels-last [N][H][W][C].
  */
-int cds_instnorm_act_f32(const float* x, float* out, float* stats, int C, int H, int W, int act,
+int cds_instnorm_act_f32(const float* x, float* out, float* stats, int N, int C, int H, int W, int act,
                          int out_hwc, void* stream);
 
 #ifdef __cplusplus

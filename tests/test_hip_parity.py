@@ -223,11 +223,14 @@ def test_dynconv_and_epipoles(dev, ops, seeded_state):
     packed["dc.m1"] = (dc.att_weights[0].weight.detach().reshape(4, 3) * scale.view(4, 1)).contiguous()
     packed["dc.mb"] = shift.contiguous()
     packed["dc.m2"] = dc.att_weights[3].weight.detach().reshape(3, 4).contiguous()
-    epi = (float(g["epipole_ref"][0, 0]), float(g["epipole_ref"][0, 1]))
+    # batch of two images with different epipoles: row 0 must match the golden, row 1 must differ from it
+    epi = torch.cat((g["epipole_ref"], g["epipole_src"])).contiguous()
+    x2 = torch.stack((g["img"], g["img"])).to(dev).contiguous()
     for T in (1.0, 0.1, 0.01):
-        y, nc = runner._dynamic(packed, "dc", dc, g["img"].to(dev).contiguous(), epi, T)
-        assert (y.cpu() - g[f"y_T{T}"]).abs().max() < 5e-5, T
-        assert (nc.cpu() - g[f"nc_T{T}"]).abs().max() < 5e-5, T
+        y, nc = runner._dynamic(packed, "dc", dc, x2, epi, T)
+        assert (y[0].cpu() - g[f"y_T{T}"]).abs().max() < 5e-5, T
+        assert (nc[0].cpu() - g[f"nc_T{T}"]).abs().max() < 5e-5, T
+        assert (nc[1] - nc[0]).abs().max() > 1e-4
 
 
 def test_featurenet(dev, seeded_state):
@@ -238,10 +241,13 @@ def test_featurenet(dev, seeded_state):
     seeded_init_(net, 7)
     net = net.to(dev).eval()
     run = _FeatureRunner(net)
-    epi = (float(g["epipole"][0, 0]), float(g["epipole"][0, 1]))
+    epi = g["epipole"].contiguous()
+    img = g["img"].to(dev).unsqueeze(0).contiguous()
     for T in (1.0, 0.01):
-        out = run(g["img"].to(dev).contiguous(), epi, T, hwc=False)
-        out_hwc = run(g["img"].to(dev).contiguous(), epi, T, hwc=True)
+        o = run(img, epi, T)                                   # one image, CHW
+        o2 = run(torch.cat((img, img)), torch.cat((epi, epi)), T, n_chw=1)   # same image twice: CHW + HWC
+        out = {s: (o[s][0][0], o[s][2][0], o[s][3][0]) for s in o}
+        out_hwc = {s: (o2[s][1][0],) for s in o2}
         # 9 InstanceNorm'd layers deep; at T=0.01 the softmax(./T) blend amplifies fp32 round-off of the
         # curvature responses by up to 0.25/T per layer (per-layer errors measured with scripts/diag_featurenet.py:
         # <=3e-5 at T=1, <=3e-4 at T=0.01, InstanceNorm itself 5e-7) -> bound the mean tightly, the max loosely.
