@@ -306,7 +306,7 @@ __global__ __launch_bounds__(256) void deconv3d_k3s2_mfma_kernel(const float* __
 bool cds_conv3d_mfma_launch(const float* x, const float* w, const float* b, const float* skip, float* out, int Cin,
                             int Cout, int D, int H, int W, int stride, int act, hipStream_t st, int* rc) {
   const int Wo = (W - 1) / stride + 1;
-  if ((Cout % 16) || (Cin % 4) || (W % 4) || Wo < 32 || (size_t)Cin * D * H * W >= (size_t)0x7fffffff) return false;
+  if ((Cout % 16) || (Cin % 4) || (W % 4) || Wo < 8 || (size_t)Cin * D * H * W >= (size_t)0x7fffffff) return false;
   *rc = stride == 1 ? launch_mfma<1>(x, w, b, skip, out, Cin, Cout, D, H, W, act, st)
                     : launch_mfma<2>(x, w, b, skip, out, Cin, Cout, D, H, W, act, st);
   return true;
@@ -314,7 +314,7 @@ bool cds_conv3d_mfma_launch(const float* x, const float* w, const float* b, cons
 
 bool cds_deconv3d_mfma_launch(const float* x, const float* w, const float* b, const float* skip, float* out, int Cin,
                               int Cout, int D, int H, int W, int act, hipStream_t st, int* rc) {
-  if ((Cout % 16) || (Cin % 4) || (W % 4) || W < 32 || (size_t)Cin * D * H * W >= (size_t)0x7fffffff) return false;
+  if ((Cout % 16) || (Cin % 4) || (W % 4) || W < 8 || (size_t)Cin * D * H * W >= (size_t)0x7fffffff) return false;
   using Cfg = MDCfg;
   const int tx = cds_ceil_div(W, Cfg::CX), ty = cds_ceil_div(H, Cfg::CY), tz = cds_ceil_div(D, Cfg::CZ);
   const int ntiles = tx * ty * tz;
