@@ -319,3 +319,114 @@ def test_oracle_parity_midsize(dev, ops, seeded_state):
 def test_cpu_tensors_fail_loudly(ops):
     with pytest.raises(RuntimeError):
         ops.chw_to_hwc(torch.zeros(8, 4, 4))
+
+
+# ------------------------------------------------------------------------------------------------
+# edge cases and size-independent properties (shapes the goldens do not cover, up to BASELINE's full M1 size)
+# ------------------------------------------------------------------------------------------------
+def _random_stage(ops, dev, V, C, D, h, w, seed, sharp=True):
+    from cds_mvsnet_amd import geometry, synth
+    feats = synth.make_pair_features(V, C, h, w, seed=seed, sharp=sharp)
+    cams = synth.stage_cameras(V + 1, h, w, seed=seed + 1)
+    hyp = synth.make_hypotheses(D, h, w, seed=seed + 2)
+    ref = torch.stack([f["ref"][0][0] for f in feats]).to(dev).contiguous()
+    src = torch.stack([ops.chw_to_hwc(f["src"][0][0].to(dev).contiguous()) for f in feats])
+    return feats, cams, hyp, ref, src, geometry.warp_matrices(cams[0]), hyp[0].to(dev).contiguous()
+
+
+@pytest.mark.parametrize("V,C,D,h,w", [(1, 8, 7, 9, 70), (4, 8, 33, 12, 130), (6, 8, 5, 16, 24), (3, 16, 9, 10, 50),
+                                       (2, 32, 4, 8, 66), (4, 8, 2, 5, 3)])
+def test_warp_kernels_vs_oracle_odd_shapes(V, C, D, h, w, dev, ops):
+    """Odd D / widths that are not tile multiples / V = 1, 6 (direct path) / C = 16, 32 / tiny images: K1 and K3 against
+    the CPU oracle (explicit fp32 gather)."""
+    from oracle import cds_oracle as O
+    feats, cams, hyp, ref, src, mats, hyp_d = _random_stage(ops, dev, V, C, D, h, w, seed=40 + V + C)
+    vis = torch.rand(V, h, w, generator=torch.Generator().manual_seed(1)) * 0.8 + 0.1
+    ent = ops.warp_entropy(ref, src, mats, hyp_d).cpu()
+    vol, vis_sum = ops.warp_aggregate(ref, src, vis.to(dev).contiguous(), mats, hyp_d)
+    P_ref = O.compose_projection(cams[:, 0])
+    want_vol, want_ent = 0.0, []
+    for v in range(V):
+        warped = O.warp_volume(feats[v]["src"][0], O.compose_projection(cams[:, v + 1]), P_ref, hyp)
+        in_prod, e = O.correlation_entropy(feats[v]["ref"][0], warped)
+        want_vol = want_vol + in_prod * vis[v].view(1, 1, 1, h, w)
+        want_ent.append(e[0, 0])
+    want_vol = want_vol[0] / (vis.sum(0).view(1, 1, h, w) + 1e-6)
+    assert (vol.cpu() - want_vol).abs().max() < 1e-5
+    assert (ent - torch.stack(want_ent)).abs().max() < 5e-5
+    assert (vis_sum.cpu() - vis.sum(0)).abs().max() < 1e-6
+
+
+def test_warp_paths_agree_lds_vs_direct(dev, ops):
+    """The LDS-staged kernels and the direct (L1 gather) kernels are two implementations of the same arithmetic:
+    identical positions / interpolation, accumulation differs by one rounding per view."""
+    import os, subprocess, sys
+    code = ("import torch,sys; sys.path.insert(0,'.'); from cds_mvsnet_amd import ops, synth, geometry;"
+            "dev=torch.device('cuda:0'); V,C,D,h,w=4,8,40,64,200;"
+            "f=synth.make_pair_features(V,C,h,w,seed=9,sharp=True); cams=synth.stage_cameras(V+1,h,w,seed=8);"
+            "hyp=synth.make_hypotheses(D,h,w,seed=7)[0].to(dev);"
+            "ref=torch.stack([x['ref'][0][0] for x in f]).to(dev).contiguous();"
+            "src=torch.stack([ops.chw_to_hwc(x['src'][0][0].to(dev).contiguous()) for x in f]);"
+            "vis=torch.rand(V,h,w,generator=torch.Generator().manual_seed(3)).to(dev);"
+            "m=geometry.warp_matrices(cams[0]); e=ops.warp_entropy(ref,src,m,hyp); v,_=ops.warp_aggregate(ref,src,vis,m,hyp);"
+            "torch.save((e.cpu(),v.cpu()), sys.argv[1])")
+    outs = []
+    for flag in ("0", "1"):
+        path = f"/tmp/cds_paths_{flag}.pt"
+        env = dict(os.environ, CDS_WARP_DIRECT=flag)
+        subprocess.run([sys.executable, "-c", code, path], check=True, env=env, cwd=os.path.dirname(os.path.dirname(__file__)))
+        outs.append(torch.load(path))
+    assert (outs[0][0] - outs[1][0]).abs().max() < 2e-5
+    assert (outs[0][1] - outs[1][1]).abs().max() < 2e-6
+
+
+def test_per_plane_hypotheses_equal_broadcast(dev, ops):
+    feats, cams, hyp, ref, src, mats, _ = _random_stage(ops, dev, 2, 8, 6, 16, 40, seed=77)
+    planes = torch.linspace(430, 890, 6, device=dev)
+    full = planes.view(-1, 1, 1).expand(-1, 16, 40).contiguous()
+    vis = torch.rand(2, 16, 40, device=dev)
+    assert (ops.warp_entropy(ref, src, mats, planes) - ops.warp_entropy(ref, src, mats, full)).abs().max() < 2e-5
+    assert (ops.warp_aggregate(ref, src, vis, mats, planes)[0] - ops.warp_aggregate(ref, src, vis, mats, full)[0]).abs().max() < 2e-6
+
+
+def test_full_size_M1_properties(dev, ops):
+    """BASELINE's full single-stage size (640x512, D=192, C=8, N=5; 2 GB volume) through size-independent properties:
+    (1) the visibility-weighted mean is invariant to a common scale of the weights; (2) the partial sums of two view
+    shards add up to the unsharded volume; (3) |volume| <= max|ref|*max|src| (convex combination of products);
+    (4) entropy in [0, log D]; (5) depth inside the hypothesis range and confidence in [0, 1] after CostRegNet."""
+    import math
+    from cds_mvsnet_amd import CDSMVSNet, seeded_init_
+    V, C, D, h, w = 4, 8, 192, 512, 640
+    feats, cams, hyp, ref, src, mats, hyp_d = _random_stage(ops, dev, V, C, D, h, w, seed=5, sharp=False)
+    vis = (torch.rand(V, h, w, generator=torch.Generator().manual_seed(2)) * 0.9 + 0.05).to(dev)
+    ent = ops.warp_entropy(ref, src, mats, hyp_d)
+    assert ent.min() >= -1e-5 and ent.max() <= math.log(D) + 1e-4
+    vol, _ = ops.warp_aggregate(ref, src, vis, mats, hyp_d)
+    bound = ref.abs().max() * src.abs().max()
+    assert vol.abs().max() <= bound * (1 + 1e-5)
+    vol2, _ = ops.warp_aggregate(ref, src, (vis * 0.5).contiguous(), mats, hyp_d)      # (1) exact: scaling by 0.5
+    assert (vol - vol2).abs().max() < 2e-6
+    del vol2
+    pa, sa = ops.warp_aggregate(ref[:2], src[:2], vis[:2].contiguous(), mats[:2].contiguous(), hyp_d, normalize=False)
+    pb, sb = ops.warp_aggregate(ref[2:], src[2:], vis[2:].contiguous(), mats[2:].contiguous(), hyp_d, normalize=False)
+    pa += pb
+    del pb
+    ops.volume_normalize_(pa, sa + sb)                                               # (2)
+    assert (pa - vol).abs().max() < 1e-6
+    del pa
+    model = seeded_init_(CDSMVSNet(), 0).eval().to(dev)
+    prob_pre = model.cost_regularization[2](vol)
+    depth, conf = ops.softargmin_conf(prob_pre, hyp_d)
+    assert torch.isfinite(depth).all() and depth.min() >= hyp_d.min() - 1e-3 and depth.max() <= hyp_d.max() + 1e-3
+    assert conf.min() >= 0 and conf.max() <= 1 + 1e-5
+    # CostRegNet is translation covariant along x away from the borders: shift the volume by 8 voxels
+    shifted = model.cost_regularization[2](torch.roll(vol, 8, dims=3))
+    assert (shifted[:, :, 40:-40] - torch.roll(prob_pre, 8, dims=2)[:, :, 40:-40]).abs().max() < 1e-4
+
+
+def test_model_input_validation(dev):
+    from cds_mvsnet_amd import CDSMVSNet, synth
+    m = CDSMVSNet().eval().to(dev)
+    with pytest.raises(ValueError):
+        m(synth.make_images(3, 72, 96).to(dev), {k: v.to(dev) for k, v in synth.make_cameras(3, 72, 96).items()},
+          synth.make_depth_values().to(dev))   # 72 is not a multiple of 32
