@@ -8,6 +8,8 @@
 //   B: lane l -> weight [ci0 + (l >> 4)][tap][co0 + (l & 15)]: one cached global load per (tap, chunk), reused by
 //      every M-tile of the wave
 //   C/D: lane l holds cout (l & 15), voxels (l >> 4) * 4 + 0..3 of the run -> one 16-byte store per M-tile
+#include <stdlib.h>
+
 #include "cds_common.hpp"
 
 namespace {
@@ -184,6 +186,9 @@ struct MDCfg {
   static constexpr int NSLOT = (CI_CHUNK * NS + 255) / 256;
 };
 
+// NCO = 16: N = 16 output channels, x parities in two accumulators.  NCO = 8: N = (cout, x parity) = 8 x 2 in ONE
+// accumulator (2 MFMAs per tap row instead of 3; the B operand of the second one is zero for the even parity).
+template <int NCO>
 __global__ __launch_bounds__(256) void deconv3d_k3s2_mfma_kernel(const float* __restrict__ x,
                                                                  const float* __restrict__ wpk,
                                                                  const float* __restrict__ bias,
@@ -192,7 +197,7 @@ __global__ __launch_bounds__(256) void deconv3d_k3s2_mfma_kernel(const float* __
                                                                  int tiles_x, int tiles_y, int tiles_z, int ntiles) {
   using Cfg = MDCfg;
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int co_blocks = Cout / 16;
+  const int co_blocks = Cout / NCO;
   int lin = cds_xcd_remap(blockIdx.x, ntiles * co_blocks * 4);
   const int cls = lin & 3;
   lin >>= 2;
@@ -202,7 +207,7 @@ __global__ __launch_bounds__(256) void deconv3d_k3s2_mfma_kernel(const float* __
   tile /= tiles_x;
   const int ty_i = tile % tiles_y;
   const int tz_i = tile / tiles_y;
-  const int co0 = cob * 16;
+  const int co0 = cob * NCO;
   const int pz = cls >> 1, py = cls & 1;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -236,7 +241,9 @@ __global__ __launch_bounds__(256) void deconv3d_k3s2_mfma_kernel(const float* __
   for (int t = 0; t < Cfg::NT; ++t) acc0[t] = acc1[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const float* a_base = lds + (lane >> 4) * Cfg::SLAB + wave * Cfg::IXP + (lane & 15);
-  const float* __restrict__ b_base = wpk + (size_t)(lane >> 4) * 27 * Cout + co0 + (lane & 15);
+  const int nco = NCO == 16 ? (lane & 15) : ((lane & 15) >> 1);   // output channel of this lane's column
+  const int npx = (lane & 1);                                      // NCO = 8: x parity of this lane's column
+  const float* __restrict__ b_base = wpk + (size_t)(lane >> 4) * 27 * Cout + co0 + nco;
 
   issue(0);
   for (int ci0 = 0; ci0 < Cin; ci0 += Cfg::CI_CHUNK) {
@@ -262,9 +269,15 @@ __global__ __launch_bounds__(256) void deconv3d_k3s2_mfma_kernel(const float* __
           const int tz = t / Cfg::XT, txr = t % Cfg::XT;
           const float* ap = arow + (tz * Cfg::IY) * Cfg::IXP + txr * 16;
           const float a0 = ap[0], a1 = ap[1];
-          acc0[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b1, acc0[t], 0, 0, 0);  // x = 2a   : (cell a,   tap 1)
-          acc1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b0, acc1[t], 0, 0, 0);  // x = 2a+1 : (cell a+1, tap 0)
-          acc1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b2, acc1[t], 0, 0, 0);  //            (cell a,   tap 2)
+          if constexpr (NCO == 16) {
+            acc0[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b1, acc0[t], 0, 0, 0);  // x = 2a   : (cell a,   tap 1)
+            acc1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b0, acc1[t], 0, 0, 0);  // x = 2a+1 : (cell a+1, tap 0)
+            acc1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b2, acc1[t], 0, 0, 0);  //            (cell a,   tap 2)
+          } else {
+            // column (cout, parity): cell a feeds tap 1 (even) / tap 2 (odd); cell a+1 feeds tap 0 (odd only)
+            acc0[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, npx ? b2 : b1, acc0[t], 0, 0, 0);
+            acc0[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, npx ? b0 : 0.f, acc0[t], 0, 0, 0);
+          }
         }
       }
     }
@@ -272,7 +285,7 @@ __global__ __launch_bounds__(256) void deconv3d_k3s2_mfma_kernel(const float* __
 
   const int ay = ay0 + wave;
   if (ay >= H) return;
-  const int co = co0 + (lane & 15);
+  const int co = co0 + nco;
   const float b = bias ? bias[co] : 0.f;
   const int Do = 2 * D, Ho = 2 * H, Wo = 2 * W;
   const size_t oplane = (size_t)Ho * Wo, ovol = (size_t)Do * oplane;
@@ -280,22 +293,43 @@ __global__ __launch_bounds__(256) void deconv3d_k3s2_mfma_kernel(const float* __
   for (int t = 0; t < Cfg::NT; ++t) {
     const int tz = t / Cfg::XT, txr = t % Cfg::XT;
     const int az = az0 + tz, ax = ax0 + txr * 16 + (lane >> 4) * 4;   // first of this lane's 4 cells
-    if (az >= D || ax >= W) continue;                                  // W % 4 == 0: the 4 cells are all in or all out
+    const bool inside = az < D && ax < W;                              // W % 4 == 0: the 4 cells are all in or all out
     const size_t base = (size_t)co * ovol + (size_t)(2 * az + pz) * oplane + (size_t)(2 * ay + py) * Wo + 2 * ax;
-    float v[8] = {acc0[t].x, acc1[t].x, acc0[t].y, acc1[t].y, acc0[t].z, acc1[t].z, acc0[t].w, acc1[t].w};
+    if constexpr (NCO == 16) {
+      if (!inside) continue;
+      float v[8] = {acc0[t].x, acc1[t].x, acc0[t].y, acc1[t].y, acc0[t].z, acc1[t].z, acc0[t].w, acc1[t].w};
 #pragma unroll
-    for (int p = 0; p < 8; ++p) {
-      v[p] += b;
-      if (act == CDS_ACT_RELU) v[p] = fmaxf(v[p], 0.f);
-    }
+      for (int p = 0; p < 8; ++p) {
+        v[p] += b;
+        if (act == CDS_ACT_RELU) v[p] = fmaxf(v[p], 0.f);
+      }
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      float4 o = make_float4(v[4 * half], v[4 * half + 1], v[4 * half + 2], v[4 * half + 3]);
+      for (int half = 0; half < 2; ++half) {
+        float4 o = make_float4(v[4 * half], v[4 * half + 1], v[4 * half + 2], v[4 * half + 3]);
+        if (skip) {
+          const float4 s4 = *reinterpret_cast<const float4*>(skip + base + 4 * half);
+          o.x = s4.x + o.x; o.y = s4.y + o.y; o.z = s4.z + o.z; o.w = s4.w + o.w;
+        }
+        *reinterpret_cast<float4*>(out + base + 4 * half) = o;
+      }
+    } else {
+      // this lane: parity npx of cells c0..c3; the neighbouring lane (l ^ 1): the other parity of the same cells.
+      float mine[4] = {acc0[t].x + b, acc0[t].y + b, acc0[t].z + b, acc0[t].w + b};
+      float other[4];
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        if (act == CDS_ACT_RELU) mine[p] = fmaxf(mine[p], 0.f);
+        other[p] = __shfl_xor(mine[p], 1);
+      }
+      if (!inside) continue;
+      // even lane stores x = 2c0 .. 2c0+3 (cells c0, c1), odd lane x = 2c2 .. 2c2+3 (cells c2, c3)
+      float4 o = npx ? make_float4(other[2], mine[2], other[3], mine[3]) : make_float4(mine[0], other[0], mine[1], other[1]);
+      const size_t addr = base + (npx ? 4 : 0);
       if (skip) {
-        const float4 s4 = *reinterpret_cast<const float4*>(skip + base + 4 * half);
+        const float4 s4 = *reinterpret_cast<const float4*>(skip + addr);
         o.x = s4.x + o.x; o.y = s4.y + o.y; o.z = s4.z + o.z; o.w = s4.w + o.w;
       }
-      *reinterpret_cast<float4*>(out + base + 4 * half) = o;
+      *reinterpret_cast<float4*>(out + addr) = o;
     }
   }
 }
@@ -314,13 +348,20 @@ bool cds_conv3d_mfma_launch(const float* x, const float* w, const float* b, cons
 
 bool cds_deconv3d_mfma_launch(const float* x, const float* w, const float* b, const float* skip, float* out, int Cin,
                               int Cout, int D, int H, int W, int act, hipStream_t st, int* rc) {
-  if ((Cout % 16) || (Cin % 4) || (W % 4) || W < 8 || (size_t)Cin * D * H * W >= (size_t)0x7fffffff) return false;
+  // Cout % 16 != 0 (conv11, 16 -> 8): the (cout, parity) MFMA variant below is correct but measured slower than the
+  // packed-VALU v2 kernel on this memory-bound layer (2.2 vs 1.5 ms at M1), so it is only used when CDS_DECONV_MFMA8=1.
+  static const bool mfma8 = []() { const char* e = getenv("CDS_DECONV_MFMA8"); return e && e[0] == '1'; }();
+  if ((Cout % 8) || (Cout % 16 && !mfma8) || (Cin % 4) || (W % 4) || W < 8 || (size_t)Cin * D * H * W >= (size_t)0x7fffffff) return false;
   using Cfg = MDCfg;
   const int tx = cds_ceil_div(W, Cfg::CX), ty = cds_ceil_div(H, Cfg::CY), tz = cds_ceil_div(D, Cfg::CZ);
   const int ntiles = tx * ty * tz;
   const size_t lds_bytes = (size_t)Cfg::SLAB * Cfg::CI_CHUNK * sizeof(float);
-  hipLaunchKernelGGL(deconv3d_k3s2_mfma_kernel, dim3(ntiles * (Cout / 16) * 4), dim3(256), lds_bytes, st, x, w, b, skip,
-                     out, Cin, Cout, D, H, W, act, tx, ty, tz, ntiles);
+  if (Cout % 16 == 0)
+    hipLaunchKernelGGL(deconv3d_k3s2_mfma_kernel<16>, dim3(ntiles * (Cout / 16) * 4), dim3(256), lds_bytes, st, x, w, b,
+                       skip, out, Cin, Cout, D, H, W, act, tx, ty, tz, ntiles);
+  else
+    hipLaunchKernelGGL(deconv3d_k3s2_mfma_kernel<8>, dim3(ntiles * (Cout / 8) * 4), dim3(256), lds_bytes, st, x, w, b,
+                       skip, out, Cin, Cout, D, H, W, act, tx, ty, tz, ntiles);
   *rc = cds_launch_status();
   return true;
 }
