@@ -270,7 +270,7 @@ __device__ __forceinline__ void plane_weights(v2f ix, v2f iy, v2f& x0f, v2f& y0f
 // pixel, quotient corrected with two fmas (correctly rounded like the IEEE sequence, 3 instead of ~10 VALU ops).
 // Addressing: per-channel slab base (uniform) + one 32-bit byte offset per plane (slab = D*h*w*4 < 4 GB).
 // ---------------------------------------------------------------------------------------------
-template <int VMAX>
+template <int VMAX, bool ACCUMULATE, bool NORMALIZE>
 __global__ __launch_bounds__(256, CDS_K3_MINW) void warp_aggregate_lds_kernel(
     const float* __restrict__ ref, const float* __restrict__ src, const float* __restrict__ vis, WarpMats mats,
     const float* __restrict__ hyp, float* __restrict__ volume, const float* __restrict__ vis_sum, int V, int D, int h,
@@ -309,8 +309,8 @@ __global__ __launch_bounds__(256, CDS_K3_MINW) void warp_aggregate_lds_kernel(
       cds_row_terms(mats.m[v], (float)xc, (float)yc, r[v]);
     }
   }
-  const bool accumulate = flags & CDS_AGG_ACCUMULATE;
-  const bool normalize = flags & CDS_AGG_NORMALIZE;
+  constexpr bool accumulate = ACCUMULATE, normalize = NORMALIZE;
+  (void)flags;
   const float denom = (normalize ? vis_sum[pix] : 1.0f) + 1e-6f;
   float yden = __builtin_amdgcn_rcpf(denom);
   yden = fmaf(fmaf(-denom, yden, 1.0f), yden, yden);
@@ -339,16 +339,17 @@ __global__ __launch_bounds__(256, CDS_K3_MINW) void warp_aggregate_lds_kernel(
 
     unsigned boff = ((unsigned)d0 * hw + pix) * 4u;  // byte offset of (plane d, pixel) inside a channel slab / hyp
     const unsigned bstep = hw * 4u;
-    v2f dnext;  // hypotheses of the next plane pair, loaded one iteration ahead
+    // hypotheses of the next plane pair are loaded one iteration ahead; plane indices are clamped to the chunk's last
+    // plane so the loads are unconditional (no branch, no early wait)
+    const unsigned blast = ((unsigned)(d1 - 1) * hw + pix) * 4u;
+    v2f dnext;
     dnext.x = *reinterpret_cast<const float*>(hyp_b + boff);
-    dnext.y = (d0 + 1 < d1) ? *reinterpret_cast<const float*>(hyp_b + boff + bstep) : dnext.x;
+    dnext.y = *reinterpret_cast<const float*>(hyp_b + min(boff + bstep, blast));
     for (int d = d0; d < d1; d += 2, boff += 2u * bstep) {
       const bool two = d + 1 < d1;
       const v2f dv = dnext;
-      if (d + 2 < d1) {
-        dnext.x = *reinterpret_cast<const float*>(hyp_b + boff + 2u * bstep);
-        dnext.y = (d + 3 < d1) ? *reinterpret_cast<const float*>(hyp_b + boff + 3u * bstep) : dnext.x;
-      }
+      dnext.x = *reinterpret_cast<const float*>(hyp_b + min(boff + 2u * bstep, blast));
+      dnext.y = *reinterpret_cast<const float*>(hyp_b + min(boff + 3u * bstep, blast));
       v2f acc[2][4];
 #pragma unroll
       for (int k = 0; k < 2; ++k)
@@ -474,16 +475,15 @@ __global__ __launch_bounds__(256) void warp_entropy_lds_kernel(const float* __re
     __syncthreads();
     unsigned boff = ((unsigned)d0 * hw + pix) * 4u;
     const unsigned bstep = hw * 4u;
+    const unsigned blast = ((unsigned)(d1 - 1) * hw + pix) * 4u;
     v2f dnext;
     dnext.x = *reinterpret_cast<const float*>(hyp_b + boff);
-    dnext.y = (d0 + 1 < d1) ? *reinterpret_cast<const float*>(hyp_b + boff + bstep) : dnext.x;
+    dnext.y = *reinterpret_cast<const float*>(hyp_b + min(boff + bstep, blast));
     for (int d = d0; d < d1; d += 2, boff += 2u * bstep) {
       const bool two = d + 1 < d1;
       const v2f dv = dnext;
-      if (d + 2 < d1) {
-        dnext.x = *reinterpret_cast<const float*>(hyp_b + boff + 2u * bstep);
-        dnext.y = (d + 3 < d1) ? *reinterpret_cast<const float*>(hyp_b + boff + 3u * bstep) : dnext.x;
-      }
+      dnext.x = *reinterpret_cast<const float*>(hyp_b + min(boff + 2u * bstep, blast));
+      dnext.y = *reinterpret_cast<const float*>(hyp_b + min(boff + 3u * bstep, blast));
       v2f ix, iy, x0f, y0f, wt[4];
       positions2(r, m + 9, dv, g, ix, iy);
       plane_weights(ix, iy, x0f, y0f, wt);
@@ -530,12 +530,21 @@ bool cds_warp_aggregate_lds_launch(const float* ref, const float* src, const flo
   if (const char* e = getenv("CDS_K3_NSEG")) nseg = atoi(e) > 0 ? (atoi(e) < chunks ? atoi(e) : chunks) : nseg;  // tuning knob
   const int seg_planes = cds_ceil_div(chunks, nseg) * DC;
   nseg = cds_ceil_div(D, seg_planes);
-#define LAUNCH(VM)                                                                                                     \
-  hipLaunchKernelGGL(warp_aggregate_lds_kernel<VM>, dim3(ntiles * nseg), dim3(256),                                    \
+  const bool acc_f = flags & CDS_AGG_ACCUMULATE, nrm_f = flags & CDS_AGG_NORMALIZE;
+#define LAUNCH3(VM, A, N)                                                                                              \
+  hipLaunchKernelGGL((warp_aggregate_lds_kernel<VM, A, N>), dim3(ntiles * nseg), dim3(256),                            \
                      (size_t)VM * 2 * BOX_CAP * sizeof(float4) + 4 * VM * 4 * sizeof(int), st, ref, src, vis, wm, hyp, \
                      volume, vis_sum, V, D, h, w, rhw, rhh, flags, tiles_x, ntiles, nseg, seg_planes)
+#define LAUNCH(VM)                                 \
+  do {                                             \
+    if (acc_f && nrm_f) LAUNCH3(VM, true, true);   \
+    else if (acc_f) LAUNCH3(VM, true, false);      \
+    else if (nrm_f) LAUNCH3(VM, false, true);      \
+    else LAUNCH3(VM, false, false);                \
+  } while (0)
   if (V <= 2) LAUNCH(2);
   else LAUNCH(4);
+#undef LAUNCH3
 #undef LAUNCH
   return true;
 }
