@@ -180,10 +180,17 @@ __device__ __forceinline__ void positions2(const float r[3], const float* __rest
   y0.y = __builtin_amdgcn_rcpf(z.y);
   const v2f e = fma2(-z, y0, splat2(1.0f));
   const v2f y = fma2(e, y0, y0);
-  const v2f u = div2_refine(px, z, y);
-  const v2f v = div2_refine(py, z, y);
-  const v2f gx = div2_const(u, g.half_w, g.rhw) - 1.0f;
-  const v2f gy = div2_const(v, g.half_h, g.rhh) - 1.0f;
+  // u = px / z and v = py / z (div2_refine), written interleaved: two independent dependency chains
+  v2f qu = px * y, qv = py * y;
+  v2f ru = fma2(-z, qu, px), rv = fma2(-z, qv, py);
+  qu = fma2(ru, y, qu); qv = fma2(rv, y, qv);
+  ru = fma2(-z, qu, px); rv = fma2(-z, qv, py);
+  const v2f u = fma2(ru, y, qu), v = fma2(rv, y, qv);
+  // g = u / half - 1 (div2_const), interleaved as well
+  v2f qx = u * g.rhw, qy = v * g.rhh;
+  const v2f rx = fma2(splat2(-g.half_w), qx, u), ry = fma2(splat2(-g.half_h), qy, v);
+  qx = fma2(rx, splat2(g.rhw), qx); qy = fma2(ry, splat2(g.rhh), qy);
+  const v2f gx = qx - 1.0f, gy = qy - 1.0f;
   ix = (gx + 1.0f) * g.half_w;
   iy = (gy + 1.0f) * g.half_h;
 }
@@ -211,6 +218,15 @@ __device__ __forceinline__ void fetch_cell(float x0f, float y0f, const Geo& g, c
   const int y0 = clamp_m2((int)y0f, g.h);
   const unsigned ux = (unsigned)(x0 - b.x0), uy = (unsigned)(y0 - b.y0);
   const bool inside = (ux + 2u <= (unsigned)b.bw) && (uy + 2u <= (unsigned)b.bh);  // bw = bh = 0 when not staged
+  // LDS reads are unconditional (index 0 when the cell is not inside: the values are then replaced below); keeping
+  // them out of an if/else stops the compiler from merging the LDS and global reads into slow generic flat loads.
+  const unsigned i0 = inside ? __umul24(uy, (unsigned)b.bw) + ux : 0u;
+  const cds_f4* r0 = lds + i0;
+  const cds_f4* r1 = r0 + (inside ? b.bw : 0);
+  t[0].lo = r0[0]; t[0].hi = r0[CAP];
+  t[1].lo = r0[1]; t[1].hi = r0[CAP + 1];
+  t[2].lo = r1[0]; t[2].hi = r1[CAP];
+  t[3].lo = r1[1]; t[3].hi = r1[CAP + 1];
   if (__builtin_expect(!inside, 0)) {
     const bool x0ok = (unsigned)x0 < (unsigned)g.w, x1ok = (unsigned)(x0 + 1) < (unsigned)g.w;
     const bool y0ok = (unsigned)y0 < (unsigned)g.h, y1ok = (unsigned)(y0 + 1) < (unsigned)g.h;
@@ -225,14 +241,6 @@ __device__ __forceinline__ void fetch_cell(float x0f, float y0f, const Geo& g, c
     p = reinterpret_cast<const cds_f4*>(srcv + ((size_t)ya * g.w + xb) * C8); t[1].lo = p[0]; t[1].hi = p[1];
     p = reinterpret_cast<const cds_f4*>(srcv + ((size_t)yb * g.w + xa) * C8); t[2].lo = p[0]; t[2].hi = p[1];
     p = reinterpret_cast<const cds_f4*>(srcv + ((size_t)yb * g.w + xb) * C8); t[3].lo = p[0]; t[3].hi = p[1];
-  } else {
-    const unsigned i0 = __umul24(uy, (unsigned)b.bw) + ux;
-    const cds_f4* r0 = lds + i0;
-    const cds_f4* r1 = r0 + b.bw;
-    t[0].lo = r0[0]; t[0].hi = r0[CAP];
-    t[1].lo = r0[1]; t[1].hi = r0[CAP + 1];
-    t[2].lo = r1[0]; t[2].hi = r1[CAP];
-    t[3].lo = r1[1]; t[3].hi = r1[CAP + 1];
   }
 }
 
