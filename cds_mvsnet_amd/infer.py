@@ -1,0 +1,88 @@
+"""Depth-map inference harness (the counterpart of the reference's test.py:153-265 `save_depth`).
+
+    python -m cds_mvsnet_amd.infer --testpath <scenes> --testlist <list.txt> --outdir <out> \
+        [--resume ckpt.pth] [--refine] [--num_view 5] [--numdepth 192] [--max_h 512 --max_w 640] [--temperature 0.01]
+
+One process per GPU: with `python -m torch.distributed.run --nproc-per-node N -m cds_mvsnet_amd.infer ...` every rank takes
+the reference views `idx % world == rank` (independent depth maps, no collective).  Outputs follow the reference layout:
+`<out>/<scan>/depth_est/%08d.pfm`, `confidence/%08d.pfm` (3 channels = stage 1-3 confidences), `cams/%08d_cam.txt`,
+`images/%08d.jpg`, ready for the fusion step.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import time
+
+import numpy as np
+import torch
+
+from . import CDSMVSNet, seeded_init_
+from .mvs_io import EvalScenes, save_outputs
+
+
+def load_checkpoint(model: torch.nn.Module, path: str) -> None:
+    """Reference checkpoints: {'state_dict': ...} with a 'module.' prefix when saved under DataParallel (test.py:180-187)."""
+    ck = torch.load(path, map_location="cpu", weights_only=False)
+    sd = ck["state_dict"] if "state_dict" in ck else ck
+    sd = {k[len("module."):] if k.startswith("module.") else k: v for k, v in sd.items()}
+    model.load_state_dict(sd, strict=False)
+
+
+def run(args) -> float:
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    torch.cuda.set_device(dev)
+    with open(args.testlist) as f:
+        scans = [ln.strip() for ln in f if ln.strip()]
+    data = EvalScenes(args.testpath, scans, nviews=args.num_view, ndepths=args.numdepth,
+                      interval_scale=args.interval_scale, max_h=args.max_h, max_w=args.max_w, refine=args.refine,
+                      dataset=args.dataset)
+    model = CDSMVSNet(refine=args.refine, ndepths=(48, 32, 8), depth_interals_ratio=(4.0, 1.5, 0.75))
+    if args.resume:
+        load_checkpoint(model, args.resume)
+    else:
+        seeded_init_(model, 0)  # no checkpoint given: deterministic synthetic weights (plumbing runs)
+    model = model.to(dev).eval()
+    last = "stage4" if args.refine else "stage3"
+    times = []
+    with torch.no_grad():
+        for idx in range(rank, len(data), world):
+            s = data[idx]
+            t0 = time.time()
+            imgs = torch.from_numpy(s["imgs"]).unsqueeze(0).to(dev)
+            cams = {k: torch.from_numpy(v).unsqueeze(0).to(dev) for k, v in s["proj_matrices"].items()}
+            dv = torch.from_numpy(s["depth_values"]).unsqueeze(0).to(dev)
+            out = model(imgs, cams, dv, temperature=args.temperature)
+            torch.cuda.synchronize()
+            times.append(time.time() - t0)
+            confs = [out["stage1"]["photometric_confidence"][0].cpu().numpy(),
+                     out["stage2"]["photometric_confidence"][0].cpu().numpy(),
+                     out["photometric_confidence"][0].cpu().numpy()]
+            save_outputs(args.outdir, s["filename"], out["refined_depth"][0].cpu().numpy(), confs,
+                         s["proj_matrices"][last][0], s["imgs"][0])
+            print(f"[{rank}] {idx + 1}/{len(data)} {s['filename'].format('depth_est', '.pfm')} {times[-1] * 1e3:.1f} ms", flush=True)
+    avg = float(np.mean(times)) if times else 0.0
+    print(f"[{rank}] average time: {avg:.4f} s over {len(times)} depth maps")
+    return avg
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    ap.add_argument("--testpath", required=True)
+    ap.add_argument("--testlist", required=True)
+    ap.add_argument("--outdir", required=True)
+    ap.add_argument("--resume", default=None)
+    ap.add_argument("--refine", action="store_true")
+    ap.add_argument("--num_view", type=int, default=5)
+    ap.add_argument("--numdepth", type=int, default=192)
+    ap.add_argument("--interval_scale", type=float, default=1.06)
+    ap.add_argument("--max_h", type=int, default=512)
+    ap.add_argument("--max_w", type=int, default=640)
+    ap.add_argument("--temperature", type=float, default=0.01)
+    ap.add_argument("--dataset", default="dtu", choices=["dtu", "tt", "general"])
+    run(ap.parse_args(argv))
+
+
+if __name__ == "__main__":
+    main()

@@ -430,3 +430,21 @@ def test_model_input_validation(dev):
     with pytest.raises(ValueError):
         m(synth.make_images(3, 72, 96).to(dev), {k: v.to(dev) for k, v in synth.make_cameras(3, 72, 96).items()},
           synth.make_depth_values().to(dev))   # 72 is not a multiple of 32
+
+
+def test_batch_of_two_equals_two_singles(dev, seeded_state):
+    """The reference forward is batched (B > 1 in training / DataParallel); each batch item must equal its own run."""
+    from cds_mvsnet_amd import synth
+    model = seeded_state(False).to(dev)
+    a = (synth.make_images(3, 64, 96, seed=1), synth.make_cameras(3, 64, 96, seed=1))
+    b = (synth.make_images(3, 64, 96, seed=2), synth.make_cameras(3, 64, 96, seed=2))
+    dv = synth.make_depth_values()
+    imgs = torch.cat((a[0], b[0])).to(dev)
+    cams = {k: torch.cat((a[1][k], b[1][k])).to(dev) for k in a[1]}
+    dv2 = torch.cat((dv, dv + 10.0)).to(dev)
+    with torch.no_grad():
+        both = model(imgs, cams, dv2, temperature=0.01)
+        one = model(b[0].to(dev), {k: v.to(dev) for k, v in b[1].items()}, (dv + 10.0).to(dev), temperature=0.01)
+    assert both["depth"].shape == (2, 64, 96) and both["stage1"]["norm_curv"].shape == (2, 1, 16, 24)
+    assert torch.equal(both["depth"][1], one["depth"][0])
+    assert torch.equal(both["photometric_confidence"][1], one["photometric_confidence"][0])
