@@ -31,6 +31,7 @@ SIGNATURES = {
     "cds_homo_warp_f32": [P, P, P, P, I, I, I, I, I, P],
     "cds_warp_entropy_f32": [P, P, P, P, P, I, I, I, I, I, I, P],
     "cds_warp_aggregate_f32": [P, P, P, P, P, P, P, I, I, I, I, I, I, I, P],
+    "cds_warp_aggregate_bwd_f32": [P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, P],
     "cds_volume_normalize_f32": [P, P, I, I, I, P],
     "cds_softargmin_conf_f32": [P, P, P, P, P, I, I, I, I, P],
     "cds_depth_hypotheses_f32": [P, P, I, I, I, I, I, I, F, F, F, P],

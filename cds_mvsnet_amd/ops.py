@@ -146,6 +146,42 @@ def warp_aggregate(ref_chw: Tensor, src_hwc: Tensor, vis_w: Tensor, mats: Tensor
     return volume, vis_sum
 
 
+def warp_aggregate_bwd(ref_chw: Tensor, src_hwc: Tensor, vis_w: Tensor, mats: Tensor, hyp: Tensor,
+                       grad_volume: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
+    """Backward of the un-normalised K3: returns (grad_ref [V,C,h,w], grad_src_hwc [V,h,w,C], grad_vis [V,h,w])."""
+    V, C, h, w = ref_chw.shape
+    D, pp = _hyp_args(hyp, None, h, w)
+    if tuple(grad_volume.shape) != (C, D, h, w) or V > MAX_VIEWS:
+        raise ValueError("warp_aggregate_bwd: inconsistent shapes")
+    g_ref = torch.empty_like(ref_chw)
+    g_src = torch.zeros_like(src_hwc)
+    g_vis = torch.empty_like(vis_w)
+    check(_lib.load().cds_warp_aggregate_bwd_f32(_dev(ref_chw, "ref"), _dev(src_hwc, "src"), _dev(vis_w, "vis"),
+                                                 _host(mats, "mats"), _dev(hyp, "hyp"), _dev(grad_volume, "grad_volume"),
+                                                 g_ref.data_ptr(), g_src.data_ptr(), g_vis.data_ptr(), V, C, D, h, w, pp,
+                                                 _stream(g_ref)), "cds_warp_aggregate_bwd_f32")
+    return g_ref, g_src, g_vis
+
+
+class WarpAggregate(torch.autograd.Function):
+    """volume_sum = sum_v vis_v * ref_v (x) warp(src_v) with hand-written forward (K3) and backward kernels.
+    Gradients: ref, src (channels-last), vis.  mats (CPU) and hyp carry none (warping.py:79)."""
+
+    @staticmethod
+    def forward(ctx, ref_chw, src_hwc, vis_w, mats, hyp):
+        ref_chw, src_hwc, vis_w, hyp = (t.contiguous() for t in (ref_chw, src_hwc, vis_w, hyp))
+        ctx.save_for_backward(ref_chw, src_hwc, vis_w, hyp)
+        ctx.mats = mats
+        volume, _ = warp_aggregate(ref_chw, src_hwc, vis_w, mats, hyp, normalize=False)
+        return volume
+
+    @staticmethod
+    def backward(ctx, grad_volume):
+        ref_chw, src_hwc, vis_w, hyp = ctx.saved_tensors
+        g_ref, g_src, g_vis = warp_aggregate_bwd(ref_chw, src_hwc, vis_w, ctx.mats, hyp, grad_volume.contiguous())
+        return g_ref, g_src, g_vis, None, None
+
+
 def volume_normalize_(volume: Tensor, vis_sum: Tensor) -> Tensor:
     C, D, h, w = volume.shape
     check(_lib.load().cds_volume_normalize_f32(_dev(volume, "volume"), _dev(vis_sum, "vis_sum"), C, D, h * w,

@@ -83,6 +83,19 @@ int cds_warp_aggregate_f32(const float* ref_chw, const float* src_hwc, const flo
                            int V, int C, int D, int h, int w, int hyp_per_pixel, int flags,
                            void* stream);
 
+/*
+ * Backward of the un-normalised K3 (training step).  With volume = sum_v vis_v * ref_v (x) warp(src_v):
+ *   grad_volume  [C][D][h][w]   incoming gradient
+ *   grad_ref     [V][C][h][w]   written
+ *   grad_src_hwc [V][h][w][C]   ACCUMULATED with atomics (bilinear scatter): the caller zeroes it first
+ *   grad_vis     [V][h][w]      written
+ * The sampling grid has no gradient (built under no_grad, warping.py:79): nothing flows to hypotheses / cameras.
+ */
+int cds_warp_aggregate_bwd_f32(const float* ref_chw, const float* src_hwc, const float* vis_w,
+                               const float* mats_host, const float* hyp, const float* grad_volume,
+                               float* grad_ref, float* grad_src_hwc, float* grad_vis, int V, int C, int D,
+                               int h, int w, int hyp_per_pixel, void* stream);
+
 /* volume[c][d][p] /= (vis_sum[p] + 1e-6)  (model.py:74) — the finalisation after a view-shard
  * all-reduce of partial sums. */
 int cds_volume_normalize_f32(float* volume, const float* vis_sum, int C, int D, int hw, void* stream);

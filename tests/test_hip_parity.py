@@ -448,3 +448,31 @@ def test_batch_of_two_equals_two_singles(dev, seeded_state):
     assert both["depth"].shape == (2, 64, 96) and both["stage1"]["norm_curv"].shape == (2, 1, 16, 24)
     assert torch.equal(both["depth"][1], one["depth"][0])
     assert torch.equal(both["photometric_confidence"][1], one["photometric_confidence"][0])
+
+
+@pytest.mark.parametrize("V,C,D,h,w", [(2, 8, 6, 12, 40), (3, 16, 4, 9, 70), (1, 32, 3, 8, 20)])
+def test_warp_aggregate_backward_vs_autograd(V, C, D, h, w, dev, ops):
+    """Training step: gradients of the un-normalised warp-aggregate w.r.t. ref / src / vis against
+    torch autograd through the CPU oracle's warp (F.grid_sample)."""
+    from oracle import cds_oracle as O
+    feats, cams, hyp, _, _, mats, hyp_d = _random_stage(ops, dev, V, C, D, h, w, seed=60 + V)
+    g = torch.Generator().manual_seed(5)
+    ref = torch.stack([f["ref"][0][0] for f in feats]).requires_grad_(True)
+    src = torch.stack([f["src"][0][0] for f in feats]).requires_grad_(True)
+    vis = (torch.rand(V, h, w, generator=g) * 0.8 + 0.1).requires_grad_(True)
+    G = torch.randn(C, D, h, w, generator=g)
+    P_ref = O.compose_projection(cams[:, 0])
+    vol = 0.0
+    for v in range(V):
+        warped = O.warp_volume(src[v:v + 1], O.compose_projection(cams[:, v + 1]), P_ref, hyp, exact=False)[0]
+        vol = vol + ref[v].unsqueeze(1) * warped * vis[v].view(1, 1, h, w)
+    (vol * G).sum().backward()
+    ref_d = ref.detach().to(dev).requires_grad_(True)
+    src_d = src.detach().to(dev).requires_grad_(True)
+    vis_d = vis.detach().to(dev).requires_grad_(True)
+    vol_d = ops.WarpAggregate.apply(ref_d, src_d.permute(0, 2, 3, 1).contiguous(), vis_d, mats, hyp_d)
+    assert (vol_d.detach().cpu() - vol.detach()).abs().max() < 1e-5
+    (vol_d * G.to(dev)).sum().backward()
+    for name, a, b in (("ref", ref_d.grad, ref.grad), ("src", src_d.grad, src.grad), ("vis", vis_d.grad, vis.grad)):
+        err = (a.cpu() - b).abs().max().item()
+        assert err < 2e-4 * max(1.0, b.abs().max().item()), (name, err)
