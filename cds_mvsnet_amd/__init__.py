@@ -6,6 +6,7 @@ through the C ABI of ``include/cds_mvsnet_hip.h``.  No CPU / PyTorch fallback ex
 """
 from .model import CDSMVSNet, CostRegNet, FeatureNet, Refinement, StageNet  # noqa: F401
 from .init import seeded_init_  # noqa: F401
+from .losses import final_loss  # noqa: F401
 
-__all__ = ["CDSMVSNet", "CostRegNet", "FeatureNet", "Refinement", "StageNet", "seeded_init_"]
+__all__ = ["CDSMVSNet", "CostRegNet", "FeatureNet", "Refinement", "StageNet", "seeded_init_", "final_loss"]
 __version__ = "0.1.0"

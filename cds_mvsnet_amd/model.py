@@ -8,8 +8,9 @@ checkpoints load unchanged (387 entries, e.g. ``feature.conv00.conv.att_convs.0.
 ``nn.Conv*`` modules is ever called on the hot path: weights are BN-folded and packed once
 (:class:`_Packed`) and handed to the C ABI through :mod:`cds_mvsnet_amd.ops`.
 
-Scope: inference (``model.eval()``).  Training-mode forward (``gt_depths`` /
-batch-statistics BatchNorm) is the next row of §8(f) and raises ``NotImplementedError``.
+Scope: inference (``model.eval()``) runs entirely on the HIP kernels.  ``model.train()`` dispatches to
+``training.forward_train`` (first step): the fused warp-aggregate has hand-written forward AND
+backward kernels, the convolution stacks use stock PyTorch-ROCm autograd ops for now.
 """
 from __future__ import annotations
 
@@ -470,9 +471,6 @@ class CDSMVSNet(nn.Module):
         return self._feature_runner[0](batch, epipoles, T, n_chw=V)
 
     def forward(self, imgs, proj_matrices, depth_values, gt_depths=None, temperature=0.001):
-        if self.training or gt_depths is not None:
-            raise NotImplementedError("CDSMVSNet: training forward (gt_depths / batch-stat BN) is SURVEY §8(f)-2; "
-                                      "call model.eval()")
         if not imgs.is_cuda:
             raise RuntimeError("cds_mvsnet_amd.CDSMVSNet runs on a ROCm device only (no CPU fallback); "
                                "move the model and inputs with .cuda()")
@@ -480,6 +478,9 @@ class CDSMVSNet(nn.Module):
         H, W = (Him // 2, Wim // 2) if self.refine else (Him, Wim)
         if H % 32 or W % 32:
             raise ValueError("internal resolution must be a multiple of 32 (three stride-2 levels at 1/4 scale)")
+        if self.training:
+            from .training import forward_train   # autograd path: HIP warp-aggregate fwd/bwd + torch conv stacks
+            return forward_train(self, imgs.float(), proj_matrices, depth_values, gt_depths, temperature)
         T = float(temperature)
         dv = depth_values.detach().float().cpu()
         cams = {k: v.detach().float().cpu() for k, v in proj_matrices.items()}

@@ -1,0 +1,174 @@
+"""Training-mode forward of CDSMVSNet (reference: models/model.py:52-56,63-69,140-223 with ``self.training``).
+
+SURVEY §8(f)-2, first step.  What is native here: the fused homography warp + visibility-weighted aggregation runs on
+the hand-written HIP kernels in BOTH directions (``ops.WarpAggregate``: K3 forward, scatter-add backward), as do the
+no-gradient pieces (K1 entropy, hypothesis generation, confidence).  The convolution stacks (FeatureNet, visibility
+CNN, CostRegNet with batch-statistics BatchNorm, Refinement) run on stock PyTorch-ROCm autograd ops through the same
+parameter-holder modules, so ``state_dict`` / optimisers / checkpoints are unchanged; their HIP backward kernels are
+the next step.  Gradient topology follows the reference: the sampling grid has no gradient, the entropy input of the
+visibility CNN is detached, depth is detached between stages.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+from . import geometry, ops
+
+Tensor = torch.Tensor
+
+
+def _dynamic_conv(dc, x: Tensor, epi: Tensor, T: float) -> Tuple[Tensor, Tensor]:
+    """models/dynamic_conv.py:97-122 with torch ops.  x [N,Cin,H,W]; epi [N,2] on x's device."""
+    N, _, H, W = x.shape
+    ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float32, device=x.device),
+                            torch.arange(W, dtype=torch.float32, device=x.device), indexing="ij")
+    u = xs.view(1, 1, H, W) - epi[:, 0].view(N, 1, 1, 1)
+    v = ys.view(1, 1, H, W) - epi[:, 1].view(N, 1, 1, 1)
+    nrm = torch.sqrt(u ** 2 + v ** 2)
+    u, v = u / (nrm + 1e-6), v / (nrm + 1e-6)
+    basis = torch.cat((u ** 2, 2 * u * v, v ** 2), dim=1)
+    curvs, res = [], []
+    for att, conv in zip(dc.att_convs, dc.convs):
+        curvs.append((att(x) * basis).sum(dim=1, keepdim=True))
+        res.append(conv(x).unsqueeze(1))
+    curvs = torch.cat(curvs, dim=1)
+    wts = F.softmax(dc.att_weights(curvs) / T, dim=1)
+    return (torch.cat(res, dim=1) * wts.unsqueeze(2)).sum(dim=1), (curvs * wts).sum(dim=1, keepdim=True)
+
+
+def _unit(unit, x: Tensor, epi: Optional[Tensor], T: float):
+    if unit.dynamic:
+        y, nc = _dynamic_conv(unit.conv, x, epi, T)
+        return F.leaky_relu(F.instance_norm(y), 0.1), nc
+    return F.leaky_relu(F.instance_norm(unit.conv(x)), 0.1)
+
+
+def feature_net(net, x: Tensor, epi: Tensor, T: float) -> Dict[str, Tuple[Tensor, Tensor, Tensor]]:
+    """models/module.py:234-267.  x [N,3,H,W], epi [N,2] -> {'stageK': (fea, nc_sum, |nc|)} batched over N."""
+    e0, e1, e2 = epi, epi / 2, epi / 4
+    c00, n00 = _unit(net.conv00, x, e0, T)
+    c01, n01 = _unit(net.conv01, c00, e0, T)
+    d0 = _unit(net.downsample1, c01, None, T)
+    c10, n10 = _unit(net.conv10, d0, e1, T)
+    c11, n11 = _unit(net.conv11, c10, e1, T)
+    d1 = _unit(net.downsample2, c11, None, T)
+    c20, n20 = _unit(net.conv20, d1, e2, T)
+    c21, n21 = _unit(net.conv21, c20, e2, T)
+    out = {}
+    o1, n22 = _dynamic_conv(net.out1, c21, e2, T)
+    out["stage1"] = (torch.tanh(F.instance_norm(o1)), (n20 ** 2 + n21 ** 2 + n22 ** 2) / 3, n22.abs())
+    t = _unit(net.inner1, torch.cat((F.interpolate(c21, scale_factor=2, mode="nearest"), c11), dim=1), None, T)
+    o2, n12 = _dynamic_conv(net.out2, t, e1, T)
+    o2 = torch.tanh(F.instance_norm(o2))
+    out["stage2"] = (o2, (n10 ** 2 + n11 ** 2 + n12 ** 2) / 3, n12.abs())
+    t = _unit(net.inner2, torch.cat((F.interpolate(o2, scale_factor=2, mode="nearest"), c01), dim=1), None, T)
+    o3, n02 = _dynamic_conv(net.out3, t, e0, T)
+    out["stage3"] = (torch.tanh(F.instance_norm(o3)), (n00 ** 2 + n01 ** 2 + n02 ** 2) / 3, n02.abs())
+    return out
+
+
+def _cbr3(unit, x: Tensor) -> Tensor:
+    return F.relu(unit.bn(unit.conv(x)))
+
+
+def cost_regularization(cr, x: Tensor) -> Tensor:
+    """models/module.py:305-315 (BatchNorm in the module's current mode).  x [B,C,D,h,w] -> [B,1,D,h,w]."""
+    c0 = _cbr3(cr.conv0, x)
+    c2 = _cbr3(cr.conv2, _cbr3(cr.conv1, c0))
+    c4 = _cbr3(cr.conv4, _cbr3(cr.conv3, c2))
+    y = _cbr3(cr.conv6, _cbr3(cr.conv5, c4))
+    y = c4 + _cbr3(cr.conv7, y)
+    y = c2 + _cbr3(cr.conv9, y)
+    y = c0 + _cbr3(cr.conv11, y)
+    return cr.prob(y)
+
+
+def _visibility(seq, x: Tensor) -> Tensor:
+    for i in range(3):
+        x = F.relu(seq[i].bn(seq[i].conv(x)))
+    return torch.sigmoid(seq[3](x))
+
+
+def forward_train(model, imgs: Tensor, proj_matrices: Dict[str, Tensor], depth_values: Tensor,
+                  gt_depths: Optional[Dict[str, Tensor]], temperature: float):
+    """CDSMVSNet.forward in training mode.  Same inputs / outputs as the reference (adds 'feat_distance' and
+    'feat_target' per stage).  Module calls are grouped exactly like the reference's (FeatureNet once per image of
+    every pair over the batch, the visibility CNN once per source view over the batch, CostRegNet once per stage over the
+    batch) so the batch statistics of every BatchNorm layer are taken over the same sets."""
+    B, N, _, Him, Wim = imgs.shape
+    H, W = (Him // 2, Wim // 2) if model.refine else (Him, Wim)
+    T = float(temperature)
+    dev = imgs.device
+    dv = depth_values.detach().float().cpu()
+    cams = {k: v.detach().float().cpu() for k, v in proj_matrices.items()}
+    V = N - 1
+    ref_img = F.interpolate(imgs[:, 0], (H, W))
+    feats = []
+    for v in range(V):                                                       # model.py:154-161
+        epi = [geometry.pair_epipoles(cams["stage3"][b, 0], cams["stage3"][b, v + 1]) for b in range(B)]
+        e_ref = torch.tensor([e[0] for e in epi], dtype=torch.float32, device=dev)
+        e_src = torch.tensor([e[1] for e in epi], dtype=torch.float32, device=dev)
+        feats.append((feature_net(model.feature, ref_img, e_ref, T),
+                      feature_net(model.feature, F.interpolate(imgs[:, v + 1], (H, W)), e_src, T)))
+    outputs: Dict[str, object] = {}
+    depth = None
+    dint_all = (dv[:, 1] - dv[:, 0])
+    for s in range(model.num_stage):
+        name = f"stage{s + 1}"
+        scale = int(model.stage_infos[name]["scale"])
+        h, w = H // scale, W // scale
+        D = model.ndepths[s]
+        hyps = []
+        for b in range(B):
+            dmin, dmax = float(dv[b, 0]), float(dv[b, -1])
+            if depth is None:
+                hyps.append(ops.depth_planes(D, h, w, dmin, dmax, dev))
+            else:
+                hyps.append(ops.depth_hypotheses(depth[b].detach().contiguous(), D, H, W, scale,
+                                                 float(model.depth_interals_ratio[s] * dint_all[b]), dmin, dmax))
+        mats = [geometry.warp_matrices(cams[name][b]) for b in range(B)]
+        ref = [torch.stack([feats[v][0][name][0][b] for v in range(V)]) for b in range(B)]                 # [V,C,h,w]
+        src = [torch.stack([feats[v][1][name][0][b] for v in range(V)]).permute(0, 2, 3, 1).contiguous() for b in range(B)]
+        with torch.no_grad():                                               # K1, detached input (model.py:49)
+            ent = torch.stack([ops.warp_entropy(ref[b].detach().contiguous(), src[b].detach(), mats[b], hyps[b])
+                               for b in range(B)])                           # [B,V,h,w]
+        vis = [_visibility(model.stage_net.vis[s], torch.cat((ent[:, v:v + 1], feats[v][0][name][2]), dim=1))[:, 0]
+               for v in range(V)]                                            # V x [B,h,w]  (model.py:51)
+        vols, fds = [], []
+        for b in range(B):
+            vis_b = torch.stack([vis[v][b] for v in range(V)])               # [V,h,w]
+            vol_sum = ops.WarpAggregate.apply(ref[b], src[b], vis_b, mats[b], hyps[b])       # K3 fwd / bwd kernels
+            denom = (vis_b.sum(dim=0) + 1e-6).unsqueeze(0)
+            vols.append(vol_sum / denom.unsqueeze(0))                        # model.py:74
+            fd = vol_sum.sum(dim=0) / denom                                  # sum_v sim_v * vis_v / vis_sum (model.py:56,75)
+            if gt_depths is not None:                                        # model.py:63-69,76-78
+                gt_sum = ops.WarpAggregate.apply(ref[b], src[b], vis_b, mats[b], gt_depths[name][b:b + 1].contiguous())
+                fd = torch.cat((fd, gt_sum.sum(dim=0) / denom), dim=0)
+            fds.append(fd)
+        nc_mean = sum((feats[v][0][name][1] + feats[v][1][name][1]) / 2 for v in range(V)) / V       # [B,1,h,w]
+        hyp_b = torch.stack(hyps)
+        prob_pre = cost_regularization(model.cost_regularization[s], torch.stack(vols)).squeeze(1)
+        prob = F.softmax(prob_pre, dim=1)
+        depth = torch.sum(prob * hyp_b, dim=1)
+        with torch.no_grad():
+            conf = torch.stack([ops.softargmin_conf(prob_pre[b].detach().contiguous(), hyp_b[b])[1] for b in range(B)])
+        st = {"depth": depth, "photometric_confidence": conf, "feat_distance": torch.stack(fds), "norm_curv": nc_mean}
+        if gt_depths is not None:                                            # model.py:202-207
+            gt_s = gt_depths[name].unsqueeze(1)
+            di_stage = dint_all.to(dev).view(B, 1, 1, 1) * float(scale)
+            target = ((hyp_b - gt_s).abs() / di_stage < 0.5 / float(scale)).float()
+            st["feat_target"] = torch.cat((target, torch.ones_like(gt_s)), dim=1)
+        outputs[name] = st
+        outputs.update(st)
+    if model.refine:
+        dvd = depth_values.float()
+        dint = (dvd[:, 1] - dvd[:, 0]).view(B, 1, 1)
+        refined = model.refine_network(imgs[:, 0], (depth.detach() / dint).unsqueeze(1), dvd[:, 0] / dint[:, 0, 0],
+                                       dvd[:, -1] / dint[:, 0, 0])
+        outputs["refined_depth"] = refined.squeeze(1) * dint
+    else:
+        outputs["refined_depth"] = depth
+    return outputs

@@ -217,3 +217,45 @@ if __name__ == "__main__":
     g4_hypotheses()
     g5_features()
     g6_forward()
+    g7_training_step()
+
+
+def g7_training_step():
+    """Reference training step on CPU (model.train(), gt depths, final_loss, backward): loss and per-parameter gradient
+    norms.  B = 2 so every BatchNorm sees real batch statistics."""
+    from models.losses import final_loss as ref_loss
+    torch.manual_seed(0)
+    B, N, H, W = 2, 3, 64, 96
+    model = RefNet(refine=False, ndepths=(48, 32, 8), depth_interals_ratio=(4.0, 2.0, 1.0))
+    seeded_init_(model, SEED)
+    model.train()
+    imgs = torch.cat([synth.make_images(N, H, W, seed=20 + b) for b in range(B)])
+    cams_l = [synth.make_cameras(N, H, W, refine=False, seed=20 + b) for b in range(B)]
+    cams = {k: torch.cat([c[k] for c in cams_l]) for k in cams_l[0]}
+    dv = synth.make_depth_values().repeat(B, 1)
+    g = torch.Generator().manual_seed(9)
+    gt, mask = {}, {}
+    base = 600.0 + 120.0 * F.interpolate(torch.rand(B, 1, 4, 6, generator=g), (H, W), mode="bicubic", align_corners=False)[:, 0]
+    for s, sc in (("stage1", 4), ("stage2", 2), ("stage3", 1)):
+        gt[s] = F.interpolate(base.unsqueeze(1), (H // sc, W // sc), mode="nearest")[:, 0].contiguous()
+        mask[s] = (torch.rand(B, H // sc, W // sc, generator=g) > 0.15).float()
+    gt["stage4"], mask["stage4"] = gt["stage3"], mask["stage3"]   # refine=False: refined_depth is the stage-3 depth
+    out = model(imgs, cams, dv, gt_depths=gt, temperature=0.1)
+    loss, depth_loss = ref_loss(out, gt, mask, dlossw=[0.5, 1.0, 2.0], depth_interval=dv[:, 1] - dv[:, 0])
+    loss.backward()
+    names, norms = [], []
+    for n, p in model.named_parameters():
+        names.append(n)
+        norms.append(0.0 if p.grad is None else float(p.grad.norm()))
+    arrays = {"imgs": imgs, "depth_values": dv, "loss": loss.detach(), "depth_loss": depth_loss.detach(),
+              "grad_norms": np.array(norms, dtype=np.float64), "param_names": np.array(names),
+              "stage3_depth": out["stage3"]["depth"].detach(), "stage1_feat_distance_mean": out["stage1"]["feat_distance"].detach().mean(),
+              "grad_prob3": model.cost_regularization[2].prob.weight.grad.clone(),
+              "grad_vis0": model.stage_net.vis[0][3].weight.grad.clone()}
+    for k, v in cams.items():
+        arrays["cam_" + k] = v
+    for s in gt:
+        arrays["gt_" + s] = gt[s]
+        arrays["mask_" + s] = mask[s]
+    save("g7_training_step", **arrays)
+    print("loss", float(loss), "depth_loss", float(depth_loss), "zero-grad params", sum(1 for x in norms if x == 0.0), "of", len(norms))

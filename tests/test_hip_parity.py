@@ -476,3 +476,34 @@ def test_warp_aggregate_backward_vs_autograd(V, C, D, h, w, dev, ops):
     for name, a, b in (("ref", ref_d.grad, ref.grad), ("src", src_d.grad, src.grad), ("vis", vis_d.grad, vis.grad)):
         err = (a.cpu() - b).abs().max().item()
         assert err < 2e-4 * max(1.0, b.abs().max().item()), (name, err)
+
+
+def test_training_step_matches_reference(dev):
+    """model.train() forward + final_loss + backward against the reference's CPU training step
+    (tests/golden/g7_training_step.npz): loss, depth, and every parameter's gradient norm."""
+    from cds_mvsnet_amd import CDSMVSNet, final_loss, seeded_init_
+    g = load_golden("g7_training_step")
+    model = seeded_init_(CDSMVSNet(refine=False, ndepths=(48, 32, 8), depth_interals_ratio=(4.0, 2.0, 1.0)), 7).to(dev).train()
+    cams = {k[4:]: v.to(dev) for k, v in g.items() if k.startswith("cam_")}
+    gt = {k[3:]: v.to(dev) for k, v in g.items() if k.startswith("gt_")}
+    mask = {k[5:]: v.to(dev) for k, v in g.items() if k.startswith("mask_")}
+    dv = g["depth_values"].to(dev)
+    out = model(g["imgs"].to(dev), cams, dv, gt_depths=gt, temperature=0.1)
+    assert set(out["stage1"].keys()) == {"depth", "photometric_confidence", "feat_distance", "norm_curv", "feat_target"}
+    assert out["stage2"]["feat_distance"].shape == (2, 33, 32, 48) and out["stage2"]["feat_target"].shape == (2, 33, 32, 48)
+    loss, depth_loss = final_loss(out, gt, mask, dlossw=[0.5, 1.0, 2.0], depth_interval=dv[:, 1] - dv[:, 0])
+    loss.backward()
+    assert abs(loss.item() - float(g["loss"])) < 2e-3 * abs(float(g["loss"]))
+    assert abs(depth_loss.item() - float(g["depth_loss"])) < 2e-3 * abs(float(g["depth_loss"]))
+    assert (out["stage3"]["depth"].detach().cpu() - g["stage3_depth"]).abs().mean() < 5e-3
+    names = [str(n) for n in g["param_names"]]
+    want = dict(zip(names, g["grad_norms"]))
+    got = {n: float(p.grad.norm()) for n, p in model.named_parameters()}
+    assert set(got) == set(want)
+    rel = {n: abs(got[n] - want[n]) / max(want[n], 1e-6) for n in want}
+    worst = max(rel, key=rel.get)
+    assert rel[worst] < 0.03, (worst, got[worst], want[worst])
+    assert sorted(rel.values())[len(rel) // 2] < 2e-3          # median parameter: 0.2 %
+    assert (model.cost_regularization[2].prob.weight.grad.cpu() - g["grad_prob3"]).abs().max() < 2e-3 * g["grad_prob3"].abs().max()
+    # BatchNorm running statistics were updated by the step (training-mode BN, momentum 0.1)
+    assert model.cost_regularization[0].conv0.bn.num_batches_tracked.item() == 101

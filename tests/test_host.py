@@ -73,7 +73,7 @@ def test_no_cpu_fallback():
     imgs = synth.make_images(3, 64, 64)
     with pytest.raises(RuntimeError):
         m(imgs, synth.make_cameras(3, 64, 64), synth.make_depth_values())
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(RuntimeError):
         m.train()(imgs, synth.make_cameras(3, 64, 64), synth.make_depth_values())
 
 
