@@ -186,7 +186,7 @@ def main():
                 traffic = json.load(open(pmc)).get(args.workload, {}).get("warp_aggregate_hbm_bytes")
             except Exception:
                 traffic = None
-        roof = {"kernel": "warp_aggregate_kernel (K3, fused homography warp + visibility-weighted aggregation)",
+        roof = {"kernel": "warp_aggregate_lds_kernel (K3, fused homography warp + visibility-weighted aggregation)",
                 "bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK, "frac_of_measured_copy_ceiling": achieved / 6.29e12,
                 "algorithmic_bytes": b_alg, "kernel_ms": kern["warp_aggregate"], "traffic": traffic}

@@ -64,6 +64,20 @@ def run(args) -> float:
             print(f"[{rank}] {idx + 1}/{len(data)} {s['filename'].format('depth_est', '.pfm')} {times[-1] * 1e3:.1f} ms", flush=True)
     avg = float(np.mean(times)) if times else 0.0
     print(f"[{rank}] average time: {avg:.4f} s over {len(times)} depth maps")
+    if args.fuse:
+        # step 2 of the reference's test.py (pcd_filter, test.py:386-396): scans are independent -> shard over ranks
+        from .fusion import filter_depth
+        if world > 1:  # every rank's depth maps must be on disk before any scan is fused
+            if not torch.distributed.is_initialized():
+                torch.distributed.init_process_group("nccl", device_id=dev)
+            torch.distributed.barrier()
+        for i, scan in enumerate(scans):
+            if i % world != rank:
+                continue
+            info = filter_depth(os.path.join(args.testpath, scan), os.path.join(args.outdir, scan),
+                                os.path.join(args.outdir, f"{scan}.ply"), conf=[float(c) for c in args.conf.split(",")],
+                                thres_disp=args.thres_disp, thres_view=args.thres_view, device=str(dev))
+            print(f"[{rank}] {scan}.ply: {info['points']} points, final mask {info['mean_final_mask']:.3f}", flush=True)
     return avg
 
 
@@ -81,6 +95,10 @@ def main(argv=None):
     ap.add_argument("--max_w", type=int, default=640)
     ap.add_argument("--temperature", type=float, default=0.01)
     ap.add_argument("--dataset", default="dtu", choices=["dtu", "tt", "general"])
+    ap.add_argument("--fuse", action="store_true", help="filter + fuse the saved depth maps into <outdir>/<scan>.ply")
+    ap.add_argument("--conf", default="0.0,0.0,0.0", help="per-stage confidence thresholds (test.py:61)")
+    ap.add_argument("--thres_view", type=int, default=3)
+    ap.add_argument("--thres_disp", type=float, default=1.0)
     run(ap.parse_args(argv))
 
 

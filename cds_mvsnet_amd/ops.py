@@ -299,3 +299,30 @@ def instnorm_act(x: Tensor, act: int, out_hwc: bool = False) -> Tensor:
     check(_lib.load().cds_instnorm_act_f32(_dev(x, "x"), out.data_ptr(), stats.data_ptr(), N, C, H, W, act,
                                            1 if out_hwc else 0, _stream(x)), "cds_instnorm_act_f32")
     return out
+
+
+def depth_fusion(ref_depth: Tensor, ref_conf: Tensor, src_depths: Tensor, src_confs: Tensor, cams: Tensor,
+                 prob_thresh, dist_thresh: float, depth_thresh: float, view_thresh: float,
+                 want_view_masks: bool = False):
+    """Depth-map filtering + average fusion for one reference view (fusion.py:75-114, test.py:334-351).
+    ref_depth [h,w], ref_conf [3,h,w], src_depths [V,h,w], src_confs [V,3,h,w], cams [V,100] (device, layout in
+    include/cds_mvsnet_hip.h) -> (fused [h,w], mask [h,w] in {0,1}, points [3,h,w], view_masks [V,h,w] | None)."""
+    V, h, w = src_depths.shape
+    if tuple(ref_depth.shape) != (h, w) or tuple(ref_conf.shape) != (3, h, w) or tuple(src_confs.shape) != (V, 3, h, w) \
+            or tuple(cams.shape) != (V, 100):
+        raise ValueError("depth_fusion: inconsistent shapes")
+    dev = ref_depth.device
+    fused = torch.empty((h, w), dtype=torch.float32, device=dev)
+    mask = torch.empty((h, w), dtype=torch.float32, device=dev)
+    points = torch.empty((3, h, w), dtype=torch.float32, device=dev)
+    vm = torch.empty((V, h, w), dtype=torch.float32, device=dev) if want_view_masks else None
+    th = torch.tensor([float(p) for p in prob_thresh], dtype=torch.float32)
+    if th.numel() != 3:
+        raise ValueError("depth_fusion: three confidence thresholds expected")
+    check(_lib.load().cds_depth_fusion_f32(_dev(ref_depth, "ref_depth"), _dev(ref_conf, "ref_conf"),
+                                           _dev(src_depths, "src_depths"), _dev(src_confs, "src_confs"),
+                                           _dev(cams, "cams"), fused.data_ptr(), mask.data_ptr(), points.data_ptr(),
+                                           vm.data_ptr() if vm is not None else None, V, h, w, _host(th, "prob_thresh"),
+                                           float(dist_thresh), float(depth_thresh), float(view_thresh),
+                                           _stream(fused)), "cds_depth_fusion_f32")
+    return fused, mask, points, vm

@@ -109,3 +109,35 @@ def make_hypotheses(D: int, h: int, w: int, lo: float = 425.0, hi: float = 902.5
     g = torch.Generator().manual_seed(seed + 1000)
     planes = torch.linspace(lo, hi, D).view(1, D, 1, 1)
     return (planes + jitter * torch.rand(1, D, h, w, generator=g)).contiguous()
+
+
+def make_fusion_scene(n_views: int, h: int, w: int, seed: int = 0, outlier_frac: float = 0.15) -> Dict[str, Tensor]:
+    """Geometrically consistent depth maps for the filtering / fusion step: every camera of ``make_cameras`` looks at
+    the height field Z = 650 + 40 sin(X/60) cos(Y/50) (world = reference-camera frame); per-view depth = camera-frame z of
+    the ray/surface intersection (fixed-point iteration in float64).  A fraction of the pixels gets a ±(2..6)% depth
+    error so that the geometric masks are mixed; confidences are uniform in [0,1).
+    -> depths [N,h,w], confs [N,3,h,w], cams [N,2,4,4] (intrinsic [3,3] = 1), imgs [N,h,w,3]."""
+    cams = make_cameras(n_views, h, w, refine=False, seed=seed)["stage3"][0].clone()
+    cams[:, 1, 3, 3] = 1.0
+    rs = np.random.RandomState(seed + 77)
+    ys, xs = np.meshgrid(np.arange(h) + 0.5, np.arange(w) + 0.5, indexing="ij")
+    pix = np.stack([xs, ys, np.ones_like(xs)], 0).reshape(3, -1)
+    depths = []
+    for i in range(n_views):
+        E = cams[i, 0].double().numpy()
+        K = cams[i, 1, :3, :3].double().numpy()
+        R, t = E[:3, :3], E[:3, 3:4]
+        d = np.linalg.inv(K) @ pix                         # camera-frame rays with z = 1
+        rd, rt = R.T @ d, R.T @ t
+        lam = np.full(pix.shape[1], 650.0)
+        for _ in range(20):
+            P = rd * lam - rt
+            surf = 650.0 + 40.0 * np.sin(P[0] / 60.0) * np.cos(P[1] / 50.0)
+            lam = (surf + rt[2]) / rd[2]
+        dep = lam.reshape(h, w)
+        bad = rs.rand(h, w) < outlier_frac
+        dep = np.where(bad, dep * (1.0 + rs.choice([-1.0, 1.0], (h, w)) * rs.uniform(0.02, 0.06, (h, w))), dep)
+        depths.append(dep.astype(np.float32))
+    g = torch.Generator().manual_seed(seed + 5)
+    return {"depths": torch.from_numpy(np.stack(depths)), "confs": torch.rand(n_views, 3, h, w, generator=g),
+            "cams": cams.contiguous(), "imgs": torch.rand(n_views, h, w, 3, generator=g)}

@@ -177,6 +177,19 @@ int cds_dynconv_blend_f32(const float* branches, const float* w1, const float* b
 int cds_instnorm_act_f32(const float* x, float* out, float* stats, int N, int C, int H, int W, int act,
                          int out_hwc, void* stream);
 
+/*
+ * Depth-map filtering + fusion (fusion.py:7-114, test.py:334-351).  Per reference pixel and source
+ * view: re-projection through the source depth map, pixel-distance / relative-depth / in-range tests, average fusion.
+ *   ref_depth [h][w]; ref_conf [3][h][w]; src_depths [V][h][w]; src_confs [V][3][h][w] (probability filter
+ *   conf_k > prob_thresh_host[k] applied to the source depths and to the final mask)
+ *   cams [V][100]: per view Kinv_ref(9) Einv_ref(16) E_src(16) K_src(9) Kinv_src(9) Einv_src(16) E_ref(16) K_ref(9)
+ *   fused [h][w], mask [h][w] (0/1), points [3][h][w] (world), view_masks [V][h][w] or NULL
+ */
+int cds_depth_fusion_f32(const float* ref_depth, const float* ref_conf, const float* src_depths,
+                         const float* src_confs, const float* cams, float* fused, float* mask, float* points,
+                         float* view_masks, int V, int h, int w, const float* prob_thresh_host,
+                         float dist_thresh, float depth_thresh, float view_thresh, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -494,3 +494,71 @@ def forward(imgs: Tensor, proj_matrices: Dict[str, Tensor], depth_values: Tensor
     else:
         out["refined_depth"] = depth
     return out
+
+
+# ----------------------------------------------------------------------------
+# a16  depth-map filtering + average fusion  (fusion.py:7-114, test.py:334-351)
+# ----------------------------------------------------------------------------
+def _pixel_centres(h: int, w: int) -> Tensor:
+    """[h,w,3,1] homogeneous pixel centres (x+0.5, y+0.5, 1) (fusion.py:7-12)."""
+    ys, xs = torch.meshgrid(torch.arange(h, dtype=torch.float32) + 0.5, torch.arange(w, dtype=torch.float32) + 0.5,
+                            indexing="ij")
+    return torch.stack([xs, ys, torch.ones_like(xs)], -1).unsqueeze(-1)
+
+
+def _lift_and_project(pix: Tensor, depth: Tensor, cam_from: Tensor, cam_to: Tensor) -> Tuple[Tensor, Tensor]:
+    """pix [h,w,3,1], depth [h,w], cams [2,4,4] -> (image coords [h,w,2] in cam_to, depth [h,w] in cam_to), with the
+    reference's +1e-9 homogeneous normalisation after every step (fusion.py:24-46)."""
+    ray = torch.inverse(cam_from[1, :3, :3]) @ pix
+    pc = ray / (ray[..., -1:, :] + 1e-9) * depth[..., None, None]
+    pc = torch.cat([pc, torch.ones_like(pc[..., -1:, :])], -2)
+    pw = torch.inverse(cam_from[0]) @ pc
+    pw = pw / (pw[..., -1:, :] + 1e-9)
+    po = cam_to[0] @ pw
+    po = po / (po[..., -1:, :] + 1e-9)
+    q = po[..., :3, :] / (po[..., 3:4, :] + 1e-9)
+    im = cam_to[1, :3, :3] @ q
+    im = im / (im[..., -1:, :] + 1e-9)
+    return im[..., :2, 0], po[..., 2, 0]
+
+
+def confidence_mask(conf: Tensor, thresh) -> Tensor:
+    """conf [3,h,w] -> bool [h,w]: every stage confidence above its threshold (fusion.py:64-72)."""
+    m = torch.ones_like(conf[0], dtype=torch.bool)
+    for i, p in enumerate(thresh):
+        m = m & (conf[i] > p)
+    return m
+
+
+def fuse_view(ref_depth: Tensor, ref_conf: Tensor, ref_cam: Tensor, src_depths: Tensor, src_confs: Tensor,
+              src_cams: Tensor, conf=(0.0, 0.0, 0.0), thres_disp: float = 1.0, thres_view: int = 3,
+              depth_thresh: float = 0.01) -> Dict[str, Tensor]:
+    """One reference view of test.py:334-351.  ref_depth [h,w], ref_conf [3,h,w], src_depths [V,h,w],
+    src_confs [V,3,h,w], cams [2,4,4] / [V,2,4,4] -> fused depth, final mask, world points, per-view masks."""
+    h, w = ref_depth.shape
+    pix = _pixel_centres(h, w)
+    view_masks, reproj_d = [], []
+    for v in range(src_depths.shape[0]):
+        sd = src_depths[v] * confidence_mask(src_confs[v], conf).float()
+        xy_sr, d_sr = _lift_and_project(pix, sd, src_cams[v], ref_cam)            # source pixel -> reference view
+        xyd = torch.cat([xy_sr, d_sr.unsqueeze(-1)], -1).permute(2, 0, 1).unsqueeze(0)   # [1,3,h,w]
+        xy_rs, _ = _lift_and_project(pix, ref_depth, ref_cam, src_cams[v])        # reference pixel -> source view
+        grid = torch.stack([xy_rs[..., 0] / w, xy_rs[..., 1] / h], -1)
+        grid = (grid * 2 - 1).clamp(-1.1, 1.1)
+        inside = ((grid[..., 0] >= -1) & (grid[..., 0] <= 1) & (grid[..., 1] >= -1) & (grid[..., 1] <= 1))
+        rep = F.grid_sample(xyd, grid.unsqueeze(0), mode="bilinear", padding_mode="zeros", align_corners=True)[0]
+        dist_ok = (rep[:2] - pix[..., :2, 0].permute(2, 0, 1)).norm(dim=0) < thres_disp
+        depth_ok = (ref_depth - rep[2]).abs() < torch.max(ref_depth, rep[2]) * depth_thresh
+        view_masks.append((inside & dist_ok & depth_ok).float())
+        reproj_d.append(rep[2])
+    vm, rz = torch.stack(view_masks), torch.stack(reproj_d)
+    geo = vm.sum(0) >= (thres_view - 1.1)
+    fused = ((rz * vm).sum(0) + ref_depth) / (vm.sum(0) + 1)
+    mask = geo & confidence_mask(ref_conf, conf)
+    ray = torch.inverse(ref_cam[1, :3, :3]) @ pix
+    pc = ray / (ray[..., -1:, :] + 1e-9) * fused[..., None, None]
+    pc = torch.cat([pc, torch.ones_like(pc[..., -1:, :])], -2)
+    pw = torch.inverse(ref_cam[0]) @ pc
+    pw = pw / (pw[..., -1:, :] + 1e-9)
+    return {"depth": fused, "mask": mask.float(), "points": pw[..., :3, 0].permute(2, 0, 1), "view_masks": vm,
+            "reproj_depth": rz}

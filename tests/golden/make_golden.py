@@ -210,16 +210,6 @@ def g6_forward():
         save(f"g6_forward_{tag}", **arrays)
 
 
-if __name__ == "__main__":
-    g1_warp_aggregate()
-    g2_costreg()
-    g3_regress()
-    g4_hypotheses()
-    g5_features()
-    g6_forward()
-    g7_training_step()
-
-
 def g7_training_step():
     """Reference training step on CPU (model.train(), gt depths, final_loss, backward): loss and per-parameter gradient
     norms.  B = 2 so every BatchNorm sees real batch statistics."""
@@ -259,3 +249,46 @@ def g7_training_step():
         arrays["mask_" + s] = mask[s]
     save("g7_training_step", **arrays)
     print("loss", float(loss), "depth_loss", float(depth_loss), "zero-grad params", sum(1 for x in norms if x == 0.0), "of", len(norms))
+
+
+def g8_fusion():
+    """Reference depth filtering / fusion (fusion.py, driven as test.py:334-351 drives it) on a synthetic consistent
+    scene.  fusion.py builds its pixel grids with ``.cuda()``; there is no GPU here, so ``Tensor.cuda`` is made an
+    identity for the duration of the call (CPU fp32 run of the same functions)."""
+    import fusion as ref_fusion
+    orig = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        sc = synth.make_fusion_scene(5, 96, 128, seed=3)
+        conf, thres_disp, thres_view = [0.1, 0.05, 0.02], 1.0, 3
+        ref_depth = sc["depths"][0][None, None]                 # n1hw
+        ref_conf = sc["confs"][0][None]                          # n3hw
+        src_depths = sc["depths"][1:][None, :, None].clone()    # nv1hw
+        src_confs = sc["confs"][1:][None]                        # nv3hw
+        ref_cam, src_cams = sc["cams"][0][None], sc["cams"][1:][None]
+        for ids in range(src_depths.size(1)):
+            m = ref_fusion.prob_filter(src_confs[:, ids, ...], conf)
+            src_depths[:, ids, ...] *= m.float()
+        prob_mask = ref_fusion.prob_filter(ref_conf, conf)
+        reproj_xyd, in_range = ref_fusion.get_reproj(ref_depth, src_depths, ref_cam, src_cams)
+        vis_masks, vis_mask = ref_fusion.vis_filter(ref_depth, reproj_xyd, in_range, thres_disp, 0.01, thres_view)
+        ave = ref_fusion.ave_fusion(ref_depth, reproj_xyd, vis_masks)
+        mask = ref_fusion.bin_op_reduce([prob_mask, vis_mask], torch.min)
+        idx_img = ref_fusion.get_pixel_grids(*ave.size()[-2:]).unsqueeze(0)
+        idx_cam = ref_fusion.idx_img2cam(idx_img, ave, ref_cam)
+        points = ref_fusion.idx_cam2world(idx_cam, ref_cam)[..., :3, 0].permute(0, 3, 1, 2)
+    finally:
+        torch.Tensor.cuda = orig
+    save("g8_fusion", depths=sc["depths"], confs=sc["confs"], cams=sc["cams"], conf=np.array(conf, np.float32),
+         thres_disp=thres_disp, thres_view=thres_view, fused=ave[0, 0], mask=mask[0, 0].float(), points=points[0],
+         view_masks=vis_masks[0, :, 0], reproj_xyd=reproj_xyd[0])
+    print("photo/geo/final", float(prob_mask.float().mean()), float(vis_mask.float().mean()), float(mask.float().mean()),
+          "per-view", vis_masks[0, :, 0].mean(dim=(1, 2)))
+
+
+if __name__ == "__main__":
+    only = sys.argv[1:]
+    for fn in (g1_warp_aggregate, g2_costreg, g3_regress, g4_hypotheses, g5_features, g6_forward, g7_training_step,
+               g8_fusion):
+        if not only or fn.__name__.split("_")[0] in only:
+            fn()
