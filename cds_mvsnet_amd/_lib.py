@@ -11,7 +11,8 @@ import os
 from ctypes import c_float, c_int, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcdsmvs_hip.so")
+# CDS_MVSNET_LIB: developer knob to A/B a differently built copy of the same library (scripts/build_variant.sh)
+LIB_PATH = os.environ.get("CDS_MVSNET_LIB") or os.path.join(_HERE, "libcdsmvs_hip.so")
 
 # activation / flag codes (mirror include/cds_mvsnet_hip.h)
 ACT_NONE, ACT_RELU, ACT_LEAKY01, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3, 4

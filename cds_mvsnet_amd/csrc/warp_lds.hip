@@ -9,7 +9,7 @@
 //
 // LDS image of a box: two planes [BH][BW] of float4 (channels 0-3 and 4-7) so that consecutive lanes, which
 // sample (nearly) consecutive texels, read consecutive 16-byte slots (conflict-free ds_read_b128).
-// Robustness: the box is the min/max over every lane's own first/last plane of the chunk; any tap that still
+// Robustness: the box is the min/max over every lane's cells at the chunk's smallest/largest depth; any tap that still
 // falls outside it (non-monotone hypotheses, projective pole) and any box larger than the LDS budget take the
 // original global-memory path per lane / per block, so results never depend on the geometry assumptions.
 // Arithmetic and operation order are identical to warp.hip (same cds_taps / cds_interp).
@@ -24,7 +24,7 @@ namespace {
 #define CDS_K3_TH 4
 #define CDS_K3_BOX 504
 #define CDS_K3_DC 32
-#define CDS_K3_MINW 1
+#define CDS_K3_MINW 2
 #endif
 constexpr int C8 = 8;
 constexpr int TW = CDS_K3_TW, TH = CDS_K3_TH;  // reference-pixel tile of a workgroup (TW*TH = 256)
@@ -41,6 +41,32 @@ struct Box {
   int x0, y0, bw, bh;  // origin, width, height in texels (block-uniform)
   bool staged;
 };
+// What the branch-free path keeps live in the plane loop: cells (x0f, y0f) with fx0 <= x0f <= fx1 and
+// fy0 <= y0f <= fy1 have all four texels in the box; org = y0 * bw + x0 is the linear index of the box origin.
+// The cell is first clamped to [-2, n] (everything further out is zero padding, like the border cells), then into the
+// box; the second clamp must be a no-op for the fast path to be valid.
+struct FastBox {
+  float fx0, fx1, fy0, fy1;   // cells of the box whose four texels are all staged
+  int bw, org;
+};
+__device__ __forceinline__ FastBox fast_box(const Box& b, int h, int w) {
+  FastBox f;
+  f.fx0 = (float)b.x0;
+  f.fx1 = (float)(b.x0 + b.bw - 2);
+  f.fy0 = (float)b.y0;
+  f.fy1 = (float)(b.y0 + b.bh - 2);
+  (void)h; (void)w;
+  f.bw = b.bw;
+  f.org = b.y0 * b.bw + b.x0;
+  return f;
+}
+// The generic path re-reads the box from LDS (int[4] per view, written by reduce_boxes) instead of pinning SGPRs.
+__device__ __forceinline__ Box load_box(const int* p) {
+  Box b;
+  b.x0 = p[0]; b.y0 = p[1]; b.bw = p[2]; b.bh = p[3];
+  b.staged = b.bw > 0;
+  return b;
+}
 
 __device__ __forceinline__ int wave_min(int v) {
 #pragma unroll
@@ -69,6 +95,23 @@ __device__ __forceinline__ void cell_of(const float r[3], const float* __restric
   fy = fminf(fy, (float)h);
   cx = (int)fx;
   cy = (int)fy;
+}
+
+// Smallest and largest hypothesis of a chunk for this pixel.  The sample position is a Moebius function of the depth,
+// so every plane of the chunk lands between the positions of these two (up to fp32 rounding and a projective pole
+// inside the interval, both caught by the fast path's acceptance test); first/last plane alone is not enough because
+// per-pixel hypotheses need not be monotone.
+__device__ __forceinline__ void chunk_depth_range(const float* __restrict__ hyp, unsigned hw, unsigned pix, int d0, int d1,
+                                                  float& dlo, float& dhi) {
+  dlo = INFINITY;
+  dhi = -INFINITY;
+  const float* p = hyp + (size_t)d0 * hw + pix;
+#pragma unroll 8
+  for (int d = d0; d < d1; ++d, p += hw) {
+    const float v = *p;
+    dlo = fminf(dlo, v);
+    dhi = fmaxf(dhi, v);
+  }
 }
 
 // Block-wide bounding boxes for NV views.  lo/hi: this thread's cells at the chunk's first and last plane.
@@ -117,6 +160,10 @@ __device__ __forceinline__ void reduce_boxes(const int cx0[NV], const int cy0[NV
     box[v].bw = __builtin_amdgcn_readfirstlane(ok ? bw : 0);
     box[v].bh = __builtin_amdgcn_readfirstlane(ok ? bh : 0);
     box[v].staged = __builtin_amdgcn_readfirstlane((int)ok) != 0;
+    if (threadIdx.x == 0) {  // copy for the generic path (visible after the staging barrier)
+      int* q = red + 4 * NV * 4 + v * 4;
+      q[0] = box[v].x0; q[1] = box[v].y0; q[2] = box[v].bw; q[3] = box[v].bh;
+    }
   }
 }
 
@@ -244,6 +291,33 @@ __device__ __forceinline__ void fetch_cell(float x0f, float y0f, const Geo& g, c
   }
 }
 
+// Branch-free variant for the common case: the cell is clamped into the staged box in the float domain (so the LDS
+// address is always valid) and the caller is told whether the clamp changed anything.  If any lane of the wave
+// reports a changed cell (or a box is not staged) the caller redoes the plane pair with fetch_cell.
+template <int CAP>
+__device__ __forceinline__ bool cell_addr_fast(float x0f, float y0f, float wf, float hf, const FastBox& b,
+                                               const cds_f4* __restrict__ lds, const cds_f4*& r0, const cds_f4*& r1) {
+  const float xa = __builtin_amdgcn_fmed3f(x0f, -2.0f, wf);
+  const float ya = __builtin_amdgcn_fmed3f(y0f, -2.0f, hf);
+  const float xc = __builtin_amdgcn_fmed3f(xa, b.fx0, b.fx1);
+  const float yc = __builtin_amdgcn_fmed3f(ya, b.fy0, b.fy1);
+#ifdef CDS_EXP_LDS_BCAST
+  const int idx = 0 * ((int)yc + (int)xc);
+#else
+  const int idx = __mul24((int)yc, b.bw) + (int)xc - b.org;
+#endif
+  r0 = lds + idx;
+  r1 = r0 + b.bw;
+  return (xc == xa) & (yc == ya);
+}
+template <int CAP>
+__device__ __forceinline__ void load_cell(const cds_f4* r0, const cds_f4* r1, Tex8 t[4]) {
+  t[0].lo = r0[0]; t[0].hi = r0[CAP];
+  t[1].lo = r0[1]; t[1].hi = r0[CAP + 1];
+  t[2].lo = r1[0]; t[2].hi = r1[CAP];
+  t[3].lo = r1[1]; t[3].hi = r1[CAP + 1];
+}
+
 // bilinear interpolation of the 8 channels as four channel pairs (v_pk_mul / v_pk_fma), cds_interp's operation order
 __device__ __forceinline__ void interp8(const Tex8 t[4], const float wgt[4], v2f o[4]) {
   const v2f w0 = splat2(wgt[0]), w1 = splat2(wgt[1]), w2 = splat2(wgt[2]), w3 = splat2(wgt[3]);
@@ -275,7 +349,7 @@ __device__ __forceinline__ void plane_weights(v2f ix, v2f iy, v2f& x0f, v2f& y0f
 // Two planes per iteration so the position / weight arithmetic issues as packed fp32 (v_pk_*).
 // Accumulation: volume += (ref*vis) * warp as one fma per channel (re-association of the reference's
 // (ref*warp)*vis, <= 2 ulp of a value below 1).  Normalisation a/(vis_sum+1e-6): reciprocal refined once per
-// pixel, quotient corrected with two fmas (correctly rounded like the IEEE sequence, 3 instead of ~10 VALU ops).
+// pixel and folded into the (ref*vis) factors.
 // Addressing: per-channel slab base (uniform) + one 32-bit byte offset per plane (slab = D*h*w*4 < 4 GB).
 // ---------------------------------------------------------------------------------------------
 template <int VMAX, bool ACCUMULATE, bool NORMALIZE>
@@ -283,7 +357,7 @@ __global__ __launch_bounds__(256, CDS_K3_MINW) void warp_aggregate_lds_kernel(
     const float* __restrict__ ref, const float* __restrict__ src, const float* __restrict__ vis, WarpMats mats,
     const float* __restrict__ hyp, float* __restrict__ volume, const float* __restrict__ vis_sum, int V, int D, int h,
     int w, float rhw, float rhh, int flags, int tiles_x, int ntiles, int nseg, int seg_planes) {
-  extern __shared__ __attribute__((aligned(16))) cds_f4 lds4[];  // VMAX * 2*BOX_CAP float4, then int red[4*VMAX*4]
+  extern __shared__ __attribute__((aligned(16))) cds_f4 lds4[];  // VMAX * 2*BOX_CAP float4, then int red[4*VMAX*4], int boxes[VMAX*4]
   int* red = reinterpret_cast<int*>(lds4 + VMAX * 2 * BOX_CAP);
 
   // depth segment is the fastest-varying index: the nseg blocks of a tile run together and share its features in L2
@@ -307,7 +381,7 @@ __global__ __launch_bounds__(256, CDS_K3_MINW) void warp_aggregate_lds_kernel(
   float r[VMAX][3];
 #pragma unroll
   for (int v = 0; v < VMAX; ++v) {
-    if (v < V) {
+    {
       const float vw = vis[(size_t)v * hw + pix];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -319,31 +393,53 @@ __global__ __launch_bounds__(256, CDS_K3_MINW) void warp_aggregate_lds_kernel(
   }
   constexpr bool accumulate = ACCUMULATE, normalize = NORMALIZE;
   (void)flags;
-  const float denom = (normalize ? vis_sum[pix] : 1.0f) + 1e-6f;
-  float yden = __builtin_amdgcn_rcpf(denom);
-  yden = fmaf(fmaf(-denom, yden, 1.0f), yden, yden);
+  // Normalisation volume_sum / (vis_sum + 1e-6) is folded into the per-pixel factors: (ref * vis) * RN(1/denom)
+  // (a re-association of the reference's division, a few ulp of a value below 1; no per-plane work left).
+  const float yden = normalize ? 1.0f / (vis_sum[pix] + 1e-6f) : 1.0f;
+  if (normalize) {
+#pragma unroll
+    for (int v = 0; v < VMAX; ++v)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) rv[v][j] = rv[v][j] * yden;
+  }
   const char* hyp_b = reinterpret_cast<const char*>(hyp);
+  const float wf = (float)w, hf = (float)h;
 
   const int dseg0 = seg * seg_planes, dseg1 = min(D, dseg0 + seg_planes);
-  for (int d0 = dseg0; d0 < dseg1; d0 += DC) {
-    const int d1 = min(dseg1, d0 + DC);
-    int cx0[VMAX], cy0[VMAX], cx1[VMAX], cy1[VMAX];
-    const float dfirst = hyp[(size_t)d0 * hw + pix], dlast = hyp[(size_t)(d1 - 1) * hw + pix];
+  for (int d0 = dseg0, d1 = 0; d0 < dseg1; d0 = d1) {
+    d1 = min(dseg1, d0 + DC);
+    Box box[VMAX];
+    // Adaptive chunk length: if some view's footprint over DC planes does not fit its LDS budget (~10 % of the
+    // tiles at M1), halve the chunk instead of sending the whole tile down the global-memory path.
+    for (;;) {
+      int cx0[VMAX], cy0[VMAX], cx1[VMAX], cy1[VMAX];
+      float dfirst, dlast;
+      chunk_depth_range(hyp, hw, pix, d0, d1, dfirst, dlast);
 #pragma unroll
-    for (int v = 0; v < VMAX; ++v) {
-      cx0[v] = cy0[v] = cx1[v] = cy1[v] = 0;
-      if (v < V) {
+      for (int v = 0; v < VMAX; ++v) {
         cell_of(r[v], mats.m[v] + 9, dfirst, h, w, g.half_w, g.half_h, cx0[v], cy0[v]);
         cell_of(r[v], mats.m[v] + 9, dlast, h, w, g.half_w, g.half_h, cx1[v], cy1[v]);
       }
+      __syncthreads();  // previous chunk's LDS reads are done (also protects `red`)
+      reduce_boxes<VMAX, BOX_CAP>(cx0, cy0, cx1, cy1, active, VMAX, h, w, red, box);
+      bool fits = true;
+#pragma unroll
+      for (int v = 0; v < VMAX; ++v) fits = fits && box[v].staged;
+      if (fits || d1 - d0 <= 8) break;
+      d1 = d0 + ((((d1 - d0) >> 1) + 1) & ~1);  // even length: plane pairs stay whole
     }
-    Box box[VMAX];
-    __syncthreads();  // previous chunk's LDS reads are done (also protects `red`)
-    reduce_boxes<VMAX, BOX_CAP>(cx0, cy0, cx1, cy1, active, V, h, w, red, box);
 #pragma unroll
     for (int v = 0; v < VMAX; ++v)
-      if (v < V) stage_box<BOX_CAP>(src + (size_t)v * hw * C8, h, w, box[v], reinterpret_cast<float4*>(lds4 + v * 2 * BOX_CAP));
+      stage_box<BOX_CAP>(src + (size_t)v * hw * C8, h, w, box[v], reinterpret_cast<float4*>(lds4 + v * 2 * BOX_CAP));
     __syncthreads();
+    bool all_staged = true;
+    FastBox fb[VMAX];
+#pragma unroll
+    for (int v = 0; v < VMAX; ++v) {
+      fb[v] = fast_box(box[v], h, w);
+      all_staged = all_staged && box[v].staged;
+    }
+    const int* boxmem = red + 4 * VMAX * 4;
 
     unsigned boff = ((unsigned)d0 * hw + pix) * 4u;  // byte offset of (plane d, pixel) inside a channel slab / hyp
     const unsigned bstep = hw * 4u;
@@ -359,29 +455,78 @@ __global__ __launch_bounds__(256, CDS_K3_MINW) void warp_aggregate_lds_kernel(
       dnext.x = *reinterpret_cast<const float*>(hyp_b + min(boff + 2u * bstep, blast));
       dnext.y = *reinterpret_cast<const float*>(hyp_b + min(boff + 3u * bstep, blast));
       v2f acc[2][4];
+      auto init_acc = [&]() {
 #pragma unroll
-      for (int k = 0; k < 2; ++k)
+        for (int k = 0; k < 2; ++k)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          acc[k][j] = splat2(0.f);
-          if (accumulate && (k == 0 || two)) {
-            acc[k][j].x = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(volume + (size_t)(2 * j) * slab) + boff + k * bstep);
-            acc[k][j].y = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(volume + (size_t)(2 * j + 1) * slab) + boff + k * bstep);
+          for (int j = 0; j < 4; ++j) {
+            acc[k][j] = splat2(0.f);
+            if (accumulate && (k == 0 || two)) {
+              acc[k][j].x = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(volume + (size_t)(2 * j) * slab) + boff + k * bstep);
+              acc[k][j].y = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(volume + (size_t)(2 * j + 1) * slab) + boff + k * bstep);
+              if (normalize) acc[k][j] = acc[k][j] * yden;  // partial sums of an earlier launch
+            }
+          }
+      };
+      init_acc();
+      bool ok = all_staged;
+      if (all_staged) {  // block-uniform
+        // Software pipeline over the views: the LDS reads of view v+1 are issued while view v is interpolated, and
+        // the position / address arithmetic of view v+1 runs while the reads of view v are in flight.  The
+        // sched_barriers pin that order (left alone, the scheduler hoists every read to the top and spills).
+        v2f wt[2][4];
+        const cds_f4 *p0[2], *p1[2];
+        Tex8 tc[2][4];
+        auto prep = [&](int v, v2f w4[4]) {
+          v2f ix, iy, x0f, y0f;
+          positions2(r[v], mats.m[v] + 9, dv, g, ix, iy);
+          plane_weights(ix, iy, x0f, y0f, w4);
+          const cds_f4* lv = lds4 + v * 2 * BOX_CAP;
+          ok &= cell_addr_fast<BOX_CAP>(x0f.x, y0f.x, wf, hf, fb[v], lv, p0[0], p1[0]);
+          ok &= cell_addr_fast<BOX_CAP>(x0f.y, y0f.y, wf, hf, fb[v], lv, p0[1], p1[1]);
+        };
+        prep(0, wt[0]);
+        load_cell<BOX_CAP>(p0[0], p1[0], tc[0]);
+        load_cell<BOX_CAP>(p0[1], p1[1], tc[1]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int v = 0; v < VMAX; ++v) {
+          const int cur = v & 1, nxt = cur ^ 1;
+          if (v + 1 < VMAX) prep(v + 1, wt[nxt]);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            const float wgt[4] = {k ? wt[cur][0].y : wt[cur][0].x, k ? wt[cur][1].y : wt[cur][1].x,
+                                  k ? wt[cur][2].y : wt[cur][2].x, k ? wt[cur][3].y : wt[cur][3].x};
+            v2f o[4];
+            interp8(tc[k], wgt, o);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[k][j] = fma2(rv[v][j], o[j], acc[k][j]);
+            if (v + 1 < VMAX) load_cell<BOX_CAP>(p0[k], p1[k], tc[k]);
+            __builtin_amdgcn_sched_barrier(0);
           }
         }
+      }
+#ifndef CDS_K3_NOREDO
+      if (__builtin_expect(__builtin_amdgcn_ballot_w64(!ok) != 0, 0)) {  // wave-uniform: redo the pair, any geometry
+        init_acc();
+        // opaque copy of the hypotheses: keeps CSE from pinning the fast path's per-view weights for this cold block
+        float dgx = dv.x, dgy = dv.y;
+        asm volatile("" : "+v"(dgx), "+v"(dgy));
+        const v2f dvg = {dgx, dgy};
 #pragma unroll
-      for (int v = 0; v < VMAX; ++v) {
-        if (v < V) {
+        for (int v = 0; v < VMAX; ++v) {
           const float* __restrict__ srcv = src + (size_t)v * hw * C8;
           const cds_f4* lv = lds4 + v * 2 * BOX_CAP;
+          const Box bg = load_box(boxmem + v * 4);
           v2f ix, iy, x0f, y0f, wt[4];
-          positions2(r[v], mats.m[v] + 9, dv, g, ix, iy);
+          positions2(r[v], mats.m[v] + 9, dvg, g, ix, iy);
           plane_weights(ix, iy, x0f, y0f, wt);
 #pragma unroll
           for (int k = 0; k < 2; ++k) {
             float wgt[4] = {k ? wt[0].y : wt[0].x, k ? wt[1].y : wt[1].x, k ? wt[2].y : wt[2].x, k ? wt[3].y : wt[3].x};
             Tex8 t[4];
-            fetch_cell<BOX_CAP>(k ? x0f.y : x0f.x, k ? y0f.y : y0f.x, g, box[v], lv, srcv, t, wgt);
+            fetch_cell<BOX_CAP>(k ? x0f.y : x0f.x, k ? y0f.y : y0f.x, g, bg, lv, srcv, t, wgt);
             v2f o[4];
             interp8(t, wgt, o);
 #pragma unroll
@@ -389,20 +534,18 @@ __global__ __launch_bounds__(256, CDS_K3_MINW) void warp_aggregate_lds_kernel(
           }
         }
       }
+#endif
+#ifdef CDS_EXP_NOSTORE
+      if (active && acc[0][0].x == 123456.0f) {
+#else
       if (active) {
+#endif
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
           if (k == 0 || two) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
               v2f o = acc[k][j];
-              if (normalize) {
-                v2f q = o * yden;
-                v2f rr = fma2(splat2(-denom), q, o);
-                q = fma2(rr, splat2(yden), q);
-                rr = fma2(splat2(-denom), q, o);
-                o = fma2(rr, splat2(yden), q);
-              }
               float* p0 = reinterpret_cast<float*>(reinterpret_cast<char*>(volume + (size_t)(2 * j) * slab) + boff + k * bstep);
               float* p1 = reinterpret_cast<float*>(reinterpret_cast<char*>(volume + (size_t)(2 * j + 1) * slab) + boff + k * bstep);
               __builtin_nontemporal_store(o.x, p0);
@@ -470,17 +613,22 @@ __global__ __launch_bounds__(256) void warp_entropy_lds_kernel(const float* __re
   float r[3];
   cds_row_terms(m, (float)xc, (float)yc, r);
   const char* hyp_b = reinterpret_cast<const char*>(hyp);
+  const float wf = (float)w, hf = (float)h;
   float mx = -INFINITY, Z = 0.f, T = 0.f;
   for (int d0 = 0; d0 < D; d0 += DC1) {
     const int d1 = min(D, d0 + DC1);
     int cx0[1], cy0[1], cx1[1], cy1[1];
-    cell_of(r, m + 9, hyp[(size_t)d0 * hw + pix], h, w, g.half_w, g.half_h, cx0[0], cy0[0]);
-    cell_of(r, m + 9, hyp[(size_t)(d1 - 1) * hw + pix], h, w, g.half_w, g.half_h, cx1[0], cy1[0]);
+    float dlo, dhi;
+    chunk_depth_range(hyp, hw, pix, d0, d1, dlo, dhi);
+    cell_of(r, m + 9, dlo, h, w, g.half_w, g.half_h, cx0[0], cy0[0]);
+    cell_of(r, m + 9, dhi, h, w, g.half_w, g.half_h, cx1[0], cy1[0]);
     Box box[1];
     __syncthreads();
     reduce_boxes<1, BOX1>(cx0, cy0, cx1, cy1, active, 1, h, w, red, box);
     stage_box<BOX1>(srcv, h, w, box[0], reinterpret_cast<float4*>(lds4));
     __syncthreads();
+    const FastBox fb = fast_box(box[0], h, w);
+    const bool staged = box[0].staged;
     unsigned boff = ((unsigned)d0 * hw + pix) * 4u;
     const unsigned bstep = hw * 4u;
     const unsigned blast = ((unsigned)(d1 - 1) * hw + pix) * 4u;
@@ -496,14 +644,10 @@ __global__ __launch_bounds__(256) void warp_entropy_lds_kernel(const float* __re
       positions2(r, m + 9, dv, g, ix, iy);
       plane_weights(ix, iy, x0f, y0f, wt);
       float sim[2];
-#pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        float wgt[4] = {k ? wt[0].y : wt[0].x, k ? wt[1].y : wt[1].x, k ? wt[2].y : wt[2].x, k ? wt[3].y : wt[3].x};
-        Tex8 t[4];
-        fetch_cell<BOX1>(k ? x0f.y : x0f.x, k ? y0f.y : y0f.x, g, box[0], lds4, srcv, t, wgt);
+      // sum_C ref*warp, channel order 0..7 (ATen's sequential outer-dim sum for C <= 16)
+      auto correlate = [&](const Tex8 t[4], const float wgt[4]) {
         v2f o[4];
         interp8(t, wgt, o);
-        // sum_C ref*warp, channel order 0..7 (ATen's sequential outer-dim sum for C <= 16)
         float sacc = 0.f;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -511,7 +655,29 @@ __global__ __launch_bounds__(256) void warp_entropy_lds_kernel(const float* __re
           sacc = sacc + p.x;
           sacc = sacc + p.y;
         }
-        sim[k] = sacc;
+        return sacc;
+      };
+      bool ok = staged;
+      if (staged) {  // block-uniform
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const float wgt[4] = {k ? wt[0].y : wt[0].x, k ? wt[1].y : wt[1].x, k ? wt[2].y : wt[2].x, k ? wt[3].y : wt[3].x};
+          Tex8 t[4];
+          const cds_f4 *q0, *q1;
+          ok &= cell_addr_fast<BOX1>(k ? x0f.y : x0f.x, k ? y0f.y : y0f.x, wf, hf, fb, lds4, q0, q1);
+          load_cell<BOX1>(q0, q1, t);
+          sim[k] = correlate(t, wgt);
+        }
+      }
+      if (__builtin_expect(__builtin_amdgcn_ballot_w64(!ok) != 0, 0)) {  // wave-uniform: redo the pair, any geometry
+        const Box bg = load_box(red + 4 * 4);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          float wgt[4] = {k ? wt[0].y : wt[0].x, k ? wt[1].y : wt[1].x, k ? wt[2].y : wt[2].x, k ? wt[3].y : wt[3].x};
+          Tex8 t[4];
+          fetch_cell<BOX1>(k ? x0f.y : x0f.x, k ? y0f.y : y0f.x, g, bg, lds4, srcv, t, wgt);
+          sim[k] = correlate(t, wgt);
+        }
       }
       online_entropy_update(sim[0], mx, Z, T);
       if (two) online_entropy_update(sim[1], mx, Z, T);
@@ -526,7 +692,7 @@ __global__ __launch_bounds__(256) void warp_entropy_lds_kernel(const float* __re
 bool cds_warp_aggregate_lds_launch(const float* ref, const float* src, const float* vis, const WarpMats& wm,
                                    const float* hyp, float* volume, const float* vis_sum, int V, int C, int D, int h,
                                    int w, int hyp_pp, int flags, hipStream_t st) {
-  if (C != 8 || V > 4 || !hyp_pp || w < 2 || h < 2 || (size_t)D * h * w * 4 >= ((size_t)1 << 32)) return false;
+  if (C != 8 || V < 1 || V > 4 || !hyp_pp || w < 2 || h < 2 || (size_t)D * h * w * 4 >= ((size_t)1 << 32)) return false;
   const int tiles_x = cds_ceil_div(w, TW), tiles_y = cds_ceil_div(h, TH);
   const int ntiles = tiles_x * tiles_y;
   const float rhw = (float)(1.0 / (double)(float)((w - 1) / 2.0)), rhh = (float)(1.0 / (double)(float)((h - 1) / 2.0));
@@ -541,7 +707,7 @@ bool cds_warp_aggregate_lds_launch(const float* ref, const float* src, const flo
   const bool acc_f = flags & CDS_AGG_ACCUMULATE, nrm_f = flags & CDS_AGG_NORMALIZE;
 #define LAUNCH3(VM, A, N)                                                                                              \
   hipLaunchKernelGGL((warp_aggregate_lds_kernel<VM, A, N>), dim3(ntiles * nseg), dim3(256),                            \
-                     (size_t)VM * 2 * BOX_CAP * sizeof(float4) + 4 * VM * 4 * sizeof(int), st, ref, src, vis, wm, hyp, \
+                     (size_t)VM * 2 * BOX_CAP * sizeof(float4) + 5 * VM * 4 * sizeof(int), st, ref, src, vis, wm, hyp, \
                      volume, vis_sum, V, D, h, w, rhw, rhh, flags, tiles_x, ntiles, nseg, seg_planes)
 #define LAUNCH(VM)                                 \
   do {                                             \
@@ -550,8 +716,12 @@ bool cds_warp_aggregate_lds_launch(const float* ref, const float* src, const flo
     else if (nrm_f) LAUNCH3(VM, false, true);      \
     else LAUNCH3(VM, false, false);                \
   } while (0)
-  if (V <= 2) LAUNCH(2);
-  else LAUNCH(4);
+  switch (V) {   // the kernel is specialised on the exact view count
+    case 1: LAUNCH(1); break;
+    case 2: LAUNCH(2); break;
+    case 3: LAUNCH(3); break;
+    default: LAUNCH(4); break;
+  }
 #undef LAUNCH3
 #undef LAUNCH
   return true;
@@ -564,7 +734,7 @@ bool cds_warp_entropy_lds_launch(const float* ref, const float* src, const WarpM
   const int ntiles = tiles_x * tiles_y;
   const float rhw = (float)(1.0 / (double)(float)((w - 1) / 2.0)), rhh = (float)(1.0 / (double)(float)((h - 1) / 2.0));
   hipLaunchKernelGGL(warp_entropy_lds_kernel, dim3(ntiles * V), dim3(256),
-                     (size_t)2 * BOX1 * sizeof(float4) + 4 * 4 * sizeof(int), st, ref, src, wm, hyp, entropy, V, D, h,
+                     (size_t)2 * BOX1 * sizeof(float4) + 5 * 4 * sizeof(int), st, ref, src, wm, hyp, entropy, V, D, h,
                      w, rhw, rhh, tiles_x, ntiles);
   return true;
 }
