@@ -765,6 +765,170 @@ int launch_deconv_v2(const float* x, const float* w, const float* b, const float
   return cds_launch_status();
 }
 
+// ---------------------------------------------------------------------------------------------
+// transposed conv v3 (Cout = 8, Cin <= 16, wide volumes).  The v2 kernel stages the same input tile once per
+// (z,y) parity class and per channel chunk (6.6x the input bytes through L2 -> LDS at M1) and leaves the skip-tensor
+// reads of the epilogue exposed.  Here a workgroup stages its (16*PC)x4x2 input cells (+1 halo) for ALL input
+// channels once, then waves 0-1 produce the parity classes (0,0) and (1,1) (1 + 4 tap pairs) and waves 2-3 the
+// classes (0,1) and (1,0) (2 + 2) from the resident tile.  Thread = PC x-adjacent cells -> 2*PC x-adjacent outputs
+// x 8 channels.  The skip values of a class are requested before its FMA loop and consumed after it (that alone is
+// 1.55 -> 1.2 ms at M1; with 5 GB of compulsory HBM traffic the layer then sits at ~4.3 TB/s).
+// PC = 4: 63.75 KB of LDS for Cin = 16 (2 workgroups per CU); PC = 2: 34.5 KB (4 per CU), same speed at M1.
+// ---------------------------------------------------------------------------------------------
+template <int PC_>
+struct D3Cfg {
+  static constexpr int LX = 16, LY = 4, LZ = 2, PC = PC_;
+  static constexpr int IY = LY + 1, IZ = LZ + 1;
+  static constexpr int IXP = (LX * PC + 1 + 3) & ~3;   // 68 / 36
+  static constexpr int Q = IXP / 4;
+  static constexpr int NS = IZ * IY * Q;               // float4 per channel
+  static constexpr int TILE = NS * 4;
+  static constexpr int NB = (16 * NS + 255) / 256 > 8 ? 8 : (16 * NS + 255) / 256;   // staging loads in flight
+};
+constexpr int D3_MAX_CIN = 16;
+
+template <int CO, int PC>
+__global__ __launch_bounds__(256) void deconv3d_k3s2_v3_kernel(const float* __restrict__ x, const float* __restrict__ wpk,
+                                                               const float* __restrict__ bias,
+                                                               const float* __restrict__ skip, float* __restrict__ out,
+                                                               int Cin, int Cout, int D, int H, int W, int act,
+                                                               int tiles_x, int tiles_y, int tiles_z, int ntiles) {
+  using Cfg = D3Cfg<PC>;
+  static_assert(PC == 2 || PC == 4, "PC");
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  int tile = cds_xcd_remap(blockIdx.x, ntiles);
+  const int tx_i = tile % tiles_x;
+  tile /= tiles_x;
+  const int ty_i = tile % tiles_y;
+  const int tz_i = tile / tiles_y;
+  const int tid = threadIdx.x;
+  const int ax0 = tx_i * Cfg::LX * PC, ay0 = ty_i * Cfg::LY, az0 = tz_i * Cfg::LZ;
+  const size_t plane = (size_t)H * W, vol = (size_t)D * plane;
+
+  // ---- stage every input channel of the tile: Cin * NS float4 slots, 256 at a time, loads batched by NB ----
+  const int nslots = Cin * Cfg::NS;
+  for (int s0 = 0; s0 < nslots; s0 += 256 * Cfg::NB) {
+    float4 pre[Cfg::NB];
+    bool okv[Cfg::NB];
+#pragma unroll
+    for (int j = 0; j < Cfg::NB; ++j) {
+      const int s = s0 + 256 * j + tid;
+      const int ci = s / Cfg::NS;
+      const int r = s - ci * Cfg::NS;
+      const int row = r / Cfg::Q, c4 = r - row * Cfg::Q;
+      const int rz = row / Cfg::IY, ry = row - rz * Cfg::IY;
+      const int gz = az0 + rz, gy = ay0 + ry, gx = ax0 + 4 * c4;
+      okv[j] = s < nslots && gz < D && gy < H && gx + 3 < W;
+      const size_t off = okv[j] ? (size_t)ci * vol + (size_t)gz * plane + (size_t)gy * W + gx : 0;
+      pre[j] = *reinterpret_cast<const float4*>(x + off);
+    }
+#pragma unroll
+    for (int j = 0; j < Cfg::NB; ++j) {
+      const int s = s0 + 256 * j + tid;
+      if (s < nslots) *reinterpret_cast<float4*>(lds + 4 * s) = okv[j] ? pre[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  __syncthreads();
+
+  const int half = __builtin_amdgcn_readfirstlane(tid >> 7);   // wave pair
+  const int t128 = tid & 127;
+  const int lx = t128 % Cfg::LX, ly = (t128 / Cfg::LX) % Cfg::LY, lz = t128 / (Cfg::LX * Cfg::LY);
+  const int az = az0 + lz, ay = ay0 + ly, ax = ax0 + lx * PC;
+  const int Do = 2 * D, Ho = 2 * H, Wo = 2 * W;
+  const size_t oplane = (size_t)Ho * Wo, ovol = (size_t)Do * oplane;
+  const float* tbase = lds + (lz * Cfg::IY + ly) * Cfg::IXP + lx * PC;
+  const bool inside = az < D && ay < H && ax < W;   // W % 4 == 0 and ax % PC == 0: all 2*PC outputs inside or outside
+  constexpr int NV = PC / 2;                           // float4 stores per (channel, thread)
+
+#pragma unroll 1
+  for (int pass = 0; pass < 2; ++pass) {
+    // half 0: (pz,py) = (0,0) then (1,1); half 1: (0,1) then (1,0)
+    const int pz = pass, py = half ? 1 - pass : pass;
+    float acc[2 * PC][CO];
+#pragma unroll
+    for (int q = 0; q < 2 * PC; ++q)
+#pragma unroll
+      for (int c = 0; c < CO; ++c) acc[q][c] = 0.f;
+    const size_t obase = (size_t)(2 * az + pz) * oplane + (size_t)(2 * ay + py) * Wo + 2 * ax;
+    float4 sk[CO][NV];
+#pragma unroll
+    for (int c = 0; c < CO; ++c)
+#pragma unroll
+      for (int hf = 0; hf < NV; ++hf) {
+        const bool ok = skip && inside;
+        sk[c][hf] = *reinterpret_cast<const float4*>(ok ? skip + (size_t)c * ovol + obase + 4 * hf : x);
+      }
+    // Steps = (input channel, tap pair of this parity class), flattened.  (Software-pipelining the LDS row and the
+    // 3x8 scalar weight loads one step ahead was measured and does not help: 2+ waves per SIMD already cover them.)
+    // along z (and y): parity 0 -> (input +0, tap 1); parity 1 -> (input +1, tap 0) and (input +0, tap 2)
+    const int ncombo = (1 << pz) << py;
+    const int nsteps = Cin * ncombo;
+#pragma unroll 1
+    for (int step = 0; step < nsteps; ++step) {
+      const int ci = step / ncombo, combo = step - ci * ncombo;
+      const int sy = py ? (combo & 1) : 0, sz = pz ? ((combo >> py) & 1) : 0;
+      const int iz = pz ? 1 - sz : 0, kz = pz ? 2 * sz : 1;
+      const int iy = py ? 1 - sy : 0, ky = py ? 2 * sy : 1;
+      const float* rowp = tbase + ci * Cfg::TILE + (iz * Cfg::IY + iy) * Cfg::IXP;
+      float in[PC + 1];
+      if constexpr (PC == 4) {
+        const cds_f4 b = *reinterpret_cast<const cds_f4*>(rowp);
+        in[0] = b.x; in[1] = b.y; in[2] = b.z; in[3] = b.w;
+      } else {
+        const float2 b = *reinterpret_cast<const float2*>(rowp);
+        in[0] = b.x; in[1] = b.y;
+      }
+      in[PC] = rowp[PC];
+      const float* __restrict__ wrow = wpk + __builtin_amdgcn_readfirstlane(((ci * 9 + kz * 3 + ky) * 3) * Cout);
+#pragma unroll
+      for (int c = 0; c < CO; ++c) {
+        const float w0 = wrow[c], w1 = wrow[Cout + c], w2 = wrow[2 * Cout + c];
+#pragma unroll
+        for (int p = 0; p < PC; ++p) {
+          acc[2 * p][c] = fmaf(in[p], w1, acc[2 * p][c]);              // x = 2a   : (input a,   tap 1)
+          acc[2 * p + 1][c] = fmaf(in[p + 1], w0, acc[2 * p + 1][c]);  // x = 2a+1 : (input a+1, tap 0)
+          acc[2 * p + 1][c] = fmaf(in[p], w2, acc[2 * p + 1][c]);      //            (input a,   tap 2)
+        }
+      }
+    }
+    if (inside) {
+#pragma unroll
+      for (int c = 0; c < CO; ++c) {
+        const float b = bias ? bias[c] : 0.f;
+        const size_t base = (size_t)c * ovol + obase;
+#pragma unroll
+        for (int hf = 0; hf < NV; ++hf) {
+          float4 o;
+          o.x = acc[4 * hf + 0][c] + b;
+          o.y = acc[4 * hf + 1][c] + b;
+          o.z = acc[4 * hf + 2][c] + b;
+          o.w = acc[4 * hf + 3][c] + b;
+          if (act == CDS_ACT_RELU) {
+            o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
+          }
+          if (skip) {
+            const float4 s4 = sk[c][hf];
+            o.x = s4.x + o.x; o.y = s4.y + o.y; o.z = s4.z + o.z; o.w = s4.w + o.w;
+          }
+          *reinterpret_cast<float4*>(out + base + 4 * hf) = o;
+        }
+      }
+    }
+  }
+}
+
+template <int PC>
+int launch_deconv_v3(const float* x, const float* w, const float* b, const float* skip, float* out, int Cin, int Cout,
+                     int D, int H, int W, int act, hipStream_t st) {
+  using Cfg = D3Cfg<PC>;
+  const int tx = cds_ceil_div(W, Cfg::LX * PC), ty = cds_ceil_div(H, Cfg::LY), tz = cds_ceil_div(D, Cfg::LZ);
+  const int ntiles = tx * ty * tz;
+  const size_t lds_bytes = (size_t)Cfg::TILE * Cin * sizeof(float);
+  hipLaunchKernelGGL((deconv3d_k3s2_v3_kernel<8, PC>), dim3(ntiles), dim3(256), lds_bytes, st, x, w, b, skip, out, Cin,
+                     Cout, D, H, W, act, tx, ty, tz, ntiles);
+  return cds_launch_status();
+}
+
 }  // namespace
 
 bool cds_conv3d_mfma_launch(const float* x, const float* w, const float* b, const float* skip, float* out, int Cin,
@@ -826,6 +990,11 @@ extern "C" int cds_deconv3d_k3s2_f32(const float* x, const float* weight, const 
   if ((W % 4 == 0) && W >= 32 && ((size_t)Cin * D * H * W < (size_t)0x7fffffff)) {
     static const bool v1 = []() { const char* e = getenv("CDS_DECONV_V1"); return e && e[0] == '1'; }();  // A/B knob
     if (v1) return launch_deconv_pipe<64, 2, 2, 8, 8>(x, weight, bias, skip, out, Cin, Cout, D, H, W, act, st);
+    static const bool v2 = []() { const char* e = getenv("CDS_DECONV_V2"); return e && e[0] == '1'; }();          // A/B knobs
+    static const int v3pc = []() { const char* e = getenv("CDS_DECONV_V3_PC"); return e ? atoi(e) : 4; }();
+    if (!v2 && Cout == 8 && Cin <= D3_MAX_CIN)
+      return v3pc == 4 ? launch_deconv_v3<4>(x, weight, bias, skip, out, Cin, Cout, D, H, W, act, st)
+                       : launch_deconv_v3<2>(x, weight, bias, skip, out, Cin, Cout, D, H, W, act, st);
     return launch_deconv_v2<8, 4>(x, weight, bias, skip, out, Cin, Cout, D, H, W, act, st);
   }
   return W >= 48 ? launch_deconv<64, 2, 2, 8, 8>(x, weight, bias, skip, out, Cin, Cout, D, H, W, act, st)
