@@ -166,8 +166,10 @@ class CostRegNet(nn.Module):
 
 
 class Refinement(nn.Module):
-    """2x depth up-sampling with image guidance (module.py:318-370).  3.6 % of the reference's CPU time
-    and adjacent to — not on — the plane-sweep path: it stays on stock PyTorch-ROCm ops."""
+    """2x depth up-sampling with image guidance (module.py:318-370).  Eval mode runs on the HIP
+    kernels (3x3 Conv+BN+ReLU units on cds_conv2d_f32 with the BatchNorm folded in, the transposed conv, the depth
+    pre-scale and the bilinear-upsample + residual epilogue in refine.hip); training mode keeps PyTorch autograd ops
+    like the other convolution stacks (training.py)."""
 
     def __init__(self):
         super().__init__()
@@ -178,12 +180,27 @@ class Refinement(nn.Module):
         self.bn = nn.BatchNorm2d(8)
         self.conv3 = ConvBn2d(16, 8)
         self.res = nn.Conv2d(8, 1, 3, padding=1, bias=False)
+        self._packed = _Packed(self)
+
+    def _pack(self) -> Dict[str, Tensor]:
+        out: Dict[str, Tensor] = {}
+        for name in ("conv0", "conv1", "conv2", "conv3"):
+            unit: ConvBn2d = getattr(self, name)
+            scale, shift = _bn_fold(unit.bn)
+            out[name + ".w"] = _pack2d(unit.conv.weight.detach() * scale.view(-1, 1, 1, 1))
+            out[name + ".b"] = shift.contiguous()
+        scale, shift = _bn_fold(self.bn)
+        w = self.deconv.weight.detach() * scale.view(1, -1, 1, 1)          # [Cin,Cout,3,3]
+        out["deconv.w"] = w.permute(0, 2, 3, 1).reshape(8, 9, 8).contiguous()
+        out["deconv.b"] = shift.contiguous()
+        out["res.w"] = _pack2d(self.res.weight.detach())
+        return out
 
     @staticmethod
     def _cbr(unit: ConvBn2d, x: Tensor) -> Tensor:
         return F.relu(unit.bn(unit.conv(x)))
 
-    def forward(self, img: Tensor, depth0: Tensor, dmin: Tensor, dmax: Tensor) -> Tensor:
+    def _forward_autograd(self, img: Tensor, depth0: Tensor, dmin: Tensor, dmax: Tensor) -> Tensor:
         B = dmin.shape[0]
         lo, hi = dmin.view(B, 1, 1, 1), dmax.view(B, 1, 1, 1)
         d = (depth0 - lo) / (hi - lo) * 10
@@ -192,6 +209,31 @@ class Refinement(nn.Module):
         res = self.res(self._cbr(self.conv3, torch.cat((f_d, f_img), dim=1)))
         d = (F.interpolate(d, scale_factor=2, mode="bilinear", align_corners=True) + res) / 10
         return d * (hi - lo) + lo
+
+    def forward(self, img: Tensor, depth0: Tensor, dmin: Tensor, dmax: Tensor) -> Tensor:
+        """img [B,3,H,W], depth0 [B,1,H/2,W/2], dmin/dmax [B] -> refined depth [B,1,H,W]."""
+        if self.training:
+            return self._forward_autograd(img, depth0, dmin, dmax)
+        p = self._packed.get(self._pack)
+        B, _, H, W = img.shape
+        h, w = depth0.shape[-2:]
+        if (2 * h, 2 * w) != (H, W):
+            raise ValueError(f"Refinement: image {(H, W)} must be twice the depth map {(h, w)}")
+        lo_hi = torch.stack((dmin.float(), dmax.float()), 1).cpu()            # scalars for the launches
+        outs = []
+        with ops.prof("refinement"):
+            for b in range(B):
+                lo, hi = float(lo_hi[b, 0]), float(lo_hi[b, 1])
+                d = ops.depth_affine(depth0[b, 0].contiguous(), lo, hi)                              # [h,w]
+                cat = torch.empty((1, 16, H, W), dtype=torch.float32, device=img.device)            # deconv | conv0
+                ops.conv2d(img[b:b + 1].contiguous(), p["conv0.w"], p["conv0.b"], 8, 3, 1, 1, ACT_RELU, out=cat[0, 8:])
+                x = ops.conv2d(d.view(1, 1, h, w), p["conv1.w"], p["conv1.b"], 8, 3, 1, 1, ACT_RELU)
+                x = ops.conv2d(x, p["conv2.w"], p["conv2.b"], 8, 3, 1, 1, ACT_RELU)
+                ops.deconv2d_k3s2(x[0], p["deconv.w"], p["deconv.b"], ACT_RELU, out=cat[0, :8])
+                x = ops.conv2d(cat, p["conv3.w"], p["conv3.b"], 8, 3, 1, 1, ACT_RELU)
+                res = ops.conv2d(x, p["res.w"], None, 1, 3, 1, 1, ACT_NONE)
+                outs.append(ops.refine_finish(d, res[0, 0], lo, hi))
+        return torch.stack(outs).unsqueeze(1)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -326,3 +326,36 @@ def depth_fusion(ref_depth: Tensor, ref_conf: Tensor, src_depths: Tensor, src_co
                                            float(dist_thresh), float(depth_thresh), float(view_thresh),
                                            _stream(fused)), "cds_depth_fusion_f32")
     return fused, mask, points, vm
+
+
+def depth_affine(depth: Tensor, lo: float, hi: float) -> Tensor:
+    """(depth - lo) / (hi - lo) * 10   (Refinement pre-scale, module.py:353-355)."""
+    out = torch.empty_like(depth)
+    check(_lib.load().cds_depth_affine_f32(_dev(depth, "depth"), out.data_ptr(), depth.numel(), float(lo), float(hi),
+                                           _stream(depth)), "cds_depth_affine_f32")
+    return out
+
+
+def deconv2d_k3s2(x: Tensor, wpk: Tensor, bias: Optional[Tensor], act: int = ACT_NONE, out: Optional[Tensor] = None) -> Tensor:
+    """ConvTranspose2d k3 s2 p1 op1: x [Cin,H,W], wpk packed [Cin,9,8] -> [8,2H,2W] (written into `out` if given)."""
+    Cin, H, W = x.shape
+    if tuple(wpk.shape) != (Cin, 9, 8):
+        raise ValueError(f"deconv2d_k3s2: packed weight must be [{Cin},9,8], got {tuple(wpk.shape)}")
+    if out is None:
+        out = torch.empty((8, 2 * H, 2 * W), dtype=torch.float32, device=x.device)
+    elif out.numel() != 8 * 4 * H * W:
+        raise ValueError("deconv2d_k3s2: bad output buffer")
+    check(_lib.load().cds_deconv2d_k3s2_f32(_dev(x, "x"), _dev(wpk, "weight"), _dev(bias, "bias") if bias is not None else None,
+                                            _dev(out, "out"), Cin, 8, H, W, act, _stream(x)), "cds_deconv2d_k3s2_f32")
+    return out
+
+
+def refine_finish(d_norm: Tensor, res: Tensor, lo: float, hi: float) -> Tensor:
+    """((bilinear x2, align_corners=True)(d_norm [h,w]) + res [2h,2w]) / 10 * (hi - lo) + lo   (module.py:366-368)."""
+    h, w = d_norm.shape
+    if tuple(res.shape) != (2 * h, 2 * w):
+        raise ValueError("refine_finish: res must be [2h,2w]")
+    out = torch.empty_like(res)
+    check(_lib.load().cds_refine_finish_f32(_dev(d_norm, "d_norm"), _dev(res, "res"), out.data_ptr(), h, w, float(lo),
+                                            float(hi), _stream(res)), "cds_refine_finish_f32")
+    return out

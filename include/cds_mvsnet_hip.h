@@ -190,6 +190,20 @@ int cds_depth_fusion_f32(const float* ref_depth, const float* ref_conf, const fl
                          float* view_masks, int V, int h, int w, const float* prob_thresh_host,
                          float dist_thresh, float depth_thresh, float view_thresh, void* stream);
 
+/*
+ * Refinement network (module.py:318-370) pieces besides its 3x3 Conv+BN+ReLU units (those run on cds_conv2d_f32):
+ *   cds_depth_affine_f32   out[i] = (depth[i] - lo) / (hi - lo) * 10                      (module.py:353-355)
+ *   cds_deconv2d_k3s2_f32  ConvTranspose2d k=3, stride 2, padding 1, output_padding 1 (+ bias + activation);
+ *                          x [Cin][H][W] -> out [Cout][2H][2W]; weight PACKED [Cin][9][Cout] = PyTorch's
+ *                          [Cin][Cout][3][3] permuted (0,2,3,1) (BatchNorm folded in by the caller); Cout = 8
+ *   cds_refine_finish_f32  out = ((bilinear x2, align_corners=True)(d_norm [h][w]) + res [2h][2w]) / 10 * (hi - lo) + lo
+ */
+int cds_depth_affine_f32(const float* depth, float* out, int n, float lo, float hi, void* stream);
+int cds_deconv2d_k3s2_f32(const float* x, const float* weight, const float* bias, float* out, int Cin, int Cout,
+                          int H, int W, int act, void* stream);
+int cds_refine_finish_f32(const float* d_norm, const float* res, float* out, int h, int w, float lo, float hi,
+                          void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -510,3 +510,21 @@ def test_training_step_matches_reference(dev):
     assert (model.cost_regularization[2].prob.weight.grad.cpu() - g["grad_prob3"]).abs().max() < 2e-3 * g["grad_prob3"].abs().max()
     # BatchNorm running statistics were updated by the step (training-mode BN, momentum 0.1)
     assert model.cost_regularization[0].conv0.bn.num_batches_tracked.item() == 101
+
+
+@pytest.mark.parametrize("h,w", [(32, 48), (19, 27)])
+def test_refinement_hip_vs_oracle(h, w, seeded_state):
+    """a15 on the HIP kernels (conv2d + deconv2d + finish) against the oracle restatement, incl. odd sizes."""
+    from oracle import cds_oracle as O
+    model = seeded_state(True)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    net = model.refine_network.eval().cuda()
+    g = torch.Generator().manual_seed(5)
+    img = torch.rand(2, 3, 2 * h, 2 * w, generator=g)
+    dmin, dmax = torch.tensor([170.0, 160.0]), torch.tensor([361.0, 350.0])
+    depth0 = dmin.view(2, 1, 1, 1) + (dmax - dmin).view(2, 1, 1, 1) * torch.rand(2, 1, h, w, generator=g)
+    exp = O.refinement(img, depth0, dmin, dmax, sd)
+    with torch.no_grad():
+        got = net(img.cuda(), depth0.cuda(), dmin.cuda(), dmax.cuda()).cpu()
+    assert got.shape == exp.shape
+    assert (got - exp).abs().max() < 2e-3 and (got - exp).abs().mean() < 1e-4      # depths ~160-360
