@@ -7,6 +7,7 @@ through the C ABI of ``include/cds_mvsnet_hip.h``.  No CPU / PyTorch fallback ex
 from .model import CDSMVSNet, CostRegNet, FeatureNet, Refinement, StageNet  # noqa: F401
 from .init import seeded_init_  # noqa: F401
 from .losses import final_loss  # noqa: F401
+from . import train  # noqa: F401  (schedules, gradient all-reduce, train_step)
 
 __all__ = ["CDSMVSNet", "CostRegNet", "FeatureNet", "Refinement", "StageNet", "seeded_init_", "final_loss"]
 __version__ = "0.1.0"

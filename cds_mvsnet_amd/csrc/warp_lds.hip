@@ -548,8 +548,13 @@ __global__ __launch_bounds__(256, CDS_K3_MINW) void warp_aggregate_lds_kernel(
               v2f o = acc[k][j];
               float* p0 = reinterpret_cast<float*>(reinterpret_cast<char*>(volume + (size_t)(2 * j) * slab) + boff + k * bstep);
               float* p1 = reinterpret_cast<float*>(reinterpret_cast<char*>(volume + (size_t)(2 * j + 1) * slab) + boff + k * bstep);
+#ifdef CDS_EXP_PLAIN_STORE
+              *p0 = o.x;
+              *p1 = o.y;
+#else
               __builtin_nontemporal_store(o.x, p0);
               __builtin_nontemporal_store(o.y, p1);
+#endif
             }
           }
         }

@@ -168,6 +168,7 @@ class WarpAggregate(torch.autograd.Function):
     Gradients: ref, src (channels-last), vis.  mats (CPU) and hyp carry none (warping.py:79)."""
 
     @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)   # fp32 kernels, also under bf16 autocast
     def forward(ctx, ref_chw, src_hwc, vis_w, mats, hyp):
         ref_chw, src_hwc, vis_w, hyp = (t.contiguous() for t in (ref_chw, src_hwc, vis_w, hyp))
         ctx.save_for_backward(ref_chw, src_hwc, vis_w, hyp)
@@ -176,6 +177,7 @@ class WarpAggregate(torch.autograd.Function):
         return volume
 
     @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, grad_volume):
         ref_chw, src_hwc, vis_w, hyp = ctx.saved_tensors
         g_ref, g_src, g_vis = warp_aggregate_bwd(ref_chw, src_hwc, vis_w, ctx.mats, hyp, grad_volume.contiguous())

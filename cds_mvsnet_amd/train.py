@@ -1,0 +1,127 @@
+"""Training loop pieces around ``CDSMVSNet.train()``: what the reference's ``trainer/trainer.py`` and
+``train.py`` do, laid out for one process per GPU over RCCL instead of ``nn.DataParallel``.
+
+* :func:`temperature_for_epoch` — DynamicConv softmax temperature schedule (trainer/trainer.py:45-49).
+* :func:`make_optimizer` / :func:`make_scheduler` — SGD(lr 1e-4, weight_decay 0.01) + StepLR(step 3, gamma 0.5)
+  (configs/config_blended.json:34-50); the scheduler steps once per epoch (trainer.py:94).
+* :class:`GradAllReducer` — data-parallel gradient averaging: all gradients are packed into flat fp32 buckets
+  (981 622 parameters = 3.9 MB -> one bucket, one RCCL all-reduce per step: the exchange is latency-bound on xGMI, so
+  fewer/larger messages, not NCCL-style 25 MB overlap buckets), divided by the world size and unpacked.  BatchNorm
+  statistics stay per replica like ``nn.DataParallel``.
+* :func:`train_step` — forward (optionally under bf16 autocast for the PyTorch-op convolution stacks; the HIP
+  warp/aggregate Function, the soft-argmin and the loss stay fp32), ``final_loss``, backward, gradient exchange,
+  optimizer step (trainer.py:69-82).
+
+bf16 note: the reference trains in fp32 and has no AMP; BASELINE config 5 asks for bf16.  Autocast covers conv / matmul
+ops only, InstanceNorm/BatchNorm statistics and softmax run in fp32 through autocast's own promotion rules.
+"""
+from __future__ import annotations
+
+import contextlib
+from typing import Dict, Iterable, List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+from .losses import final_loss
+
+Tensor = torch.Tensor
+
+
+def temperature_for_epoch(epoch: int) -> float:
+    """epoch is 1-based: 1, 10^-0.5, 0.1, 10^-1.5 for epochs 1-4, then 0.01 (trainer/trainer.py:45-49)."""
+    if epoch <= 4:
+        return float(10.0 ** (-(epoch - 1) / 2.0))
+    return 0.01
+
+
+def make_optimizer(model: torch.nn.Module, lr: float = 1e-4, weight_decay: float = 0.01) -> torch.optim.Optimizer:
+    return torch.optim.SGD(model.parameters(), lr=lr, weight_decay=weight_decay)
+
+
+def make_scheduler(optimizer: torch.optim.Optimizer, step_size: int = 3, gamma: float = 0.5):
+    return torch.optim.lr_scheduler.StepLR(optimizer, step_size=step_size, gamma=gamma)
+
+
+class GradAllReducer:
+    """Flat-bucket gradient averaging over a process group (default group; RCCL when the tensors are on the GPU)."""
+
+    def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = 64 << 20,
+                 group: Optional["dist.ProcessGroup"] = None):
+        self.params = [p for p in params if p.requires_grad]
+        self.group = group
+        self.buckets: List[List[torch.nn.Parameter]] = [[]]
+        size = 0
+        for p in self.params:
+            nbytes = p.numel() * 4
+            if self.buckets[-1] and size + nbytes > bucket_bytes:
+                self.buckets.append([])
+                size = 0
+            self.buckets[-1].append(p)
+            size += nbytes
+        self._flat: List[Optional[Tensor]] = [None] * len(self.buckets)
+
+    def world_size(self) -> int:
+        return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
+
+    @torch.no_grad()
+    def reduce(self) -> int:
+        """Average ``p.grad`` over the ranks in place; parameters without a gradient contribute zeros (a rank whose
+        batch did not touch a parameter must still take part in the collective).  Returns the number of collectives."""
+        world = self.world_size()
+        if world == 1:
+            return 0
+        for i, bucket in enumerate(self.buckets):
+            n = sum(p.numel() for p in bucket)
+            dev = bucket[0].device
+            flat = self._flat[i]
+            if flat is None or flat.device != dev:
+                flat = self._flat[i] = torch.empty(n, dtype=torch.float32, device=dev)
+            off = 0
+            for p in bucket:
+                k = p.numel()
+                if p.grad is None:
+                    flat[off:off + k].zero_()
+                else:
+                    flat[off:off + k].copy_(p.grad.reshape(-1))
+                off += k
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+            flat.div_(world)
+            off = 0
+            for p in bucket:
+                k = p.numel()
+                if p.grad is None:
+                    p.grad = flat[off:off + k].view_as(p).clone()
+                else:
+                    p.grad.copy_(flat[off:off + k].view_as(p))
+                off += k
+        return len(self.buckets)
+
+
+def train_step(model: torch.nn.Module, optimizer: torch.optim.Optimizer, sample: Dict[str, object], temperature: float,
+               dlossw: Sequence[float] = (0.5, 1.0, 2.0), reducer: Optional[GradAllReducer] = None,
+               bf16: bool = False) -> Tuple[float, float]:
+    """One optimisation step on ``sample`` = {imgs, proj_matrices, depth_values, depth: {stageK}, mask: {stageK}}
+    (already on the model's device).  Returns (loss, depth_loss) as Python floats."""
+    model.train()
+    optimizer.zero_grad(set_to_none=True)
+    dv = sample["depth_values"]
+    interval = dv[:, 1] - dv[:, 0]
+    ctx = torch.autocast("cuda", dtype=torch.bfloat16) if bf16 else contextlib.nullcontext()
+    with ctx:
+        outputs = model(sample["imgs"], sample["proj_matrices"], dv, gt_depths=sample["depth"], temperature=temperature)
+    outputs = _to_float(outputs)
+    loss, depth_loss = final_loss(outputs, sample["depth"], sample["mask"], dlossw=list(dlossw), depth_interval=interval)
+    loss.backward()
+    if reducer is not None:
+        reducer.reduce()
+    optimizer.step()
+    return float(loss.detach()), float(depth_loss.detach())
+
+
+def _to_float(x):
+    if isinstance(x, torch.Tensor):
+        return x.float() if x.is_floating_point() else x
+    if isinstance(x, dict):
+        return {k: _to_float(v) for k, v in x.items()}
+    return x

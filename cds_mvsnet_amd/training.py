@@ -130,16 +130,17 @@ def forward_train(model, imgs: Tensor, proj_matrices: Dict[str, Tensor], depth_v
                 hyps.append(ops.depth_hypotheses(depth[b].detach().contiguous(), D, H, W, scale,
                                                  float(model.depth_interals_ratio[s] * dint_all[b]), dmin, dmax))
         mats = [geometry.warp_matrices(cams[name][b]) for b in range(B)]
-        ref = [torch.stack([feats[v][0][name][0][b] for v in range(V)]) for b in range(B)]                 # [V,C,h,w]
-        src = [torch.stack([feats[v][1][name][0][b] for v in range(V)]).permute(0, 2, 3, 1).contiguous() for b in range(B)]
+        # .float(): under bf16 autocast the convolution stacks hand over bf16 activations; the HIP kernels are fp32
+        ref = [torch.stack([feats[v][0][name][0][b] for v in range(V)]).float() for b in range(B)]         # [V,C,h,w]
+        src = [torch.stack([feats[v][1][name][0][b] for v in range(V)]).float().permute(0, 2, 3, 1).contiguous() for b in range(B)]
         with torch.no_grad():                                               # K1, detached input (model.py:49)
             ent = torch.stack([ops.warp_entropy(ref[b].detach().contiguous(), src[b].detach(), mats[b], hyps[b])
                                for b in range(B)])                           # [B,V,h,w]
-        vis = [_visibility(model.stage_net.vis[s], torch.cat((ent[:, v:v + 1], feats[v][0][name][2]), dim=1))[:, 0]
+        vis = [_visibility(model.stage_net.vis[s], torch.cat((ent[:, v:v + 1], feats[v][0][name][2].float()), dim=1))[:, 0]
                for v in range(V)]                                            # V x [B,h,w]  (model.py:51)
         vols, fds = [], []
         for b in range(B):
-            vis_b = torch.stack([vis[v][b] for v in range(V)])               # [V,h,w]
+            vis_b = torch.stack([vis[v][b] for v in range(V)]).float()       # [V,h,w]
             vol_sum = ops.WarpAggregate.apply(ref[b], src[b], vis_b, mats[b], hyps[b])       # K3 fwd / bwd kernels
             denom = (vis_b.sum(dim=0) + 1e-6).unsqueeze(0)
             vols.append(vol_sum / denom.unsqueeze(0))                        # model.py:74
@@ -150,7 +151,7 @@ def forward_train(model, imgs: Tensor, proj_matrices: Dict[str, Tensor], depth_v
             fds.append(fd)
         nc_mean = sum((feats[v][0][name][1] + feats[v][1][name][1]) / 2 for v in range(V)) / V       # [B,1,h,w]
         hyp_b = torch.stack(hyps)
-        prob_pre = cost_regularization(model.cost_regularization[s], torch.stack(vols)).squeeze(1)
+        prob_pre = cost_regularization(model.cost_regularization[s], torch.stack(vols)).squeeze(1).float()
         prob = F.softmax(prob_pre, dim=1)
         depth = torch.sum(prob * hyp_b, dim=1)
         with torch.no_grad():

@@ -10,7 +10,9 @@ n = len(rows)
 k = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 lo = n - n // k if k > 1 else 0
 for name, s, e in rows[lo:]:
-    key = name.split("(")[0][-70:]
+    import re
+    key = re.sub(r"\(anonymous namespace\)::", "", name)
+    key = re.sub(r"^void ", "", key).split("(")[0][:90]
     d = agg.setdefault(key, [0, 0.0]); d[0] += 1; d[1] += (e - s) / 1e3
     tot += (e - s) / 1e3
 for key, (c, us) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:30]:

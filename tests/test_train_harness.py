@@ -1,0 +1,121 @@
+"""Training-loop pieces: schedules, optimiser set-up, the flat-bucket gradient all-reduce on gloo
+(world size 2, CPU) and one optimisation step on the GPU in fp32 and under bf16 autocast."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from cds_mvsnet_amd import train as T
+
+
+def test_temperature_schedule():
+    # trainer/trainer.py:45-49: p = (epoch-1)/2, T = 10^-p for epoch <= 4, then 0.01
+    want = {1: 1.0, 2: 10 ** -0.5, 3: 0.1, 4: 10 ** -1.5, 5: 0.01, 9: 0.01}
+    for e, t in want.items():
+        assert T.temperature_for_epoch(e) == pytest.approx(t, rel=1e-12)
+
+
+def test_optimizer_and_scheduler_follow_config_blended():
+    m = torch.nn.Linear(4, 4)
+    opt = T.make_optimizer(m)
+    g = opt.param_groups[0]
+    assert isinstance(opt, torch.optim.SGD) and g["lr"] == 1e-4 and g["weight_decay"] == 0.01 and g["momentum"] == 0
+    sch = T.make_scheduler(opt)
+    lrs = []
+    for _ in range(7):
+        lrs.append(opt.param_groups[0]["lr"])
+        opt.step(); sch.step()
+    assert np.allclose(lrs, [1e-4] * 3 + [5e-5] * 3 + [2.5e-5])
+
+
+def test_reducer_single_process_is_a_no_op():
+    m = torch.nn.Linear(3, 2)
+    m.weight.grad = torch.ones_like(m.weight)
+    r = T.GradAllReducer(m.parameters())
+    assert r.reduce() == 0 and torch.equal(m.weight.grad, torch.ones_like(m.weight))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(0)
+        net = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.ReLU(), torch.nn.Linear(7, 3), torch.nn.Linear(3, 1))
+        for p in net[3].parameters():      # a parameter that no rank's loss touches: must still go through the collective
+            p.requires_grad_(True)
+        x = torch.randn(4, 5, generator=torch.Generator().manual_seed(10 + rank))
+        net[:3](x).pow(2).mean().backward()
+        if rank == 1:
+            net[2].bias.grad = None        # a parameter without a gradient on ONE rank only
+        own = [None if p.grad is None else p.grad.clone() for p in net.parameters()]
+        red = T.GradAllReducer(net.parameters(), bucket_bytes=128)       # several buckets
+        n = red.reduce()
+        q.put((rank, n, own, [p.grad.clone() for p in net.parameters()]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_flat_gradient_allreduce_gloo_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, n0, own0, red0), (_, n1, own1, red1) = res
+    assert n0 == n1 and n0 > 1
+    for a, b, r0, r1 in zip(own0, own1, red0, red1):
+        za = torch.zeros_like(r0) if a is None else a
+        zb = torch.zeros_like(r0) if b is None else b
+        assert torch.allclose(r0, (za + zb) / 2, atol=1e-7) and torch.equal(r0, r1)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+def _train_sample(dev, B=1, N=3, H=64, W=96):
+    from cds_mvsnet_amd import synth
+    import torch.nn.functional as F
+    imgs = torch.cat([synth.make_images(N, H, W, seed=20 + b) for b in range(B)]).to(dev)
+    cams_l = [synth.make_cameras(N, H, W, refine=False, seed=20 + b) for b in range(B)]
+    cams = {k: torch.cat([c[k] for c in cams_l]).to(dev) for k in cams_l[0]}
+    dv = synth.make_depth_values().repeat(B, 1).to(dev)
+    g = torch.Generator().manual_seed(9)
+    base = 600.0 + 120.0 * F.interpolate(torch.rand(B, 1, 4, 6, generator=g), (H, W), mode="bicubic", align_corners=False)[:, 0]
+    gt, mask = {}, {}
+    for s, sc in (("stage1", 4), ("stage2", 2), ("stage3", 1)):
+        gt[s] = F.interpolate(base.unsqueeze(1), (H // sc, W // sc), mode="nearest")[:, 0].contiguous().to(dev)
+        mask[s] = (torch.rand(B, H // sc, W // sc, generator=g) > 0.15).float().to(dev)
+    gt["stage4"], mask["stage4"] = gt["stage3"], mask["stage3"]
+    return {"imgs": imgs, "proj_matrices": cams, "depth_values": dv, "depth": gt, "mask": mask}
+
+
+@pytest.mark.gpu
+def test_train_step_fp32_and_bf16():
+    from cds_mvsnet_amd import CDSMVSNet, seeded_init_
+    dev = torch.device("cuda")
+    sample = _train_sample(dev)
+    losses = {}
+    for bf16 in (False, True):
+        model = seeded_init_(CDSMVSNet(refine=False, ndepths=(48, 32, 8), depth_interals_ratio=(4.0, 2.0, 1.0)), 7).to(dev)
+        opt = T.make_optimizer(model, lr=1e-3)
+        before = {n: p.detach().clone() for n, p in model.named_parameters()}
+        l0, d0 = T.train_step(model, opt, sample, temperature=0.1, reducer=T.GradAllReducer(model.parameters()), bf16=bf16)
+        assert np.isfinite(l0) and np.isfinite(d0) and d0 > 0
+        moved = sum(1 for n, p in model.named_parameters() if not torch.equal(p.detach(), before[n]))
+        assert moved > 0.9 * len(before)                 # every layer is trained (weight decay touches all of them)
+        losses[bf16] = (l0, d0)
+    # bf16 autocast only changes the convolution stacks' arithmetic: same loss to a few per cent
+    assert abs(losses[True][0] - losses[False][0]) < 0.05 * abs(losses[False][0])
