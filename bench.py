@@ -102,6 +102,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="M1", choices=sorted(WORKLOADS))
     ap.add_argument("--parallelism", default="replicas", choices=["replicas", "viewshard"])
+    ap.add_argument("--streams", type=int, default=1,
+                    help="depth maps in flight per GPU on separate HIP streams (a step = that many depth maps; "
+                         "per-kernel event timing and the roofline object need 1)")
     ap.add_argument("--cpu-sample", type=float, default=0.25, help="linear window fraction for the CPU baseline (0 = skip)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) in production; gloo only for single-GPU dry runs")
     args = ap.parse_args()
@@ -146,6 +149,17 @@ def main():
             return model.stage_net(dfe, cams_d, depth_values=hyp_d, num_depth=D,
                                    cost_regularization=model.cost_regularization[stage], stage_idx=stage)
 
+    if args.streams > 1:   # independent pipelines on separate streams: memory-bound and issue-bound kernels overlap
+        one_map = step
+        lanes = [torch.cuda.Stream(device=dev) for _ in range(args.streams)]
+
+        def step():
+            out = None
+            for st in lanes:
+                with torch.cuda.stream(st):
+                    out = one_map()
+            return out
+
     def barrier():
         if dist is not None:
             dist.barrier()
@@ -155,7 +169,7 @@ def main():
         for _ in range(args.warmup):
             out = step()
         ops.PROFILE.clear()
-        ops.PROFILE_ON = True
+        ops.PROFILE_ON = args.streams == 1
         barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
@@ -168,7 +182,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3
-    maps_per_step = world if args.parallelism == "replicas" else 1
+    maps_per_step = (world if args.parallelism == "replicas" else 1) * args.streams
     value = maps_per_step * args.steps / dt
     depth_mean = float(out["depth"].mean().item())
 
@@ -213,7 +227,8 @@ def main():
             "scaling": "weak" if args.parallelism == "replicas" else "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic (seeded features/cameras/hypotheses, seeded random weights)",
             "config": {"workload": f"{args.workload}: single-stage StageNet volume {w}x{h}, D={D}, C={C}, N={n_views} views",
-                       "parallelism": args.parallelism if world > 1 else "single", "depth_mean": depth_mean},
+                       "parallelism": args.parallelism if world > 1 else "single", "depth_maps_per_step_per_gpu": args.streams,
+                       "depth_mean": depth_mean},
             "roofline": roof, "cpu_baseline": cpu,
         }
         line.update(extra)
