@@ -38,6 +38,7 @@ SIGNATURES = {
     "cds_depth_hypotheses_f32": [P, P, I, I, I, I, I, I, F, F, F, P],
     "cds_depth_planes_f32": [P, I, I, I, F, F, P],
     "cds_conv3d_k3_f32": [P, P, P, P, P, I, I, I, I, I, I, I, P],
+    "cds_conv3d_k3_cl_f32": [P, P, P, P, P, I, I, I, I, I, I, P],
     "cds_deconv3d_k3s2_f32": [P, P, P, P, P, I, I, I, I, I, I, P],
     "cds_conv2d_f32": [P, P, P, P, I, I, I, I, I, I, I, I, I, P],
     "cds_dynconv_blend_f32": [P, P, P, P, P, F, P, P, I, I, I, I, I, P],

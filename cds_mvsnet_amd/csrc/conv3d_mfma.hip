@@ -154,6 +154,167 @@ __global__ __launch_bounds__(256) void conv3d_k3_mfma_kernel(const float* __rest
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Channels-last LDS variant (stride 1, Cin % 16 == 0, Cout % 16 == 0).  Micro-benchmark (scripts/ubench/mfma_rate.hip):
+// back-to-back v_mfma_f32_16x16x4_f32 reach 148 TF, but with ONE ds_read_b32 per MFMA (the kernel above) only 86 TF at
+// 2 waves/SIMD — an LDS read costs ~10 ns of its SIMD regardless of width.  Here the LDS tile is [z][y][x][16 ci]
+// (64 B per position, 16-byte slots XOR-swizzled by (x >> 1) & 3 so the 16 lanes of an M-run are conflict-free) and
+// lane (m, k) fetches ci = 4k..4k+3 of its voxel with one ds_read_b128 = the A operands of FOUR MFMAs (K-step c
+// multiplies ci = 4k + c); the matching B operands w[tap][co][4k..4k+3] are one global_load_dwordx4 from a
+// ci-fastest weight copy.  5 operand fetches per 16 MFMAs instead of 17.
+//   tile 32 x 4 x 2 outputs (wave = y row, 4 M-tiles of 16 voxels), LDS 4*6*40 positions * 64 B = 60 KB
+// ---------------------------------------------------------------------------------------------
+struct MClCfg {
+  static constexpr int TX = 32, TY = 4, TZ = 2, XT = TX / 16, NT = XT * TZ;
+  static constexpr int IY = TY + 2, IZ = TZ + 2;
+  static constexpr int IXP = TX + 8;                 // column c <-> x = ox0 - 4 + c (16-byte aligned global rows)
+  static constexpr int Q = IXP / 4;
+  static constexpr int NPOS = IZ * IY * IXP;          // 960
+  static constexpr int CI = 16;                       // input channels resident per chunk
+  static constexpr int NSLOTS = IZ * IY * Q * 4;      // (row, x-group, k-group) staging slots
+  static constexpr int NSLOT = (NSLOTS + 255) / 256;  // per thread
+};
+
+__global__ __launch_bounds__(256, 2) void conv3d_k3_mfma_cl_kernel(const float* __restrict__ x,
+                                                                    const float* __restrict__ wcl,
+                                                                    const float* __restrict__ bias,
+                                                                    const float* __restrict__ skip,
+                                                                    float* __restrict__ out, int Cin, int Cout, int D,
+                                                                    int H, int W, int act, int tiles_x, int tiles_y,
+                                                                    int tiles_z, int ntiles) {
+  using Cfg = MClCfg;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int co_blocks = Cout / 16;
+  int lin = cds_xcd_remap(blockIdx.x, ntiles * co_blocks);
+  const int cob = lin % co_blocks;
+  int tile = lin / co_blocks;
+  const int tx_i = tile % tiles_x;
+  tile /= tiles_x;
+  const int ty_i = tile % tiles_y;
+  const int tz_i = tile / tiles_y;
+  const int co0 = cob * 16;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // = output row y of this wave inside the tile
+  const int ox0 = tx_i * Cfg::TX, oy0 = ty_i * Cfg::TY, oz0 = tz_i * Cfg::TZ;
+  const int gx0 = ox0 - 4, gy0 = oy0 - 1, gz0 = oz0 - 1;
+  const size_t plane = (size_t)H * W, vol = (size_t)D * plane;
+
+  // ---- staging: slot = (row, x-group q, k-group kg): 4 channels x 4 x-positions, transposed in registers ----
+  int goff[Cfg::NSLOT];    // element offset of (ci = 4 kg, row, 4q) inside the chunk, -1 = outside / unused
+  int loff[Cfg::NSLOT][2]; // LDS float offsets of x = 4q (+1 shares the swizzle) and x = 4q + 2 (+3)
+#pragma unroll
+  for (int j = 0; j < Cfg::NSLOT; ++j) {
+    const int s = tid + 256 * j;
+    const int kg = s & 3;
+    const int q = (s >> 2) % Cfg::Q;
+    const int row = (s >> 2) / Cfg::Q;
+    const int rz = row / Cfg::IY, ry = row - rz * Cfg::IY;
+    const int gz = gz0 + rz, gy = gy0 + ry, gx = gx0 + 4 * q;
+    const bool ok = (s < Cfg::NSLOTS) && gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx + 3 < W;
+    goff[j] = ok ? (int)((size_t)(4 * kg) * vol + (size_t)gz * plane + (size_t)gy * W + gx) : -1;
+    const int pos = row * Cfg::IXP + 4 * q;
+    loff[j][0] = pos * 16 + ((kg ^ ((2 * q) & 3)) << 2);
+    loff[j][1] = (pos + 2) * 16 + ((kg ^ ((2 * q + 1) & 3)) << 2);
+  }
+  float4 pre[Cfg::NSLOT][4];
+  auto issue = [&](int ci0) {
+    const float* __restrict__ xb = x + (size_t)ci0 * vol;
+#pragma unroll
+    for (int j = 0; j < Cfg::NSLOT; ++j) {
+      const bool ok = goff[j] >= 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) pre[j][i] = *reinterpret_cast<const float4*>(ok ? xb + goff[j] + (size_t)i * vol : x);
+    }
+  };
+  auto deposit = [&]() {
+#pragma unroll
+    for (int j = 0; j < Cfg::NSLOT; ++j) {
+      const int s = tid + 256 * j;
+      if (s < Cfg::NSLOTS) {
+        const bool ok = goff[j] >= 0;
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 c0 = ok ? make_float4(pre[j][0].x, pre[j][1].x, pre[j][2].x, pre[j][3].x) : z4;
+        const float4 c1 = ok ? make_float4(pre[j][0].y, pre[j][1].y, pre[j][2].y, pre[j][3].y) : z4;
+        const float4 c2 = ok ? make_float4(pre[j][0].z, pre[j][1].z, pre[j][2].z, pre[j][3].z) : z4;
+        const float4 c3 = ok ? make_float4(pre[j][0].w, pre[j][1].w, pre[j][2].w, pre[j][3].w) : z4;
+        *reinterpret_cast<float4*>(lds + loff[j][0]) = c0;
+        *reinterpret_cast<float4*>(lds + loff[j][0] + 16) = c1;
+        *reinterpret_cast<float4*>(lds + loff[j][1]) = c2;
+        *reinterpret_cast<float4*>(lds + loff[j][1] + 16) = c3;
+      }
+    }
+  };
+
+  // ---- lane-constant A addresses: voxel m = l & 15 of run txr, tap column kx; row / plane offsets are immediates ----
+  const int m = lane & 15, kq = lane >> 4;
+  const float* a_ptr[3][Cfg::XT];
+#pragma unroll
+  for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+    for (int txr = 0; txr < Cfg::XT; ++txr) {
+      const int col = 3 + txr * 16 + m + kx;
+      a_ptr[kx][txr] = lds + (wave * Cfg::IXP + col) * 16 + ((kq ^ ((col >> 1) & 3)) << 2);
+    }
+  // B: w_cl[tap][co][ci], lane (n = l & 15, k) reads ci = ci0 + 4k .. +3 of output channel co0 + n
+  const float* __restrict__ b_lane = wcl + (size_t)(co0 + m) * Cin + 4 * kq;
+  const size_t tap_stride = (size_t)Cout * Cin;
+
+  f32x4 acc[Cfg::NT];
+#pragma unroll
+  for (int t = 0; t < Cfg::NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  issue(0);
+  for (int ci0 = 0; ci0 < Cin; ci0 += Cfg::CI) {
+    __syncthreads();
+    deposit();
+    __syncthreads();
+    if (ci0 + Cfg::CI < Cin) issue(ci0 + Cfg::CI);
+    const float* __restrict__ bw = b_lane + ci0;
+#pragma unroll
+    for (int kz = 0; kz < 3; ++kz) {
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const cds_f4 bv = *reinterpret_cast<const cds_f4*>(bw + (size_t)((kz * 3 + ky) * 3 + kx) * tap_stride);
+#pragma unroll
+          for (int t = 0; t < Cfg::NT; ++t) {
+            const int tz = t / Cfg::XT, txr = t % Cfg::XT;
+            const cds_f4 av = *reinterpret_cast<const cds_f4*>(a_ptr[kx][txr] + ((tz + kz) * Cfg::IY + ky) * Cfg::IXP * 16);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc[t], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+
+  // ---- epilogue: lane -> cout (l & 15), voxels x = run*16 + (l >> 4)*4 + 0..3 ----
+  const int oy = oy0 + wave;
+  if (oy >= H) return;
+  const int co = co0 + m;
+  const float b = bias ? bias[co] : 0.f;
+#pragma unroll
+  for (int t = 0; t < Cfg::NT; ++t) {
+    const int tz = t / Cfg::XT, txr = t % Cfg::XT;
+    const int oz = oz0 + tz, oxb = ox0 + txr * 16 + kq * 4;
+    if (oz >= D || oxb >= W) continue;          // W % 4 == 0: the four voxels are inside together
+    const size_t base = (size_t)co * vol + (size_t)oz * plane + (size_t)oy * W + oxb;
+    float4 o = make_float4(acc[t].x + b, acc[t].y + b, acc[t].z + b, acc[t].w + b);
+    if (act == CDS_ACT_RELU) {
+      o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
+    }
+    if (skip) {
+      const float4 s4 = *reinterpret_cast<const float4*>(skip + base);
+      o.x = s4.x + o.x; o.y = s4.y + o.y; o.z = s4.z + o.z; o.w = s4.w + o.w;
+    }
+    *reinterpret_cast<float4*>(out + base) = o;
+  }
+}
+
 template <int S>
 int launch_mfma(const float* x, const float* w, const float* b, const float* skip, float* out, int Cin, int Cout, int D,
                 int H, int W, int act, hipStream_t st) {
@@ -365,3 +526,20 @@ bool cds_deconv3d_mfma_launch(const float* x, const float* w, const float* b, co
   *rc = cds_launch_status();
   return true;
 }
+
+// stride-1 3x3x3 convolution with the ci-fastest weight copy (see conv3d_k3_mfma_cl_kernel)
+extern "C" int cds_conv3d_k3_cl_f32(const float* x, const float* weight_cl, const float* bias, const float* skip,
+                                    float* out, int Cin, int Cout, int D, int H, int W, int act, void* stream) {
+  if (!x || !weight_cl || !out || Cin < 16 || (Cin % 16) || Cout < 16 || (Cout % 16) || D < 1 || H < 1 || W < 4 || (W % 4) ||
+      (size_t)Cin * D * H * W >= (size_t)0x7fffffff)
+    return CDS_EINVAL;
+  using Cfg = MClCfg;
+  const int tx = cds_ceil_div(W, Cfg::TX), ty = cds_ceil_div(H, Cfg::TY), tz = cds_ceil_div(D, Cfg::TZ);
+  const int ntiles = tx * ty * tz;
+  const size_t lds_bytes = (size_t)Cfg::NPOS * 16 * sizeof(float);
+  static_assert(Cfg::NPOS * 16 * sizeof(float) <= 65536, "LDS tile above 64 KB");
+  hipLaunchKernelGGL(conv3d_k3_mfma_cl_kernel, dim3(ntiles * (Cout / 16)), dim3(256), lds_bytes, (hipStream_t)stream, x,
+                     weight_cl, bias, skip, out, Cin, Cout, D, H, W, act, tx, ty, tz, ntiles);
+  return cds_launch_status();
+}
+

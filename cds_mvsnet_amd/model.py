@@ -129,6 +129,9 @@ class CostRegNet(nn.Module):
                 w = (w * scale.view(-1, 1, 1, 1, 1)).permute(1, 2, 3, 4, 0)
             out[name + ".w"] = w.reshape(w.shape[0], 27, w.shape[-1]).contiguous()
             out[name + ".b"] = shift.contiguous()
+            if not unit.transposed and unit.stride == 1 and w.shape[0] % 16 == 0 and w.shape[-1] % 16 == 0:
+                # ci-fastest copy [27,Cout,Cin] for the channels-last MFMA kernel (conv2, conv4, conv6)
+                out[name + ".wcl"] = w.permute(1, 2, 3, 4, 0).reshape(27, w.shape[-1], w.shape[0]).contiguous()
         w = self.prob.weight.detach().permute(1, 2, 3, 4, 0)
         out["prob.w"] = w.reshape(w.shape[0], 27, 1).contiguous()
         return out
@@ -148,13 +151,13 @@ class CostRegNet(nn.Module):
     def _run(volume: Tensor, p: Dict[str, Tensor]) -> Tensor:
         c0 = ops.conv3d_k3(volume, p["conv0.w"], p["conv0.b"])
         c1 = ops.conv3d_k3(c0, p["conv1.w"], p["conv1.b"], stride=2)
-        c2 = ops.conv3d_k3(c1, p["conv2.w"], p["conv2.b"])
+        c2 = ops.conv3d_k3(c1, p["conv2.w"], p["conv2.b"], wcl=p.get("conv2.wcl"))
         del c1
         c3 = ops.conv3d_k3(c2, p["conv3.w"], p["conv3.b"], stride=2)
-        c4 = ops.conv3d_k3(c3, p["conv4.w"], p["conv4.b"])
+        c4 = ops.conv3d_k3(c3, p["conv4.w"], p["conv4.b"], wcl=p.get("conv4.wcl"))
         del c3
         c5 = ops.conv3d_k3(c4, p["conv5.w"], p["conv5.b"], stride=2)
-        x = ops.conv3d_k3(c5, p["conv6.w"], p["conv6.b"])
+        x = ops.conv3d_k3(c5, p["conv6.w"], p["conv6.b"], wcl=p.get("conv6.wcl"))
         del c5
         x = ops.deconv3d_k3s2(x, p["conv7.w"], p["conv7.b"], skip=c4)
         del c4

@@ -6,6 +6,7 @@ contiguous, ROCm-resident tensors and raises otherwise — there is no CPU path.
 """
 from __future__ import annotations
 
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -225,10 +226,37 @@ def depth_planes(D: int, h: int, w: int, lo: float, hi: float, device) -> Tensor
     return out
 
 
+def conv3d_cl_supported(Cin: int, Cout: int, W: int, stride: int) -> bool:
+    """Shapes covered by cds_conv3d_k3_cl_f32 (channels-last LDS tile on the matrix cores)."""
+    return stride == 1 and Cin % 16 == 0 and Cout % 16 == 0 and W % 4 == 0 and W >= 16 and USE_CONV3D_CL
+
+
+def conv3d_cl_preferred(Cin: int) -> bool:
+    """Measured at M1: the channels-last kernel stages a whole 16-channel chunk before its first MFMA, which is only
+    amortised from 4 chunks on (conv6, 64 -> 64: 345 vs 462 us; conv4 32 -> 32: 596 vs 580; conv2 16 -> 16: 1386 vs 1127)."""
+    return Cin >= 64 or os.environ.get("CDS_CONV_CL", "1") == "2"
+
+
+USE_CONV3D_CL = os.environ.get("CDS_CONV_CL", "1") != "0"     # A/B knob
+
+
 def conv3d_k3(x: Tensor, wpk: Tensor, bias: Optional[Tensor], stride: int = 1, relu: bool = True,
-              skip: Optional[Tensor] = None) -> Tensor:
-    """K4.  x [Cin,D,H,W], wpk packed [Cin,27,Cout] -> [Cout,Do,Ho,Wo]."""
+              skip: Optional[Tensor] = None, wcl: Optional[Tensor] = None) -> Tensor:
+    """K4.  x [Cin,D,H,W], wpk packed [Cin,27,Cout] -> [Cout,Do,Ho,Wo].  wcl: optional ci-fastest copy [27,Cout,Cin]
+    of the same weights; when given and the shape is covered the channels-last MFMA kernel is used."""
     Cin, D, H, W = x.shape
+    if (wcl is not None and conv3d_cl_supported(Cin, wpk.shape[2], W, stride) and conv3d_cl_preferred(Cin)
+            and Cin * D * H * W < 0x7fffffff):
+        Cout = wpk.shape[2]
+        if tuple(wcl.shape) != (27, Cout, Cin):
+            raise ValueError("conv3d_k3: wcl must be [27,Cout,Cin]")
+        out = torch.empty((Cout, D, H, W), dtype=torch.float32, device=x.device)
+        if skip is not None and skip.shape != out.shape:
+            raise ValueError("conv3d_k3: residual shape mismatch")
+        check(_lib.load().cds_conv3d_k3_cl_f32(_dev(x, "x"), _dev(wcl, "weight_cl"), _dev(bias, "bias") if bias is not None else None,
+                                               _dev(skip, "skip") if skip is not None else None, out.data_ptr(), Cin, Cout,
+                                               D, H, W, ACT_RELU if relu else ACT_NONE, _stream(x)), "cds_conv3d_k3_cl_f32")
+        return out
     if wpk.shape[0] != Cin or wpk.shape[1] != 27:
         raise ValueError("conv3d_k3: packed weight must be [Cin,27,Cout]")
     Cout = wpk.shape[2]

@@ -135,6 +135,15 @@ int cds_conv3d_k3_f32(const float* x, const float* weight, const float* bias, co
                       void* stream);
 
 /*
+ * Same convolution at stride 1 for Cin % 16 == 0, Cout % 16 == 0, W % 4 == 0 on the matrix cores with a
+ * channels-last LDS tile (one 16-byte LDS read feeds four MFMAs).
+ *   weight_cl PACKED [27][Cout][Cin] (cin fastest) = PyTorch's [Cout][Cin][3][3][3] permuted (2,3,4,0,1)
+ * Returns CDS_EINVAL for shapes it does not cover (callers fall back to cds_conv3d_k3_f32).
+ */
+int cds_conv3d_k3_cl_f32(const float* x, const float* weight_cl, const float* bias, const float* skip,
+                         float* out, int Cin, int Cout, int D, int H, int W, int act, void* stream);
+
+/*
  * K4 (module.py:125-160): ConvTranspose3d k=3, stride 2, padding 1, output_padding 1 (doubles
  * D,H,W) + bias + activation + residual.
  *   weight PACKED [Cin][27][Cout] — PyTorch's transposed-conv layout [Cin][Cout][3][3][3]

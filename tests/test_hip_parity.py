@@ -6,6 +6,8 @@ entropy / visibility <= 2e-5, CostRegNet output <= 1e-4, single DynamicConv <= 5
 mean <= 2e-5 (max <= 2e-3 at T=0.01, round-off amplified by softmax(./T)), stage depth mean-L1 <= 1e-3
 (the reference is not bit-stable against itself below ~2e-4).
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -528,3 +530,31 @@ def test_refinement_hip_vs_oracle(h, w, seeded_state):
         got = net(img.cuda(), depth0.cuda(), dmin.cuda(), dmax.cuda()).cpu()
     assert got.shape == exp.shape
     assert (got - exp).abs().max() < 2e-3 and (got - exp).abs().mean() < 1e-4      # depths ~160-360
+
+
+def test_conv3d_channels_last_mfma_vs_torch(dev, ops):
+    """cds_conv3d_k3_cl_f32 (channels-last LDS tile, one b128 LDS read per four MFMAs) vs torch fp32: one and several
+    16-channel chunks, several cout blocks, partial tiles in x / y / z, with and without bias / skip / ReLU."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(3)
+    for (cin, cout, D, H, W, relu, use_skip, use_bias) in [(16, 16, 2, 4, 32, True, True, True), (16, 16, 3, 7, 36, True, False, True),
+                                                           (32, 32, 5, 6, 40, True, True, True), (64, 64, 3, 5, 20, False, False, False),
+                                                           (16, 48, 1, 1, 16, True, True, False), (32, 16, 7, 9, 100, True, True, True)]:
+        assert ops.conv3d_cl_supported(cin, cout, W, 1)
+        x = torch.randn(cin, D, H, W, generator=g)
+        w = torch.randn(cout, cin, 3, 3, 3, generator=g) * 0.1
+        b = torch.randn(cout, generator=g) if use_bias else None
+        ref = F.conv3d(x[None], w, b, padding=1)[0]
+        if relu:
+            ref = F.relu(ref)
+        skip = torch.randn(ref.shape, generator=g) if use_skip else None
+        wpk = w.permute(1, 2, 3, 4, 0).reshape(cin, 27, cout).contiguous().to(dev)
+        wcl = w.permute(2, 3, 4, 0, 1).reshape(27, cout, cin).contiguous().to(dev)
+        os.environ["CDS_CONV_CL"] = "2"          # force the channels-last kernel for every covered shape
+        try:
+            out = ops.conv3d_k3(x.to(dev), wpk, b.to(dev) if use_bias else None, relu=relu,
+                                skip=skip.to(dev) if use_skip else None, wcl=wcl).cpu()
+        finally:
+            os.environ.pop("CDS_CONV_CL")
+        want = ref + skip if use_skip else ref
+        assert (out - want).abs().max() < 2e-5 * max(1.0, ref.abs().max().item()), (cin, cout, D, H, W)
