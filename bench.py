@@ -105,7 +105,7 @@ def main():
     ap.add_argument("--streams", type=int, default=1,
                     help="depth maps in flight per GPU on separate HIP streams (a step = that many depth maps; "
                          "per-kernel event timing and the roofline object need 1)")
-    ap.add_argument("--cpu-sample", type=float, default=0.25, help="linear window fraction for the CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-sample", type=float, default=0.75, help="linear window fraction for the CPU baseline (0 = skip)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) in production; gloo only for single-GPU dry runs")
     args = ap.parse_args()
 
