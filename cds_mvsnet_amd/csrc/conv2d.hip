@@ -9,6 +9,8 @@
 // x-adjacent outputs x 8 output channels of accumulators per thread, weights packed
 // [Cin][k*k][CoutP] (cout fastest, CoutP = Cout rounded up to 8, zero padded) and fetched as
 // wave-uniform scalar loads.
+#include <stdlib.h>
+
 #include "cds_common.hpp"
 
 namespace {
@@ -25,22 +27,28 @@ struct C2Cfg {
   static constexpr int NIN = (PX - 1) * S + K;
 };
 
-template <int K, int S, int PX, int CI_CHUNK>
+// NCB = number of 8-wide output-channel blocks a workgroup produces from ONE staged input tile (the launcher only
+// picks values that divide CoutP / 8, so every group is full width).  The DynamicConv branches have Cout + 3 =
+// 11 / 19 / 35 output channels (2 / 3 / 5 blocks): with one block per workgroup the input tile is staged 2-5 times.
+// K = 1 needs no halo and reads its inputs straight from global memory (the 1x1 convolutions ran at 1/7 of the HBM
+// rate through the LDS path).
+template <int K, int S, int PX, int CI_CHUNK, int NCB>
 __global__ __launch_bounds__(256) void conv2d_kernel(const float* __restrict__ x, const float* __restrict__ wpk,
                                                      const float* __restrict__ bias, float* __restrict__ out, int N,
                                                      int Cin, int Cout, int CoutP, int H, int W, int Ho, int Wo, int pad,
                                                      int act, int tiles_x, int tiles_y) {
   using Cfg = C2Cfg<K, S, PX, CI_CHUNK>;
+  constexpr int CW = CO * NCB;   // output channels per workgroup
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int co_blocks = CoutP / CO;
+  const int co_groups = CoutP / CW;
   const int ntiles = tiles_x * tiles_y;
-  int lin = cds_xcd_remap(blockIdx.x, ntiles * co_blocks * N);
-  const int cob = lin % co_blocks;
-  lin /= co_blocks;
+  int lin = cds_xcd_remap(blockIdx.x, ntiles * co_groups * N);
+  const int cog = lin % co_groups;
+  lin /= co_groups;
   const int tile = lin % ntiles;
   const int n = lin / ntiles;
   const int tx_i = tile % tiles_x, ty_i = tile / tiles_x;
-  const int co0 = cob * CO;
+  const int co0 = cog * CW;
   const int tid = threadIdx.x;
   const int lx = tid % Cfg::LX, ly = tid / Cfg::LX;
   const int ox0 = tx_i * Cfg::TX, oy0 = ty_i * Cfg::TY;
@@ -48,46 +56,65 @@ __global__ __launch_bounds__(256) void conv2d_kernel(const float* __restrict__ x
   const size_t plane = (size_t)H * W;
   const float* __restrict__ xn = x + (size_t)n * Cin * plane;
 
-  float acc[PX][CO];
+  float acc[PX][CW];
 #pragma unroll
   for (int p = 0; p < PX; ++p)
 #pragma unroll
-    for (int c = 0; c < CO; ++c) acc[p][c] = 0.f;
+    for (int c = 0; c < CW; ++c) acc[p][c] = 0.f;
 
-  for (int ci0 = 0; ci0 < Cin; ci0 += CI_CHUNK) {
-    __syncthreads();
-    const int nrows = CI_CHUNK * Cfg::IY;
-    for (int row = tid / 64; row < nrows; row += 4) {
-      const int ci = row / Cfg::IY, ry = row % Cfg::IY;
-      const int gy = gy0 + ry;
-      const bool row_ok = (ci0 + ci < Cin) && gy >= 0 && gy < H;
-      const float* __restrict__ src = xn + (size_t)(ci0 + ci) * plane + (size_t)gy * W;
-      float* dst = lds + ci * Cfg::TILE + ry * Cfg::IXP;
-      for (int i = tid & 63; i < Cfg::IXP; i += 64) {
-        const int gx = gx0 + i;
-        float v = 0.f;
-        if (row_ok && gx >= 0 && gx < W && i < Cfg::IX) v = src[gx];
-        dst[i] = v;
+  if constexpr (K == 1 && S == 1) {
+    // pointwise (pad = 0): out[co][p] = sum_ci w[ci][co] * in[ci][p]
+    const int oyp = oy0 + ly, oxp = ox0 + lx * PX;
+    const bool rowok = oyp < H;
+    for (int ci = 0; ci < Cin; ++ci) {
+      const float* __restrict__ src = xn + (size_t)ci * plane + (size_t)(rowok ? oyp : 0) * W;
+      float in[PX];
+#pragma unroll
+      for (int p = 0; p < PX; ++p) in[p] = (rowok && oxp + p < W) ? src[oxp + p] : 0.f;
+      const float* __restrict__ wc = wpk + __builtin_amdgcn_readfirstlane(ci * CoutP + co0);
+#pragma unroll
+      for (int c = 0; c < CW; ++c) {
+        const float wv = wc[c];
+#pragma unroll
+        for (int p = 0; p < PX; ++p) acc[p][c] = fmaf(in[p], wv, acc[p][c]);
       }
     }
-    __syncthreads();
-    const int cmax = min(CI_CHUNK, Cin - ci0);
-    for (int ci = 0; ci < cmax; ++ci) {
-      const float* __restrict__ wc = wpk + __builtin_amdgcn_readfirstlane(((ci0 + ci) * K * K) * CoutP + co0);
-      const float* tile_ci = lds + ci * Cfg::TILE;
+  } else {
+    for (int ci0 = 0; ci0 < Cin; ci0 += CI_CHUNK) {
+      __syncthreads();
+      const int nrows = CI_CHUNK * Cfg::IY;
+      for (int row = tid / 64; row < nrows; row += 4) {
+        const int ci = row / Cfg::IY, ry = row % Cfg::IY;
+        const int gy = gy0 + ry;
+        const bool row_ok = (ci0 + ci < Cin) && gy >= 0 && gy < H;
+        const float* __restrict__ src = xn + (size_t)(ci0 + ci) * plane + (size_t)gy * W;
+        float* dst = lds + ci * Cfg::TILE + ry * Cfg::IXP;
+        for (int i = tid & 63; i < Cfg::IXP; i += 64) {
+          const int gx = gx0 + i;
+          float v = 0.f;
+          if (row_ok && gx >= 0 && gx < W && i < Cfg::IX) v = src[gx];
+          dst[i] = v;
+        }
+      }
+      __syncthreads();
+      const int cmax = min(CI_CHUNK, Cin - ci0);
+      for (int ci = 0; ci < cmax; ++ci) {
+        const float* __restrict__ wc = wpk + __builtin_amdgcn_readfirstlane(((ci0 + ci) * K * K) * CoutP + co0);
+        const float* tile_ci = lds + ci * Cfg::TILE;
 #pragma unroll
-      for (int ky = 0; ky < K; ++ky) {
-        const float* rowp = tile_ci + (ly * S + ky) * Cfg::IXP + lx * PX * S;
-        float in[Cfg::NIN];
+        for (int ky = 0; ky < K; ++ky) {
+          const float* rowp = tile_ci + (ly * S + ky) * Cfg::IXP + lx * PX * S;
+          float in[Cfg::NIN];
 #pragma unroll
-        for (int i = 0; i < Cfg::NIN; ++i) in[i] = rowp[i];
+          for (int i = 0; i < Cfg::NIN; ++i) in[i] = rowp[i];
 #pragma unroll
-        for (int kx = 0; kx < K; ++kx) {
+          for (int kx = 0; kx < K; ++kx) {
 #pragma unroll
-          for (int c = 0; c < CO; ++c) {
-            const float wv = wc[(ky * K + kx) * CoutP + c];
+            for (int c = 0; c < CW; ++c) {
+              const float wv = wc[(ky * K + kx) * CoutP + c];
 #pragma unroll
-            for (int p = 0; p < PX; ++p) acc[p][c] = fmaf(in[p * S + kx], wv, acc[p][c]);
+              for (int p = 0; p < PX; ++p) acc[p][c] = fmaf(in[p * S + kx], wv, acc[p][c]);
+            }
           }
         }
       }
@@ -98,7 +125,7 @@ __global__ __launch_bounds__(256) void conv2d_kernel(const float* __restrict__ x
   if (oy >= Ho) return;
   const size_t oplane = (size_t)Ho * Wo;
 #pragma unroll
-  for (int c = 0; c < CO; ++c) {
+  for (int c = 0; c < CW; ++c) {
     if (co0 + c < Cout) {
       const float b = bias ? bias[co0 + c] : 0.f;
       const size_t base = ((size_t)n * Cout + co0 + c) * oplane + (size_t)oy * Wo + oxb;
@@ -109,18 +136,41 @@ __global__ __launch_bounds__(256) void conv2d_kernel(const float* __restrict__ x
   }
 }
 
-template <int K, int S, int PX, int CI_CHUNK>
-int launch_conv2d(const float* x, const float* w, const float* b, float* out, int N, int Cin, int Cout, int H, int W,
-                  int pad, int act, hipStream_t st) {
+template <int K, int S, int PX, int CI_CHUNK, int NCB>
+int launch_conv2d_n(const float* x, const float* w, const float* b, float* out, int N, int Cin, int Cout, int H, int W,
+                    int pad, int act, hipStream_t st) {
   using Cfg = C2Cfg<K, S, PX, CI_CHUNK>;
   const int Ho = (H + 2 * pad - K) / S + 1, Wo = (W + 2 * pad - K) / S + 1;
   const int CoutP = (Cout + CO - 1) / CO * CO;
   const int tx = cds_ceil_div(Wo, Cfg::TX), ty = cds_ceil_div(Ho, Cfg::TY);
-  const size_t lds_bytes = (size_t)Cfg::TILE * CI_CHUNK * sizeof(float);
-  auto kern = conv2d_kernel<K, S, PX, CI_CHUNK>;
-  hipLaunchKernelGGL(kern, dim3(tx * ty * (CoutP / CO) * N), dim3(256), lds_bytes, st, x, w, b, out, N, Cin, Cout,
-                     CoutP, H, W, Ho, Wo, pad, act, tx, ty);
+  const int co_groups = CoutP / (CO * NCB);
+  const size_t lds_bytes = (K == 1 && S == 1) ? 0 : (size_t)Cfg::TILE * CI_CHUNK * sizeof(float);
+  auto kern = conv2d_kernel<K, S, PX, CI_CHUNK, NCB>;
+  hipLaunchKernelGGL(kern, dim3(tx * ty * co_groups * N), dim3(256), lds_bytes, st, x, w, b, out, N, Cin, Cout, CoutP, H,
+                     W, Ho, Wo, pad, act, tx, ty);
   return cds_launch_status();
+}
+
+// CDS_CONV2D_NCB (A/B knob): 1 = one 8-wide block per workgroup everywhere (default: measured faster for K > 1, the
+// wide variants spill their accumulators past the point where the saved staging pays); 0 = wide variants for K > 1.
+template <int K, int S, int CI_CHUNK>
+int launch_conv2d(const float* x, const float* w, const float* b, float* out, int N, int Cin, int Cout, int H, int W,
+                  int pad, int act, hipStream_t st) {
+  static const int wide = []() { const char* e = getenv("CDS_CONV2D_WIDE"); return e ? atoi(e) : -1; }();
+  const int blocks = (Cout + CO - 1) / CO;
+  constexpr int PXW = (S == 2) ? 2 : 4;
+  const bool use_wide = wide >= 0 ? wide != 0 : (K == 1);
+  if (use_wide) {
+    if (blocks % 2 == 0 && (blocks == 2 || K > 5))
+      return launch_conv2d_n<K, S, PXW, CI_CHUNK, 2>(x, w, b, out, N, Cin, Cout, H, W, pad, act, st);
+    if constexpr (K <= 5) {
+      if (K <= 3 && blocks % 5 == 0) return launch_conv2d_n<K, S, 2, CI_CHUNK, 5>(x, w, b, out, N, Cin, Cout, H, W, pad, act, st);
+      if (blocks % 4 == 0) return launch_conv2d_n<K, S, 2, CI_CHUNK, 4>(x, w, b, out, N, Cin, Cout, H, W, pad, act, st);
+      if (blocks % 3 == 0) return launch_conv2d_n<K, S, 2, CI_CHUNK, 3>(x, w, b, out, N, Cin, Cout, H, W, pad, act, st);
+      if (blocks % 2 == 0) return launch_conv2d_n<K, S, PXW, CI_CHUNK, 2>(x, w, b, out, N, Cin, Cout, H, W, pad, act, st);
+    }
+  }
+  return launch_conv2d_n<K, S, PXW, CI_CHUNK, 1>(x, w, b, out, N, Cin, Cout, H, W, pad, act, st);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -261,15 +311,15 @@ extern "C" int cds_conv2d_f32(const float* x, const float* weight, const float* 
   hipStream_t st = (hipStream_t)stream;
   if (stride == 1) {
     switch (k) {
-      case 1: return launch_conv2d<1, 1, 4, 8>(x, weight, bias, out, N, Cin, Cout, H, W, pad, act, st);
-      case 3: return launch_conv2d<3, 1, 4, 4>(x, weight, bias, out, N, Cin, Cout, H, W, pad, act, st);
-      case 5: return launch_conv2d<5, 1, 4, 4>(x, weight, bias, out, N, Cin, Cout, H, W, pad, act, st);
-      case 7: return launch_conv2d<7, 1, 4, 4>(x, weight, bias, out, N, Cin, Cout, H, W, pad, act, st);
-      case 11: return launch_conv2d<11, 1, 4, 4>(x, weight, bias, out, N, Cin, Cout, H, W, pad, act, st);
+      case 1: return pad == 0 ? launch_conv2d<1, 1, 8>(x, weight, bias, out, N, Cin, Cout, H, W, pad, act, st) : CDS_EINVAL;
+      case 3: return launch_conv2d<3, 1, 4>(x, weight, bias, out, N, Cin, Cout, H, W, pad, act, st);
+      case 5: return launch_conv2d<5, 1, 4>(x, weight, bias, out, N, Cin, Cout, H, W, pad, act, st);
+      case 7: return launch_conv2d<7, 1, 4>(x, weight, bias, out, N, Cin, Cout, H, W, pad, act, st);
+      case 11: return launch_conv2d<11, 1, 4>(x, weight, bias, out, N, Cin, Cout, H, W, pad, act, st);
       default: return CDS_EINVAL;
     }
   }
-  if (stride == 2 && k == 3) return launch_conv2d<3, 2, 2, 4>(x, weight, bias, out, N, Cin, Cout, H, W, pad, act, st);
+  if (stride == 2 && k == 3) return launch_conv2d<3, 2, 4>(x, weight, bias, out, N, Cin, Cout, H, W, pad, act, st);
   return CDS_EINVAL;
 }
 
