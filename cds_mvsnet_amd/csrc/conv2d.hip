@@ -151,15 +151,15 @@ int launch_conv2d_n(const float* x, const float* w, const float* b, float* out, 
   return cds_launch_status();
 }
 
-// CDS_CONV2D_NCB (A/B knob): 1 = one 8-wide block per workgroup everywhere (default: measured faster for K > 1, the
-// wide variants spill their accumulators past the point where the saved staging pays); 0 = wide variants for K > 1.
+// CDS_CONV2D_WIDE (A/B knob): 0 = one 8-wide block per workgroup everywhere.  Default: all output-channel blocks of a
+// layer from one staged tile where a variant exists (cascade forward 640x512: 11.0 -> 9.8 ms, 1600x1184: 46.9 -> 41.4 ms).
 template <int K, int S, int CI_CHUNK>
 int launch_conv2d(const float* x, const float* w, const float* b, float* out, int N, int Cin, int Cout, int H, int W,
                   int pad, int act, hipStream_t st) {
   static const int wide = []() { const char* e = getenv("CDS_CONV2D_WIDE"); return e ? atoi(e) : -1; }();
   const int blocks = (Cout + CO - 1) / CO;
   constexpr int PXW = (S == 2) ? 2 : 4;
-  const bool use_wide = wide >= 0 ? wide != 0 : (K == 1);
+  const bool use_wide = wide != 0;
   if (use_wide) {
     if (blocks % 2 == 0 && (blocks == 2 || K > 5))
       return launch_conv2d_n<K, S, PXW, CI_CHUNK, 2>(x, w, b, out, N, Cin, Cout, H, W, pad, act, st);
