@@ -95,7 +95,12 @@ def test_inference_harness_end_to_end(tmp_path):
         f.write("scanA\n")
     out = str(tmp_path / "out")
     infer.main(["--testpath", root, "--testlist", str(tmp_path / "list.txt"), "--outdir", out, "--num_view", "3",
-                "--max_h", "128", "--max_w", "160", "--interval_scale", "1.0"])
+                "--max_h", "128", "--max_w", "160", "--interval_scale", "1.0", "--fuse", "--thres_view", "1",
+                "--conf", "0.0,0.0,0.0"])
+    # step 2 of the harness (test.py:386-396): the filtered / fused point cloud of the scan
+    from cds_mvsnet_amd import fusion
+    pts, col = fusion.read_ply(os.path.join(out, "scanA.ply"))
+    assert pts.shape == col.shape and pts.shape[1] == 3 and np.isfinite(pts).all()
     for sub, ext in (("depth_est", ".pfm"), ("confidence", ".pfm"), ("cams", "_cam.txt"), ("images", ".jpg")):
         assert os.path.exists(os.path.join(out, "scanA", sub, f"00000002{ext}"))
     depth, _ = mvs_io.read_pfm(os.path.join(out, "scanA", "depth_est", "00000000.pfm"))
