@@ -16,11 +16,14 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int S>
+// VAR = 0: wave = one y row of the tile, its M-tiles cover XT runs x TZ planes.
+// VAR = 1 (stride 2): 64 x 2 x 2 output tile, wave = one (y, z) row with 4 runs: the staged input rows are 132 floats
+// (528 B) instead of 72, which the stride-2 layers (whole input volume streamed once, little reuse) read faster.
+template <int S, int VAR>
 struct MCfg {
-  static constexpr int TX = 64 / S, TY = 4, TZ = (S == 1 ? 4 : 2);           // output tile
+  static constexpr int TX = VAR ? 64 : 64 / S, TY = VAR ? 2 : 4, TZ = VAR ? 2 : (S == 1 ? 4 : 2);   // output tile
   static constexpr int XT = TX / 16;                                           // 16-voxel runs per row
-  static constexpr int NT = XT * TZ;                                          // M-tiles per wave (wave = one y row)
+  static constexpr int NT = VAR ? XT : XT * TZ;                               // M-tiles per wave
   static constexpr int IY = (TY - 1) * S + 3, IZ = (TZ - 1) * S + 3;
   static constexpr int IXP = ((TX - 1) * S + 6 + 3) & ~3;                     // tile x origin = S*ox0 - 4
   static constexpr int Q = IXP / 4;
@@ -30,14 +33,14 @@ struct MCfg {
   static constexpr int NSLOT = (CI_CHUNK * NS + 255) / 256;
 };
 
-template <int S>
+template <int S, int VAR>
 __global__ __launch_bounds__(256) void conv3d_k3_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wpk,
                                                              const float* __restrict__ bias,
                                                              const float* __restrict__ skip, float* __restrict__ out,
                                                              int Cin, int Cout, int D, int H, int W, int Do, int Ho,
                                                              int Wo, int act, int tiles_x, int tiles_y, int tiles_z,
                                                              int ntiles) {
-  using Cfg = MCfg<S>;
+  using Cfg = MCfg<S, VAR>;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int co_blocks = Cout / 16;
   int lin = cds_xcd_remap(blockIdx.x, ntiles * co_blocks);
@@ -85,7 +88,8 @@ __global__ __launch_bounds__(256) void conv3d_k3_mfma_kernel(const float* __rest
   for (int t = 0; t < Cfg::NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   // lane-constant part of the A address: channel slab (l >> 4), voxel (l & 15) of the run, this wave's row
-  const float* a_base = lds + (lane >> 4) * Cfg::SLAB + (wave * S) * Cfg::IXP + (lane & 15) * S + 3;
+  const int wy = VAR ? (wave & 1) : wave, wz = VAR ? (wave >> 1) : 0;
+  const float* a_base = lds + (lane >> 4) * Cfg::SLAB + ((wz * S) * Cfg::IY + wy * S) * Cfg::IXP + (lane & 15) * S + 3;
   // lane-constant part of the B address: [ci0 + (l >> 4)][tap][co0 + (l & 15)]
   const float* __restrict__ b_base = wpk + (size_t)(lane >> 4) * 27 * Cout + co0 + (lane & 15);
 
@@ -112,7 +116,7 @@ __global__ __launch_bounds__(256) void conv3d_k3_mfma_kernel(const float* __rest
         for (int kx = 0; kx < 3; ++kx) {
 #pragma unroll
           for (int t = 0; t < Cfg::NT; ++t) {
-            const int tz = t / Cfg::XT, txr = t % Cfg::XT;
+            const int tz = VAR ? 0 : t / Cfg::XT, txr = VAR ? t : t % Cfg::XT;
             const float a = a_base[((tz * S + kz) * Cfg::IY + ky) * Cfg::IXP + txr * 16 * S + kx];
             acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[kx], acc[t], 0, 0, 0);
           }
@@ -122,7 +126,7 @@ __global__ __launch_bounds__(256) void conv3d_k3_mfma_kernel(const float* __rest
   }
 
   // ---- epilogue: lane -> cout (l & 15), voxels x = run*16 + (l >> 4)*4 + 0..3 ----
-  const int oy = oy0 + wave;
+  const int oy = oy0 + wy;
   if (oy >= Ho) return;
   const int co = co0 + (lane & 15);
   const float b = bias ? bias[co] : 0.f;
@@ -130,7 +134,7 @@ __global__ __launch_bounds__(256) void conv3d_k3_mfma_kernel(const float* __rest
   const bool vec = (Wo & 3) == 0;
 #pragma unroll
   for (int t = 0; t < Cfg::NT; ++t) {
-    const int tz = t / Cfg::XT, txr = t % Cfg::XT;
+    const int tz = VAR ? wz : t / Cfg::XT, txr = VAR ? t : t % Cfg::XT;
     const int oz = oz0 + tz, oxb = ox0 + txr * 16 + (lane >> 4) * 4;
     if (oz >= Do || oxb >= Wo) continue;
     const size_t base = (size_t)co * ovol + (size_t)oz * oplane + (size_t)oy * Wo + oxb;
@@ -315,16 +319,16 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_mfma_cl_kernel(const float* 
   }
 }
 
-template <int S>
+template <int S, int VAR>
 int launch_mfma(const float* x, const float* w, const float* b, const float* skip, float* out, int Cin, int Cout, int D,
                 int H, int W, int act, hipStream_t st) {
-  using Cfg = MCfg<S>;
+  using Cfg = MCfg<S, VAR>;
   const int Do = (D - 1) / S + 1, Ho = (H - 1) / S + 1, Wo = (W - 1) / S + 1;
   const int tx = cds_ceil_div(Wo, Cfg::TX), ty = cds_ceil_div(Ho, Cfg::TY), tz = cds_ceil_div(Do, Cfg::TZ);
   const int ntiles = tx * ty * tz;
   const size_t lds_bytes = (size_t)Cfg::SLAB * Cfg::CI_CHUNK * sizeof(float);
   static_assert(Cfg::SLAB * Cfg::CI_CHUNK * sizeof(float) <= 65536, "LDS tile above 64 KB");
-  hipLaunchKernelGGL(conv3d_k3_mfma_kernel<S>, dim3(ntiles * (Cout / 16)), dim3(256), lds_bytes, st, x, w, b, skip, out,
+  hipLaunchKernelGGL((conv3d_k3_mfma_kernel<S, VAR>), dim3(ntiles * (Cout / 16)), dim3(256), lds_bytes, st, x, w, b, skip, out,
                      Cin, Cout, D, H, W, Do, Ho, Wo, act, tx, ty, tz, ntiles);
   return cds_launch_status();
 }
@@ -502,8 +506,10 @@ bool cds_conv3d_mfma_launch(const float* x, const float* w, const float* b, cons
                             int Cout, int D, int H, int W, int stride, int act, hipStream_t st, int* rc) {
   const int Wo = (W - 1) / stride + 1;
   if ((Cout % 16) || (Cin % 4) || (W % 4) || Wo < 8 || (size_t)Cin * D * H * W >= (size_t)0x7fffffff) return false;
-  *rc = stride == 1 ? launch_mfma<1>(x, w, b, skip, out, Cin, Cout, D, H, W, act, st)
-                    : launch_mfma<2>(x, w, b, skip, out, Cin, Cout, D, H, W, act, st);
+  static const int s2var = []() { const char* e = getenv("CDS_MFMA_S2VAR"); return e ? atoi(e) : 1; }();   // A/B knob
+  if (stride == 1) *rc = launch_mfma<1, 0>(x, w, b, skip, out, Cin, Cout, D, H, W, act, st);
+  else if (s2var && Wo >= 256 && Wo % 64 == 0) *rc = launch_mfma<2, 1>(x, w, b, skip, out, Cin, Cout, D, H, W, act, st);
+  else *rc = launch_mfma<2, 0>(x, w, b, skip, out, Cin, Cout, D, H, W, act, st);
   return true;
 }
 
