@@ -281,6 +281,34 @@ class _Packed:
 
 
 # ------------------------------------------------------------------------------------------------
+# host readback of the (tiny) camera / depth-range tensors
+# ------------------------------------------------------------------------------------------------
+_READBACK_STREAMS: Dict[int, "torch.cuda.Stream"] = {}
+
+
+def _to_host(tensors: List[Tensor]) -> List[Tensor]:
+    """fp32 CPU copies of small device tensors WITHOUT draining the compute stream: `.cpu()` on the current stream
+    waits for every kernel queued before it (the previous depth map), which serialises the host side of forward k+1
+    behind the GPU side of forward k.  The copies run on a side stream that only waits for the tensors' producer
+    event-free inputs (they are dataloader outputs, complete long before), so host and GPU pipeline across calls."""
+    out: List[Optional[Tensor]] = [None] * len(tensors)
+    dev_idx = [i for i, t in enumerate(tensors) if t.is_cuda]
+    for i, t in enumerate(tensors):
+        if not t.is_cuda:
+            out[i] = t.detach().float()
+    if dev_idx:
+        dev = tensors[dev_idx[0]].device
+        side = _READBACK_STREAMS.get(dev.index)
+        if side is None:
+            side = _READBACK_STREAMS[dev.index] = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(side):
+            for i in dev_idx:
+                out[i] = tensors[i].detach().float().to("cpu", non_blocking=True)
+        side.synchronize()
+    return out  # type: ignore[return-value]
+
+
+# ------------------------------------------------------------------------------------------------
 # FeatureNet on the HIP kernels (module.py:234-267, dynamic_conv.py:97-122)
 # ------------------------------------------------------------------------------------------------
 class _FeatureRunner:
@@ -527,8 +555,9 @@ class CDSMVSNet(nn.Module):
             from .training import forward_train   # autograd path: HIP warp-aggregate fwd/bwd + torch conv stacks
             return forward_train(self, imgs.float(), proj_matrices, depth_values, gt_depths, temperature)
         T = float(temperature)
-        dv = depth_values.detach().float().cpu()
-        cams = {k: v.detach().float().cpu() for k, v in proj_matrices.items()}
+        keys = list(proj_matrices.keys())
+        host = _to_host([depth_values] + [proj_matrices[k] for k in keys])
+        dv, cams = host[0], dict(zip(keys, host[1:]))
         imgs = imgs.float()
 
         per_b: List[Dict[str, object]] = []
@@ -574,11 +603,10 @@ class CDSMVSNet(nn.Module):
             outputs.update(st)
         depth = outputs["depth"]
         if self.refine:
-            dvd = depth_values.float()
-            dint = (dvd[:, 1] - dvd[:, 0]).view(B, 1, 1)
-            cur = depth / dint
-            refined = self.refine_network(imgs[:, 0], cur.unsqueeze(1), dvd[:, 0] / dint[:, 0, 0], dvd[:, -1] / dint[:, 0, 0])
-            outputs["refined_depth"] = refined.squeeze(1) * dint
+            dint_h = dv[:, 1] - dv[:, 0]                                   # host copies: no readback / upload here
+            cur = torch.stack([depth[b] / float(dint_h[b]) for b in range(B)])
+            refined = self.refine_network(imgs[:, 0], cur.unsqueeze(1), dv[:, 0] / dint_h, dv[:, -1] / dint_h)
+            outputs["refined_depth"] = torch.stack([refined[b, 0] * float(dint_h[b]) for b in range(B)])
         else:
             outputs["refined_depth"] = depth
         return outputs
