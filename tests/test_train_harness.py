@@ -57,10 +57,11 @@ def _worker(rank, world, port, q):
         net[:3](x).pow(2).mean().backward()
         if rank == 1:
             net[2].bias.grad = None        # a parameter without a gradient on ONE rank only
-        own = [None if p.grad is None else p.grad.clone() for p in net.parameters()]
+        own = [None if p.grad is None else p.grad.clone().numpy() for p in net.parameters()]
         red = T.GradAllReducer(net.parameters(), bucket_bytes=128)       # several buckets
         n = red.reduce()
-        q.put((rank, n, own, [p.grad.clone() for p in net.parameters()]))
+        # numpy payloads: torch tensors travel through mp queues as shared-memory handles that die with the producer
+        q.put((rank, n, own, [p.grad.clone().numpy() for p in net.parameters()]))
     finally:
         dist.destroy_process_group()
 
@@ -79,9 +80,9 @@ def test_flat_gradient_allreduce_gloo_world2():
     (_, n0, own0, red0), (_, n1, own1, red1) = res
     assert n0 == n1 and n0 > 1
     for a, b, r0, r1 in zip(own0, own1, red0, red1):
-        za = torch.zeros_like(r0) if a is None else a
-        zb = torch.zeros_like(r0) if b is None else b
-        assert torch.allclose(r0, (za + zb) / 2, atol=1e-7) and torch.equal(r0, r1)
+        za = np.zeros_like(r0) if a is None else a
+        zb = np.zeros_like(r0) if b is None else b
+        assert np.allclose(r0, (za + zb) / 2, atol=1e-7) and np.array_equal(r0, r1)
 
 
 # ---------------------------------------------------------------------------------------------------------------
