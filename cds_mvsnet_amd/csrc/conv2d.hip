@@ -303,7 +303,26 @@ __global__ __launch_bounds__(256) void instnorm_apply_kernel(const float* __rest
   }
 }
 
+// norm-curvature bookkeeping of a FeatureNet level (module.py:250-251,257-258,264-265): (a^2 + b^2 + c^2) / 3 and |c|
+__global__ __launch_bounds__(256) void curvature_stats_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                              const float* __restrict__ c, float* __restrict__ nc_sum,
+                                                              float* __restrict__ nc_abs, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float va = a[i], vb = b[i], vc = c[i];
+  nc_sum[i] = ((va * va + vb * vb) + vc * vc) / 3.0f;
+  nc_abs[i] = fabsf(vc);
+}
+
 }  // namespace
+
+extern "C" int cds_curvature_stats_f32(const float* a, const float* b, const float* c, float* nc_sum, float* nc_abs, int n,
+                                       void* stream) {
+  if (!a || !b || !c || !nc_sum || !nc_abs || n < 1) return CDS_EINVAL;
+  hipLaunchKernelGGL(curvature_stats_kernel, dim3(cds_ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, a, b, c,
+                     nc_sum, nc_abs, n);
+  return cds_launch_status();
+}
 
 extern "C" int cds_conv2d_f32(const float* x, const float* weight, const float* bias, float* out, int N, int Cin,
                               int Cout, int H, int W, int k, int stride, int pad, int act, void* stream) {

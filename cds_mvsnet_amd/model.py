@@ -396,19 +396,19 @@ class _FeatureRunner:
 
         out = {}
         o1, n22 = self._dynamic(p, "out1", net.out1, c21, e2, T)
-        out["stage1"] = self._final(o1, n_chw) + ((n20 ** 2 + n21 ** 2 + n22 ** 2) / 3, n22.abs())
+        out["stage1"] = self._final(o1, n_chw) + ops.curvature_stats(n20, n21, n22)
 
         x = torch.cat((_nearest2x(c21), c11), dim=1)
         x = self._plain_unit(p, "inner1", x)
         o2, n12 = self._dynamic(p, "out2", net.out2, x, e1, T)
         o2n = ops.instnorm_act(o2, ACT_TANH)
         hwc2 = torch.stack([ops.chw_to_hwc(o2n[i]) for i in range(n_chw, N)]) if n_chw < N else None
-        out["stage2"] = (o2n[:n_chw] if n_chw > 0 else None, hwc2, (n10 ** 2 + n11 ** 2 + n12 ** 2) / 3, n12.abs())
+        out["stage2"] = (o2n[:n_chw] if n_chw > 0 else None, hwc2) + ops.curvature_stats(n10, n11, n12)
 
         x = torch.cat((_nearest2x(o2n), c01), dim=1)
         x = self._plain_unit(p, "inner2", x)
         o3, n02 = self._dynamic(p, "out3", net.out3, x, e0, T)
-        out["stage3"] = self._final(o3, n_chw) + ((n00 ** 2 + n01 ** 2 + n02 ** 2) / 3, n02.abs())
+        out["stage3"] = self._final(o3, n_chw) + ops.curvature_stats(n00, n01, n02)
         return out
 
 

@@ -389,3 +389,13 @@ def refine_finish(d_norm: Tensor, res: Tensor, lo: float, hi: float) -> Tensor:
     check(_lib.load().cds_refine_finish_f32(_dev(d_norm, "d_norm"), _dev(res, "res"), out.data_ptr(), h, w, float(lo),
                                             float(hi), _stream(res)), "cds_refine_finish_f32")
     return out
+
+
+def curvature_stats(a: Tensor, b: Tensor, c: Tensor) -> Tuple[Tensor, Tensor]:
+    """(a^2 + b^2 + c^2) / 3 and |c| of the three curvature maps of a FeatureNet level, one launch."""
+    if a.shape != b.shape or a.shape != c.shape:
+        raise ValueError("curvature_stats: shape mismatch")
+    s, m = torch.empty_like(a), torch.empty_like(a)
+    check(_lib.load().cds_curvature_stats_f32(_dev(a, "a"), _dev(b, "b"), _dev(c, "c"), s.data_ptr(), m.data_ptr(), a.numel(),
+                                              _stream(a)), "cds_curvature_stats_f32")
+    return s, m

@@ -200,6 +200,13 @@ int cds_depth_fusion_f32(const float* ref_depth, const float* ref_conf, const fl
                          float dist_thresh, float depth_thresh, float view_thresh, void* stream);
 
 /*
+ * Norm-curvature bookkeeping of one FeatureNet level (module.py:250-251,257-258,264-265) in one launch:
+ *   nc_sum[i] = (a[i]^2 + b[i]^2 + c[i]^2) / 3,  nc_abs[i] = |c[i]|   for the three DynamicConv curvature maps of the level
+ */
+int cds_curvature_stats_f32(const float* a, const float* b, const float* c, float* nc_sum, float* nc_abs, int n,
+                            void* stream);
+
+/*
  * Refinement network (module.py:318-370) pieces besides its 3x3 Conv+BN+ReLU units (those run on cds_conv2d_f32):
  *   cds_depth_affine_f32   out[i] = (depth[i] - lo) / (hi - lo) * 10                      (module.py:353-355)
  *   cds_deconv2d_k3s2_f32  ConvTranspose2d k=3, stride 2, padding 1, output_padding 1 (+ bias + activation);
