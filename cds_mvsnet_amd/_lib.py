@@ -44,6 +44,8 @@ SIGNATURES = {
     "cds_dynconv_blend_f32": [P, P, P, P, P, F, P, P, I, I, I, I, I, P],
     "cds_instnorm_act_f32": [P, P, P, I, I, I, I, I, I, P],
     "cds_curvature_stats_f32": [P, P, P, P, P, I, P],
+    "cds_pair_mean_f32": [P, P, I, I, P],
+    "cds_view_mean_f32": [P, P, I, I, P],
     "cds_depth_affine_f32": [P, P, I, F, F, P],
     "cds_deconv2d_k3s2_f32": [P, P, P, P, I, I, I, I, I, P],
     "cds_refine_finish_f32": [P, P, P, I, I, F, F, P],

@@ -314,7 +314,35 @@ __global__ __launch_bounds__(256) void curvature_stats_kernel(const float* __res
   nc_abs[i] = fabsf(vc);
 }
 
+// out[v][i] = (x[v][i] + x[V+v][i]) / 2: per pair (ref_nc_sum + src_nc_sum) / 2 (model.py:59)
+__global__ __launch_bounds__(256) void pair_mean_kernel(const float* __restrict__ x, float* __restrict__ out, int V, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  for (int v = 0; v < V; ++v) out[(size_t)v * n + i] = (x[(size_t)v * n + i] + x[(size_t)(V + v) * n + i]) / 2.0f;
+}
+
+// out[i] = (sum_v x[v][i]) / V, summed in view order (model.py:60,79)
+__global__ __launch_bounds__(256) void view_mean_kernel(const float* __restrict__ x, float* __restrict__ out, int V, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = x[i];
+  for (int v = 1; v < V; ++v) s = s + x[(size_t)v * n + i];
+  out[i] = s / (float)V;
+}
+
 }  // namespace
+
+extern "C" int cds_pair_mean_f32(const float* x, float* out, int V, int n, void* stream) {
+  if (!x || !out || V < 1 || n < 1) return CDS_EINVAL;
+  hipLaunchKernelGGL(pair_mean_kernel, dim3(cds_ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, x, out, V, n);
+  return cds_launch_status();
+}
+
+extern "C" int cds_view_mean_f32(const float* x, float* out, int V, int n, void* stream) {
+  if (!x || !out || V < 1 || n < 1) return CDS_EINVAL;
+  hipLaunchKernelGGL(view_mean_kernel, dim3(cds_ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, x, out, V, n);
+  return cds_launch_status();
+}
 
 extern "C" int cds_curvature_stats_f32(const float* a, const float* b, const float* c, float* nc_sum, float* nc_abs, int n,
                                        void* stream) {

@@ -464,7 +464,7 @@ class StageNet(nn.Module):
         prob_pre = cost_regularization(volume)
         del volume
         depth, conf = ops.softargmin_conf(prob_pre, hyp)
-        nc_mean = nc_sums.sum(dim=0) / nc_sums.shape[0]
+        nc_mean = ops.view_mean(nc_sums.contiguous())
         return depth, conf, nc_mean
 
     def forward(self, features, proj_matrices, depth_values, num_depth, cost_regularization, prob_volume_init=None,
@@ -587,7 +587,7 @@ class CDSMVSNet(nn.Module):
                 if V:
                     ref, src, nc_sum, nc_abs = feats[name]
                     ref_nc = nc_abs[:V].contiguous()
-                    nc_sums = (nc_sum[:V] + nc_sum[V:]) / 2
+                    nc_sums = ops.pair_mean(nc_sum, V)
                     mats = geometry.warp_matrices(cams[name][b])[views].contiguous()
                 else:  # a view-shard rank without a source view of its own (more GPUs than views)
                     ref = src = ref_nc = nc_sums = mats = None
@@ -598,7 +598,8 @@ class CDSMVSNet(nn.Module):
         outputs: Dict[str, object] = {}
         for s in range(self.num_stage):
             name = f"stage{s + 1}"
-            st = {k: torch.stack([pb[name][k] for pb in per_b]) for k in ("depth", "photometric_confidence", "norm_curv")}
+            st = {k: (per_b[0][name][k].unsqueeze(0) if B == 1 else torch.stack([pb[name][k] for pb in per_b]))
+                  for k in ("depth", "photometric_confidence", "norm_curv")}   # B = 1: a view, no copy launch
             outputs[name] = st
             outputs.update(st)
         depth = outputs["depth"]

@@ -399,3 +399,19 @@ def curvature_stats(a: Tensor, b: Tensor, c: Tensor) -> Tuple[Tensor, Tensor]:
     check(_lib.load().cds_curvature_stats_f32(_dev(a, "a"), _dev(b, "b"), _dev(c, "c"), s.data_ptr(), m.data_ptr(), a.numel(),
                                               _stream(a)), "cds_curvature_stats_f32")
     return s, m
+
+
+def pair_mean(x: Tensor, V: int) -> Tensor:
+    """x [2V,...] -> [V,...]: (x[v] + x[V+v]) / 2 (per-pair norm-curvature mean, model.py:59)."""
+    if x.shape[0] != 2 * V:
+        raise ValueError("pair_mean: leading dimension must be 2V")
+    out = torch.empty((V,) + tuple(x.shape[1:]), dtype=torch.float32, device=x.device)
+    check(_lib.load().cds_pair_mean_f32(_dev(x, "x"), out.data_ptr(), V, out[0].numel(), _stream(x)), "cds_pair_mean_f32")
+    return out
+
+
+def view_mean(x: Tensor) -> Tensor:
+    """x [V,...] -> mean over the leading (view) dimension, summed in view order (model.py:60,79)."""
+    out = torch.empty(tuple(x.shape[1:]), dtype=torch.float32, device=x.device)
+    check(_lib.load().cds_view_mean_f32(_dev(x, "x"), out.data_ptr(), x.shape[0], out.numel(), _stream(x)), "cds_view_mean_f32")
+    return out

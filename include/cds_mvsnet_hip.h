@@ -205,6 +205,10 @@ int cds_depth_fusion_f32(const float* ref_depth, const float* ref_conf, const fl
  */
 int cds_curvature_stats_f32(const float* a, const float* b, const float* c, float* nc_sum, float* nc_abs, int n,
                             void* stream);
+/* out[v][i] = (x[v][i] + x[V+v][i]) / 2 for v < V (model.py:59); x [2V][n] */
+int cds_pair_mean_f32(const float* x, float* out, int V, int n, void* stream);
+/* out[i] = (sum over v of x[v][i]) / V (model.py:60,79); x [V][n] */
+int cds_view_mean_f32(const float* x, float* out, int V, int n, void* stream);
 
 /*
  * Refinement network (module.py:318-370) pieces besides its 3x3 Conv+BN+ReLU units (those run on cds_conv2d_f32):
