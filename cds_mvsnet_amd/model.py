@@ -479,13 +479,15 @@ class StageNet(nn.Module):
         assert len(features) == proj_matrices.shape[1] - 1, "Different number of images and projection matrices"
         assert depth_values.shape[1] == num_depth, f"depth_values.shape[1]:{depth_values.shape[1]}  num_depth:{num_depth}"
         B = depth_values.shape[0]
-        cams = proj_matrices.detach().float().cpu()
+        cams = _to_host([proj_matrices])[0]
+        V = len(features)
         depths, confs, ncs = [], [], []
         for b in range(B):
             ref = torch.stack([f["ref"][0][b] for f in features]).contiguous()
             src = torch.stack([ops.chw_to_hwc(f["src"][0][b].contiguous()) for f in features])
             ref_nc = torch.stack([f["ref"][2][b, 0] for f in features]).contiguous()
-            nc_sums = torch.stack([(f["ref"][1][b, 0] + f["src"][1][b, 0]) / 2 for f in features])
+            nc_sums = ops.pair_mean(torch.stack([f["ref"][1][b, 0] for f in features] +
+                                                [f["src"][1][b, 0] for f in features]), V)
             hyp = depth_values[b]
             if hyp.dim() == 1:
                 h, w = ref.shape[-2:]
