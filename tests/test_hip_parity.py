@@ -558,3 +558,34 @@ def test_conv3d_channels_last_mfma_vs_torch(dev, ops):
             os.environ.pop("CDS_CONV_CL")
         want = ref + skip if use_skip else ref
         assert (out - want).abs().max() < 2e-5 * max(1.0, ref.abs().max().item()), (cin, cout, D, H, W)
+
+
+@pytest.mark.parametrize("H,W,N,refine", [(1184, 1600, 5, False), (1056, 1920, 7, False), (1152, 1536, 5, True)])
+def test_full_size_cascade_configs(H, W, N, refine):
+    """BASELINE configs 3 / 4 / 3alt at full size through size-independent properties (the CPU oracle needs minutes
+    there): finite outputs, depths inside the hypothesis range, confidences in [0,1], output shapes, run-to-run agreement
+    (InstanceNorm statistics use atomics, so not bit-identical) and view-order covariance of the stage-1 depth."""
+    from cds_mvsnet_amd import CDSMVSNet, seeded_init_, synth
+    dev = torch.device("cuda")
+    model = seeded_init_(CDSMVSNet(refine=refine, depth_interals_ratio=(4.0, 1.5, 0.75)), 0).eval().to(dev)
+    imgs = synth.make_images(N, H, W, seed=4).to(dev)
+    cams = {k: v.to(dev) for k, v in synth.make_cameras(N, H, W, refine=refine, seed=4).items()}
+    dv = synth.make_depth_values().to(dev)
+    with torch.no_grad():
+        a = model(imgs, cams, dv, temperature=0.01)
+        b = model(imgs, cams, dv, temperature=0.01)
+        perm = [0] + list(range(N - 1, 0, -1))          # same views, reversed source order
+        c = model(imgs[:, perm], {k: v[:, perm] for k, v in cams.items()}, dv, temperature=0.01)
+    Hs, Ws = (H // 2, W // 2) if refine else (H, W)
+    assert a["depth"].shape == (1, Hs, Ws) and a["refined_depth"].shape == (1, H, W)
+    assert a["stage1"]["depth"].shape == (1, Hs // 4, Ws // 4) and a["stage2"]["depth"].shape == (1, Hs // 2, Ws // 2)
+    lo, hi = float(dv[0, 0]), float(dv[0, -1])
+    for k in ("stage1", "stage2", "stage3"):
+        d, cf = a[k]["depth"], a[k]["photometric_confidence"]
+        assert torch.isfinite(d).all() and torch.isfinite(cf).all() and torch.isfinite(a[k]["norm_curv"]).all()
+        assert d.min() >= lo - 1e-3 and d.max() <= hi + 1e-3
+        assert cf.min() >= 0 and cf.max() <= 1 + 1e-5
+    assert torch.isfinite(a["refined_depth"]).all()
+    assert (a["depth"] - b["depth"]).abs().mean() < 1e-3
+    # the aggregation is a sum over source views: their order only changes fp32 summation order
+    assert (a["stage1"]["depth"] - c["stage1"]["depth"]).abs().mean() < 5e-3
