@@ -42,6 +42,7 @@ SIGNATURES = {
     "cds_deconv3d_k3s2_f32": [P, P, P, P, P, I, I, I, I, I, I, P],
     "cds_conv2d_f32": [P, P, P, P, I, I, I, I, I, I, I, I, I, P],
     "cds_dynconv_blend_f32": [P, P, P, P, P, F, P, P, I, I, I, I, I, P],
+    "cds_dynconv_blend_shared_f32": [P, P, P, P, P, F, P, P, I, I, I, I, I, I, P],
     "cds_instnorm_act_f32": [P, P, P, I, I, I, I, I, I, P],
     "cds_curvature_stats_f32": [P, P, P, P, P, I, P],
     "cds_pair_mean_f32": [P, P, I, I, P],

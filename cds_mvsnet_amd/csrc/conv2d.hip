@@ -187,13 +187,16 @@ __global__ __launch_bounds__(256) void dynconv_blend_kernel(const float* __restr
                                                             const float* __restrict__ w1, const float* __restrict__ b1,
                                                             const float* __restrict__ w2, EpiBatch epi, float temperature,
                                                             float* __restrict__ out, float* __restrict__ norm_curv,
-                                                            int N, int Cout, int H, int W) {
+                                                            int N, int Cout, int H, int W, int n_shared) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   const int hw = H * W;
   if (p >= hw) return;
   const int n = blockIdx.y;
   const float epi_x = epi.x[n], epi_y = epi.y[n];
-  branch += (size_t)n * (Cout + 3) * hw;
+  // the first n_shared images (copies of the reference image, each with its own epipole) share branch slot 0
+  const int slot = n < n_shared ? 0 : n - n_shared + 1;
+  const int nslots = N - n_shared + 1;
+  branch += (size_t)slot * (Cout + 3) * hw;
   out += (size_t)n * Cout * hw;
   norm_curv += (size_t)n * hw;
   const int y = p / W, x = p % W;
@@ -202,7 +205,7 @@ __global__ __launch_bounds__(256) void dynconv_blend_kernel(const float* __restr
   u = u / (nrm + 1e-6f);
   v = v / (nrm + 1e-6f);
   const float b0 = u * u, b1v = 2.0f * u * v, b2 = v * v;
-  const size_t bstride = (size_t)N * (Cout + 3) * hw;  // stride between kernel sizes
+  const size_t bstride = (size_t)nslots * (Cout + 3) * hw;  // stride between kernel sizes
   float curv[K];
 #pragma unroll
   for (int k = 0; k < K; ++k) {
@@ -370,11 +373,11 @@ extern "C" int cds_conv2d_f32(const float* x, const float* weight, const float* 
   return CDS_EINVAL;
 }
 
-extern "C" int cds_dynconv_blend_f32(const float* branches, const float* w1, const float* b1, const float* w2,
-                                     const float* epipoles_host, float temperature, float* out, float* norm_curv, int N,
-                                     int K, int Cout, int H, int W, void* stream) {
+extern "C" int cds_dynconv_blend_shared_f32(const float* branches, const float* w1, const float* b1, const float* w2,
+                                            const float* epipoles_host, float temperature, float* out, float* norm_curv,
+                                            int N, int K, int Cout, int H, int W, int n_shared, void* stream) {
   if (!branches || !w1 || !b1 || !w2 || !epipoles_host || !out || !norm_curv || N < 1 || N > CDS_MAX_IMAGES ||
-      Cout < 1 || H < 1 || W < 1)
+      Cout < 1 || H < 1 || W < 1 || n_shared < 1 || n_shared > N)
     return CDS_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   EpiBatch epi;
@@ -385,13 +388,20 @@ extern "C" int cds_dynconv_blend_f32(const float* branches, const float* w1, con
   dim3 grid(cds_ceil_div(H * W, 256), N), block(256);
   if (K == 2)
     hipLaunchKernelGGL(dynconv_blend_kernel<2>, grid, block, 0, st, branches, w1, b1, w2, epi, temperature, out,
-                       norm_curv, N, Cout, H, W);
+                       norm_curv, N, Cout, H, W, n_shared);
   else if (K == 3)
     hipLaunchKernelGGL(dynconv_blend_kernel<3>, grid, block, 0, st, branches, w1, b1, w2, epi, temperature, out,
-                       norm_curv, N, Cout, H, W);
+                       norm_curv, N, Cout, H, W, n_shared);
   else
     return CDS_EINVAL;
   return cds_launch_status();
+}
+
+extern "C" int cds_dynconv_blend_f32(const float* branches, const float* w1, const float* b1, const float* w2,
+                                     const float* epipoles_host, float temperature, float* out, float* norm_curv, int N,
+                                     int K, int Cout, int H, int W, void* stream) {
+  return cds_dynconv_blend_shared_f32(branches, w1, b1, w2, epipoles_host, temperature, out, norm_curv, N, K, Cout, H, W, 1,
+                                      stream);
 }
 
 extern "C" int cds_instnorm_act_f32(const float* x, float* out, float* stats, int N, int C, int H, int W, int act,

@@ -341,18 +341,21 @@ class _FeatureRunner:
             out[f"{name}.w"] = _pack2d(getattr(net, name).conv.weight.detach())
         return out
 
-    def _dynamic(self, p, name: str, dc: DynamicConv, x: Tensor, epi: Tensor, T: float):
-        """x [N,Cin,H,W], epi CPU [N,2] (pixels at this resolution) -> (out [N,Cout,H,W], norm_curv [N,H,W])."""
+    def _dynamic(self, p, name: str, dc: DynamicConv, x: Tensor, epi: Tensor, T: float, n_shared: int = 1):
+        """x [N,Cin,H,W], epi CPU [N,2] (pixels at this resolution) -> (out [N,Cout,H,W], norm_curv [N,H,W]).
+        n_shared > 1: the first n_shared images are copies of one image: their epipole-independent
+        branch responses are convolved once (image n_shared - 1 stands for all of them)."""
         N, Cin, H, W = x.shape
         nk = len(dc.size_kernels)
-        branches = torch.empty((nk, N, dc.out_c + 3, H, W), dtype=torch.float32, device=x.device)
+        xs = x[n_shared - 1:] if n_shared > 1 else x
+        branches = torch.empty((nk, xs.shape[0], dc.out_c + 3, H, W), dtype=torch.float32, device=x.device)
         for i, k in enumerate(dc.size_kernels):
-            ops.conv2d(x, p[f"{name}.w{i}"], p.get(f"{name}.b{i}"), dc.out_c + 3, k, 1, (k - 1) // 2, ACT_NONE,
+            ops.conv2d(xs, p[f"{name}.w{i}"], p.get(f"{name}.b{i}"), dc.out_c + 3, k, 1, (k - 1) // 2, ACT_NONE,
                        out=branches[i])
-        return ops.dynconv_blend(branches, p[f"{name}.m1"], p[f"{name}.mb"], p[f"{name}.m2"], epi, T)
+        return ops.dynconv_blend(branches, p[f"{name}.m1"], p[f"{name}.mb"], p[f"{name}.m2"], epi, T, n_shared)
 
-    def _dyn_unit(self, p, name, x, epi, T):
-        y, nc = self._dynamic(p, name, getattr(self.net, name).conv, x, epi, T)
+    def _dyn_unit(self, p, name, x, epi, T, n_shared: int = 1):
+        y, nc = self._dynamic(p, name, getattr(self.net, name).conv, x, epi, T, n_shared)
         return ops.instnorm_act(y, ACT_LEAKY01), nc
 
     def _plain_unit(self, p, name, x):
@@ -370,7 +373,7 @@ class _FeatureRunner:
         hwc = ops.instnorm_act(o[n_chw:].contiguous(), ACT_TANH, out_hwc=True) if n_chw < N else None
         return chw, hwc
 
-    def __call__(self, imgs: Tensor, epipoles: Tensor, T: float, n_chw: Optional[int] = None):
+    def __call__(self, imgs: Tensor, epipoles: Tensor, T: float, n_chw: Optional[int] = None, n_shared: int = 1):
         """imgs [N,3,H,W], epipoles CPU [N,2] (one epipole per image, full-resolution pixels).
         Returns {'stageK': (fea_chw [n_chw,C,h,w] | None, fea_hwc [N-n_chw,h,w,C] | None, nc_sum [N,h,w], |nc| [N,h,w])}."""
         net = self.net
@@ -385,7 +388,9 @@ class _FeatureRunner:
         e0 = epipoles.float().contiguous()
         e1 = (e0 / 2).contiguous()
         e2 = (e0 / 4).contiguous()
-        c00, n00 = self._dyn_unit(p, "conv00", imgs, e0, T)
+        # conv00 sees the raw images: with n_shared copies of the reference image its branch convolutions (3x3, 7x7,
+        # 11x11) run once for all of them; from conv01 on the inputs differ (the blend depends on the epipole)
+        c00, n00 = self._dyn_unit(p, "conv00", imgs, e0, T, n_shared)
         c01, n01 = self._dyn_unit(p, "conv01", c00, e0, T)
         d0 = self._plain_unit(p, "downsample1", c01)
         c10, n10 = self._dyn_unit(p, "conv10", d0, e1, T)
@@ -543,7 +548,7 @@ class CDSMVSNet(nn.Module):
             epi.append(geometry.pair_epipoles(cam_ref, cam_src))
         epipoles = torch.tensor([e[0] for e in epi] + [e[1] for e in epi], dtype=torch.float32)
         batch = torch.stack([ref_img] * V + list(src_imgs))
-        return self._feature_runner[0](batch, epipoles, T, n_chw=V)
+        return self._feature_runner[0](batch, epipoles, T, n_chw=V, n_shared=V)
 
     def forward(self, imgs, proj_matrices, depth_values, gt_depths=None, temperature=0.001):
         if not imgs.is_cuda:

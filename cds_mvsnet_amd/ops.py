@@ -307,17 +307,20 @@ def conv2d(x: Tensor, wpk: Tensor, bias: Optional[Tensor], cout: int, k: int, st
 
 
 def dynconv_blend(branches: Tensor, w1: Tensor, b1: Tensor, w2: Tensor, epipoles: Tensor,
-                  temperature: float) -> Tuple[Tensor, Tensor]:
-    """K7 epilogue.  branches [K,N,Cout+3,H,W], epipoles CPU [N,2] -> (out [N,Cout,H,W], norm_curv [N,H,W])."""
-    K, N, C3, H, W = branches.shape
+                  temperature: float, n_shared: int = 1) -> Tuple[Tensor, Tensor]:
+    """K7 epilogue.  branches [K,N - n_shared + 1,Cout+3,H,W] (the first n_shared images share slot 0), epipoles CPU
+    [N,2] -> (out [N,Cout,H,W], norm_curv [N,H,W])."""
+    K, nslots, C3, H, W = branches.shape
+    N = nslots + n_shared - 1
     cout = C3 - 3
-    if tuple(epipoles.shape) != (N, 2):
+    if tuple(epipoles.shape) != (N, 2) or n_shared < 1:
         raise ValueError("dynconv_blend: epipoles must be [N,2]")
     out = torch.empty((N, cout, H, W), dtype=torch.float32, device=branches.device)
     nc = torch.empty((N, H, W), dtype=torch.float32, device=branches.device)
-    check(_lib.load().cds_dynconv_blend_f32(_dev(branches, "branches"), _dev(w1, "w1"), _dev(b1, "b1"), _dev(w2, "w2"),
-                                            _host(epipoles, "epipoles"), float(temperature), out.data_ptr(),
-                                            nc.data_ptr(), N, K, cout, H, W, _stream(out)), "cds_dynconv_blend_f32")
+    check(_lib.load().cds_dynconv_blend_shared_f32(_dev(branches, "branches"), _dev(w1, "w1"), _dev(b1, "b1"), _dev(w2, "w2"),
+                                                   _host(epipoles, "epipoles"), float(temperature), out.data_ptr(),
+                                                   nc.data_ptr(), N, K, cout, H, W, n_shared, _stream(out)),
+          "cds_dynconv_blend_shared_f32")
     return out, nc
 
 

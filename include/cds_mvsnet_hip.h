@@ -176,6 +176,15 @@ int cds_conv2d_f32(const float* x, const float* weight, const float* bias, float
 int cds_dynconv_blend_f32(const float* branches, const float* w1, const float* b1, const float* w2,
                           const float* epipoles_host, float temperature, float* out, float* norm_curv,
                           int N, int K, int Cout, int H, int W, void* stream);
+/*
+ * Same, when the first n_shared images of the batch are copies of ONE image (the reference image of every pair,
+ * model.py:154-161) that only differ in their epipole: the responses of convs[k] / att_convs[k] do not depend on the
+ * epipole (dynamic_conv.py:112,116), so they are computed once.
+ *   branches [K][N - n_shared + 1][Cout+3][H][W]: slot 0 = the shared image, slot n - n_shared + 1 = image n >= n_shared
+ */
+int cds_dynconv_blend_shared_f32(const float* branches, const float* w1, const float* b1, const float* w2,
+                                 const float* epipoles_host, float temperature, float* out, float* norm_curv, int N,
+                                 int K, int Cout, int H, int W, int n_shared, void* stream);
 
 /*
  * K8 (module.py:53,66-69,223,230,232): InstanceNorm2d (no affine, eps 1e-5, biased variance) followed by
