@@ -337,7 +337,10 @@ def _random_stage(ops, dev, V, C, D, h, w, seed, sharp=True):
 
 
 @pytest.mark.parametrize("V,C,D,h,w", [(1, 8, 7, 9, 70), (4, 8, 33, 12, 130), (6, 8, 5, 16, 24), (3, 16, 9, 10, 50),
-                                       (2, 32, 4, 8, 66), (4, 8, 2, 5, 3)])
+                                       (2, 32, 4, 8, 66), (4, 8, 2, 5, 3),
+                                       # C = 8 with 2 / 3 views: the LDS kernels are specialised per view count; D = 70
+                                       # spans three chunks (32 + 32 + 6) and an odd plane pair at the end
+                                       (2, 8, 70, 11, 67), (3, 8, 35, 6, 129)])
 def test_warp_kernels_vs_oracle_odd_shapes(V, C, D, h, w, dev, ops):
     """Odd D / widths that are not tile multiples / V = 1, 6 (direct path) / C = 16, 32 / tiny images: K1 and K3 against
     the CPU oracle (explicit fp32 gather)."""
