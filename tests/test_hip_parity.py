@@ -592,3 +592,36 @@ def test_full_size_cascade_configs(H, W, N, refine):
     assert (a["depth"] - b["depth"]).abs().mean() < 1e-3
     # the aggregation is a sum over source views: their order only changes fp32 summation order
     assert (a["stage1"]["depth"] - c["stage1"]["depth"]).abs().mean() < 5e-3
+
+
+def test_warp_lds_fallbacks_wild_geometry(dev, ops):
+    """Geometry that defeats the LDS fast path: a wide baseline and near depths give tens of pixels of parallax per plane
+    (boxes over the LDS budget even after the chunk is halved to 8 planes -> global-memory path), randomly permuted
+    (non-monotone) hypotheses, and a source camera whose principal plane cuts the depth range (projective pole: samples
+    jump across the image).  K1 / K3 must still agree with the CPU oracle."""
+    from oracle import cds_oracle as O
+    from cds_mvsnet_amd import synth, geometry
+    V, C, D, h, w = 3, 8, 40, 24, 136
+    feats = synth.make_pair_features(V, C, h, w, seed=91, sharp=True)
+    cams = synth.make_cameras(V + 1, h, w, refine=False, seed=91, baseline=(900.0, 300.0, 40.0))["stage3"]
+    cams[0, 3, 0, :3, 3] += torch.tensor([0.0, 0.0, -260.0])            # view 3: its z = 0 plane lies inside the sweep
+    g = torch.Generator().manual_seed(91)
+    hyp = 120.0 + 600.0 * torch.rand(1, D, h, w, generator=g)             # 120..720, unordered per pixel
+    ref = torch.stack([f["ref"][0][0] for f in feats]).to(dev).contiguous()
+    src = torch.stack([ops.chw_to_hwc(f["src"][0][0].to(dev).contiguous()) for f in feats])
+    mats = geometry.warp_matrices(cams[0])
+    hyp_d = hyp[0].to(dev).contiguous()
+    P_ref = O.compose_projection(cams[:, 0])
+    ent = ops.warp_entropy(ref, src, mats, hyp_d).cpu()
+    vis = torch.rand(V, h, w, generator=g)
+    vol, _ = ops.warp_aggregate(ref, src, vis.to(dev), mats, hyp_d, normalize=False)
+    want = torch.zeros(C, D, h, w)
+    for v in range(V):
+        warped = O.warp_volume(feats[v]["src"][0], O.compose_projection(cams[:, v + 1]), P_ref, hyp)
+        in_prod, e = O.correlation_entropy(feats[v]["ref"][0], warped)
+        ok = torch.isfinite(e[0, 0])
+        assert ((ent[v] - e[0, 0]).abs()[ok]).max() < 5e-5
+        want += (in_prod * vis[v].view(1, 1, 1, h, w))[0]
+    fin = torch.isfinite(want)
+    assert fin.float().mean() > 0.99
+    assert ((vol.cpu() - want).abs()[fin]).max() < 2e-5
