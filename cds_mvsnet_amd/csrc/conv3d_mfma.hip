@@ -12,6 +12,10 @@
 
 #include "cds_common.hpp"
 
+#ifndef CDS_MFMA_MINW
+#define CDS_MFMA_MINW 3   // 3 waves per SIMD (<= 168 VGPRs): measured 5 % faster than 2 despite a few spilled staging registers
+#endif
+
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -34,7 +38,7 @@ struct MCfg {
 };
 
 template <int S, int VAR>
-__global__ __launch_bounds__(256) void conv3d_k3_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wpk,
+__global__ __launch_bounds__(256, CDS_MFMA_MINW) void conv3d_k3_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wpk,
                                                              const float* __restrict__ bias,
                                                              const float* __restrict__ skip, float* __restrict__ out,
                                                              int Cin, int Cout, int D, int H, int W, int Do, int Ho,
