@@ -955,14 +955,20 @@ extern "C" int cds_conv3d_k3_f32(const float* x, const float* weight, const floa
   if (pipe_ok && Cout % 8 == 0) {
     if (stride == 1) {
       if (pz_knob == 2) return launch_conv_pipe<1, 16, 4, 4, 4, 2, 8, 2>(x, weight, bias, skip, out, Cin, Cout, D, H, W, act, st);
-      return launch_conv_pipe<1, 16, 4, 4, 4, 1, 8, 4>(x, weight, bias, skip, out, Cin, Cout, D, H, W, act, st);
+      // one input channel per staged chunk (10 KB of LDS, fewer staging registers -> more resident waves): conv0 at M1
+      // 2810 us with 4 channels per chunk, 2610 with 2, 2370 with 1
+      if (pz_knob == 4) return launch_conv_pipe<1, 16, 4, 4, 4, 1, 8, 4>(x, weight, bias, skip, out, Cin, Cout, D, H, W, act, st);
+      if (pz_knob == 5) return launch_conv_pipe<1, 16, 4, 4, 4, 1, 8, 2>(x, weight, bias, skip, out, Cin, Cout, D, H, W, act, st);
+      return launch_conv_pipe<1, 16, 4, 4, 4, 1, 8, 1>(x, weight, bias, skip, out, Cin, Cout, D, H, W, act, st);
     }
     return launch_conv_pipe<2, 16, 4, 4, 2, 1, 8, 2>(x, weight, bias, skip, out, Cin, Cout, D, H, W, act, st);
   }
   if (pipe_ok && Cout == 1 && stride == 1) {
     // Cout = 1 (prob): 4 z-outputs per thread so every LDS row read feeds up to 3 outputs (LDS-bound otherwise)
     if (pz_knob == 1) return launch_conv_pipe<1, 16, 4, 4, 4, 1, 1, 4>(x, weight, bias, skip, out, Cin, Cout, D, H, W, act, st);
-    return launch_conv_pipe<1, 16, 4, 4, 4, 4, 1, 2>(x, weight, bias, skip, out, Cin, Cout, D, H, W, act, st);
+    // one input channel per staged chunk: 31 KB of LDS -> 5 workgroups per CU (2 with two channels); 898 -> 627 us at M1
+    if (pz_knob == 3) return launch_conv_pipe<1, 16, 4, 4, 4, 4, 1, 2>(x, weight, bias, skip, out, Cin, Cout, D, H, W, act, st);
+    return launch_conv_pipe<1, 16, 4, 4, 4, 4, 1, 1>(x, weight, bias, skip, out, Cin, Cout, D, H, W, act, st);
   }
   if (Cout == 1) {
     if (stride != 1) return CDS_EINVAL;
