@@ -15,6 +15,9 @@
 #ifndef CDS_MFMA_TZ1
 #define CDS_MFMA_TZ1 2   // z planes per stride-1 tile: 2 (28 KB of LDS, 32 accumulators) measured 4-5 % faster than 4
 #endif
+#ifndef CDS_MFMA_TZ2
+#define CDS_MFMA_TZ2 2
+#endif
 #ifndef CDS_MFMA_MINW
 #define CDS_MFMA_MINW 3   // 3 waves per SIMD (<= 168 VGPRs): measured 5 % faster than 2 despite a few spilled staging registers
 #endif
@@ -28,7 +31,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // (528 B) instead of 72, which the stride-2 layers (whole input volume streamed once, little reuse) read faster.
 template <int S, int VAR>
 struct MCfg {
-  static constexpr int TX = VAR ? 64 : 64 / S, TY = VAR ? 2 : 4, TZ = VAR ? 2 : (S == 1 ? CDS_MFMA_TZ1 : 2);   // output tile
+  static constexpr int TX = VAR ? 64 : 64 / S, TY = VAR ? 2 : 4, TZ = VAR ? 2 : (S == 1 ? CDS_MFMA_TZ1 : CDS_MFMA_TZ2);   // output tile
   static constexpr int XT = TX / 16;                                           // 16-voxel runs per row
   static constexpr int NT = VAR ? XT : XT * TZ;                               // M-tiles per wave
   static constexpr int IY = (TY - 1) * S + 3, IZ = (TZ - 1) * S + 3;
