@@ -957,6 +957,7 @@ extern "C" int cds_conv3d_k3_f32(const float* x, const float* weight, const floa
       if (pz_knob == 2) return launch_conv_pipe<1, 16, 4, 4, 4, 2, 8, 2>(x, weight, bias, skip, out, Cin, Cout, D, H, W, act, st);
       // one input channel per staged chunk (10 KB of LDS, fewer staging registers -> more resident waves): conv0 at M1
       // 2810 us with 4 channels per chunk, 2610 with 2, 2370 with 1
+      if (pz_knob == 6) return launch_conv_pipe<1, 16, 4, 4, 4, 2, 8, 1>(x, weight, bias, skip, out, Cin, Cout, D, H, W, act, st);
       if (pz_knob == 4) return launch_conv_pipe<1, 16, 4, 4, 4, 1, 8, 4>(x, weight, bias, skip, out, Cin, Cout, D, H, W, act, st);
       if (pz_knob == 5) return launch_conv_pipe<1, 16, 4, 4, 4, 1, 8, 2>(x, weight, bias, skip, out, Cin, Cout, D, H, W, act, st);
       return launch_conv_pipe<1, 16, 4, 4, 4, 1, 8, 1>(x, weight, bias, skip, out, Cin, Cout, D, H, W, act, st);
