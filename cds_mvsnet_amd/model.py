@@ -289,8 +289,8 @@ _READBACK_STREAMS: Dict[int, "torch.cuda.Stream"] = {}
 def _to_host(tensors: List[Tensor]) -> List[Tensor]:
     """fp32 CPU copies of small device tensors WITHOUT draining the compute stream: `.cpu()` on the current stream
     waits for every kernel queued before it (the previous depth map), which serialises the host side of forward k+1
-    behind the GPU side of forward k.  The copies run on a side stream that only waits for the tensors' producer
-    event-free inputs (they are dataloader outputs, complete long before), so host and GPU pipeline across calls."""
+    behind the GPU side of forward k.  The copies run on a side stream, which does not wait for the compute stream (the
+    tensors are dataloader outputs, complete long before the call), so host and GPU work pipeline across calls."""
     out: List[Optional[Tensor]] = [None] * len(tensors)
     dev_idx = [i for i, t in enumerate(tensors) if t.is_cuda]
     for i, t in enumerate(tensors):

@@ -226,6 +226,9 @@ def depth_planes(D: int, h: int, w: int, lo: float, hi: float, device) -> Tensor
     return out
 
 
+USE_CONV3D_CL = os.environ.get("CDS_CONV_CL", "1") != "0"     # A/B knob
+
+
 def conv3d_cl_supported(Cin: int, Cout: int, W: int, stride: int) -> bool:
     """Shapes covered by cds_conv3d_k3_cl_f32 (channels-last LDS tile on the matrix cores)."""
     return stride == 1 and Cin % 16 == 0 and Cout % 16 == 0 and W % 4 == 0 and W >= 16 and USE_CONV3D_CL
@@ -235,9 +238,6 @@ def conv3d_cl_preferred(Cin: int) -> bool:
     """Measured at M1: the channels-last kernel stages a whole 16-channel chunk before its first MFMA, which is only
     amortised from 4 chunks on (conv6, 64 -> 64: 345 vs 462 us; conv4 32 -> 32: 596 vs 580; conv2 16 -> 16: 1386 vs 1127)."""
     return Cin >= 64 or os.environ.get("CDS_CONV_CL", "1") == "2"
-
-
-USE_CONV3D_CL = os.environ.get("CDS_CONV_CL", "1") != "0"     # A/B knob
 
 
 def conv3d_k3(x: Tensor, wpk: Tensor, bias: Optional[Tensor], stride: int = 1, relu: bool = True,
