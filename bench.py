@@ -138,7 +138,9 @@ def main():
     # replicas: every rank owns a different reference view (different seed); viewshard: same depth map everywhere
     seed = rank if args.parallelism == "replicas" else 0
     _, cams, hyp, dfe = make_workload(args.workload, seed, dev)
-    cams_d, hyp_d = cams.to(dev), hyp.to(dev)
+    # cameras stay on the host (the module turns them into 12 kernel-argument floats per view there); a device copy is
+    # accepted as well but costs a readback per call
+    cams_d, hyp_d = cams, hyp.to(dev)
     if world > 1 and args.parallelism == "viewshard":
         from cds_mvsnet_amd import distributed as cdist
         runner = cdist.ViewShardedStage(model, dist.group.WORLD)

@@ -51,8 +51,10 @@ def run(args) -> float:
             s = data[idx]
             t0 = time.time()
             imgs = torch.from_numpy(s["imgs"]).unsqueeze(0).to(dev)
-            cams = {k: torch.from_numpy(v).unsqueeze(0).to(dev) for k, v in s["proj_matrices"].items()}
-            dv = torch.from_numpy(s["depth_values"]).unsqueeze(0).to(dev)
+            # cameras and the depth range stay on the host: the model needs them there (12 floats per view become kernel
+            # arguments), so no device round trip
+            cams = {k: torch.from_numpy(v).unsqueeze(0) for k, v in s["proj_matrices"].items()}
+            dv = torch.from_numpy(s["depth_values"]).unsqueeze(0)
             out = model(imgs, cams, dv, temperature=args.temperature)
             torch.cuda.synchronize()
             times.append(time.time() - t0)

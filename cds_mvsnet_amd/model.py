@@ -287,10 +287,11 @@ _READBACK_STREAMS: Dict[int, "torch.cuda.Stream"] = {}
 
 
 def _to_host(tensors: List[Tensor]) -> List[Tensor]:
-    """fp32 CPU copies of small device tensors WITHOUT draining the compute stream: `.cpu()` on the current stream
-    waits for every kernel queued before it (the previous depth map), which serialises the host side of forward k+1
-    behind the GPU side of forward k.  The copies run on a side stream, which does not wait for the compute stream (the
-    tensors are dataloader outputs, complete long before the call), so host and GPU work pipeline across calls."""
+    """fp32 CPU copies of the small camera / depth-range tensors.  CPU inputs are used as they are: callers that keep
+    these tensors on the host (they come from the data loader on the host anyway; `infer.py` and `bench.py` do) pay no
+    readback, and the host side of forward k+1 overlaps the GPU side of forward k.  Device inputs are copied on a side
+    stream that first waits for the work queued on the current stream (their producers may still be running there), which
+    is what `.cpu()` costs as well."""
     out: List[Optional[Tensor]] = [None] * len(tensors)
     dev_idx = [i for i, t in enumerate(tensors) if t.is_cuda]
     for i, t in enumerate(tensors):
@@ -301,6 +302,7 @@ def _to_host(tensors: List[Tensor]) -> List[Tensor]:
         side = _READBACK_STREAMS.get(dev.index)
         if side is None:
             side = _READBACK_STREAMS[dev.index] = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
             for i in dev_idx:
                 out[i] = tensors[i].detach().float().to("cpu", non_blocking=True)

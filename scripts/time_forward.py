@@ -8,8 +8,8 @@ refine = len(sys.argv) > 4 and sys.argv[4] == "refine"
 dev = torch.device("cuda:0")
 model = seeded_init_(CDSMVSNet(refine=refine, depth_interals_ratio=(4.0, 1.5, 0.75)), 0).eval().to(dev)
 imgs = synth.make_images(N, H, W, seed=0).to(dev)
-cams = {k: v.to(dev) for k, v in synth.make_cameras(N, H, W, refine=refine, seed=0).items()}
-dv = synth.make_depth_values().to(dev)
+cams = synth.make_cameras(N, H, W, refine=refine, seed=0)     # host tensors: no readback in the forward
+dv = synth.make_depth_values()
 with torch.no_grad():
     for _ in range(2): out = model(imgs, cams, dv, temperature=0.01)
     torch.cuda.synchronize(); t0 = time.perf_counter()
