@@ -70,6 +70,36 @@ def make_workload(name, seed, device):
     return feats, cams, hyp, dfe
 
 
+def other_workloads(model, dev):
+    """BASELINE's config 2 can be read as the 640x512 volume grid (M1, the headline above), as its 160x128 /
+    C=32 cousin (M1b) or as the full three-stage cascade on 640x512 images (M2).  The other two are reported here,
+    untimed by the driver, measured after the timed region (5 iterations each after 2 warm-ups)."""
+    from cds_mvsnet_amd import synth
+    out = {}
+
+    def timeit(fn, n=5):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n * 1e3
+
+    with torch.no_grad():
+        h, w, D, C, n_views = WORKLOADS["M1b"]
+        _, cams, hyp, dfe = make_workload("M1b", 0, dev)
+        hyp_d = hyp.to(dev)
+        out["M1b_single_stage_160x128_D192_C32_ms"] = timeit(lambda: model.stage_net(
+            dfe, cams, depth_values=hyp_d, num_depth=D, cost_regularization=model.cost_regularization[0], stage_idx=0))
+        imgs = synth.make_images(5, 512, 640, seed=0).to(dev)
+        pm = synth.make_cameras(5, 512, 640, refine=False, seed=0)
+        dv = synth.make_depth_values()
+        out["M2_cascade_forward_640x512_N5_ms"] = timeit(lambda: model(imgs, pm, dv, temperature=0.01))
+    return {k: round(v, 3) for k, v in out.items()}
+
+
 def cpu_baseline(model_cpu, name, budget_frac):
     """The CPU oracle (proved equal to the reference, tests/test_oracle_golden.py) on a window of the same
     workload: top-left (h*f) x (w*f) pixels, all D planes, all views.  Returns the JSON object."""
@@ -102,6 +132,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="M1", choices=sorted(WORKLOADS))
     ap.add_argument("--parallelism", default="replicas", choices=["replicas", "viewshard"])
+    ap.add_argument("--no-extras", action="store_true", help="skip the M1b / M2 side measurements")
     ap.add_argument("--streams", type=int, default=1,
                     help="depth maps in flight per GPU on separate HIP streams (a step = that many depth maps; "
                          "per-kernel event timing and the roofline object need 1)")
@@ -218,6 +249,9 @@ def main():
                                      "flops": fl}
     extra["kernel_ms"] = {k: round(v, 4) for k, v in sorted(kern.items())}
 
+    others = None
+    if world == 1 and args.streams == 1 and args.workload == "M1" and not args.no_extras:
+        others = other_workloads(model, dev)
     if rank == 0:
         cpu = None
         if world == 1 and args.cpu_sample > 0:
@@ -234,6 +268,8 @@ def main():
             "roofline": roof, "cpu_baseline": cpu,
         }
         line.update(extra)
+        if others is not None:
+            line["other_workloads"] = others
         print(json.dumps(line))
     if dist is not None:
         dist.barrier()
