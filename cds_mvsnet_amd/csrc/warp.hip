@@ -50,7 +50,10 @@ __global__ __launch_bounds__(256) void warp_kernel(const float* __restrict__ src
 // Online softmax statistics: m (running max), Z = sum e^(s-m), T = sum (s-m) e^(s-m);
 // entropy = log Z - T/Z   (algebraically -sum p log p, finite where the textbook form is 0*log 0).
 // ---------------------------------------------------------------------------------------------
-template <int C>
+// DS = depth slices per pixel: DS = 1 -> 64x4 pixel tile, one thread per pixel over all planes; DS = 4 -> 64x1 pixel tile,
+// the four waves of a workgroup take the planes d = s, s + 4, ... and their (m, Z, T) statistics are merged through LDS
+// (small images: 4x the workgroups, 1/4 of the serial plane loop).
+template <int C, int DS>
 __global__ __launch_bounds__(256) void warp_entropy_kernel(const float* __restrict__ ref,
                                                            const float* __restrict__ src, WarpMats mats,
                                                            const float* __restrict__ hyp,
@@ -62,9 +65,13 @@ __global__ __launch_bounds__(256) void warp_entropy_kernel(const float* __restri
   int v = lin % V;
   int tile = lin / V;
   int tx = tile % tiles_x, ty = tile / tiles_x;
+  const int slice = (DS == 1) ? 0 : (int)(threadIdx.x >> 6);
   int x = tx * CDS_TILE_X + (threadIdx.x & 63);
-  int y = ty * CDS_TILE_Y + (threadIdx.x >> 6);
-  if (x >= w || y >= h) return;
+  int y = (DS == 1) ? ty * CDS_TILE_Y + (int)(threadIdx.x >> 6) : ty;
+  const bool inside = x < w && y < h;
+  if (DS == 1 && !inside) return;
+  x = min(x, w - 1);
+  y = min(y, h - 1);
   const float half_w = (float)((w - 1) / 2.0), half_h = (float)((h - 1) / 2.0);
   const size_t hw = (size_t)h * w;
   const size_t pix = (size_t)y * w + x;
@@ -75,7 +82,7 @@ __global__ __launch_bounds__(256) void warp_entropy_kernel(const float* __restri
   float r[3];
   cds_row_terms(mats.m[v], (float)x, (float)y, r);
   float m = -INFINITY, Z = 0.f, T = 0.f;
-  for (int d = 0; d < D; ++d) {
+  for (int d = slice; d < D; d += DS) {
     float dv = hyp_pp ? hyp[d * hw + pix] : hyp[d];
     Taps tp = cds_taps(r, mats.m[v] + 9, dv, h, w, half_w, half_h);
     float s = 0.f;
@@ -107,6 +114,31 @@ __global__ __launch_bounds__(256) void warp_entropy_kernel(const float* __restri
     Z += e;
     T = fmaf(dlt, e, T);
   }
+  if (DS > 1) {
+    __shared__ float red[3][DS][64];
+    const int lane = threadIdx.x & 63;
+    red[0][slice][lane] = m;
+    red[1][slice][lane] = Z;
+    red[2][slice][lane] = T;
+    __syncthreads();
+    if (slice != 0) return;
+    float mm = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < DS; ++i) mm = fmaxf(mm, red[0][i][lane]);
+    float Zs = 0.f, Ts = 0.f;
+#pragma unroll
+    for (int i = 0; i < DS; ++i) {
+      const float mi = red[0][i][lane], Zi = red[1][i][lane], Ti = red[2][i][lane];
+      if (Zi > 0.f) {            // a slice without planes (D < DS) contributes nothing
+        const float sc = expf(mi - mm);
+        Zs += Zi * sc;
+        Ts += sc * (Ti + (mi - mm) * Zi);
+      }
+    }
+    Z = Zs;
+    T = Ts;
+    if (!inside) return;
+  }
   entropy[(size_t)v * hw + pix] = logf(Z) - T / Z;
 }
 
@@ -119,10 +151,14 @@ template <int VMAX>
 __global__ __launch_bounds__(256) void warp_aggregate_kernel(
     const float* __restrict__ ref, const float* __restrict__ src, const float* __restrict__ vis, WarpMats mats,
     const float* __restrict__ hyp, float* __restrict__ volume, const float* __restrict__ vis_sum, int V, int C,
-    int D, int h, int w, int hyp_pp, int flags, int tiles_x, int ntiles) {
+    int D, int h, int w, int hyp_pp, int flags, int tiles_x, int ntiles, int nseg, int seg_planes) {
   constexpr int CG = 8;
   const int ngroups = C / CG;
-  int lin = cds_xcd_remap(blockIdx.x, ntiles * ngroups);
+  // depth segment fastest, then channel group: the blocks of one pixel tile run together (same features in L2).
+  // Small images (cascade stage 1: 160x128) would otherwise give 1-2 workgroups per CU looping over all planes.
+  int lin = cds_xcd_remap(blockIdx.x, ntiles * ngroups * nseg);
+  const int seg = lin % nseg;
+  lin /= nseg;
   int g = lin % ngroups;
   int tile = lin / ngroups;
   int tx = tile % tiles_x, ty = tile / tiles_x;
@@ -150,10 +186,12 @@ __global__ __launch_bounds__(256) void warp_aggregate_kernel(
   const bool normalize = flags & CDS_AGG_NORMALIZE;
   const float denom = (normalize ? vis_sum[pix] : 1.0f) + 1e-6f;  // vis_sum finalised by vis_sum_kernel
 
-  float dnext = hyp_pp ? hyp[pix] : hyp[0];
-  for (int d = 0; d < D; ++d) {
+  const int dbeg = seg * seg_planes, dend = min(D, dbeg + seg_planes);
+  if (dbeg >= dend) return;
+  float dnext = hyp_pp ? hyp[(size_t)dbeg * hw + pix] : hyp[dbeg];
+  for (int d = dbeg; d < dend; ++d) {
     float dv = dnext;
-    if (d + 1 < D) dnext = hyp_pp ? hyp[(size_t)(d + 1) * hw + pix] : hyp[d + 1];
+    if (d + 1 < dend) dnext = hyp_pp ? hyp[(size_t)(d + 1) * hw + pix] : hyp[d + 1];
     float acc[CG];
 #pragma unroll
     for (int c = 0; c < CG; ++c) acc[c] = accumulate ? volume[((size_t)(c_base + c) * D + d) * hw + pix] : 0.f;
@@ -292,9 +330,18 @@ extern "C" int cds_warp_entropy_f32(const float* ref_chw, const float* src_hwc, 
   hipStream_t st = (hipStream_t)stream;
   if (cds_use_lds_path() && cds_warp_entropy_lds_launch(ref_chw, src_hwc, wm, hyp, entropy, V, C, D, h, w, hyp_per_pixel, st))
     return cds_launch_status();
-#define LAUNCH(CC)                                                                                          \
-  hipLaunchKernelGGL(warp_entropy_kernel<CC>, dim3(ntiles * V), dim3(256), 0, st, ref_chw, src_hwc, wm, hyp, \
-                     entropy, V, D, h, w, hyp_per_pixel, tiles_x, ntiles)
+  // small images: one pixel row of 64 per workgroup, planes split over its four waves (>= ~6 workgroups per CU otherwise)
+  const bool dsplit = (long)ntiles * V < 6L * 256 && D >= 8;
+  const int tiles_y1 = dsplit ? h : tiles_y, nt = tiles_x * tiles_y1;
+#define LAUNCH(CC)                                                                                                 \
+  do {                                                                                                             \
+    if (dsplit)                                                                                                    \
+      hipLaunchKernelGGL((warp_entropy_kernel<CC, 4>), dim3(nt * V), dim3(256), 0, st, ref_chw, src_hwc, wm, hyp,  \
+                         entropy, V, D, h, w, hyp_per_pixel, tiles_x, nt);                                         \
+    else                                                                                                           \
+      hipLaunchKernelGGL((warp_entropy_kernel<CC, 1>), dim3(nt * V), dim3(256), 0, st, ref_chw, src_hwc, wm, hyp,  \
+                         entropy, V, D, h, w, hyp_per_pixel, tiles_x, nt);                                         \
+  } while (0)
   if (C == 8) LAUNCH(8);
   else if (C == 16) LAUNCH(16);
   else LAUNCH(32);
@@ -318,9 +365,14 @@ extern "C" int cds_warp_aggregate_f32(const float* ref_chw, const float* src_hwc
   if (cds_use_lds_path() &&
       cds_warp_aggregate_lds_launch(ref_chw, src_hwc, vis_w, wm, hyp, volume, vis_sum, V, C, D, h, w, hyp_per_pixel, flags, st))
     return cds_launch_status();
+  // depth segments: aim at >= ~6 workgroups per CU, at least 8 planes per segment
+  int nseg = 1;
+  while ((long)ntiles * ngroups * nseg < 6L * 256 && D / (2 * nseg) >= 8) nseg *= 2;
+  const int seg_planes = cds_ceil_div(D, nseg);
+  nseg = cds_ceil_div(D, seg_planes);
 #define LAUNCH(VM)                                                                                                  \
-  hipLaunchKernelGGL(warp_aggregate_kernel<VM>, dim3(ntiles * ngroups), dim3(256), 0, st, ref_chw, src_hwc, vis_w, wm, \
-                     hyp, volume, vis_sum, V, C, D, h, w, hyp_per_pixel, flags, tiles_x, ntiles)
+  hipLaunchKernelGGL(warp_aggregate_kernel<VM>, dim3(ntiles * ngroups * nseg), dim3(256), 0, st, ref_chw, src_hwc, vis_w, wm, \
+                     hyp, volume, vis_sum, V, C, D, h, w, hyp_per_pixel, flags, tiles_x, ntiles, nseg, seg_planes)
   if (V <= 2) LAUNCH(2);
   else if (V <= 4) LAUNCH(4);
   else if (V <= 6) LAUNCH(6);
