@@ -60,6 +60,21 @@ def costreg_flops(h, w, D, C):
     return 2.0 * f
 
 
+def costreg_min_bytes(h, w, D, C):
+    """Compulsory fp32 activation traffic of CostRegNet: every layer reads its input (+ skip) and writes its output once."""
+    v = D * h * w
+    b = 8
+    t = (C + b) * v                                   # conv0
+    t += b * v + 2 * b * v / 8 + 2 * (2 * b * v / 8)  # conv1, conv2
+    t += 2 * b * v / 8 + 4 * b * v / 64 + 2 * (4 * b * v / 64)   # conv3, conv4
+    t += 4 * b * v / 64 + 8 * b * v / 512 + 2 * (8 * b * v / 512)  # conv5, conv6
+    t += 8 * b * v / 512 + 2 * (4 * b * v / 64)       # conv7: in, skip + out
+    t += 4 * b * v / 64 + 2 * (2 * b * v / 8)         # conv9
+    t += 2 * b * v / 8 + 2 * (b * v)                  # conv11
+    t += b * v + v                                    # prob
+    return 4.0 * t
+
+
 def make_workload(name, seed, device):
     from cds_mvsnet_amd import synth
     h, w, D, C, n_views = WORKLOADS[name]
@@ -246,7 +261,8 @@ def main():
         extra["roofline_costreg"] = {"bound": "fp32", "achieved": fl / (kern["costreg"] * 1e-3) / 1e12,
                                      "peak": FP32_PEAK / 1e12, "unit": "TFLOP/s",
                                      "frac": fl / (kern["costreg"] * 1e-3) / FP32_PEAK, "kernel_ms": kern["costreg"],
-                                     "flops": fl}
+                                     "flops": fl, "min_activation_bytes": costreg_min_bytes(h, w, D, C),
+                                     "activation_gbs": costreg_min_bytes(h, w, D, C) / (kern["costreg"] * 1e-3) / 1e9}
     extra["kernel_ms"] = {k: round(v, 4) for k, v in sorted(kern.items())}
 
     others = None
