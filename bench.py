@@ -147,6 +147,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="M1", choices=sorted(WORKLOADS))
     ap.add_argument("--parallelism", default="replicas", choices=["replicas", "viewshard"])
+    ap.add_argument("--exchange", default="allreduce", choices=["allreduce", "p2p"],
+                    help="viewshard exchange: one RCCL all-reduce, or reduce-scatter + all-gather as direct P2P sends")
     ap.add_argument("--no-extras", action="store_true", help="skip the M1b / M2 side measurements")
     ap.add_argument("--streams", type=int, default=1,
                     help="depth maps in flight per GPU on separate HIP streams (a step = that many depth maps; "
@@ -189,7 +191,7 @@ def main():
     cams_d, hyp_d = cams, hyp.to(dev)
     if world > 1 and args.parallelism == "viewshard":
         from cds_mvsnet_amd import distributed as cdist
-        runner = cdist.ViewShardedStage(model, dist.group.WORLD)
+        runner = cdist.ViewShardedStage(model, dist.group.WORLD, exchange=args.exchange)
         def step():
             return runner(dfe, cams_d, hyp_d, D, stage)
     else:

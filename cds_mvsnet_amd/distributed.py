@@ -26,8 +26,17 @@ Tensor = torch.Tensor
 
 
 class ViewShard:
-    def __init__(self, group: Optional["dist.ProcessGroup"] = None):
+    """`exchange`: "allreduce" (one collective, the library picks ring / tree) or "p2p" (reduce-scatter + all-gather
+    written as direct point-to-point transfers: every rank sends slice j of its buffer to rank j, sums the world-1
+    slices it receives, then sends its reduced slice to everybody).  On xGMI every pair of GPUs has its own link, so the
+    p2p form moves 2 (world-1)/world of the buffer per rank with all links busy, where a ring is bound by one link
+    (SURVEY §8(e)).  Both give the same sums up to fp32 re-association."""
+
+    def __init__(self, group: Optional["dist.ProcessGroup"] = None, exchange: str = "allreduce"):
+        if exchange not in ("allreduce", "p2p"):
+            raise ValueError("exchange must be 'allreduce' or 'p2p'")
         self.group = group
+        self.exchange = exchange
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
 
@@ -45,9 +54,52 @@ class ViewShard:
         return flat[:n].view(C, D, h, w), flat[n:n + h * w].view(h, w), flat[n + h * w:].view(h, w)
 
     def all_reduce_partials(self, flat: Tensor) -> Tensor:
-        """The single exchange step: SUM over ranks of volume_sum ++ vis_sum ++ nc_sum."""
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        """The single exchange step: SUM over ranks of volume_sum ++ vis_sum ++ nc_sum (in place)."""
+        if self.exchange == "allreduce" or self.world == 1:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+            return flat
+        return self._p2p_all_reduce(flat)
+
+    def _slices(self, n: int) -> List[Tuple[int, int]]:
+        step = (n + self.world - 1) // self.world
+        return [(min(r * step, n), min((r + 1) * step, n)) for r in range(self.world)]
+
+    def _p2p_all_reduce(self, flat: Tensor) -> Tensor:
+        W, me = self.world, self.rank
+        sl = self._slices(flat.numel())
+        a, b = sl[me]
+        peers = [r for r in range(W) if r != me]
+        # reduce-scatter: my slice of every peer's buffer comes to me; theirs go out
+        recv = [torch.empty(b - a, dtype=flat.dtype, device=flat.device) for _ in peers]
+        ops_ = []
+        for i, r in enumerate(peers):
+            ra, rb = sl[r]
+            if rb > ra:
+                ops_.append(dist.P2POp(dist.isend, flat[ra:rb], self._global(r), self.group))
+            if b > a:
+                ops_.append(dist.P2POp(dist.irecv, recv[i], self._global(r), self.group))
+        if ops_:
+            for req in dist.batch_isend_irecv(ops_):
+                req.wait()
+        mine = flat[a:b]
+        for i, r in enumerate(peers):          # rank order: the same association on every rank
+            if b > a:
+                mine.add_(recv[i])
+        # all-gather of the reduced slices
+        ops_ = []
+        for r in peers:
+            ra, rb = sl[r]
+            if b > a:
+                ops_.append(dist.P2POp(dist.isend, mine, self._global(r), self.group))
+            if rb > ra:
+                ops_.append(dist.P2POp(dist.irecv, flat[ra:rb], self._global(r), self.group))
+        if ops_:
+            for req in dist.batch_isend_irecv(ops_):
+                req.wait()
         return flat
+
+    def _global(self, group_rank: int) -> int:
+        return dist.get_global_rank(self.group, group_rank) if self.group is not None else group_rank
 
     # ---- one stage on this rank's views (GPU) --------------------------------------------------
     def run_stage(self, model, ref: Optional[Tensor], src: Optional[Tensor], ref_nc: Optional[Tensor],
@@ -71,9 +123,9 @@ class ViewShard:
         return depth, conf, nc_sum / n_src_total
 
 
-def shard_views(model, group: Optional["dist.ProcessGroup"] = None) -> ViewShard:
+def shard_views(model, group: Optional["dist.ProcessGroup"] = None, exchange: str = "allreduce") -> ViewShard:
     """Make ``model.forward`` shard the source views of every depth map over the ranks of ``group``."""
-    sh = ViewShard(group)
+    sh = ViewShard(group, exchange)
     model._view_shard = sh
     return sh
 
@@ -82,9 +134,9 @@ class ViewShardedStage:
     """Single-stage driver with the reference's StageNet argument layout (used by bench.py --parallelism
     viewshard): every rank is handed all views and picks its own."""
 
-    def __init__(self, model, group=None):
+    def __init__(self, model, group=None, exchange: str = "allreduce"):
         self.model = model
-        self.shard = ViewShard(group)
+        self.shard = ViewShard(group, exchange)
 
     def __call__(self, features, proj_matrices: Tensor, depth_values: Tensor, num_depth: int, stage_idx: int):
         sh = self.shard

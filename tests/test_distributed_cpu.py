@@ -90,3 +90,42 @@ def test_more_ranks_than_views_bookkeeping():
     vol, vs, nc = ViewShard.split_flat(flat, C, D, h, w)
     assert vol.shape == (C, D, h, w) and vs.shape == (h, w) and nc.shape == (h, w)
     assert vol.data_ptr() == flat.data_ptr() and nc[-1, -1] == flat[-1]
+
+
+def _p2p_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import sys
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from cds_mvsnet_amd.distributed import ViewShard
+        res = []
+        for n in (1, 5, 1000, 4099):                      # fewer elements than ranks, uneven slices
+            g = torch.Generator().manual_seed(100 + rank)
+            a = torch.randn(n, generator=g)
+            ref = a.clone()
+            dist.all_reduce(ref)
+            got = ViewShard(exchange="p2p").all_reduce_partials(a.clone())
+            res.append(float((got - ref).abs().max()))
+        q.put((rank, res))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_p2p_reduce_scatter_all_gather_equals_allreduce(world):
+    """The point-to-point exchange (reduce-scatter + all-gather as direct sends) against the library
+    all-reduce on gloo, world sizes 2 and 3."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_p2p_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for _, errs in res:
+        assert max(errs) < 1e-6
