@@ -33,7 +33,8 @@ struct C2Cfg {
 // K = 1 needs no halo and reads its inputs straight from global memory (the 1x1 convolutions ran at 1/7 of the HBM
 // rate through the LDS path).
 template <int K, int S, int PX, int CI_CHUNK, int NCB>
-__global__ __launch_bounds__(256) void conv2d_kernel(const float* __restrict__ x, const float* __restrict__ wpk,
+__global__ __launch_bounds__(256) void conv2d_kernel(const float* __restrict__ x, const float* __restrict__ in_affine,
+                                                     const float* __restrict__ wpk,
                                                      const float* __restrict__ bias, float* __restrict__ out, int N,
                                                      int Cin, int Cout, int CoutP, int H, int W, int Ho, int Wo, int pad,
                                                      int act, int tiles_x, int tiles_y) {
@@ -55,6 +56,9 @@ __global__ __launch_bounds__(256) void conv2d_kernel(const float* __restrict__ x
   const int gx0 = ox0 * S - pad, gy0 = oy0 * S - pad;
   const size_t plane = (size_t)H * W;
   const float* __restrict__ xn = x + (size_t)n * Cin * plane;
+  // optional per-(image, channel) affine + leaky slope applied to every in-bounds input value on load: the lazily applied
+  // InstanceNorm + LeakyReLU of the producing layer (zero padding stays zero, as padding follows the normalisation)
+  const float* __restrict__ aff = in_affine ? in_affine + (size_t)n * Cin * 3 : nullptr;
 
   float acc[PX][CW];
 #pragma unroll
@@ -71,6 +75,14 @@ __global__ __launch_bounds__(256) void conv2d_kernel(const float* __restrict__ x
       float in[PX];
 #pragma unroll
       for (int p = 0; p < PX; ++p) in[p] = (rowok && oxp + p < W) ? src[oxp + p] : 0.f;
+      if (aff) {
+        const float al = aff[3 * ci], be = aff[3 * ci + 1], sl = aff[3 * ci + 2];
+#pragma unroll
+        for (int p = 0; p < PX; ++p) {
+          const float t = in[p] * al + be;
+          in[p] = (rowok && oxp + p < W) ? (t > 0.f ? t : t * sl) : 0.f;
+        }
+      }
       const float* __restrict__ wc = wpk + __builtin_amdgcn_readfirstlane(ci * CoutP + co0);
 #pragma unroll
       for (int c = 0; c < CW; ++c) {
@@ -89,10 +101,20 @@ __global__ __launch_bounds__(256) void conv2d_kernel(const float* __restrict__ x
         const bool row_ok = (ci0 + ci < Cin) && gy >= 0 && gy < H;
         const float* __restrict__ src = xn + (size_t)(ci0 + ci) * plane + (size_t)gy * W;
         float* dst = lds + ci * Cfg::TILE + ry * Cfg::IXP;
+        float al = 1.f, be = 0.f, sl = 1.f;
+        if (aff && ci0 + ci < Cin) {
+          al = aff[3 * (ci0 + ci)]; be = aff[3 * (ci0 + ci) + 1]; sl = aff[3 * (ci0 + ci) + 2];
+        }
         for (int i = tid & 63; i < Cfg::IXP; i += 64) {
           const int gx = gx0 + i;
           float v = 0.f;
-          if (row_ok && gx >= 0 && gx < W && i < Cfg::IX) v = src[gx];
+          if (row_ok && gx >= 0 && gx < W && i < Cfg::IX) {
+            v = src[gx];
+            if (aff) {
+              const float t = v * al + be;
+              v = t > 0.f ? t : t * sl;
+            }
+          }
           dst[i] = v;
         }
       }
@@ -137,8 +159,8 @@ __global__ __launch_bounds__(256) void conv2d_kernel(const float* __restrict__ x
 }
 
 template <int K, int S, int PX, int CI_CHUNK, int NCB>
-int launch_conv2d_n(const float* x, const float* w, const float* b, float* out, int N, int Cin, int Cout, int H, int W,
-                    int pad, int act, hipStream_t st) {
+int launch_conv2d_n(const float* x, const float* aff, const float* w, const float* b, float* out, int N, int Cin, int Cout,
+                    int H, int W, int pad, int act, hipStream_t st) {
   using Cfg = C2Cfg<K, S, PX, CI_CHUNK>;
   const int Ho = (H + 2 * pad - K) / S + 1, Wo = (W + 2 * pad - K) / S + 1;
   const int CoutP = (Cout + CO - 1) / CO * CO;
@@ -146,7 +168,7 @@ int launch_conv2d_n(const float* x, const float* w, const float* b, float* out, 
   const int co_groups = CoutP / (CO * NCB);
   const size_t lds_bytes = (K == 1 && S == 1) ? 0 : (size_t)Cfg::TILE * CI_CHUNK * sizeof(float);
   auto kern = conv2d_kernel<K, S, PX, CI_CHUNK, NCB>;
-  hipLaunchKernelGGL(kern, dim3(tx * ty * co_groups * N), dim3(256), lds_bytes, st, x, w, b, out, N, Cin, Cout, CoutP, H,
+  hipLaunchKernelGGL(kern, dim3(tx * ty * co_groups * N), dim3(256), lds_bytes, st, x, aff, w, b, out, N, Cin, Cout, CoutP, H,
                      W, Ho, Wo, pad, act, tx, ty);
   return cds_launch_status();
 }
@@ -154,23 +176,23 @@ int launch_conv2d_n(const float* x, const float* w, const float* b, float* out, 
 // CDS_CONV2D_WIDE (A/B knob): 0 = one 8-wide block per workgroup everywhere.  Default: all output-channel blocks of a
 // layer from one staged tile where a variant exists (cascade forward 640x512: 11.0 -> 9.8 ms, 1600x1184: 46.9 -> 41.4 ms).
 template <int K, int S, int CI_CHUNK>
-int launch_conv2d(const float* x, const float* w, const float* b, float* out, int N, int Cin, int Cout, int H, int W,
-                  int pad, int act, hipStream_t st) {
+int launch_conv2d(const float* x, const float* aff, const float* w, const float* b, float* out, int N, int Cin, int Cout,
+                  int H, int W, int pad, int act, hipStream_t st) {
   static const int wide = []() { const char* e = getenv("CDS_CONV2D_WIDE"); return e ? atoi(e) : -1; }();
   const int blocks = (Cout + CO - 1) / CO;
   constexpr int PXW = (S == 2) ? 2 : 4;
   const bool use_wide = wide != 0;
   if (use_wide) {
     if (blocks % 2 == 0 && (blocks == 2 || K > 5))
-      return launch_conv2d_n<K, S, PXW, CI_CHUNK, 2>(x, w, b, out, N, Cin, Cout, H, W, pad, act, st);
+      return launch_conv2d_n<K, S, PXW, CI_CHUNK, 2>(x, aff, w, b, out, N, Cin, Cout, H, W, pad, act, st);
     if constexpr (K <= 5) {
-      if (K <= 3 && blocks % 5 == 0) return launch_conv2d_n<K, S, 2, CI_CHUNK, 5>(x, w, b, out, N, Cin, Cout, H, W, pad, act, st);
-      if (blocks % 4 == 0) return launch_conv2d_n<K, S, 2, CI_CHUNK, 4>(x, w, b, out, N, Cin, Cout, H, W, pad, act, st);
-      if (blocks % 3 == 0) return launch_conv2d_n<K, S, 2, CI_CHUNK, 3>(x, w, b, out, N, Cin, Cout, H, W, pad, act, st);
-      if (blocks % 2 == 0) return launch_conv2d_n<K, S, PXW, CI_CHUNK, 2>(x, w, b, out, N, Cin, Cout, H, W, pad, act, st);
+      if (K <= 3 && blocks % 5 == 0) return launch_conv2d_n<K, S, 2, CI_CHUNK, 5>(x, aff, w, b, out, N, Cin, Cout, H, W, pad, act, st);
+      if (blocks % 4 == 0) return launch_conv2d_n<K, S, 2, CI_CHUNK, 4>(x, aff, w, b, out, N, Cin, Cout, H, W, pad, act, st);
+      if (blocks % 3 == 0) return launch_conv2d_n<K, S, 2, CI_CHUNK, 3>(x, aff, w, b, out, N, Cin, Cout, H, W, pad, act, st);
+      if (blocks % 2 == 0) return launch_conv2d_n<K, S, PXW, CI_CHUNK, 2>(x, aff, w, b, out, N, Cin, Cout, H, W, pad, act, st);
     }
   }
-  return launch_conv2d_n<K, S, PXW, CI_CHUNK, 1>(x, w, b, out, N, Cin, Cout, H, W, pad, act, st);
+  return launch_conv2d_n<K, S, PXW, CI_CHUNK, 1>(x, aff, w, b, out, N, Cin, Cout, H, W, pad, act, st);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -306,6 +328,20 @@ __global__ __launch_bounds__(256) void instnorm_apply_kernel(const float* __rest
   }
 }
 
+// (sum, sum of squares) -> (alpha, beta, slope) so that a consumer applies y = leaky(x * alpha + beta, slope) on load
+__global__ void instnorm_affine_kernel(const double* __restrict__ stats, float* __restrict__ affine, int nc, int hw,
+                                       float slope) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nc) return;
+  const double mean = stats[2 * i] / hw;
+  double var = stats[2 * i + 1] / hw - mean * mean;
+  var = var < 0.0 ? 0.0 : var;
+  const float invstd = (float)(1.0 / sqrt(var + 1e-5));
+  affine[3 * i] = invstd;
+  affine[3 * i + 1] = -(float)mean * invstd;
+  affine[3 * i + 2] = slope;
+}
+
 // norm-curvature bookkeeping of a FeatureNet level (module.py:250-251,257-258,264-265): (a^2 + b^2 + c^2) / 3 and |c|
 __global__ __launch_bounds__(256) void curvature_stats_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                               const float* __restrict__ c, float* __restrict__ nc_sum,
@@ -355,22 +391,29 @@ extern "C" int cds_curvature_stats_f32(const float* a, const float* b, const flo
   return cds_launch_status();
 }
 
-extern "C" int cds_conv2d_f32(const float* x, const float* weight, const float* bias, float* out, int N, int Cin,
-                              int Cout, int H, int W, int k, int stride, int pad, int act, void* stream) {
+extern "C" int cds_conv2d_affine_f32(const float* x, const float* in_affine, const float* weight, const float* bias,
+                                     float* out, int N, int Cin, int Cout, int H, int W, int k, int stride, int pad,
+                                     int act, void* stream) {
   if (!x || !weight || !out || N < 1 || Cin < 1 || Cout < 1 || H < 1 || W < 1 || pad < 0) return CDS_EINVAL;
   hipStream_t st = (hipStream_t)stream;
+  const float* a = in_affine;
   if (stride == 1) {
     switch (k) {
-      case 1: return pad == 0 ? launch_conv2d<1, 1, 8>(x, weight, bias, out, N, Cin, Cout, H, W, pad, act, st) : CDS_EINVAL;
-      case 3: return launch_conv2d<3, 1, 4>(x, weight, bias, out, N, Cin, Cout, H, W, pad, act, st);
-      case 5: return launch_conv2d<5, 1, 4>(x, weight, bias, out, N, Cin, Cout, H, W, pad, act, st);
-      case 7: return launch_conv2d<7, 1, 4>(x, weight, bias, out, N, Cin, Cout, H, W, pad, act, st);
-      case 11: return launch_conv2d<11, 1, 4>(x, weight, bias, out, N, Cin, Cout, H, W, pad, act, st);
+      case 1: return pad == 0 ? launch_conv2d<1, 1, 8>(x, a, weight, bias, out, N, Cin, Cout, H, W, pad, act, st) : CDS_EINVAL;
+      case 3: return launch_conv2d<3, 1, 4>(x, a, weight, bias, out, N, Cin, Cout, H, W, pad, act, st);
+      case 5: return launch_conv2d<5, 1, 4>(x, a, weight, bias, out, N, Cin, Cout, H, W, pad, act, st);
+      case 7: return launch_conv2d<7, 1, 4>(x, a, weight, bias, out, N, Cin, Cout, H, W, pad, act, st);
+      case 11: return launch_conv2d<11, 1, 4>(x, a, weight, bias, out, N, Cin, Cout, H, W, pad, act, st);
       default: return CDS_EINVAL;
     }
   }
-  if (stride == 2 && k == 3) return launch_conv2d<3, 2, 4>(x, weight, bias, out, N, Cin, Cout, H, W, pad, act, st);
+  if (stride == 2 && k == 3) return launch_conv2d<3, 2, 4>(x, a, weight, bias, out, N, Cin, Cout, H, W, pad, act, st);
   return CDS_EINVAL;
+}
+
+extern "C" int cds_conv2d_f32(const float* x, const float* weight, const float* bias, float* out, int N, int Cin,
+                              int Cout, int H, int W, int k, int stride, int pad, int act, void* stream) {
+  return cds_conv2d_affine_f32(x, nullptr, weight, bias, out, N, Cin, Cout, H, W, k, stride, pad, act, stream);
 }
 
 extern "C" int cds_dynconv_blend_shared_f32(const float* branches, const float* w1, const float* b1, const float* w2,
@@ -402,6 +445,24 @@ extern "C" int cds_dynconv_blend_f32(const float* branches, const float* w1, con
                                      int K, int Cout, int H, int W, void* stream) {
   return cds_dynconv_blend_shared_f32(branches, w1, b1, w2, epipoles_host, temperature, out, norm_curv, N, K, Cout, H, W, 1,
                                       stream);
+}
+
+// InstanceNorm statistics only: affine[n][c] = (1/std, -mean/std, slope) for a consumer that normalises on load
+// (same fp64 statistics and the same x * alpha + beta expression as cds_instnorm_act_f32: bit-identical values)
+extern "C" int cds_instnorm_affine_f32(const float* x, float* affine, float* stats, int N, int C, int H, int W, float slope,
+                                       void* stream) {
+  if (!x || !affine || !stats || N < 1 || C < 1 || H < 1 || W < 1) return CDS_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int hw = H * W;
+  double* dstats = reinterpret_cast<double*>(stats);  // scratch: 2*N*C doubles
+  hipError_t e = hipMemsetAsync(dstats, 0, sizeof(double) * 2 * N * C, st);
+  if (e != hipSuccess) return -(int)e;
+  int bpc = cds_ceil_div(hw, 256 * 16);
+  if (bpc < 1) bpc = 1;
+  hipLaunchKernelGGL(instnorm_stats_kernel, dim3(N * C * bpc), dim3(256), 0, st, x, dstats, hw, bpc);
+  hipLaunchKernelGGL(instnorm_affine_kernel, dim3(cds_ceil_div(N * C, 256)), dim3(256), 0, st, dstats, affine, N * C, hw,
+                     slope);
+  return cds_launch_status();
 }
 
 extern "C" int cds_instnorm_act_f32(const float* x, float* out, float* stats, int N, int C, int H, int W, int act,

@@ -343,28 +343,38 @@ class _FeatureRunner:
             out[f"{name}.w"] = _pack2d(getattr(net, name).conv.weight.detach())
         return out
 
-    def _dynamic(self, p, name: str, dc: DynamicConv, x: Tensor, epi: Tensor, T: float, n_shared: int = 1):
-        """x [N,Cin,H,W], epi CPU [N,2] (pixels at this resolution) -> (out [N,Cout,H,W], norm_curv [N,H,W]).
-        n_shared > 1: the first n_shared images are copies of one image: their epipole-independent
-        branch responses are convolved once (image n_shared - 1 stands for all of them)."""
+    # A layer output travels as (raw, affine): the un-normalised convolution result plus the [N,C,3] table
+    # (1/std, -mean/std, leaky slope) of its InstanceNorm + LeakyReLU, which the consuming convolutions apply on load
+    # (`cds_conv2d_affine_f32`) - the normalised tensor is never written.  affine = None marks a materialised tensor.
+    def _dynamic(self, p, name: str, dc: DynamicConv, x: Tensor, epi: Tensor, T: float, n_shared: int = 1,
+                 aff: Optional[Tensor] = None):
+        """x [N,Cin,H,W] (with its pending affine), epi CPU [N,2] (pixels at this resolution) ->
+        (out [N,Cout,H,W], norm_curv [N,H,W]).  n_shared > 1: the first n_shared images are copies of one image (SURVEY
+        §8(f)-4): their epipole-independent branch responses are convolved once (image n_shared - 1 stands for all)."""
         N, Cin, H, W = x.shape
         nk = len(dc.size_kernels)
         xs = x[n_shared - 1:] if n_shared > 1 else x
+        affs = aff[n_shared - 1:].contiguous() if (aff is not None and n_shared > 1) else aff
         branches = torch.empty((nk, xs.shape[0], dc.out_c + 3, H, W), dtype=torch.float32, device=x.device)
         for i, k in enumerate(dc.size_kernels):
             ops.conv2d(xs, p[f"{name}.w{i}"], p.get(f"{name}.b{i}"), dc.out_c + 3, k, 1, (k - 1) // 2, ACT_NONE,
-                       out=branches[i])
+                       out=branches[i], in_affine=affs)
         return ops.dynconv_blend(branches, p[f"{name}.m1"], p[f"{name}.mb"], p[f"{name}.m2"], epi, T, n_shared)
 
-    def _dyn_unit(self, p, name, x, epi, T, n_shared: int = 1):
-        y, nc = self._dynamic(p, name, getattr(self.net, name).conv, x, epi, T, n_shared)
-        return ops.instnorm_act(y, ACT_LEAKY01), nc
+    def _dyn_unit(self, p, name, x, epi, T, n_shared: int = 1, aff: Optional[Tensor] = None):
+        y, nc = self._dynamic(p, name, getattr(self.net, name).conv, x, epi, T, n_shared, aff)
+        return y, ops.instnorm_affine(y, 0.1), nc
 
-    def _plain_unit(self, p, name, x):
+    def _plain_unit(self, p, name, x, aff: Optional[Tensor] = None):
         unit: ConvUnit = getattr(self.net, name)
         k = unit.conv.kernel_size[0]
-        y = ops.conv2d(x, p[f"{name}.w"], None, unit.conv.out_channels, k, unit.stride, unit.padding)
-        return ops.instnorm_act(y, ACT_LEAKY01)
+        y = ops.conv2d(x, p[f"{name}.w"], None, unit.conv.out_channels, k, unit.stride, unit.padding, in_affine=aff)
+        return y, ops.instnorm_affine(y, 0.1)
+
+    @staticmethod
+    def _identity_affine(N: int, C: int, device) -> Tensor:
+        """(1, 0, 1) rows: a materialised tensor inside a lazily normalised concatenation."""
+        return torch.tensor([1.0, 0.0, 1.0], dtype=torch.float32, device=device).expand(N, C, 3).contiguous()
 
     @staticmethod
     def _final(o: Tensor, n_chw: int) -> Tuple[Tensor, Optional[Tensor]]:
@@ -392,29 +402,30 @@ class _FeatureRunner:
         e2 = (e0 / 4).contiguous()
         # conv00 sees the raw images: with n_shared copies of the reference image its branch convolutions (3x3, 7x7,
         # 11x11) run once for all of them; from conv01 on the inputs differ (the blend depends on the epipole)
-        c00, n00 = self._dyn_unit(p, "conv00", imgs, e0, T, n_shared)
-        c01, n01 = self._dyn_unit(p, "conv01", c00, e0, T)
-        d0 = self._plain_unit(p, "downsample1", c01)
-        c10, n10 = self._dyn_unit(p, "conv10", d0, e1, T)
-        c11, n11 = self._dyn_unit(p, "conv11", c10, e1, T)
-        d1 = self._plain_unit(p, "downsample2", c11)
-        c20, n20 = self._dyn_unit(p, "conv20", d1, e2, T)
-        c21, n21 = self._dyn_unit(p, "conv21", c20, e2, T)
+        c00, a00, n00 = self._dyn_unit(p, "conv00", imgs, e0, T, n_shared)
+        c01, a01, n01 = self._dyn_unit(p, "conv01", c00, e0, T, aff=a00)
+        d0, ad0 = self._plain_unit(p, "downsample1", c01, a01)
+        c10, a10, n10 = self._dyn_unit(p, "conv10", d0, e1, T, aff=ad0)
+        c11, a11, n11 = self._dyn_unit(p, "conv11", c10, e1, T, aff=a10)
+        d1, ad1 = self._plain_unit(p, "downsample2", c11, a11)
+        c20, a20, n20 = self._dyn_unit(p, "conv20", d1, e2, T, aff=ad1)
+        c21, a21, n21 = self._dyn_unit(p, "conv21", c20, e2, T, aff=a20)
 
         out = {}
-        o1, n22 = self._dynamic(p, "out1", net.out1, c21, e2, T)
+        o1, n22 = self._dynamic(p, "out1", net.out1, c21, e2, T, aff=a21)
         out["stage1"] = self._final(o1, n_chw) + ops.curvature_stats(n20, n21, n22)
 
+        # FPN: nearest-neighbour up-sampling and concatenation move raw values; the affine tables concatenate alike
         x = torch.cat((_nearest2x(c21), c11), dim=1)
-        x = self._plain_unit(p, "inner1", x)
-        o2, n12 = self._dynamic(p, "out2", net.out2, x, e1, T)
+        x, ax = self._plain_unit(p, "inner1", x, torch.cat((a21, a11), dim=1))
+        o2, n12 = self._dynamic(p, "out2", net.out2, x, e1, T, aff=ax)
         o2n = ops.instnorm_act(o2, ACT_TANH)
         hwc2 = torch.stack([ops.chw_to_hwc(o2n[i]) for i in range(n_chw, N)]) if n_chw < N else None
         out["stage2"] = (o2n[:n_chw] if n_chw > 0 else None, hwc2) + ops.curvature_stats(n10, n11, n12)
 
-        x = torch.cat((_nearest2x(o2n), c01), dim=1)
-        x = self._plain_unit(p, "inner2", x)
-        o3, n02 = self._dynamic(p, "out3", net.out3, x, e0, T)
+        x = torch.cat((_nearest2x(o2n), c01), dim=1)                       # o2n is materialised (tanh features)
+        x, ax = self._plain_unit(p, "inner2", x, torch.cat((self._identity_affine(N, o2n.shape[1], x.device), a01), dim=1))
+        o3, n02 = self._dynamic(p, "out3", net.out3, x, e0, T, aff=ax)
         out["stage3"] = self._final(o3, n_chw) + ops.curvature_stats(n00, n01, n02)
         return out
 

@@ -289,9 +289,12 @@ def deconv3d_k3s2(x: Tensor, wpk: Tensor, bias: Optional[Tensor], relu: bool = T
 
 
 def conv2d(x: Tensor, wpk: Tensor, bias: Optional[Tensor], cout: int, k: int, stride: int = 1, pad: int = 0,
-           act: int = ACT_NONE, out: Optional[Tensor] = None) -> Tensor:
-    """x [N,Cin,H,W], wpk packed [Cin,k*k,CoutP] -> [N,cout,Ho,Wo] (written into `out` if given)."""
+           act: int = ACT_NONE, out: Optional[Tensor] = None, in_affine: Optional[Tensor] = None) -> Tensor:
+    """x [N,Cin,H,W], wpk packed [Cin,k*k,CoutP] -> [N,cout,Ho,Wo] (written into `out` if given).
+    in_affine [N,Cin,3] (alpha, beta, slope): the producing layer's InstanceNorm + LeakyReLU applied on load."""
     N, Cin, H, W = x.shape
+    if in_affine is not None and tuple(in_affine.shape) != (N, Cin, 3):
+        raise ValueError(f"conv2d: in_affine must be [{N},{Cin},3], got {tuple(in_affine.shape)}")
     coutp = (cout + 7) // 8 * 8
     if tuple(wpk.shape) != (Cin, k * k, coutp):
         raise ValueError(f"conv2d: packed weight must be [{Cin},{k * k},{coutp}], got {tuple(wpk.shape)}")
@@ -300,10 +303,22 @@ def conv2d(x: Tensor, wpk: Tensor, bias: Optional[Tensor], cout: int, k: int, st
         out = torch.empty((N, cout, Ho, Wo), dtype=torch.float32, device=x.device)
     elif out.numel() != N * cout * Ho * Wo:
         raise ValueError("conv2d: bad output buffer")
-    check(_lib.load().cds_conv2d_f32(_dev(x, "x"), _dev(wpk, "weight"), _dev(bias, "bias") if bias is not None else None,
-                                     _dev(out, "out"), N, Cin, cout, H, W, k, stride, pad, act, _stream(x)),
-          "cds_conv2d_f32")
+    check(_lib.load().cds_conv2d_affine_f32(_dev(x, "x"), _dev(in_affine, "in_affine") if in_affine is not None else None,
+                                            _dev(wpk, "weight"), _dev(bias, "bias") if bias is not None else None,
+                                            _dev(out, "out"), N, Cin, cout, H, W, k, stride, pad, act, _stream(x)),
+          "cds_conv2d_affine_f32")
     return out
+
+
+def instnorm_affine(x: Tensor, slope: float = 0.1) -> Tensor:
+    """InstanceNorm statistics of x [N,C,H,W] as (alpha, beta, slope) rows [N,C,3] for a consumer that normalises on
+    load (conv2d(in_affine=...)); same statistics and expression as instnorm_act."""
+    N, C, H, W = x.shape
+    aff = torch.empty((N, C, 3), dtype=torch.float32, device=x.device)
+    stats = torch.empty((2 * N * C,), dtype=torch.float64, device=x.device)
+    check(_lib.load().cds_instnorm_affine_f32(_dev(x, "x"), aff.data_ptr(), stats.data_ptr(), N, C, H, W, float(slope),
+                                              _stream(x)), "cds_instnorm_affine_f32")
+    return aff
 
 
 def dynconv_blend(branches: Tensor, w1: Tensor, b1: Tensor, w2: Tensor, epipoles: Tensor,

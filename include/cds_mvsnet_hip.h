@@ -162,6 +162,14 @@ int cds_deconv3d_k3s2_f32(const float* x, const float* weight, const float* bias
  */
 int cds_conv2d_f32(const float* x, const float* weight, const float* bias, float* out, int N, int Cin,
                    int Cout, int H, int W, int k, int stride, int pad, int act, void* stream);
+/*
+ * Same convolution with the producing layer's InstanceNorm + LeakyReLU applied on load:
+ *   in_affine [N][Cin][3] = (alpha, beta, slope) per image and input channel (device) or NULL; every in-bounds input
+ *   value v is replaced by t = v * alpha + beta, t > 0 ? t : t * slope before it is multiplied (zero padding stays zero).
+ *   (alpha, beta, slope) = (1, 0, 1) leaves a channel untouched.  Built by cds_instnorm_affine_f32.
+ */
+int cds_conv2d_affine_f32(const float* x, const float* in_affine, const float* weight, const float* bias, float* out,
+                          int N, int Cin, int Cout, int H, int W, int k, int stride, int pad, int act, void* stream);
 
 /*
  * K7 epilogue of DynamicConv (dynamic_conv.py:97-122) for a batch of N images (each with its own epipole):
@@ -194,6 +202,12 @@ int cds_dynconv_blend_shared_f32(const float* branches, const float* w1, const f
  */
 int cds_instnorm_act_f32(const float* x, float* out, float* stats, int N, int C, int H, int W, int act,
                          int out_hwc, void* stream);
+/*
+ * InstanceNorm statistics only (module.py:53,66-69): affine [N][C][3] = (1/sqrt(var + 1e-5), -mean/sqrt(var + 1e-5), slope)
+ * for consumers that normalise on load (cds_conv2d_affine_f32); stats = scratch of 4*N*C floats like cds_instnorm_act_f32.
+ */
+int cds_instnorm_affine_f32(const float* x, float* affine, float* stats, int N, int C, int H, int W, float slope,
+                            void* stream);
 
 /*
  * Depth-map filtering + fusion (fusion.py:7-114, test.py:334-351).  Per reference pixel and source
