@@ -625,3 +625,29 @@ def test_warp_lds_fallbacks_wild_geometry(dev, ops):
     fin = torch.isfinite(want)
     assert fin.float().mean() > 0.99
     assert ((vol.cpu() - want).abs()[fin]).max() < 2e-5
+
+
+@pytest.mark.parametrize("k,stride,cin,cout,H,W", [(3, 1, 8, 11, 37, 70), (1, 1, 24, 8, 20, 33), (5, 1, 16, 19, 18, 40), (3, 2, 16, 32, 21, 50)])
+def test_conv2d_normalise_on_load_equals_materialised(k, stride, cin, cout, H, W, dev, ops):
+    """cds_instnorm_affine_f32 + cds_conv2d_affine_f32 (InstanceNorm + LeakyReLU applied while the input tile is loaded)
+    must give what the materialised path gives (cds_instnorm_act_f32 then cds_conv2d_f32), including the zero
+    padding, mixed with an untouched (1, 0, 1) channel group, at odd sizes."""
+    from cds_mvsnet_amd.ops import ACT_LEAKY01, ACT_NONE
+    g = torch.Generator().manual_seed(k * 10 + stride)
+    N = 3
+    x = (torch.randn(N, cin, H, W, generator=g) * 2 + 0.5).to(dev)
+    w = torch.randn(cout, cin, k, k, generator=g) * 0.1
+    coutp = (cout + 7) // 8 * 8
+    wpk = torch.nn.functional.pad(w.permute(1, 2, 3, 0).reshape(cin, k * k, cout), (0, coutp - cout)).contiguous().to(dev)
+    pad = (k - 1) // 2
+    want = ops.conv2d(ops.instnorm_act(x, ACT_LEAKY01), wpk, None, cout, k, stride, pad, ACT_NONE)
+    aff = ops.instnorm_affine(x, 0.1)
+    got = ops.conv2d(x, wpk, None, cout, k, stride, pad, ACT_NONE, in_affine=aff)
+    # same arithmetic; the two statistics passes add their block partials with atomics, so allow the last bit of 1/std
+    assert (got - want).abs().max() < 1e-5
+    # half of the channels already materialised: identity rows leave them as they are
+    xm = x.clone()
+    xm[:, : cin // 2] = ops.instnorm_act(x[:, : cin // 2].contiguous(), ACT_LEAKY01)
+    aff2 = aff.clone()
+    aff2[:, : cin // 2] = torch.tensor([1.0, 0.0, 1.0], device=dev)
+    assert (ops.conv2d(xm, wpk, None, cout, k, stride, pad, ACT_NONE, in_affine=aff2) - want).abs().max() < 1e-5
