@@ -1,0 +1,44 @@
+"""One-off fuzz of the LDS K1/K3 kernels (C = 8, V = 1..4) against the CPU oracle on random shapes / cameras."""
+import os, sys, random
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from cds_mvsnet_amd import ops, synth, geometry
+from oracle import cds_oracle as O
+
+
+def one_case(rng, dev, verbose=True):
+    V = rng.randint(1, 4); D = rng.choice([1, 2, 3, 9, 31, 32, 33, 48, 65]); h = rng.randint(2, 40); w = rng.randint(2, 200)
+    seed = rng.randint(0, 10_000)
+    base = rng.choice([(40.0, 15.0, 10.0), (200.0, 60.0, 20.0), (5.0, 2.0, 1.0)])
+    feats = synth.make_pair_features(V, 8, h, w, seed=seed, sharp=True)
+    cams = synth.make_cameras(V + 1, h, w, refine=False, seed=seed, baseline=base)["stage3"]
+    jit = rng.choice([0.0, 3.0, 30.0])
+    hyp = synth.make_hypotheses(D, h, w, lo=rng.choice([200.0, 425.0]), hi=rng.choice([500.0, 902.5]), jitter=jit, seed=seed)
+    ref = torch.stack([f["ref"][0][0] for f in feats]).to(dev).contiguous()
+    src = torch.stack([ops.chw_to_hwc(f["src"][0][0].to(dev).contiguous()) for f in feats])
+    mats = geometry.warp_matrices(cams[0]); hyp_d = hyp[0].to(dev).contiguous()
+    g = torch.Generator().manual_seed(seed); vis = torch.rand(V, h, w, generator=g)
+    ent = ops.warp_entropy(ref, src, mats, hyp_d).cpu()
+    vol, _ = ops.warp_aggregate(ref, src, vis.to(dev), mats, hyp_d, normalize=True)
+    P_ref = O.compose_projection(cams[:, 0])
+    want = torch.zeros(8, D, h, w); e_max = 0.0
+    for v in range(V):
+        warped = O.warp_volume(feats[v]["src"][0], O.compose_projection(cams[:, v + 1]), P_ref, hyp)
+        in_prod, e = O.correlation_entropy(feats[v]["ref"][0], warped)
+        e_max = max(e_max, float((ent[v] - e[0, 0]).abs().max()))
+        want += (in_prod * vis[v].view(1, 1, 1, h, w))[0]
+    want = want / (vis.sum(0).view(1, 1, h, w) + 1e-6)
+    err = float((vol.cpu() - want).abs().max())
+    if verbose:
+        flag = "" if (err < 2e-5 and e_max < 5e-5) else "  <-- FAIL"
+        print(f"V={V} D={D:3d} h={h:3d} w={w:3d} base={base[0]:5.0f} jitter={jit:4.0f}: vol {err:.2e} ent {e_max:.2e}{flag}")
+    return err, e_max
+
+
+if __name__ == "__main__":
+    rng = random.Random(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+    dev = torch.device("cuda:0")
+    worst = (0.0, 0.0)
+    for _ in range(int(sys.argv[2]) if len(sys.argv) > 2 else 24):
+        worst = tuple(max(a, b) for a, b in zip(worst, one_case(rng, dev)))
+    print("worst vol / entropy error:", worst)

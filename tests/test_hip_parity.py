@@ -651,3 +651,21 @@ def test_conv2d_normalise_on_load_equals_materialised(k, stride, cin, cout, H, W
     aff2 = aff.clone()
     aff2[:, : cin // 2] = torch.tensor([1.0, 0.0, 1.0], device=dev)
     assert (ops.conv2d(xm, wpk, None, cout, k, stride, pad, ACT_NONE, in_affine=aff2) - want).abs().max() < 1e-5
+
+
+@pytest.mark.parametrize("seed", [3, 17, 91])
+def test_warp_kernels_random_shapes_against_oracle(dev, seed):
+    """Seeded fuzz of K1 / K3 (C = 8 LDS kernels and their direct fallbacks): random view counts 1..4,
+    plane counts around the 32-plane chunk boundary, ragged widths / heights, short and long baselines and
+    per-pixel hypothesis jitter, each compared with the oracle's explicit gather (scripts/fuzz_warp.py)."""
+    import importlib.util
+    import random
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "fuzz_warp.py")
+    spec = importlib.util.spec_from_file_location("fuzz_warp", path)
+    fuzz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fuzz)
+    rng = random.Random(seed)
+    for _ in range(6):
+        vol_err, ent_err = fuzz.one_case(rng, dev, verbose=False)
+        assert vol_err < 1e-5, vol_err
+        assert ent_err < 2e-5, ent_err
