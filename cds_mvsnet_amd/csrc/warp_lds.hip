@@ -168,8 +168,9 @@ __device__ __forceinline__ void reduce_boxes(const int cx0[NV], const int cy0[NV
 }
 
 // Cooperative copy of one box into its two LDS planes, zero outside the image.  Each wave takes rows wave, wave+4, ...
+// srcv points at the first of the 8 channels staged; cs = channels per texel of the source image (8, 16 or 32).
 template <int CAP>
-__device__ __forceinline__ void stage_box(const float* __restrict__ srcv, int h, int w, const Box& b,
+__device__ __forceinline__ void stage_box(const float* __restrict__ srcv, int cs, int h, int w, const Box& b,
                                           float4* __restrict__ dst) {
   if (!b.staged) return;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -177,14 +178,13 @@ __device__ __forceinline__ void stage_box(const float* __restrict__ srcv, int h,
   for (int row = wave; row < b.bh; row += 4) {
     const int gy = b.y0 + row;
     const bool row_ok = (unsigned)gy < (unsigned)h;
-    const float4* __restrict__ g =
-        reinterpret_cast<const float4*>(srcv + ((ptrdiff_t)(row_ok ? gy : 0) * w + b.x0) * C8);
+    const float* __restrict__ g = srcv + ((ptrdiff_t)(row_ok ? gy : 0) * w + b.x0) * cs;
     float4* lo = dst + row * b.bw;
     float4* hi = dst + CAP + row * b.bw;
     for (int i = lane; i < n4; i += 64) {
       const bool ok = row_ok && (unsigned)(b.x0 + (i >> 1)) < (unsigned)w;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (ok) v = g[i];
+      if (ok) v = *reinterpret_cast<const float4*>(g + (ptrdiff_t)(i >> 1) * cs + (i & 1) * 4);
       ((i & 1) ? hi : lo)[i >> 1] = v;
     }
   }
@@ -259,8 +259,8 @@ struct Tex8 {
 // with per-tap image tests.  Returns the weights to use (zeroed for out-of-image taps on the slow path).
 template <int CAP>
 __device__ __forceinline__ void fetch_cell(float x0f, float y0f, const Geo& g, const Box& b,
-                                           const cds_f4* __restrict__ lds, const float* __restrict__ srcv, Tex8 t[4],
-                                           float wgt[4]) {
+                                           const cds_f4* __restrict__ lds, const float* __restrict__ srcv, int cs,
+                                           Tex8 t[4], float wgt[4]) {
   const int x0 = clamp_m2((int)x0f, g.w);  // v_cvt_i32_f32 saturates, NaN -> 0 (NaN weights then propagate)
   const int y0 = clamp_m2((int)y0f, g.h);
   const unsigned ux = (unsigned)(x0 - b.x0), uy = (unsigned)(y0 - b.y0);
@@ -284,10 +284,10 @@ __device__ __forceinline__ void fetch_cell(float x0f, float y0f, const Geo& g, c
     const int xa = min(max(x0, 0), g.w - 1), xb = min(max(x0 + 1, 0), g.w - 1);
     const int ya = min(max(y0, 0), g.h - 1), yb = min(max(y0 + 1, 0), g.h - 1);
     const cds_f4* p;
-    p = reinterpret_cast<const cds_f4*>(srcv + ((size_t)ya * g.w + xa) * C8); t[0].lo = p[0]; t[0].hi = p[1];
-    p = reinterpret_cast<const cds_f4*>(srcv + ((size_t)ya * g.w + xb) * C8); t[1].lo = p[0]; t[1].hi = p[1];
-    p = reinterpret_cast<const cds_f4*>(srcv + ((size_t)yb * g.w + xa) * C8); t[2].lo = p[0]; t[2].hi = p[1];
-    p = reinterpret_cast<const cds_f4*>(srcv + ((size_t)yb * g.w + xb) * C8); t[3].lo = p[0]; t[3].hi = p[1];
+    p = reinterpret_cast<const cds_f4*>(srcv + ((size_t)ya * g.w + xa) * cs); t[0].lo = p[0]; t[0].hi = p[1];
+    p = reinterpret_cast<const cds_f4*>(srcv + ((size_t)ya * g.w + xb) * cs); t[1].lo = p[0]; t[1].hi = p[1];
+    p = reinterpret_cast<const cds_f4*>(srcv + ((size_t)yb * g.w + xa) * cs); t[2].lo = p[0]; t[2].hi = p[1];
+    p = reinterpret_cast<const cds_f4*>(srcv + ((size_t)yb * g.w + xb) * cs); t[3].lo = p[0]; t[3].hi = p[1];
   }
 }
 
@@ -355,15 +355,20 @@ __device__ __forceinline__ void plane_weights(v2f ix, v2f iy, v2f& x0f, v2f& y0f
 template <int VMAX, bool ACCUMULATE, bool NORMALIZE>
 __global__ __launch_bounds__(256, CDS_K3_MINW) void warp_aggregate_lds_kernel(
     const float* __restrict__ ref, const float* __restrict__ src, const float* __restrict__ vis, WarpMats mats,
-    const float* __restrict__ hyp, float* __restrict__ volume, const float* __restrict__ vis_sum, int V, int D, int h,
+    const float* __restrict__ hyp, float* __restrict__ volume, const float* __restrict__ vis_sum, int C, int D, int h,
     int w, float rhw, float rhh, int flags, int tiles_x, int ntiles, int nseg, int seg_planes) {
   extern __shared__ __attribute__((aligned(16))) cds_f4 lds4[];  // VMAX * 2*BOX_CAP float4, then int red[4*VMAX*4], int boxes[VMAX*4]
   int* red = reinterpret_cast<int*>(lds4 + VMAX * 2 * BOX_CAP);
 
   // depth segment is the fastest-varying index: the nseg blocks of a tile run together and share its features in L2
-  const int lin = cds_xcd_remap(blockIdx.x, ntiles * nseg);
+  // then the group of 8 channels (C = 16 / 32: one workgroup per group; the groups of a tile run together, so the
+  // 64 / 128-byte texels they share are fetched from HBM once)
+  const int ngroups = C >> 3;
+  int lin = cds_xcd_remap(blockIdx.x, ntiles * ngroups * nseg);
   const int seg = lin % nseg;
-  const int tile = lin / nseg;
+  lin /= nseg;
+  const int c_off = (lin % ngroups) * C8;
+  const int tile = lin / ngroups;
   const int tx = tile % tiles_x, ty = tile / tiles_x;
   const int x = tx * TW + (threadIdx.x % TW);
   const int y = ty * TH + (threadIdx.x / TW);
@@ -376,6 +381,9 @@ __global__ __launch_bounds__(256, CDS_K3_MINW) void warp_aggregate_lds_kernel(
   const unsigned hw = (unsigned)h * (unsigned)w;
   const unsigned pix = (unsigned)yc * (unsigned)w + (unsigned)xc;
   const size_t slab = (size_t)D * hw;  // elements per channel of the volume
+  ref += (size_t)c_off * hw;
+  src += c_off;
+  volume += (size_t)c_off * slab;
 
   v2f rv[VMAX][4];  // (ref * vis) per channel pair
   float r[VMAX][3];
@@ -385,8 +393,8 @@ __global__ __launch_bounds__(256, CDS_K3_MINW) void warp_aggregate_lds_kernel(
       const float vw = vis[(size_t)v * hw + pix];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        rv[v][j].x = ref[((size_t)v * C8 + 2 * j) * hw + pix] * vw;
-        rv[v][j].y = ref[((size_t)v * C8 + 2 * j + 1) * hw + pix] * vw;
+        rv[v][j].x = ref[((size_t)v * C + 2 * j) * hw + pix] * vw;
+        rv[v][j].y = ref[((size_t)v * C + 2 * j + 1) * hw + pix] * vw;
       }
       cds_row_terms(mats.m[v], (float)xc, (float)yc, r[v]);
     }
@@ -430,7 +438,7 @@ __global__ __launch_bounds__(256, CDS_K3_MINW) void warp_aggregate_lds_kernel(
     }
 #pragma unroll
     for (int v = 0; v < VMAX; ++v)
-      stage_box<BOX_CAP>(src + (size_t)v * hw * C8, h, w, box[v], reinterpret_cast<float4*>(lds4 + v * 2 * BOX_CAP));
+      stage_box<BOX_CAP>(src + (size_t)v * hw * C, C, h, w, box[v], reinterpret_cast<float4*>(lds4 + v * 2 * BOX_CAP));
     __syncthreads();
     bool all_staged = true;
     FastBox fb[VMAX];
@@ -516,7 +524,7 @@ __global__ __launch_bounds__(256, CDS_K3_MINW) void warp_aggregate_lds_kernel(
         const v2f dvg = {dgx, dgy};
 #pragma unroll
         for (int v = 0; v < VMAX; ++v) {
-          const float* __restrict__ srcv = src + (size_t)v * hw * C8;
+          const float* __restrict__ srcv = src + (size_t)v * hw * C;
           const cds_f4* lv = lds4 + v * 2 * BOX_CAP;
           const Box bg = load_box(boxmem + v * 4);
           v2f ix, iy, x0f, y0f, wt[4];
@@ -526,7 +534,7 @@ __global__ __launch_bounds__(256, CDS_K3_MINW) void warp_aggregate_lds_kernel(
           for (int k = 0; k < 2; ++k) {
             float wgt[4] = {k ? wt[0].y : wt[0].x, k ? wt[1].y : wt[1].x, k ? wt[2].y : wt[2].x, k ? wt[3].y : wt[3].x};
             Tex8 t[4];
-            fetch_cell<BOX_CAP>(k ? x0f.y : x0f.x, k ? y0f.y : y0f.x, g, bg, lv, srcv, t, wgt);
+            fetch_cell<BOX_CAP>(k ? x0f.y : x0f.x, k ? y0f.y : y0f.x, g, bg, lv, srcv, C, t, wgt);
             v2f o[4];
             interp8(t, wgt, o);
 #pragma unroll
@@ -587,13 +595,16 @@ __device__ __forceinline__ void online_entropy_update(float s, float& mx, float&
 #ifndef CDS_K1_MINW
 #define CDS_K1_MINW 4   // 4 waves per SIMD (32.6 KB of LDS per workgroup allows it): 0.82 -> 0.79 ms at M1
 #endif
-__global__ __launch_bounds__(256, CDS_K1_MINW) void warp_entropy_lds_kernel(const float* __restrict__ ref,
-                                                               const float* __restrict__ src, WarpMats mats,
-                                                               const float* __restrict__ hyp,
-                                                               float* __restrict__ entropy, int V, int D, int h, int w,
-                                                               float rhw, float rhh, int tiles_x, int ntiles) {
+// NG = groups of 8 channels (C = 8 NG); the box of a view holds all of them: 2 NG planes of CAP float4.
+// C = 8: CAP 1016 texels, 64-plane chunks (32 KB);  C = 16: 504 texels, 32 planes (32 KB);  C = 32: 504 texels,
+// 32 planes (63 KB, two workgroups per CU).  A box that does not fit halves its chunk, as in K3.
+template <int NG, int CAP, int DCK>
+__global__ __launch_bounds__(256, (NG == 4 ? 2 : CDS_K1_MINW)) void warp_entropy_lds_kernel(
+    const float* __restrict__ ref, const float* __restrict__ src, WarpMats mats, const float* __restrict__ hyp,
+    float* __restrict__ entropy, int V, int D, int h, int w, float rhw, float rhh, int tiles_x, int ntiles) {
+  constexpr int C = NG * C8;
   extern __shared__ __attribute__((aligned(16))) cds_f4 lds4[];
-  int* red = reinterpret_cast<int*>(lds4 + 2 * BOX1);
+  int* red = reinterpret_cast<int*>(lds4 + 2 * NG * CAP);
   const int lin = cds_xcd_remap(blockIdx.x, ntiles * V);
   const int v = lin % V;
   const int tile = lin / V;
@@ -608,32 +619,39 @@ __global__ __launch_bounds__(256, CDS_K1_MINW) void warp_entropy_lds_kernel(cons
   g.rhw = rhw; g.rhh = rhh;
   const unsigned hw = (unsigned)h * (unsigned)w;
   const unsigned pix = (unsigned)yc * (unsigned)w + (unsigned)xc;
-  const float* __restrict__ srcv = src + (size_t)v * hw * C8;
+  const float* __restrict__ srcv = src + (size_t)v * hw * C;
   float m[12];
 #pragma unroll
   for (int i = 0; i < 12; ++i) m[i] = mats.m[v][i];
-  v2f rf[4];
+  v2f rf[NG][4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    rf[j].x = ref[((size_t)v * C8 + 2 * j) * hw + pix];
-    rf[j].y = ref[((size_t)v * C8 + 2 * j + 1) * hw + pix];
-  }
+  for (int q = 0; q < NG; ++q)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      rf[q][j].x = ref[((size_t)v * C + q * C8 + 2 * j) * hw + pix];
+      rf[q][j].y = ref[((size_t)v * C + q * C8 + 2 * j + 1) * hw + pix];
+    }
   float r[3];
   cds_row_terms(m, (float)xc, (float)yc, r);
   const char* hyp_b = reinterpret_cast<const char*>(hyp);
   const float wf = (float)w, hf = (float)h;
   float mx = -INFINITY, Z = 0.f, T = 0.f;
-  for (int d0 = 0; d0 < D; d0 += DC1) {
-    const int d1 = min(D, d0 + DC1);
-    int cx0[1], cy0[1], cx1[1], cy1[1];
-    float dlo, dhi;
-    chunk_depth_range(hyp, hw, pix, d0, d1, dlo, dhi);
-    cell_of(r, m + 9, dlo, h, w, g.half_w, g.half_h, cx0[0], cy0[0]);
-    cell_of(r, m + 9, dhi, h, w, g.half_w, g.half_h, cx1[0], cy1[0]);
+  for (int d0 = 0, d1 = 0; d0 < D; d0 = d1) {
+    d1 = min(D, d0 + DCK);
     Box box[1];
-    __syncthreads();
-    reduce_boxes<1, BOX1>(cx0, cy0, cx1, cy1, active, 1, h, w, red, box);
-    stage_box<BOX1>(srcv, h, w, box[0], reinterpret_cast<float4*>(lds4));
+    for (;;) {
+      int cx0[1], cy0[1], cx1[1], cy1[1];
+      float dlo, dhi;
+      chunk_depth_range(hyp, hw, pix, d0, d1, dlo, dhi);
+      cell_of(r, m + 9, dlo, h, w, g.half_w, g.half_h, cx0[0], cy0[0]);
+      cell_of(r, m + 9, dhi, h, w, g.half_w, g.half_h, cx1[0], cy1[0]);
+      __syncthreads();
+      reduce_boxes<1, CAP>(cx0, cy0, cx1, cy1, active, 1, h, w, red, box);
+      if (box[0].staged || d1 - d0 <= 8) break;
+      d1 = d0 + ((((d1 - d0) >> 1) + 1) & ~1);  // even length: plane pairs stay whole
+    }
+#pragma unroll
+    for (int q = 0; q < NG; ++q) stage_box<CAP>(srcv + q * C8, C, h, w, box[0], reinterpret_cast<float4*>(lds4 + q * 2 * CAP));
     __syncthreads();
     const FastBox fb = fast_box(box[0], h, w);
     const bool staged = box[0].staged;
@@ -652,39 +670,59 @@ __global__ __launch_bounds__(256, CDS_K1_MINW) void warp_entropy_lds_kernel(cons
       positions2(r, m + 9, dv, g, ix, iy);
       plane_weights(ix, iy, x0f, y0f, wt);
       float sim[2];
-      // sum_C ref*warp, channel order 0..7 (ATen's sequential outer-dim sum for C <= 16)
-      auto correlate = [&](const Tex8 t[4], const float wgt[4]) {
+      // sum_C ref*warp in ATen's outer-dim order: sequential inside 16-channel levels, level sums added in order
+      // (C <= 16: plainly sequential).  `part` runs over the two groups of a level.
+      auto correlate = [&](const Tex8 t[4], const float wgt[4], int q, float part) {
         v2f o[4];
         interp8(t, wgt, o);
-        float sacc = 0.f;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const v2f p = rf[j] * o[j];
-          sacc = sacc + p.x;
-          sacc = sacc + p.y;
+          const v2f p = rf[q][j] * o[j];
+          part = part + p.x;
+          part = part + p.y;
         }
-        return sacc;
+        return part;
       };
       bool ok = staged;
       if (staged) {  // block-uniform
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
           const float wgt[4] = {k ? wt[0].y : wt[0].x, k ? wt[1].y : wt[1].x, k ? wt[2].y : wt[2].x, k ? wt[3].y : wt[3].x};
-          Tex8 t[4];
           const cds_f4 *q0, *q1;
-          ok &= cell_addr_fast<BOX1>(k ? x0f.y : x0f.x, k ? y0f.y : y0f.x, wf, hf, fb, lds4, q0, q1);
-          load_cell<BOX1>(q0, q1, t);
-          sim[k] = correlate(t, wgt);
+          ok &= cell_addr_fast<CAP>(k ? x0f.y : x0f.x, k ? y0f.y : y0f.x, wf, hf, fb, lds4, q0, q1);
+          float s = 0.f, part = 0.f;
+#pragma unroll
+          for (int q = 0; q < NG; ++q) {
+            Tex8 t[4];
+            load_cell<CAP>(q0 + q * 2 * CAP, q1 + q * 2 * CAP, t);
+            part = correlate(t, wgt, q, part);
+            if ((q & 1) || q == NG - 1) {
+              s = s + part;
+              part = 0.f;
+            }
+            if (NG > 1) __builtin_amdgcn_sched_barrier(0);  // one group's texels live at a time
+          }
+          sim[k] = s;
         }
       }
       if (__builtin_expect(__builtin_amdgcn_ballot_w64(!ok) != 0, 0)) {  // wave-uniform: redo the pair, any geometry
         const Box bg = load_box(red + 4 * 4);
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-          float wgt[4] = {k ? wt[0].y : wt[0].x, k ? wt[1].y : wt[1].x, k ? wt[2].y : wt[2].x, k ? wt[3].y : wt[3].x};
-          Tex8 t[4];
-          fetch_cell<BOX1>(k ? x0f.y : x0f.x, k ? y0f.y : y0f.x, g, bg, lds4, srcv, t, wgt);
-          sim[k] = correlate(t, wgt);
+          float s = 0.f, part = 0.f;
+#pragma unroll
+          for (int q = 0; q < NG; ++q) {
+            float wgt[4] = {k ? wt[0].y : wt[0].x, k ? wt[1].y : wt[1].x, k ? wt[2].y : wt[2].x, k ? wt[3].y : wt[3].x};
+            Tex8 t[4];
+            fetch_cell<CAP>(k ? x0f.y : x0f.x, k ? y0f.y : y0f.x, g, bg, lds4 + q * 2 * CAP, srcv + q * C8, C, t, wgt);
+            part = correlate(t, wgt, q, part);
+            if ((q & 1) || q == NG - 1) {
+              s = s + part;
+              part = 0.f;
+            }
+            if (NG > 1) __builtin_amdgcn_sched_barrier(0);  // one group's texels live at a time
+          }
+          sim[k] = s;
         }
       }
       online_entropy_update(sim[0], mx, Z, T);
@@ -700,23 +738,40 @@ __global__ __launch_bounds__(256, CDS_K1_MINW) void warp_entropy_lds_kernel(cons
 bool cds_warp_aggregate_lds_launch(const float* ref, const float* src, const float* vis, const WarpMats& wm,
                                    const float* hyp, float* volume, const float* vis_sum, int V, int C, int D, int h,
                                    int w, int hyp_pp, int flags, hipStream_t st) {
-  if (C != 8 || V < 1 || V > 4 || !hyp_pp || w < 2 || h < 2 || (size_t)D * h * w * 4 >= ((size_t)1 << 32)) return false;
+  if ((C != 8 && C != 16 && C != 32) || V < 1 || V > CDS_MAX_VIEWS || !hyp_pp || w < 2 || h < 2 ||
+      (size_t)D * h * w * 4 >= ((size_t)1 << 32))
+    return false;
+  if (V > 4) {
+    // more views than fit the LDS budget: two launches over halves of the view list; the second adds to the first's
+    // partial sums (and normalises).  Costs one extra read of the volume, still far cheaper than L1 gathers.
+    const int v1 = (V + 1) / 2;
+    const size_t hw = (size_t)h * w;
+    WarpMats wm2;
+    for (int v = 0; v < CDS_MAX_VIEWS; ++v)
+      for (int i = 0; i < 12; ++i) wm2.m[v][i] = (v + v1 < CDS_MAX_VIEWS) ? wm.m[v + v1][i] : 0.f;
+    return cds_warp_aggregate_lds_launch(ref, src, vis, wm, hyp, volume, vis_sum, v1, C, D, h, w, hyp_pp,
+                                         flags & CDS_AGG_ACCUMULATE, st) &&
+           cds_warp_aggregate_lds_launch(ref + (size_t)v1 * C * hw, src + (size_t)v1 * hw * C, vis + (size_t)v1 * hw, wm2,
+                                         hyp, volume, vis_sum, V - v1, C, D, h, w, hyp_pp,
+                                         CDS_AGG_ACCUMULATE | (flags & CDS_AGG_NORMALIZE), st);
+  }
   const int tiles_x = cds_ceil_div(w, TW), tiles_y = cds_ceil_div(h, TH);
   const int ntiles = tiles_x * tiles_y;
+  const int ngroups = C / C8;
   const float rhw = (float)(1.0 / (double)(float)((w - 1) / 2.0)), rhh = (float)(1.0 / (double)(float)((h - 1) / 2.0));
   // Depth segments: enough workgroups for ~10 waves per SIMD (2 are resident), each a whole number of DC chunks.
   const int chunks = cds_ceil_div(D, DC);
   int nseg = 1;
-  while (nseg < chunks && (size_t)ntiles * nseg * 4 < (size_t)10 * 1024) nseg *= 2;
+  while (nseg < chunks && (size_t)ntiles * ngroups * nseg * 4 < (size_t)10 * 1024) nseg *= 2;
   if (nseg > chunks) nseg = chunks;
   if (const char* e = getenv("CDS_K3_NSEG")) nseg = atoi(e) > 0 ? (atoi(e) < chunks ? atoi(e) : chunks) : nseg;  // tuning knob
   const int seg_planes = cds_ceil_div(chunks, nseg) * DC;
   nseg = cds_ceil_div(D, seg_planes);
   const bool acc_f = flags & CDS_AGG_ACCUMULATE, nrm_f = flags & CDS_AGG_NORMALIZE;
 #define LAUNCH3(VM, A, N)                                                                                              \
-  hipLaunchKernelGGL((warp_aggregate_lds_kernel<VM, A, N>), dim3(ntiles * nseg), dim3(256),                            \
+  hipLaunchKernelGGL((warp_aggregate_lds_kernel<VM, A, N>), dim3(ntiles * ngroups * nseg), dim3(256),                  \
                      (size_t)VM * 2 * BOX_CAP * sizeof(float4) + 5 * VM * 4 * sizeof(int), st, ref, src, vis, wm, hyp, \
-                     volume, vis_sum, V, D, h, w, rhw, rhh, flags, tiles_x, ntiles, nseg, seg_planes)
+                     volume, vis_sum, C, D, h, w, rhw, rhh, flags, tiles_x, ntiles, nseg, seg_planes)
 #define LAUNCH(VM)                                 \
   do {                                             \
     if (acc_f && nrm_f) LAUNCH3(VM, true, true);   \
@@ -737,12 +792,17 @@ bool cds_warp_aggregate_lds_launch(const float* ref, const float* src, const flo
 
 bool cds_warp_entropy_lds_launch(const float* ref, const float* src, const WarpMats& wm, const float* hyp,
                                  float* entropy, int V, int C, int D, int h, int w, int hyp_pp, hipStream_t st) {
-  if (C != 8 || !hyp_pp || w < 2 || h < 2 || (size_t)D * h * w * 4 >= ((size_t)1 << 32)) return false;
+  if ((C != 8 && C != 16 && C != 32) || !hyp_pp || w < 2 || h < 2 || (size_t)D * h * w * 4 >= ((size_t)1 << 32)) return false;
   const int tiles_x = cds_ceil_div(w, TW), tiles_y = cds_ceil_div(h, TH);
   const int ntiles = tiles_x * tiles_y;
   const float rhw = (float)(1.0 / (double)(float)((w - 1) / 2.0)), rhh = (float)(1.0 / (double)(float)((h - 1) / 2.0));
-  hipLaunchKernelGGL(warp_entropy_lds_kernel, dim3(ntiles * V), dim3(256),
-                     (size_t)2 * BOX1 * sizeof(float4) + 5 * 4 * sizeof(int), st, ref, src, wm, hyp, entropy, V, D, h,
-                     w, rhw, rhh, tiles_x, ntiles);
+#define LAUNCH1(NG, CAP, DCK)                                                                                      \
+  hipLaunchKernelGGL((warp_entropy_lds_kernel<NG, CAP, DCK>), dim3(ntiles * V), dim3(256),                         \
+                     (size_t)2 * NG * CAP * sizeof(float4) + 5 * 4 * sizeof(int), st, ref, src, wm, hyp, entropy, V, D, \
+                     h, w, rhw, rhh, tiles_x, ntiles)
+  if (C == 8) LAUNCH1(1, BOX1, DC1);
+  else if (C == 16) LAUNCH1(2, BOX_CAP, DC);
+  else LAUNCH1(4, BOX_CAP, DC);
+#undef LAUNCH1
   return true;
 }

@@ -1,4 +1,4 @@
-"""One-off fuzz of the LDS K1/K3 kernels (C = 8, V = 1..4) against the CPU oracle on random shapes / cameras."""
+"""Fuzz of the LDS K1/K3 kernels (C = 8/16/32, V = 1..6) against the CPU oracle on random shapes / cameras."""
 import os, sys, random
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -7,10 +7,10 @@ from oracle import cds_oracle as O
 
 
 def one_case(rng, dev, verbose=True):
-    V = rng.randint(1, 4); D = rng.choice([1, 2, 3, 9, 31, 32, 33, 48, 65]); h = rng.randint(2, 40); w = rng.randint(2, 200)
+    V = rng.choice([1, 2, 3, 4, 4, 5, 6]); C = rng.choice([8, 8, 16, 32]); D = rng.choice([1, 2, 3, 9, 31, 32, 33, 48, 65]); h = rng.randint(2, 40); w = rng.randint(2, 200)
     seed = rng.randint(0, 10_000)
     base = rng.choice([(40.0, 15.0, 10.0), (200.0, 60.0, 20.0), (5.0, 2.0, 1.0)])
-    feats = synth.make_pair_features(V, 8, h, w, seed=seed, sharp=True)
+    feats = synth.make_pair_features(V, C, h, w, seed=seed, sharp=True)
     cams = synth.make_cameras(V + 1, h, w, refine=False, seed=seed, baseline=base)["stage3"]
     jit = rng.choice([0.0, 3.0, 30.0])
     hyp = synth.make_hypotheses(D, h, w, lo=rng.choice([200.0, 425.0]), hi=rng.choice([500.0, 902.5]), jitter=jit, seed=seed)
@@ -21,7 +21,7 @@ def one_case(rng, dev, verbose=True):
     ent = ops.warp_entropy(ref, src, mats, hyp_d).cpu()
     vol, _ = ops.warp_aggregate(ref, src, vis.to(dev), mats, hyp_d, normalize=True)
     P_ref = O.compose_projection(cams[:, 0])
-    want = torch.zeros(8, D, h, w); e_max = 0.0
+    want = torch.zeros(C, D, h, w); e_max = 0.0
     for v in range(V):
         warped = O.warp_volume(feats[v]["src"][0], O.compose_projection(cams[:, v + 1]), P_ref, hyp)
         in_prod, e = O.correlation_entropy(feats[v]["ref"][0], warped)
@@ -31,7 +31,7 @@ def one_case(rng, dev, verbose=True):
     err = float((vol.cpu() - want).abs().max())
     if verbose:
         flag = "" if (err < 2e-5 and e_max < 5e-5) else "  <-- FAIL"
-        print(f"V={V} D={D:3d} h={h:3d} w={w:3d} base={base[0]:5.0f} jitter={jit:4.0f}: vol {err:.2e} ent {e_max:.2e}{flag}")
+        print(f"V={V} C={C:2d} D={D:3d} h={h:3d} w={w:3d} base={base[0]:5.0f} jitter={jit:4.0f}: vol {err:.2e} ent {e_max:.2e}{flag}")
     return err, e_max
 
 
