@@ -196,6 +196,93 @@ int launch_conv2d(const float* x, const float* aff, const float* w, const float*
 }
 
 // ---------------------------------------------------------------------------------------------
+// FPN lateral (module.py:253-254,260-261): 1x1 convolution over cat(nearest2x(coarse), skip) without building either
+// the up-sampled tensor or the concatenation.  coarse [N][Ca][H/2][W/2], skip [N][Cb][H][W], weights packed
+// [Ca + Cb][CoutP]; each source has its own optional normalise-on-load table.  Channel order and fp32 operation
+// order are those of conv2d_kernel<1,...> run on the materialised concatenation (bit-identical results).
+// ---------------------------------------------------------------------------------------------
+template <int NCB>
+__global__ __launch_bounds__(256) void fpn_lateral_kernel(const float* __restrict__ xa, const float* __restrict__ affa,
+                                                          const float* __restrict__ xb, const float* __restrict__ affb,
+                                                          const float* __restrict__ wpk, float* __restrict__ out, int N,
+                                                          int Ca, int Cb, int Cout, int CoutP, int H, int W, int tiles_x,
+                                                          int tiles_y) {
+  constexpr int PX = 4, LX = 16, CW = CO * NCB;
+  const int co_groups = CoutP / CW;
+  const int ntiles = tiles_x * tiles_y;
+  int lin = cds_xcd_remap(blockIdx.x, ntiles * co_groups * N);
+  const int cog = lin % co_groups;
+  lin /= co_groups;
+  const int tile = lin % ntiles;
+  const int n = lin / ntiles;
+  const int co0 = cog * CW;
+  const int lx = threadIdx.x % LX, ly = threadIdx.x / LX;
+  const int oy = (tile / tiles_x) * 16 + ly, ox = ((tile % tiles_x) * LX + lx) * PX;
+  if (oy >= H || ox >= W) return;
+  const int Hc = H >> 1, Wc = W >> 1;
+  const size_t plane = (size_t)H * W, cplane = (size_t)Hc * Wc;
+  float acc[PX][CW];
+#pragma unroll
+  for (int p = 0; p < PX; ++p)
+#pragma unroll
+    for (int c = 0; c < CW; ++c) acc[p][c] = 0.f;
+
+  auto mac = [&](const float in[PX], int ci) {
+    const float* __restrict__ wc = wpk + __builtin_amdgcn_readfirstlane(ci * CoutP + co0);
+#pragma unroll
+    for (int c = 0; c < CW; ++c) {
+      const float wv = wc[c];
+#pragma unroll
+      for (int p = 0; p < PX; ++p) acc[p][c] = fmaf(in[p], wv, acc[p][c]);
+    }
+  };
+  // coarse source: output pixels ox..ox+3 (ox % 4 == 0) read the two coarse pixels ox/2, ox/2 + 1 of row oy/2
+  {
+    const float* __restrict__ src = xa + (size_t)n * Ca * cplane + (size_t)(oy >> 1) * Wc + (ox >> 1);
+    const float* __restrict__ aff = affa ? affa + (size_t)n * Ca * 3 : nullptr;
+    const bool second = (ox >> 1) + 1 < Wc;
+    for (int ci = 0; ci < Ca; ++ci, src += cplane) {
+      float v0 = src[0], v1 = second ? src[1] : 0.f;
+      if (aff) {
+        const float al = aff[3 * ci], be = aff[3 * ci + 1], sl = aff[3 * ci + 2];
+        const float t0 = v0 * al + be, t1 = v1 * al + be;
+        v0 = t0 > 0.f ? t0 : t0 * sl;
+        v1 = t1 > 0.f ? t1 : t1 * sl;
+      }
+      const float in[PX] = {v0, v0, v1, v1};
+      mac(in, ci);
+    }
+  }
+  {
+    const float* __restrict__ src = xb + (size_t)n * Cb * plane + (size_t)oy * W + ox;
+    const float* __restrict__ aff = affb ? affb + (size_t)n * Cb * 3 : nullptr;
+    for (int ci = 0; ci < Cb; ++ci, src += plane) {
+      float in[PX];
+#pragma unroll
+      for (int p = 0; p < PX; ++p) in[p] = (ox + p < W) ? src[p] : 0.f;
+      if (aff) {
+        const float al = aff[3 * ci], be = aff[3 * ci + 1], sl = aff[3 * ci + 2];
+#pragma unroll
+        for (int p = 0; p < PX; ++p) {
+          const float t = in[p] * al + be;
+          in[p] = t > 0.f ? t : t * sl;
+        }
+      }
+      mac(in, Ca + ci);
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < CW; ++c) {
+    if (co0 + c < Cout) {
+      float* o = out + ((size_t)n * Cout + co0 + c) * plane + (size_t)oy * W + ox;
+#pragma unroll
+      for (int p = 0; p < PX; ++p)
+        if (ox + p < W) o[p] = acc[p][c];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // DynamicConv epilogue.  `branch` holds, for each kernel size k, the Cout conv responses followed
 // by the 3 curvature responses: [K][Cout+3][H][W].
 // ---------------------------------------------------------------------------------------------
@@ -409,6 +496,23 @@ extern "C" int cds_conv2d_affine_f32(const float* x, const float* in_affine, con
   }
   if (stride == 2 && k == 3) return launch_conv2d<3, 2, 4>(x, a, weight, bias, out, N, Cin, Cout, H, W, pad, act, st);
   return CDS_EINVAL;
+}
+
+extern "C" int cds_conv2d_fpn_f32(const float* coarse, const float* coarse_affine, const float* skip,
+                                  const float* skip_affine, const float* weight, float* out, int N, int Ca, int Cb,
+                                  int Cout, int H, int W, void* stream) {
+  if (!coarse || !skip || !weight || !out || N < 1 || Ca < 1 || Cb < 1 || Cout < 1 || H < 2 || W < 2 || (H & 1) || (W & 1))
+    return CDS_EINVAL;
+  const int CoutP = (Cout + CO - 1) / CO * CO;
+  const int tx = cds_ceil_div(W, 64), ty = cds_ceil_div(H, 16);
+  hipStream_t st = (hipStream_t)stream;
+  if ((CoutP / CO) % 2 == 0)
+    hipLaunchKernelGGL(fpn_lateral_kernel<2>, dim3(tx * ty * (CoutP / 16) * N), dim3(256), 0, st, coarse, coarse_affine, skip,
+                       skip_affine, weight, out, N, Ca, Cb, Cout, CoutP, H, W, tx, ty);
+  else
+    hipLaunchKernelGGL(fpn_lateral_kernel<1>, dim3(tx * ty * (CoutP / 8) * N), dim3(256), 0, st, coarse, coarse_affine, skip,
+                       skip_affine, weight, out, N, Ca, Cb, Cout, CoutP, H, W, tx, ty);
+  return cds_launch_status();
 }
 
 extern "C" int cds_conv2d_f32(const float* x, const float* weight, const float* bias, float* out, int N, int Cin,

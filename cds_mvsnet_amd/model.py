@@ -371,10 +371,11 @@ class _FeatureRunner:
         y = ops.conv2d(x, p[f"{name}.w"], None, unit.conv.out_channels, k, unit.stride, unit.padding, in_affine=aff)
         return y, ops.instnorm_affine(y, 0.1)
 
-    @staticmethod
-    def _identity_affine(N: int, C: int, device) -> Tensor:
-        """(1, 0, 1) rows: a materialised tensor inside a lazily normalised concatenation."""
-        return torch.tensor([1.0, 0.0, 1.0], dtype=torch.float32, device=device).expand(N, C, 3).contiguous()
+    def _lateral_unit(self, p, name, coarse, a_coarse, skip, a_skip):
+        """FPN lateral: ConvUnit 1x1 over cat(nearest2x(coarse), skip), neither of which is materialised."""
+        unit: ConvUnit = getattr(self.net, name)
+        y = ops.conv2d_fpn(coarse, skip, p[f"{name}.w"], unit.conv.out_channels, a_coarse, a_skip)
+        return y, ops.instnorm_affine(y, 0.1)
 
     @staticmethod
     def _final(o: Tensor, n_chw: int) -> Tuple[Tensor, Optional[Tensor]]:
@@ -416,24 +417,16 @@ class _FeatureRunner:
         out["stage1"] = self._final(o1, n_chw) + ops.curvature_stats(n20, n21, n22)
 
         # FPN: nearest-neighbour up-sampling and concatenation move raw values; the affine tables concatenate alike
-        x = torch.cat((_nearest2x(c21), c11), dim=1)
-        x, ax = self._plain_unit(p, "inner1", x, torch.cat((a21, a11), dim=1))
+        x, ax = self._lateral_unit(p, "inner1", c21, a21, c11, a11)
         o2, n12 = self._dynamic(p, "out2", net.out2, x, e1, T, aff=ax)
         o2n = ops.instnorm_act(o2, ACT_TANH)
         hwc2 = torch.stack([ops.chw_to_hwc(o2n[i]) for i in range(n_chw, N)]) if n_chw < N else None
         out["stage2"] = (o2n[:n_chw] if n_chw > 0 else None, hwc2) + ops.curvature_stats(n10, n11, n12)
 
-        x = torch.cat((_nearest2x(o2n), c01), dim=1)                       # o2n is materialised (tanh features)
-        x, ax = self._plain_unit(p, "inner2", x, torch.cat((self._identity_affine(N, o2n.shape[1], x.device), a01), dim=1))
+        x, ax = self._lateral_unit(p, "inner2", o2n, None, c01, a01)      # o2n is materialised (tanh features)
         o3, n02 = self._dynamic(p, "out3", net.out3, x, e0, T, aff=ax)
         out["stage3"] = self._final(o3, n_chw) + ops.curvature_stats(n00, n01, n02)
         return out
-
-
-def _nearest2x(x: Tensor) -> Tensor:
-    """[N,C,h,w] -> [N,C,2h,2w] nearest-neighbour (pure data movement; module.py:253,260)."""
-    N, C, h, w = x.shape
-    return x.view(N, C, h, 1, w, 1).expand(N, C, h, 2, w, 2).reshape(N, C, 2 * h, 2 * w)
 
 
 # ------------------------------------------------------------------------------------------------

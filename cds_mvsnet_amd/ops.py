@@ -310,6 +310,31 @@ def conv2d(x: Tensor, wpk: Tensor, bias: Optional[Tensor], cout: int, k: int, st
     return out
 
 
+def conv2d_fpn(coarse: Tensor, skip: Tensor, wpk: Tensor, cout: int, coarse_affine: Optional[Tensor] = None,
+               skip_affine: Optional[Tensor] = None) -> Tensor:
+    """FPN lateral (module.py:253-254,260-261): 1x1 conv of cat(nearest2x(coarse), skip) without building either.
+    coarse [N,Ca,H/2,W/2], skip [N,Cb,H,W], wpk packed [Ca+Cb,1,CoutP] -> [N,cout,H,W]; the affine tables are the
+    sources' pending InstanceNorm + LeakyReLU (see conv2d)."""
+    N, Ca, hc, wc = coarse.shape
+    Nb, Cb, H, W = skip.shape
+    if Nb != N or H != 2 * hc or W != 2 * wc:
+        raise ValueError(f"conv2d_fpn: skip {tuple(skip.shape)} is not twice coarse {tuple(coarse.shape)}")
+    coutp = (cout + 7) // 8 * 8
+    if tuple(wpk.shape) != (Ca + Cb, 1, coutp):
+        raise ValueError(f"conv2d_fpn: packed weight must be [{Ca + Cb},1,{coutp}], got {tuple(wpk.shape)}")
+    for a, c, nm in ((coarse_affine, Ca, "coarse_affine"), (skip_affine, Cb, "skip_affine")):
+        if a is not None and tuple(a.shape) != (N, c, 3):
+            raise ValueError(f"conv2d_fpn: {nm} must be [{N},{c},3], got {tuple(a.shape)}")
+    out = torch.empty((N, cout, H, W), dtype=torch.float32, device=skip.device)
+    check(_lib.load().cds_conv2d_fpn_f32(_dev(coarse, "coarse"),
+                                         _dev(coarse_affine, "coarse_affine") if coarse_affine is not None else None,
+                                         _dev(skip, "skip"),
+                                         _dev(skip_affine, "skip_affine") if skip_affine is not None else None,
+                                         _dev(wpk, "weight"), _dev(out, "out"), N, Ca, Cb, cout, H, W, _stream(skip)),
+          "cds_conv2d_fpn_f32")
+    return out
+
+
 def instnorm_affine(x: Tensor, slope: float = 0.1) -> Tensor:
     """InstanceNorm statistics of x [N,C,H,W] as (alpha, beta, slope) rows [N,C,3] for a consumer that normalises on
     load (conv2d(in_affine=...)); same statistics and expression as instnorm_act."""

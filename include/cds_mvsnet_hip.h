@@ -172,6 +172,18 @@ int cds_conv2d_affine_f32(const float* x, const float* in_affine, const float* w
                           int N, int Cin, int Cout, int H, int W, int k, int stride, int pad, int act, void* stream);
 
 /*
+ * FPN lateral connection (module.py:253-254, 260-261): the 1x1 convolution of
+ *   cat(interpolate(coarse, scale_factor=2, mode="nearest"), skip)
+ * without materialising the up-sampled tensor or the concatenation.
+ *   coarse [N][Ca][H/2][W/2], skip [N][Cb][H][W] (H, W even), out [N][Cout][H][W]
+ *   weight PACKED [Ca + Cb][CoutP] (coarse channels first, as in the concatenation)
+ *   coarse_affine [N][Ca][3] / skip_affine [N][Cb][3]: normalise-on-load tables like cds_conv2d_affine_f32, or NULL.
+ * Results are bit-identical to cds_conv2d_affine_f32 (k = 1) on the materialised concatenation.
+ */
+int cds_conv2d_fpn_f32(const float* coarse, const float* coarse_affine, const float* skip, const float* skip_affine,
+                       const float* weight, float* out, int N, int Ca, int Cb, int Cout, int H, int W, void* stream);
+
+/*
  * K7 epilogue of DynamicConv (dynamic_conv.py:97-122) for a batch of N images (each with its own epipole):
  * epipolar projection of the K 3-channel curvature responses, 1x1 MLP (K->4, folded BN, ReLU, 4->K),
  * softmax(./temperature), blend.

@@ -669,3 +669,32 @@ def test_warp_kernels_random_shapes_against_oracle(dev, seed):
         vol_err, ent_err = fuzz.one_case(rng, dev, verbose=False)
         assert vol_err < 1e-5, vol_err
         assert ent_err < 2e-5, ent_err
+
+
+@pytest.mark.parametrize("ca,cb,cout,h,w", [(32, 16, 16, 12, 38), (16, 8, 8, 34, 70), (16, 8, 12, 6, 2)])
+def test_fpn_lateral_equals_conv_of_concatenation(dev, ops, ca, cb, cout, h, w):
+    """cds_conv2d_fpn_f32 == the 1x1 convolution of cat(nearest2x(coarse), skip) (module.py:253-254,260-261), with and
+    without pending normalisation tables, bit for bit (same channel and fma order)."""
+    g = torch.Generator().manual_seed(ca * 100 + w)
+    N = 3
+    coarse = torch.randn(N, ca, h, w, generator=g).to(dev)
+    skip = torch.randn(N, cb, 2 * h, 2 * w, generator=g).to(dev)
+    weight = torch.randn(cout, ca + cb, 1, 1, generator=g) * 0.2
+    coutp = (cout + 7) // 8 * 8
+    wpk = torch.zeros(ca + cb, 1, coutp)
+    wpk[:, 0, :cout] = weight[:, :, 0, 0].t()
+    wpk = wpk.to(dev)
+    up = torch.nn.functional.interpolate(coarse, scale_factor=2, mode="nearest")
+    cat = torch.cat((up, skip), dim=1).contiguous()
+    a_c, a_s = ops.instnorm_affine(coarse, 0.1), ops.instnorm_affine(skip, 0.1)
+    ident = torch.tensor([1.0, 0.0, 1.0], device=dev).expand(N, ca, 3)
+    for ac, asx, acat in ((None, None, None), (a_c, a_s, torch.cat((a_c, a_s), 1).contiguous()),
+                          (None, a_s, torch.cat((ident, a_s), 1).contiguous())):
+        want = ops.conv2d(cat, wpk, None, cout, 1, 1, 0, in_affine=acat)
+        got = ops.conv2d_fpn(coarse, skip, wpk, cout, ac, asx)
+        assert torch.equal(got, want), (got - want).abs().max()
+    # and against plain PyTorch
+    ref = torch.nn.functional.conv2d(cat.cpu(), weight)
+    assert (ops.conv2d_fpn(coarse, skip, wpk, cout).cpu() - ref).abs().max() < 1e-4
+    with pytest.raises(ValueError):
+        ops.conv2d_fpn(coarse, skip[:, :, :-1], wpk, cout)
