@@ -32,16 +32,18 @@ struct C2Cfg {
 // 11 / 19 / 35 output channels (2 / 3 / 5 blocks): with one block per workgroup the input tile is staged 2-5 times.
 // K = 1 needs no halo and reads its inputs straight from global memory (the 1x1 convolutions ran at 1/7 of the HBM
 // rate through the LDS path).
-template <int K, int S, int PX, int CI_CHUNK, int NCB>
+// CWE = output channels actually computed (<= 8 NCB): the DynamicConv widths 11 / 19 / 35 are not multiples of 8, and a
+// workgroup that owns all of them skips the 5 zero-padded columns (31 / 21 / 12 % of the multiply-adds).
+template <int K, int S, int PX, int CI_CHUNK, int NCB, int CWE = 8 * NCB>
 __global__ __launch_bounds__(256) void conv2d_kernel(const float* __restrict__ x, const float* __restrict__ in_affine,
                                                      const float* __restrict__ wpk,
                                                      const float* __restrict__ bias, float* __restrict__ out, int N,
                                                      int Cin, int Cout, int CoutP, int H, int W, int Ho, int Wo, int pad,
                                                      int act, int tiles_x, int tiles_y) {
   using Cfg = C2Cfg<K, S, PX, CI_CHUNK>;
-  constexpr int CW = CO * NCB;   // output channels per workgroup
+  constexpr int CW = CWE;        // output channels per workgroup
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int co_groups = CoutP / CW;
+  const int co_groups = CoutP / (CO * NCB);
   const int ntiles = tiles_x * tiles_y;
   int lin = cds_xcd_remap(blockIdx.x, ntiles * co_groups * N);
   const int cog = lin % co_groups;
@@ -49,7 +51,7 @@ __global__ __launch_bounds__(256) void conv2d_kernel(const float* __restrict__ x
   const int tile = lin % ntiles;
   const int n = lin / ntiles;
   const int tx_i = tile % tiles_x, ty_i = tile / tiles_x;
-  const int co0 = cog * CW;
+  const int co0 = cog * (CO * NCB);
   const int tid = threadIdx.x;
   const int lx = tid % Cfg::LX, ly = tid / Cfg::LX;
   const int ox0 = tx_i * Cfg::TX, oy0 = ty_i * Cfg::TY;
@@ -158,7 +160,7 @@ __global__ __launch_bounds__(256) void conv2d_kernel(const float* __restrict__ x
   }
 }
 
-template <int K, int S, int PX, int CI_CHUNK, int NCB>
+template <int K, int S, int PX, int CI_CHUNK, int NCB, int CWE = 8 * NCB>
 int launch_conv2d_n(const float* x, const float* aff, const float* w, const float* b, float* out, int N, int Cin, int Cout,
                     int H, int W, int pad, int act, hipStream_t st) {
   using Cfg = C2Cfg<K, S, PX, CI_CHUNK>;
@@ -167,7 +169,7 @@ int launch_conv2d_n(const float* x, const float* aff, const float* w, const floa
   const int tx = cds_ceil_div(Wo, Cfg::TX), ty = cds_ceil_div(Ho, Cfg::TY);
   const int co_groups = CoutP / (CO * NCB);
   const size_t lds_bytes = (K == 1 && S == 1) ? 0 : (size_t)Cfg::TILE * CI_CHUNK * sizeof(float);
-  auto kern = conv2d_kernel<K, S, PX, CI_CHUNK, NCB>;
+  auto kern = conv2d_kernel<K, S, PX, CI_CHUNK, NCB, CWE>;
   hipLaunchKernelGGL(kern, dim3(tx * ty * co_groups * N), dim3(256), lds_bytes, st, x, aff, w, b, out, N, Cin, Cout, CoutP, H,
                      W, Ho, Wo, pad, act, tx, ty);
   return cds_launch_status();
@@ -183,6 +185,14 @@ int launch_conv2d(const float* x, const float* aff, const float* w, const float*
   constexpr int PXW = (S == 2) ? 2 : 4;
   const bool use_wide = wide != 0;
   if (use_wide) {
+    static const bool exact = []() { const char* e = getenv("CDS_CONV2D_EXACT"); return !(e && e[0] == '0'); }();
+    if (exact && S == 1) {   // DynamicConv branch widths: one workgroup owns every output channel, no padded columns
+      if (Cout == 11) return launch_conv2d_n<K, S, PXW, CI_CHUNK, 2, 11>(x, aff, w, b, out, N, Cin, Cout, H, W, pad, act, st);
+      if constexpr (K <= 5) {
+        if (Cout == 19) return launch_conv2d_n<K, S, 2, CI_CHUNK, 3, 19>(x, aff, w, b, out, N, Cin, Cout, H, W, pad, act, st);
+        if (K <= 3 && Cout == 35) return launch_conv2d_n<K, S, 2, CI_CHUNK, 5, 35>(x, aff, w, b, out, N, Cin, Cout, H, W, pad, act, st);
+      }
+    }
     if (blocks % 2 == 0 && (blocks == 2 || K > 5))
       return launch_conv2d_n<K, S, PXW, CI_CHUNK, 2>(x, aff, w, b, out, N, Cin, Cout, H, W, pad, act, st);
     if constexpr (K <= 5) {
