@@ -44,6 +44,7 @@ SIGNATURES = {
     "cds_conv2d_affine_f32": [P, P, P, P, P, I, I, I, I, I, I, I, I, I, P],
     "cds_instnorm_affine_f32": [P, P, P, I, I, I, I, F, P],
     "cds_conv2d_fpn_f32": [P, P, P, P, P, P, I, I, I, I, I, I, P],
+    "cds_conv2d_k3_c16_f32": [P, P, P, P, P, P, I, I, I, I, P],
     "cds_dynconv_blend_f32": [P, P, P, P, P, F, P, P, I, I, I, I, I, P],
     "cds_dynconv_blend_shared_f32": [P, P, P, P, P, F, P, P, I, I, I, I, I, I, P],
     "cds_instnorm_act_f32": [P, P, P, I, I, I, I, I, I, P],

@@ -444,10 +444,14 @@ class StageNet(nn.Module):
         for s, seq in enumerate(self.vis):
             for i in range(3):
                 scale, shift = _bn_fold(seq[i].bn)
-                out[f"{s}.w{i}"] = _pack2d(seq[i].conv.weight.detach() * scale.view(-1, 1, 1, 1))
+                wf = seq[i].conv.weight.detach() * scale.view(-1, 1, 1, 1)
+                out[f"{s}.w{i}"] = _pack2d(wf)
                 out[f"{s}.b{i}"] = shift.contiguous()
+                if i > 0:    # 16 -> 16: matrix-core layout [tap][cout][cin]
+                    out[f"{s}.wcl{i}"] = wf.permute(2, 3, 0, 1).reshape(9, 16, 16).contiguous()
             out[f"{s}.w3"] = _pack2d(seq[3].weight.detach())
             out[f"{s}.b3"] = seq[3].bias.detach().contiguous()
+            out[f"{s}.hw"] = seq[3].weight.detach().reshape(16).contiguous()
         return out
 
     def visibility(self, entropy: Tensor, ref_nc: Tensor, stage_idx: int) -> Tensor:
@@ -456,7 +460,12 @@ class StageNet(nn.Module):
         s = stage_idx
         with ops.prof("visibility_cnn"):
             x = torch.stack((entropy, ref_nc), dim=1)
-            for i in range(3):
+            x = ops.conv2d(x, p[f"{s}.w0"], p[f"{s}.b0"], 16, 3, 1, 1, ACT_RELU)
+            if ops.conv2d_c16_supported(x):
+                # matrix-core layers; the last one also applies the 1x1 head + sigmoid
+                x = ops.conv2d_k3_c16(x, p[f"{s}.wcl1"], p[f"{s}.b1"], ACT_RELU)
+                return ops.conv2d_k3_c16(x, p[f"{s}.wcl2"], p[f"{s}.b2"], ACT_RELU, head_w=p[f"{s}.hw"], head_b=p[f"{s}.b3"])
+            for i in (1, 2):
                 x = ops.conv2d(x, p[f"{s}.w{i}"], p[f"{s}.b{i}"], 16, 3, 1, 1, ACT_RELU)
             return ops.conv2d(x, p[f"{s}.w3"], p[f"{s}.b3"], 1, 1, 1, 0, ACT_SIGMOID)[:, 0]
 

@@ -310,6 +310,32 @@ def conv2d(x: Tensor, wpk: Tensor, bias: Optional[Tensor], cout: int, k: int, st
     return out
 
 
+USE_CONV2D_MFMA = os.environ.get("CDS_CONV2D_MFMA", "1") != "0"   # A/B knob
+
+
+def conv2d_c16_supported(x: Tensor) -> bool:
+    """Shapes the matrix-core 16 -> 16 3x3 convolution covers (rows must be whole 16-byte groups)."""
+    return USE_CONV2D_MFMA and x.dim() == 4 and x.shape[1] == 16 and x.shape[3] % 4 == 0 and x.shape[3] >= 4
+
+
+def conv2d_k3_c16(x: Tensor, wcl: Tensor, bias: Optional[Tensor], act: int = ACT_RELU, head_w: Optional[Tensor] = None,
+                  head_b: Optional[Tensor] = None) -> Tensor:
+    """3x3, pad 1, 16 -> 16 channels on the matrix cores (visibility CNN, model.py:14).  x [N,16,H,W], wcl [9,16,16]
+    = weight.permute(2,3,0,1) (tap, cout, cin), bias [16].  With head_w [16] / head_b [1] the 1x1 head + sigmoid is
+    applied in the same kernel and the result is [N,H,W]."""
+    N, C, H, W = x.shape
+    if C != 16 or tuple(wcl.shape) != (9, 16, 16) or W % 4:
+        raise ValueError(f"conv2d_k3_c16: need x [N,16,H,W%4==0] and wcl [9,16,16], got {tuple(x.shape)}, {tuple(wcl.shape)}")
+    if (head_w is None) != (head_b is None) or (head_w is not None and (head_w.numel() != 16 or head_b.numel() != 1)):
+        raise ValueError("conv2d_k3_c16: head_w [16] and head_b [1] go together")
+    out = torch.empty((N, H, W) if head_w is not None else (N, 16, H, W), dtype=torch.float32, device=x.device)
+    check(_lib.load().cds_conv2d_k3_c16_f32(_dev(x, "x"), _dev(wcl, "weight_cl"), _dev(bias, "bias") if bias is not None else None,
+                                            _dev(head_w, "head_w") if head_w is not None else None,
+                                            _dev(head_b, "head_b") if head_b is not None else None,
+                                            _dev(out, "out"), N, H, W, act, _stream(x)), "cds_conv2d_k3_c16_f32")
+    return out
+
+
 def conv2d_fpn(coarse: Tensor, skip: Tensor, wpk: Tensor, cout: int, coarse_affine: Optional[Tensor] = None,
                skip_affine: Optional[Tensor] = None) -> Tensor:
     """FPN lateral (module.py:253-254,260-261): 1x1 conv of cat(nearest2x(coarse), skip) without building either.

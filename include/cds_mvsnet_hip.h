@@ -172,6 +172,18 @@ int cds_conv2d_affine_f32(const float* x, const float* in_affine, const float* w
                           int N, int Cin, int Cout, int H, int W, int k, int stride, int pad, int act, void* stream);
 
 /*
+ * 3x3 convolution, padding 1, 16 -> 16 channels, on the matrix cores: the inner ConvBn2d layers of the visibility CNN
+ * (model.py:14, BN folded by the caller).  x [N][16][H][W], W % 4 == 0;
+ *   weight_cl [9][16][16] = (tap ky*3+kx, cout, cin)  — PyTorch's [Cout][Cin][3][3] permuted (2,3,0,1);  bias [16] or NULL;
+ *   act = CDS_ACT_NONE | CDS_ACT_RELU.
+ * head_w / head_b NULL: out [N][16][H][W].  Otherwise (head_w [16], head_b [1], device) the CNN's 1x1 head follows in the
+ * same kernel: out [N][H][W] = sigmoid(head_b + sum_c head_w[c] * act(conv + bias)[c])   (nn.Conv2d(16,1,1) + Sigmoid).
+ * fp32 inputs and accumulation (v_mfma_f32_16x16x4_f32); the summation order differs from cds_conv2d_f32 (~1e-6).
+ */
+int cds_conv2d_k3_c16_f32(const float* x, const float* weight_cl, const float* bias, const float* head_w,
+                          const float* head_b, float* out, int N, int H, int W, int act, void* stream);
+
+/*
  * FPN lateral connection (module.py:253-254, 260-261): the 1x1 convolution of
  *   cat(interpolate(coarse, scale_factor=2, mode="nearest"), skip)
  * without materialising the up-sampled tensor or the concatenation.

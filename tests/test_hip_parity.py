@@ -698,3 +698,27 @@ def test_fpn_lateral_equals_conv_of_concatenation(dev, ops, ca, cb, cout, h, w):
     assert (ops.conv2d_fpn(coarse, skip, wpk, cout).cpu() - ref).abs().max() < 1e-4
     with pytest.raises(ValueError):
         ops.conv2d_fpn(coarse, skip[:, :, :-1], wpk, cout)
+
+
+@pytest.mark.parametrize("N,H,W", [(1, 8, 64), (3, 37, 100), (2, 5, 4), (4, 128, 160)])
+def test_conv2d_c16_mfma_against_torch(dev, ops, N, H, W):
+    """Matrix-core 16 -> 16 3x3 convolution (+ fused 1x1 head) against PyTorch fp32 and the VALU kernel; tolerance 2e-5
+    abs on O(1) outputs (fp32 MFMA accumulation, different summation order)."""
+    g = torch.Generator().manual_seed(N * 1000 + W)
+    x = torch.randn(N, 16, H, W, generator=g)
+    weight = torch.randn(16, 16, 3, 3, generator=g) * 0.1
+    bias = torch.randn(16, generator=g) * 0.1
+    hw_, hb_ = torch.randn(16, generator=g) * 0.3, torch.randn(1, generator=g)
+    wcl = weight.permute(2, 3, 0, 1).reshape(9, 16, 16).contiguous().to(dev)
+    want = torch.relu(torch.nn.functional.conv2d(x, weight, bias, padding=1))
+    got = ops.conv2d_k3_c16(x.to(dev), wcl, bias.to(dev), 1)
+    assert (got.cpu() - want).abs().max() < 2e-5
+    wpk = weight.permute(1, 2, 3, 0).reshape(16, 9, 16).contiguous().to(dev)
+    valu = ops.conv2d(x.to(dev), wpk, bias.to(dev), 16, 3, 1, 1, 1)
+    assert (got - valu).abs().max() < 2e-5
+    head = torch.sigmoid(torch.nn.functional.conv2d(want, hw_.view(1, 16, 1, 1), hb_))[:, 0]
+    got_h = ops.conv2d_k3_c16(x.to(dev), wcl, bias.to(dev), 1, head_w=hw_.to(dev), head_b=hb_.to(dev))
+    assert got_h.shape == (N, H, W)
+    assert (got_h.cpu() - head).abs().max() < 1e-5
+    with pytest.raises(ValueError):
+        ops.conv2d_k3_c16(x[:, :, :, :3].contiguous().to(dev), wcl, None)
