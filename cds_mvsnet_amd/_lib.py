@@ -43,10 +43,15 @@ SIGNATURES = {
     "cds_conv2d_f32": [P, P, P, P, I, I, I, I, I, I, I, I, I, P],
     "cds_conv2d_affine_f32": [P, P, P, P, P, I, I, I, I, I, I, I, I, I, P],
     "cds_instnorm_affine_f32": [P, P, P, I, I, I, I, F, P],
-    "cds_conv2d_fpn_f32": [P, P, P, P, P, P, I, I, I, I, I, I, P],
+    "cds_fpn_stats_parts": [I, I],
+    "cds_conv2d_fpn_f32": [P, P, P, P, P, P, P, I, I, I, I, I, I, P],
     "cds_conv2d_k3_c16_f32": [P, P, P, P, P, P, I, I, I, I, P],
     "cds_dynconv_blend_f32": [P, P, P, P, P, F, P, P, I, I, I, I, I, P],
     "cds_dynconv_blend_shared_f32": [P, P, P, P, P, F, P, P, I, I, I, I, I, I, P],
+    "cds_blend_stats_parts": [I, I],
+    "cds_dynconv_blend_stats_f32": [P, P, P, P, P, F, P, P, P, I, I, I, I, I, I, P],
+    "cds_instnorm_reduce_f32": [P, I, P, P, I, I, I, I, F, P],
+    "cds_instnorm_apply_f32": [P, P, P, I, I, I, I, I, I, P],
     "cds_instnorm_act_f32": [P, P, P, I, I, I, I, I, I, P],
     "cds_curvature_stats_f32": [P, P, P, P, P, I, P],
     "cds_pair_mean_f32": [P, P, I, I, P],

@@ -205,6 +205,26 @@ int launch_conv2d(const float* x, const float* aff, const float* w, const float*
   return launch_conv2d_n<K, S, PXW, CI_CHUNK, 1>(x, aff, w, b, out, N, Cin, Cout, H, W, pad, act, st);
 }
 
+// fp64 sum over the 64 lanes of a wave without the LDS crossbar: four DPP steps inside each row of 16 lanes, then the
+// four row totals through v_readlane.
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane),
+                          __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+__device__ __forceinline__ double wave_sum_f64(double v) {
+  v += dpp_f64<0xB1>(v);    // quad_perm [1,0,3,2]
+  v += dpp_f64<0x4E>(v);    // quad_perm [2,3,0,1]
+  v += dpp_f64<0x141>(v);   // row_half_mirror
+  v += dpp_f64<0x140>(v);   // row_mirror
+  return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
+}
+
 // ---------------------------------------------------------------------------------------------
 // FPN lateral (module.py:253-254,260-261): 1x1 convolution over cat(nearest2x(coarse), skip) without building either
 // the up-sampled tensor or the concatenation.  coarse [N][Ca][H/2][W/2], skip [N][Cb][H][W], weights packed
@@ -214,9 +234,9 @@ int launch_conv2d(const float* x, const float* aff, const float* w, const float*
 template <int NCB>
 __global__ __launch_bounds__(256) void fpn_lateral_kernel(const float* __restrict__ xa, const float* __restrict__ affa,
                                                           const float* __restrict__ xb, const float* __restrict__ affb,
-                                                          const float* __restrict__ wpk, float* __restrict__ out, int N,
-                                                          int Ca, int Cb, int Cout, int CoutP, int H, int W, int tiles_x,
-                                                          int tiles_y) {
+                                                          const float* __restrict__ wpk, float* __restrict__ out,
+                                                          double* __restrict__ partial, int N, int Ca, int Cb, int Cout,
+                                                          int CoutP, int H, int W, int tiles_x, int tiles_y) {
   constexpr int PX = 4, LX = 16, CW = CO * NCB;
   const int co_groups = CoutP / CW;
   const int ntiles = tiles_x * tiles_y;
@@ -227,8 +247,13 @@ __global__ __launch_bounds__(256) void fpn_lateral_kernel(const float* __restric
   const int n = lin / ntiles;
   const int co0 = cog * CW;
   const int lx = threadIdx.x % LX, ly = threadIdx.x / LX;
-  const int oy = (tile / tiles_x) * 16 + ly, ox = ((tile % tiles_x) * LX + lx) * PX;
-  if (oy >= H || ox >= W) return;
+  int oy = (tile / tiles_x) * 16 + ly, ox = ((tile % tiles_x) * LX + lx) * PX;
+  const bool valid = oy < H && ox < W;
+  if (!partial && !valid) return;
+  if (!valid) {   // statistics: the wave reduction needs every lane; out-of-image lanes shadow pixel (0, 0), store nothing
+    oy = 0;
+    ox = 0;
+  }
   const int Hc = H >> 1, Wc = W >> 1;
   const size_t plane = (size_t)H * W, cplane = (size_t)Hc * Wc;
   float acc[PX][CW];
@@ -281,13 +306,29 @@ __global__ __launch_bounds__(256) void fpn_lateral_kernel(const float* __restric
       mac(in, Ca + ci);
     }
   }
+  // InstanceNorm statistics of the output (see dynconv_blend_stats_kernel): one record per (tile, wave) and channel
+  double* rec = partial ? partial + (((size_t)n * (ntiles * 4) + tile * 4 + (threadIdx.x >> 6)) * Cout) * 2 : nullptr;
 #pragma unroll
   for (int c = 0; c < CW; ++c) {
     if (co0 + c < Cout) {
       float* o = out + ((size_t)n * Cout + co0 + c) * plane + (size_t)oy * W + ox;
+      double ds = 0.0, dq = 0.0;
 #pragma unroll
       for (int p = 0; p < PX; ++p)
-        if (ox + p < W) o[p] = acc[p][c];
+        if (valid && ox + p < W) {
+          o[p] = acc[p][c];
+          const double v = (double)acc[p][c];
+          ds += v;
+          dq += v * v;
+        }
+      if (partial) {
+        ds = wave_sum_f64(ds);
+        dq = wave_sum_f64(dq);
+        if ((threadIdx.x & 63) == 0) {
+          rec[2 * (co0 + c)] = ds;
+          rec[2 * (co0 + c) + 1] = dq;
+        }
+      }
     }
   }
 }
@@ -300,31 +341,19 @@ struct EpiBatch {
   float x[CDS_MAX_IMAGES], y[CDS_MAX_IMAGES];
 };
 
-// branch: [K][N][Cout+3][H][W]; out: [N][Cout][H][W]; norm_curv: [N][H][W]; image n = blockIdx.y
+// Per-pixel part of the epilogue: epipolar projection of the K curvature responses, 1x1 MLP, softmax(./T).
+// Returns the blend weights in logit[] and the weighted curvature.
 template <int K>
-__global__ __launch_bounds__(256) void dynconv_blend_kernel(const float* __restrict__ branch,
-                                                            const float* __restrict__ w1, const float* __restrict__ b1,
-                                                            const float* __restrict__ w2, EpiBatch epi, float temperature,
-                                                            float* __restrict__ out, float* __restrict__ norm_curv,
-                                                            int N, int Cout, int H, int W, int n_shared) {
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  const int hw = H * W;
-  if (p >= hw) return;
-  const int n = blockIdx.y;
-  const float epi_x = epi.x[n], epi_y = epi.y[n];
-  // the first n_shared images (copies of the reference image, each with its own epipole) share branch slot 0
-  const int slot = n < n_shared ? 0 : n - n_shared + 1;
-  const int nslots = N - n_shared + 1;
-  branch += (size_t)slot * (Cout + 3) * hw;
-  out += (size_t)n * Cout * hw;
-  norm_curv += (size_t)n * hw;
+__device__ __forceinline__ float blend_weights(const float* __restrict__ branch, size_t bstride, int Cout, int hw, int p,
+                                               int W, float epi_x, float epi_y, const float* __restrict__ w1,
+                                               const float* __restrict__ b1, const float* __restrict__ w2,
+                                               float temperature, float logit[K]) {
   const int y = p / W, x = p % W;
   float u = (float)x - epi_x, v = (float)y - epi_y;
   const float nrm = sqrtf(u * u + v * v);
   u = u / (nrm + 1e-6f);
   v = v / (nrm + 1e-6f);
   const float b0 = u * u, b1v = 2.0f * u * v, b2 = v * v;
-  const size_t bstride = (size_t)nslots * (Cout + 3) * hw;  // stride between kernel sizes
   float curv[K];
 #pragma unroll
   for (int k = 0; k < K; ++k) {
@@ -339,7 +368,7 @@ __global__ __launch_bounds__(256) void dynconv_blend_kernel(const float* __restr
     for (int k = 0; k < K; ++k) s = fmaf(w1[j * K + k], curv[k], s);
     hid[j] = fmaxf(s + b1[j], 0.f);
   }
-  float logit[K], mx = -INFINITY;
+  float mx = -INFINITY;
 #pragma unroll
   for (int k = 0; k < K; ++k) {
     float s = 0.f;
@@ -360,12 +389,94 @@ __global__ __launch_bounds__(256) void dynconv_blend_kernel(const float* __restr
     logit[k] = logit[k] / den;
     nc = nc + curv[k] * logit[k];
   }
-  norm_curv[p] = nc;
+  return nc;
+}
+
+// branch: [K][N][Cout+3][H][W]; out: [N][Cout][H][W]; norm_curv: [N][H][W]; image n = blockIdx.y
+template <int K>
+__global__ __launch_bounds__(256) void dynconv_blend_kernel(const float* __restrict__ branch,
+                                                            const float* __restrict__ w1, const float* __restrict__ b1,
+                                                            const float* __restrict__ w2, EpiBatch epi, float temperature,
+                                                            float* __restrict__ out, float* __restrict__ norm_curv,
+                                                            int N, int Cout, int H, int W, int n_shared) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  const int hw = H * W;
+  if (p >= hw) return;
+  const int n = blockIdx.y;
+  // the first n_shared images (copies of the reference image, each with its own epipole) share branch slot 0
+  const int slot = n < n_shared ? 0 : n - n_shared + 1;
+  const int nslots = N - n_shared + 1;
+  branch += (size_t)slot * (Cout + 3) * hw;
+  out += (size_t)n * Cout * hw;
+  const size_t bstride = (size_t)nslots * (Cout + 3) * hw;  // stride between kernel sizes
+  float logit[K];
+  norm_curv[(size_t)n * hw + p] = blend_weights<K>(branch, bstride, Cout, hw, p, W, epi.x[n], epi.y[n], w1, b1, w2,
+                                                   temperature, logit);
   for (int c = 0; c < Cout; ++c) {
     float s = 0.f;
 #pragma unroll
     for (int k = 0; k < K; ++k) s = s + branch[k * bstride + (size_t)c * hw + p] * logit[k];
     out[(size_t)c * hw + p] = s;
+  }
+}
+
+// The same epilogue, PXT pixels per thread, that also leaves the InstanceNorm statistics of its output: every wave
+// writes one (sum, sum of squares) record per channel (fp64, of the rounded fp32 outputs = what a separate statistics
+// pass would read back), reduced in a fixed order by instnorm_reduce_kernel: no atomics, bit-reproducible.
+// partial: [N][parts][Cout][2], parts = 4 * gridDim.x.
+constexpr int BLEND_PXT = 4;
+template <int K>
+__global__ __launch_bounds__(256) void dynconv_blend_stats_kernel(const float* __restrict__ branch,
+                                                                  const float* __restrict__ w1,
+                                                                  const float* __restrict__ b1,
+                                                                  const float* __restrict__ w2, EpiBatch epi,
+                                                                  float temperature, float* __restrict__ out,
+                                                                  float* __restrict__ norm_curv,
+                                                                  double* __restrict__ partial, int N, int Cout, int H,
+                                                                  int W, int n_shared) {
+  constexpr int PXT = BLEND_PXT;
+  const int hw = H * W;
+  const int n = blockIdx.y;
+  const int slot = n < n_shared ? 0 : n - n_shared + 1;
+  const int nslots = N - n_shared + 1;
+  branch += (size_t)slot * (Cout + 3) * hw;
+  out += (size_t)n * Cout * hw;
+  const size_t bstride = (size_t)nslots * (Cout + 3) * hw;
+  const int base = blockIdx.x * (256 * PXT) + threadIdx.x;
+  float lg[PXT][K];
+  int px[PXT];
+  bool ok[PXT];
+#pragma unroll
+  for (int j = 0; j < PXT; ++j) {
+    const int p = base + 256 * j;
+    ok[j] = p < hw;
+    px[j] = ok[j] ? p : hw - 1;
+    const float nc = blend_weights<K>(branch, bstride, Cout, hw, px[j], W, epi.x[n], epi.y[n], w1, b1, w2, temperature, lg[j]);
+    if (ok[j]) norm_curv[(size_t)n * hw + p] = nc;
+  }
+  const int wave = threadIdx.x >> 6;
+  const int parts = 4 * gridDim.x;
+  double* rec = partial + (((size_t)n * parts + blockIdx.x * 4 + wave) * Cout) * 2;
+  for (int c = 0; c < Cout; ++c) {
+    double ds = 0.0, dq = 0.0;
+#pragma unroll
+    for (int j = 0; j < PXT; ++j) {
+      float s = 0.f;
+#pragma unroll
+      for (int k = 0; k < K; ++k) s = s + branch[k * bstride + (size_t)c * hw + px[j]] * lg[j][k];
+      if (ok[j]) {
+        out[(size_t)c * hw + px[j]] = s;
+        const double v = (double)s;
+        ds += v;
+        dq += v * v;
+      }
+    }
+    ds = wave_sum_f64(ds);
+    dq = wave_sum_f64(dq);
+    if ((threadIdx.x & 63) == 0) {
+      rec[2 * c] = ds;
+      rec[2 * c + 1] = dq;
+    }
   }
 }
 
@@ -439,6 +550,43 @@ __global__ void instnorm_affine_kernel(const double* __restrict__ stats, float* 
   affine[3 * i + 2] = slope;
 }
 
+// partial [N][parts][C][2] -> stats [N][C][2] (sum, sum of squares) and, if asked, the (alpha, beta, slope) rows.
+// One workgroup per (image, channel); fixed summation order.
+__global__ __launch_bounds__(256) void instnorm_reduce_kernel(const double* __restrict__ partial, int parts, int C, int hw,
+                                                              float slope, double* __restrict__ stats,
+                                                              float* __restrict__ affine) {
+  const int nc = blockIdx.x, n = nc / C, c = nc % C;
+  const double* __restrict__ p = partial + ((size_t)n * parts * C + c) * 2;
+  double s = 0.0, q = 0.0;
+  for (int i = threadIdx.x; i < parts; i += 256) {
+    s += p[(size_t)i * C * 2];
+    q += p[(size_t)i * C * 2 + 1];
+  }
+  s = wave_sum_f64(s);
+  q = wave_sum_f64(q);
+  __shared__ double red[2][4];
+  if ((threadIdx.x & 63) == 0) {
+    red[0][threadIdx.x >> 6] = s;
+    red[1][threadIdx.x >> 6] = q;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    s = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    q = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    stats[2 * nc] = s;
+    stats[2 * nc + 1] = q;
+    if (affine) {
+      const double mean = s / hw;
+      double var = q / hw - mean * mean;
+      var = var < 0.0 ? 0.0 : var;
+      const float invstd = (float)(1.0 / sqrt(var + 1e-5));
+      affine[3 * nc] = invstd;
+      affine[3 * nc + 1] = -(float)mean * invstd;
+      affine[3 * nc + 2] = slope;
+    }
+  }
+}
+
 // norm-curvature bookkeeping of a FeatureNet level (module.py:250-251,257-258,264-265): (a^2 + b^2 + c^2) / 3 and |c|
 __global__ __launch_bounds__(256) void curvature_stats_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                               const float* __restrict__ c, float* __restrict__ nc_sum,
@@ -508,9 +656,12 @@ extern "C" int cds_conv2d_affine_f32(const float* x, const float* in_affine, con
   return CDS_EINVAL;
 }
 
+extern "C" int cds_fpn_stats_parts(int H, int W) { return 4 * cds_ceil_div(W, 64) * cds_ceil_div(H, 16); }
+
 extern "C" int cds_conv2d_fpn_f32(const float* coarse, const float* coarse_affine, const float* skip,
-                                  const float* skip_affine, const float* weight, float* out, int N, int Ca, int Cb,
-                                  int Cout, int H, int W, void* stream) {
+                                  const float* skip_affine, const float* weight, float* out, float* partial, int N,
+                                  int Ca, int Cb, int Cout, int H, int W, void* stream) {
+  double* dpart = reinterpret_cast<double*>(partial);
   if (!coarse || !skip || !weight || !out || N < 1 || Ca < 1 || Cb < 1 || Cout < 1 || H < 2 || W < 2 || (H & 1) || (W & 1))
     return CDS_EINVAL;
   const int CoutP = (Cout + CO - 1) / CO * CO;
@@ -518,10 +669,10 @@ extern "C" int cds_conv2d_fpn_f32(const float* coarse, const float* coarse_affin
   hipStream_t st = (hipStream_t)stream;
   if ((CoutP / CO) % 2 == 0)
     hipLaunchKernelGGL(fpn_lateral_kernel<2>, dim3(tx * ty * (CoutP / 16) * N), dim3(256), 0, st, coarse, coarse_affine, skip,
-                       skip_affine, weight, out, N, Ca, Cb, Cout, CoutP, H, W, tx, ty);
+                       skip_affine, weight, out, dpart, N, Ca, Cb, Cout, CoutP, H, W, tx, ty);
   else
     hipLaunchKernelGGL(fpn_lateral_kernel<1>, dim3(tx * ty * (CoutP / 8) * N), dim3(256), 0, st, coarse, coarse_affine, skip,
-                       skip_affine, weight, out, N, Ca, Cb, Cout, CoutP, H, W, tx, ty);
+                       skip_affine, weight, out, dpart, N, Ca, Cb, Cout, CoutP, H, W, tx, ty);
   return cds_launch_status();
 }
 
@@ -551,6 +702,52 @@ extern "C" int cds_dynconv_blend_shared_f32(const float* branches, const float* 
                        norm_curv, N, Cout, H, W, n_shared);
   else
     return CDS_EINVAL;
+  return cds_launch_status();
+}
+
+extern "C" int cds_blend_stats_parts(int H, int W) { return 4 * cds_ceil_div(H * W, 256 * BLEND_PXT); }
+
+extern "C" int cds_dynconv_blend_stats_f32(const float* branches, const float* w1, const float* b1, const float* w2,
+                                           const float* epipoles_host, float temperature, float* out, float* norm_curv,
+                                           float* partial, int N, int K, int Cout, int H, int W, int n_shared,
+                                           void* stream) {
+  if (!branches || !w1 || !b1 || !w2 || !epipoles_host || !out || !norm_curv || !partial || N < 1 || N > CDS_MAX_IMAGES ||
+      Cout < 1 || H < 1 || W < 1 || n_shared < 1 || n_shared > N)
+    return CDS_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  EpiBatch epi;
+  for (int n = 0; n < CDS_MAX_IMAGES; ++n) {
+    epi.x[n] = n < N ? epipoles_host[2 * n] : 0.f;
+    epi.y[n] = n < N ? epipoles_host[2 * n + 1] : 0.f;
+  }
+  dim3 grid(cds_ceil_div(H * W, 256 * BLEND_PXT), N), block(256);
+  double* dpart = reinterpret_cast<double*>(partial);
+  if (K == 2)
+    hipLaunchKernelGGL(dynconv_blend_stats_kernel<2>, grid, block, 0, st, branches, w1, b1, w2, epi, temperature, out,
+                       norm_curv, dpart, N, Cout, H, W, n_shared);
+  else if (K == 3)
+    hipLaunchKernelGGL(dynconv_blend_stats_kernel<3>, grid, block, 0, st, branches, w1, b1, w2, epi, temperature, out,
+                       norm_curv, dpart, N, Cout, H, W, n_shared);
+  else
+    return CDS_EINVAL;
+  return cds_launch_status();
+}
+
+extern "C" int cds_instnorm_reduce_f32(const float* partial, int parts, float* stats, float* affine, int N, int C, int H,
+                                       int W, float slope, void* stream) {
+  if (!partial || !stats || parts < 1 || N < 1 || C < 1 || H < 1 || W < 1) return CDS_EINVAL;
+  hipLaunchKernelGGL(instnorm_reduce_kernel, dim3(N * C), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const double*>(partial), parts, C, H * W, slope, reinterpret_cast<double*>(stats),
+                     affine);
+  return cds_launch_status();
+}
+
+extern "C" int cds_instnorm_apply_f32(const float* x, const float* stats, float* out, int N, int C, int H, int W, int act,
+                                      int out_hwc, void* stream) {
+  if (!x || !out || !stats || N < 1 || C < 1 || H < 1 || W < 1) return CDS_EINVAL;
+  const int hw = H * W;
+  hipLaunchKernelGGL(instnorm_apply_kernel, dim3(cds_ceil_div(hw, 256), N), dim3(256), 0, (hipStream_t)stream, x,
+                     reinterpret_cast<const double*>(stats), out, C, hw, act, out_hwc);
   return cds_launch_status();
 }
 

@@ -347,7 +347,7 @@ class _FeatureRunner:
     # (1/std, -mean/std, leaky slope) of its InstanceNorm + LeakyReLU, which the consuming convolutions apply on load
     # (`cds_conv2d_affine_f32`) - the normalised tensor is never written.  affine = None marks a materialised tensor.
     def _dynamic(self, p, name: str, dc: DynamicConv, x: Tensor, epi: Tensor, T: float, n_shared: int = 1,
-                 aff: Optional[Tensor] = None):
+                 aff: Optional[Tensor] = None, stats_slope: Optional[float] = 0.1):
         """x [N,Cin,H,W] (with its pending affine), epi CPU [N,2] (pixels at this resolution) ->
         (out [N,Cout,H,W], norm_curv [N,H,W]).  n_shared > 1: the first n_shared images are copies of one image (SURVEY
         §8(f)-4): their epipole-independent branch responses are convolved once (image n_shared - 1 stands for all)."""
@@ -359,11 +359,13 @@ class _FeatureRunner:
         for i, k in enumerate(dc.size_kernels):
             ops.conv2d(xs, p[f"{name}.w{i}"], p.get(f"{name}.b{i}"), dc.out_c + 3, k, 1, (k - 1) // 2, ACT_NONE,
                        out=branches[i], in_affine=affs)
-        return ops.dynconv_blend(branches, p[f"{name}.m1"], p[f"{name}.mb"], p[f"{name}.m2"], epi, T, n_shared)
+        return ops.dynconv_blend(branches, p[f"{name}.m1"], p[f"{name}.mb"], p[f"{name}.m2"], epi, T, n_shared,
+                                 stats_slope=stats_slope)
 
     def _dyn_unit(self, p, name, x, epi, T, n_shared: int = 1, aff: Optional[Tensor] = None):
-        y, nc = self._dynamic(p, name, getattr(self.net, name).conv, x, epi, T, n_shared, aff)
-        return y, ops.instnorm_affine(y, 0.1), nc
+        # the blend kernel leaves the InstanceNorm statistics of its output: (raw, affine) without another pass
+        y, nc, _, a = self._dynamic(p, name, getattr(self.net, name).conv, x, epi, T, n_shared, aff)
+        return y, a, nc
 
     def _plain_unit(self, p, name, x, aff: Optional[Tensor] = None):
         unit: ConvUnit = getattr(self.net, name)
@@ -374,16 +376,15 @@ class _FeatureRunner:
     def _lateral_unit(self, p, name, coarse, a_coarse, skip, a_skip):
         """FPN lateral: ConvUnit 1x1 over cat(nearest2x(coarse), skip), neither of which is materialised."""
         unit: ConvUnit = getattr(self.net, name)
-        y = ops.conv2d_fpn(coarse, skip, p[f"{name}.w"], unit.conv.out_channels, a_coarse, a_skip)
-        return y, ops.instnorm_affine(y, 0.1)
+        return ops.conv2d_fpn(coarse, skip, p[f"{name}.w"], unit.conv.out_channels, a_coarse, a_skip, stats_slope=0.1)
 
     @staticmethod
-    def _final(o: Tensor, n_chw: int) -> Tuple[Tensor, Optional[Tensor]]:
-        """InstanceNorm + tanh of the stage output; the first n_chw images stay [C,h,w] (reference features), the
-        rest are emitted channels-last [h,w,C] (source features, gathered by K1/K3)."""
+    def _final(o: Tensor, st: Tensor, n_chw: int) -> Tuple[Tensor, Optional[Tensor]]:
+        """InstanceNorm + tanh of the stage output (st = its statistics from the blend kernel); the first n_chw images
+        stay [C,h,w] (reference features), the rest are emitted channels-last [h,w,C] (source features, gathered by K1/K3)."""
         N = o.shape[0]
-        chw = ops.instnorm_act(o[:n_chw].contiguous(), ACT_TANH) if n_chw > 0 else None
-        hwc = ops.instnorm_act(o[n_chw:].contiguous(), ACT_TANH, out_hwc=True) if n_chw < N else None
+        chw = ops.instnorm_apply(o[:n_chw], st[:n_chw], ACT_TANH) if n_chw > 0 else None
+        hwc = ops.instnorm_apply(o[n_chw:], st[n_chw:], ACT_TANH, out_hwc=True) if n_chw < N else None
         return chw, hwc
 
     def __call__(self, imgs: Tensor, epipoles: Tensor, T: float, n_chw: Optional[int] = None, n_shared: int = 1):
@@ -413,19 +414,19 @@ class _FeatureRunner:
         c21, a21, n21 = self._dyn_unit(p, "conv21", c20, e2, T, aff=a20)
 
         out = {}
-        o1, n22 = self._dynamic(p, "out1", net.out1, c21, e2, T, aff=a21)
-        out["stage1"] = self._final(o1, n_chw) + ops.curvature_stats(n20, n21, n22)
+        o1, n22, s1, _ = self._dynamic(p, "out1", net.out1, c21, e2, T, aff=a21)
+        out["stage1"] = self._final(o1, s1, n_chw) + ops.curvature_stats(n20, n21, n22)
 
         # FPN: nearest-neighbour up-sampling and concatenation move raw values; the affine tables concatenate alike
         x, ax = self._lateral_unit(p, "inner1", c21, a21, c11, a11)
-        o2, n12 = self._dynamic(p, "out2", net.out2, x, e1, T, aff=ax)
-        o2n = ops.instnorm_act(o2, ACT_TANH)
+        o2, n12, s2, _ = self._dynamic(p, "out2", net.out2, x, e1, T, aff=ax)
+        o2n = ops.instnorm_apply(o2, s2, ACT_TANH)
         hwc2 = torch.stack([ops.chw_to_hwc(o2n[i]) for i in range(n_chw, N)]) if n_chw < N else None
         out["stage2"] = (o2n[:n_chw] if n_chw > 0 else None, hwc2) + ops.curvature_stats(n10, n11, n12)
 
         x, ax = self._lateral_unit(p, "inner2", o2n, None, c01, a01)      # o2n is materialised (tanh features)
-        o3, n02 = self._dynamic(p, "out3", net.out3, x, e0, T, aff=ax)
-        out["stage3"] = self._final(o3, n_chw) + ops.curvature_stats(n00, n01, n02)
+        o3, n02, s3, _ = self._dynamic(p, "out3", net.out3, x, e0, T, aff=ax)
+        out["stage3"] = self._final(o3, s3, n_chw) + ops.curvature_stats(n00, n01, n02)
         return out
 
 

@@ -56,6 +56,12 @@ def _dev(t: Tensor, name: str) -> int:
     return t.data_ptr()
 
 
+def _dev64(t: Tensor, name: str) -> int:
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float64 and t.is_contiguous()):
+        raise ValueError(f"{name}: expected a contiguous float64 device tensor")
+    return t.data_ptr()
+
+
 def _host(t: Tensor, name: str) -> int:
     if t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous():
         raise ValueError(f"{name}: expected a contiguous float32 CPU tensor")
@@ -337,10 +343,11 @@ def conv2d_k3_c16(x: Tensor, wcl: Tensor, bias: Optional[Tensor], act: int = ACT
 
 
 def conv2d_fpn(coarse: Tensor, skip: Tensor, wpk: Tensor, cout: int, coarse_affine: Optional[Tensor] = None,
-               skip_affine: Optional[Tensor] = None) -> Tensor:
+               skip_affine: Optional[Tensor] = None, stats_slope: Optional[float] = None):
     """FPN lateral (module.py:253-254,260-261): 1x1 conv of cat(nearest2x(coarse), skip) without building either.
     coarse [N,Ca,H/2,W/2], skip [N,Cb,H,W], wpk packed [Ca+Cb,1,CoutP] -> [N,cout,H,W]; the affine tables are the
-    sources' pending InstanceNorm + LeakyReLU (see conv2d)."""
+    sources' pending InstanceNorm + LeakyReLU (see conv2d).  stats_slope given: returns (out, affine [N,cout,3]) with the
+    output's own InstanceNorm table (= instnorm_affine(out, stats_slope)) from statistics taken inside the kernel."""
     N, Ca, hc, wc = coarse.shape
     Nb, Cb, H, W = skip.shape
     if Nb != N or H != 2 * hc or W != 2 * wc:
@@ -351,14 +358,23 @@ def conv2d_fpn(coarse: Tensor, skip: Tensor, wpk: Tensor, cout: int, coarse_affi
     for a, c, nm in ((coarse_affine, Ca, "coarse_affine"), (skip_affine, Cb, "skip_affine")):
         if a is not None and tuple(a.shape) != (N, c, 3):
             raise ValueError(f"conv2d_fpn: {nm} must be [{N},{c},3], got {tuple(a.shape)}")
-    out = torch.empty((N, cout, H, W), dtype=torch.float32, device=skip.device)
-    check(_lib.load().cds_conv2d_fpn_f32(_dev(coarse, "coarse"),
-                                         _dev(coarse_affine, "coarse_affine") if coarse_affine is not None else None,
-                                         _dev(skip, "skip"),
-                                         _dev(skip_affine, "skip_affine") if skip_affine is not None else None,
-                                         _dev(wpk, "weight"), _dev(out, "out"), N, Ca, Cb, cout, H, W, _stream(skip)),
-          "cds_conv2d_fpn_f32")
-    return out
+    dev = skip.device
+    lib = _lib.load()
+    out = torch.empty((N, cout, H, W), dtype=torch.float32, device=dev)
+    parts = lib.cds_fpn_stats_parts(H, W) if stats_slope is not None else 0
+    partial = torch.empty((N, parts, cout, 2), dtype=torch.float64, device=dev) if parts else None
+    check(lib.cds_conv2d_fpn_f32(_dev(coarse, "coarse"),
+                                 _dev(coarse_affine, "coarse_affine") if coarse_affine is not None else None,
+                                 _dev(skip, "skip"), _dev(skip_affine, "skip_affine") if skip_affine is not None else None,
+                                 _dev(wpk, "weight"), _dev(out, "out"), partial.data_ptr() if parts else None,
+                                 N, Ca, Cb, cout, H, W, _stream(skip)), "cds_conv2d_fpn_f32")
+    if stats_slope is None:
+        return out
+    stats = torch.empty((N, cout, 2), dtype=torch.float64, device=dev)
+    affine = torch.empty((N, cout, 3), dtype=torch.float32, device=dev)
+    check(lib.cds_instnorm_reduce_f32(partial.data_ptr(), parts, stats.data_ptr(), affine.data_ptr(), N, cout, H, W,
+                                      float(stats_slope), _stream(skip)), "cds_instnorm_reduce_f32")
+    return out, affine
 
 
 def instnorm_affine(x: Tensor, slope: float = 0.1) -> Tensor:
@@ -373,21 +389,50 @@ def instnorm_affine(x: Tensor, slope: float = 0.1) -> Tensor:
 
 
 def dynconv_blend(branches: Tensor, w1: Tensor, b1: Tensor, w2: Tensor, epipoles: Tensor,
-                  temperature: float, n_shared: int = 1) -> Tuple[Tensor, Tensor]:
+                  temperature: float, n_shared: int = 1, stats_slope: Optional[float] = None):
     """K7 epilogue.  branches [K,N - n_shared + 1,Cout+3,H,W] (the first n_shared images share slot 0), epipoles CPU
-    [N,2] -> (out [N,Cout,H,W], norm_curv [N,H,W])."""
+    [N,2] -> (out [N,Cout,H,W], norm_curv [N,H,W]).
+    stats_slope given: the kernel also leaves the InstanceNorm statistics of `out` (no second pass over it) and the call
+    returns (out, norm_curv, stats [N,Cout,2] float64 = (sum, sum of squares), affine [N,Cout,3]) - affine as from
+    instnorm_affine(out, stats_slope), stats for instnorm_apply."""
     K, nslots, C3, H, W = branches.shape
     N = nslots + n_shared - 1
     cout = C3 - 3
     if tuple(epipoles.shape) != (N, 2) or n_shared < 1:
         raise ValueError("dynconv_blend: epipoles must be [N,2]")
-    out = torch.empty((N, cout, H, W), dtype=torch.float32, device=branches.device)
-    nc = torch.empty((N, H, W), dtype=torch.float32, device=branches.device)
-    check(_lib.load().cds_dynconv_blend_shared_f32(_dev(branches, "branches"), _dev(w1, "w1"), _dev(b1, "b1"), _dev(w2, "w2"),
-                                                   _host(epipoles, "epipoles"), float(temperature), out.data_ptr(),
-                                                   nc.data_ptr(), N, K, cout, H, W, n_shared, _stream(out)),
-          "cds_dynconv_blend_shared_f32")
-    return out, nc
+    dev = branches.device
+    out = torch.empty((N, cout, H, W), dtype=torch.float32, device=dev)
+    nc = torch.empty((N, H, W), dtype=torch.float32, device=dev)
+    lib = _lib.load()
+    if stats_slope is None:
+        check(lib.cds_dynconv_blend_shared_f32(_dev(branches, "branches"), _dev(w1, "w1"), _dev(b1, "b1"), _dev(w2, "w2"),
+                                               _host(epipoles, "epipoles"), float(temperature), out.data_ptr(),
+                                               nc.data_ptr(), N, K, cout, H, W, n_shared, _stream(out)),
+              "cds_dynconv_blend_shared_f32")
+        return out, nc
+    parts = lib.cds_blend_stats_parts(H, W)
+    partial = torch.empty((N, parts, cout, 2), dtype=torch.float64, device=dev)
+    stats = torch.empty((N, cout, 2), dtype=torch.float64, device=dev)
+    affine = torch.empty((N, cout, 3), dtype=torch.float32, device=dev)
+    check(lib.cds_dynconv_blend_stats_f32(_dev(branches, "branches"), _dev(w1, "w1"), _dev(b1, "b1"), _dev(w2, "w2"),
+                                          _host(epipoles, "epipoles"), float(temperature), out.data_ptr(), nc.data_ptr(),
+                                          partial.data_ptr(), N, K, cout, H, W, n_shared, _stream(out)),
+          "cds_dynconv_blend_stats_f32")
+    check(lib.cds_instnorm_reduce_f32(partial.data_ptr(), parts, stats.data_ptr(), affine.data_ptr(), N, cout, H, W,
+                                      float(stats_slope), _stream(out)), "cds_instnorm_reduce_f32")
+    return out, nc, stats, affine
+
+
+def instnorm_apply(x: Tensor, stats: Tensor, act: int, out_hwc: bool = False) -> Tensor:
+    """Second half of K8: x [N,C,H,W] with its statistics [N,C,2] float64 (sum, sum of squares; from
+    dynconv_blend(stats_slope=...)) -> InstanceNorm + activation; [N,H,W,C] if out_hwc."""
+    N, C, H, W = x.shape
+    if stats.dtype != torch.float64 or tuple(stats.shape) != (N, C, 2):
+        raise ValueError(f"instnorm_apply: stats must be float64 [{N},{C},2], got {stats.dtype} {tuple(stats.shape)}")
+    out = torch.empty((N, H, W, C) if out_hwc else (N, C, H, W), dtype=torch.float32, device=x.device)
+    check(_lib.load().cds_instnorm_apply_f32(_dev(x, "x"), _dev64(stats, "stats"), out.data_ptr(), N, C, H, W, act,
+                                             1 if out_hwc else 0, _stream(x)), "cds_instnorm_apply_f32")
+    return out
 
 
 def instnorm_act(x: Tensor, act: int, out_hwc: bool = False) -> Tensor:

@@ -191,9 +191,13 @@ int cds_conv2d_k3_c16_f32(const float* x, const float* weight_cl, const float* b
  *   weight PACKED [Ca + Cb][CoutP] (coarse channels first, as in the concatenation)
  *   coarse_affine [N][Ca][3] / skip_affine [N][Cb][3]: normalise-on-load tables like cds_conv2d_affine_f32, or NULL.
  * Results are bit-identical to cds_conv2d_affine_f32 (k = 1) on the materialised concatenation.
+ *   partial: NULL, or a scratch of 4 * N * cds_fpn_stats_parts(H, W) * Cout floats that receives the per-wave
+ *   InstanceNorm records of `out` (as in cds_dynconv_blend_stats_f32; reduce with cds_instnorm_reduce_f32).
  */
+int cds_fpn_stats_parts(int H, int W);
 int cds_conv2d_fpn_f32(const float* coarse, const float* coarse_affine, const float* skip, const float* skip_affine,
-                       const float* weight, float* out, int N, int Ca, int Cb, int Cout, int H, int W, void* stream);
+                       const float* weight, float* out, float* partial, int N, int Ca, int Cb, int Cout, int H, int W,
+                       void* stream);
 
 /*
  * K7 epilogue of DynamicConv (dynamic_conv.py:97-122) for a batch of N images (each with its own epipole):
@@ -217,6 +221,25 @@ int cds_dynconv_blend_f32(const float* branches, const float* w1, const float* b
 int cds_dynconv_blend_shared_f32(const float* branches, const float* w1, const float* b1, const float* w2,
                                  const float* epipoles_host, float temperature, float* out, float* norm_curv, int N,
                                  int K, int Cout, int H, int W, int n_shared, void* stream);
+
+/*
+ * cds_dynconv_blend_shared_f32 that also leaves the InstanceNorm statistics of `out`, so that the normalisation that
+ * follows every DynamicConv (module.py:53,66-69) needs no second pass over the tensor.  Every wave writes one
+ * (sum, sum of squares) fp64 record per channel of the rounded fp32 outputs:
+ *   partial: caller-provided, 8-byte aligned scratch of 4 * N * parts * Cout floats, parts = cds_blend_stats_parts(H, W)
+ * cds_instnorm_reduce_f32 adds the records in a fixed order (no atomics: bit-reproducible) into
+ *   stats  [N][C][2] doubles (sum, sum of squares) — stored in a float* scratch of 4*N*C floats like cds_instnorm_act_f32's
+ *   affine [N][C][3] (alpha, beta, slope) as cds_instnorm_affine_f32 would produce, or NULL
+ * cds_instnorm_apply_f32 is the second half of cds_instnorm_act_f32 for given statistics.
+ */
+int cds_blend_stats_parts(int H, int W);
+int cds_dynconv_blend_stats_f32(const float* branches, const float* w1, const float* b1, const float* w2,
+                                const float* epipoles_host, float temperature, float* out, float* norm_curv,
+                                float* partial, int N, int K, int Cout, int H, int W, int n_shared, void* stream);
+int cds_instnorm_reduce_f32(const float* partial, int parts, float* stats, float* affine, int N, int C, int H, int W,
+                            float slope, void* stream);
+int cds_instnorm_apply_f32(const float* x, const float* stats, float* out, int N, int C, int H, int W, int act,
+                           int out_hwc, void* stream);
 
 /*
  * K8 (module.py:53,66-69,223,230,232): InstanceNorm2d (no affine, eps 1e-5, biased variance) followed by

@@ -27,7 +27,7 @@ for T in (1.0, 0.01):
         else:
             pre_ref, nc_ref = O.dynamic_conv(x, et, T, sd, "feature."+name+".conv", sizes)
             y_ref = F.leaky_relu(F.instance_norm(pre_ref, eps=1e-5), 0.1)
-            pre, nc = run._dynamic(p, name, getattr(net, name).conv, x[0].to(dev).contiguous(), eg, T)
+            pre, nc = run._dynamic(p, name, getattr(net, name).conv, x[0].to(dev).contiguous(), eg, T, stats_slope=None)
             y = ops.instnorm_act(pre, ops.ACT_LEAKY01).cpu()
             y2 = ops.instnorm_act(pre_ref[0].to(dev).contiguous(), ops.ACT_LEAKY01).cpu()
             print(T, name, "pre err", (pre.cpu()-pre_ref[0]).abs().max().item(), "nc err", (nc.cpu()-nc_ref[0,0]).abs().max().item(),

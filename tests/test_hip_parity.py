@@ -230,8 +230,20 @@ def test_dynconv_and_epipoles(dev, ops, seeded_state):
     epi = torch.cat((g["epipole_ref"], g["epipole_src"])).contiguous()
     x2 = torch.stack((g["img"], g["img"])).to(dev).contiguous()
     for T in (1.0, 0.1, 0.01):
-        y, nc = runner._dynamic(packed, "dc", dc, x2, epi, T)
+        y, nc = runner._dynamic(packed, "dc", dc, x2, epi, T, stats_slope=None)
         assert (y[0].cpu() - g[f"y_T{T}"]).abs().max() < 5e-5, T
+        # the statistics-carrying variant (4 pixels per thread) gives the same tensors, exact fp64 sums of its output and
+        # the normalisation table / normalised tensor of the two-pass path
+        y2, nc2, st, aff = runner._dynamic(packed, "dc", dc, x2, epi, T, stats_slope=0.1)
+        assert torch.equal(y2, y) and torch.equal(nc2, nc)
+        yd = y.double()
+        want = torch.stack((yd.sum((2, 3)), (yd * yd).sum((2, 3))), dim=-1)
+        assert ((st - want).abs() / want.abs().clamp_min(1.0)).max() < 1e-12
+        assert (aff - ops.instnorm_affine(y, 0.1)).abs().max() < 1e-6
+        for hwc in (False, True):
+            assert (ops.instnorm_apply(y, st, 4, out_hwc=hwc) - ops.instnorm_act(y, 4, out_hwc=hwc)).abs().max() < 1e-6
+        again = runner._dynamic(packed, "dc", dc, x2, epi, T, stats_slope=0.1)[2]
+        assert torch.equal(again, st)                                       # fixed summation order: bit-reproducible
         assert (nc[0].cpu() - g[f"nc_T{T}"]).abs().max() < 5e-5, T
         assert (nc[1] - nc[0]).abs().max() > 1e-4
 
@@ -693,6 +705,11 @@ def test_fpn_lateral_equals_conv_of_concatenation(dev, ops, ca, cb, cout, h, w):
         want = ops.conv2d(cat, wpk, None, cout, 1, 1, 0, in_affine=acat)
         got = ops.conv2d_fpn(coarse, skip, wpk, cout, ac, asx)
         assert torch.equal(got, want), (got - want).abs().max()
+    # statistics taken inside the kernel: same output, the normalisation table of the two-pass path
+    got2, aff2 = ops.conv2d_fpn(coarse, skip, wpk, cout, a_c, a_s, stats_slope=0.1)
+    want2 = ops.conv2d_fpn(coarse, skip, wpk, cout, a_c, a_s)
+    assert torch.equal(got2, want2)
+    assert (aff2 - ops.instnorm_affine(want2, 0.1)).abs().max() < 1e-6
     # and against plain PyTorch
     ref = torch.nn.functional.conv2d(cat.cpu(), weight)
     assert (ops.conv2d_fpn(coarse, skip, wpk, cout).cpu() - ref).abs().max() < 1e-4
