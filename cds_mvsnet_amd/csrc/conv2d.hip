@@ -160,6 +160,164 @@ __global__ __launch_bounds__(256) void conv2d_kernel(const float* __restrict__ x
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// "pipe" variant (W % 4 == 0, k = 3 / 5): as conv3d_k3_pipe_kernel.  The input tile starts at an x that is a multiple of 4
+// (column c <-> x = S*ox0 - 4 + c), so it is staged with aligned 16-byte loads, a handful per thread instead of one dword
+// per lane and row; the loads of chunk k+1 are issued before the FMAs of chunk k and land in registers meanwhile.  The
+// row-per-wave staging of conv2d_kernel costs ~540 instructions per thread and chunk against the 1584 FMAs of a 3x3
+// chunk: 3x3 layers ran at 30-45 TF where the 7x7 layers (5x the FMAs per staged byte) reach 80.
+// ---------------------------------------------------------------------------------------------
+template <int K, int S, int PX, int CI_CHUNK>
+struct C2PipeCfg {
+  static constexpr int LX = 16, LY = 16;
+  static constexpr int TX = LX * PX, TY = LY;
+  static constexpr int OFFX = 4 - (K - 1) / 2;                     // first needed column of a thread's window
+  static constexpr int IY = (TY - 1) * S + K;
+  static constexpr int IXP = (OFFX + (TX - 1) * S + K + 3) & ~3;
+  static constexpr int Q = IXP / 4;
+  static constexpr int NS = IY * Q;                                // float4 per input channel
+  static constexpr int TILE = NS * 4;
+  static constexpr int NSLOT = (CI_CHUNK * NS + 255) / 256;
+  static constexpr int NIN = (PX - 1) * S + K;
+  static constexpr int NV4 = (OFFX + NIN + 3) / 4;                 // aligned float4 reads covering the window (PX = 4)
+};
+
+template <int K, int S, int PX, int CI_CHUNK, int NCB, int CWE = 8 * NCB>
+__global__ __launch_bounds__(256) void conv2d_pipe_kernel(const float* __restrict__ x, const float* __restrict__ in_affine,
+                                                          const float* __restrict__ wpk, const float* __restrict__ bias,
+                                                          float* __restrict__ out, int N, int Cin, int Cout, int CoutP,
+                                                          int H, int W, int Ho, int Wo, int pad, int act, int tiles_x,
+                                                          int tiles_y) {
+  using Cfg = C2PipeCfg<K, S, PX, CI_CHUNK>;
+  constexpr int CW = CWE;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int co_groups = CoutP / (CO * NCB);
+  const int ntiles = tiles_x * tiles_y;
+  int lin = cds_xcd_remap(blockIdx.x, ntiles * co_groups * N);
+  const int cog = lin % co_groups;
+  lin /= co_groups;
+  const int tile = lin % ntiles;
+  const int n = lin / ntiles;
+  const int tx_i = tile % tiles_x, ty_i = tile / tiles_x;
+  const int co0 = cog * (CO * NCB);
+  const int tid = threadIdx.x;
+  const int lx = tid % Cfg::LX, ly = tid / Cfg::LX;
+  const int ox0 = tx_i * Cfg::TX, oy0 = ty_i * Cfg::TY;
+  const int gx0 = ox0 * S - 4, gy0 = oy0 * S - pad;
+  const size_t plane = (size_t)H * W;
+  const float* __restrict__ xn = x + (size_t)n * Cin * plane;
+  const float* __restrict__ aff = in_affine ? in_affine + (size_t)n * Cin * 3 : nullptr;
+
+  int goff[Cfg::NSLOT];   // element offset of the slot's float4 inside channel ci0 (+ ci * plane), -1 = outside / unused
+#pragma unroll
+  for (int j = 0; j < Cfg::NSLOT; ++j) {
+    const int s = tid + 256 * j;
+    const int ci = s / Cfg::NS;
+    const int r = s - ci * Cfg::NS;
+    const int row = r / Cfg::Q, c4 = r - row * Cfg::Q;
+    const int gy = gy0 + row, gx = gx0 + 4 * c4;
+    const bool ok = (s < CI_CHUNK * Cfg::NS) && gy >= 0 && gy < H && gx >= 0 && gx + 3 < W;   // W % 4 == 0: whole groups
+    goff[j] = ok ? (int)((size_t)ci * plane + (size_t)gy * W + gx) : -1;
+  }
+  float4 pre[Cfg::NSLOT];
+  auto issue = [&](int ci0) {
+    const float* __restrict__ xb = xn + (size_t)ci0 * plane;
+#pragma unroll
+    for (int j = 0; j < Cfg::NSLOT; ++j) {
+      const int ci = (tid + 256 * j) / Cfg::NS;
+      const bool ok = goff[j] >= 0 && ci0 + ci < Cin;
+      pre[j] = *reinterpret_cast<const float4*>(ok ? xb + goff[j] : x);   // branch-free; masked when deposited
+    }
+  };
+
+  float acc[PX][CW];
+#pragma unroll
+  for (int p = 0; p < PX; ++p)
+#pragma unroll
+    for (int c = 0; c < CW; ++c) acc[p][c] = 0.f;
+
+  issue(0);
+  for (int ci0 = 0; ci0 < Cin; ci0 += CI_CHUNK) {
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < Cfg::NSLOT; ++j) {
+      const int s = tid + 256 * j;
+      const int ci = s / Cfg::NS;
+      const bool ok = goff[j] >= 0 && ci0 + ci < Cin;
+      if (s < CI_CHUNK * Cfg::NS) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok) {
+          v = pre[j];
+          if (aff) {   // InstanceNorm + LeakyReLU of the producing layer, in-bounds values only (padding stays zero)
+            const float al = aff[3 * (ci0 + ci)], be = aff[3 * (ci0 + ci) + 1], sl = aff[3 * (ci0 + ci) + 2];
+            float t;
+            t = v.x * al + be; v.x = t > 0.f ? t : t * sl;
+            t = v.y * al + be; v.y = t > 0.f ? t : t * sl;
+            t = v.z * al + be; v.z = t > 0.f ? t : t * sl;
+            t = v.w * al + be; v.w = t > 0.f ? t : t * sl;
+          }
+        }
+        *reinterpret_cast<float4*>(lds + 4 * s) = v;
+      }
+    }
+    __syncthreads();
+    if (ci0 + CI_CHUNK < Cin) issue(ci0 + CI_CHUNK);
+    const int cmax = min(CI_CHUNK, Cin - ci0);
+#pragma unroll 1
+    for (int ci = 0; ci < cmax; ++ci) {
+      const float* __restrict__ wc = wpk + __builtin_amdgcn_readfirstlane(((ci0 + ci) * K * K) * CoutP + co0);
+      const float* tile_ci = lds + ci * Cfg::TILE;
+#pragma unroll 1
+      for (int ky = 0; ky < K; ++ky) {   // not unrolled: one tap row of weights (K x CW scalars) in SGPRs at a time
+        const float* rowp = tile_ci + (ly * S + ky) * Cfg::IXP + lx * PX * S;
+        float in[Cfg::NIN];
+        if constexpr (S == 1 && PX == 4) {
+          float win[4 * Cfg::NV4];   // aligned 16-byte reads covering columns OFFX .. OFFX + NIN - 1 of the window
+#pragma unroll
+          for (int q = 0; q < Cfg::NV4; ++q) {
+            const cds_f4 b = *reinterpret_cast<const cds_f4*>(rowp + 4 * q);
+            win[4 * q] = b.x; win[4 * q + 1] = b.y; win[4 * q + 2] = b.z; win[4 * q + 3] = b.w;
+          }
+#pragma unroll
+          for (int i = 0; i < Cfg::NIN; ++i) in[i] = win[Cfg::OFFX + i];
+        } else {
+#pragma unroll
+          for (int i = 0; i < Cfg::NIN; ++i) in[i] = rowp[Cfg::OFFX + i];
+        }
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx) {
+#pragma unroll
+          for (int c = 0; c < CW; ++c) {
+            const float wv = wc[(ky * K + kx) * CoutP + c];
+#pragma unroll
+            for (int p = 0; p < PX; ++p) acc[p][c] = fmaf(in[p * S + kx], wv, acc[p][c]);
+          }
+        }
+      }
+    }
+  }
+
+  const int oy = oy0 + ly, oxb = ox0 + lx * PX;
+  if (oy >= Ho || oxb >= Wo) return;
+  const size_t oplane = (size_t)Ho * Wo;
+  const bool vec = (PX == 4) && ((Wo & 3) == 0);
+#pragma unroll
+  for (int c = 0; c < CW; ++c) {
+    if (co0 + c < Cout) {
+      const float b = bias ? bias[co0 + c] : 0.f;
+      const size_t base = ((size_t)n * Cout + co0 + c) * oplane + (size_t)oy * Wo + oxb;
+      if (vec) {
+        *reinterpret_cast<float4*>(out + base) = make_float4(cds_act_conv(acc[0][c] + b, act), cds_act_conv(acc[1 % PX][c] + b, act),
+                                                             cds_act_conv(acc[2 % PX][c] + b, act), cds_act_conv(acc[3 % PX][c] + b, act));
+      } else {
+#pragma unroll
+        for (int p = 0; p < PX; ++p)
+          if (oxb + p < Wo) out[base + p] = cds_act_conv(acc[p][c] + b, act);
+      }
+    }
+  }
+}
+
 template <int K, int S, int PX, int CI_CHUNK, int NCB, int CWE = 8 * NCB>
 int launch_conv2d_n(const float* x, const float* aff, const float* w, const float* b, float* out, int N, int Cin, int Cout,
                     int H, int W, int pad, int act, hipStream_t st) {
@@ -169,6 +327,16 @@ int launch_conv2d_n(const float* x, const float* aff, const float* w, const floa
   const int tx = cds_ceil_div(Wo, Cfg::TX), ty = cds_ceil_div(Ho, Cfg::TY);
   const int co_groups = CoutP / (CO * NCB);
   const size_t lds_bytes = (K == 1 && S == 1) ? 0 : (size_t)Cfg::TILE * CI_CHUNK * sizeof(float);
+  if constexpr (K >= 3 && K <= 5) {   // 7x7 / 11x11 amortise their staging already (80+ TF); measured slower here
+    static const bool pipe = []() { const char* e = getenv("CDS_CONV2D_PIPE"); return !(e && e[0] == '0'); }();   // A/B knob
+    if (pipe && W % 4 == 0 && pad == (K - 1) / 2) {
+      using PCfg = C2PipeCfg<K, S, PX, CI_CHUNK>;
+      auto pk = conv2d_pipe_kernel<K, S, PX, CI_CHUNK, NCB, CWE>;
+      hipLaunchKernelGGL(pk, dim3(tx * ty * co_groups * N), dim3(256), (size_t)PCfg::TILE * CI_CHUNK * sizeof(float), st, x, aff,
+                         w, b, out, N, Cin, Cout, CoutP, H, W, Ho, Wo, pad, act, tx, ty);
+      return cds_launch_status();
+    }
+  }
   auto kern = conv2d_kernel<K, S, PX, CI_CHUNK, NCB, CWE>;
   hipLaunchKernelGGL(kern, dim3(tx * ty * co_groups * N), dim3(256), lds_bytes, st, x, aff, w, b, out, N, Cin, Cout, CoutP, H,
                      W, Ho, Wo, pad, act, tx, ty);

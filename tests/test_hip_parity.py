@@ -159,7 +159,12 @@ def test_conv2d_vs_torch(dev, ops):
     g = torch.Generator().manual_seed(1)
     for (n, cin, cout, H, W, k, s) in [(1, 3, 11, 37, 70, 11, 1), (2, 8, 11, 20, 33, 7, 1), (1, 16, 19, 18, 30, 5, 1),
                                        (3, 2, 16, 16, 24, 3, 1), (1, 8, 16, 21, 35, 3, 2), (1, 48, 16, 9, 14, 1, 1),
-                                       (2, 16, 1, 9, 14, 1, 1)]:
+                                       (2, 16, 1, 9, 14, 1, 1),
+                                       # W % 4 == 0: the aligned, register-prefetched "pipe" kernels (partial chunks, tile
+                                       # edges, exact widths 11 / 19 / 35, stride 2, a 4-pixel-wide image)
+                                       (2, 8, 11, 37, 72, 3, 1), (1, 3, 11, 20, 68, 7, 1), (1, 16, 19, 18, 36, 5, 1),
+                                       (1, 32, 35, 19, 44, 3, 1), (1, 8, 16, 21, 36, 3, 2), (2, 16, 32, 17, 132, 3, 2),
+                                       (1, 8, 11, 9, 4, 3, 1), (1, 6, 11, 33, 200, 5, 1), (1, 16, 24, 16, 64, 3, 1)]:
         x = torch.randn(n, cin, H, W, generator=g)
         w = torch.randn(cout, cin, k, k, generator=g) * 0.1
         b = torch.randn(cout, generator=g)
@@ -639,7 +644,8 @@ def test_warp_lds_fallbacks_wild_geometry(dev, ops):
     assert ((vol.cpu() - want).abs()[fin]).max() < 2e-5
 
 
-@pytest.mark.parametrize("k,stride,cin,cout,H,W", [(3, 1, 8, 11, 37, 70), (1, 1, 24, 8, 20, 33), (5, 1, 16, 19, 18, 40), (3, 2, 16, 32, 21, 50)])
+@pytest.mark.parametrize("k,stride,cin,cout,H,W", [(3, 1, 8, 11, 37, 70), (1, 1, 24, 8, 20, 33), (5, 1, 16, 19, 18, 40), (3, 2, 16, 32, 21, 50),
+                                                     (3, 1, 8, 11, 37, 72), (7, 1, 8, 11, 20, 36), (3, 2, 16, 32, 21, 52)])
 def test_conv2d_normalise_on_load_equals_materialised(k, stride, cin, cout, H, W, dev, ops):
     """cds_instnorm_affine_f32 + cds_conv2d_affine_f32 (InstanceNorm + LeakyReLU applied while the input tile is loaded)
     must give what the materialised path gives (cds_instnorm_act_f32 then cds_conv2d_f32), including the zero
