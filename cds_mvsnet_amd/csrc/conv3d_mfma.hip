@@ -43,7 +43,9 @@ struct MCfg {
   static constexpr int NSLOT = (CI_CHUNK * NS + 255) / 256;
 };
 
-template <int S, int VAR>
+// UNAL: W % 4 != 0 (e.g. the 50-wide deepest level of a 1600-wide scene): rows are not 16-byte aligned, the tile is staged
+// with four bounds-checked dword loads per slot instead of one dwordx4 (small layers; the point is to stay on the MFMA path).
+template <int S, int VAR, bool UNAL = false>
 __global__ __launch_bounds__(256, CDS_MFMA_MINW) void conv3d_k3_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wpk,
                                                              const float* __restrict__ bias,
                                                              const float* __restrict__ skip, float* __restrict__ out,
@@ -71,6 +73,7 @@ __global__ __launch_bounds__(256, CDS_MFMA_MINW) void conv3d_k3_mfma_kernel(cons
   // ---- staging slots (same scheme as conv3d_k3_pipe_kernel: aligned float4, one chunk ahead) ----
   int goff[Cfg::NSLOT];
   int loff[Cfg::NSLOT];
+  int gxs[UNAL ? Cfg::NSLOT : 1];   // UNAL: goff is the offset of the row start, the columns are tested one by one
 #pragma unroll
   for (int j = 0; j < Cfg::NSLOT; ++j) {
     const int s = tid + 256 * j;
@@ -79,8 +82,14 @@ __global__ __launch_bounds__(256, CDS_MFMA_MINW) void conv3d_k3_mfma_kernel(cons
     const int row = r / Cfg::Q, c4 = r - row * Cfg::Q;
     const int rz = row / Cfg::IY, ry = row - rz * Cfg::IY;
     const int gz = gz0 + rz, gy = gy0 + ry, gx = gx0 + 4 * c4;
-    const bool ok = (s < Cfg::CI_CHUNK * Cfg::NS) && gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx + 3 < W;
-    goff[j] = ok ? (int)((size_t)ci * vol + (size_t)gz * plane + (size_t)gy * W + gx) : -1;
+    const bool row_ok = (s < Cfg::CI_CHUNK * Cfg::NS) && gz >= 0 && gz < D && gy >= 0 && gy < H;
+    if constexpr (UNAL) {
+      goff[j] = row_ok ? (int)((size_t)ci * vol + (size_t)gz * plane + (size_t)gy * W) : -1;
+      gxs[j] = gx;
+    } else {
+      const bool ok = row_ok && gx >= 0 && gx + 3 < W;
+      goff[j] = ok ? (int)((size_t)ci * vol + (size_t)gz * plane + (size_t)gy * W + gx) : -1;
+    }
     loff[j] = ci * Cfg::SLAB + 4 * r;
   }
   float4 pre[Cfg::NSLOT];
@@ -89,7 +98,16 @@ __global__ __launch_bounds__(256, CDS_MFMA_MINW) void conv3d_k3_mfma_kernel(cons
 #pragma unroll
     for (int j = 0; j < Cfg::NSLOT; ++j) {
       const bool ok = goff[j] >= 0;
-      pre[j] = *reinterpret_cast<const float4*>(ok ? xb + goff[j] : x);
+      if constexpr (UNAL) {
+        const float* __restrict__ rowp = xb + (ok ? goff[j] : 0);
+        const int g = gxs[j];
+        pre[j].x = (ok && (unsigned)(g + 0) < (unsigned)W) ? rowp[g + 0] : 0.f;
+        pre[j].y = (ok && (unsigned)(g + 1) < (unsigned)W) ? rowp[g + 1] : 0.f;
+        pre[j].z = (ok && (unsigned)(g + 2) < (unsigned)W) ? rowp[g + 2] : 0.f;
+        pre[j].w = (ok && (unsigned)(g + 3) < (unsigned)W) ? rowp[g + 3] : 0.f;
+      } else {
+        pre[j] = *reinterpret_cast<const float4*>(ok ? xb + goff[j] : x);
+      }
     }
   };
 
@@ -329,7 +347,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_mfma_cl_kernel(const float* 
   }
 }
 
-template <int S, int VAR>
+template <int S, int VAR, bool UNAL = false>
 int launch_mfma(const float* x, const float* w, const float* b, const float* skip, float* out, int Cin, int Cout, int D,
                 int H, int W, int act, hipStream_t st) {
   using Cfg = MCfg<S, VAR>;
@@ -338,7 +356,7 @@ int launch_mfma(const float* x, const float* w, const float* b, const float* ski
   const int ntiles = tx * ty * tz;
   const size_t lds_bytes = (size_t)Cfg::SLAB * Cfg::CI_CHUNK * sizeof(float);
   static_assert(Cfg::SLAB * Cfg::CI_CHUNK * sizeof(float) <= 65536, "LDS tile above 64 KB");
-  hipLaunchKernelGGL((conv3d_k3_mfma_kernel<S, VAR>), dim3(ntiles * (Cout / 16)), dim3(256), lds_bytes, st, x, w, b, skip, out,
+  hipLaunchKernelGGL((conv3d_k3_mfma_kernel<S, VAR, UNAL>), dim3(ntiles * (Cout / 16)), dim3(256), lds_bytes, st, x, w, b, skip, out,
                      Cin, Cout, D, H, W, Do, Ho, Wo, act, tx, ty, tz, ntiles);
   return cds_launch_status();
 }
@@ -363,7 +381,8 @@ struct MDCfg {
 
 // NCO = 16: N = 16 output channels, x parities in two accumulators.  NCO = 8: N = (cout, x parity) = 8 x 2 in ONE
 // accumulator (2 MFMAs per tap row instead of 3; the B operand of the second one is zero for the even parity).
-template <int NCO>
+// UNAL (NCO = 16 only): W even but not a multiple of 4 — bounds-checked dword staging, output stored per pair of cells.
+template <int NCO, bool UNAL = false>
 __global__ __launch_bounds__(256) void deconv3d_k3s2_mfma_kernel(const float* __restrict__ x,
                                                                  const float* __restrict__ wpk,
                                                                  const float* __restrict__ bias,
@@ -400,7 +419,7 @@ __global__ __launch_bounds__(256) void deconv3d_k3s2_mfma_kernel(const float* __
     const int row = r / Cfg::Q, c4 = r - row * Cfg::Q;
     const int rz = row / Cfg::IY, ry = row - rz * Cfg::IY;
     const int gz = az0 + rz, gy = ay0 + ry, gx = ax0 + 4 * c4;
-    const bool ok = (s < Cfg::CI_CHUNK * Cfg::NS) && gz < D && gy < H && gx + 3 < W;
+    const bool ok = (s < Cfg::CI_CHUNK * Cfg::NS) && gz < D && gy < H && (UNAL ? gx < W : gx + 3 < W);
     goff[j] = ok ? (int)((size_t)ci * vol + (size_t)gz * plane + (size_t)gy * W + gx) : -1;
     loff[j] = ci * Cfg::SLAB + 4 * r;
   }
@@ -408,7 +427,19 @@ __global__ __launch_bounds__(256) void deconv3d_k3s2_mfma_kernel(const float* __
   auto issue = [&](int ci0) {
     const float* __restrict__ xb = x + (size_t)ci0 * vol;
 #pragma unroll
-    for (int j = 0; j < Cfg::NSLOT; ++j) pre[j] = *reinterpret_cast<const float4*>(goff[j] >= 0 ? xb + goff[j] : x);
+    for (int j = 0; j < Cfg::NSLOT; ++j) {
+      if constexpr (UNAL) {
+        const bool ok = goff[j] >= 0;
+        const float* __restrict__ p = xb + (ok ? goff[j] : 0);
+        const int gx = ax0 + 4 * (((tid + 256 * j) % Cfg::NS) % Cfg::Q);
+        pre[j].x = ok ? p[0] : 0.f;                      // gx < W by construction of goff
+        pre[j].y = (ok && gx + 1 < W) ? p[1] : 0.f;
+        pre[j].z = (ok && gx + 2 < W) ? p[2] : 0.f;
+        pre[j].w = (ok && gx + 3 < W) ? p[3] : 0.f;
+      } else {
+        pre[j] = *reinterpret_cast<const float4*>(goff[j] >= 0 ? xb + goff[j] : x);
+      }
+    }
   };
 
   f32x4 acc0[Cfg::NT], acc1[Cfg::NT];
@@ -480,6 +511,7 @@ __global__ __launch_bounds__(256) void deconv3d_k3s2_mfma_kernel(const float* __
       }
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
+        if (UNAL && ax + 2 * half >= W) continue;   // W even: cells come in pairs, a pair = 4 consecutive outputs
         float4 o = make_float4(v[4 * half], v[4 * half + 1], v[4 * half + 2], v[4 * half + 3]);
         if (skip) {
           const float4 s4 = *reinterpret_cast<const float4*>(skip + base + 4 * half);
@@ -515,7 +547,12 @@ __global__ __launch_bounds__(256) void deconv3d_k3s2_mfma_kernel(const float* __
 bool cds_conv3d_mfma_launch(const float* x, const float* w, const float* b, const float* skip, float* out, int Cin,
                             int Cout, int D, int H, int W, int stride, int act, hipStream_t st, int* rc) {
   const int Wo = (W - 1) / stride + 1;
-  if ((Cout % 16) || (Cin % 4) || (W % 4) || Wo < 8 || (size_t)Cin * D * H * W >= (size_t)0x7fffffff) return false;
+  if ((Cout % 16) || (Cin % 4) || Wo < 8 || (size_t)Cin * D * H * W >= (size_t)0x7fffffff) return false;
+  if (W % 4) {   // unaligned rows: same kernels with dword staging
+    if (stride == 1) *rc = launch_mfma<1, 0, true>(x, w, b, skip, out, Cin, Cout, D, H, W, act, st);
+    else *rc = launch_mfma<2, 0, true>(x, w, b, skip, out, Cin, Cout, D, H, W, act, st);
+    return true;
+  }
   static const int s2var = []() { const char* e = getenv("CDS_MFMA_S2VAR"); return e ? atoi(e) : 1; }();   // A/B knob
   if (stride == 1) *rc = launch_mfma<1, 0>(x, w, b, skip, out, Cin, Cout, D, H, W, act, st);
   else if (s2var && Wo >= 256 && Wo % 64 == 0) *rc = launch_mfma<2, 1>(x, w, b, skip, out, Cin, Cout, D, H, W, act, st);
@@ -528,12 +565,17 @@ bool cds_deconv3d_mfma_launch(const float* x, const float* w, const float* b, co
   // Cout % 16 != 0 (conv11, 16 -> 8): the (cout, parity) MFMA variant below is correct but measured slower than the
   // packed-VALU v2 kernel on this memory-bound layer (2.2 vs 1.5 ms at M1), so it is only used when CDS_DECONV_MFMA8=1.
   static const bool mfma8 = []() { const char* e = getenv("CDS_DECONV_MFMA8"); return e && e[0] == '1'; }();
-  if ((Cout % 8) || (Cout % 16 && !mfma8) || (Cin % 4) || (W % 4) || W < 8 || (size_t)Cin * D * H * W >= (size_t)0x7fffffff) return false;
+  if ((Cout % 8) || (Cout % 16 && !mfma8) || (Cin % 4) || (W % 2) || (W % 4 && Cout % 16) || W < 8 ||
+      (size_t)Cin * D * H * W >= (size_t)0x7fffffff)
+    return false;
   using Cfg = MDCfg;
   const int tx = cds_ceil_div(W, Cfg::CX), ty = cds_ceil_div(H, Cfg::CY), tz = cds_ceil_div(D, Cfg::CZ);
   const int ntiles = tx * ty * tz;
   const size_t lds_bytes = (size_t)Cfg::SLAB * Cfg::CI_CHUNK * sizeof(float);
-  if (Cout % 16 == 0)
+  if (W % 4)
+    hipLaunchKernelGGL((deconv3d_k3s2_mfma_kernel<16, true>), dim3(ntiles * (Cout / 16) * 4), dim3(256), lds_bytes, st, x, w, b,
+                       skip, out, Cin, Cout, D, H, W, act, tx, ty, tz, ntiles);
+  else if (Cout % 16 == 0)
     hipLaunchKernelGGL(deconv3d_k3s2_mfma_kernel<16>, dim3(ntiles * (Cout / 16) * 4), dim3(256), lds_bytes, st, x, w, b,
                        skip, out, Cin, Cout, D, H, W, act, tx, ty, tz, ntiles);
   else

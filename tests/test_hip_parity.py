@@ -132,7 +132,10 @@ def test_conv3d_layers_vs_torch(dev, ops):
                                           # Cout % 16 == 0, Cin % 4 == 0: the fp32-MFMA implicit-GEMM kernels
                                           (8, 16, 5, 9, 64, 1), (64, 64, 3, 5, 40, 1), (32, 64, 9, 7, 128, 2),
                                           (4, 48, 2, 6, 76, 2), (12, 16, 7, 3, 132, 1), (32, 64, 6, 16, 40, 2), (64, 64, 3, 8, 20, 1),
-                                          (16, 16, 2, 4, 12, 1)]:
+                                          (16, 16, 2, 4, 12, 1),
+                                          # same kernels with unaligned rows (W % 4 != 0): the 50-wide deepest level of a
+                                          # 1600-wide scene and friends
+                                          (64, 64, 6, 37, 50, 1), (32, 64, 5, 9, 50, 2), (16, 16, 3, 5, 18, 1), (8, 16, 2, 3, 33, 1)]:
         x = torch.randn(cin, D, H, W, generator=g)
         w = torch.randn(cout, cin, 3, 3, 3, generator=g) * 0.1
         b = torch.randn(cout, generator=g)
@@ -142,7 +145,8 @@ def test_conv3d_layers_vs_torch(dev, ops):
         out = ops.conv3d_k3(x.to(dev), wpk, b.to(dev), stride=stride, relu=True, skip=skip.to(dev)).cpu()
         assert (out - (ref + skip)).abs().max() < 2e-5 * max(1.0, ref.abs().max().item()), (cin, cout, stride)
     for (cin, cout, D, H, W) in [(16, 8, 3, 5, 50), (64, 32, 1, 2, 3), (32, 16, 2, 6, 9), (16, 8, 3, 5, 64),
-                                 (10, 16, 2, 3, 36), (32, 16, 3, 3, 100), (64, 32, 3, 5, 40), (8, 48, 1, 6, 68), (64, 32, 3, 8, 20), (32, 16, 2, 4, 8)]:
+                                 (10, 16, 2, 3, 36), (32, 16, 3, 3, 100), (64, 32, 3, 5, 40), (8, 48, 1, 6, 68), (64, 32, 3, 8, 20), (32, 16, 2, 4, 8),
+                                 (64, 32, 6, 37, 50), (32, 16, 3, 5, 18), (16, 16, 2, 4, 10)]:   # W even, not a multiple of 4
         x = torch.randn(cin, D, H, W, generator=g)
         w = torch.randn(cin, cout, 3, 3, 3, generator=g) * 0.1
         b = torch.randn(cout, generator=g)
