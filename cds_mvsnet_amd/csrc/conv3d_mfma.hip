@@ -541,6 +541,160 @@ __global__ __launch_bounds__(256) void deconv3d_k3s2_mfma_kernel(const float* __
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Transposed conv, all four (z, y) output parity classes in ONE workgroup.  The kernel above launches a workgroup per
+// class and each stages the same input tile (PMC: 28-33 % MFMA-pipe utilisation, the rest is staging); here the 27 taps
+// of a staged chunk go to their class accumulators (tap (kz, ky) belongs to class (kz != 1, ky != 1)), so the tile is
+// staged once for 27 MFMAs per M-tile instead of four times for 3 / 6 / 6 / 12.  64 x 4 x 1 input cells per workgroup
+// (4 M-tiles per wave x 4 classes x 2 x-parities = 32 accumulators).  Cout % 16 == 0; UNAL as above.
+// ---------------------------------------------------------------------------------------------
+struct MD4Cfg {
+  static constexpr int CX = 64, CY = 4;                        // input cells per workgroup (one z plane of cells)
+  static constexpr int XT = CX / 16;                           // M-tiles per wave (wave = one y row of cells)
+  static constexpr int IY = CY + 1, IZ = 2;
+  static constexpr int IXP = (CX + 1 + 3) & ~3;                // 68
+  static constexpr int Q = IXP / 4;
+  static constexpr int NS = IZ * IY * Q;
+  static constexpr int SLAB = NS * 4 + 16;
+  static constexpr int CI_CHUNK = 4;
+  static constexpr int NSLOT = (CI_CHUNK * NS + 255) / 256;
+};
+
+template <bool UNAL>
+__global__ __launch_bounds__(256, 2) void deconv3d_k3s2_mfma4_kernel(const float* __restrict__ x, const float* __restrict__ wpk,
+                                                                  const float* __restrict__ bias,
+                                                                  const float* __restrict__ skip, float* __restrict__ out,
+                                                                  int Cin, int Cout, int D, int H, int W, int act,
+                                                                  int tiles_x, int tiles_y, int ntiles) {
+  using Cfg = MD4Cfg;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int co_blocks = Cout / 16;
+  int lin = cds_xcd_remap(blockIdx.x, ntiles * co_blocks);
+  const int cob = lin % co_blocks;
+  int tile = lin / co_blocks;
+  const int tx_i = tile % tiles_x;
+  tile /= tiles_x;
+  const int ty_i = tile % tiles_y;
+  const int az = tile / tiles_y;                               // one plane of cells per workgroup
+  const int co0 = cob * 16;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ax0 = tx_i * Cfg::CX, ay0 = ty_i * Cfg::CY;
+  const size_t plane = (size_t)H * W, vol = (size_t)D * plane;
+
+  int goff[Cfg::NSLOT];
+  int loff[Cfg::NSLOT];
+#pragma unroll
+  for (int j = 0; j < Cfg::NSLOT; ++j) {
+    const int s = tid + 256 * j;
+    const int ci = s / Cfg::NS;
+    int r = s - ci * Cfg::NS;
+    const int row = r / Cfg::Q, c4 = r - row * Cfg::Q;
+    const int rz = row / Cfg::IY, ry = row - rz * Cfg::IY;
+    const int gz = az + rz, gy = ay0 + ry, gx = ax0 + 4 * c4;
+    const bool ok = (s < Cfg::CI_CHUNK * Cfg::NS) && gz < D && gy < H && (UNAL ? gx < W : gx + 3 < W);
+    goff[j] = ok ? (int)((size_t)ci * vol + (size_t)gz * plane + (size_t)gy * W + gx) : -1;
+    loff[j] = ci * Cfg::SLAB + 4 * r;
+  }
+  float4 pre[Cfg::NSLOT];
+  auto issue = [&](int ci0) {
+    const float* __restrict__ xb = x + (size_t)ci0 * vol;
+#pragma unroll
+    for (int j = 0; j < Cfg::NSLOT; ++j) {
+      if constexpr (UNAL) {
+        const bool ok = goff[j] >= 0;
+        const float* __restrict__ p = xb + (ok ? goff[j] : 0);
+        const int gx = ax0 + 4 * (((tid + 256 * j) % Cfg::NS) % Cfg::Q);
+        pre[j].x = ok ? p[0] : 0.f;
+        pre[j].y = (ok && gx + 1 < W) ? p[1] : 0.f;
+        pre[j].z = (ok && gx + 2 < W) ? p[2] : 0.f;
+        pre[j].w = (ok && gx + 3 < W) ? p[3] : 0.f;
+      } else {
+        pre[j] = *reinterpret_cast<const float4*>(goff[j] >= 0 ? xb + goff[j] : x);
+      }
+    }
+  };
+
+  // [class = 2 pz + py][M-tile]: acc0 -> x = 2a, acc1 -> x = 2a + 1
+  f32x4 acc0[4][Cfg::XT], acc1[4][Cfg::XT];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int t = 0; t < Cfg::XT; ++t) acc0[c][t] = acc1[c][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const float* a_base = lds + (lane >> 4) * Cfg::SLAB + wave * Cfg::IXP + (lane & 15);
+  const float* __restrict__ b_base = wpk + (size_t)(lane >> 4) * 27 * Cout + co0 + (lane & 15);
+
+  issue(0);
+  for (int ci0 = 0; ci0 < Cin; ci0 += Cfg::CI_CHUNK) {
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < Cfg::NSLOT; ++j) {
+      const int s = tid + 256 * j;
+      if (s < Cfg::CI_CHUNK * Cfg::NS)
+        *reinterpret_cast<float4*>(lds + loff[j]) = goff[j] >= 0 ? pre[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
+    if (ci0 + Cfg::CI_CHUNK < Cin) issue(ci0 + Cfg::CI_CHUNK);
+    const float* __restrict__ bw = b_base + (size_t)ci0 * 27 * Cout;
+#pragma unroll
+    for (int kz = 0; kz < 3; ++kz) {
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        // output (2a + p) takes tap k from input cell a + (p + 1 - k) / 2: k = 1 -> parity 0, cell a; k = 2 -> parity 1,
+        // cell a; k = 0 -> parity 1, cell a + 1
+        const int cls = (kz != 1 ? 2 : 0) + (ky != 1 ? 1 : 0);
+        const int iz = kz == 0 ? 1 : 0, iy = ky == 0 ? 1 : 0;
+        const float* __restrict__ bt = bw + ((kz * 3 + ky) * 3) * Cout;
+        const float b0 = bt[0], b1 = bt[Cout], b2 = bt[2 * Cout];
+        const float* arow = a_base + (iz * Cfg::IY + iy) * Cfg::IXP;
+#pragma unroll
+        for (int t = 0; t < Cfg::XT; ++t) {
+          const float a0 = arow[t * 16], a1 = arow[t * 16 + 1];
+          acc0[cls][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b1, acc0[cls][t], 0, 0, 0);
+          acc1[cls][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b0, acc1[cls][t], 0, 0, 0);
+          acc1[cls][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b2, acc1[cls][t], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  const int ay = ay0 + wave;
+  if (ay >= H) return;
+  const int co = co0 + (lane & 15);
+  const float b = bias ? bias[co] : 0.f;
+  const int Do = 2 * D, Ho = 2 * H, Wo = 2 * W;
+  const size_t oplane = (size_t)Ho * Wo, ovol = (size_t)Do * oplane;
+#pragma unroll
+  for (int cls = 0; cls < 4; ++cls) {
+    const int pz = cls >> 1, py = cls & 1;
+#pragma unroll
+    for (int t = 0; t < Cfg::XT; ++t) {
+      const int ax = ax0 + t * 16 + (lane >> 4) * 4;   // first of this lane's 4 cells
+      if (ax >= W) continue;
+      const size_t base = (size_t)co * ovol + (size_t)(2 * az + pz) * oplane + (size_t)(2 * ay + py) * Wo + 2 * ax;
+      float v[8] = {acc0[cls][t].x, acc1[cls][t].x, acc0[cls][t].y, acc1[cls][t].y,
+                    acc0[cls][t].z, acc1[cls][t].z, acc0[cls][t].w, acc1[cls][t].w};
+#pragma unroll
+      for (int p = 0; p < 8; ++p) {
+        v[p] += b;
+        if (act == CDS_ACT_RELU) v[p] = fmaxf(v[p], 0.f);
+      }
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        if (UNAL && ax + 2 * half >= W) continue;   // W even: cells come in pairs, a pair = 4 consecutive outputs
+        float4 o = make_float4(v[4 * half], v[4 * half + 1], v[4 * half + 2], v[4 * half + 3]);
+        if (skip) {
+          const float4 s4 = *reinterpret_cast<const float4*>(skip + base + 4 * half);
+          o.x = s4.x + o.x; o.y = s4.y + o.y; o.z = s4.z + o.z; o.w = s4.w + o.w;
+        }
+        *reinterpret_cast<float4*>(out + base + 4 * half) = o;
+      }
+    }
+  }
+}
+
 }  // namespace
 
 // Returns false when the shape is not covered (caller falls back to the VALU kernels).
@@ -572,6 +726,24 @@ bool cds_deconv3d_mfma_launch(const float* x, const float* w, const float* b, co
   const int tx = cds_ceil_div(W, Cfg::CX), ty = cds_ceil_div(H, Cfg::CY), tz = cds_ceil_div(D, Cfg::CZ);
   const int ntiles = tx * ty * tz;
   const size_t lds_bytes = (size_t)Cfg::SLAB * Cfg::CI_CHUNK * sizeof(float);
+  static const bool split = []() { const char* e = getenv("CDS_DECONV_MFMA_SPLIT"); return e && e[0] == '1'; }();   // A/B knob
+  using C4 = MD4Cfg;
+  const int tx4 = cds_ceil_div(W, C4::CX), ty4 = cds_ceil_div(H, C4::CY);
+  const int nt4 = tx4 * ty4 * D;
+  // all four parity classes per workgroup (the input tile is staged once, not four times): 64->32 at 80x64x24 399 -> 339 us,
+  // 32->16 at 160x128x48 695 -> 635 us; levels too small to give every CU a workgroup keep the one-class-per-workgroup kernel
+  // (50x37x6: 63 vs 81 us)
+  if (Cout % 16 == 0 && !split && (long)nt4 * (Cout / 16) >= 256) {
+    const size_t lds4 = (size_t)C4::SLAB * C4::CI_CHUNK * sizeof(float);
+    if (W % 4)
+      hipLaunchKernelGGL(deconv3d_k3s2_mfma4_kernel<true>, dim3(nt4 * (Cout / 16)), dim3(256), lds4, st, x, w, b, skip, out, Cin,
+                         Cout, D, H, W, act, tx4, ty4, nt4);
+    else
+      hipLaunchKernelGGL(deconv3d_k3s2_mfma4_kernel<false>, dim3(nt4 * (Cout / 16)), dim3(256), lds4, st, x, w, b, skip, out,
+                         Cin, Cout, D, H, W, act, tx4, ty4, nt4);
+    *rc = cds_launch_status();
+    return true;
+  }
   if (W % 4)
     hipLaunchKernelGGL((deconv3d_k3s2_mfma_kernel<16, true>), dim3(ntiles * (Cout / 16) * 4), dim3(256), lds_bytes, st, x, w, b,
                        skip, out, Cin, Cout, D, H, W, act, tx, ty, tz, ntiles);
