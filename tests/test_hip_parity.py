@@ -146,7 +146,8 @@ def test_conv3d_layers_vs_torch(dev, ops):
         assert (out - (ref + skip)).abs().max() < 2e-5 * max(1.0, ref.abs().max().item()), (cin, cout, stride)
     for (cin, cout, D, H, W) in [(16, 8, 3, 5, 50), (64, 32, 1, 2, 3), (32, 16, 2, 6, 9), (16, 8, 3, 5, 64),
                                  (10, 16, 2, 3, 36), (32, 16, 3, 3, 100), (64, 32, 3, 5, 40), (8, 48, 1, 6, 68), (64, 32, 3, 8, 20), (32, 16, 2, 4, 8),
-                                 (64, 32, 6, 37, 50), (32, 16, 3, 5, 18), (16, 16, 2, 4, 10)]:   # W even, not a multiple of 4
+                                 (64, 32, 6, 37, 50), (32, 16, 3, 5, 18), (16, 16, 2, 4, 10),   # W even, not a multiple of 4
+                                 (32, 32, 8, 40, 132), (16, 32, 10, 44, 66)]:   # >= 256 workgroups: the four-classes-per-workgroup kernel
         x = torch.randn(cin, D, H, W, generator=g)
         w = torch.randn(cin, cout, 3, 3, 3, generator=g) * 0.1
         b = torch.randn(cout, generator=g)
