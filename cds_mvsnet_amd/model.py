@@ -505,7 +505,10 @@ class StageNet(nn.Module):
         depths, confs, ncs = [], [], []
         for b in range(B):
             ref = torch.stack([f["ref"][0][b] for f in features]).contiguous()
-            src = torch.stack([ops.chw_to_hwc(f["src"][0][b].contiguous()) for f in features])
+            C, h, w = ref.shape[1:]
+            src = torch.empty((V, h, w, C), dtype=torch.float32, device=ref.device)
+            for v, f in enumerate(features):   # transposed straight into the stacked buffer (no second copy)
+                ops.chw_to_hwc(f["src"][0][b].contiguous(), out=src[v])
             ref_nc = torch.stack([f["ref"][2][b, 0] for f in features]).contiguous()
             nc_sums = ops.pair_mean(torch.stack([f["ref"][1][b, 0] for f in features] +
                                                 [f["src"][1][b, 0] for f in features]), V)

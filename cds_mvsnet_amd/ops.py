@@ -76,9 +76,13 @@ def version() -> int:
     return _lib.load().cds_version()
 
 
-def chw_to_hwc(x: Tensor) -> Tensor:
+def chw_to_hwc(x: Tensor, out: Optional[Tensor] = None) -> Tensor:
+    """[C,h,w] -> channels-last [h,w,C] (the layout K1 / K3 gather from); written into `out` if given."""
     C, h, w = x.shape
-    out = torch.empty((h, w, C), dtype=torch.float32, device=x.device)
+    if out is None:
+        out = torch.empty((h, w, C), dtype=torch.float32, device=x.device)
+    elif tuple(out.shape) != (h, w, C) or not out.is_contiguous() or out.dtype != torch.float32 or out.device != x.device:
+        raise ValueError(f"chw_to_hwc: out must be a contiguous float32 [{h},{w},{C}] tensor on {x.device}")
     check(_lib.load().cds_chw_to_hwc_f32(_dev(x, "x"), out.data_ptr(), C, h, w, _stream(x)), "cds_chw_to_hwc_f32")
     return out
 
