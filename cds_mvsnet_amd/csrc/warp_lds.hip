@@ -2,9 +2,9 @@
 //
 // The direct kernels in warp.hip gather 4 taps x 32 B per (voxel, view) through the vector L1 and are
 // bound by its address/tag rate (measured 1.4-1.8 ms at M1 against 0.3-0.5 ms of HBM time).  Here a
-// workgroup owns a 64x4 tile of reference pixels; for a chunk of DC consecutive depth planes the source
+// workgroup owns a 32x8 tile of reference pixels; for a chunk of DC consecutive depth planes the source
 // footprint of the tile is a thin parallelogram along the epipolar line (~0.15 px per plane at M1), so its
-// bounding box (tile + halo, ~70x7 texels = 16 KB per view) is staged once into LDS with coalesced 16-byte
+// bounding box (tile + halo, ~40x10 texels = 13 KB per view) is staged once into LDS with coalesced 16-byte
 // loads and reused by every plane of the chunk and every pixel of the tile; the taps are then ds_read_b128s.
 //
 // LDS image of a box: two planes [BH][BW] of float4 (channels 0-3 and 4-7) so that consecutive lanes, which
@@ -19,11 +19,16 @@
 
 namespace {
 
+// Tile and chunk geometry (A/B through scripts/build_variant.sh).  A 32x8 tile has a smaller source footprint than 64x4
+// for the same 256 pixels ((34 + parallax) x 10 against (66 + parallax) x 6 texels), so fewer chunks are halved and less
+// is staged: K3 at M1 1.07 -> 0.96 ms, cascade stage 2 0.60 -> 0.55 ms; 48-plane chunks make the D = 48 stage a single
+// chunk (stage 1 of the 1600x1184 cascade: 0.77 -> 0.48 ms) and change nothing at D = 192; 64-plane chunks overflow the
+// box too often (1.19 ms at M1); 16x16 tiles and 3 waves per SIMD (spills) are slower.
 #ifndef CDS_K3_TW
-#define CDS_K3_TW 64
-#define CDS_K3_TH 4
+#define CDS_K3_TW 32
+#define CDS_K3_TH 8
 #define CDS_K3_BOX 504
-#define CDS_K3_DC 32
+#define CDS_K3_DC 48
 #define CDS_K3_MINW 2
 #endif
 constexpr int C8 = 8;
