@@ -23,11 +23,13 @@ namespace {
 // for the same 256 pixels ((34 + parallax) x 10 against (66 + parallax) x 6 texels), so fewer chunks are halved and less
 // is staged: K3 at M1 1.07 -> 0.96 ms, cascade stage 2 0.60 -> 0.55 ms; 48-plane chunks make the D = 48 stage a single
 // chunk (stage 1 of the 1600x1184 cascade: 0.77 -> 0.48 ms) and change nothing at D = 192; 64-plane chunks overflow the
-// box too often (1.19 ms at M1); 16x16 tiles and 3 waves per SIMD (spills) are slower.
+// box too often (1.19 ms at M1); 16x16 tiles and 3 waves per SIMD (spills) are slower.  Box budget 632 texels per view
+// (4 views: 79 KB, two workgroups per CU still fit the 160 KB): fewer halved chunks than with 504 (0.96 -> 0.90-0.93 ms at M1,
+// stage 1 of the cascade 0.48 -> 0.42 ms); 568 is in between, 440 clearly worse (1.12 ms).
 #ifndef CDS_K3_TW
 #define CDS_K3_TW 32
 #define CDS_K3_TH 8
-#define CDS_K3_BOX 504
+#define CDS_K3_BOX 632
 #define CDS_K3_DC 48
 #define CDS_K3_MINW 2
 #endif
@@ -350,7 +352,7 @@ __device__ __forceinline__ void plane_weights(v2f ix, v2f iy, v2f& x0f, v2f& y0f
 }
 
 // ---------------------------------------------------------------------------------------------
-// K3 with LDS-staged boxes, C = 8, V <= 4 (all views of a chunk resident: 4 x 15.75 KB).
+// K3 with LDS-staged boxes, 8 channels per workgroup, V <= 4 (all views of a chunk resident: 4 x 19.75 KB).
 // Two planes per iteration so the position / weight arithmetic issues as packed fp32 (v_pk_*).
 // Accumulation: volume += (ref*vis) * warp as one fma per channel (re-association of the reference's
 // (ref*warp)*vis, <= 2 ulp of a value below 1).  Normalisation a/(vis_sum+1e-6): reciprocal refined once per
