@@ -13,9 +13,12 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+#ifndef CDS_V16_RW
+#define CDS_V16_RW 2   // tile rows per wave (A/B: 1 -> 64x4 tile, 28 KB of LDS; 4 -> 64x16 tile, 83 KB)
+#endif
 struct V16Cfg {
-  static constexpr int TX = 64, TY = 8, XT = TX / 16;
-  static constexpr int RW = 2;                       // tile rows per wave
+  static constexpr int RW = CDS_V16_RW;              // tile rows per wave
+  static constexpr int TX = 64, TY = 4 * RW, XT = TX / 16;
   static constexpr int NT = XT * RW;                 // M-tiles per wave
   static constexpr int IY = TY + 2;
   static constexpr int IXP = TX + 8;                 // column c <-> x = ox0 - 4 + c (16-byte aligned global rows)
