@@ -565,9 +565,25 @@ class CDSMVSNet(nn.Module):
         epi = []
         for cam_src in cam_srcs:
             epi.append(geometry.pair_epipoles(cam_ref, cam_src))
-        epipoles = torch.tensor([e[0] for e in epi] + [e[1] for e in epi], dtype=torch.float32)
-        batch = torch.stack([ref_img] * V + list(src_imgs))
-        return self._feature_runner[0](batch, epipoles, T, n_chw=V, n_shared=V)
+        G = ops.MAX_IMAGES // 2   # pairs per batched pass (2 images per pair); more views run in groups
+        parts = []
+        for v0 in range(0, V, G):
+            g = epi[v0:v0 + G]
+            epipoles = torch.tensor([e[0] for e in g] + [e[1] for e in g], dtype=torch.float32)
+            batch = torch.stack([ref_img] * len(g) + list(src_imgs[v0:v0 + G]))
+            parts.append((len(g), self._feature_runner[0](batch, epipoles, T, n_chw=len(g), n_shared=len(g))))
+        if len(parts) == 1:
+            return parts[0][1]
+        out = {}
+        for name in parts[0][1]:
+            chw = torch.cat([p[name][0] for _, p in parts])
+            hwc = torch.cat([p[name][1] for _, p in parts])
+            # per-image maps are ordered [reference copies ..., sources ...] inside a group: regroup to that order overall
+            maps = []
+            for k in (2, 3):
+                maps.append(torch.cat([p[name][k][:n] for n, p in parts] + [p[name][k][n:] for n, p in parts]))
+            out[name] = (chw, hwc, maps[0], maps[1])
+        return out
 
     def forward(self, imgs, proj_matrices, depth_values, gt_depths=None, temperature=0.001):
         if not imgs.is_cuda:

@@ -750,3 +750,27 @@ def test_conv2d_c16_mfma_against_torch(dev, ops, N, H, W):
     assert (got_h.cpu() - head).abs().max() < 1e-5
     with pytest.raises(ValueError):
         ops.conv2d_k3_c16(x[:, :, :, :3].contiguous().to(dev), wcl, None)
+
+
+@pytest.mark.parametrize("N", [2, 10])
+def test_full_forward_view_counts(dev, seeded_state, N):
+    """Whole model against the CPU oracle with a single source view (V = 1 kernels) and with 9 source views: more than
+    one batched FeatureNet pass (CDS_MAX_IMAGES / 2 pairs each) and more than CDS_MAX_VIEWS views in K1 / K3 (chunked
+    launches, two-pass aggregation)."""
+    from cds_mvsnet_amd import synth
+    from oracle import cds_oracle as O
+    H, W = 64, 96
+    model = seeded_state(False)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    imgs = synth.make_images(N, H, W, seed=13)
+    cams = synth.make_cameras(N, H, W, refine=False, seed=13)
+    dv = synth.make_depth_values()
+    want = O.forward(imgs, cams, dv, sd, refine=False, temperature=0.01, exact=False)
+    model = model.to(dev)
+    with torch.no_grad():
+        got = model(imgs.to(dev), cams, dv, temperature=0.01)
+    for s in (1, 2, 3):
+        a, b = got[f"stage{s}"], want[f"stage{s}"]
+        assert (a["depth"].cpu() - b["depth"]).abs().mean() < 1e-3, s
+        assert (a["photometric_confidence"].cpu() - b["photometric_confidence"]).abs().mean() < 1e-3, s
+        assert (a["norm_curv"].cpu() - b["norm_curv"]).abs().max() < 1e-4, s
