@@ -603,8 +603,8 @@ __device__ __forceinline__ void online_entropy_update(float s, float& mx, float&
 #define CDS_K1_MINW 4   // 4 waves per SIMD (32.6 KB of LDS per workgroup allows it): 0.82 -> 0.79 ms at M1
 #endif
 // NG = groups of 8 channels (C = 8 NG); the box of a view holds all of them: 2 NG planes of CAP float4.
-// C = 8: CAP 1016 texels, 64-plane chunks (32 KB);  C = 16: 504 texels, 32 planes (32 KB);  C = 32: 504 texels,
-// 32 planes (63 KB, two workgroups per CU).  A box that does not fit halves its chunk, as in K3.
+// C = 8: CAP 1016 texels, 64-plane chunks (32 KB);  C = 16 / 32: the K3 budget (CDS_K3_BOX texels, CDS_K3_DC planes: 40 /
+// 79 KB, two workgroups per CU at C = 32).  A box that does not fit halves its chunk, as in K3.
 template <int NG, int CAP, int DCK>
 __global__ __launch_bounds__(256, (NG == 4 ? 2 : CDS_K1_MINW)) void warp_entropy_lds_kernel(
     const float* __restrict__ ref, const float* __restrict__ src, WarpMats mats, const float* __restrict__ hyp,
