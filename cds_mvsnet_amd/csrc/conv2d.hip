@@ -1,9 +1,16 @@
 // 2D feature path:
-//   cds_conv2d_f32         direct LDS-tiled k x k convolution (k in 1,3,5,7,11; stride 1|2)
+//   cds_conv2d_f32 / cds_conv2d_affine_f32   direct LDS-tiled k x k convolution (k in 1,3,5,7,11; stride 1|2), optionally
+//                          with the producing layer's InstanceNorm + LeakyReLU applied while the tile is loaded
 //                          models/module.py:28-71, models/dynamic_conv.py:86-87,112,116, model.py:14
-//   cds_dynconv_blend_f32  DynamicConv epilogue: epipolar curvature projection, 1x1 MLP,
-//                          softmax(./T), blend                       models/dynamic_conv.py:97-122
-//   cds_instnorm_act_f32   InstanceNorm2d (+LeakyReLU(0.1) | tanh)   models/module.py:53,66-69,223
+//       conv2d_kernel        row-per-wave staging (any width; the 7x7 / 11x11 layers, 1x1 straight from global memory)
+//       conv2d_pipe_kernel   aligned 16-byte staging with register prefetch (3x3 / 5x5, W % 4 == 0)
+//   cds_conv2d_fpn_f32     FPN lateral: 1x1 convolution over the virtual nearest-2x up-sample + concatenation
+//                          models/module.py:253-254,260-261
+//   cds_dynconv_blend*_f32 DynamicConv epilogue: epipolar curvature projection, 1x1 MLP, softmax(./T), blend; the
+//                          _stats variant also leaves the InstanceNorm records of its output   models/dynamic_conv.py:97-122
+//   cds_instnorm_*_f32     InstanceNorm2d (+LeakyReLU(0.1) | tanh): two-pass (act), statistics only (affine), fixed-order
+//                          reduction of in-kernel records (reduce), normalisation for given statistics (apply)
+//                          models/module.py:53,66-69,223
 //
 // Convolution scheme (same as conv3d.hip): input tile + halo of CI_CHUNK channels in LDS, PX
 // x-adjacent outputs x 8 output channels of accumulators per thread, weights packed
