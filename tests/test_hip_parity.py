@@ -274,7 +274,7 @@ def test_featurenet(dev, seeded_state):
         out = {s: (o[s][0][0], o[s][2][0], o[s][3][0]) for s in o}
         out_hwc = {s: (o2[s][1][0],) for s in o2}
         # 9 InstanceNorm'd layers deep; at T=0.01 the softmax(./T) blend amplifies fp32 round-off of the
-        # curvature responses by up to 0.25/T per layer (per-layer errors measured with scripts/diag_featurenet.py:
+        # curvature responses by up to 0.25/T per layer (per-layer errors measured with tests/tools/diag_featurenet.py:
         # <=3e-5 at T=1, <=3e-4 at T=0.01, InstanceNorm itself 5e-7) -> bound the mean tightly, the max loosely.
         for s in ("stage1", "stage2", "stage3"):
             for j, key in enumerate(("fea", "ncsum", "nc")):
@@ -680,10 +680,10 @@ def test_conv2d_normalise_on_load_equals_materialised(k, stride, cin, cout, H, W
 def test_warp_kernels_random_shapes_against_oracle(dev, seed):
     """Seeded fuzz of K1 / K3 (C = 8 LDS kernels and their direct fallbacks): random view counts 1..4,
     plane counts around the 32-plane chunk boundary, ragged widths / heights, short and long baselines and
-    per-pixel hypothesis jitter, each compared with the oracle's explicit gather (scripts/fuzz_warp.py)."""
+    per-pixel hypothesis jitter, each compared with the oracle's explicit gather (tests/tools/fuzz_warp.py)."""
     import importlib.util
     import random
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "fuzz_warp.py")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "fuzz_warp.py")
     spec = importlib.util.spec_from_file_location("fuzz_warp", path)
     fuzz = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(fuzz)

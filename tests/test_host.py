@@ -84,6 +84,12 @@ def test_product_path_does_not_import_the_oracle():
             src = open(os.path.join(pkg, fn)).read()
             assert "oracle" not in src.replace("SURVEY", ""), fn
             assert "/root/reference" not in src, fn
+    # helper scripts outside tests/ (timing, profiling, variant builds) must not touch the oracle either: the fuzzers
+    # that compare against it live under tests/tools/
+    scripts = os.path.join(ROOT, "scripts")
+    for fn in os.listdir(scripts):
+        if fn.endswith((".py", ".sh")):
+            assert "oracle" not in open(os.path.join(scripts, fn)).read(), fn
 
 
 def test_synthetic_inputs_are_deterministic():

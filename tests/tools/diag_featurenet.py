@@ -1,6 +1,6 @@
 """Per-layer FeatureNet error (GPU layer fed with the oracle's input) — diagnostic, run on the GPU box."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch, torch.nn.functional as F
 from cds_mvsnet_amd import FeatureNet, seeded_init_, ops
 from cds_mvsnet_amd.model import _FeatureRunner

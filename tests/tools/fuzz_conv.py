@@ -1,7 +1,7 @@
 """Random-shape fuzz of the 3D / 2D convolution entry points against PyTorch fp32 on the CPU (tile edges, unaligned widths,
 every kernel family the dispatchers can pick).  Usage: fuzz_conv.py [seed] [cases]"""
 import os, sys, random
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import torch.nn.functional as F
 from cds_mvsnet_amd import ops

@@ -2,7 +2,7 @@
 cross-pair sharing) against the CPU oracle.  Sizes are multiples of 4, so the coarse levels get widths that are not multiples
 of 4 (the aligned 'pipe' kernels step aside there).  Usage: fuzz_feature.py [seed] [cases]"""
 import os, sys, random
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from cds_mvsnet_amd import FeatureNet, seeded_init_
 from cds_mvsnet_amd.model import _FeatureRunner

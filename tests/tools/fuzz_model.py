@@ -1,7 +1,7 @@
 """Random-configuration fuzz of the whole CDSMVSNet forward (sizes, view counts, refinement, batch) against the CPU oracle.
 Usage: fuzz_model.py [seed] [cases]"""
 import os, sys, random
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from cds_mvsnet_amd import CDSMVSNet, seeded_init_, synth
 from oracle import cds_oracle as O

@@ -1,7 +1,7 @@
 """Random-shape fuzz of K5 (soft-argmin + confidence) and K6 (depth hypotheses) against the CPU oracle.
 Usage: fuzz_regress.py [seed] [cases]"""
 import os, sys, random
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from cds_mvsnet_amd import ops
 from oracle import cds_oracle as O

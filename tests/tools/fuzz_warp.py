@@ -1,6 +1,6 @@
 """Fuzz of the LDS K1/K3 kernels (C = 8/16/32, V = 1..6) against the CPU oracle on random shapes / cameras."""
 import os, sys, random
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from cds_mvsnet_amd import ops, synth, geometry
 from oracle import cds_oracle as O
