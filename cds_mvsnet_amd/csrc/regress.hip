@@ -34,21 +34,32 @@ __global__ __launch_bounds__(256) void softargmin_conf_kernel(const float* __res
   const int d0 = slice * chunk;
   const int d1 = min(D, d0 + chunk);
 
-  float m = -INFINITY;
-  for (int d = d0; d < d1; ++d) m = fmaxf(m, pre[(size_t)d * hw + p]);
-  m = cds_slice_max(m);
-
-  float Z = 0.f, Sd = 0.f, Si = 0.f;
+  // one pass over the logits (online softmax: the running maximum rescales the partial sums when it moves), so the
+  // volume is read once instead of twice; the four slices of a pixel are merged with their own rescale factors
+  float m = -INFINITY, Z = 0.f, Sd = 0.f, Si = 0.f;
   for (int d = d0; d < d1; ++d) {
-    float e = expf(pre[(size_t)d * hw + p] - m);
-    float hv = hyp_pp ? hyp[(size_t)d * hw + p] : hyp[d];
+    const float x = pre[(size_t)d * hw + p];
+    const float hv = hyp_pp ? hyp[(size_t)d * hw + p] : hyp[d];
+    if (x > m) {                      // also taken on the first plane (m = -inf: the sums are still zero)
+      const float sc = expf(m - x);   // exp(-inf) = 0
+      Z *= sc;
+      Sd *= sc;
+      Si *= sc;
+      m = x;
+    }
+    const float e = expf(x - m);
     Z += e;
     Sd = fmaf(e, hv, Sd);
     Si = fmaf(e, (float)d, Si);
   }
-  Z = cds_slice_sum(Z);
-  Sd = cds_slice_sum(Sd);
-  Si = cds_slice_sum(Si);
+  {
+    const float M = cds_slice_max(m);
+    const float sc = (d0 < d1) ? expf(m - M) : 0.f;   // a slice without planes (D < 4) contributes nothing
+    Z = cds_slice_sum(Z * sc);
+    Sd = cds_slice_sum(Sd * sc);
+    Si = cds_slice_sum(Si * sc);
+    m = M;
+  }
   const float inv = 1.0f / Z;
 
   // confidence: slice k contributes probability at index i-1+k (zero outside [0,D))
