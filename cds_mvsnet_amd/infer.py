@@ -21,12 +21,71 @@ from . import CDSMVSNet, seeded_init_
 from .mvs_io import EvalScenes, save_outputs
 
 
-def load_checkpoint(model: torch.nn.Module, path: str) -> None:
-    """Reference checkpoints: {'state_dict': ...} with a 'module.' prefix when saved under DataParallel (test.py:180-187)."""
-    ck = torch.load(path, map_location="cpu", weights_only=False)
-    sd = ck["state_dict"] if "state_dict" in ck else ck
+class _Opaque:
+    """Inert stand-in for a class the checkpoint pickles but this process does not have (the reference's
+    ``parse_config.ConfigParser`` rides along in its checkpoints): accepts any construction / state, does nothing."""
+
+    def __init__(self, *a, **k):
+        pass
+
+    def __setstate__(self, state):
+        pass
+
+    def __call__(self, *a, **k):
+        return _Opaque()
+
+
+_SAFE_BUILTINS = {"set", "frozenset", "list", "dict", "tuple", "int", "float", "bool", "str", "bytes", "bytearray",
+                  "complex", "slice", "range", "object"}
+
+
+class _placeholder_pickle:
+    """A ``pickle_module`` for ``torch.load`` whose unpickler resolves torch / collections / a few builtin globals and
+    replaces every other global by :class:`_Opaque` instead of importing it — foreign objects in a checkpoint can neither
+    fail the load nor run code."""
+    import pickle as _pickle
+    __name__ = "cds_mvsnet_amd.infer._placeholder_pickle"
+
+    class Unpickler(_pickle.Unpickler):
+        def find_class(self, module, name):
+            root = module.split(".")[0]
+            if root in ("torch", "collections", "_codecs") or (root == "numpy" and name in ("dtype", "ndarray", "_reconstruct", "scalar")) \
+                    or (root == "numpy" and module.startswith("numpy.core.multiarray")) \
+                    or (module == "builtins" and name in _SAFE_BUILTINS):
+                return super().find_class(module, name)
+            return _Opaque
+
+    @staticmethod
+    def load(f, **kw):
+        return _placeholder_pickle.Unpickler(f, **kw).load()
+
+
+def load_checkpoint(model: torch.nn.Module, path: str, trust_pickle: bool = False) -> None:
+    """Reference checkpoints: {'state_dict': ...} with a 'module.' prefix when saved under DataParallel (test.py:180-187).
+
+    Loaded with ``weights_only=True`` (tensors only).  The checkpoints the reference ships also pickle their
+    ``ConfigParser``, which that mode refuses: pass ``trust_pickle=True`` (``--trust-checkpoint``) to read such a file
+    through a restricted unpickler that turns every non-torch class into an inert placeholder (the reference itself
+    does a full ``torch.load``).  Keys are checked: anything missing from the file, or unexpected in it, raises (the
+    reference loads with ``strict=False`` and silently keeps random weights); exempt are ``num_batches_tracked`` counters and,
+    for a model built with ``refine=False``, the ``refine_network.*`` entries of a checkpoint trained with refinement."""
+    try:
+        ck = torch.load(path, map_location="cpu", weights_only=True)
+    except Exception as e:
+        if not trust_pickle:
+            raise RuntimeError(f"{path}: not loadable with weights_only=True ({type(e).__name__}: {str(e)[:200]}). "
+                               "If the file is trusted, retry with trust_pickle=True / --trust-checkpoint.") from e
+        ck = torch.load(path, map_location="cpu", weights_only=False, pickle_module=_placeholder_pickle)
+    sd = ck["state_dict"] if isinstance(ck, dict) and "state_dict" in ck else ck
     sd = {k[len("module."):] if k.startswith("module.") else k: v for k, v in sd.items()}
-    model.load_state_dict(sd, strict=False)
+    res = model.load_state_dict(sd, strict=False)
+    has_refine = hasattr(model, "refine_network")
+    missing = [k for k in res.missing_keys if not k.endswith("num_batches_tracked")]
+    unexpected = [k for k in res.unexpected_keys
+                  if not k.endswith("num_batches_tracked") and (has_refine or not k.startswith("refine_network."))]
+    if missing or unexpected:
+        raise RuntimeError(f"{path}: state dict does not match the model: {len(missing)} missing "
+                           f"(e.g. {missing[:3]}), {len(unexpected)} unexpected (e.g. {unexpected[:3]})")
 
 
 def run(args) -> float:
@@ -40,7 +99,7 @@ def run(args) -> float:
                       dataset=args.dataset)
     model = CDSMVSNet(refine=args.refine, ndepths=(48, 32, 8), depth_interals_ratio=(4.0, 1.5, 0.75))
     if args.resume:
-        load_checkpoint(model, args.resume)
+        load_checkpoint(model, args.resume, trust_pickle=args.trust_checkpoint)
     else:
         seeded_init_(model, 0)  # no checkpoint given: deterministic synthetic weights (plumbing runs)
     model = model.to(dev).eval()
@@ -89,6 +148,8 @@ def main(argv=None):
     ap.add_argument("--testlist", required=True)
     ap.add_argument("--outdir", required=True)
     ap.add_argument("--resume", default=None)
+    ap.add_argument("--trust-checkpoint", dest="trust_checkpoint", action="store_true",
+                    help="allow full unpickling of --resume (the reference's shipped checkpoints need it; runs arbitrary code)")
     ap.add_argument("--refine", action="store_true")
     ap.add_argument("--num_view", type=int, default=5)
     ap.add_argument("--numdepth", type=int, default=192)

@@ -28,6 +28,83 @@ BN_EPS = 1e-5
 
 
 # ------------------------------------------------------------------------------------------------
+# weight folding / packing
+# ------------------------------------------------------------------------------------------------
+def _bn_fold(bn: nn.Module) -> Tuple[Tensor, Tensor]:
+    """Eval-mode BatchNorm as y = x*scale + shift."""
+    scale = bn.weight.detach() / torch.sqrt(bn.running_var + bn.eps)
+    shift = bn.bias.detach() - bn.running_mean * scale
+    return scale, shift
+
+
+def _pack2d(w: Tensor) -> Tensor:
+    """[Cout,Cin,k,k] -> [Cin,k*k,CoutP] (cout fastest, zero padded to a multiple of 8)."""
+    cout, cin, k, _ = w.shape
+    p = w.permute(1, 2, 3, 0).reshape(cin, k * k, cout)
+    pad = (-cout) % 8
+    if pad:
+        p = F.pad(p, (0, pad))
+    return p.contiguous()
+
+
+class _Packed:
+    """Lazily built cache of the folded / packed weights of one holder module, one entry per device.
+
+    An entry is rebuilt when the holder's parameters / buffers were replaced or modified through autograd-visible
+    in-place ops (``data_ptr`` / ``_version`` signature), and the holders drop the whole cache from ``_apply`` (``.to()``,
+    ``.cuda()``, ``.float()``), ``train()`` / ``eval()`` and ``load_state_dict``.  Edits through ``.data``
+    (``p.data.copy_()``, EMA swaps) keep both the pointer and the version: call :meth:`CDSMVSNet.repack` after them.
+    ``nn.DataParallel`` replicas (``_is_replica``: shallow copies that share this object and receive freshly broadcast
+    weight tensors on every forward, base/base_trainer.py:17-18, test.py:185-186) are never cached: they pack from
+    their own tensors each call."""
+
+    def __init__(self):
+        self._entries: Dict[object, Tuple[tuple, Dict[str, Tensor]]] = {}
+
+    def invalidate(self) -> None:
+        self._entries = {}
+
+    @staticmethod
+    def _tensors(owner: nn.Module) -> List[Tensor]:
+        return list(owner.parameters()) + list(owner.buffers())
+
+    def get(self, owner: nn.Module, builder) -> Dict[str, Tensor]:
+        if getattr(owner, "_is_replica", False):
+            with torch.no_grad():
+                return builder()
+        ts = self._tensors(owner)
+        key = ts[0].device if ts else None
+        sig = tuple((t.data_ptr(), t._version) for t in ts)
+        hit = self._entries.get(key)
+        if hit is None or hit[0] != sig:
+            with torch.no_grad():
+                hit = (sig, builder())
+            self._entries[key] = hit
+        return hit[1]
+
+
+class _PackedHolder(nn.Module):
+    """Mixin of the modules that own a :class:`_Packed` cache: every way PyTorch itself rewrites parameters drops it."""
+
+    def _init_packed(self) -> None:
+        self._packed = _Packed()
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module._packed.invalidate())
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        self._packed.invalidate()
+        return out
+
+    def train(self, mode: bool = True):
+        self._packed.invalidate()
+        return super().train(mode)
+
+    def repack(self) -> None:
+        """Forget the packed weights (needed after edits that bypass autograd's version counter, e.g. ``p.data``)."""
+        self._packed.invalidate()
+
+
+# ------------------------------------------------------------------------------------------------
 # parameter holders (names fix the state-dict keys)
 # ------------------------------------------------------------------------------------------------
 class DynamicConv(nn.Module):
@@ -58,7 +135,7 @@ class ConvUnit(nn.Module):
             self.conv = nn.Conv2d(in_c, out_c, kernel, stride=stride, padding=padding, bias=False)
 
 
-class FeatureNet(nn.Module):
+class FeatureNet(_PackedHolder):
     """Parameter layout of the 3-level dynamic-conv pyramid (module.py:201-232)."""
 
     def __init__(self, base_channels: int = 8):
@@ -78,6 +155,7 @@ class FeatureNet(nn.Module):
         self.out2 = DynamicConv(2 * b, 2 * b, (1, 3))
         self.out3 = DynamicConv(b, b, (1, 3))
         self.out_channels = [4 * b, 2 * b, b]
+        self._init_packed()
 
 
 class ConvBn2d(nn.Module):
@@ -98,7 +176,7 @@ class ConvBn3d(nn.Module):
         self.bn = nn.BatchNorm3d(out_c)
 
 
-class CostRegNet(nn.Module):
+class CostRegNet(_PackedHolder):
     """3D U-Net regulariser (module.py:270-315); forward runs on the HIP conv kernels."""
 
     def __init__(self, in_channels: int, base_channels: int):
@@ -115,7 +193,7 @@ class CostRegNet(nn.Module):
         self.conv9 = ConvBn3d(4 * b, 2 * b, transposed=True)
         self.conv11 = ConvBn3d(2 * b, b, transposed=True)
         self.prob = nn.Conv3d(b, 1, 3, stride=1, padding=1, bias=False)
-        self._packed = _Packed(self)
+        self._init_packed()
 
     def _pack(self) -> Dict[str, Tensor]:
         out: Dict[str, Tensor] = {}
@@ -143,7 +221,7 @@ class CostRegNet(nn.Module):
         C, D, h, w = volume.shape
         if D % 8 or h % 8 or w % 8:
             raise ValueError(f"CostRegNet needs D,h,w divisible by 8, got {(D, h, w)}")
-        p = self._packed.get(self._pack)
+        p = self._packed.get(self, self._pack)
         with ops.prof("costreg"):
             return self._run(volume, p)
 
@@ -168,7 +246,7 @@ class CostRegNet(nn.Module):
         return ops.conv3d_k3(x, p["prob.w"], None, relu=False)[0]
 
 
-class Refinement(nn.Module):
+class Refinement(_PackedHolder):
     """2x depth up-sampling with image guidance (module.py:318-370).  Eval mode runs on the HIP
     kernels (3x3 Conv+BN+ReLU units on cds_conv2d_f32 with the BatchNorm folded in, the transposed conv, the depth
     pre-scale and the bilinear-upsample + residual epilogue in refine.hip); training mode keeps PyTorch autograd ops
@@ -183,7 +261,7 @@ class Refinement(nn.Module):
         self.bn = nn.BatchNorm2d(8)
         self.conv3 = ConvBn2d(16, 8)
         self.res = nn.Conv2d(8, 1, 3, padding=1, bias=False)
-        self._packed = _Packed(self)
+        self._init_packed()
 
     def _pack(self) -> Dict[str, Tensor]:
         out: Dict[str, Tensor] = {}
@@ -217,7 +295,7 @@ class Refinement(nn.Module):
         """img [B,3,H,W], depth0 [B,1,H/2,W/2], dmin/dmax [B] -> refined depth [B,1,H,W]."""
         if self.training:
             return self._forward_autograd(img, depth0, dmin, dmax)
-        p = self._packed.get(self._pack)
+        p = self._packed.get(self, self._pack)
         B, _, H, W = img.shape
         h, w = depth0.shape[-2:]
         if (2 * h, 2 * w) != (H, W):
@@ -237,47 +315,6 @@ class Refinement(nn.Module):
                 res = ops.conv2d(x, p["res.w"], None, 1, 3, 1, 1, ACT_NONE)
                 outs.append(ops.refine_finish(d, res[0, 0], lo, hi))
         return torch.stack(outs).unsqueeze(1)
-
-
-# ------------------------------------------------------------------------------------------------
-# weight folding / packing
-# ------------------------------------------------------------------------------------------------
-def _bn_fold(bn: nn.Module) -> Tuple[Tensor, Tensor]:
-    """Eval-mode BatchNorm as y = x*scale + shift."""
-    scale = bn.weight.detach() / torch.sqrt(bn.running_var + bn.eps)
-    shift = bn.bias.detach() - bn.running_mean * scale
-    return scale, shift
-
-
-def _pack2d(w: Tensor) -> Tensor:
-    """[Cout,Cin,k,k] -> [Cin,k*k,CoutP] (cout fastest, zero padded to a multiple of 8)."""
-    cout, cin, k, _ = w.shape
-    p = w.permute(1, 2, 3, 0).reshape(cin, k * k, cout)
-    pad = (-cout) % 8
-    if pad:
-        p = F.pad(p, (0, pad))
-    return p.contiguous()
-
-
-class _Packed:
-    """Lazily built, version-checked cache of folded/packed weights for one holder module."""
-
-    def __init__(self, owner: nn.Module):
-        self._owner_ref = [owner]  # list: keep nn.Module from registering it as a sub-module
-        self._sig = None
-        self._data: Dict[str, Tensor] = {}
-
-    def _signature(self):
-        owner = self._owner_ref[0]
-        return tuple((t.data_ptr(), t._version) for t in list(owner.parameters()) + list(owner.buffers()))
-
-    def get(self, builder) -> Dict[str, Tensor]:
-        sig = self._signature()
-        if sig != self._sig:
-            with torch.no_grad():
-                self._data = builder()
-            self._sig = sig
-        return self._data
 
 
 # ------------------------------------------------------------------------------------------------
@@ -314,9 +351,11 @@ def _to_host(tensors: List[Tensor]) -> List[Tensor]:
 # FeatureNet on the HIP kernels (module.py:234-267, dynamic_conv.py:97-122)
 # ------------------------------------------------------------------------------------------------
 class _FeatureRunner:
+    """FeatureNet forward over the HIP kernels.  Holds no state besides the net it is bound to for one call
+    (``CDSMVSNet`` binds a fresh runner per forward, so ``nn.DataParallel`` replicas use their own parameter tensors)."""
+
     def __init__(self, net: FeatureNet):
         self.net = net
-        self.packed = _Packed(net)
 
     def _pack(self) -> Dict[str, Tensor]:
         out: Dict[str, Tensor] = {}
@@ -398,7 +437,7 @@ class _FeatureRunner:
             n_chw = N
         if N > ops.MAX_IMAGES:
             raise ValueError(f"at most {ops.MAX_IMAGES} images per FeatureNet batch")
-        p = self.packed.get(self._pack)
+        p = net._packed.get(net, self._pack)
         e0 = epipoles.float().contiguous()
         e1 = (e0 / 2).contiguous()
         e2 = (e0 / 4).contiguous()
@@ -433,12 +472,12 @@ class _FeatureRunner:
 # ------------------------------------------------------------------------------------------------
 # StageNet: one cost-volume stage (models/model.py:11-94)
 # ------------------------------------------------------------------------------------------------
-class StageNet(nn.Module):
+class StageNet(_PackedHolder):
     def __init__(self, num_mvs_stages: int = 3):
         super().__init__()
         self.vis = nn.ModuleList([nn.Sequential(ConvBn2d(2, 16), ConvBn2d(16, 16), ConvBn2d(16, 16),
                                                 nn.Conv2d(16, 1, 1), nn.Sigmoid()) for _ in range(num_mvs_stages)])
-        self._packed = _Packed(self)
+        self._init_packed()
 
     def _pack(self) -> Dict[str, Tensor]:
         out: Dict[str, Tensor] = {}
@@ -457,7 +496,7 @@ class StageNet(nn.Module):
 
     def visibility(self, entropy: Tensor, ref_nc: Tensor, stage_idx: int) -> Tensor:
         """entropy, ref_nc [V,h,w] -> visibility weight [V,h,w]   (model.py:14,51)."""
-        p = self._packed.get(self._pack)
+        p = self._packed.get(self, self._pack)
         s = stage_idx
         with ops.prof("visibility_cnn"):
             x = torch.stack((entropy, ref_nc), dim=1)
@@ -499,6 +538,10 @@ class StageNet(nn.Module):
             raise NotImplementedError("prob_volume_init is dead code in the reference (never passed)")
         assert len(features) == proj_matrices.shape[1] - 1, "Different number of images and projection matrices"
         assert depth_values.shape[1] == num_depth, f"depth_values.shape[1]:{depth_values.shape[1]}  num_depth:{num_depth}"
+        with torch.cuda.device(depth_values.device):   # launches go to the current device's stream
+            return self._forward(features, proj_matrices, depth_values, cost_regularization, stage_idx)
+
+    def _forward(self, features, proj_matrices, depth_values, cost_regularization, stage_idx):
         B = depth_values.shape[0]
         cams = _to_host([proj_matrices])[0]
         V = len(features)
@@ -551,7 +594,6 @@ class CDSMVSNet(nn.Module):
                                                   for i in range(self.num_stage)])
         if self.refine:
             self.refine_network = Refinement()
-        self._feature_runner = [_FeatureRunner(self.feature)]  # in a list: not a sub-module
         # view-shard hook: set by cds_mvsnet_amd.distributed.shard_views(); None = all views on this GPU
         self._view_shard = None
 
@@ -571,7 +613,7 @@ class CDSMVSNet(nn.Module):
             g = epi[v0:v0 + G]
             epipoles = torch.tensor([e[0] for e in g] + [e[1] for e in g], dtype=torch.float32)
             batch = torch.stack([ref_img] * len(g) + list(src_imgs[v0:v0 + G]))
-            parts.append((len(g), self._feature_runner[0](batch, epipoles, T, n_chw=len(g), n_shared=len(g))))
+            parts.append((len(g), _FeatureRunner(self.feature)(batch, epipoles, T, n_chw=len(g), n_shared=len(g))))
         if len(parts) == 1:
             return parts[0][1]
         out = {}
@@ -585,10 +627,24 @@ class CDSMVSNet(nn.Module):
             out[name] = (chw, hwc, maps[0], maps[1])
         return out
 
+    def repack(self) -> None:
+        """Drop every cached folded / packed weight table.  PyTorch's own parameter rewrites (``load_state_dict``,
+        ``.to()`` / ``.cuda()``, ``train()`` / ``eval()``, optimizer steps) are tracked automatically; call this after
+        edits that bypass them (``p.data.copy_(...)``, EMA / SWA swaps through ``.data``)."""
+        for m in self.modules():
+            if isinstance(m, _PackedHolder):
+                m.repack()
+
     def forward(self, imgs, proj_matrices, depth_values, gt_depths=None, temperature=0.001):
         if not imgs.is_cuda:
             raise RuntimeError("cds_mvsnet_amd.CDSMVSNet runs on a ROCm device only (no CPU fallback); "
                                "move the model and inputs with .cuda()")
+        # the kernels are launched on the CURRENT device's stream: make the inputs' device current for the whole call
+        # (nn.DataParallel replicas, models on cuda:k in a process whose current device is another one)
+        with torch.cuda.device(imgs.device):
+            return self._forward(imgs, proj_matrices, depth_values, gt_depths, temperature)
+
+    def _forward(self, imgs, proj_matrices, depth_values, gt_depths, temperature):
         B, N, _, Him, Wim = imgs.shape
         H, W = (Him // 2, Wim // 2) if self.refine else (Him, Wim)
         if H % 32 or W % 32:

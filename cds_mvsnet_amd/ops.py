@@ -53,6 +53,9 @@ def _dev(t: Tensor, name: str) -> int:
         raise TypeError(f"{name}: expected float32, got {t.dtype}")
     if not t.is_contiguous():
         raise ValueError(f"{name}: tensor must be contiguous")
+    if t.device.index != torch.cuda.current_device():
+        raise RuntimeError(f"{name}: tensor on {t.device} but the current device is cuda:{torch.cuda.current_device()} "
+                           "(the launch goes to the current device; use `with torch.cuda.device(t.device):`)")
     return t.data_ptr()
 
 
@@ -69,6 +72,13 @@ def _host(t: Tensor, name: str) -> int:
 
 
 def _stream(t: Tensor) -> int:
+    """The current HIP stream of t's device.  The C entry points launch on the calling thread's current device, so that
+    device must be t's: the model's forward makes it so (``torch.cuda.device``); direct callers get a clear error
+    instead of a launch on the wrong GPU."""
+    idx = t.device.index
+    if idx is not None and idx != torch.cuda.current_device():
+        raise RuntimeError(f"cds_mvsnet_amd ops launch on the current device (cuda:{torch.cuda.current_device()}) but the "
+                           f"tensors live on {t.device}: wrap the call in `with torch.cuda.device(t.device):`")
     return torch.cuda.current_stream(t.device).cuda_stream
 
 
@@ -162,15 +172,22 @@ def warp_aggregate_bwd(ref_chw: Tensor, src_hwc: Tensor, vis_w: Tensor, mats: Te
     """Backward of the un-normalised K3: returns (grad_ref [V,C,h,w], grad_src_hwc [V,h,w,C], grad_vis [V,h,w])."""
     V, C, h, w = ref_chw.shape
     D, pp = _hyp_args(hyp, None, h, w)
-    if tuple(grad_volume.shape) != (C, D, h, w) or V > MAX_VIEWS:
+    if tuple(grad_volume.shape) != (C, D, h, w):
+        raise ValueError(f"warp_aggregate_bwd: grad_volume must be {(C, D, h, w)}, got {tuple(grad_volume.shape)}")
+    if tuple(src_hwc.shape) != (V, h, w, C) or tuple(mats.shape) != (V, 12) or tuple(vis_w.shape) != (V, h, w):
         raise ValueError("warp_aggregate_bwd: inconsistent shapes")
     g_ref = torch.empty_like(ref_chw)
     g_src = torch.zeros_like(src_hwc)
     g_vis = torch.empty_like(vis_w)
-    check(_lib.load().cds_warp_aggregate_bwd_f32(_dev(ref_chw, "ref"), _dev(src_hwc, "src"), _dev(vis_w, "vis"),
-                                                 _host(mats, "mats"), _dev(hyp, "hyp"), _dev(grad_volume, "grad_volume"),
-                                                 g_ref.data_ptr(), g_src.data_ptr(), g_vis.data_ptr(), V, C, D, h, w, pp,
-                                                 _stream(g_ref)), "cds_warp_aggregate_bwd_f32")
+    lib = _lib.load()
+    # every gradient is per view: groups of MAX_VIEWS views are independent launches (like the forward's chunks)
+    for v0 in range(0, V, MAX_VIEWS):
+        v1 = min(V, v0 + MAX_VIEWS)
+        check(lib.cds_warp_aggregate_bwd_f32(_dev(ref_chw[v0:v1], "ref"), _dev(src_hwc[v0:v1], "src"),
+                                             _dev(vis_w[v0:v1], "vis"), _host(mats[v0:v1], "mats"), _dev(hyp, "hyp"),
+                                             _dev(grad_volume, "grad_volume"), g_ref[v0:v1].data_ptr(),
+                                             g_src[v0:v1].data_ptr(), g_vis[v0:v1].data_ptr(), v1 - v0, C, D, h, w, pp,
+                                             _stream(g_ref)), "cds_warp_aggregate_bwd_f32")
     return g_ref, g_src, g_vis
 
 

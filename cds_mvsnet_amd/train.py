@@ -43,13 +43,46 @@ def make_scheduler(optimizer: torch.optim.Optimizer, step_size: int = 3, gamma: 
     return torch.optim.lr_scheduler.StepLR(optimizer, step_size=step_size, gamma=gamma)
 
 
+@torch.no_grad()
+def broadcast_model_(module: torch.nn.Module, src: int = 0, group: Optional["dist.ProcessGroup"] = None) -> int:
+    """Make every rank start from rank ``src``'s parameters AND buffers (BatchNorm running statistics): what
+    ``nn.DataParallel`` gets for free by replicating one module (base/base_trainer.py:17-18) has to be done explicitly with
+    one process per GPU — each rank's ``CDSMVSNet()`` draws its own random initial weights.  One flat fp32 broadcast
+    for the floating-point tensors, one int64 broadcast for the ``num_batches_tracked`` counters.  Returns the number
+    of tensors synchronised (0 when there is a single rank)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return 0
+    src_global = dist.get_global_rank(group, src) if group is not None else src
+    tensors = list(module.parameters()) + list(module.buffers())
+    n = 0
+    for is_float in (True, False):
+        sel = [t for t in tensors if t.is_floating_point() == is_float]
+        if not sel:
+            continue
+        flat = torch.cat([t.detach().reshape(-1).to(torch.float32 if is_float else torch.int64) for t in sel])
+        dist.broadcast(flat, src=src_global, group=group)
+        off = 0
+        for t in sel:
+            k = t.numel()
+            t.copy_(flat[off:off + k].view_as(t).to(t.dtype))
+            off += k
+        n += len(sel)
+    if hasattr(module, "repack"):
+        module.repack()          # the copies above bypass nothing, but be explicit: packed eval weights are stale now
+    return n
+
+
 class GradAllReducer:
-    """Flat-bucket gradient averaging over a process group (default group; RCCL when the tensors are on the GPU)."""
+    """Flat-bucket gradient averaging over a process group (default group; RCCL when the tensors are on the GPU).
+    Pass ``module=`` to also broadcast rank 0's initial parameters and buffers at construction (:func:`broadcast_model_`):
+    averaged gradients only make sense on identical replicas."""
 
     def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = 64 << 20,
-                 group: Optional["dist.ProcessGroup"] = None):
+                 group: Optional["dist.ProcessGroup"] = None, module: Optional[torch.nn.Module] = None):
         self.params = [p for p in params if p.requires_grad]
         self.group = group
+        if module is not None:
+            broadcast_model_(module, 0, group)
         self.buckets: List[List[torch.nn.Parameter]] = [[]]
         size = 0
         for p in self.params:

@@ -129,3 +129,49 @@ def test_p2p_reduce_scatter_all_gather_equals_allreduce(world):
         assert p.exitcode == 0
     for _, errs in res:
         assert max(errs) < 1e-6
+
+
+def _bcast_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import sys
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from cds_mvsnet_amd import CDSMVSNet, seeded_init_
+        from cds_mvsnet_amd.train import GradAllReducer
+        model = seeded_init_(CDSMVSNet(refine=True), 10 + rank)        # every rank starts from DIFFERENT weights
+        before = torch.cat([t.detach().reshape(-1).double() for t in model.state_dict().values()])
+        red = GradAllReducer(model.parameters(), module=model)          # broadcasts rank 0's parameters + buffers
+        after = torch.cat([t.detach().reshape(-1).double() for t in model.state_dict().values()])
+        gathered = [torch.empty_like(after) for _ in range(world)]
+        dist.all_gather(gathered, after)
+        same = all(torch.equal(g, gathered[0]) for g in gathered)
+        changed = not torch.equal(before, after)
+        # gradient averaging on the now identical replicas: rank r contributes (r + 1), the mean is (world + 1) / 2
+        for p in model.parameters():
+            p.grad = torch.full_like(p, float(rank + 1))
+        n_coll = red.reduce()
+        gerr = max(float((p.grad - (world + 1) / 2).abs().max()) for p in model.parameters())
+        q.put((rank, same, changed, n_coll, gerr))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_broadcast_initial_weights_then_average_gradients_world2():
+    """replicas built from different seeds must start identical (rank 0's parameters AND BatchNorm buffers),
+    then the flat-bucket gradient all-reduce averages (one collective for the 3.9 MB of gradients)."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bcast_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(r[1] for r in res), "replicas differ after the broadcast"
+    assert not res[0][2] and res[1][2], "rank 0 must keep its weights, rank 1 must take them"
+    assert all(r[3] == 1 and r[4] < 1e-6 for r in res)
