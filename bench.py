@@ -12,8 +12,14 @@ Inputs are synthetic (seeded), resident in HBM before the timed region; weights 
 
 Multi-GPU: default ``--parallelism replicas`` — every rank computes the depth map of its own reference view
 (the reference's only multi-GPU mode, nn.DataParallel batch scatter, as one process per GPU; no data-path
-collective; weak scaling).  ``--parallelism viewshard`` shards the source views of ONE depth map over the ranks
-with a single RCCL all-reduce of the partial volume (north_star; strong scaling).
+collective; weak scaling) — that is `value`.  Every line with N > 1 ALSO carries a `viewshard` object: the
+north_star exchange (source views of ONE depth map sharded over the ranks, one RCCL all-reduce of
+volume_sum ++ vis_sum ++ nc_sum per stage) measured after the timed region on the M1 stage and on the BASELINE
+config-4 cascade (Tanks&Temples 1920x1056, N=7, through `shard_views(model)`): ms per depth map, all-reduce bytes
+and ms, ranks in the RCCL communicator, NCCL_ALGO.  ``--parallelism viewshard`` makes that mode the timed one
+(strong scaling).  ``--workload M2|M3|M4`` times the full three-stage cascade (640x512 N=5 / DTU 1600x1184 N=5 /
+Tanks&Temples 1920x1056 N=7) instead of the single-stage M1; ``--workload T5`` times BASELINE config 5, one
+BlendedMVS-shaped training step (768x576, N=5, refine=True, data-parallel gradient all-reduce).
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (fused warp-aggregate kernel,
 HBM bound) and `cpu_baseline` (the CPU oracle timed on the host cores on a bounded sample) objects.
@@ -40,6 +46,24 @@ WORKLOADS = {
     "M1b": (128, 160, 192, 32, 5),
     "tiny": (64, 80, 48, 8, 3),
 }
+CASCADES = {
+    # name: (H, W, n_views): full three-stage forward (FeatureNet + 3 x StageNet), refine=False
+    "M2": (512, 640, 5),
+    "M3": (1184, 1600, 5),
+    "M4": (1056, 1920, 7),
+    "tinycascade": (128, 160, 3),
+}
+TRAIN = {
+    # name: (H, W, n_views, refine)   BASELINE config 5 (configs/config_blended.json)
+    "T5": (576, 768, 5, True),
+    "tinytrain": (64, 96, 3, False),
+}
+NDEPTHS, RATIOS, STAGE_C = (48, 32, 8), (4.0, 1.5, 0.75), (32, 16, 8)
+
+
+def cascade_algorithmic_bytes(H, W, n_views):
+    """Sum of the three stages' warp-aggregate algorithmic bytes (stage s: H/scale x W/scale, D_s planes, C_s channels)."""
+    return sum(algorithmic_bytes(H // sc, W // sc, D, C, n_views) for sc, D, C in zip((4, 2, 1), NDEPTHS, STAGE_C))
 
 
 def algorithmic_bytes(h, w, D, C, n_views):
@@ -130,11 +154,20 @@ def other_workloads(model, dev):
 
 
 def cpu_baseline(model_cpu, name, budget_frac):
-    """The CPU oracle (proved equal to the reference, tests/test_oracle_golden.py) on a window of the same
-    workload: top-left (h*f) x (w*f) pixels, all D planes, all views.  Returns the JSON object."""
+    """The CPU oracle (proved equal to the reference, tests/test_oracle_golden.py) on the same workload — by default
+    the FULL M1 size, one run (~20 s and ~20 GB on 64 cores); `budget_frac` < 1 (or a host with less than
+    48 GB of free memory) takes the top-left (h*f) x (w*f) window instead: all D planes, all views, cost linear in the
+    pixel count (profiles/r02_cpu_baseline_linearity.md).  Returns the JSON object."""
     from cds_mvsnet_amd import synth
     from oracle import cds_oracle as O
     h, w, D, C, n_views = WORKLOADS[name]
+    try:
+        avail = os.sysconf("SC_AVPHYS_PAGES") * os.sysconf("SC_PAGE_SIZE")
+    except (ValueError, OSError):
+        avail = 0
+    need = 10.0 * C * D * h * w * 4 * budget_frac ** 2          # ~5 full-volume temporaries per view, with slack
+    if avail and need > 0.8 * avail:
+        budget_frac = min(budget_frac, 0.5)
     hs, ws = max(8, int(h * budget_frac) // 8 * 8), max(8, int(w * budget_frac) // 8 * 8)
     cores = min(os.cpu_count() or 1, 64)
     torch.set_num_threads(cores)
@@ -149,9 +182,112 @@ def cpu_baseline(model_cpu, name, budget_frac):
         O.stage_forward(feats, cams, hyp, sd, stage, exact=False)
         dt = time.time() - t0
     frac = (hs * ws) / float(h * w)
+    what = "full size" if frac == 1.0 else f"window {ws}x{hs} of {w}x{h} ({frac:.4f} of the pixels, linear extrapolation)"
     return {"value": frac / dt, "unit": "depth-maps/s", "cores": cores, "kind": "port",
-            "sample": f"{name} window {ws}x{hs} of {w}x{h} ({frac:.4f} of the pixels), D={D}, C={C}, N={n_views}, "
-                      f"1 run, {dt:.2f} s of torch-CPU oracle (F.grid_sample path)"}
+            "sample": f"{name} {what}, D={D}, C={C}, N={n_views}, 1 run, {dt:.2f} s of torch-CPU oracle (F.grid_sample path)"}
+
+
+def build_id():
+    """sha256 (16 hex) of the loaded libcdsmvs_hip.so and of the kernel sources it was built from."""
+    import hashlib
+    from cds_mvsnet_amd import _lib
+    out = {}
+    try:
+        out["lib_sha16"] = hashlib.sha256(open(_lib.LIB_PATH, "rb").read()).hexdigest()[:16]
+    except OSError:
+        out["lib_sha16"] = None
+    hsh = hashlib.sha256()
+    csrc = os.path.join(ROOT, "cds_mvsnet_amd", "csrc")
+    for fn in sorted(os.listdir(csrc)):
+        if fn.endswith((".hip", ".hpp", ".h")) or fn == "Makefile":
+            hsh.update(open(os.path.join(csrc, fn), "rb").read())
+    out["csrc_sha16"] = hsh.hexdigest()[:16]
+    out["abi_version"] = int(_lib.load().cds_version())
+    return out
+
+
+def train_sample(H, W, n_views, refine, dev, seed=21):
+    """Synthetic BlendedMVS-shaped training sample (images, multi-scale cameras, depth range, GT depth + masks per stage)."""
+    import torch.nn.functional as F
+    from cds_mvsnet_amd import synth
+    imgs = synth.make_images(n_views, H, W, seed=seed).to(dev)
+    cams = {k: v.to(dev) for k, v in synth.make_cameras(n_views, H, W, refine=refine, seed=seed).items()}
+    dv = synth.make_depth_values().to(dev)
+    g = torch.Generator().manual_seed(9)
+    base = 600.0 + 120.0 * F.interpolate(torch.rand(1, 1, 6, 8, generator=g), (H, W), mode="bicubic", align_corners=False)[:, 0]
+    gt, mask = {}, {}
+    scales = (("stage1", 8), ("stage2", 4), ("stage3", 2), ("stage4", 1)) if refine else (("stage1", 4), ("stage2", 2), ("stage3", 1))
+    for sname, sc in scales:
+        gt[sname] = F.interpolate(base.unsqueeze(1), (H // sc, W // sc), mode="nearest")[:, 0].contiguous().to(dev)
+        mask[sname] = (torch.rand(1, H // sc, W // sc, generator=g) > 0.15).float().to(dev)
+    if not refine:
+        gt["stage4"], mask["stage4"] = gt["stage3"], mask["stage3"]
+    return {"imgs": imgs, "proj_matrices": cams, "depth_values": dv, "depth": gt, "mask": mask}
+
+
+def measure_viewshard(model, dev, dist, rank, world, exchange, stage_name="M1", cascade_name="M4"):
+    """The north_star exchange on N > 1 ranks, measured outside the headline's timed region: (i) the single-stage
+    workload through `ViewShardedStage`, (ii) the BASELINE config-4 cascade through `shard_views(model)`.  Same
+    bracket as the headline: barrier + synchronize on both sides, max over ranks."""
+    from cds_mvsnet_amd import distributed as cdist, ops, synth
+
+    def timed(fn, n, warm):
+        for _ in range(warm):
+            fn()
+        ops.PROFILE.clear()
+        ops.PROFILE_ON = True
+        dist.barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        dist.barrier(); torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        ops.PROFILE_ON = False
+        t = torch.tensor([dt], device=dev if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        kern = {k: sum(a.elapsed_time(b) for a, b in v) / n for k, v in ops.PROFILE.items() if v}
+        return float(t.item()) / n * 1e3, kern
+
+    out = {"ranks": dist.get_world_size(), "backend": dist.get_backend(), "exchange": exchange,
+           "NCCL_ALGO": os.environ.get("NCCL_ALGO"), "NCCL_PROTO": os.environ.get("NCCL_PROTO"),
+           "collective": "one fp32 SUM all-reduce of volume_sum ++ vis_sum ++ nc_sum per stage (models/model.py:57-60,74)"}
+    try:
+        out["rccl_version"] = ".".join(str(x) for x in torch.cuda.nccl.version())
+    except Exception:
+        out["rccl_version"] = None
+    with torch.no_grad():
+        h, w, D, C, n_views = WORKLOADS[stage_name]
+        stage = {8: 2, 16: 1, 32: 0}[C]
+        _, cams, hyp, dfe = make_workload(stage_name, 0, dev)
+        hyp_d = hyp.to(dev)
+        runner = cdist.ViewShardedStage(model, dist.group.WORLD, exchange=exchange)
+        ms, kern = timed(lambda: runner(dfe, cams, hyp_d, D, stage), 5, 2)
+        out["stage"] = {"workload": f"{stage_name}: {w}x{h}, D={D}, C={C}, N={n_views}", "ms_per_depth_map": ms,
+                        "depth_maps_per_s": 1e3 / ms, "allreduce_bytes": 4 * cdist.ViewShard.flat_size(C, D, h, w),
+                        "allreduce_ms": kern.get("allreduce"), "local_source_views": len(runner.shard.local_views(n_views - 1)),
+                        "kernel_ms": {k: round(v, 4) for k, v in sorted(kern.items())}}
+        if kern.get("allreduce"):
+            out["stage"]["allreduce_busbw_GBps"] = (2.0 * (world - 1) / world * out["stage"]["allreduce_bytes"]
+                                                    / (kern["allreduce"] * 1e-3) / 1e9)
+        del dfe, hyp_d, runner
+        H, W, nv = CASCADES[cascade_name]
+        imgs = synth.make_images(nv, H, W, seed=0).to(dev)
+        pm = synth.make_cameras(nv, H, W, refine=False, seed=0)
+        dv = synth.make_depth_values()
+        sh = cdist.shard_views(model, dist.group.WORLD, exchange=exchange)
+        try:
+            ms, kern = timed(lambda: model(imgs, pm, dv, temperature=0.01), 3, 2)
+        finally:
+            model._view_shard = None
+        bytes_per_map = sum(4 * cdist.ViewShard.flat_size(Cs, Ds, H // sc, W // sc)
+                            for sc, Ds, Cs in zip((4, 2, 1), NDEPTHS, STAGE_C))
+        out["cascade"] = {"workload": f"{cascade_name}: cascade {W}x{H}, N={nv}, D={NDEPTHS}", "ms_per_depth_map": ms,
+                          "depth_maps_per_s": 1e3 / ms, "allreduce_bytes": bytes_per_map, "allreduces_per_depth_map": 3,
+                          "allreduce_ms": kern.get("allreduce"), "local_source_views": len(sh.local_views(nv - 1)),
+                          "kernel_ms": {k: round(v, 4) for k, v in sorted(kern.items())}}
+        if kern.get("allreduce"):
+            out["cascade"]["allreduce_busbw_GBps"] = (2.0 * (world - 1) / world * bytes_per_map / (kern["allreduce"] * 1e-3) / 1e9)
+    return out
 
 
 def main():
@@ -159,15 +295,18 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="M1", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="M1", choices=sorted(WORKLOADS) + sorted(CASCADES) + sorted(TRAIN))
     ap.add_argument("--parallelism", default="replicas", choices=["replicas", "viewshard"])
     ap.add_argument("--exchange", default="allreduce", choices=["allreduce", "p2p"],
                     help="viewshard exchange: one RCCL all-reduce, or reduce-scatter + all-gather as direct P2P sends")
-    ap.add_argument("--no-extras", action="store_true", help="skip the M1b / M2 side measurements")
+    ap.add_argument("--no-extras", action="store_true", help="skip the M1b / M2 / M3 / M4 side measurements")
+    ap.add_argument("--no-viewshard", action="store_true", help="N > 1: skip the north-star view-shard measurement")
     ap.add_argument("--streams", type=int, default=1,
                     help="depth maps in flight per GPU on separate HIP streams (a step = that many depth maps; "
                          "per-kernel event timing and the roofline object need 1)")
-    ap.add_argument("--cpu-sample", type=float, default=0.75, help="linear window fraction for the CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-sample", type=float, default=1.0,
+                    help="linear window fraction for the CPU baseline (1 = the full workload once; 0 = skip)")
+    ap.add_argument("--train-dtype", default="bf16", choices=["bf16", "fp32"], help="T5: autocast dtype of the conv stacks")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) in production; gloo only for single-GPU dry runs")
     args = ap.parse_args()
 
@@ -191,27 +330,62 @@ def main():
         else:
             dist.init_process_group(args.dist_backend)
 
-    from cds_mvsnet_amd import CDSMVSNet, ops, seeded_init_
-    h, w, D, C, n_views = WORKLOADS[args.workload]
-    stage = {8: 2, 16: 1, 32: 0}[C]
-    model_cpu = seeded_init_(CDSMVSNet(refine=False, ndepths=(48, 32, 8), depth_interals_ratio=(4.0, 1.5, 0.75)), 0).eval()
+    from cds_mvsnet_amd import CDSMVSNet, ops, seeded_init_, synth
+    kind = "stage" if args.workload in WORKLOADS else ("cascade" if args.workload in CASCADES else "train")
+    refine = kind == "train" and TRAIN[args.workload][3]
+    model_cpu = seeded_init_(CDSMVSNet(refine=refine, ndepths=NDEPTHS, depth_interals_ratio=RATIOS), 0).eval()
     import copy
     model = copy.deepcopy(model_cpu).to(dev)
     # replicas: every rank owns a different reference view (different seed); viewshard: same depth map everywhere
     seed = rank if args.parallelism == "replicas" else 0
-    _, cams, hyp, dfe = make_workload(args.workload, seed, dev)
-    # cameras stay on the host (the module turns them into 12 kernel-argument floats per view there); a device copy is
-    # accepted as well but costs a readback per call
-    cams_d, hyp_d = cams, hyp.to(dev)
-    if world > 1 and args.parallelism == "viewshard":
-        from cds_mvsnet_amd import distributed as cdist
-        runner = cdist.ViewShardedStage(model, dist.group.WORLD, exchange=args.exchange)
+    viewshard_timed = world > 1 and args.parallelism == "viewshard"
+    metric = "depth-maps/sec per ref view at 640x512 N=5 D=192 (single-stage plane sweep incl. CostRegNet + regression)"
+    unit = "depth-maps/s"
+    if kind == "stage":
+        h, w, D, C, n_views = WORKLOADS[args.workload]
+        stage = {8: 2, 16: 1, 32: 0}[C]
+        _, cams, hyp, dfe = make_workload(args.workload, seed, dev)
+        # cameras stay on the host (the module turns them into 12 kernel-argument floats per view there); a device copy
+        # is accepted as well but costs a readback per call
+        cams_d, hyp_d = cams, hyp.to(dev)
+        workload_desc = f"{args.workload}: single-stage StageNet volume {w}x{h}, D={D}, C={C}, N={n_views} views"
+        b_alg = algorithmic_bytes(h, w, D, C, n_views)
+        if viewshard_timed:
+            from cds_mvsnet_amd import distributed as cdist
+            runner = cdist.ViewShardedStage(model, dist.group.WORLD, exchange=args.exchange)
+            def step():
+                return runner(dfe, cams_d, hyp_d, D, stage)
+        else:
+            def step():
+                return model.stage_net(dfe, cams_d, depth_values=hyp_d, num_depth=D,
+                                       cost_regularization=model.cost_regularization[stage], stage_idx=stage)
+    elif kind == "cascade":
+        H, W, n_views = CASCADES[args.workload]
+        imgs = synth.make_images(n_views, H, W, seed=seed).to(dev)
+        pm = synth.make_cameras(n_views, H, W, refine=False, seed=seed)
+        dv = synth.make_depth_values()
+        workload_desc = f"{args.workload}: three-stage cascade forward {W}x{H}, N={n_views} views, D={NDEPTHS}, ratios {RATIOS}"
+        metric = f"depth-maps/sec per ref view, full cascade at {W}x{H} N={n_views}"
+        b_alg = cascade_algorithmic_bytes(H, W, n_views)
+        if viewshard_timed:
+            from cds_mvsnet_amd import distributed as cdist
+            cdist.shard_views(model, dist.group.WORLD, exchange=args.exchange)
         def step():
-            return runner(dfe, cams_d, hyp_d, D, stage)
+            return model(imgs, pm, dv, temperature=0.01)
     else:
+        from cds_mvsnet_amd import train as T
+        H, W, n_views, _ = TRAIN[args.workload]
+        sample = train_sample(H, W, n_views, refine, dev, seed=21 + seed)
+        opt = T.make_optimizer(model)
+        reducer = T.GradAllReducer(model.parameters(), module=model)       # broadcasts rank 0's weights when world > 1
+        bf16 = args.train_dtype == "bf16"
+        workload_desc = (f"{args.workload}: BlendedMVS-shaped training step {W}x{H}, N={n_views}, refine={refine}, "
+                         f"{args.train_dtype} autocast on the conv stacks, SGD, flat-bucket gradient all-reduce")
+        metric, unit = f"training samples/sec ({W}x{H} N={n_views} step: forward + loss + backward + all-reduce + SGD)", "samples/s"
+        b_alg = None
         def step():
-            return model.stage_net(dfe, cams_d, depth_values=hyp_d, num_depth=D,
-                                   cost_regularization=model.cost_regularization[stage], stage_idx=stage)
+            l, _ = T.train_step(model, opt, sample, temperature=0.1, reducer=reducer, bf16=bf16)
+            return {"depth": torch.tensor([l])}
 
     if args.streams > 1:   # independent pipelines on separate streams: memory-bound and issue-bound kernels overlap
         one_map = step
@@ -229,7 +403,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    with torch.no_grad():
+    grad_ctx = torch.enable_grad() if kind == "train" else torch.no_grad()
+    with grad_ctx:
         for _ in range(args.warmup):
             out = step()
         ops.PROFILE.clear()
@@ -249,15 +424,15 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3
-    maps_per_step = (world if args.parallelism == "replicas" else 1) * args.streams
+    maps_per_step = (1 if viewshard_timed else world) * args.streams
     value = maps_per_step * args.steps / dt
-    depth_mean = float(out["depth"].mean().item())
+    depth_mean = float(out["depth"].float().mean().item())
 
-    # per-kernel durations from the HIP events recorded inside the timed region (same stream as the launches)
-    kern = {k: sum(a.elapsed_time(b) for a, b in v) / len(v) for k, v in ops.PROFILE.items() if v}
-    b_alg = algorithmic_bytes(h, w, D, C, n_views)
+    # per-kernel durations from the HIP events recorded inside the timed region (same stream as the launches); per STEP
+    # (a cascade step launches every kernel family three times)
+    kern = {k: sum(a.elapsed_time(b) for a, b in v) / args.steps for k, v in ops.PROFILE.items() if v}
     roof = None
-    if "warp_aggregate" in kern:
+    if "warp_aggregate" in kern and b_alg is not None:
         t_k3 = kern["warp_aggregate"] * 1e-3
         achieved = b_alg / t_k3
         traffic = None
@@ -270,12 +445,14 @@ def main():
         roof = {"kernel": "warp_aggregate_lds_kernel (K3, fused homography warp + visibility-weighted aggregation)",
                 "bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK, "frac_of_measured_copy_ceiling": achieved / 6.29e12,
-                "algorithmic_bytes": b_alg, "kernel_ms": kern["warp_aggregate"], "traffic": traffic}
+                "algorithmic_bytes": b_alg, "kernel_ms": kern["warp_aggregate"], "traffic": traffic,
+                "traffic_source": "profiles/pmc_traffic.json: static, from the committed rocprofv3 --pmc passes of this "
+                                  "kernel (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE), not re-measured in this run"}
         span = sum(kern.get(k, 0.0) for k in ("warp_entropy", "visibility_cnn", "warp_aggregate"))
         roof["k1_vis_k3_span_ms"] = span
         roof["k1_vis_k3_span_frac"] = b_alg / (span * 1e-3) / HBM_PEAK if span > 0 else None
     extra = {}
-    if "costreg" in kern:
+    if "costreg" in kern and kind == "stage":
         fl = costreg_flops(h, w, D, C)
         extra["roofline_costreg"] = {"bound": "fp32", "achieved": fl / (kern["costreg"] * 1e-3) / 1e12,
                                      "peak": FP32_PEAK / 1e12, "unit": "TFLOP/s",
@@ -287,24 +464,31 @@ def main():
     others = None
     if world == 1 and args.streams == 1 and args.workload == "M1" and not args.no_extras:
         others = other_workloads(model, dev)
+    vs = None
+    if world > 1 and kind != "train" and not args.no_viewshard:
+        model._view_shard = None
+        vs = measure_viewshard(model, dev, dist, rank, world, args.exchange)
     if rank == 0:
         cpu = None
-        if world == 1 and args.cpu_sample > 0:
+        if world == 1 and args.cpu_sample > 0 and kind == "stage":
             cpu = cpu_baseline(model_cpu, args.workload, args.cpu_sample)
         line = {
-            "metric": "depth-maps/sec per ref view at 640x512 N=5 D=192 (single-stage plane sweep incl. CostRegNet + regression)",
-            "value": value, "unit": "depth-maps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "metric": metric,
+            "value": value, "unit": unit, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "weak" if args.parallelism == "replicas" else "strong",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic (seeded features/cameras/hypotheses, seeded random weights)",
-            "config": {"workload": f"{args.workload}: single-stage StageNet volume {w}x{h}, D={D}, C={C}, N={n_views} views",
-                       "parallelism": args.parallelism if world > 1 else "single", "depth_maps_per_step_per_gpu": args.streams,
-                       "depth_mean": depth_mean},
-            "roofline": roof, "cpu_baseline": cpu,
+            "scaling": "strong" if viewshard_timed else "weak",
+            "vs_baseline": None, "dtype": "f32" if kind != "train" else args.train_dtype,
+            "data": "synthetic (seeded features/cameras/hypotheses, seeded random weights)",
+            "config": {"workload": workload_desc,
+                       "parallelism": (args.parallelism if kind != "train" else "data-parallel") if world > 1 else "single",
+                       "depth_maps_per_step_per_gpu": args.streams, "depth_mean": depth_mean},
+            "roofline": roof, "cpu_baseline": cpu, "build": build_id(),
         }
         line.update(extra)
         if others is not None:
             line["other_workloads"] = others
+        if vs is not None:
+            line["viewshard"] = vs
         print(json.dumps(line))
     if dist is not None:
         dist.barrier()

@@ -39,6 +39,11 @@ class ViewShard:
         self.exchange = exchange
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
+        # diagnostics: the last exchange (bytes, events) and, on request, the normalised volume of the last stage
+        self.keep_volume = False
+        self.last_volume: Optional[Tensor] = None
+        self.exchanged_bytes = 0
+        self.exchanges = 0
 
     # ---- bookkeeping (device independent) ----------------------------------------------------
     def local_views(self, n_src: int) -> List[int]:
@@ -55,6 +60,8 @@ class ViewShard:
 
     def all_reduce_partials(self, flat: Tensor) -> Tensor:
         """The single exchange step: SUM over ranks of volume_sum ++ vis_sum ++ nc_sum (in place)."""
+        self.exchanges += 1
+        self.exchanged_bytes += flat.numel() * flat.element_size()
         if self.exchange == "allreduce" or self.world == 1:
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
             return flat
@@ -118,6 +125,8 @@ class ViewShard:
         with ops.prof("allreduce"):
             self.all_reduce_partials(flat)
         ops.volume_normalize_(vol, vis_sum)
+        if self.keep_volume:
+            self.last_volume = vol
         prob_pre = model.cost_regularization[stage_idx](vol)
         depth, conf = ops.softargmin_conf(prob_pre, hyp)
         return depth, conf, nc_sum / n_src_total

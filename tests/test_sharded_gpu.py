@@ -1,0 +1,220 @@
+"""The view-sharded PRODUCT path on the HIP kernels (reference sums: models/model.py:57-60,74):
+``shard_views(model)`` / ``ViewShard.run_stage`` = zero-initialised flat buffer, K1, visibility CNN, un-normalised K3
+written into a view of it, ONE all-reduce, ``volume_normalize_``, CostRegNet, regression.
+
+* world size 1 (a single-process gloo group): the sharded cascade must equal the unsharded one;
+* world size 2 on ONE device (two processes pinned to cuda:0, gloo — RCCL refuses two ranks on one GPU): every rank's
+  sharded forward against the unsharded forward, depth mean <= 1e-3, stage volume <= 1e-6 (fp32 re-association only);
+* ``nn.DataParallel`` (the reference's own multi-GPU mode, base/base_trainer.py:17-18, test.py:185-186) with two
+  replicas on cuda:0, and the packed-weight cache invalidation rules."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _inputs(N, H, W, seed, dev):
+    from cds_mvsnet_amd import synth
+    imgs = synth.make_images(N, H, W, seed=seed).to(dev)
+    cams = synth.make_cameras(N, H, W, refine=False, seed=seed)     # host-side cameras, as the harness passes them
+    return imgs, cams, synth.make_depth_values()
+
+
+def _model(dev, refine=False, seed=7):
+    from cds_mvsnet_amd import CDSMVSNet, seeded_init_
+    return seeded_init_(CDSMVSNet(refine=refine, depth_interals_ratio=(4.0, 1.5, 0.75)), seed).eval().to(dev)
+
+
+def _stage_inputs(V, C, D, h, w, dev):
+    from cds_mvsnet_amd import synth
+    feats = synth.make_pair_features(V, C, h, w, seed=31, sharp=True)
+    cams = synth.stage_cameras(V + 1, h, w, seed=32)
+    hyp = synth.make_hypotheses(D, h, w, seed=33)
+    dfe = [{k: tuple(t.to(dev) for t in f[k]) for k in ("ref", "src")} for f in feats]
+    return dfe, cams, hyp.to(dev)
+
+
+def _unsharded_volume(model, dfe, cams, hyp, stage):
+    from cds_mvsnet_amd import geometry, ops
+    ref = torch.stack([f["ref"][0][0] for f in dfe]).contiguous()
+    src = torch.stack([ops.chw_to_hwc(f["src"][0][0].contiguous()) for f in dfe])
+    ref_nc = torch.stack([f["ref"][2][0, 0] for f in dfe]).contiguous()
+    vol, _, _, _ = model.stage_net.aggregate(ref, src, ref_nc, geometry.warp_matrices(cams[0]), hyp[0].contiguous(), stage)
+    return vol
+
+
+def test_shard_views_world1_equals_unsharded():
+    from cds_mvsnet_amd import distributed as cdist
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        model = _model(dev)
+        imgs, cams, dv = _inputs(4, 128, 160, 3, dev)
+        with torch.no_grad():
+            want = model(imgs, cams, dv, temperature=0.01)
+            sh = cdist.shard_views(model)
+            sh.keep_volume = True
+            got = model(imgs, cams, dv, temperature=0.01)
+            assert sh.exchanges == 3 and sh.local_views(3) == [0, 1, 2]
+            for k in ("stage1", "stage2", "stage3"):
+                assert (got[k]["depth"] - want[k]["depth"]).abs().mean() < 1e-3, k
+                assert (got[k]["photometric_confidence"] - want[k]["photometric_confidence"]).abs().mean() < 1e-3, k
+                assert (got[k]["norm_curv"] - want[k]["norm_curv"]).abs().max() < 1e-5, k
+            # single stage, volume level: normalising after the (identity) exchange == the fused normalisation of K3
+            model._view_shard = None
+            dfe, scams, hyp = _stage_inputs(3, 8, 16, 40, 64, dev)
+            vol = _unsharded_volume(model, dfe, scams, hyp, 2)
+            runner = cdist.ViewShardedStage(model)
+            runner.shard.keep_volume = True
+            out = runner(dfe, scams, hyp, 16, 2)
+            full = model.stage_net(dfe, scams, depth_values=hyp, num_depth=16,
+                                   cost_regularization=model.cost_regularization[2], stage_idx=2)
+            assert (runner.shard.last_volume - vol).abs().max() < 1e-6
+            assert (out["depth"] - full["depth"]).abs().mean() < 1e-3
+    finally:
+        dist.destroy_process_group()
+
+
+def _two_rank_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cds_mvsnet_amd import distributed as cdist
+        dev = torch.device("cuda:0")                                # both ranks on the one GPU of the box
+        torch.cuda.set_device(dev)
+        model = _model(dev)
+        N = 4                                                       # 3 source views: rank 0 owns {0, 2}, rank 1 owns {1}
+        imgs, cams, dv = _inputs(N, 128, 160, 5, dev)
+        res = {}
+        with torch.no_grad():
+            want = model(imgs, cams, dv, temperature=0.01)          # unsharded, on this rank
+            for exchange in ("allreduce", "p2p"):
+                sh = cdist.shard_views(model, exchange=exchange)
+                got = model(imgs, cams, dv, temperature=0.01)
+                res[exchange] = [float((got[k]["depth"] - want[k]["depth"]).abs().mean()) for k in ("stage1", "stage2", "stage3")]
+                res[exchange + "_views"] = sh.local_views(N - 1)
+                res[exchange + "_n"] = sh.exchanges
+            model._view_shard = None
+            # stage level: the all-reduced, normalised volume against the unsharded K3 output
+            dfe, scams, hyp = _stage_inputs(3, 8, 16, 40, 64, dev)
+            vol = _unsharded_volume(model, dfe, scams, hyp, 2)
+            runner = cdist.ViewShardedStage(model)
+            runner.shard.keep_volume = True
+            runner(dfe, scams, hyp, 16, 2)
+            res["volume"] = float((runner.shard.last_volume - vol).abs().max())
+        torch.cuda.synchronize()
+        q.put((rank, res))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_shard_views_two_ranks_on_one_device():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_two_rank_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=600) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert res[0]["allreduce_views"] == [0, 2] and res[1]["allreduce_views"] == [1]
+    for r in range(world):
+        for exchange in ("allreduce", "p2p"):
+            assert res[r][exchange + "_n"] == 3                     # ONE exchange per cascade stage
+            assert max(res[r][exchange]) < 1e-3, (r, exchange, res[r][exchange])
+        assert res[r]["volume"] < 1e-6, res[r]["volume"]
+
+
+def test_data_parallel_two_replicas_one_device():
+    """The reference wraps the model in nn.DataParallel when n_gpu > 1: replicas are shallow copies that receive freshly
+    broadcast weights each forward — they must pack from THEIR tensors (not the original module's cached, device-0
+    pointers) and launch on their own device."""
+    dev = torch.device("cuda:0")
+    model = _model(dev)
+    from cds_mvsnet_amd import synth
+    B, N, H, W = 2, 3, 64, 96
+    imgs = torch.cat([synth.make_images(N, H, W, seed=40 + b) for b in range(B)]).to(dev)
+    cams_l = [synth.make_cameras(N, H, W, seed=40 + b) for b in range(B)]
+    cams = {k: torch.cat([c[k] for c in cams_l]).to(dev) for k in cams_l[0]}   # device tensors: DataParallel scatters them
+    dv = synth.make_depth_values().repeat(B, 1).to(dev)
+    with torch.no_grad():
+        want = model(imgs, cams, dv, temperature=0.01)
+        dp = torch.nn.DataParallel(model, device_ids=[0, 0])
+        got = dp(imgs, cams, dv, temperature=0.01)
+    assert got["depth"].shape == want["depth"].shape
+    assert (got["depth"] - want["depth"]).abs().mean() < 1e-3
+    assert (got["stage1"]["photometric_confidence"] - want["stage1"]["photometric_confidence"]).abs().mean() < 1e-3
+
+
+def test_packed_weights_follow_parameter_updates():
+    """load_state_dict / .to() / optimizer-style in-place updates are tracked; `.data` edits need repack()."""
+    dev = torch.device("cuda:0")
+    model = _model(dev)
+    imgs, cams, dv = _inputs(3, 64, 96, 9, dev)
+    with torch.no_grad():
+        a = model(imgs, cams, dv, temperature=0.01)["depth"].clone()
+        other = _model(dev, seed=8)
+        model.load_state_dict(other.state_dict())                   # same storage, new values: the post-hook invalidates
+        b = model(imgs, cams, dv, temperature=0.01)["depth"].clone()
+        want_b = other(imgs, cams, dv, temperature=0.01)["depth"]
+        assert (b - want_b).abs().mean() < 1e-3 and (a - b).abs().mean() > 1e-2
+        for p in model.cost_regularization.parameters():
+            p.data.mul_(0.5)                                        # bypasses the version counter...
+        model.repack()                                              # ...so the documented contract is an explicit repack
+        c = model(imgs, cams, dv, temperature=0.01)["depth"]
+        assert (c - b).abs().mean() > 1e-3
+        for p in model.cost_regularization.parameters():
+            p.mul_(2.0)                                             # in-place through autograd's counter: tracked
+        d = model(imgs, cams, dv, temperature=0.01)["depth"]
+        assert (d - b).abs().mean() < 1e-3
+
+
+def test_config5_training_step_768x576():
+    """BASELINE config 5: BlendedMVS training shape 768x576, N=5, refine=True (configs/config_blended.json), one
+    optimisation step in fp32 and under bf16 autocast: finite losses that agree, every layer updated."""
+    import numpy as np
+    from cds_mvsnet_amd import CDSMVSNet, seeded_init_, synth, train as T
+    import torch.nn.functional as F
+    dev = torch.device("cuda:0")
+    B, N, H, W = 1, 5, 576, 768
+    imgs = synth.make_images(N, H, W, seed=21).to(dev)
+    cams = {k: v.to(dev) for k, v in synth.make_cameras(N, H, W, refine=True, seed=21).items()}
+    dv = synth.make_depth_values().to(dev)
+    g = torch.Generator().manual_seed(9)
+    base = 600.0 + 120.0 * F.interpolate(torch.rand(B, 1, 6, 8, generator=g), (H, W), mode="bicubic", align_corners=False)[:, 0]
+    gt, mask = {}, {}
+    for s, sc in (("stage1", 8), ("stage2", 4), ("stage3", 2), ("stage4", 1)):     # refine=True: stages at 1/8, 1/4, 1/2, 1
+        gt[s] = F.interpolate(base.unsqueeze(1), (H // sc, W // sc), mode="nearest")[:, 0].contiguous().to(dev)
+        mask[s] = (torch.rand(B, H // sc, W // sc, generator=g) > 0.15).float().to(dev)
+    sample = {"imgs": imgs, "proj_matrices": cams, "depth_values": dv, "depth": gt, "mask": mask}
+    losses = {}
+    for bf16 in (False, True):
+        model = seeded_init_(CDSMVSNet(refine=True, ndepths=(48, 32, 8), depth_interals_ratio=(4.0, 1.5, 0.75)), 7).to(dev)
+        opt = T.make_optimizer(model, lr=1e-3)
+        before = {n: p.detach().clone() for n, p in model.named_parameters()}
+        l0, d0 = T.train_step(model, opt, sample, temperature=0.1, reducer=T.GradAllReducer(model.parameters(), module=model),
+                              bf16=bf16)
+        assert np.isfinite(l0) and np.isfinite(d0) and d0 > 0
+        moved = sum(1 for n, p in model.named_parameters() if not torch.equal(p.detach(), before[n]))
+        assert moved > 0.9 * len(before)
+        losses[bf16] = l0
+        del model, opt
+        torch.cuda.empty_cache()
+    assert abs(losses[True] - losses[False]) < 0.05 * abs(losses[False]), losses
