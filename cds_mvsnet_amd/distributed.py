@@ -72,6 +72,13 @@ class ViewShard:
         return [(min(r * step, n), min((r + 1) * step, n)) for r in range(self.world)]
 
     def _p2p_all_reduce(self, flat: Tensor) -> Tensor:
+        if flat.is_cuda and dist.get_backend(self.group) != "nccl":
+            # gloo has no device-tensor send / recv (dry runs of the N > 1 control flow on one GPU): stage through the
+            # host.  RCCL ("nccl") sends straight from HBM over xGMI.
+            host = flat.cpu()
+            self._p2p_all_reduce(host)
+            flat.copy_(host)
+            return flat
         W, me = self.world, self.rank
         sl = self._slices(flat.numel())
         a, b = sl[me]

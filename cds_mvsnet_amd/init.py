@@ -38,9 +38,13 @@ def seeded_init_(module: nn.Module, seed: int = 0) -> nn.Module:
             if "att_convs" in name:
                 std = 0.1
             elif "att_weights.3" in name:
-                # keep softmax(logits / T) un-saturated at the evaluation temperature T = 0.01, the regime of the
-                # trained checkpoints (99.9 % of pixels have max-weight < 0.99); O(1) logits would
-                # turn the blend into a hard switch that amplifies fp32 round-off by 0.25/T per layer.
+                # blend logits of the size the trained checkpoints have.  Measured on the three shipped checkpoints
+                # (profiles/r02_trained_blend_regime.md): per-layer logit gaps 0.002-0.09 at T = 0.01 (largest softmax
+                # weight 0.5-0.9 on average, <= 3 % of pixels saturated), against 0.008-0.05 (0.5-0.95; up to 55 %
+                # saturated in conv10) with this std: the seeded regime is at least as hard on fp32 round-off as the
+                # trained one (the reference's own fp32 forward misses its float64 evaluation by 1.5e-4 .. 3.8e-4 with
+                # these weights and by 1e-5 .. 7e-5 with the trained ones).  O(1) logits would make the blend a hard
+                # switch everywhere, which no trained checkpoint does.
                 std = 0.01
             else:
                 is_transposed = "conv7.conv" in name or "conv9.conv" in name or "conv11.conv" in name or ".deconv." in name

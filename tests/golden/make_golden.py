@@ -183,6 +183,43 @@ def g5_features():
 
 
 @torch.no_grad()
+def g9_feature_noise():
+    """The reference's OWN fp32 round-off on the G5 FeatureNet case, so the FeatureNet tolerances are derived instead of
+    chosen: the same module evaluated (i) in float64 (stored rounded to fp32: the 'exact' answer), (ii) in fp32 with the
+    oneDNN convolutions (= G5) and (iii) in fp32 with ATen's native convolutions (``mkldnn`` off: another valid fp32
+    summation order).  At T = 0.01 the softmax(./T) blend amplifies convolution round-off by up to 0.25 / T per layer,
+    and the reference's two fp32 evaluations already differ by ~1.6e-4 on this image (3.5e-4 at 256x320)."""
+    import copy
+    H, W = 64, 96
+    cams = synth.make_cameras(3, H, W, refine=False, seed=5)["stage3"]
+    e_ref = compute_epipole(compute_Fmatrix(cams[:, 0], cams[:, 1]))
+    img = synth.make_images(1, H, W, seed=5)[:, 0]
+    net = RefFeatureNet(base_channels=8, arch_mode="fpn")
+    seeded_init_(net, SEED)
+    net.eval()
+    net64 = copy.deepcopy(net).double()
+    arrays = {}
+    for T in (1.0, 0.01):
+        a = net(img, epipole=e_ref, temperature=T)
+        with torch.backends.mkldnn.flags(enabled=False):
+            b = net(img, epipole=e_ref, temperature=T)
+        c = net64(img.double(), epipole=e_ref.double(), temperature=T)
+        for s in ("stage1", "stage2", "stage3"):
+            for j, key in enumerate(("fea", "ncsum", "nc")):
+                x64 = c[s][j][0] if j == 0 else c[s][j][0, 0]
+                xa = a[s][j][0] if j == 0 else a[s][j][0, 0]
+                xb = b[s][j][0] if j == 0 else b[s][j][0, 0]
+                arrays[f"{s}_{key}_T{T}_f64"] = x64.float()
+                arrays[f"{s}_{key}_T{T}_ref32_vs_f64_max"] = np.float64((xa.double() - x64).abs().max())
+                arrays[f"{s}_{key}_T{T}_native32_vs_f64_max"] = np.float64((xb.double() - x64).abs().max())
+                arrays[f"{s}_{key}_T{T}_ref32_vs_native32_max"] = np.float64((xa - xb).abs().max())
+    save("g9_featurenet_noise", **arrays)
+    for k, v in arrays.items():
+        if k.endswith("_max"):
+            print(f"  {k}: {float(v):.2e}")
+
+
+@torch.no_grad()
 def g6_forward():
     for tag, (refine, H, W) in {"norefine": (False, 128, 160), "refine": (True, 128, 192)}.items():
         model = ref_model(refine)
@@ -289,6 +326,6 @@ def g8_fusion():
 if __name__ == "__main__":
     only = sys.argv[1:]
     for fn in (g1_warp_aggregate, g2_costreg, g3_regress, g4_hypotheses, g5_features, g6_forward, g7_training_step,
-               g8_fusion):
+               g8_fusion, g9_feature_noise):
         if not only or fn.__name__.split("_")[0] in only:
             fn()

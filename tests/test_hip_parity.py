@@ -268,21 +268,32 @@ def test_featurenet(dev, seeded_state):
     run = _FeatureRunner(net)
     epi = g["epipole"].contiguous()
     img = g["img"].to(dev).unsqueeze(0).contiguous()
+    gn = load_golden("g9_featurenet_noise")
+    worst = {}
     for T in (1.0, 0.01):
         o = run(img, epi, T)                                   # one image, CHW
         o2 = run(torch.cat((img, img)), torch.cat((epi, epi)), T, n_chw=1)   # same image twice: CHW + HWC
         out = {s: (o[s][0][0], o[s][2][0], o[s][3][0]) for s in o}
         out_hwc = {s: (o2[s][1][0],) for s in o2}
-        # 9 InstanceNorm'd layers deep; at T=0.01 the softmax(./T) blend amplifies fp32 round-off of the
-        # curvature responses by up to 0.25/T per layer (per-layer errors measured with tests/tools/diag_featurenet.py:
-        # <=3e-5 at T=1, <=3e-4 at T=0.01, InstanceNorm itself 5e-7) -> bound the mean tightly, the max loosely.
+        # Tolerances are DERIVED from the reference's own fp32 round-off on this input (g9_featurenet_noise, captured by
+        # make_golden.py): the module in float64 is the exact answer, and the reference's two fp32 evaluations of it
+        # (oneDNN / native convolutions) miss it by up to 1.5e-4 at T = 0.01, where the softmax(./T) blend amplifies
+        # convolution round-off by up to 0.25 / T per layer (2.5e-5 at T = 1).  The HIP path must sit inside 3x that
+        # envelope around the float64 answer; the mean error is bounded at the fp32 round-off level as before.
         for s in ("stage1", "stage2", "stage3"):
             for j, key in enumerate(("fea", "ncsum", "nc")):
-                err = (out[s][j].cpu() - g[f"{s}_{key}_T{T}"]).abs()
-                scale = max(1.0, g[f"{s}_{key}_T{T}"].abs().max().item())
-                assert err.mean() < 2e-5 * scale, (s, key, T, err.mean())
-                assert err.max() < 2e-3 * scale, (s, key, T, err.max())
+                k = f"{s}_{key}_T{T}"
+                got = out[s][j].cpu()
+                err32 = (got - g[k]).abs()
+                err64 = (got - gn[k + "_f64"]).abs()
+                envelope = max(float(gn[k + "_ref32_vs_f64_max"]), float(gn[k + "_native32_vs_f64_max"]))
+                scale = max(1.0, g[k].abs().max().item())
+                assert err32.mean() < 2e-5 * scale, (s, key, T, err32.mean())
+                assert err64.max() <= 3.0 * envelope, (s, key, T, float(err64.max()), envelope)
+                worst[k] = (float(err64.max()), envelope)
             assert torch.equal(out_hwc[s][0].permute(2, 0, 1), out[s][0])
+    print("FeatureNet max |HIP - float64 reference| vs the reference's own fp32 envelope:",
+          {k: f"{a:.1e} / {b:.1e}" for k, (a, b) in worst.items()})
 
 
 @pytest.mark.parametrize("tag", ["a", "b", "c"])

@@ -105,12 +105,19 @@ def test_featurenet():
     net = FeatureNet(8)
     seeded_init_(net, 7)
     sd = {"feature." + k: v for k, v in net.state_dict().items()}
+    gn = load_golden("g9_featurenet_noise")
     for T in (1.0, 0.01):
         out = O.feature_net(g["img"].unsqueeze(0), g["epipole"], T, sd)
         for s in ("stage1", "stage2", "stage3"):
             assert (out[s][0][0] - g[f"{s}_fea_T{T}"]).abs().max() < 2e-5, (s, T)
             assert (out[s][1][0, 0] - g[f"{s}_ncsum_T{T}"]).abs().max() < 2e-5, (s, T)
             assert (out[s][2][0, 0] - g[f"{s}_nc_T{T}"]).abs().max() < 2e-5, (s, T)
+            # and against the float64 evaluation of the reference module: inside the reference's own fp32 envelope
+            for j, key in enumerate(("fea", "ncsum", "nc")):
+                k = f"{s}_{key}_T{T}"
+                got = out[s][j][0] if j == 0 else out[s][j][0, 0]
+                env = max(float(gn[k + "_ref32_vs_f64_max"]), float(gn[k + "_native32_vs_f64_max"]))
+                assert (got - gn[k + "_f64"]).abs().max() <= 1.5 * env, (k, env)
 
 
 @pytest.mark.parametrize("tag,refine", [("norefine", False), ("refine", True)])
