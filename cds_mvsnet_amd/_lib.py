@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("CDS_MVSNET_LIB") or os.path.join(_HERE, "libcdsmvs_hi
 
 # activation / flag codes (mirror include/cds_mvsnet_hip.h)
 ACT_NONE, ACT_RELU, ACT_LEAKY01, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3, 4
-AGG_ACCUMULATE, AGG_NORMALIZE = 1, 2
+AGG_ACCUMULATE, AGG_NORMALIZE, AGG_CHANNELS_LAST = 1, 2, 4
 MAX_VIEWS = 8
 MAX_IMAGES = 16
 EINVAL = -1000
@@ -34,11 +34,15 @@ SIGNATURES = {
     "cds_warp_aggregate_f32": [P, P, P, P, P, P, P, I, I, I, I, I, I, I, P],
     "cds_warp_aggregate_bwd_f32": [P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, P],
     "cds_volume_normalize_f32": [P, P, I, I, I, P],
+    "cds_volume_normalize_cl_f32": [P, P, I, I, I, P],
     "cds_softargmin_conf_f32": [P, P, P, P, P, I, I, I, I, P],
     "cds_depth_hypotheses_f32": [P, P, I, I, I, I, I, I, F, F, F, P],
     "cds_depth_planes_f32": [P, I, I, I, F, F, P],
     "cds_conv3d_k3_f32": [P, P, P, P, P, I, I, I, I, I, I, I, P],
     "cds_conv3d_k3_cl_f32": [P, P, P, P, P, I, I, I, I, I, I, P],
+    "cds_conv3d_sbf_f32": [P, P, P, P, P, I, I, I, I, I, I, I, P],
+    "cds_deconv3d_sbf_f32": [P, P, P, P, P, I, I, I, I, I, I, I, P],
+    "cds_conv3d_prob_cl8_f32": [P, P, P, I, I, I, P],
     "cds_deconv3d_k3s2_f32": [P, P, P, P, P, I, I, I, I, I, I, P],
     "cds_conv2d_f32": [P, P, P, P, I, I, I, I, I, I, I, I, I, P],
     "cds_conv2d_affine_f32": [P, P, P, P, P, I, I, I, I, I, I, I, I, I, P],

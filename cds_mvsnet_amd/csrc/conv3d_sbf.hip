@@ -1,0 +1,703 @@
+// K4 on the bf16 matrix cores with fp32-equivalent arithmetic ("split-bf16", 3xBF16 error-compensated products).
+//
+// Every fp32 operand is split exactly into three bf16 terms, a = a1 + a2 + a3 (a1 = RN_bf16(a), a2 = RN_bf16(a - a1),
+// a3 = a - a1 - a2: 3 x 8 significand bits = the 24 bits of fp32, the residuals are exact), and a product a*b is
+// evaluated as the six partial products of order <= 2^-16,
+//       a1 b1 + (a1 b2 + a2 b1) + (a1 b3 + a2 b2 + a3 b1),
+// each exact in the MFMA (bf16 x bf16 fits fp32) and accumulated in fp32 by v_mfma_f32_16x16x32_bf16.  The dropped
+// terms (a2 b3, a3 b2, a3 b3) are <= 2^-23 |a b|: the size of the ONE rounding an fp32 multiply makes, so the result
+// carries fp32-class error (tests/test_hip_parity.py::test_conv3d_split_bf16_*: measured against float64, inside 1.5x
+// the error of PyTorch's own fp32 convolution) while the matrix pipe runs the bf16 instruction at 16x the fp32-MFMA
+// rate: 6 bf16 MFMAs (K = 32 each) replace 16 fp32 ones (K = 4 each), and ONE ds_read_b128 feeds a 16-voxel x 8-channel
+// operand instead of one ds_read_b32 per MFMA.
+//
+// Activations are channels-last fp32 in HBM, [D][H][W][C] (a voxel's C channels are contiguous: 32 B at C = 8), which is
+// what the fused warp-aggregate kernel stores (one 32-byte vector store per voxel) and what makes the staging loads and
+// the epilogue stores of every layer full 16-byte lanes on contiguous runs.
+//
+//   transposed implicit GEMM:  D[i = cout][j = voxel] += A[i][k] * B[k][j],  K-step = 32 = 4 taps x 8 channels
+//   LDS tile: [position][term 0..2][8 channels] bf16 (48 B per position: 16 consecutive positions hit all 64 banks once),
+//             staged 8 input channels per round from the fp32 volume with the split done in registers
+//   B (data): lane l -> voxel (l & 15) of a 16-voxel x-run, tap (l >> 4) of the K-step: one ds_read_b128 per term
+//   A (weights): host-split [round][kstep][mblock][term][lane][8]: one coalesced 16-byte load per lane, term, K-step
+//   C/D: lane l holds voxel (l & 15), couts 16 mb + 4 (l >> 4) + 0..3 -> one 16-byte channels-last store per N-tile
+#include <stdlib.h>
+
+#include "cds_common.hpp"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+union BV {
+  uint4 u;
+  bf16x8 v;
+};
+
+// exact three-way split of two floats: packed (hi0,hi1), (mid0,mid1), (lo0,lo1)
+__device__ __forceinline__ void split2(float a, float b, uint32_t& hi, uint32_t& mid, uint32_t& lo) {
+  f32x2 v = {a, b};
+  bf16x2 h = __builtin_convertvector(v, bf16x2);
+  f32x2 r = v - __builtin_convertvector(h, f32x2);
+  bf16x2 m = __builtin_convertvector(r, bf16x2);
+  f32x2 r2 = r - __builtin_convertvector(m, f32x2);
+  bf16x2 l = __builtin_convertvector(r2, bf16x2);
+  hi = *reinterpret_cast<uint32_t*>(&h);
+  mid = *reinterpret_cast<uint32_t*>(&m);
+  lo = *reinterpret_cast<uint32_t*>(&l);
+}
+
+// split the 8 channels of one position (two float4) and store them as [term][8] bf16 (48 B)
+__device__ __forceinline__ void split_store8(unsigned char* dst, const float4& a, const float4& b) {
+  uint32_t h[4], m[4], l[4];
+  split2(a.x, a.y, h[0], m[0], l[0]);
+  split2(a.z, a.w, h[1], m[1], l[1]);
+  split2(b.x, b.y, h[2], m[2], l[2]);
+  split2(b.z, b.w, h[3], m[3], l[3]);
+  uint4* d4 = reinterpret_cast<uint4*>(dst);
+  d4[0] = make_uint4(h[0], h[1], h[2], h[3]);
+  d4[1] = make_uint4(m[0], m[1], m[2], m[3]);
+  d4[2] = make_uint4(l[0], l[1], l[2], l[3]);
+}
+
+#define SBF_MFMA(acc, a, b) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16((a).v, (b).v, acc, 0, 0, 0)
+
+// The six partial products of one K-step for NQ independent accumulators, smallest terms first; W[term] = weights
+// (hi, mid, lo), X[q][term] = data of N-tile q.
+#define SBF_TERMS(ACC, T0, NQ, W, X)                                             \
+  _Pragma("unroll") for (int q_ = 0; q_ < (NQ); ++q_) SBF_MFMA(ACC[(T0) + q_], (W)[2], (X)[q_][0]); /* lo x hi  */ \
+  __builtin_amdgcn_sched_barrier(0);                                             \
+  _Pragma("unroll") for (int q_ = 0; q_ < (NQ); ++q_) SBF_MFMA(ACC[(T0) + q_], (W)[1], (X)[q_][1]); /* mid x mid */ \
+  __builtin_amdgcn_sched_barrier(0);                                             \
+  _Pragma("unroll") for (int q_ = 0; q_ < (NQ); ++q_) SBF_MFMA(ACC[(T0) + q_], (W)[0], (X)[q_][2]); /* hi x lo  */ \
+  __builtin_amdgcn_sched_barrier(0);                                             \
+  _Pragma("unroll") for (int q_ = 0; q_ < (NQ); ++q_) SBF_MFMA(ACC[(T0) + q_], (W)[1], (X)[q_][0]); /* mid x hi */ \
+  __builtin_amdgcn_sched_barrier(0);                                             \
+  _Pragma("unroll") for (int q_ = 0; q_ < (NQ); ++q_) SBF_MFMA(ACC[(T0) + q_], (W)[0], (X)[q_][1]); /* hi x mid */ \
+  __builtin_amdgcn_sched_barrier(0);                                             \
+  _Pragma("unroll") for (int q_ = 0; q_ < (NQ); ++q_) SBF_MFMA(ACC[(T0) + q_], (W)[0], (X)[q_][0]); /* hi x hi  */ \
+  __builtin_amdgcn_sched_barrier(0);
+
+constexpr int POSB = 48;   // bytes per LDS position
+
+// ---------------------------------------------------------------------------------------------
+// forward convolution, stride S in {1, 2}, pad 1.  MB: 16-cout blocks; output tile TX x 4 x TZ (wave = y row).
+// Stride 2 de-interleaves the x parities of the staged tile (position = row * IXP + parity * IXH + (col >> 1)), so that the
+// 16 voxels of an N-tile read 16 consecutive positions for every tap.
+// ---------------------------------------------------------------------------------------------
+// PAIR (stride 1, Cout == 8): an MFMA column is a PAIR of x-adjacent voxels and its 16 rows are (x parity, cout): both
+// halves of the matrix tile carry real outputs (with rows = 16 couts, half of every MFMA would multiply zero padding).  The
+// K window is 3 x 3 x 4 taps (x' = 0..3 relative to the pair; weight row (p, co) is w[x' - p] or 0): 9 K-steps per 32 voxels
+// instead of 14, and as many fewer LDS operand reads.  The x parities of the staged tile are de-interleaved as for stride 2.
+template <int S, int MB, int TX_, int TZ_, bool PAIR = false>
+struct FCfg {
+  static constexpr int TX = TX_, TY = 4, TZ = TZ_;
+  static constexpr bool DEINT = S == 2 || PAIR;
+  static constexpr int XT = TX / (PAIR ? 32 : 16), NT = XT * TZ;   // N-tiles per y row of the tile
+  static constexpr int IX = (TX - 1) * S + 3, IY = (TY - 1) * S + 3, IZ = (TZ - 1) * S + 3;
+  static constexpr int IXH = DEINT ? (IX + 1) / 2 : 0;              // positions per parity half-row
+  static constexpr int IXP = DEINT ? 2 * IXH : (IX + 7) / 8 * 8;    // positions per row
+  static constexpr int NPOS = IZ * IY * IXP;
+  static constexpr int LDSB = NPOS * POSB;
+  static constexpr int KW = PAIR ? 4 : 3;                            // taps along x
+  static constexpr int KSTEPS = (9 * KW + 3) / 4;                    // 27 taps + 1 zero tap (7) | 36 taps (9), 4 per K-step
+  // consumer waves: two per SIMD when a y row has >= 2 N-tiles to split between them (one waits for LDS, the other issues)
+  static constexpr int CW = (NT >= 2 && MB < 4) ? 8 : 4;             // (MB = 4: the accumulators need the 256-register budget)
+  static constexpr int NTW = NT / (CW / 4);                          // N-tiles per consumer wave
+  static constexpr int NG = MB == 1 ? (NTW < 4 ? NTW : 4) : (NTW < 2 ? NTW : 2);   // N-tiles whose operands are in registers together
+  static constexpr bool WDB = MB < 4;                                // weights double-buffered across K-steps (register budget)
+  static constexpr int THREADS = (CW + 4) * 64;
+};
+
+// Warp-specialised, persistent over TPW consecutive tiles (and the Cin / 8 channel rounds of each): 512 threads = 4 consumer
+// waves (one per SIMD; wave = output row y: LDS reads + MFMAs + epilogue stores, nothing else) and 4 producer waves (global
+// loads -> exact bf16 split in registers -> LDS writes), double-buffered LDS tile, ONE workgroup barrier per stage.  The
+// producers run a stage ahead in LDS and another one ahead in registers, so the matrix pipe never waits for staging: with
+// the staging in the same waves as the MFMAs, the two workgroups of a CU fell into lock-step and the pipe idled half the time.
+template <int S, int MB, int TX_, int TZ_, bool PAIR = false>
+__global__ __launch_bounds__((FCfg<S, MB, TX_, TZ_, PAIR>::THREADS)) void conv3d_sbf_kernel(const float* __restrict__ x, const uint4* __restrict__ wsp,
+                                                            const float* __restrict__ bias, const float* __restrict__ skip,
+                                                            float* __restrict__ out, int Cin, int Cout, int D, int H, int W,
+                                                            int Do, int Ho, int Wo, int act, int tiles_x, int tiles_y,
+                                                            int ntiles, int tpw) {
+  using Cfg = FCfg<S, MB, TX_, TZ_, PAIR>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nwg = gridDim.x;
+  const int wg = cds_xcd_remap(blockIdx.x, nwg);
+  const int tile0 = wg * tpw, tile1 = min(ntiles, tile0 + tpw);
+  const int rounds = Cin >> 3;
+  const int nstages = (tile1 - tile0) * rounds;
+  if (nstages <= 0) return;
+
+  if (wave >= Cfg::CW) {
+    // ============================== producers ==============================
+    const int ptid = tid - Cfg::CW * 64;
+    constexpr int NP = Cfg::IZ * Cfg::IY * Cfg::IX;
+    constexpr int PPT = (NP + 255) / 256;
+    int s_rel[PPT];   // packed (rz << 20) | (ry << 10) | c, -1 = no position
+    int s_dst[PPT];   // LDS byte offset inside a buffer
+#pragma unroll
+    for (int h = 0; h < PPT; ++h) {
+      const int p = h * 256 + ptid;
+      const int row = p / Cfg::IX, c = p - row * Cfg::IX;
+      const int rz = row / Cfg::IY, ry = row - rz * Cfg::IY;
+      s_rel[h] = p < NP ? ((rz << 20) | (ry << 10) | c) : -1;
+      s_dst[h] = (row * Cfg::IXP + (Cfg::DEINT ? ((c & 1) * Cfg::IXH + (c >> 1)) : c)) * POSB;
+    }
+    float4 va[PPT], vb[PPT];
+    auto issue = [&](int st) {
+      const int tile = tile0 + st / rounds, rd = st % rounds;
+      const int tx_i = tile % tiles_x, ty_i = (tile / tiles_x) % tiles_y, tz_i = tile / (tiles_x * tiles_y);
+      const int gx0 = tx_i * Cfg::TX * S - 1, gy0 = ty_i * Cfg::TY * S - 1, gz0 = tz_i * Cfg::TZ * S - 1;
+#pragma unroll
+      for (int h = 0; h < PPT; ++h) {
+        const int gz = gz0 + (s_rel[h] >> 20), gy = gy0 + ((s_rel[h] >> 10) & 1023), gx = gx0 + (s_rel[h] & 1023);
+        const bool ok = s_rel[h] >= 0 && (unsigned)gz < (unsigned)D && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+        const float* __restrict__ src = x + ((size_t)((size_t)gz * H + gy) * W + gx) * Cin + rd * 8;
+        va[h] = ok ? *reinterpret_cast<const float4*>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
+        vb[h] = ok ? *reinterpret_cast<const float4*>(src + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    };
+    auto deposit = [&](int buf) {
+      unsigned char* base = lds + buf * Cfg::LDSB;
+#pragma unroll
+      for (int h = 0; h < PPT; ++h)
+        if (s_rel[h] >= 0) split_store8(base + s_dst[h], va[h], vb[h]);
+    };
+    issue(0);
+    deposit(0);
+    if (nstages > 1) issue(1);
+    __syncthreads();                                   // #0: buffer 0 holds stage 0
+    for (int st = 0; st < nstages; ++st) {
+#ifndef CDS_EXP_SBF_NOPRODUCE
+      if (st + 1 < nstages) {
+        deposit((st + 1) & 1);                         // its loads were issued one stage ago
+        if (st + 2 < nstages) issue(st + 2);
+      }
+#endif
+      __syncthreads();                                 // #(st + 1): stage st consumed, stage st + 1 staged
+    }
+    return;
+  }
+
+  // ============================== consumers ==============================
+  const int j = lane & 15, g = lane >> 4;
+  // per-lane byte offset of the tap this lane group multiplies in K-step t (tap 27 = zero weights -> any in-tile data)
+  int toff[Cfg::KSTEPS];
+#pragma unroll
+  for (int t = 0; t < Cfg::KSTEPS; ++t) {
+    int tap = 4 * t + g;
+    if (tap > 9 * Cfg::KW - 1) tap = 9 * Cfg::KW - 1;
+    const int kz = tap / (3 * Cfg::KW), ky = (tap / Cfg::KW) % 3, kx = tap % Cfg::KW;
+    const int xoff = Cfg::DEINT ? ((kx & 1) * Cfg::IXH + (kx >> 1)) : kx;
+    toff[t] = ((kz * Cfg::IY + ky) * Cfg::IXP + xoff) * POSB;
+  }
+  const int wy = wave & 3, wh = wave >> 2;             // output row y, share of the row's N-tiles
+  const int b_base = (wy * S * Cfg::IXP + j) * POSB;
+
+  f32x4 acc[MB][Cfg::NTW];
+  const uint4* __restrict__ wl = wsp + lane;
+  __syncthreads();                                     // #0
+  int st = 0;
+  for (int tile = tile0; tile < tile1; ++tile) {
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int t = 0; t < Cfg::NTW; ++t) acc[mb][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int rd = 0; rd < rounds; ++rd, ++st) {
+      const unsigned char* tbuf = lds + (st & 1) * Cfg::LDSB;
+      // Flat software pipeline over the NS = KSTEPS x (NT / NG) stages of the round: the operands of step s + 1 (data
+      // from LDS; the weights of the next K-step from L1 / L2) are requested BEFORE the 6 NG MB MFMAs of step s.
+      const uint4* __restrict__ wr = wl + (size_t)rd * Cfg::KSTEPS * MB * 3 * 64;
+      constexpr int NGRP = Cfg::NTW / Cfg::NG, NS = Cfg::KSTEPS * NGRP;
+      BV wa[2][MB][3];
+      BV bd[2][Cfg::NG][3];
+      auto load_w = [&](int buf, int t) {
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+#ifdef CDS_EXP_SBF_NOWLOAD
+          wa[buf][mb][0].u = make_uint4(t, mb, lane, 1); wa[buf][mb][1].u = make_uint4(t, mb, lane, 2); wa[buf][mb][2].u = make_uint4(t, mb, lane, 3);
+#else
+          const uint4* p = wr + (size_t)((t * MB + mb) * 3) * 64;
+          wa[buf][mb][0].u = p[0];
+          wa[buf][mb][1].u = p[64];
+          wa[buf][mb][2].u = p[128];
+#endif
+        }
+      };
+      auto load_b = [&](int buf, int t, int grp) {
+        const unsigned char* bp = tbuf + b_base + toff[t];
+#pragma unroll
+        for (int q = 0; q < Cfg::NG; ++q) {
+          const int ti = wh * Cfg::NTW + grp * Cfg::NG + q, tz = ti / Cfg::XT, txr = ti % Cfg::XT;
+          const unsigned char* b = bp + ((tz * S * Cfg::IY) * Cfg::IXP + txr * 16) * POSB;
+#ifdef CDS_EXP_SBF_NOLDSREAD
+          bd[buf][q][0].u = make_uint4(t, ti, lane, 1); bd[buf][q][1].u = make_uint4(t, ti, lane, 2); bd[buf][q][2].u = make_uint4(t, ti, lane, 3);
+          (void)b;
+#else
+          bd[buf][q][0].u = *reinterpret_cast<const uint4*>(b);
+          bd[buf][q][1].u = *reinterpret_cast<const uint4*>(b + 16);
+          bd[buf][q][2].u = *reinterpret_cast<const uint4*>(b + 32);
+#endif
+        }
+      };
+      load_w(0, 0);
+      load_b(0, 0, 0);
+#pragma unroll
+      for (int ss = 0; ss < NS; ++ss) {
+        const int t = ss / NGRP, grp = ss % NGRP;
+        const int wb = Cfg::WDB ? (t & 1) : 0, db = ss & 1;
+        if (ss + 1 < NS) load_b(db ^ 1, (ss + 1) / NGRP, (ss + 1) % NGRP);
+        if (Cfg::WDB) {
+          if (grp == 0 && t + 1 < Cfg::KSTEPS) load_w(wb ^ 1, t + 1);
+        } else if (grp == 0 && t > 0) {
+          load_w(0, t);
+        }
+        const int t0 = grp * Cfg::NG;
+        // Term-major over independent accumulators; the sched_barriers pin that order and keep the operand requests above
+        // ahead of the MFMAs (left alone, the machine scheduler sinks the loads to their first use).
+        __builtin_amdgcn_sched_barrier(0);
+#ifndef CDS_EXP_SBF_NOMFMA
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+          SBF_TERMS(acc[mb], t0, Cfg::NG, wa[wb][mb], bd[db]);
+        }
+#else
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+          for (int q = 0; q < Cfg::NG; ++q) {
+            acc[mb][t0 + q].x += __uint_as_float(wa[wb][mb][0].u.x ^ bd[db][q][0].u.x ^ bd[db][q][1].u.y ^ bd[db][q][2].u.z ^ wa[wb][mb][1].u.w ^ wa[wb][mb][2].u.x);
+          }
+#endif
+      }
+      if (rd + 1 == rounds) {
+        // ---- epilogue: lane -> voxel j of the run, couts 16 mb + 4 g + 0..3: one 16-byte channels-last store ----
+        const int tx_i = tile % tiles_x, ty_i = (tile / tiles_x) % tiles_y, tz_i = tile / (tiles_x * tiles_y);
+        const int ox0 = tx_i * Cfg::TX, oy = ty_i * Cfg::TY + wy, oz0 = tz_i * Cfg::TZ;
+        if (oy < Ho) {
+#pragma unroll
+          for (int mb = 0; mb < MB; ++mb) {
+            const int co = PAIR ? 4 * (g & 1) : mb * 16 + 4 * g;   // PAIR: rows = (x parity g >> 1, cout)
+            if (co >= Cout) continue;                          // Cout % 4 == 0 (host)
+            const float4 bv = bias ? *reinterpret_cast<const float4*>(bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int tl = 0; tl < Cfg::NTW; ++tl) {
+              const int ti = wh * Cfg::NTW + tl, tz = ti / Cfg::XT, txr = ti % Cfg::XT;
+              const int oz = oz0 + tz, ox = PAIR ? ox0 + txr * 32 + 2 * j + (g >> 1) : ox0 + txr * 16 + j;
+              if (oz >= Do || ox >= Wo) continue;
+              const size_t base = ((size_t)((size_t)oz * Ho + oy) * Wo + ox) * Cout + co;
+              float4 o = make_float4(acc[mb][tl].x + bv.x, acc[mb][tl].y + bv.y, acc[mb][tl].z + bv.z, acc[mb][tl].w + bv.w);
+              if (act == CDS_ACT_RELU) {
+                o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
+              }
+              if (skip) {
+                const float4 s4 = *reinterpret_cast<const float4*>(skip + base);
+                o.x = s4.x + o.x; o.y = s4.y + o.y; o.z = s4.z + o.z; o.w = s4.w + o.w;
+              }
+#ifdef CDS_EXP_SBF_NOSTORE
+              if (o.x == 1234.5f)
+#endif
+              *reinterpret_cast<float4*>(out + base) = o;
+            }
+          }
+        }
+      }
+      __syncthreads();                                 // #(st + 1)
+    }
+  }
+}
+
+template <int S, int MB, int TX, int TZ, bool PAIR = false>
+int launch_fwd(const float* x, const void* wsp, const float* b, const float* skip, float* out, int Cin, int Cout, int D, int H,
+               int W, int act, hipStream_t st) {
+  using Cfg = FCfg<S, MB, TX, TZ, PAIR>;
+  static_assert(2 * Cfg::LDSB <= 160 * 1024, "two LDS tile buffers above 160 KB");
+  const int Do = (D - 1) / S + 1, Ho = (H - 1) / S + 1, Wo = (W - 1) / S + 1;
+  const int tx = cds_ceil_div(Wo, Cfg::TX), ty = cds_ceil_div(Ho, Cfg::TY), tz = cds_ceil_div(Do, Cfg::TZ);
+  const int ntiles = tx * ty * tz;
+  // tiles per workgroup: enough workgroups for ~6 rounds of one per CU (two where the LDS allows), at most 32 tiles each
+  static const int tpw_env = []() { const char* e = getenv("CDS_SBF_TPW"); return e ? atoi(e) : 0; }();   // A/B knob
+  int tpw = tpw_env > 0 ? tpw_env : max(1, min(32, ntiles / (256 * 6)));
+  const int nwg = cds_ceil_div(ntiles, tpw);
+  auto kern = conv3d_sbf_kernel<S, MB, TX, TZ, PAIR>;
+  constexpr int lds_bytes = 2 * Cfg::LDSB;
+  if (lds_bytes > 64 * 1024) {
+    static bool attr_done = false;   // once per instantiation
+    if (!attr_done) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+      attr_done = true;
+    }
+  }
+  hipLaunchKernelGGL(kern, dim3(nwg), dim3(Cfg::THREADS), lds_bytes, st, x, reinterpret_cast<const uint4*>(wsp), b, skip, out, Cin,
+                     Cout, D, H, W, Do, Ho, Wo, act, tx, ty, ntiles, tpw);
+  return cds_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Transposed convolution k3 s2 p1 op1 (ConvTranspose3d, models/module.py:125-160), channels-last, split-bf16.
+// Output voxel o = 2 a + p per axis: parity 0 takes tap k = 1 of input cell a; parity 1 takes tap 2 of cell a and tap 0 of
+// cell a + 1.  A workgroup stages 32 x 4 x 1 input cells (+1 halo on the high sides) and produces all 8 parity classes:
+// class c = (pz, py, px) is a small convolution over (1 + pz)(1 + py)(1 + px) taps.
+//   MERGE = false (Cout % 16 == 0): one accumulator set per class, M rows = 16 couts; K-steps per round: 1,1,1,1,1,1,1,2.
+//   MERGE = true  (Cout == 8): the two x parities of a (pz, py) class share an MFMA: M rows = (px, cout), K = its taps x
+//     {cell a, cell a + 1}; K-steps per round: 1,1,1,2; a lane's four rows are 4 couts of ONE output voxel, and the two
+//     voxels of a cell are adjacent in memory: each wave store covers 1 KB of contiguous channels-last output.
+// ---------------------------------------------------------------------------------------------
+template <bool MERGE>
+struct DTab {
+  static constexpr int NCLS = MERGE ? 4 : 8;
+  static constexpr int NKS = MERGE ? 5 : 9;                 // K-steps per round over all classes
+  // K-step index -> class, first tap slot
+  __host__ __device__ static constexpr int cls_of(int ks) { return MERGE ? (ks < 3 ? ks : 3) : (ks < 7 ? ks : 7); }
+  __host__ __device__ static constexpr int slot0_of(int ks) { return MERGE ? (ks == 4 ? 4 : 0) : (ks == 8 ? 4 : 0); }
+  // tap slot s of class c -> (dz, dy, dx) cell offsets, or -1 when the slot is padding
+  __host__ __device__ static constexpr int ntaps(int c) {
+    return MERGE ? (1 + (c >> 1)) * (1 + (c & 1)) * 2 : (1 + (c >> 2)) * (1 + ((c >> 1) & 1)) * (1 + (c & 1));
+  }
+  __host__ __device__ static constexpr int tap_d(int c, int s, int axis) {   // axis 0 = z, 1 = y, 2 = x
+    const int pz = MERGE ? (c >> 1) : (c >> 2), py = MERGE ? (c & 1) : ((c >> 1) & 1), px = MERGE ? 1 : (c & 1);
+    const int nz = 1 + pz, ny = 1 + py, nx = 1 + px;
+    if (s >= nz * ny * nx) return -1;
+    const int iz = s / (ny * nx), iy = (s / nx) % ny, ix = s % nx;
+    return axis == 0 ? iz : axis == 1 ? iy : ix;
+  }
+};
+
+struct DCfg {
+  static constexpr int CX = 32, CY = 4;
+  static constexpr int XT = CX / 16, NT = XT;
+  static constexpr int IX = CX + 1, IY = CY + 1, IZ = 2;
+  static constexpr int IXP = 40;
+  static constexpr int NPOS = IZ * IY * IXP;
+  static constexpr int LDSB = NPOS * POSB;
+};
+
+template <bool MERGE, int MB>
+__global__ __launch_bounds__(256, 2) void deconv3d_sbf_kernel(const float* __restrict__ x, const uint4* __restrict__ wsp,
+                                                              const float* __restrict__ bias, const float* __restrict__ skip,
+                                                              float* __restrict__ out, int Cin, int Cout, int D, int H, int W,
+                                                              int act, int out_planar, int tiles_x, int tiles_y, int ntiles,
+                                                              int tpw) {
+  using Cfg = DCfg;
+  using Tab = DTab<MERGE>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // = cell row y of this wave inside the tile
+  const int j = lane & 15, g = lane >> 4;
+  const int nwg = gridDim.x;
+  const int wg = cds_xcd_remap(blockIdx.x, nwg);
+  const int tile0 = wg * tpw, tile1 = min(ntiles, tile0 + tpw);
+  const int rounds = Cin >> 3;
+
+  int toff[Tab::NKS];
+#pragma unroll
+  for (int ks = 0; ks < Tab::NKS; ++ks) {
+    const int c = Tab::cls_of(ks), s0 = Tab::slot0_of(ks);
+    int off = 0;
+#pragma unroll
+    for (int gg = 0; gg < 4; ++gg) {
+      const int dz = Tab::tap_d(c, s0 + gg, 0), dy = Tab::tap_d(c, s0 + gg, 1), dx = Tab::tap_d(c, s0 + gg, 2);
+      const int o = dz < 0 ? 0 : ((dz * Cfg::IY + dy) * Cfg::IXP + dx) * POSB;
+      off = g == gg ? o : off;
+    }
+    toff[ks] = off;
+  }
+  const int b_base = (wave * Cfg::IXP + j) * POSB;
+
+  constexpr int NP = Cfg::IZ * Cfg::IY * Cfg::IX;
+  constexpr int PPT = (NP + 255) / 256;
+  int s_rel[PPT], s_dst[PPT];
+#pragma unroll
+  for (int h = 0; h < PPT; ++h) {
+    const int p = h * 256 + tid;
+    const int row = p / Cfg::IX, c = p - row * Cfg::IX;
+    const int rz = row / Cfg::IY, ry = row - rz * Cfg::IY;
+    s_rel[h] = p < NP ? ((rz << 20) | (ry << 10) | c) : -1;
+    s_dst[h] = (row * Cfg::IXP + c) * POSB;
+  }
+  float4 va[PPT], vb[PPT];
+  auto issue = [&](int tile, int rd) {
+    const int tx_i = tile % tiles_x, ty_i = (tile / tiles_x) % tiles_y, az = tile / (tiles_x * tiles_y);
+    const int gx0 = tx_i * Cfg::CX, gy0 = ty_i * Cfg::CY;
+#pragma unroll
+    for (int h = 0; h < PPT; ++h) {
+      const int gz = az + (s_rel[h] >> 20), gy = gy0 + ((s_rel[h] >> 10) & 1023), gx = gx0 + (s_rel[h] & 1023);
+      const bool ok = s_rel[h] >= 0 && gz < D && gy < H && gx < W;
+      const float* __restrict__ src = x + ((size_t)((size_t)gz * H + gy) * W + gx) * Cin + rd * 8;
+      va[h] = ok ? *reinterpret_cast<const float4*>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
+      vb[h] = ok ? *reinterpret_cast<const float4*>(src + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto deposit = [&]() {
+#pragma unroll
+    for (int h = 0; h < PPT; ++h)
+      if (s_rel[h] >= 0) split_store8(lds + s_dst[h], va[h], vb[h]);
+  };
+
+  f32x4 acc[Tab::NCLS][MB][Cfg::NT];
+  constexpr bool SKIP_PF = MERGE;                      // residual prefetched ahead of the last round's MFMAs (register budget)
+  constexpr bool WDB = MB == 1;                        // weights double-buffered across K-steps (register budget)
+  float4 skv[SKIP_PF ? Tab::NCLS : 1][Cfg::NT];
+  const uint4* __restrict__ wl = wsp + lane;
+  const int Ho = 2 * H, Wo = 2 * W;
+  if (tile0 < tile1) issue(tile0, 0);
+  for (int tile = tile0; tile < tile1; ++tile) {
+    const int tx_i = tile % tiles_x, ty_i = (tile / tiles_x) % tiles_y, az = tile / (tiles_x * tiles_y);
+    const int ay = ty_i * Cfg::CY + wave;
+#pragma unroll
+    for (int c = 0; c < Tab::NCLS; ++c)
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int t = 0; t < Cfg::NT; ++t) acc[c][mb][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int rd = 0; rd < rounds; ++rd) {
+      __syncthreads();
+      deposit();
+      __syncthreads();
+      if (rd + 1 < rounds) issue(tile, rd + 1);
+      else if (tile + 1 < tile1) issue(tile + 1, 0);
+      if (SKIP_PF && skip && rd + 1 == rounds && ay < H) {
+        // the U-Net skip tensor of this tile's outputs: requested now, added after the MFMAs
+#pragma unroll
+        for (int c = 0; c < Tab::NCLS; ++c) {
+          const int pz = MERGE ? (c >> 1) : (c >> 2), py = MERGE ? (c & 1) : ((c >> 1) & 1);
+          const int px = MERGE ? (g >> 1) : (c & 1);
+          const int co = MERGE ? 4 * (g & 1) : 4 * g;
+          const size_t rowbase = ((size_t)(2 * az + pz) * Ho + (2 * ay + py)) * Wo;
+#pragma unroll
+          for (int q = 0; q < Cfg::NT; ++q) {
+            const int ax = min(tx_i * Cfg::CX + q * 16 + j, W - 1);
+            skv[c][q] = *reinterpret_cast<const float4*>(skip + (rowbase + 2 * ax + px) * Cout + co);
+          }
+        }
+      }
+      // K-steps of all classes, software-pipelined: the operands of K-step ks + 1 are requested before the MFMAs of ks
+      const uint4* __restrict__ wr = wl + (size_t)rd * Tab::NKS * MB * 3 * 64;
+      BV wa[2][MB][3];
+      BV bd[2][Cfg::NT][3];
+      auto load_w = [&](int buf, int ks) {
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+          const uint4* p = wr + (size_t)((ks * MB + mb) * 3) * 64;
+          wa[buf][mb][0].u = p[0];
+          wa[buf][mb][1].u = p[64];
+          wa[buf][mb][2].u = p[128];
+        }
+      };
+      auto load_b = [&](int buf, int ks) {
+        const unsigned char* bp = lds + b_base + toff[ks];
+#pragma unroll
+        for (int q = 0; q < Cfg::NT; ++q) {
+          const unsigned char* b = bp + q * 16 * POSB;
+          bd[buf][q][0].u = *reinterpret_cast<const uint4*>(b);
+          bd[buf][q][1].u = *reinterpret_cast<const uint4*>(b + 16);
+          bd[buf][q][2].u = *reinterpret_cast<const uint4*>(b + 32);
+        }
+      };
+      load_w(0, 0);
+      load_b(0, 0);
+#pragma unroll
+      for (int ks = 0; ks < Tab::NKS; ++ks) {
+        const int c = Tab::cls_of(ks), cur = ks & 1, wcur = WDB ? cur : 0;
+        if (!WDB && ks > 0) load_w(0, ks);
+        if (ks + 1 < Tab::NKS) {
+          load_b(cur ^ 1, ks + 1);
+          if (WDB) load_w(cur ^ 1, ks + 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+          SBF_TERMS(acc[c][mb], 0, Cfg::NT, wa[wcur][mb], bd[cur]);
+        }
+      }
+    }
+
+    // ---- epilogue ----
+    if (ay < H) {
+#pragma unroll
+      for (int c = 0; c < Tab::NCLS; ++c) {
+        const int pz = MERGE ? (c >> 1) : (c >> 2), py = MERGE ? (c & 1) : ((c >> 1) & 1);
+        const int px = MERGE ? (g >> 1) : (c & 1);
+        const size_t rowbase = ((size_t)(2 * az + pz) * Ho + (2 * ay + py)) * Wo;
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+          const int co = MERGE ? 4 * (g & 1) : mb * 16 + 4 * g;
+          const float4 bv = bias ? *reinterpret_cast<const float4*>(bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+          for (int q = 0; q < Cfg::NT; ++q) {
+            const int ax = tx_i * Cfg::CX + q * 16 + j;
+            if (ax >= W) continue;
+            const size_t base = (rowbase + 2 * ax + px) * Cout + co;
+            const f32x4 a = acc[c][mb][q];
+            float4 o = make_float4(a.x + bv.x, a.y + bv.y, a.z + bv.z, a.w + bv.w);
+            if (act == CDS_ACT_RELU) {
+              o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
+            }
+            if (skip) {
+              const float4 s4 = SKIP_PF ? skv[SKIP_PF ? c : 0][q] : *reinterpret_cast<const float4*>(skip + base);
+              o.x = s4.x + o.x; o.y = s4.y + o.y; o.z = s4.z + o.z; o.w = s4.w + o.w;
+            }
+            if (out_planar) {
+              // [Cout][2D][2H][2W] for a planar consumer (the prob layer): per component the lanes of a store cover runs of
+              // 32 consecutive x (both x parities of 16 cells) -> whole 128-byte segments
+              const size_t ovol = (size_t)(2 * D) * Ho * Wo;
+              float* po = out + (size_t)co * ovol + (rowbase + 2 * ax + px);
+              po[0] = o.x; po[ovol] = o.y; po[2 * ovol] = o.z; po[3 * ovol] = o.w;
+            } else {
+              *reinterpret_cast<float4*>(out + base) = o;
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+template <bool MERGE, int MB>
+int launch_deconv(const float* x, const void* wsp, const float* b, const float* skip, float* out, int Cin, int Cout, int D, int H,
+                  int W, int act, int out_planar, hipStream_t st) {
+  using Cfg = DCfg;
+  const int tx = cds_ceil_div(W, Cfg::CX), ty = cds_ceil_div(H, Cfg::CY);
+  const int ntiles = tx * ty * D;
+  static const int tpw_env = []() { const char* e = getenv("CDS_SBF_TPW"); return e ? atoi(e) : 0; }();   // A/B knob
+  int tpw = tpw_env > 0 ? tpw_env : max(1, min(16, ntiles / (256 * 2 * 8)));
+  const int nwg = cds_ceil_div(ntiles, tpw);
+  hipLaunchKernelGGL((deconv3d_sbf_kernel<MERGE, MB>), dim3(nwg), dim3(256), Cfg::LDSB, st, x, reinterpret_cast<const uint4*>(wsp),
+                     b, skip, out, Cin, Cout, D, H, W, act, out_planar, tx, ty, ntiles, tpw);
+  return cds_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------
+// prob layer: Conv3d(8 -> 1, k3, p1, no bias / BN / ReLU; module.py:303) on a channels-last input, plain fp32 FMAs
+// (one output channel cannot fill a matrix tile), planar output [D][H][W] for the soft-argmin.
+// Tile 64 x 4 x 4 outputs: lane = x, wave = y, four z outputs per thread.  The input tile (66 x 6 x 6 positions) sits in
+// LDS as two channel-half planes of 16-byte slots (lane stride 16 B: conflict-free ds_read_b128); every position read
+// feeds up to three outputs (27 x 8 x 4 = 864 FMAs for 108 reads).  The 24 weights of a (ky, kx) column of taps are
+// wave-uniform scalars (s_load).  Two workgroups per CU overlap each other's staging.
+// ---------------------------------------------------------------------------------------------
+struct PCfg {
+  static constexpr int TX = 64, TY = 4, TZ = 4;
+  static constexpr int IX = TX + 2, IY = TY + 2, IZ = TZ + 2;
+  static constexpr int NPOS = IZ * IY * IX;
+  static constexpr int LDSB = 2 * NPOS * 16;
+};
+
+__global__ __launch_bounds__(256, 2) void prob_cl8_kernel(const float* __restrict__ x, const float* __restrict__ wtap,
+                                                          float* __restrict__ out, int D, int H, int W, int tiles_x,
+                                                          int tiles_y, int ntiles) {
+  using Cfg = PCfg;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  cds_f4* l0 = reinterpret_cast<cds_f4*>(lds);
+  cds_f4* l1 = l0 + Cfg::NPOS;
+  int tile = cds_xcd_remap(blockIdx.x, ntiles);
+  const int tx_i = tile % tiles_x;
+  tile /= tiles_x;
+  const int ty_i = tile % tiles_y, tz_i = tile / tiles_y;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ox0 = tx_i * Cfg::TX, oy0 = ty_i * Cfg::TY, oz0 = tz_i * Cfg::TZ;
+  for (int p = tid; p < Cfg::NPOS; p += 256) {
+    const int row = p / Cfg::IX, c = p - row * Cfg::IX;
+    const int rz = row / Cfg::IY, ry = row - rz * Cfg::IY;
+    const int gz = oz0 - 1 + rz, gy = oy0 - 1 + ry, gx = ox0 - 1 + c;
+    const bool ok = (unsigned)gz < (unsigned)D && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+    const float* __restrict__ src = x + ((size_t)((size_t)gz * H + gy) * W + gx) * 8;
+    const cds_f4 z4 = {0.f, 0.f, 0.f, 0.f};
+    l0[p] = ok ? *reinterpret_cast<const cds_f4*>(src) : z4;
+    l1[p] = ok ? *reinterpret_cast<const cds_f4*>(src + 4) : z4;
+  }
+  __syncthreads();
+  float acc[Cfg::TZ] = {0.f, 0.f, 0.f, 0.f};
+  const cds_f4* p0 = l0 + wave * Cfg::IX + lane;
+  const cds_f4* p1 = l1 + wave * Cfg::IX + lane;
+#pragma unroll 1
+  for (int kyx = 0; kyx < 9; ++kyx) {
+    // the 24 weights [kz][ci] of this (ky, kx) column of taps: wave-uniform -> scalar loads into SGPRs
+    const float* __restrict__ wk = wtap + __builtin_amdgcn_readfirstlane(kyx * 24);
+    const int ky = kyx / 3, kx = kyx - 3 * ky;
+    const int off = ky * Cfg::IX + kx;
+#pragma unroll
+    for (int zp = 0; zp < Cfg::IZ; ++zp) {
+      const cds_f4 a = p0[off + zp * Cfg::IY * Cfg::IX], b = p1[off + zp * Cfg::IY * Cfg::IX];
+#pragma unroll
+      for (int dz = 0; dz < Cfg::TZ; ++dz) {
+        const int kz = zp - dz;
+        if (kz < 0 || kz > 2) continue;
+        float v = acc[dz];
+        v = fmaf(a.x, wk[kz * 8 + 0], v); v = fmaf(a.y, wk[kz * 8 + 1], v); v = fmaf(a.z, wk[kz * 8 + 2], v); v = fmaf(a.w, wk[kz * 8 + 3], v);
+        v = fmaf(b.x, wk[kz * 8 + 4], v); v = fmaf(b.y, wk[kz * 8 + 5], v); v = fmaf(b.z, wk[kz * 8 + 6], v); v = fmaf(b.w, wk[kz * 8 + 7], v);
+        acc[dz] = v;
+      }
+    }
+  }
+  const int ox = ox0 + lane, oy = oy0 + wave;
+  if (ox < W && oy < H) {
+#pragma unroll
+    for (int dz = 0; dz < Cfg::TZ; ++dz)
+      if (oz0 + dz < D) out[((size_t)(oz0 + dz) * H + oy) * W + ox] = acc[dz];
+  }
+}
+
+}  // namespace
+
+// 3x3x3 convolution (pad 1, stride 1 | 2) in split-bf16 arithmetic on channels-last volumes.  x [D][H][W][Cin],
+// out [Do][Ho][Wo][Cout]; weight_split from the host packer (ops.split_pack_conv3d): int16 [Cin/8][7][ceil(Cout/16)][3][64][8].
+extern "C" int cds_conv3d_sbf_f32(const float* x, const void* weight_split, const float* bias, const float* skip, float* out,
+                                  int Cin, int Cout, int D, int H, int W, int stride, int act, void* stream) {
+  if (!x || !weight_split || !out || Cin < 8 || (Cin % 8) || Cout < 4 || (Cout % 4) || Cout > 64 || D < 1 || H < 1 || W < 1 ||
+      (stride != 1 && stride != 2 && stride != CDS_SBF_PAIR))
+    return CDS_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int mb = (Cout + 15) / 16;
+  if (stride == CDS_SBF_PAIR) {   // stride 1, Cout == 8, pair-packed weights
+    if (Cout != 8) return CDS_EINVAL;
+    return launch_fwd<1, 1, 32, 4, true>(x, weight_split, bias, skip, out, Cin, Cout, D, H, W, act, st);
+  }
+  if (stride == 1) {
+    if (mb == 1) return launch_fwd<1, 1, 32, 4>(x, weight_split, bias, skip, out, Cin, Cout, D, H, W, act, st);
+    if (mb == 2) return launch_fwd<1, 2, 32, 2>(x, weight_split, bias, skip, out, Cin, Cout, D, H, W, act, st);
+    if (mb == 4) return launch_fwd<1, 4, 32, 2>(x, weight_split, bias, skip, out, Cin, Cout, D, H, W, act, st);
+    return CDS_EINVAL;
+  }
+  if (mb == 1) return launch_fwd<2, 1, 16, 2>(x, weight_split, bias, skip, out, Cin, Cout, D, H, W, act, st);
+  if (mb == 2) return launch_fwd<2, 2, 16, 2>(x, weight_split, bias, skip, out, Cin, Cout, D, H, W, act, st);
+  if (mb == 4) return launch_fwd<2, 4, 16, 2>(x, weight_split, bias, skip, out, Cin, Cout, D, H, W, act, st);
+  return CDS_EINVAL;
+}
+
+// ConvTranspose3d k3 s2 p1 op1 (+bias +ReLU +residual) in split-bf16 arithmetic on channels-last volumes.  x [D][H][W][Cin]
+// -> out [2D][2H][2W][Cout]; weight_split from ops.split_pack_deconv3d (class / K-step tables: DTab above).  Cout == 8 or
+// Cout in {16, 32}; Cin % 8 == 0.
+extern "C" int cds_deconv3d_sbf_f32(const float* x, const void* weight_split, const float* bias, const float* skip, float* out,
+                                    int Cin, int Cout, int D, int H, int W, int act, int out_planar, void* stream) {
+  if (!x || !weight_split || !out || Cin < 8 || (Cin % 8) || D < 1 || H < 1 || W < 1) return CDS_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  if (Cout == 8) return launch_deconv<true, 1>(x, weight_split, bias, skip, out, Cin, Cout, D, H, W, act, out_planar, st);
+  if (Cout == 16) return launch_deconv<false, 1>(x, weight_split, bias, skip, out, Cin, Cout, D, H, W, act, out_planar, st);
+  if (Cout == 32) return launch_deconv<false, 2>(x, weight_split, bias, skip, out, Cin, Cout, D, H, W, act, out_planar, st);
+  return CDS_EINVAL;
+}
+
+// prob layer (Conv3d 8 -> 1, no bias / activation; models/module.py:303) on a channels-last input: x [D][H][W][8] -> out
+// [D][H][W].  weight_tap: fp32 [3 ky][3 kx][3 kz][8 ci] (ops.pack_prob_cl).
+extern "C" int cds_conv3d_prob_cl8_f32(const float* x, const float* weight_tap, float* out, int D, int H, int W, void* stream) {
+  if (!x || !weight_tap || !out || D < 1 || H < 1 || W < 1) return CDS_EINVAL;
+  using Cfg = PCfg;
+  const int tx = cds_ceil_div(W, Cfg::TX), ty = cds_ceil_div(H, Cfg::TY), tz = cds_ceil_div(D, Cfg::TZ);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(prob_cl8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDSB);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(prob_cl8_kernel, dim3(tx * ty * tz), dim3(256), Cfg::LDSB, (hipStream_t)stream, x, weight_tap, out, D, H, W,
+                     tx, ty, tx * ty * tz);
+  return cds_launch_status();
+}

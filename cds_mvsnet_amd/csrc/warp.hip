@@ -184,6 +184,7 @@ __global__ __launch_bounds__(256) void warp_aggregate_kernel(
   }
   const bool accumulate = flags & CDS_AGG_ACCUMULATE;
   const bool normalize = flags & CDS_AGG_NORMALIZE;
+  const bool cl = flags & CDS_AGG_CHANNELS_LAST;                  // volume [D][h][w][C] instead of [C][D][h][w]
   const float denom = (normalize ? vis_sum[pix] : 1.0f) + 1e-6f;  // vis_sum finalised by vis_sum_kernel
 
   const int dbeg = seg * seg_planes, dend = min(D, dbeg + seg_planes);
@@ -194,7 +195,8 @@ __global__ __launch_bounds__(256) void warp_aggregate_kernel(
     if (d + 1 < dend) dnext = hyp_pp ? hyp[(size_t)(d + 1) * hw + pix] : hyp[d + 1];
     float acc[CG];
 #pragma unroll
-    for (int c = 0; c < CG; ++c) acc[c] = accumulate ? volume[((size_t)(c_base + c) * D + d) * hw + pix] : 0.f;
+    for (int c = 0; c < CG; ++c)
+      acc[c] = accumulate ? (cl ? volume[((size_t)d * hw + pix) * C + c_base + c] : volume[((size_t)(c_base + c) * D + d) * hw + pix]) : 0.f;
 #pragma unroll
     for (int v = 0; v < VMAX; ++v) {
       if (v < V) {
@@ -215,10 +217,19 @@ __global__ __launch_bounds__(256) void warp_aggregate_kernel(
         }
       }
     }
+    if (cl) {
+      float o[CG];
 #pragma unroll
-    for (int c = 0; c < CG; ++c) {
-      float o = normalize ? acc[c] / denom : acc[c];
-      __builtin_nontemporal_store(o, &volume[((size_t)(c_base + c) * D + d) * hw + pix]);
+      for (int c = 0; c < CG; ++c) o[c] = normalize ? acc[c] / denom : acc[c];
+      float4* dst = reinterpret_cast<float4*>(volume + ((size_t)d * hw + pix) * C + c_base);
+      dst[0] = make_float4(o[0], o[1], o[2], o[3]);
+      dst[1] = make_float4(o[4], o[5], o[6], o[7]);
+    } else {
+#pragma unroll
+      for (int c = 0; c < CG; ++c) {
+        float o = normalize ? acc[c] / denom : acc[c];
+        __builtin_nontemporal_store(o, &volume[((size_t)(c_base + c) * D + d) * hw + pix]);
+      }
     }
   }
 }
@@ -250,6 +261,18 @@ __global__ void volume_normalize_kernel(float* __restrict__ vol, const float* __
     if (blockIdx.x == 0) {
       for (size_t i = n4 * 4 + threadIdx.x; i < hw; i += blockDim.x) vol[pl * hw + i] = vol[pl * hw + i] / (vis_sum[i] + 1e-6f);
     }
+  }
+}
+
+// channels-last volume [n pixels x planes][C]: every voxel's C channels scaled by 1 / (vis_sum[pixel] + 1e-6)
+__global__ void volume_normalize_cl_kernel(float* __restrict__ vol, const float* __restrict__ vis_sum, size_t hw, size_t nvox,
+                                           int c4) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < nvox * c4; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t vox = i / c4;
+    const float s = vis_sum[vox % hw] + 1e-6f;
+    float4 a = reinterpret_cast<float4*>(vol)[i];
+    a.x = a.x / s; a.y = a.y / s; a.z = a.z / s; a.w = a.w / s;
+    reinterpret_cast<float4*>(vol)[i] = a;
   }
 }
 
@@ -378,6 +401,16 @@ extern "C" int cds_warp_aggregate_f32(const float* ref_chw, const float* src_hwc
   else if (V <= 6) LAUNCH(6);
   else LAUNCH(8);
 #undef LAUNCH
+  return cds_launch_status();
+}
+
+extern "C" int cds_volume_normalize_cl_f32(float* volume, const float* vis_sum, int C, int D, int hw, void* stream) {
+  if (!volume || !vis_sum || C < 4 || (C % 4) || D < 1 || hw < 1) return CDS_EINVAL;
+  const size_t nvox = (size_t)D * hw;
+  size_t blocks = (nvox * (C / 4) + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(volume_normalize_cl_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, volume, vis_sum,
+                     (size_t)hw, nvox, C / 4);
   return cds_launch_status();
 }
 

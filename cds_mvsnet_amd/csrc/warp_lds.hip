@@ -407,7 +407,8 @@ __global__ __launch_bounds__(256, CDS_K3_MINW) void warp_aggregate_lds_kernel(
     }
   }
   constexpr bool accumulate = ACCUMULATE, normalize = NORMALIZE;
-  (void)flags;
+  const bool cl = flags & CDS_AGG_CHANNELS_LAST;   // volume [D][h][w][C]: a voxel's 8 channels of this group are 32 contiguous bytes
+  float* vol_cl = volume - (size_t)c_off * slab + c_off;   // (the planar base was advanced by the group's slabs above)
   // Normalisation volume_sum / (vis_sum + 1e-6) is folded into the per-pixel factors: (ref * vis) * RN(1/denom)
   // (a re-association of the reference's division, a few ulp of a value below 1; no per-plane work left).
   const float yden = normalize ? 1.0f / (vis_sum[pix] + 1e-6f) : 1.0f;
@@ -477,8 +478,14 @@ __global__ __launch_bounds__(256, CDS_K3_MINW) void warp_aggregate_lds_kernel(
           for (int j = 0; j < 4; ++j) {
             acc[k][j] = splat2(0.f);
             if (accumulate && (k == 0 || two)) {
-              acc[k][j].x = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(volume + (size_t)(2 * j) * slab) + boff + k * bstep);
-              acc[k][j].y = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(volume + (size_t)(2 * j + 1) * slab) + boff + k * bstep);
+              if (cl) {
+                const float* pv = vol_cl + ((size_t)(d + k) * hw + pix) * C + 2 * j;
+                acc[k][j].x = pv[0];
+                acc[k][j].y = pv[1];
+              } else {
+                acc[k][j].x = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(volume + (size_t)(2 * j) * slab) + boff + k * bstep);
+                acc[k][j].y = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(volume + (size_t)(2 * j + 1) * slab) + boff + k * bstep);
+              }
               if (normalize) acc[k][j] = acc[k][j] * yden;  // partial sums of an earlier launch
             }
           }
@@ -557,7 +564,13 @@ __global__ __launch_bounds__(256, CDS_K3_MINW) void warp_aggregate_lds_kernel(
 #endif
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-          if (k == 0 || two) {
+          if (cl) {
+            if (k == 0 || two) {   // one voxel = 8 channels = two 16-byte stores on 32 contiguous bytes
+              float4* dst = reinterpret_cast<float4*>(vol_cl + ((size_t)(d + k) * hw + pix) * C);
+              dst[0] = make_float4(acc[k][0].x, acc[k][0].y, acc[k][1].x, acc[k][1].y);
+              dst[1] = make_float4(acc[k][2].x, acc[k][2].y, acc[k][3].x, acc[k][3].y);
+            }
+          } else if (k == 0 || two) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
               v2f o = acc[k][j];
@@ -761,11 +774,12 @@ bool cds_warp_aggregate_lds_launch(const float* ref, const float* src, const flo
     WarpMats wm2;
     for (int v = 0; v < CDS_MAX_VIEWS; ++v)
       for (int i = 0; i < 12; ++i) wm2.m[v][i] = (v + v1 < CDS_MAX_VIEWS) ? wm.m[v + v1][i] : 0.f;
+    const int layout = flags & CDS_AGG_CHANNELS_LAST;
     return cds_warp_aggregate_lds_launch(ref, src, vis, wm, hyp, volume, vis_sum, v1, C, D, h, w, hyp_pp,
-                                         flags & CDS_AGG_ACCUMULATE, st) &&
+                                         (flags & CDS_AGG_ACCUMULATE) | layout, st) &&
            cds_warp_aggregate_lds_launch(ref + (size_t)v1 * C * hw, src + (size_t)v1 * hw * C, vis + (size_t)v1 * hw, wm2,
                                          hyp, volume, vis_sum, V - v1, C, D, h, w, hyp_pp,
-                                         CDS_AGG_ACCUMULATE | (flags & CDS_AGG_NORMALIZE), st);
+                                         CDS_AGG_ACCUMULATE | (flags & CDS_AGG_NORMALIZE) | layout, st);
   }
   const int tiles_x = cds_ceil_div(w, TW), tiles_y = cds_ceil_div(h, TH);
   const int ntiles = tiles_x * tiles_y;

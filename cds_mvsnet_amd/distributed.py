@@ -122,19 +122,23 @@ class ViewShard:
         D, h, w = hyp.shape
         if ref is not None:
             C = ref.shape[1]
+        cr = model.cost_regularization[stage_idx]
+        cl = cr.split_bf16_supported()          # channels-last volume for the split-bf16 CostRegNet kernels
         flat = torch.zeros(self.flat_size(C, D, h, w), dtype=torch.float32, device=hyp.device)
         vol, vis_sum, nc_sum = self.split_flat(flat, C, D, h, w)
+        if cl:
+            vol = vol.view(D, h, w, C)          # same bytes of the flat buffer, [D][h][w][C]
         if ref is not None and ref.shape[0] > 0:
             ent = ops.warp_entropy(ref, src, mats, hyp)
             vis = model.stage_net.visibility(ent, ref_nc, stage_idx).contiguous()
-            ops.warp_aggregate(ref, src, vis, mats, hyp, normalize=False, volume=vol, vis_sum=vis_sum)
+            ops.warp_aggregate(ref, src, vis, mats, hyp, normalize=False, volume=vol, vis_sum=vis_sum, channels_last=cl)
             nc_sum.copy_(nc_sums.sum(dim=0))
         with ops.prof("allreduce"):
             self.all_reduce_partials(flat)
-        ops.volume_normalize_(vol, vis_sum)
+        ops.volume_normalize_(vol, vis_sum, channels_last=cl)
         if self.keep_volume:
-            self.last_volume = vol
-        prob_pre = model.cost_regularization[stage_idx](vol)
+            self.last_volume = vol.permute(3, 0, 1, 2) if cl else vol
+        prob_pre = cr(vol, channels_last=True) if cl else cr(vol)
         depth, conf = ops.softargmin_conf(prob_pre, hyp)
         return depth, conf, nc_sum / n_src_total
 

@@ -14,6 +14,7 @@ backward kernels, the convolution stacks use stock PyTorch-ROCm autograd ops for
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -25,6 +26,9 @@ from .ops import ACT_LEAKY01, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH
 
 Tensor = torch.Tensor
 BN_EPS = 1e-5
+# CDS_CONV_EXACT=1: CostRegNet on the exact-fp32 kernels (sequential fmaf chains, planar volumes) instead of the
+# split-bf16 matrix-core kernels (fp32-class error, channels-last volumes)
+USE_SPLIT_BF16 = os.environ.get("CDS_CONV_EXACT", "0") != "1"
 
 
 # ------------------------------------------------------------------------------------------------
@@ -212,18 +216,62 @@ class CostRegNet(_PackedHolder):
                 out[name + ".wcl"] = w.permute(1, 2, 3, 4, 0).reshape(27, w.shape[-1], w.shape[0]).contiguous()
         w = self.prob.weight.detach().permute(1, 2, 3, 4, 0)
         out["prob.w"] = w.reshape(w.shape[0], 27, 1).contiguous()
+        if self.split_bf16_supported():
+            # operands of the split-bf16 matrix-core kernels (csrc/conv3d_sbf.hip): BN-folded weights split exactly into
+            # three bf16 terms, laid out per MFMA lane
+            for name in ("conv0", "conv1", "conv2", "conv3", "conv4", "conv5", "conv6", "conv7", "conv9", "conv11"):
+                unit = getattr(self, name)
+                scale, _ = _bn_fold(unit.bn)
+                if unit.transposed:
+                    out[name + ".ws"] = ops.split_pack_deconv3d(unit.conv.weight.detach() * scale.view(1, -1, 1, 1, 1))
+                elif name == "conv0":   # Cout = 8, stride 1: voxel-pair columns (no matrix row multiplies padding)
+                    out[name + ".ws"] = ops.split_pack_conv3d_pair(unit.conv.weight.detach() * scale.view(-1, 1, 1, 1, 1))
+                else:
+                    out[name + ".ws"] = ops.split_pack_conv3d(unit.conv.weight.detach() * scale.view(-1, 1, 1, 1, 1))
+            out["prob.wt"] = ops.pack_prob_cl(self.prob.weight)
         return out
 
-    def forward(self, volume: Tensor) -> Tensor:
-        """volume [C,D,h,w] (one batch item) -> [D,h,w].  D, h, w must be multiples of 8."""
+    def split_bf16_supported(self) -> bool:
+        """The split-bf16 kernels cover base_channels = 8 with 8 / 16 / 32 input channels (the three cascade stages)."""
+        return (USE_SPLIT_BF16 and self.conv0.conv.out_channels == 8 and self.conv0.conv.in_channels % 8 == 0
+                and self.conv0.conv.weight.is_cuda)
+
+    def forward(self, volume: Tensor, channels_last: bool = False) -> Tensor:
+        """volume [C,D,h,w] (one batch item; [D,h,w,C] with channels_last) -> [D,h,w].  D, h, w must be multiples of 8.
+        The channels-last form runs the split-bf16 matrix-core kernels (fp32-class arithmetic, csrc/conv3d_sbf.hip), the
+        planar form the exact-fp32 kernels (one fmaf chain per output)."""
         if self.training:
             raise NotImplementedError("CostRegNet: training-mode BatchNorm is not built yet (SURVEY §8(f)-2)")
-        C, D, h, w = volume.shape
+        D, h, w = volume.shape[:3] if channels_last else volume.shape[1:]
         if D % 8 or h % 8 or w % 8:
             raise ValueError(f"CostRegNet needs D,h,w divisible by 8, got {(D, h, w)}")
         p = self._packed.get(self, self._pack)
         with ops.prof("costreg"):
+            if channels_last:
+                if "conv0.ws" not in p:
+                    raise RuntimeError("CostRegNet: channels-last input needs the split-bf16 kernels (CDS_CONV_EXACT=1 disables them)")
+                return self._run_cl(volume, p)
             return self._run(volume, p)
+
+    @staticmethod
+    def _run_cl(v: Tensor, p: Dict[str, Tensor]) -> Tensor:
+        c0 = ops.conv3d_sbf(v, p["conv0.ws"], p["conv0.b"], 8, stride=ops.SBF_PAIR)
+        c1 = ops.conv3d_sbf(c0, p["conv1.ws"], p["conv1.b"], 16, stride=2)
+        c2 = ops.conv3d_sbf(c1, p["conv2.ws"], p["conv2.b"], 16)
+        del c1
+        c3 = ops.conv3d_sbf(c2, p["conv3.ws"], p["conv3.b"], 32, stride=2)
+        c4 = ops.conv3d_sbf(c3, p["conv4.ws"], p["conv4.b"], 32)
+        del c3
+        c5 = ops.conv3d_sbf(c4, p["conv5.ws"], p["conv5.b"], 64, stride=2)
+        x = ops.conv3d_sbf(c5, p["conv6.ws"], p["conv6.b"], 64)
+        del c5
+        x = ops.deconv3d_sbf(x, p["conv7.ws"], p["conv7.b"], 32, skip=c4)
+        del c4
+        x = ops.deconv3d_sbf(x, p["conv9.ws"], p["conv9.b"], 16, skip=c2)
+        del c2
+        x = ops.deconv3d_sbf(x, p["conv11.ws"], p["conv11.b"], 8, skip=c0, out_planar=True)   # prob reads planar
+        del c0
+        return ops.conv3d_k3(x, p["prob.w"], None, relu=False)[0]
 
     @staticmethod
     def _run(volume: Tensor, p: Dict[str, Tensor]) -> Tensor:
@@ -510,18 +558,20 @@ class StageNet(_PackedHolder):
             return ops.conv2d(x, p[f"{s}.w3"], p[f"{s}.b3"], 1, 1, 1, 0, ACT_SIGMOID)[:, 0]
 
     def aggregate(self, ref_chw: Tensor, src_hwc: Tensor, ref_nc: Tensor, mats: Tensor, hyp: Tensor, stage_idx: int,
-                  normalize: bool = True):
-        """K1 -> vis CNN -> K3 for the given source views.  Returns (volume, vis_sum, entropy, vis_w)."""
+                  normalize: bool = True, channels_last: bool = False):
+        """K1 -> vis CNN -> K3 for the given source views.  Returns (volume, vis_sum, entropy, vis_w); the volume is
+        [C,D,h,w], or [D,h,w,C] with channels_last."""
         ent = ops.warp_entropy(ref_chw, src_hwc, mats, hyp)
         vis = self.visibility(ent, ref_nc, stage_idx).contiguous()
-        volume, vis_sum = ops.warp_aggregate(ref_chw, src_hwc, vis, mats, hyp, normalize=normalize)
+        volume, vis_sum = ops.warp_aggregate(ref_chw, src_hwc, vis, mats, hyp, normalize=normalize, channels_last=channels_last)
         return volume, vis_sum, ent, vis
 
     def run_single(self, ref_chw, src_hwc, ref_nc, nc_sums, mats, hyp, cost_regularization, stage_idx):
         """One batch item.  ref_chw [V,C,h,w], src_hwc [V,h,w,C], ref_nc [V,h,w], nc_sums [V,h,w] (already
         (ref+src)/2 per view), hyp [D,h,w]."""
-        volume, _, _, _ = self.aggregate(ref_chw, src_hwc, ref_nc, mats, hyp, stage_idx)
-        prob_pre = cost_regularization(volume)
+        cl = isinstance(cost_regularization, CostRegNet) and cost_regularization.split_bf16_supported()
+        volume, _, _, _ = self.aggregate(ref_chw, src_hwc, ref_nc, mats, hyp, stage_idx, channels_last=cl)
+        prob_pre = cost_regularization(volume, channels_last=True) if cl else cost_regularization(volume)
         del volume
         depth, conf = ops.softargmin_conf(prob_pre, hyp)
         nc_mean = ops.view_mean(nc_sums.contiguous())

@@ -12,7 +12,7 @@ from typing import Optional, Tuple
 import torch
 
 from . import _lib
-from ._lib import (ACT_LEAKY01, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, AGG_ACCUMULATE, AGG_NORMALIZE,
+from ._lib import (ACT_LEAKY01, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, AGG_ACCUMULATE, AGG_CHANNELS_LAST, AGG_NORMALIZE,
                    MAX_IMAGES, MAX_VIEWS, check)
 
 Tensor = torch.Tensor
@@ -134,28 +134,30 @@ def warp_entropy(ref_chw: Tensor, src_hwc: Tensor, mats: Tensor, hyp: Tensor) ->
 
 def warp_aggregate(ref_chw: Tensor, src_hwc: Tensor, vis_w: Tensor, mats: Tensor, hyp: Tensor,
                    normalize: bool = True, volume: Optional[Tensor] = None, vis_sum: Optional[Tensor] = None,
-                   accumulate: bool = False) -> Tuple[Tensor, Tensor]:
-    """K3.  Returns (volume [C,D,h,w], vis_sum [h,w]).  With normalize=False the raw visibility-weighted
-    sums are returned (what a source-view shard contributes to the all-reduce)."""
+                   accumulate: bool = False, channels_last: bool = False) -> Tuple[Tensor, Tensor]:
+    """K3.  Returns (volume [C,D,h,w] — or [D,h,w,C] with channels_last, the layout the split-bf16 CostRegNet kernels
+    read — and vis_sum [h,w]).  With normalize=False the raw visibility-weighted sums are returned (what a source-view
+    shard contributes to the all-reduce)."""
     V, C, h, w = ref_chw.shape
     if tuple(src_hwc.shape) != (V, h, w, C) or tuple(mats.shape) != (V, 12) or tuple(vis_w.shape) != (V, h, w):
         raise ValueError("warp_aggregate: inconsistent shapes")
     D, pp = _hyp_args(hyp, None, h, w)
     dev = ref_chw.device
+    vshape = (D, h, w, C) if channels_last else (C, D, h, w)
     if volume is None:
         if accumulate:
             raise ValueError("accumulate=True needs an existing volume")
-        volume = torch.empty((C, D, h, w), dtype=torch.float32, device=dev)
+        volume = torch.empty(vshape, dtype=torch.float32, device=dev)
     if vis_sum is None:
         vis_sum = torch.empty((h, w), dtype=torch.float32, device=dev)
-    if tuple(volume.shape) != (C, D, h, w) or tuple(vis_sum.shape) != (h, w):
+    if tuple(volume.shape) != vshape or tuple(vis_sum.shape) != (h, w):
         raise ValueError("warp_aggregate: bad output buffers")
     lib = _lib.load()
     nchunks = (V + MAX_VIEWS - 1) // MAX_VIEWS
     with prof("warp_aggregate"):
         for i, v0 in enumerate(range(0, V, MAX_VIEWS)):
             v1 = min(V, v0 + MAX_VIEWS)
-            flags = 0
+            flags = AGG_CHANNELS_LAST if channels_last else 0
             if accumulate or i > 0:
                 flags |= AGG_ACCUMULATE
             if normalize and i == nchunks - 1:
@@ -212,7 +214,13 @@ class WarpAggregate(torch.autograd.Function):
         return g_ref, g_src, g_vis, None, None
 
 
-def volume_normalize_(volume: Tensor, vis_sum: Tensor) -> Tensor:
+def volume_normalize_(volume: Tensor, vis_sum: Tensor, channels_last: bool = False) -> Tensor:
+    """volume /= (vis_sum + 1e-6) per pixel, in place (model.py:74); volume [C,D,h,w], or [D,h,w,C] with channels_last."""
+    if channels_last:
+        D, h, w, C = volume.shape
+        check(_lib.load().cds_volume_normalize_cl_f32(_dev(volume, "volume"), _dev(vis_sum, "vis_sum"), C, D, h * w,
+                                                      _stream(volume)), "cds_volume_normalize_cl_f32")
+        return volume
     C, D, h, w = volume.shape
     check(_lib.load().cds_volume_normalize_f32(_dev(volume, "volume"), _dev(vis_sum, "vis_sum"), C, D, h * w,
                                                _stream(volume)), "cds_volume_normalize_f32")
@@ -294,6 +302,158 @@ def conv3d_k3(x: Tensor, wpk: Tensor, bias: Optional[Tensor], stride: int = 1, r
     check(_lib.load().cds_conv3d_k3_f32(_dev(x, "x"), _dev(wpk, "weight"), _dev(bias, "bias") if bias is not None else None,
                                         _dev(skip, "skip") if skip is not None else None, out.data_ptr(), Cin, Cout, D, H,
                                         W, stride, ACT_RELU if relu else ACT_NONE, _stream(x)), "cds_conv3d_k3_f32")
+    return out
+
+
+def split_pack_conv3d(w: Tensor) -> Tensor:
+    """Pack a (BN-folded) Conv3d weight [Cout,Cin,3,3,3] for cds_conv3d_sbf_f32: every weight is split exactly into
+    three bf16 terms (hi = RN(w), mid = RN(w - hi), lo = w - hi - mid) and laid out as the A operands of
+    v_mfma_f32_16x16x32_bf16: int16 [Cin/8][7 ksteps][ceil(Cout/16)][3][64 lanes][8].  Lane l = 16 g + i multiplies output
+    channel 16 mb + i by tap 4 t + g (tap = (kz*3 + ky)*3 + kx; tap 27 is a zero pad) of input channels 8 rd + 0..7."""
+    Cout, Cin = w.shape[:2]
+    if Cin % 8:
+        raise ValueError("split_pack_conv3d: Cin must be a multiple of 8")
+    rounds, mbl = Cin // 8, (Cout + 15) // 16
+    taps = torch.zeros((mbl * 16, rounds, 28, 8), dtype=torch.float32, device=w.device)         # [co][rd][tap][j]
+    taps[:Cout, :, :27] = w.detach().float().reshape(Cout, rounds, 8, 27).permute(0, 1, 3, 2)
+    # -> [rd][t][mb][g][i][j] -> lanes l = 16 g + i
+    a = taps.reshape(mbl, 16, rounds, 7, 4, 8).permute(2, 3, 0, 4, 1, 5).reshape(rounds, 7, mbl, 64, 8)
+    return _split3(a)                                                                            # [rd][t][mb][3][64][8]
+
+
+def _split3(a: Tensor) -> Tensor:
+    """Exact three-term bf16 split of a float tensor [...,64,8] -> int16 [...,3,64,8] (hi, mid, lo)."""
+    hi = a.to(torch.bfloat16)
+    r1 = a - hi.float()
+    mid = r1.to(torch.bfloat16)
+    lo = (r1 - mid.float()).to(torch.bfloat16)
+    return torch.stack((hi, mid, lo), dim=-3).contiguous().view(torch.int16)
+
+
+def _deconv_tables(merge: bool):
+    """Mirror of DTab in csrc/conv3d_sbf.hip: per K-step (class, first tap slot); per class its tap list of per-axis
+    (kernel index k, cell offset d) pairs.  Output parity 0 of an axis takes (k=1, d=0); parity 1 takes (2, 0) and (0, 1)."""
+    ax = {0: [(1, 0)], 1: [(2, 0), (0, 1)]}
+    if merge:   # class = (pz, py); x slots are the cell offsets d = 0, 1 shared by both x parities
+        classes = [(pz, py, None) for pz in (0, 1) for py in (0, 1)]
+        ksteps = [(0, 0), (1, 0), (2, 0), (3, 0), (3, 4)]
+    else:
+        classes = [(pz, py, px) for pz in (0, 1) for py in (0, 1) for px in (0, 1)]
+        ksteps = [(c, 0) for c in range(8)] + [(7, 4)]
+    taps = []
+    for pz, py, px in classes:
+        tl = []
+        for kz, dz in ax[pz]:
+            for ky, dy in ax[py]:
+                for xs in ([0, 1] if merge else ax[px]):
+                    tl.append((kz, ky, xs))        # merge: xs = cell offset dx; else (kx, dx)
+        taps.append(tl)
+    return classes, ksteps, taps
+
+
+def split_pack_deconv3d(w: Tensor) -> Tensor:
+    """Pack a (BN-folded) ConvTranspose3d weight [Cin,Cout,3,3,3] for cds_deconv3d_sbf_f32 (Cout == 8: the two x parities
+    share an MFMA, rows = (px, cout); Cout in {16, 32}: rows = couts).  int16 [Cin/8][nks][mb][3][64][8]."""
+    Cin, Cout = w.shape[:2]
+    if Cin % 8 or Cout not in (8, 16, 32):
+        raise ValueError("split_pack_deconv3d: Cin % 8 == 0 and Cout in {8, 16, 32}")
+    merge = Cout == 8
+    mbl = 1 if merge else Cout // 16
+    rounds = Cin // 8
+    _, ksteps, taps = _deconv_tables(merge)
+    wf = w.detach().float().reshape(rounds, 8, Cout, 3, 3, 3)                       # [rd][j][co][kz][ky][kx]
+    a = torch.zeros((rounds, len(ksteps), mbl, 4, 16, 8), dtype=torch.float32, device=w.device)   # [rd][ks][mb][g][i][j]
+    for ks, (c, s0) in enumerate(ksteps):
+        for gg in range(4):
+            s = s0 + gg
+            if s >= len(taps[c]):
+                continue
+            kz, ky, xs = taps[c][s]
+            if merge:
+                dx = xs
+                if dx == 0:
+                    a[:, ks, 0, gg, 0:8] = wf[:, :, :, kz, ky, 1].permute(0, 2, 1)      # px = 0: tap 1 of cell a
+                    a[:, ks, 0, gg, 8:16] = wf[:, :, :, kz, ky, 2].permute(0, 2, 1)     # px = 1: tap 2 of cell a
+                else:
+                    a[:, ks, 0, gg, 8:16] = wf[:, :, :, kz, ky, 0].permute(0, 2, 1)     # px = 1: tap 0 of cell a + 1
+            else:
+                kx = xs[0]
+                for mb in range(mbl):
+                    a[:, ks, mb, gg] = wf[:, :, mb * 16:(mb + 1) * 16, kz, ky, kx].permute(0, 2, 1)
+    return _split3(a.reshape(rounds, len(ksteps), mbl, 64, 8))
+
+
+def deconv3d_sbf(x_cl: Tensor, wsplit: Tensor, bias: Optional[Tensor], cout: int, relu: bool = True,
+                 skip: Optional[Tensor] = None, out_planar: bool = False) -> Tensor:
+    """ConvTranspose3d k3 s2 p1 op1 in split-bf16 arithmetic, channels-last: x_cl [D,H,W,Cin] -> [2D,2H,2W,cout]
+    (or planar [cout,2D,2H,2W] with out_planar; the residual `skip` is channels-last either way)."""
+    D, H, W, Cin = x_cl.shape
+    out = torch.empty((cout, 2 * D, 2 * H, 2 * W) if out_planar else (2 * D, 2 * H, 2 * W, cout), dtype=torch.float32,
+                      device=x_cl.device)
+    if skip is not None and tuple(skip.shape) != (2 * D, 2 * H, 2 * W, cout):
+        raise ValueError("deconv3d_sbf: residual shape mismatch")
+    if wsplit.dtype != torch.int16 or not wsplit.is_cuda or not wsplit.is_contiguous():
+        raise ValueError("deconv3d_sbf: wsplit must be the contiguous int16 device tensor from split_pack_deconv3d")
+    check(_lib.load().cds_deconv3d_sbf_f32(_dev(x_cl, "x"), wsplit.data_ptr(), _dev(bias, "bias") if bias is not None else None,
+                                           _dev(skip, "skip") if skip is not None else None, out.data_ptr(), Cin, cout,
+                                           D, H, W, ACT_RELU if relu else ACT_NONE, 1 if out_planar else 0, _stream(x_cl)),
+          "cds_deconv3d_sbf_f32")
+    return out
+
+
+SBF_PAIR = 101   # CDS_SBF_PAIR: stride code of the pair-packed stride-1, Cout = 8 form
+
+
+def split_pack_conv3d_pair(w: Tensor) -> Tensor:
+    """Pair packing of a (BN-folded) Conv3d weight [8,Cin,3,3,3] for cds_conv3d_sbf_f32(stride=CDS_SBF_PAIR): an MFMA column
+    is the voxel pair (2 j, 2 j + 1), row i = 8 p + co is output channel co of voxel 2 j + p, and the K window is 3 x 3 x 4
+    taps (x' = 0..3 relative to the pair): row (p, co) multiplies w[co][ci][kz][ky][x' - p], or 0 outside 0..2.
+    int16 [Cin/8][9 ksteps][1][3][64][8]; lane l = 16 g + i holds tap 4 t + g = (kz * 3 + ky) * 4 + x'."""
+    Cout, Cin = w.shape[:2]
+    if Cout != 8 or Cin % 8:
+        raise ValueError("split_pack_conv3d_pair: Cout == 8 and Cin % 8 == 0")
+    rounds = Cin // 8
+    wf = w.detach().float().reshape(8, rounds, 8, 3, 3, 3)                          # [co][rd][j][kz][ky][kx]
+    taps = torch.zeros((2, 8, rounds, 3, 3, 4, 8), dtype=torch.float32, device=w.device)   # [p][co][rd][kz][ky][x'][j]
+    for p_ in (0, 1):
+        taps[p_, :, :, :, :, p_:p_ + 3] = wf.permute(0, 1, 3, 4, 5, 2)
+    a = taps.reshape(16, rounds, 9, 4, 8).permute(1, 2, 3, 0, 4).reshape(rounds, 9, 1, 64, 8)   # [rd][t][mb][16 g + i][j]
+    return _split3(a)
+
+
+def conv3d_sbf(x_cl: Tensor, wsplit: Tensor, bias: Optional[Tensor], cout: int, stride: int = 1, relu: bool = True,
+               skip: Optional[Tensor] = None) -> Tensor:
+    """K4 in split-bf16 arithmetic (fp32-class error on the bf16 matrix cores) on channels-last volumes.
+    x_cl [D,H,W,Cin] fp32, wsplit from split_pack_conv3d -> [Do,Ho,Wo,cout]."""
+    D, H, W, Cin = x_cl.shape
+    sg = 1 if stride == SBF_PAIR else stride        # geometric stride (SBF_PAIR: stride 1, pair-packed weights)
+    Do, Ho, Wo = (D - 1) // sg + 1, (H - 1) // sg + 1, (W - 1) // sg + 1
+    out = torch.empty((Do, Ho, Wo, cout), dtype=torch.float32, device=x_cl.device)
+    if skip is not None and skip.shape != out.shape:
+        raise ValueError("conv3d_sbf: residual shape mismatch")
+    if wsplit.dtype != torch.int16 or not wsplit.is_cuda or not wsplit.is_contiguous():
+        raise ValueError("conv3d_sbf: wsplit must be the contiguous int16 device tensor from split_pack_conv3d")
+    check(_lib.load().cds_conv3d_sbf_f32(_dev(x_cl, "x"), wsplit.data_ptr(), _dev(bias, "bias") if bias is not None else None,
+                                         _dev(skip, "skip") if skip is not None else None, out.data_ptr(), Cin, cout,
+                                         D, H, W, stride, ACT_RELU if relu else ACT_NONE, _stream(x_cl)), "cds_conv3d_sbf_f32")
+    return out
+
+
+def pack_prob_cl(w: Tensor) -> Tensor:
+    """prob.weight [1,8,3,3,3] -> fp32 [ky][kx][kz][ci] for cds_conv3d_prob_cl8_f32."""
+    if tuple(w.shape) != (1, 8, 3, 3, 3):
+        raise ValueError("pack_prob_cl: expected a [1,8,3,3,3] weight")
+    return w.detach().float()[0].permute(2, 3, 1, 0).contiguous()        # [ci,kz,ky,kx] -> [ky,kx,kz,ci]
+
+
+def conv3d_prob_cl8(x_cl: Tensor, wtap: Tensor) -> Tensor:
+    """Conv3d(8 -> 1, k3, p1) on a channels-last volume: x_cl [D,H,W,8] -> [D,H,W]."""
+    D, H, W, C = x_cl.shape
+    if C != 8 or tuple(wtap.shape) != (3, 3, 3, 8):
+        raise ValueError("conv3d_prob_cl8: x_cl [D,H,W,8], wtap [3,3,3,8]")
+    out = torch.empty((D, H, W), dtype=torch.float32, device=x_cl.device)
+    check(_lib.load().cds_conv3d_prob_cl8_f32(_dev(x_cl, "x"), _dev(wtap, "weight_tap"), out.data_ptr(), D, H, W, _stream(x_cl)),
+          "cds_conv3d_prob_cl8_f32")
     return out
 
 

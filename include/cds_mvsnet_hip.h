@@ -39,6 +39,7 @@ extern "C" {
 /* flags of cds_warp_aggregate_f32 */
 #define CDS_AGG_ACCUMULATE 1 /* add onto the existing volume / vis_sum instead of overwriting */
 #define CDS_AGG_NORMALIZE 2  /* divide by (vis_sum + 1e-6) before the store (model.py:74) */
+#define CDS_AGG_CHANNELS_LAST 4 /* volume laid out [D][h][w][C] (a voxel's channels contiguous: one 32-byte store per 8 channels) */
 
 /* Library version (major*10000 + minor*100 + patch). */
 int cds_version(void);
@@ -73,7 +74,7 @@ int cds_warp_entropy_f32(const float* ref_chw, const float* src_hwc, const float
  * K3 "warp-aggregate" (model.py:44-47,57-60,74): volume = sum_v vis_v * (ref_v (x) warp(src_v)),
  * vis_sum = sum_v vis_v, optionally normalised by (vis_sum + 1e-6).  The volume is written once.
  *   vis_w     [V][h][w]
- *   volume    [C][D][h][w]
+ *   volume    [C][D][h][w], or [D][h][w][C] with CDS_AGG_CHANNELS_LAST (what the split-bf16 CostRegNet kernels read)
  *   vis_sum   [h][w]
  *   flags     CDS_AGG_*
  * V <= CDS_MAX_VIEWS per call.
@@ -99,6 +100,10 @@ int cds_warp_aggregate_bwd_f32(const float* ref_chw, const float* src_hwc, const
 /* volume[c][d][p] /= (vis_sum[p] + 1e-6)  (model.py:74) — the finalisation after a view-shard
  * all-reduce of partial sums. */
 int cds_volume_normalize_f32(float* volume, const float* vis_sum, int C, int D, int hw, void* stream);
+
+/* The same division for a channels-last partial volume [D][h][w][C] (C % 4 == 0): every channel of voxel (d, p) is divided
+ * by (vis_sum[p] + 1e-6).  Used after the view-shard all-reduce (model.py:74). */
+int cds_volume_normalize_cl_f32(float* volume, const float* vis_sum, int C, int D, int hw, void* stream);
 
 /*
  * K5 (model.py:90-92, module.py:373-391): softmax over D, depth = sum p*hyp, confidence =
@@ -142,6 +147,31 @@ int cds_conv3d_k3_f32(const float* x, const float* weight, const float* bias, co
  */
 int cds_conv3d_k3_cl_f32(const float* x, const float* weight_cl, const float* bias, const float* skip,
                          float* out, int Cin, int Cout, int D, int H, int W, int act, void* stream);
+
+/* K4, split-bf16 arithmetic on channels-last volumes (csrc/conv3d_sbf.hip): 3x3x3 convolution, pad 1, stride 1 | 2
+ * (+bias +ReLU +residual).  Every fp32 operand is split exactly into three bf16 terms and multiplied as six error-compensated
+ * partial products on v_mfma_f32_16x16x32_bf16 with fp32 accumulation: fp32-class error (dropped terms <= 2^-23 |a b| per
+ * product) at the bf16 matrix rate.  Replaces models/module.py:80-116 (Conv3d + BatchNorm3d(eval, folded) + ReLU) like
+ * cds_conv3d_k3_f32, on x [D][H][W][Cin] -> out [Do][Ho][Wo][Cout] (a voxel's channels contiguous).
+ * weight_split: int16 [Cin/8][7][ceil(Cout/16)][3][64][8] packed by the host (ops.split_pack_conv3d).
+ * stride == CDS_SBF_PAIR: stride 1 with Cout == 8 and pair-packed weights [Cin/8][9][1][3][64][8] (ops.split_pack_conv3d_pair):
+ * an MFMA column is a pair of x-adjacent voxels, its rows (x parity, cout), so no matrix row multiplies padding.
+ * Needs Cin % 8 == 0, Cout % 4 == 0, Cout <= 64; CDS_EINVAL otherwise. */
+#define CDS_SBF_PAIR 101
+int cds_conv3d_sbf_f32(const float* x, const void* weight_split, const float* bias, const float* skip, float* out,
+                       int Cin, int Cout, int D, int H, int W, int stride, int act, void* stream);
+
+/* ConvTranspose3d k3 s2 p1 op1 (+bias +ReLU +residual) in the same split-bf16 arithmetic, channels-last: x [D][H][W][Cin]
+ * -> out [2D][2H][2W][Cout].  Replaces models/module.py:125-160 (Deconv3d + BatchNorm3d(eval, folded) + ReLU + the U-Net
+ * skip addition of :310-312).  weight_split from ops.split_pack_deconv3d.  Cout in {8, 16, 32}, Cin % 8 == 0.
+ * out_planar != 0: the output is written [Cout][2D][2H][2W] (for a planar consumer: conv11 -> prob); skip stays channels-last. */
+int cds_deconv3d_sbf_f32(const float* x, const void* weight_split, const float* bias, const float* skip, float* out,
+                         int Cin, int Cout, int D, int H, int W, int act, int out_planar, void* stream);
+
+/* CostRegNet's last layer (Conv3d 8 -> 1, k3 p1, no bias / BatchNorm / ReLU; models/module.py:303) on a channels-last
+ * input: x [D][H][W][8] -> out [D][H][W] (the planar logits cds_softargmin_conf_f32 reads).  Plain fp32 FMAs.
+ * weight_tap: fp32 [3 ky][3 kx][3 kz][8 ci]. */
+int cds_conv3d_prob_cl8_f32(const float* x, const float* weight_tap, float* out, int D, int H, int W, void* stream);
 
 /*
  * K4 (module.py:125-160): ConvTranspose3d k=3, stride 2, padding 1, output_padding 1 (doubles

@@ -11,6 +11,7 @@ import os
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 from conftest import load_golden
 
@@ -785,3 +786,90 @@ def test_full_forward_view_counts(dev, seeded_state, N):
         assert (a["depth"].cpu() - b["depth"]).abs().mean() < 1e-3, s
         assert (a["photometric_confidence"].cpu() - b["photometric_confidence"]).abs().mean() < 1e-3, s
         assert (a["norm_curv"].cpu() - b["norm_curv"]).abs().max() < 1e-4, s
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cin,cout,stride,D,H,W", [(8, 8, 1, 9, 13, 40), (8, 8, 1, 16, 32, 64), (16, 16, 1, 6, 10, 36),
+                                                  (32, 32, 1, 5, 9, 20), (64, 64, 1, 4, 6, 16), (8, 4, 1, 7, 8, 44),
+                                                  (8, 16, 2, 9, 17, 35), (16, 32, 2, 8, 16, 32), (32, 64, 2, 6, 9, 21),
+                                                  (8, 16, 2, 16, 32, 64), (8, 8, 101, 9, 13, 40), (16, 8, 101, 5, 8, 33),
+                                                  (32, 8, 101, 8, 16, 64)])
+def test_conv3d_split_bf16_is_fp32_class(cin, cout, stride, D, H, W, dev, ops):
+    """csrc/conv3d_sbf.hip: 3 x 3 x 3 convolution with every fp32 operand split exactly into three bf16 terms and six
+    error-compensated partial products on the bf16 matrix cores (fp32 accumulate).  The claim is fp32-CLASS accuracy,
+    measured against a float64 convolution: its error must not exceed 1.5x the error of a plain fp32 evaluation of the same
+    convolution (+ one fp32 ulp of the result scale) — the larger of PyTorch's fp32 CPU convolution (blocked summation)
+    and this library's exact-fp32 kernel (cds_conv3d_k3_f32: one sequential fmaf chain over the 27 Cin products per output) —
+    with bias, ReLU and residual fused like the fp32 kernels."""
+    g = torch.Generator().manual_seed(cin * 100 + cout)
+    x = torch.randn(cin, D, H, W, generator=g) * torch.exp(torch.randn(cin, 1, 1, 1, generator=g))     # uneven channel scales
+    w = torch.randn(cout, cin, 3, 3, 3, generator=g) / (27 * cin) ** 0.5
+    b = torch.randn(cout, generator=g)
+    pair = stride == ops.SBF_PAIR        # stride 1, Cout = 8, voxel-pair columns
+    code, stride = stride, (1 if pair else stride)
+    want64 = F.conv3d(x.double().unsqueeze(0), w.double(), b.double(), padding=1, stride=stride)[0]
+    want32 = F.conv3d(x.unsqueeze(0), w, b, padding=1, stride=stride)[0]
+    skip = torch.randn(want32.shape, generator=g)
+    ws = ops.split_pack_conv3d_pair(w.to(dev)) if pair else ops.split_pack_conv3d(w.to(dev))
+    x_cl = x.permute(1, 2, 3, 0).contiguous().to(dev)
+    got = ops.conv3d_sbf(x_cl, ws, b.to(dev), cout, stride=code, relu=False).cpu().permute(3, 0, 1, 2)
+    wpk = w.permute(1, 2, 3, 4, 0).reshape(cin, 27, cout).contiguous().to(dev)
+    try:
+        chain32 = ops.conv3d_k3(x.to(dev), wpk, b.to(dev), stride=stride, relu=False).cpu()
+    except ValueError:          # Cout = 4 is outside the fp32 kernels' coverage
+        chain32 = want32
+    err_sbf = (got.double() - want64).abs().max().item()
+    err_f32 = max((want32.double() - want64).abs().max().item(), (chain32.double() - want64).abs().max().item())
+    ulp = want64.abs().max().item() * 2.0 ** -23
+    print(f"conv3d {cin}->{cout} s{stride}: max err vs float64: split-bf16 {err_sbf:.2e}, torch fp32 "
+          f"{(want32.double() - want64).abs().max().item():.2e}, fp32 fmaf-chain kernel {(chain32.double() - want64).abs().max().item():.2e}")
+    assert err_sbf <= 1.5 * err_f32 + ulp, (err_sbf, err_f32)
+    got2 = ops.conv3d_sbf(x_cl, ws, b.to(dev), cout, stride=code, relu=True,
+                          skip=skip.permute(1, 2, 3, 0).contiguous().to(dev)).cpu().permute(3, 0, 1, 2)
+    want2 = skip.double() + want64.clamp_min(0)
+    assert (got2.double() - want2).abs().max().item() <= 1.5 * err_f32 + 2 * ulp
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cin,cout,D,H,W", [(16, 8, 5, 7, 37), (16, 8, 4, 8, 32), (32, 16, 3, 6, 20), (64, 32, 2, 5, 18),
+                                            (8, 8, 3, 4, 16)])
+def test_deconv3d_split_bf16_is_fp32_class(cin, cout, D, H, W, dev, ops):
+    """ConvTranspose3d k3 s2 p1 op1 on the split-bf16 kernel (all 8 output parity classes per workgroup; Cout = 8: the x
+    parities share an MFMA) against float64, same acceptance as the forward convolution."""
+    g = torch.Generator().manual_seed(cin * 10 + cout)
+    x = torch.randn(cin, D, H, W, generator=g) * torch.exp(torch.randn(cin, 1, 1, 1, generator=g))
+    w = torch.randn(cin, cout, 3, 3, 3, generator=g) / (27 * cin / 8) ** 0.5
+    b = torch.randn(cout, generator=g)
+    want64 = F.conv_transpose3d(x.double().unsqueeze(0), w.double(), b.double(), stride=2, padding=1, output_padding=1)[0]
+    want32 = F.conv_transpose3d(x.unsqueeze(0), w, b, stride=2, padding=1, output_padding=1)[0]
+    skip = torch.randn(want32.shape, generator=g)
+    ws = ops.split_pack_deconv3d(w.to(dev))
+    x_cl = x.permute(1, 2, 3, 0).contiguous().to(dev)
+    got = ops.deconv3d_sbf(x_cl, ws, b.to(dev), cout, relu=False).cpu().permute(3, 0, 1, 2)
+    wpk = w.permute(0, 2, 3, 4, 1).reshape(cin, 27, cout).contiguous().to(dev)
+    chain32 = ops.deconv3d_k3s2(x.to(dev), wpk, b.to(dev), relu=False).cpu()
+    err_sbf = (got.double() - want64).abs().max().item()
+    err_f32 = max((want32.double() - want64).abs().max().item(), (chain32.double() - want64).abs().max().item())
+    ulp = want64.abs().max().item() * 2.0 ** -23
+    print(f"deconv3d {cin}->{cout}: max err vs float64: split-bf16 {err_sbf:.2e}, torch fp32 "
+          f"{(want32.double() - want64).abs().max().item():.2e}, fp32 fmaf-chain kernel {(chain32.double() - want64).abs().max().item():.2e}")
+    assert err_sbf <= 1.5 * err_f32 + ulp, (err_sbf, err_f32)
+    got2 = ops.deconv3d_sbf(x_cl, ws, b.to(dev), cout, relu=True,
+                            skip=skip.permute(1, 2, 3, 0).contiguous().to(dev)).cpu().permute(3, 0, 1, 2)
+    want2 = skip.double() + want64.clamp_min(0)
+    assert (got2.double() - want2).abs().max().item() <= 1.5 * err_f32 + 2 * ulp
+    got3 = ops.deconv3d_sbf(x_cl, ws, b.to(dev), cout, relu=True, skip=skip.permute(1, 2, 3, 0).contiguous().to(dev),
+                            out_planar=True).cpu()                      # same values, planar output (conv11 -> prob)
+    assert torch.equal(got3, got2.contiguous())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("D,H,W", [(9, 7, 70), (4, 4, 64), (6, 9, 131)])
+def test_prob_layer_channels_last(D, H, W, dev, ops):
+    """CostRegNet's last layer (Conv3d 8 -> 1, module.py:303) on a channels-last input against PyTorch fp32."""
+    g = torch.Generator().manual_seed(D * 100 + W)
+    x = torch.randn(8, D, H, W, generator=g)
+    w = torch.randn(1, 8, 3, 3, 3, generator=g) / 216 ** 0.5
+    want = F.conv3d(x.unsqueeze(0), w, padding=1)[0, 0]
+    got = ops.conv3d_prob_cl8(x.permute(1, 2, 3, 0).contiguous().to(dev), ops.pack_prob_cl(w).to(dev)).cpu()
+    assert (got - want).abs().max() < 2e-6 * max(1.0, want.abs().max().item())
