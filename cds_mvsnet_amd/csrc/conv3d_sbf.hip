@@ -105,11 +105,14 @@ struct FCfg {
   static constexpr int KW = PAIR ? 4 : 3;                            // taps along x
   static constexpr int KSTEPS = (9 * KW + 3) / 4;                    // 27 taps + 1 zero tap (7) | 36 taps (9), 4 per K-step
   // consumer waves: two per SIMD when a y row has >= 2 N-tiles to split between them (one waits for LDS, the other issues)
-  static constexpr int CW = (NT >= 2 && MB < 4) ? 8 : 4;             // (MB = 4: the accumulators need the 256-register budget)
+  // (MB = 4: the accumulators need the 256-register budget; stride 2 stages 8 input voxels per output: the extra waves go
+  // to the producers instead)
+  static constexpr int CW = (NT >= 2 && MB < 4 && S == 1) ? 8 : 4;
+  static constexpr int PW = S == 2 ? 8 : 4;                          // producer waves
   static constexpr int NTW = NT / (CW / 4);                          // N-tiles per consumer wave
   static constexpr int NG = MB == 1 ? (NTW < 4 ? NTW : 4) : (NTW < 2 ? NTW : 2);   // N-tiles whose operands are in registers together
   static constexpr bool WDB = MB < 4;                                // weights double-buffered across K-steps (register budget)
-  static constexpr int THREADS = (CW + 4) * 64;
+  static constexpr int THREADS = (CW + PW) * 64;
 };
 
 // Warp-specialised, persistent over TPW consecutive tiles (and the Cin / 8 channel rounds of each): 512 threads = 4 consumer
@@ -138,13 +141,13 @@ __global__ __launch_bounds__((FCfg<S, MB, TX_, TZ_, PAIR>::THREADS)) void conv3d
   if (wave >= Cfg::CW) {
     // ============================== producers ==============================
     const int ptid = tid - Cfg::CW * 64;
-    constexpr int NP = Cfg::IZ * Cfg::IY * Cfg::IX;
-    constexpr int PPT = (NP + 255) / 256;
+    constexpr int NP = Cfg::IZ * Cfg::IY * Cfg::IX, PT = Cfg::PW * 64;
+    constexpr int PPT = (NP + PT - 1) / PT;
     int s_rel[PPT];   // packed (rz << 20) | (ry << 10) | c, -1 = no position
     int s_dst[PPT];   // LDS byte offset inside a buffer
 #pragma unroll
     for (int h = 0; h < PPT; ++h) {
-      const int p = h * 256 + ptid;
+      const int p = h * PT + ptid;
       const int row = p / Cfg::IX, c = p - row * Cfg::IX;
       const int rz = row / Cfg::IY, ry = row - rz * Cfg::IY;
       s_rel[h] = p < NP ? ((rz << 20) | (ry << 10) | c) : -1;
