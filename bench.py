@@ -133,6 +133,22 @@ def other_workloads(model, dev):
         return dt / n * 1e3
 
     with torch.no_grad():
+        # the headline workload once more with CostRegNet on the exact-fp32 kernels (sequential fmaf chains on the fp32
+        # matrix / vector pipes, planar volumes) instead of the split-bf16 matrix-core kernels
+        import cds_mvsnet_amd.model as cm
+        if cm.USE_SPLIT_BF16:
+            h, w, D, C, n_views = WORKLOADS["M1"]
+            _, cams, hyp, dfe = make_workload("M1", 0, dev)
+            hyp_d = hyp.to(dev)
+            cm.USE_SPLIT_BF16 = False
+            model.repack()
+            try:
+                out["M1_exact_fp32_costreg_ms"] = timeit(lambda: model.stage_net(
+                    dfe, cams, depth_values=hyp_d, num_depth=D, cost_regularization=model.cost_regularization[2], stage_idx=2))
+            finally:
+                cm.USE_SPLIT_BF16 = True
+                model.repack()
+            del dfe, hyp_d
         h, w, D, C, n_views = WORKLOADS["M1b"]
         _, cams, hyp, dfe = make_workload("M1b", 0, dev)
         hyp_d = hyp.to(dev)
@@ -481,7 +497,12 @@ def main():
             "data": "synthetic (seeded features/cameras/hypotheses, seeded random weights)",
             "config": {"workload": workload_desc,
                        "parallelism": (args.parallelism if kind != "train" else "data-parallel") if world > 1 else "single",
-                       "depth_maps_per_step_per_gpu": args.streams, "depth_mean": depth_mean},
+                       "depth_maps_per_step_per_gpu": args.streams, "depth_mean": depth_mean,
+                       "costreg_arithmetic": ("split-bf16: every fp32 operand split exactly into 3 bf16 terms, 6 error-compensated "
+                                              "partial products on v_mfma_f32_16x16x32_bf16, fp32 accumulate (error vs float64 <= the "
+                                              "exact-fp32 fmaf-chain kernels'; CDS_CONV_EXACT=1 selects those)"
+                                              if __import__("cds_mvsnet_amd.model", fromlist=["x"]).USE_SPLIT_BF16
+                                              else "exact fp32 (fmaf chains on the fp32 matrix / vector pipes)")},
             "roofline": roof, "cpu_baseline": cpu, "build": build_id(),
         }
         line.update(extra)

@@ -92,7 +92,7 @@ constexpr int POSB = 48;   // bytes per LDS position
 // halves of the matrix tile carry real outputs (with rows = 16 couts, half of every MFMA would multiply zero padding).  The
 // K window is 3 x 3 x 4 taps (x' = 0..3 relative to the pair; weight row (p, co) is w[x' - p] or 0): 9 K-steps per 32 voxels
 // instead of 14, and as many fewer LDS operand reads.  The x parities of the staged tile are de-interleaved as for stride 2.
-template <int S, int MB, int TX_, int TZ_, bool PAIR = false>
+template <int S, int MB, int TX_, int TZ_, bool PAIR = false, int PWO = 0>
 struct FCfg {
   static constexpr int TX = TX_, TY = 4, TZ = TZ_;
   static constexpr bool DEINT = S == 2 || PAIR;
@@ -108,7 +108,7 @@ struct FCfg {
   // (MB = 4: the accumulators need the 256-register budget; stride 2 stages 8 input voxels per output: the extra waves go
   // to the producers instead)
   static constexpr int CW = (NT >= 2 && MB < 4 && S == 1) ? 8 : 4;
-  static constexpr int PW = S == 2 ? 8 : 4;                          // producer waves
+  static constexpr int PW = PWO ? PWO : (S == 2 ? 8 : 4);            // producer waves
   static constexpr int NTW = NT / (CW / 4);                          // N-tiles per consumer wave
   static constexpr int NG = MB == 1 ? (NTW < 4 ? NTW : 4) : (NTW < 2 ? NTW : 2);   // N-tiles whose operands are in registers together
   static constexpr bool WDB = MB < 4;                                // weights double-buffered across K-steps (register budget)
@@ -120,13 +120,13 @@ struct FCfg {
 // loads -> exact bf16 split in registers -> LDS writes), double-buffered LDS tile, ONE workgroup barrier per stage.  The
 // producers run a stage ahead in LDS and another one ahead in registers, so the matrix pipe never waits for staging: with
 // the staging in the same waves as the MFMAs, the two workgroups of a CU fell into lock-step and the pipe idled half the time.
-template <int S, int MB, int TX_, int TZ_, bool PAIR = false>
-__global__ __launch_bounds__((FCfg<S, MB, TX_, TZ_, PAIR>::THREADS)) void conv3d_sbf_kernel(const float* __restrict__ x, const uint4* __restrict__ wsp,
+template <int S, int MB, int TX_, int TZ_, bool PAIR = false, int PWO = 0>
+__global__ __launch_bounds__((FCfg<S, MB, TX_, TZ_, PAIR, PWO>::THREADS)) void conv3d_sbf_kernel(const float* __restrict__ x, const uint4* __restrict__ wsp,
                                                             const float* __restrict__ bias, const float* __restrict__ skip,
                                                             float* __restrict__ out, int Cin, int Cout, int D, int H, int W,
                                                             int Do, int Ho, int Wo, int act, int tiles_x, int tiles_y,
                                                             int ntiles, int tpw) {
-  using Cfg = FCfg<S, MB, TX_, TZ_, PAIR>;
+  using Cfg = FCfg<S, MB, TX_, TZ_, PAIR, PWO>;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -148,10 +148,13 @@ __global__ __launch_bounds__((FCfg<S, MB, TX_, TZ_, PAIR>::THREADS)) void conv3d
 #pragma unroll
     for (int h = 0; h < PPT; ++h) {
       const int p = h * PT + ptid;
-      const int row = p / Cfg::IX, c = p - row * Cfg::IX;
+      const int row = p / Cfg::IX, q = p - row * Cfg::IX;
+      // de-interleaved tiles: consecutive threads fill consecutive LDS positions of ONE parity half-row (conflict-free
+      // 16-byte stores); their global columns are then 2 apart
+      const int c = Cfg::DEINT ? (2 * (q % Cfg::IXH) + q / Cfg::IXH) : q;
       const int rz = row / Cfg::IY, ry = row - rz * Cfg::IY;
-      s_rel[h] = p < NP ? ((rz << 20) | (ry << 10) | c) : -1;
-      s_dst[h] = (row * Cfg::IXP + (Cfg::DEINT ? ((c & 1) * Cfg::IXH + (c >> 1)) : c)) * POSB;
+      s_rel[h] = (p < NP && c < Cfg::IX) ? ((rz << 20) | (ry << 10) | c) : -1;
+      s_dst[h] = (row * Cfg::IXP + q) * POSB;
     }
     float4 va[PPT], vb[PPT];
     auto issue = [&](int st) {
@@ -195,7 +198,10 @@ __global__ __launch_bounds__((FCfg<S, MB, TX_, TZ_, PAIR>::THREADS)) void conv3d
   int toff[Cfg::KSTEPS];
 #pragma unroll
   for (int t = 0; t < Cfg::KSTEPS; ++t) {
-    int tap = 4 * t + g;
+    // PAIR: K-step t is the (kz, ky) row t, and the lane groups take x' = 0, 2, 1, 3: the two groups that share an LDS
+    // service group (g = 0, 1 and g = 2, 3) then read the SAME parity plane one position apart (overlapping addresses
+    // broadcast) instead of two planes whose bank windows collide (PMC: half of the LDS cycles were conflicts).
+    int tap = PAIR ? 4 * t + ((g & 1) * 2 + (g >> 1)) : 4 * t + g;
     if (tap > 9 * Cfg::KW - 1) tap = 9 * Cfg::KW - 1;
     const int kz = tap / (3 * Cfg::KW), ky = (tap / Cfg::KW) % 3, kx = tap % Cfg::KW;
     const int xoff = Cfg::DEINT ? ((kx & 1) * Cfg::IXH + (kx >> 1)) : kx;
@@ -224,14 +230,10 @@ __global__ __launch_bounds__((FCfg<S, MB, TX_, TZ_, PAIR>::THREADS)) void conv3d
       auto load_w = [&](int buf, int t) {
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) {
-#ifdef CDS_EXP_SBF_NOWLOAD
-          wa[buf][mb][0].u = make_uint4(t, mb, lane, 1); wa[buf][mb][1].u = make_uint4(t, mb, lane, 2); wa[buf][mb][2].u = make_uint4(t, mb, lane, 3);
-#else
           const uint4* p = wr + (size_t)((t * MB + mb) * 3) * 64;
           wa[buf][mb][0].u = p[0];
           wa[buf][mb][1].u = p[64];
           wa[buf][mb][2].u = p[128];
-#endif
         }
       };
       auto load_b = [&](int buf, int t, int grp) {
@@ -240,14 +242,9 @@ __global__ __launch_bounds__((FCfg<S, MB, TX_, TZ_, PAIR>::THREADS)) void conv3d
         for (int q = 0; q < Cfg::NG; ++q) {
           const int ti = wh * Cfg::NTW + grp * Cfg::NG + q, tz = ti / Cfg::XT, txr = ti % Cfg::XT;
           const unsigned char* b = bp + ((tz * S * Cfg::IY) * Cfg::IXP + txr * 16) * POSB;
-#ifdef CDS_EXP_SBF_NOLDSREAD
-          bd[buf][q][0].u = make_uint4(t, ti, lane, 1); bd[buf][q][1].u = make_uint4(t, ti, lane, 2); bd[buf][q][2].u = make_uint4(t, ti, lane, 3);
-          (void)b;
-#else
           bd[buf][q][0].u = *reinterpret_cast<const uint4*>(b);
           bd[buf][q][1].u = *reinterpret_cast<const uint4*>(b + 16);
           bd[buf][q][2].u = *reinterpret_cast<const uint4*>(b + 32);
-#endif
         }
       };
       load_w(0, 0);
@@ -266,19 +263,10 @@ __global__ __launch_bounds__((FCfg<S, MB, TX_, TZ_, PAIR>::THREADS)) void conv3d
         // Term-major over independent accumulators; the sched_barriers pin that order and keep the operand requests above
         // ahead of the MFMAs (left alone, the machine scheduler sinks the loads to their first use).
         __builtin_amdgcn_sched_barrier(0);
-#ifndef CDS_EXP_SBF_NOMFMA
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) {
           SBF_TERMS(acc[mb], t0, Cfg::NG, wa[wb][mb], bd[db]);
         }
-#else
-#pragma unroll
-        for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-          for (int q = 0; q < Cfg::NG; ++q) {
-            acc[mb][t0 + q].x += __uint_as_float(wa[wb][mb][0].u.x ^ bd[db][q][0].u.x ^ bd[db][q][1].u.y ^ bd[db][q][2].u.z ^ wa[wb][mb][1].u.w ^ wa[wb][mb][2].u.x);
-          }
-#endif
       }
       if (rd + 1 == rounds) {
         // ---- epilogue: lane -> voxel j of the run, couts 16 mb + 4 g + 0..3: one 16-byte channels-last store ----
@@ -317,10 +305,10 @@ __global__ __launch_bounds__((FCfg<S, MB, TX_, TZ_, PAIR>::THREADS)) void conv3d
   }
 }
 
-template <int S, int MB, int TX, int TZ, bool PAIR = false>
+template <int S, int MB, int TX, int TZ, bool PAIR = false, int PWO = 0>
 int launch_fwd(const float* x, const void* wsp, const float* b, const float* skip, float* out, int Cin, int Cout, int D, int H,
                int W, int act, hipStream_t st) {
-  using Cfg = FCfg<S, MB, TX, TZ, PAIR>;
+  using Cfg = FCfg<S, MB, TX, TZ, PAIR, PWO>;
   static_assert(2 * Cfg::LDSB <= 160 * 1024, "two LDS tile buffers above 160 KB");
   const int Do = (D - 1) / S + 1, Ho = (H - 1) / S + 1, Wo = (W - 1) / S + 1;
   const int tx = cds_ceil_div(Wo, Cfg::TX), ty = cds_ceil_div(Ho, Cfg::TY), tz = cds_ceil_div(Do, Cfg::TZ);
@@ -329,7 +317,7 @@ int launch_fwd(const float* x, const void* wsp, const float* b, const float* ski
   static const int tpw_env = []() { const char* e = getenv("CDS_SBF_TPW"); return e ? atoi(e) : 0; }();   // A/B knob
   int tpw = tpw_env > 0 ? tpw_env : max(1, min(32, ntiles / (256 * 6)));
   const int nwg = cds_ceil_div(ntiles, tpw);
-  auto kern = conv3d_sbf_kernel<S, MB, TX, TZ, PAIR>;
+  auto kern = conv3d_sbf_kernel<S, MB, TX, TZ, PAIR, PWO>;
   constexpr int lds_bytes = 2 * Cfg::LDSB;
   if (lds_bytes > 64 * 1024) {
     static bool attr_done = false;   // once per instantiation
@@ -662,6 +650,9 @@ extern "C" int cds_conv3d_sbf_f32(const float* x, const void* weight_split, cons
   const int mb = (Cout + 15) / 16;
   if (stride == CDS_SBF_PAIR) {   // stride 1, Cout == 8, pair-packed weights
     if (Cout != 8) return CDS_EINVAL;
+    static const int pwo = []() { const char* e = getenv("CDS_SBF_PW"); return e ? atoi(e) : 0; }();   // A/B knob
+    if (pwo == 8) return launch_fwd<1, 1, 32, 4, true, 8>(x, weight_split, bias, skip, out, Cin, Cout, D, H, W, act, st);
+    if (pwo == 2) return launch_fwd<1, 1, 32, 4, true, 2>(x, weight_split, bias, skip, out, Cin, Cout, D, H, W, act, st);
     return launch_fwd<1, 1, 32, 4, true>(x, weight_split, bias, skip, out, Cin, Cout, D, H, W, act, st);
   }
   if (stride == 1) {

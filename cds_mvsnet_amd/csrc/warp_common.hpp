@@ -27,12 +27,17 @@ __device__ __forceinline__ Taps cds_taps(const float r[3], const float* __restri
   float py = r[1] * d + t[1];
   float pz = r[2] * d + t[2];
   float z = pz + 1e-6f;
+#ifdef CDS_WARP_RELAXED   // A/B build only, see positions2() in warp_lds.hip
+  float ry = __builtin_amdgcn_rcpf(z);
+  float ix = px * ry, iy = py * ry;
+#else
   float u = px / z;
   float v = py / z;
   float gx = u / half_w - 1.0f;
   float gy = v / half_h - 1.0f;
   float ix = (gx + 1.0f) * half_w;
   float iy = (gy + 1.0f) * half_h;
+#endif
   float x0f = floorf(ix), y0f = floorf(iy);
   float wx = ix - x0f, ex = 1.0f - wx;
   float ny = iy - y0f, sy = 1.0f - ny;

@@ -232,6 +232,15 @@ __device__ __forceinline__ void positions2(const float r[3], const float* __rest
   v2f y0;
   y0.x = __builtin_amdgcn_rcpf(z.x);
   y0.y = __builtin_amdgcn_rcpf(z.y);
+#ifdef CDS_WARP_RELAXED
+  // A/B build only (scripts/build_variant.sh relaxed -DCDS_WARP_RELAXED, profiles/r02_relaxed_positions_ab.md): sample at
+  // (u, v) = p.xy * rcp(z) directly -- no correctly rounded divisions, no ATen normalise / de-normalise round trip.
+  // 13 instead of 33 packed instructions per plane pair and view; moves samples by up to ~1e-4 px.
+  ix = px * y0;
+  iy = py * y0;
+  (void)g;
+  return;
+#endif
   const v2f e = fma2(-z, y0, splat2(1.0f));
   const v2f y = fma2(e, y0, y0);
   // u = px / z and v = py / z (div2_refine), written interleaved: two independent dependency chains

@@ -416,6 +416,11 @@ class _FeatureRunner:
                 out[f"{name}.w{i}"] = _pack2d(w)
                 if dc.convs[i].bias is not None:
                     out[f"{name}.b{i}"] = torch.cat((dc.convs[i].bias.detach(), torch.zeros(3, device=dev))).contiguous()
+            if ops.dynconv_sbf_supported(dc.in_c, dc.out_c + 3, dc.size_kernels, 4) and dc.att_convs[0].weight.is_cuda:
+                out[f"{name}.ws"] = ops.split_pack_dynconv([torch.cat((dc.convs[i].weight.detach(), dc.att_convs[i].weight.detach()), dim=0)
+                                                            for i in range(len(dc.size_kernels))])
+                if dc.convs[0].bias is not None:
+                    out[f"{name}.bs"] = torch.stack([out[f"{name}.b{i}"] for i in range(len(dc.size_kernels))]).contiguous()
             scale, shift = _bn_fold(dc.att_weights[1])
             nk = len(dc.size_kernels)
             out[f"{name}.m1"] = (dc.att_weights[0].weight.detach().reshape(4, nk) * scale.view(4, 1)).contiguous()
@@ -443,9 +448,14 @@ class _FeatureRunner:
         xs = x[n_shared - 1:] if n_shared > 1 else x
         affs = aff[n_shared - 1:].contiguous() if (aff is not None and n_shared > 1) else aff
         branches = torch.empty((nk, xs.shape[0], dc.out_c + 3, H, W), dtype=torch.float32, device=x.device)
-        for i, k in enumerate(dc.size_kernels):
-            ops.conv2d(xs, p[f"{name}.w{i}"], p.get(f"{name}.b{i}"), dc.out_c + 3, k, 1, (k - 1) // 2, ACT_NONE,
-                       out=branches[i], in_affine=affs)
+        if f"{name}.ws" in p and ops.dynconv_sbf_supported(Cin, dc.out_c + 3, dc.size_kernels, W):
+            # all kernel sizes from one staged tile on the matrix cores (split-bf16 arithmetic)
+            ops.dynconv_branches_sbf(xs.contiguous(), p[f"{name}.ws"], p.get(f"{name}.bs"), dc.out_c + 3, dc.size_kernels,
+                                     out=branches, in_affine=affs)
+        else:
+            for i, k in enumerate(dc.size_kernels):
+                ops.conv2d(xs, p[f"{name}.w{i}"], p.get(f"{name}.b{i}"), dc.out_c + 3, k, 1, (k - 1) // 2, ACT_NONE,
+                           out=branches[i], in_affine=affs)
         return ops.dynconv_blend(branches, p[f"{name}.m1"], p[f"{name}.mb"], p[f"{name}.m2"], epi, T, n_shared,
                                  stats_slope=stats_slope)
 

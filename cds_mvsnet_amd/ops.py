@@ -408,7 +408,7 @@ def split_pack_conv3d_pair(w: Tensor) -> Tensor:
     """Pair packing of a (BN-folded) Conv3d weight [8,Cin,3,3,3] for cds_conv3d_sbf_f32(stride=CDS_SBF_PAIR): an MFMA column
     is the voxel pair (2 j, 2 j + 1), row i = 8 p + co is output channel co of voxel 2 j + p, and the K window is 3 x 3 x 4
     taps (x' = 0..3 relative to the pair): row (p, co) multiplies w[co][ci][kz][ky][x' - p], or 0 outside 0..2.
-    int16 [Cin/8][9 ksteps][1][3][64][8]; lane l = 16 g + i holds tap 4 t + g = (kz * 3 + ky) * 4 + x'."""
+    int16 [Cin/8][9 ksteps][1][3][64][8]; K-step t = kz * 3 + ky, lane l = 16 g + i holds x' = (0, 2, 1, 3)[g]."""
     Cout, Cin = w.shape[:2]
     if Cout != 8 or Cin % 8:
         raise ValueError("split_pack_conv3d_pair: Cout == 8 and Cin % 8 == 0")
@@ -417,6 +417,7 @@ def split_pack_conv3d_pair(w: Tensor) -> Tensor:
     taps = torch.zeros((2, 8, rounds, 3, 3, 4, 8), dtype=torch.float32, device=w.device)   # [p][co][rd][kz][ky][x'][j]
     for p_ in (0, 1):
         taps[p_, :, :, :, :, p_:p_ + 3] = wf.permute(0, 1, 3, 4, 5, 2)
+    taps = taps[:, :, :, :, :, [0, 2, 1, 3]]          # lane group g multiplies x' = (0, 2, 1, 3)[g] (LDS bank pairing)
     a = taps.reshape(16, rounds, 9, 4, 8).permute(1, 2, 3, 0, 4).reshape(rounds, 9, 1, 64, 8)   # [rd][t][mb][16 g + i][j]
     return _split3(a)
 
@@ -498,6 +499,8 @@ def conv2d(x: Tensor, wpk: Tensor, bias: Optional[Tensor], cout: int, k: int, st
 
 
 USE_CONV2D_MFMA = os.environ.get("CDS_CONV2D_MFMA", "1") != "0"   # A/B knob
+# DynamicConv branch convolutions on the bf16 matrix cores in split-bf16 arithmetic (CDS_CONV_EXACT=1: exact-fp32 VALU kernels)
+USE_CONV2D_SBF = os.environ.get("CDS_CONV_EXACT", "0") != "1" and os.environ.get("CDS_CONV2D_SBF", "1") != "0"
 
 
 def conv2d_c16_supported(x: Tensor) -> bool:
@@ -520,6 +523,54 @@ def conv2d_k3_c16(x: Tensor, wcl: Tensor, bias: Optional[Tensor], act: int = ACT
                                             _dev(head_w, "head_w") if head_w is not None else None,
                                             _dev(head_b, "head_b") if head_b is not None else None,
                                             _dev(out, "out"), N, H, W, act, _stream(x)), "cds_conv2d_k3_c16_f32")
+    return out
+
+
+def dynconv_sbf_supported(Cin: int, co3: int, ksizes, W: int) -> bool:
+    """Shapes cds_dynconv_branches_sbf_f32 covers (everything in FeatureNet but conv00, whose 3 input channels and 11 x 11
+    kernel would leave the matrix tiles mostly padding)."""
+    nb, nblk = len(ksizes), (co3 + 15) // 16
+    return (USE_CONV2D_SBF and Cin % 8 == 0 and W % 4 == 0 and all(k in (1, 3, 5, 7) for k in ksizes)
+            and (nb, nblk) in ((3, 1), (3, 2), (2, 1), (2, 2), (2, 3)))
+
+
+def split_pack_dynconv(ws) -> Tensor:
+    """Pack the branch weights of one DynamicConv for cds_dynconv_branches_sbf_f32.  ws: list over kernel sizes of
+    [Co3,Cin,k,k] (convs[k] and att_convs[k] concatenated).  int16 [Cin/8][nks][nblk][3][64][8]; within a round branch b
+    owns K-steps ks0_b .. ks0_b + ceil(k_b^2 / 4); lane l = 16 g + n multiplies output channel 16 nb + n by tap 4 t + g
+    (tap = ky * k + kx; taps beyond k^2 and channels beyond Co3 are zero) of input channels 8 rd + 0..7."""
+    Co3, Cin = ws[0].shape[:2]
+    rounds, nblk = Cin // 8, (Co3 + 15) // 16
+    parts = []
+    for w in ws:
+        k = w.shape[-1]
+        nks = (k * k + 3) // 4
+        taps = torch.zeros((nblk * 16, rounds, nks * 4, 8), dtype=torch.float32, device=w.device)     # [co][rd][tap][j]
+        taps[:Co3, :, :k * k] = w.detach().float().reshape(Co3, rounds, 8, k * k).permute(0, 1, 3, 2)
+        # -> [rd][t][nb][g][n][j]
+        parts.append(taps.reshape(nblk, 16, rounds, nks, 4, 8).permute(2, 3, 0, 4, 1, 5).reshape(rounds, nks, nblk, 64, 8))
+    return _split3(torch.cat(parts, dim=1))
+
+
+def dynconv_branches_sbf(x: Tensor, wsplit: Tensor, bias: Optional[Tensor], co3: int, ksizes, out: Optional[Tensor] = None,
+                         in_affine: Optional[Tensor] = None) -> Tensor:
+    """All branch convolutions of a DynamicConv on the matrix cores: x [N,Cin,H,W] -> branches [K,N,co3,H,W]."""
+    N, Cin, H, W = x.shape
+    K = len(ksizes)
+    if in_affine is not None and tuple(in_affine.shape) != (N, Cin, 3):
+        raise ValueError(f"dynconv_branches_sbf: in_affine must be [{N},{Cin},3]")
+    if out is None:
+        out = torch.empty((K, N, co3, H, W), dtype=torch.float32, device=x.device)
+    elif tuple(out.shape) != (K, N, co3, H, W):
+        raise ValueError("dynconv_branches_sbf: bad output buffer")
+    if bias is not None and tuple(bias.shape) != (K, co3):
+        raise ValueError("dynconv_branches_sbf: bias must be [K, co3]")
+    import ctypes
+    ks = (ctypes.c_int * K)(*[int(k) for k in ksizes])
+    check(_lib.load().cds_dynconv_branches_sbf_f32(_dev(x, "x"), _dev(in_affine, "in_affine") if in_affine is not None else None,
+                                                   wsplit.data_ptr(), _dev(bias, "bias") if bias is not None else None,
+                                                   _dev(out, "out"), N, Cin, co3, H, W, ks, K, _stream(x)),
+          "cds_dynconv_branches_sbf_f32")
     return out
 
 

@@ -214,6 +214,19 @@ int cds_conv2d_k3_c16_f32(const float* x, const float* weight_cl, const float* b
                           const float* head_b, float* out, int N, int H, int W, int act, void* stream);
 
 /*
+ * K7 on the matrix cores (csrc/conv2d_sbf.hip): ALL branch convolutions of one DynamicConv (models/dynamic_conv.py:112,116:
+ * convs[k] and the 3-channel att_convs[k] of every kernel size k, concatenated to Co3 = Cout + 3 output channels per branch)
+ * from one staged input tile, stride 1, "same" padding, in split-bf16 arithmetic (every fp32 operand split exactly into three
+ * bf16 terms, six error-compensated partial products on v_mfma_f32_16x16x32_bf16, fp32 accumulation: fp32-class error).
+ *   x [N][Cin][H][W]; in_affine [N][Cin][3] or NULL (normalise-on-load like cds_conv2d_affine_f32); bias [nb][Co3] or NULL
+ *   weight_split: int16 [Cin/8][sum_b ceil(k_b^2/4)][ceil(Co3/16)][3][64][8] (ops.split_pack_dynconv)
+ *   out [nb][N][Co3][H][W] (the `branches` tensor of cds_dynconv_blend_*_f32); ksizes: HOST array of nb kernel sizes in {1,3,5,7}
+ * Covers Cin % 8 == 0, Co3 <= 48, W % 4 == 0, (nb, ceil(Co3/16)) in {(3,1), (3,2), (2,1), (2,2), (2,3)}; CDS_EINVAL otherwise.
+ */
+int cds_dynconv_branches_sbf_f32(const float* x, const float* in_affine, const void* weight_split, const float* bias,
+                                 float* out, int N, int Cin, int Co3, int H, int W, const int* ksizes, int nb, void* stream);
+
+/*
  * FPN lateral connection (module.py:253-254, 260-261): the 1x1 convolution of
  *   cat(interpolate(coarse, scale_factor=2, mode="nearest"), skip)
  * without materialising the up-sampled tensor or the concatenation.

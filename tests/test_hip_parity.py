@@ -116,9 +116,17 @@ def test_costreg(tag, C, dev):
     net = CostRegNet(C, 8)
     seeded_init_(net, int(g["seed"]))
     net = net.to(dev).eval()
-    out = net(g["volume"].to(dev).contiguous()).cpu()
+    out = net(g["volume"].to(dev).contiguous()).cpu()               # planar volume: exact-fp32 kernels (fmaf chains)
     err = (out - g["cost_reg"]).abs().max()
     assert err < 1e-4, err
+    # channels-last volume: the split-bf16 matrix-core kernels (what the model runs); same golden, same tolerance, and
+    # the two arithmetic paths agree with each other far inside it
+    assert net.split_bf16_supported()
+    out_cl = net(g["volume"].permute(1, 2, 3, 0).contiguous().to(dev), channels_last=True).cpu()
+    err_cl = (out_cl - g["cost_reg"]).abs().max()
+    assert err_cl < 1e-4, err_cl
+    assert (out_cl - out).abs().max() < 2e-5
+    print(f"CostRegNet {tag}: max |HIP - reference| exact-fp32 {err:.2e}, split-bf16 {err_cl:.2e}")
 
 
 def test_conv3d_layers_vs_torch(dev, ops):
@@ -873,3 +881,36 @@ def test_prob_layer_channels_last(D, H, W, dev, ops):
     want = F.conv3d(x.unsqueeze(0), w, padding=1)[0, 0]
     got = ops.conv3d_prob_cl8(x.permute(1, 2, 3, 0).contiguous().to(dev), ops.pack_prob_cl(w).to(dev)).cpu()
     assert (got - want).abs().max() < 2e-6 * max(1.0, want.abs().max().item())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cin,cout,ks,N,H,W,bias", [(8, 8, (3, 5, 7), 2, 21, 44, False), (16, 16, (3, 5), 1, 16, 36, False),
+                                                   (32, 32, (1, 3), 2, 9, 20, True), (16, 16, (1, 3), 1, 12, 32, True),
+                                                   (8, 8, (1, 3), 3, 8, 64, True)])
+def test_dynconv_branches_on_matrix_cores(cin, cout, ks, N, H, W, bias, dev, ops):
+    """csrc/conv2d_sbf.hip: all branch convolutions of a DynamicConv (convs[k] + att_convs[k] for every kernel size,
+    dynamic_conv.py:112,116) in one launch on the bf16 matrix cores in split-bf16 arithmetic, with the producer's
+    InstanceNorm + LeakyReLU applied on load.  fp32-class: against float64 no worse than 1.5x PyTorch's / the VALU kernel's
+    fp32 error, and within 2e-5 of the exact-fp32 VALU kernel (cds_conv2d_affine_f32) it replaces."""
+    g = torch.Generator().manual_seed(cin + 7 * len(ks))
+    x = torch.randn(N, cin, H, W, generator=g)
+    aff = torch.stack((0.5 + torch.rand(N, cin, generator=g), 0.3 * torch.randn(N, cin, generator=g),
+                       torch.full((N, cin), 0.1)), dim=-1).contiguous()
+    t = x * aff[:, :, 0, None, None] + aff[:, :, 1, None, None]
+    xin = torch.where(t > 0, t, t * 0.1)
+    co3 = cout + 3
+    ws = [torch.randn(co3, cin, k, k, generator=g) / (cin * k * k) ** 0.5 for k in ks]
+    bs = torch.randn(len(ks), co3, generator=g) if bias else None
+    got = ops.dynconv_branches_sbf(x.to(dev), ops.split_pack_dynconv([w.to(dev) for w in ws]), bs.to(dev) if bias else None,
+                                   co3, ks, in_affine=aff.to(dev)).cpu()
+    for i, k in enumerate(ks):
+        want64 = F.conv2d(xin.double(), ws[i].double(), bs[i].double() if bias else None, padding=(k - 1) // 2)
+        want32 = F.conv2d(xin, ws[i], bs[i] if bias else None, padding=(k - 1) // 2)
+        pad = (-co3) % 8
+        wpk = F.pad(ws[i].permute(1, 2, 3, 0).reshape(cin, k * k, co3), (0, pad)).contiguous().to(dev)
+        valu = ops.conv2d(x.to(dev), wpk, bs[i].to(dev) if bias else None, co3, k, 1, (k - 1) // 2, in_affine=aff.to(dev)).cpu()
+        err = (got[i].double() - want64).abs().max().item()
+        ref = max((want32.double() - want64).abs().max().item(), (valu.double() - want64).abs().max().item())
+        ulp = want64.abs().max().item() * 2.0 ** -23
+        assert err <= 1.5 * ref + ulp, (k, err, ref)
+        assert (got[i] - valu).abs().max().item() < 2e-5 * max(1.0, want64.abs().max().item())
