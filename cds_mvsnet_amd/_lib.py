@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_float, c_int, c_void_p
+from ctypes import c_float, c_int, c_longlong, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # CDS_MVSNET_LIB: developer knob to A/B a differently built copy of the same library (scripts/build_variant.sh)
@@ -24,6 +24,7 @@ EINVAL = -1000
 P = c_void_p
 I = c_int
 F = c_float
+L = c_longlong
 
 # name -> argtypes; every function returns int
 SIGNATURES = {
@@ -64,6 +65,11 @@ SIGNATURES = {
     "cds_depth_affine_f32": [P, P, I, F, F, P],
     "cds_deconv2d_k3s2_f32": [P, P, P, P, I, I, I, I, I, P],
     "cds_refine_finish_f32": [P, P, P, I, I, F, F, P],
+    "cds_bn3d_stats_f32": [P, P, I, I, L, P],
+    "cds_bn3d_apply_f32": [P, P, P, P, P, I, I, L, I, P],
+    "cds_bn3d_bwd_reduce_f32": [P, P, P, P, P, I, I, L, I, P],
+    "cds_bn3d_bwd_apply_f32": [P, P, P, P, P, P, P, I, I, L, I, P],
+    "cds_conv3d_wgrad_f32": [P, P, P, I, I, I, I, I, I, I, I, I, I, P],
     "cds_depth_fusion_f32": [P, P, P, P, P, P, P, P, P, I, I, I, P, F, F, F, P],
 }
 

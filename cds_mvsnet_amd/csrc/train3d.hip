@@ -1,0 +1,230 @@
+// Training kernels of the CostRegNet stack (reference: models/module.py:80-160 Conv3d / Deconv3d with
+// BatchNorm3d in training mode, trainer/trainer.py:78-82).  The forward convolutions and the data gradients reuse the
+// inference kernels (cds_conv3d_k3_f32 / cds_deconv3d_k3s2_f32: the data gradient of a convolution is the transposed
+// convolution with the same weights and vice versa; a stride-1 convolution's is the convolution with flipped, transposed
+// weights).  New here:
+//   cds_bn3d_stats_f32        per-channel sum / sum of squares over (batch, voxels), fp64 accumulation
+//   cds_bn3d_apply_f32        y -> relu(y * scale[c] + shift[c]) (+ residual): BatchNorm(train) + ReLU + U-Net skip, fused
+//   cds_bn3d_bwd_reduce_f32   sum g and sum g*y per channel, g = dout * [relu argument > 0]
+//   cds_bn3d_bwd_apply_f32    dy = g * scale[c] + y * k1[c] + k0[c]   (the BatchNorm backward in closed form)
+//   cds_conv3d_wgrad_f32      dw[a][b][tap] = sum_o g[a][o] * xin[b][S*o - 1 + tap]   (conv: g = dy, xin = x, S = stride;
+//                             transposed conv: g = x, xin = dy, S = 2: the same sum with the roles swapped)
+// Layouts: activations [B][C][D][H][W] fp32 planar (PyTorch's), statistics fp64 [C].
+#include "cds_common.hpp"
+
+namespace {
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// grid (chunks, C, B); sums [C][2] fp64 (zeroed by the caller)
+__global__ __launch_bounds__(256) void bn3d_stats_kernel(const float* __restrict__ x, double* __restrict__ sums, int C, size_t V) {
+  const int c = blockIdx.y, b = blockIdx.z;
+  const float* __restrict__ p = x + ((size_t)b * C + c) * V;
+  double s = 0.0, q = 0.0;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < V; i += (size_t)gridDim.x * 256) {
+    const double v = p[i];
+    s += v;
+    q += v * v;
+  }
+  __shared__ double red[2][4];
+  s = wave_sum(s);
+  q = wave_sum(q);
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s; red[1][threadIdx.x >> 6] = q; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(&sums[2 * c], red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+    atomicAdd(&sums[2 * c + 1], red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+  }
+}
+
+// out = relu(y * scale[c] + shift[c]) (+ skip).  grid (chunks, C, B)
+__global__ __launch_bounds__(256) void bn3d_apply_kernel(const float* __restrict__ y, const float* __restrict__ scale,
+                                                         const float* __restrict__ shift, const float* __restrict__ skip,
+                                                         float* __restrict__ out, int C, size_t V, int relu) {
+  const int c = blockIdx.y, b = blockIdx.z;
+  const size_t base = ((size_t)b * C + c) * V;
+  const float sc = scale[c], sh = shift[c];
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < V; i += (size_t)gridDim.x * 256) {
+    float v = fmaf(y[base + i], sc, sh);
+    if (relu) v = fmaxf(v, 0.f);
+    if (skip) v = skip[base + i] + v;
+    out[base + i] = v;
+  }
+}
+
+// sums[c] = (sum g, sum g * y), g = dout * [y * scale + shift > 0]
+__global__ __launch_bounds__(256) void bn3d_bwd_reduce_kernel(const float* __restrict__ dout, const float* __restrict__ y,
+                                                              const float* __restrict__ scale, const float* __restrict__ shift,
+                                                              double* __restrict__ sums, int C, size_t V, int relu) {
+  const int c = blockIdx.y, b = blockIdx.z;
+  const size_t base = ((size_t)b * C + c) * V;
+  const float sc = scale[c], sh = shift[c];
+  double s = 0.0, q = 0.0;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < V; i += (size_t)gridDim.x * 256) {
+    const float yv = y[base + i];
+    const float g = (!relu || fmaf(yv, sc, sh) > 0.f) ? dout[base + i] : 0.f;
+    s += (double)g;
+    q += (double)g * (double)yv;
+  }
+  __shared__ double red[2][4];
+  s = wave_sum(s);
+  q = wave_sum(q);
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s; red[1][threadIdx.x >> 6] = q; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(&sums[2 * c], red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+    atomicAdd(&sums[2 * c + 1], red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+  }
+}
+
+// dy = g * scale[c] + y * k1[c] + k0[c]
+__global__ __launch_bounds__(256) void bn3d_bwd_apply_kernel(const float* __restrict__ dout, const float* __restrict__ y,
+                                                             const float* __restrict__ scale, const float* __restrict__ shift,
+                                                             const float* __restrict__ k1, const float* __restrict__ k0,
+                                                             float* __restrict__ dy, int C, size_t V, int relu) {
+  const int c = blockIdx.y, b = blockIdx.z;
+  const size_t base = ((size_t)b * C + c) * V;
+  const float sc = scale[c], sh = shift[c], a1 = k1[c], a0 = k0[c];
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < V; i += (size_t)gridDim.x * 256) {
+    const float yv = y[base + i];
+    const float g = (!relu || fmaf(yv, sc, sh) > 0.f) ? dout[base + i] : 0.f;
+    dy[base + i] = fmaf(g, sc, fmaf(yv, a1, a0));
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight gradient.  dw[a][b][tap] += sum over the o-tiles of this workgroup of g[a][o] * xin[b][S o - 1 + tap].
+// Workgroup = (group of o-tiles) x (8 a-channels) x (8 b-channels); thread = (a, b, tap group of 7): 7 accumulators.
+// o-tile 8 x 4 x 4 voxels of g; the matching xin tile ((8-1) S + 3) x ((4-1) S + 3)^2 with zero padding, both in LDS.
+// ---------------------------------------------------------------------------------------------
+template <int S>
+struct WCfg {
+  static constexpr int OX = 8, OY = 4, OZ = 4, NO = OX * OY * OZ;
+  static constexpr int IX = (OX - 1) * S + 3, IY = (OY - 1) * S + 3, IZ = (OZ - 1) * S + 3;
+  static constexpr int NI = IX * IY * IZ;
+};
+
+template <int S>
+__global__ __launch_bounds__(256) void conv3d_wgrad_kernel(const float* __restrict__ g, const float* __restrict__ xin,
+                                                           float* __restrict__ dw, int B, int Ca, int Cb, int Do, int Ho, int Wo,
+                                                           int Di, int Hi, int Wi, int tiles_x, int tiles_y, int ntiles,
+                                                           int tiles_per_wg) {
+  using Cfg = WCfg<S>;
+  __shared__ float lg[8][Cfg::NO];
+  __shared__ float lx[8][Cfg::NI];
+  const int tid = threadIdx.x;
+  const int a = tid >> 5, b = (tid >> 2) & 7, kg = tid & 3;       // tap group kg: taps 7 kg .. 7 kg + 6 (27 taps, last group 6)
+  const int a0 = blockIdx.y * 8, b0 = blockIdx.z * 8;
+  const size_t vo = (size_t)Do * Ho * Wo, vi = (size_t)Di * Hi * Wi;
+  float acc[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  int toff[7];
+#pragma unroll
+  for (int t = 0; t < 7; ++t) {
+    const int k = min(7 * kg + t, 26);
+    toff[t] = ((k / 9) * Cfg::IY + (k / 3) % 3) * Cfg::IX + k % 3;
+  }
+  const int t0 = blockIdx.x * tiles_per_wg, t1 = min(ntiles * B, t0 + tiles_per_wg);
+  for (int tile = t0; tile < t1; ++tile) {
+    const int bi = tile / ntiles;
+    int r = tile - bi * ntiles;
+    const int tx_i = r % tiles_x;
+    r /= tiles_x;
+    const int ty_i = r % tiles_y, tz_i = r / tiles_y;
+    const int ox0 = tx_i * Cfg::OX, oy0 = ty_i * Cfg::OY, oz0 = tz_i * Cfg::OZ;
+    __syncthreads();
+    for (int i = tid; i < 8 * Cfg::NO; i += 256) {
+      const int ch = i / Cfg::NO, p = i - ch * Cfg::NO;
+      const int px = p % Cfg::OX, py = (p / Cfg::OX) % Cfg::OY, pz = p / (Cfg::OX * Cfg::OY);
+      const int ox = ox0 + px, oy = oy0 + py, oz = oz0 + pz;
+      const bool ok = a0 + ch < Ca && ox < Wo && oy < Ho && oz < Do;
+      lg[ch][p] = ok ? g[((size_t)bi * Ca + a0 + ch) * vo + ((size_t)oz * Ho + oy) * Wo + ox] : 0.f;
+    }
+    for (int i = tid; i < 8 * Cfg::NI; i += 256) {
+      const int ch = i / Cfg::NI, p = i - ch * Cfg::NI;
+      const int px = p % Cfg::IX, py = (p / Cfg::IX) % Cfg::IY, pz = p / (Cfg::IX * Cfg::IY);
+      const int ix = ox0 * S - 1 + px, iy = oy0 * S - 1 + py, iz = oz0 * S - 1 + pz;
+      const bool ok = b0 + ch < Cb && (unsigned)ix < (unsigned)Wi && (unsigned)iy < (unsigned)Hi && (unsigned)iz < (unsigned)Di;
+      lx[ch][p] = ok ? xin[((size_t)bi * Cb + b0 + ch) * vi + ((size_t)iz * Hi + iy) * Wi + ix] : 0.f;
+    }
+    __syncthreads();
+    const float* __restrict__ ga = lg[a];
+    const float* __restrict__ xb = lx[b];
+#pragma unroll 4
+    for (int p = 0; p < Cfg::NO; ++p) {
+      const int px = p % Cfg::OX, py = (p / Cfg::OX) % Cfg::OY, pz = p / (Cfg::OX * Cfg::OY);
+      const float gv = ga[p];
+      const int base = ((pz * S) * Cfg::IY + py * S) * Cfg::IX + px * S;
+#pragma unroll
+      for (int t = 0; t < 7; ++t) acc[t] = fmaf(gv, xb[base + toff[t]], acc[t]);
+    }
+  }
+  if (a0 + a < Ca && b0 + b < Cb) {
+#pragma unroll
+    for (int t = 0; t < 7; ++t) {
+      const int k = 7 * kg + t;
+      if (k < 27) atomicAdd(&dw[((size_t)(a0 + a) * Cb + b0 + b) * 27 + k], acc[t]);
+    }
+  }
+}
+
+inline dim3 ew_grid(size_t V, int C, int B) {
+  size_t chunks = (V + 256 * 8 - 1) / (256 * 8);
+  if (chunks > 512) chunks = 512;
+  if (chunks < 1) chunks = 1;
+  return dim3((unsigned)chunks, C, B);
+}
+
+}  // namespace
+
+extern "C" int cds_bn3d_stats_f32(const float* x, double* sums, int B, int C, long long V, void* stream) {
+  if (!x || !sums || B < 1 || C < 1 || V < 1) return CDS_EINVAL;
+  hipLaunchKernelGGL(bn3d_stats_kernel, ew_grid((size_t)V, C, B), dim3(256), 0, (hipStream_t)stream, x, sums, C, (size_t)V);
+  return cds_launch_status();
+}
+
+extern "C" int cds_bn3d_apply_f32(const float* y, const float* scale, const float* shift, const float* skip, float* out, int B,
+                                  int C, long long V, int relu, void* stream) {
+  if (!y || !scale || !shift || !out || B < 1 || C < 1 || V < 1) return CDS_EINVAL;
+  hipLaunchKernelGGL(bn3d_apply_kernel, ew_grid((size_t)V, C, B), dim3(256), 0, (hipStream_t)stream, y, scale, shift, skip, out, C,
+                     (size_t)V, relu);
+  return cds_launch_status();
+}
+
+extern "C" int cds_bn3d_bwd_reduce_f32(const float* dout, const float* y, const float* scale, const float* shift, double* sums,
+                                       int B, int C, long long V, int relu, void* stream) {
+  if (!dout || !y || !scale || !shift || !sums || B < 1 || C < 1 || V < 1) return CDS_EINVAL;
+  hipLaunchKernelGGL(bn3d_bwd_reduce_kernel, ew_grid((size_t)V, C, B), dim3(256), 0, (hipStream_t)stream, dout, y, scale, shift,
+                     sums, C, (size_t)V, relu);
+  return cds_launch_status();
+}
+
+extern "C" int cds_bn3d_bwd_apply_f32(const float* dout, const float* y, const float* scale, const float* shift, const float* k1,
+                                      const float* k0, float* dy, int B, int C, long long V, int relu, void* stream) {
+  if (!dout || !y || !scale || !shift || !k1 || !k0 || !dy || B < 1 || C < 1 || V < 1) return CDS_EINVAL;
+  hipLaunchKernelGGL(bn3d_bwd_apply_kernel, ew_grid((size_t)V, C, B), dim3(256), 0, (hipStream_t)stream, dout, y, scale, shift, k1,
+                     k0, dy, C, (size_t)V, relu);
+  return cds_launch_status();
+}
+
+// dw [Ca][Cb][27] (accumulated onto: zero it first).  g [B][Ca][Do][Ho][Wo], xin [B][Cb][Di][Hi][Wi], stride S in {1, 2},
+// pad 1: dw[a][b][(kz*3+ky)*3+kx] += sum_{b', o} g[a][o] * xin[b][S o - 1 + k].
+extern "C" int cds_conv3d_wgrad_f32(const float* g, const float* xin, float* dw, int B, int Ca, int Cb, int Do, int Ho, int Wo,
+                                    int Di, int Hi, int Wi, int stride, void* stream) {
+  if (!g || !xin || !dw || B < 1 || Ca < 1 || Cb < 1 || Do < 1 || Ho < 1 || Wo < 1 || (stride != 1 && stride != 2)) return CDS_EINVAL;
+  const int tx = cds_ceil_div(Wo, 8), ty = cds_ceil_div(Ho, 4), tz = cds_ceil_div(Do, 4);
+  const int ntiles = tx * ty * tz;
+  int per = cds_ceil_div(ntiles * B, 1024);      // ~1024 tile groups: a handful of atomics per output, enough workgroups
+  if (per < 1) per = 1;
+  const dim3 grid(cds_ceil_div(ntiles * B, per), cds_ceil_div(Ca, 8), cds_ceil_div(Cb, 8));
+  if (stride == 1)
+    hipLaunchKernelGGL(conv3d_wgrad_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, g, xin, dw, B, Ca, Cb, Do, Ho, Wo, Di, Hi, Wi,
+                       tx, ty, ntiles, per);
+  else
+    hipLaunchKernelGGL(conv3d_wgrad_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, g, xin, dw, B, Ca, Cb, Do, Ho, Wo, Di, Hi, Wi,
+                       tx, ty, ntiles, per);
+  return cds_launch_status();
+}

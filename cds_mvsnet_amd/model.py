@@ -241,7 +241,10 @@ class CostRegNet(_PackedHolder):
         The channels-last form runs the split-bf16 matrix-core kernels (fp32-class arithmetic, csrc/conv3d_sbf.hip), the
         planar form the exact-fp32 kernels (one fmaf chain per output)."""
         if self.training:
-            raise NotImplementedError("CostRegNet: training-mode BatchNorm is not built yet (SURVEY §8(f)-2)")
+            # training / autograd path (SURVEY §8(f)-2): HIP forward + backward kernels behind autograd Functions
+            from . import train_ops
+            v = volume.permute(3, 0, 1, 2) if channels_last else volume
+            return train_ops.cost_regularization(self, v.unsqueeze(0).contiguous())[0, 0]
         D, h, w = volume.shape[:3] if channels_last else volume.shape[1:]
         if D % 8 or h % 8 or w % 8:
             raise ValueError(f"CostRegNet needs D,h,w divisible by 8, got {(D, h, w)}")

@@ -1,0 +1,164 @@
+"""Autograd ops of the CostRegNet training path on the hand-written HIP kernels (reference:
+models/module.py:80-160 Conv3d / Deconv3d + BatchNorm3d(train) + ReLU, :305-315 the U-Net wiring).
+
+* :class:`Conv3dK3` — ``nn.Conv3d(k=3, p=1, stride 1|2, bias=False)`` / ``nn.ConvTranspose3d(k=3, s=2, p=1, op=1, bias=False)``:
+  forward and data gradient on the inference kernels (``cds_conv3d_k3_f32`` / ``cds_deconv3d_k3s2_f32``: the data gradient
+  of a stride-2 convolution is the transposed convolution with the same weights and vice versa, a stride-1 convolution's is
+  the convolution with flipped, transposed weights), weight gradient on ``cds_conv3d_wgrad_f32``.
+* :class:`BnRelu3d` — BatchNorm3d with batch statistics + ReLU + optional residual, fused forward (``cds_bn3d_stats_f32`` ->
+  ``cds_bn3d_apply_f32``) and closed-form backward (``cds_bn3d_bwd_reduce_f32`` -> ``cds_bn3d_bwd_apply_f32``); running
+  statistics are updated like ``nn.BatchNorm3d`` (momentum 0.1, unbiased variance).
+
+All kernels are fp32; under bf16 autocast the Functions cast their inputs up (the reference trains in fp32)."""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import _lib, ops
+from ._lib import check
+
+Tensor = torch.Tensor
+
+
+def _dev(t: Tensor) -> int:
+    return ops._dev(t, "tensor")
+
+
+def conv3d_wgrad(g: Tensor, xin: Tensor, stride: int) -> Tensor:
+    """dw[a][b][kz][ky][kx] = sum_{batch, o} g[:, a][o] * xin[:, b][stride * o - 1 + k]  ->  [Ca,Cb,3,3,3]."""
+    B, Ca, Do, Ho, Wo = g.shape
+    Bx, Cb, Di, Hi, Wi = xin.shape
+    if Bx != B:
+        raise ValueError("conv3d_wgrad: batch mismatch")
+    dw = torch.zeros((Ca, Cb, 3, 3, 3), dtype=torch.float32, device=g.device)
+    check(_lib.load().cds_conv3d_wgrad_f32(_dev(g), _dev(xin), dw.data_ptr(), B, Ca, Cb, Do, Ho, Wo, Di, Hi, Wi, stride,
+                                           ops._stream(g)), "cds_conv3d_wgrad_f32")
+    return dw
+
+
+class Conv3dK3(torch.autograd.Function):
+    """x [B,Cin,D,H,W], weight (Conv3d: [Cout,Cin,3,3,3]; ConvTranspose3d: [Cin,Cout,3,3,3]) -> y."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, x, weight, stride: int, transposed: bool):
+        x = x.contiguous()
+        ctx.save_for_backward(x, weight)
+        ctx.stride, ctx.transposed = stride, transposed
+        w = weight.detach()
+        if transposed:
+            cin, cout = w.shape[:2]
+            wpk = w.permute(0, 2, 3, 4, 1).reshape(cin, 27, cout).contiguous()
+            return torch.stack([ops.deconv3d_k3s2(x[b], wpk, None, relu=False) for b in range(x.shape[0])])
+        cout, cin = w.shape[:2]
+        wpk = w.permute(1, 2, 3, 4, 0).reshape(cin, 27, cout).contiguous()
+        return torch.stack([ops.conv3d_k3(x[b], wpk, None, stride=stride, relu=False) for b in range(x.shape[0])])
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy = dy.contiguous().float()
+        w = weight.detach().float()
+        B = x.shape[0]
+        dx = dw = None
+        if ctx.transposed:                                   # y = convT(x, w[Cin,Cout]):  dx = conv_s2(dy, w as [Cout'=Cin][Cin'=Cout])
+            cin, cout = w.shape[:2]
+            if ctx.needs_input_grad[0]:
+                wpk = w.permute(1, 2, 3, 4, 0).reshape(cout, 27, cin).contiguous()
+                dx = torch.stack([ops.conv3d_k3(dy[b], wpk, None, stride=2, relu=False) for b in range(B)])
+            if ctx.needs_input_grad[1]:
+                dw = conv3d_wgrad(x, dy, 2)                  # [Cin,Cout,3,3,3]
+        else:
+            cout, cin = w.shape[:2]
+            if ctx.needs_input_grad[0]:
+                if ctx.stride == 1:                          # dx = conv(dy, flipped taps, channels swapped)
+                    wpk = w.flip(2, 3, 4).permute(0, 2, 3, 4, 1).reshape(cout, 27, cin).contiguous()
+                    dx = torch.stack([ops.conv3d_k3(dy[b], wpk, None, relu=False) for b in range(B)])
+                else:                                        # dx = convT(dy, w)
+                    wpk = w.permute(0, 2, 3, 4, 1).reshape(cout, 27, cin).contiguous()
+                    dx = torch.stack([ops.deconv3d_k3s2(dy[b], wpk, None, relu=False) for b in range(B)])
+            if ctx.needs_input_grad[1]:
+                dw = conv3d_wgrad(dy, x, ctx.stride)         # [Cout,Cin,3,3,3]
+        return dx, dw, None, None
+
+
+class BnRelu3d(torch.autograd.Function):
+    """out = [skip +] relu?(batchnorm_train(y; gamma, beta)).  running_mean / running_var are updated in place."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, y, gamma, beta, skip, running_mean, running_var, momentum: float, eps: float, relu: bool):
+        y = y.contiguous()
+        B, C = y.shape[:2]
+        V = y[0, 0].numel()
+        n = B * V
+        lib = _lib.load()
+        sums = torch.zeros((C, 2), dtype=torch.float64, device=y.device)
+        check(lib.cds_bn3d_stats_f32(_dev(y), sums.data_ptr(), B, C, V, ops._stream(y)), "cds_bn3d_stats_f32")
+        mean = sums[:, 0] / n
+        var = (sums[:, 1] / n - mean * mean).clamp_min(0.0)                     # biased, like F.batch_norm in training
+        invstd = torch.rsqrt(var + eps)
+        scale = (gamma.detach().double() * invstd).float().contiguous()
+        shift = (beta.detach().double() - mean * gamma.detach().double() * invstd).float().contiguous()
+        out = torch.empty_like(y)
+        skip_c = skip.contiguous() if skip is not None else None
+        check(lib.cds_bn3d_apply_f32(_dev(y), _dev(scale), _dev(shift), _dev(skip_c) if skip_c is not None else None,
+                                     out.data_ptr(), B, C, V, 1 if relu else 0, ops._stream(y)), "cds_bn3d_apply_f32")
+        if running_mean is not None:
+            with torch.no_grad():
+                running_mean.mul_(1 - momentum).add_(mean.float(), alpha=momentum)
+                running_var.mul_(1 - momentum).add_((var * (n / max(n - 1, 1))).float(), alpha=momentum)
+        ctx.save_for_backward(y, scale, shift, mean, invstd, gamma)
+        ctx.relu, ctx.has_skip, ctx.n = relu, skip is not None, n
+        return out
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, dout):
+        y, scale, shift, mean, invstd, gamma = ctx.saved_tensors
+        dout = dout.contiguous().float()
+        B, C = y.shape[:2]
+        V = y[0, 0].numel()
+        n = ctx.n
+        lib = _lib.load()
+        sums = torch.zeros((C, 2), dtype=torch.float64, device=y.device)
+        check(lib.cds_bn3d_bwd_reduce_f32(_dev(dout), _dev(y), _dev(scale), _dev(shift), sums.data_ptr(), B, C, V,
+                                          1 if ctx.relu else 0, ops._stream(y)), "cds_bn3d_bwd_reduce_f32")
+        dbeta = sums[:, 0]
+        dgamma = invstd * (sums[:, 1] - mean * sums[:, 0])                      # sum g * xhat
+        sc = scale.double()
+        k1 = (-sc * dgamma * invstd / n).float().contiguous()
+        k0 = (-sc * dbeta / n + sc * dgamma * invstd * mean / n).float().contiguous()
+        dy = torch.empty_like(y)
+        check(lib.cds_bn3d_bwd_apply_f32(_dev(dout), _dev(y), _dev(scale), _dev(shift), _dev(k1), _dev(k0), dy.data_ptr(), B, C,
+                                         V, 1 if ctx.relu else 0, ops._stream(y)), "cds_bn3d_bwd_apply_f32")
+        return (dy, dgamma.float().to(gamma.dtype), dbeta.float().to(gamma.dtype), dout if ctx.has_skip else None,
+                None, None, None, None, None)
+
+
+def conv_bn_relu3d(unit, x: Tensor, skip: Optional[Tensor] = None) -> Tensor:
+    """One ConvBn3d holder (model.py) in its module mode: training -> batch statistics (and running-stat update),
+    eval -> running statistics; Conv3d / ConvTranspose3d + BatchNorm3d + ReLU (+ skip), all on the HIP kernels."""
+    y = Conv3dK3.apply(x, unit.conv.weight, unit.stride, unit.transposed)
+    bn = unit.bn
+    if bn.training:
+        if bn.num_batches_tracked is not None:
+            bn.num_batches_tracked += 1
+        return BnRelu3d.apply(y, bn.weight, bn.bias, skip, bn.running_mean, bn.running_var, bn.momentum, bn.eps, True)
+    out = torch.relu(torch.nn.functional.batch_norm(y, bn.running_mean, bn.running_var, bn.weight, bn.bias, False, 0.0, bn.eps))
+    return out if skip is None else skip + out
+
+
+def cost_regularization(cr, x: Tensor) -> Tensor:
+    """models/module.py:305-315 on the HIP training ops.  x [B,C,D,h,w] -> [B,1,D,h,w]."""
+    c0 = conv_bn_relu3d(cr.conv0, x)
+    c2 = conv_bn_relu3d(cr.conv2, conv_bn_relu3d(cr.conv1, c0))
+    c4 = conv_bn_relu3d(cr.conv4, conv_bn_relu3d(cr.conv3, c2))
+    y = conv_bn_relu3d(cr.conv6, conv_bn_relu3d(cr.conv5, c4))
+    y = conv_bn_relu3d(cr.conv7, y, skip=c4)
+    y = conv_bn_relu3d(cr.conv9, y, skip=c2)
+    y = conv_bn_relu3d(cr.conv11, y, skip=c0)
+    return Conv3dK3.apply(y, cr.prob.weight, 1, False)

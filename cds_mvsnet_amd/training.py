@@ -10,6 +10,7 @@ visibility CNN is detached, depth is detached between stages.
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -74,8 +75,16 @@ def _cbr3(unit, x: Tensor) -> Tensor:
     return F.relu(unit.bn(unit.conv(x)))
 
 
+USE_HIP_TRAIN = os.environ.get("CDS_TRAIN_HIP", "1") != "0"   # A/B knob: 0 = PyTorch-ROCm (MIOpen) autograd ops for CostRegNet
+
+
 def cost_regularization(cr, x: Tensor) -> Tensor:
-    """models/module.py:305-315 (BatchNorm in the module's current mode).  x [B,C,D,h,w] -> [B,1,D,h,w]."""
+    """models/module.py:305-315 (BatchNorm in the module's current mode).  x [B,C,D,h,w] -> [B,1,D,h,w].
+    Default: the hand-written HIP training ops (train_ops.py: convolution forward / data gradient / weight gradient and
+    fused BatchNorm(train) + ReLU + skip kernels); CDS_TRAIN_HIP=0 keeps the stock PyTorch-ROCm autograd ops."""
+    if USE_HIP_TRAIN and x.is_cuda:
+        from . import train_ops
+        return train_ops.cost_regularization(cr, x)
     c0 = _cbr3(cr.conv0, x)
     c2 = _cbr3(cr.conv2, _cbr3(cr.conv1, c0))
     c4 = _cbr3(cr.conv4, _cbr3(cr.conv3, c2))

@@ -337,6 +337,28 @@ int cds_deconv2d_k3s2_f32(const float* x, const float* weight, const float* bias
 int cds_refine_finish_f32(const float* d_norm, const float* res, float* out, int h, int w, float lo, float hi,
                           void* stream);
 
+/*
+ * Training kernels of the CostRegNet stack (models/module.py:80-160 with BatchNorm3d in training mode).
+ * Activations [B][C][D][H][W] fp32 (V = D*H*W), statistics fp64.  Forward convolutions and data gradients use
+ * cds_conv3d_k3_f32 / cds_deconv3d_k3s2_f32 (a convolution's data gradient is the transposed convolution and vice versa).
+ *   cds_bn3d_stats_f32:       sums[c] = (sum x, sum x^2) over batch and voxels, ADDED onto sums [C][2] (zero it first)
+ *   cds_bn3d_apply_f32:       out = relu?(y * scale[c] + shift[c]) (+ skip)            BatchNorm(train) + ReLU + U-Net skip
+ *   cds_bn3d_bwd_reduce_f32:  sums[c] += (sum g, sum g*y), g = dout * [relu ? y*scale+shift > 0 : 1]
+ *   cds_bn3d_bwd_apply_f32:   dy = g * scale[c] + y * k1[c] + k0[c]                    BatchNorm backward in closed form
+ *   cds_conv3d_wgrad_f32:     dw[a][b][tap] += sum_{batch, o} g[a][o] * xin[b][stride * o - 1 + tap]   (k3, pad 1)
+ *                             Conv3d: g = dy, xin = x -> dw [Cout][Cin][27]; ConvTranspose3d: g = x, xin = dy, stride 2 ->
+ *                             dw [Cin][Cout][27] (PyTorch's layouts).  dw is accumulated onto: zero it first.
+ */
+int cds_bn3d_stats_f32(const float* x, double* sums, int B, int C, long long V, void* stream);
+int cds_bn3d_apply_f32(const float* y, const float* scale, const float* shift, const float* skip, float* out, int B, int C,
+                       long long V, int relu, void* stream);
+int cds_bn3d_bwd_reduce_f32(const float* dout, const float* y, const float* scale, const float* shift, double* sums, int B,
+                            int C, long long V, int relu, void* stream);
+int cds_bn3d_bwd_apply_f32(const float* dout, const float* y, const float* scale, const float* shift, const float* k1,
+                           const float* k0, float* dy, int B, int C, long long V, int relu, void* stream);
+int cds_conv3d_wgrad_f32(const float* g, const float* xin, float* dw, int B, int Ca, int Cb, int Do, int Ho, int Wo, int Di,
+                         int Hi, int Wi, int stride, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -12,10 +12,10 @@ ref = torch.stack([f["ref"][0][0] for f in feats]).to(dev).contiguous()
 src = torch.stack([ops.chw_to_hwc(f["src"][0][0].to(dev).contiguous()) for f in feats])
 vis = torch.rand(N - 1, h, w, device=dev)
 mats = geometry.warp_matrices(cams[0])
-vol = torch.empty(C, D, h, w, device=dev); vs = torch.empty(h, w, device=dev)
+vol = torch.empty(D, h, w, C, device=dev); vs = torch.empty(h, w, device=dev)   # channels-last: what the model runs
 for _ in range(3):
-    ops.warp_aggregate(ref, src, vis, mats, hyp, volume=vol, vis_sum=vs)      # B_alg = 2 354 053 120 B
+    ops.warp_aggregate(ref, src, vis, mats, hyp, volume=vol, vis_sum=vs, channels_last=True)      # B_alg = 2 354 053 120 B
     ops.warp_entropy(ref, src, mats, hyp)
-    ops.volume_normalize_(vol, vs + 1.0)   # calibration: reads 2 013 265 920 B (+1.3 MB), writes 2 013 265 920 B
+    ops.volume_normalize_(vol.view(C, D, h, w), vs + 1.0)   # calibration (planar view of the same bytes): reads 2 013 265 920 B (+1.3 MB), writes 2 013 265 920 B
 torch.cuda.synchronize()
 print("ok")

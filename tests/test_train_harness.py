@@ -120,3 +120,43 @@ def test_train_step_fp32_and_bf16():
         losses[bf16] = (l0, d0)
     # bf16 autocast only changes the convolution stacks' arithmetic: same loss to a few per cent
     assert abs(losses[True][0] - losses[False][0]) < 0.05 * abs(losses[False][0])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("C,B,D,h,w", [(8, 2, 8, 16, 24), (16, 1, 8, 8, 16), (32, 2, 16, 16, 16)])
+def test_costreg_training_kernels_vs_torch_autograd(C, B, D, h, w):
+    """The HIP training path of CostRegNet (train_ops.py: conv forward / data gradient / weight gradient kernels, fused
+    BatchNorm(train) + ReLU + skip forward and backward) against the same network written with PyTorch's autograd ops in
+    float64 on the CPU: output, input gradient, every parameter gradient and the updated BatchNorm running statistics."""
+    import copy
+    from cds_mvsnet_amd import CostRegNet, seeded_init_, train_ops, training
+    dev = torch.device("cuda")
+    net = seeded_init_(CostRegNet(C, 8), 3).train()
+    ref = copy.deepcopy(net).double()
+    g = torch.Generator().manual_seed(C + B)
+    x = torch.randn(B, C, D, h, w, generator=g)
+    gout = torch.randn(B, 1, D, h, w, generator=g)
+    xr = x.double().requires_grad_(True)
+    old = training.USE_HIP_TRAIN
+    training.USE_HIP_TRAIN = False
+    try:
+        yr = training.cost_regularization(ref, xr)            # stock PyTorch ops, float64, CPU
+    finally:
+        training.USE_HIP_TRAIN = old
+    yr.backward(gout.double())
+    net = net.to(dev)
+    xg = x.to(dev).requires_grad_(True)
+    yg = train_ops.cost_regularization(net, xg)
+    yg.backward(gout.to(dev))
+    scale = yr.abs().max().item()
+    assert (yg.detach().cpu().double() - yr.detach()).abs().max().item() < 2e-5 * max(1.0, scale)
+    assert (xg.grad.cpu().double() - xr.grad).abs().max().item() < 1e-4 * max(1.0, xr.grad.abs().max().item())
+    for (n, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
+        assert p.grad is not None, n
+        err = (p.grad.cpu().double() - q.grad).abs().max().item()
+        assert err < 5e-4 * max(1e-3, q.grad.abs().max().item()), (n, err, q.grad.abs().max().item())   # fp32 vs float64
+    for (n, b_), (_, c_) in zip(net.named_buffers(), ref.named_buffers()):
+        if b_.dtype.is_floating_point:
+            assert (b_.cpu().double() - c_).abs().max().item() < 1e-5 * max(1.0, c_.abs().max().item()), n
+        else:
+            assert int(b_) == int(c_), n
