@@ -108,7 +108,7 @@ struct FCfg {
   // (MB = 4: the accumulators need the 256-register budget; stride 2 stages 8 input voxels per output: the extra waves go
   // to the producers instead)
   static constexpr int CW = (NT >= 2 && MB < 4 && S == 1) ? 8 : 4;
-  static constexpr int PW = PWO ? PWO : (S == 2 ? 8 : 4);            // producer waves
+  static constexpr int PW = PWO ? PWO : ((S == 2 && MB < 4) ? 8 : 4);   // producer waves (MB = 4 keeps the 256-register budget)
   static constexpr int NTW = NT / (CW / 4);                          // N-tiles per consumer wave
   static constexpr int NG = MB == 1 ? (NTW < 4 ? NTW : 4) : (NTW < 2 ? NTW : 2);   // N-tiles whose operands are in registers together
   static constexpr bool WDB = MB < 4;                                // weights double-buffered across K-steps (register budget)
@@ -212,6 +212,17 @@ __global__ __launch_bounds__((FCfg<S, MB, TX_, TZ_, PAIR, PWO>::THREADS)) void c
 
   f32x4 acc[MB][Cfg::NTW];
   const uint4* __restrict__ wl = wsp + lane;
+  BV wa[Cfg::WDB ? 2 : 1][MB][3];                      // weights of the current / next K-step (live across stages)
+  auto load_w_from = [&](const uint4* __restrict__ wrp, int buf, int t) {
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+      const uint4* p = wrp + (size_t)((t * MB + mb) * 3) * 64;
+      wa[buf][mb][0].u = p[0];
+      wa[buf][mb][1].u = p[64];
+      wa[buf][mb][2].u = p[128];
+    }
+  };
+  load_w_from(wl, 0, 0);                               // first K-step of the first stage: requested before the barrier
   __syncthreads();                                     // #0
   int st = 0;
   for (int tile = tile0; tile < tile1; ++tile) {
@@ -225,17 +236,8 @@ __global__ __launch_bounds__((FCfg<S, MB, TX_, TZ_, PAIR, PWO>::THREADS)) void c
       // from LDS; the weights of the next K-step from L1 / L2) are requested BEFORE the 6 NG MB MFMAs of step s.
       const uint4* __restrict__ wr = wl + (size_t)rd * Cfg::KSTEPS * MB * 3 * 64;
       constexpr int NGRP = Cfg::NTW / Cfg::NG, NS = Cfg::KSTEPS * NGRP;
-      BV wa[2][MB][3];
       BV bd[2][Cfg::NG][3];
-      auto load_w = [&](int buf, int t) {
-#pragma unroll
-        for (int mb = 0; mb < MB; ++mb) {
-          const uint4* p = wr + (size_t)((t * MB + mb) * 3) * 64;
-          wa[buf][mb][0].u = p[0];
-          wa[buf][mb][1].u = p[64];
-          wa[buf][mb][2].u = p[128];
-        }
-      };
+      auto load_w = [&](int buf, int t) { load_w_from(wr, buf, t); };
       auto load_b = [&](int buf, int t, int grp) {
         const unsigned char* bp = tbuf + b_base + toff[t];
 #pragma unroll
@@ -247,8 +249,7 @@ __global__ __launch_bounds__((FCfg<S, MB, TX_, TZ_, PAIR, PWO>::THREADS)) void c
           bd[buf][q][2].u = *reinterpret_cast<const uint4*>(b + 32);
         }
       };
-      load_w(0, 0);
-      load_b(0, 0, 0);
+      load_b(0, 0, 0);                                 // (the K-step-0 weights were requested before the stage barrier)
 #pragma unroll
       for (int ss = 0; ss < NS; ++ss) {
         const int t = ss / NGRP, grp = ss % NGRP;
@@ -300,6 +301,8 @@ __global__ __launch_bounds__((FCfg<S, MB, TX_, TZ_, PAIR, PWO>::THREADS)) void c
           }
         }
       }
+      // the first K-step's weights of the next stage travel during the epilogue stores and the barrier wait
+      if (st + 1 < nstages) load_w_from(wl + (size_t)(rd + 1 < rounds ? rd + 1 : 0) * Cfg::KSTEPS * MB * 3 * 64, 0, 0);
       __syncthreads();                                 // #(st + 1)
     }
   }
@@ -652,7 +655,6 @@ extern "C" int cds_conv3d_sbf_f32(const float* x, const void* weight_split, cons
     if (Cout != 8) return CDS_EINVAL;
     static const int pwo = []() { const char* e = getenv("CDS_SBF_PW"); return e ? atoi(e) : 0; }();   // A/B knob
     if (pwo == 8) return launch_fwd<1, 1, 32, 4, true, 8>(x, weight_split, bias, skip, out, Cin, Cout, D, H, W, act, st);
-    if (pwo == 2) return launch_fwd<1, 1, 32, 4, true, 2>(x, weight_split, bias, skip, out, Cin, Cout, D, H, W, act, st);
     return launch_fwd<1, 1, 32, 4, true>(x, weight_split, bias, skip, out, Cin, Cout, D, H, W, act, st);
   }
   if (stride == 1) {
