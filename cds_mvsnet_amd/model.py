@@ -492,7 +492,8 @@ class _FeatureRunner:
         Returns {'stageK': (fea_chw [n_chw,C,h,w] | None, fea_hwc [N-n_chw,h,w,C] | None, nc_sum [N,h,w], |nc| [N,h,w])}."""
         net = self.net
         if net.training:
-            raise NotImplementedError("FeatureNet: training mode is not built yet (SURVEY §8(f)-2)")
+            raise NotImplementedError("_FeatureRunner is the inference runner (InstanceNorm applied on load, packed weights); "
+                                      "in training mode CDSMVSNet.forward uses training.feature_net (autograd ops)")
         N = imgs.shape[0]
         if n_chw is None:
             n_chw = N
@@ -595,12 +596,19 @@ class StageNet(_PackedHolder):
         """Reference signature (model.py:16).  features: list over source views of
         {'ref': (fea [B,C,h,w], nc_sum [B,1,h,w], nc [B,1,h,w]), 'src': (fea, nc_sum, _)}; proj_matrices
         [B,N,2,4,4]; depth_values [B,D,h,w]."""
-        if self.training or gt_depth is not None:
-            raise NotImplementedError("StageNet: the training branch (model.py:52-56,63-69) is not built yet")
         if prob_volume_init is not None:
             raise NotImplementedError("prob_volume_init is dead code in the reference (never passed)")
         assert len(features) == proj_matrices.shape[1] - 1, "Different number of images and projection matrices"
         assert depth_values.shape[1] == num_depth, f"depth_values.shape[1]:{depth_values.shape[1]}  num_depth:{num_depth}"
+        if self.training or gt_depth is not None:
+            # training branch (model.py:52-56,63-69): autograd path on the HIP forward / backward kernels
+            from .training import stage_forward_train
+            dv = depth_values
+            if dv.dim() == 2:
+                h, w = features[0]["ref"][0].shape[-2:]
+                dv = dv.view(*dv.shape, 1, 1).expand(-1, -1, h, w)
+            with torch.cuda.device(dv.device):
+                return stage_forward_train(self, features, proj_matrices, dv, cost_regularization, stage_idx, gt_depth)
         with torch.cuda.device(depth_values.device):   # launches go to the current device's stream
             return self._forward(features, proj_matrices, depth_values, cost_regularization, stage_idx)
 

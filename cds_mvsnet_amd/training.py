@@ -101,6 +101,47 @@ def _visibility(seq, x: Tensor) -> Tensor:
     return torch.sigmoid(seq[3](x))
 
 
+def stage_forward_train(stage_net, features, cams: Tensor, depth_values: Tensor, cost_reg, stage_idx: int,
+                        gt_depth: Optional[Tensor] = None) -> Dict[str, Tensor]:
+    """``StageNet.forward`` in training mode (models/model.py:16-94 with ``self.training``), reference argument layout:
+    features = list over source views of {'ref': (fea [B,C,h,w], nc_sum [B,1,h,w], nc [B,1,h,w]), 'src': (fea, nc_sum, _)};
+    cams [B,N,2,4,4] (host); depth_values [B,D,h,w].  Returns depth / photometric_confidence / feat_distance / norm_curv.
+    K1 (detached, model.py:49), hypotheses and confidence run on the HIP kernels without gradient; K3 forward / backward and
+    CostRegNet forward / backward on the HIP kernels with gradient; the visibility CNN on PyTorch-ROCm autograd ops."""
+    V = len(features)
+    B = depth_values.shape[0]
+    cams = cams.detach().float().cpu()
+    mats = [geometry.warp_matrices(cams[b]) for b in range(B)]
+    hyps = [depth_values[b].detach().float().contiguous() for b in range(B)]
+    # .float(): under bf16 autocast the convolution stacks hand over bf16 activations; the HIP kernels are fp32
+    ref = [torch.stack([features[v]["ref"][0][b] for v in range(V)]).float() for b in range(B)]         # [V,C,h,w]
+    src = [torch.stack([features[v]["src"][0][b] for v in range(V)]).float().permute(0, 2, 3, 1).contiguous() for b in range(B)]
+    with torch.no_grad():                                               # K1, detached input (model.py:49)
+        ent = torch.stack([ops.warp_entropy(ref[b].detach().contiguous(), src[b].detach(), mats[b], hyps[b])
+                           for b in range(B)])                           # [B,V,h,w]
+    vis = [_visibility(stage_net.vis[stage_idx], torch.cat((ent[:, v:v + 1], features[v]["ref"][2].float()), dim=1))[:, 0]
+           for v in range(V)]                                            # V x [B,h,w]  (model.py:51)
+    vols, fds = [], []
+    for b in range(B):
+        vis_b = torch.stack([vis[v][b] for v in range(V)]).float()       # [V,h,w]
+        vol_sum = ops.WarpAggregate.apply(ref[b], src[b], vis_b, mats[b], hyps[b])       # K3 fwd / bwd kernels
+        denom = (vis_b.sum(dim=0) + 1e-6).unsqueeze(0)
+        vols.append(vol_sum / denom.unsqueeze(0))                        # model.py:74
+        fd = vol_sum.sum(dim=0) / denom                                  # sum_v sim_v * vis_v / vis_sum (model.py:56,75)
+        if gt_depth is not None:                                         # model.py:63-69,76-78
+            gt_sum = ops.WarpAggregate.apply(ref[b], src[b], vis_b, mats[b], gt_depth[b:b + 1].float().contiguous())
+            fd = torch.cat((fd, gt_sum.sum(dim=0) / denom), dim=0)
+        fds.append(fd)
+    nc_mean = sum((features[v]["ref"][1] + features[v]["src"][1]) / 2 for v in range(V)) / V       # [B,1,h,w]
+    hyp_b = torch.stack(hyps)
+    prob_pre = cost_regularization(cost_reg, torch.stack(vols)).squeeze(1).float()
+    prob = F.softmax(prob_pre, dim=1)
+    depth = torch.sum(prob * hyp_b, dim=1)
+    with torch.no_grad():
+        conf = torch.stack([ops.softargmin_conf(prob_pre[b].detach().contiguous(), hyp_b[b])[1] for b in range(B)])
+    return {"depth": depth, "photometric_confidence": conf, "feat_distance": torch.stack(fds), "norm_curv": nc_mean}
+
+
 def forward_train(model, imgs: Tensor, proj_matrices: Dict[str, Tensor], depth_values: Tensor,
                   gt_depths: Optional[Dict[str, Tensor]], temperature: float):
     """CDSMVSNet.forward in training mode.  Same inputs / outputs as the reference (adds 'feat_distance' and
@@ -138,34 +179,11 @@ def forward_train(model, imgs: Tensor, proj_matrices: Dict[str, Tensor], depth_v
             else:
                 hyps.append(ops.depth_hypotheses(depth[b].detach().contiguous(), D, H, W, scale,
                                                  float(model.depth_interals_ratio[s] * dint_all[b]), dmin, dmax))
-        mats = [geometry.warp_matrices(cams[name][b]) for b in range(B)]
-        # .float(): under bf16 autocast the convolution stacks hand over bf16 activations; the HIP kernels are fp32
-        ref = [torch.stack([feats[v][0][name][0][b] for v in range(V)]).float() for b in range(B)]         # [V,C,h,w]
-        src = [torch.stack([feats[v][1][name][0][b] for v in range(V)]).float().permute(0, 2, 3, 1).contiguous() for b in range(B)]
-        with torch.no_grad():                                               # K1, detached input (model.py:49)
-            ent = torch.stack([ops.warp_entropy(ref[b].detach().contiguous(), src[b].detach(), mats[b], hyps[b])
-                               for b in range(B)])                           # [B,V,h,w]
-        vis = [_visibility(model.stage_net.vis[s], torch.cat((ent[:, v:v + 1], feats[v][0][name][2].float()), dim=1))[:, 0]
-               for v in range(V)]                                            # V x [B,h,w]  (model.py:51)
-        vols, fds = [], []
-        for b in range(B):
-            vis_b = torch.stack([vis[v][b] for v in range(V)]).float()       # [V,h,w]
-            vol_sum = ops.WarpAggregate.apply(ref[b], src[b], vis_b, mats[b], hyps[b])       # K3 fwd / bwd kernels
-            denom = (vis_b.sum(dim=0) + 1e-6).unsqueeze(0)
-            vols.append(vol_sum / denom.unsqueeze(0))                        # model.py:74
-            fd = vol_sum.sum(dim=0) / denom                                  # sum_v sim_v * vis_v / vis_sum (model.py:56,75)
-            if gt_depths is not None:                                        # model.py:63-69,76-78
-                gt_sum = ops.WarpAggregate.apply(ref[b], src[b], vis_b, mats[b], gt_depths[name][b:b + 1].contiguous())
-                fd = torch.cat((fd, gt_sum.sum(dim=0) / denom), dim=0)
-            fds.append(fd)
-        nc_mean = sum((feats[v][0][name][1] + feats[v][1][name][1]) / 2 for v in range(V)) / V       # [B,1,h,w]
+        features = [{"ref": feats[v][0][name], "src": feats[v][1][name]} for v in range(V)]
         hyp_b = torch.stack(hyps)
-        prob_pre = cost_regularization(model.cost_regularization[s], torch.stack(vols)).squeeze(1).float()
-        prob = F.softmax(prob_pre, dim=1)
-        depth = torch.sum(prob * hyp_b, dim=1)
-        with torch.no_grad():
-            conf = torch.stack([ops.softargmin_conf(prob_pre[b].detach().contiguous(), hyp_b[b])[1] for b in range(B)])
-        st = {"depth": depth, "photometric_confidence": conf, "feat_distance": torch.stack(fds), "norm_curv": nc_mean}
+        st = stage_forward_train(model.stage_net, features, cams[name], hyp_b, model.cost_regularization[s], s,
+                                 gt_depth=gt_depths[name] if gt_depths is not None else None)
+        depth = st["depth"]
         if gt_depths is not None:                                            # model.py:202-207
             gt_s = gt_depths[name].unsqueeze(1)
             di_stage = dint_all.to(dev).view(B, 1, 1, 1) * float(scale)

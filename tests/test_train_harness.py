@@ -160,3 +160,29 @@ def test_costreg_training_kernels_vs_torch_autograd(C, B, D, h, w):
             assert (b_.cpu().double() - c_).abs().max().item() < 1e-5 * max(1.0, c_.abs().max().item()), n
         else:
             assert int(b_) == int(c_), n
+
+
+@pytest.mark.gpu
+def test_stage_net_training_mode_reference_signature():
+    """StageNet.forward in training mode with the reference's call signature (models/model.py:16, gt_depth given):
+    the feat_distance head (model.py:56,63-69), differentiable depth, gradients reaching the features, the visibility CNN
+    and CostRegNet through the HIP backward kernels."""
+    from cds_mvsnet_amd import CDSMVSNet, seeded_init_, synth
+    dev = torch.device("cuda")
+    model = seeded_init_(CDSMVSNet(refine=False, depth_interals_ratio=(4.0, 1.5, 0.75)), 5).to(dev).train()
+    V, C, h, w, D, stage = 2, 8, 32, 48, 8, 2
+    feats = synth.make_pair_features(V, C, h, w, seed=3, sharp=True)
+    dfe = [{k: tuple(t.to(dev).requires_grad_(i == 0) if t is not None else None for i, t in enumerate(f[k])) for k in ("ref", "src")}
+           for f in feats]
+    cams = synth.stage_cameras(V + 1, h, w, seed=4)
+    hyp = synth.make_hypotheses(D, h, w, seed=5).to(dev)
+    gt = (hyp[:, D // 2] + 0.3).contiguous()
+    out = model.stage_net(dfe, cams, depth_values=hyp, num_depth=D, cost_regularization=model.cost_regularization[stage],
+                          stage_idx=stage, gt_depth=gt)
+    assert set(out) == {"depth", "photometric_confidence", "feat_distance", "norm_curv"}
+    assert out["feat_distance"].shape == (1, D + 1, h, w) and out["depth"].shape == (1, h, w)
+    (out["depth"].mean() + out["feat_distance"].mean()).backward()
+    assert all(f["ref"][0].grad is not None and torch.isfinite(f["ref"][0].grad).all() for f in dfe)
+    assert all(f["src"][0].grad is not None and f["src"][0].grad.abs().sum() > 0 for f in dfe)
+    for n, p in list(model.cost_regularization[stage].named_parameters()) + list(model.stage_net.vis[stage].named_parameters()):
+        assert p.grad is not None and torch.isfinite(p.grad).all(), n
