@@ -156,8 +156,10 @@ __global__ __launch_bounds__((FCfg<S, MB, TX_, TZ_, PAIR, PWO>::THREADS)) void c
       s_rel[h] = (p < NP && c < Cfg::IX) ? ((rz << 20) | (ry << 10) | c) : -1;
       s_dst[h] = (row * Cfg::IXP + q) * POSB;
     }
-    float4 va[PPT], vb[PPT];
-    auto issue = [&](int st) {
+    // Two register sets: the loads of stage st + 2 are in flight while stage st + 1 is split and written, so a stage's loads
+    // have two stage times to arrive (the stride-2 and deep layers have stages of a few microseconds, about one HBM latency).
+    float4 va[2][PPT], vb[2][PPT];
+    auto issue = [&](int st, int set) {
       const int tile = tile0 + st / rounds, rd = st % rounds;
       const int tx_i = tile % tiles_x, ty_i = (tile / tiles_x) % tiles_y, tz_i = tile / (tiles_x * tiles_y);
       const int gx0 = tx_i * Cfg::TX * S - 1, gy0 = ty_i * Cfg::TY * S - 1, gz0 = tz_i * Cfg::TZ * S - 1;
@@ -166,28 +168,38 @@ __global__ __launch_bounds__((FCfg<S, MB, TX_, TZ_, PAIR, PWO>::THREADS)) void c
         const int gz = gz0 + (s_rel[h] >> 20), gy = gy0 + ((s_rel[h] >> 10) & 1023), gx = gx0 + (s_rel[h] & 1023);
         const bool ok = s_rel[h] >= 0 && (unsigned)gz < (unsigned)D && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
         const float* __restrict__ src = x + ((size_t)((size_t)gz * H + gy) * W + gx) * Cin + rd * 8;
-        va[h] = ok ? *reinterpret_cast<const float4*>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
-        vb[h] = ok ? *reinterpret_cast<const float4*>(src + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        va[set][h] = ok ? *reinterpret_cast<const float4*>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
+        vb[set][h] = ok ? *reinterpret_cast<const float4*>(src + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
       }
     };
-    auto deposit = [&](int buf) {
+    auto deposit = [&](int buf, int set) {
       unsigned char* base = lds + buf * Cfg::LDSB;
 #pragma unroll
       for (int h = 0; h < PPT; ++h)
-        if (s_rel[h] >= 0) split_store8(base + s_dst[h], va[h], vb[h]);
+        if (s_rel[h] >= 0) split_store8(base + s_dst[h], va[set][h], vb[set][h]);
     };
-    issue(0);
-    deposit(0);
-    if (nstages > 1) issue(1);
+    // stage s travels in register set s & 1 and lands in LDS buffer s & 1
+    issue(0, 0);
+    if (nstages > 1) issue(1, 1);
+    deposit(0, 0);
+    if (nstages > 2) issue(2, 0);
     __syncthreads();                                   // #0: buffer 0 holds stage 0
-    for (int st = 0; st < nstages; ++st) {
+    for (int st = 0; st < nstages; st += 2) {
 #ifndef CDS_EXP_SBF_NOPRODUCE
       if (st + 1 < nstages) {
-        deposit((st + 1) & 1);                         // its loads were issued one stage ago
-        if (st + 2 < nstages) issue(st + 2);
+        deposit(1, 1);                                 // stage st + 1 (odd): loads issued two stages ago
+        if (st + 3 < nstages) issue(st + 3, 1);
       }
 #endif
       __syncthreads();                                 // #(st + 1): stage st consumed, stage st + 1 staged
+      if (st + 1 >= nstages) break;
+#ifndef CDS_EXP_SBF_NOPRODUCE
+      if (st + 2 < nstages) {
+        deposit(0, 0);                                 // stage st + 2 (even)
+        if (st + 4 < nstages) issue(st + 4, 0);
+      }
+#endif
+      __syncthreads();                                 // #(st + 2)
     }
     return;
   }
