@@ -482,11 +482,18 @@ def main():
     extra = {}
     if "costreg" in kern and kind == "stage":
         fl = costreg_flops(h, w, D, C)
-        extra["roofline_costreg"] = {"bound": "fp32", "achieved": fl / (kern["costreg"] * 1e-3) / 1e12,
-                                     "peak": FP32_PEAK / 1e12, "unit": "TFLOP/s",
-                                     "frac": fl / (kern["costreg"] * 1e-3) / FP32_PEAK, "kernel_ms": kern["costreg"],
-                                     "flops": fl, "min_activation_bytes": costreg_min_bytes(h, w, D, C),
-                                     "activation_gbs": costreg_min_bytes(h, w, D, C) / (kern["costreg"] * 1e-3) / 1e9}
+        import cds_mvsnet_amd.model as cm
+        tf = fl / (kern["costreg"] * 1e-3) / 1e12
+        act = costreg_min_bytes(h, w, D, C)
+        extra["roofline_costreg"] = {
+            # split-bf16: 6 bf16 MFMAs per fp32-equivalent product set -> 2.5 PFLOP/s / 6; exact path: the fp32 pipes
+            "bound": "mfma bf16 / 6 (split-bf16) and hbm" if cm.USE_SPLIT_BF16 else "fp32",
+            "achieved": tf, "unit": "TFLOP/s (fp32-equivalent algorithmic flops)",
+            "peak": (2500.0 / 6.0) if cm.USE_SPLIT_BF16 else FP32_PEAK / 1e12,
+            "frac": tf / ((2500.0 / 6.0) if cm.USE_SPLIT_BF16 else FP32_PEAK / 1e12),
+            "frac_of_fp32_peak": tf / (FP32_PEAK / 1e12), "kernel_ms": kern["costreg"], "flops": fl,
+            "min_activation_bytes": act, "activation_gbs": act / (kern["costreg"] * 1e-3) / 1e9,
+            "frac_of_hbm_peak": act / (kern["costreg"] * 1e-3) / HBM_PEAK}
     extra["kernel_ms"] = {k: round(v, 4) for k, v in sorted(kern.items())}
 
     others = None
