@@ -178,9 +178,9 @@ def warp_aggregate_bwd(ref_chw: Tensor, src_hwc: Tensor, vis_w: Tensor, mats: Te
         raise ValueError(f"warp_aggregate_bwd: grad_volume must be {(C, D, h, w)}, got {tuple(grad_volume.shape)}")
     if tuple(src_hwc.shape) != (V, h, w, C) or tuple(mats.shape) != (V, 12) or tuple(vis_w.shape) != (V, h, w):
         raise ValueError("warp_aggregate_bwd: inconsistent shapes")
-    g_ref = torch.empty_like(ref_chw)
+    g_ref = torch.zeros_like(ref_chw)      # the kernel accumulates partial sums (channel groups x depth segments) with atomics
     g_src = torch.zeros_like(src_hwc)
-    g_vis = torch.empty_like(vis_w)
+    g_vis = torch.zeros_like(vis_w)
     lib = _lib.load()
     # every gradient is per view: groups of MAX_VIEWS views are independent launches (like the forward's chunks)
     for v0 in range(0, V, MAX_VIEWS):

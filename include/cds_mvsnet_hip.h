@@ -87,9 +87,9 @@ int cds_warp_aggregate_f32(const float* ref_chw, const float* src_hwc, const flo
 /*
  * Backward of the un-normalised K3 (training step).  With volume = sum_v vis_v * ref_v (x) warp(src_v):
  *   grad_volume  [C][D][h][w]   incoming gradient
- *   grad_ref     [V][C][h][w]   written
- *   grad_src_hwc [V][h][w][C]   ACCUMULATED with atomics (bilinear scatter): the caller zeroes it first
- *   grad_vis     [V][h][w]      written
+ *   grad_ref     [V][C][h][w]   ACCUMULATED with atomics (partial sums per depth segment): the caller zeroes it first
+ *   grad_src_hwc [V][h][w][C]   ACCUMULATED with atomics (bilinear scatter; runs of planes in one texel cell are merged first)
+ *   grad_vis     [V][h][w]      ACCUMULATED with atomics (partial sums per channel group and depth segment)
  * The sampling grid has no gradient (built under no_grad, warping.py:79): nothing flows to hypotheses / cameras.
  */
 int cds_warp_aggregate_bwd_f32(const float* ref_chw, const float* src_hwc, const float* vis_w,

@@ -100,3 +100,52 @@ def test_synthetic_inputs_are_deterministic():
     f1 = synth.make_pair_features(2, 8, 16, 24, seed=1)
     f2 = synth.make_pair_features(2, 8, 16, 24, seed=1)
     assert torch.equal(f1[1]["src"][0], f2[1]["src"][0]) and f1[0]["ref"][0].abs().max() < 1
+
+
+def _unsplit(packed):
+    """int16 [..., 3, 64, 8] split-bf16 operand -> float [..., 64, 8] (hi + mid + lo)."""
+    return packed.view(torch.bfloat16).float().sum(dim=-3)
+
+
+def test_split_bf16_packers_reconstruct_the_weights_exactly():
+    """Host side of the split-bf16 kernels (ops.split_pack_*): the three bf16 terms sum back to the fp32 weight bit for bit,
+    and every (round, K-step, block, lane group, row) slot holds the tap / channel the kernels' address tables expect."""
+    from cds_mvsnet_amd import ops
+    g = torch.Generator().manual_seed(0)
+    # 3D convolution: lane l = 16 g + i of K-step t multiplies cout 16 mb + i by tap 4 t + g, channels 8 rd + j
+    w = torch.randn(24, 16, 3, 3, 3, generator=g)
+    a = _unsplit(ops.split_pack_conv3d(w))                        # [rd][t][mb][64][8]
+    assert a.shape == (2, 7, 2, 64, 8)
+    for rd, t, mb, gg, i in ((0, 0, 0, 0, 0), (1, 3, 1, 2, 5), (1, 6, 0, 2, 15), (0, 5, 1, 3, 7)):
+        tap, co = 4 * t + gg, 16 * mb + i
+        want = w[co, 8 * rd:8 * rd + 8].reshape(8, 27)[:, tap] if (tap < 27 and co < 24) else torch.zeros(8)
+        assert torch.equal(a[rd, t, mb, 16 * gg + i], want), (rd, t, mb, gg, i)
+    assert a[:, 6, :, 48:].abs().max() == 0                       # tap 27 is the zero pad
+    assert a[:, :, 1, :, :].reshape(2, 7, 4, 16, 8)[:, :, :, 8:].abs().max() == 0     # couts 24..31 of block 1
+    # voxel-pair packing (Cout = 8): row i = 8 p + co, K-step = (kz, ky), lane group g -> x' = (0, 2, 1, 3)[g]
+    w8 = torch.randn(8, 8, 3, 3, 3, generator=g)
+    p = _unsplit(ops.split_pack_conv3d_pair(w8))                  # [1][9][1][64][8]
+    for kz, ky, gg, par, co in ((0, 0, 0, 0, 3), (1, 2, 1, 1, 7), (2, 1, 3, 0, 0), (2, 2, 2, 1, 4), (0, 1, 3, 1, 2)):
+        xp = (0, 2, 1, 3)[gg]
+        kx = xp - par
+        want = w8[co, :, kz, ky, kx] if 0 <= kx <= 2 else torch.zeros(8)
+        assert torch.equal(p[0, kz * 3 + ky, 0, 16 * gg + 8 * par + co], want), (kz, ky, gg, par, co)
+    # transposed convolution, Cout = 16: class (pz, py, px) K-steps, parity 1 axes take (k=2, d=0) then (k=0, d=1)
+    wt = torch.randn(8, 16, 3, 3, 3, generator=g)
+    d = _unsplit(ops.split_pack_deconv3d(wt))                     # [1][9][1][64][8]
+    assert d.shape == (1, 9, 1, 64, 8)
+    assert torch.equal(d[0, 0, 0, 5], wt[:, 5, 1, 1, 1])          # class (0,0,0): the single tap (1,1,1)
+    assert d[0, 0, 0, 16:].abs().max() == 0                       # its three padded slots
+    assert torch.equal(d[0, 7, 0, 16 * 3 + 2], wt[:, 2, 2, 0, 0])  # class (1,1,1), slot 3 = (iz, iy, ix) = (0, 1, 1) -> k = (2, 0, 0)
+    assert torch.equal(d[0, 8, 0, 16 * 0 + 9], wt[:, 9, 0, 2, 2])  # second K-step of class 7, slot 4 = (1, 0, 0) -> k = (0, 2, 2)
+    # DynamicConv branches: K-steps of branch b start at ks0_b, tap = ky * k + kx
+    ws = [torch.randn(11, 8, k, k, generator=g) for k in (3, 5, 7)]
+    q = _unsplit(ops.split_pack_dynconv(ws))                      # [1][3 + 7 + 13][1][64][8]
+    assert q.shape == (1, 23, 1, 64, 8)
+    assert torch.equal(q[0, 3 + 2, 0, 16 * 1 + 4], ws[1][4, :, 1, 4])       # 5x5: tap 4*2+1 = 9 -> (ky, kx) = (1, 4)
+    assert torch.equal(q[0, 10 + 12, 0, 16 * 0 + 10], ws[2][10, :, 6, 6])   # 7x7: tap 48 -> (6, 6)
+    assert q[0, 10 + 12, 0, 16:].abs().max() == 0                           # taps 49..51 padded
+    # exactness of the three-term split on awkward values
+    x = torch.tensor([1.0, 1 + 2 ** -23, 3.1415927, -1e-30, 6.5e37, 2 ** -120, 0.0]).reshape(1, 1, 7).expand(1, 64, 7)
+    x = torch.cat((x, torch.zeros(1, 64, 1)), dim=-1).contiguous()
+    assert torch.equal(_unsplit(ops._split3(x)), x)
