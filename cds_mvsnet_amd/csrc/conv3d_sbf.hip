@@ -92,7 +92,7 @@ constexpr int POSB = 48;   // bytes per LDS position
 // halves of the matrix tile carry real outputs (with rows = 16 couts, half of every MFMA would multiply zero padding).  The
 // K window is 3 x 3 x 4 taps (x' = 0..3 relative to the pair; weight row (p, co) is w[x' - p] or 0): 9 K-steps per 32 voxels
 // instead of 14, and as many fewer LDS operand reads.  The x parities of the staged tile are de-interleaved as for stride 2.
-template <int S, int MB, int TX_, int TZ_, bool PAIR = false, int PWO = 0>
+template <int S, int MB, int TX_, int TZ_, bool PAIR = false, bool WRES_ = false>
 struct FCfg {
   static constexpr int TX = TX_, TY = 4, TZ = TZ_;
   static constexpr bool DEINT = S == 2 || PAIR;
@@ -107,10 +107,15 @@ struct FCfg {
   // consumer waves: two per SIMD when a y row has >= 2 N-tiles to split between them (one waits for LDS, the other issues)
   // (MB = 4: the accumulators need the 256-register budget; stride 2 stages 8 input voxels per output: the extra waves go
   // to the producers instead)
-  static constexpr int CW = (NT >= 2 && MB < 4 && S == 1) ? 8 : 4;
-  static constexpr int PW = PWO ? PWO : ((S == 2 && MB < 4) ? 8 : 4);   // producer waves (MB = 4 keeps the 256-register budget)
+  // (PAIR: the 27 weight vectors of the layer stay in registers (WRES) -> one consumer wave per SIMD with the 256-register budget)
+  static constexpr bool WRES = WRES_;                                // Cin == 8: weights do not change between stages
+#ifndef CDS_SBF_V
+#define CDS_SBF_V 1
+#endif
+  static constexpr int CW = (WRES || MB == 2 || (CDS_SBF_V == 2 && MB == 1 && S == 1)) ? 4 : ((NT >= 2 && MB < 4 && S == 1) ? 8 : 4);
+  static constexpr int PW = (S == 2 && MB < 2) ? 8 : 4;           // producer waves (MB >= 2 keeps the 256-register budget)
   static constexpr int NTW = NT / (CW / 4);                          // N-tiles per consumer wave
-  static constexpr int NG = MB == 1 ? (NTW < 4 ? NTW : 4) : (NTW < 2 ? NTW : 2);   // N-tiles whose operands are in registers together
+  static constexpr int NG = (MB == 1 && (CW == 4 || CDS_SBF_V != 1)) ? (NTW < 4 ? NTW : 4) : (NTW < 2 ? NTW : 2);   // N-tiles whose operands are in registers together
   static constexpr bool WDB = MB < 4;                                // weights double-buffered across K-steps (register budget)
   static constexpr int THREADS = (CW + PW) * 64;
 };
@@ -120,13 +125,13 @@ struct FCfg {
 // loads -> exact bf16 split in registers -> LDS writes), double-buffered LDS tile, ONE workgroup barrier per stage.  The
 // producers run a stage ahead in LDS and another one ahead in registers, so the matrix pipe never waits for staging: with
 // the staging in the same waves as the MFMAs, the two workgroups of a CU fell into lock-step and the pipe idled half the time.
-template <int S, int MB, int TX_, int TZ_, bool PAIR = false, int PWO = 0>
-__global__ __launch_bounds__((FCfg<S, MB, TX_, TZ_, PAIR, PWO>::THREADS)) void conv3d_sbf_kernel(const float* __restrict__ x, const uint4* __restrict__ wsp,
+template <int S, int MB, int TX_, int TZ_, bool PAIR = false, bool WRES_ = false>
+__global__ __launch_bounds__((FCfg<S, MB, TX_, TZ_, PAIR, WRES_>::THREADS)) void conv3d_sbf_kernel(const float* __restrict__ x, const uint4* __restrict__ wsp,
                                                             const float* __restrict__ bias, const float* __restrict__ skip,
                                                             float* __restrict__ out, int Cin, int Cout, int D, int H, int W,
                                                             int Do, int Ho, int Wo, int act, int tiles_x, int tiles_y,
                                                             int ntiles, int tpw) {
-  using Cfg = FCfg<S, MB, TX_, TZ_, PAIR, PWO>;
+  using Cfg = FCfg<S, MB, TX_, TZ_, PAIR, WRES_>;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -187,16 +192,25 @@ __global__ __launch_bounds__((FCfg<S, MB, TX_, TZ_, PAIR, PWO>::THREADS)) void c
     for (int st = 0; st < nstages; st += 2) {
 #ifndef CDS_EXP_SBF_NOPRODUCE
       if (st + 1 < nstages) {
+#ifdef CDS_EXP_SBF_NODEPOSIT
+        if (st < 1)
+#endif
         deposit(1, 1);                                 // stage st + 1 (odd): loads issued two stages ago
+#ifndef CDS_EXP_SBF_NOISSUE
         if (st + 3 < nstages) issue(st + 3, 1);
+#endif
       }
 #endif
       __syncthreads();                                 // #(st + 1): stage st consumed, stage st + 1 staged
       if (st + 1 >= nstages) break;
 #ifndef CDS_EXP_SBF_NOPRODUCE
       if (st + 2 < nstages) {
+#ifndef CDS_EXP_SBF_NODEPOSIT
         deposit(0, 0);                                 // stage st + 2 (even)
+#endif
+#ifndef CDS_EXP_SBF_NOISSUE
         if (st + 4 < nstages) issue(st + 4, 0);
+#endif
       }
 #endif
       __syncthreads();                                 // #(st + 2)
@@ -234,7 +248,40 @@ __global__ __launch_bounds__((FCfg<S, MB, TX_, TZ_, PAIR, PWO>::THREADS)) void c
       wa[buf][mb][2].u = p[128];
     }
   };
-  load_w_from(wl, 0, 0);                               // first K-step of the first stage: requested before the barrier
+  // WDB (streamed weights, double-buffered): K-step 0 of a stage multiplies from its own registers w0, requested during the
+  // stage BEFORE (at its K-step 1) together with K-step 1 (-> wa[1], at its last K-step): both are issued ahead of that
+  // stage's epilogue stores, so the first MFMAs of a stage never wait for those stores to be acknowledged (vmcnt is in-order).
+  BV w0[Cfg::WDB && !Cfg::WRES ? MB : 1][3];
+  auto load_w0 = [&](const uint4* __restrict__ wrp) {
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+      w0[mb][0].u = wrp[(size_t)(mb * 3) * 64];
+      w0[mb][1].u = wrp[(size_t)(mb * 3 + 1) * 64];
+      w0[mb][2].u = wrp[(size_t)(mb * 3 + 2) * 64];
+    }
+  };
+  // WRES: every K-step's weights are loaded ONCE.  The consumer waves then issue no vector-memory loads in the stage loop,
+  // so nothing ever waits (s_waitcnt vmcnt counts loads and stores in order) for the epilogue stores of the stage before.
+  BV wres[Cfg::WRES ? Cfg::KSTEPS : 1][3];
+  if (Cfg::WRES) {
+#pragma unroll
+    for (int t = 0; t < Cfg::KSTEPS; ++t) {
+      wres[t][0].u = wl[(size_t)(t * 3) * 64];
+      wres[t][1].u = wl[(size_t)(t * 3 + 1) * 64];
+      wres[t][2].u = wl[(size_t)(t * 3 + 2) * 64];
+    }
+  } else if (Cfg::WDB) {
+    load_w0(wl);                                       // first stage: K-steps 0 and 1 requested before the barrier
+    load_w_from(wl, 1, 1);
+  } else {
+    load_w_from(wl, 0, 0);
+  }
+  float4 bvr[MB];                                      // bias of this lane's four couts per 16-cout block
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
+    const int co = PAIR ? 4 * (g & 1) : mb * 16 + 4 * g;
+    bvr[mb] = (bias && co < Cout) ? *reinterpret_cast<const float4*>(bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
   __syncthreads();                                     // #0
   int st = 0;
   for (int tile = tile0; tile < tile1; ++tile) {
@@ -250,6 +297,7 @@ __global__ __launch_bounds__((FCfg<S, MB, TX_, TZ_, PAIR, PWO>::THREADS)) void c
       constexpr int NGRP = Cfg::NTW / Cfg::NG, NS = Cfg::KSTEPS * NGRP;
       BV bd[2][Cfg::NG][3];
       auto load_w = [&](int buf, int t) { load_w_from(wr, buf, t); };
+      const uint4* __restrict__ wnext = wl + (size_t)(rd + 1 < rounds ? rd + 1 : 0) * Cfg::KSTEPS * MB * 3 * 64;
       auto load_b = [&](int buf, int t, int grp) {
         const unsigned char* bp = tbuf + b_base + toff[t];
 #pragma unroll
@@ -267,8 +315,14 @@ __global__ __launch_bounds__((FCfg<S, MB, TX_, TZ_, PAIR, PWO>::THREADS)) void c
         const int t = ss / NGRP, grp = ss % NGRP;
         const int wb = Cfg::WDB ? (t & 1) : 0, db = ss & 1;
         if (ss + 1 < NS) load_b(db ^ 1, (ss + 1) / NGRP, (ss + 1) % NGRP);
-        if (Cfg::WDB) {
-          if (grp == 0 && t + 1 < Cfg::KSTEPS) load_w(wb ^ 1, t + 1);
+        if (Cfg::WRES) {
+        } else if (Cfg::WDB) {
+          if (grp == 0) {
+            if (t == 0) load_w(0, 2);                                   // K-step 2 -> wa[0] (K-step 0 multiplies from w0)
+            else if (t >= 2 && t + 1 < Cfg::KSTEPS) load_w(wb ^ 1, t + 1);
+            if (t == 1) load_w0(wnext);                                 // next stage: K-step 0 -> w0 (free since K-step 0)
+            if (t == Cfg::KSTEPS - 1) load_w_from(wnext, 1, 1);        // next stage: K-step 1 -> wa[1] (free since K-step L - 1)
+          }
         } else if (grp == 0 && t > 0) {
           load_w(0, t);
         }
@@ -278,7 +332,13 @@ __global__ __launch_bounds__((FCfg<S, MB, TX_, TZ_, PAIR, PWO>::THREADS)) void c
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) {
-          SBF_TERMS(acc[mb], t0, Cfg::NG, wa[wb][mb], bd[db]);
+          if (Cfg::WRES) {
+            SBF_TERMS(acc[mb], t0, Cfg::NG, wres[t], bd[db]);
+          } else if (Cfg::WDB && t == 0) {
+            SBF_TERMS(acc[mb], t0, Cfg::NG, w0[mb], bd[db]);
+          } else {
+            SBF_TERMS(acc[mb], t0, Cfg::NG, wa[wb][mb], bd[db]);
+          }
         }
       }
       if (rd + 1 == rounds) {
@@ -290,7 +350,7 @@ __global__ __launch_bounds__((FCfg<S, MB, TX_, TZ_, PAIR, PWO>::THREADS)) void c
           for (int mb = 0; mb < MB; ++mb) {
             const int co = PAIR ? 4 * (g & 1) : mb * 16 + 4 * g;   // PAIR: rows = (x parity g >> 1, cout)
             if (co >= Cout) continue;                          // Cout % 4 == 0 (host)
-            const float4 bv = bias ? *reinterpret_cast<const float4*>(bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 bv = bvr[mb];
 #pragma unroll
             for (int tl = 0; tl < Cfg::NTW; ++tl) {
               const int ti = wh * Cfg::NTW + tl, tz = ti / Cfg::XT, txr = ti % Cfg::XT;
@@ -314,16 +374,17 @@ __global__ __launch_bounds__((FCfg<S, MB, TX_, TZ_, PAIR, PWO>::THREADS)) void c
         }
       }
       // the first K-step's weights of the next stage travel during the epilogue stores and the barrier wait
-      if (st + 1 < nstages) load_w_from(wl + (size_t)(rd + 1 < rounds ? rd + 1 : 0) * Cfg::KSTEPS * MB * 3 * 64, 0, 0);
+      if (!Cfg::WDB && st + 1 < nstages) load_w_from(wnext, 0, 0);
       __syncthreads();                                 // #(st + 1)
     }
   }
 }
 
-template <int S, int MB, int TX, int TZ, bool PAIR = false, int PWO = 0>
+template <int S, int MB, int TX, int TZ, bool PAIR = false, bool WRES_ = false>
 int launch_fwd(const float* x, const void* wsp, const float* b, const float* skip, float* out, int Cin, int Cout, int D, int H,
                int W, int act, hipStream_t st) {
-  using Cfg = FCfg<S, MB, TX, TZ, PAIR, PWO>;
+  using Cfg = FCfg<S, MB, TX, TZ, PAIR, WRES_>;
+  static_assert(Cfg::KSTEPS % 2 == 1, "the weight ring assumes an even last K-step");
   static_assert(2 * Cfg::LDSB <= 160 * 1024, "two LDS tile buffers above 160 KB");
   const int Do = (D - 1) / S + 1, Ho = (H - 1) / S + 1, Wo = (W - 1) / S + 1;
   const int tx = cds_ceil_div(Wo, Cfg::TX), ty = cds_ceil_div(Ho, Cfg::TY), tz = cds_ceil_div(Do, Cfg::TZ);
@@ -332,7 +393,7 @@ int launch_fwd(const float* x, const void* wsp, const float* b, const float* ski
   static const int tpw_env = []() { const char* e = getenv("CDS_SBF_TPW"); return e ? atoi(e) : 0; }();   // A/B knob
   int tpw = tpw_env > 0 ? tpw_env : max(1, min(32, ntiles / (256 * 6)));
   const int nwg = cds_ceil_div(ntiles, tpw);
-  auto kern = conv3d_sbf_kernel<S, MB, TX, TZ, PAIR, PWO>;
+  auto kern = conv3d_sbf_kernel<S, MB, TX, TZ, PAIR, WRES_>;
   constexpr int lds_bytes = 2 * Cfg::LDSB;
   if (lds_bytes > 64 * 1024) {
     static bool attr_done = false;   // once per instantiation
@@ -668,8 +729,7 @@ extern "C" int cds_conv3d_sbf_f32(const float* x, const void* weight_split, cons
   const int mb = (Cout + 15) / 16;
   if (stride == CDS_SBF_PAIR) {   // stride 1, Cout == 8, pair-packed weights
     if (Cout != 8) return CDS_EINVAL;
-    static const int pwo = []() { const char* e = getenv("CDS_SBF_PW"); return e ? atoi(e) : 0; }();   // A/B knob
-    if (pwo == 8) return launch_fwd<1, 1, 32, 4, true, 8>(x, weight_split, bias, skip, out, Cin, Cout, D, H, W, act, st);
+    if (Cin == 8) return launch_fwd<1, 1, 32, 4, true, true>(x, weight_split, bias, skip, out, Cin, Cout, D, H, W, act, st);
     return launch_fwd<1, 1, 32, 4, true>(x, weight_split, bias, skip, out, Cin, Cout, D, H, W, act, st);
   }
   if (stride == 1) {
