@@ -83,6 +83,18 @@ __device__ __forceinline__ void split_store8(unsigned char* dst, const float4& a
 
 constexpr int POSB = 48;   // bytes per LDS position
 
+// Tile order: z fastest, then x, then y.  A workgroup walks consecutive tiles, i.e. a column of z-adjacent tiles: the halo
+// planes it shares with the tile before are still in its XCD's L2.  (Measured, FETCH_SIZE: with x fastest the halo re-reads
+// of conv0 went to the fabric almost entirely, 4.5 GB fetched for a 2.0 GB input, and the layer ran at the fabric's mixed
+// read/write rate instead of the matrix pipe's.)
+#ifdef CDS_SBF_XFAST
+#define SBF_TILE(tile, A, B, C) const int A = (tile) % tiles_x, B = ((tile) / tiles_x) % tiles_y, C = (tile) / (tiles_x * tiles_y)
+#else
+#define SBF_TILE(tile, A, B, C) \
+  const int tiles_z_ = ntiles / (tiles_x * tiles_y); \
+  const int C = (tile) % tiles_z_, A = ((tile) / tiles_z_) % tiles_x, B = (tile) / (tiles_z_ * tiles_x)
+#endif
+
 // ---------------------------------------------------------------------------------------------
 // forward convolution, stride S in {1, 2}, pad 1.  MB: 16-cout blocks; output tile TX x 4 x TZ (wave = y row).
 // Stride 2 de-interleaves the x parities of the staged tile (position = row * IXP + parity * IXH + (col >> 1)), so that the
@@ -118,6 +130,11 @@ struct FCfg {
   static constexpr int NG = (MB == 1 && (CW == 4 || CDS_SBF_V != 1)) ? (NTW < 4 ? NTW : 4) : (NTW < 2 ? NTW : 2);   // N-tiles whose operands are in registers together
   static constexpr bool WDB = MB < 4;                                // weights double-buffered across K-steps (register budget)
   static constexpr int THREADS = (CW + PW) * 64;
+#ifndef CDS_SBF_NSETS
+#define CDS_SBF_NSETS 2
+#endif
+  // register sets of the producers = stages between a stage's loads and its split (even: buffer parity == set parity)
+  static constexpr int NSETS = CDS_SBF_NSETS;
 };
 
 // Warp-specialised, persistent over TPW consecutive tiles (and the Cin / 8 channel rounds of each): 512 threads = 4 consumer
@@ -163,10 +180,10 @@ __global__ __launch_bounds__((FCfg<S, MB, TX_, TZ_, PAIR, WRES_>::THREADS)) void
     }
     // Two register sets: the loads of stage st + 2 are in flight while stage st + 1 is split and written, so a stage's loads
     // have two stage times to arrive (the stride-2 and deep layers have stages of a few microseconds, about one HBM latency).
-    float4 va[2][PPT], vb[2][PPT];
+    float4 va[Cfg::NSETS][PPT], vb[Cfg::NSETS][PPT];
     auto issue = [&](int st, int set) {
       const int tile = tile0 + st / rounds, rd = st % rounds;
-      const int tx_i = tile % tiles_x, ty_i = (tile / tiles_x) % tiles_y, tz_i = tile / (tiles_x * tiles_y);
+      SBF_TILE(tile, tx_i, ty_i, tz_i);
       const int gx0 = tx_i * Cfg::TX * S - 1, gy0 = ty_i * Cfg::TY * S - 1, gz0 = tz_i * Cfg::TZ * S - 1;
 #pragma unroll
       for (int h = 0; h < PPT; ++h) {
@@ -183,37 +200,26 @@ __global__ __launch_bounds__((FCfg<S, MB, TX_, TZ_, PAIR, WRES_>::THREADS)) void
       for (int h = 0; h < PPT; ++h)
         if (s_rel[h] >= 0) split_store8(base + s_dst[h], va[set][h], vb[set][h]);
     };
-    // stage s travels in register set s & 1 and lands in LDS buffer s & 1
-    issue(0, 0);
-    if (nstages > 1) issue(1, 1);
+    // Stage s travels in register set s % NSETS and lands in LDS buffer s & 1; its loads are issued NSETS stages before it is
+    // split and written.  (NSETS = 4 measured no faster than 2 on any layer: the staging loads are not latency-bound.)
+#pragma unroll
+    for (int u = 0; u < Cfg::NSETS; ++u)
+      if (u < nstages) issue(u, u);
     deposit(0, 0);
-    if (nstages > 2) issue(2, 0);
+    if (Cfg::NSETS < nstages) issue(Cfg::NSETS, 0);
     __syncthreads();                                   // #0: buffer 0 holds stage 0
-    for (int st = 0; st < nstages; st += 2) {
-#ifndef CDS_EXP_SBF_NOPRODUCE
-      if (st + 1 < nstages) {
-#ifdef CDS_EXP_SBF_NODEPOSIT
-        if (st < 1)
-#endif
-        deposit(1, 1);                                 // stage st + 1 (odd): loads issued two stages ago
-#ifndef CDS_EXP_SBF_NOISSUE
-        if (st + 3 < nstages) issue(st + 3, 1);
-#endif
+    for (int st = 0; st < nstages; st += Cfg::NSETS) {
+      bool done = false;
+#pragma unroll
+      for (int u = 1; u <= Cfg::NSETS; ++u) {          // during stage st + u - 1: stage st + u -> buffer u & 1, set u % NSETS
+        if (st + u < nstages) {
+          deposit(u & 1, u % Cfg::NSETS);
+          if (st + u + Cfg::NSETS < nstages) issue(st + u + Cfg::NSETS, u % Cfg::NSETS);
+        }
+        __syncthreads();                               // #(st + u): stage st + u - 1 consumed, stage st + u staged
+        if (st + u >= nstages) { done = true; break; }
       }
-#endif
-      __syncthreads();                                 // #(st + 1): stage st consumed, stage st + 1 staged
-      if (st + 1 >= nstages) break;
-#ifndef CDS_EXP_SBF_NOPRODUCE
-      if (st + 2 < nstages) {
-#ifndef CDS_EXP_SBF_NODEPOSIT
-        deposit(0, 0);                                 // stage st + 2 (even)
-#endif
-#ifndef CDS_EXP_SBF_NOISSUE
-        if (st + 4 < nstages) issue(st + 4, 0);
-#endif
-      }
-#endif
-      __syncthreads();                                 // #(st + 2)
+      if (done) break;
     }
     return;
   }
@@ -343,7 +349,7 @@ __global__ __launch_bounds__((FCfg<S, MB, TX_, TZ_, PAIR, WRES_>::THREADS)) void
       }
       if (rd + 1 == rounds) {
         // ---- epilogue: lane -> voxel j of the run, couts 16 mb + 4 g + 0..3: one 16-byte channels-last store ----
-        const int tx_i = tile % tiles_x, ty_i = (tile / tiles_x) % tiles_y, tz_i = tile / (tiles_x * tiles_y);
+        SBF_TILE(tile, tx_i, ty_i, tz_i);
         const int ox0 = tx_i * Cfg::TX, oy = ty_i * Cfg::TY + wy, oz0 = tz_i * Cfg::TZ;
         if (oy < Ho) {
 #pragma unroll
@@ -378,6 +384,208 @@ __global__ __launch_bounds__((FCfg<S, MB, TX_, TZ_, PAIR, WRES_>::THREADS)) void
       __syncthreads();                                 // #(st + 1)
     }
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// z-marching variant of the Cin = 8 pair layer (conv0: the largest kernel of the network).
+// What bounds the tiled kernel above on this layer (measured): its K-loop runs at the matrix pipe's peak, but a 32 x 4 x 4
+// tile stages 34 x 6 x 6 input positions, 2.4 per output voxel, and those halo re-reads mostly miss L2 (FETCH_SIZE: 3.7-4.5 GB
+// for a 2.0 GB input) while the four producer waves split every one of them again.  Here a workgroup owns a 32 x 8 column
+// and marches along z: the staged input lives in a ring of 8 z-planes (34 x 10 positions each) in LDS, a stage computes three
+// output planes from five resident input planes while the producers stage the next three: 1.33 input positions per output
+// voxel, no re-read along z at all, and 1.5x the MFMAs per workgroup barrier.  Same operand layout, weights resident in
+// registers, consumer waves free of vector-memory loads as above.
+// ---------------------------------------------------------------------------------------------
+struct ZCfg {
+  static constexpr int TX = 32, TY = 8, G = 3, R = 2 * G + 2;
+  static constexpr int IX = TX + 2, IY = TY + 2, IXH = IX / 2, IXP = IX;
+  static constexpr int PPOS = IY * IXP, PLANEB = PPOS * POSB;       // one z-plane of the ring: 340 positions, 16,320 B
+  static constexpr int LDSB = R * PLANEB;                           // 130,560 B
+  static constexpr int CW = 4, PW = 4, THREADS = (CW + PW) * 64;
+  static constexpr int KSTEPS = 9;
+  static constexpr int NTW = 2 * G;                                 // N-tiles per consumer wave and stage: 2 rows x G planes
+  static constexpr int NG = G;                                      // operands of one row's G planes in registers together
+};
+
+__global__ __launch_bounds__(ZCfg::THREADS) void conv3d_sbf_zm_kernel(const float* __restrict__ x, const uint4* __restrict__ wsp,
+                                                                     const float* __restrict__ bias, float* __restrict__ out,
+                                                                     int D, int H, int W, int act, int tiles_x, int tiles_y,
+                                                                     int zseg) {
+  using Cfg = ZCfg;
+  constexpr int Cin = 8, Cout = 8, G = Cfg::G, R = Cfg::R;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // unit = (column tx, ty; z segment): z segments of a column are consecutive workgroups
+  const int nseg = (D + zseg - 1) / zseg;
+  int unit = cds_xcd_remap(blockIdx.x, gridDim.x);
+  const int seg = unit % nseg;
+  unit /= nseg;
+  const int tx_i = unit % tiles_x, ty_i = unit / tiles_x;
+  const int z0 = seg * zseg, z1 = min(D, z0 + zseg);
+  const int nstages = (z1 - z0 + G - 1) / G;
+  const int gx0 = tx_i * Cfg::TX - 1, gy0 = ty_i * Cfg::TY - 1;
+  // input plane p (-1 <= p - z0, any p) lives in ring slot (p - z0 + 1) % R
+
+  if (wave >= Cfg::CW) {
+    // ============================== producers ==============================
+    constexpr int PT = Cfg::PW * 64;
+    const int ptid = tid - Cfg::CW * 64;
+    constexpr int NP = G * Cfg::PPOS, PPT = (NP + PT - 1) / PT;     // positions of the G planes of a stage
+    int s_pl[PPT], s_yx[PPT], s_dst[PPT];
+#pragma unroll
+    for (int h = 0; h < PPT; ++h) {
+      const int p = h * PT + ptid;
+      const int pl = p / Cfg::PPOS, pp = p - pl * Cfg::PPOS;
+      const int row = pp / Cfg::IXP, q = pp - row * Cfg::IXP;
+      const int c = 2 * (q % Cfg::IXH) + q / Cfg::IXH;            // de-interleaved x parities (as the tiled pair kernel)
+      s_pl[h] = p < NP ? pl : -1;
+      s_yx[h] = (row << 10) | c;
+      s_dst[h] = (row * Cfg::IXP + q) * POSB;
+    }
+    float4 va[2][PPT], vb[2][PPT];
+    auto load_pos = [&](int z, int yx, float4& a, float4& b) {
+      const int gy = gy0 + (yx >> 10), gx = gx0 + (yx & 1023);
+      const bool ok = (unsigned)z < (unsigned)D && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+      const float* __restrict__ src = x + ((size_t)((size_t)z * H + gy) * W + gx) * Cin;
+      a = ok ? *reinterpret_cast<const float4*>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
+      b = ok ? *reinterpret_cast<const float4*>(src + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    // stage st needs input planes z0 + st G - 1 .. z0 + st G + G; its NEW planes are the last G of them
+    auto issue = [&](int st, int set) {
+#pragma unroll
+      for (int h = 0; h < PPT; ++h)
+        if (s_pl[h] >= 0) load_pos(z0 + st * G + 1 + s_pl[h], s_yx[h], va[set][h], vb[set][h]);
+    };
+    auto deposit = [&](int st, int set) {
+      const int slot0 = (st * G + 2) % R;                            // slot of plane z0 + st G + 1
+#pragma unroll
+      for (int h = 0; h < PPT; ++h) {
+        if (s_pl[h] < 0) continue;
+        int slot = slot0 + s_pl[h];
+        slot = slot >= R ? slot - R : slot;
+        split_store8(lds + slot * Cfg::PLANEB + s_dst[h], va[set][h], vb[set][h]);
+      }
+    };
+    // the two lowest planes of the segment (z0 - 1, z0): loaded, split and stored directly
+    for (int p = ptid; p < 2 * Cfg::PPOS; p += PT) {
+      const int pl = p / Cfg::PPOS, pp = p - pl * Cfg::PPOS;
+      const int row = pp / Cfg::IXP, q = pp - row * Cfg::IXP;
+      const int c = 2 * (q % Cfg::IXH) + q / Cfg::IXH;
+      float4 a, b;
+      load_pos(z0 - 1 + pl, (row << 10) | c, a, b);
+      split_store8(lds + pl * Cfg::PLANEB + (row * Cfg::IXP + q) * POSB, a, b);
+    }
+    issue(0, 0);
+    if (nstages > 1) issue(1, 1);
+    deposit(0, 0);
+    if (nstages > 2) issue(2, 0);
+    __syncthreads();                                   // #0: stage 0 staged
+    for (int st = 0; st < nstages; st += 2) {
+      if (st + 1 < nstages) {
+        deposit(st + 1, 1);
+        if (st + 3 < nstages) issue(st + 3, 1);
+      }
+      __syncthreads();                                 // #(st + 1): stage st consumed, stage st + 1 staged
+      if (st + 1 >= nstages) break;
+      if (st + 2 < nstages) {
+        deposit(st + 2, 0);
+        if (st + 4 < nstages) issue(st + 4, 0);
+      }
+      __syncthreads();                                 // #(st + 2)
+    }
+    return;
+  }
+
+  // ============================== consumers: wave = rows wave and wave + 4 ==============================
+  const int j = lane & 15, g = lane >> 4;
+  const int kxl = (g & 1) * 2 + (g >> 1);              // lane groups take x' = 0, 2, 1, 3 (see the tiled kernel)
+  const int lane_base = (wave * Cfg::IXP + j + (kxl & 1) * Cfg::IXH + (kxl >> 1)) * POSB;
+  const uint4* __restrict__ wl = wsp + lane;
+  BV wres[Cfg::KSTEPS][3];
+#pragma unroll
+  for (int t = 0; t < Cfg::KSTEPS; ++t) {
+    wres[t][0].u = wl[(size_t)(t * 3) * 64];
+    wres[t][1].u = wl[(size_t)(t * 3 + 1) * 64];
+    wres[t][2].u = wl[(size_t)(t * 3 + 2) * 64];
+  }
+  const int co = 4 * (g & 1);
+  const float4 bv = bias ? *reinterpret_cast<const float4*>(bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+  const int ox = tx_i * Cfg::TX + 2 * j + (g >> 1);
+  f32x4 acc[Cfg::NTW];                                 // [row r][plane i] -> r * G + i
+  __syncthreads();                                     // #0
+  for (int st = 0; st < nstages; ++st) {
+#pragma unroll
+    for (int t = 0; t < Cfg::NTW; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // LDS address of input plane z0 + st G - 1 + u (u = 0 .. G + 1) for this lane
+    const unsigned char* vpl[G + 2];
+    {
+      int slot = (st * G) % R;
+#pragma unroll
+      for (int u = 0; u < G + 2; ++u) {
+        vpl[u] = lds + slot * Cfg::PLANEB + lane_base;
+        slot = slot + 1 >= R ? slot + 1 - R : slot + 1;
+      }
+    }
+    // steps: K-step t = (kz, ky) x row r; the G planes of a row are one operand group
+    constexpr int NS = Cfg::KSTEPS * 2;
+    BV bd[2][G][3];
+    auto load_b = [&](int buf, int ss) {
+      const int t = ss >> 1, r = ss & 1;
+      const int kz = t / 3, ky = t - 3 * kz;
+#pragma unroll
+      for (int i = 0; i < G; ++i) {
+        const unsigned char* b = vpl[i + kz] + ((r * 4 + ky) * Cfg::IXP) * POSB;
+        bd[buf][i][0].u = *reinterpret_cast<const uint4*>(b);
+        bd[buf][i][1].u = *reinterpret_cast<const uint4*>(b + 16);
+        bd[buf][i][2].u = *reinterpret_cast<const uint4*>(b + 32);
+      }
+    };
+    load_b(0, 0);
+#pragma unroll
+    for (int ss = 0; ss < NS; ++ss) {
+      const int t = ss >> 1, r = ss & 1, db = ss & 1;
+      if (ss + 1 < NS) load_b(db ^ 1, ss + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      SBF_TERMS(acc, r * G, G, wres[t], bd[db]);
+    }
+    // ---- epilogue ----
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int oy = ty_i * Cfg::TY + wave + 4 * r;
+#pragma unroll
+      for (int i = 0; i < G; ++i) {
+        const int oz = z0 + st * G + i;
+        if (oz >= z1 || oy >= H || ox >= W) continue;
+        const f32x4 a = acc[r * G + i];
+        float4 o = make_float4(a.x + bv.x, a.y + bv.y, a.z + bv.z, a.w + bv.w);
+        if (act == CDS_ACT_RELU) {
+          o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
+        }
+        *reinterpret_cast<float4*>(out + ((size_t)((size_t)oz * H + oy) * W + ox) * Cout + co) = o;
+      }
+    }
+    __syncthreads();                                   // #(st + 1)
+  }
+}
+
+int launch_fwd_zm(const float* x, const void* wsp, const float* b, float* out, int D, int H, int W, int act, hipStream_t st) {
+  using Cfg = ZCfg;
+  const int tx = cds_ceil_div(W, Cfg::TX), ty = cds_ceil_div(H, Cfg::TY);
+  // z segments: whole columns when there are enough of them for ~8 rounds of workgroups, else segments of >= 8 stages
+  int nseg = 1;
+  while (tx * ty * nseg < 256 * 8 && cds_ceil_div(D, nseg * 2) >= 8 * Cfg::G) nseg *= 2;
+  int zseg = cds_ceil_div(cds_ceil_div(D, nseg), Cfg::G) * Cfg::G;
+  nseg = cds_ceil_div(D, zseg);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_sbf_zm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDSB);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(conv3d_sbf_zm_kernel, dim3(tx * ty * nseg), dim3(Cfg::THREADS), Cfg::LDSB, st, x, reinterpret_cast<const uint4*>(wsp), b,
+                     out, D, H, W, act, tx, ty, zseg);
+  return cds_launch_status();
 }
 
 template <int S, int MB, int TX, int TZ, bool PAIR = false, bool WRES_ = false>
@@ -495,7 +703,7 @@ __global__ __launch_bounds__(256, (MERGE ? CDS_DECONV_SBF_MINW : 2)) void deconv
   }
   float4 va[PPT], vb[PPT];
   auto issue = [&](int tile, int rd) {
-    const int tx_i = tile % tiles_x, ty_i = (tile / tiles_x) % tiles_y, az = tile / (tiles_x * tiles_y);
+    SBF_TILE(tile, tx_i, ty_i, az);
     const int gx0 = tx_i * Cfg::CX, gy0 = ty_i * Cfg::CY;
 #pragma unroll
     for (int h = 0; h < PPT; ++h) {
@@ -520,7 +728,7 @@ __global__ __launch_bounds__(256, (MERGE ? CDS_DECONV_SBF_MINW : 2)) void deconv
   const int Ho = 2 * H, Wo = 2 * W;
   if (tile0 < tile1) issue(tile0, 0);
   for (int tile = tile0; tile < tile1; ++tile) {
-    const int tx_i = tile % tiles_x, ty_i = (tile / tiles_x) % tiles_y, az = tile / (tiles_x * tiles_y);
+    SBF_TILE(tile, tx_i, ty_i, az);
     const int ay = ty_i * Cfg::CY + wave;
 #pragma unroll
     for (int c = 0; c < Tab::NCLS; ++c)
@@ -646,6 +854,224 @@ int launch_deconv(const float* x, const void* wsp, const float* b, const float* 
 }
 
 // ---------------------------------------------------------------------------------------------
+// Transposed convolution to Cout = 8 (conv11: the full-resolution, memory-bound layer), warp-specialised.
+// In the kernel above every wave loads, splits, multiplies and stores; s_waitcnt vmcnt counts loads and stores in
+// order, so each weight wait of the K-loop also waited for the HBM loads of the next tile and the stores of the tile
+// before (16 % matrix-pipe utilisation, 3.7 TB/s).  Here 4 consumer waves (cell row y) touch vector memory only for the
+// residual prefetch (one tile ahead of its use) and the fire-and-forget output stores: the split weights of ALL rounds sit
+// in LDS (rounds x 5 K-steps x 3 KB), the staged input tile is double-buffered and filled by 2 producer waves that run
+// two stages ahead.  One workgroup barrier per stage (tile, 8-channel round); 2-3 workgroups per CU.
+// ---------------------------------------------------------------------------------------------
+constexpr int DWS_CW = 4, DWS_PW = 2, DWS_THREADS = (DWS_CW + DWS_PW) * 64;
+
+__global__ __launch_bounds__(DWS_THREADS, 3) void deconv3d_sbf_ws_kernel(const float* __restrict__ x, const uint4* __restrict__ wsp,
+                                                                       const float* __restrict__ bias, const float* __restrict__ skip,
+                                                                       float* __restrict__ out, int Cin, int Cout, int D, int H, int W,
+                                                                       int act, int out_planar, int tiles_x, int tiles_y, int ntiles,
+                                                                       int tpw) {
+  using Cfg = DCfg;
+  using Tab = DTab<true>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nwg = gridDim.x;
+  const int wg = cds_xcd_remap(blockIdx.x, nwg);
+  const int tile0 = wg * tpw, tile1 = min(ntiles, tile0 + tpw);
+  const int rounds = Cin >> 3;
+  const int nstages = (tile1 - tile0) * rounds;
+  if (nstages <= 0) return;
+  const int wbytes = rounds * Tab::NKS * 3 * 1024;          // the layer's split weights: [round][K-step][term][lane] x 16 B
+  unsigned char* tiles = lds + wbytes;
+  {
+    uint4* wdst = reinterpret_cast<uint4*>(lds);
+    for (int i = tid; i < wbytes / 16; i += DWS_THREADS) wdst[i] = wsp[i];
+  }
+
+  if (wave >= DWS_CW) {
+    // ============================== producers ==============================
+    const int ptid = tid - DWS_CW * 64;
+    constexpr int NP = Cfg::IZ * Cfg::IY * Cfg::IX;
+    constexpr int PPT = (NP + DWS_PW * 64 - 1) / (DWS_PW * 64);
+    int s_rel[PPT], s_dst[PPT];
+#pragma unroll
+    for (int h = 0; h < PPT; ++h) {
+      const int p = h * DWS_PW * 64 + ptid;
+      const int row = p / Cfg::IX, c = p - row * Cfg::IX;
+      const int rz = row / Cfg::IY, ry = row - rz * Cfg::IY;
+      s_rel[h] = p < NP ? ((rz << 20) | (ry << 10) | c) : -1;
+      s_dst[h] = (row * Cfg::IXP + c) * POSB;
+    }
+    float4 va[2][PPT], vb[2][PPT];
+    auto issue = [&](int st, int set) {
+      const int tile = tile0 + st / rounds, rd = st % rounds;
+      SBF_TILE(tile, tx_i, ty_i, az);
+      const int gx0 = tx_i * Cfg::CX, gy0 = ty_i * Cfg::CY;
+#pragma unroll
+      for (int h = 0; h < PPT; ++h) {
+        const int gz = az + (s_rel[h] >> 20), gy = gy0 + ((s_rel[h] >> 10) & 1023), gx = gx0 + (s_rel[h] & 1023);
+        const bool ok = s_rel[h] >= 0 && gz < D && gy < H && gx < W;
+        const float* __restrict__ src = x + ((size_t)((size_t)gz * H + gy) * W + gx) * Cin + rd * 8;
+        va[set][h] = ok ? *reinterpret_cast<const float4*>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
+        vb[set][h] = ok ? *reinterpret_cast<const float4*>(src + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    };
+    auto deposit = [&](int buf, int set) {
+      unsigned char* base = tiles + buf * Cfg::LDSB;
+#pragma unroll
+      for (int h = 0; h < PPT; ++h)
+        if (s_rel[h] >= 0) split_store8(base + s_dst[h], va[set][h], vb[set][h]);
+    };
+    issue(0, 0);
+    if (nstages > 1) issue(1, 1);
+    deposit(0, 0);
+    if (nstages > 2) issue(2, 0);
+    __syncthreads();                                   // #0: weights + stage 0 staged
+    for (int st = 0; st < nstages; st += 2) {
+      if (st + 1 < nstages) {
+        deposit(1, 1);
+        if (st + 3 < nstages) issue(st + 3, 1);
+      }
+      __syncthreads();
+      if (st + 1 >= nstages) break;
+      if (st + 2 < nstages) {
+        deposit(0, 0);
+        if (st + 4 < nstages) issue(st + 4, 0);
+      }
+      __syncthreads();
+    }
+    return;
+  }
+
+  // ============================== consumers ==============================
+  const int j = lane & 15, g = lane >> 4;
+  int toff[Tab::NKS];
+#pragma unroll
+  for (int ks = 0; ks < Tab::NKS; ++ks) {
+    const int c = Tab::cls_of(ks), s0 = Tab::slot0_of(ks);
+    int off = 0;
+#pragma unroll
+    for (int gg = 0; gg < 4; ++gg) {
+      const int dz = Tab::tap_d(c, s0 + gg, 0), dy = Tab::tap_d(c, s0 + gg, 1), dx = Tab::tap_d(c, s0 + gg, 2);
+      const int o = dz < 0 ? 0 : ((dz * Cfg::IY + dy) * Cfg::IXP + dx) * POSB;
+      off = g == gg ? o : off;
+    }
+    toff[ks] = off;
+  }
+  const int b_base = (wave * Cfg::IXP + j) * POSB;
+  const unsigned char* wlds = lds + lane * 16;
+  const int co = 4 * (g & 1), px = g >> 1;             // rows of the matrix tile = (x parity, cout)
+  const float4 bv = bias ? *reinterpret_cast<const float4*>(bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+  const int Ho = 2 * H, Wo = 2 * W;
+  f32x4 acc[Tab::NCLS][Cfg::NT];
+  float4 skv[Tab::NCLS][Cfg::NT];
+  __syncthreads();                                     // #0
+  int st = 0;
+  for (int tile = tile0; tile < tile1; ++tile) {
+    SBF_TILE(tile, tx_i, ty_i, az);
+    const int ay = ty_i * Cfg::CY + wave;
+#pragma unroll
+    for (int c = 0; c < Tab::NCLS; ++c)
+#pragma unroll
+      for (int t = 0; t < Cfg::NT; ++t) acc[c][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (skip && ay < H) {
+      // the U-Net skip rows of this tile: requested a whole tile ahead of the epilogue that adds them
+#pragma unroll
+      for (int c = 0; c < Tab::NCLS; ++c) {
+        const size_t rowbase = ((size_t)(2 * az + (c >> 1)) * Ho + (2 * ay + (c & 1))) * Wo;
+#pragma unroll
+        for (int q = 0; q < Cfg::NT; ++q) {
+          const int ax = min(tx_i * Cfg::CX + q * 16 + j, W - 1);
+          skv[c][q] = *reinterpret_cast<const float4*>(skip + (rowbase + 2 * ax + px) * Cout + co);
+        }
+      }
+    }
+    for (int rd = 0; rd < rounds; ++rd, ++st) {
+      const unsigned char* tbuf = tiles + (st & 1) * Cfg::LDSB;
+      const unsigned char* wr = wlds + rd * Tab::NKS * 3 * 1024;
+      BV wa[2][3];
+      BV bd[2][Cfg::NT][3];
+      auto load_w = [&](int buf, int ks) {
+        wa[buf][0].u = *reinterpret_cast<const uint4*>(wr + (ks * 3) * 1024);
+        wa[buf][1].u = *reinterpret_cast<const uint4*>(wr + (ks * 3 + 1) * 1024);
+        wa[buf][2].u = *reinterpret_cast<const uint4*>(wr + (ks * 3 + 2) * 1024);
+      };
+      auto load_b = [&](int buf, int ks) {
+        const unsigned char* bp = tbuf + b_base + toff[ks];
+#pragma unroll
+        for (int q = 0; q < Cfg::NT; ++q) {
+          const unsigned char* b = bp + q * 16 * POSB;
+          bd[buf][q][0].u = *reinterpret_cast<const uint4*>(b);
+          bd[buf][q][1].u = *reinterpret_cast<const uint4*>(b + 16);
+          bd[buf][q][2].u = *reinterpret_cast<const uint4*>(b + 32);
+        }
+      };
+      load_w(0, 0);
+      load_b(0, 0);
+#pragma unroll
+      for (int ks = 0; ks < Tab::NKS; ++ks) {
+        const int c = Tab::cls_of(ks), cur = ks & 1;
+        if (ks + 1 < Tab::NKS) {
+          load_b(cur ^ 1, ks + 1);
+          load_w(cur ^ 1, ks + 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        SBF_TERMS(acc[c], 0, Cfg::NT, wa[cur], bd[cur]);
+      }
+      if (rd + 1 == rounds && ay < H) {
+        // ---- epilogue ----
+#pragma unroll
+        for (int c = 0; c < Tab::NCLS; ++c) {
+          const size_t rowbase = ((size_t)(2 * az + (c >> 1)) * Ho + (2 * ay + (c & 1))) * Wo;
+#pragma unroll
+          for (int q = 0; q < Cfg::NT; ++q) {
+            const int ax = tx_i * Cfg::CX + q * 16 + j;
+            if (ax >= W) continue;
+            const size_t base = (rowbase + 2 * ax + px) * Cout + co;
+            const f32x4 a = acc[c][q];
+            float4 o = make_float4(a.x + bv.x, a.y + bv.y, a.z + bv.z, a.w + bv.w);
+            if (act == CDS_ACT_RELU) {
+              o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
+            }
+            if (skip) {
+              const float4 s4 = skv[c][q];
+              o.x = s4.x + o.x; o.y = s4.y + o.y; o.z = s4.z + o.z; o.w = s4.w + o.w;
+            }
+            if (out_planar) {
+              const size_t ovol = (size_t)(2 * D) * Ho * Wo;
+              float* po = out + (size_t)co * ovol + (rowbase + 2 * ax + px);
+              po[0] = o.x; po[ovol] = o.y; po[2 * ovol] = o.z; po[3 * ovol] = o.w;
+            } else {
+              *reinterpret_cast<float4*>(out + base) = o;
+            }
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+int launch_deconv_ws(const float* x, const void* wsp, const float* b, const float* skip, float* out, int Cin, int Cout, int D, int H,
+                     int W, int act, int out_planar, hipStream_t st) {
+  using Cfg = DCfg;
+  const int tx = cds_ceil_div(W, Cfg::CX), ty = cds_ceil_div(H, Cfg::CY);
+  const int ntiles = tx * ty * D;
+  static const int tpw_env = []() { const char* e = getenv("CDS_SBF_TPW"); return e ? atoi(e) : 0; }();   // A/B knob
+  int tpw = tpw_env > 0 ? tpw_env : max(1, min(16, ntiles / (256 * 2 * 8)));
+  const int nwg = cds_ceil_div(ntiles, tpw);
+  const int lds_bytes = (Cin >> 3) * DTab<true>::NKS * 3 * 1024 + 2 * Cfg::LDSB;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(deconv3d_sbf_ws_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(deconv3d_sbf_ws_kernel, dim3(nwg), dim3(DWS_THREADS), lds_bytes, st, x, reinterpret_cast<const uint4*>(wsp), b,
+                     skip, out, Cin, Cout, D, H, W, act, out_planar, tx, ty, ntiles, tpw);
+  return cds_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------
 // prob layer: Conv3d(8 -> 1, k3, p1, no bias / BN / ReLU; module.py:303) on a channels-last input, plain fp32 FMAs
 // (one output channel cannot fill a matrix tile), planar output [D][H][W] for the soft-argmin.
 // Tile 64 x 4 x 4 outputs: lane = x, wave = y, four z outputs per thread.  The input tile (66 x 6 x 6 positions) sits in
@@ -729,7 +1155,11 @@ extern "C" int cds_conv3d_sbf_f32(const float* x, const void* weight_split, cons
   const int mb = (Cout + 15) / 16;
   if (stride == CDS_SBF_PAIR) {   // stride 1, Cout == 8, pair-packed weights
     if (Cout != 8) return CDS_EINVAL;
-    if (Cin == 8) return launch_fwd<1, 1, 32, 4, true, true>(x, weight_split, bias, skip, out, Cin, Cout, D, H, W, act, st);
+    if (Cin == 8) {
+      static const bool tiled = getenv("CDS_SBF_NOZM") != nullptr;   // A/B knob: the tiled kernel
+      if (!skip && !tiled) return launch_fwd_zm(x, weight_split, bias, out, D, H, W, act, st);
+      return launch_fwd<1, 1, 32, 4, true, true>(x, weight_split, bias, skip, out, Cin, Cout, D, H, W, act, st);
+    }
     return launch_fwd<1, 1, 32, 4, true>(x, weight_split, bias, skip, out, Cin, Cout, D, H, W, act, st);
   }
   if (stride == 1) {
@@ -751,7 +1181,11 @@ extern "C" int cds_deconv3d_sbf_f32(const float* x, const void* weight_split, co
                                     int Cin, int Cout, int D, int H, int W, int act, int out_planar, void* stream) {
   if (!x || !weight_split || !out || Cin < 8 || (Cin % 8) || D < 1 || H < 1 || W < 1) return CDS_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  if (Cout == 8) return launch_deconv<true, 1>(x, weight_split, bias, skip, out, Cin, Cout, D, H, W, act, out_planar, st);
+  if (Cout == 8) {
+    static const bool old = getenv("CDS_DECONV_OLD") != nullptr;   // A/B knob
+    if (Cin <= 32 && !old) return launch_deconv_ws(x, weight_split, bias, skip, out, Cin, Cout, D, H, W, act, out_planar, st);
+    return launch_deconv<true, 1>(x, weight_split, bias, skip, out, Cin, Cout, D, H, W, act, out_planar, st);
+  }
   if (Cout == 16) return launch_deconv<false, 1>(x, weight_split, bias, skip, out, Cin, Cout, D, H, W, act, out_planar, st);
   if (Cout == 32) return launch_deconv<false, 2>(x, weight_split, bias, skip, out, Cin, Cout, D, H, W, act, out_planar, st);
   return CDS_EINVAL;

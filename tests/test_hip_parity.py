@@ -800,7 +800,7 @@ def test_full_forward_view_counts(dev, seeded_state, N):
 @pytest.mark.parametrize("cin,cout,stride,D,H,W", [(8, 8, 1, 9, 13, 40), (8, 8, 1, 16, 32, 64), (16, 16, 1, 6, 10, 36),
                                                   (32, 32, 1, 5, 9, 20), (64, 64, 1, 4, 6, 16), (8, 4, 1, 7, 8, 44),
                                                   (8, 16, 2, 9, 17, 35), (16, 32, 2, 8, 16, 32), (32, 64, 2, 6, 9, 21),
-                                                  (8, 16, 2, 16, 32, 64), (8, 8, 101, 9, 13, 40), (16, 8, 101, 5, 8, 33),
+                                                  (8, 16, 2, 16, 32, 64), (8, 8, 101, 9, 13, 40), (8, 8, 101, 50, 9, 70), (16, 8, 101, 5, 8, 33),
                                                   (32, 8, 101, 8, 16, 64)])
 def test_conv3d_split_bf16_is_fp32_class(cin, cout, stride, D, H, W, dev, ops):
     """csrc/conv3d_sbf.hip: 3 x 3 x 3 convolution with every fp32 operand split exactly into three bf16 terms and six
