@@ -21,8 +21,33 @@ from . import geometry, ops
 Tensor = torch.Tensor
 
 
-def _dynamic_conv(dc, x: Tensor, epi: Tensor, T: float) -> Tuple[Tensor, Tensor]:
-    """models/dynamic_conv.py:97-122 with torch ops.  x [N,Cin,H,W]; epi [N,2] on x's device."""
+def _att_weights_grouped(seq, curvs: Tensor, groups: int) -> Tensor:
+    """``DynamicConv.att_weights`` (1x1 conv -> BatchNorm2d -> ReLU -> 1x1 conv, dynamic_conv.py:88-91) on a batch that
+    stacks ``groups`` separate calls of the reference: the BatchNorm statistics are taken per group of N / groups samples
+    (what each of those calls would have seen) and the running statistics receive the groups' updates in call order."""
+    conv_a, bn, _, conv_b = seq[0], seq[1], seq[2], seq[3]
+    h = conv_a(curvs)
+    N, C, H, W = h.shape
+    hg = h.view(groups, N // groups, C, H, W)
+    mean = hg.mean(dim=(1, 3, 4))                                            # [G,C]
+    var = hg.var(dim=(1, 3, 4), unbiased=False)
+    y = (hg - mean.view(groups, 1, C, 1, 1)) * torch.rsqrt(var.view(groups, 1, C, 1, 1) + bn.eps)
+    y = y * bn.weight.view(1, 1, C, 1, 1) + bn.bias.view(1, 1, C, 1, 1)
+    if bn.training and bn.track_running_stats:
+        with torch.no_grad():
+            m = bn.momentum if bn.momentum is not None else 0.1
+            n = (N // groups) * H * W
+            rdt = bn.running_mean.dtype
+            wts = m * (1.0 - m) ** torch.arange(groups - 1, -1, -1, device=h.device, dtype=rdt)   # call g, then g+1, ...
+            bn.running_mean.mul_((1.0 - m) ** groups).add_((wts.view(-1, 1) * mean.detach().to(rdt)).sum(dim=0))
+            bn.running_var.mul_((1.0 - m) ** groups).add_((wts.view(-1, 1) * (var.detach().to(rdt) * (n / max(n - 1, 1)))).sum(dim=0))
+            bn.num_batches_tracked += groups
+    return conv_b(F.relu(y.view(N, C, H, W)))
+
+
+def _dynamic_conv(dc, x: Tensor, epi: Tensor, T: float, groups: int = 1) -> Tuple[Tensor, Tensor]:
+    """models/dynamic_conv.py:97-122 with torch ops.  x [N,Cin,H,W]; epi [N,2] on x's device.  groups > 1: the batch stacks
+    that many separate calls of the reference (see ``_att_weights_grouped``)."""
     N, _, H, W = x.shape
     ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float32, device=x.device),
                             torch.arange(W, dtype=torch.float32, device=x.device), indexing="ij")
@@ -36,37 +61,40 @@ def _dynamic_conv(dc, x: Tensor, epi: Tensor, T: float) -> Tuple[Tensor, Tensor]
         curvs.append((att(x) * basis).sum(dim=1, keepdim=True))
         res.append(conv(x).unsqueeze(1))
     curvs = torch.cat(curvs, dim=1)
-    wts = F.softmax(dc.att_weights(curvs) / T, dim=1)
+    aw = dc.att_weights(curvs) if (groups == 1 or not dc.att_weights[1].training) else _att_weights_grouped(dc.att_weights, curvs, groups)
+    wts = F.softmax(aw / T, dim=1)
     return (torch.cat(res, dim=1) * wts.unsqueeze(2)).sum(dim=1), (curvs * wts).sum(dim=1, keepdim=True)
 
 
-def _unit(unit, x: Tensor, epi: Optional[Tensor], T: float):
+def _unit(unit, x: Tensor, epi: Optional[Tensor], T: float, groups: int = 1):
     if unit.dynamic:
-        y, nc = _dynamic_conv(unit.conv, x, epi, T)
+        y, nc = _dynamic_conv(unit.conv, x, epi, T, groups)
         return F.leaky_relu(F.instance_norm(y), 0.1), nc
     return F.leaky_relu(F.instance_norm(unit.conv(x)), 0.1)
 
 
-def feature_net(net, x: Tensor, epi: Tensor, T: float) -> Dict[str, Tuple[Tensor, Tensor, Tensor]]:
-    """models/module.py:234-267.  x [N,3,H,W], epi [N,2] -> {'stageK': (fea, nc_sum, |nc|)} batched over N."""
+def feature_net(net, x: Tensor, epi: Tensor, T: float, groups: int = 1) -> Dict[str, Tuple[Tensor, Tensor, Tensor]]:
+    """models/module.py:234-267.  x [N,3,H,W], epi [N,2] -> {'stageK': (fea, nc_sum, |nc|)} batched over N.  groups > 1: x stacks
+    that many separate calls of the reference (the only cross-sample operation in FeatureNet is the BatchNorm2d inside each
+    DynamicConv's attention MLP: its statistics are then taken per group)."""
     e0, e1, e2 = epi, epi / 2, epi / 4
-    c00, n00 = _unit(net.conv00, x, e0, T)
-    c01, n01 = _unit(net.conv01, c00, e0, T)
+    c00, n00 = _unit(net.conv00, x, e0, T, groups)
+    c01, n01 = _unit(net.conv01, c00, e0, T, groups)
     d0 = _unit(net.downsample1, c01, None, T)
-    c10, n10 = _unit(net.conv10, d0, e1, T)
-    c11, n11 = _unit(net.conv11, c10, e1, T)
+    c10, n10 = _unit(net.conv10, d0, e1, T, groups)
+    c11, n11 = _unit(net.conv11, c10, e1, T, groups)
     d1 = _unit(net.downsample2, c11, None, T)
-    c20, n20 = _unit(net.conv20, d1, e2, T)
-    c21, n21 = _unit(net.conv21, c20, e2, T)
+    c20, n20 = _unit(net.conv20, d1, e2, T, groups)
+    c21, n21 = _unit(net.conv21, c20, e2, T, groups)
     out = {}
-    o1, n22 = _dynamic_conv(net.out1, c21, e2, T)
+    o1, n22 = _dynamic_conv(net.out1, c21, e2, T, groups)
     out["stage1"] = (torch.tanh(F.instance_norm(o1)), (n20 ** 2 + n21 ** 2 + n22 ** 2) / 3, n22.abs())
     t = _unit(net.inner1, torch.cat((F.interpolate(c21, scale_factor=2, mode="nearest"), c11), dim=1), None, T)
-    o2, n12 = _dynamic_conv(net.out2, t, e1, T)
+    o2, n12 = _dynamic_conv(net.out2, t, e1, T, groups)
     o2 = torch.tanh(F.instance_norm(o2))
     out["stage2"] = (o2, (n10 ** 2 + n11 ** 2 + n12 ** 2) / 3, n12.abs())
     t = _unit(net.inner2, torch.cat((F.interpolate(o2, scale_factor=2, mode="nearest"), c01), dim=1), None, T)
-    o3, n02 = _dynamic_conv(net.out3, t, e0, T)
+    o3, n02 = _dynamic_conv(net.out3, t, e0, T, groups)
     out["stage3"] = (torch.tanh(F.instance_norm(o3)), (n00 ** 2 + n01 ** 2 + n02 ** 2) / 3, n02.abs())
     return out
 
@@ -75,6 +103,7 @@ def _cbr3(unit, x: Tensor) -> Tensor:
     return F.relu(unit.bn(unit.conv(x)))
 
 
+BATCH_FEATURES = os.environ.get("CDS_TRAIN_BATCH_FEATURES", "1") != "0"   # 0 = one FeatureNet call per image of every pair, as the reference
 USE_HIP_TRAIN = os.environ.get("CDS_TRAIN_HIP", "1") != "0"   # A/B knob: 0 = PyTorch-ROCm (MIOpen) autograd ops for CostRegNet
 
 
@@ -156,13 +185,27 @@ def forward_train(model, imgs: Tensor, proj_matrices: Dict[str, Tensor], depth_v
     cams = {k: v.detach().float().cpu() for k, v in proj_matrices.items()}
     V = N - 1
     ref_img = F.interpolate(imgs[:, 0], (H, W))
+    # model.py:154-161 calls FeatureNet once per image of every pair.  Its InstanceNorms are per sample and the BatchNorm2d of
+    # each DynamicConv's attention MLP is evaluated per group of B samples (_att_weights_grouped), so the 2 V calls are ONE call
+    # on the 2 V B images stacked along the batch axis: same values, an eighth of the kernel launches and of the per-parameter
+    # gradient accumulations (the step is launch-bound).
+    epi = [[geometry.pair_epipoles(cams["stage3"][b, 0], cams["stage3"][b, v + 1]) for b in range(B)] for v in range(V)]
     feats = []
-    for v in range(V):                                                       # model.py:154-161
-        epi = [geometry.pair_epipoles(cams["stage3"][b, 0], cams["stage3"][b, v + 1]) for b in range(B)]
-        e_ref = torch.tensor([e[0] for e in epi], dtype=torch.float32, device=dev)
-        e_src = torch.tensor([e[1] for e in epi], dtype=torch.float32, device=dev)
-        feats.append((feature_net(model.feature, ref_img, e_ref, T),
-                      feature_net(model.feature, F.interpolate(imgs[:, v + 1], (H, W)), e_src, T)))
+    if BATCH_FEATURES:
+        # one call on the 2 V B images, stacked in the reference's call order (ref of pair 0, src of pair 0, ref of pair 1, ...)
+        e_all = torch.tensor([epi[v][b][k] for v in range(V) for k in (0, 1) for b in range(B)], dtype=torch.float32, device=dev)
+        x_all = torch.cat([t for v in range(V) for t in (ref_img, F.interpolate(imgs[:, v + 1], (H, W)))], dim=0)
+        f_all = feature_net(model.feature, x_all, e_all, T, groups=2 * V)
+        for v in range(V):
+            r0, s0 = 2 * v * B, (2 * v + 1) * B
+            feats.append(({k: tuple(t[r0:r0 + B] for t in f_all[k]) for k in f_all},
+                          {k: tuple(t[s0:s0 + B] for t in f_all[k]) for k in f_all}))
+    else:
+        for v in range(V):
+            e_ref = torch.tensor([e[0] for e in epi[v]], dtype=torch.float32, device=dev)
+            e_src = torch.tensor([e[1] for e in epi[v]], dtype=torch.float32, device=dev)
+            feats.append((feature_net(model.feature, ref_img, e_ref, T),
+                          feature_net(model.feature, F.interpolate(imgs[:, v + 1], (H, W)), e_src, T)))
     outputs: Dict[str, object] = {}
     depth = None
     dint_all = (dv[:, 1] - dv[:, 0])

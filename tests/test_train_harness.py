@@ -186,3 +186,33 @@ def test_stage_net_training_mode_reference_signature():
     assert all(f["src"][0].grad is not None and f["src"][0].grad.abs().sum() > 0 for f in dfe)
     for n, p in list(model.cost_regularization[stage].named_parameters()) + list(model.stage_net.vis[stage].named_parameters()):
         assert p.grad is not None and torch.isfinite(p.grad).all(), n
+
+
+def test_stacked_feature_net_calls_equal_separate_calls():
+    """training.forward_train runs FeatureNet ONCE on the 2 V B images of all pairs (launch-bound step) where the reference
+    makes 2 V calls (models/model.py:154-161).  The only cross-sample operation in FeatureNet is the BatchNorm2d inside every
+    DynamicConv's attention MLP (dynamic_conv.py:88-91): stacked, its statistics must be taken per original call and the
+    running statistics must receive the calls' updates in order.  CPU, torch ops: features, gradients and running statistics
+    of the stacked call against the separate calls."""
+    import copy
+    from cds_mvsnet_amd import CDSMVSNet, seeded_init_
+    from cds_mvsnet_amd.training import feature_net
+    a = seeded_init_(CDSMVSNet(refine=False), 7).double().train()       # float64: the comparison is about semantics
+    b = copy.deepcopy(a)
+    g = torch.Generator().manual_seed(3)
+    x = torch.rand(6, 3, 48, 64, generator=g).double()
+    e = torch.rand(6, 2, generator=g).double() * 80
+    fa = feature_net(a.feature, x, e, 0.1, groups=3)
+    sum(fa[k][0].square().sum() + fa[k][1].sum() for k in fa).backward()
+    loss_b = 0
+    for i in range(3):
+        fb = feature_net(b.feature, x[2 * i:2 * i + 2], e[2 * i:2 * i + 2], 0.1)
+        for k in fa:
+            for q in range(3):
+                assert (fa[k][q][2 * i:2 * i + 2] - fb[k][q]).abs().max() < 1e-9, (k, q)
+        loss_b = loss_b + sum(fb[k][0].square().sum() + fb[k][1].sum() for k in fb)
+    loss_b.backward()
+    for (n, pa), (_, pb) in zip(a.feature.named_parameters(), b.feature.named_parameters()):
+        assert (pa.grad - pb.grad).abs().max() <= 1e-8 * max(pb.grad.abs().max().item(), 1e-3), n
+    for (n, ba), (_, bb) in zip(a.feature.named_buffers(), b.feature.named_buffers()):
+        assert torch.allclose(ba.double(), bb.double(), rtol=1e-6, atol=1e-8), n
