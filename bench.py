@@ -181,11 +181,13 @@ def other_workloads(model, dev):
     return {k: round(v, 3) for k, v in out.items()}
 
 
-def cpu_baseline(model_cpu, name, budget_frac):
+def cpu_baseline(model_cpu, name, budget_frac, seed=0, gpu_depth=None):
     """The CPU oracle (proved equal to the reference, tests/test_oracle_golden.py) on the same workload — by default
     the FULL M1 size, one run (~20 s and ~20 GB on 64 cores); `budget_frac` < 1 (or a host with less than
     48 GB of free memory) takes the top-left (h*f) x (w*f) window instead: all D planes, all views, cost linear in the
-    pixel count (profiles/r02_cpu_baseline_linearity.md).  Returns the JSON object."""
+    pixel count (profiles/r02_cpu_baseline_linearity.md).  The inputs are the ones of the timed GPU workload (same seeds), so at full
+    size the oracle's depth map is also the parity reference of the run: `abs_depth_l1_vs_gpu` = mean |depth_cpu - depth_gpu| over
+    the depth map the timed region produced (BASELINE.json's metric: "...; abs-depth L1 vs ref").  Returns the JSON object."""
     from cds_mvsnet_amd import synth
     from oracle import cds_oracle as O
     h, w, D, C, n_views = WORKLOADS[name]
@@ -199,20 +201,28 @@ def cpu_baseline(model_cpu, name, budget_frac):
     hs, ws = max(8, int(h * budget_frac) // 8 * 8), max(8, int(w * budget_frac) // 8 * 8)
     cores = min(os.cpu_count() or 1, 64)
     torch.set_num_threads(cores)
-    feats = synth.make_pair_features(n_views - 1, C, hs, ws, seed=2)
-    cams = synth.stage_cameras(n_views, hs, ws, seed=1)
-    hyp = synth.make_hypotheses(D, hs, ws, seed=2)
+    feats = synth.make_pair_features(n_views - 1, C, hs, ws, seed=seed + 1)
+    cams = synth.stage_cameras(n_views, hs, ws, seed=seed)
+    hyp = synth.make_hypotheses(D, hs, ws, seed=seed + 1)
     sd = model_cpu.state_dict()
     stage = {8: 2, 16: 1, 32: 0}[C]
     with torch.no_grad():
         O.stage_forward(feats, cams, hyp[:, :8], sd, stage, exact=False)  # warm-up (thread pool, oneDNN primitives)
         t0 = time.time()
-        O.stage_forward(feats, cams, hyp, sd, stage, exact=False)
+        ref = O.stage_forward(feats, cams, hyp, sd, stage, exact=False)
         dt = time.time() - t0
     frac = (hs * ws) / float(h * w)
     what = "full size" if frac == 1.0 else f"window {ws}x{hs} of {w}x{h} ({frac:.4f} of the pixels, linear extrapolation)"
-    return {"value": frac / dt, "unit": "depth-maps/s", "cores": cores, "kind": "port",
-            "sample": f"{name} {what}, D={D}, C={C}, N={n_views}, 1 run, {dt:.2f} s of torch-CPU oracle (F.grid_sample path)"}
+    out = {"value": frac / dt, "unit": "depth-maps/s", "cores": cores, "kind": "port",
+           "sample": f"{name} {what}, D={D}, C={C}, N={n_views}, 1 run, {dt:.2f} s of torch-CPU oracle (F.grid_sample path)"}
+    if gpu_depth is not None and frac == 1.0:
+        dcpu = ref["depth"].reshape(h, w).float()
+        dgpu = gpu_depth.reshape(h, w).float().cpu()
+        err = (dcpu - dgpu).abs()
+        out["abs_depth_l1_vs_gpu"] = float(err.mean())
+        out["abs_depth_max_vs_gpu"] = float(err.max())
+        out["depth_range"] = [float(hyp.min()), float(hyp.max())]
+    return out
 
 
 def build_id():
@@ -506,7 +516,7 @@ def main():
     if rank == 0:
         cpu = None
         if world == 1 and args.cpu_sample > 0 and kind == "stage":
-            cpu = cpu_baseline(model_cpu, args.workload, args.cpu_sample)
+            cpu = cpu_baseline(model_cpu, args.workload, args.cpu_sample, seed=seed, gpu_depth=out["depth"][0] if args.streams == 1 else None)
         line = {
             "metric": metric,
             "value": value, "unit": unit, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

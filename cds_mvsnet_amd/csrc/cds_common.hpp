@@ -6,6 +6,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "../../include/cds_mvsnet_hip.h"
 
 #define CDS_WAVE 64
@@ -19,6 +21,16 @@ static inline int cds_launch_status() {
 }
 
 static inline int cds_ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// Opt a kernel into more than 64 KB of dynamic LDS once per DEVICE (function attributes are per device: one process may
+// drive several, e.g. nn.DataParallel replicas; `mask` is a per-kernel static).
+static inline void cds_allow_lds(const void* kernel, int bytes, std::atomic<unsigned long long>& mask) {
+  int d = 0;
+  (void)hipGetDevice(&d);
+  const unsigned long long bit = 1ull << (d & 63);
+  if (mask.fetch_or(bit) & bit) return;
+  (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
 
 // Bijective XCD-aware remap of a linear workgroup id (guide T1): the dispatcher places block b on
 // XCD b % 8, so consecutive logical tiles are handed to the same XCD to share its private L2.

@@ -578,11 +578,8 @@ int launch_fwd_zm(const float* x, const void* wsp, const float* b, float* out, i
   while (tx * ty * nseg < 256 * 8 && cds_ceil_div(D, nseg * 2) >= 8 * Cfg::G) nseg *= 2;
   int zseg = cds_ceil_div(cds_ceil_div(D, nseg), Cfg::G) * Cfg::G;
   nseg = cds_ceil_div(D, zseg);
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_sbf_zm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDSB);
-    attr_done = true;
-  }
+  static std::atomic<unsigned long long> lds_ok{0};
+  cds_allow_lds(reinterpret_cast<const void*>(conv3d_sbf_zm_kernel), Cfg::LDSB, lds_ok);
   hipLaunchKernelGGL(conv3d_sbf_zm_kernel, dim3(tx * ty * nseg), dim3(Cfg::THREADS), Cfg::LDSB, st, x, reinterpret_cast<const uint4*>(wsp), b,
                      out, D, H, W, act, tx, ty, zseg);
   return cds_launch_status();
@@ -604,11 +601,8 @@ int launch_fwd(const float* x, const void* wsp, const float* b, const float* ski
   auto kern = conv3d_sbf_kernel<S, MB, TX, TZ, PAIR, WRES_>;
   constexpr int lds_bytes = 2 * Cfg::LDSB;
   if (lds_bytes > 64 * 1024) {
-    static bool attr_done = false;   // once per instantiation
-    if (!attr_done) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-      attr_done = true;
-    }
+    static std::atomic<unsigned long long> lds_ok{0};   // per instantiation
+    cds_allow_lds(reinterpret_cast<const void*>(kern), lds_bytes, lds_ok);
   }
   hipLaunchKernelGGL(kern, dim3(nwg), dim3(Cfg::THREADS), lds_bytes, st, x, reinterpret_cast<const uint4*>(wsp), b, skip, out, Cin,
                      Cout, D, H, W, Do, Ho, Wo, act, tx, ty, ntiles, tpw);
@@ -1061,11 +1055,8 @@ int launch_deconv_ws(const float* x, const void* wsp, const float* b, const floa
   int tpw = tpw_env > 0 ? tpw_env : max(1, min(16, ntiles / (256 * 2 * 8)));
   const int nwg = cds_ceil_div(ntiles, tpw);
   const int lds_bytes = (Cin >> 3) * DTab<true>::NKS * 3 * 1024 + 2 * Cfg::LDSB;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(deconv3d_sbf_ws_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_done = true;
-  }
+  static std::atomic<unsigned long long> lds_ok{0};
+  cds_allow_lds(reinterpret_cast<const void*>(deconv3d_sbf_ws_kernel), 160 * 1024, lds_ok);
   hipLaunchKernelGGL(deconv3d_sbf_ws_kernel, dim3(nwg), dim3(DWS_THREADS), lds_bytes, st, x, reinterpret_cast<const uint4*>(wsp), b,
                      skip, out, Cin, Cout, D, H, W, act, out_planar, tx, ty, ntiles, tpw);
   return cds_launch_status();
@@ -1197,11 +1188,8 @@ extern "C" int cds_conv3d_prob_cl8_f32(const float* x, const float* weight_tap, 
   if (!x || !weight_tap || !out || D < 1 || H < 1 || W < 1) return CDS_EINVAL;
   using Cfg = PCfg;
   const int tx = cds_ceil_div(W, Cfg::TX), ty = cds_ceil_div(H, Cfg::TY), tz = cds_ceil_div(D, Cfg::TZ);
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(prob_cl8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDSB);
-    attr_done = true;
-  }
+  static std::atomic<unsigned long long> lds_ok{0};
+  cds_allow_lds(reinterpret_cast<const void*>(prob_cl8_kernel), Cfg::LDSB, lds_ok);
   hipLaunchKernelGGL(prob_cl8_kernel, dim3(tx * ty * tz), dim3(256), Cfg::LDSB, (hipStream_t)stream, x, weight_tap, out, D, H, W,
                      tx, ty, tx * ty * tz);
   return cds_launch_status();
