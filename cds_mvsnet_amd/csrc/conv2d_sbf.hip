@@ -57,12 +57,26 @@ struct Branches {
   int nks;            // K-steps per round over all branches
 };
 
+// The DynamicConv epilogue of cds_dynconv_blend_stats_f32 (dynamic_conv.py:113-122: epipolar projection of the curvature
+// responses, 1x1 MLP with the BatchNorm folded in, softmax(./T), blend; plus the InstanceNorm records of the result), fused
+// behind the branch convolutions: the [K][N][Cout + 3] branch tensor is never written or read back.
+struct Blend {
+  const float* w1;      // [4][K]
+  const float* b1;      // [4]
+  const float* w2;      // [K][4]
+  float* out;           // [N][Cout][H][W]
+  float* norm_curv;     // [N][H][W]
+  double* partial;      // [N][parts = tiles * 4][Cout][2]
+  float temperature;
+  float ex[CDS_MAX_IMAGES], ey[CDS_MAX_IMAGES];
+};
+
 // NBR branches, NBLK 16-cout blocks (Cout + 3 <= 16 NBLK)
-template <int NBR, int NBLK>
+template <int NBR, int NBLK, bool FUSE>
 __global__ __launch_bounds__(256, 2) void dynconv_branches_sbf_kernel(const float* __restrict__ x, const float* __restrict__ affine,
                                                                       const uint4* __restrict__ wsp, const float* __restrict__ bias,
                                                                       float* __restrict__ out, Branches br, int N, int Cin, int Co3,
-                                                                      int H, int W, int tiles_x, int tiles_y) {
+                                                                      int H, int W, int tiles_x, int tiles_y, Blend bl) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   int lin = cds_xcd_remap(blockIdx.x, tiles_x * tiles_y * N);
   const int tx_i = lin % tiles_x;
@@ -175,6 +189,128 @@ __global__ __launch_bounds__(256, 2) void dynconv_branches_sbf_kernel(const floa
     }
   }
 
+  if (FUSE) {
+    // Accumulator layout: lane (m, g) holds column 16 nb + m of pixels x = (q & 1) 16 + 4 g + i, y = 2 wave + (q >> 1).
+    // (1) the lanes of the three curvature columns leave them in LDS; (2) lane m of a 16-lane group owns pixel (q, i) = (m >> 2,
+    // m & 3) of its group: projection, MLP, softmax -> K weights into LDS, norm_curv to memory; (3) every lane reads the weights
+    // of its 16 pixels and blends its column; InstanceNorm records per (wave, channel) as the separate kernel leaves them.
+    const int Cout = Co3 - 3;
+    float* attL = reinterpret_cast<float*>(lds);               // [b][j][256 pixels of the tile]
+    float* wL = attL + NBR * 3 * 256;                           // [b][256]
+    __syncthreads();                                            // every wave is done with the staged input tile
+#pragma unroll
+    for (int nb = 0; nb < NBLK; ++nb) {
+      const int jj = nb * 16 + m - Cout;
+      if (jj < 0 || jj > 2) continue;
+#pragma unroll
+      for (int b = 0; b < NBR; ++b) {
+        const float bv = bias ? bias[b * Co3 + nb * 16 + m] : 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 a = acc[b][nb][q];
+          *reinterpret_cast<float4*>(attL + (b * 3 + jj) * 256 + wave * 64 + q * 16 + g * 4) =
+              make_float4(a.x + bv, a.y + bv, a.z + bv, a.w + bv);
+        }
+      }
+    }
+    {
+      const int wp = wave * 64 + (m >> 2) * 16 + g * 4 + (m & 3);
+      const int px = ox0 + ((m >> 2) & 1) * 16 + g * 4 + (m & 3), py = oy0 + wave * 2 + (m >> 3);
+      float u = (float)px - bl.ex[img], v = (float)py - bl.ey[img];
+      const float nrm = sqrtf(u * u + v * v);
+      u = u / (nrm + 1e-6f);
+      v = v / (nrm + 1e-6f);
+      const float b0 = u * u, b1v = 2.0f * u * v, b2 = v * v;
+      float curv[NBR];
+#pragma unroll
+      for (int b = 0; b < NBR; ++b)
+        curv[b] = attL[(b * 3) * 256 + wp] * b0 + attL[(b * 3 + 1) * 256 + wp] * b1v + attL[(b * 3 + 2) * 256 + wp] * b2;
+      float hid[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float sacc = 0.f;
+#pragma unroll
+        for (int b = 0; b < NBR; ++b) sacc = fmaf(bl.w1[j * NBR + b], curv[b], sacc);
+        hid[j] = fmaxf(sacc + bl.b1[j], 0.f);
+      }
+      float logit[NBR], mx = -INFINITY;
+#pragma unroll
+      for (int b = 0; b < NBR; ++b) {
+        float sacc = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sacc = fmaf(bl.w2[b * 4 + j], hid[j], sacc);
+        logit[b] = sacc / bl.temperature;
+        mx = fmaxf(mx, logit[b]);
+      }
+      float den = 0.f;
+#pragma unroll
+      for (int b = 0; b < NBR; ++b) {
+        logit[b] = expf(logit[b] - mx);
+        den += logit[b];
+      }
+      float nc = 0.f;
+#pragma unroll
+      for (int b = 0; b < NBR; ++b) {
+        logit[b] = logit[b] / den;
+        nc = nc + curv[b] * logit[b];
+        wL[b * 256 + wp] = logit[b];
+      }
+      if (px < W && py < H) bl.norm_curv[(size_t)img * plane + (size_t)py * W + px] = nc;
+    }
+    float4 wq[NBR][4];
+#pragma unroll
+    for (int b = 0; b < NBR; ++b)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) wq[b][q] = *reinterpret_cast<const float4*>(wL + b * 256 + wave * 64 + q * 16 + g * 4);
+    const int parts = tiles_x * tiles_y * 4;
+    double* rec = bl.partial + (((size_t)img * parts + (size_t)(ty_i * tiles_x + tx_i) * 4 + wave) * Cout) * 2;
+#pragma unroll
+    for (int nb = 0; nb < NBLK; ++nb) {
+      const int co = nb * 16 + m;
+      const bool col = co < Cout;
+      float bvb[NBR];
+#pragma unroll
+      for (int b = 0; b < NBR; ++b) bvb[b] = (bias && col) ? bias[b * Co3 + co] : 0.f;
+      float* __restrict__ ob = bl.out + ((size_t)img * Cout + (col ? co : 0)) * plane;
+      double ds = 0.0, dq = 0.0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int oy = oy0 + wave * 2 + (q >> 1), ox = ox0 + (q & 1) * 16 + g * 4;
+        float o[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float sacc = 0.f;
+#pragma unroll
+          for (int b = 0; b < NBR; ++b) {
+            const f32x4 a = acc[b][nb][q];
+            const float av = (i == 0 ? a.x : i == 1 ? a.y : i == 2 ? a.z : a.w) + bvb[b];
+            const float wv = i == 0 ? wq[b][q].x : i == 1 ? wq[b][q].y : i == 2 ? wq[b][q].z : wq[b][q].w;
+            sacc = sacc + av * wv;
+          }
+          o[i] = sacc;
+        }
+        if (col && oy < H && ox < W) {                           // W % 4 == 0
+          *reinterpret_cast<float4*>(ob + (size_t)oy * W + ox) = make_float4(o[0], o[1], o[2], o[3]);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const double dv = (double)o[i];
+            ds += dv;
+            dq += dv * dv;
+          }
+        }
+      }
+      // the wave's 64 pixels of this channel: lanes (m, g = 0..3)
+      ds += __shfl_xor(ds, 16);
+      dq += __shfl_xor(dq, 16);
+      ds += __shfl_xor(ds, 32);
+      dq += __shfl_xor(dq, 32);
+      if (col && g == 0) {
+        rec[2 * co] = ds;
+        rec[2 * co + 1] = dq;
+      }
+    }
+    return;
+  }
   // ---- epilogue: lane -> cout (l & 15) of block nb, pixels x = run * 16 + (l >> 4) * 4 + 0..3 ----
 #pragma unroll
   for (int b = 0; b < NBR; ++b) {
@@ -224,8 +360,8 @@ extern "C" int cds_dynconv_branches_sbf_f32(const float* x, const float* in_affi
   const size_t ldsb = (size_t)NPOS * POSB;
   hipStream_t st = (hipStream_t)stream;
 #define LAUNCH(NBR, NBLK)                                                                                                    \
-  hipLaunchKernelGGL((dynconv_branches_sbf_kernel<NBR, NBLK>), grid, block, ldsb, st, x, in_affine,                          \
-                     reinterpret_cast<const uint4*>(weight_split), bias, out, br, N, Cin, Co3, H, W, tx, ty)
+  hipLaunchKernelGGL((dynconv_branches_sbf_kernel<NBR, NBLK, false>), grid, block, ldsb, st, x, in_affine,                   \
+                     reinterpret_cast<const uint4*>(weight_split), bias, out, br, N, Cin, Co3, H, W, tx, ty, Blend{})
   if (nb == 3 && nblk == 1) LAUNCH(3, 1);
   else if (nb == 2 && nblk == 1) LAUNCH(2, 1);
   else if (nb == 2 && nblk == 2) LAUNCH(2, 2);
@@ -233,5 +369,58 @@ extern "C" int cds_dynconv_branches_sbf_f32(const float* x, const float* in_affi
   else if (nb == 3 && nblk == 2) LAUNCH(3, 2);
   else return CDS_EINVAL;
 #undef LAUNCH
+  return cds_launch_status();
+}
+
+// Records per image that cds_dynconv_fused_sbf_f32 leaves for cds_instnorm_reduce_f32: 4 per 32 x 8 tile.
+extern "C" int cds_dynconv_fused_parts(int H, int W) { return 4 * cds_ceil_div(W, TX) * cds_ceil_div(H, TY); }
+
+// One DynamicConv (dynamic_conv.py:97-122) in ONE kernel: the branch convolutions of cds_dynconv_branches_sbf_f32 with the
+// epilogue of cds_dynconv_blend_stats_f32 applied to the accumulators.  out [N][Cout][H][W] (before its InstanceNorm),
+// norm_curv [N][H][W], partial: 8-byte aligned scratch of 2 * N * parts * Cout doubles, parts = cds_dynconv_fused_parts(H, W)
+// (reduce with cds_instnorm_reduce_f32).  w1 [4][K], b1 [4], w2 [K][4]: the attention MLP with its BatchNorm folded in;
+// epipoles_host [N][2] pixels at this resolution.  Same shape limits as cds_dynconv_branches_sbf_f32; N <= CDS_MAX_IMAGES.
+extern "C" int cds_dynconv_fused_sbf_f32(const float* x, const float* in_affine, const void* weight_split, const float* bias,
+                                         const float* w1, const float* b1, const float* w2, const float* epipoles_host,
+                                         float temperature, float* out, float* norm_curv, double* partial, int N, int Cin,
+                                         int Cout, int H, int W, const int* ksizes, int nb, void* stream) {
+  const int Co3 = Cout + 3;
+  if (!x || !weight_split || !w1 || !b1 || !w2 || !epipoles_host || !out || !norm_curv || !partial || !ksizes || N < 1 ||
+      N > CDS_MAX_IMAGES || Cin < 8 || (Cin % 8) || Cout < 1 || Co3 > 48 || (Cout % 16) + 2 > 15 || H < 1 || W < 4 || (W % 4) ||
+      nb < 2 || nb > MAXB)
+    return CDS_EINVAL;
+  Branches br;
+  br.nb = nb;
+  int ks = 0;
+  for (int b = 0; b < MAXB; ++b) {
+    br.k[b] = b < nb ? ksizes[b] : 1;
+    br.ks0[b] = ks;
+    if (b < nb) {
+      if (br.k[b] != 1 && br.k[b] != 3 && br.k[b] != 5 && br.k[b] != 7) return CDS_EINVAL;
+      ks += (br.k[b] * br.k[b] + 3) / 4;
+    }
+  }
+  br.nks = ks;
+  Blend bl;
+  bl.w1 = w1; bl.b1 = b1; bl.w2 = w2; bl.out = out; bl.norm_curv = norm_curv; bl.partial = partial; bl.temperature = temperature;
+  for (int n = 0; n < CDS_MAX_IMAGES; ++n) {
+    bl.ex[n] = n < N ? epipoles_host[2 * n] : 0.f;
+    bl.ey[n] = n < N ? epipoles_host[2 * n + 1] : 0.f;
+  }
+  const int nblk = (Co3 + 15) / 16;
+  const int tx = cds_ceil_div(W, TX), ty = cds_ceil_div(H, TY);
+  const dim3 grid(tx * ty * N), block(256);
+  const size_t ldsb = (size_t)NPOS * POSB;
+  hipStream_t st = (hipStream_t)stream;
+#define LAUNCHF(NBR, NBLK)                                                                                                   \
+  hipLaunchKernelGGL((dynconv_branches_sbf_kernel<NBR, NBLK, true>), grid, block, ldsb, st, x, in_affine,                    \
+                     reinterpret_cast<const uint4*>(weight_split), bias, nullptr, br, N, Cin, Co3, H, W, tx, ty, bl)
+  if (nb == 3 && nblk == 1) LAUNCHF(3, 1);
+  else if (nb == 2 && nblk == 1) LAUNCHF(2, 1);
+  else if (nb == 2 && nblk == 2) LAUNCHF(2, 2);
+  else if (nb == 2 && nblk == 3) LAUNCHF(2, 3);
+  else if (nb == 3 && nblk == 2) LAUNCHF(3, 2);
+  else return CDS_EINVAL;
+#undef LAUNCHF
   return cds_launch_status();
 }

@@ -29,6 +29,7 @@ BN_EPS = 1e-5
 # CDS_CONV_EXACT=1: CostRegNet on the exact-fp32 kernels (sequential fmaf chains, planar volumes) instead of the
 # split-bf16 matrix-core kernels (fp32-class error, channels-last volumes)
 USE_SPLIT_BF16 = os.environ.get("CDS_CONV_EXACT", "0") != "1"
+USE_FUSED_BLEND = os.environ.get("CDS_FUSED_BLEND", "1") != "0"   # A/B knob: 0 = DynamicConv branches and blend as two kernels
 
 
 # ------------------------------------------------------------------------------------------------
@@ -450,8 +451,13 @@ class _FeatureRunner:
         nk = len(dc.size_kernels)
         xs = x[n_shared - 1:] if n_shared > 1 else x
         affs = aff[n_shared - 1:].contiguous() if (aff is not None and n_shared > 1) else aff
+        sbf = f"{name}.ws" in p and ops.dynconv_sbf_supported(Cin, dc.out_c + 3, dc.size_kernels, W)
+        if sbf and USE_FUSED_BLEND and n_shared == 1 and stats_slope is not None and nk >= 2 and N <= ops.MAX_IMAGES:
+            # branch convolutions + blend epilogue in one kernel: the [K, N, Cout + 3] branch tensor never exists
+            return ops.dynconv_fused_sbf(x.contiguous(), p[f"{name}.ws"], p.get(f"{name}.bs"), dc.out_c, dc.size_kernels,
+                                         p[f"{name}.m1"], p[f"{name}.mb"], p[f"{name}.m2"], epi, T, stats_slope, in_affine=aff)
         branches = torch.empty((nk, xs.shape[0], dc.out_c + 3, H, W), dtype=torch.float32, device=x.device)
-        if f"{name}.ws" in p and ops.dynconv_sbf_supported(Cin, dc.out_c + 3, dc.size_kernels, W):
+        if sbf:
             # all kernel sizes from one staged tile on the matrix cores (split-bf16 arithmetic)
             ops.dynconv_branches_sbf(xs.contiguous(), p[f"{name}.ws"], p.get(f"{name}.bs"), dc.out_c + 3, dc.size_kernels,
                                      out=branches, in_affine=affs)

@@ -578,6 +578,39 @@ def dynconv_branches_sbf(x: Tensor, wsplit: Tensor, bias: Optional[Tensor], co3:
     return out
 
 
+def dynconv_fused_sbf(x: Tensor, wsplit: Tensor, bias: Optional[Tensor], cout: int, ksizes, w1: Tensor, b1: Tensor, w2: Tensor,
+                      epipoles: Tensor, temperature: float, stats_slope: float, in_affine: Optional[Tensor] = None):
+    """One DynamicConv in one kernel (branch convolutions on the matrix cores + the blend epilogue on their accumulators):
+    x [N,Cin,H,W] (+ its pending affine) -> (out [N,cout,H,W], norm_curv [N,H,W], stats [N,cout,2] float64, affine [N,cout,3]),
+    the same tuple as ``dynconv_blend(dynconv_branches_sbf(...), ..., stats_slope=...)`` without the branch tensor."""
+    N, Cin, H, W = x.shape
+    K = len(ksizes)
+    if in_affine is not None and tuple(in_affine.shape) != (N, Cin, 3):
+        raise ValueError(f"dynconv_fused_sbf: in_affine must be [{N},{Cin},3]")
+    if bias is not None and tuple(bias.shape) != (K, cout + 3):
+        raise ValueError("dynconv_fused_sbf: bias must be [K, cout + 3]")
+    if tuple(epipoles.shape) != (N, 2):
+        raise ValueError("dynconv_fused_sbf: epipoles must be [N,2]")
+    dev = x.device
+    lib = _lib.load()
+    out = torch.empty((N, cout, H, W), dtype=torch.float32, device=dev)
+    nc = torch.empty((N, H, W), dtype=torch.float32, device=dev)
+    parts = lib.cds_dynconv_fused_parts(H, W)
+    partial = torch.empty((N, parts, cout, 2), dtype=torch.float64, device=dev)
+    stats = torch.empty((N, cout, 2), dtype=torch.float64, device=dev)
+    affine = torch.empty((N, cout, 3), dtype=torch.float32, device=dev)
+    import ctypes
+    ks = (ctypes.c_int * K)(*[int(k) for k in ksizes])
+    check(lib.cds_dynconv_fused_sbf_f32(_dev(x, "x"), _dev(in_affine, "in_affine") if in_affine is not None else None,
+                                        wsplit.data_ptr(), _dev(bias, "bias") if bias is not None else None, _dev(w1, "w1"),
+                                        _dev(b1, "b1"), _dev(w2, "w2"), _host(epipoles, "epipoles"), float(temperature),
+                                        out.data_ptr(), nc.data_ptr(), partial.data_ptr(), N, Cin, cout, H, W, ks, K, _stream(x)),
+          "cds_dynconv_fused_sbf_f32")
+    check(lib.cds_instnorm_reduce_f32(partial.data_ptr(), parts, stats.data_ptr(), affine.data_ptr(), N, cout, H, W,
+                                      float(stats_slope), _stream(out)), "cds_instnorm_reduce_f32")
+    return out, nc, stats, affine
+
+
 def conv2d_fpn(coarse: Tensor, skip: Tensor, wpk: Tensor, cout: int, coarse_affine: Optional[Tensor] = None,
                skip_affine: Optional[Tensor] = None, stats_slope: Optional[float] = None):
     """FPN lateral (module.py:253-254,260-261): 1x1 conv of cat(nearest2x(coarse), skip) without building either.

@@ -226,6 +226,20 @@ int cds_conv2d_k3_c16_f32(const float* x, const float* weight_cl, const float* b
 int cds_dynconv_branches_sbf_f32(const float* x, const float* in_affine, const void* weight_split, const float* bias,
                                  float* out, int N, int Cin, int Co3, int H, int W, const int* ksizes, int nb, void* stream);
 
+/* One DynamicConv (models/dynamic_conv.py:97-122) in ONE kernel: the branch convolutions of cds_dynconv_branches_sbf_f32 with
+ * the epilogue of cds_dynconv_blend_stats_f32 (epipolar projection of the curvature responses, 1x1 MLP, softmax(./T), blend,
+ * InstanceNorm records of the result) applied to the accumulators: the [K][N][Cout + 3] branch tensor never reaches HBM.
+ *   out [N][Cout][H][W] (before its InstanceNorm), norm_curv [N][H][W]
+ *   partial: 8-byte aligned scratch of 2 * N * parts * Cout doubles, parts = cds_dynconv_fused_parts(H, W); reduce with
+ *            cds_instnorm_reduce_f32
+ *   w1 [4][K], b1 [4], w2 [K][4]: the attention MLP with its BatchNorm folded in; epipoles_host [N][2] (pixels, this resolution)
+ * K in {2, 3}, kernel sizes in {1, 3, 5, 7}, Cin % 8 == 0, Cout + 3 <= 48, Cout % 16 <= 13, W % 4 == 0, N <= CDS_MAX_IMAGES. */
+int cds_dynconv_fused_sbf_f32(const float* x, const float* in_affine, const void* weight_split, const float* bias,
+                              const float* w1, const float* b1, const float* w2, const float* epipoles_host,
+                              float temperature, float* out, float* norm_curv, double* partial, int N, int Cin, int Cout,
+                              int H, int W, const int* ksizes, int nb, void* stream);
+int cds_dynconv_fused_parts(int H, int W);
+
 /*
  * FPN lateral connection (module.py:253-254, 260-261): the 1x1 convolution of
  *   cat(interpolate(coarse, scale_factor=2, mode="nearest"), skip)

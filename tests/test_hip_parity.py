@@ -914,3 +914,31 @@ def test_dynconv_branches_on_matrix_cores(cin, cout, ks, N, H, W, bias, dev, ops
         ulp = want64.abs().max().item() * 2.0 ** -23
         assert err <= 1.5 * ref + ulp, (k, err, ref)
         assert (got[i] - valu).abs().max().item() < 2e-5 * max(1.0, want64.abs().max().item())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cin,cout,ks,N,H,W,bias", [(8, 8, (3, 5, 7), 2, 21, 44, True), (16, 16, (3, 5), 3, 16, 36, True),
+                                                   (32, 32, (1, 3), 2, 9, 20, False), (8, 8, (1, 3), 1, 8, 64, True),
+                                                   (16, 16, (3, 5), 1, 40, 100, False)])
+def test_dynconv_fused_equals_branches_then_blend(cin, cout, ks, N, H, W, bias, dev, ops):
+    """cds_dynconv_fused_sbf_f32 (branch convolutions + the blend epilogue on their accumulators, one kernel) against the two
+    kernels it replaces (cds_dynconv_branches_sbf_f32 -> cds_dynconv_blend_stats_f32): same arithmetic in the same order, so the
+    blended output and the norm-curvature map must be bit-identical; the InstanceNorm statistics are summed in another grouping
+    (fp64) and agree to rounding.  Sizes with partial tiles, several images, T that saturates and T that does not."""
+    g = torch.Generator().manual_seed(cin * 3 + len(ks) + H)
+    K = len(ks)
+    x = torch.randn(N, cin, H, W, generator=g)
+    aff = torch.stack((0.5 + torch.rand(N, cin, generator=g), 0.3 * torch.randn(N, cin, generator=g),
+                       torch.full((N, cin), 0.1)), dim=-1).contiguous()
+    co3 = cout + 3
+    ws = ops.split_pack_dynconv([(torch.randn(co3, cin, k, k, generator=g) / (cin * k * k) ** 0.5).to(dev) for k in ks])
+    bs = torch.randn(K, co3, generator=g).to(dev) if bias else None
+    w1, b1, w2 = torch.randn(4, K, generator=g).to(dev), torch.randn(4, generator=g).to(dev), torch.randn(K, 4, generator=g).to(dev)
+    epi = torch.tensor([[W * 0.3 + 5.0 * n, -H * 1.7 - n] for n in range(N)], dtype=torch.float32)
+    for T in (1.0, 0.01):
+        br = ops.dynconv_branches_sbf(x.to(dev), ws, bs, co3, ks, in_affine=aff.to(dev))
+        o2, n2, s2, a2 = ops.dynconv_blend(br, w1, b1, w2, epi, T, 1, stats_slope=0.1)
+        o1, n1, s1, a1 = ops.dynconv_fused_sbf(x.to(dev), ws, bs, cout, ks, w1, b1, w2, epi, T, 0.1, in_affine=aff.to(dev))
+        assert torch.equal(o1, o2) and torch.equal(n1, n2)
+        assert torch.allclose(s1, s2, rtol=1e-12, atol=1e-9)
+        assert torch.allclose(a1, a2, rtol=1e-6, atol=1e-7)
