@@ -420,7 +420,7 @@ class _FeatureRunner:
                 out[f"{name}.w{i}"] = _pack2d(w)
                 if dc.convs[i].bias is not None:
                     out[f"{name}.b{i}"] = torch.cat((dc.convs[i].bias.detach(), torch.zeros(3, device=dev))).contiguous()
-            if ops.dynconv_sbf_supported(dc.in_c, dc.out_c + 3, dc.size_kernels, 4) and dc.att_convs[0].weight.is_cuda:
+            if ops.dynconv_sbf_supported(dc.in_c, dc.out_c + 3, dc.size_kernels, 4, fused=USE_FUSED_BLEND) and dc.att_convs[0].weight.is_cuda:
                 out[f"{name}.ws"] = ops.split_pack_dynconv([torch.cat((dc.convs[i].weight.detach(), dc.att_convs[i].weight.detach()), dim=0)
                                                             for i in range(len(dc.size_kernels))])
                 if dc.convs[0].bias is not None:
@@ -451,8 +451,9 @@ class _FeatureRunner:
         nk = len(dc.size_kernels)
         xs = x[n_shared - 1:] if n_shared > 1 else x
         affs = aff[n_shared - 1:].contiguous() if (aff is not None and n_shared > 1) else aff
-        sbf = f"{name}.ws" in p and ops.dynconv_sbf_supported(Cin, dc.out_c + 3, dc.size_kernels, W)
-        if sbf and USE_FUSED_BLEND and n_shared == 1 and stats_slope is not None and nk >= 2 and N <= ops.MAX_IMAGES:
+        fusable = USE_FUSED_BLEND and n_shared == 1 and stats_slope is not None and nk >= 2 and N <= ops.MAX_IMAGES
+        sbf = f"{name}.ws" in p and ops.dynconv_sbf_supported(Cin, dc.out_c + 3, dc.size_kernels, W, fused=fusable)
+        if sbf and fusable:
             # branch convolutions + blend epilogue in one kernel: the [K, N, Cout + 3] branch tensor never exists
             return ops.dynconv_fused_sbf(x.contiguous(), p[f"{name}.ws"], p.get(f"{name}.bs"), dc.out_c, dc.size_kernels,
                                          p[f"{name}.m1"], p[f"{name}.mb"], p[f"{name}.m2"], epi, T, stats_slope, in_affine=aff)

@@ -526,14 +526,15 @@ def conv2d_k3_c16(x: Tensor, wcl: Tensor, bias: Optional[Tensor], act: int = ACT
     return out
 
 
-def dynconv_sbf_supported(Cin: int, co3: int, ksizes, W: int) -> bool:
+def dynconv_sbf_supported(Cin: int, co3: int, ksizes, W: int, fused: bool = False) -> bool:
     """Shapes cds_dynconv_branches_sbf_f32 covers (everything in FeatureNet but conv00, whose 3 input channels and 11 x 11
     kernel would leave the matrix tiles mostly padding)."""
     nb, nblk = len(ksizes), (co3 + 15) // 16
     # measured at the 1600x1184 cascade shapes (scripts/time_dynconv_sbf.py, 8 images): conv01 3.02 -> 1.96 ms, conv10 1.21 ->
     # 0.75, conv20 0.42 -> 0.37; the (1, 3) branches of the 8- / 16-channel output layers have too few taps to amortise the
     # staged tile (out2 0.44 -> 0.50, out3 0.77 -> 0.88): those stay on the VALU kernels
-    worth = max(ksizes) >= 5 or Cin >= 32
+    # (with the blend fused behind them - dynconv_fused_sbf - they pay as well: the VALU branches + the separate blend cost more)
+    worth = fused or max(ksizes) >= 5 or Cin >= 32
     return (USE_CONV2D_SBF and worth and Cin % 8 == 0 and W % 4 == 0 and all(k in (1, 3, 5, 7) for k in ksizes)
             and (nb, nblk) in ((3, 1), (3, 2), (2, 1), (2, 2), (2, 3)))
 
