@@ -66,7 +66,7 @@ struct Blend {
   const float* w2;      // [K][4]
   float* out;           // [N][Cout][H][W]
   float* norm_curv;     // [N][H][W]
-  double* partial;      // [N][parts = tiles * 4][Cout][2]
+  double* partial;      // [N][parts = tiles][Cout][2]
   float temperature;
   float ex[CDS_MAX_IMAGES], ey[CDS_MAX_IMAGES];
 };
@@ -262,8 +262,7 @@ __global__ __launch_bounds__(256, 2) void dynconv_branches_sbf_kernel(const floa
     for (int b = 0; b < NBR; ++b)
 #pragma unroll
       for (int q = 0; q < 4; ++q) wq[b][q] = *reinterpret_cast<const float4*>(wL + b * 256 + wave * 64 + q * 16 + g * 4);
-    const int parts = tiles_x * tiles_y * 4;
-    double* rec = bl.partial + (((size_t)img * parts + (size_t)(ty_i * tiles_x + tx_i) * 4 + wave) * Cout) * 2;
+    double* red = reinterpret_cast<double*>(lds + 16384);      // [wave][NBLK * 16][2]: the four waves' sums of a tile, added below
 #pragma unroll
     for (int nb = 0; nb < NBLK; ++nb) {
       const int co = nb * 16 + m;
@@ -304,10 +303,18 @@ __global__ __launch_bounds__(256, 2) void dynconv_branches_sbf_kernel(const floa
       dq += __shfl_xor(dq, 16);
       ds += __shfl_xor(ds, 32);
       dq += __shfl_xor(dq, 32);
-      if (col && g == 0) {
-        rec[2 * co] = ds;
-        rec[2 * co + 1] = dq;
+      if (g == 0) {
+        red[(wave * NBLK * 16 + co) * 2] = ds;
+        red[(wave * NBLK * 16 + co) * 2 + 1] = dq;
       }
+    }
+    __syncthreads();
+    // one record per (tile, channel): the four waves in a fixed order
+    if (tid < NBLK * 16 && tid < Cout) {
+      const int parts = tiles_x * tiles_y;
+      double* rec = bl.partial + (((size_t)img * parts + (size_t)(ty_i * tiles_x + tx_i)) * Cout + tid) * 2;
+      rec[0] = (red[tid * 2] + red[(NBLK * 16 + tid) * 2]) + (red[(2 * NBLK * 16 + tid) * 2] + red[(3 * NBLK * 16 + tid) * 2]);
+      rec[1] = (red[tid * 2 + 1] + red[(NBLK * 16 + tid) * 2 + 1]) + (red[(2 * NBLK * 16 + tid) * 2 + 1] + red[(3 * NBLK * 16 + tid) * 2 + 1]);
     }
     return;
   }
@@ -372,8 +379,8 @@ extern "C" int cds_dynconv_branches_sbf_f32(const float* x, const float* in_affi
   return cds_launch_status();
 }
 
-// Records per image that cds_dynconv_fused_sbf_f32 leaves for cds_instnorm_reduce_f32: 4 per 32 x 8 tile.
-extern "C" int cds_dynconv_fused_parts(int H, int W) { return 4 * cds_ceil_div(W, TX) * cds_ceil_div(H, TY); }
+// Records per image that cds_dynconv_fused_sbf_f32 leaves for cds_instnorm_reduce_f32: one per 32 x 8 tile.
+extern "C" int cds_dynconv_fused_parts(int H, int W) { return cds_ceil_div(W, TX) * cds_ceil_div(H, TY); }
 
 // One DynamicConv (dynamic_conv.py:97-122) in ONE kernel: the branch convolutions of cds_dynconv_branches_sbf_f32 with the
 // epilogue of cds_dynconv_blend_stats_f32 applied to the accumulators.  out [N][Cout][H][W] (before its InstanceNorm),
