@@ -54,6 +54,7 @@ SIGNATURES = {
     "cds_dynconv_branches_sbf_f32": [P, P, P, P, P, I, I, I, I, I, P, I, P],
     "cds_dynconv_fused_sbf_f32": [P, P, P, P, P, P, P, P, F, P, P, P, I, I, I, I, I, P, I, P],
     "cds_dynconv_fused_parts": [I, I],
+    "cds_conv2d_k3_relu_sbf_f32": [P, P, P, P, P, P, I, I, I, I, P],
     "cds_dynconv_blend_f32": [P, P, P, P, P, F, P, P, I, I, I, I, I, P],
     "cds_dynconv_blend_shared_f32": [P, P, P, P, P, F, P, P, I, I, I, I, I, I, P],
     "cds_blend_stats_parts": [I, I],

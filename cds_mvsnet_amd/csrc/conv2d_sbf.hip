@@ -45,6 +45,15 @@ __device__ __forceinline__ void split2(float a, float b, uint32_t& hi, uint32_t&
 #define SBF_MFMA(acc, a, b) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16((a).v, (b).v, acc, 0, 0, 0)
 
 constexpr int POSB = 48;
+
+// sum over the 16 lanes of a DPP row (all lanes end up with the total)
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+  v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
+  v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x141, 0xf, 0xf, true));  // row_half_mirror
+  v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x140, 0xf, 0xf, true));  // row_mirror
+  return v;
+}
 constexpr int TX = 32, TY = 8, R = 3;                 // tile, halo
 constexpr int IXP = TX + 8, IY = TY + 2 * R;          // column c <-> x = ox0 - 4 + c (16-byte aligned global rows)
 constexpr int NPOS = IY * IXP;                        // 560 positions = 26.9 KB
@@ -72,7 +81,7 @@ struct Blend {
 };
 
 // NBR branches, NBLK 16-cout blocks (Cout + 3 <= 16 NBLK)
-template <int NBR, int NBLK, bool FUSE>
+template <int NBR, int NBLK, int MODE>   // MODE 0: branch tensor; 1: blend epilogue fused; 2: ReLU (+ 1x1 head + sigmoid), one branch
 __global__ __launch_bounds__(256, 2) void dynconv_branches_sbf_kernel(const float* __restrict__ x, const float* __restrict__ affine,
                                                                       const uint4* __restrict__ wsp, const float* __restrict__ bias,
                                                                       float* __restrict__ out, Branches br, int N, int Cin, int Co3,
@@ -189,7 +198,32 @@ __global__ __launch_bounds__(256, 2) void dynconv_branches_sbf_kernel(const floa
     }
   }
 
-  if (FUSE) {
+  if (MODE == 2) {
+    // visibility CNN layer (model.py:14): ReLU(conv + folded BatchNorm), and for the last layer the 1x1 head + sigmoid
+    // (bl.w1 = head weights [16], bl.b1 = head bias [1], bl.out = [N][H][W]); else out [N][16][H][W]
+    const float bv = bias ? bias[m] : 0.f;
+    const bool head = bl.w1 != nullptr;
+    const float hw_n = head ? bl.w1[m] : 0.f, hb = head ? bl.b1[0] : 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int oy = oy0 + wave * 2 + (q >> 1), ox = ox0 + (q & 1) * 16 + g * 4;
+      const f32x4 a = acc[0][0][q];
+      float v[4] = {fmaxf(a.x + bv, 0.f), fmaxf(a.y + bv, 0.f), fmaxf(a.z + bv, 0.f), fmaxf(a.w + bv, 0.f)};
+      if (head) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float sacc = row16_sum(v[i] * hw_n) + hb;
+          v[i] = 1.0f / (1.0f + expf(-sacc));
+        }
+        if (m == 0 && oy < H && ox < W)
+          *reinterpret_cast<float4*>(bl.out + (size_t)img * plane + (size_t)oy * W + ox) = make_float4(v[0], v[1], v[2], v[3]);
+      } else if (m < Co3 && oy < H && ox < W) {
+        *reinterpret_cast<float4*>(bl.out + ((size_t)img * Co3 + m) * plane + (size_t)oy * W + ox) = make_float4(v[0], v[1], v[2], v[3]);
+      }
+    }
+    return;
+  }
+  if (MODE == 1) {
     // Accumulator layout: lane (m, g) holds column 16 nb + m of pixels x = (q & 1) 16 + 4 g + i, y = 2 wave + (q >> 1).
     // (1) the lanes of the three curvature columns leave them in LDS; (2) lane m of a 16-lane group owns pixel (q, i) = (m >> 2,
     // m & 3) of its group: projection, MLP, softmax -> K weights into LDS, norm_curv to memory; (3) every lane reads the weights
@@ -367,7 +401,7 @@ extern "C" int cds_dynconv_branches_sbf_f32(const float* x, const float* in_affi
   const size_t ldsb = (size_t)NPOS * POSB;
   hipStream_t st = (hipStream_t)stream;
 #define LAUNCH(NBR, NBLK)                                                                                                    \
-  hipLaunchKernelGGL((dynconv_branches_sbf_kernel<NBR, NBLK, false>), grid, block, ldsb, st, x, in_affine,                   \
+  hipLaunchKernelGGL((dynconv_branches_sbf_kernel<NBR, NBLK, 0>), grid, block, ldsb, st, x, in_affine,                   \
                      reinterpret_cast<const uint4*>(weight_split), bias, out, br, N, Cin, Co3, H, W, tx, ty, Blend{})
   if (nb == 3 && nblk == 1) LAUNCH(3, 1);
   else if (nb == 2 && nblk == 1) LAUNCH(2, 1);
@@ -420,7 +454,7 @@ extern "C" int cds_dynconv_fused_sbf_f32(const float* x, const float* in_affine,
   const size_t ldsb = (size_t)NPOS * POSB;
   hipStream_t st = (hipStream_t)stream;
 #define LAUNCHF(NBR, NBLK)                                                                                                   \
-  hipLaunchKernelGGL((dynconv_branches_sbf_kernel<NBR, NBLK, true>), grid, block, ldsb, st, x, in_affine,                    \
+  hipLaunchKernelGGL((dynconv_branches_sbf_kernel<NBR, NBLK, 1>), grid, block, ldsb, st, x, in_affine,                    \
                      reinterpret_cast<const uint4*>(weight_split), bias, nullptr, br, N, Cin, Co3, H, W, tx, ty, bl)
   if (nb == 3 && nblk == 1) LAUNCHF(3, 1);
   else if (nb == 2 && nblk == 1) LAUNCHF(2, 1);
@@ -429,5 +463,32 @@ extern "C" int cds_dynconv_fused_sbf_f32(const float* x, const float* in_affine,
   else if (nb == 3 && nblk == 2) LAUNCHF(3, 2);
   else return CDS_EINVAL;
 #undef LAUNCHF
+  return cds_launch_status();
+}
+
+
+// 3x3 convolution 8k -> 16 channels (pad 1) + bias + ReLU in split-bf16 arithmetic on the matrix cores, optionally followed by
+// a 1x1 head (16 -> 1) + sigmoid: the visibility CNN's layers 2 and 3 + head (models/model.py:14; BatchNorm folded by the
+// caller).  x [N][Cin][H][W], weight_split from ops.split_pack_dynconv([w]) with w [16][Cin][3][3], bias [16];
+// head_w [16] / head_b [1] or both NULL; out [N][16][H][W], or [N][H][W] with the head.  Cin % 8 == 0, W % 4 == 0.
+extern "C" int cds_conv2d_k3_relu_sbf_f32(const float* x, const void* weight_split, const float* bias, const float* head_w,
+                                          const float* head_b, float* out, int N, int Cin, int H, int W, void* stream) {
+  if (!x || !weight_split || !out || N < 1 || Cin < 8 || (Cin % 8) || H < 1 || W < 4 || (W % 4) ||
+      (head_w != nullptr) != (head_b != nullptr))
+    return CDS_EINVAL;
+  Branches br;
+  br.nb = 1;
+  for (int b = 0; b < MAXB; ++b) {
+    br.k[b] = b == 0 ? 3 : 1;
+    br.ks0[b] = b == 0 ? 0 : 3;
+  }
+  br.nks = 3;
+  Blend bl{};
+  bl.w1 = head_w;
+  bl.b1 = head_b;
+  bl.out = out;
+  const int tx = cds_ceil_div(W, TX), ty = cds_ceil_div(H, TY);
+  hipLaunchKernelGGL((dynconv_branches_sbf_kernel<1, 1, 2>), dim3(tx * ty * N), dim3(256), (size_t)NPOS * POSB, (hipStream_t)stream, x,
+                     nullptr, reinterpret_cast<const uint4*>(weight_split), bias, nullptr, br, N, Cin, 16, H, W, tx, ty, bl);
   return cds_launch_status();
 }

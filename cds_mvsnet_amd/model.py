@@ -556,8 +556,10 @@ class StageNet(_PackedHolder):
                 wf = seq[i].conv.weight.detach() * scale.view(-1, 1, 1, 1)
                 out[f"{s}.w{i}"] = _pack2d(wf)
                 out[f"{s}.b{i}"] = shift.contiguous()
-                if i > 0:    # 16 -> 16: matrix-core layout [tap][cout][cin]
+                if i > 0:    # 16 -> 16: matrix-core layouts: fp32 MFMA [tap][cout][cin]; split-bf16 (the DynamicConv kernel's)
                     out[f"{s}.wcl{i}"] = wf.permute(2, 3, 0, 1).reshape(9, 16, 16).contiguous()
+                    if USE_SPLIT_BF16 and wf.is_cuda:
+                        out[f"{s}.ws{i}"] = ops.split_pack_dynconv([wf])
             out[f"{s}.w3"] = _pack2d(seq[3].weight.detach())
             out[f"{s}.b3"] = seq[3].bias.detach().contiguous()
             out[f"{s}.hw"] = seq[3].weight.detach().reshape(16).contiguous()
@@ -570,6 +572,10 @@ class StageNet(_PackedHolder):
         with ops.prof("visibility_cnn"):
             x = torch.stack((entropy, ref_nc), dim=1)
             x = ops.conv2d(x, p[f"{s}.w0"], p[f"{s}.b0"], 16, 3, 1, 1, ACT_RELU)
+            if f"{s}.ws1" in p and ops.USE_CONV2D_SBF and x.shape[-1] % 4 == 0:
+                # layers 2 and 3 on the bf16 matrix cores in split-bf16 arithmetic; the last one applies the 1x1 head + sigmoid
+                x = ops.conv2d_k3_relu_sbf(x, p[f"{s}.ws1"], p[f"{s}.b1"])
+                return ops.conv2d_k3_relu_sbf(x, p[f"{s}.ws2"], p[f"{s}.b2"], head_w=p[f"{s}.hw"], head_b=p[f"{s}.b3"])
             if ops.conv2d_c16_supported(x):
                 # matrix-core layers; the last one also applies the 1x1 head + sigmoid
                 x = ops.conv2d_k3_c16(x, p[f"{s}.wcl1"], p[f"{s}.b1"], ACT_RELU)

@@ -526,6 +526,24 @@ def conv2d_k3_c16(x: Tensor, wcl: Tensor, bias: Optional[Tensor], act: int = ACT
     return out
 
 
+def conv2d_k3_relu_sbf(x: Tensor, wsplit: Tensor, bias: Optional[Tensor], head_w: Optional[Tensor] = None,
+                       head_b: Optional[Tensor] = None) -> Tensor:
+    """3x3, pad 1, Cin -> 16 channels + bias + ReLU in split-bf16 arithmetic on the matrix cores (visibility CNN, model.py:14);
+    with head_w [16] / head_b [1] the 1x1 head + sigmoid is applied in the same kernel and the result is [N,H,W].
+    wsplit = split_pack_dynconv([w]) with w [16,Cin,3,3]."""
+    N, C, H, W = x.shape
+    if C % 8 or W % 4:
+        raise ValueError(f"conv2d_k3_relu_sbf: need Cin % 8 == 0 and W % 4 == 0, got {tuple(x.shape)}")
+    if (head_w is None) != (head_b is None) or (head_w is not None and (head_w.numel() != 16 or head_b.numel() != 1)):
+        raise ValueError("conv2d_k3_relu_sbf: head_w [16] and head_b [1] go together")
+    out = torch.empty((N, H, W) if head_w is not None else (N, 16, H, W), dtype=torch.float32, device=x.device)
+    check(_lib.load().cds_conv2d_k3_relu_sbf_f32(_dev(x, "x"), wsplit.data_ptr(), _dev(bias, "bias") if bias is not None else None,
+                                                 _dev(head_w, "head_w") if head_w is not None else None,
+                                                 _dev(head_b, "head_b") if head_b is not None else None,
+                                                 _dev(out, "out"), N, C, H, W, _stream(x)), "cds_conv2d_k3_relu_sbf_f32")
+    return out
+
+
 def dynconv_sbf_supported(Cin: int, co3: int, ksizes, W: int, fused: bool = False) -> bool:
     """Shapes cds_dynconv_branches_sbf_f32 covers (everything in FeatureNet but conv00, whose 3 input channels and 11 x 11
     kernel would leave the matrix tiles mostly padding)."""

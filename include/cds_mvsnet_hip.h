@@ -240,6 +240,13 @@ int cds_dynconv_fused_sbf_f32(const float* x, const float* in_affine, const void
                               int H, int W, const int* ksizes, int nb, void* stream);
 int cds_dynconv_fused_parts(int H, int W);
 
+/* Visibility-CNN layers 2 and 3 (models/model.py:14: Conv2d 16 -> 16 k3 p1 + BatchNorm(folded) + ReLU; the last one followed by
+ * the 1x1 head 16 -> 1 + sigmoid) in split-bf16 arithmetic on the bf16 matrix cores (the same kernel as the DynamicConv
+ * branches, one branch).  x [N][Cin][H][W], weight_split = ops.split_pack_dynconv([w]) with w [16][Cin][3][3], bias [16];
+ * head_w [16] / head_b [1] or both NULL; out [N][16][H][W], or [N][H][W] with the head.  Cin % 8 == 0, W % 4 == 0. */
+int cds_conv2d_k3_relu_sbf_f32(const float* x, const void* weight_split, const float* bias, const float* head_w,
+                               const float* head_b, float* out, int N, int Cin, int H, int W, void* stream);
+
 /*
  * FPN lateral connection (module.py:253-254, 260-261): the 1x1 convolution of
  *   cat(interpolate(coarse, scale_factor=2, mode="nearest"), skip)

@@ -942,3 +942,27 @@ def test_dynconv_fused_equals_branches_then_blend(cin, cout, ks, N, H, W, bias, 
         assert torch.equal(o1, o2) and torch.equal(n1, n2)
         assert torch.allclose(s1, s2, rtol=1e-12, atol=1e-9)
         assert torch.allclose(a1, a2, rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,H,W", [(4, 20, 36), (1, 8, 32), (3, 13, 100)])
+def test_visibility_layers_split_bf16(N, H, W, dev, ops):
+    """cds_conv2d_k3_relu_sbf_f32 (visibility CNN layers 2 / 3 + head, model.py:14, split-bf16 on the bf16 matrix cores) against
+    float64 and the fp32-MFMA kernel it replaces (cds_conv2d_k3_c16_f32): fp32-class, with and without the fused 1x1 head."""
+    g = torch.Generator().manual_seed(N * 100 + W)
+    x = torch.randn(N, 16, H, W, generator=g).clamp_min(0)
+    w = torch.randn(16, 16, 3, 3, generator=g) / 12.0
+    b = torch.randn(16, generator=g) * 0.2
+    hw, hb = torch.randn(16, generator=g) * 0.3, torch.randn(1, generator=g)
+    y64 = F.conv2d(x.double(), w.double(), b.double(), padding=1).clamp_min(0)
+    ws = ops.split_pack_dynconv([w.to(dev)])
+    wcl = w.permute(2, 3, 0, 1).reshape(9, 16, 16).contiguous().to(dev)
+    got = ops.conv2d_k3_relu_sbf(x.to(dev), ws, b.to(dev)).cpu()
+    old = ops.conv2d_k3_c16(x.to(dev), wcl, b.to(dev)).cpu()
+    e_new, e_old = (got.double() - y64).abs().max().item(), (old.double() - y64).abs().max().item()
+    ulp = y64.abs().max().item() * 2.0 ** -23
+    assert e_new <= 1.5 * e_old + ulp, (e_new, e_old)
+    h64 = torch.sigmoid((y64 * hw.double().view(1, 16, 1, 1)).sum(1) + hb.double())
+    goth = ops.conv2d_k3_relu_sbf(x.to(dev), ws, b.to(dev), head_w=hw.to(dev), head_b=hb.to(dev)).cpu()
+    oldh = ops.conv2d_k3_c16(x.to(dev), wcl, b.to(dev), head_w=hw.to(dev), head_b=hb.to(dev)).cpu()
+    assert (goth.double() - h64).abs().max().item() <= 1.5 * (oldh.double() - h64).abs().max().item() + 2.0 ** -23
