@@ -695,22 +695,46 @@ __global__ __launch_bounds__(256) void instnorm_stats_kernel(const float* __rest
 }
 
 // x: [N][C][hw]; stats per (n,c); out: [N][C][hw] or channels-last [N][hw][C]; image n = blockIdx.y
+// CT > 0: C == CT known at compile time (8 / 16 / 32: the FeatureNet stage outputs): the per-channel (alpha, beta) are
+// computed once per workgroup (they were two fp64 divisions and a square root per thread and channel) and a channels-last
+// pixel leaves as CT / 4 16-byte stores on CT * 4 contiguous bytes instead of CT scattered dwords.
+template <int CT>
 __global__ __launch_bounds__(256) void instnorm_apply_kernel(const float* __restrict__ x,
                                                              const double* __restrict__ stats, float* __restrict__ out,
                                                              int C, int hw, int act, int out_hwc) {
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= hw) return;
+  __shared__ float ab[2][64];
   const int n = blockIdx.y;
-  x += (size_t)n * C * hw;
-  out += (size_t)n * C * hw;
   stats += (size_t)n * 2 * C;
-  for (int c = 0; c < C; ++c) {
+  if ((int)threadIdx.x < C) {
+    const int c = threadIdx.x;
     const double mean = stats[2 * c] / hw;
     double var = stats[2 * c + 1] / hw - mean * mean;
     var = var < 0.0 ? 0.0 : var;
     const float invstd = (float)(1.0 / sqrt(var + 1e-5));
-    const float alpha = invstd, beta = -(float)mean * invstd;
-    float v = cds_apply_act(x[(size_t)c * hw + p] * alpha + beta, act);
+    ab[0][c] = invstd;
+    ab[1][c] = -(float)mean * invstd;
+  }
+  __syncthreads();
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= hw) return;
+  x += (size_t)n * C * hw;
+  out += (size_t)n * C * hw;
+  if (CT > 0) {
+    float v[CT > 0 ? CT : 1];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) v[c] = cds_apply_act(x[(size_t)c * hw + p] * ab[0][c] + ab[1][c], act);
+    if (out_hwc) {
+      float4* o4 = reinterpret_cast<float4*>(out + (size_t)p * CT);
+#pragma unroll
+      for (int c = 0; c < CT; c += 4) o4[c >> 2] = make_float4(v[c], v[c + 1], v[c + 2], v[c + 3]);
+    } else {
+#pragma unroll
+      for (int c = 0; c < CT; ++c) out[(size_t)c * hw + p] = v[c];
+    }
+    return;
+  }
+  for (int c = 0; c < C; ++c) {
+    float v = cds_apply_act(x[(size_t)c * hw + p] * ab[0][c] + ab[1][c], act);
     if (out_hwc)
       out[(size_t)p * C + c] = v;
     else
@@ -928,8 +952,14 @@ extern "C" int cds_instnorm_apply_f32(const float* x, const float* stats, float*
                                       int out_hwc, void* stream) {
   if (!x || !out || !stats || N < 1 || C < 1 || H < 1 || W < 1) return CDS_EINVAL;
   const int hw = H * W;
-  hipLaunchKernelGGL(instnorm_apply_kernel, dim3(cds_ceil_div(hw, 256), N), dim3(256), 0, (hipStream_t)stream, x,
-                     reinterpret_cast<const double*>(stats), out, C, hw, act, out_hwc);
+  if (C > 64) return CDS_EINVAL;
+  const dim3 grid(cds_ceil_div(hw, 256), N), block(256);
+  const double* st64 = reinterpret_cast<const double*>(stats);
+  hipStream_t st = (hipStream_t)stream;
+  if (C == 8) hipLaunchKernelGGL(instnorm_apply_kernel<8>, grid, block, 0, st, x, st64, out, C, hw, act, out_hwc);
+  else if (C == 16) hipLaunchKernelGGL(instnorm_apply_kernel<16>, grid, block, 0, st, x, st64, out, C, hw, act, out_hwc);
+  else if (C == 32) hipLaunchKernelGGL(instnorm_apply_kernel<32>, grid, block, 0, st, x, st64, out, C, hw, act, out_hwc);
+  else hipLaunchKernelGGL(instnorm_apply_kernel<0>, grid, block, 0, st, x, st64, out, C, hw, act, out_hwc);
   return cds_launch_status();
 }
 
@@ -969,7 +999,8 @@ extern "C" int cds_instnorm_act_f32(const float* x, float* out, float* stats, in
   int bpc = cds_ceil_div(hw, 256 * 16);
   if (bpc < 1) bpc = 1;
   hipLaunchKernelGGL(instnorm_stats_kernel, dim3(N * C * bpc), dim3(256), 0, st, x, dstats, hw, bpc);
-  hipLaunchKernelGGL(instnorm_apply_kernel, dim3(cds_ceil_div(hw, 256), N), dim3(256), 0, st, x, dstats, out, C, hw, act,
+  if (C > 64) return CDS_EINVAL;
+  hipLaunchKernelGGL(instnorm_apply_kernel<0>, dim3(cds_ceil_div(hw, 256), N), dim3(256), 0, st, x, dstats, out, C, hw, act,
                      out_hwc);
   return cds_launch_status();
 }
