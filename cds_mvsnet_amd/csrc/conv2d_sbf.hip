@@ -113,8 +113,10 @@ __global__ __launch_bounds__(256, 2) void dynconv_branches_sbf_kernel(const floa
   for (int rd = 0; rd < rounds; ++rd) {
     if (rd) __syncthreads();
     // ---- stage 8 channels: unit = (row, x-quad): 8 float4 (one per channel), normalise-on-load, split, 4 positions ----
-    for (int u = tid; u < IY * (IXP / 4); u += 256) {
-      const int row = u / (IXP / 4), q = u - row * (IXP / 4);
+    // (mode 2 is always 3x3: only the rows of a 1-pixel halo are staged)
+    constexpr int ROW0 = MODE == 2 ? R - 1 : 0, ROWS = MODE == 2 ? TY + 2 : IY;
+    for (int u = tid; u < ROWS * (IXP / 4); u += 256) {
+      const int row = ROW0 + u / (IXP / 4), q = u - (row - ROW0) * (IXP / 4);
       const int gy = oy0 - R + row, gx = ox0 - 4 + 4 * q;
       const bool ok = (unsigned)gy < (unsigned)H && gx >= 0 && gx + 3 < W;
       const float* __restrict__ src = x + ((size_t)img * Cin + rd * 8) * plane + (size_t)gy * W + gx;
