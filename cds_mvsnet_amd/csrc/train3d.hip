@@ -10,6 +10,8 @@
 //   cds_conv3d_wgrad_f32      dw[a][b][tap] = sum_o g[a][o] * xin[b][S*o - 1 + tap]   (conv: g = dy, xin = x, S = stride;
 //                             transposed conv: g = x, xin = dy, S = 2: the same sum with the roles swapped)
 // Layouts: activations [B][C][D][H][W] fp32 planar (PyTorch's), statistics fp64 [C].
+#include <stdlib.h>
+
 #include "cds_common.hpp"
 
 namespace {
@@ -171,6 +173,88 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_kernel(const float* __restri
   }
 }
 
+// The same sums on the fp32 matrix pipe (v_mfma_f32_16x16x4_f32: exact fp32 products, fp32 accumulation):
+//   D[a][n] += A[a][k] B[k][n],  a = 16 channels of g, n = (b, tap) column (8 b-channels x 27 taps = 216 of 224), k = voxel.
+// A lane reads ONE float of g and one float of the xin tile per MFMA (the VALU kernel above read 8 per 7 FMAs and was
+// LDS-bound at ~12 TFLOP/s); the four waves own 3-4 of the 14 column blocks each and all walk the tile's 128 voxels.
+template <int S>
+__global__ __launch_bounds__(256) void conv3d_wgrad_mfma_kernel(const float* __restrict__ g, const float* __restrict__ xin,
+                                                                float* __restrict__ dw, int B, int Ca, int Cb, int Do, int Ho,
+                                                                int Wo, int Di, int Hi, int Wi, int tiles_x, int tiles_y, int ntiles,
+                                                                int tiles_per_wg) {
+  using Cfg = WCfg<S>;
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  extern __shared__ __attribute__((aligned(16))) float wlds[];
+  float* lg = wlds;                       // [16][NO]
+  float* lx = wlds + 16 * Cfg::NO;        // [8][NI]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 15, kq = lane >> 4;
+  const int a0 = blockIdx.y * 16, b0 = blockIdx.z * 8;
+  const size_t vo = (size_t)Do * Ho * Wo, vi = (size_t)Di * Hi * Wi;
+  constexpr int NBLK = 14, QW = 4;        // column blocks; per wave: blocks wave, wave + 4, ...
+  int colofs[QW];
+#pragma unroll
+  for (int q = 0; q < QW; ++q) {
+    const int n = min((wave + 4 * q) * 16 + j, 8 * 27 - 1);
+    const int b = n / 27, tap = n - b * 27;
+    colofs[q] = b * Cfg::NI + ((tap / 9) * Cfg::IY + (tap / 3) % 3) * Cfg::IX + tap % 3;
+  }
+  f32x4 acc[QW];
+#pragma unroll
+  for (int q = 0; q < QW; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int t0 = blockIdx.x * tiles_per_wg, t1 = min(ntiles * B, t0 + tiles_per_wg);
+  for (int tile = t0; tile < t1; ++tile) {
+    const int bi = tile / ntiles;
+    int r = tile - bi * ntiles;
+    const int tx_i = r % tiles_x;
+    r /= tiles_x;
+    const int ty_i = r % tiles_y, tz_i = r / tiles_y;
+    const int ox0 = tx_i * Cfg::OX, oy0 = ty_i * Cfg::OY, oz0 = tz_i * Cfg::OZ;
+    __syncthreads();
+    for (int i = tid; i < 16 * Cfg::NO; i += 256) {
+      const int ch = i / Cfg::NO, p = i - ch * Cfg::NO;
+      const int px = p % Cfg::OX, py = (p / Cfg::OX) % Cfg::OY, pz = p / (Cfg::OX * Cfg::OY);
+      const int ox = ox0 + px, oy = oy0 + py, oz = oz0 + pz;
+      const bool ok = a0 + ch < Ca && ox < Wo && oy < Ho && oz < Do;
+      lg[i] = ok ? g[((size_t)bi * Ca + a0 + ch) * vo + ((size_t)oz * Ho + oy) * Wo + ox] : 0.f;
+    }
+    for (int i = tid; i < 8 * Cfg::NI; i += 256) {
+      const int ch = i / Cfg::NI, p = i - ch * Cfg::NI;
+      const int px = p % Cfg::IX, py = (p / Cfg::IX) % Cfg::IY, pz = p / (Cfg::IX * Cfg::IY);
+      const int ix = ox0 * S - 1 + px, iy = oy0 * S - 1 + py, iz = oz0 * S - 1 + pz;
+      const bool ok = b0 + ch < Cb && (unsigned)ix < (unsigned)Wi && (unsigned)iy < (unsigned)Hi && (unsigned)iz < (unsigned)Di;
+      lx[i] = ok ? xin[((size_t)bi * Cb + b0 + ch) * vi + ((size_t)iz * Hi + iy) * Wi + ix] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int ks = 0; ks < Cfg::NO / 4; ++ks) {
+      const int p = 4 * ks + kq;                       // this lane's voxel of the K-step
+      const int px = p % Cfg::OX, py = (p / Cfg::OX) % Cfg::OY, pz = p / (Cfg::OX * Cfg::OY);
+      const int base = ((pz * S) * Cfg::IY + py * S) * Cfg::IX + px * S;
+      const float av = lg[j * Cfg::NO + p];
+#pragma unroll
+      for (int q = 0; q < QW; ++q) {
+        if (wave + 4 * q >= NBLK) continue;            // (wave-uniform)
+        acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, lx[base + colofs[q]], acc[q], 0, 0, 0);
+      }
+    }
+  }
+  // D: lane holds rows a = 4 kq + 0..3 of column n = 16 (wave + 4 q) + j
+#pragma unroll
+  for (int q = 0; q < QW; ++q) {
+    const int n = (wave + 4 * q) * 16 + j;
+    if (wave + 4 * q >= NBLK || n >= 8 * 27) continue;
+    const int b = n / 27, tap = n - b * 27;
+    if (b0 + b >= Cb) continue;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int a = a0 + 4 * kq + r;
+      if (a < Ca) atomicAdd(&dw[((size_t)a * Cb + b0 + b) * 27 + tap], r == 0 ? acc[q].x : r == 1 ? acc[q].y : r == 2 ? acc[q].z : acc[q].w);
+    }
+  }
+}
+
 inline dim3 ew_grid(size_t V, int C, int B) {
   size_t chunks = (V + 256 * 8 - 1) / (256 * 8);
   if (chunks > 512) chunks = 512;
@@ -219,6 +303,20 @@ extern "C" int cds_conv3d_wgrad_f32(const float* g, const float* xin, float* dw,
   const int ntiles = tx * ty * tz;
   int per = cds_ceil_div(ntiles * B, 1024);      // ~1024 tile groups: a handful of atomics per output, enough workgroups
   if (per < 1) per = 1;
+  static const bool valu = getenv("CDS_WGRAD_VALU") != nullptr;   // A/B knob: the VALU kernel
+  if (!valu) {
+    const dim3 gm(cds_ceil_div(ntiles * B, per), cds_ceil_div(Ca, 16), cds_ceil_div(Cb, 8));
+    if (stride == 1) {
+      const size_t ldsb = (16 * WCfg<1>::NO + 8 * WCfg<1>::NI) * sizeof(float);
+      hipLaunchKernelGGL(conv3d_wgrad_mfma_kernel<1>, gm, dim3(256), ldsb, (hipStream_t)stream, g, xin, dw, B, Ca, Cb, Do, Ho, Wo, Di,
+                         Hi, Wi, tx, ty, ntiles, per);
+    } else {
+      const size_t ldsb = (16 * WCfg<2>::NO + 8 * WCfg<2>::NI) * sizeof(float);
+      hipLaunchKernelGGL(conv3d_wgrad_mfma_kernel<2>, gm, dim3(256), ldsb, (hipStream_t)stream, g, xin, dw, B, Ca, Cb, Do, Ho, Wo, Di,
+                         Hi, Wi, tx, ty, ntiles, per);
+    }
+    return cds_launch_status();
+  }
   const dim3 grid(cds_ceil_div(ntiles * B, per), cds_ceil_div(Ca, 8), cds_ceil_div(Cb, 8));
   if (stride == 1)
     hipLaunchKernelGGL(conv3d_wgrad_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, g, xin, dw, B, Ca, Cb, Do, Ho, Wo, Di, Hi, Wi,

@@ -5,7 +5,7 @@ R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=$(pwd)
 cd /tmp && export TMPDIR=/tmp
 O=$R/gpurun_out
 rm -rf $O/prof_t5
-timeout 400 rocprofv3 --kernel-trace -d $O/prof_t5 -o t -- python $R/bench.py --workload T5 --train-dtype fp32 --steps 2 --warmup 1 > $O/${tag}_t5_trace.log 2>&1
+timeout 400 rocprofv3 --kernel-trace -d $O/prof_t5 -o t -- python $R/bench.py --workload T5 --train-dtype fp32 --steps 3 --warmup 3 > $O/${tag}_t5_trace.log 2>&1
 cd $R
-python scripts/kernel_breakdown.py $(find $O/prof_t5 -name "*.db" | head -1) 3 > $O/${tag}_t5_breakdown.txt 2>&1
+python scripts/kernel_breakdown.py $(find $O/prof_t5 -name "*.db" | head -1) 6 > $O/${tag}_t5_breakdown.txt 2>&1
 find $O/prof_t5 -name "*.db" -delete
