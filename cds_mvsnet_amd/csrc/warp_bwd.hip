@@ -5,6 +5,8 @@
 //             grad_src_v[tap][c] += g[c][d][p] * ref_v[c][p] * vis_v[p] * w_tap      (scatter-add, atomics)
 // The sampling grid carries no gradient (it is built under no_grad in the reference, models/utils/warping.py:79), so
 // nothing flows to the hypotheses or the cameras.  Positions / weights are recomputed with the forward's arithmetic.
+#include <stdlib.h>
+
 #include "warp_common.hpp"
 
 namespace {
@@ -112,6 +114,191 @@ __global__ __launch_bounds__(256) void warp_aggregate_bwd_kernel(const float* __
   atomicAdd(&gvis[(size_t)v * hw + pix], gv);
 }
 
+// The same gradients with the scatter into grad_src privatised in LDS.  The samples of a (tile, view, depth segment) land in a
+// bounded box of source texels (the warp is a homography: neighbouring pixels and planes map to neighbouring texels), so the
+// workgroup first finds that box (a cheap pass over the sample positions), accumulates the 4 x 8 tap contributions of every
+// sample with LDS atomics into [box texel][8 channels], and then adds the box to grad_src with ONE coalesced pass of global
+// atomics (box-size many, on consecutive addresses) instead of 32 scattered ones per pixel and cell change.  Boxes that do
+// not fit (BWD_BOX texels) fall back to the direct scatter above, decided per workgroup.
+constexpr int BWD_BOX = 1536;   // texels: 48 KB of LDS -> three workgroups per CU
+
+struct TapsXY {
+  int x0, y0;          // top-left texel of the 2 x 2 cell (may be -1: left / top neighbour outside)
+  bool ok[4];          // nw, ne, sw, se inside the map
+  float wt[4];
+  bool any;
+};
+
+// cds_taps with the cell coordinates kept (same arithmetic, same operation order)
+__device__ __forceinline__ TapsXY cds_taps_xy(const float r[3], const float* __restrict__ t, float d, int h, int w, float half_w,
+                                              float half_h) {
+  float px = r[0] * d + t[0];
+  float py = r[1] * d + t[1];
+  float pz = r[2] * d + t[2];
+  float z = pz + 1e-6f;
+  float u = px / z;
+  float v = py / z;
+  float gx = u / half_w - 1.0f;
+  float gy = v / half_h - 1.0f;
+  float ix = (gx + 1.0f) * half_w;
+  float iy = (gy + 1.0f) * half_h;
+  float x0f = floorf(ix), y0f = floorf(iy);
+  float wx = ix - x0f, ex = 1.0f - wx;
+  float ny = iy - y0f, sy = 1.0f - ny;
+  TapsXY tp;
+  tp.wt[0] = sy * ex;
+  tp.wt[1] = sy * wx;
+  tp.wt[2] = ny * ex;
+  tp.wt[3] = ny * wx;
+  const bool x0ok = (x0f >= 0.0f) && (x0f <= (float)(w - 1));
+  const bool x1ok = (x0f >= -1.0f) && (x0f <= (float)(w - 2));
+  const bool y0ok = (y0f >= 0.0f) && (y0f <= (float)(h - 1));
+  const bool y1ok = (y0f >= -1.0f) && (y0f <= (float)(h - 2));
+  tp.x0 = (x0ok || x1ok) ? (int)x0f : 0;
+  tp.y0 = (y0ok || y1ok) ? (int)y0f : 0;
+  tp.ok[0] = x0ok && y0ok;
+  tp.ok[1] = x1ok && y0ok;
+  tp.ok[2] = x0ok && y1ok;
+  tp.ok[3] = x1ok && y1ok;
+  tp.any = tp.ok[0] || tp.ok[1] || tp.ok[2] || tp.ok[3];
+  return tp;
+}
+
+__global__ __launch_bounds__(256) void warp_aggregate_bwd_box_kernel(const float* __restrict__ ref, const float* __restrict__ src,
+                                                                     const float* __restrict__ vis, WarpMats mats,
+                                                                     const float* __restrict__ hyp,
+                                                                     const float* __restrict__ gvol, float* __restrict__ gref,
+                                                                     float* __restrict__ gsrc, float* __restrict__ gvis, int V,
+                                                                     int C, int D, int h, int w, int hyp_pp, int tiles_x,
+                                                                     int ntiles, int nseg, int seg_planes) {
+  constexpr int CG = 8;
+  __shared__ float box[BWD_BOX * CG];
+  __shared__ int lim[4];                                   // xmin, ymin, xmax, ymax of the touched texels
+  const int ngroups = C / CG;
+  int lin = cds_xcd_remap(blockIdx.x, ntiles * V * ngroups * nseg);
+  const int seg = lin % nseg;
+  lin /= nseg;
+  const int c0 = (lin % ngroups) * CG;
+  lin /= ngroups;
+  const int v = lin % V;
+  const int tile = lin / V;
+  const int tx = tile % tiles_x, ty = tile / tiles_x;
+  const int x = tx * CDS_TILE_X + (threadIdx.x & 63);
+  const int y = ty * CDS_TILE_Y + (threadIdx.x >> 6);
+  const bool live = x < w && y < h;
+  const float half_w = (float)((w - 1) / 2.0), half_h = (float)((h - 1) / 2.0);
+  const size_t hw = (size_t)h * w;
+  const size_t pix = live ? (size_t)y * w + x : 0;
+  const float* __restrict__ srcv = src + (size_t)v * hw * C;
+  float* __restrict__ gsrcv = gsrc + (size_t)v * hw * C;
+  float m[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) m[i] = mats.m[v][i];
+  float r[3];
+  cds_row_terms(m, (float)x, (float)y, r);
+  const int d_lo = seg * seg_planes, d_hi = min(D, d_lo + seg_planes);
+
+  // ---- pass 1: the box ----
+  if (threadIdx.x == 0) {
+    lim[0] = 1 << 30; lim[1] = 1 << 30; lim[2] = -(1 << 30); lim[3] = -(1 << 30);
+  }
+  __syncthreads();
+  {
+    int xmin = 1 << 30, ymin = 1 << 30, xmax = -(1 << 30), ymax = -(1 << 30);
+    if (live)
+      for (int d = d_lo; d < d_hi; ++d) {
+        const float dv = hyp_pp ? hyp[(size_t)d * hw + pix] : hyp[d];
+        const TapsXY tp = cds_taps_xy(r, m + 9, dv, h, w, half_w, half_h);
+        if (tp.any) {
+          xmin = min(xmin, max(tp.x0, 0)); ymin = min(ymin, max(tp.y0, 0));
+          xmax = max(xmax, min(tp.x0 + 1, w - 1)); ymax = max(ymax, min(tp.y0 + 1, h - 1));
+        }
+      }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      xmin = min(xmin, __shfl_xor(xmin, o)); ymin = min(ymin, __shfl_xor(ymin, o));
+      xmax = max(xmax, __shfl_xor(xmax, o)); ymax = max(ymax, __shfl_xor(ymax, o));
+    }
+    if ((threadIdx.x & 63) == 0) {
+      atomicMin(&lim[0], xmin); atomicMin(&lim[1], ymin); atomicMax(&lim[2], xmax); atomicMax(&lim[3], ymax);
+    }
+  }
+  __syncthreads();
+  const int bx0 = lim[0], by0 = lim[1];
+  const int bw = lim[2] - lim[0] + 1, bh = lim[3] - lim[1] + 1;
+  const bool empty = bw <= 0 || bh <= 0;
+  const bool boxed = !empty && bw * bh <= BWD_BOX;          // (workgroup-uniform)
+  if (boxed) {
+    for (int i = threadIdx.x; i < bw * bh * CG; i += 256) box[i] = 0.f;
+    __syncthreads();
+  }
+
+  // ---- pass 2 ----
+  float gv = 0.f;
+  float gr[CG];
+#pragma unroll
+  for (int c = 0; c < CG; ++c) gr[c] = 0.f;
+  if (live && !empty) {
+    const float vw = vis[(size_t)v * hw + pix];
+    float rf[CG];
+#pragma unroll
+    for (int c = 0; c < CG; ++c) rf[c] = ref[((size_t)v * C + c0 + c) * hw + pix];
+    for (int d = d_lo; d < d_hi; ++d) {
+      const float dv = hyp_pp ? hyp[(size_t)d * hw + pix] : hyp[d];
+      const TapsXY tp = cds_taps_xy(r, m + 9, dv, h, w, half_w, half_h);
+      if (!tp.any) continue;                                // all four taps outside: the sample and its gradients are zero
+      const int base = tp.y0 * w + tp.x0;
+      const int off[4] = {tp.ok[0] ? base : -1, tp.ok[1] ? base + 1 : -1, tp.ok[2] ? base + w : -1, tp.ok[3] ? base + w + 1 : -1};
+      float g[CG], wv[CG];
+#pragma unroll
+      for (int c = 0; c < CG; ++c) g[c] = gvol[((size_t)(c0 + c) * D + d) * hw + pix];
+#pragma unroll
+      for (int q = 0; q < CG; q += 4) {
+        const float4 a = cds_ld4(srcv, off[0], C, c0 + q), b = cds_ld4(srcv, off[1], C, c0 + q);
+        const float4 cc = cds_ld4(srcv, off[2], C, c0 + q), e = cds_ld4(srcv, off[3], C, c0 + q);
+        wv[q + 0] = cds_interp(a.x, b.x, cc.x, e.x, tp.wt);
+        wv[q + 1] = cds_interp(a.y, b.y, cc.y, e.y, tp.wt);
+        wv[q + 2] = cds_interp(a.z, b.z, cc.z, e.z, tp.wt);
+        wv[q + 3] = cds_interp(a.w, b.w, cc.w, e.w, tp.wt);
+      }
+      float coef[CG];
+#pragma unroll
+      for (int c = 0; c < CG; ++c) {
+        gr[c] = fmaf(g[c], wv[c], gr[c]);
+        gv = fmaf(g[c] * rf[c], wv[c], gv);
+        coef[c] = g[c] * rf[c] * vw;
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        if (off[t] < 0) continue;
+        if (boxed) {
+          float* dst = box + (((tp.y0 + (t >> 1) - by0) * bw + (tp.x0 + (t & 1) - bx0)) * CG);
+#pragma unroll
+          for (int c = 0; c < CG; ++c) atomicAdd(dst + c, coef[c] * tp.wt[t]);      // ds_add_f32
+        } else {
+          float* dst = gsrcv + (size_t)off[t] * C + c0;
+#pragma unroll
+          for (int c = 0; c < CG; ++c) atomicAdd(dst + c, coef[c] * tp.wt[t]);
+        }
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < CG; ++c) atomicAdd(&gref[((size_t)v * C + c0 + c) * hw + pix], gr[c] * vw);
+    atomicAdd(&gvis[(size_t)v * hw + pix], gv);
+  }
+  if (boxed) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < bw * bh * CG; i += 256) {
+      const float val = box[i];
+      if (val != 0.f) {
+        const int t = i / CG, c = i - t * CG;
+        const int by = t / bw, bxx = t - by * bw;
+        atomicAdd(&gsrcv[((size_t)(by0 + by) * w + bx0 + bxx) * C + c0 + c], val);
+      }
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int cds_warp_aggregate_bwd_f32(const float* ref_chw, const float* src_hwc, const float* vis_w,
@@ -126,8 +313,20 @@ extern "C" int cds_warp_aggregate_bwd_f32(const float* ref_chw, const float* src
     for (int i = 0; i < 12; ++i) wm.m[v][i] = v < V ? mats_host[v * 12 + i] : 0.f;
   const int tiles_x = cds_ceil_div(w, CDS_TILE_X), tiles_y = cds_ceil_div(h, CDS_TILE_Y);
   const int ntiles = tiles_x * tiles_y;
-  // depth segments: aim at >= 4096 workgroups, at least 4 planes per segment
   const int base = ntiles * V * (C / 8);
+  static const bool direct = getenv("CDS_K3BWD_DIRECT") != nullptr;   // A/B knob: the direct-scatter kernel
+  if (!direct) {
+    // LDS-privatised scatter: segments only until ~1024 workgroups (every segment pays one box flush), >= 8 planes each
+    int nseg = 1;
+    while (base * nseg < 1024 && D / (2 * nseg) >= 8) nseg *= 2;
+    const int seg_planes = cds_ceil_div(D, nseg);
+    nseg = cds_ceil_div(D, seg_planes);
+    hipLaunchKernelGGL(warp_aggregate_bwd_box_kernel, dim3(base * nseg), dim3(256), 0, (hipStream_t)stream, ref_chw, src_hwc, vis_w,
+                       wm, hyp, grad_volume, grad_ref, grad_src_hwc, grad_vis, V, C, D, h, w, hyp_per_pixel, tiles_x, ntiles, nseg,
+                       seg_planes);
+    return cds_launch_status();
+  }
+  // depth segments: aim at >= 4096 workgroups, at least 4 planes per segment
   int nseg = 1;
   while (base * nseg < 4096 && D / (2 * nseg) >= 4) nseg *= 2;
   const int seg_planes = cds_ceil_div(D, nseg);
