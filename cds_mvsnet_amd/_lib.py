@@ -24,6 +24,7 @@ EINVAL = -1000
 P = c_void_p
 I = c_int
 F = c_float
+DB = ctypes.c_double
 L = c_longlong
 
 # name -> argtypes; every function returns int
@@ -72,6 +73,8 @@ SIGNATURES = {
     "cds_bn3d_apply_f32": [P, P, P, P, P, I, I, L, I, P],
     "cds_bn3d_bwd_reduce_f32": [P, P, P, P, P, I, I, L, I, P],
     "cds_bn3d_bwd_apply_f32": [P, P, P, P, P, P, P, I, I, L, I, P],
+    "cds_bn3d_finalize_f32": [P, P, P, DB, DB, F, P, P, P, P, P, P, I, P],
+    "cds_bn3d_bwd_finalize_f32": [P, P, P, P, DB, P, P, P, P, I, P],
     "cds_conv3d_wgrad_f32": [P, P, P, I, I, I, I, I, I, I, I, I, I, P],
     "cds_depth_fusion_f32": [P, P, P, P, P, P, P, P, P, I, I, I, P, F, F, F, P],
 }

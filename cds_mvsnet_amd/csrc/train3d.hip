@@ -255,6 +255,45 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_mfma_kernel(const float* __r
   }
 }
 
+// The per-channel arithmetic between the reduction and the apply kernels (it was ~20 tiny ATen launches per layer and direction
+// in a launch-bound training step).  sums[c] = (sum y, sum y^2) in fp64.
+__global__ void bn3d_finalize_kernel(const double* __restrict__ sums, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                     double n, double eps, float momentum, float* __restrict__ running_mean,
+                                     float* __restrict__ running_var, float* __restrict__ scale, float* __restrict__ shift,
+                                     double* __restrict__ mean_out, double* __restrict__ invstd_out, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double mean = sums[2 * c] / n;
+  double var = sums[2 * c + 1] / n - mean * mean;                  // biased, like F.batch_norm in training
+  var = var < 0.0 ? 0.0 : var;
+  const double invstd = 1.0 / sqrt(var + eps);
+  const double gm = (double)gamma[c];
+  scale[c] = (float)(gm * invstd);
+  shift[c] = (float)((double)beta[c] - mean * gm * invstd);
+  mean_out[c] = mean;
+  invstd_out[c] = invstd;
+  if (running_mean) {
+    running_mean[c] = running_mean[c] * (1.0f - momentum) + momentum * (float)mean;
+    running_var[c] = running_var[c] * (1.0f - momentum) + momentum * (float)(var * (n / (n > 1.0 ? n - 1.0 : 1.0)));
+  }
+}
+
+// sums[c] = (sum g, sum g * y_bn_input) from cds_bn3d_bwd_reduce_f32 -> dgamma, dbeta and the (k1, k0) of dy = g scale + y k1 + k0
+__global__ void bn3d_bwd_finalize_kernel(const double* __restrict__ sums, const double* __restrict__ mean,
+                                         const double* __restrict__ invstd, const float* __restrict__ scale, double n,
+                                         float* __restrict__ k1, float* __restrict__ k0, float* __restrict__ dgamma,
+                                         float* __restrict__ dbeta, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double db = sums[2 * c];
+  const double dg = invstd[c] * (sums[2 * c + 1] - mean[c] * sums[2 * c]);      // sum g * xhat
+  const double sc = (double)scale[c];
+  k1[c] = (float)(-sc * dg * invstd[c] / n);
+  k0[c] = (float)(-sc * db / n + sc * dg * invstd[c] * mean[c] / n);
+  dgamma[c] = (float)dg;
+  dbeta[c] = (float)db;
+}
+
 inline dim3 ew_grid(size_t V, int C, int B) {
   size_t chunks = (V + 256 * 8 - 1) / (256 * 8);
   if (chunks > 512) chunks = 512;
@@ -324,5 +363,26 @@ extern "C" int cds_conv3d_wgrad_f32(const float* g, const float* xin, float* dw,
   else
     hipLaunchKernelGGL(conv3d_wgrad_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, g, xin, dw, B, Ca, Cb, Do, Ho, Wo, Di, Hi, Wi,
                        tx, ty, ntiles, per);
+  return cds_launch_status();
+}
+
+// BatchNorm3d (training) between the statistics pass and the apply pass, one launch: scale / shift of y -> y * scale + shift,
+// the saved (mean, invstd) in fp64 for the backward, and the running-statistics update (running_* may be NULL).
+extern "C" int cds_bn3d_finalize_f32(const double* sums, const float* gamma, const float* beta, double n, double eps, float momentum,
+                                     float* running_mean, float* running_var, float* scale, float* shift, double* mean,
+                                     double* invstd, int C, void* stream) {
+  if (!sums || !gamma || !beta || !scale || !shift || !mean || !invstd || C < 1 || n < 1.0 || (running_mean != nullptr) != (running_var != nullptr))
+    return CDS_EINVAL;
+  hipLaunchKernelGGL(bn3d_finalize_kernel, dim3(cds_ceil_div(C, 64)), dim3(64), 0, (hipStream_t)stream, sums, gamma, beta, n, eps,
+                     momentum, running_mean, running_var, scale, shift, mean, invstd, C);
+  return cds_launch_status();
+}
+
+// The backward's per-channel step: (sum g, sum g y) -> dgamma, dbeta, and k1 / k0 for cds_bn3d_bwd_apply_f32.
+extern "C" int cds_bn3d_bwd_finalize_f32(const double* sums, const double* mean, const double* invstd, const float* scale, double n,
+                                         float* k1, float* k0, float* dgamma, float* dbeta, int C, void* stream) {
+  if (!sums || !mean || !invstd || !scale || !k1 || !k0 || !dgamma || !dbeta || C < 1 || n < 1.0) return CDS_EINVAL;
+  hipLaunchKernelGGL(bn3d_bwd_finalize_kernel, dim3(cds_ceil_div(C, 64)), dim3(64), 0, (hipStream_t)stream, sums, mean, invstd, scale,
+                     n, k1, k0, dgamma, dbeta, C);
   return cds_launch_status();
 }

@@ -98,19 +98,21 @@ class BnRelu3d(torch.autograd.Function):
         lib = _lib.load()
         sums = torch.zeros((C, 2), dtype=torch.float64, device=y.device)
         check(lib.cds_bn3d_stats_f32(_dev(y), sums.data_ptr(), B, C, V, ops._stream(y)), "cds_bn3d_stats_f32")
-        mean = sums[:, 0] / n
-        var = (sums[:, 1] / n - mean * mean).clamp_min(0.0)                     # biased, like F.batch_norm in training
-        invstd = torch.rsqrt(var + eps)
-        scale = (gamma.detach().double() * invstd).float().contiguous()
-        shift = (beta.detach().double() - mean * gamma.detach().double() * invstd).float().contiguous()
+        # per-channel step in ONE launch (fp64): scale / shift, the saved mean / invstd, the running-statistics update
+        scale = torch.empty((C,), dtype=torch.float32, device=y.device)
+        shift = torch.empty_like(scale)
+        mean = torch.empty((C,), dtype=torch.float64, device=y.device)
+        invstd = torch.empty_like(mean)
+        g32, b32 = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
+        track = running_mean is not None
+        check(lib.cds_bn3d_finalize_f32(sums.data_ptr(), _dev(g32), _dev(b32), float(n), float(eps), float(momentum),
+                                        _dev(running_mean) if track else None, _dev(running_var) if track else None,
+                                        scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), invstd.data_ptr(), C, ops._stream(y)),
+              "cds_bn3d_finalize_f32")
         out = torch.empty_like(y)
         skip_c = skip.contiguous() if skip is not None else None
         check(lib.cds_bn3d_apply_f32(_dev(y), _dev(scale), _dev(shift), _dev(skip_c) if skip_c is not None else None,
                                      out.data_ptr(), B, C, V, 1 if relu else 0, ops._stream(y)), "cds_bn3d_apply_f32")
-        if running_mean is not None:
-            with torch.no_grad():
-                running_mean.mul_(1 - momentum).add_(mean.float(), alpha=momentum)
-                running_var.mul_(1 - momentum).add_((var * (n / max(n - 1, 1))).float(), alpha=momentum)
         ctx.save_for_backward(y, scale, shift, mean, invstd, gamma)
         ctx.relu, ctx.has_skip, ctx.n = relu, skip is not None, n
         return out
@@ -127,15 +129,15 @@ class BnRelu3d(torch.autograd.Function):
         sums = torch.zeros((C, 2), dtype=torch.float64, device=y.device)
         check(lib.cds_bn3d_bwd_reduce_f32(_dev(dout), _dev(y), _dev(scale), _dev(shift), sums.data_ptr(), B, C, V,
                                           1 if ctx.relu else 0, ops._stream(y)), "cds_bn3d_bwd_reduce_f32")
-        dbeta = sums[:, 0]
-        dgamma = invstd * (sums[:, 1] - mean * sums[:, 0])                      # sum g * xhat
-        sc = scale.double()
-        k1 = (-sc * dgamma * invstd / n).float().contiguous()
-        k0 = (-sc * dbeta / n + sc * dgamma * invstd * mean / n).float().contiguous()
+        k1 = torch.empty((C,), dtype=torch.float32, device=y.device)
+        k0, dgamma, dbeta = torch.empty_like(k1), torch.empty_like(k1), torch.empty_like(k1)
+        check(lib.cds_bn3d_bwd_finalize_f32(sums.data_ptr(), mean.data_ptr(), invstd.data_ptr(), _dev(scale), float(n), k1.data_ptr(),
+                                            k0.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), C, ops._stream(y)),
+              "cds_bn3d_bwd_finalize_f32")
         dy = torch.empty_like(y)
         check(lib.cds_bn3d_bwd_apply_f32(_dev(dout), _dev(y), _dev(scale), _dev(shift), _dev(k1), _dev(k0), dy.data_ptr(), B, C,
                                          V, 1 if ctx.relu else 0, ops._stream(y)), "cds_bn3d_bwd_apply_f32")
-        return (dy, dgamma.float().to(gamma.dtype), dbeta.float().to(gamma.dtype), dout if ctx.has_skip else None,
+        return (dy, dgamma.to(gamma.dtype), dbeta.to(gamma.dtype), dout if ctx.has_skip else None,
                 None, None, None, None, None)
 
 

@@ -377,6 +377,17 @@ int cds_bn3d_bwd_reduce_f32(const float* dout, const float* y, const float* scal
                             int C, long long V, int relu, void* stream);
 int cds_bn3d_bwd_apply_f32(const float* dout, const float* y, const float* scale, const float* shift, const float* k1,
                            const float* k0, float* dy, int B, int C, long long V, int relu, void* stream);
+
+/* The per-channel arithmetic of BatchNorm3d (training) between those passes, one launch each (fp64 like the statistics):
+ * forward: sums [C][2] = (sum y, sum y^2), n = elements per channel -> scale / shift for cds_bn3d_apply_f32, the saved mean / invstd
+ * [C] doubles, and running_mean / running_var updated in place with `momentum` (unbiased variance; both may be NULL);
+ * backward: sums [C][2] from cds_bn3d_bwd_reduce_f32 -> dgamma, dbeta [C] and k1 / k0 [C] for cds_bn3d_bwd_apply_f32
+ * (models/module.py:80-160 in training mode: nn.BatchNorm3d). */
+int cds_bn3d_finalize_f32(const double* sums, const float* gamma, const float* beta, double n, double eps, float momentum,
+                          float* running_mean, float* running_var, float* scale, float* shift, double* mean, double* invstd,
+                          int C, void* stream);
+int cds_bn3d_bwd_finalize_f32(const double* sums, const double* mean, const double* invstd, const float* scale, double n,
+                              float* k1, float* k0, float* dgamma, float* dbeta, int C, void* stream);
 int cds_conv3d_wgrad_f32(const float* g, const float* xin, float* dw, int B, int Ca, int Cb, int Do, int Ho, int Wo, int Di,
                          int Hi, int Wi, int stride, void* stream);
 
