@@ -38,6 +38,13 @@ def conv3d_wgrad(g: Tensor, xin: Tensor, stride: int) -> Tensor:
     return dw
 
 
+def _per_item(fn, x: Tensor) -> Tensor:
+    """fn on every batch item (the inference kernels take one item per call); a batch of one is not copied again."""
+    if x.shape[0] == 1:
+        return fn(x[0]).unsqueeze(0)
+    return torch.stack([fn(x[b]) for b in range(x.shape[0])])
+
+
 class Conv3dK3(torch.autograd.Function):
     """x [B,Cin,D,H,W], weight (Conv3d: [Cout,Cin,3,3,3]; ConvTranspose3d: [Cin,Cout,3,3,3]) -> y."""
 
@@ -51,10 +58,10 @@ class Conv3dK3(torch.autograd.Function):
         if transposed:
             cin, cout = w.shape[:2]
             wpk = w.permute(0, 2, 3, 4, 1).reshape(cin, 27, cout).contiguous()
-            return torch.stack([ops.deconv3d_k3s2(x[b], wpk, None, relu=False) for b in range(x.shape[0])])
+            return _per_item(lambda xb: ops.deconv3d_k3s2(xb, wpk, None, relu=False), x)
         cout, cin = w.shape[:2]
         wpk = w.permute(1, 2, 3, 4, 0).reshape(cin, 27, cout).contiguous()
-        return torch.stack([ops.conv3d_k3(x[b], wpk, None, stride=stride, relu=False) for b in range(x.shape[0])])
+        return _per_item(lambda xb: ops.conv3d_k3(xb, wpk, None, stride=stride, relu=False), x)
 
     @staticmethod
     @torch.amp.custom_bwd(device_type="cuda")
@@ -68,7 +75,7 @@ class Conv3dK3(torch.autograd.Function):
             cin, cout = w.shape[:2]
             if ctx.needs_input_grad[0]:
                 wpk = w.permute(1, 2, 3, 4, 0).reshape(cout, 27, cin).contiguous()
-                dx = torch.stack([ops.conv3d_k3(dy[b], wpk, None, stride=2, relu=False) for b in range(B)])
+                dx = _per_item(lambda gb: ops.conv3d_k3(gb, wpk, None, stride=2, relu=False), dy)
             if ctx.needs_input_grad[1]:
                 dw = conv3d_wgrad(x, dy, 2)                  # [Cin,Cout,3,3,3]
         else:
@@ -76,10 +83,10 @@ class Conv3dK3(torch.autograd.Function):
             if ctx.needs_input_grad[0]:
                 if ctx.stride == 1:                          # dx = conv(dy, flipped taps, channels swapped)
                     wpk = w.flip(2, 3, 4).permute(0, 2, 3, 4, 1).reshape(cout, 27, cin).contiguous()
-                    dx = torch.stack([ops.conv3d_k3(dy[b], wpk, None, relu=False) for b in range(B)])
+                    dx = _per_item(lambda gb: ops.conv3d_k3(gb, wpk, None, relu=False), dy)
                 else:                                        # dx = convT(dy, w)
                     wpk = w.permute(0, 2, 3, 4, 1).reshape(cout, 27, cin).contiguous()
-                    dx = torch.stack([ops.deconv3d_k3s2(dy[b], wpk, None, relu=False) for b in range(B)])
+                    dx = _per_item(lambda gb: ops.deconv3d_k3s2(gb, wpk, None, relu=False), dy)
             if ctx.needs_input_grad[1]:
                 dw = conv3d_wgrad(dy, x, ctx.stride)         # [Cout,Cin,3,3,3]
         return dx, dw, None, None
