@@ -59,8 +59,9 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_view_shard_allreduce_world2():
-    world = 2
+@pytest.mark.parametrize("world", [2, 8])
+def test_view_shard_allreduce(world):
+    """world 2: 3 source views over 2 ranks; world 8 (a full node): ranks 3..7 own no view and contribute zeros."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -71,7 +72,7 @@ def test_view_shard_allreduce_world2():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert sorted(r[3] for r in res) == [1, 2]          # 3 source views over 2 ranks
+    assert sorted(r[3] for r in res) == ([1, 2] if world == 2 else [0, 0, 0, 0, 0, 1, 1, 1])
     for _, err, err_nc, _ in res:
         assert err < 1e-6 and err_nc < 1e-6
 
@@ -113,10 +114,10 @@ def _p2p_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_p2p_reduce_scatter_all_gather_equals_allreduce(world):
     """The point-to-point exchange (reduce-scatter + all-gather as direct sends) against the library
-    all-reduce on gloo, world sizes 2 and 3."""
+    all-reduce on gloo, world sizes 2, 3 and 8 (a full node)."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -128,7 +129,7 @@ def test_p2p_reduce_scatter_all_gather_equals_allreduce(world):
         p.join(timeout=60)
         assert p.exitcode == 0
     for _, errs in res:
-        assert max(errs) < 1e-6
+        assert max(errs) < 1e-6 * max(1.0, world / 2)      # fp32 re-association of `world` addends of magnitude ~1
 
 
 def _bcast_worker(rank, world, port, q):
