@@ -120,7 +120,10 @@ __global__ __launch_bounds__(256) void warp_aggregate_bwd_kernel(const float* __
 // sample with LDS atomics into [box texel][8 channels], and then adds the box to grad_src with ONE coalesced pass of global
 // atomics (box-size many, on consecutive addresses) instead of 32 scattered ones per pixel and cell change.  Boxes that do
 // not fit (BWD_BOX texels) fall back to the direct scatter above, decided per workgroup.
-constexpr int BWD_BOX = 1536;   // texels: 48 KB of LDS -> three workgroups per CU
+#ifndef CDS_K3BWD_BOX
+#define CDS_K3BWD_BOX 1536   // texels: 48 KB of LDS -> three workgroups per CU (build with a tiny value to force the fallback path)
+#endif
+constexpr int BWD_BOX = CDS_K3BWD_BOX;
 
 struct TapsXY {
   int x0, y0;          // top-left texel of the 2 x 2 cell (may be -1: left / top neighbour outside)

@@ -497,7 +497,7 @@ def test_batch_of_two_equals_two_singles(dev, seeded_state):
     assert torch.equal(both["photometric_confidence"][1], one["photometric_confidence"][0])
 
 
-@pytest.mark.parametrize("V,C,D,h,w", [(2, 8, 6, 12, 40), (3, 16, 4, 9, 70), (1, 32, 3, 8, 20)])
+@pytest.mark.parametrize("V,C,D,h,w", [(2, 8, 6, 12, 40), (3, 16, 4, 9, 70), (1, 32, 3, 8, 20), (2, 8, 40, 24, 130), (4, 16, 20, 33, 65)])
 def test_warp_aggregate_backward_vs_autograd(V, C, D, h, w, dev, ops):
     """Training step: gradients of the un-normalised warp-aggregate w.r.t. ref / src / vis against
     torch autograd through the CPU oracle's warp (F.grid_sample)."""
@@ -518,7 +518,7 @@ def test_warp_aggregate_backward_vs_autograd(V, C, D, h, w, dev, ops):
     src_d = src.detach().to(dev).requires_grad_(True)
     vis_d = vis.detach().to(dev).requires_grad_(True)
     vol_d = ops.WarpAggregate.apply(ref_d, src_d.permute(0, 2, 3, 1).contiguous(), vis_d, mats, hyp_d)
-    assert (vol_d.detach().cpu() - vol.detach()).abs().max() < 1e-5
+    assert (vol_d.detach().cpu() - vol.detach()).abs().max() < 1e-5 * max(1.0, vol.detach().abs().max().item())   # un-normalised sum over V views
     (vol_d * G.to(dev)).sum().backward()
     for name, a, b in (("ref", ref_d.grad, ref.grad), ("src", src_d.grad, src.grad), ("vis", vis_d.grad, vis.grad)):
         err = (a.cpu() - b).abs().max().item()
