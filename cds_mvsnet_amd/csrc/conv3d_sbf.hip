@@ -573,9 +573,12 @@ __global__ __launch_bounds__(ZCfg::THREADS) void conv3d_sbf_zm_kernel(const floa
 int launch_fwd_zm(const float* x, const void* wsp, const float* b, float* out, int D, int H, int W, int act, hipStream_t st) {
   using Cfg = ZCfg;
   const int tx = cds_ceil_div(W, Cfg::TX), ty = cds_ceil_div(H, Cfg::TY);
-  // z segments: whole columns when there are enough of them for ~8 rounds of workgroups, else segments of >= 8 stages
+  // z segments: whole columns when there are enough of them for ~4 rounds of workgroups (every segment re-stages two halo planes and
+  // refills the pipeline: M1 1.56 / 1.59 / 1.63 / 1.72 ms with 1 / 2 / 4 / 8 segments), else segments of >= 8 stages
   int nseg = 1;
-  while (tx * ty * nseg < 256 * 8 && cds_ceil_div(D, nseg * 2) >= 8 * Cfg::G) nseg *= 2;
+  while (tx * ty * nseg < 256 * 4 && cds_ceil_div(D, nseg * 2) >= 8 * Cfg::G) nseg *= 2;
+  static const int nseg_env = []() { const char* e = getenv("CDS_ZM_NSEG"); return e ? atoi(e) : 0; }();   // A/B knob
+  if (nseg_env > 0) nseg = nseg_env;
   int zseg = cds_ceil_div(cds_ceil_div(D, nseg), Cfg::G) * Cfg::G;
   nseg = cds_ceil_div(D, zseg);
   static std::atomic<unsigned long long> lds_ok{0};
