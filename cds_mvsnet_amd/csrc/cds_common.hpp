@@ -24,12 +24,17 @@ static inline int cds_ceil_div(int a, int b) { return (a + b - 1) / b; }
 
 // Opt a kernel into more than 64 KB of dynamic LDS once per DEVICE (function attributes are per device: one process may
 // drive several, e.g. nn.DataParallel replicas; `mask` is a per-kernel static).
-static inline void cds_allow_lds(const void* kernel, int bytes, std::atomic<unsigned long long>& mask) {
+static inline int cds_allow_lds(const void* kernel, int bytes, std::atomic<unsigned long long>& mask) {
   int d = 0;
   (void)hipGetDevice(&d);
   const unsigned long long bit = 1ull << (d & 63);
-  if (mask.fetch_or(bit) & bit) return;
-  (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (mask.load(std::memory_order_acquire) & bit) return 0;
+  // idempotent: two host threads may both apply it; the bit is published only AFTER the attribute is in place,
+  // so no thread can launch the > 64 KB kernel on this device before it
+  hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) { (void)hipGetLastError(); return -(int)e; }
+  mask.fetch_or(bit, std::memory_order_release);
+  return 0;
 }
 
 // Bijective XCD-aware remap of a linear workgroup id (guide T1): the dispatcher places block b on

@@ -582,7 +582,7 @@ int launch_fwd_zm(const float* x, const void* wsp, const float* b, float* out, i
   int zseg = cds_ceil_div(cds_ceil_div(D, nseg), Cfg::G) * Cfg::G;
   nseg = cds_ceil_div(D, zseg);
   static std::atomic<unsigned long long> lds_ok{0};
-  cds_allow_lds(reinterpret_cast<const void*>(conv3d_sbf_zm_kernel), Cfg::LDSB, lds_ok);
+  if (int e_lds = cds_allow_lds(reinterpret_cast<const void*>(conv3d_sbf_zm_kernel), Cfg::LDSB, lds_ok)) return e_lds;
   hipLaunchKernelGGL(conv3d_sbf_zm_kernel, dim3(tx * ty * nseg), dim3(Cfg::THREADS), Cfg::LDSB, st, x, reinterpret_cast<const uint4*>(wsp), b,
                      out, D, H, W, act, tx, ty, zseg);
   return cds_launch_status();
@@ -606,7 +606,7 @@ int launch_fwd(const float* x, const void* wsp, const float* b, const float* ski
   constexpr int lds_bytes = 2 * Cfg::LDSB;
   if (lds_bytes > 64 * 1024) {
     static std::atomic<unsigned long long> lds_ok{0};   // per instantiation
-    cds_allow_lds(reinterpret_cast<const void*>(kern), lds_bytes, lds_ok);
+    if (int e_lds = cds_allow_lds(reinterpret_cast<const void*>(kern), lds_bytes, lds_ok)) return e_lds;
   }
   hipLaunchKernelGGL(kern, dim3(nwg), dim3(Cfg::THREADS), lds_bytes, st, x, reinterpret_cast<const uint4*>(wsp), b, skip, out, Cin,
                      Cout, D, H, W, Do, Ho, Wo, act, tx, ty, ntiles, tpw);
@@ -1060,7 +1060,7 @@ int launch_deconv_ws(const float* x, const void* wsp, const float* b, const floa
   const int nwg = cds_ceil_div(ntiles, tpw);
   const int lds_bytes = (Cin >> 3) * DTab<true>::NKS * 3 * 1024 + 2 * Cfg::LDSB;
   static std::atomic<unsigned long long> lds_ok{0};
-  cds_allow_lds(reinterpret_cast<const void*>(deconv3d_sbf_ws_kernel), 160 * 1024, lds_ok);
+  if (int e_lds = cds_allow_lds(reinterpret_cast<const void*>(deconv3d_sbf_ws_kernel), 160 * 1024, lds_ok)) return e_lds;
   hipLaunchKernelGGL(deconv3d_sbf_ws_kernel, dim3(nwg), dim3(DWS_THREADS), lds_bytes, st, x, reinterpret_cast<const uint4*>(wsp), b,
                      skip, out, Cin, Cout, D, H, W, act, out_planar, tx, ty, ntiles, tpw);
   return cds_launch_status();
@@ -1193,7 +1193,7 @@ extern "C" int cds_conv3d_prob_cl8_f32(const float* x, const float* weight_tap, 
   using Cfg = PCfg;
   const int tx = cds_ceil_div(W, Cfg::TX), ty = cds_ceil_div(H, Cfg::TY), tz = cds_ceil_div(D, Cfg::TZ);
   static std::atomic<unsigned long long> lds_ok{0};
-  cds_allow_lds(reinterpret_cast<const void*>(prob_cl8_kernel), Cfg::LDSB, lds_ok);
+  if (int e_lds = cds_allow_lds(reinterpret_cast<const void*>(prob_cl8_kernel), Cfg::LDSB, lds_ok)) return e_lds;
   hipLaunchKernelGGL(prob_cl8_kernel, dim3(tx * ty * tz), dim3(256), Cfg::LDSB, (hipStream_t)stream, x, weight_tap, out, D, H, W,
                      tx, ty, tx * ty * tz);
   return cds_launch_status();

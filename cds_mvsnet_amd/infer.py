@@ -39,18 +39,31 @@ _SAFE_BUILTINS = {"set", "frozenset", "list", "dict", "tuple", "int", "float", "
                   "complex", "slice", "range", "object"}
 
 
+# exact globals a tensor state dict needs; everything else in the pickle stream becomes an inert _Opaque
+_SAFE_GLOBALS = {
+    ("collections", "OrderedDict"), ("torch._utils", "_rebuild_tensor_v2"), ("torch._utils", "_rebuild_parameter"),
+    ("torch._utils", "_rebuild_tensor"), ("torch", "Size"), ("torch", "device"), ("torch", "dtype"),
+    ("torch.serialization", "_get_layout"), ("torch._tensor", "_rebuild_from_type_v2"),
+    ("_codecs", "encode"), ("numpy", "dtype"), ("numpy", "ndarray"),
+    ("numpy.core.multiarray", "_reconstruct"), ("numpy.core.multiarray", "scalar"),
+    ("numpy._core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "scalar"),
+}
+_SAFE_TORCH_ATTRS = ({n for n in dir(torch) if n.endswith("Storage")}
+                     | {n for n in dir(torch) if isinstance(getattr(torch, n, None), torch.dtype)})
+
+
 class _placeholder_pickle:
-    """A ``pickle_module`` for ``torch.load`` whose unpickler resolves torch / collections / a few builtin globals and
-    replaces every other global by :class:`_Opaque` instead of importing it — foreign objects in a checkpoint can neither
-    fail the load nor run code."""
+    """A ``pickle_module`` for ``torch.load`` whose unpickler resolves ONLY an allowlist of globals (the tensor / storage
+    rebuild helpers, ``torch.Size`` / ``dtype`` / ``device``, ``OrderedDict``, numpy array reconstruction, a few builtin
+    containers) and replaces every other global by :class:`_Opaque` instead of importing it: ``torch.hub.load``,
+    ``torch.jit.load`` and the like are NOT resolvable through it."""
     import pickle as _pickle
     __name__ = "cds_mvsnet_amd.infer._placeholder_pickle"
 
     class Unpickler(_pickle.Unpickler):
         def find_class(self, module, name):
-            root = module.split(".")[0]
-            if root in ("torch", "collections", "_codecs") or (root == "numpy" and name in ("dtype", "ndarray", "_reconstruct", "scalar")) \
-                    or (root == "numpy" and module.startswith("numpy.core.multiarray")) \
+            if (module, name) in _SAFE_GLOBALS or (module == "torch" and name in _SAFE_TORCH_ATTRS) \
+                    or (module == "torch.storage" and name in ("TypedStorage", "UntypedStorage", "_load_from_bytes")) \
                     or (module == "builtins" and name in _SAFE_BUILTINS):
                 return super().find_class(module, name)
             return _Opaque
@@ -69,9 +82,12 @@ def load_checkpoint(model: torch.nn.Module, path: str, trust_pickle: bool = Fals
     does a full ``torch.load``).  Keys are checked: anything missing from the file, or unexpected in it, raises (the
     reference loads with ``strict=False`` and silently keeps random weights); exempt are ``num_batches_tracked`` counters and,
     for a model built with ``refine=False``, the ``refine_network.*`` entries of a checkpoint trained with refinement."""
+    import pickle
     try:
         ck = torch.load(path, map_location="cpu", weights_only=True)
-    except Exception as e:
+    except (pickle.UnpicklingError, RuntimeError) as e:          # refused global / legacy format; I/O errors propagate
+        if isinstance(e, RuntimeError) and "eights only" not in str(e) and "nsupported" not in str(e):
+            raise
         if not trust_pickle:
             raise RuntimeError(f"{path}: not loadable with weights_only=True ({type(e).__name__}: {str(e)[:200]}). "
                                "If the file is trusted, retry with trust_pickle=True / --trust-checkpoint.") from e

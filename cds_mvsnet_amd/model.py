@@ -243,9 +243,9 @@ class CostRegNet(_PackedHolder):
         planar form the exact-fp32 kernels (one fmaf chain per output)."""
         if self.training:
             # training / autograd path (SURVEY §8(f)-2): HIP forward + backward kernels behind autograd Functions
-            from . import train_ops
+            from . import training                                      # honours the CDS_TRAIN_HIP A/B knob, validates the dims
             v = volume.permute(3, 0, 1, 2) if channels_last else volume
-            return train_ops.cost_regularization(self, v.unsqueeze(0).contiguous())[0, 0]
+            return training.cost_regularization(self, v.unsqueeze(0).contiguous())[0, 0]
         D, h, w = volume.shape[:3] if channels_last else volume.shape[1:]
         if D % 8 or h % 8 or w % 8:
             raise ValueError(f"CostRegNet needs D,h,w divisible by 8, got {(D, h, w)}")

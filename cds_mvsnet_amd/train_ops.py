@@ -154,15 +154,22 @@ def conv_bn_relu3d(unit, x: Tensor, skip: Optional[Tensor] = None) -> Tensor:
     y = Conv3dK3.apply(x, unit.conv.weight, unit.stride, unit.transposed)
     bn = unit.bn
     if bn.training:
+        momentum = bn.momentum
         if bn.num_batches_tracked is not None:
             bn.num_batches_tracked += 1
-        return BnRelu3d.apply(y, bn.weight, bn.bias, skip, bn.running_mean, bn.running_var, bn.momentum, bn.eps, True)
+            if momentum is None:                                         # cumulative moving average (nn.BatchNorm semantics)
+                momentum = 1.0 / float(bn.num_batches_tracked)
+        if momentum is None:
+            momentum = 0.0
+        return BnRelu3d.apply(y, bn.weight, bn.bias, skip, bn.running_mean, bn.running_var, float(momentum), bn.eps, True)
     out = torch.relu(torch.nn.functional.batch_norm(y, bn.running_mean, bn.running_var, bn.weight, bn.bias, False, 0.0, bn.eps))
     return out if skip is None else skip + out
 
 
 def cost_regularization(cr, x: Tensor) -> Tensor:
     """models/module.py:305-315 on the HIP training ops.  x [B,C,D,h,w] -> [B,1,D,h,w]."""
+    if x.shape[2] % 8 or x.shape[3] % 8 or x.shape[4] % 8:
+        raise ValueError(f"CostRegNet needs D,h,w divisible by 8, got {tuple(x.shape[2:])}")
     c0 = conv_bn_relu3d(cr.conv0, x)
     c2 = conv_bn_relu3d(cr.conv2, conv_bn_relu3d(cr.conv1, c0))
     c4 = conv_bn_relu3d(cr.conv4, conv_bn_relu3d(cr.conv3, c2))

@@ -26,13 +26,17 @@ def _att_weights_grouped(seq, curvs: Tensor, groups: int) -> Tensor:
     stacks ``groups`` separate calls of the reference: the BatchNorm statistics are taken per group of N / groups samples
     (what each of those calls would have seen) and the running statistics receive the groups' updates in call order."""
     conv_a, bn, _, conv_b = seq[0], seq[1], seq[2], seq[3]
+    # statistics and normalisation in fp32 also under bf16 autocast, like nn.BatchNorm2d (the groups == 1 path)
     h = conv_a(curvs)
+    act_dtype = h.dtype
+    if h.dtype in (torch.bfloat16, torch.float16):
+        h = h.float()
     N, C, H, W = h.shape
     hg = h.view(groups, N // groups, C, H, W)
     mean = hg.mean(dim=(1, 3, 4))                                            # [G,C]
     var = hg.var(dim=(1, 3, 4), unbiased=False)
     y = (hg - mean.view(groups, 1, C, 1, 1)) * torch.rsqrt(var.view(groups, 1, C, 1, 1) + bn.eps)
-    y = y * bn.weight.view(1, 1, C, 1, 1) + bn.bias.view(1, 1, C, 1, 1)
+    y = y * bn.weight.view(1, 1, C, 1, 1).to(y.dtype) + bn.bias.view(1, 1, C, 1, 1).to(y.dtype)
     if bn.training and bn.track_running_stats:
         with torch.no_grad():
             m = bn.momentum if bn.momentum is not None else 0.1
@@ -42,7 +46,7 @@ def _att_weights_grouped(seq, curvs: Tensor, groups: int) -> Tensor:
             bn.running_mean.mul_((1.0 - m) ** groups).add_((wts.view(-1, 1) * mean.detach().to(rdt)).sum(dim=0))
             bn.running_var.mul_((1.0 - m) ** groups).add_((wts.view(-1, 1) * (var.detach().to(rdt) * (n / max(n - 1, 1)))).sum(dim=0))
             bn.num_batches_tracked += groups
-    return conv_b(F.relu(y.view(N, C, H, W)))
+    return conv_b(F.relu(y.view(N, C, H, W)).to(act_dtype))
 
 
 def _dynamic_conv(dc, x: Tensor, epi: Tensor, T: float, groups: int = 1) -> Tuple[Tensor, Tensor]:
@@ -139,6 +143,10 @@ def stage_forward_train(stage_net, features, cams: Tensor, depth_values: Tensor,
     CostRegNet forward / backward on the HIP kernels with gradient; the visibility CNN on PyTorch-ROCm autograd ops."""
     V = len(features)
     B = depth_values.shape[0]
+    if gt_depth is not None and gt_depth.dim() == 4:                    # the reference passes gt_depths[stage].unsqueeze(1): [B,1,h,w]
+        if gt_depth.shape[1] != 1:
+            raise ValueError(f"gt_depth must be [B,h,w] or [B,1,h,w], got {tuple(gt_depth.shape)}")
+        gt_depth = gt_depth[:, 0]
     cams = cams.detach().float().cpu()
     mats = [geometry.warp_matrices(cams[b]) for b in range(B)]
     hyps = [depth_values[b].detach().float().contiguous() for b in range(B)]

@@ -163,7 +163,8 @@ def test_costreg_training_kernels_vs_torch_autograd(C, B, D, h, w):
 
 
 @pytest.mark.gpu
-def test_stage_net_training_mode_reference_signature():
+@pytest.mark.parametrize("gt_rank", [3, 4])
+def test_stage_net_training_mode_reference_signature(gt_rank):
     """StageNet.forward in training mode with the reference's call signature (models/model.py:16, gt_depth given):
     the feat_distance head (model.py:56,63-69), differentiable depth, gradients reaching the features, the visibility CNN
     and CostRegNet through the HIP backward kernels."""
@@ -177,6 +178,8 @@ def test_stage_net_training_mode_reference_signature():
     cams = synth.stage_cameras(V + 1, h, w, seed=4)
     hyp = synth.make_hypotheses(D, h, w, seed=5).to(dev)
     gt = (hyp[:, D // 2] + 0.3).contiguous()
+    if gt_rank == 4:                    # models/model.py:201 hands gt_depths[stage].unsqueeze(1) = [B,1,h,w] to StageNet
+        gt = gt.unsqueeze(1)
     out = model.stage_net(dfe, cams, depth_values=hyp, num_depth=D, cost_regularization=model.cost_regularization[stage],
                           stage_idx=stage, gt_depth=gt)
     assert set(out) == {"depth", "photometric_confidence", "feat_distance", "norm_curv"}
