@@ -77,15 +77,19 @@ def read_cam_file(path: str, ndepths: int = 192, interval_scale: float = 1.0) ->
 
 
 def write_cam_file(path: str, cam: np.ndarray) -> None:
-    """cam [2,4,4] (extrinsic, intrinsic in [:3,:3]) in the layout the reference's fusion step reads back."""
+    """cam [2,4,4] (extrinsic, intrinsic in [:3,:3]) in the layout the reference's fusion step reads back; byte-identical
+    to the reference's writer (test.py:132-149: every number as ``str(np.float32)`` followed by one space, then row 3
+    of the intrinsic slot on the depth-range line)."""
+    cam = np.asarray(cam)
     with open(path, "w") as f:
         f.write("extrinsic\n")
         for i in range(4):
-            f.write(" ".join(str(float(v)) for v in cam[0, i]) + "\n")
+            f.write("".join(str(cam[0][i][j]) + " " for j in range(4)) + "\n")
         f.write("\nintrinsic\n")
         for i in range(3):
-            f.write(" ".join(str(float(v)) for v in cam[1, i, :3]) + "\n")
-        f.write("\n")
+            f.write("".join(str(cam[1][i][j]) + " " for j in range(3)) + "\n")
+        # the reference closes the file with row 3 of the intrinsic slot (the dataset leaves it zero): "0.0 0.0 0.0 0.0"
+        f.write("\n" + " ".join(str(cam[1][3][j]) for j in range(4)) + "\n")
 
 
 def read_pair_file(path: str) -> List[Tuple[int, List[int]]]:

@@ -323,9 +323,129 @@ def g8_fusion():
           "per-view", vis_masks[0, :, 0].mean(dim=(1, 2)))
 
 
+def _reference_function(path, name, extra_globals=None):
+    """Compile ONE top-level function of a reference script that cannot be imported as a module (test.py parses
+    ``sys.argv`` and imports cv2 / plyfile at import time) straight from the file where it lies.  Nothing is copied:
+    the function object is built from the reference's own source at capture time."""
+    import ast
+    with open(path) as f:
+        tree = ast.parse(f.read(), filename=path)
+    fn = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == name)
+    glb = {"np": np, "__builtins__": __builtins__}
+    glb.update(extra_globals or {})
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), path, "exec"), glb)
+    return glb[name]
+
+
+def g10_formats():
+    """On-disk formats written / parsed BY THE REFERENCE: PFM bytes from ``datasets/data_io.save_pfm``,
+    arrays from its ``read_pfm``, the camera text from ``test.py:write_cam``, and the sample dict its ``MVSDataset``
+    (``datasets/general_eval.py``) builds from a small synthetic MVSNet-format scene (dtu and tt layouts, refine on/off).
+    ``cv2`` does not exist in this image: it is stubbed in ``sys.modules`` (as torchvision is for the checkpoints); the only
+    cv2 call on this path, ``cv2.resize`` to the size the image already has, is an identity checked by the stub."""
+    import io
+    import tempfile
+    import types
+    from PIL import Image
+
+    cv2 = types.ModuleType("cv2")
+
+    def _resize(img, size, interpolation=None):
+        assert (img.shape[1], img.shape[0]) == tuple(size), "the fixture never resizes (cv2 is absent)"
+        return img
+    cv2.resize = _resize
+    cv2.INTER_NEAREST, cv2.INTER_LINEAR = 0, 1
+    sys.modules.setdefault("cv2", cv2)
+    from datasets import data_io as ref_io                        # reference
+    from datasets.general_eval import MVSDataset as RefDataset    # reference
+
+    out = {}
+    rs = np.random.RandomState(10)
+    tmp = tempfile.mkdtemp()
+    # ---- PFM ----
+    grey = (rs.rand(5, 7).astype(np.float32) * 900 + 400)
+    col = rs.rand(6, 4, 3).astype(np.float32)
+    one = rs.rand(3, 5, 1).astype(np.float32)
+    for tag, arr in (("grey", grey), ("color", col), ("hw1", one)):
+        pth = os.path.join(tmp, tag + ".pfm")
+        ref_io.save_pfm(pth, arr)
+        out[f"pfm_{tag}_array"] = arr
+        out[f"pfm_{tag}_bytes"] = np.frombuffer(open(pth, "rb").read(), dtype=np.uint8)
+        back, scale = ref_io.read_pfm(pth) if tag != "hw1" else (None, None)
+        if back is not None:
+            out[f"pfm_{tag}_read"] = np.ascontiguousarray(back)
+            out[f"pfm_{tag}_scale"] = np.float64(scale)
+    be = os.path.join(tmp, "be.pfm")                             # a big-endian file with scale 2.5, as another tool writes it
+    with open(be, "wb") as f:
+        f.write(b"Pf\n3 2\n2.5\n" + np.arange(6, dtype=">f4").tobytes())
+    back, scale = ref_io.read_pfm(be)
+    out["pfm_be_bytes"] = np.frombuffer(open(be, "rb").read(), dtype=np.uint8)
+    out["pfm_be_read"] = np.ascontiguousarray(back).astype(np.float32)
+    out["pfm_be_scale"] = np.float64(scale)
+    # ---- camera text written by the reference's inference script ----
+    write_cam = _reference_function("/root/reference/test.py", "write_cam")
+    read_params = _reference_function("/root/reference/test.py", "read_camera_parameters")
+    cam = np.zeros((2, 4, 4), np.float32)
+    cam[0] = np.eye(4, dtype=np.float32)
+    cam[0, :3, :3] += (rs.rand(3, 3).astype(np.float32) - 0.5) * 0.1
+    cam[0, :3, 3] = rs.rand(3).astype(np.float32) * 100 - 50
+    cam[1, :3, :3] = np.array([[361.54125, 0, 82.900625], [0, 360.3975, 66.383875], [0, 0, 1]], np.float32)
+    pth = os.path.join(tmp, "w_cam.txt")
+    write_cam(pth, cam)
+    out["cam_array"] = cam
+    out["cam_bytes"] = np.frombuffer(open(pth, "rb").read(), dtype=np.uint8)
+    intr, extr = read_params(pth)
+    out["cam_read_intrinsic"], out["cam_read_extrinsic"] = intr, extr
+    # ---- a scene parsed by the reference's evaluation dataset ----
+    names, blobs = [], []
+    for ds_name, H, W, depth_line in (("dtu", 64, 80, "425.0 2.5"), ("tt", 56, 80, "0.35 0.0125 96 1.55")):
+        root = os.path.join(tmp, ds_name)
+        scan = "scan_" + ds_name
+        os.makedirs(os.path.join(root, scan, "images"))
+        os.makedirs(os.path.join(root, scan, "cams"))
+        nv = 4
+        for v in range(nv):
+            img = (rs.rand(H, W, 3) * 255).astype(np.uint8)
+            Image.fromarray(img).save(os.path.join(root, scan, "images", f"{v:08d}.jpg"), quality=95)
+            R = np.eye(4)
+            R[:3, :3] += (rs.rand(3, 3) - 0.5) * 0.05
+            R[:3, 3] = rs.rand(3) * 60 - 30
+            K = np.array([[2892.33 / 16 + v, 0, W / 2 + 0.37], [0, 2883.18 / 16 - v, H / 2 - 0.21], [0, 0, 1]])
+            with open(os.path.join(root, scan, "cams", f"{v:08d}_cam.txt"), "w") as f:
+                f.write("extrinsic\n" + "\n".join(" ".join(repr(float(x)) for x in r) for r in R) + "\n\nintrinsic\n")
+                f.write("\n".join(" ".join(repr(float(x)) for x in r) for r in K) + "\n\n" + depth_line + "\n")
+        with open(os.path.join(root, scan, "pair.txt"), "w") as f:
+            f.write(f"{nv}\n")
+            for v in range(nv):
+                others = [u for u in range(nv) if u != v]
+                f.write(f"{v}\n{len(others)} " + " ".join(f"{u} {1000.0 / (1 + abs(u - v)):.3f}" for u in others) + "\n")
+        for dirpath, _, files in os.walk(root):
+            for fn in sorted(files):
+                full = os.path.join(dirpath, fn)
+                names.append(os.path.relpath(full, tmp))
+                blobs.append(np.frombuffer(open(full, "rb").read(), dtype=np.uint8))
+        Hm = 64                                                  # tt: 56 rows + 4 + 4 edge padding
+        for refine in (False, True):
+            ds = RefDataset(root, [scan], "test", 4, ndepths=192, interval_scale=1.06, max_h=Hm, max_w=W, fix_res=False,
+                            dataset=ds_name, refine=refine)
+            assert len(ds) == nv
+            for idx in (0, 2):
+                smp = ds[idx]
+                key = f"scene_{ds_name}_{'refine' if refine else 'norefine'}_{idx}"
+                out[key + "_imgs"] = smp["imgs"].astype(np.float32)
+                for st, m in smp["proj_matrices"].items():
+                    out[key + "_proj_" + st] = m
+                out[key + "_depth_values"] = smp["depth_values"]
+                out[key + "_filename"] = np.array(smp["filename"])
+    out["scene_file_names"] = np.array(names)
+    for i, b in enumerate(blobs):
+        out[f"scene_file_{i}"] = b
+    save("g10_formats", **out)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
     for fn in (g1_warp_aggregate, g2_costreg, g3_regress, g4_hypotheses, g5_features, g6_forward, g7_training_step,
-               g8_fusion, g9_feature_noise):
+               g8_fusion, g9_feature_noise, g10_formats):
         if not only or fn.__name__.split("_")[0] in only:
             fn()

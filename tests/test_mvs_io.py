@@ -116,3 +116,58 @@ def test_inference_harness_end_to_end(tmp_path):
     assert np.array_equal(depth, o["refined_depth"][0].cpu().numpy())
     assert np.array_equal(conf[..., 2], o["photometric_confidence"][0].cpu().numpy())
     assert 425 <= depth.min() and depth.max() <= 425 + 2.5 * 192
+
+
+# ------------------------------------------------------------------------------------------------
+# G10: bytes written / arrays parsed by the REFERENCE (tests/golden/make_golden.py::g10_formats)
+# ------------------------------------------------------------------------------------------------
+def test_pfm_and_cam_files_match_reference_bytes(tmp_path, golden):
+    """write_pfm / write_cam_file are byte-identical to the reference's save_pfm (datasets/data_io.py:42-71) and write_cam
+    (test.py:132-146); read_pfm / read_cam_file return what the reference's readers return for the same files."""
+    g = golden("g10_formats")
+    for tag in ("grey", "color", "hw1"):
+        arr = g[f"pfm_{tag}_array"].numpy()
+        p = str(tmp_path / f"{tag}.pfm")
+        mvs_io.write_pfm(p, arr)
+        assert open(p, "rb").read() == g[f"pfm_{tag}_bytes"].tobytes(), tag
+    for tag in ("grey", "color", "be"):
+        p = str(tmp_path / f"r_{tag}.pfm")
+        with open(p, "wb") as f:
+            f.write(g[f"pfm_{tag}_bytes"].tobytes())
+        got, scale = mvs_io.read_pfm(p)
+        assert np.array_equal(got, g[f"pfm_{tag}_read"].numpy()) and scale == float(g[f"pfm_{tag}_scale"]), tag
+    p = str(tmp_path / "00000000_cam.txt")
+    mvs_io.write_cam_file(p, g["cam_array"].numpy())
+    assert open(p, "rb").read() == g["cam_bytes"].tobytes()
+    # the reference's fusion step reads that file back with read_camera_parameters (test.py:82-93): same numbers here
+    with open(p) as f:
+        lines = [ln.rstrip() for ln in f.readlines()]
+    assert np.array_equal(np.array(" ".join(lines[1:5]).split(), np.float32).reshape(4, 4), g["cam_read_extrinsic"].numpy())
+    assert np.array_equal(np.array(" ".join(lines[7:10]).split(), np.float32).reshape(3, 3), g["cam_read_intrinsic"].numpy())
+
+
+@pytest.mark.parametrize("dataset", ["dtu", "tt"])
+@pytest.mark.parametrize("refine", [False, True])
+def test_eval_scene_samples_match_reference_dataset(tmp_path, golden, dataset, refine):
+    """EvalScenes on the fixture scene == the sample dict of the reference's MVSDataset (datasets/general_eval.py:118-215):
+    images, per-stage projection matrices (incl. the Tanks&Temples +4 px principal point and edge padding, and the
+    4-field depth line), depth values and the output file-name pattern, exactly."""
+    g = golden("g10_formats")
+    for i, name in enumerate(g["scene_file_names"]):
+        p = tmp_path / str(name)
+        p.parent.mkdir(parents=True, exist_ok=True)
+        p.write_bytes(g[f"scene_file_{i}"].tobytes())
+    scan = "scan_" + dataset
+    ds = mvs_io.EvalScenes(str(tmp_path / dataset), [scan], nviews=4, ndepths=192, interval_scale=1.06, max_h=64, max_w=80,
+                           refine=refine, dataset=dataset)
+    assert len(ds) == 4
+    for idx in (0, 2):
+        key = f"scene_{dataset}_{'refine' if refine else 'norefine'}_{idx}"
+        smp = ds[idx]
+        assert smp["filename"] == str(g[key + "_filename"])
+        assert np.array_equal(smp["imgs"], g[key + "_imgs"].numpy())
+        assert np.array_equal(smp["depth_values"], g[key + "_depth_values"].numpy())
+        stages = [k[len(key) + 6:] for k in g if k.startswith(key + "_proj_")]
+        assert sorted(smp["proj_matrices"]) == sorted(stages)
+        for st in stages:
+            assert np.array_equal(smp["proj_matrices"][st], g[key + "_proj_" + st].numpy()), st
