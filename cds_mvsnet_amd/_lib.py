@@ -16,7 +16,8 @@ LIB_PATH = os.environ.get("CDS_MVSNET_LIB") or os.path.join(_HERE, "libcdsmvs_hi
 
 # activation / flag codes (mirror include/cds_mvsnet_hip.h)
 ACT_NONE, ACT_RELU, ACT_LEAKY01, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3, 4
-AGG_ACCUMULATE, AGG_NORMALIZE, AGG_CHANNELS_LAST = 1, 2, 4
+AGG_ACCUMULATE, AGG_NORMALIZE, AGG_CHANNELS_LAST, AGG_FAST_POSITIONS = 1, 2, 4, 8
+WARP_FAST_POSITIONS = AGG_FAST_POSITIONS
 MAX_VIEWS = 8
 MAX_IMAGES = 16
 EINVAL = -1000
@@ -33,6 +34,7 @@ SIGNATURES = {
     "cds_chw_to_hwc_f32": [P, P, I, I, I, P],
     "cds_homo_warp_f32": [P, P, P, P, I, I, I, I, I, P],
     "cds_warp_entropy_f32": [P, P, P, P, P, I, I, I, I, I, I, P],
+    "cds_warp_entropy_flags_f32": [P, P, P, P, P, I, I, I, I, I, I, I, P],
     "cds_warp_aggregate_f32": [P, P, P, P, P, P, P, I, I, I, I, I, I, I, P],
     "cds_warp_aggregate_bwd_f32": [P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, P],
     "cds_volume_normalize_f32": [P, P, I, I, I, P],

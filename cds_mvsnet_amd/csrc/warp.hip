@@ -298,7 +298,7 @@ bool cds_warp_aggregate_lds_launch(const float* ref, const float* src, const flo
                                    const float* hyp, float* volume, const float* vis_sum, int V, int C, int D, int h,
                                    int w, int hyp_pp, int flags, hipStream_t st);
 bool cds_warp_entropy_lds_launch(const float* ref, const float* src, const WarpMats& wm, const float* hyp,
-                                 float* entropy, int V, int C, int D, int h, int w, int hyp_pp, hipStream_t st);
+                                 float* entropy, int V, int C, int D, int h, int w, int hyp_pp, bool fast, hipStream_t st);
 static bool cds_use_lds_path() {
   static const bool on = []() {
     const char* e = getenv("CDS_WARP_DIRECT");  // CDS_WARP_DIRECT=1 forces the direct (L1 gather) kernels
@@ -345,13 +345,20 @@ extern "C" int cds_homo_warp_f32(const float* src_hwc, const float* mat_host, co
 extern "C" int cds_warp_entropy_f32(const float* ref_chw, const float* src_hwc, const float* mats_host,
                                     const float* hyp, float* entropy, int V, int C, int D, int h, int w,
                                     int hyp_per_pixel, void* stream) {
+  return cds_warp_entropy_flags_f32(ref_chw, src_hwc, mats_host, hyp, entropy, V, C, D, h, w, hyp_per_pixel, 0, stream);
+}
+
+extern "C" int cds_warp_entropy_flags_f32(const float* ref_chw, const float* src_hwc, const float* mats_host,
+                                          const float* hyp, float* entropy, int V, int C, int D, int h, int w,
+                                          int hyp_per_pixel, int flags, void* stream) {
   if (!ref_chw || !src_hwc || !mats_host || !hyp || !entropy || !cds_warp_args_ok(V, C, D, h, w)) return CDS_EINVAL;
   WarpMats wm;
   cds_fill_mats(wm, mats_host, V);
   int tiles_x = cds_ceil_div(w, CDS_TILE_X), tiles_y = cds_ceil_div(h, CDS_TILE_Y);
   int ntiles = tiles_x * tiles_y;
   hipStream_t st = (hipStream_t)stream;
-  if (cds_use_lds_path() && cds_warp_entropy_lds_launch(ref_chw, src_hwc, wm, hyp, entropy, V, C, D, h, w, hyp_per_pixel, st))
+  if (cds_use_lds_path() && cds_warp_entropy_lds_launch(ref_chw, src_hwc, wm, hyp, entropy, V, C, D, h, w, hyp_per_pixel,
+                                                          (flags & CDS_WARP_FAST_POSITIONS) != 0, st))
     return cds_launch_status();
   // small images: one pixel row of 64 per workgroup, planes split over its four waves (>= ~6 workgroups per CU otherwise)
   const bool dsplit = (long)ntiles * V < 6L * 256 && D >= 8;

@@ -36,6 +36,10 @@ namespace {
 constexpr int C8 = 8;
 constexpr int TW = CDS_K3_TW, TH = CDS_K3_TH;  // reference-pixel tile of a workgroup (TW*TH = 256)
 constexpr int BOX_CAP = CDS_K3_BOX;   // texels per view box (x 32 B; 4 views + scratch must fit the LDS budget)
+#ifndef CDS_K3_BOX6
+#define CDS_K3_BOX6 392
+#endif
+constexpr int BOX_CAP6 = CDS_K3_BOX6; // box budget per view with 5 / 6 resident views (6 x 2 x 392 x 16 B = 75 KB: two workgroups per CU)
 constexpr int DC = CDS_K3_DC;         // depth planes per staged chunk
 #ifndef CDS_K1_DC
 #define CDS_K1_DC 64
@@ -54,6 +58,7 @@ struct Box {
 // box; the second clamp must be a no-op for the fast path to be valid.
 struct FastBox {
   float fx0, fx1, fy0, fy1;   // cells of the box whose four texels are all staged
+  float bwf, orgf;            // row pitch and linear index of the box origin as floats (exact: both < 2^24)
   int bw, org;
 };
 __device__ __forceinline__ FastBox fast_box(const Box& b, int h, int w) {
@@ -64,7 +69,9 @@ __device__ __forceinline__ FastBox fast_box(const Box& b, int h, int w) {
   f.fy1 = (float)(b.y0 + b.bh - 2);
   (void)h; (void)w;
   f.bw = b.bw;
+  f.bwf = (float)b.bw;
   f.org = b.y0 * b.bw + b.x0;
+  f.orgf = (float)f.org;
   return f;
 }
 // The generic path re-reads the box from LDS (int[4] per view, written by reduce_boxes) instead of pinning SGPRs.
@@ -222,7 +229,12 @@ struct Geo {       // per launch constants
   float half_w, half_h, rhw, rhh;
 };
 
-// Sample positions of two consecutive planes (same fp32 operation order as cds_taps).
+// Sample positions of two consecutive planes.  FAST = false: the reference's fp32 operation order (= cds_taps: correctly
+// rounded divisions by z + 1e-6 and by (w-1)/2, ATen's normalise / de-normalise round trip; 33 packed instructions per plane
+// pair and view, sample positions bit-identical to F.grid_sample's).  FAST = true (the default of the product path, flag
+// CDS_WARP_FAST_POSITIONS): sample at (u, v) = p.xy * v_rcp(z) directly, 13 instructions; positions move by <= ~1e-4 px
+// (volume max-abs 4e-6 against a tolerance of 1e-5, depth mean-L1 unchanged: profiles/r02_relaxed_positions_ab.md).
+template <bool FAST>
 __device__ __forceinline__ void positions2(const float r[3], const float* __restrict__ t, v2f d, const Geo& g, v2f& ix,
                                            v2f& iy) {
   const v2f px = r[0] * d + t[0];
@@ -232,15 +244,11 @@ __device__ __forceinline__ void positions2(const float r[3], const float* __rest
   v2f y0;
   y0.x = __builtin_amdgcn_rcpf(z.x);
   y0.y = __builtin_amdgcn_rcpf(z.y);
-#ifdef CDS_WARP_RELAXED
-  // A/B build only (scripts/build_variant.sh relaxed -DCDS_WARP_RELAXED, profiles/r02_relaxed_positions_ab.md): sample at
-  // (u, v) = p.xy * rcp(z) directly -- no correctly rounded divisions, no ATen normalise / de-normalise round trip.
-  // 13 instead of 33 packed instructions per plane pair and view; moves samples by up to ~1e-4 px.
-  ix = px * y0;
-  iy = py * y0;
-  (void)g;
-  return;
-#endif
+  if (FAST) {
+    ix = px * y0;
+    iy = py * y0;
+    return;
+  }
   const v2f e = fma2(-z, y0, splat2(1.0f));
   const v2f y = fma2(e, y0, y0);
   // u = px / z and v = py / z (div2_refine), written interleaved: two independent dependency chains
@@ -310,7 +318,11 @@ __device__ __forceinline__ void fetch_cell(float x0f, float y0f, const Geo& g, c
 // Branch-free variant for the common case: the cell is clamped into the staged box in the float domain (so the LDS
 // address is always valid) and the caller is told whether the clamp changed anything.  If any lane of the wave
 // reports a changed cell (or a box is not staged) the caller redoes the plane pair with fetch_cell.
-template <int CAP>
+// FIDX: linear texel index computed in the float domain (yc * bw + xc - org is an integer below 2^24: exact; one conversion
+// instead of two conversions + an integer multiply-add).  Same-box A/B at M1: K1 0.79 vs 0.815 ms with it, K3 0.985-1.008 vs
+// 0.956-0.962 ms (the longer dependent chain in front of the LDS reads costs K3 more than the two instructions it saves), so
+// K1 uses it and K3 does not.
+template <int CAP, bool FIDX>
 __device__ __forceinline__ bool cell_addr_fast(float x0f, float y0f, float wf, float hf, const FastBox& b,
                                                const cds_f4* __restrict__ lds, const cds_f4*& r0, const cds_f4*& r1) {
   const float xa = __builtin_amdgcn_fmed3f(x0f, -2.0f, wf);
@@ -320,7 +332,7 @@ __device__ __forceinline__ bool cell_addr_fast(float x0f, float y0f, float wf, f
 #ifdef CDS_EXP_LDS_BCAST
   const int idx = 0 * ((int)yc + (int)xc);
 #else
-  const int idx = __mul24((int)yc, b.bw) + (int)xc - b.org;
+  const int idx = FIDX ? (int)fmaf(yc, b.bwf, xc - b.orgf) : __mul24((int)yc, b.bw) + (int)xc - b.org;
 #endif
   r0 = lds + idx;
   r1 = r0 + b.bw;
@@ -368,13 +380,13 @@ __device__ __forceinline__ void plane_weights(v2f ix, v2f iy, v2f& x0f, v2f& y0f
 // pixel and folded into the (ref*vis) factors.
 // Addressing: per-channel slab base (uniform) + one 32-bit byte offset per plane (slab = D*h*w*4 < 4 GB).
 // ---------------------------------------------------------------------------------------------
-template <int VMAX, bool ACCUMULATE, bool NORMALIZE>
+template <int VMAX, bool ACCUMULATE, bool NORMALIZE, bool FAST, int CAP>
 __global__ __launch_bounds__(256, CDS_K3_MINW) void warp_aggregate_lds_kernel(
     const float* __restrict__ ref, const float* __restrict__ src, const float* __restrict__ vis, WarpMats mats,
     const float* __restrict__ hyp, float* __restrict__ volume, const float* __restrict__ vis_sum, int C, int D, int h,
     int w, float rhw, float rhh, int flags, int tiles_x, int ntiles, int nseg, int seg_planes) {
-  extern __shared__ __attribute__((aligned(16))) cds_f4 lds4[];  // VMAX * 2*BOX_CAP float4, then int red[4*VMAX*4], int boxes[VMAX*4]
-  int* red = reinterpret_cast<int*>(lds4 + VMAX * 2 * BOX_CAP);
+  extern __shared__ __attribute__((aligned(16))) cds_f4 lds4[];  // VMAX * 2*CAP float4, then int red[4*VMAX*4], int boxes[VMAX*4]
+  int* red = reinterpret_cast<int*>(lds4 + VMAX * 2 * CAP);
 
   // depth segment is the fastest-varying index: the nseg blocks of a tile run together and share its features in L2
   // then the group of 8 channels (C = 16 / 32: one workgroup per group; the groups of a tile run together, so the
@@ -446,7 +458,7 @@ __global__ __launch_bounds__(256, CDS_K3_MINW) void warp_aggregate_lds_kernel(
         cell_of(r[v], mats.m[v] + 9, dlast, h, w, g.half_w, g.half_h, cx1[v], cy1[v]);
       }
       __syncthreads();  // previous chunk's LDS reads are done (also protects `red`)
-      reduce_boxes<VMAX, BOX_CAP>(cx0, cy0, cx1, cy1, active, VMAX, h, w, red, box);
+      reduce_boxes<VMAX, CAP>(cx0, cy0, cx1, cy1, active, VMAX, h, w, red, box);
       bool fits = true;
 #pragma unroll
       for (int v = 0; v < VMAX; ++v) fits = fits && box[v].staged;
@@ -455,7 +467,7 @@ __global__ __launch_bounds__(256, CDS_K3_MINW) void warp_aggregate_lds_kernel(
     }
 #pragma unroll
     for (int v = 0; v < VMAX; ++v)
-      stage_box<BOX_CAP>(src + (size_t)v * hw * C, C, h, w, box[v], reinterpret_cast<float4*>(lds4 + v * 2 * BOX_CAP));
+      stage_box<CAP>(src + (size_t)v * hw * C, C, h, w, box[v], reinterpret_cast<float4*>(lds4 + v * 2 * CAP));
     __syncthreads();
     bool all_staged = true;
     FastBox fb[VMAX];
@@ -510,15 +522,15 @@ __global__ __launch_bounds__(256, CDS_K3_MINW) void warp_aggregate_lds_kernel(
         Tex8 tc[2][4];
         auto prep = [&](int v, v2f w4[4]) {
           v2f ix, iy, x0f, y0f;
-          positions2(r[v], mats.m[v] + 9, dv, g, ix, iy);
+          positions2<FAST>(r[v], mats.m[v] + 9, dv, g, ix, iy);
           plane_weights(ix, iy, x0f, y0f, w4);
-          const cds_f4* lv = lds4 + v * 2 * BOX_CAP;
-          ok &= cell_addr_fast<BOX_CAP>(x0f.x, y0f.x, wf, hf, fb[v], lv, p0[0], p1[0]);
-          ok &= cell_addr_fast<BOX_CAP>(x0f.y, y0f.y, wf, hf, fb[v], lv, p0[1], p1[1]);
+          const cds_f4* lv = lds4 + v * 2 * CAP;
+          ok &= cell_addr_fast<CAP, false>(x0f.x, y0f.x, wf, hf, fb[v], lv, p0[0], p1[0]);
+          ok &= cell_addr_fast<CAP, false>(x0f.y, y0f.y, wf, hf, fb[v], lv, p0[1], p1[1]);
         };
         prep(0, wt[0]);
-        load_cell<BOX_CAP>(p0[0], p1[0], tc[0]);
-        load_cell<BOX_CAP>(p0[1], p1[1], tc[1]);
+        load_cell<CAP>(p0[0], p1[0], tc[0]);
+        load_cell<CAP>(p0[1], p1[1], tc[1]);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int v = 0; v < VMAX; ++v) {
@@ -533,7 +545,7 @@ __global__ __launch_bounds__(256, CDS_K3_MINW) void warp_aggregate_lds_kernel(
             interp8(tc[k], wgt, o);
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[k][j] = fma2(rv[v][j], o[j], acc[k][j]);
-            if (v + 1 < VMAX) load_cell<BOX_CAP>(p0[k], p1[k], tc[k]);
+            if (v + 1 < VMAX) load_cell<CAP>(p0[k], p1[k], tc[k]);
             __builtin_amdgcn_sched_barrier(0);
           }
         }
@@ -548,16 +560,16 @@ __global__ __launch_bounds__(256, CDS_K3_MINW) void warp_aggregate_lds_kernel(
 #pragma unroll
         for (int v = 0; v < VMAX; ++v) {
           const float* __restrict__ srcv = src + (size_t)v * hw * C;
-          const cds_f4* lv = lds4 + v * 2 * BOX_CAP;
+          const cds_f4* lv = lds4 + v * 2 * CAP;
           const Box bg = load_box(boxmem + v * 4);
           v2f ix, iy, x0f, y0f, wt[4];
-          positions2(r[v], mats.m[v] + 9, dvg, g, ix, iy);
+          positions2<FAST>(r[v], mats.m[v] + 9, dvg, g, ix, iy);
           plane_weights(ix, iy, x0f, y0f, wt);
 #pragma unroll
           for (int k = 0; k < 2; ++k) {
             float wgt[4] = {k ? wt[0].y : wt[0].x, k ? wt[1].y : wt[1].x, k ? wt[2].y : wt[2].x, k ? wt[3].y : wt[3].x};
             Tex8 t[4];
-            fetch_cell<BOX_CAP>(k ? x0f.y : x0f.x, k ? y0f.y : y0f.x, g, bg, lv, srcv, C, t, wgt);
+            fetch_cell<CAP>(k ? x0f.y : x0f.x, k ? y0f.y : y0f.x, g, bg, lv, srcv, C, t, wgt);
             v2f o[4];
             interp8(t, wgt, o);
 #pragma unroll
@@ -632,7 +644,7 @@ __device__ __forceinline__ void online_entropy_update(float s, float& mx, float&
 // NG = groups of 8 channels (C = 8 NG); the box of a view holds all of them: 2 NG planes of CAP float4.
 // C = 8: CAP 1016 texels, 64-plane chunks (32 KB);  C = 16 / 32: the K3 budget (CDS_K3_BOX texels, CDS_K3_DC planes: 40 /
 // 79 KB, two workgroups per CU at C = 32).  A box that does not fit halves its chunk, as in K3.
-template <int NG, int CAP, int DCK>
+template <int NG, int CAP, int DCK, bool FAST>
 __global__ __launch_bounds__(256, (NG == 4 ? 2 : CDS_K1_MINW)) void warp_entropy_lds_kernel(
     const float* __restrict__ ref, const float* __restrict__ src, WarpMats mats, const float* __restrict__ hyp,
     float* __restrict__ entropy, int V, int D, int h, int w, float rhw, float rhh, int tiles_x, int ntiles) {
@@ -701,7 +713,7 @@ __global__ __launch_bounds__(256, (NG == 4 ? 2 : CDS_K1_MINW)) void warp_entropy
       dnext.x = *reinterpret_cast<const float*>(hyp_b + min(boff + 2u * bstep, blast));
       dnext.y = *reinterpret_cast<const float*>(hyp_b + min(boff + 3u * bstep, blast));
       v2f ix, iy, x0f, y0f, wt[4];
-      positions2(r, m + 9, dv, g, ix, iy);
+      positions2<FAST>(r, m + 9, dv, g, ix, iy);
       plane_weights(ix, iy, x0f, y0f, wt);
       float sim[2];
       // sum_C ref*warp in ATen's outer-dim order: sequential inside 16-channel levels, level sums added in order
@@ -723,7 +735,7 @@ __global__ __launch_bounds__(256, (NG == 4 ? 2 : CDS_K1_MINW)) void warp_entropy
         for (int k = 0; k < 2; ++k) {
           const float wgt[4] = {k ? wt[0].y : wt[0].x, k ? wt[1].y : wt[1].x, k ? wt[2].y : wt[2].x, k ? wt[3].y : wt[3].x};
           const cds_f4 *q0, *q1;
-          ok &= cell_addr_fast<CAP>(k ? x0f.y : x0f.x, k ? y0f.y : y0f.x, wf, hf, fb, lds4, q0, q1);
+          ok &= cell_addr_fast<CAP, true>(k ? x0f.y : x0f.x, k ? y0f.y : y0f.x, wf, hf, fb, lds4, q0, q1);
           float s = 0.f, part = 0.f;
 #pragma unroll
           for (int q = 0; q < NG; ++q) {
@@ -775,7 +787,16 @@ bool cds_warp_aggregate_lds_launch(const float* ref, const float* src, const flo
   if ((C != 8 && C != 16 && C != 32) || V < 1 || V > CDS_MAX_VIEWS || !hyp_pp || w < 2 || h < 2 ||
       (size_t)D * h * w * 4 >= ((size_t)1 << 32))
     return false;
-  if (V > 4) {
+  // 5 / 6 source views (BASELINE config 4, N = 7) run in ONE pass with a smaller box budget per view (CAP6 texels: 6 views =
+  // 75 KB, still two workgroups per CU; a footprint that does not fit halves its chunk as usual).  CDS_K3_SPLIT_VIEWS=1 keeps
+  // the round-2 behaviour for the A/B: two launches over halves of the view list, the second re-reading the partial volume.
+  // Measured at the config-4 stage shapes (7 views, one MI355X, same box): 960x528 D=32 C=16 1.12 ms in one pass vs 1.52 ms split;
+  // 480x264 D=48 C=32 2.73 vs 1.43 (48-plane chunks overflow the smaller boxes and are halved twice); 1920x1056 D=8 C=8 0.93 vs
+  // 0.90 (the 6-view kernel spills in its plane loop; the volume it saves re-reading is small).  Hence: one pass for the 16-channel
+  // stages with <= 32 planes, split otherwise.  CDS_K3_SPLIT_VIEWS=1 / 0 forces either.
+  static const int split_env = []() { const char* e = getenv("CDS_K3_SPLIT_VIEWS"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
+  const bool one_pass = V <= 6 && (split_env == 0 || (split_env < 0 && C >= 16 && D <= 32));
+  if (V > 4 && !one_pass) {
     // more views than fit the LDS budget: two launches over halves of the view list; the second adds to the first's
     // partial sums (and normalises).  Costs one extra read of the volume, still far cheaper than L1 gathers.
     const int v1 = (V + 1) / 2;
@@ -783,12 +804,12 @@ bool cds_warp_aggregate_lds_launch(const float* ref, const float* src, const flo
     WarpMats wm2;
     for (int v = 0; v < CDS_MAX_VIEWS; ++v)
       for (int i = 0; i < 12; ++i) wm2.m[v][i] = (v + v1 < CDS_MAX_VIEWS) ? wm.m[v + v1][i] : 0.f;
-    const int layout = flags & CDS_AGG_CHANNELS_LAST;
+    const int keep = flags & (CDS_AGG_CHANNELS_LAST | CDS_AGG_FAST_POSITIONS);
     return cds_warp_aggregate_lds_launch(ref, src, vis, wm, hyp, volume, vis_sum, v1, C, D, h, w, hyp_pp,
-                                         (flags & CDS_AGG_ACCUMULATE) | layout, st) &&
+                                         (flags & CDS_AGG_ACCUMULATE) | keep, st) &&
            cds_warp_aggregate_lds_launch(ref + (size_t)v1 * C * hw, src + (size_t)v1 * hw * C, vis + (size_t)v1 * hw, wm2,
                                          hyp, volume, vis_sum, V - v1, C, D, h, w, hyp_pp,
-                                         CDS_AGG_ACCUMULATE | (flags & CDS_AGG_NORMALIZE) | layout, st);
+                                         CDS_AGG_ACCUMULATE | (flags & CDS_AGG_NORMALIZE) | keep, st);
   }
   const int tiles_x = cds_ceil_div(w, TW), tiles_y = cds_ceil_div(h, TH);
   const int ntiles = tiles_x * tiles_y;
@@ -803,41 +824,56 @@ bool cds_warp_aggregate_lds_launch(const float* ref, const float* src, const flo
   const int seg_planes = cds_ceil_div(chunks, nseg) * DC;
   nseg = cds_ceil_div(D, seg_planes);
   const bool acc_f = flags & CDS_AGG_ACCUMULATE, nrm_f = flags & CDS_AGG_NORMALIZE;
-#define LAUNCH3(VM, A, N)                                                                                              \
-  hipLaunchKernelGGL((warp_aggregate_lds_kernel<VM, A, N>), dim3(ntiles * ngroups * nseg), dim3(256),                  \
-                     (size_t)VM * 2 * BOX_CAP * sizeof(float4) + 5 * VM * 4 * sizeof(int), st, ref, src, vis, wm, hyp, \
+  const bool fast_f = flags & CDS_AGG_FAST_POSITIONS;
+#define LAUNCH4(VM, A, N, F, CAPV)                                                                                      \
+  hipLaunchKernelGGL((warp_aggregate_lds_kernel<VM, A, N, F, CAPV>), dim3(ntiles * ngroups * nseg), dim3(256),         \
+                     (size_t)VM * 2 * CAPV * sizeof(float4) + 5 * VM * 4 * sizeof(int), st, ref, src, vis, wm, hyp,    \
                      volume, vis_sum, C, D, h, w, rhw, rhh, flags, tiles_x, ntiles, nseg, seg_planes)
-#define LAUNCH(VM)                                 \
+#define LAUNCH3(VM, A, N, CAPV)                    \
   do {                                             \
-    if (acc_f && nrm_f) LAUNCH3(VM, true, true);   \
-    else if (acc_f) LAUNCH3(VM, true, false);      \
-    else if (nrm_f) LAUNCH3(VM, false, true);      \
-    else LAUNCH3(VM, false, false);                \
+    if (fast_f) LAUNCH4(VM, A, N, true, CAPV);     \
+    else LAUNCH4(VM, A, N, false, CAPV);           \
+  } while (0)
+#define LAUNCH(VM, CAPV)                                 \
+  do {                                                   \
+    if (acc_f && nrm_f) LAUNCH3(VM, true, true, CAPV);   \
+    else if (acc_f) LAUNCH3(VM, true, false, CAPV);      \
+    else if (nrm_f) LAUNCH3(VM, false, true, CAPV);      \
+    else LAUNCH3(VM, false, false, CAPV);                \
   } while (0)
   switch (V) {   // the kernel is specialised on the exact view count
-    case 1: LAUNCH(1); break;
-    case 2: LAUNCH(2); break;
-    case 3: LAUNCH(3); break;
-    default: LAUNCH(4); break;
+    case 1: LAUNCH(1, BOX_CAP); break;
+    case 2: LAUNCH(2, BOX_CAP); break;
+    case 3: LAUNCH(3, BOX_CAP); break;
+    case 4: LAUNCH(4, BOX_CAP); break;
+    case 5: LAUNCH(5, BOX_CAP6); break;
+    default: LAUNCH(6, BOX_CAP6); break;
   }
+#undef LAUNCH4
 #undef LAUNCH3
 #undef LAUNCH
   return true;
 }
 
 bool cds_warp_entropy_lds_launch(const float* ref, const float* src, const WarpMats& wm, const float* hyp,
-                                 float* entropy, int V, int C, int D, int h, int w, int hyp_pp, hipStream_t st) {
+                                 float* entropy, int V, int C, int D, int h, int w, int hyp_pp, bool fast, hipStream_t st) {
   if ((C != 8 && C != 16 && C != 32) || !hyp_pp || w < 2 || h < 2 || (size_t)D * h * w * 4 >= ((size_t)1 << 32)) return false;
   const int tiles_x = cds_ceil_div(w, TW), tiles_y = cds_ceil_div(h, TH);
   const int ntiles = tiles_x * tiles_y;
   const float rhw = (float)(1.0 / (double)(float)((w - 1) / 2.0)), rhh = (float)(1.0 / (double)(float)((h - 1) / 2.0));
-#define LAUNCH1(NG, CAP, DCK)                                                                                      \
-  hipLaunchKernelGGL((warp_entropy_lds_kernel<NG, CAP, DCK>), dim3(ntiles * V), dim3(256),                         \
+#define LAUNCH2(NG, CAP, DCK, F)                                                                                   \
+  hipLaunchKernelGGL((warp_entropy_lds_kernel<NG, CAP, DCK, F>), dim3(ntiles * V), dim3(256),                      \
                      (size_t)2 * NG * CAP * sizeof(float4) + 5 * 4 * sizeof(int), st, ref, src, wm, hyp, entropy, V, D, \
                      h, w, rhw, rhh, tiles_x, ntiles)
+#define LAUNCH1(NG, CAP, DCK)                \
+  do {                                       \
+    if (fast) LAUNCH2(NG, CAP, DCK, true);   \
+    else LAUNCH2(NG, CAP, DCK, false);       \
+  } while (0)
   if (C == 8) LAUNCH1(1, BOX1, DC1);
   else if (C == 16) LAUNCH1(2, BOX_CAP, DC);
   else LAUNCH1(4, BOX_CAP, DC);
+#undef LAUNCH2
 #undef LAUNCH1
   return true;
 }

@@ -12,7 +12,8 @@ from typing import Optional, Tuple
 import torch
 
 from . import _lib
-from ._lib import (ACT_LEAKY01, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, AGG_ACCUMULATE, AGG_CHANNELS_LAST, AGG_NORMALIZE,
+from ._lib import (ACT_LEAKY01, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, AGG_ACCUMULATE, AGG_CHANNELS_LAST, AGG_FAST_POSITIONS,
+                   AGG_NORMALIZE,
                    MAX_IMAGES, MAX_VIEWS, check)
 
 Tensor = torch.Tensor
@@ -115,8 +116,21 @@ def homo_warp(src_hwc: Tensor, mat: Tensor, hyp: Tensor) -> Tensor:
     return out
 
 
-def warp_entropy(ref_chw: Tensor, src_hwc: Tensor, mats: Tensor, hyp: Tensor) -> Tensor:
-    """K1.  ref_chw [V,C,h,w], src_hwc [V,h,w,C], mats CPU [V,12], hyp [D,h,w]|[D] -> entropy [V,h,w]."""
+# Sample-position arithmetic of the LDS-staged K1 / K3 kernels (decision and measurements: DESIGN.md section 4).
+# Default: the reference's fp32 operation order (true divisions + ATen's normalise / de-normalise round trip), sample positions
+# bit-identical to F.grid_sample's.  CDS_WARP_FAST=1 (or exact=False per call) samples at p.xy * rcp(p.z + 1e-6) directly:
+# K1 / K3 7-12 % faster, but the positions move by up to ~1e-4 px at w = 640, which moves the volume of SHARP feature maps past the
+# 1e-5 parity tolerance (the small goldens, w = 40, do not show it) -- so it stays opt-in.
+WARP_EXACT = os.environ.get("CDS_WARP_FAST", "0") != "1"
+
+
+def _pos_flag(exact: Optional[bool]) -> int:
+    return 0 if (WARP_EXACT if exact is None else exact) else AGG_FAST_POSITIONS
+
+
+def warp_entropy(ref_chw: Tensor, src_hwc: Tensor, mats: Tensor, hyp: Tensor, exact: Optional[bool] = None) -> Tensor:
+    """K1.  ref_chw [V,C,h,w], src_hwc [V,h,w,C], mats CPU [V,12], hyp [D,h,w]|[D] -> entropy [V,h,w].
+    exact: sample-position arithmetic (None = the module default ``WARP_EXACT``)."""
     V, C, h, w = ref_chw.shape
     if tuple(src_hwc.shape) != (V, h, w, C) or tuple(mats.shape) != (V, 12):
         raise ValueError("warp_entropy: inconsistent shapes")
@@ -126,15 +140,17 @@ def warp_entropy(ref_chw: Tensor, src_hwc: Tensor, mats: Tensor, hyp: Tensor) ->
     with prof("warp_entropy"):
         for v0 in range(0, V, MAX_VIEWS):
             v1 = min(V, v0 + MAX_VIEWS)
-            check(lib.cds_warp_entropy_f32(_dev(ref_chw[v0:v1], "ref"), _dev(src_hwc[v0:v1], "src"),
-                                           _host(mats[v0:v1], "mats"), _dev(hyp, "hyp"), ent[v0:v1].data_ptr(),
-                                           v1 - v0, C, D, h, w, pp, _stream(ent)), "cds_warp_entropy_f32")
+            check(lib.cds_warp_entropy_flags_f32(_dev(ref_chw[v0:v1], "ref"), _dev(src_hwc[v0:v1], "src"),
+                                                 _host(mats[v0:v1], "mats"), _dev(hyp, "hyp"), ent[v0:v1].data_ptr(),
+                                                 v1 - v0, C, D, h, w, pp, _pos_flag(exact), _stream(ent)),
+                  "cds_warp_entropy_flags_f32")
     return ent
 
 
 def warp_aggregate(ref_chw: Tensor, src_hwc: Tensor, vis_w: Tensor, mats: Tensor, hyp: Tensor,
                    normalize: bool = True, volume: Optional[Tensor] = None, vis_sum: Optional[Tensor] = None,
-                   accumulate: bool = False, channels_last: bool = False) -> Tuple[Tensor, Tensor]:
+                   accumulate: bool = False, channels_last: bool = False,
+                   exact: Optional[bool] = None) -> Tuple[Tensor, Tensor]:
     """K3.  Returns (volume [C,D,h,w] — or [D,h,w,C] with channels_last, the layout the split-bf16 CostRegNet kernels
     read — and vis_sum [h,w]).  With normalize=False the raw visibility-weighted sums are returned (what a source-view
     shard contributes to the all-reduce)."""
@@ -157,7 +173,7 @@ def warp_aggregate(ref_chw: Tensor, src_hwc: Tensor, vis_w: Tensor, mats: Tensor
     with prof("warp_aggregate"):
         for i, v0 in enumerate(range(0, V, MAX_VIEWS)):
             v1 = min(V, v0 + MAX_VIEWS)
-            flags = AGG_CHANNELS_LAST if channels_last else 0
+            flags = (AGG_CHANNELS_LAST if channels_last else 0) | _pos_flag(exact)
             if accumulate or i > 0:
                 flags |= AGG_ACCUMULATE
             if normalize and i == nchunks - 1:
@@ -203,7 +219,7 @@ class WarpAggregate(torch.autograd.Function):
         ref_chw, src_hwc, vis_w, hyp = (t.contiguous() for t in (ref_chw, src_hwc, vis_w, hyp))
         ctx.save_for_backward(ref_chw, src_hwc, vis_w, hyp)
         ctx.mats = mats
-        volume, _ = warp_aggregate(ref_chw, src_hwc, vis_w, mats, hyp, normalize=False)
+        volume, _ = warp_aggregate(ref_chw, src_hwc, vis_w, mats, hyp, normalize=False, exact=True)   # the backward kernel differentiates the reference-order positions
         return volume
 
     @staticmethod

@@ -40,6 +40,15 @@ extern "C" {
 #define CDS_AGG_ACCUMULATE 1 /* add onto the existing volume / vis_sum instead of overwriting */
 #define CDS_AGG_NORMALIZE 2  /* divide by (vis_sum + 1e-6) before the store (model.py:74) */
 #define CDS_AGG_CHANNELS_LAST 4 /* volume laid out [D][h][w][C] (a voxel's channels contiguous: one 32-byte store per 8 channels) */
+/*
+ * Sample-position arithmetic of the LDS-staged K1 / K3 kernels (flag of cds_warp_aggregate_f32 and cds_warp_entropy_flags_f32).
+ * Absent: the reference's fp32 operation order (true divisions, ATen's normalise / de-normalise round trip): positions
+ * bit-identical to F.grid_sample's.  Set: (u, v) = p.xy * rcp(p.z + 1e-6) directly; positions move by <= ~1e-4 px, the volume by
+ * <= 4e-6 (tolerance 1e-5), the depth mean-L1 not at all (profiles/r02_relaxed_positions_ab.md); 9 % faster.  The direct
+ * (non-LDS) fallback kernels always use the reference order.
+ */
+#define CDS_AGG_FAST_POSITIONS 8
+#define CDS_WARP_FAST_POSITIONS CDS_AGG_FAST_POSITIONS
 
 /* Library version (major*10000 + minor*100 + patch). */
 int cds_version(void);
@@ -69,6 +78,10 @@ int cds_homo_warp_f32(const float* src_hwc, const float* mat_host, const float* 
 int cds_warp_entropy_f32(const float* ref_chw, const float* src_hwc, const float* mats_host,
                          const float* hyp, float* entropy, int V, int C, int D, int h, int w,
                          int hyp_per_pixel, void* stream);
+/* the same with flags: CDS_WARP_FAST_POSITIONS (cds_warp_entropy_f32 == flags 0) */
+int cds_warp_entropy_flags_f32(const float* ref_chw, const float* src_hwc, const float* mats_host,
+                               const float* hyp, float* entropy, int V, int C, int D, int h, int w,
+                               int hyp_per_pixel, int flags, void* stream);
 
 /*
  * K3 "warp-aggregate" (model.py:44-47,57-60,74): volume = sum_v vis_v * (ref_v (x) warp(src_v)),

@@ -62,12 +62,19 @@ def test_homo_warp_plane_hypotheses(dev, ops):
     assert torch.equal(a, b)
 
 
+# Both sample-position modes of the LDS-staged K1 / K3 kernels are held to the reference goldens at the SAME tolerances:
+# exact=True is the product default (the reference's fp32 operation order, ops.WARP_EXACT) and must in addition stay at round-off
+# level (bit-identical positions); exact=False is the opt-in fast form (CDS_WARP_FAST=1).
+POSITION_MODES = [pytest.param(False, id="fast"), pytest.param(True, id="exact")]
+
+
+@pytest.mark.parametrize("exact", POSITION_MODES)
 @pytest.mark.parametrize("tag", ["a", "b", "c"])
-def test_warp_entropy(tag, dev, ops):
+def test_warp_entropy(tag, exact, dev, ops):
     g = load_golden(f"g1_warp_aggregate_{tag}")
     ref, src_hwc, mats, hyp = _stage_inputs(g, dev, ops)
-    ent = ops.warp_entropy(ref, src_hwc, mats, hyp).cpu()
-    assert (ent - g["entropy"]).abs().max() < 2e-5
+    ent = ops.warp_entropy(ref, src_hwc, mats, hyp, exact=exact).cpu()
+    assert (ent - g["entropy"]).abs().max() < (5e-6 if exact else 2e-5)
 
 
 @pytest.mark.parametrize("tag", ["a", "b", "c"])
@@ -78,13 +85,14 @@ def test_visibility_cnn(tag, dev, seeded_state):
     assert (vis - g["vis_w"]).abs().max() < 1e-5
 
 
+@pytest.mark.parametrize("exact", POSITION_MODES)
 @pytest.mark.parametrize("tag", ["a", "b", "c"])
-def test_warp_aggregate(tag, dev, ops):
+def test_warp_aggregate(tag, exact, dev, ops):
     g = load_golden(f"g1_warp_aggregate_{tag}")
     ref, src_hwc, mats, hyp = _stage_inputs(g, dev, ops)
-    vol, vis_sum = ops.warp_aggregate(ref, src_hwc, g["vis_w"].to(dev).contiguous(), mats, hyp)
+    vol, vis_sum = ops.warp_aggregate(ref, src_hwc, g["vis_w"].to(dev).contiguous(), mats, hyp, exact=exact)
     diff = (vol.cpu() - g["volume_mean"]).abs()
-    assert diff.max() < 1e-5, diff.max()
+    assert diff.max() < (2e-6 if exact else 1e-5), diff.max()
     assert (vis_sum.cpu() - g["vis_w"].sum(0)).abs().max() < 1e-6
 
 
@@ -382,15 +390,19 @@ def _random_stage(ops, dev, V, C, D, h, w, seed, sharp=True):
                                        (2, 32, 4, 8, 66), (4, 8, 2, 5, 3),
                                        # C = 8 with 2 / 3 views: the LDS kernels are specialised per view count; D = 70
                                        # spans three chunks (32 + 32 + 6) and an odd plane pair at the end
-                                       (2, 8, 70, 11, 67), (3, 8, 35, 6, 129)])
-def test_warp_kernels_vs_oracle_odd_shapes(V, C, D, h, w, dev, ops):
-    """Odd D / widths that are not tile multiples / V = 1, 6 (direct path) / C = 16, 32 / tiny images: K1 and K3 against
-    the CPU oracle (explicit fp32 gather)."""
+                                       (2, 8, 70, 11, 67), (3, 8, 35, 6, 129),
+                                       # 5 / 6 views: one pass with the smaller per-view boxes (BASELINE config 4, N = 7);
+                                       # 7 views: two launches, the second accumulating onto the first
+                                       (5, 8, 50, 20, 90), (6, 32, 10, 16, 40), (6, 16, 49, 24, 72), (7, 8, 12, 12, 70)])
+@pytest.mark.parametrize("exact", POSITION_MODES)
+def test_warp_kernels_vs_oracle_odd_shapes(V, C, D, h, w, exact, dev, ops):
+    """Odd D / widths that are not tile multiples / V = 1, 6 (one pass with the smaller 6-view boxes) / C = 16, 32 / tiny
+    images: K1 and K3 against the CPU oracle (explicit fp32 gather), both position modes."""
     from oracle import cds_oracle as O
     feats, cams, hyp, ref, src, mats, hyp_d = _random_stage(ops, dev, V, C, D, h, w, seed=40 + V + C)
     vis = torch.rand(V, h, w, generator=torch.Generator().manual_seed(1)) * 0.8 + 0.1
-    ent = ops.warp_entropy(ref, src, mats, hyp_d).cpu()
-    vol, vis_sum = ops.warp_aggregate(ref, src, vis.to(dev).contiguous(), mats, hyp_d)
+    ent = ops.warp_entropy(ref, src, mats, hyp_d, exact=exact).cpu()
+    vol, vis_sum = ops.warp_aggregate(ref, src, vis.to(dev).contiguous(), mats, hyp_d, exact=exact)
     P_ref = O.compose_projection(cams[:, 0])
     want_vol, want_ent = 0.0, []
     for v in range(V):
@@ -399,9 +411,34 @@ def test_warp_kernels_vs_oracle_odd_shapes(V, C, D, h, w, dev, ops):
         want_vol = want_vol + in_prod * vis[v].view(1, 1, 1, h, w)
         want_ent.append(e[0, 0])
     want_vol = want_vol[0] / (vis.sum(0).view(1, 1, h, w) + 1e-6)
-    assert (vol.cpu() - want_vol).abs().max() < 1e-5
-    assert (ent - torch.stack(want_ent)).abs().max() < 5e-5
+    # fast positions differ from the reference's by ~1e-7 w px: on these white-noise-sharp maps that is up to ~3e-5 in the volume
+    assert (vol.cpu() - want_vol).abs().max() < (1e-5 if exact else 5e-5)
+    assert (ent - torch.stack(want_ent)).abs().max() < (5e-5 if exact else 2e-4)
     assert (vis_sum.cpu() - vis.sum(0)).abs().max() < 1e-6
+
+
+def test_fast_positions_leave_the_parity_tolerance_at_full_width(dev, ops):
+    """Why the reference-order positions are the default: at w = 640 the fast form p.xy * rcp(z) and the
+    reference's normalise / de-normalise round trip place the samples up to ~1e-4 px apart; on sharp feature maps that moves
+    the volume past the 1e-5 parity tolerance, while the exact mode stays at round-off level against the CPU oracle."""
+    from oracle import cds_oracle as O
+    V, C, D, h, w = 2, 8, 6, 16, 640
+    feats, cams, hyp, ref, src, mats, hyp_d = _random_stage(ops, dev, V, C, D, h, w, seed=11)
+    vis = (torch.rand(V, h, w, generator=torch.Generator().manual_seed(1)) * 0.8 + 0.1)
+    P_ref = O.compose_projection(cams[:, 0])
+    want = 0.0
+    for v in range(V):
+        warped = O.warp_volume(feats[v]["src"][0], O.compose_projection(cams[:, v + 1]), P_ref, hyp)
+        want = want + O.correlation_entropy(feats[v]["ref"][0], warped)[0] * vis[v].view(1, 1, 1, h, w)
+    want = want[0] / (vis.sum(0).view(1, 1, h, w) + 1e-6)
+    err = {}
+    for exact in (True, False):
+        vol, _ = ops.warp_aggregate(ref, src, vis.to(dev).contiguous(), mats, hyp_d, exact=exact)
+        err[exact] = (vol.cpu() - want).abs().max().item()
+    print("volume max-abs vs oracle at w=640: exact", err[True], "fast", err[False])
+    assert err[True] < 2e-6
+    assert err[False] < 1e-3          # bounded (a position error, not a bug) ...
+    assert err[False] > err[True]     # ... but not at round-off level
 
 
 def test_warp_paths_agree_lds_vs_direct(dev, ops):
@@ -420,7 +457,7 @@ def test_warp_paths_agree_lds_vs_direct(dev, ops):
     outs = []
     for flag in ("0", "1"):
         path = f"/tmp/cds_paths_{flag}.pt"
-        env = dict(os.environ, CDS_WARP_DIRECT=flag)
+        env = dict(os.environ, CDS_WARP_DIRECT=flag, CDS_WARP_EXACT="1")   # the direct kernels always use the reference order
         subprocess.run([sys.executable, "-c", code, path], check=True, env=env, cwd=os.path.dirname(os.path.dirname(__file__)))
         outs.append(torch.load(path))
     assert (outs[0][0] - outs[1][0]).abs().max() < 2e-5
@@ -432,8 +469,10 @@ def test_per_plane_hypotheses_equal_broadcast(dev, ops):
     planes = torch.linspace(430, 890, 6, device=dev)
     full = planes.view(-1, 1, 1).expand(-1, 16, 40).contiguous()
     vis = torch.rand(2, 16, 40, device=dev)
-    assert (ops.warp_entropy(ref, src, mats, planes) - ops.warp_entropy(ref, src, mats, full)).abs().max() < 2e-5
-    assert (ops.warp_aggregate(ref, src, vis, mats, planes)[0] - ops.warp_aggregate(ref, src, vis, mats, full)[0]).abs().max() < 2e-6
+    # [D] hypotheses run on the direct kernels (always the reference-order positions): compare like with like
+    assert (ops.warp_entropy(ref, src, mats, planes) - ops.warp_entropy(ref, src, mats, full, exact=True)).abs().max() < 2e-5
+    assert (ops.warp_aggregate(ref, src, vis, mats, planes)[0] - ops.warp_aggregate(ref, src, vis, mats, full, exact=True)[0]).abs().max() < 2e-6
+    assert (ops.warp_aggregate(ref, src, vis, mats, planes)[0] - ops.warp_aggregate(ref, src, vis, mats, full, exact=False)[0]).abs().max() < 1e-5
 
 
 def test_full_size_M1_properties(dev, ops):
@@ -636,7 +675,8 @@ def test_full_size_cascade_configs(H, W, N, refine):
     assert (a["stage1"]["depth"] - c["stage1"]["depth"]).abs().mean() < 5e-3
 
 
-def test_warp_lds_fallbacks_wild_geometry(dev, ops):
+@pytest.mark.parametrize("exact", POSITION_MODES)
+def test_warp_lds_fallbacks_wild_geometry(exact, dev, ops):
     """Geometry that defeats the LDS fast path: a wide baseline and near depths give tens of pixels of parallax per plane
     (boxes over the LDS budget even after the chunk is halved to 8 planes -> global-memory path), randomly permuted
     (non-monotone) hypotheses, and a source camera whose principal plane cuts the depth range (projective pole: samples
@@ -654,9 +694,9 @@ def test_warp_lds_fallbacks_wild_geometry(dev, ops):
     mats = geometry.warp_matrices(cams[0])
     hyp_d = hyp[0].to(dev).contiguous()
     P_ref = O.compose_projection(cams[:, 0])
-    ent = ops.warp_entropy(ref, src, mats, hyp_d).cpu()
+    ent = ops.warp_entropy(ref, src, mats, hyp_d, exact=exact).cpu()
     vis = torch.rand(V, h, w, generator=g)
-    vol, _ = ops.warp_aggregate(ref, src, vis.to(dev), mats, hyp_d, normalize=False)
+    vol, _ = ops.warp_aggregate(ref, src, vis.to(dev), mats, hyp_d, normalize=False, exact=exact)
     want = torch.zeros(C, D, h, w)
     for v in range(V):
         warped = O.warp_volume(feats[v]["src"][0], O.compose_projection(cams[:, v + 1]), P_ref, hyp)
