@@ -289,42 +289,61 @@ def measure_viewshard(model, dev, dist, rank, world, exchange, stage_name="M1", 
     out = {"ranks": dist.get_world_size(), "backend": dist.get_backend(), "exchange": exchange,
            "NCCL_ALGO": os.environ.get("NCCL_ALGO"), "NCCL_PROTO": os.environ.get("NCCL_PROTO"),
            "collective": "one fp32 SUM all-reduce of volume_sum ++ vis_sum ++ nc_sum per stage (models/model.py:57-60,74)"}
+    # self-check of the first RCCL run: one rank per GPU in ONE communicator, and that communicator is RCCL
+    out["self_check"] = {"ranks_equal_n_gpus": dist.get_world_size() == world, "backend_is_nccl": dist.get_backend() == "nccl"}
+    if dev.type == "cuda" and torch.cuda.device_count() >= world and not all(out["self_check"].values()):
+        raise RuntimeError(f"viewshard self-check failed: {out['self_check']} (ranks {dist.get_world_size()}, N {world}, "
+                           f"backend {dist.get_backend()})")
     try:
         out["rccl_version"] = ".".join(str(x) for x in torch.cuda.nccl.version())
     except Exception:
         out["rccl_version"] = None
-    with torch.no_grad():
-        h, w, D, C, n_views = WORKLOADS[stage_name]
-        stage = {8: 2, 16: 1, 32: 0}[C]
-        _, cams, hyp, dfe = make_workload(stage_name, 0, dev)
-        hyp_d = hyp.to(dev)
-        runner = cdist.ViewShardedStage(model, dist.group.WORLD, exchange=exchange)
-        ms, kern = timed(lambda: runner(dfe, cams, hyp_d, D, stage), 5, 2)
-        out["stage"] = {"workload": f"{stage_name}: {w}x{h}, D={D}, C={C}, N={n_views}", "ms_per_depth_map": ms,
-                        "depth_maps_per_s": 1e3 / ms, "allreduce_bytes": 4 * cdist.ViewShard.flat_size(C, D, h, w),
-                        "allreduce_ms": kern.get("allreduce"), "local_source_views": len(runner.shard.local_views(n_views - 1)),
-                        "kernel_ms": {k: round(v, 4) for k, v in sorted(kern.items())}}
-        if kern.get("allreduce"):
-            out["stage"]["allreduce_busbw_GBps"] = (2.0 * (world - 1) / world * out["stage"]["allreduce_bytes"]
-                                                    / (kern["allreduce"] * 1e-3) / 1e9)
-        del dfe, hyp_d, runner
-        H, W, nv = CASCADES[cascade_name]
-        imgs = synth.make_images(nv, H, W, seed=0).to(dev)
-        pm = synth.make_cameras(nv, H, W, refine=False, seed=0)
-        dv = synth.make_depth_values()
-        sh = cdist.shard_views(model, dist.group.WORLD, exchange=exchange)
-        try:
-            ms, kern = timed(lambda: model(imgs, pm, dv, temperature=0.01), 3, 2)
-        finally:
-            model._view_shard = None
-        bytes_per_map = sum(4 * cdist.ViewShard.flat_size(Cs, Ds, H // sc, W // sc)
-                            for sc, Ds, Cs in zip((4, 2, 1), NDEPTHS, STAGE_C))
-        out["cascade"] = {"workload": f"{cascade_name}: cascade {W}x{H}, N={nv}, D={NDEPTHS}", "ms_per_depth_map": ms,
-                          "depth_maps_per_s": 1e3 / ms, "allreduce_bytes": bytes_per_map, "allreduces_per_depth_map": 3,
-                          "allreduce_ms": kern.get("allreduce"), "local_source_views": len(sh.local_views(nv - 1)),
-                          "kernel_ms": {k: round(v, 4) for k, v in sorted(kern.items())}}
-        if kern.get("allreduce"):
-            out["cascade"]["allreduce_busbw_GBps"] = (2.0 * (world - 1) / world * bytes_per_map / (kern["allreduce"] * 1e-3) / 1e9)
+
+    def one_mode(exch):
+        res = {}
+        key = "reduce_scatter" if exch == "reduce_scatter" else "allreduce"
+        with torch.no_grad():
+            h, w, D, C, n_views = WORKLOADS[stage_name]
+            stage = {8: 2, 16: 1, 32: 0}[C]
+            _, cams, hyp, dfe = make_workload(stage_name, 0, dev)
+            hyp_d = hyp.to(dev)
+            runner = cdist.ViewShardedStage(model, dist.group.WORLD, exchange=exch)
+            ms, kern = timed(lambda: runner(dfe, cams, hyp_d, D, stage), 5, 2)
+            nbytes = 4 * cdist.ViewShard.flat_size(C, D, h, w)
+            res["stage"] = {"workload": f"{stage_name}: {w}x{h}, D={D}, C={C}, N={n_views}", "ms_per_depth_map": ms,
+                            "depth_maps_per_s": 1e3 / ms, "exchange_bytes_per_rank": nbytes if key == "allreduce" else
+                            runner.shard.exchanged_bytes // max(1, runner.shard.exchanges),
+                            "exchange_ms": kern.get(key), "local_source_views": len(runner.shard.local_views(n_views - 1)),
+                            "halo_exchanges_per_depth_map": runner.shard.halo_exchanges // max(1, runner.shard.exchanges),
+                            "halo_bytes_sent_per_rank": runner.shard.halo_bytes // max(1, runner.shard.exchanges),
+                            "kernel_ms": {k: round(v, 4) for k, v in sorted(kern.items())}}
+            if key == "allreduce" and kern.get("allreduce"):
+                res["stage"]["allreduce_busbw_GBps"] = 2.0 * (world - 1) / world * nbytes / (kern["allreduce"] * 1e-3) / 1e9
+            del dfe, hyp_d, runner
+            H, W, nv = CASCADES[cascade_name]
+            imgs = synth.make_images(nv, H, W, seed=0).to(dev)
+            pm = synth.make_cameras(nv, H, W, refine=False, seed=0)
+            dv = synth.make_depth_values()
+            sh = cdist.shard_views(model, dist.group.WORLD, exchange=exch)
+            try:
+                ms, kern = timed(lambda: model(imgs, pm, dv, temperature=0.01), 3, 2)
+            finally:
+                model._view_shard = None
+            bytes_per_map = sum(4 * cdist.ViewShard.flat_size(Cs, Ds, H // sc, W // sc)
+                                for sc, Ds, Cs in zip((4, 2, 1), NDEPTHS, STAGE_C))
+            res["cascade"] = {"workload": f"{cascade_name}: cascade {W}x{H}, N={nv}, D={NDEPTHS}", "ms_per_depth_map": ms,
+                              "depth_maps_per_s": 1e3 / ms, "volume_bytes": bytes_per_map, "exchanges_per_depth_map": 3,
+                              "exchange_ms": kern.get(key), "local_source_views": len(sh.local_views(nv - 1)),
+                              "kernel_ms": {k: round(v, 4) for k, v in sorted(kern.items())}}
+            if key == "allreduce" and kern.get("allreduce"):
+                res["cascade"]["allreduce_busbw_GBps"] = 2.0 * (world - 1) / world * bytes_per_map / (kern["allreduce"] * 1e-3) / 1e9
+        return res
+
+    out.update(one_mode(exchange if exchange != "reduce_scatter" else "allreduce"))     # north-star form: stage / cascade keys
+    # the form that scales (round 3): rows of the sum + slab-parallel CostRegNet with per-layer halo exchange + row gather
+    out["reduce_scatter"] = one_mode("reduce_scatter")
+    out["reduce_scatter"]["collective"] = ("point-to-point reduce-scatter of the partial sums by rows, 11 one-row halo exchanges "
+                                           "inside the slab-parallel CostRegNet, gather of 3 h w floats")
     return out
 
 
@@ -335,8 +354,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="M1", choices=sorted(WORKLOADS) + sorted(CASCADES) + sorted(TRAIN))
     ap.add_argument("--parallelism", default="replicas", choices=["replicas", "viewshard"])
-    ap.add_argument("--exchange", default="allreduce", choices=["allreduce", "p2p"],
-                    help="viewshard exchange: one RCCL all-reduce, or reduce-scatter + all-gather as direct P2P sends")
+    ap.add_argument("--exchange", default="allreduce", choices=["allreduce", "p2p", "reduce_scatter"],
+                    help="viewshard exchange: one RCCL all-reduce; reduce-scatter + all-gather as direct P2P sends; or "
+                         "reduce_scatter = rows of the sum per rank + slab-parallel CostRegNet (the form that scales)")
     ap.add_argument("--no-extras", action="store_true", help="skip the M1b / M2 / M3 / M4 side measurements")
     ap.add_argument("--no-viewshard", action="store_true", help="N > 1: skip the north-star view-shard measurement")
     ap.add_argument("--streams", type=int, default=1,

@@ -83,6 +83,21 @@ __device__ __forceinline__ void split_store8(unsigned char* dst, const float4& a
 
 constexpr int POSB = 48;   // bytes per LDS position
 
+// A/B build knobs (scripts/build_variant.sh): CDS_SBF_PRIO = s_setprio level of the consumer (MFMA) waves, the producers stay at 0;
+// CDS_SBF_NTSTORE = nontemporal epilogue stores (the activations are far larger than L2 + MALL and are read back a layer later).
+#ifdef CDS_SBF_PRIO
+#define SBF_CONSUMER_PRIO() __builtin_amdgcn_s_setprio(CDS_SBF_PRIO)
+#else
+#define SBF_CONSUMER_PRIO()
+#endif
+__device__ __forceinline__ void sbf_store4(float* p, const float4& o) {
+#ifdef CDS_SBF_NTSTORE
+  __builtin_nontemporal_store((f32x4){o.x, o.y, o.z, o.w}, reinterpret_cast<f32x4*>(p));
+#else
+  *reinterpret_cast<float4*>(p) = o;
+#endif
+}
+
 // Tile order: z fastest, then x, then y.  A workgroup walks consecutive tiles, i.e. a column of z-adjacent tiles: the halo
 // planes it shares with the tile before are still in its XCD's L2.  (Measured, FETCH_SIZE: with x fastest the halo re-reads
 // of conv0 went to the fabric almost entirely, 4.5 GB fetched for a 2.0 GB input, and the layer ran at the fabric's mixed
@@ -225,6 +240,7 @@ __global__ __launch_bounds__((FCfg<S, MB, TX_, TZ_, PAIR, WRES_>::THREADS)) void
   }
 
   // ============================== consumers ==============================
+  SBF_CONSUMER_PRIO();
   const int j = lane & 15, g = lane >> 4;
   // per-lane byte offset of the tap this lane group multiplies in K-step t (tap 27 = zero weights -> any in-tile data)
   int toff[Cfg::KSTEPS];
@@ -374,7 +390,7 @@ __global__ __launch_bounds__((FCfg<S, MB, TX_, TZ_, PAIR, WRES_>::THREADS)) void
 #ifdef CDS_EXP_SBF_NOSTORE
               if (o.x == 1234.5f)
 #endif
-              *reinterpret_cast<float4*>(out + base) = o;
+              sbf_store4(out + base, o);
             }
           }
         }
@@ -499,6 +515,7 @@ __global__ __launch_bounds__(ZCfg::THREADS) void conv3d_sbf_zm_kernel(const floa
   }
 
   // ============================== consumers: wave = rows wave and wave + 4 ==============================
+  SBF_CONSUMER_PRIO();
   const int j = lane & 15, g = lane >> 4;
   const int kxl = (g & 1) * 2 + (g >> 1);              // lane groups take x' = 0, 2, 1, 3 (see the tiled kernel)
   const int lane_base = (wave * Cfg::IXP + j + (kxl & 1) * Cfg::IXH + (kxl >> 1)) * POSB;
@@ -563,7 +580,7 @@ __global__ __launch_bounds__(ZCfg::THREADS) void conv3d_sbf_zm_kernel(const floa
         if (act == CDS_ACT_RELU) {
           o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
         }
-        *reinterpret_cast<float4*>(out + ((size_t)((size_t)oz * H + oy) * W + ox) * Cout + co) = o;
+        sbf_store4(out + ((size_t)((size_t)oz * H + oy) * W + ox) * Cout + co, o);
       }
     }
     __syncthreads();                                   // #(st + 1)
@@ -826,9 +843,14 @@ __global__ __launch_bounds__(256, (MERGE ? CDS_DECONV_SBF_MINW : 2)) void deconv
               // 32 consecutive x (both x parities of 16 cells) -> whole 128-byte segments
               const size_t ovol = (size_t)(2 * D) * Ho * Wo;
               float* po = out + (size_t)co * ovol + (rowbase + 2 * ax + px);
+#ifdef CDS_SBF_NTSTORE
+              __builtin_nontemporal_store(o.x, po); __builtin_nontemporal_store(o.y, po + ovol);
+              __builtin_nontemporal_store(o.z, po + 2 * ovol); __builtin_nontemporal_store(o.w, po + 3 * ovol);
+#else
               po[0] = o.x; po[ovol] = o.y; po[2 * ovol] = o.z; po[3 * ovol] = o.w;
+#endif
             } else {
-              *reinterpret_cast<float4*>(out + base) = o;
+              sbf_store4(out + base, o);
             }
           }
         }
@@ -942,6 +964,7 @@ __global__ __launch_bounds__(DWS_THREADS, 3) void deconv3d_sbf_ws_kernel(const f
   }
 
   // ============================== consumers ==============================
+  SBF_CONSUMER_PRIO();
   const int j = lane & 15, g = lane >> 4;
   int toff[Tab::NKS];
 #pragma unroll
@@ -1038,9 +1061,14 @@ __global__ __launch_bounds__(DWS_THREADS, 3) void deconv3d_sbf_ws_kernel(const f
             if (out_planar) {
               const size_t ovol = (size_t)(2 * D) * Ho * Wo;
               float* po = out + (size_t)co * ovol + (rowbase + 2 * ax + px);
+#ifdef CDS_SBF_NTSTORE
+              __builtin_nontemporal_store(o.x, po); __builtin_nontemporal_store(o.y, po + ovol);
+              __builtin_nontemporal_store(o.z, po + 2 * ovol); __builtin_nontemporal_store(o.w, po + 3 * ovol);
+#else
               po[0] = o.x; po[ovol] = o.y; po[2 * ovol] = o.z; po[3 * ovol] = o.w;
+#endif
             } else {
-              *reinterpret_cast<float4*>(out + base) = o;
+              sbf_store4(out + base, o);
             }
           }
         }

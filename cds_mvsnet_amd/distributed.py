@@ -12,6 +12,12 @@ unsharded sum only by fp32 re-association.
 xGMI is point-to-point (7 links per GPU): a ring all-reduce of the 0.5-2 GB volume is single-link bound, which
 at the single-stage M1 size costs more than the warp work it parallelises — this mode
 exists for the many-view / large-image configs; bench.py defaults to independent replicas.
+
+``exchange="reduce_scatter"`` (round 3) is the form that can scale: the partial sums are reduce-scattered BY ROWS (rank r
+receives rows [a_r, b_r) of the sum: (world-1)/world of the volume leaves each rank once, nothing comes back), every rank
+normalises and regularises only its own rows (``slab.slab_cost_regularization``: CostRegNet with one one-row halo exchange
+per layer between neighbouring ranks), runs the soft-argmin on them, and the depth / confidence / curvature rows are
+gathered at the end (3 h w floats).  ``"allreduce"`` / ``"p2p"`` keep the round-1/2 behaviour (everybody regularises all).
 """
 from __future__ import annotations
 
@@ -21,6 +27,7 @@ import torch
 import torch.distributed as dist
 
 from . import geometry, ops
+from .slab import HaloComm, HipCostRegLayers, slab_cost_regularization, slab_rows
 
 Tensor = torch.Tensor
 
@@ -33,8 +40,8 @@ class ViewShard:
     (SURVEY §8(e)).  Both give the same sums up to fp32 re-association."""
 
     def __init__(self, group: Optional["dist.ProcessGroup"] = None, exchange: str = "allreduce"):
-        if exchange not in ("allreduce", "p2p"):
-            raise ValueError("exchange must be 'allreduce' or 'p2p'")
+        if exchange not in ("allreduce", "p2p", "reduce_scatter"):
+            raise ValueError("exchange must be 'allreduce', 'p2p' or 'reduce_scatter'")
         self.group = group
         self.exchange = exchange
         self.rank = dist.get_rank(group)
@@ -44,6 +51,10 @@ class ViewShard:
         self.last_volume: Optional[Tensor] = None
         self.exchanged_bytes = 0
         self.exchanges = 0
+        self.halo_exchanges = 0          # reduce_scatter mode: one-row exchanges of the slab-parallel CostRegNet
+        self.halo_bytes = 0
+        self.gather_bytes = 0
+        self.layers_factory = HipCostRegLayers     # tests plug torch reference layers in here
 
     # ---- bookkeeping (device independent) ----------------------------------------------------
     def local_views(self, n_src: int) -> List[int]:
@@ -115,6 +126,80 @@ class ViewShard:
     def _global(self, group_rank: int) -> int:
         return dist.get_global_rank(self.group, group_rank) if self.group is not None else group_rank
 
+    def reduce_scatter_rows(self, vol_cl: Tensor, vis_sum: Tensor, nc_sum: Tensor, rows):
+        """SUM over ranks, scattered by rows: returns this rank's rows of (volume [D][n][w][C], vis_sum [n][w], nc_sum [n][w]).
+        Point-to-point: rank r sends rows [a_j, b_j) of its partial sums to every rank j (packed into one message per peer)
+        and adds the world-1 messages it receives in rank order.  (world-1)/world of the buffer leaves each rank, once."""
+        self.exchanges += 1
+        W, me = self.world, self.rank
+        D, h, w, C = vol_cl.shape
+        a, b = rows[me]
+
+        def pack(ra, rb):
+            return torch.cat((vol_cl[:, ra:rb].reshape(-1), vis_sum[ra:rb].reshape(-1), nc_sum[ra:rb].reshape(-1)))
+
+        mine = pack(a, b)
+        if W == 1:
+            parts = [mine]
+        else:
+            staged = vol_cl.is_cuda and dist.get_backend(self.group) != "nccl"     # gloo dry runs: through the host
+            peers = [r for r in range(W) if r != me]
+            send = {r: pack(*rows[r]) for r in peers if rows[r][1] > rows[r][0]}
+            if staged:
+                send = {r: t.cpu() for r, t in send.items()}
+            recv = {r: torch.empty(mine.numel(), dtype=mine.dtype, device="cpu" if staged else mine.device)
+                    for r in peers if b > a}
+            ops_ = [dist.P2POp(dist.isend, t, self._global(r), self.group) for r, t in send.items()]
+            ops_ += [dist.P2POp(dist.irecv, t, self._global(r), self.group) for r, t in recv.items()]
+            self.exchanged_bytes += sum(t.numel() * t.element_size() for t in send.values())
+            if ops_:
+                for req in dist.batch_isend_irecv(ops_):
+                    req.wait()
+            parts = [mine if r == me else recv[r].to(mine.device) for r in range(W)] if b > a else [mine]
+        tot = parts[0].clone()
+        for t in parts[1:]:                     # rank order
+            tot.add_(t)
+        n = b - a
+        nv = D * n * w * C
+        return tot[:nv].view(D, n, w, C), tot[nv:nv + n * w].view(n, w), tot[nv + n * w:].view(n, w)
+
+    def _run_stage_slabs(self, model, vol_cl: Tensor, vis_sum: Tensor, nc_sum: Tensor, hyp: Tensor, stage_idx: int,
+                         n_src_total: int):
+        """reduce_scatter mode after the local partial sums: rows -> normalise -> slab CostRegNet -> soft-argmin -> gather."""
+        D, h, w, C = vol_cl.shape
+        rows = slab_rows(h, self.world)
+        a, b = rows[self.rank]
+        with ops.prof("reduce_scatter"):
+            vol_r, vis_r, nc_r = self.reduce_scatter_rows(vol_cl, vis_sum, nc_sum, rows)
+        comm = HaloComm(self.group, rows)
+        out = torch.zeros((3, h, w), dtype=hyp.dtype, device=hyp.device)
+        if b > a:
+            vol_r = vol_r.contiguous()
+            self._normalize_rows(vol_r, vis_r.contiguous())
+            if self.keep_volume:
+                self.last_volume = vol_r.permute(3, 0, 1, 2)
+            prob_pre = slab_cost_regularization(self.layers_factory(model.cost_regularization[stage_idx]), comm, vol_r)
+            depth, conf = self._regress_rows(prob_pre, hyp[:, a:b].contiguous())
+            out[0, a:b], out[1, a:b], out[2, a:b] = depth, conf, nc_r / n_src_total
+        else:
+            slab_cost_regularization(None, comm, vol_r)
+        self.halo_exchanges += comm.exchanges
+        self.halo_bytes += comm.bytes_sent
+        with ops.prof("gather_rows"):
+            if self.world > 1:
+                dist.all_reduce(out, op=dist.ReduceOp.SUM, group=self.group)     # disjoint rows: a gather written as a sum
+                self.gather_bytes += out.numel() * out.element_size()
+        return out[0], out[1], out[2]
+
+    # the two per-pixel device ops of the slab path, overridable by the CPU tests
+    @staticmethod
+    def _normalize_rows(vol_rows: Tensor, vis_rows: Tensor) -> None:
+        ops.volume_normalize_(vol_rows, vis_rows, channels_last=True)
+
+    @staticmethod
+    def _regress_rows(prob_pre: Tensor, hyp_rows: Tensor):
+        return ops.softargmin_conf(prob_pre, hyp_rows)
+
     # ---- one stage on this rank's views (GPU) --------------------------------------------------
     def run_stage(self, model, ref: Optional[Tensor], src: Optional[Tensor], ref_nc: Optional[Tensor],
                   nc_sums: Optional[Tensor], mats: Optional[Tensor], hyp: Tensor, stage_idx: int, n_src_total: int,
@@ -124,6 +209,8 @@ class ViewShard:
             C = ref.shape[1]
         cr = model.cost_regularization[stage_idx]
         cl = cr.split_bf16_supported()          # channels-last volume for the split-bf16 CostRegNet kernels
+        if self.exchange == "reduce_scatter" and not cl:
+            raise RuntimeError("exchange='reduce_scatter' needs the channels-last split-bf16 CostRegNet path")
         flat = torch.zeros(self.flat_size(C, D, h, w), dtype=torch.float32, device=hyp.device)
         vol, vis_sum, nc_sum = self.split_flat(flat, C, D, h, w)
         if cl:
@@ -133,6 +220,8 @@ class ViewShard:
             vis = model.stage_net.visibility(ent, ref_nc, stage_idx).contiguous()
             ops.warp_aggregate(ref, src, vis, mats, hyp, normalize=False, volume=vol, vis_sum=vis_sum, channels_last=cl)
             nc_sum.copy_(nc_sums.sum(dim=0))
+        if self.exchange == "reduce_scatter":
+            return self._run_stage_slabs(model, vol, vis_sum, nc_sum, hyp, stage_idx, n_src_total)
         with ops.prof("allreduce"):
             self.all_reduce_partials(flat)
         ops.volume_normalize_(vol, vis_sum, channels_last=cl)

@@ -65,14 +65,15 @@ def test_shard_views_world1_equals_unsharded():
         imgs, cams, dv = _inputs(4, 128, 160, 3, dev)
         with torch.no_grad():
             want = model(imgs, cams, dv, temperature=0.01)
-            sh = cdist.shard_views(model)
-            sh.keep_volume = True
-            got = model(imgs, cams, dv, temperature=0.01)
-            assert sh.exchanges == 3 and sh.local_views(3) == [0, 1, 2]
-            for k in ("stage1", "stage2", "stage3"):
-                assert (got[k]["depth"] - want[k]["depth"]).abs().mean() < 1e-3, k
-                assert (got[k]["photometric_confidence"] - want[k]["photometric_confidence"]).abs().mean() < 1e-3, k
-                assert (got[k]["norm_curv"] - want[k]["norm_curv"]).abs().max() < 1e-5, k
+            for exchange in ("allreduce", "reduce_scatter"):        # world 1: one slab = the whole grid, no neighbours
+                sh = cdist.shard_views(model, exchange=exchange)
+                sh.keep_volume = True
+                got = model(imgs, cams, dv, temperature=0.01)
+                assert sh.exchanges == 3 and sh.local_views(3) == [0, 1, 2]
+                for k in ("stage1", "stage2", "stage3"):
+                    assert (got[k]["depth"] - want[k]["depth"]).abs().mean() < 1e-3, k
+                    assert (got[k]["photometric_confidence"] - want[k]["photometric_confidence"]).abs().mean() < 1e-3, k
+                    assert (got[k]["norm_curv"] - want[k]["norm_curv"]).abs().max() < 1e-5, k
             # single stage, volume level: normalising after the (identity) exchange == the fused normalisation of K3
             model._view_shard = None
             dfe, scams, hyp = _stage_inputs(3, 8, 16, 40, 64, dev)
@@ -102,12 +103,16 @@ def _two_rank_worker(rank, world, port, q):
         res = {}
         with torch.no_grad():
             want = model(imgs, cams, dv, temperature=0.01)          # unsharded, on this rank
-            for exchange in ("allreduce", "p2p"):
+            for exchange in ("allreduce", "p2p", "reduce_scatter"):
                 sh = cdist.shard_views(model, exchange=exchange)
                 got = model(imgs, cams, dv, temperature=0.01)
                 res[exchange] = [float((got[k]["depth"] - want[k]["depth"]).abs().mean()) for k in ("stage1", "stage2", "stage3")]
+                res[exchange + "_conf"] = max(float((got[k]["photometric_confidence"] - want[k]["photometric_confidence"]).abs().mean())
+                                              for k in ("stage1", "stage2", "stage3"))
+                res[exchange + "_nc"] = max(float((got[k]["norm_curv"] - want[k]["norm_curv"]).abs().max()) for k in ("stage1", "stage2", "stage3"))
                 res[exchange + "_views"] = sh.local_views(N - 1)
                 res[exchange + "_n"] = sh.exchanges
+                res[exchange + "_halo"] = sh.halo_exchanges
             model._view_shard = None
             # stage level: the all-reduced, normalised volume against the unsharded K3 output
             dfe, scams, hyp = _stage_inputs(3, 8, 16, 40, 64, dev)
@@ -136,9 +141,12 @@ def test_shard_views_two_ranks_on_one_device():
         assert p.exitcode == 0
     assert res[0]["allreduce_views"] == [0, 2] and res[1]["allreduce_views"] == [1]
     for r in range(world):
-        for exchange in ("allreduce", "p2p"):
-            assert res[r][exchange + "_n"] == 3                     # ONE exchange per cascade stage
+        for exchange in ("allreduce", "p2p", "reduce_scatter"):
+            assert res[r][exchange + "_n"] == 3                     # ONE volume exchange per cascade stage
             assert max(res[r][exchange]) < 1e-3, (r, exchange, res[r][exchange])
+            assert res[r][exchange + "_conf"] < 1e-3 and res[r][exchange + "_nc"] < 1e-5, (r, exchange)
+        # reduce_scatter: rows of the sum + slab-parallel CostRegNet on the HIP kernels: 11 one-row halo exchanges per stage
+        assert res[r]["reduce_scatter_halo"] == 33 and res[r]["allreduce_halo"] == 0
         assert res[r]["volume"] < 1e-6, res[r]["volume"]
 
 
