@@ -301,7 +301,7 @@ def measure_viewshard(model, dev, dist, rank, world, exchange, stage_name="M1", 
 
     def one_mode(exch):
         res = {}
-        key = "reduce_scatter" if exch == "reduce_scatter" else "allreduce"
+        key = {"reduce_scatter": "reduce_scatter", "slab": "gather_rows"}.get(exch, "allreduce")
         with torch.no_grad():
             h, w, D, C, n_views = WORKLOADS[stage_name]
             stage = {8: 2, 16: 1, 32: 0}[C]
@@ -344,6 +344,10 @@ def measure_viewshard(model, dev, dist, rank, world, exchange, stage_name="M1", 
     out["reduce_scatter"] = one_mode("reduce_scatter")
     out["reduce_scatter"]["collective"] = ("point-to-point reduce-scatter of the partial sums by rows, 11 one-row halo exchanges "
                                            "inside the slab-parallel CostRegNet, gather of 3 h w floats")
+    # pixel slabs: no volume on any link (view-sharded FeatureNet + all-gather of the feature maps, then all views for own rows)
+    out["slab"] = one_mode("slab")
+    out["slab"]["collective"] = ("all-gather of the per-view feature maps (cascade only), 11 one-row halo exchanges per stage, gather "
+                                 "of 3 h w floats; no cost volume crosses a link")
     return out
 
 
@@ -354,7 +358,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="M1", choices=sorted(WORKLOADS) + sorted(CASCADES) + sorted(TRAIN))
     ap.add_argument("--parallelism", default="replicas", choices=["replicas", "viewshard"])
-    ap.add_argument("--exchange", default="allreduce", choices=["allreduce", "p2p", "reduce_scatter"],
+    ap.add_argument("--exchange", default="allreduce", choices=["allreduce", "p2p", "reduce_scatter", "slab"],
                     help="viewshard exchange: one RCCL all-reduce; reduce-scatter + all-gather as direct P2P sends; or "
                          "reduce_scatter = rows of the sum per rank + slab-parallel CostRegNet (the form that scales)")
     ap.add_argument("--no-extras", action="store_true", help="skip the M1b / M2 / M3 / M4 side measurements")

@@ -36,6 +36,8 @@ SIGNATURES = {
     "cds_warp_entropy_f32": [P, P, P, P, P, I, I, I, I, I, I, P],
     "cds_warp_entropy_flags_f32": [P, P, P, P, P, I, I, I, I, I, I, I, P],
     "cds_warp_aggregate_f32": [P, P, P, P, P, P, P, I, I, I, I, I, I, I, P],
+    "cds_warp_entropy_window_f32": [P, P, P, P, P, I, I, I, I, I, I, I, I, P],
+    "cds_warp_aggregate_window_f32": [P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, P],
     "cds_warp_aggregate_bwd_f32": [P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, P],
     "cds_volume_normalize_f32": [P, P, I, I, I, P],
     "cds_volume_normalize_cl_f32": [P, P, I, I, I, P],

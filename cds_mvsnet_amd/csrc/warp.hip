@@ -296,9 +296,10 @@ __global__ void chw_to_hwc_kernel(const float* __restrict__ src, float* __restri
 // LDS-staged fast paths (warp_lds.hip); return false when the shape is not covered.
 bool cds_warp_aggregate_lds_launch(const float* ref, const float* src, const float* vis, const WarpMats& wm,
                                    const float* hyp, float* volume, const float* vis_sum, int V, int C, int D, int h,
-                                   int w, int hyp_pp, int flags, hipStream_t st);
+                                   int w, int hyp_pp, int flags, hipStream_t st, int hs = 0, int y_off = 0);
 bool cds_warp_entropy_lds_launch(const float* ref, const float* src, const WarpMats& wm, const float* hyp,
-                                 float* entropy, int V, int C, int D, int h, int w, int hyp_pp, bool fast, hipStream_t st);
+                                 float* entropy, int V, int C, int D, int h, int w, int hyp_pp, bool fast, hipStream_t st, int hs = 0,
+                                 int y_off = 0);
 static bool cds_use_lds_path() {
   static const bool on = []() {
     const char* e = getenv("CDS_WARP_DIRECT");  // CDS_WARP_DIRECT=1 forces the direct (L1 gather) kernels
@@ -376,6 +377,40 @@ extern "C" int cds_warp_entropy_flags_f32(const float* ref_chw, const float* src
   else if (C == 16) LAUNCH(16);
   else LAUNCH(32);
 #undef LAUNCH
+  return cds_launch_status();
+}
+
+// Row-window forms (pixel-slab sharding, cds_mvsnet_amd/distributed.py): the reference-side tensors (ref features, hypotheses,
+// weights, entropy / volume outputs) cover rows [y_off, y_off + h) of the hs x w image grid, the source maps the whole grid.
+// Sample positions are computed from the GLOBAL pixel row, so the window of a result is bit-identical to the same rows of the
+// full-grid call.  LDS-staged kernels only (per-pixel hypotheses, C in {8, 16, 32}): anything else is CDS_EINVAL.
+extern "C" int cds_warp_entropy_window_f32(const float* ref_chw, const float* src_hwc, const float* mats_host, const float* hyp,
+                                           float* entropy, int V, int C, int D, int h, int w, int hs, int y_off, int flags,
+                                           void* stream) {
+  if (!ref_chw || !src_hwc || !mats_host || !hyp || !entropy || V < 1 || V > CDS_MAX_VIEWS || D < 1 || h < 1 || hs < h || y_off < 0 ||
+      y_off + h > hs)
+    return CDS_EINVAL;
+  WarpMats wm;
+  cds_fill_mats(wm, mats_host, V);
+  if (!cds_warp_entropy_lds_launch(ref_chw, src_hwc, wm, hyp, entropy, V, C, D, h, w, 1, (flags & CDS_WARP_FAST_POSITIONS) != 0,
+                                   (hipStream_t)stream, hs, y_off))
+    return CDS_EINVAL;
+  return cds_launch_status();
+}
+
+extern "C" int cds_warp_aggregate_window_f32(const float* ref_chw, const float* src_hwc, const float* vis_w, const float* mats_host,
+                                             const float* hyp, float* volume, float* vis_sum, int V, int C, int D, int h, int w,
+                                             int hs, int y_off, int flags, void* stream) {
+  if (!ref_chw || !src_hwc || !vis_w || !mats_host || !hyp || !volume || !vis_sum || V < 1 || V > CDS_MAX_VIEWS || D < 1 || h < 1 ||
+      hs < h || y_off < 0 || y_off + h > hs)
+    return CDS_EINVAL;
+  WarpMats wm;
+  cds_fill_mats(wm, mats_host, V);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(vis_sum_kernel, dim3(cds_ceil_div(h * w, 256)), dim3(256), 0, st, vis_w, vis_sum, V, h * w,
+                     flags & CDS_AGG_ACCUMULATE);
+  if (!cds_warp_aggregate_lds_launch(ref_chw, src_hwc, vis_w, wm, hyp, volume, vis_sum, V, C, D, h, w, 1, flags, st, hs, y_off))
+    return CDS_EINVAL;
   return cds_launch_status();
 }
 

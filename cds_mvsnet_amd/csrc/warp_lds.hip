@@ -384,7 +384,9 @@ template <int VMAX, bool ACCUMULATE, bool NORMALIZE, bool FAST, int CAP>
 __global__ __launch_bounds__(256, CDS_K3_MINW) void warp_aggregate_lds_kernel(
     const float* __restrict__ ref, const float* __restrict__ src, const float* __restrict__ vis, WarpMats mats,
     const float* __restrict__ hyp, float* __restrict__ volume, const float* __restrict__ vis_sum, int C, int D, int h,
-    int w, float rhw, float rhh, int flags, int tiles_x, int ntiles, int nseg, int seg_planes) {
+    int w, float rhw, float rhh, int flags, int tiles_x, int ntiles, int nseg, int seg_planes, int hs, int y_off) {
+  // h x w: the reference-side grid of this call (features, hypotheses, weights, volume); it is the window of rows
+  // [y_off, y_off + h) of the full image grid hs x w that the SOURCE feature maps cover (hs == h, y_off == 0: the whole grid)
   extern __shared__ __attribute__((aligned(16))) cds_f4 lds4[];  // VMAX * 2*CAP float4, then int red[4*VMAX*4], int boxes[VMAX*4]
   int* red = reinterpret_cast<int*>(lds4 + VMAX * 2 * CAP);
 
@@ -403,10 +405,11 @@ __global__ __launch_bounds__(256, CDS_K3_MINW) void warp_aggregate_lds_kernel(
   const bool active = x < w && y < h;
   const int xc = min(x, w - 1), yc = min(y, h - 1);  // inactive lanes shadow a valid pixel, never store
   Geo g;
-  g.h = h; g.w = w;
-  g.half_w = (float)((w - 1) / 2.0); g.half_h = (float)((h - 1) / 2.0);
+  g.h = hs; g.w = w;
+  g.half_w = (float)((w - 1) / 2.0); g.half_h = (float)((hs - 1) / 2.0);
   g.rhw = rhw; g.rhh = rhh;
   const unsigned hw = (unsigned)h * (unsigned)w;
+  const size_t hws = (size_t)hs * w;                 // pixels of a source feature map
   const unsigned pix = (unsigned)yc * (unsigned)w + (unsigned)xc;
   const size_t slab = (size_t)D * hw;  // elements per channel of the volume
   ref += (size_t)c_off * hw;
@@ -424,7 +427,7 @@ __global__ __launch_bounds__(256, CDS_K3_MINW) void warp_aggregate_lds_kernel(
         rv[v][j].x = ref[((size_t)v * C + 2 * j) * hw + pix] * vw;
         rv[v][j].y = ref[((size_t)v * C + 2 * j + 1) * hw + pix] * vw;
       }
-      cds_row_terms(mats.m[v], (float)xc, (float)yc, r[v]);
+      cds_row_terms(mats.m[v], (float)xc, (float)(yc + y_off), r[v]);
     }
   }
   constexpr bool accumulate = ACCUMULATE, normalize = NORMALIZE;
@@ -440,7 +443,7 @@ __global__ __launch_bounds__(256, CDS_K3_MINW) void warp_aggregate_lds_kernel(
       for (int j = 0; j < 4; ++j) rv[v][j] = rv[v][j] * yden;
   }
   const char* hyp_b = reinterpret_cast<const char*>(hyp);
-  const float wf = (float)w, hf = (float)h;
+  const float wf = (float)w, hf = (float)hs;
 
   const int dseg0 = seg * seg_planes, dseg1 = min(D, dseg0 + seg_planes);
   for (int d0 = dseg0, d1 = 0; d0 < dseg1; d0 = d1) {
@@ -454,11 +457,11 @@ __global__ __launch_bounds__(256, CDS_K3_MINW) void warp_aggregate_lds_kernel(
       chunk_depth_range(hyp, hw, pix, d0, d1, dfirst, dlast);
 #pragma unroll
       for (int v = 0; v < VMAX; ++v) {
-        cell_of(r[v], mats.m[v] + 9, dfirst, h, w, g.half_w, g.half_h, cx0[v], cy0[v]);
-        cell_of(r[v], mats.m[v] + 9, dlast, h, w, g.half_w, g.half_h, cx1[v], cy1[v]);
+        cell_of(r[v], mats.m[v] + 9, dfirst, hs, w, g.half_w, g.half_h, cx0[v], cy0[v]);
+        cell_of(r[v], mats.m[v] + 9, dlast, hs, w, g.half_w, g.half_h, cx1[v], cy1[v]);
       }
       __syncthreads();  // previous chunk's LDS reads are done (also protects `red`)
-      reduce_boxes<VMAX, CAP>(cx0, cy0, cx1, cy1, active, VMAX, h, w, red, box);
+      reduce_boxes<VMAX, CAP>(cx0, cy0, cx1, cy1, active, VMAX, hs, w, red, box);
       bool fits = true;
 #pragma unroll
       for (int v = 0; v < VMAX; ++v) fits = fits && box[v].staged;
@@ -467,13 +470,13 @@ __global__ __launch_bounds__(256, CDS_K3_MINW) void warp_aggregate_lds_kernel(
     }
 #pragma unroll
     for (int v = 0; v < VMAX; ++v)
-      stage_box<CAP>(src + (size_t)v * hw * C, C, h, w, box[v], reinterpret_cast<float4*>(lds4 + v * 2 * CAP));
+      stage_box<CAP>(src + v * hws * C, C, hs, w, box[v], reinterpret_cast<float4*>(lds4 + v * 2 * CAP));
     __syncthreads();
     bool all_staged = true;
     FastBox fb[VMAX];
 #pragma unroll
     for (int v = 0; v < VMAX; ++v) {
-      fb[v] = fast_box(box[v], h, w);
+      fb[v] = fast_box(box[v], hs, w);
       all_staged = all_staged && box[v].staged;
     }
     const int* boxmem = red + 4 * VMAX * 4;
@@ -559,7 +562,7 @@ __global__ __launch_bounds__(256, CDS_K3_MINW) void warp_aggregate_lds_kernel(
         const v2f dvg = {dgx, dgy};
 #pragma unroll
         for (int v = 0; v < VMAX; ++v) {
-          const float* __restrict__ srcv = src + (size_t)v * hw * C;
+          const float* __restrict__ srcv = src + v * hws * C;
           const cds_f4* lv = lds4 + v * 2 * CAP;
           const Box bg = load_box(boxmem + v * 4);
           v2f ix, iy, x0f, y0f, wt[4];
@@ -647,7 +650,8 @@ __device__ __forceinline__ void online_entropy_update(float s, float& mx, float&
 template <int NG, int CAP, int DCK, bool FAST>
 __global__ __launch_bounds__(256, (NG == 4 ? 2 : CDS_K1_MINW)) void warp_entropy_lds_kernel(
     const float* __restrict__ ref, const float* __restrict__ src, WarpMats mats, const float* __restrict__ hyp,
-    float* __restrict__ entropy, int V, int D, int h, int w, float rhw, float rhh, int tiles_x, int ntiles) {
+    float* __restrict__ entropy, int V, int D, int h, int w, float rhw, float rhh, int tiles_x, int ntiles, int hs, int y_off) {
+  // h x w = rows [y_off, y_off + h) of the full hs x w grid of the source maps (see warp_aggregate_lds_kernel)
   constexpr int C = NG * C8;
   extern __shared__ __attribute__((aligned(16))) cds_f4 lds4[];
   int* red = reinterpret_cast<int*>(lds4 + 2 * NG * CAP);
@@ -660,12 +664,12 @@ __global__ __launch_bounds__(256, (NG == 4 ? 2 : CDS_K1_MINW)) void warp_entropy
   const bool active = x < w && y < h;
   const int xc = min(x, w - 1), yc = min(y, h - 1);
   Geo g;
-  g.h = h; g.w = w;
-  g.half_w = (float)((w - 1) / 2.0); g.half_h = (float)((h - 1) / 2.0);
+  g.h = hs; g.w = w;
+  g.half_w = (float)((w - 1) / 2.0); g.half_h = (float)((hs - 1) / 2.0);
   g.rhw = rhw; g.rhh = rhh;
   const unsigned hw = (unsigned)h * (unsigned)w;
   const unsigned pix = (unsigned)yc * (unsigned)w + (unsigned)xc;
-  const float* __restrict__ srcv = src + (size_t)v * hw * C;
+  const float* __restrict__ srcv = src + (size_t)v * hs * w * C;
   float m[12];
 #pragma unroll
   for (int i = 0; i < 12; ++i) m[i] = mats.m[v][i];
@@ -678,9 +682,9 @@ __global__ __launch_bounds__(256, (NG == 4 ? 2 : CDS_K1_MINW)) void warp_entropy
       rf[q][j].y = ref[((size_t)v * C + q * C8 + 2 * j + 1) * hw + pix];
     }
   float r[3];
-  cds_row_terms(m, (float)xc, (float)yc, r);
+  cds_row_terms(m, (float)xc, (float)(yc + y_off), r);
   const char* hyp_b = reinterpret_cast<const char*>(hyp);
-  const float wf = (float)w, hf = (float)h;
+  const float wf = (float)w, hf = (float)hs;
   float mx = -INFINITY, Z = 0.f, T = 0.f;
   for (int d0 = 0, d1 = 0; d0 < D; d0 = d1) {
     d1 = min(D, d0 + DCK);
@@ -689,17 +693,17 @@ __global__ __launch_bounds__(256, (NG == 4 ? 2 : CDS_K1_MINW)) void warp_entropy
       int cx0[1], cy0[1], cx1[1], cy1[1];
       float dlo, dhi;
       chunk_depth_range(hyp, hw, pix, d0, d1, dlo, dhi);
-      cell_of(r, m + 9, dlo, h, w, g.half_w, g.half_h, cx0[0], cy0[0]);
-      cell_of(r, m + 9, dhi, h, w, g.half_w, g.half_h, cx1[0], cy1[0]);
+      cell_of(r, m + 9, dlo, hs, w, g.half_w, g.half_h, cx0[0], cy0[0]);
+      cell_of(r, m + 9, dhi, hs, w, g.half_w, g.half_h, cx1[0], cy1[0]);
       __syncthreads();
-      reduce_boxes<1, CAP>(cx0, cy0, cx1, cy1, active, 1, h, w, red, box);
+      reduce_boxes<1, CAP>(cx0, cy0, cx1, cy1, active, 1, hs, w, red, box);
       if (box[0].staged || d1 - d0 <= 8) break;
       d1 = d0 + ((((d1 - d0) >> 1) + 1) & ~1);  // even length: plane pairs stay whole
     }
 #pragma unroll
-    for (int q = 0; q < NG; ++q) stage_box<CAP>(srcv + q * C8, C, h, w, box[0], reinterpret_cast<float4*>(lds4 + q * 2 * CAP));
+    for (int q = 0; q < NG; ++q) stage_box<CAP>(srcv + q * C8, C, hs, w, box[0], reinterpret_cast<float4*>(lds4 + q * 2 * CAP));
     __syncthreads();
-    const FastBox fb = fast_box(box[0], h, w);
+    const FastBox fb = fast_box(box[0], hs, w);
     const bool staged = box[0].staged;
     unsigned boff = ((unsigned)d0 * hw + pix) * 4u;
     const unsigned bstep = hw * 4u;
@@ -783,9 +787,10 @@ __global__ __launch_bounds__(256, (NG == 4 ? 2 : CDS_K1_MINW)) void warp_entropy
 // Launchers used by the extern "C" entry points in warp.hip.  Return false if the shape is not covered.
 bool cds_warp_aggregate_lds_launch(const float* ref, const float* src, const float* vis, const WarpMats& wm,
                                    const float* hyp, float* volume, const float* vis_sum, int V, int C, int D, int h,
-                                   int w, int hyp_pp, int flags, hipStream_t st) {
-  if ((C != 8 && C != 16 && C != 32) || V < 1 || V > CDS_MAX_VIEWS || !hyp_pp || w < 2 || h < 2 ||
-      (size_t)D * h * w * 4 >= ((size_t)1 << 32))
+                                   int w, int hyp_pp, int flags, hipStream_t st, int hs, int y_off) {
+  if (hs <= 0) { hs = h; y_off = 0; }      // whole grid
+  if ((C != 8 && C != 16 && C != 32) || V < 1 || V > CDS_MAX_VIEWS || !hyp_pp || w < 2 || hs < 2 || h < 1 || y_off < 0 ||
+      y_off + h > hs || (size_t)D * h * w * 4 >= ((size_t)1 << 32))
     return false;
   // 5 / 6 source views (BASELINE config 4, N = 7) run in ONE pass with a smaller box budget per view (CAP6 texels: 6 views =
   // 75 KB, still two workgroups per CU; a footprint that does not fit halves its chunk as usual).  CDS_K3_SPLIT_VIEWS=1 keeps
@@ -800,21 +805,21 @@ bool cds_warp_aggregate_lds_launch(const float* ref, const float* src, const flo
     // more views than fit the LDS budget: two launches over halves of the view list; the second adds to the first's
     // partial sums (and normalises).  Costs one extra read of the volume, still far cheaper than L1 gathers.
     const int v1 = (V + 1) / 2;
-    const size_t hw = (size_t)h * w;
+    const size_t hw = (size_t)h * w, hws = (size_t)hs * w;
     WarpMats wm2;
     for (int v = 0; v < CDS_MAX_VIEWS; ++v)
       for (int i = 0; i < 12; ++i) wm2.m[v][i] = (v + v1 < CDS_MAX_VIEWS) ? wm.m[v + v1][i] : 0.f;
     const int keep = flags & (CDS_AGG_CHANNELS_LAST | CDS_AGG_FAST_POSITIONS);
     return cds_warp_aggregate_lds_launch(ref, src, vis, wm, hyp, volume, vis_sum, v1, C, D, h, w, hyp_pp,
-                                         (flags & CDS_AGG_ACCUMULATE) | keep, st) &&
-           cds_warp_aggregate_lds_launch(ref + (size_t)v1 * C * hw, src + (size_t)v1 * hw * C, vis + (size_t)v1 * hw, wm2,
+                                         (flags & CDS_AGG_ACCUMULATE) | keep, st, hs, y_off) &&
+           cds_warp_aggregate_lds_launch(ref + (size_t)v1 * C * hw, src + (size_t)v1 * hws * C, vis + (size_t)v1 * hw, wm2,
                                          hyp, volume, vis_sum, V - v1, C, D, h, w, hyp_pp,
-                                         CDS_AGG_ACCUMULATE | (flags & CDS_AGG_NORMALIZE) | keep, st);
+                                         CDS_AGG_ACCUMULATE | (flags & CDS_AGG_NORMALIZE) | keep, st, hs, y_off);
   }
   const int tiles_x = cds_ceil_div(w, TW), tiles_y = cds_ceil_div(h, TH);
   const int ntiles = tiles_x * tiles_y;
   const int ngroups = C / C8;
-  const float rhw = (float)(1.0 / (double)(float)((w - 1) / 2.0)), rhh = (float)(1.0 / (double)(float)((h - 1) / 2.0));
+  const float rhw = (float)(1.0 / (double)(float)((w - 1) / 2.0)), rhh = (float)(1.0 / (double)(float)((hs - 1) / 2.0));
   // Depth segments: enough workgroups for ~10 waves per SIMD (2 are resident), each a whole number of DC chunks.
   const int chunks = cds_ceil_div(D, DC);
   int nseg = 1;
@@ -828,7 +833,7 @@ bool cds_warp_aggregate_lds_launch(const float* ref, const float* src, const flo
 #define LAUNCH4(VM, A, N, F, CAPV)                                                                                      \
   hipLaunchKernelGGL((warp_aggregate_lds_kernel<VM, A, N, F, CAPV>), dim3(ntiles * ngroups * nseg), dim3(256),         \
                      (size_t)VM * 2 * CAPV * sizeof(float4) + 5 * VM * 4 * sizeof(int), st, ref, src, vis, wm, hyp,    \
-                     volume, vis_sum, C, D, h, w, rhw, rhh, flags, tiles_x, ntiles, nseg, seg_planes)
+                     volume, vis_sum, C, D, h, w, rhw, rhh, flags, tiles_x, ntiles, nseg, seg_planes, hs, y_off)
 #define LAUNCH3(VM, A, N, CAPV)                    \
   do {                                             \
     if (fast_f) LAUNCH4(VM, A, N, true, CAPV);     \
@@ -856,15 +861,19 @@ bool cds_warp_aggregate_lds_launch(const float* ref, const float* src, const flo
 }
 
 bool cds_warp_entropy_lds_launch(const float* ref, const float* src, const WarpMats& wm, const float* hyp,
-                                 float* entropy, int V, int C, int D, int h, int w, int hyp_pp, bool fast, hipStream_t st) {
-  if ((C != 8 && C != 16 && C != 32) || !hyp_pp || w < 2 || h < 2 || (size_t)D * h * w * 4 >= ((size_t)1 << 32)) return false;
+                                 float* entropy, int V, int C, int D, int h, int w, int hyp_pp, bool fast, hipStream_t st, int hs,
+                                 int y_off) {
+  if (hs <= 0) { hs = h; y_off = 0; }
+  if ((C != 8 && C != 16 && C != 32) || !hyp_pp || w < 2 || hs < 2 || h < 1 || y_off < 0 || y_off + h > hs ||
+      (size_t)D * h * w * 4 >= ((size_t)1 << 32))
+    return false;
   const int tiles_x = cds_ceil_div(w, TW), tiles_y = cds_ceil_div(h, TH);
   const int ntiles = tiles_x * tiles_y;
-  const float rhw = (float)(1.0 / (double)(float)((w - 1) / 2.0)), rhh = (float)(1.0 / (double)(float)((h - 1) / 2.0));
+  const float rhw = (float)(1.0 / (double)(float)((w - 1) / 2.0)), rhh = (float)(1.0 / (double)(float)((hs - 1) / 2.0));
 #define LAUNCH2(NG, CAP, DCK, F)                                                                                   \
   hipLaunchKernelGGL((warp_entropy_lds_kernel<NG, CAP, DCK, F>), dim3(ntiles * V), dim3(256),                      \
                      (size_t)2 * NG * CAP * sizeof(float4) + 5 * 4 * sizeof(int), st, ref, src, wm, hyp, entropy, V, D, \
-                     h, w, rhw, rhh, tiles_x, ntiles)
+                     h, w, rhw, rhh, tiles_x, ntiles, hs, y_off)
 #define LAUNCH1(NG, CAP, DCK)                \
   do {                                       \
     if (fast) LAUNCH2(NG, CAP, DCK, true);   \

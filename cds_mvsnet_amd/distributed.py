@@ -18,6 +18,13 @@ receives rows [a_r, b_r) of the sum: (world-1)/world of the volume leaves each r
 normalises and regularises only its own rows (``slab.slab_cost_regularization``: CostRegNet with one one-row halo exchange
 per layer between neighbouring ranks), runs the soft-argmin on them, and the depth / confidence / curvature rows are
 gathered at the end (3 h w floats).  ``"allreduce"`` / ``"p2p"`` keep the round-1/2 behaviour (everybody regularises all).
+
+``exchange="slab"`` shards PIXELS instead of partial sums (the plane sweep is independent per reference pixel: K1's entropy,
+the visibility weight, K3's sum over views and the soft-argmin all live on one pixel; only the visibility CNN (3 px) and
+CostRegNet (one row per layer) look sideways).  FeatureNet stays sharded by view, the per-view feature maps are all-gathered
+once per depth map (1/C/D of a volume each), and then every rank runs K1 -> visibility CNN -> K3 over ALL views for its own
+rows only (row-window kernels, ``cds_warp_*_window_f32``), the slab-parallel CostRegNet and the soft-argmin.  No cost volume
+ever crosses a link.
 """
 from __future__ import annotations
 
@@ -40,8 +47,8 @@ class ViewShard:
     (SURVEY §8(e)).  Both give the same sums up to fp32 re-association."""
 
     def __init__(self, group: Optional["dist.ProcessGroup"] = None, exchange: str = "allreduce"):
-        if exchange not in ("allreduce", "p2p", "reduce_scatter"):
-            raise ValueError("exchange must be 'allreduce', 'p2p' or 'reduce_scatter'")
+        if exchange not in ("allreduce", "p2p", "reduce_scatter", "slab"):
+            raise ValueError("exchange must be 'allreduce', 'p2p', 'reduce_scatter' or 'slab'")
         self.group = group
         self.exchange = exchange
         self.rank = dist.get_rank(group)
@@ -54,6 +61,7 @@ class ViewShard:
         self.halo_exchanges = 0          # reduce_scatter mode: one-row exchanges of the slab-parallel CostRegNet
         self.halo_bytes = 0
         self.gather_bytes = 0
+        self.feature_gather_bytes = 0    # slab mode: all-gather of the per-view feature maps
         self.layers_factory = HipCostRegLayers     # tests plug torch reference layers in here
 
     # ---- bookkeeping (device independent) ----------------------------------------------------
@@ -191,6 +199,100 @@ class ViewShard:
                 self.gather_bytes += out.numel() * out.element_size()
         return out[0], out[1], out[2]
 
+    # ---- pixel-slab mode ("slab") --------------------------------------------------------------
+    def gather_features(self, feats, n_src: int):
+        """All-gather of the view-sharded FeatureNet outputs: ``feats[stage] = (ref_chw [Vl,C,h,w], src_hwc [Vl,h,w,C],
+        nc_sum [2 Vl,h,w], nc_abs [2 Vl,h,w])`` for this rank's views (None if it has none; per-image maps are ordered
+        [reference copies ..., sources ...]) -> the same structure for ALL n_src views in view order.  ONE collective:
+        every view travels as one flat record of fixed size, every rank contributes ceil(n_src / world) records."""
+        W = self.world
+        if W == 1:
+            return feats
+        mine = self.local_views(n_src)
+        per_rank = (n_src + W - 1) // W
+        names = sorted(self._feat_shapes) if feats is None else sorted(feats)
+        shapes = self._feat_shapes if feats is None else {k: tuple(tuple(t.shape[1:]) for t in feats[k]) for k in names}
+        rec = sum(int(torch.Size(sh[0]).numel()) + int(torch.Size(sh[1]).numel()) + 2 * int(torch.Size(sh[2]).numel()) +
+                  2 * int(torch.Size(sh[3]).numel()) for sh in shapes.values())
+        dev = self._feat_device if feats is None else feats[names[0]][0].device
+        buf = torch.zeros((per_rank, rec), dtype=torch.float32, device=dev)
+        Vl = len(mine)
+        for i in range(Vl):
+            parts = []
+            for k in names:
+                ref, src, ncs, nca = feats[k]
+                parts += [ref[i].reshape(-1), src[i].reshape(-1), ncs[i].reshape(-1), ncs[Vl + i].reshape(-1),
+                          nca[i].reshape(-1), nca[Vl + i].reshape(-1)]
+            buf[i] = torch.cat(parts)
+        got = [torch.empty_like(buf) for _ in range(W)]
+        dist.all_gather(got, buf, group=self.group)
+        self.feature_gather_bytes += buf.numel() * 4 * (W - 1)
+        out = {}
+        recs = [got[v % W][v // W] for v in range(n_src)]
+        off = 0
+        for k in names:
+            s_ref, s_src, s_nc, s_na = shapes[k]
+            n_ref, n_src_el, n_nc, n_na = (int(torch.Size(x).numel()) for x in (s_ref, s_src, s_nc, s_na))
+            ref = torch.stack([r[off:off + n_ref].view(s_ref) for r in recs])
+            o = off + n_ref
+            src = torch.stack([r[o:o + n_src_el].view(s_src) for r in recs])
+            o += n_src_el
+            ncs = torch.stack([r[o:o + n_nc].view(s_nc) for r in recs] + [r[o + n_nc:o + 2 * n_nc].view(s_nc) for r in recs])
+            o += 2 * n_nc
+            nca = torch.stack([r[o:o + n_na].view(s_na) for r in recs] + [r[o + n_na:o + 2 * n_na].view(s_na) for r in recs])
+            off = o + 2 * n_na
+            out[k] = (ref, src, ncs, nca)
+        return out
+
+    def set_feature_shapes(self, shapes, device) -> None:
+        """Ranks without a view of their own still take part in ``gather_features``: they need the record layout
+        ({stage: (ref, src, nc_sum, nc_abs) per-view shapes})."""
+        self._feat_shapes, self._feat_device = shapes, device
+
+    def _run_stage_pixel_slab(self, model, ref: Tensor, src: Tensor, ref_nc: Tensor, nc_sums: Tensor, mats: Tensor, hyp: Tensor,
+                              stage_idx: int, n_src_total: int):
+        """slab mode: ALL views (gathered features) for this rank's rows.  ref [V,C,h,w], src [V,h,w,C], ref_nc / nc_sums
+        [V,h,w], hyp [D,h,w]."""
+        D, h, w = hyp.shape
+        rows = slab_rows(h, self.world)
+        a, b = rows[self.rank]
+        comm = HaloComm(self.group, rows)
+        out = torch.zeros((3, h, w), dtype=hyp.dtype, device=hyp.device)
+        self.exchanges += 1
+        if b > a:
+            # K1 + visibility CNN on the rows plus a margin of one 8-row tile (the three 3x3 layers look 3 px sideways)
+            a1, b1 = max(0, a - 8), min(h, b + 8)
+            ent = self._warp_entropy_rows(ref[:, :, a1:b1].contiguous(), src, mats, hyp[:, a1:b1].contiguous(), (h, a1))
+            vis = self._visibility_rows(model, ent, ref_nc[:, a1:b1].contiguous(), stage_idx)[:, a - a1:b - a1].contiguous()
+            vol = self._warp_aggregate_rows(ref[:, :, a:b].contiguous(), src, vis, mats, hyp[:, a:b].contiguous(), (h, a))
+            if self.keep_volume:
+                self.last_volume = vol.permute(3, 0, 1, 2)
+            prob_pre = slab_cost_regularization(self.layers_factory(model.cost_regularization[stage_idx]), comm, vol)
+            depth, conf = self._regress_rows(prob_pre, hyp[:, a:b].contiguous())
+            out[0, a:b], out[1, a:b], out[2, a:b] = depth, conf, nc_sums[:, a:b].sum(dim=0) / n_src_total
+        else:
+            slab_cost_regularization(None, comm, hyp.new_zeros((D, 0, w, 1)))
+        self.halo_exchanges += comm.exchanges
+        self.halo_bytes += comm.bytes_sent
+        with ops.prof("gather_rows"):
+            if self.world > 1:
+                dist.all_reduce(out, op=dist.ReduceOp.SUM, group=self.group)
+                self.gather_bytes += out.numel() * out.element_size()
+        return out[0], out[1], out[2]
+
+    # device ops of the pixel-slab path on row windows, overridable by the CPU tests (window = (grid rows, first row))
+    @staticmethod
+    def _warp_entropy_rows(ref_w, src, mats, hyp_w, window):
+        return ops.warp_entropy(ref_w, src, mats, hyp_w, window=window)
+
+    @staticmethod
+    def _visibility_rows(model, ent, ref_nc_w, stage_idx):
+        return model.stage_net.visibility(ent, ref_nc_w, stage_idx)
+
+    @staticmethod
+    def _warp_aggregate_rows(ref_w, src, vis_w, mats, hyp_w, window):
+        return ops.warp_aggregate(ref_w, src, vis_w, mats, hyp_w, normalize=True, channels_last=True, window=window)[0]
+
     # the two per-pixel device ops of the slab path, overridable by the CPU tests
     @staticmethod
     def _normalize_rows(vol_rows: Tensor, vis_rows: Tensor) -> None:
@@ -209,8 +311,10 @@ class ViewShard:
             C = ref.shape[1]
         cr = model.cost_regularization[stage_idx]
         cl = cr.split_bf16_supported()          # channels-last volume for the split-bf16 CostRegNet kernels
-        if self.exchange == "reduce_scatter" and not cl:
-            raise RuntimeError("exchange='reduce_scatter' needs the channels-last split-bf16 CostRegNet path")
+        if self.exchange in ("reduce_scatter", "slab") and not cl:
+            raise RuntimeError(f"exchange='{self.exchange}' needs the channels-last split-bf16 CostRegNet path")
+        if self.exchange == "slab":             # ref .. mats hold ALL views here (gather_features ran in the model's forward)
+            return self._run_stage_pixel_slab(model, ref, src, ref_nc, nc_sums, mats, hyp, stage_idx, n_src_total)
         flat = torch.zeros(self.flat_size(C, D, h, w), dtype=torch.float32, device=hyp.device)
         vol, vis_sum, nc_sum = self.split_flat(flat, C, D, h, w)
         if cl:
@@ -250,7 +354,7 @@ class ViewShardedStage:
     def __call__(self, features, proj_matrices: Tensor, depth_values: Tensor, num_depth: int, stage_idx: int):
         sh = self.shard
         V = len(features)
-        mine = sh.local_views(V)
+        mine = list(range(V)) if sh.exchange == "slab" else sh.local_views(V)   # pixel slabs: every rank sweeps all views for its rows
         cams = proj_matrices.detach().float().cpu()
         hyp = depth_values[0].contiguous()
         C = features[0]["ref"][0].shape[1]

@@ -754,6 +754,17 @@ class CDSMVSNet(nn.Module):
             if V:
                 feats = self.extract_features(ref_img, [_resize_nearest(imgs[b, v + 1], H, W) for v in views],
                                               cams["stage3"][b, 0], [cams["stage3"][b, v + 1] for v in views], T)
+            sh = self._view_shard
+            if sh is not None and sh.exchange == "slab":
+                # pixel-slab sharding: FeatureNet stays sharded by view; every rank then needs every view's maps for its rows
+                C_s = self.feature.out_channels
+                sh.set_feature_shapes({f"stage{s + 1}": ((C_s[s], H // sc, W // sc), (H // sc, W // sc, C_s[s]), (H // sc, W // sc),
+                                                         (H // sc, W // sc))
+                                       for s, sc in enumerate(int(self.stage_infos[f"stage{k + 1}"]["scale"]) for k in range(self.num_stage))},
+                                      imgs.device)
+                feats = sh.gather_features(feats, N - 1)
+                views = list(range(N - 1))
+                V = len(views)
             out_b: Dict[str, object] = {}
             depth = None
             for s in range(self.num_stage):

@@ -128,18 +128,39 @@ def _pos_flag(exact: Optional[bool]) -> int:
     return 0 if (WARP_EXACT if exact is None else exact) else AGG_FAST_POSITIONS
 
 
-def warp_entropy(ref_chw: Tensor, src_hwc: Tensor, mats: Tensor, hyp: Tensor, exact: Optional[bool] = None) -> Tensor:
+def _window_args(window: Optional[Tuple[int, int]], h: int) -> Tuple[int, int]:
+    """window = (hs, y_off): the reference-side tensors cover rows [y_off, y_off + h) of an hs-row image grid."""
+    if window is None:
+        return h, 0
+    hs, y_off = int(window[0]), int(window[1])
+    if y_off < 0 or y_off + h > hs:
+        raise ValueError(f"window rows [{y_off}, {y_off + h}) outside the {hs}-row grid")
+    return hs, y_off
+
+
+def warp_entropy(ref_chw: Tensor, src_hwc: Tensor, mats: Tensor, hyp: Tensor, exact: Optional[bool] = None,
+                 window: Optional[Tuple[int, int]] = None) -> Tensor:
     """K1.  ref_chw [V,C,h,w], src_hwc [V,h,w,C], mats CPU [V,12], hyp [D,h,w]|[D] -> entropy [V,h,w].
-    exact: sample-position arithmetic (None = the module default ``WARP_EXACT``)."""
+    exact: sample-position arithmetic (None = the module default ``WARP_EXACT``).
+    window = (hs, y_off): ref_chw / hyp / the result cover rows [y_off, y_off + h) of the grid, src_hwc is [V,hs,w,C]."""
     V, C, h, w = ref_chw.shape
-    if tuple(src_hwc.shape) != (V, h, w, C) or tuple(mats.shape) != (V, 12):
+    hs, y_off = _window_args(window, h)
+    if tuple(src_hwc.shape) != (V, hs, w, C) or tuple(mats.shape) != (V, 12):
         raise ValueError("warp_entropy: inconsistent shapes")
     D, pp = _hyp_args(hyp, None, h, w)
+    if window is not None and not pp:
+        raise ValueError("warp_entropy: a row window needs per-pixel hypotheses [D,h,w]")
     ent = torch.empty((V, h, w), dtype=torch.float32, device=ref_chw.device)
     lib = _lib.load()
     with prof("warp_entropy"):
         for v0 in range(0, V, MAX_VIEWS):
             v1 = min(V, v0 + MAX_VIEWS)
+            if window is not None:
+                check(lib.cds_warp_entropy_window_f32(_dev(ref_chw[v0:v1], "ref"), _dev(src_hwc[v0:v1], "src"),
+                                                      _host(mats[v0:v1], "mats"), _dev(hyp, "hyp"), ent[v0:v1].data_ptr(),
+                                                      v1 - v0, C, D, h, w, hs, y_off, _pos_flag(exact), _stream(ent)),
+                      "cds_warp_entropy_window_f32")
+                continue
             check(lib.cds_warp_entropy_flags_f32(_dev(ref_chw[v0:v1], "ref"), _dev(src_hwc[v0:v1], "src"),
                                                  _host(mats[v0:v1], "mats"), _dev(hyp, "hyp"), ent[v0:v1].data_ptr(),
                                                  v1 - v0, C, D, h, w, pp, _pos_flag(exact), _stream(ent)),
@@ -150,14 +171,17 @@ def warp_entropy(ref_chw: Tensor, src_hwc: Tensor, mats: Tensor, hyp: Tensor, ex
 def warp_aggregate(ref_chw: Tensor, src_hwc: Tensor, vis_w: Tensor, mats: Tensor, hyp: Tensor,
                    normalize: bool = True, volume: Optional[Tensor] = None, vis_sum: Optional[Tensor] = None,
                    accumulate: bool = False, channels_last: bool = False,
-                   exact: Optional[bool] = None) -> Tuple[Tensor, Tensor]:
+                   exact: Optional[bool] = None, window: Optional[Tuple[int, int]] = None) -> Tuple[Tensor, Tensor]:
     """K3.  Returns (volume [C,D,h,w] — or [D,h,w,C] with channels_last, the layout the split-bf16 CostRegNet kernels
     read — and vis_sum [h,w]).  With normalize=False the raw visibility-weighted sums are returned (what a source-view
     shard contributes to the all-reduce)."""
     V, C, h, w = ref_chw.shape
-    if tuple(src_hwc.shape) != (V, h, w, C) or tuple(mats.shape) != (V, 12) or tuple(vis_w.shape) != (V, h, w):
+    hs, y_off = _window_args(window, h)          # window: see warp_entropy
+    if tuple(src_hwc.shape) != (V, hs, w, C) or tuple(mats.shape) != (V, 12) or tuple(vis_w.shape) != (V, h, w):
         raise ValueError("warp_aggregate: inconsistent shapes")
     D, pp = _hyp_args(hyp, None, h, w)
+    if window is not None and not pp:
+        raise ValueError("warp_aggregate: a row window needs per-pixel hypotheses [D,h,w]")
     dev = ref_chw.device
     vshape = (D, h, w, C) if channels_last else (C, D, h, w)
     if volume is None:
@@ -178,6 +202,12 @@ def warp_aggregate(ref_chw: Tensor, src_hwc: Tensor, vis_w: Tensor, mats: Tensor
                 flags |= AGG_ACCUMULATE
             if normalize and i == nchunks - 1:
                 flags |= AGG_NORMALIZE
+            if window is not None:
+                check(lib.cds_warp_aggregate_window_f32(_dev(ref_chw[v0:v1], "ref"), _dev(src_hwc[v0:v1], "src"),
+                                                        _dev(vis_w[v0:v1], "vis"), _host(mats[v0:v1], "mats"), _dev(hyp, "hyp"),
+                                                        _dev(volume, "volume"), _dev(vis_sum, "vis_sum"), v1 - v0, C, D, h, w,
+                                                        hs, y_off, flags, _stream(volume)), "cds_warp_aggregate_window_f32")
+                continue
             check(lib.cds_warp_aggregate_f32(_dev(ref_chw[v0:v1], "ref"), _dev(src_hwc[v0:v1], "src"),
                                              _dev(vis_w[v0:v1], "vis"), _host(mats[v0:v1], "mats"), _dev(hyp, "hyp"),
                                              _dev(volume, "volume"), _dev(vis_sum, "vis_sum"), v1 - v0, C, D, h, w, pp,

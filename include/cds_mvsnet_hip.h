@@ -98,6 +98,19 @@ int cds_warp_aggregate_f32(const float* ref_chw, const float* src_hwc, const flo
                            void* stream);
 
 /*
+ * Row-window forms of K1 / K3 (pixel-slab sharding across GPUs): the reference-side tensors cover rows [y_off, y_off + h) of the
+ * hs x w image grid -- ref_chw [V][C][h][w], hyp [D][h][w] (per pixel), vis_w / entropy [V][h][w], volume [C][D][h][w] or
+ * [D][h][w][C], vis_sum [h][w] -- while src_hwc [V][hs][w][C] covers the whole grid.  Positions are computed from the global row
+ * y_off + y: a window's result equals the same rows of the full-grid call bit for bit.  flags as in the full-grid calls.
+ * Returns CDS_EINVAL for shapes outside the LDS-staged kernels (C not in {8, 16, 32}, w < 2).
+ */
+int cds_warp_entropy_window_f32(const float* ref_chw, const float* src_hwc, const float* mats_host, const float* hyp,
+                                float* entropy, int V, int C, int D, int h, int w, int hs, int y_off, int flags, void* stream);
+int cds_warp_aggregate_window_f32(const float* ref_chw, const float* src_hwc, const float* vis_w, const float* mats_host,
+                                  const float* hyp, float* volume, float* vis_sum, int V, int C, int D, int h, int w, int hs,
+                                  int y_off, int flags, void* stream);
+
+/*
  * Backward of the un-normalised K3 (training step).  With volume = sum_v vis_v * ref_v (x) warp(src_v):
  *   grad_volume  [C][D][h][w]   incoming gradient
  *   grad_ref     [V][C][h][w]   ACCUMULATED with atomics (partial sums per depth segment): the caller zeroes it first

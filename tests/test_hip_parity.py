@@ -1006,3 +1006,23 @@ def test_visibility_layers_split_bf16(N, H, W, dev, ops):
     goth = ops.conv2d_k3_relu_sbf(x.to(dev), ws, b.to(dev), head_w=hw.to(dev), head_b=hb.to(dev)).cpu()
     oldh = ops.conv2d_k3_c16(x.to(dev), wcl, b.to(dev), head_w=hw.to(dev), head_b=hb.to(dev)).cpu()
     assert (goth.double() - h64).abs().max().item() <= 1.5 * (oldh.double() - h64).abs().max().item() + 2.0 ** -23
+
+
+@pytest.mark.parametrize("V,C,D,h,w,y0,y1", [(4, 8, 40, 64, 136, 16, 40), (2, 16, 9, 40, 72, 0, 8), (3, 32, 12, 32, 48, 24, 32),
+                                            (6, 16, 20, 48, 64, 8, 48), (1, 8, 70, 24, 200, 8, 24)])
+def test_warp_row_windows_equal_full_grid_rows(V, C, D, h, w, y0, y1, dev, ops):
+    """Row-window forms of K1 / K3 (pixel-slab sharding): reference-side tensors restricted to rows [y0, y1), source maps whole.
+    The window's entropy and volume must equal the same rows of the full-grid call BIT FOR BIT (positions come from the global
+    pixel row), planar and channels-last, both position modes."""
+    feats, cams, hyp, ref, src, mats, hyp_d = _random_stage(ops, dev, V, C, D, h, w, seed=60 + V)
+    vis = (torch.rand(V, h, w, generator=torch.Generator().manual_seed(4)) * 0.8 + 0.1).to(dev)
+    for exact in (True, False):
+        ent_full = ops.warp_entropy(ref, src, mats, hyp_d, exact=exact)
+        ref_w, hyp_w, vis_w = ref[:, :, y0:y1].contiguous(), hyp_d[:, y0:y1].contiguous(), vis[:, y0:y1].contiguous()
+        ent_w = ops.warp_entropy(ref_w, src, mats, hyp_w, exact=exact, window=(h, y0))
+        assert torch.equal(ent_w, ent_full[:, y0:y1])
+        for cl in (False, True):
+            vol_full, vs_full = ops.warp_aggregate(ref, src, vis, mats, hyp_d, channels_last=cl, exact=exact)
+            vol_w, vs_w = ops.warp_aggregate(ref_w, src, vis_w, mats, hyp_w, channels_last=cl, exact=exact, window=(h, y0))
+            assert torch.equal(vs_w, vs_full[y0:y1])
+            assert torch.equal(vol_w, vol_full[:, y0:y1] if cl else vol_full[:, :, y0:y1])

@@ -65,7 +65,7 @@ def test_shard_views_world1_equals_unsharded():
         imgs, cams, dv = _inputs(4, 128, 160, 3, dev)
         with torch.no_grad():
             want = model(imgs, cams, dv, temperature=0.01)
-            for exchange in ("allreduce", "reduce_scatter"):        # world 1: one slab = the whole grid, no neighbours
+            for exchange in ("allreduce", "reduce_scatter", "slab"):   # world 1: one slab = the whole grid, no neighbours
                 sh = cdist.shard_views(model, exchange=exchange)
                 sh.keep_volume = True
                 got = model(imgs, cams, dv, temperature=0.01)
@@ -103,7 +103,7 @@ def _two_rank_worker(rank, world, port, q):
         res = {}
         with torch.no_grad():
             want = model(imgs, cams, dv, temperature=0.01)          # unsharded, on this rank
-            for exchange in ("allreduce", "p2p", "reduce_scatter"):
+            for exchange in ("allreduce", "p2p", "reduce_scatter", "slab"):
                 sh = cdist.shard_views(model, exchange=exchange)
                 got = model(imgs, cams, dv, temperature=0.01)
                 res[exchange] = [float((got[k]["depth"] - want[k]["depth"]).abs().mean()) for k in ("stage1", "stage2", "stage3")]
@@ -141,12 +141,12 @@ def test_shard_views_two_ranks_on_one_device():
         assert p.exitcode == 0
     assert res[0]["allreduce_views"] == [0, 2] and res[1]["allreduce_views"] == [1]
     for r in range(world):
-        for exchange in ("allreduce", "p2p", "reduce_scatter"):
+        for exchange in ("allreduce", "p2p", "reduce_scatter", "slab"):
             assert res[r][exchange + "_n"] == 3                     # ONE volume exchange per cascade stage
             assert max(res[r][exchange]) < 1e-3, (r, exchange, res[r][exchange])
             assert res[r][exchange + "_conf"] < 1e-3 and res[r][exchange + "_nc"] < 1e-5, (r, exchange)
         # reduce_scatter: rows of the sum + slab-parallel CostRegNet on the HIP kernels: 11 one-row halo exchanges per stage
-        assert res[r]["reduce_scatter_halo"] == 33 and res[r]["allreduce_halo"] == 0
+        assert res[r]["reduce_scatter_halo"] == 33 and res[r]["slab_halo"] == 33 and res[r]["allreduce_halo"] == 0
         assert res[r]["volume"] < 1e-6, res[r]["volume"]
 
 
