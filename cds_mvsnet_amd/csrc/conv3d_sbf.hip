@@ -1165,6 +1165,342 @@ __global__ __launch_bounds__(256, 2) void prob_cl8_kernel(const float* __restric
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// conv11 FUSED with the prob layer: ConvTranspose3d(16 -> 8) + BN + ReLU + skip c0 (module.py:299-301,313) and the 3x3 in-plane
+// part of Conv3d(8 -> 1) (module.py:303,314).  The 8-channel full-resolution tensor y = c0 + relu(deconv(x)) (2 GB at 640x512x192)
+// is never written: a workgroup owns a 32 x 8 fine tile of TWO fine planes (one cell plane az), computes y on the tile plus a
+// one-voxel ring (recomputed, 34 x 10), keeps one plane of it in LDS already split into its three bf16 terms, and emits for
+// every fine voxel the three in-plane sums
+//       P_kz[z][y][x] = sum_{ky, kx, c} w_prob[c][kz][ky][kx] * y[c][z][y + ky - 1][x + kx - 1]          (kz = 0, 1, 2)
+// -- the prob layer is separable along z as prob[z] = P_0[z - 1] + P_1[z] + P_2[z + 1], which the soft-argmin kernel adds while it
+// reads (cds_softargmin_conf_p3_f32).  12 B per voxel leave the kernel instead of 32 B out + 32 B back in + 4 B out.
+//
+// Transposed-convolution phase (A): the MERGE form of deconv3d_sbf_ws_kernel (rows = (x parity, cout), columns = 16 cells, classes
+// (pz, py)), over 7 column groups: the 6 cell rows cy = -1 .. 4 of the tile (16 main cells each) and one group holding the 12 ring
+// cells (cx = -1 and 16 of every row).  Phase E(pz): + bias, ReLU, + skip (prefetched at tile start), exact 3-way bf16 split,
+// 8-byte LDS writes into the fine plane F[row][x de-interleaved mod 4][term][8 ch]; voxels outside the volume are written as zeros
+// (the prob layer's zero padding).  Phase P(pz): matrix tile rows = (kz, x offset 0..3), columns = 8 quads x 2 rows, K = 3 x 6
+// in-plane positions x 8 channels (5 K-steps): lane group kz ends with P_kz of four consecutive x = one 16-byte store.
+// 4 compute + 2 staging waves, 80 KB of LDS: two workgroups per CU overlap each other's E phases and barriers.
+// ---------------------------------------------------------------------------------------------
+#ifndef CDS_FP_IXP
+#define CDS_FP_IXP 24
+#endif
+struct FPCfg {
+  static constexpr int TX = 32, TY = 8;
+  static constexpr int CXM = 16, CYM = 4;                   // main cells of a tile
+  static constexpr int IX = CXM + 3, IY = CYM + 3, IZ = 2;   // staged input cells: cx -1 .. 17, cy -1 .. 5, cz az .. az + 1
+  static constexpr int IXP = CDS_FP_IXP;
+  static constexpr int INB = IZ * IY * IXP * POSB;           // one (tile, round) buffer: 16,128 B
+  static constexpr int FW = 36, FH = TY + 2;                 // fine plane incl. ring: 34 columns, stored as 4 residue runs of 9
+  static constexpr int FB = FH * FW * POSB;                  // 17,280 B
+  static constexpr int CW = 4, PW = 2, THREADS = (CW + PW) * 64;
+  static constexpr int WB = 2 * DTab<true>::NKS * 3 * 1024;  // conv11's split weights: 30,720 B
+#ifdef CDS_FP_PWLDS
+  static constexpr int PWB = 5 * 3 * 1024;                   // prob weights in LDS (experiment)
+#else
+  static constexpr int PWB = 0;
+#endif
+  static constexpr int LDSB = WB + 2 * INB + FB + PWB;       // 80,256 B
+  static constexpr int PKS = 5;                              // K-steps of the P phase (18 positions + 2 zero slots)
+};
+
+#ifndef CDS_FP_MINW
+#define CDS_FP_MINW 3
+#endif
+__global__ __launch_bounds__(FPCfg::THREADS, CDS_FP_MINW) void deconv_prob_kernel(const float* __restrict__ x, const uint4* __restrict__ wsp,
+                                                                        const float* __restrict__ bias, const float* __restrict__ skip,
+                                                                        const uint4* __restrict__ pw, float* __restrict__ out, int Da,
+                                                                        int Ha, int Wa, int tiles_x, int tiles_y, int ntiles, int tpw) {
+  using Cfg = FPCfg;
+  using Tab = DTab<true>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nwg = gridDim.x;
+  const int wg = cds_xcd_remap(blockIdx.x, nwg);
+  const int tile0 = wg * tpw, tile1 = min(ntiles, tile0 + tpw);
+  if (tile0 >= tile1) return;
+  const int D = 2 * Da, H = 2 * Ha, W = 2 * Wa;
+  constexpr int Cin = 16;
+  unsigned char* inb = lds + Cfg::WB;
+  unsigned char* fpl = inb + 2 * Cfg::INB;
+  {
+    uint4* wdst = reinterpret_cast<uint4*>(lds);
+    for (int i = tid; i < Cfg::WB / 16; i += Cfg::THREADS) wdst[i] = wsp[i];
+#ifdef CDS_FP_PWLDS
+    uint4* pdst = reinterpret_cast<uint4*>(fpl + Cfg::FB);
+    for (int i = tid; i < Cfg::PWB / 16; i += Cfg::THREADS) pdst[i] = pw[i];
+#endif
+  }
+
+  if (wave >= Cfg::CW) {
+    // ============================== staging waves ==============================
+    const int ptid = tid - Cfg::CW * 64;
+    constexpr int NP = Cfg::IZ * Cfg::IY * Cfg::IX, PT = Cfg::PW * 64;
+    constexpr int PPT = (NP + PT - 1) / PT;
+    int s_rel[PPT], s_dst[PPT];
+#pragma unroll
+    for (int h = 0; h < PPT; ++h) {
+      const int p = h * PT + ptid;
+      const int row = p / Cfg::IX, c = p - row * Cfg::IX;
+      const int rz = row / Cfg::IY, ry = row - rz * Cfg::IY;
+      s_rel[h] = p < NP ? ((rz << 20) | (ry << 10) | c) : -1;
+      s_dst[h] = (row * Cfg::IXP + c) * POSB;
+    }
+    float4 va[2][PPT], vb[2][PPT];                      // [round][position]: one tile in flight in registers
+    auto issue = [&](int tile) {
+      SBF_TILE(tile, tx_i, ty_i, az);
+      const int gx0 = tx_i * Cfg::CXM - 1, gy0 = ty_i * Cfg::CYM - 1;
+#pragma unroll
+      for (int h = 0; h < PPT; ++h) {
+        const int gz = az + (s_rel[h] >> 20), gy = gy0 + ((s_rel[h] >> 10) & 1023), gx = gx0 + (s_rel[h] & 1023);
+        const bool ok = s_rel[h] >= 0 && gz < Da && (unsigned)gy < (unsigned)Ha && (unsigned)gx < (unsigned)Wa;
+        const float* __restrict__ src = x + ((size_t)((size_t)gz * Ha + gy) * Wa + gx) * Cin;
+#pragma unroll
+        for (int rd = 0; rd < 2; ++rd) {
+          va[rd][h] = ok ? *reinterpret_cast<const float4*>(src + rd * 8) : make_float4(0.f, 0.f, 0.f, 0.f);
+          vb[rd][h] = ok ? *reinterpret_cast<const float4*>(src + rd * 8 + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      }
+    };
+    auto deposit = [&](int rd) {
+      unsigned char* base = inb + rd * Cfg::INB;
+#pragma unroll
+      for (int h = 0; h < PPT; ++h)
+        if (s_rel[h] >= 0) split_store8(base + s_dst[h], va[rd][h], vb[rd][h]);
+    };
+    issue(tile0);
+    deposit(0);
+    deposit(1);
+    if (tile0 + 1 < tile1) issue(tile0 + 1);
+    __syncthreads();                                    // B0: weights + both rounds of the first tile staged
+    for (int tile = tile0; tile < tile1; ++tile) {
+      __syncthreads();                                  // B1: round 0 of `tile` consumed
+      if (tile + 1 < tile1) deposit(0);
+      __syncthreads();                                  // B2: round 1 consumed
+      if (tile + 1 < tile1) deposit(1);
+      __syncthreads();                                  // B3
+      if (tile + 2 < tile1) issue(tile + 2);
+      __syncthreads();                                  // B4
+      __syncthreads();                                  // B5
+    }
+    return;
+  }
+
+  // ============================== compute waves ==============================
+  SBF_CONSUMER_PRIO();
+  const int j = lane & 15, g = lane >> 4;
+  int toff[Tab::NKS];
+#pragma unroll
+  for (int ks = 0; ks < Tab::NKS; ++ks) {
+    const int c = Tab::cls_of(ks), s0 = Tab::slot0_of(ks);
+    int off = 0;
+#pragma unroll
+    for (int gg = 0; gg < 4; ++gg) {
+      const int dz = Tab::tap_d(c, s0 + gg, 0), dy = Tab::tap_d(c, s0 + gg, 1), dx = Tab::tap_d(c, s0 + gg, 2);
+      const int o = dz < 0 ? 0 : ((dz * Cfg::IY + dy) * Cfg::IXP + dx) * POSB;
+      off = g == gg ? o : off;
+    }
+    toff[ks] = off;
+  }
+  // column groups of this wave: q = 0 -> cell row cy = wave - 1; q = 1 -> group wave + 4: cell rows 3, 4, then the ring cells
+  // (lane j: cy = (j >> 1) - 1, cx = -1 | 16); wave 3 has no second group (it recomputes its first one, nothing is written)
+  int cyq[2], cxq[2], b_base[2];
+  bool colq[2];                                         // this lane's column carries a cell of the tile
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int gi = (q == 0 || wave == 3) ? wave : wave + 4;
+    const bool ring = gi == 6;
+    cyq[q] = ring ? (j < 12 ? (j >> 1) - 1 : -1) : gi - 1;
+    cxq[q] = ring ? ((j & 1) ? Cfg::CXM : -1) : j;
+    colq[q] = (q == 0 || wave != 3) && (!ring || j < 12);
+    b_base[q] = ((cyq[q] + 1) * Cfg::IXP + (cxq[q] + 1)) * POSB;
+  }
+  const unsigned char* wlds = lds + lane * 16;
+  const int co = 4 * (g & 1), px = g >> 1;              // rows of the transposed-convolution tile = (x parity, cout)
+  const float4 bv = bias ? *reinterpret_cast<const float4*>(bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+  // P phase: lane -> column (quad qd, fine row rr), K-step t multiplies in-plane position s = 4 t + g = (ky, dx)
+  const int qd = j & 7, rr = 2 * wave + (j >> 3);
+  int poff[Cfg::PKS];
+#pragma unroll
+  for (int t = 0; t < Cfg::PKS; ++t) {
+    const int s = min(4 * t + g, 17);                   // slots 18, 19: zero weights, any valid address
+    const int ky = s / 6, dx = s - 6 * ky;
+    poff[t] = ((rr + ky) * Cfg::FW + (dx & 3) * 9 + qd + (dx >> 2)) * POSB;
+  }
+  const uint4* __restrict__ pwl = pw + lane;
+  const size_t planeHW = (size_t)H * W;
+
+  f32x4 acc[Tab::NCLS][2];
+  float4 skv[Tab::NCLS][2];
+  __syncthreads();                                      // B0
+  for (int tile = tile0; tile < tile1; ++tile) {
+    SBF_TILE(tile, tx_i, ty_i, az);
+    const int X0 = tx_i * Cfg::TX, Y0 = ty_i * Cfg::TY;
+    // fine voxel of (group q, class c) on this lane, and whether it lies in the 34 x 10 plane / inside the volume
+    auto fine = [&](int q, int c, int& fy, int& fx, bool& in_tile, bool& in_vol) {
+      fy = 2 * cyq[q] + (c & 1);
+      fx = 2 * cxq[q] + px;
+      in_tile = colq[q] && fy >= -1 && fy <= Cfg::TY && fx >= -1 && fx <= Cfg::TX;
+      const int gy = Y0 + fy, gx = X0 + fx;
+      in_vol = in_tile && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+    };
+#pragma unroll
+    for (int c = 0; c < Tab::NCLS; ++c)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        acc[c][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        int fy, fx;
+        bool it, iv;
+        fine(q, c, fy, fx, it, iv);
+        const size_t vox = ((size_t)(2 * az + (c >> 1)) * H + (Y0 + fy)) * W + (X0 + fx);
+#ifdef CDS_FP_NOSKIP
+        skv[c][q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        (void)vox;
+#else
+        skv[c][q] = iv ? *reinterpret_cast<const float4*>(skip + vox * 8 + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+#endif
+      }
+    // ---------------- phase A: transposed convolution, both rounds ----------------
+#pragma unroll
+    for (int rd = 0; rd < 2; ++rd) {
+      const unsigned char* tbuf = inb + rd * Cfg::INB;
+      const unsigned char* wr = wlds + rd * Tab::NKS * 3 * 1024;
+      BV wa[2][3];
+      BV bd[2][2][3];
+      auto load_w = [&](int buf, int ks) {
+        wa[buf][0].u = *reinterpret_cast<const uint4*>(wr + (ks * 3) * 1024);
+        wa[buf][1].u = *reinterpret_cast<const uint4*>(wr + (ks * 3 + 1) * 1024);
+        wa[buf][2].u = *reinterpret_cast<const uint4*>(wr + (ks * 3 + 2) * 1024);
+      };
+      auto load_b = [&](int buf, int ks) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const unsigned char* b = tbuf + b_base[q] + toff[ks];
+          bd[buf][q][0].u = *reinterpret_cast<const uint4*>(b);
+          bd[buf][q][1].u = *reinterpret_cast<const uint4*>(b + 16);
+          bd[buf][q][2].u = *reinterpret_cast<const uint4*>(b + 32);
+        }
+      };
+#ifdef CDS_FP_DIET
+      // register diet (<= 128 VGPRs: four waves per SIMD, so that two 6-wave workgroups are always co-resident): operands
+      // single-buffered, the other waves of the SIMD cover the LDS latency
+#pragma unroll
+      for (int ks = 0; ks < Tab::NKS; ++ks) {
+        const int c = Tab::cls_of(ks);
+        load_b(0, ks);
+        load_w(0, ks);
+        __builtin_amdgcn_sched_barrier(0);
+        SBF_TERMS(acc[c], 0, 2, wa[0], bd[0]);
+      }
+#else
+      load_w(0, 0);
+      load_b(0, 0);
+#pragma unroll
+      for (int ks = 0; ks < Tab::NKS; ++ks) {
+        const int c = Tab::cls_of(ks), cur = ks & 1;
+        if (ks + 1 < Tab::NKS) {
+          load_b(cur ^ 1, ks + 1);
+          load_w(cur ^ 1, ks + 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        SBF_TERMS(acc[c], 0, 2, wa[cur], bd[cur]);
+      }
+#endif
+      __syncthreads();                                  // B1 / B2
+    }
+#pragma unroll
+    for (int pz = 0; pz < 2; ++pz) {
+      // ---------------- phase E: y = skip + relu(acc + bias), split, into the fine plane ----------------
+      // prob weights of the P phase: streamed from L1 / L2 two K-steps ahead (all 15 vectors in registers spilled to scratch:
+      // 30 GB of scratch traffic per launch at M1); the first two are requested here, ahead of the barrier
+      BV pwr[2][3];
+#ifdef CDS_FP_PWLDS
+      const uint4* pwo = reinterpret_cast<const uint4*>(fpl + Cfg::FB) + lane;
+#else
+      const uint4* pwo = pwl;
+      asm volatile("" : "+v"(pwo));                     // opaque: keeps the compiler from hoisting the 15 loads out of the tile loop
+#endif
+      auto load_pw = [&](int buf, int t) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) pwr[buf][k].u = pwo[(t * 3 + k) * 64];
+      };
+      load_pw(0, 0);
+      load_pw(1, 1);
+#pragma unroll
+      for (int py = 0; py < 2; ++py) {
+        const int c = 2 * pz + py;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          int fy, fx;
+          bool it, iv;
+          fine(q, c, fy, fx, it, iv);
+          if (!it) continue;
+          const f32x4 a = acc[c][q];
+          const float4 s4 = skv[c][q];
+          float o0 = fmaxf(a.x + bv.x, 0.f), o1 = fmaxf(a.y + bv.y, 0.f), o2 = fmaxf(a.z + bv.z, 0.f), o3 = fmaxf(a.w + bv.w, 0.f);
+          o0 = iv ? s4.x + o0 : 0.f; o1 = iv ? s4.y + o1 : 0.f; o2 = iv ? s4.z + o2 : 0.f; o3 = iv ? s4.w + o3 : 0.f;
+          uint32_t h0, m0, l0, h1, m1, l1;
+          split2(o0, o1, h0, m0, l0);
+          split2(o2, o3, h1, m1, l1);
+          const int xs = fx + 1;
+          unsigned char* d = fpl + ((fy + 1) * Cfg::FW + (xs & 3) * 9 + (xs >> 2)) * POSB + co * 2;
+          *reinterpret_cast<uint2*>(d) = make_uint2(h0, h1);
+          *reinterpret_cast<uint2*>(d + 16) = make_uint2(m0, m1);
+          *reinterpret_cast<uint2*>(d + 32) = make_uint2(l0, l1);
+        }
+      }
+      __syncthreads();                                  // B3 / B5: the fine plane is complete
+      // ---------------- phase P: in-plane 3x3 part of the prob layer for plane 2 az + pz ----------------
+      f32x4 pacc[1] = {(f32x4){0.f, 0.f, 0.f, 0.f}};
+      BV pb[2][1][3];
+      auto load_p = [&](int buf, int t) {
+        const unsigned char* b = fpl + poff[t];
+        pb[buf][0][0].u = *reinterpret_cast<const uint4*>(b);
+        pb[buf][0][1].u = *reinterpret_cast<const uint4*>(b + 16);
+        pb[buf][0][2].u = *reinterpret_cast<const uint4*>(b + 32);
+      };
+      load_p(0, 0);
+#pragma unroll
+      for (int t = 0; t < Cfg::PKS; ++t) {
+        if (t + 1 < Cfg::PKS) load_p((t & 1) ^ 1, t + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        SBF_TERMS(pacc, 0, 1, pwr[t & 1], pb[t & 1]);
+        if (t + 2 < Cfg::PKS) load_pw(t & 1, t + 2);
+      }
+      {
+        const int gz = 2 * az + pz, gy = Y0 + rr, gx = X0 + 4 * qd;
+#ifdef CDS_FP_NOSTORE
+        if (g < 3 && gy < H && gx < W && pacc[0].x == 1234.5f) {
+#else
+        if (g < 3 && gy < H && gx < W) {
+#endif
+          float* po = out + ((size_t)g * D + gz) * planeHW + (size_t)gy * W + gx;
+          sbf_store4(po, make_float4(pacc[0].x, pacc[0].y, pacc[0].z, pacc[0].w));
+        }
+      }
+      if (pz == 0) __syncthreads();                     // B4: the fine plane may be overwritten
+    }
+  }
+}
+
+int launch_deconv_prob(const float* x, const void* wsp, const float* b, const float* skip, const void* pw, float* out, int Da, int Ha,
+                       int Wa, hipStream_t st) {
+  using Cfg = FPCfg;
+  const int tx = cds_ceil_div(2 * Wa, Cfg::TX), ty = cds_ceil_div(2 * Ha, Cfg::TY);
+  const int ntiles = tx * ty * Da;
+  static const int tpw_env = []() { const char* e = getenv("CDS_FP_TPW"); return e ? atoi(e) : 0; }();   // A/B knob
+  int tpw = tpw_env > 0 ? tpw_env : max(1, min(16, ntiles / (256 * 2 * 6)));
+  const int nwg = cds_ceil_div(ntiles, tpw);
+  static std::atomic<unsigned long long> lds_ok{0};
+  if (int e_lds = cds_allow_lds(reinterpret_cast<const void*>(deconv_prob_kernel), Cfg::LDSB, lds_ok)) return e_lds;
+  hipLaunchKernelGGL(deconv_prob_kernel, dim3(nwg), dim3(Cfg::THREADS), Cfg::LDSB, st, x, reinterpret_cast<const uint4*>(wsp), b, skip,
+                     reinterpret_cast<const uint4*>(pw), out, Da, Ha, Wa, tx, ty, ntiles, tpw);
+  return cds_launch_status();
+}
+
 }  // namespace
 
 // 3x3x3 convolution (pad 1, stride 1 | 2) in split-bf16 arithmetic on channels-last volumes.  x [D][H][W][Cin],
@@ -1225,4 +1561,13 @@ extern "C" int cds_conv3d_prob_cl8_f32(const float* x, const float* weight_tap, 
   hipLaunchKernelGGL(prob_cl8_kernel, dim3(tx * ty * tz), dim3(256), Cfg::LDSB, (hipStream_t)stream, x, weight_tap, out, D, H, W,
                      tx, ty, tx * ty * tz);
   return cds_launch_status();
+}
+
+// conv11 + prob fused (deconv_prob_kernel above): x [Da][Ha][Wa][16] channels-last, skip = c0 [2Da][2Ha][2Wa][8], weight_split =
+// conv11's split weights (ops.split_pack_deconv3d), prob_split = ops.split_pack_prob_toeplitz(prob.weight); out = the three
+// in-plane maps P_kz [3][2Da][2Ha][2Wa] of the prob layer (prob[z] = P_0[z-1] + P_1[z] + P_2[z+1]: cds_softargmin_conf_p3_f32).
+extern "C" int cds_deconv3d_prob_sbf_f32(const float* x, const void* weight_split, const float* bias, const float* skip,
+                                         const void* prob_split, float* out_p3, int Da, int Ha, int Wa, void* stream) {
+  if (!x || !weight_split || !skip || !prob_split || !out_p3 || Da < 1 || Ha < 1 || Wa < 2 || (Wa & 1)) return CDS_EINVAL;
+  return launch_deconv_prob(x, weight_split, bias, skip, prob_split, out_p3, Da, Ha, Wa, (hipStream_t)stream);
 }

@@ -331,8 +331,10 @@ class ViewShard:
         ops.volume_normalize_(vol, vis_sum, channels_last=cl)
         if self.keep_volume:
             self.last_volume = vol.permute(3, 0, 1, 2) if cl else vol
-        prob_pre = cr(vol, channels_last=True) if cl else cr(vol)
-        depth, conf = ops.softargmin_conf(prob_pre, hyp)
+        if cl:
+            depth, conf = cr.regress(vol, hyp)
+        else:
+            depth, conf = ops.softargmin_conf(cr(vol), hyp)
         return depth, conf, nc_sum / n_src_total
 
 

@@ -30,6 +30,10 @@ BN_EPS = 1e-5
 # split-bf16 matrix-core kernels (fp32-class error, channels-last volumes)
 USE_SPLIT_BF16 = os.environ.get("CDS_CONV_EXACT", "0") != "1"
 USE_FUSED_BLEND = os.environ.get("CDS_FUSED_BLEND", "1") != "0"   # A/B knob: 0 = DynamicConv branches and blend as two kernels
+# conv11 + prob fused (csrc/conv3d_sbf.hip: deconv_prob_kernel; parity-tested, the 2 GB 8-channel tensor is never written) is OFF by
+# default: at M1 it measures 3.5 ms + 0.27 ms of soft-argmin against 1.16 + 0.67 + 0.12 ms for the three separate kernels
+# (profiles/r03_costreg_experiments.md section 5).  CDS_FUSED_PROB=1 selects it.
+USE_FUSED_PROB = os.environ.get("CDS_FUSED_PROB", "0") == "1"
 
 
 # ------------------------------------------------------------------------------------------------
@@ -230,6 +234,7 @@ class CostRegNet(_PackedHolder):
                 else:
                     out[name + ".ws"] = ops.split_pack_conv3d(unit.conv.weight.detach() * scale.view(-1, 1, 1, 1, 1))
             out["prob.wt"] = ops.pack_prob_cl(self.prob.weight)
+            out["prob.ws"] = ops.split_pack_prob_toeplitz(self.prob.weight)      # A operand of the fused conv11 + prob kernel
         return out
 
     def split_bf16_supported(self) -> bool:
@@ -256,6 +261,44 @@ class CostRegNet(_PackedHolder):
                     raise RuntimeError("CostRegNet: channels-last input needs the split-bf16 kernels (CDS_CONV_EXACT=1 disables them)")
                 return self._run_cl(volume, p)
             return self._run(volume, p)
+
+    def regress(self, volume_cl: Tensor, hyp: Tensor) -> Tuple[Tensor, Tensor]:
+        """volume [D,h,w,C] channels-last + hypotheses [D,h,w] -> (depth [h,w], confidence [h,w]): CostRegNet followed by the
+        soft-argmin (models/model.py:83-92).  With the split-bf16 kernels the last transposed convolution is fused with the
+        prob layer (csrc/conv3d_sbf.hip: deconv_prob_kernel): the 8-channel full-resolution tensor is never written, the three
+        in-plane maps of the prob layer go straight to the soft-argmin, which adds the z-shifted planes as it reads them.
+        Opt-in (CDS_FUSED_PROB=1): the fused kernel is correct but slower than the separate kernels so far."""
+        D, h, w = volume_cl.shape[:3]
+        if D % 8 or h % 8 or w % 8:
+            raise ValueError(f"CostRegNet needs D,h,w divisible by 8, got {(D, h, w)}")
+        if self.training:
+            raise RuntimeError("CostRegNet.regress is the inference path")
+        p = self._packed.get(self, self._pack)
+        if not (USE_FUSED_PROB and "prob.ws" in p):
+            return ops.softargmin_conf(self.forward(volume_cl, channels_last=True), hyp)
+        with ops.prof("costreg"):
+            x, c0 = self._run_cl_trunk(volume_cl, p)
+            p3 = ops.deconv3d_prob_sbf(x, p["conv11.ws"], p["conv11.b"], c0, p["prob.ws"])
+            del x, c0
+        return ops.softargmin_conf_p3(p3, hyp)
+
+    @staticmethod
+    def _run_cl_trunk(v: Tensor, p: Dict[str, Tensor]) -> Tuple[Tensor, Tensor]:
+        """conv0 .. conv9 on the split-bf16 kernels: returns (conv9's output [D/2,h/2,w/2,16], conv0's output = conv11's skip)."""
+        c0 = ops.conv3d_sbf(v, p["conv0.ws"], p["conv0.b"], 8, stride=ops.SBF_PAIR)
+        c1 = ops.conv3d_sbf(c0, p["conv1.ws"], p["conv1.b"], 16, stride=2)
+        c2 = ops.conv3d_sbf(c1, p["conv2.ws"], p["conv2.b"], 16)
+        del c1
+        c3 = ops.conv3d_sbf(c2, p["conv3.ws"], p["conv3.b"], 32, stride=2)
+        c4 = ops.conv3d_sbf(c3, p["conv4.ws"], p["conv4.b"], 32)
+        del c3
+        c5 = ops.conv3d_sbf(c4, p["conv5.ws"], p["conv5.b"], 64, stride=2)
+        x = ops.conv3d_sbf(c5, p["conv6.ws"], p["conv6.b"], 64)
+        del c5
+        x = ops.deconv3d_sbf(x, p["conv7.ws"], p["conv7.b"], 32, skip=c4)
+        del c4
+        x = ops.deconv3d_sbf(x, p["conv9.ws"], p["conv9.b"], 16, skip=c2)
+        return x, c0
 
     @staticmethod
     def _run_cl(v: Tensor, p: Dict[str, Tensor]) -> Tensor:
@@ -598,9 +641,11 @@ class StageNet(_PackedHolder):
         (ref+src)/2 per view), hyp [D,h,w]."""
         cl = isinstance(cost_regularization, CostRegNet) and cost_regularization.split_bf16_supported()
         volume, _, _, _ = self.aggregate(ref_chw, src_hwc, ref_nc, mats, hyp, stage_idx, channels_last=cl)
-        prob_pre = cost_regularization(volume, channels_last=True) if cl else cost_regularization(volume)
+        if cl:
+            depth, conf = cost_regularization.regress(volume, hyp)       # conv11 + prob fused, soft-argmin on the three maps
+        else:
+            depth, conf = ops.softargmin_conf(cost_regularization(volume), hyp)
         del volume
-        depth, conf = ops.softargmin_conf(prob_pre, hyp)
         nc_mean = ops.view_mean(nc_sums.contiguous())
         return depth, conf, nc_mean
 

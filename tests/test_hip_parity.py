@@ -1026,3 +1026,38 @@ def test_warp_row_windows_equal_full_grid_rows(V, C, D, h, w, y0, y1, dev, ops):
             vol_w, vs_w = ops.warp_aggregate(ref_w, src, vis_w, mats, hyp_w, channels_last=cl, exact=exact, window=(h, y0))
             assert torch.equal(vs_w, vs_full[y0:y1])
             assert torch.equal(vol_w, vol_full[:, y0:y1] if cl else vol_full[:, :, y0:y1])
+
+
+@pytest.mark.parametrize("Da,Ha,Wa", [(2, 4, 16), (3, 8, 24), (4, 12, 40), (1, 4, 18), (5, 20, 64)])
+def test_fused_conv11_prob_equals_two_kernels(Da, Ha, Wa, dev, ops):
+    """cds_deconv3d_prob_sbf_f32 (conv11 + in-plane prob, y never written) against the two shipped kernels (transposed convolution
+    + skip -> planar y -> prob) and against a float64 reference: logits P_0[d-1] + P_1[d] + P_2[d+1] and the soft-argmin on the
+    three maps.  Odd tile counts, a width that is not a multiple of 32, a single cell plane."""
+    g = torch.Generator().manual_seed(100 + Wa)
+    x = torch.randn(Da, Ha, Wa, 16, generator=g).to(dev)
+    skip = torch.randn(2 * Da, 2 * Ha, 2 * Wa, 8, generator=g).to(dev)
+    w = (torch.randn(16, 8, 3, 3, 3, generator=g) / (27 * 16 / 8) ** 0.5).to(dev)
+    b = torch.randn(8, generator=g).to(dev)
+    wp = (torch.randn(1, 8, 3, 3, 3, generator=g) / 216 ** 0.5).to(dev)
+    ws, pws = ops.split_pack_deconv3d(w), ops.split_pack_prob_toeplitz(wp)
+    p3 = ops.deconv3d_prob_sbf(x, ws, b, skip, pws)
+    D = 2 * Da
+    got = p3[1].clone()
+    got[1:] += p3[0][:-1]
+    got[:-1] += p3[2][1:]
+    # the shipped two-kernel path
+    y = ops.deconv3d_sbf(x, ws, b, 8, skip=skip, out_planar=True)
+    want = ops.conv3d_k3(y, wp.permute(1, 2, 3, 4, 0).reshape(8, 27, 1).contiguous(), None, relu=False)[0]
+    # float64 reference
+    xd = x.double().permute(3, 0, 1, 2)[None].cpu()
+    yd = torch.relu(F.conv_transpose3d(xd, w.double().cpu(), b.double().cpu(), stride=2, padding=1, output_padding=1))
+    yd = yd + skip.double().permute(3, 0, 1, 2)[None].cpu()
+    ref = F.conv3d(yd, wp.double().cpu(), padding=1)[0, 0]
+    scale = ref.abs().max().item()
+    e_fused, e_two = (got.double().cpu() - ref).abs().max().item(), (want.double().cpu() - ref).abs().max().item()
+    assert e_fused <= max(2.0 * e_two, 2e-6 * scale), (e_fused, e_two, scale)      # fp32-class, like the two-kernel path
+    assert (got - want).abs().max().item() < 1e-5 * max(1.0, scale)
+    hyp = (400.0 + 500.0 * torch.rand(D, 2 * Ha, 2 * Wa, generator=g)).to(dev)
+    d_f, c_f = ops.softargmin_conf_p3(p3, hyp)
+    d_t, c_t = ops.softargmin_conf(want, hyp)
+    assert (d_f - d_t).abs().max() < 2e-3 and (c_f - c_t).abs().mean() < 1e-4
