@@ -884,7 +884,10 @@ int launch_deconv(const float* x, const void* wsp, const float* b, const float* 
 // ---------------------------------------------------------------------------------------------
 constexpr int DWS_CW = 4, DWS_PW = 2, DWS_THREADS = (DWS_CW + DWS_PW) * 64;
 
-__global__ __launch_bounds__(DWS_THREADS, 3) void deconv3d_sbf_ws_kernel(const float* __restrict__ x, const uint4* __restrict__ wsp,
+#ifndef CDS_DWS_MINW
+#define CDS_DWS_MINW 3
+#endif
+__global__ __launch_bounds__(DWS_THREADS, CDS_DWS_MINW) void deconv3d_sbf_ws_kernel(const float* __restrict__ x, const uint4* __restrict__ wsp,
                                                                        const float* __restrict__ bias, const float* __restrict__ skip,
                                                                        float* __restrict__ out, int Cin, int Cout, int D, int H, int W,
                                                                        int act, int out_planar, int tiles_x, int tiles_y, int ntiles,
