@@ -882,17 +882,32 @@ int launch_deconv(const float* x, const void* wsp, const float* b, const float* 
 // in LDS (rounds x 5 K-steps x 3 KB), the staged input tile is double-buffered and filled by 2 producer waves that run
 // two stages ahead.  One workgroup barrier per stage (tile, 8-channel round); 2-3 workgroups per CU.
 // ---------------------------------------------------------------------------------------------
-constexpr int DWS_CW = 4, DWS_PW = 2, DWS_THREADS = (DWS_CW + DWS_PW) * 64;
+// Round 3: the 6-wave (4 + 2) workgroups of round 2 never paired up on a CU (PMC: 5.9 resident waves per CU, SQ_WAVE_CYCLES x 4 /
+// (GRBM_GUI_ACTIVE / 8 x 256): a 6-wave workgroup occupies the SIMDs 2-2-1-1 and a second one does not fit the 3-waves-per-SIMD register
+// budget on the two fuller SIMDs).  CYT = 8: ONE 12-wave workgroup per CU (8 consumer waves = 8 cell rows, 4 producers): 3 waves on every
+// SIMD, twice the loads in flight, two consumer waves per SIMD issuing MFMAs.  CYT = 4 keeps the old shape (A/B, small volumes).
+template <int CYT>
+struct DWSCfg {
+  static constexpr int CX = 32, CY = CYT;
+  static constexpr int XT = CX / 16, NT = XT;
+  static constexpr int IX = CX + 1, IY = CY + 1, IZ = 2;
+  static constexpr int IXP = 40;
+  static constexpr int NPOS = IZ * IY * IXP;
+  static constexpr int LDSB = NPOS * POSB;
+  static constexpr int CW = CYT, PW = CYT / 2, THREADS = (CW + PW) * 64;
+};
 
 #ifndef CDS_DWS_MINW
 #define CDS_DWS_MINW 3
 #endif
-__global__ __launch_bounds__(DWS_THREADS, CDS_DWS_MINW) void deconv3d_sbf_ws_kernel(const float* __restrict__ x, const uint4* __restrict__ wsp,
+template <int CYT>
+__global__ __launch_bounds__((DWSCfg<CYT>::THREADS), CDS_DWS_MINW) void deconv3d_sbf_ws_kernel(const float* __restrict__ x, const uint4* __restrict__ wsp,
                                                                        const float* __restrict__ bias, const float* __restrict__ skip,
                                                                        float* __restrict__ out, int Cin, int Cout, int D, int H, int W,
                                                                        int act, int out_planar, int tiles_x, int tiles_y, int ntiles,
                                                                        int tpw) {
-  using Cfg = DCfg;
+  using Cfg = DWSCfg<CYT>;
+  constexpr int DWS_CW = Cfg::CW, DWS_PW = Cfg::PW, DWS_THREADS = Cfg::THREADS;
   using Tab = DTab<true>;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int tid = threadIdx.x;
@@ -1081,20 +1096,29 @@ __global__ __launch_bounds__(DWS_THREADS, CDS_DWS_MINW) void deconv3d_sbf_ws_ker
   }
 }
 
-int launch_deconv_ws(const float* x, const void* wsp, const float* b, const float* skip, float* out, int Cin, int Cout, int D, int H,
-                     int W, int act, int out_planar, hipStream_t st) {
-  using Cfg = DCfg;
+template <int CYT>
+int launch_deconv_ws_t(const float* x, const void* wsp, const float* b, const float* skip, float* out, int Cin, int Cout, int D, int H,
+                       int W, int act, int out_planar, hipStream_t st) {
+  using Cfg = DWSCfg<CYT>;
   const int tx = cds_ceil_div(W, Cfg::CX), ty = cds_ceil_div(H, Cfg::CY);
   const int ntiles = tx * ty * D;
   static const int tpw_env = []() { const char* e = getenv("CDS_SBF_TPW"); return e ? atoi(e) : 0; }();   // A/B knob
-  int tpw = tpw_env > 0 ? tpw_env : max(1, min(16, ntiles / (256 * 2 * 8)));
+  int tpw = tpw_env > 0 ? tpw_env : max(1, min(16, ntiles / (256 * (CYT == 8 ? 1 : 2) * 8)));
   const int nwg = cds_ceil_div(ntiles, tpw);
   const int lds_bytes = (Cin >> 3) * DTab<true>::NKS * 3 * 1024 + 2 * Cfg::LDSB;
   static std::atomic<unsigned long long> lds_ok{0};
-  if (int e_lds = cds_allow_lds(reinterpret_cast<const void*>(deconv3d_sbf_ws_kernel), 160 * 1024, lds_ok)) return e_lds;
-  hipLaunchKernelGGL(deconv3d_sbf_ws_kernel, dim3(nwg), dim3(DWS_THREADS), lds_bytes, st, x, reinterpret_cast<const uint4*>(wsp), b,
+  if (int e_lds = cds_allow_lds(reinterpret_cast<const void*>(deconv3d_sbf_ws_kernel<CYT>), 160 * 1024, lds_ok)) return e_lds;
+  hipLaunchKernelGGL(deconv3d_sbf_ws_kernel<CYT>, dim3(nwg), dim3(Cfg::THREADS), lds_bytes, st, x, reinterpret_cast<const uint4*>(wsp), b,
                      skip, out, Cin, Cout, D, H, W, act, out_planar, tx, ty, ntiles, tpw);
   return cds_launch_status();
+}
+
+int launch_deconv_ws(const float* x, const void* wsp, const float* b, const float* skip, float* out, int Cin, int Cout, int D, int H,
+                     int W, int act, int out_planar, hipStream_t st) {
+  static const int cyt_env = []() { const char* e = getenv("CDS_DWS_CYT"); return e ? atoi(e) : 0; }();   // A/B knob: 4 | 8
+  const bool big = cyt_env ? cyt_env == 8 : (H >= 16 && (long)cds_ceil_div(W, 32) * cds_ceil_div(H, 8) * D >= 2 * 256);
+  if (big) return launch_deconv_ws_t<8>(x, wsp, b, skip, out, Cin, Cout, D, H, W, act, out_planar, st);
+  return launch_deconv_ws_t<4>(x, wsp, b, skip, out, Cin, Cout, D, H, W, act, out_planar, st);
 }
 
 // ---------------------------------------------------------------------------------------------
