@@ -263,6 +263,49 @@ def train_sample(H, W, n_views, refine, dev, seed=21):
     return {"imgs": imgs, "proj_matrices": cams, "depth_values": dv, "depth": gt, "mask": mask}
 
 
+def measure_k3_traffic(timeout_s: float = 300.0):
+    """HBM bytes of ONE K3 launch at M1, measured in THIS run: two counter-only rocprofv3 passes (`--pmc FETCH_SIZE`, `--pmc
+    WRITE_SIZE`; no trace domains) over scripts/run_k3_traffic.py in a child process, collected and corrected as
+    MI355X_MICROARCH.md prescribes (KiB units; on gfx950 FETCH_SIZE tallies a wide streaming read at half its bytes -> doubled),
+    with the correction re-checked on the spot against `volume_normalize` (reads and writes 2 013 265 920 B exactly).
+    Returns (dict | None, note)."""
+    import collections, glob, shutil, sqlite3, subprocess, tempfile
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None, "rocprofv3 not on PATH"
+    tmp = tempfile.mkdtemp(prefix="cds_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    raw = {}
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, ctr)
+            subprocess.run([exe, "--pmc", ctr, "-d", d, "-o", "p", "--", sys.executable, os.path.join(ROOT, "scripts", "run_k3_traffic.py")],
+                           cwd="/tmp", env=env, timeout=timeout_s, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            dbs = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
+            if not dbs:
+                return None, f"rocprofv3 wrote no database for {ctr}"
+            agg = collections.defaultdict(list)
+            for k, c, v in sqlite3.connect(dbs[0]).cursor().execute("select kernel_name, counter_name, value from counters_collection"):
+                if c == ctr:
+                    agg[k].append(v)
+            raw[ctr] = {k: sum(v) / len(v) * 1024.0 for k, v in agg.items()}
+    except Exception as e:   # a failed profiler run must not take the benchmark down
+        return None, f"{type(e).__name__}: {str(e)[:160]}"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+    def pick(d, sub):
+        return next((v for k, v in d.items() if sub in k), None)
+    f3, w3 = pick(raw["FETCH_SIZE"], "warp_aggregate"), pick(raw["WRITE_SIZE"], "warp_aggregate")
+    fc, wc = pick(raw["FETCH_SIZE"], "volume_normalize"), pick(raw["WRITE_SIZE"], "volume_normalize")
+    if None in (f3, w3, fc, wc):
+        return None, "kernels not found in the counter databases"
+    known = 4.0 * 8 * 192 * 512 * 640
+    return {"bytes": w3 + 2.0 * f3, "write_bytes": w3, "fetch_bytes_raw": f3, "fetch_bytes_corrected": 2.0 * f3,
+            "calibration_volume_normalize": {"known_read_bytes": known, "fetch_raw_over_known": fc / known,
+                                             "write_raw_over_known": wc / known}}, "measured"
+
+
 def measure_viewshard(model, dev, dist, rank, world, exchange, stage_name="M1", cascade_name="M4"):
     """The north_star exchange on N > 1 ranks, measured outside the headline's timed region: (i) the single-stage
     workload through `ViewShardedStage`, (ii) the BASELINE config-4 cascade through `shard_views(model)`.  Same
@@ -362,13 +405,15 @@ def main():
                     help="viewshard exchange: one RCCL all-reduce; reduce-scatter + all-gather as direct P2P sends; or "
                          "reduce_scatter = rows of the sum per rank + slab-parallel CostRegNet (the form that scales)")
     ap.add_argument("--no-extras", action="store_true", help="skip the M1b / M2 / M3 / M4 side measurements")
+    ap.add_argument("--no-pmc", action="store_true", help="do not re-measure roofline.traffic with rocprofv3 in this run")
     ap.add_argument("--no-viewshard", action="store_true", help="N > 1: skip the north-star view-shard measurement")
     ap.add_argument("--streams", type=int, default=1,
                     help="depth maps in flight per GPU on separate HIP streams (a step = that many depth maps; "
                          "per-kernel event timing and the roofline object need 1)")
     ap.add_argument("--cpu-sample", type=float, default=1.0,
                     help="linear window fraction for the CPU baseline (1 = the full workload once; 0 = skip)")
-    ap.add_argument("--train-dtype", default="bf16", choices=["bf16", "fp32"], help="T5: autocast dtype of the conv stacks")
+    ap.add_argument("--train-dtype", default="fp32", choices=["bf16", "fp32"],
+                    help="T5: fp32 (default) or torch.autocast(bf16) around the torch conv stacks (an experiment: slower than fp32)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) in production; gloo only for single-GPU dry runs")
     args = ap.parse_args()
 
@@ -442,7 +487,8 @@ def main():
         reducer = T.GradAllReducer(model.parameters(), module=model)       # broadcasts rank 0's weights when world > 1
         bf16 = args.train_dtype == "bf16"
         workload_desc = (f"{args.workload}: BlendedMVS-shaped training step {W}x{H}, N={n_views}, refine={refine}, "
-                         f"{args.train_dtype} autocast on the conv stacks, SGD, flat-bucket gradient all-reduce")
+                         + ("torch.autocast(bf16) around the torch conv stacks (experiment), " if bf16 else "fp32, ")
+                         + "SGD, flat-bucket gradient all-reduce")
         metric, unit = f"training samples/sec ({W}x{H} N={n_views} step: forward + loss + backward + all-reduce + SGD)", "samples/s"
         b_alg = None
         def step():
@@ -497,9 +543,14 @@ def main():
     if "warp_aggregate" in kern and b_alg is not None:
         t_k3 = kern["warp_aggregate"] * 1e-3
         achieved = b_alg / t_k3
-        traffic = None
+        traffic, traffic_detail, traffic_note = None, None, "static"
+        if world == 1 and args.workload == "M1" and not args.no_extras and not args.no_pmc:
+            torch.cuda.synchronize()
+            traffic_detail, traffic_note = measure_k3_traffic()
+            if traffic_detail is not None:
+                traffic = traffic_detail["bytes"]
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
+        if traffic is None and os.path.exists(pmc):
             try:
                 traffic = json.load(open(pmc)).get(args.workload, {}).get("warp_aggregate_hbm_bytes")
             except Exception:
@@ -508,8 +559,13 @@ def main():
                 "bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK, "frac_of_measured_copy_ceiling": achieved / 6.29e12,
                 "algorithmic_bytes": b_alg, "kernel_ms": kern["warp_aggregate"], "traffic": traffic,
-                "traffic_source": "profiles/pmc_traffic.json: static, from the committed rocprofv3 --pmc passes of this "
-                                  "kernel (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE), not re-measured in this run"}
+                "traffic_source": ("measured in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate counter-only "
+                                   "passes over scripts/run_k3_traffic.py in a child process), WRITE + 2 x FETCH per the gfx950 "
+                                   "correction, re-checked on volume_normalize's known byte count (traffic_detail)"
+                                   if traffic_detail is not None else
+                                   f"profiles/pmc_traffic.json: static, from the committed rocprofv3 --pmc passes of this kernel "
+                                   f"(FETCH_SIZE x2 + WRITE_SIZE); in-run measurement: {traffic_note}"),
+                "traffic_detail": traffic_detail}
         span = sum(kern.get(k, 0.0) for k in ("warp_entropy", "visibility_cnn", "warp_aggregate"))
         roof["k1_vis_k3_span_ms"] = span
         roof["k1_vis_k3_span_frac"] = b_alg / (span * 1e-3) / HBM_PEAK if span > 0 else None

@@ -587,6 +587,182 @@ __global__ __launch_bounds__(ZCfg::THREADS) void conv3d_sbf_zm_kernel(const floa
   }
 }
 
+// Round 3 variant: EIGHT consumer waves (two per SIMD, one output row each) + four producers = 12 waves, three on every SIMD; the 27
+// weight vectors move from registers (108 VGPRs, one consumer wave per SIMD with the 256-register budget) into LDS (27 KB next to the
+// 130 KB ring).  Why: one wave per SIMD issues v_mfma_f32_16x16x32_bf16 every 10.0 ns, two waves every 8.1 ns (scripts/ubench), and the
+// second wave covers the first one's epilogue stores and barrier waits.
+struct ZCfg8 : ZCfg {
+  static constexpr int CW = 8, THREADS = (CW + PW) * 64;
+  static constexpr int WBYTES = KSTEPS * 3 * 1024;
+  static constexpr int LDSB8 = LDSB + WBYTES;                       // 158,208 B
+};
+
+__global__ __launch_bounds__(ZCfg8::THREADS, 3) void conv3d_sbf_zm8_kernel(const float* __restrict__ x, const uint4* __restrict__ wsp,
+                                                                     const float* __restrict__ bias, float* __restrict__ out,
+                                                                     int D, int H, int W, int act, int tiles_x, int tiles_y,
+                                                                     int zseg) {
+  using Cfg = ZCfg8;
+  constexpr int Cin = 8, Cout = 8, G = Cfg::G, R = Cfg::R;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // unit = (column tx, ty; z segment): z segments of a column are consecutive workgroups
+  const int nseg = (D + zseg - 1) / zseg;
+  int unit = cds_xcd_remap(blockIdx.x, gridDim.x);
+  const int seg = unit % nseg;
+  unit /= nseg;
+  const int tx_i = unit % tiles_x, ty_i = unit / tiles_x;
+  const int z0 = seg * zseg, z1 = min(D, z0 + zseg);
+  const int nstages = (z1 - z0 + G - 1) / G;
+  const int gx0 = tx_i * Cfg::TX - 1, gy0 = ty_i * Cfg::TY - 1;
+  // input plane p (-1 <= p - z0, any p) lives in ring slot (p - z0 + 1) % R
+  {
+    uint4* wdst = reinterpret_cast<uint4*>(lds + Cfg::LDSB);
+    for (int i = tid; i < Cfg::WBYTES / 16; i += Cfg::THREADS) wdst[i] = wsp[i];
+  }
+
+  if (wave >= Cfg::CW) {
+    // ============================== producers ==============================
+    constexpr int PT = Cfg::PW * 64;
+    const int ptid = tid - Cfg::CW * 64;
+    constexpr int NP = G * Cfg::PPOS, PPT = (NP + PT - 1) / PT;     // positions of the G planes of a stage
+    int s_pl[PPT], s_yx[PPT], s_dst[PPT];
+#pragma unroll
+    for (int h = 0; h < PPT; ++h) {
+      const int p = h * PT + ptid;
+      const int pl = p / Cfg::PPOS, pp = p - pl * Cfg::PPOS;
+      const int row = pp / Cfg::IXP, q = pp - row * Cfg::IXP;
+      const int c = 2 * (q % Cfg::IXH) + q / Cfg::IXH;            // de-interleaved x parities (as the tiled pair kernel)
+      s_pl[h] = p < NP ? pl : -1;
+      s_yx[h] = (row << 10) | c;
+      s_dst[h] = (row * Cfg::IXP + q) * POSB;
+    }
+    float4 va[2][PPT], vb[2][PPT];
+    auto load_pos = [&](int z, int yx, float4& a, float4& b) {
+      const int gy = gy0 + (yx >> 10), gx = gx0 + (yx & 1023);
+      const bool ok = (unsigned)z < (unsigned)D && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+      const float* __restrict__ src = x + ((size_t)((size_t)z * H + gy) * W + gx) * Cin;
+      a = ok ? *reinterpret_cast<const float4*>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
+      b = ok ? *reinterpret_cast<const float4*>(src + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    // stage st needs input planes z0 + st G - 1 .. z0 + st G + G; its NEW planes are the last G of them
+    auto issue = [&](int st, int set) {
+#pragma unroll
+      for (int h = 0; h < PPT; ++h)
+        if (s_pl[h] >= 0) load_pos(z0 + st * G + 1 + s_pl[h], s_yx[h], va[set][h], vb[set][h]);
+    };
+    auto deposit = [&](int st, int set) {
+      const int slot0 = (st * G + 2) % R;                            // slot of plane z0 + st G + 1
+#pragma unroll
+      for (int h = 0; h < PPT; ++h) {
+        if (s_pl[h] < 0) continue;
+        int slot = slot0 + s_pl[h];
+        slot = slot >= R ? slot - R : slot;
+        split_store8(lds + slot * Cfg::PLANEB + s_dst[h], va[set][h], vb[set][h]);
+      }
+    };
+    // the two lowest planes of the segment (z0 - 1, z0): loaded, split and stored directly
+    for (int p = ptid; p < 2 * Cfg::PPOS; p += PT) {
+      const int pl = p / Cfg::PPOS, pp = p - pl * Cfg::PPOS;
+      const int row = pp / Cfg::IXP, q = pp - row * Cfg::IXP;
+      const int c = 2 * (q % Cfg::IXH) + q / Cfg::IXH;
+      float4 a, b;
+      load_pos(z0 - 1 + pl, (row << 10) | c, a, b);
+      split_store8(lds + pl * Cfg::PLANEB + (row * Cfg::IXP + q) * POSB, a, b);
+    }
+    issue(0, 0);
+    if (nstages > 1) issue(1, 1);
+    deposit(0, 0);
+    if (nstages > 2) issue(2, 0);
+    __syncthreads();                                   // #0: stage 0 staged
+    for (int st = 0; st < nstages; st += 2) {
+      if (st + 1 < nstages) {
+        deposit(st + 1, 1);
+        if (st + 3 < nstages) issue(st + 3, 1);
+      }
+      __syncthreads();                                 // #(st + 1): stage st consumed, stage st + 1 staged
+      if (st + 1 >= nstages) break;
+      if (st + 2 < nstages) {
+        deposit(st + 2, 0);
+        if (st + 4 < nstages) issue(st + 4, 0);
+      }
+      __syncthreads();                                 // #(st + 2)
+    }
+    return;
+  }
+
+  // ============================== consumers: wave = output row ==============================
+  SBF_CONSUMER_PRIO();
+  const int j = lane & 15, g = lane >> 4;
+  const int kxl = (g & 1) * 2 + (g >> 1);              // lane groups take x' = 0, 2, 1, 3 (see the tiled kernel)
+  const int lane_base = (wave * Cfg::IXP + j + (kxl & 1) * Cfg::IXH + (kxl >> 1)) * POSB;
+  const unsigned char* wlds = lds + Cfg::LDSB + lane * 16;
+  const int co = 4 * (g & 1);
+  const float4 bv = bias ? *reinterpret_cast<const float4*>(bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+  const int ox = tx_i * Cfg::TX + 2 * j + (g >> 1);
+  f32x4 acc[G];                                        // [plane i]
+  __syncthreads();                                     // #0
+  for (int st = 0; st < nstages; ++st) {
+#pragma unroll
+    for (int t = 0; t < G; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // LDS address of input plane z0 + st G - 1 + u (u = 0 .. G + 1) for this lane
+    const unsigned char* vpl[G + 2];
+    {
+      int slot = (st * G) % R;
+#pragma unroll
+      for (int u = 0; u < G + 2; ++u) {
+        vpl[u] = lds + slot * Cfg::PLANEB + lane_base;
+        slot = slot + 1 >= R ? slot + 1 - R : slot + 1;
+      }
+    }
+    // steps: K-step t = (kz, ky); the G planes of this wave's row are one operand group; weights of the step from LDS
+    constexpr int NS = Cfg::KSTEPS;
+    BV bd[2][G][3];
+    BV wa[2][3];
+    auto load_b = [&](int buf, int t) {
+      const int kz = t / 3, ky = t - 3 * kz;
+      wa[buf][0].u = *reinterpret_cast<const uint4*>(wlds + (t * 3) * 1024);
+      wa[buf][1].u = *reinterpret_cast<const uint4*>(wlds + (t * 3 + 1) * 1024);
+      wa[buf][2].u = *reinterpret_cast<const uint4*>(wlds + (t * 3 + 2) * 1024);
+#pragma unroll
+      for (int i = 0; i < G; ++i) {
+        const unsigned char* b = vpl[i + kz] + (ky * Cfg::IXP) * POSB;
+        bd[buf][i][0].u = *reinterpret_cast<const uint4*>(b);
+        bd[buf][i][1].u = *reinterpret_cast<const uint4*>(b + 16);
+        bd[buf][i][2].u = *reinterpret_cast<const uint4*>(b + 32);
+      }
+    };
+    load_b(0, 0);
+#pragma unroll
+    for (int ss = 0; ss < NS; ++ss) {
+      const int db = ss & 1;
+      if (ss + 1 < NS) load_b(db ^ 1, ss + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      SBF_TERMS(acc, 0, G, wa[db], bd[db]);
+    }
+    // ---- epilogue ----
+    {
+      const int oy = ty_i * Cfg::TY + wave;
+#pragma unroll
+      for (int i = 0; i < G; ++i) {
+        const int oz = z0 + st * G + i;
+        if (oz >= z1 || oy >= H || ox >= W) continue;
+        const f32x4 a = acc[i];
+        float4 o = make_float4(a.x + bv.x, a.y + bv.y, a.z + bv.z, a.w + bv.w);
+        if (act == CDS_ACT_RELU) {
+          o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
+        }
+        sbf_store4(out + ((size_t)((size_t)oz * H + oy) * W + ox) * Cout + co, o);
+      }
+    }
+    __syncthreads();                                   // #(st + 1)
+  }
+}
+
+#ifndef CDS_ZM8_DEFAULT
+#define CDS_ZM8_DEFAULT false
+#endif
 int launch_fwd_zm(const float* x, const void* wsp, const float* b, float* out, int D, int H, int W, int act, hipStream_t st) {
   using Cfg = ZCfg;
   const int tx = cds_ceil_div(W, Cfg::TX), ty = cds_ceil_div(H, Cfg::TY);
@@ -598,6 +774,14 @@ int launch_fwd_zm(const float* x, const void* wsp, const float* b, float* out, i
   if (nseg_env > 0) nseg = nseg_env;
   int zseg = cds_ceil_div(cds_ceil_div(D, nseg), Cfg::G) * Cfg::G;
   nseg = cds_ceil_div(D, zseg);
+  static const bool zm8 = []() { const char* e = getenv("CDS_ZM8"); return e ? e[0] == '1' : CDS_ZM8_DEFAULT; }();   // A/B knob
+  if (zm8) {
+    static std::atomic<unsigned long long> lds_ok8{0};
+    if (int e_lds = cds_allow_lds(reinterpret_cast<const void*>(conv3d_sbf_zm8_kernel), ZCfg8::LDSB8, lds_ok8)) return e_lds;
+    hipLaunchKernelGGL(conv3d_sbf_zm8_kernel, dim3(tx * ty * nseg), dim3(ZCfg8::THREADS), ZCfg8::LDSB8, st, x,
+                       reinterpret_cast<const uint4*>(wsp), b, out, D, H, W, act, tx, ty, zseg);
+    return cds_launch_status();
+  }
   static std::atomic<unsigned long long> lds_ok{0};
   if (int e_lds = cds_allow_lds(reinterpret_cast<const void*>(conv3d_sbf_zm_kernel), Cfg::LDSB, lds_ok)) return e_lds;
   hipLaunchKernelGGL(conv3d_sbf_zm_kernel, dim3(tx * ty * nseg), dim3(Cfg::THREADS), Cfg::LDSB, st, x, reinterpret_cast<const uint4*>(wsp), b,
