@@ -1566,12 +1566,16 @@ __global__ __launch_bounds__(FPCfg::THREADS, CDS_FP_MINW) void deconv_prob_kerne
         int fy, fx;
         bool it, iv;
         fine(q, c, fy, fx, it, iv);
-        const size_t vox = ((size_t)(2 * az + (c >> 1)) * H + (Y0 + fy)) * W + (X0 + fx);
+        // unconditional load from a clamped (always valid) address: a per-lane `iv ? load : 0` compiles to exec-masked blocks with an
+        // s_waitcnt vmcnt(0) at every join, i.e. eight SERIALISED HBM round trips per tile (measured: 1.3-2.1 ms of the kernel)
+        const int sy = min(max(Y0 + fy, 0), H - 1), sx = min(max(X0 + fx, 0), W - 1);
+        const size_t vox = ((size_t)(2 * az + (c >> 1)) * H + sy) * W + sx;
 #ifdef CDS_FP_NOSKIP
         skv[c][q] = make_float4(0.f, 0.f, 0.f, 0.f);
         (void)vox;
 #else
-        skv[c][q] = iv ? *reinterpret_cast<const float4*>(skip + vox * 8 + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+        skv[c][q] = *reinterpret_cast<const float4*>(skip + vox * 8 + co);
+        (void)iv;
 #endif
       }
     // ---------------- phase A: transposed convolution, both rounds ----------------
