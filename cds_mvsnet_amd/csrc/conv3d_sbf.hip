@@ -1380,46 +1380,48 @@ __global__ __launch_bounds__(256, 2) void prob_cl8_kernel(const float* __restric
 // conv11 FUSED with the prob layer: ConvTranspose3d(16 -> 8) + BN + ReLU + skip c0 (module.py:299-301,313) and the 3x3 in-plane
 // part of Conv3d(8 -> 1) (module.py:303,314).  The 8-channel full-resolution tensor y = c0 + relu(deconv(x)) (2 GB at 640x512x192)
 // is never written: a workgroup owns a 32 x 8 fine tile of TWO fine planes (one cell plane az), computes y on the tile plus a
-// one-voxel ring (recomputed, 34 x 10), keeps one plane of it in LDS already split into its three bf16 terms, and emits for
+// one-voxel ring (recomputed, 34 x 10), keeps both planes of it in LDS already split into their three bf16 terms, and emits for
 // every fine voxel the three in-plane sums
 //       P_kz[z][y][x] = sum_{ky, kx, c} w_prob[c][kz][ky][kx] * y[c][z][y + ky - 1][x + kx - 1]          (kz = 0, 1, 2)
 // -- the prob layer is separable along z as prob[z] = P_0[z - 1] + P_1[z] + P_2[z + 1], which the soft-argmin kernel adds while it
 // reads (cds_softargmin_conf_p3_f32).  12 B per voxel leave the kernel instead of 32 B out + 32 B back in + 4 B out.
 //
-// Transposed-convolution phase (A): the MERGE form of deconv3d_sbf_ws_kernel (rows = (x parity, cout), columns = 16 cells, classes
-// (pz, py)), over 7 column groups: the 6 cell rows cy = -1 .. 4 of the tile (16 main cells each) and one group holding the 12 ring
-// cells (cx = -1 and 16 of every row).  Phase E(pz): + bias, ReLU, + skip (prefetched at tile start), exact 3-way bf16 split,
-// 8-byte LDS writes into the fine plane F[row][x de-interleaved mod 4][term][8 ch]; voxels outside the volume are written as zeros
-// (the prob layer's zero padding).  Phase P(pz): matrix tile rows = (kz, x offset 0..3), columns = 8 quads x 2 rows, K = 3 x 6
-// in-plane positions x 8 channels (5 K-steps): lane group kz ends with P_kz of four consecutive x = one 16-byte store.
-// 4 compute + 2 staging waves, 80 KB of LDS: two workgroups per CU overlap each other's E phases and barriers.
+// ONE 12-wave workgroup per CU (three waves on every SIMD; 6-wave workgroups do not pair up on a CU): 8 compute waves + 4 staging waves.
+// Everything a compute wave touches is in LDS -- conv11's split weights (30 KB), the prob weights in Toeplitz split form (15 KB), the
+// input tile of both 8-channel rounds (double-buffered across tiles), the skip tile c0 (fp32) -- so the compute waves issue no
+// vector-memory load at all (the first version loaded skip and prob weights from global memory in the compute waves: every HBM / L2
+// latency ended up exposed behind an s_waitcnt vmcnt(0), 3.2-3.5 ms).  Per tile, two workgroup barriers:
+//   A  transposed convolution, MERGE form of deconv3d_sbf_ws_kernel (rows = (x parity, cout), columns = 16 cells, classes (pz, py)):
+//      seven column groups -- the cell rows cy = -1 .. 4 and one group with the 12 ring cells (cx = -1 | 16 of every row) -- one per
+//      wave (wave 7 idles), both rounds, 60 MFMAs;
+//   E  + bias, ReLU, + skip from LDS, zero outside the volume (the prob layer's zero padding), exact 3-way bf16 split, 8-byte LDS
+//      writes into the fine planes F[pz][row][x de-interleaved mod 4][term][8 ch];
+//   P  in-plane 3x3 part of the prob layer: matrix rows = (kz, x offset 0..3), columns = 8 quads x 2 rows, K = 3 x 6 positions x 8
+//      channels (5 K-steps, 30 MFMAs): one unit (plane, row pair) per wave; lane group kz stores P_kz of four consecutive x.
+// The staging waves deposit the NEXT tile's input during A and its skip tile during P / the next A, loads a tile ahead in registers.
 // ---------------------------------------------------------------------------------------------
 #ifndef CDS_FP_IXP
-#define CDS_FP_IXP 24
+#define CDS_FP_IXP 20
 #endif
 struct FPCfg {
   static constexpr int TX = 32, TY = 8;
   static constexpr int CXM = 16, CYM = 4;                   // main cells of a tile
   static constexpr int IX = CXM + 3, IY = CYM + 3, IZ = 2;   // staged input cells: cx -1 .. 17, cy -1 .. 5, cz az .. az + 1
   static constexpr int IXP = CDS_FP_IXP;
-  static constexpr int INB = IZ * IY * IXP * POSB;           // one (tile, round) buffer: 16,128 B
+  static constexpr int INB1 = IZ * IY * IXP * POSB;          // one round of a tile: 13,440 B
+  static constexpr int INB = 2 * INB1;                       // both rounds
   static constexpr int FW = 36, FH = TY + 2;                 // fine plane incl. ring: 34 columns, stored as 4 residue runs of 9
-  static constexpr int FB = FH * FW * POSB;                  // 17,280 B
-  static constexpr int CW = 4, PW = 2, THREADS = (CW + PW) * 64;
+  static constexpr int FB1 = FH * FW * POSB;                 // 17,280 B
+  static constexpr int SKW = TX + 2, SKH = TY + 2;
+  static constexpr int SKB = 2 * SKH * SKW * 32;             // skip tile, two planes, fp32: 21,760 B
+  static constexpr int CW = 8, PW = 4, THREADS = (CW + PW) * 64;
   static constexpr int WB = 2 * DTab<true>::NKS * 3 * 1024;  // conv11's split weights: 30,720 B
-#ifdef CDS_FP_PWLDS
-  static constexpr int PWB = 5 * 3 * 1024;                   // prob weights in LDS (experiment)
-#else
-  static constexpr int PWB = 0;
-#endif
-  static constexpr int LDSB = WB + 2 * INB + FB + PWB;       // 80,256 B
   static constexpr int PKS = 5;                              // K-steps of the P phase (18 positions + 2 zero slots)
+  static constexpr int PWB = PKS * 3 * 1024;                 // prob weights: 15,360 B
+  static constexpr int LDSB = WB + PWB + 2 * INB + 2 * FB1 + SKB;   // 156,160 B
 };
 
-#ifndef CDS_FP_MINW
-#define CDS_FP_MINW 3
-#endif
-__global__ __launch_bounds__(FPCfg::THREADS, CDS_FP_MINW) void deconv_prob_kernel(const float* __restrict__ x, const uint4* __restrict__ wsp,
+__global__ __launch_bounds__(FPCfg::THREADS, 3) void deconv_prob_kernel(const float* __restrict__ x, const uint4* __restrict__ wsp,
                                                                         const float* __restrict__ bias, const float* __restrict__ skip,
                                                                         const uint4* __restrict__ pw, float* __restrict__ out, int Da,
                                                                         int Ha, int Wa, int tiles_x, int tiles_y, int ntiles, int tpw) {
@@ -1435,22 +1437,25 @@ __global__ __launch_bounds__(FPCfg::THREADS, CDS_FP_MINW) void deconv_prob_kerne
   if (tile0 >= tile1) return;
   const int D = 2 * Da, H = 2 * Ha, W = 2 * Wa;
   constexpr int Cin = 16;
-  unsigned char* inb = lds + Cfg::WB;
+  unsigned char* pwb = lds + Cfg::WB;
+  unsigned char* inb = pwb + Cfg::PWB;
   unsigned char* fpl = inb + 2 * Cfg::INB;
+  unsigned char* skb = fpl + 2 * Cfg::FB1;
   {
     uint4* wdst = reinterpret_cast<uint4*>(lds);
     for (int i = tid; i < Cfg::WB / 16; i += Cfg::THREADS) wdst[i] = wsp[i];
-#ifdef CDS_FP_PWLDS
-    uint4* pdst = reinterpret_cast<uint4*>(fpl + Cfg::FB);
+    uint4* pdst = reinterpret_cast<uint4*>(pwb);
     for (int i = tid; i < Cfg::PWB / 16; i += Cfg::THREADS) pdst[i] = pw[i];
-#endif
   }
 
   if (wave >= Cfg::CW) {
     // ============================== staging waves ==============================
     const int ptid = tid - Cfg::CW * 64;
-    constexpr int NP = Cfg::IZ * Cfg::IY * Cfg::IX, PT = Cfg::PW * 64;
+    constexpr int PT = Cfg::PW * 64;
+    constexpr int NP = Cfg::IZ * Cfg::IY * Cfg::IX;
     constexpr int PPT = (NP + PT - 1) / PT;
+    constexpr int NSK = 2 * Cfg::SKH * Cfg::SKW;
+    constexpr int SPT = (NSK + PT - 1) / PT;
     int s_rel[PPT], s_dst[PPT];
 #pragma unroll
     for (int h = 0; h < PPT; ++h) {
@@ -1460,8 +1465,9 @@ __global__ __launch_bounds__(FPCfg::THREADS, CDS_FP_MINW) void deconv_prob_kerne
       s_rel[h] = p < NP ? ((rz << 20) | (ry << 10) | c) : -1;
       s_dst[h] = (row * Cfg::IXP + c) * POSB;
     }
-    float4 va[2][PPT], vb[2][PPT];                      // [round][position]: one tile in flight in registers
-    auto issue = [&](int tile) {
+    float4 va[2][PPT], vb[2][PPT];                      // [round][position]: the input of one tile in flight
+    float4 ka[SPT], kb[SPT];                            // the skip tile of one tile in flight
+    auto issue_in = [&](int tile) {
       SBF_TILE(tile, tx_i, ty_i, az);
       const int gx0 = tx_i * Cfg::CXM - 1, gy0 = ty_i * Cfg::CYM - 1;
 #pragma unroll
@@ -1476,26 +1482,57 @@ __global__ __launch_bounds__(FPCfg::THREADS, CDS_FP_MINW) void deconv_prob_kerne
         }
       }
     };
-    auto deposit = [&](int rd) {
-      unsigned char* base = inb + rd * Cfg::INB;
+    auto deposit_in = [&](int buf) {
 #pragma unroll
-      for (int h = 0; h < PPT; ++h)
-        if (s_rel[h] >= 0) split_store8(base + s_dst[h], va[rd][h], vb[rd][h]);
+      for (int rd = 0; rd < 2; ++rd) {
+        unsigned char* base = inb + buf * Cfg::INB + rd * Cfg::INB1;
+#pragma unroll
+        for (int h = 0; h < PPT; ++h)
+          if (s_rel[h] >= 0) split_store8(base + s_dst[h], va[rd][h], vb[rd][h]);
+      }
     };
-    issue(tile0);
-    deposit(0);
-    deposit(1);
-    if (tile0 + 1 < tile1) issue(tile0 + 1);
-    __syncthreads();                                    // B0: weights + both rounds of the first tile staged
+    auto issue_sk = [&](int tile) {
+      SBF_TILE(tile, tx_i, ty_i, az);
+      const int X0 = tx_i * Cfg::TX, Y0 = ty_i * Cfg::TY;
+#pragma unroll
+      for (int h = 0; h < SPT; ++h) {
+        const int p = h * PT + ptid;
+        const int pz = p / (Cfg::SKH * Cfg::SKW), r = p - pz * (Cfg::SKH * Cfg::SKW);
+        const int ry = r / Cfg::SKW, rx = r - ry * Cfg::SKW;
+        const int gz = 2 * az + pz, gy = Y0 - 1 + ry, gx = X0 - 1 + rx;
+        const bool ok = p < NSK && gz < D && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+        const float* __restrict__ src = skip + ((size_t)((size_t)gz * H + gy) * W + gx) * 8;
+        ka[h] = ok ? *reinterpret_cast<const float4*>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
+        kb[h] = ok ? *reinterpret_cast<const float4*>(src + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    };
+    auto deposit_sk = [&]() {
+#pragma unroll
+      for (int h = 0; h < SPT; ++h) {
+        const int p = h * PT + ptid;
+        if (p < NSK) {
+          float4* d = reinterpret_cast<float4*>(skb + p * 32);
+          d[0] = ka[h];
+          d[1] = kb[h];
+        }
+      }
+    };
+    issue_in(tile0);
+    issue_sk(tile0);
+    deposit_in(0);
+    deposit_sk();
+    if (tile0 + 1 < tile1) {
+      issue_in(tile0 + 1);
+      issue_sk(tile0 + 1);
+    }
+    __syncthreads();                                    // B0: weights, input and skip of the first tile staged
     for (int tile = tile0; tile < tile1; ++tile) {
-      __syncthreads();                                  // B1: round 0 of `tile` consumed
-      if (tile + 1 < tile1) deposit(0);
-      __syncthreads();                                  // B2: round 1 consumed
-      if (tile + 1 < tile1) deposit(1);
-      __syncthreads();                                  // B3
-      if (tile + 2 < tile1) issue(tile + 2);
-      __syncthreads();                                  // B4
-      __syncthreads();                                  // B5
+      if (tile + 1 < tile1) deposit_in((tile + 1 - tile0) & 1);       // during A(tile): the other input buffer
+      if (tile + 2 < tile1) issue_in(tile + 2);
+      __syncthreads();                                  // B1
+      __syncthreads();                                  // B2: E(tile) has read the skip tile
+      if (tile + 1 < tile1) deposit_sk();
+      if (tile + 2 < tile1) issue_sk(tile + 2);
     }
     return;
   }
@@ -1516,166 +1553,101 @@ __global__ __launch_bounds__(FPCfg::THREADS, CDS_FP_MINW) void deconv_prob_kerne
     }
     toff[ks] = off;
   }
-  // column groups of this wave: q = 0 -> cell row cy = wave - 1; q = 1 -> group wave + 4: cell rows 3, 4, then the ring cells
-  // (lane j: cy = (j >> 1) - 1, cx = -1 | 16); wave 3 has no second group (it recomputes its first one, nothing is written)
-  int cyq[2], cxq[2], b_base[2];
-  bool colq[2];                                         // this lane's column carries a cell of the tile
-#pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    const int gi = (q == 0 || wave == 3) ? wave : wave + 4;
-    const bool ring = gi == 6;
-    cyq[q] = ring ? (j < 12 ? (j >> 1) - 1 : -1) : gi - 1;
-    cxq[q] = ring ? ((j & 1) ? Cfg::CXM : -1) : j;
-    colq[q] = (q == 0 || wave != 3) && (!ring || j < 12);
-    b_base[q] = ((cyq[q] + 1) * Cfg::IXP + (cxq[q] + 1)) * POSB;
-  }
+  // phase A / E: wave = column group: cell row cy = wave - 1 (waves 0..5), the ring cells (wave 6: lane j -> cy = (j >> 1) - 1,
+  // cx = -1 | 16), nothing (wave 7)
+  const bool has_group = wave < 7;
+  const bool ring = wave == 6;
+  const int cyq = ring ? (j < 12 ? (j >> 1) - 1 : -1) : wave - 1;
+  const int cxq = ring ? ((j & 1) ? Cfg::CXM : -1) : j;
+  const bool colq = has_group && (!ring || j < 12);
+  const int b_base = has_group ? ((cyq + 1) * Cfg::IXP + (cxq + 1)) * POSB : 0;
   const unsigned char* wlds = lds + lane * 16;
   const int co = 4 * (g & 1), px = g >> 1;              // rows of the transposed-convolution tile = (x parity, cout)
   const float4 bv = bias ? *reinterpret_cast<const float4*>(bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
-  // P phase: lane -> column (quad qd, fine row rr), K-step t multiplies in-plane position s = 4 t + g = (ky, dx)
-  const int qd = j & 7, rr = 2 * wave + (j >> 3);
+  // phase P: wave = unit (plane pzp, row pair): lane -> column (quad qd, fine row rr); K-step t multiplies position s = 4 t + g
+  const int pzp = wave >> 2;
+  const int qd = j & 7, rr = 2 * (wave & 3) + (j >> 3);
   int poff[Cfg::PKS];
 #pragma unroll
   for (int t = 0; t < Cfg::PKS; ++t) {
     const int s = min(4 * t + g, 17);                   // slots 18, 19: zero weights, any valid address
     const int ky = s / 6, dx = s - 6 * ky;
-    poff[t] = ((rr + ky) * Cfg::FW + (dx & 3) * 9 + qd + (dx >> 2)) * POSB;
+    poff[t] = pzp * Cfg::FB1 + ((rr + ky) * Cfg::FW + (dx & 3) * 9 + qd + (dx >> 2)) * POSB;
   }
-  const uint4* __restrict__ pwl = pw + lane;
+  const unsigned char* pwl = pwb + lane * 16;
   const size_t planeHW = (size_t)H * W;
 
-  f32x4 acc[Tab::NCLS][2];
-  float4 skv[Tab::NCLS][2];
   __syncthreads();                                      // B0
   for (int tile = tile0; tile < tile1; ++tile) {
     SBF_TILE(tile, tx_i, ty_i, az);
     const int X0 = tx_i * Cfg::TX, Y0 = ty_i * Cfg::TY;
-    // fine voxel of (group q, class c) on this lane, and whether it lies in the 34 x 10 plane / inside the volume
-    auto fine = [&](int q, int c, int& fy, int& fx, bool& in_tile, bool& in_vol) {
-      fy = 2 * cyq[q] + (c & 1);
-      fx = 2 * cxq[q] + px;
-      in_tile = colq[q] && fy >= -1 && fy <= Cfg::TY && fx >= -1 && fx <= Cfg::TX;
-      const int gy = Y0 + fy, gx = X0 + fx;
-      in_vol = in_tile && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
-    };
+    // ---------------- phase A: transposed convolution of this wave's column group, both rounds ----------------
+    f32x4 acc[Tab::NCLS][1];
 #pragma unroll
-    for (int c = 0; c < Tab::NCLS; ++c)
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        acc[c][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        int fy, fx;
-        bool it, iv;
-        fine(q, c, fy, fx, it, iv);
-        // unconditional load from a clamped (always valid) address: a per-lane `iv ? load : 0` compiles to exec-masked blocks with an
-        // s_waitcnt vmcnt(0) at every join, i.e. eight SERIALISED HBM round trips per tile (measured: 1.3-2.1 ms of the kernel)
-        const int sy = min(max(Y0 + fy, 0), H - 1), sx = min(max(X0 + fx, 0), W - 1);
-        const size_t vox = ((size_t)(2 * az + (c >> 1)) * H + sy) * W + sx;
-#ifdef CDS_FP_NOSKIP
-        skv[c][q] = make_float4(0.f, 0.f, 0.f, 0.f);
-        (void)vox;
-#else
-        skv[c][q] = *reinterpret_cast<const float4*>(skip + vox * 8 + co);
-        (void)iv;
-#endif
-      }
-    // ---------------- phase A: transposed convolution, both rounds ----------------
-#pragma unroll
-    for (int rd = 0; rd < 2; ++rd) {
-      const unsigned char* tbuf = inb + rd * Cfg::INB;
-      const unsigned char* wr = wlds + rd * Tab::NKS * 3 * 1024;
+    for (int c = 0; c < Tab::NCLS; ++c) acc[c][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (has_group) {
+      const unsigned char* tile_in = inb + ((tile - tile0) & 1) * Cfg::INB + b_base;
       BV wa[2][3];
-      BV bd[2][2][3];
-      auto load_w = [&](int buf, int ks) {
-        wa[buf][0].u = *reinterpret_cast<const uint4*>(wr + (ks * 3) * 1024);
-        wa[buf][1].u = *reinterpret_cast<const uint4*>(wr + (ks * 3 + 1) * 1024);
-        wa[buf][2].u = *reinterpret_cast<const uint4*>(wr + (ks * 3 + 2) * 1024);
+      BV bd[2][1][3];
+      auto load_ab = [&](int buf, int s) {               // s = round * NKS + K-step
+        const int rd = s / Tab::NKS, ks = s - rd * Tab::NKS;
+        const unsigned char* wr = wlds + (rd * Tab::NKS + ks) * 3 * 1024;
+        wa[buf][0].u = *reinterpret_cast<const uint4*>(wr);
+        wa[buf][1].u = *reinterpret_cast<const uint4*>(wr + 1024);
+        wa[buf][2].u = *reinterpret_cast<const uint4*>(wr + 2048);
+        const unsigned char* b = tile_in + rd * Cfg::INB1 + toff[ks];
+        bd[buf][0][0].u = *reinterpret_cast<const uint4*>(b);
+        bd[buf][0][1].u = *reinterpret_cast<const uint4*>(b + 16);
+        bd[buf][0][2].u = *reinterpret_cast<const uint4*>(b + 32);
       };
-      auto load_b = [&](int buf, int ks) {
+      load_ab(0, 0);
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          const unsigned char* b = tbuf + b_base[q] + toff[ks];
-          bd[buf][q][0].u = *reinterpret_cast<const uint4*>(b);
-          bd[buf][q][1].u = *reinterpret_cast<const uint4*>(b + 16);
-          bd[buf][q][2].u = *reinterpret_cast<const uint4*>(b + 32);
-        }
-      };
-#ifdef CDS_FP_DIET
-      // register diet (<= 128 VGPRs: four waves per SIMD, so that two 6-wave workgroups are always co-resident): operands
-      // single-buffered, the other waves of the SIMD cover the LDS latency
-#pragma unroll
-      for (int ks = 0; ks < Tab::NKS; ++ks) {
-        const int c = Tab::cls_of(ks);
-        load_b(0, ks);
-        load_w(0, ks);
+      for (int s = 0; s < 2 * Tab::NKS; ++s) {
+        const int c = Tab::cls_of(s % Tab::NKS), cur = s & 1;
+        if (s + 1 < 2 * Tab::NKS) load_ab(cur ^ 1, s + 1);
         __builtin_amdgcn_sched_barrier(0);
-        SBF_TERMS(acc[c], 0, 2, wa[0], bd[0]);
+        SBF_TERMS(acc[c], 0, 1, wa[cur], bd[cur]);
       }
-#else
-      load_w(0, 0);
-      load_b(0, 0);
-#pragma unroll
-      for (int ks = 0; ks < Tab::NKS; ++ks) {
-        const int c = Tab::cls_of(ks), cur = ks & 1;
-        if (ks + 1 < Tab::NKS) {
-          load_b(cur ^ 1, ks + 1);
-          load_w(cur ^ 1, ks + 1);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        SBF_TERMS(acc[c], 0, 2, wa[cur], bd[cur]);
-      }
-#endif
-      __syncthreads();                                  // B1 / B2
     }
+    __syncthreads();                                    // B1: F and the skip tile are free / staged
+    // ---------------- phase E: y = skip + relu(acc + bias), split, into the fine planes ----------------
+    if (has_group) {
 #pragma unroll
-    for (int pz = 0; pz < 2; ++pz) {
-      // ---------------- phase E: y = skip + relu(acc + bias), split, into the fine plane ----------------
-      // prob weights of the P phase: streamed from L1 / L2 two K-steps ahead (all 15 vectors in registers spilled to scratch:
-      // 30 GB of scratch traffic per launch at M1); the first two are requested here, ahead of the barrier
-      BV pwr[2][3];
-#ifdef CDS_FP_PWLDS
-      const uint4* pwo = reinterpret_cast<const uint4*>(fpl + Cfg::FB) + lane;
-#else
-      const uint4* pwo = pwl;
-      asm volatile("" : "+v"(pwo));                     // opaque: keeps the compiler from hoisting the 15 loads out of the tile loop
-#endif
-      auto load_pw = [&](int buf, int t) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) pwr[buf][k].u = pwo[(t * 3 + k) * 64];
-      };
-      load_pw(0, 0);
-      load_pw(1, 1);
-#pragma unroll
-      for (int py = 0; py < 2; ++py) {
-        const int c = 2 * pz + py;
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          int fy, fx;
-          bool it, iv;
-          fine(q, c, fy, fx, it, iv);
-          if (!it) continue;
-          const f32x4 a = acc[c][q];
-          const float4 s4 = skv[c][q];
-          float o0 = fmaxf(a.x + bv.x, 0.f), o1 = fmaxf(a.y + bv.y, 0.f), o2 = fmaxf(a.z + bv.z, 0.f), o3 = fmaxf(a.w + bv.w, 0.f);
-          o0 = iv ? s4.x + o0 : 0.f; o1 = iv ? s4.y + o1 : 0.f; o2 = iv ? s4.z + o2 : 0.f; o3 = iv ? s4.w + o3 : 0.f;
-          uint32_t h0, m0, l0, h1, m1, l1;
-          split2(o0, o1, h0, m0, l0);
-          split2(o2, o3, h1, m1, l1);
-          const int xs = fx + 1;
-          unsigned char* d = fpl + ((fy + 1) * Cfg::FW + (xs & 3) * 9 + (xs >> 2)) * POSB + co * 2;
-          *reinterpret_cast<uint2*>(d) = make_uint2(h0, h1);
-          *reinterpret_cast<uint2*>(d + 16) = make_uint2(m0, m1);
-          *reinterpret_cast<uint2*>(d + 32) = make_uint2(l0, l1);
-        }
+      for (int c = 0; c < Tab::NCLS; ++c) {
+        const int pz = c >> 1;
+        const int fy = 2 * cyq + (c & 1), fx = 2 * cxq + px;
+        const bool in_tile = colq && fy >= -1 && fy <= Cfg::TY && fx >= -1 && fx <= Cfg::TX;
+        if (!in_tile) continue;
+        const int gy = Y0 + fy, gx = X0 + fx;
+        const bool in_vol = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+        const float4 s4 = *reinterpret_cast<const float4*>(skb + ((pz * Cfg::SKH + fy + 1) * Cfg::SKW + fx + 1) * 32 + co * 4);
+        const f32x4 a = acc[c][0];
+        float o0 = fmaxf(a.x + bv.x, 0.f), o1 = fmaxf(a.y + bv.y, 0.f), o2 = fmaxf(a.z + bv.z, 0.f), o3 = fmaxf(a.w + bv.w, 0.f);
+        o0 = in_vol ? s4.x + o0 : 0.f; o1 = in_vol ? s4.y + o1 : 0.f; o2 = in_vol ? s4.z + o2 : 0.f; o3 = in_vol ? s4.w + o3 : 0.f;
+        uint32_t h0, m0, l0, h1, m1, l1;
+        split2(o0, o1, h0, m0, l0);
+        split2(o2, o3, h1, m1, l1);
+        const int xs = fx + 1;
+        unsigned char* d = fpl + pz * Cfg::FB1 + ((fy + 1) * Cfg::FW + (xs & 3) * 9 + (xs >> 2)) * POSB + co * 2;
+        *reinterpret_cast<uint2*>(d) = make_uint2(h0, h1);
+        *reinterpret_cast<uint2*>(d + 16) = make_uint2(m0, m1);
+        *reinterpret_cast<uint2*>(d + 32) = make_uint2(l0, l1);
       }
-      __syncthreads();                                  // B3 / B5: the fine plane is complete
-      // ---------------- phase P: in-plane 3x3 part of the prob layer for plane 2 az + pz ----------------
+    }
+    __syncthreads();                                    // B2: both fine planes complete
+    // ---------------- phase P: in-plane 3x3 part of the prob layer, one (plane, row pair) unit per wave ----------------
+    {
       f32x4 pacc[1] = {(f32x4){0.f, 0.f, 0.f, 0.f}};
-      BV pb[2][1][3];
+      BV pb[2][1][3], pwr[2][3];
       auto load_p = [&](int buf, int t) {
         const unsigned char* b = fpl + poff[t];
         pb[buf][0][0].u = *reinterpret_cast<const uint4*>(b);
         pb[buf][0][1].u = *reinterpret_cast<const uint4*>(b + 16);
         pb[buf][0][2].u = *reinterpret_cast<const uint4*>(b + 32);
+        const unsigned char* wq = pwl + t * 3 * 1024;
+        pwr[buf][0].u = *reinterpret_cast<const uint4*>(wq);
+        pwr[buf][1].u = *reinterpret_cast<const uint4*>(wq + 1024);
+        pwr[buf][2].u = *reinterpret_cast<const uint4*>(wq + 2048);
       };
       load_p(0, 0);
 #pragma unroll
@@ -1683,20 +1655,12 @@ __global__ __launch_bounds__(FPCfg::THREADS, CDS_FP_MINW) void deconv_prob_kerne
         if (t + 1 < Cfg::PKS) load_p((t & 1) ^ 1, t + 1);
         __builtin_amdgcn_sched_barrier(0);
         SBF_TERMS(pacc, 0, 1, pwr[t & 1], pb[t & 1]);
-        if (t + 2 < Cfg::PKS) load_pw(t & 1, t + 2);
       }
-      {
-        const int gz = 2 * az + pz, gy = Y0 + rr, gx = X0 + 4 * qd;
-#ifdef CDS_FP_NOSTORE
-        if (g < 3 && gy < H && gx < W && pacc[0].x == 1234.5f) {
-#else
-        if (g < 3 && gy < H && gx < W) {
-#endif
-          float* po = out + ((size_t)g * D + gz) * planeHW + (size_t)gy * W + gx;
-          sbf_store4(po, make_float4(pacc[0].x, pacc[0].y, pacc[0].z, pacc[0].w));
-        }
+      const int gz = 2 * az + pzp, gy = Y0 + rr, gx = X0 + 4 * qd;
+      if (g < 3 && gy < H && gx < W) {
+        float* po = out + ((size_t)g * D + gz) * planeHW + (size_t)gy * W + gx;
+        sbf_store4(po, make_float4(pacc[0].x, pacc[0].y, pacc[0].z, pacc[0].w));
       }
-      if (pz == 0) __syncthreads();                     // B4: the fine plane may be overwritten
     }
   }
 }
@@ -1707,7 +1671,7 @@ int launch_deconv_prob(const float* x, const void* wsp, const float* b, const fl
   const int tx = cds_ceil_div(2 * Wa, Cfg::TX), ty = cds_ceil_div(2 * Ha, Cfg::TY);
   const int ntiles = tx * ty * Da;
   static const int tpw_env = []() { const char* e = getenv("CDS_FP_TPW"); return e ? atoi(e) : 0; }();   // A/B knob
-  int tpw = tpw_env > 0 ? tpw_env : max(1, min(16, ntiles / (256 * 2 * 6)));
+  int tpw = tpw_env > 0 ? tpw_env : max(1, min(32, ntiles / (256 * 6)));
   const int nwg = cds_ceil_div(ntiles, tpw);
   static std::atomic<unsigned long long> lds_ok{0};
   if (int e_lds = cds_allow_lds(reinterpret_cast<const void*>(deconv_prob_kernel), Cfg::LDSB, lds_ok)) return e_lds;
