@@ -127,8 +127,10 @@ def _two_rank_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_shard_views_two_ranks_on_one_device():
-    world = 2
+@pytest.mark.parametrize("world", [2, 3])
+def test_shard_views_two_ranks_on_one_device(world):
+    """world 2: views {0, 2} | {1}; world 3: one view per rank and UNEVEN row slabs (stage 1 has 32 rows = 4 groups of 8 over 3 ranks:
+    16 + 8 + 8; a rank's coarsest CostRegNet level then holds a single row)."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -139,7 +141,10 @@ def test_shard_views_two_ranks_on_one_device():
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
-    assert res[0]["allreduce_views"] == [0, 2] and res[1]["allreduce_views"] == [1]
+    if world == 2:
+        assert res[0]["allreduce_views"] == [0, 2] and res[1]["allreduce_views"] == [1]
+    else:
+        assert [res[r]["allreduce_views"] for r in range(3)] == [[0], [1], [2]]
     for r in range(world):
         for exchange in ("allreduce", "p2p", "reduce_scatter", "slab"):
             assert res[r][exchange + "_n"] == 3                     # ONE volume exchange per cascade stage
