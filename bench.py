@@ -208,13 +208,17 @@ def cpu_baseline(model_cpu, name, budget_frac, seed=0, gpu_depth=None):
     stage = {8: 2, 16: 1, 32: 0}[C]
     with torch.no_grad():
         O.stage_forward(feats, cams, hyp[:, :8], sd, stage, exact=False)  # warm-up (thread pool, oneDNN primitives)
-        t0 = time.time()
-        ref = O.stage_forward(feats, cams, hyp, sd, stage, exact=False)
-        dt = time.time() - t0
+        times = []
+        for _ in range(2):                              # two timed runs (~18 s each on 64 cores): the faster one is the baseline
+            t0 = time.time()
+            ref = O.stage_forward(feats, cams, hyp, sd, stage, exact=False)
+            times.append(time.time() - t0)
+        dt = min(times)
     frac = (hs * ws) / float(h * w)
     what = "full size" if frac == 1.0 else f"window {ws}x{hs} of {w}x{h} ({frac:.4f} of the pixels, linear extrapolation)"
     out = {"value": frac / dt, "unit": "depth-maps/s", "cores": cores, "kind": "port",
-           "sample": f"{name} {what}, D={D}, C={C}, N={n_views}, 1 run, {dt:.2f} s of torch-CPU oracle (F.grid_sample path)"}
+           "sample": f"{name} {what}, D={D}, C={C}, N={n_views}, best of 2 runs ({times[0]:.2f} s, {times[1]:.2f} s) of the torch-CPU "
+                     f"oracle (F.grid_sample path)", "run_seconds": [round(t, 2) for t in times]}
     if gpu_depth is not None and frac == 1.0:
         dcpu = ref["depth"].reshape(h, w).float()
         dgpu = gpu_depth.reshape(h, w).float().cpu()
