@@ -857,7 +857,10 @@ struct DCfg {
 #define CDS_DECONV_SBF_MINW 2   // minimum waves per SIMD of the Cout = 8 (memory-bound) variant: A/B build knob
 #endif
 template <bool MERGE, int MB>
-__global__ __launch_bounds__(256, (MERGE ? CDS_DECONV_SBF_MINW : 2)) void deconv3d_sbf_kernel(const float* __restrict__ x, const uint4* __restrict__ wsp,
+#ifndef CDS_DECONV_NM_MINW
+#define CDS_DECONV_NM_MINW 2   // waves per SIMD of the Cout = 16 / 32 variants (A/B build knob)
+#endif
+__global__ __launch_bounds__(256, (MERGE ? CDS_DECONV_SBF_MINW : (MB == 1 ? CDS_DECONV_NM_MINW : 2))) void deconv3d_sbf_kernel(const float* __restrict__ x, const uint4* __restrict__ wsp,
                                                               const float* __restrict__ bias, const float* __restrict__ skip,
                                                               float* __restrict__ out, int Cin, int Cout, int D, int H, int W,
                                                               int act, int out_planar, int tiles_x, int tiles_y, int ntiles,
