@@ -792,15 +792,15 @@ bool cds_warp_aggregate_lds_launch(const float* ref, const float* src, const flo
   if ((C != 8 && C != 16 && C != 32) || V < 1 || V > CDS_MAX_VIEWS || !hyp_pp || w < 2 || hs < 2 || h < 1 || y_off < 0 ||
       y_off + h > hs || (size_t)D * h * w * 4 >= ((size_t)1 << 32))
     return false;
-  // 5 / 6 source views (BASELINE config 4, N = 7) run in ONE pass with a smaller box budget per view (CAP6 texels: 6 views =
-  // 75 KB, still two workgroups per CU; a footprint that does not fit halves its chunk as usual).  CDS_K3_SPLIT_VIEWS=1 keeps
-  // the round-2 behaviour for the A/B: two launches over halves of the view list, the second re-reading the partial volume.
-  // Measured at the config-4 stage shapes (7 views, one MI355X, same box): 960x528 D=32 C=16 1.12 ms in one pass vs 1.52 ms split;
-  // 480x264 D=48 C=32 2.73 vs 1.43 (48-plane chunks overflow the smaller boxes and are halved twice); 1920x1056 D=8 C=8 0.93 vs
-  // 0.90 (the 6-view kernel spills in its plane loop; the volume it saves re-reading is small).  Hence: one pass for the 16-channel
-  // stages with <= 32 planes, split otherwise.  CDS_K3_SPLIT_VIEWS=1 / 0 forces either.
+  // 5 / 6 source views (BASELINE config 4, N = 7) CAN run in one pass with a smaller box budget per view (CAP6 texels: 6 views = 75 KB,
+  // still two workgroups per CU; a footprint that does not fit halves its chunk).  Measured at the config-4 stage shapes with the
+  // cascade's real hypothesis ranges (7 views, same box, one pass vs two launches with a re-read of the partial volume): 960x528 D=32 C=16
+  // 1.78 vs 1.58 ms; 1920x1056 D=8 C=8 2.16 vs 0.99 ms; 480x264 D=48 C=32 2.68 vs 1.44 ms -- the smaller boxes overflow, the 6-view
+  // kernel spills in its plane loop, and the volume it saves re-reading is cheap.  (A first A/B with narrower ranges had the 16-channel
+  // stage at 1.12 vs 1.52 ms and shipped a heuristic for a few hours; the cascade bench caught it: 28.7 -> 30.0 ms at config 4.)
+  // Two launches stay the rule; CDS_K3_SPLIT_VIEWS=0 selects the single pass for experiments.
   static const int split_env = []() { const char* e = getenv("CDS_K3_SPLIT_VIEWS"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
-  const bool one_pass = V <= 6 && (split_env == 0 || (split_env < 0 && C >= 16 && D <= 32));
+  const bool one_pass = V <= 6 && split_env == 0;
   if (V > 4 && !one_pass) {
     // more views than fit the LDS budget: two launches over halves of the view list; the second adds to the first's
     // partial sums (and normalises).  Costs one extra read of the volume, still far cheaper than L1 gathers.

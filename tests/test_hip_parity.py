@@ -391,12 +391,11 @@ def _random_stage(ops, dev, V, C, D, h, w, seed, sharp=True):
                                        # C = 8 with 2 / 3 views: the LDS kernels are specialised per view count; D = 70
                                        # spans three chunks (32 + 32 + 6) and an odd plane pair at the end
                                        (2, 8, 70, 11, 67), (3, 8, 35, 6, 129),
-                                       # 5 / 6 views: one pass with the smaller per-view boxes (BASELINE config 4, N = 7);
-                                       # 7 views: two launches, the second accumulating onto the first
+                                       # 5 - 7 views (BASELINE config 4: N = 7): two launches, the second accumulating onto the first
                                        (5, 8, 50, 20, 90), (6, 32, 10, 16, 40), (6, 16, 49, 24, 72), (7, 8, 12, 12, 70)])
 @pytest.mark.parametrize("exact", POSITION_MODES)
 def test_warp_kernels_vs_oracle_odd_shapes(V, C, D, h, w, exact, dev, ops):
-    """Odd D / widths that are not tile multiples / V = 1, 6 (one pass with the smaller 6-view boxes) / C = 16, 32 / tiny
+    """Odd D / widths that are not tile multiples / V = 1, 5, 6, 7 (more than 4: two launches) / C = 16, 32 / tiny
     images: K1 and K3 against the CPU oracle (explicit fp32 gather), both position modes."""
     from oracle import cds_oracle as O
     feats, cams, hyp, ref, src, mats, hyp_d = _random_stage(ops, dev, V, C, D, h, w, seed=40 + V + C)
@@ -462,6 +461,29 @@ def test_warp_paths_agree_lds_vs_direct(dev, ops):
         outs.append(torch.load(path))
     assert (outs[0][0] - outs[1][0]).abs().max() < 2e-5
     assert (outs[0][1] - outs[1][1]).abs().max() < 2e-6
+
+
+def test_k3_single_pass_six_views_equals_two_launches(dev, ops):
+    """The experiment form of K3 for 5 / 6 views (CDS_K3_SPLIT_VIEWS=0: all views resident with 392-texel boxes, one pass) against the
+    shipped two-launch form: same arithmetic per view, the sums differ by fp32 re-association only."""
+    import os, subprocess, sys
+    code = ("import torch,sys; sys.path.insert(0,'.'); from cds_mvsnet_amd import ops, synth, geometry;"
+            "dev=torch.device('cuda:0'); V,C,D,h,w=6,16,20,48,136;"
+            "f=synth.make_pair_features(V,C,h,w,seed=9,sharp=True); cams=synth.stage_cameras(V+1,h,w,seed=8);"
+            "hyp=synth.make_hypotheses(D,h,w,seed=7)[0].to(dev);"
+            "ref=torch.stack([x['ref'][0][0] for x in f]).to(dev).contiguous();"
+            "src=torch.stack([ops.chw_to_hwc(x['src'][0][0].to(dev).contiguous()) for x in f]);"
+            "vis=torch.rand(V,h,w,generator=torch.Generator().manual_seed(3)).to(dev);"
+            "m=geometry.warp_matrices(cams[0]); v,s=ops.warp_aggregate(ref,src,vis,m,hyp,channels_last=True);"
+            "torch.save((v.cpu(),s.cpu()), sys.argv[1])")
+    outs = []
+    for flag in ("0", "1"):
+        path = f"/tmp/cds_split_{flag}.pt"
+        env = dict(os.environ, CDS_K3_SPLIT_VIEWS=flag)
+        subprocess.run([sys.executable, "-c", code, path], check=True, env=env, cwd=os.path.dirname(os.path.dirname(__file__)))
+        outs.append(torch.load(path))
+    assert (outs[0][0] - outs[1][0]).abs().max() < 2e-6
+    assert torch.equal(outs[0][1], outs[1][1])
 
 
 def test_per_plane_hypotheses_equal_broadcast(dev, ops):
