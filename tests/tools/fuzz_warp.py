@@ -29,6 +29,18 @@ def one_case(rng, dev, verbose=True):
         want += (in_prod * vis[v].view(1, 1, 1, h, w))[0]
     want = want / (vis.sum(0).view(1, 1, h, w) + 1e-6)
     err = float((vol.cpu() - want).abs().max())
+    # row windows (pixel-slab sharding): any window of rows must reproduce the full-grid rows bit for bit, both layouts
+    if w >= 2 and h >= 2:
+        y0 = rng.randint(0, h - 1); y1 = rng.randint(y0 + 1, h)
+        cl = rng.random() < 0.5
+        full, _ = ops.warp_aggregate(ref, src, vis.to(dev), mats, hyp_d, channels_last=cl)
+        ent_w = ops.warp_entropy(ref[:, :, y0:y1].contiguous(), src, mats, hyp_d[:, y0:y1].contiguous(), window=(h, y0))
+        vol_w, _ = ops.warp_aggregate(ref[:, :, y0:y1].contiguous(), src, vis[:, y0:y1].to(dev).contiguous(), mats,
+                                      hyp_d[:, y0:y1].contiguous(), channels_last=cl, window=(h, y0))
+        same = torch.equal(ent_w.cpu(), ent[:, y0:y1]) and torch.equal(vol_w, full[:, y0:y1] if cl else full[:, :, y0:y1])
+        if not same:
+            print(f"   WINDOW MISMATCH rows [{y0},{y1}) of {h}, cl={cl}  <-- FAIL")
+            err = max(err, 1.0)
     if verbose:
         flag = "" if (err < 2e-5 and e_max < 5e-5) else "  <-- FAIL"
         print(f"V={V} C={C:2d} D={D:3d} h={h:3d} w={w:3d} base={base[0]:5.0f} jitter={jit:4.0f}: vol {err:.2e} ent {e_max:.2e}{flag}")
