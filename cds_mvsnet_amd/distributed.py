@@ -34,7 +34,7 @@ import torch
 import torch.distributed as dist
 
 from . import geometry, ops
-from .slab import HaloComm, HipCostRegLayers, slab_cost_regularization, slab_rows
+from .slab import HaloComm, HipCostRegLayers, slab_cost_regularization, slab_rows, slab_window
 
 Tensor = torch.Tensor
 
@@ -135,12 +135,14 @@ class ViewShard:
         return dist.get_global_rank(self.group, group_rank) if self.group is not None else group_rank
 
     def reduce_scatter_rows(self, vol_cl: Tensor, vis_sum: Tensor, nc_sum: Tensor, rows):
-        """SUM over ranks, scattered by rows: returns this rank's rows of (volume [D][n][w][C], vis_sum [n][w], nc_sum [n][w]).
+        """SUM over ranks, scattered by rows: returns this rank's WINDOW rows (own rows + 8 halo rows each side, `slab.slab_window`) of
+        (volume [D][m][w][C], vis_sum [m][w], nc_sum [m][w]).
         Point-to-point: rank r sends rows [a_j, b_j) of its partial sums to every rank j (packed into one message per peer)
         and adds the world-1 messages it receives in rank order.  (world-1)/world of the buffer leaves each rank, once."""
         self.exchanges += 1
         W, me = self.world, self.rank
         D, h, w, C = vol_cl.shape
+        rows = [slab_window(ra, rb, h) if rb > ra else (ra, rb) for ra, rb in rows]     # own rows + the 8-row halo the slab network reads
         a, b = rows[me]
 
         def pack(ra, rb):
@@ -182,15 +184,16 @@ class ViewShard:
         comm = HaloComm(self.group, rows)
         out = torch.zeros((3, h, w), dtype=hyp.dtype, device=hyp.device)
         if b > a:
+            lo, _ = slab_window(a, b, h)
             vol_r = vol_r.contiguous()
             self._normalize_rows(vol_r, vis_r.contiguous())
             if self.keep_volume:
-                self.last_volume = vol_r.permute(3, 0, 1, 2)
-            prob_pre = slab_cost_regularization(self.layers_factory(model.cost_regularization[stage_idx]), comm, vol_r)
-            depth, conf = self._regress_rows(prob_pre, hyp[:, a:b].contiguous())
-            out[0, a:b], out[1, a:b], out[2, a:b] = depth, conf, nc_r / n_src_total
+                self.last_volume = vol_r[:, a - lo:b - lo].permute(3, 0, 1, 2)
+            prob_pre = slab_cost_regularization(self.layers_factory(model.cost_regularization[stage_idx]), comm, vol_r, a, b, h)
+            depth, conf = self._regress_rows(prob_pre.contiguous(), hyp[:, a:b].contiguous())
+            out[0, a:b], out[1, a:b], out[2, a:b] = depth, conf, nc_r[a - lo:b - lo] / n_src_total
         else:
-            slab_cost_regularization(None, comm, vol_r)
+            slab_cost_regularization(None, comm, vol_r, a, b, h)
         self.halo_exchanges += comm.exchanges
         self.halo_bytes += comm.bytes_sent
         with ops.prof("gather_rows"):
@@ -263,15 +266,20 @@ class ViewShard:
             # K1 + visibility CNN on the rows plus a margin of one 8-row tile (the three 3x3 layers look 3 px sideways)
             a1, b1 = max(0, a - 8), min(h, b + 8)
             ent = self._warp_entropy_rows(ref[:, :, a1:b1].contiguous(), src, mats, hyp[:, a1:b1].contiguous(), (h, a1))
-            vis = self._visibility_rows(model, ent, ref_nc[:, a1:b1].contiguous(), stage_idx)[:, a - a1:b - a1].contiguous()
-            vol = self._warp_aggregate_rows(ref[:, :, a:b].contiguous(), src, vis, mats, hyp[:, a:b].contiguous(), (h, a))
+            # the visibility weight is exact on the rows [a1 + 3, b1 - 3) (three 3x3 layers): the own rows need a margin of >= 3, the
+            # slab window's halo rows [lo, hi) are only read by conv0 of the halo rows themselves ... which are discarded: the
+            # weights there may be the window-edge approximation
+            vis_w = self._visibility_rows(model, ent, ref_nc[:, a1:b1].contiguous(), stage_idx)
+            lo, hi = slab_window(a, b, h)                   # = (a1, b1): K3 sweeps the slab network's halo rows as well
+            vol = self._warp_aggregate_rows(ref[:, :, lo:hi].contiguous(), src, vis_w[:, lo - a1:hi - a1].contiguous(), mats,
+                                            hyp[:, lo:hi].contiguous(), (h, lo))
             if self.keep_volume:
-                self.last_volume = vol.permute(3, 0, 1, 2)
-            prob_pre = slab_cost_regularization(self.layers_factory(model.cost_regularization[stage_idx]), comm, vol)
-            depth, conf = self._regress_rows(prob_pre, hyp[:, a:b].contiguous())
+                self.last_volume = vol[:, a - lo:b - lo].permute(3, 0, 1, 2)
+            prob_pre = slab_cost_regularization(self.layers_factory(model.cost_regularization[stage_idx]), comm, vol, a, b, h)
+            depth, conf = self._regress_rows(prob_pre.contiguous(), hyp[:, a:b].contiguous())
             out[0, a:b], out[1, a:b], out[2, a:b] = depth, conf, nc_sums[:, a:b].sum(dim=0) / n_src_total
         else:
-            slab_cost_regularization(None, comm, hyp.new_zeros((D, 0, w, 1)))
+            slab_cost_regularization(None, comm, hyp.new_zeros((D, 0, w, 1)), a, b, h)
         self.halo_exchanges += comm.exchanges
         self.halo_bytes += comm.bytes_sent
         with ops.prof("gather_rows"):

@@ -17,6 +17,10 @@ so a slab owns whole rows at every level L = 0..3: rows [a / 2^L, b / 2^L).  Wha
   transposed convolution k3 s2 p1 op1 (conv7/9/11): fine row r reads coarse rows (r-1)/2 .. (r+1)/2: ONE coarse row below, none
         above; the U-Net skip rows are the rank's own.
 
+Buffers (round 3, second form): the first version rebuilt every layer's input with ``torch.cat`` (own rows + halo rows): at two ranks the
+copies doubled the slab CostRegNet (6.8 vs 3.5 ms at 256 rows of the M1 volume).  Now every level-L activation is ONE dense buffer with
+8 >> L halo rows on each side (`slab_cost_regularization`), layers run on whole buffers and an exchanged row is written in place.
+
 The layer arithmetic itself is not in this file: `layers` is any object with conv / deconv / prob methods on dense channels-last
 tensors (product: `HipCostRegLayers`, the split-bf16 matrix-core kernels; the CPU tests plug in torch reference ops to check the
 slab bookkeeping and the exchanges against the unsharded network over gloo).
@@ -112,80 +116,78 @@ class HaloComm:
         return recv_top, recv_bot
 
 
-def _with_halo(own: Tensor, row_dim: int, above: List[Optional[Tensor]], below: List[Optional[Tensor]]) -> Tensor:
-    """Dense tensor [above rows ..., own rows, below rows ...]; None entries are dropped."""
-    parts = [t for t in above if t is not None] + [own] + [t for t in below if t is not None]
-    return parts[0].contiguous() if len(parts) == 1 else torch.cat(parts, dim=row_dim)
+HALO0 = 8     # rows of halo of a level-0 slab buffer; level L carries HALO0 >> L (8, 4, 2, 1)
 
 
-def slab_cost_regularization(layers, comm: HaloComm, vol: Tensor) -> Tensor:
-    """CostRegNet on this rank's rows.  vol: [D][n][w][C] channels-last, the rank's own rows of the normalised volume.
-    Returns prob_pre for the same rows, [D][n][w].  `layers`:
-        conv(name, x [D][R][W][Cin], stride) -> [Do][Ro][Wo][Cout]            (BN folded, ReLU; zero padding 1)
-        deconv(name, x [D][R][W][Cin], skip [2D][2R][2W][Cout]) -> same shape as skip, plus `planar` = True for a
-                                                                  [Cout][2D][2R][2W] result (conv11 feeds the planar prob kernel)
-        prob(x) -> [D][R][W]                                                   (x in the layout deconv('conv11') returned)
-        prob_row_dim: the row dimension of that layout (1 channels-last, 2 planar)."""
-    n = vol.shape[1]
+def slab_window(a: int, b: int, h: int) -> Tuple[int, int]:
+    """Rows [lo, hi) of the level-0 buffer of a slab [a, b): HALO0 rows beyond each side, clipped at the grid border."""
+    return max(0, a - HALO0), min(h, b + HALO0)
 
-    def zeros_row(t: Tensor, row_dim: int) -> Tensor:
-        shape = list(t.shape)
-        shape[row_dim] = 1
-        return torch.zeros(shape, dtype=t.dtype, device=t.device)
 
-    def conv_s1(name: str, own: Tensor) -> Tensor:
-        top, bot = comm.exchange(own, 1, True, True)
-        x = _with_halo(own, 1, [top], [bot])
-        y = layers.conv(name, x, 1)
-        t = 0 if top is None else 1
-        return y[:, t:t + own.shape[1]]
+def slab_cost_regularization(layers, comm: HaloComm, vol: Tensor, a: int, b: int, h: int) -> Tensor:
+    """CostRegNet on this rank's rows [a, b) of an h-row grid, WITHOUT copying activations.
 
-    def conv_s2(name: str, own: Tensor) -> Tensor:
-        top, _ = comm.exchange(own, 1, True, False)
-        # the local tensor must start at an even global row: [zero row, row above, own rows]
-        x = _with_halo(own, 1, [zeros_row(own, 1), top] if top is not None else [], [])
-        y = layers.conv(name, x, 2)
-        t = 0 if top is None else 1
-        return y[:, t:t + own.shape[1] // 2]
-
-    def deconv(name: str, own: Tensor, skip_own: Tensor, planar: bool = False) -> Tensor:
-        _, bot = comm.exchange(own, 1, False, True)
-        x = _with_halo(own, 1, [], [bot])
-        skip = skip_own.contiguous()
-        if bot is not None:     # two more (discarded) output rows: pad the skip tensor to the kernel's output shape
-            pad = torch.zeros((skip.shape[0], 2, skip.shape[2], skip.shape[3]), dtype=skip.dtype, device=skip.device)
-            skip = torch.cat((skip, pad), dim=1)
-        y = layers.deconv(name, x, skip, planar)
-        rows = 2 * own.shape[1]
-        return y[:, :, :rows] if planar else y[:, :rows]
-
+    vol: [D][hi - lo][w][C] channels-last, the rows ``slab_window(a, b, h)`` of the normalised volume -- every row of it VALID (the
+    plane sweep is per pixel: the rank computes / receives its 8 halo rows itself).  Every activation of level L lives in one dense
+    buffer that covers the rows [a_L - H_L, b_L + H_L) with H_L = 8 >> L (clipped at the grid border), which makes every layer a plain
+    dense call on whole buffers: a stride-1 layer keeps the rows, a stride-2 layer maps a level-L buffer onto exactly the level-(L+1)
+    buffer (it starts at an even global row), a transposed layer maps it back and its skip tensor IS the level-L buffer.  Only the own
+    rows (and, for the input volume, the halo) of a buffer are valid; what a layer needs beyond them -- ONE row -- is fetched from the
+    neighbour and written over the garbage row in place (`HaloComm.exchange`, 11 per stage); garbage further out only ever feeds rows
+    that are overwritten or discarded.  Redundant arithmetic: 16 rows per slab (1.25x at 64 rows), no `torch.cat`.
+    Returns prob_pre for the rows [a, b): [D][b - a][w] (a view).  `layers`: conv / deconv / prob on dense channels-last tensors
+    (product: `HipCostRegLayers`; the CPU tests plug in torch reference ops)."""
+    n = b - a
     if not comm.active or n == 0:
-        # a rank without rows still takes part in nothing: the exchanges are between active neighbours only
         for _ in range(11):
             comm.exchanges += 1
         return vol.new_zeros((vol.shape[0], 0, vol.shape[2]))
-    c0 = conv_s1("conv0", vol)
-    c1 = conv_s2("conv1", c0)
-    c2 = conv_s1("conv2", c1)
+    top = [HALO0 >> L if a > 0 else 0 for L in range(4)]            # halo rows above / below the own rows, per level
+    bot = [HALO0 >> L if b < h else 0 for L in range(4)]
+    own = [n >> L for L in range(4)]
+    if vol.shape[1] != top[0] + n + bot[0]:
+        raise ValueError(f"slab volume has {vol.shape[1]} rows, expected the window {slab_window(a, b, h)}")
+
+    def refresh(buf: Tensor, L: int, row_dim: int, need_top: bool, need_bot: bool) -> None:
+        """Overwrite the row just above / below the own rows of a level-L buffer with the neighbour's edge row."""
+        t, m = top[L], own[L]
+        view = buf.narrow(row_dim, t, m)
+        r_top, r_bot = comm.exchange(view, row_dim, need_top, need_bot)
+        if r_top is not None:
+            buf.narrow(row_dim, t - 1, 1).copy_(r_top)
+        if r_bot is not None:
+            buf.narrow(row_dim, t + m, 1).copy_(r_bot)
+
+    comm.exchanges += 1                                   # conv0's halo rows are valid already: no message (counted as a no-op)
+    c0 = layers.conv("conv0", vol, 1)
+    refresh(c0, 0, 1, True, False)                        # conv1 (stride 2) reads one row above
+    c1 = layers.conv("conv1", c0, 2)
+    refresh(c1, 1, 1, True, True)
+    c2 = layers.conv("conv2", c1, 1)
     del c1
-    c3 = conv_s2("conv3", c2)
-    c4 = conv_s1("conv4", c3)
+    refresh(c2, 1, 1, True, False)
+    c3 = layers.conv("conv3", c2, 2)
+    refresh(c3, 2, 1, True, True)
+    c4 = layers.conv("conv4", c3, 1)
     del c3
-    c5 = conv_s2("conv5", c4)
-    x = conv_s1("conv6", c5)
+    refresh(c4, 2, 1, True, False)
+    c5 = layers.conv("conv5", c4, 2)
+    refresh(c5, 3, 1, True, True)
+    x = layers.conv("conv6", c5, 1)
     del c5
-    x = deconv("conv7", x, c4)
+    refresh(x, 3, 1, False, True)                         # a transposed layer reads one coarse row below
+    x = layers.deconv("conv7", x, c4, False)
     del c4
-    x = deconv("conv9", x, c2)
+    refresh(x, 2, 1, False, True)
+    x = layers.deconv("conv9", x, c2, False)
     del c2
+    refresh(x, 1, 1, False, True)
     planar = bool(getattr(layers, "conv11_planar", False))
-    x = deconv("conv11", x, c0, planar)
+    x = layers.deconv("conv11", x, c0, planar)
     del c0
-    rd = 2 if planar else 1
-    top, bot = comm.exchange(x, rd, True, True)
-    y = layers.prob(_with_halo(x, rd, [top], [bot]))
-    t = 0 if top is None else 1
-    return y[:, t:t + n].contiguous()
+    refresh(x, 0, 2 if planar else 1, True, True)
+    y = layers.prob(x)
+    return y[:, top[0]:top[0] + n]
 
 
 class HipCostRegLayers:

@@ -41,3 +41,27 @@ with torch.no_grad():
         pre = cr(volh, channels_last=True)
         t_s = t(lambda: ops.softargmin_conf(pre[:, :rows].contiguous(), hyp_d[:, a:b].contiguous()))
         print(f"N={N}: rows {rows}: K1+vis+K3 on the window {t_w:.3f} ms | CostRegNet on {volh.shape[1]} rows {t_c:.3f} ms | soft-argmin {t_s:.3f} ms | sum {t_w + t_c + t_s:.3f} ms")
+
+# the slab CostRegNet as the product runs it (level buffers with 8 >> L halo rows, exchanged rows written in place), with a stand-in
+# communicator that hands back zero rows: the per-rank compute INCLUDING the halo bookkeeping
+from cds_mvsnet_amd.slab import HipCostRegLayers, slab_cost_regularization, slab_window
+class FakeComm:
+    active = True
+    exchanges = 0
+    bytes_sent = 0
+    def __init__(self, top, bottom): self.t, self.b = top, bottom
+    def exchange(self, own, row_dim, top, bottom):
+        self.exchanges += 1
+        shape = list(own.shape); shape[row_dim] = 1
+        z = torch.zeros(shape, dtype=own.dtype, device=own.device)
+        return (z if (top and self.t) else None), (z if (bottom and self.b) else None)
+with torch.no_grad():
+    layers = HipCostRegLayers(cr)
+    for N in (1, 2, 4, 8):
+        rows = h // N
+        a = (h - rows) // 2 // 8 * 8; b = a + rows
+        lo, hi = slab_window(a, b, h)
+        vol = torch.randn(D, hi - lo, w, C, device=dev)
+        comm = FakeComm(a > 0, b < h)
+        t_c = t(lambda: slab_cost_regularization(layers, comm, vol, a, b, h))
+        print(f"N={N}: slab_cost_regularization on rows [{a},{b}) (buffer {hi - lo} rows, halo rows written in place): {t_c:.3f} ms")

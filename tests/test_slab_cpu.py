@@ -75,7 +75,7 @@ def _worker(rank, world, port, q, case):
         sys.path.insert(0, ROOT)
         from cds_mvsnet_amd import CostRegNet, seeded_init_
         from cds_mvsnet_amd.distributed import ViewShard
-        from cds_mvsnet_amd.slab import HaloComm, slab_cost_regularization, slab_rows
+        from cds_mvsnet_amd.slab import HaloComm, slab_cost_regularization, slab_rows, slab_window
         torch.set_num_threads(1)
         C, D, h, w, V = case
         cr = seeded_init_(CostRegNet(C, 8), 3).eval()
@@ -93,7 +93,12 @@ def _worker(rank, world, port, q, case):
         rows = slab_rows(h, world)
         a, b = rows[rank]
         comm = HaloComm(None, rows)
-        got = slab_cost_regularization(layers if b > a else None, comm, vol_full[:, a:b].contiguous())
+        lo, hi = slab_window(a, b, h)
+        vol_win = vol_full[:, lo:hi].clone()
+        if b > a:                 # only the rows a - 1 .. b of the window have to be valid: poison the rest of the halo
+            vol_win[:, :max(0, a - 1 - lo)] = float("nan")
+            vol_win[:, b + 1 - lo:] = float("nan")
+        got = slab_cost_regularization(layers if b > a else None, comm, vol_win, a, b, h)
         err_pre = (got - want_pre[:, a:b]).abs().max().item() if b > a else 0.0
         assert comm.exchanges == 11
         # ---- (2) the product's reduce_scatter stage: view shard -> rows -> slab CostRegNet -> regression -> gather ----
@@ -112,7 +117,9 @@ def _worker(rank, world, port, q, case):
         err_depth = (depth.double() - want_depth).abs().max().item()
         err_conf = (conf.double() - want_conf).abs().max().item()
         err_nc = (ncm.double() - nc.sum(0) / V).abs().max().item()
-        q.put((rank, err_pre, err_depth, err_conf, err_nc, sh.exchanges, sh.halo_exchanges, sh.exchanged_bytes, b - a))
+        expect_sent = sum((slab_window(ra, rb, h)[1] - slab_window(ra, rb, h)[0]) for r, (ra, rb) in enumerate(rows) if r != rank and rb > ra)
+        q.put((rank, err_pre, err_depth, err_conf, err_nc, sh.exchanges, sh.halo_exchanges, sh.exchanged_bytes, b - a,
+               expect_sent * (D * w * C + 2 * w) * 8))
     finally:
         dist.destroy_process_group()
 
@@ -134,12 +141,12 @@ def test_slab_costreg_and_reduce_scatter_equal_unsharded(world, case):
         assert p.exitcode == 0
     C, D, h, w, V = case
     assert sum(r[8] for r in res) == h
-    for rank, err_pre, err_depth, err_conf, err_nc, nx, nhalo, sent, n in res:
+    for rank, err_pre, err_depth, err_conf, err_nc, nx, nhalo, sent, n, expect_sent in res:
         assert err_pre < 1e-10, (rank, err_pre)            # float64: the slab network IS the unsharded network
         assert err_depth < 1e-8 and err_conf < 1e-10 and err_nc < 1e-12, (rank, err_depth, err_conf, err_nc)
         assert nx == 1 and nhalo == 11                     # one volume exchange + 11 one-row halo exchanges per stage
-        # exactly the rows a rank does not own leave it, once ((world-1)/world of the partial sums for an even partition)
-        assert sent == (D * w * C + 2 * w) * (h - n) * 8 * (1 if world > 1 else 0)
+        # what leaves a rank, once: every other rank's rows plus the 8 halo rows per side its slab network is laid out on
+        assert sent == expect_sent
 
 
 def test_slab_rows_partition():
@@ -269,5 +276,5 @@ def test_pixel_slab_stage_equals_oracle(world):
     for rank, gather_ok, e_depth, e_conf, e_nc, calls, (a, b), nhalo, fbytes in res:
         assert gather_ok
         assert e_depth < 1e-3 and e_conf < 1e-3 and e_nc < 1e-6, (rank, e_depth, e_conf, e_nc)
-        assert calls["k3"] == (a, b) and calls["k1"] == (max(0, a - 8), min(40, b + 8))
+        assert calls["k3"] == (max(0, a - 8), min(40, b + 8)) and calls["k1"] == (max(0, a - 8), min(40, b + 8))
         assert nhalo == 11 and fbytes > 0
