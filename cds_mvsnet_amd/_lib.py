@@ -16,6 +16,7 @@ LIB_PATH = os.environ.get("CDS_MVSNET_LIB") or os.path.join(_HERE, "libcdsmvs_hi
 
 # activation / flag codes (mirror include/cds_mvsnet_hip.h)
 ACT_NONE, ACT_RELU, ACT_LEAKY01, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3, 4
+ACT_ACCUM = 16
 AGG_ACCUMULATE, AGG_NORMALIZE, AGG_CHANNELS_LAST, AGG_FAST_POSITIONS = 1, 2, 4, 8
 WARP_FAST_POSITIONS = AGG_FAST_POSITIONS
 MAX_VIEWS = 8
@@ -82,6 +83,13 @@ SIGNATURES = {
     "cds_bn3d_finalize_f32": [P, P, P, DB, DB, F, P, P, P, P, P, P, I, P],
     "cds_bn3d_bwd_finalize_f32": [P, P, P, P, DB, P, P, P, P, I, P],
     "cds_conv3d_wgrad_f32": [P, P, P, I, I, I, I, I, I, I, I, I, I, P],
+    "cds_conv2d_wgrad_f32": [P, P, P, I, I, I, I, I, I, I, I, I, I, P],
+    "cds_conv2d_dgrad_s2_f32": [P, P, P, I, I, I, I, I, I, I, P],
+    "cds_instnorm_bwd_f32": [P, P, P, P, P, I, I, I, I, I, P],
+    "cds_dynconv_bn_stats_f32": [P, P, P, P, P, P, P, P, I, I, I, I, I, I, F, F, I, P],
+    "cds_dynconv_blend_train_f32": [P, P, P, P, P, P, P, P, F, P, P, I, I, I, I, I, I, P],
+    "cds_dynconv_blend_bwd_f32": [P, P, P, P, P, P, P, P, F, P, P, P, P, P, I, I, I, I, I, I, I, P],
+    "cds_softargmin_bwd_f32": [P, P, P, P, I, I, I, I, P],
     "cds_depth_fusion_f32": [P, P, P, P, P, P, P, P, P, I, I, I, P, F, F, F, P],
 }
 

@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256) void conv2d_kernel(const float* __restrict__ x
       const size_t base = ((size_t)n * Cout + co0 + c) * oplane + (size_t)oy * Wo + oxb;
 #pragma unroll
       for (int p = 0; p < PX; ++p)
-        if (oxb + p < Wo) out[base + p] = cds_act_conv(acc[p][c] + b, act);
+        if (oxb + p < Wo) out[base + p] = cds_act_conv(acc[p][c] + b, act & 15) + ((act & CDS_ACT_ACCUM) ? out[base + p] : 0.f);
     }
   }
 }
@@ -321,12 +321,15 @@ __global__ __launch_bounds__(256) void conv2d_pipe_kernel(const float* __restric
       const float b = bias ? bias[co0 + c] : 0.f;
       const size_t base = ((size_t)n * Cout + co0 + c) * oplane + (size_t)oy * Wo + oxb;
       if (vec) {
-        *reinterpret_cast<float4*>(out + base) = make_float4(cds_act_conv(acc[0][c] + b, act), cds_act_conv(acc[1 % PX][c] + b, act),
-                                                             cds_act_conv(acc[2 % PX][c] + b, act), cds_act_conv(acc[3 % PX][c] + b, act));
+        float4 prev = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (act & CDS_ACT_ACCUM) prev = *reinterpret_cast<const float4*>(out + base);
+        *reinterpret_cast<float4*>(out + base) =
+            make_float4(cds_act_conv(acc[0][c] + b, act & 15) + prev.x, cds_act_conv(acc[1 % PX][c] + b, act & 15) + prev.y,
+                        cds_act_conv(acc[2 % PX][c] + b, act & 15) + prev.z, cds_act_conv(acc[3 % PX][c] + b, act & 15) + prev.w);
       } else {
 #pragma unroll
         for (int p = 0; p < PX; ++p)
-          if (oxb + p < Wo) out[base + p] = cds_act_conv(acc[p][c] + b, act);
+          if (oxb + p < Wo) out[base + p] = cds_act_conv(acc[p][c] + b, act & 15) + ((act & CDS_ACT_ACCUM) ? out[base + p] : 0.f);
       }
     }
   }

@@ -389,6 +389,10 @@ class Refinement(_PackedHolder):
     def forward(self, img: Tensor, depth0: Tensor, dmin: Tensor, dmax: Tensor) -> Tensor:
         """img [B,3,H,W], depth0 [B,1,H/2,W/2], dmin/dmax [B] -> refined depth [B,1,H,W]."""
         if self.training:
+            from . import training
+            if training.USE_HIP_TRAIN2D and img.is_cuda:                      # HIP forward / backward kernels (train2d_ops.py)
+                from . import train2d_ops
+                return train2d_ops.refinement(self, img, depth0, dmin, dmax)
             return self._forward_autograd(img, depth0, dmin, dmax)
         p = self._packed.get(self, self._pack)
         B, _, H, W = img.shape

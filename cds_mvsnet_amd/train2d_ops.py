@@ -1,0 +1,341 @@
+"""Training ops of the 2D stacks on the hand-written HIP kernels (csrc/train2d.hip + the forward kernels of conv2d.hip):
+FeatureNet / DynamicConv, the visibility CNN, Refinement and the soft-argmin, each a ``torch.autograd.Function`` whose forward AND
+backward are HIP kernels.  They replace the PyTorch-ROCm autograd ops (MIOpen convolutions, ATen elementwise
+chains) ``training.py`` used for these stacks; parameters, ``state_dict`` and optimisers are unchanged (the functions take the
+parameter tensors of the holder modules in ``model.py``).
+
+Reference semantics (forward; the backward is what torch.autograd derives from it):
+  models/dynamic_conv.py:97-122 (DynamicConv.forward), models/module.py:28-71 (conv -> InstanceNorm2d -> LeakyReLU(0.1)),
+  models/module.py:234-267 (FeatureNet.forward), models/model.py:14,51 (visibility CNN), models/module.py:318-370 (Refinement),
+  models/module.py:373-379 (depth_regression).
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn.functional as F
+
+from . import _lib, ops
+from ._lib import ACT_ACCUM, ACT_LEAKY01, ACT_NONE, ACT_TANH, check
+
+Tensor = torch.Tensor
+
+_KS_DIRECT = (1, 3, 5, 7, 11)
+
+
+def _p(t: Optional[Tensor]) -> Optional[int]:
+    return None if t is None else ops._dev(t, "tensor")
+
+
+def _p64(t: Tensor) -> int:
+    if t.dtype != torch.float64 or not t.is_contiguous():
+        raise ValueError("expected a contiguous float64 tensor")
+    return t.data_ptr()
+
+
+def pack_conv(w: Tensor) -> Tensor:
+    """[Cout,Cin,k,k] -> [Cin,k*k,CoutP] (cout fastest, zero padded to a multiple of 8): the layout of cds_conv2d_f32."""
+    cout, cin, k, _ = w.shape
+    p = w.permute(1, 2, 3, 0).reshape(cin, k * k, cout)
+    pad = (-cout) % 8
+    if pad:
+        p = F.pad(p, (0, pad))
+    return p.contiguous()
+
+
+def pack_dgrad(w: Tensor) -> Tensor:
+    """Weights of the stride-1 data gradient as a forward convolution: dx = conv(dy, w'), w'[ci][co][ky][kx] = w[co][ci][k-1-ky][k-1-kx]."""
+    return pack_conv(w.flip(2, 3).transpose(0, 1))
+
+
+def conv2d_wgrad(g: Tensor, x: Tensor, k: int, stride: int, pad: int) -> Tensor:
+    """dw[co][ci][ky][kx] = sum_{n, o} g[n][co][o] x[n][ci][stride o - pad + k]  ->  [Co,Cin,k,k]."""
+    N, Co, Ho, Wo = g.shape
+    Nx, Cin, H, W = x.shape
+    if Nx != N:
+        raise ValueError("conv2d_wgrad: batch mismatch")
+    dw = torch.zeros((Co, Cin, k, k), dtype=torch.float32, device=g.device)
+    check(_lib.load().cds_conv2d_wgrad_f32(_p(g), _p(x), dw.data_ptr(), N, Co, Cin, Ho, Wo, H, W, k, stride, pad, ops._stream(g)),
+          "cds_conv2d_wgrad_f32")
+    return dw
+
+
+def conv2d_dgrad_s2(g: Tensor, w: Tensor, H: int, W: int) -> Tensor:
+    """Data gradient of Conv2d(k 3, stride 2, pad 1): g [N,Co,Ho,Wo], w [Co,Cin,3,3] -> [N,Cin,H,W]."""
+    N, Co, Ho, Wo = g.shape
+    Cin = w.shape[1]
+    gx = torch.empty((N, Cin, H, W), dtype=torch.float32, device=g.device)
+    check(_lib.load().cds_conv2d_dgrad_s2_f32(_p(g), _p(w.contiguous()), gx.data_ptr(), N, Co, Cin, Ho, Wo, H, W, ops._stream(g)),
+          "cds_conv2d_dgrad_s2_f32")
+    return gx
+
+
+class Conv2d(torch.autograd.Function):
+    """y = conv2d(x, weight [Cout,Cin,k,k], bias | None; stride 1 with k in (1,3,5,7,11), or k 3 stride 2 pad 1)."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, x, weight, bias, stride: int, pad: int):
+        x = x.contiguous()
+        k = weight.shape[-1]
+        if k not in _KS_DIRECT or (stride == 2 and (k != 3 or pad != 1)) or stride not in (1, 2):
+            raise ValueError(f"train2d_ops.Conv2d: unsupported kernel {k} / stride {stride} / pad {pad}")
+        ctx.save_for_backward(x, weight)
+        ctx.stride, ctx.pad, ctx.has_bias = stride, pad, bias is not None
+        return ops.conv2d(x, pack_conv(weight.detach()), bias.detach().contiguous() if bias is not None else None, weight.shape[0], k,
+                          stride, pad)
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy = dy.contiguous().float()
+        w = weight.detach().float()
+        k = w.shape[-1]
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            if ctx.stride == 1:
+                if 2 * ctx.pad != k - 1:
+                    raise ValueError("train2d_ops.Conv2d: the stride-1 data gradient needs 'same' padding")
+                dx = ops.conv2d(dy, pack_dgrad(w), None, w.shape[1], k, 1, ctx.pad)
+            else:
+                dx = conv2d_dgrad_s2(dy, w, x.shape[2], x.shape[3])
+        if ctx.needs_input_grad[1]:
+            dw = conv2d_wgrad(dy, x, k, ctx.stride, ctx.pad)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = dy.sum(dim=(0, 2, 3))
+        return dx, dw, db, None, None
+
+
+class InstNormAct(torch.autograd.Function):
+    """z = act(InstanceNorm2d(y)), act in (ACT_LEAKY01, ACT_TANH, ACT_NONE)."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, y, act: int):
+        y = y.contiguous()
+        N, C, H, W = y.shape
+        out = torch.empty_like(y)
+        stats = torch.empty((N, C, 2), dtype=torch.float64, device=y.device)
+        check(_lib.load().cds_instnorm_act_f32(_p(y), out.data_ptr(), stats.data_ptr(), N, C, H, W, act, 0, ops._stream(y)),
+              "cds_instnorm_act_f32")
+        ctx.save_for_backward(y, stats)
+        ctx.act = act
+        return out
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, gz):
+        y, stats = ctx.saved_tensors
+        gz = gz.contiguous().float()
+        N, C, H, W = y.shape
+        gy = torch.empty_like(y)
+        sums = torch.empty((N, C, 2), dtype=torch.float64, device=y.device)
+        check(_lib.load().cds_instnorm_bwd_f32(_p(gz), _p(y), _p64(stats), _p64(sums), gy.data_ptr(), N, C, H, W, ctx.act,
+                                               ops._stream(y)), "cds_instnorm_bwd_f32")
+        return gy, None
+
+
+class _DynConvFn(torch.autograd.Function):
+    """One DynamicConv (dynamic_conv.py:97-122): (x, epipoles) -> (y [N,Cout,H,W], norm_curv [N,1,H,W]).
+    Tensor arguments after the fixed ones: K convolution weights, K attention-convolution weights, K biases (or none), then
+    att_weights[0].weight, BatchNorm weight, bias, att_weights[3].weight."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, x, epi, T: float, groups: int, bn, ksizes: Tuple[int, ...], has_bias: bool, *params):
+        K = len(ksizes)
+        x = x.contiguous()
+        N, Cin, H, W = x.shape
+        convs, atts = params[:K], params[K:2 * K]
+        biases = params[2 * K:3 * K] if has_bias else ()
+        w1, gamma, beta, w2 = params[-4:]
+        cout = convs[0].shape[0]
+        dev = x.device
+        epi = epi.detach().float().contiguous()
+        lib = _lib.load()
+        st = ops._stream(x)
+        wcat = [torch.cat((convs[i].detach(), atts[i].detach()), dim=0) for i in range(K)]            # [Cout+3,Cin,k,k]
+        bcat = [torch.cat((biases[i].detach(), torch.zeros(3, device=dev))) for i in range(K)] if has_bias else None
+        branches = torch.empty((K, N, cout + 3, H, W), dtype=torch.float32, device=dev)
+        if ops.dynconv_sbf_supported(Cin, cout + 3, ksizes, W):
+            # all kernel sizes from one staged tile on the matrix cores (split-bf16 arithmetic, fp32-level accuracy)
+            ops.dynconv_branches_sbf(x, ops.split_pack_dynconv(wcat), torch.stack(bcat).contiguous() if has_bias else None, cout + 3,
+                                     ksizes, out=branches)
+        else:
+            for i, k in enumerate(ksizes):
+                ops.conv2d(x, pack_conv(wcat[i]), bcat[i] if has_bias else None, cout + 3, k, 1, (k - 1) // 2, out=branches[i])
+        use_batch = bool(bn.training or not bn.track_running_stats)
+        G = groups if use_batch else 1
+        if N % G:
+            raise ValueError(f"DynamicConv: {N} images do not split into {G} groups")
+        w1m = w1.detach().reshape(4, K).contiguous()
+        w2m = w2.detach().reshape(K, 4).contiguous()
+        mean = torch.empty((G, 4), dtype=torch.float32, device=dev)
+        rstd = torch.empty((G, 4), dtype=torch.float32, device=dev)
+        mom = torch.empty((G, K + K * (K + 1) // 2), dtype=torch.float64, device=dev)
+        track = use_batch and bn.training and bn.track_running_stats
+        momentum = bn.momentum if bn.momentum is not None else 0.1
+        check(lib.cds_dynconv_bn_stats_f32(_p(branches), _p(epi), _p(w1m), mom.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                           bn.running_mean.data_ptr() if (track or not use_batch) else None,
+                                           bn.running_var.data_ptr() if (track or not use_batch) else None,
+                                           N, G, K, cout, H, W, float(bn.eps), float(momentum), 1 if use_batch else 0, st),
+              "cds_dynconv_bn_stats_f32")
+        if track:
+            bn.num_batches_tracked += G
+        y = torch.empty((N, cout, H, W), dtype=torch.float32, device=dev)
+        nc = torch.empty((N, 1, H, W), dtype=torch.float32, device=dev)
+        gm, bt = gamma.detach().contiguous(), beta.detach().contiguous()
+        check(lib.cds_dynconv_blend_train_f32(_p(branches), _p(epi), _p(w1m), _p(w2m), _p(gm), _p(bt), _p(mean), _p(rstd), float(T),
+                                              y.data_ptr(), nc.data_ptr(), N, G, K, cout, H, W, st), "cds_dynconv_blend_train_f32")
+        ctx.save_for_backward(x, epi, branches, mean, rstd, *params)
+        ctx.cfg = (float(T), G, tuple(ksizes), has_bias, use_batch)
+        return y, nc
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, gy, gnc):
+        T, G, ksizes, has_bias, use_batch = ctx.cfg
+        K = len(ksizes)
+        x, epi, branches, mean, rstd = ctx.saved_tensors[:5]
+        params = ctx.saved_tensors[5:]
+        convs, atts = params[:K], params[K:2 * K]
+        w1, gamma, beta, w2 = params[-4:]
+        N, Cin, H, W = x.shape
+        cout = convs[0].shape[0]
+        dev = x.device
+        lib = _lib.load()
+        st = ops._stream(x)
+        gy = gy.contiguous().float() if gy is not None else torch.zeros((N, cout, H, W), dtype=torch.float32, device=dev)
+        gnc = gnc.contiguous().float() if gnc is not None else None
+        w1m = w1.detach().reshape(4, K).contiguous()
+        w2m = w2.detach().reshape(K, 4).contiguous()
+        gbr = torch.empty_like(branches)
+        sums = torch.empty((G * 8 + K * 4,), dtype=torch.float64, device=dev)
+        dw1 = torch.empty((4, K), dtype=torch.float64, device=dev)
+        check(lib.cds_dynconv_blend_bwd_f32(_p(branches), _p(epi), _p(w1m), _p(w2m), _p(gamma.detach().contiguous()),
+                                            _p(beta.detach().contiguous()), _p(mean), _p(rstd), T, _p(gy), _p(gnc), gbr.data_ptr(),
+                                            sums.data_ptr(), dw1.data_ptr(), N, G, K, cout, H, W, 1 if use_batch else 0, st),
+              "cds_dynconv_blend_bwd_f32")
+        grp = sums[:G * 8].view(G, 2, 4).sum(dim=0)
+        g_beta, g_gamma = grp[0].float(), grp[1].float()
+        g_w2 = sums[G * 8:].view(K, 4).float().view_as(w2)
+        g_w1 = dw1.float().view_as(w1)
+        dx = None
+        g_convs: List[Optional[Tensor]] = []
+        g_atts: List[Optional[Tensor]] = []
+        g_bias: List[Optional[Tensor]] = []
+        for i, k in enumerate(ksizes):
+            wcat = torch.cat((convs[i].detach(), atts[i].detach()), dim=0).float()
+            if ctx.needs_input_grad[0]:
+                if dx is None:
+                    dx = torch.empty_like(x)
+                ops.conv2d(gbr[i], pack_dgrad(wcat), None, Cin, k, 1, (k - 1) // 2, act=ACT_NONE if i == 0 else ACT_ACCUM, out=dx)
+            dw = conv2d_wgrad(gbr[i], x, k, 1, (k - 1) // 2)
+            g_convs.append(dw[:cout])
+            g_atts.append(dw[cout:])
+            if has_bias:
+                g_bias.append(gbr[i][:, :cout].sum(dim=(0, 2, 3)))
+        return (dx, None, None, None, None, None, None, *g_convs, *g_atts, *g_bias, g_w1, g_gamma, g_beta, g_w2)
+
+
+def dynamic_conv(dc, x: Tensor, epi: Tensor, T: float, groups: int = 1) -> Tuple[Tensor, Tensor]:
+    """``DynamicConv.forward`` of the holder module `dc` on the HIP kernels.  x [N,Cin,H,W], epi [N,2] on x's device.
+    groups > 1: the batch stacks that many separate calls of the reference (BatchNorm statistics per group of N / groups images)."""
+    K = len(dc.size_kernels)
+    has_bias = dc.convs[0].bias is not None
+    params = [c.weight for c in dc.convs] + [a.weight for a in dc.att_convs]
+    if has_bias:
+        params += [c.bias for c in dc.convs]
+    params += [dc.att_weights[0].weight, dc.att_weights[1].weight, dc.att_weights[1].bias, dc.att_weights[3].weight]
+    return _DynConvFn.apply(x, epi, float(T), int(groups), dc.att_weights[1], tuple(dc.size_kernels), has_bias, *params)
+
+
+def conv_in_act(conv, x: Tensor, act: int = ACT_LEAKY01) -> Tensor:
+    """Plain ConvUnit (module.py:28-71): Conv2d (no bias) -> InstanceNorm2d -> LeakyReLU(0.1)."""
+    y = Conv2d.apply(x, conv.weight, conv.bias, conv.stride[0], conv.padding[0])
+    return InstNormAct.apply(y, act)
+
+
+class SoftArgmin(torch.autograd.Function):
+    """depth [B,h,w] = sum_d softmax(prob_pre, dim=1) * hyp  (module.py:373-379); prob_pre, hyp [B,D,h,w]."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, prob_pre, hyp):
+        prob_pre, hyp = prob_pre.contiguous(), hyp.contiguous()
+        ctx.save_for_backward(prob_pre, hyp)
+        return torch.stack([ops.softargmin_conf(prob_pre[b], hyp[b])[0] for b in range(prob_pre.shape[0])])
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, gd):
+        prob_pre, hyp = ctx.saved_tensors
+        gd = gd.contiguous().float()
+        B, D, h, w = prob_pre.shape
+        gp = torch.empty_like(prob_pre)
+        lib = _lib.load()
+        for b in range(B):
+            check(lib.cds_softargmin_bwd_f32(_p(prob_pre[b]), _p(hyp[b]), _p(gd[b]), gp[b].data_ptr(), D, h, w, 1, ops._stream(gd)),
+                  "cds_softargmin_bwd_f32")
+        return gp, None
+
+
+def bn_relu2d(bn, y: Tensor, relu: bool = True) -> Tensor:
+    """BatchNorm2d in the module's mode (+ ReLU) on the BatchNorm kernels of train3d.hip (a [B,C,H,W] map is a one-slice volume)."""
+    from . import train_ops
+    if bn.training:
+        momentum = bn.momentum
+        if bn.num_batches_tracked is not None:
+            bn.num_batches_tracked += 1
+            if momentum is None:                                         # cumulative moving average (nn.BatchNorm semantics)
+                momentum = 1.0 / float(bn.num_batches_tracked)
+        if momentum is None:
+            momentum = 0.0
+        return train_ops.BnRelu3d.apply(y.unsqueeze(2), bn.weight, bn.bias, None, bn.running_mean, bn.running_var, float(momentum),
+                                        bn.eps, relu).squeeze(2)
+    out = F.batch_norm(y, bn.running_mean, bn.running_var, bn.weight, bn.bias, False, 0.0, bn.eps)
+    return torch.relu(out) if relu else out
+
+
+class Deconv2dK3S2(torch.autograd.Function):
+    """ConvTranspose2d(k 3, stride 2, pad 1, output_padding 1, no bias) with 8 output channels: x [B,Cin,H,W], weight [Cin,8,3,3]."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, x, weight):
+        x = x.contiguous()
+        cin, cout = weight.shape[:2]
+        ctx.save_for_backward(x, weight)
+        wpk = weight.detach().permute(0, 2, 3, 1).reshape(cin, 9, cout).contiguous()
+        return torch.stack([ops.deconv2d_k3s2(x[b], wpk, None) for b in range(x.shape[0])])
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy = dy.contiguous().float()
+        w = weight.detach().float()
+        dx = dw = None
+        if ctx.needs_input_grad[0]:                              # the stride-2 convolution this layer is the transpose of
+            dx = ops.conv2d(dy, pack_conv(w), None, w.shape[0], 3, 2, 1)
+        if ctx.needs_input_grad[1]:
+            dw = conv2d_wgrad(x, dy, 3, 2, 1)                    # roles swapped: [Cin,Cout,3,3]
+        return dx, dw
+
+
+def _cbr(unit, x: Tensor) -> Tensor:
+    return bn_relu2d(unit.bn, Conv2d.apply(x, unit.conv.weight, unit.conv.bias, 1, 1))
+
+
+def refinement(net, img: Tensor, depth0: Tensor, dmin: Tensor, dmax: Tensor) -> Tensor:
+    """Refinement.forward in training mode (module.py:351-370) on the HIP training ops.  img [B,3,H,W], depth0 [B,1,H/2,W/2]."""
+    B = dmin.shape[0]
+    lo, hi = dmin.view(B, 1, 1, 1).float(), dmax.view(B, 1, 1, 1).float()
+    d = ((depth0.float() - lo) / (hi - lo) * 10).contiguous()
+    f_img = _cbr(net.conv0, img.float())
+    f_d = bn_relu2d(net.bn, Deconv2dK3S2.apply(_cbr(net.conv2, _cbr(net.conv1, d)), net.deconv.weight))
+    res = Conv2d.apply(_cbr(net.conv3, torch.cat((f_d, f_img), dim=1)), net.res.weight, net.res.bias, 1, 1)
+    d = (F.interpolate(d, scale_factor=2, mode="bilinear", align_corners=True) + res) / 10
+    return d * (hi - lo) + lo

@@ -70,11 +70,39 @@ def _dynamic_conv(dc, x: Tensor, epi: Tensor, T: float, groups: int = 1) -> Tupl
     return (torch.cat(res, dim=1) * wts.unsqueeze(2)).sum(dim=1), (curvs * wts).sum(dim=1, keepdim=True)
 
 
+def _hip2d(x: Tensor) -> bool:
+    return USE_HIP_TRAIN2D and x.is_cuda
+
+
+def _dyn(dc, x: Tensor, epi: Tensor, T: float, groups: int = 1) -> Tuple[Tensor, Tensor]:
+    """One DynamicConv: the HIP forward / backward kernels (train2d_ops.dynamic_conv) or, with CDS_TRAIN_HIP2D=0 / on the CPU, torch ops."""
+    if _hip2d(x):
+        from . import train2d_ops
+        return train2d_ops.dynamic_conv(dc, x, epi, T, groups)
+    return _dynamic_conv(dc, x, epi, T, groups)
+
+
+def _in_act(y: Tensor, tanh: bool = False) -> Tensor:
+    """InstanceNorm2d + LeakyReLU(0.1) (module.py:66-69) or + tanh (module.py:223)."""
+    if _hip2d(y):
+        from . import train2d_ops
+        return train2d_ops.InstNormAct.apply(y, ops.ACT_TANH if tanh else ops.ACT_LEAKY01)
+    return torch.tanh(F.instance_norm(y)) if tanh else F.leaky_relu(F.instance_norm(y), 0.1)
+
+
+def _conv(conv, x: Tensor) -> Tensor:
+    """A plain nn.Conv2d holder (3x3 stride 1 | 2, 1x1) on the HIP training kernels, or torch."""
+    if _hip2d(x):
+        from . import train2d_ops
+        return train2d_ops.Conv2d.apply(x, conv.weight, conv.bias, conv.stride[0], conv.padding[0])
+    return conv(x)
+
+
 def _unit(unit, x: Tensor, epi: Optional[Tensor], T: float, groups: int = 1):
     if unit.dynamic:
-        y, nc = _dynamic_conv(unit.conv, x, epi, T, groups)
-        return F.leaky_relu(F.instance_norm(y), 0.1), nc
-    return F.leaky_relu(F.instance_norm(unit.conv(x)), 0.1)
+        y, nc = _dyn(unit.conv, x, epi, T, groups)
+        return _in_act(y), nc
+    return _in_act(_conv(unit.conv, x))
 
 
 def feature_net(net, x: Tensor, epi: Tensor, T: float, groups: int = 1) -> Dict[str, Tuple[Tensor, Tensor, Tensor]]:
@@ -91,15 +119,15 @@ def feature_net(net, x: Tensor, epi: Tensor, T: float, groups: int = 1) -> Dict[
     c20, n20 = _unit(net.conv20, d1, e2, T, groups)
     c21, n21 = _unit(net.conv21, c20, e2, T, groups)
     out = {}
-    o1, n22 = _dynamic_conv(net.out1, c21, e2, T, groups)
-    out["stage1"] = (torch.tanh(F.instance_norm(o1)), (n20 ** 2 + n21 ** 2 + n22 ** 2) / 3, n22.abs())
+    o1, n22 = _dyn(net.out1, c21, e2, T, groups)
+    out["stage1"] = (_in_act(o1, tanh=True), (n20 ** 2 + n21 ** 2 + n22 ** 2) / 3, n22.abs())
     t = _unit(net.inner1, torch.cat((F.interpolate(c21, scale_factor=2, mode="nearest"), c11), dim=1), None, T)
-    o2, n12 = _dynamic_conv(net.out2, t, e1, T, groups)
-    o2 = torch.tanh(F.instance_norm(o2))
+    o2, n12 = _dyn(net.out2, t, e1, T, groups)
+    o2 = _in_act(o2, tanh=True)
     out["stage2"] = (o2, (n10 ** 2 + n11 ** 2 + n12 ** 2) / 3, n12.abs())
     t = _unit(net.inner2, torch.cat((F.interpolate(o2, scale_factor=2, mode="nearest"), c01), dim=1), None, T)
-    o3, n02 = _dynamic_conv(net.out3, t, e0, T, groups)
-    out["stage3"] = (torch.tanh(F.instance_norm(o3)), (n00 ** 2 + n01 ** 2 + n02 ** 2) / 3, n02.abs())
+    o3, n02 = _dyn(net.out3, t, e0, T, groups)
+    out["stage3"] = (_in_act(o3, tanh=True), (n00 ** 2 + n01 ** 2 + n02 ** 2) / 3, n02.abs())
     return out
 
 
@@ -109,6 +137,7 @@ def _cbr3(unit, x: Tensor) -> Tensor:
 
 BATCH_FEATURES = os.environ.get("CDS_TRAIN_BATCH_FEATURES", "1") != "0"   # 0 = one FeatureNet call per image of every pair, as the reference
 USE_HIP_TRAIN = os.environ.get("CDS_TRAIN_HIP", "1") != "0"   # A/B knob: 0 = PyTorch-ROCm (MIOpen) autograd ops for CostRegNet
+USE_HIP_TRAIN2D = os.environ.get("CDS_TRAIN_HIP2D", "1") != "0"   # A/B knob: 0 = PyTorch-ROCm autograd ops for the 2D stacks
 
 
 def cost_regularization(cr, x: Tensor) -> Tensor:
@@ -128,10 +157,18 @@ def cost_regularization(cr, x: Tensor) -> Tensor:
     return cr.prob(y)
 
 
+def _cbr2(unit, x: Tensor) -> Tensor:
+    """ConvBn2d holder: Conv2d 3x3 -> BatchNorm2d (module mode) -> ReLU."""
+    if _hip2d(x):
+        from . import train2d_ops
+        return train2d_ops.bn_relu2d(unit.bn, _conv(unit.conv, x))
+    return F.relu(unit.bn(unit.conv(x)))
+
+
 def _visibility(seq, x: Tensor) -> Tensor:
     for i in range(3):
-        x = F.relu(seq[i].bn(seq[i].conv(x)))
-    return torch.sigmoid(seq[3](x))
+        x = _cbr2(seq[i], x)
+    return torch.sigmoid(_conv(seq[3], x))
 
 
 def stage_forward_train(stage_net, features, cams: Tensor, depth_values: Tensor, cost_reg, stage_idx: int,
@@ -172,8 +209,11 @@ def stage_forward_train(stage_net, features, cams: Tensor, depth_values: Tensor,
     nc_mean = sum((features[v]["ref"][1] + features[v]["src"][1]) / 2 for v in range(V)) / V       # [B,1,h,w]
     hyp_b = torch.stack(hyps)
     prob_pre = cost_regularization(cost_reg, torch.stack(vols)).squeeze(1).float()
-    prob = F.softmax(prob_pre, dim=1)
-    depth = torch.sum(prob * hyp_b, dim=1)
+    if _hip2d(prob_pre):
+        from . import train2d_ops
+        depth = train2d_ops.SoftArgmin.apply(prob_pre, hyp_b)
+    else:
+        depth = torch.sum(F.softmax(prob_pre, dim=1) * hyp_b, dim=1)
     with torch.no_grad():
         conf = torch.stack([ops.softargmin_conf(prob_pre[b].detach().contiguous(), hyp_b[b])[1] for b in range(B)])
     return {"depth": depth, "photometric_confidence": conf, "feat_distance": torch.stack(fds), "norm_curv": nc_mean}

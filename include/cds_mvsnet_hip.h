@@ -34,6 +34,7 @@ extern "C" {
 #define CDS_ACT_RELU 1
 #define CDS_ACT_LEAKY01 2 /* LeakyReLU(0.1) */
 #define CDS_ACT_SIGMOID 3
+#define CDS_ACT_ACCUM 16 /* OR-ed onto an activation code of cds_conv2d_*_f32: out += act(conv) (gradient accumulation) */
 #define CDS_ACT_TANH 4
 
 /* flags of cds_warp_aggregate_f32 */
@@ -431,6 +432,44 @@ int cds_bn3d_bwd_finalize_f32(const double* sums, const double* mean, const doub
                               float* k1, float* k0, float* dgamma, float* dbeta, int C, void* stream);
 int cds_conv3d_wgrad_f32(const float* g, const float* xin, float* dw, int B, int Ca, int Cb, int Do, int Ho, int Wo, int Di,
                          int Hi, int Wi, int stride, void* stream);
+
+/* ---- training step, 2D stacks (csrc/train2d.hip) ---------------------------------------------------------------
+ * Backward kernels of FeatureNet / DynamicConv (models/dynamic_conv.py:97-122, models/module.py:28-71,234-267), the visibility CNN
+ * (models/model.py:14,51), Refinement (models/module.py:318-370) and depth_regression (models/module.py:373-379); they replace what
+ * torch.autograd + cuDNN derive from those forwards in trainer/trainer.py:69-82.
+ *   cds_conv2d_wgrad_f32:     dw[co][ci][ky][kx] += sum_{n,o} g[n][co][o] x[n][ci][stride * o - pad + k]; Conv2d: g = dy; a transposed
+ *                             convolution swaps the roles (g = x, x = dy, stride 2) and receives [Cin][Cout][k][k].  dw is accumulated
+ *                             onto (zero it first).  k in {1,3,5,7,11} at stride 1, k = 3 at stride 2.
+ *   cds_conv2d_dgrad_s2_f32:  data gradient of Conv2d(k 3, stride 2, pad 1), weight [Co][Cin][3][3].  (Stride-1 data gradients are
+ *                             cds_conv2d_f32 on flipped / transposed weights, CDS_ACT_ACCUM to sum the branches of a DynamicConv.)
+ *   cds_instnorm_bwd_f32:     backward of InstanceNorm2d(eps 1e-5) + LeakyReLU(0.1) | tanh | nothing; stats = the forward's fp64
+ *                             (sum, sum of squares) per (image, channel), sums = fp64 scratch of the same size.
+ *   cds_dynconv_bn_stats_f32: (mean, rstd) [G][4] of the attention MLP's BatchNorm2d for G groups of N / G images - batch statistics
+ *                             from the fp64 moments of the K curvature maps (use_batch), else the running ones; updates the running
+ *                             statistics group after group.  mom: fp64 scratch [G][K + K (K + 1) / 2].  epipoles: DEVICE [N][2].
+ *   cds_dynconv_blend_train_f32: the DynamicConv epilogue with those statistics: out [N][Cout][H][W], norm_curv [N][H][W].
+ *   cds_dynconv_blend_bwd_f32:   its backward.  gbr [K][N][Cout+3][H][W] = gradient of the branch tensor; fp64: sums [G][8] =
+ *                             per group (sum g_bn_j, sum g_bn_j xhat_j) (dbeta_j / dgamma_j summed over groups) followed by dw2 [K][4];
+ *                             dw1 [4][K].  gnc may be NULL.
+ *   cds_softargmin_bwd_f32:   gpre[d] = softmax(prob_pre)_d (hyp_d - depth) gdepth. */
+int cds_conv2d_wgrad_f32(const float* g, const float* x, float* dw, int N, int Co, int Cin, int Ho, int Wo, int H, int W, int k,
+                         int stride, int pad, void* stream);
+int cds_conv2d_dgrad_s2_f32(const float* g, const float* w, float* gx, int N, int Co, int Cin, int Ho, int Wo, int H, int W,
+                            void* stream);
+int cds_instnorm_bwd_f32(const float* gz, const float* y, const double* stats, double* sums, float* gy, int N, int C, int H, int W,
+                         int act, void* stream);
+int cds_dynconv_bn_stats_f32(const float* branches, const float* epipoles, const float* w1, double* mom, float* mean, float* rstd,
+                             float* running_mean, float* running_var, int N, int G, int K, int Cout, int H, int W, float eps,
+                             float momentum, int use_batch, void* stream);
+int cds_dynconv_blend_train_f32(const float* branches, const float* epipoles, const float* w1, const float* w2, const float* gamma,
+                                const float* beta, const float* mean, const float* rstd, float temperature, float* out,
+                                float* norm_curv, int N, int G, int K, int Cout, int H, int W, void* stream);
+int cds_dynconv_blend_bwd_f32(const float* branches, const float* epipoles, const float* w1, const float* w2, const float* gamma,
+                              const float* beta, const float* mean, const float* rstd, float temperature, const float* gy,
+                              const float* gnc, float* gbr, double* sums, double* dw1, int N, int G, int K, int Cout, int H, int W,
+                              int use_batch, void* stream);
+int cds_softargmin_bwd_f32(const float* prob_pre, const float* hyp, const float* gdepth, float* gpre, int D, int h, int w,
+                           int hyp_per_pixel, void* stream);
 
 #ifdef __cplusplus
 }
