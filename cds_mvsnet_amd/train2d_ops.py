@@ -71,6 +71,10 @@ def conv2d_dgrad_s2(g: Tensor, w: Tensor, H: int, W: int) -> Tensor:
     return gx
 
 
+def _c16(w: Tensor, stride: int, pad: int, width: int) -> bool:
+    return tuple(w.shape) == (16, 16, 3, 3) and stride == 1 and pad == 1 and width % 4 == 0 and ops.USE_CONV2D_MFMA
+
+
 class Conv2d(torch.autograd.Function):
     """y = conv2d(x, weight [Cout,Cin,k,k], bias | None; stride 1 with k in (1,3,5,7,11), or k 3 stride 2 pad 1)."""
 
@@ -83,6 +87,9 @@ class Conv2d(torch.autograd.Function):
             raise ValueError(f"train2d_ops.Conv2d: unsupported kernel {k} / stride {stride} / pad {pad}")
         ctx.save_for_backward(x, weight)
         ctx.stride, ctx.pad, ctx.has_bias = stride, pad, bias is not None
+        if _c16(weight, stride, pad, x.shape[-1]):               # 16 -> 16, 3x3: the fp32 matrix-core kernel of the visibility CNN
+            return ops.conv2d_k3_c16(x, weight.detach().permute(2, 3, 0, 1).reshape(9, 16, 16).contiguous(),
+                                     bias.detach().contiguous() if bias is not None else None, ACT_NONE)
         return ops.conv2d(x, pack_conv(weight.detach()), bias.detach().contiguous() if bias is not None else None, weight.shape[0], k,
                           stride, pad)
 
@@ -98,7 +105,10 @@ class Conv2d(torch.autograd.Function):
             if ctx.stride == 1:
                 if 2 * ctx.pad != k - 1:
                     raise ValueError("train2d_ops.Conv2d: the stride-1 data gradient needs 'same' padding")
-                dx = ops.conv2d(dy, pack_dgrad(w), None, w.shape[1], k, 1, ctx.pad)
+                if _c16(w, 1, ctx.pad, dy.shape[-1]):
+                    dx = ops.conv2d_k3_c16(dy, w.flip(2, 3).permute(2, 3, 1, 0).reshape(9, 16, 16).contiguous(), None, ACT_NONE)
+                else:
+                    dx = ops.conv2d(dy, pack_dgrad(w), None, w.shape[1], k, 1, ctx.pad)
             else:
                 dx = conv2d_dgrad_s2(dy, w, x.shape[2], x.shape[3])
         if ctx.needs_input_grad[1]:
@@ -282,9 +292,32 @@ class SoftArgmin(torch.autograd.Function):
         return gp, None
 
 
-def bn_relu2d(bn, y: Tensor, relu: bool = True) -> Tensor:
-    """BatchNorm2d in the module's mode (+ ReLU) on the BatchNorm kernels of train3d.hip (a [B,C,H,W] map is a one-slice volume)."""
+def bn_relu2d(bn, y: Tensor, relu: bool = True, groups: int = 1) -> Tensor:
+    """BatchNorm2d in the module's mode (+ ReLU) on the BatchNorm kernels of train3d.hip (a [B,C,H,W] map is a one-slice volume).
+    groups > 1: y stacks that many separate calls of the module along the batch axis (group-major); the batch statistics are taken
+    per group and the running statistics receive the groups' updates in call order - the same values as `groups` calls."""
     from . import train_ops
+    if bn.training and groups > 1:
+        GB, C, H, W = y.shape
+        B = GB // groups
+        if B * groups != GB:
+            raise ValueError(f"bn_relu2d: {GB} maps do not split into {groups} groups")
+        # group g, channel c -> channel g C + c of ONE BatchNorm call over B samples
+        yv = y.reshape(1, GB * C, 1, H, W) if B == 1 else y.view(groups, B, C, H, W).transpose(0, 1).reshape(B, groups * C, 1, H, W)
+        track = bn.track_running_stats and bn.running_mean is not None
+        tm = torch.zeros((groups * C,), dtype=torch.float32, device=y.device) if track else None
+        tv = torch.zeros_like(tm) if track else None
+        out = train_ops.BnRelu3d.apply(yv, bn.weight.repeat(groups), bn.bias.repeat(groups), None, tm, tv, 1.0, bn.eps, relu)
+        if track:                                                        # momentum 1 left the batch mean / unbiased variance in tm / tv
+            with torch.no_grad():
+                tm, tv = tm.view(groups, C), tv.view(groups, C)
+                for g in range(groups):
+                    bn.num_batches_tracked += 1
+                    m = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+                    bn.running_mean.mul_(1.0 - m).add_(tm[g], alpha=m)
+                    bn.running_var.mul_(1.0 - m).add_(tv[g], alpha=m)
+        out = out.view(GB, C, H, W) if B == 1 else out.view(B, groups, C, H, W).transpose(0, 1).reshape(GB, C, H, W)
+        return out
     if bn.training:
         momentum = bn.momentum
         if bn.num_batches_tracked is not None:

@@ -157,17 +157,20 @@ def cost_regularization(cr, x: Tensor) -> Tensor:
     return cr.prob(y)
 
 
-def _cbr2(unit, x: Tensor) -> Tensor:
+def _cbr2(unit, x: Tensor, groups: int = 1) -> Tensor:
     """ConvBn2d holder: Conv2d 3x3 -> BatchNorm2d (module mode) -> ReLU."""
     if _hip2d(x):
         from . import train2d_ops
-        return train2d_ops.bn_relu2d(unit.bn, _conv(unit.conv, x))
+        return train2d_ops.bn_relu2d(unit.bn, _conv(unit.conv, x), True, groups)
+    if groups > 1:
+        raise ValueError("grouped BatchNorm calls need the HIP training ops")
     return F.relu(unit.bn(unit.conv(x)))
 
 
-def _visibility(seq, x: Tensor) -> Tensor:
+def _visibility(seq, x: Tensor, groups: int = 1) -> Tensor:
+    """models/model.py:14.  groups > 1: x stacks that many calls (one per source view) along the batch axis, group-major."""
     for i in range(3):
-        x = _cbr2(seq[i], x)
+        x = _cbr2(seq[i], x, groups)
     return torch.sigmoid(_conv(seq[3], x))
 
 
@@ -193,8 +196,15 @@ def stage_forward_train(stage_net, features, cams: Tensor, depth_values: Tensor,
     with torch.no_grad():                                               # K1, detached input (model.py:49)
         ent = torch.stack([ops.warp_entropy(ref[b].detach().contiguous(), src[b].detach(), mats[b], hyps[b])
                            for b in range(B)])                           # [B,V,h,w]
-    vis = [_visibility(stage_net.vis[stage_idx], torch.cat((ent[:, v:v + 1], features[v]["ref"][2].float()), dim=1))[:, 0]
-           for v in range(V)]                                            # V x [B,h,w]  (model.py:51)
+    if _hip2d(ent) and V > 1:
+        # the V calls of model.py:51 as ONE call on the views stacked along the batch axis (BatchNorm statistics per view)
+        nc_ref = torch.stack([features[v]["ref"][2].float()[:, 0] for v in range(V)])                   # [V,B,h,w]
+        x = torch.stack((ent.transpose(0, 1), nc_ref), dim=2).reshape(V * B, 2, ent.shape[-2], ent.shape[-1])
+        vis_all = _visibility(stage_net.vis[stage_idx], x, groups=V).view(V, B, ent.shape[-2], ent.shape[-1])
+        vis = [vis_all[v] for v in range(V)]
+    else:
+        vis = [_visibility(stage_net.vis[stage_idx], torch.cat((ent[:, v:v + 1], features[v]["ref"][2].float()), dim=1))[:, 0]
+               for v in range(V)]                                        # V x [B,h,w]  (model.py:51)
     vols, fds = [], []
     for b in range(B):
         vis_b = torch.stack([vis[v][b] for v in range(V)]).float()       # [V,h,w]

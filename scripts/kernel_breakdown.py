@@ -15,6 +15,6 @@ for name, s, e in rows[lo:]:
     key = re.sub(r"^void ", "", key).split("(")[0][:90]
     d = agg.setdefault(key, [0, 0.0]); d[0] += 1; d[1] += (e - s) / 1e3
     tot += (e - s) / 1e3
-for key, (c, us) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:30]:
+for key, (c, us) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:int(__import__("os").environ.get("TOPN", "30"))]:
     print(f"{us:10.1f} us  n={c:5d}  {key}")
 print(f"total kernel time {tot:.1f} us over {n - lo} dispatches, wall span {(rows[-1][2]-rows[lo][1])/1e3:.1f} us")

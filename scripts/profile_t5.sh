@@ -7,5 +7,5 @@ O=$R/gpurun_out
 rm -rf $O/prof_t5
 timeout 400 rocprofv3 --kernel-trace -d $O/prof_t5 -o t -- python $R/bench.py --workload T5 --train-dtype fp32 --steps 3 --warmup 3 > $O/${tag}_t5_trace.log 2>&1
 cd $R
-python scripts/kernel_breakdown.py $(find $O/prof_t5 -name "*.db" | head -1) 6 > $O/${tag}_t5_breakdown.txt 2>&1
+TOPN=${TOPN:-30} python scripts/kernel_breakdown.py $(find $O/prof_t5 -name "*.db" | head -1) 6 > $O/${tag}_t5_breakdown.txt 2>&1
 find $O/prof_t5 -name "*.db" -delete

@@ -23,7 +23,7 @@ def _close(got, ref, name, rel=REL):
 
 @pytest.mark.parametrize("k,stride,cin,cout,h,w", [(1, 1, 24, 8, 20, 36), (3, 1, 8, 16, 21, 40), (3, 1, 16, 19, 24, 44), (5, 1, 8, 11, 19, 36),
                                                    (7, 1, 8, 11, 23, 52), (11, 1, 3, 11, 26, 72), (3, 2, 8, 16, 24, 40), (3, 2, 16, 32, 22, 36),
-                                                   (3, 1, 1, 8, 17, 33), (3, 1, 2, 16, 9, 70)])
+                                                   (3, 1, 1, 8, 17, 33), (3, 1, 2, 16, 9, 70), (3, 1, 16, 16, 18, 44), (3, 1, 16, 16, 18, 42)])
 def test_conv2d_forward_backward(k, stride, cin, cout, h, w):
     from cds_mvsnet_amd import train2d_ops as t2
     torch.manual_seed(k * 100 + cin)
@@ -229,3 +229,31 @@ def test_visibility_cnn_forward_backward():
     _close(xg.grad, xr.grad, "dx", rel=2e-3)
     for (name, pr), (_, ph) in zip(ref.named_parameters(), hip.named_parameters()):
         _close(ph.grad, pr.grad, name, rel=2e-3)
+
+
+@pytest.mark.parametrize("B", [1, 2])
+def test_grouped_visibility_equals_separate_calls(B):
+    """One visibility-CNN call on V views stacked along the batch axis (BatchNorm statistics per view) = V calls: outputs, input and
+    parameter gradients, running statistics."""
+    from cds_mvsnet_amd import training
+    from cds_mvsnet_amd.model import StageNet
+    torch.manual_seed(13)
+    dev = torch.device("cuda:0")
+    V = 3
+    seq = StageNet(1).vis[0].to(dev)
+    seq.train()
+    a, b = copy.deepcopy(seq), copy.deepcopy(seq)
+    x = torch.randn(V, B, 2, 24, 40, device=dev)
+    g = torch.randn(V, B, 1, 24, 40, device=dev)
+    xa = x.clone().requires_grad_(True)
+    ya = torch.stack([training._visibility(a, xa[v]) for v in range(V)])
+    (ya * g).sum().backward()
+    xb = x.clone().requires_grad_(True)
+    yb = training._visibility(b, xb.view(V * B, 2, 24, 40), groups=V).view(V, B, 1, 24, 40)
+    (yb * g).sum().backward()
+    _close(yb, ya, "vis", rel=1e-5)
+    _close(xb.grad, xa.grad, "dx", rel=1e-4)
+    for (name, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
+        _close(pb.grad, pa.grad, name, rel=1e-4)
+    for (name, ba), (_, bb) in zip(a.named_buffers(), b.named_buffers()):
+        _close(bb.double(), ba.double(), name, rel=1e-5)
