@@ -560,6 +560,30 @@ __global__ __launch_bounds__(256) void softargmin_bwd_kernel(const float* __rest
   }
 }
 
+// Weight layouts of cds_conv2d_f32 for a convolution weight w [Ca + Cb][Cin][k][k] given as two tensors (wa = the DynamicConv branch
+// convolution, wb = its 3-channel attention convolution, or NULL): fwd [Cin][k k][CoP] for y = conv(x, w), dgrad [Ca + Cb][k k][CiP] for
+// dx = conv(dy, flipped / transposed w); CoP / CiP = channel counts rounded up to 8, zero padded.  One launch instead of a dozen ATen ops.
+__global__ void pack_conv2d_kernel(const float* __restrict__ wa, const float* __restrict__ wb, float* __restrict__ fwd,
+                                   float* __restrict__ dgrad, int Ca, int Cb, int Cin, int kk) {
+  const int Co = Ca + Cb, CoP = (Co + 7) & ~7, CiP = (Cin + 7) & ~7;
+  const int nf = fwd ? Cin * kk * CoP : 0, nd = dgrad ? Co * kk * CiP : 0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nf + nd; i += gridDim.x * blockDim.x) {
+    if (i < nf) {
+      const int co = i % CoP, tap = (i / CoP) % kk, ci = i / (CoP * kk);
+      float v = 0.f;
+      if (co < Ca) v = wa[((size_t)co * Cin + ci) * kk + tap];
+      else if (co < Co) v = wb[((size_t)(co - Ca) * Cin + ci) * kk + tap];
+      fwd[i] = v;
+    } else {
+      const int jd = i - nf;
+      const int ci = jd % CiP, tap = (jd / CiP) % kk, co = jd / (CiP * kk);
+      float v = 0.f;
+      if (ci < Cin) v = co < Ca ? wa[((size_t)co * Cin + ci) * kk + (kk - 1 - tap)] : wb[((size_t)(co - Ca) * Cin + ci) * kk + (kk - 1 - tap)];
+      dgrad[jd] = v;
+    }
+  }
+}
+
 template <int K>
 int blend_dispatch(int what, const BlendArgs& a, float* out, float* nc, const float* gy, const float* gnc, double* sums, double count,
                    int use_batch, float* gbr, double* dw1, hipStream_t st) {
@@ -697,5 +721,16 @@ extern "C" int cds_softargmin_bwd_f32(const float* prob_pre, const float* hyp, c
   if (!prob_pre || !hyp || !gdepth || !gpre || D < 1 || h < 1 || w < 1) return CDS_EINVAL;
   hipLaunchKernelGGL(softargmin_bwd_kernel, dim3(cds_ceil_div(h * w, 256)), dim3(256), 0, (hipStream_t)stream, prob_pre, hyp, gdepth,
                      gpre, D, h * w, hyp_per_pixel);
+  return cds_launch_status();
+}
+
+// fwd [Cin][k k][CoP] and / or dgrad [Ca + Cb][k k][CiP] (either may be NULL) from wa [Ca][Cin][k][k] and wb [Cb][Cin][k][k] (NULL if Cb = 0).
+extern "C" int cds_pack_conv2d_f32(const float* wa, const float* wb, float* fwd, float* dgrad, int Ca, int Cb, int Cin, int k,
+                                   void* stream) {
+  if (!wa || (Cb > 0 && !wb) || (!fwd && !dgrad) || Ca < 1 || Cb < 0 || Cin < 1 || k < 1) return CDS_EINVAL;
+  const int Co = Ca + Cb, kk = k * k;
+  const int n = (fwd ? Cin * kk * ((Co + 7) & ~7) : 0) + (dgrad ? Co * kk * ((Cin + 7) & ~7) : 0);
+  hipLaunchKernelGGL(pack_conv2d_kernel, dim3(cds_ceil_div(n, 256) > 64 ? 64 : cds_ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream,
+                     wa, wb, fwd, dgrad, Ca, Cb, Cin, kk);
   return cds_launch_status();
 }

@@ -16,12 +16,13 @@ from typing import List, Optional, Sequence, Tuple
 import torch
 import torch.nn.functional as F
 
-from . import _lib, ops
+from . import _lib, _scratch, ops
 from ._lib import ACT_ACCUM, ACT_LEAKY01, ACT_NONE, ACT_TANH, check
 
 Tensor = torch.Tensor
 
 _KS_DIRECT = (1, 3, 5, 7, 11)
+SBF_MIN_PIXELS = 4 << 20      # DynamicConv forward: images x pixels from which the split-bf16 matrix-core branch kernel pays for its packing
 
 
 def _p(t: Optional[Tensor]) -> Optional[int]:
@@ -44,6 +45,19 @@ def pack_conv(w: Tensor) -> Tensor:
     return p.contiguous()
 
 
+def pack_conv2d(wa: Tensor, wb: Optional[Tensor], fwd: bool = True, dgrad: bool = False) -> Tuple[Optional[Tensor], Optional[Tensor]]:
+    """pack_conv / pack_dgrad of cat(wa, wb) in ONE launch (cds_pack_conv2d_f32): (fwd [Cin,k*k,CoP] | None, dgrad [Co,k*k,CiP] | None)."""
+    ca, cin, k, _ = wa.shape
+    cb = wb.shape[0] if wb is not None else 0
+    wa = wa.detach().float().contiguous()
+    wb = wb.detach().float().contiguous() if wb is not None else None
+    f = torch.empty((cin, k * k, (ca + cb + 7) // 8 * 8), dtype=torch.float32, device=wa.device) if fwd else None
+    d = torch.empty((ca + cb, k * k, (cin + 7) // 8 * 8), dtype=torch.float32, device=wa.device) if dgrad else None
+    check(_lib.load().cds_pack_conv2d_f32(_p(wa), _p(wb), f.data_ptr() if fwd else None, d.data_ptr() if dgrad else None, ca, cb, cin, k,
+                                          ops._stream(wa)), "cds_pack_conv2d_f32")
+    return f, d
+
+
 def pack_dgrad(w: Tensor) -> Tensor:
     """Weights of the stride-1 data gradient as a forward convolution: dx = conv(dy, w'), w'[ci][co][ky][kx] = w[co][ci][k-1-ky][k-1-kx]."""
     return pack_conv(w.flip(2, 3).transpose(0, 1))
@@ -55,7 +69,7 @@ def conv2d_wgrad(g: Tensor, x: Tensor, k: int, stride: int, pad: int) -> Tensor:
     Nx, Cin, H, W = x.shape
     if Nx != N:
         raise ValueError("conv2d_wgrad: batch mismatch")
-    dw = torch.zeros((Co, Cin, k, k), dtype=torch.float32, device=g.device)
+    dw = _scratch.zeros((Co, Cin, k, k), torch.float32, g.device)
     check(_lib.load().cds_conv2d_wgrad_f32(_p(g), _p(x), dw.data_ptr(), N, Co, Cin, Ho, Wo, H, W, k, stride, pad, ops._stream(g)),
           "cds_conv2d_wgrad_f32")
     return dw
@@ -90,7 +104,7 @@ class Conv2d(torch.autograd.Function):
         if _c16(weight, stride, pad, x.shape[-1]):               # 16 -> 16, 3x3: the fp32 matrix-core kernel of the visibility CNN
             return ops.conv2d_k3_c16(x, weight.detach().permute(2, 3, 0, 1).reshape(9, 16, 16).contiguous(),
                                      bias.detach().contiguous() if bias is not None else None, ACT_NONE)
-        return ops.conv2d(x, pack_conv(weight.detach()), bias.detach().contiguous() if bias is not None else None, weight.shape[0], k,
+        return ops.conv2d(x, pack_conv2d(weight, None)[0], bias.detach().contiguous() if bias is not None else None, weight.shape[0], k,
                           stride, pad)
 
     @staticmethod
@@ -108,7 +122,7 @@ class Conv2d(torch.autograd.Function):
                 if _c16(w, 1, ctx.pad, dy.shape[-1]):
                     dx = ops.conv2d_k3_c16(dy, w.flip(2, 3).permute(2, 3, 1, 0).reshape(9, 16, 16).contiguous(), None, ACT_NONE)
                 else:
-                    dx = ops.conv2d(dy, pack_dgrad(w), None, w.shape[1], k, 1, ctx.pad)
+                    dx = ops.conv2d(dy, pack_conv2d(w, None, fwd=False, dgrad=True)[1], None, w.shape[1], k, 1, ctx.pad)
             else:
                 dx = conv2d_dgrad_s2(dy, w, x.shape[2], x.shape[3])
         if ctx.needs_input_grad[1]:
@@ -166,16 +180,21 @@ class _DynConvFn(torch.autograd.Function):
         epi = epi.detach().float().contiguous()
         lib = _lib.load()
         st = ops._stream(x)
-        wcat = [torch.cat((convs[i].detach(), atts[i].detach()), dim=0) for i in range(K)]            # [Cout+3,Cin,k,k]
-        bcat = [torch.cat((biases[i].detach(), torch.zeros(3, device=dev))) for i in range(K)] if has_bias else None
+        bcat = None
+        if has_bias:                                              # [K, Cout + 3]: the attention convolutions have no bias
+            bcat = _scratch.zeros((K, cout + 3), torch.float32, dev)
+            bcat[:, :cout] = torch.stack([b.detach() for b in biases])
         branches = torch.empty((K, N, cout + 3, H, W), dtype=torch.float32, device=dev)
-        if ops.dynconv_sbf_supported(Cin, cout + 3, ksizes, W):
-            # all kernel sizes from one staged tile on the matrix cores (split-bf16 arithmetic, fp32-level accuracy)
-            ops.dynconv_branches_sbf(x, ops.split_pack_dynconv(wcat), torch.stack(bcat).contiguous() if has_bias else None, cout + 3,
-                                     ksizes, out=branches)
+        need_dx = ctx.needs_input_grad[0]
+        packs = [pack_conv2d(convs[i], atts[i], fwd=True, dgrad=need_dx) for i in range(K)]
+        if N * H * W >= SBF_MIN_PIXELS and ops.dynconv_sbf_supported(Cin, cout + 3, ksizes, W):
+            # all kernel sizes from one staged tile on the matrix cores (split-bf16 arithmetic, fp32-level accuracy); its weight layout
+            # costs a dozen small launches, so small batches stay on the direct kernels
+            wcat = [torch.cat((convs[i].detach(), atts[i].detach()), dim=0) for i in range(K)]        # [Cout+3,Cin,k,k]
+            ops.dynconv_branches_sbf(x, ops.split_pack_dynconv(wcat), bcat, cout + 3, ksizes, out=branches)
         else:
             for i, k in enumerate(ksizes):
-                ops.conv2d(x, pack_conv(wcat[i]), bcat[i] if has_bias else None, cout + 3, k, 1, (k - 1) // 2, out=branches[i])
+                ops.conv2d(x, packs[i][0], bcat[i] if has_bias else None, cout + 3, k, 1, (k - 1) // 2, out=branches[i])
         use_batch = bool(bn.training or not bn.track_running_stats)
         G = groups if use_batch else 1
         if N % G:
@@ -193,13 +212,14 @@ class _DynConvFn(torch.autograd.Function):
                                            N, G, K, cout, H, W, float(bn.eps), float(momentum), 1 if use_batch else 0, st),
               "cds_dynconv_bn_stats_f32")
         if track:
-            bn.num_batches_tracked += G
+            _scratch.bump(bn.num_batches_tracked, G)
         y = torch.empty((N, cout, H, W), dtype=torch.float32, device=dev)
         nc = torch.empty((N, 1, H, W), dtype=torch.float32, device=dev)
         gm, bt = gamma.detach().contiguous(), beta.detach().contiguous()
         check(lib.cds_dynconv_blend_train_f32(_p(branches), _p(epi), _p(w1m), _p(w2m), _p(gm), _p(bt), _p(mean), _p(rstd), float(T),
                                               y.data_ptr(), nc.data_ptr(), N, G, K, cout, H, W, st), "cds_dynconv_blend_train_f32")
         ctx.save_for_backward(x, epi, branches, mean, rstd, *params)
+        ctx.dgrad_packs = [pk[1] for pk in packs]
         ctx.cfg = (float(T), G, tuple(ksizes), has_bias, use_batch)
         return y, nc
 
@@ -237,11 +257,10 @@ class _DynConvFn(torch.autograd.Function):
         g_atts: List[Optional[Tensor]] = []
         g_bias: List[Optional[Tensor]] = []
         for i, k in enumerate(ksizes):
-            wcat = torch.cat((convs[i].detach(), atts[i].detach()), dim=0).float()
             if ctx.needs_input_grad[0]:
                 if dx is None:
                     dx = torch.empty_like(x)
-                ops.conv2d(gbr[i], pack_dgrad(wcat), None, Cin, k, 1, (k - 1) // 2, act=ACT_NONE if i == 0 else ACT_ACCUM, out=dx)
+                ops.conv2d(gbr[i], ctx.dgrad_packs[i], None, Cin, k, 1, (k - 1) // 2, act=ACT_NONE if i == 0 else ACT_ACCUM, out=dx)
             dw = conv2d_wgrad(gbr[i], x, k, 1, (k - 1) // 2)
             g_convs.append(dw[:cout])
             g_atts.append(dw[cout:])
@@ -292,6 +311,17 @@ class SoftArgmin(torch.autograd.Function):
         return gp, None
 
 
+_GROUP_WEIGHTS = {}
+
+
+def _group_weights(m: float, groups: int, device) -> Tensor:
+    """m (1 - m)^(G-1-g), g = 0..G-1, on the device (cached: built once, no host-to-device copy per step)."""
+    key = (m, groups, str(device))
+    if key not in _GROUP_WEIGHTS:
+        _GROUP_WEIGHTS[key] = torch.tensor([m * (1.0 - m) ** (groups - 1 - g) for g in range(groups)], dtype=torch.float32).to(device)
+    return _GROUP_WEIGHTS[key]
+
+
 def bn_relu2d(bn, y: Tensor, relu: bool = True, groups: int = 1) -> Tensor:
     """BatchNorm2d in the module's mode (+ ReLU) on the BatchNorm kernels of train3d.hip (a [B,C,H,W] map is a one-slice volume).
     groups > 1: y stacks that many separate calls of the module along the batch axis (group-major); the batch statistics are taken
@@ -305,27 +335,28 @@ def bn_relu2d(bn, y: Tensor, relu: bool = True, groups: int = 1) -> Tensor:
         # group g, channel c -> channel g C + c of ONE BatchNorm call over B samples
         yv = y.reshape(1, GB * C, 1, H, W) if B == 1 else y.view(groups, B, C, H, W).transpose(0, 1).reshape(B, groups * C, 1, H, W)
         track = bn.track_running_stats and bn.running_mean is not None
-        tm = torch.zeros((groups * C,), dtype=torch.float32, device=y.device) if track else None
-        tv = torch.zeros_like(tm) if track else None
+        tm = _scratch.zeros((groups * C,), torch.float32, y.device) if track else None
+        tv = _scratch.zeros((groups * C,), torch.float32, y.device) if track else None
         out = train_ops.BnRelu3d.apply(yv, bn.weight.repeat(groups), bn.bias.repeat(groups), None, tm, tv, 1.0, bn.eps, relu)
         if track:                                                        # momentum 1 left the batch mean / unbiased variance in tm / tv
             with torch.no_grad():
                 tm, tv = tm.view(groups, C), tv.view(groups, C)
-                for g in range(groups):
-                    bn.num_batches_tracked += 1
-                    m = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
-                    bn.running_mean.mul_(1.0 - m).add_(tm[g], alpha=m)
-                    bn.running_var.mul_(1.0 - m).add_(tv[g], alpha=m)
+                if bn.momentum is not None:                          # one fused update: r (1-m)^G + sum_g m (1-m)^(G-1-g) stat_g
+                    m = float(bn.momentum)
+                    wts = _group_weights(m, groups, y.device)
+                    bn.running_mean.mul_((1.0 - m) ** groups).addmv_(tm.t(), wts)
+                    bn.running_var.mul_((1.0 - m) ** groups).addmv_(tv.t(), wts)
+                    _scratch.bump(bn.num_batches_tracked, groups)
+                else:
+                    for g in range(groups):
+                        bn.num_batches_tracked += 1
+                        m = 1.0 / float(bn.num_batches_tracked)
+                        bn.running_mean.mul_(1.0 - m).add_(tm[g], alpha=m)
+                        bn.running_var.mul_(1.0 - m).add_(tv[g], alpha=m)
         out = out.view(GB, C, H, W) if B == 1 else out.view(B, groups, C, H, W).transpose(0, 1).reshape(GB, C, H, W)
         return out
     if bn.training:
-        momentum = bn.momentum
-        if bn.num_batches_tracked is not None:
-            bn.num_batches_tracked += 1
-            if momentum is None:                                         # cumulative moving average (nn.BatchNorm semantics)
-                momentum = 1.0 / float(bn.num_batches_tracked)
-        if momentum is None:
-            momentum = 0.0
+        momentum = train_ops.bn_momentum_and_count(bn)
         return train_ops.BnRelu3d.apply(y.unsqueeze(2), bn.weight, bn.bias, None, bn.running_mean, bn.running_var, float(momentum),
                                         bn.eps, relu).squeeze(2)
     out = F.batch_norm(y, bn.running_mean, bn.running_var, bn.weight, bn.bias, False, 0.0, bn.eps)

@@ -16,7 +16,7 @@ from typing import Optional
 
 import torch
 
-from . import _lib, ops
+from . import _lib, _scratch, ops
 from ._lib import check
 
 Tensor = torch.Tensor
@@ -32,7 +32,7 @@ def conv3d_wgrad(g: Tensor, xin: Tensor, stride: int) -> Tensor:
     Bx, Cb, Di, Hi, Wi = xin.shape
     if Bx != B:
         raise ValueError("conv3d_wgrad: batch mismatch")
-    dw = torch.zeros((Ca, Cb, 3, 3, 3), dtype=torch.float32, device=g.device)
+    dw = _scratch.zeros((Ca, Cb, 3, 3, 3), torch.float32, g.device)
     check(_lib.load().cds_conv3d_wgrad_f32(_dev(g), _dev(xin), dw.data_ptr(), B, Ca, Cb, Do, Ho, Wo, Di, Hi, Wi, stride,
                                            ops._stream(g)), "cds_conv3d_wgrad_f32")
     return dw
@@ -103,7 +103,7 @@ class BnRelu3d(torch.autograd.Function):
         V = y[0, 0].numel()
         n = B * V
         lib = _lib.load()
-        sums = torch.zeros((C, 2), dtype=torch.float64, device=y.device)
+        sums = _scratch.zeros((C, 2), torch.float64, y.device)
         check(lib.cds_bn3d_stats_f32(_dev(y), sums.data_ptr(), B, C, V, ops._stream(y)), "cds_bn3d_stats_f32")
         # per-channel step in ONE launch (fp64): scale / shift, the saved mean / invstd, the running-statistics update
         scale = torch.empty((C,), dtype=torch.float32, device=y.device)
@@ -133,7 +133,7 @@ class BnRelu3d(torch.autograd.Function):
         V = y[0, 0].numel()
         n = ctx.n
         lib = _lib.load()
-        sums = torch.zeros((C, 2), dtype=torch.float64, device=y.device)
+        sums = _scratch.zeros((C, 2), torch.float64, y.device)
         check(lib.cds_bn3d_bwd_reduce_f32(_dev(dout), _dev(y), _dev(scale), _dev(shift), sums.data_ptr(), B, C, V,
                                           1 if ctx.relu else 0, ops._stream(y)), "cds_bn3d_bwd_reduce_f32")
         k1 = torch.empty((C,), dtype=torch.float32, device=y.device)
@@ -148,19 +148,26 @@ class BnRelu3d(torch.autograd.Function):
                 None, None, None, None, None)
 
 
+def bn_momentum_and_count(bn) -> float:
+    """The momentum of this training-mode call of a BatchNorm module, counting the call in num_batches_tracked (nn.BatchNorm semantics:
+    momentum None = cumulative moving average)."""
+    momentum = bn.momentum
+    if bn.num_batches_tracked is not None:
+        if momentum is None:
+            bn.num_batches_tracked += 1
+            momentum = 1.0 / float(bn.num_batches_tracked)
+        else:
+            _scratch.bump(bn.num_batches_tracked, 1)
+    return 0.0 if momentum is None else float(momentum)
+
+
 def conv_bn_relu3d(unit, x: Tensor, skip: Optional[Tensor] = None) -> Tensor:
     """One ConvBn3d holder (model.py) in its module mode: training -> batch statistics (and running-stat update),
     eval -> running statistics; Conv3d / ConvTranspose3d + BatchNorm3d + ReLU (+ skip), all on the HIP kernels."""
     y = Conv3dK3.apply(x, unit.conv.weight, unit.stride, unit.transposed)
     bn = unit.bn
     if bn.training:
-        momentum = bn.momentum
-        if bn.num_batches_tracked is not None:
-            bn.num_batches_tracked += 1
-            if momentum is None:                                         # cumulative moving average (nn.BatchNorm semantics)
-                momentum = 1.0 / float(bn.num_batches_tracked)
-        if momentum is None:
-            momentum = 0.0
+        momentum = bn_momentum_and_count(bn)
         return BnRelu3d.apply(y, bn.weight, bn.bias, skip, bn.running_mean, bn.running_var, float(momentum), bn.eps, True)
     out = torch.relu(torch.nn.functional.batch_norm(y, bn.running_mean, bn.running_var, bn.weight, bn.bias, False, 0.0, bn.eps))
     return out if skip is None else skip + out

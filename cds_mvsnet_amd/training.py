@@ -16,7 +16,7 @@ from typing import Dict, List, Optional, Tuple
 import torch
 import torch.nn.functional as F
 
-from . import geometry, ops
+from . import _scratch, geometry, ops
 
 Tensor = torch.Tensor
 
@@ -239,6 +239,7 @@ def forward_train(model, imgs: Tensor, proj_matrices: Dict[str, Tensor], depth_v
     H, W = (Him // 2, Wim // 2) if model.refine else (Him, Wim)
     T = float(temperature)
     dev = imgs.device
+    _scratch.begin_step(dev)                                             # zero arena + deferred counters of this step's HIP training ops
     dv = depth_values.detach().float().cpu()
     cams = {k: v.detach().float().cpu() for k, v in proj_matrices.items()}
     V = N - 1
@@ -300,4 +301,5 @@ def forward_train(model, imgs: Tensor, proj_matrices: Dict[str, Tensor], depth_v
         outputs["refined_depth"] = refined.squeeze(1) * dint
     else:
         outputs["refined_depth"] = depth
+    _scratch.flush_counters(dev)
     return outputs

@@ -468,6 +468,9 @@ int cds_dynconv_blend_bwd_f32(const float* branches, const float* epipoles, cons
                               const float* beta, const float* mean, const float* rstd, float temperature, const float* gy,
                               const float* gnc, float* gbr, double* sums, double* dw1, int N, int G, int K, int Cout, int H, int W,
                               int use_batch, void* stream);
+/* The weight layouts of cds_conv2d_f32 in one launch: fwd [Cin][k k][CoP] (forward) and / or dgrad [Ca+Cb][k k][CiP] (stride-1 data
+ * gradient: taps flipped, channels swapped) from wa [Ca][Cin][k][k] and, optionally, wb [Cb][Cin][k][k] stacked behind it. */
+int cds_pack_conv2d_f32(const float* wa, const float* wb, float* fwd, float* dgrad, int Ca, int Cb, int Cin, int k, void* stream);
 int cds_softargmin_bwd_f32(const float* prob_pre, const float* hyp, const float* gdepth, float* gpre, int D, int h, int w,
                            int hyp_per_pixel, void* stream);
 
