@@ -90,6 +90,7 @@ SIGNATURES = {
     "cds_dynconv_blend_train_f32": [P, P, P, P, P, P, P, P, F, P, P, I, I, I, I, I, I, P],
     "cds_dynconv_blend_bwd_f32": [P, P, P, P, P, P, P, P, F, P, P, P, P, P, I, I, I, I, I, I, I, P],
     "cds_pack_conv2d_f32": [P, P, P, P, I, I, I, I, P],
+    "cds_pack_conv3d_f32": [P, P, P, I, I, I, P],
     "cds_softargmin_bwd_f32": [P, P, P, P, I, I, I, I, P],
     "cds_depth_fusion_f32": [P, P, P, P, P, P, P, P, P, I, I, I, P, F, F, F, P],
 }

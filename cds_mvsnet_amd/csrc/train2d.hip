@@ -584,6 +584,25 @@ __global__ void pack_conv2d_kernel(const float* __restrict__ wa, const float* __
   }
 }
 
+// The two weight layouts of a 3x3x3 CostRegNet layer (forward kernel, data-gradient kernel) in one launch.  a = outer, b = inner
+// channel count of w [a][b][27]; mode 0: Conv3d stride 1 (w [Co][Cin]: fwd [Cin][27][Co], dgrad [Co][27][Cin] with flipped taps),
+// mode 1: Conv3d stride 2 (dgrad = the transposed convolution's layout, taps as they are), mode 2: ConvTranspose3d (w [Cin][Cout]:
+// fwd [Cin][27][Cout], dgrad [Cout][27][Cin] = the stride-2 convolution it is the transpose of).
+__global__ void pack_conv3d_kernel(const float* __restrict__ w, float* __restrict__ fwd, float* __restrict__ dgrad, int A, int B, int mode) {
+  const int n = A * B * 27;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int t = i % 27, b = (i / 27) % B, a = i / (27 * B);
+    const float v = w[i];
+    if (mode == 2) {                                    // a = ci, b = co
+      if (fwd) fwd[((size_t)a * 27 + t) * B + b] = v;
+      if (dgrad) dgrad[((size_t)b * 27 + t) * A + a] = v;
+    } else {                                            // a = co, b = ci
+      if (fwd) fwd[((size_t)b * 27 + t) * A + a] = v;
+      if (dgrad) dgrad[((size_t)a * 27 + (mode == 0 ? 26 - t : t)) * B + b] = v;
+    }
+  }
+}
+
 template <int K>
 int blend_dispatch(int what, const BlendArgs& a, float* out, float* nc, const float* gy, const float* gnc, double* sums, double count,
                    int use_batch, float* gbr, double* dw1, hipStream_t st) {
@@ -732,5 +751,14 @@ extern "C" int cds_pack_conv2d_f32(const float* wa, const float* wb, float* fwd,
   const int n = (fwd ? Cin * kk * ((Co + 7) & ~7) : 0) + (dgrad ? Co * kk * ((Cin + 7) & ~7) : 0);
   hipLaunchKernelGGL(pack_conv2d_kernel, dim3(cds_ceil_div(n, 256) > 64 ? 64 : cds_ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream,
                      wa, wb, fwd, dgrad, Ca, Cb, Cin, kk);
+  return cds_launch_status();
+}
+
+// w [A][B][27] -> fwd / dgrad (either may be NULL), see pack_conv3d_kernel.
+extern "C" int cds_pack_conv3d_f32(const float* w, float* fwd, float* dgrad, int A, int B, int mode, void* stream) {
+  if (!w || (!fwd && !dgrad) || A < 1 || B < 1 || mode < 0 || mode > 2) return CDS_EINVAL;
+  const int n = A * B * 27;
+  hipLaunchKernelGGL(pack_conv3d_kernel, dim3(cds_ceil_div(n, 256) > 128 ? 128 : cds_ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, w,
+                     fwd, dgrad, A, B, mode);
   return cds_launch_status();
 }

@@ -45,6 +45,19 @@ def _per_item(fn, x: Tensor) -> Tensor:
     return torch.stack([fn(x[b]) for b in range(x.shape[0])])
 
 
+def pack_conv3d(w: Tensor, mode: int, dgrad: bool):
+    """(forward layout, data-gradient layout | None) of a 3x3x3 weight in one launch (cds_pack_conv3d_f32; mode 0 / 1: Conv3d stride
+    1 / 2, mode 2: ConvTranspose3d)."""
+    a, b = w.shape[:2]
+    w = w.detach().float().contiguous()
+    cin, cout = (a, b) if mode == 2 else (b, a)
+    f = torch.empty((cin, 27, cout), dtype=torch.float32, device=w.device)
+    d = torch.empty((cout, 27, cin), dtype=torch.float32, device=w.device) if dgrad else None
+    check(_lib.load().cds_pack_conv3d_f32(_dev(w), f.data_ptr(), d.data_ptr() if dgrad else None, a, b, mode, ops._stream(w)),
+          "cds_pack_conv3d_f32")
+    return f, d
+
+
 class Conv3dK3(torch.autograd.Function):
     """x [B,Cin,D,H,W], weight (Conv3d: [Cout,Cin,3,3,3]; ConvTranspose3d: [Cin,Cout,3,3,3]) -> y."""
 
@@ -54,13 +67,9 @@ class Conv3dK3(torch.autograd.Function):
         x = x.contiguous()
         ctx.save_for_backward(x, weight)
         ctx.stride, ctx.transposed = stride, transposed
-        w = weight.detach()
+        wpk, ctx.dgrad_pack = pack_conv3d(weight, 2 if transposed else (0 if stride == 1 else 1), ctx.needs_input_grad[0])
         if transposed:
-            cin, cout = w.shape[:2]
-            wpk = w.permute(0, 2, 3, 4, 1).reshape(cin, 27, cout).contiguous()
             return _per_item(lambda xb: ops.deconv3d_k3s2(xb, wpk, None, relu=False), x)
-        cout, cin = w.shape[:2]
-        wpk = w.permute(1, 2, 3, 4, 0).reshape(cin, 27, cout).contiguous()
         return _per_item(lambda xb: ops.conv3d_k3(xb, wpk, None, stride=stride, relu=False), x)
 
     @staticmethod
@@ -74,19 +83,16 @@ class Conv3dK3(torch.autograd.Function):
         if ctx.transposed:                                   # y = convT(x, w[Cin,Cout]):  dx = conv_s2(dy, w as [Cout'=Cin][Cin'=Cout])
             cin, cout = w.shape[:2]
             if ctx.needs_input_grad[0]:
-                wpk = w.permute(1, 2, 3, 4, 0).reshape(cout, 27, cin).contiguous()
-                dx = _per_item(lambda gb: ops.conv3d_k3(gb, wpk, None, stride=2, relu=False), dy)
+                dx = _per_item(lambda gb: ops.conv3d_k3(gb, ctx.dgrad_pack, None, stride=2, relu=False), dy)
             if ctx.needs_input_grad[1]:
                 dw = conv3d_wgrad(x, dy, 2)                  # [Cin,Cout,3,3,3]
         else:
             cout, cin = w.shape[:2]
             if ctx.needs_input_grad[0]:
                 if ctx.stride == 1:                          # dx = conv(dy, flipped taps, channels swapped)
-                    wpk = w.flip(2, 3, 4).permute(0, 2, 3, 4, 1).reshape(cout, 27, cin).contiguous()
-                    dx = _per_item(lambda gb: ops.conv3d_k3(gb, wpk, None, relu=False), dy)
+                    dx = _per_item(lambda gb: ops.conv3d_k3(gb, ctx.dgrad_pack, None, relu=False), dy)
                 else:                                        # dx = convT(dy, w)
-                    wpk = w.permute(0, 2, 3, 4, 1).reshape(cout, 27, cin).contiguous()
-                    dx = _per_item(lambda gb: ops.deconv3d_k3s2(gb, wpk, None, relu=False), dy)
+                    dx = _per_item(lambda gb: ops.deconv3d_k3s2(gb, ctx.dgrad_pack, None, relu=False), dy)
             if ctx.needs_input_grad[1]:
                 dw = conv3d_wgrad(dy, x, ctx.stride)         # [Cout,Cin,3,3,3]
         return dx, dw, None, None

@@ -174,6 +174,11 @@ def _visibility(seq, x: Tensor, groups: int = 1) -> Tensor:
     return torch.sigmoid(_conv(seq[3], x))
 
 
+def _stack(ts: List[Tensor]) -> Tensor:
+    """torch.stack along a new batch axis; a batch of one is a view, not a copy."""
+    return ts[0].unsqueeze(0) if len(ts) == 1 else torch.stack(ts)
+
+
 def stage_forward_train(stage_net, features, cams: Tensor, depth_values: Tensor, cost_reg, stage_idx: int,
                         gt_depth: Optional[Tensor] = None) -> Dict[str, Tensor]:
     """``StageNet.forward`` in training mode (models/model.py:16-94 with ``self.training``), reference argument layout:
@@ -217,8 +222,8 @@ def stage_forward_train(stage_net, features, cams: Tensor, depth_values: Tensor,
             fd = torch.cat((fd, gt_sum.sum(dim=0) / denom), dim=0)
         fds.append(fd)
     nc_mean = sum((features[v]["ref"][1] + features[v]["src"][1]) / 2 for v in range(V)) / V       # [B,1,h,w]
-    hyp_b = torch.stack(hyps)
-    prob_pre = cost_regularization(cost_reg, torch.stack(vols)).squeeze(1).float()
+    hyp_b = _stack(hyps)
+    prob_pre = cost_regularization(cost_reg, _stack(vols)).squeeze(1).float()
     if _hip2d(prob_pre):
         from . import train2d_ops
         depth = train2d_ops.SoftArgmin.apply(prob_pre, hyp_b)
@@ -226,7 +231,7 @@ def stage_forward_train(stage_net, features, cams: Tensor, depth_values: Tensor,
         depth = torch.sum(F.softmax(prob_pre, dim=1) * hyp_b, dim=1)
     with torch.no_grad():
         conf = torch.stack([ops.softargmin_conf(prob_pre[b].detach().contiguous(), hyp_b[b])[1] for b in range(B)])
-    return {"depth": depth, "photometric_confidence": conf, "feat_distance": torch.stack(fds), "norm_curv": nc_mean}
+    return {"depth": depth, "photometric_confidence": conf, "feat_distance": _stack(fds), "norm_curv": nc_mean}
 
 
 def forward_train(model, imgs: Tensor, proj_matrices: Dict[str, Tensor], depth_values: Tensor,

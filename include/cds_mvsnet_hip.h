@@ -471,6 +471,10 @@ int cds_dynconv_blend_bwd_f32(const float* branches, const float* epipoles, cons
 /* The weight layouts of cds_conv2d_f32 in one launch: fwd [Cin][k k][CoP] (forward) and / or dgrad [Ca+Cb][k k][CiP] (stride-1 data
  * gradient: taps flipped, channels swapped) from wa [Ca][Cin][k][k] and, optionally, wb [Cb][Cin][k][k] stacked behind it. */
 int cds_pack_conv2d_f32(const float* wa, const float* wb, float* fwd, float* dgrad, int Ca, int Cb, int Cin, int k, void* stream);
+/* The forward and data-gradient weight layouts of a 3x3x3 CostRegNet layer in one launch.  w [A][B][27]; mode 0: Conv3d stride 1
+ * (A = Cout, B = Cin): fwd [Cin][27][Cout], dgrad [Cout][27][Cin] with flipped taps; mode 1: Conv3d stride 2: dgrad [Cout][27][Cin]
+ * unflipped (cds_deconv3d_k3s2_f32's layout); mode 2: ConvTranspose3d (A = Cin, B = Cout): fwd [Cin][27][Cout], dgrad [Cout][27][Cin]. */
+int cds_pack_conv3d_f32(const float* w, float* fwd, float* dgrad, int A, int B, int mode, void* stream);
 int cds_softargmin_bwd_f32(const float* prob_pre, const float* hyp, const float* gdepth, float* gpre, int D, int h, int w,
                            int hyp_per_pixel, void* stream);
 
