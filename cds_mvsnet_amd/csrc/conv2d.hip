@@ -27,6 +27,12 @@
 #define CDS_C2_CHUNK3S2 2   // stride 2: 242 vs 254 us (8->16, 1600x1184), 176 vs 190 us (16->32, 800x592)
 #endif
 
+#ifdef CDS_CONV2D_NO_ACCUM          // A/B knob: the epilogues without the CDS_ACT_ACCUM path (gradient accumulation of train2d_ops.py)
+#define C2_ACCUM 0
+#else
+#define C2_ACCUM CDS_ACT_ACCUM
+#endif
+
 namespace {
 
 constexpr int CO = 8;
@@ -169,7 +175,7 @@ __global__ __launch_bounds__(256) void conv2d_kernel(const float* __restrict__ x
       const size_t base = ((size_t)n * Cout + co0 + c) * oplane + (size_t)oy * Wo + oxb;
 #pragma unroll
       for (int p = 0; p < PX; ++p)
-        if (oxb + p < Wo) out[base + p] = cds_act_conv(acc[p][c] + b, act & 15) + ((act & CDS_ACT_ACCUM) ? out[base + p] : 0.f);
+        if (oxb + p < Wo) out[base + p] = cds_act_conv(acc[p][c] + b, act & 15) + ((act & C2_ACCUM) ? out[base + p] : 0.f);
     }
   }
 }
@@ -322,14 +328,14 @@ __global__ __launch_bounds__(256) void conv2d_pipe_kernel(const float* __restric
       const size_t base = ((size_t)n * Cout + co0 + c) * oplane + (size_t)oy * Wo + oxb;
       if (vec) {
         float4 prev = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (act & CDS_ACT_ACCUM) prev = *reinterpret_cast<const float4*>(out + base);
+        if (act & C2_ACCUM) prev = *reinterpret_cast<const float4*>(out + base);
         *reinterpret_cast<float4*>(out + base) =
             make_float4(cds_act_conv(acc[0][c] + b, act & 15) + prev.x, cds_act_conv(acc[1 % PX][c] + b, act & 15) + prev.y,
                         cds_act_conv(acc[2 % PX][c] + b, act & 15) + prev.z, cds_act_conv(acc[3 % PX][c] + b, act & 15) + prev.w);
       } else {
 #pragma unroll
         for (int p = 0; p < PX; ++p)
-          if (oxb + p < Wo) out[base + p] = cds_act_conv(acc[p][c] + b, act & 15) + ((act & CDS_ACT_ACCUM) ? out[base + p] : 0.f);
+          if (oxb + p < Wo) out[base + p] = cds_act_conv(acc[p][c] + b, act & 15) + ((act & C2_ACCUM) ? out[base + p] : 0.f);
       }
     }
   }

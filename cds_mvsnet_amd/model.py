@@ -344,8 +344,8 @@ class CostRegNet(_PackedHolder):
 class Refinement(_PackedHolder):
     """2x depth up-sampling with image guidance (module.py:318-370).  Eval mode runs on the HIP
     kernels (3x3 Conv+BN+ReLU units on cds_conv2d_f32 with the BatchNorm folded in, the transposed conv, the depth
-    pre-scale and the bilinear-upsample + residual epilogue in refine.hip); training mode keeps PyTorch autograd ops
-    like the other convolution stacks (training.py)."""
+    pre-scale and the bilinear-upsample + residual epilogue in refine.hip); training mode runs the HIP forward /
+    backward training ops (train2d_ops.refinement; torch autograd ops with CDS_TRAIN_HIP2D=0 or on the CPU)."""
 
     def __init__(self):
         super().__init__()

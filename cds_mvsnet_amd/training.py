@@ -1,12 +1,12 @@
 """Training-mode forward of CDSMVSNet (reference: models/model.py:52-56,63-69,140-223 with ``self.training``).
 
-SURVEY §8(f)-2, first step.  What is native here: the fused homography warp + visibility-weighted aggregation runs on
-the hand-written HIP kernels in BOTH directions (``ops.WarpAggregate``: K3 forward, scatter-add backward), as do the
-no-gradient pieces (K1 entropy, hypothesis generation, confidence).  The convolution stacks (FeatureNet, visibility
-CNN, CostRegNet with batch-statistics BatchNorm, Refinement) run on stock PyTorch-ROCm autograd ops through the same
-parameter-holder modules, so ``state_dict`` / optimisers / checkpoints are unchanged; their HIP backward kernels are
-the next step.  Gradient topology follows the reference: the sampling grid has no gradient, the entropy input of the
-visibility CNN is detached, depth is detached between stages.
+SURVEY §8(f)-2.  Every stack runs on the hand-written HIP kernels in BOTH directions: the fused homography warp + visibility-weighted
+aggregation (``ops.WarpAggregate``: K3 forward, scatter-add backward), CostRegNet with batch-statistics BatchNorm (``train_ops.py``),
+and the 2D stacks - FeatureNet / DynamicConv, visibility CNN, Refinement, soft-argmin (``train2d_ops.py``); the no-gradient pieces
+(K1 entropy, hypothesis generation, confidence) use the inference kernels.  The parameter-holder modules are the inference ones, so
+``state_dict`` / optimisers / checkpoints are unchanged.  The torch-op forms of the 2D stacks below (``_dynamic_conv`` ...) are the
+CPU / ``CDS_TRAIN_HIP2D=0`` path and the float64 reference of tests/test_train2d_gpu.py.  Gradient topology follows the reference: the
+sampling grid has no gradient, the entropy input of the visibility CNN is detached, depth is detached between stages.
 """
 from __future__ import annotations
 
