@@ -174,6 +174,62 @@ def _visibility(seq, x: Tensor, groups: int = 1) -> Tensor:
     return torch.sigmoid(_conv(seq[3], x))
 
 
+class StackedFeatures:
+    """The FeatureNet outputs of one stage for all 2 V B images of a stacked call, in the reference's call order (pair v: its reference
+    image for every batch item, then its source image): fea [2 V B,C,h,w], nc_sum / nc [2 V B,1,h,w].  `stage_forward_train` reads the
+    K1 / K3 operands, the visibility CNN's curvature input and the curvature regulariser straight from these tensors: slicing them per
+    (pair, image) and stacking the slices again costs a full-size zero fill + copy + add per slice in the backward (~250 launches and
+    2 ms of the config-5 step)."""
+
+    def __init__(self, fea: Tensor, nc_sum: Tensor, nc: Tensor, V: int, B: int):
+        self.fea, self.nc_sum, self.nc, self.V, self.B = fea, nc_sum, nc, V, B
+
+    def __len__(self) -> int:
+        return self.V
+
+    def as_list(self):
+        """The reference's argument layout (list over source views of {'ref': ..., 'src': ...})."""
+        B = self.B
+        ts = (self.fea, self.nc_sum, self.nc)
+        return [{"ref": tuple(t[2 * v * B:(2 * v + 1) * B] for t in ts), "src": tuple(t[(2 * v + 1) * B:(2 * v + 2) * B] for t in ts)}
+                for v in range(self.V)]
+
+
+class _PairSplit(torch.autograd.Function):
+    """fea [2 V B,C,h,w] (pair-major: ref images of pair v, then its src images) -> for every batch item b the K1 / K3 operands
+    ref_b [V,C,h,w] and src_b [V,h,w,C] (channels-last), 2 B copies; the backward writes every gradient into ONE dense tensor."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, fea, V: int, B: int):
+        f = fea.view(V, 2, B, *fea.shape[1:])
+        ctx.cfg = (V, B, tuple(fea.shape))
+        ctx.set_materialize_grads(False)
+        out = []
+        for b in range(B):
+            out.append(f[:, 0, b].contiguous())
+            out.append(f[:, 1, b].permute(0, 2, 3, 1).contiguous())
+        return tuple(out)
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, *grads):
+        V, B, shape = ctx.cfg
+        ref = next(g for g in grads if g is not None)
+        gf = torch.empty(shape, dtype=torch.float32, device=ref.device).view(V, 2, B, *shape[1:])
+        for b in range(B):
+            g_ref, g_src = grads[2 * b], grads[2 * b + 1]
+            if g_ref is None:
+                gf[:, 0, b].zero_()
+            else:
+                gf[:, 0, b].copy_(g_ref)
+            if g_src is None:
+                gf[:, 1, b].zero_()
+            else:
+                gf[:, 1, b].copy_(g_src.permute(0, 3, 1, 2))
+        return gf.view(shape), None, None
+
+
 def _stack(ts: List[Tensor]) -> Tensor:
     """torch.stack along a new batch axis; a batch of one is a view, not a copy."""
     return ts[0].unsqueeze(0) if len(ts) == 1 else torch.stack(ts)
@@ -186,6 +242,9 @@ def stage_forward_train(stage_net, features, cams: Tensor, depth_values: Tensor,
     cams [B,N,2,4,4] (host); depth_values [B,D,h,w].  Returns depth / photometric_confidence / feat_distance / norm_curv.
     K1 (detached, model.py:49), hypotheses and confidence run on the HIP kernels without gradient; K3 forward / backward and
     CostRegNet forward / backward on the HIP kernels with gradient; the visibility CNN on PyTorch-ROCm autograd ops."""
+    stacked = features if isinstance(features, StackedFeatures) else None
+    if stacked is not None and not _hip2d(stacked.fea):
+        features, stacked = stacked.as_list(), None
     V = len(features)
     B = depth_values.shape[0]
     if gt_depth is not None and gt_depth.dim() == 4:                    # the reference passes gt_depths[stage].unsqueeze(1): [B,1,h,w]
@@ -196,19 +255,25 @@ def stage_forward_train(stage_net, features, cams: Tensor, depth_values: Tensor,
     mats = [geometry.warp_matrices(cams[b]) for b in range(B)]
     hyps = [depth_values[b].detach().float().contiguous() for b in range(B)]
     # .float(): under bf16 autocast the convolution stacks hand over bf16 activations; the HIP kernels are fp32
-    ref = [torch.stack([features[v]["ref"][0][b] for v in range(V)]).float() for b in range(B)]         # [V,C,h,w]
-    src = [torch.stack([features[v]["src"][0][b] for v in range(V)]).float().permute(0, 2, 3, 1).contiguous() for b in range(B)]
+    if stacked is not None:
+        parts = _PairSplit.apply(stacked.fea, V, B)
+        ref, src = [parts[2 * b] for b in range(B)], [parts[2 * b + 1] for b in range(B)]
+        nc6 = stacked.nc.float().view(V, 2, B, *stacked.nc.shape[2:])                                     # [V,2,B,h,w]
+    else:
+        ref = [torch.stack([features[v]["ref"][0][b] for v in range(V)]).float() for b in range(B)]         # [V,C,h,w]
+        src = [torch.stack([features[v]["src"][0][b] for v in range(V)]).float().permute(0, 2, 3, 1).contiguous() for b in range(B)]
     with torch.no_grad():                                               # K1, detached input (model.py:49)
         ent = torch.stack([ops.warp_entropy(ref[b].detach().contiguous(), src[b].detach(), mats[b], hyps[b])
                            for b in range(B)])                           # [B,V,h,w]
     if _hip2d(ent) and V > 1:
         # the V calls of model.py:51 as ONE call on the views stacked along the batch axis (BatchNorm statistics per view)
-        nc_ref = torch.stack([features[v]["ref"][2].float()[:, 0] for v in range(V)])                   # [V,B,h,w]
+        nc_ref = nc6[:, 0] if stacked is not None else torch.stack([features[v]["ref"][2].float()[:, 0] for v in range(V)])   # [V,B,h,w]
         x = torch.stack((ent.transpose(0, 1), nc_ref), dim=2).reshape(V * B, 2, ent.shape[-2], ent.shape[-1])
         vis_all = _visibility(stage_net.vis[stage_idx], x, groups=V).view(V, B, ent.shape[-2], ent.shape[-1])
         vis = [vis_all[v] for v in range(V)]
     else:
-        vis = [_visibility(stage_net.vis[stage_idx], torch.cat((ent[:, v:v + 1], features[v]["ref"][2].float()), dim=1))[:, 0]
+        flist = stacked.as_list() if stacked is not None else features
+        vis = [_visibility(stage_net.vis[stage_idx], torch.cat((ent[:, v:v + 1], flist[v]["ref"][2].float()), dim=1))[:, 0]
                for v in range(V)]                                        # V x [B,h,w]  (model.py:51)
     vols, fds = [], []
     for b in range(B):
@@ -221,7 +286,10 @@ def stage_forward_train(stage_net, features, cams: Tensor, depth_values: Tensor,
             gt_sum = ops.WarpAggregate.apply(ref[b], src[b], vis_b, mats[b], gt_depth[b:b + 1].float().contiguous())
             fd = torch.cat((fd, gt_sum.sum(dim=0) / denom), dim=0)
         fds.append(fd)
-    nc_mean = sum((features[v]["ref"][1] + features[v]["src"][1]) / 2 for v in range(V)) / V       # [B,1,h,w]
+    if stacked is not None:                                                                         # sum_v ((ref + src) / 2) / V
+        nc_mean = stacked.nc_sum.view(V, 2, B, *stacked.nc_sum.shape[1:]).mean(dim=(0, 1))         # [B,1,h,w]
+    else:
+        nc_mean = sum((features[v]["ref"][1] + features[v]["src"][1]) / 2 for v in range(V)) / V   # [B,1,h,w]
     hyp_b = _stack(hyps)
     prob_pre = cost_regularization(cost_reg, _stack(vols)).squeeze(1).float()
     if _hip2d(prob_pre):
@@ -260,10 +328,7 @@ def forward_train(model, imgs: Tensor, proj_matrices: Dict[str, Tensor], depth_v
         e_all = torch.tensor([epi[v][b][k] for v in range(V) for k in (0, 1) for b in range(B)], dtype=torch.float32, device=dev)
         x_all = torch.cat([t for v in range(V) for t in (ref_img, F.interpolate(imgs[:, v + 1], (H, W)))], dim=0)
         f_all = feature_net(model.feature, x_all, e_all, T, groups=2 * V)
-        for v in range(V):
-            r0, s0 = 2 * v * B, (2 * v + 1) * B
-            feats.append(({k: tuple(t[r0:r0 + B] for t in f_all[k]) for k in f_all},
-                          {k: tuple(t[s0:s0 + B] for t in f_all[k]) for k in f_all}))
+        stacked_feats = {k: StackedFeatures(*f_all[k], V, B) for k in f_all}
     else:
         for v in range(V):
             e_ref = torch.tensor([e[0] for e in epi[v]], dtype=torch.float32, device=dev)
@@ -286,7 +351,7 @@ def forward_train(model, imgs: Tensor, proj_matrices: Dict[str, Tensor], depth_v
             else:
                 hyps.append(ops.depth_hypotheses(depth[b].detach().contiguous(), D, H, W, scale,
                                                  float(model.depth_interals_ratio[s] * dint_all[b]), dmin, dmax))
-        features = [{"ref": feats[v][0][name], "src": feats[v][1][name]} for v in range(V)]
+        features = stacked_feats[name] if BATCH_FEATURES else [{"ref": feats[v][0][name], "src": feats[v][1][name]} for v in range(V)]
         hyp_b = torch.stack(hyps)
         st = stage_forward_train(model.stage_net, features, cams[name], hyp_b, model.cost_regularization[s], s,
                                  gt_depth=gt_depths[name] if gt_depths is not None else None)
