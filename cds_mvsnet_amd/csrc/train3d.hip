@@ -108,6 +108,11 @@ struct WCfg {
   static constexpr int OX = 8, OY = 4, OZ = 4, NO = OX * OY * OZ;
   static constexpr int IX = (OX - 1) * S + 3, IY = (OY - 1) * S + 3, IZ = (OZ - 1) * S + 3;
   static constexpr int NI = IX * IY * IZ;
+#ifdef CDS_WGRAD3D_NOPAD
+  static constexpr int GS = NO;
+#else
+  static constexpr int GS = NO + 4;      // row stride of the g tile in the MFMA kernel: the 16 channel rows a K-step reads fall on different banks
+#endif
 };
 
 template <int S>
@@ -185,8 +190,8 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_mfma_kernel(const float* __r
   using Cfg = WCfg<S>;
   typedef float f32x4 __attribute__((ext_vector_type(4)));
   extern __shared__ __attribute__((aligned(16))) float wlds[];
-  float* lg = wlds;                       // [16][NO]
-  float* lx = wlds + 16 * Cfg::NO;        // [8][NI]
+  float* lg = wlds;                       // [16][GS]
+  float* lx = wlds + 16 * Cfg::GS;        // [8][NI]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 15, kq = lane >> 4;
@@ -217,7 +222,7 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_mfma_kernel(const float* __r
       const int px = p % Cfg::OX, py = (p / Cfg::OX) % Cfg::OY, pz = p / (Cfg::OX * Cfg::OY);
       const int ox = ox0 + px, oy = oy0 + py, oz = oz0 + pz;
       const bool ok = a0 + ch < Ca && ox < Wo && oy < Ho && oz < Do;
-      lg[i] = ok ? g[((size_t)bi * Ca + a0 + ch) * vo + ((size_t)oz * Ho + oy) * Wo + ox] : 0.f;
+      lg[ch * Cfg::GS + p] = ok ? g[((size_t)bi * Ca + a0 + ch) * vo + ((size_t)oz * Ho + oy) * Wo + ox] : 0.f;
     }
     for (int i = tid; i < 8 * Cfg::NI; i += 256) {
       const int ch = i / Cfg::NI, p = i - ch * Cfg::NI;
@@ -232,7 +237,7 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_mfma_kernel(const float* __r
       const int p = 4 * ks + kq;                       // this lane's voxel of the K-step
       const int px = p % Cfg::OX, py = (p / Cfg::OX) % Cfg::OY, pz = p / (Cfg::OX * Cfg::OY);
       const int base = ((pz * S) * Cfg::IY + py * S) * Cfg::IX + px * S;
-      const float av = lg[j * Cfg::NO + p];
+      const float av = lg[j * Cfg::GS + p];
 #pragma unroll
       for (int q = 0; q < QW; ++q) {
         if (wave + 4 * q >= NBLK) continue;            // (wave-uniform)
@@ -346,11 +351,11 @@ extern "C" int cds_conv3d_wgrad_f32(const float* g, const float* xin, float* dw,
   if (!valu) {
     const dim3 gm(cds_ceil_div(ntiles * B, per), cds_ceil_div(Ca, 16), cds_ceil_div(Cb, 8));
     if (stride == 1) {
-      const size_t ldsb = (16 * WCfg<1>::NO + 8 * WCfg<1>::NI) * sizeof(float);
+      const size_t ldsb = (16 * WCfg<1>::GS + 8 * WCfg<1>::NI) * sizeof(float);
       hipLaunchKernelGGL(conv3d_wgrad_mfma_kernel<1>, gm, dim3(256), ldsb, (hipStream_t)stream, g, xin, dw, B, Ca, Cb, Do, Ho, Wo, Di,
                          Hi, Wi, tx, ty, ntiles, per);
     } else {
-      const size_t ldsb = (16 * WCfg<2>::NO + 8 * WCfg<2>::NI) * sizeof(float);
+      const size_t ldsb = (16 * WCfg<2>::GS + 8 * WCfg<2>::NI) * sizeof(float);
       hipLaunchKernelGGL(conv3d_wgrad_mfma_kernel<2>, gm, dim3(256), ldsb, (hipStream_t)stream, g, xin, dw, B, Ca, Cb, Do, Ho, Wo, Di,
                          Hi, Wi, tx, ty, ntiles, per);
     }
