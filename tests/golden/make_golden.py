@@ -443,9 +443,46 @@ def g10_formats():
     save("g10_formats", **out)
 
 
+def g11_loss():
+    """models/losses.py:6-48 (final_loss) on random stage outputs: the loss, the last depth loss and the gradient of every input
+    (two batch items, ragged masks, with and without stage weights / the refined depth)."""
+    from models.losses import final_loss as ref_loss
+    g = torch.Generator().manual_seed(SEED + 11)
+    shapes = {"stage1": (8, 12, 9), "stage2": (16, 24, 7), "stage3": (32, 48, 5)}
+    out = {}
+    inp, gt, mask = {}, {}, {}
+    for k, (h, w, D) in shapes.items():
+        inp[k] = {"depth": (500 + 50 * torch.rand(2, h, w, generator=g)).requires_grad_(True),
+                  "norm_curv": torch.rand(2, 1, h, w, generator=g).requires_grad_(True),
+                  "feat_distance": torch.randn(2, D, h, w, generator=g).requires_grad_(True),
+                  "feat_target": (torch.rand(2, D, h, w, generator=g) > 0.8).float()}
+        gt[k] = 500 + 50 * torch.rand(2, h, w, generator=g)
+        mask[k] = (torch.rand(2, h, w, generator=g) > 0.3).float()
+    inp["refined_depth"] = (500 + 50 * torch.rand(2, 32, 48, generator=g)).requires_grad_(True)
+    gt["stage4"] = 500 + 50 * torch.rand(2, 32, 48, generator=g)
+    mask["stage4"] = (torch.rand(2, 32, 48, generator=g) > 0.3).float()
+    interval = torch.tensor([2.5, 2.0])
+    for k in shapes:
+        for n in ("depth", "norm_curv", "feat_distance", "feat_target"):
+            out[f"{k}.{n}"] = inp[k][n].detach().clone()
+        out[f"{k}.gt"], out[f"{k}.mask"] = gt[k], mask[k]
+    out["refined_depth"], out["stage4.gt"], out["stage4.mask"], out["interval"] = inp["refined_depth"].detach().clone(), gt["stage4"], mask["stage4"], interval
+    for tag, kw in (("w", dict(dlossw=[0.5, 1.0, 2.0])), ("nw", dict())):
+        for t in [inp[k][n] for k in shapes for n in ("depth", "norm_curv", "feat_distance")] + [inp["refined_depth"]]:
+            t.grad = None
+        loss, dl = ref_loss(inp, gt, mask, depth_interval=interval, **kw)
+        loss.backward()
+        out[f"{tag}.loss"], out[f"{tag}.depth_loss"] = loss.detach().reshape(1), dl.detach().reshape(1)
+        for k in shapes:
+            for n in ("depth", "norm_curv", "feat_distance"):
+                out[f"{tag}.grad.{k}.{n}"] = inp[k][n].grad.clone()
+        out[f"{tag}.grad.refined_depth"] = inp["refined_depth"].grad.clone()
+    save("g11_loss", **out)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
     for fn in (g1_warp_aggregate, g2_costreg, g3_regress, g4_hypotheses, g5_features, g6_forward, g7_training_step,
-               g8_fusion, g9_feature_noise, g10_formats):
+               g8_fusion, g9_feature_noise, g10_formats, g11_loss):
         if not only or fn.__name__.split("_")[0] in only:
             fn()

@@ -134,3 +134,27 @@ def test_full_forward(tag, refine, seeded_state):
         assert (st["photometric_confidence"] - g[f"stage{s}_conf"]).abs().mean() < 1e-3, s
         assert (st["norm_curv"] - g[f"stage{s}_norm_curv"]).abs().max() < 1e-4, s
     assert (out["refined_depth"] - g["refined_depth"]).abs().mean() < 1e-3
+
+
+def test_final_loss_equals_reference_g11(golden):
+    """losses.final_loss (masked sums instead of the reference's boolean gathers) against the reference's loss, depth loss and
+    input gradients captured in G11 (models/losses.py:6-48)."""
+    from cds_mvsnet_amd import final_loss
+    g = golden("g11_loss")
+    stages = ("stage1", "stage2", "stage3")
+    for tag, kw in (("w", dict(dlossw=[0.5, 1.0, 2.0])), ("nw", dict())):
+        inp = {k: {"depth": g[f"{k}.depth"].clone().requires_grad_(True), "norm_curv": g[f"{k}.norm_curv"].clone().requires_grad_(True),
+                   "feat_distance": g[f"{k}.feat_distance"].clone().requires_grad_(True), "feat_target": g[f"{k}.feat_target"]} for k in stages}
+        inp["refined_depth"] = g["refined_depth"].clone().requires_grad_(True)
+        gt = {k: g[f"{k}.gt"] for k in stages + ("stage4",)}
+        mask = {k: g[f"{k}.mask"] for k in stages + ("stage4",)}
+        loss, dl = final_loss(inp, gt, mask, depth_interval=g["interval"], **kw)
+        loss.backward()
+        assert abs(loss.item() - g[f"{tag}.loss"].item()) <= 1e-5 * abs(g[f"{tag}.loss"].item())
+        assert abs(dl.item() - g[f"{tag}.depth_loss"].item()) <= 1e-5 * abs(g[f"{tag}.depth_loss"].item())
+        for k in stages:
+            for n in ("depth", "norm_curv", "feat_distance"):
+                ref = g[f"{tag}.grad.{k}.{n}"]
+                assert (inp[k][n].grad - ref).abs().max().item() <= 1e-5 * ref.abs().max().item(), (tag, k, n)
+        ref = g[f"{tag}.grad.refined_depth"]
+        assert (inp["refined_depth"].grad - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
