@@ -67,3 +67,47 @@ def zeros(shape: Sequence[int], dtype: torch.dtype, device: torch.device) -> tor
     if dtype == torch.float32:
         sl = sl.view(torch.float32)
     return sl[:numel].view(tuple(shape))
+
+
+# ---- weight gradients on a side stream ----------------------------------------------------------------------------------------------
+# A weight gradient is a leaf of the backward pass: nothing downstream waits for it until the optimiser runs.  Launched on a second
+# stream it overlaps with the data-gradient chain, whose kernels are mostly too small to fill 256 CUs.  OPT-IN (`train.train_step`
+# enables it around `loss.backward()` and joins the streams before the gradient all-reduce / optimiser step): a caller that runs
+# `backward()` itself and reads `.grad` right away must not have gradients still in flight on a stream it does not know about.
+_side: Dict[int, "torch.cuda.Stream"] = {}
+_side_enabled = False
+
+
+class side_stream_weight_gradients:
+    """Context manager: weight-gradient kernels launched inside go to a per-device side stream; leaving it makes the current stream
+    wait for them."""
+
+    def __init__(self, device: torch.device, enabled: bool = True):
+        self.device, self.enabled = device, enabled and device.type == "cuda"
+
+    def __enter__(self):
+        global _side_enabled
+        self.prev = _side_enabled
+        _side_enabled = self.enabled
+        return self
+
+    def __exit__(self, *exc):
+        global _side_enabled
+        _side_enabled = self.prev
+        if self.enabled:
+            idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+            if idx in _side:
+                torch.cuda.current_stream(self.device).wait_stream(_side[idx])
+        return False
+
+
+def side_stream(device: torch.device) -> Optional["torch.cuda.Stream"]:
+    """The side stream for a leaf kernel on `device` (it already waits for everything queued on the current stream), or None."""
+    if not _side_enabled or device.type != "cuda":
+        return None
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    st = _side.get(idx)
+    if st is None:
+        st = _side[idx] = torch.cuda.Stream(device=device)
+    st.wait_stream(torch.cuda.current_stream(device))
+    return st

@@ -18,12 +18,16 @@ ops only, InstanceNorm/BatchNorm statistics and softmax run in fp32 through auto
 from __future__ import annotations
 
 import contextlib
+import os
 from typing import Dict, Iterable, List, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
 
+from . import _scratch
 from .losses import final_loss
+
+SIDE_STREAM_WGRAD = os.environ.get("CDS_TRAIN_SIDE_STREAM", "1") != "0"   # A/B knob: weight-gradient kernels on a second stream
 
 Tensor = torch.Tensor
 
@@ -145,7 +149,9 @@ def train_step(model: torch.nn.Module, optimizer: torch.optim.Optimizer, sample:
         outputs = model(sample["imgs"], sample["proj_matrices"], dv, gt_depths=sample["depth"], temperature=temperature)
     outputs = _to_float(outputs)
     loss, depth_loss = final_loss(outputs, sample["depth"], sample["mask"], dlossw=list(dlossw), depth_interval=interval)
-    loss.backward()
+    # weight gradients on a side stream, joined before anything reads .grad (CDS_TRAIN_SIDE_STREAM=0: everything on one stream)
+    with _scratch.side_stream_weight_gradients(loss.device, SIDE_STREAM_WGRAD):
+        loss.backward()
     if reducer is not None:
         reducer.reduce()
     optimizer.step()

@@ -70,8 +70,16 @@ def conv2d_wgrad(g: Tensor, x: Tensor, k: int, stride: int, pad: int) -> Tensor:
     if Nx != N:
         raise ValueError("conv2d_wgrad: batch mismatch")
     dw = _scratch.zeros((Co, Cin, k, k), torch.float32, g.device)
-    check(_lib.load().cds_conv2d_wgrad_f32(_p(g), _p(x), dw.data_ptr(), N, Co, Cin, Ho, Wo, H, W, k, stride, pad, ops._stream(g)),
-          "cds_conv2d_wgrad_f32")
+    side = _scratch.side_stream(g.device)
+    if side is None:
+        check(_lib.load().cds_conv2d_wgrad_f32(_p(g), _p(x), dw.data_ptr(), N, Co, Cin, Ho, Wo, H, W, k, stride, pad, ops._stream(g)),
+              "cds_conv2d_wgrad_f32")
+        return dw
+    with torch.cuda.stream(side):                                # a leaf of the backward pass: overlaps with the data-gradient chain
+        check(_lib.load().cds_conv2d_wgrad_f32(_p(g), _p(x), dw.data_ptr(), N, Co, Cin, Ho, Wo, H, W, k, stride, pad, side.cuda_stream),
+              "cds_conv2d_wgrad_f32")
+    g.record_stream(side)
+    x.record_stream(side)
     return dw
 
 

@@ -33,8 +33,16 @@ def conv3d_wgrad(g: Tensor, xin: Tensor, stride: int) -> Tensor:
     if Bx != B:
         raise ValueError("conv3d_wgrad: batch mismatch")
     dw = _scratch.zeros((Ca, Cb, 3, 3, 3), torch.float32, g.device)
-    check(_lib.load().cds_conv3d_wgrad_f32(_dev(g), _dev(xin), dw.data_ptr(), B, Ca, Cb, Do, Ho, Wo, Di, Hi, Wi, stride,
-                                           ops._stream(g)), "cds_conv3d_wgrad_f32")
+    side = _scratch.side_stream(g.device)
+    if side is None:
+        check(_lib.load().cds_conv3d_wgrad_f32(_dev(g), _dev(xin), dw.data_ptr(), B, Ca, Cb, Do, Ho, Wo, Di, Hi, Wi, stride,
+                                               ops._stream(g)), "cds_conv3d_wgrad_f32")
+        return dw
+    with torch.cuda.stream(side):                                # a leaf of the backward pass: overlaps with the data-gradient chain
+        check(_lib.load().cds_conv3d_wgrad_f32(_dev(g), _dev(xin), dw.data_ptr(), B, Ca, Cb, Do, Ho, Wo, Di, Hi, Wi, stride,
+                                               side.cuda_stream), "cds_conv3d_wgrad_f32")
+    g.record_stream(side)
+    xin.record_stream(side)
     return dw
 
 

@@ -257,3 +257,38 @@ def test_grouped_visibility_equals_separate_calls(B):
         _close(pb.grad, pa.grad, name, rel=1e-4)
     for (name, ba), (_, bb) in zip(a.named_buffers(), b.named_buffers()):
         _close(bb.double(), ba.double(), name, rel=1e-5)
+
+
+def test_side_stream_weight_gradients_give_the_same_step():
+    """train_step with the weight-gradient kernels on a side stream (default) against everything on one stream: same loss, same
+    parameters after ONE optimiser step (the streams are joined before anything reads .grad).  Two warm-up steps on a throwaway model
+    first, so that the compared step runs with a warm allocator / arena / side stream (buffer reuse across streams is what could go
+    wrong); further steps cannot be compared tightly: the cascade's discrete switches amplify 1e-7 differences (two single-stream runs
+    differ by 0.3 % in the third loss, scripts/ab/side_stream_steps.py)."""
+    from cds_mvsnet_amd import CDSMVSNet, seeded_init_, train as T
+    from test_train_harness import _train_sample
+    dev = torch.device("cuda:0")
+    sample = _train_sample(dev)
+    res = {}
+    old = T.SIDE_STREAM_WGRAD
+
+    def make(seed):
+        model = seeded_init_(CDSMVSNet(refine=False, ndepths=(48, 32, 8), depth_interals_ratio=(4.0, 2.0, 1.0)), seed).to(dev)
+        return model, T.make_optimizer(model, lr=1e-3)
+
+    try:
+        for side in (False, True):
+            T.SIDE_STREAM_WGRAD = side
+            warm, wopt = make(11)
+            for _ in range(2):
+                T.train_step(warm, wopt, sample, temperature=0.1, reducer=T.GradAllReducer(warm.parameters()))
+            model, opt = make(7)
+            loss = T.train_step(model, opt, sample, temperature=0.1, reducer=T.GradAllReducer(model.parameters()))[0]
+            torch.cuda.synchronize()
+            res[side] = (loss, {n: p.detach().clone() for n, p in model.named_parameters()})
+    finally:
+        T.SIDE_STREAM_WGRAD = old
+    assert abs(res[True][0] - res[False][0]) <= 1e-6 * abs(res[False][0])
+    for n in res[False][1]:
+        a, b = res[True][1][n].double(), res[False][1][n].double()
+        assert (a - b).abs().max().item() <= 1e-5 * max(b.abs().max().item(), 1e-6), n     # gradients differ by the order of atomics only
