@@ -85,10 +85,10 @@ SIGNATURES = {
     "cds_conv3d_wgrad_f32": [P, P, P, I, I, I, I, I, I, I, I, I, I, P],
     "cds_conv2d_wgrad_f32": [P, P, P, I, I, I, I, I, I, I, I, I, I, P],
     "cds_conv2d_dgrad_s2_f32": [P, P, P, I, I, I, I, I, I, I, P],
-    "cds_instnorm_bwd_f32": [P, P, P, P, P, I, I, I, I, I, P],
-    "cds_dynconv_bn_stats_f32": [P, P, P, P, P, P, P, P, I, I, I, I, I, I, F, F, I, P],
+    "cds_instnorm_bwd_f32": [P, P, P, P, P, I, I, I, I, I, I, P],
+    "cds_dynconv_bn_stats_f32": [P, P, P, P, P, P, P, P, I, I, I, I, I, I, F, F, I, I, P],
     "cds_dynconv_blend_train_f32": [P, P, P, P, P, P, P, P, F, P, P, I, I, I, I, I, I, P],
-    "cds_dynconv_blend_bwd_f32": [P, P, P, P, P, P, P, P, F, P, P, P, P, P, I, I, I, I, I, I, I, P],
+    "cds_dynconv_blend_bwd_f32": [P, P, P, P, P, P, P, P, F, P, P, P, P, P, I, I, I, I, I, I, I, I, P],
     "cds_pack_conv2d_f32": [P, P, P, P, I, I, I, I, P],
     "cds_pack_conv3d_f32": [P, P, P, I, I, I, P],
     "cds_softargmin_bwd_f32": [P, P, P, P, I, I, I, I, P],

@@ -664,13 +664,13 @@ extern "C" int cds_conv2d_dgrad_s2_f32(const float* g, const float* w, float* gx
 }
 
 // InstanceNorm2d(eps 1e-5, no affine) + activation backward.  gz, y, gy [N][C][H][W]; stats [N][C][2] fp64 (sum, sum of squares of y:
-// what cds_instnorm_act_f32 leaves); sums [N][C][2] fp64 scratch (overwritten).  act: CDS_ACT_LEAKY01 | CDS_ACT_TANH | CDS_ACT_NONE.
+// what cds_instnorm_act_f32 leaves); sums [N][C][2] fp64 scratch (zeroed here unless scratch_zeroed says the caller did).  act: CDS_ACT_LEAKY01 | CDS_ACT_TANH | CDS_ACT_NONE.
 extern "C" int cds_instnorm_bwd_f32(const float* gz, const float* y, const double* stats, double* sums, float* gy, int N, int C, int H,
-                                    int W, int act, void* stream) {
+                                    int W, int act, int scratch_zeroed, void* stream) {
   if (!gz || !y || !stats || !sums || !gy || N < 1 || C < 1 || H < 1 || W < 1) return CDS_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const int hw = H * W;
-  if (hipMemsetAsync(sums, 0, sizeof(double) * 2 * N * C, st) != hipSuccess) return cds_launch_status();
+  if (!scratch_zeroed && hipMemsetAsync(sums, 0, sizeof(double) * 2 * N * C, st) != hipSuccess) return cds_launch_status();
   int bpc = cds_ceil_div(hw, 256 * 16);
   if (bpc > 64) bpc = 64;
   hipLaunchKernelGGL(instnorm_bwd_reduce_kernel, dim3(N * C * bpc), dim3(256), 0, st, gz, y, stats, sums, hw, act, bpc);
@@ -686,7 +686,7 @@ extern "C" int cds_instnorm_bwd_f32(const float* gz, const float* y, const doubl
 // running ones) and, if use_batch and running_mean != NULL, updates the running statistics group after group (momentum as given).
 extern "C" int cds_dynconv_bn_stats_f32(const float* branches, const float* epipoles, const float* w1, double* mom, float* mean,
                                         float* rstd, float* running_mean, float* running_var, int N, int G, int K, int Cout, int H,
-                                        int W, float eps, float momentum, int use_batch, void* stream) {
+                                        int W, float eps, float momentum, int use_batch, int scratch_zeroed, void* stream) {
   if (!branches || !epipoles || !w1 || !mom || !mean || !rstd || N < 1 || G < 1 || (N % G) || Cout < 1 || H < 1 || W < 1 || (K != 2 && K != 3))
     return CDS_EINVAL;
   if (!use_batch && (!running_mean || !running_var)) return CDS_EINVAL;
@@ -694,7 +694,7 @@ extern "C" int cds_dynconv_bn_stats_f32(const float* branches, const float* epip
   BlendArgs a{branches, epipoles, w1, nullptr, nullptr, nullptr, nullptr, nullptr, N, G, Cout, H, W, 1.f};
   const int NM = K + K * (K + 1) / 2;
   if (use_batch) {
-    if (hipMemsetAsync(mom, 0, sizeof(double) * G * NM, st) != hipSuccess) return cds_launch_status();
+    if (!scratch_zeroed && hipMemsetAsync(mom, 0, sizeof(double) * G * NM, st) != hipSuccess) return cds_launch_status();
     if (int e = blend_dispatch_k(K, 0, a, nullptr, nullptr, nullptr, nullptr, mom, 0.0, 1, nullptr, nullptr, st)) return e;
   }
   const double count = (double)(N / G) * H * W;
@@ -721,14 +721,16 @@ extern "C" int cds_dynconv_blend_train_f32(const float* branches, const float* e
 extern "C" int cds_dynconv_blend_bwd_f32(const float* branches, const float* epipoles, const float* w1, const float* w2,
                                          const float* gamma, const float* beta, const float* mean, const float* rstd,
                                          float temperature, const float* gy, const float* gnc, float* gbr, double* sums, double* dw1,
-                                         int N, int G, int K, int Cout, int H, int W, int use_batch, void* stream) {
+                                         int N, int G, int K, int Cout, int H, int W, int use_batch, int scratch_zeroed, void* stream) {
   if (!branches || !epipoles || !w1 || !w2 || !gamma || !beta || !mean || !rstd || !gy || !gbr || !sums || !dw1 || N < 1 || G < 1 ||
       (N % G) || Cout < 1 || H < 1 || W < 1 || !(temperature > 0.f))
     return CDS_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   BlendArgs a{branches, epipoles, w1, w2, gamma, beta, mean, rstd, N, G, Cout, H, W, 1.0f / temperature};
-  if (hipMemsetAsync(sums, 0, sizeof(double) * (G * 2 * HID + K * HID), st) != hipSuccess) return cds_launch_status();
-  if (hipMemsetAsync(dw1, 0, sizeof(double) * HID * K, st) != hipSuccess) return cds_launch_status();
+  if (!scratch_zeroed) {
+    if (hipMemsetAsync(sums, 0, sizeof(double) * (G * 2 * HID + K * HID), st) != hipSuccess) return cds_launch_status();
+    if (hipMemsetAsync(dw1, 0, sizeof(double) * HID * K, st) != hipSuccess) return cds_launch_status();
+  }
   const double count = (double)(N / G) * H * W;
   if (int e = blend_dispatch_k(K, 2, a, nullptr, nullptr, gy, gnc, sums, count, use_batch, nullptr, nullptr, st)) return e;
   return blend_dispatch_k(K, 3, a, nullptr, nullptr, gy, gnc, sums, count, use_batch, gbr, dw1, st);

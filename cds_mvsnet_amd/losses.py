@@ -8,7 +8,7 @@ import torch.nn.functional as F
 
 def _masked_mean(values, mask, count):
     """mean(values[mask]) without the boolean gather (its backward sorts the indices: ~300 small launches per step)."""
-    return torch.where(mask, values, torch.zeros((), dtype=values.dtype, device=values.device)).sum() / count
+    return torch.where(mask, values, 0.0).sum() / count
 
 
 def final_loss(inputs, depth_gt_ms, mask_ms, **kwargs):

@@ -163,8 +163,8 @@ class InstNormAct(torch.autograd.Function):
         gz = gz.contiguous().float()
         N, C, H, W = y.shape
         gy = torch.empty_like(y)
-        sums = torch.empty((N, C, 2), dtype=torch.float64, device=y.device)
-        check(_lib.load().cds_instnorm_bwd_f32(_p(gz), _p(y), _p64(stats), _p64(sums), gy.data_ptr(), N, C, H, W, ctx.act,
+        sums = _scratch.zeros((N, C, 2), torch.float64, y.device)
+        check(_lib.load().cds_instnorm_bwd_f32(_p(gz), _p(y), _p64(stats), _p64(sums), gy.data_ptr(), N, C, H, W, ctx.act, 1,
                                                ops._stream(y)), "cds_instnorm_bwd_f32")
         return gy, None
 
@@ -211,13 +211,13 @@ class _DynConvFn(torch.autograd.Function):
         w2m = w2.detach().reshape(K, 4).contiguous()
         mean = torch.empty((G, 4), dtype=torch.float32, device=dev)
         rstd = torch.empty((G, 4), dtype=torch.float32, device=dev)
-        mom = torch.empty((G, K + K * (K + 1) // 2), dtype=torch.float64, device=dev)
+        mom = _scratch.zeros((G, K + K * (K + 1) // 2), torch.float64, dev)
         track = use_batch and bn.training and bn.track_running_stats
         momentum = bn.momentum if bn.momentum is not None else 0.1
         check(lib.cds_dynconv_bn_stats_f32(_p(branches), _p(epi), _p(w1m), mom.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
                                            bn.running_mean.data_ptr() if (track or not use_batch) else None,
                                            bn.running_var.data_ptr() if (track or not use_batch) else None,
-                                           N, G, K, cout, H, W, float(bn.eps), float(momentum), 1 if use_batch else 0, st),
+                                           N, G, K, cout, H, W, float(bn.eps), float(momentum), 1 if use_batch else 0, 1, st),
               "cds_dynconv_bn_stats_f32")
         if track:
             _scratch.bump(bn.num_batches_tracked, G)
@@ -250,11 +250,11 @@ class _DynConvFn(torch.autograd.Function):
         w1m = w1.detach().reshape(4, K).contiguous()
         w2m = w2.detach().reshape(K, 4).contiguous()
         gbr = torch.empty_like(branches)
-        sums = torch.empty((G * 8 + K * 4,), dtype=torch.float64, device=dev)
-        dw1 = torch.empty((4, K), dtype=torch.float64, device=dev)
+        sums = _scratch.zeros((G * 8 + K * 4,), torch.float64, dev)
+        dw1 = _scratch.zeros((4, K), torch.float64, dev)
         check(lib.cds_dynconv_blend_bwd_f32(_p(branches), _p(epi), _p(w1m), _p(w2m), _p(gamma.detach().contiguous()),
                                             _p(beta.detach().contiguous()), _p(mean), _p(rstd), T, _p(gy), _p(gnc), gbr.data_ptr(),
-                                            sums.data_ptr(), dw1.data_ptr(), N, G, K, cout, H, W, 1 if use_batch else 0, st),
+                                            sums.data_ptr(), dw1.data_ptr(), N, G, K, cout, H, W, 1 if use_batch else 0, 1, st),
               "cds_dynconv_blend_bwd_f32")
         grp = sums[:G * 8].view(G, 2, 4).sum(dim=0)
         g_beta, g_gamma = grp[0].float(), grp[1].float()
@@ -352,8 +352,9 @@ def bn_relu2d(bn, y: Tensor, relu: bool = True, groups: int = 1) -> Tensor:
                 if bn.momentum is not None:                          # one fused update: r (1-m)^G + sum_g m (1-m)^(G-1-g) stat_g
                     m = float(bn.momentum)
                     wts = _group_weights(m, groups, y.device)
-                    bn.running_mean.mul_((1.0 - m) ** groups).addmv_(tm.t(), wts)
-                    bn.running_var.mul_((1.0 - m) ** groups).addmv_(tv.t(), wts)
+                    keep = (1.0 - m) ** groups
+                    torch.addmv(bn.running_mean, tm.t(), wts, beta=keep, out=bn.running_mean)      # one launch per statistic
+                    torch.addmv(bn.running_var, tv.t(), wts, beta=keep, out=bn.running_var)
                     _scratch.bump(bn.num_batches_tracked, groups)
                 else:
                     for g in range(groups):

@@ -302,6 +302,17 @@ def stage_forward_train(stage_net, features, cams: Tensor, depth_values: Tensor,
     return {"depth": depth, "photometric_confidence": conf, "feat_distance": _stack(fds), "norm_curv": nc_mean}
 
 
+_PAIR_ORDER: Dict[Tuple[int, str], Tensor] = {}
+
+
+def _pair_order(V: int, dev) -> Tensor:
+    """View indices of the stacked FeatureNet call (ref, src_1, ref, src_2, ...), cached on the device."""
+    key = (V, str(dev))
+    if key not in _PAIR_ORDER:
+        _PAIR_ORDER[key] = torch.tensor([n for v in range(V) for n in (0, v + 1)], device=dev)
+    return _PAIR_ORDER[key]
+
+
 def forward_train(model, imgs: Tensor, proj_matrices: Dict[str, Tensor], depth_values: Tensor,
                   gt_depths: Optional[Dict[str, Tensor]], temperature: float):
     """CDSMVSNet.forward in training mode.  Same inputs / outputs as the reference (adds 'feat_distance' and
@@ -316,7 +327,6 @@ def forward_train(model, imgs: Tensor, proj_matrices: Dict[str, Tensor], depth_v
     dv = depth_values.detach().float().cpu()
     cams = {k: v.detach().float().cpu() for k, v in proj_matrices.items()}
     V = N - 1
-    ref_img = F.interpolate(imgs[:, 0], (H, W))
     # model.py:154-161 calls FeatureNet once per image of every pair.  Its InstanceNorms are per sample and the BatchNorm2d of
     # each DynamicConv's attention MLP is evaluated per group of B samples (_att_weights_grouped), so the 2 V calls are ONE call
     # on the 2 V B images stacked along the batch axis: same values, an eighth of the kernel launches and of the per-parameter
@@ -326,10 +336,14 @@ def forward_train(model, imgs: Tensor, proj_matrices: Dict[str, Tensor], depth_v
     if BATCH_FEATURES:
         # one call on the 2 V B images, stacked in the reference's call order (ref of pair 0, src of pair 0, ref of pair 1, ...)
         e_all = torch.tensor([epi[v][b][k] for v in range(V) for k in (0, 1) for b in range(B)], dtype=torch.float32, device=dev)
-        x_all = torch.cat([t for v in range(V) for t in (ref_img, F.interpolate(imgs[:, v + 1], (H, W)))], dim=0)
+        # all N views resized in one call, then gathered in the reference's call order (ref, src_1, ref, src_2, ...)
+        small = imgs if (Him, Wim) == (H, W) else F.interpolate(imgs.reshape(B * N, 3, Him, Wim), (H, W)).view(B, N, 3, H, W)
+        order = _pair_order(V, dev)
+        x_all = small.index_select(1, order).transpose(0, 1).reshape(2 * V * B, 3, H, W)
         f_all = feature_net(model.feature, x_all, e_all, T, groups=2 * V)
         stacked_feats = {k: StackedFeatures(*f_all[k], V, B) for k in f_all}
     else:
+        ref_img = F.interpolate(imgs[:, 0], (H, W))
         for v in range(V):
             e_ref = torch.tensor([e[0] for e in epi[v]], dtype=torch.float32, device=dev)
             e_src = torch.tensor([e[1] for e in epi[v]], dtype=torch.float32, device=dev)

@@ -451,23 +451,25 @@ int cds_conv3d_wgrad_f32(const float* g, const float* xin, float* dw, int B, int
  *   cds_dynconv_blend_bwd_f32:   its backward.  gbr [K][N][Cout+3][H][W] = gradient of the branch tensor; fp64: sums [G][8] =
  *                             per group (sum g_bn_j, sum g_bn_j xhat_j) (dbeta_j / dgamma_j summed over groups) followed by dw2 [K][4];
  *                             dw1 [4][K].  gnc may be NULL.
- *   cds_softargmin_bwd_f32:   gpre[d] = softmax(prob_pre)_d (hyp_d - depth) gdepth. */
+ *   cds_softargmin_bwd_f32:   gpre[d] = softmax(prob_pre)_d (hyp_d - depth) gdepth.
+ * scratch_zeroed != 0: the fp64 accumulation buffers (sums / mom / dw1) arrive zero-filled (the training step zeroes ONE arena per step
+ * instead of ~40 small memsets); 0: the function zeroes them itself. */
 int cds_conv2d_wgrad_f32(const float* g, const float* x, float* dw, int N, int Co, int Cin, int Ho, int Wo, int H, int W, int k,
                          int stride, int pad, void* stream);
 int cds_conv2d_dgrad_s2_f32(const float* g, const float* w, float* gx, int N, int Co, int Cin, int Ho, int Wo, int H, int W,
                             void* stream);
 int cds_instnorm_bwd_f32(const float* gz, const float* y, const double* stats, double* sums, float* gy, int N, int C, int H, int W,
-                         int act, void* stream);
+                         int act, int scratch_zeroed, void* stream);
 int cds_dynconv_bn_stats_f32(const float* branches, const float* epipoles, const float* w1, double* mom, float* mean, float* rstd,
                              float* running_mean, float* running_var, int N, int G, int K, int Cout, int H, int W, float eps,
-                             float momentum, int use_batch, void* stream);
+                             float momentum, int use_batch, int scratch_zeroed, void* stream);
 int cds_dynconv_blend_train_f32(const float* branches, const float* epipoles, const float* w1, const float* w2, const float* gamma,
                                 const float* beta, const float* mean, const float* rstd, float temperature, float* out,
                                 float* norm_curv, int N, int G, int K, int Cout, int H, int W, void* stream);
 int cds_dynconv_blend_bwd_f32(const float* branches, const float* epipoles, const float* w1, const float* w2, const float* gamma,
                               const float* beta, const float* mean, const float* rstd, float temperature, const float* gy,
                               const float* gnc, float* gbr, double* sums, double* dw1, int N, int G, int K, int Cout, int H, int W,
-                              int use_batch, void* stream);
+                              int use_batch, int scratch_zeroed, void* stream);
 /* The weight layouts of cds_conv2d_f32 in one launch: fwd [Cin][k k][CoP] (forward) and / or dgrad [Ca+Cb][k k][CiP] (stride-1 data
  * gradient: taps flipped, channels swapped) from wa [Ca][Cin][k][k] and, optionally, wb [Cb][Cin][k][k] stacked behind it. */
 int cds_pack_conv2d_f32(const float* wa, const float* wb, float* fwd, float* dgrad, int Ca, int Cb, int Cin, int k, void* stream);
