@@ -1753,3 +1753,190 @@ extern "C" int cds_deconv3d_prob_sbf_f32(const float* x, const void* weight_spli
   if (!x || !weight_split || !skip || !prob_split || !out_p3 || Da < 1 || Ha < 1 || Wa < 2 || (Wa & 1)) return CDS_EINVAL;
   return launch_deconv_prob(x, weight_split, bias, skip, prob_split, out_p3, Da, Ha, Wa, (hipStream_t)stream);
 }
+
+// ---------------------------------------------------------------------------------------------
+// The prob layer alone on the matrix cores ("a separate light kernel rather than the fused one").
+// Conv3d(8 -> 1, k3, p1, no bias) is separable along z:  prob[z] = P_0[z-1] + P_1[z] + P_2[z+1],  P_kz = the in-plane 3x3 8 -> 1
+// convolution with the kz slice of the weights - the P phase of deconv_prob_kernel: matrix rows = (kz, x offset 0..3), columns =
+// 8 quads x 2 rows, K = 18 in-plane positions x 8 channels (5 K-steps x 6 split-bf16 MFMAs).
+// A workgroup owns a 32 x TY pixel column and MARCHES along z through a chunk of planes: every input plane is read once (plus the
+// one-voxel ring of the tile: 34 x (TY + 2) positions), split into its three bf16 terms on the way into LDS (double-buffered, one
+// barrier per plane), one wave per row pair multiplies it by the Toeplitz weights it keeps in REGISTERS, and the three z-taps meet in
+// registers: a lane keeps its P of the last two planes and the kz = 0 lanes gather P_1 / P_2 of the neighbouring lane groups with two
+// cross-lane reads - one 4-byte store per voxel, nothing else written.  Algorithmic bytes: 32 B in + 4 B out per voxel.
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+template <int TY>
+struct PMCfg {
+  static constexpr int TX = 32;
+#ifndef CDS_PROB_FW
+#define CDS_PROB_FW 40
+#endif
+  // fine plane incl. ring: 34 columns stored as 4 residue runs of 9 positions.  Row pitch 40 positions = 1920 B = 128 (mod 256): the two
+  // rows a wave's 16-lane group reads (8 quads each, 48 B apart = bank quads {0,3,6,9,12,15,2,5}) fall on disjoint bank quads; with the
+  // natural pitch of 36 every ds_read_b128 was a 2-way conflict and the kernel LDS-bound (compute-only 599 us at M1)
+  static constexpr int FW = CDS_PROB_FW, FH = TY + 2;
+  static constexpr int NPOS = FH * 34;                        // positions staged per plane
+  static constexpr int FB1 = FH * FW * POSB;
+  static constexpr int NW = TY / 2, THREADS = NW * 64;        // one wave per row pair
+  static constexpr int PKS = 5;
+  static constexpr int LDSB = 2 * FB1;
+  static constexpr int NLD = (NPOS + THREADS - 1) / THREADS;  // positions a thread stages per plane
+};
+
+template <int TY>
+__global__ __launch_bounds__(PMCfg<TY>::THREADS) void prob_sbf_kernel(const float* __restrict__ x, const uint4* __restrict__ pw,
+                                                                       float* __restrict__ out, int D, int H, int W, int tiles_x,
+                                                                       int tiles_y, int zchunk, int nwg) {
+  using Cfg = PMCfg<TY>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 15, g = lane >> 4;
+  int lin = cds_xcd_remap(blockIdx.x, nwg);
+  const int tx_i = lin % tiles_x;
+  lin /= tiles_x;
+  const int ty_i = lin % tiles_y, zc = lin / tiles_y;
+  const int X0 = tx_i * Cfg::TX, Y0 = ty_i * TY;
+  const int z0 = zc * zchunk, z1 = min(D, z0 + zchunk);
+
+  // the Toeplitz weights of this lane, all K-steps, in registers (loop invariant along the march)
+  BV pwr[Cfg::PKS][3];
+#pragma unroll
+  for (int t = 0; t < Cfg::PKS; ++t)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) pwr[t][k].u = pw[(t * 3 + k) * 64 + lane];
+
+  const int qd = j & 7, rr = 2 * wave + (j >> 3);
+  int poff[Cfg::PKS];
+#pragma unroll
+  for (int t = 0; t < Cfg::PKS; ++t) {
+    const int s = min(4 * t + g, 17);                         // slots 18, 19: zero weights, any valid address
+    const int ky = s / 6, dx = s - 6 * ky;
+    poff[t] = ((rr + ky) * Cfg::FW + (dx & 3) * 9 + qd + (dx >> 2)) * POSB;
+  }
+  // staging: position p -> (row, xs) of the ringed tile
+  int s_dst[Cfg::NLD];
+  size_t s_src[Cfg::NLD];
+  bool s_ok[Cfg::NLD];
+#pragma unroll
+  for (int k = 0; k < Cfg::NLD; ++k) {
+    const int p = tid + k * Cfg::THREADS;
+    const int row = min(p, Cfg::NPOS - 1) / 34, xs = min(p, Cfg::NPOS - 1) % 34;
+    const int gy = Y0 + row - 1, gx = X0 + xs - 1;
+    s_ok[k] = p < Cfg::NPOS && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+    s_src[k] = s_ok[k] ? ((size_t)gy * W + gx) * 8 : 0;
+    s_dst[k] = p < Cfg::NPOS ? (row * Cfg::FW + (xs & 3) * 9 + (xs >> 2)) * POSB : -1;
+  }
+  const size_t plane = (size_t)H * W * 8;
+  // two register sets: the loads of plane zp + 2 are issued before the MFMAs of plane zp and written to LDS an iteration later (an HBM
+  // round trip is ~4x the 30 MFMAs of a plane: with one plane in flight per workgroup the march waited for memory every plane)
+  struct Regs { float4 a[Cfg::NLD], b[Cfg::NLD]; };
+  Regs r0, r1;
+  auto load_plane = [&](int z, Regs& r) {
+    const bool zin = (unsigned)z < (unsigned)D;
+    const float* __restrict__ xz = x + (size_t)(zin ? z : 0) * plane;
+#pragma unroll
+    for (int k = 0; k < Cfg::NLD; ++k) {
+      const float4* s4 = reinterpret_cast<const float4*>(xz + s_src[k]);
+#ifndef CDS_PROB_NOLOAD
+      const bool ok = zin && s_ok[k];
+#else
+      const bool ok = zin && s_ok[k] && z == -12345;
+#endif
+      r.a[k] = ok ? s4[0] : make_float4(0.f, 0.f, 0.f, 0.f);
+      r.b[k] = ok ? s4[1] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto store_plane = [&](int buf, const Regs& r) {
+#pragma unroll
+    for (int k = 0; k < Cfg::NLD; ++k)
+      if (s_dst[k] >= 0) split_store8(lds + buf * Cfg::FB1 + s_dst[k], r.a[k], r.b[k]);
+  };
+
+  load_plane(z0 - 1, r0);
+  load_plane(z0, r1);
+  store_plane(0, r0);
+  __syncthreads();
+  f32x4 pb1 = (f32x4){0.f, 0.f, 0.f, 0.f}, pb2 = pb1;          // this lane's P of the planes zp - 1 and zp - 2
+  const size_t planeHW = (size_t)H * W;
+  const int gy = Y0 + rr, gx = X0 + 4 * qd;
+  const bool st_ok = g == 0 && gy < H && gx < W;
+  int cur = 0;
+  // one plane of the march; rn = the register set that holds plane zp + 1 (stored to LDS at the end), rl = the set that is free
+  // (plane zp + 2 is loaded into it)
+  auto step = [&](int zp, Regs& rl, const Regs& rn) {
+    if (zp + 1 < z1) load_plane(zp + 2, rl);                  // in flight during the MFMAs of this plane and of the next one
+    f32x4 pacc[1] = {(f32x4){0.f, 0.f, 0.f, 0.f}};
+#ifndef CDS_PROB_NOMFMA
+    if ((unsigned)zp < (unsigned)D) {
+#else
+    if (zp == -12345) {
+#endif
+      const unsigned char* fp = lds + cur * Cfg::FB1;
+      BV pbv[2][1][3];
+      auto load_b = [&](int buf, int t) {
+        const unsigned char* b = fp + poff[t];
+        pbv[buf][0][0].u = *reinterpret_cast<const uint4*>(b);
+        pbv[buf][0][1].u = *reinterpret_cast<const uint4*>(b + 16);
+        pbv[buf][0][2].u = *reinterpret_cast<const uint4*>(b + 32);
+      };
+      load_b(0, 0);
+#pragma unroll
+      for (int t = 0; t < Cfg::PKS; ++t) {
+        if (t + 1 < Cfg::PKS) load_b((t & 1) ^ 1, t + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        SBF_TERMS(pacc, 0, 1, pwr[t], pbv[t & 1]);
+      }
+    }
+    // prob[zp - 1] = P_0[zp - 2] (kz = 0 lanes: pb2) + P_1[zp - 1] (kz = 1 lanes: pb1) + P_2[zp] (kz = 2 lanes: pacc)
+    const int zo = zp - 1;
+    f32x4 o;
+    o.x = pb2.x + __shfl(pb1.x, j + 16) + __shfl(pacc[0].x, j + 32);
+    o.y = pb2.y + __shfl(pb1.y, j + 16) + __shfl(pacc[0].y, j + 32);
+    o.z = pb2.z + __shfl(pb1.z, j + 16) + __shfl(pacc[0].z, j + 32);
+    o.w = pb2.w + __shfl(pb1.w, j + 16) + __shfl(pacc[0].w, j + 32);
+    if (st_ok && zo >= z0 && zo < z1) sbf_store4(out + (size_t)zo * planeHW + (size_t)gy * W + gx, make_float4(o.x, o.y, o.z, o.w));
+    pb2 = pb1;
+    pb1 = pacc[0];
+    if (zp < z1) store_plane(cur ^ 1, rn);
+    __syncthreads();
+    cur ^= 1;
+  };
+  for (int zp = z0 - 1; zp <= z1; zp += 2) {
+    step(zp, r0, r1);                                         // r0 held plane zp (already in LDS): free; r1 holds plane zp + 1
+    if (zp + 1 <= z1) step(zp + 1, r1, r0);
+  }
+}
+
+template <int TY>
+int launch_prob_sbf(const float* x, const void* pw, float* out, int D, int H, int W, hipStream_t st) {
+  using Cfg = PMCfg<TY>;
+  const int tx = cds_ceil_div(W, Cfg::TX), ty = cds_ceil_div(H, TY);
+  static const int zc_env = []() { const char* e = getenv("CDS_PROB_ZCHUNK"); return e ? atoi(e) : 0; }();   // A/B knob
+  int zchunk = zc_env > 0 ? zc_env : 48;
+  // enough workgroups for 256 CUs: shorter chunks on small grids (2 extra planes per chunk are the price)
+  while (zchunk > 8 && (long long)tx * ty * cds_ceil_div(D, zchunk) < 2048) zchunk /= 2;
+  if (zchunk > D) zchunk = D;
+  const int nz = cds_ceil_div(D, zchunk);
+  const int nwg = tx * ty * nz;
+  static std::atomic<unsigned long long> lds_ok{0};
+  if (Cfg::LDSB > 64 * 1024)
+    if (int e_lds = cds_allow_lds(reinterpret_cast<const void*>(prob_sbf_kernel<TY>), Cfg::LDSB, lds_ok)) return e_lds;
+  hipLaunchKernelGGL(prob_sbf_kernel<TY>, dim3(nwg), dim3(Cfg::THREADS), Cfg::LDSB, st, x, reinterpret_cast<const uint4*>(pw), out, D, H,
+                     W, tx, ty, zchunk, nwg);
+  return cds_launch_status();
+}
+
+}  // namespace
+
+// prob layer (Conv3d 8 -> 1, k3, p1; models/module.py:303) on the matrix cores in split-bf16 arithmetic: x [D][H][W][8] channels-last
+// -> out [D][H][W].  prob_split = ops.split_pack_prob_toeplitz(prob.weight).  W % 4 == 0.
+extern "C" int cds_conv3d_prob_sbf_f32(const float* x, const void* prob_split, float* out, int D, int H, int W, void* stream) {
+  if (!x || !prob_split || !out || D < 1 || H < 1 || W < 4 || (W & 3)) return CDS_EINVAL;
+  static const int ty_env = []() { const char* e = getenv("CDS_PROB_TY"); return e ? atoi(e) : 0; }();       // A/B knob
+  const int ty = ty_env ? ty_env : (H >= 64 ? 16 : 8);
+  if (ty == 16) return launch_prob_sbf<16>(x, prob_split, out, D, H, W, (hipStream_t)stream);
+  return launch_prob_sbf<8>(x, prob_split, out, D, H, W, (hipStream_t)stream);
+}

@@ -34,6 +34,7 @@ USE_FUSED_BLEND = os.environ.get("CDS_FUSED_BLEND", "1") != "0"   # A/B knob: 0 
 # default: at M1 it measures 3.5 ms + 0.27 ms of soft-argmin against 1.16 + 0.67 + 0.12 ms for the three separate kernels
 # (profiles/r03_costreg_experiments.md section 5).  CDS_FUSED_PROB=1 selects it.
 USE_FUSED_PROB = os.environ.get("CDS_FUSED_PROB", "0") == "1"
+USE_PROB_MFMA = os.environ.get("CDS_PROB_MFMA", "0") == "1"   # A/B knob: the prob layer as a z-marching matrix-core kernel
 
 
 # ------------------------------------------------------------------------------------------------
@@ -316,7 +317,12 @@ class CostRegNet(_PackedHolder):
         del c4
         x = ops.deconv3d_sbf(x, p["conv9.ws"], p["conv9.b"], 16, skip=c2)
         del c2
-        x = ops.deconv3d_sbf(x, p["conv11.ws"], p["conv11.b"], 8, skip=c0, out_planar=True)   # prob reads planar
+        if USE_PROB_MFMA and "prob.ws" in p and v.shape[2] % 4 == 0:
+            # the prob layer on the matrix cores too (z-marching split-bf16 kernel on conv11's channels-last output)
+            x = ops.deconv3d_sbf(x, p["conv11.ws"], p["conv11.b"], 8, skip=c0)
+            del c0
+            return ops.conv3d_prob_sbf(x, p["prob.ws"])
+        x = ops.deconv3d_sbf(x, p["conv11.ws"], p["conv11.b"], 8, skip=c0, out_planar=True)   # the VALU prob kernel reads planar
         del c0
         return ops.conv3d_k3(x, p["prob.w"], None, relu=False)[0]
 

@@ -545,6 +545,18 @@ def deconv3d_prob_sbf(x_cl: Tensor, wsplit: Tensor, bias: Optional[Tensor], skip
     return out
 
 
+def conv3d_prob_sbf(x_cl: Tensor, prob_split: Tensor) -> Tensor:
+    """Conv3d(8 -> 1, k3, p1) on the matrix cores (split-bf16): x_cl [D,H,W,8] channels-last -> [D,H,W]; prob_split =
+    split_pack_prob_toeplitz(prob.weight).  W % 4 == 0."""
+    D, H, W, C = x_cl.shape
+    if C != 8 or W % 4 or prob_split.dtype != torch.int16 or not prob_split.is_cuda or not prob_split.is_contiguous():
+        raise ValueError("conv3d_prob_sbf: x_cl [D,H,W % 4 == 0,8], prob_split = a contiguous int16 device tensor")
+    out = torch.empty((D, H, W), dtype=torch.float32, device=x_cl.device)
+    check(_lib.load().cds_conv3d_prob_sbf_f32(_dev(x_cl, "x"), prob_split.data_ptr(), out.data_ptr(), D, H, W, _stream(x_cl)),
+          "cds_conv3d_prob_sbf_f32")
+    return out
+
+
 def conv3d_prob_cl8(x_cl: Tensor, wtap: Tensor) -> Tensor:
     """Conv3d(8 -> 1, k3, p1) on a channels-last volume: x_cl [D,H,W,8] -> [D,H,W]."""
     D, H, W, C = x_cl.shape

@@ -199,6 +199,12 @@ int cds_conv3d_sbf_f32(const float* x, const void* weight_split, const float* bi
  * out_planar != 0: the output is written [Cout][2D][2H][2W] (for a planar consumer: conv11 -> prob); skip stays channels-last. */
 int cds_deconv3d_sbf_f32(const float* x, const void* weight_split, const float* bias, const float* skip, float* out,
                          int Cin, int Cout, int D, int H, int W, int act, int out_planar, void* stream);
+/* The prob layer alone on the matrix cores (split-bf16 arithmetic): x [D][H][W][8] channels-last -> out [D][H][W]; prob_split =
+ * the Toeplitz layout of prob.weight (ops.split_pack_prob_toeplitz).  The layer is separable along z (prob[z] = P_0[z-1] + P_1[z] +
+ * P_2[z+1], P_kz the in-plane 3x3 8 -> 1 convolution): a workgroup marches along z, every plane goes through LDS once, the three
+ * z-taps meet in registers.  W % 4 == 0.  (models/module.py:303,315) */
+int cds_conv3d_prob_sbf_f32(const float* x, const void* prob_split, float* out, int D, int H, int W, void* stream);
+
 /*
  * conv11 (ConvTranspose3d 16 -> 8 + BN + ReLU + skip, models/module.py:299-301,313) FUSED with the in-plane part of the prob layer
  * (Conv3d 8 -> 1, module.py:303,314): the 8-channel full-resolution tensor is never written.

@@ -1083,3 +1083,21 @@ def test_fused_conv11_prob_equals_two_kernels(Da, Ha, Wa, dev, ops):
     d_f, c_f = ops.softargmin_conf_p3(p3, hyp)
     d_t, c_t = ops.softargmin_conf(want, hyp)
     assert (d_f - d_t).abs().max() < 2e-3 and (c_f - c_t).abs().mean() < 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("D,H,W", [(8, 24, 40), (20, 72, 100), (50, 64, 36), (3, 8, 4), (96, 40, 64)])
+def test_prob_layer_on_the_matrix_cores_is_fp32_class(D, H, W):
+    """cds_conv3d_prob_sbf_f32 (the prob layer alone, z-marching split-bf16 matrix-core kernel) against float64 Conv3d(8 -> 1, k3, p1)
+    (models/module.py:303,315): fp32-class accuracy like every split-bf16 layer, ragged tiles, chunk borders, zero padding."""
+    import torch.nn.functional as F
+    from cds_mvsnet_amd import ops
+    torch.manual_seed(D + W)
+    dev = torch.device("cuda:0")
+    x = torch.randn(D, H, W, 8, dtype=torch.float64) * 2.0
+    x[:, :, :, 3] *= 1e-3                                      # a channel of small magnitudes (exercises the lower split terms)
+    w = torch.randn(1, 8, 3, 3, 3, dtype=torch.float64) * 0.3
+    ref = F.conv3d(x.permute(3, 0, 1, 2).unsqueeze(0), w, padding=1)[0, 0]
+    out = ops.conv3d_prob_sbf(x.float().to(dev).contiguous(), ops.split_pack_prob_toeplitz(w.float().to(dev)))
+    err = (out.double().cpu() - ref).abs().max().item()
+    assert err <= 2e-6 * ref.abs().max().item(), (err, ref.abs().max().item())
