@@ -1886,8 +1886,19 @@ __global__ __launch_bounds__(PMCfg<TY>::THREADS) void prob_sbf_kernel(const floa
 #pragma unroll
       for (int t = 0; t < Cfg::PKS; ++t) {
         if (t + 1 < Cfg::PKS) load_b((t & 1) ^ 1, t + 1);
+#ifdef CDS_PROB_PINNED
         __builtin_amdgcn_sched_barrier(0);
         SBF_TERMS(pacc, 0, 1, pwr[t], pbv[t & 1]);
+#else
+        // no scheduling barriers here: the VALU work of the next plane's split (store_plane below, independent of these MFMAs) may be
+        // issued between the dependent MFMAs of the chain
+        SBF_MFMA(pacc[0], pwr[t][2], pbv[t & 1][0][0]);
+        SBF_MFMA(pacc[0], pwr[t][1], pbv[t & 1][0][1]);
+        SBF_MFMA(pacc[0], pwr[t][0], pbv[t & 1][0][2]);
+        SBF_MFMA(pacc[0], pwr[t][1], pbv[t & 1][0][0]);
+        SBF_MFMA(pacc[0], pwr[t][0], pbv[t & 1][0][1]);
+        SBF_MFMA(pacc[0], pwr[t][0], pbv[t & 1][0][0]);
+#endif
       }
     }
     // prob[zp - 1] = P_0[zp - 2] (kz = 0 lanes: pb2) + P_1[zp - 1] (kz = 1 lanes: pb1) + P_2[zp] (kz = 2 lanes: pacc)
