@@ -117,18 +117,19 @@ def test_softargmin_backward():
     _close(pg.grad, pr.grad, "dpre")
 
 
-@pytest.mark.parametrize("refine", [False, True])
-def test_full_training_forward_equals_torch_2d_stacks(refine):
+@pytest.mark.parametrize("refine,B", [(False, 1), (True, 1), (False, 2)])
+def test_full_training_forward_equals_torch_2d_stacks(refine, B):
     """The whole training forward + loss + backward with the 2D stacks on the HIP kernels against the same step with them on
     PyTorch-ROCm autograd ops (CDS_TRAIN_HIP2D=0): loss, depth and every parameter gradient."""
     from cds_mvsnet_amd import CDSMVSNet, seeded_init_, training, losses, synth
     dev = torch.device("cuda:0")
-    B, N = 1, 3
+    N = 3
     Hm, Wm = (128, 192) if refine else (64, 96)          # image size; the plane sweep runs at half of it with refine
     H, W = (Hm // 2, Wm // 2) if refine else (Hm, Wm)
-    imgs = synth.make_images(N, Hm, Wm, seed=31).to(dev)
-    cams = {k: v.to(dev) for k, v in synth.make_cameras(N, Hm, Wm, refine=refine, seed=31).items()}
-    dv = synth.make_depth_values().to(dev)
+    imgs = torch.cat([synth.make_images(N, Hm, Wm, seed=31 + b) for b in range(B)]).to(dev)
+    cams_l = [synth.make_cameras(N, Hm, Wm, refine=refine, seed=31 + b) for b in range(B)]
+    cams = {k: torch.cat([c[k] for c in cams_l]).to(dev) for k in cams_l[0]}
+    dv = synth.make_depth_values().repeat(B, 1).to(dev)
     g = torch.Generator().manual_seed(4)
     base = 600.0 + 120.0 * F.interpolate(torch.rand(B, 1, 4, 6, generator=g), (Hm, Wm), mode="bicubic", align_corners=False)[:, 0]
     gt, mask = {}, {}
