@@ -1777,6 +1777,13 @@ struct PMCfg {
   // rows a wave's 16-lane group reads (8 quads each, 48 B apart = bank quads {0,3,6,9,12,15,2,5}) fall on disjoint bank quads; with the
   // natural pitch of 36 every ds_read_b128 was a 2-way conflict and the kernel LDS-bound (compute-only 599 us at M1)
   static constexpr int FW = CDS_PROB_FW, FH = TY + 2;
+#ifndef CDS_PROB_RUN
+#define CDS_PROB_RUN 10
+#endif
+  // pitch of a residue run: with 10 positions (480 B) the eight positions that consecutive lanes STORE (x, x+1, .. x+7 = residues
+  // 0 1 2 3 0 1 2 3 of two run slots) fall on eight different 16-byte bank groups; with the natural 9 every staging store was a 2-way
+  // conflict (SQ_LDS_BANK_CONFLICT 45 % of the LDS-active cycles, the LDS 61 % busy: the kernel's bottleneck)
+  static constexpr int RUN = CDS_PROB_RUN;
   static constexpr int NPOS = FH * 34;                        // positions staged per plane
   static constexpr int FB1 = FH * FW * POSB;
   static constexpr int NW = TY / 2, THREADS = NW * 64;        // one wave per row pair
@@ -1785,8 +1792,11 @@ struct PMCfg {
   static constexpr int NLD = (NPOS + THREADS - 1) / THREADS;  // positions a thread stages per plane
 };
 
+#ifndef CDS_PROB_MINW
+#define CDS_PROB_MINW 2
+#endif
 template <int TY>
-__global__ __launch_bounds__(PMCfg<TY>::THREADS) void prob_sbf_kernel(const float* __restrict__ x, const uint4* __restrict__ pw,
+__global__ __launch_bounds__(PMCfg<TY>::THREADS, CDS_PROB_MINW) void prob_sbf_kernel(const float* __restrict__ x, const uint4* __restrict__ pw,
                                                                        float* __restrict__ out, int D, int H, int W, int tiles_x,
                                                                        int tiles_y, int zchunk, int nwg) {
   using Cfg = PMCfg<TY>;
@@ -1814,11 +1824,11 @@ __global__ __launch_bounds__(PMCfg<TY>::THREADS) void prob_sbf_kernel(const floa
   for (int t = 0; t < Cfg::PKS; ++t) {
     const int s = min(4 * t + g, 17);                         // slots 18, 19: zero weights, any valid address
     const int ky = s / 6, dx = s - 6 * ky;
-    poff[t] = ((rr + ky) * Cfg::FW + (dx & 3) * 9 + qd + (dx >> 2)) * POSB;
+    poff[t] = ((rr + ky) * Cfg::FW + (dx & 3) * Cfg::RUN + qd + (dx >> 2)) * POSB;
   }
   // staging: position p -> (row, xs) of the ringed tile
   int s_dst[Cfg::NLD];
-  size_t s_src[Cfg::NLD];
+  unsigned s_src[Cfg::NLD];                                   // byte offset inside a plane (H W 32 B < 4 GB): scalar base + 32-bit lane offset
   bool s_ok[Cfg::NLD];
 #pragma unroll
   for (int k = 0; k < Cfg::NLD; ++k) {
@@ -1826,27 +1836,40 @@ __global__ __launch_bounds__(PMCfg<TY>::THREADS) void prob_sbf_kernel(const floa
     const int row = min(p, Cfg::NPOS - 1) / 34, xs = min(p, Cfg::NPOS - 1) % 34;
     const int gy = Y0 + row - 1, gx = X0 + xs - 1;
     s_ok[k] = p < Cfg::NPOS && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
-    s_src[k] = s_ok[k] ? ((size_t)gy * W + gx) * 8 : 0;
-    s_dst[k] = p < Cfg::NPOS ? (row * Cfg::FW + (xs & 3) * 9 + (xs >> 2)) * POSB : -1;
+    s_src[k] = s_ok[k] ? (unsigned)(gy * W + gx) * 32u : 0u;
+    s_dst[k] = p < Cfg::NPOS ? (row * Cfg::FW + (xs & 3) * Cfg::RUN + (xs >> 2)) * POSB : -1;
   }
-  const size_t plane = (size_t)H * W * 8;
+  // tiles whose ring lies inside the image (all but the border tiles) load without the zero-padding selects (workgroup-uniform branch)
+  const bool interior = X0 >= 1 && X0 + Cfg::TX + 1 <= W && Y0 >= 1 && Y0 + TY + 1 <= H;
+  const size_t plane = (size_t)H * W * 32;                    // bytes
   // two register sets: the loads of plane zp + 2 are issued before the MFMAs of plane zp and written to LDS an iteration later (an HBM
   // round trip is ~4x the 30 MFMAs of a plane: with one plane in flight per workgroup the march waited for memory every plane)
   struct Regs { float4 a[Cfg::NLD], b[Cfg::NLD]; };
   Regs r0, r1;
   auto load_plane = [&](int z, Regs& r) {
-    const bool zin = (unsigned)z < (unsigned)D;
-    const float* __restrict__ xz = x + (size_t)(zin ? z : 0) * plane;
-#pragma unroll
-    for (int k = 0; k < Cfg::NLD; ++k) {
-      const float4* s4 = reinterpret_cast<const float4*>(xz + s_src[k]);
-#ifndef CDS_PROB_NOLOAD
-      const bool ok = zin && s_ok[k];
-#else
-      const bool ok = zin && s_ok[k] && z == -12345;
+#ifdef CDS_PROB_NOLOAD
+    z = -1;
 #endif
-      r.a[k] = ok ? s4[0] : make_float4(0.f, 0.f, 0.f, 0.f);
-      r.b[k] = ok ? s4[1] : make_float4(0.f, 0.f, 0.f, 0.f);
+    if ((unsigned)z >= (unsigned)D) {                          // (uniform) the zero plane beyond either end of the volume
+#pragma unroll
+      for (int k = 0; k < Cfg::NLD; ++k) r.a[k] = r.b[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      return;
+    }
+    const unsigned char* __restrict__ xz = reinterpret_cast<const unsigned char*>(x) + (size_t)z * plane;
+    if (interior) {
+#pragma unroll
+      for (int k = 0; k < Cfg::NLD; ++k) {
+        const float4* s4 = reinterpret_cast<const float4*>(xz + s_src[k]);
+        r.a[k] = s4[0];
+        r.b[k] = s4[1];
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < Cfg::NLD; ++k) {
+        const float4* s4 = reinterpret_cast<const float4*>(xz + s_src[k]);
+        r.a[k] = s_ok[k] ? s4[0] : make_float4(0.f, 0.f, 0.f, 0.f);
+        r.b[k] = s_ok[k] ? s4[1] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
     }
   };
   auto store_plane = [&](int buf, const Regs& r) {
@@ -1875,30 +1898,24 @@ __global__ __launch_bounds__(PMCfg<TY>::THREADS) void prob_sbf_kernel(const floa
     if (zp == -12345) {
 #endif
       const unsigned char* fp = lds + cur * Cfg::FB1;
-      BV pbv[2][1][3];
-      auto load_b = [&](int buf, int t) {
-        const unsigned char* b = fp + poff[t];
-        pbv[buf][0][0].u = *reinterpret_cast<const uint4*>(b);
-        pbv[buf][0][1].u = *reinterpret_cast<const uint4*>(b + 16);
-        pbv[buf][0][2].u = *reinterpret_cast<const uint4*>(b + 32);
-      };
-      load_b(0, 0);
+      // all five K-steps' operands requested up front (60 registers): the LDS round trip is paid once per plane, not once per K-step
+      // (a K-step's six dependent MFMAs are shorter than an LDS read under load)
+      BV pbv[Cfg::PKS][1][3];
 #pragma unroll
       for (int t = 0; t < Cfg::PKS; ++t) {
-        if (t + 1 < Cfg::PKS) load_b((t & 1) ^ 1, t + 1);
-#ifdef CDS_PROB_PINNED
-        __builtin_amdgcn_sched_barrier(0);
-        SBF_TERMS(pacc, 0, 1, pwr[t], pbv[t & 1]);
-#else
-        // no scheduling barriers here: the VALU work of the next plane's split (store_plane below, independent of these MFMAs) may be
-        // issued between the dependent MFMAs of the chain
-        SBF_MFMA(pacc[0], pwr[t][2], pbv[t & 1][0][0]);
-        SBF_MFMA(pacc[0], pwr[t][1], pbv[t & 1][0][1]);
-        SBF_MFMA(pacc[0], pwr[t][0], pbv[t & 1][0][2]);
-        SBF_MFMA(pacc[0], pwr[t][1], pbv[t & 1][0][0]);
-        SBF_MFMA(pacc[0], pwr[t][0], pbv[t & 1][0][1]);
-        SBF_MFMA(pacc[0], pwr[t][0], pbv[t & 1][0][0]);
-#endif
+        const unsigned char* b = fp + poff[t];
+        pbv[t][0][0].u = *reinterpret_cast<const uint4*>(b);
+        pbv[t][0][1].u = *reinterpret_cast<const uint4*>(b + 16);
+        pbv[t][0][2].u = *reinterpret_cast<const uint4*>(b + 32);
+      }
+#pragma unroll
+      for (int t = 0; t < Cfg::PKS; ++t) {
+        SBF_MFMA(pacc[0], pwr[t][2], pbv[t][0][0]);
+        SBF_MFMA(pacc[0], pwr[t][1], pbv[t][0][1]);
+        SBF_MFMA(pacc[0], pwr[t][0], pbv[t][0][2]);
+        SBF_MFMA(pacc[0], pwr[t][1], pbv[t][0][0]);
+        SBF_MFMA(pacc[0], pwr[t][0], pbv[t][0][1]);
+        SBF_MFMA(pacc[0], pwr[t][0], pbv[t][0][0]);
       }
     }
     // prob[zp - 1] = P_0[zp - 2] (kz = 0 lanes: pb2) + P_1[zp - 1] (kz = 1 lanes: pb1) + P_2[zp] (kz = 2 lanes: pacc)
