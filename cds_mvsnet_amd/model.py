@@ -34,7 +34,18 @@ USE_FUSED_BLEND = os.environ.get("CDS_FUSED_BLEND", "1") != "0"   # A/B knob: 0 
 # default: at M1 it measures 3.5 ms + 0.27 ms of soft-argmin against 1.16 + 0.67 + 0.12 ms for the three separate kernels
 # (profiles/r03_costreg_experiments.md section 5).  CDS_FUSED_PROB=1 selects it.
 USE_FUSED_PROB = os.environ.get("CDS_FUSED_PROB", "0") == "1"
-USE_PROB_MFMA = os.environ.get("CDS_PROB_MFMA", "0") == "1"   # A/B knob: the prob layer as a z-marching matrix-core kernel
+USE_PROB_MFMA = os.environ.get("CDS_PROB_MFMA", "0") == "1"
+# stage 1 on a side stream next to FeatureNet's finer levels (CDS_OVERLAP_STAGE1=0: one stream): 1600x1184 19.04 -> 18.72 ms, 640x512 4.67 -> 4.48
+OVERLAP_STAGE1 = os.environ.get("CDS_OVERLAP_STAGE1", "1") != "0"
+OVERLAP_STAGE2 = os.environ.get("CDS_OVERLAP_STAGE2", "0") == "1"   # A/B knob: stage 2 as well (next to the full-resolution FPN level)
+_SIDE_STREAMS: Dict[int, "torch.cuda.Stream"] = {}
+
+
+def _side_stream(device) -> "torch.cuda.Stream":
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    if idx not in _SIDE_STREAMS:
+        _SIDE_STREAMS[idx] = torch.cuda.Stream(device=device)
+    return _SIDE_STREAMS[idx]   # A/B knob: the prob layer as a z-marching matrix-core kernel
 
 
 # ------------------------------------------------------------------------------------------------
@@ -547,7 +558,7 @@ class _FeatureRunner:
         hwc = ops.instnorm_apply(o[n_chw:], st[n_chw:], ACT_TANH, out_hwc=True) if n_chw < N else None
         return chw, hwc
 
-    def __call__(self, imgs: Tensor, epipoles: Tensor, T: float, n_chw: Optional[int] = None, n_shared: int = 1):
+    def __call__(self, imgs: Tensor, epipoles: Tensor, T: float, n_chw: Optional[int] = None, n_shared: int = 1, on_stage1=None):
         """imgs [N,3,H,W], epipoles CPU [N,2] (one epipole per image, full-resolution pixels).
         Returns {'stageK': (fea_chw [n_chw,C,h,w] | None, fea_hwc [N-n_chw,h,w,C] | None, nc_sum [N,h,w], |nc| [N,h,w])}."""
         net = self.net
@@ -577,6 +588,8 @@ class _FeatureRunner:
         out = {}
         o1, n22, s1, _ = self._dynamic(p, "out1", net.out1, c21, e2, T, aff=a21)
         out["stage1"] = self._final(o1, s1, n_chw) + ops.curvature_stats(n20, n21, n22)
+        if on_stage1 is not None:          # the coarse stage can start (on another stream) while the finer FPN levels are computed
+            on_stage1("stage1", out["stage1"])
 
         # FPN: nearest-neighbour up-sampling and concatenation move raw values; the affine tables concatenate alike
         x, ax = self._lateral_unit(p, "inner1", c21, a21, c11, a11)
@@ -584,6 +597,8 @@ class _FeatureRunner:
         o2n = ops.instnorm_apply(o2, s2, ACT_TANH)
         hwc2 = torch.stack([ops.chw_to_hwc(o2n[i]) for i in range(n_chw, N)]) if n_chw < N else None
         out["stage2"] = (o2n[:n_chw] if n_chw > 0 else None, hwc2) + ops.curvature_stats(n10, n11, n12)
+        if on_stage1 is not None:
+            on_stage1("stage2", out["stage2"])
 
         x, ax = self._lateral_unit(p, "inner2", o2n, None, c01, a01)      # o2n is materialised (tanh features)
         o3, n02, s3, _ = self._dynamic(p, "out3", net.out3, x, e0, T, aff=ax)
@@ -737,7 +752,8 @@ class CDSMVSNet(nn.Module):
         self._view_shard = None
 
     # -- helpers -----------------------------------------------------------------------------
-    def extract_features(self, ref_img: Tensor, src_imgs: List[Tensor], cam_ref: Tensor, cam_srcs: List[Tensor], T: float):
+    def extract_features(self, ref_img: Tensor, src_imgs: List[Tensor], cam_ref: Tensor, cam_srcs: List[Tensor], T: float,
+                         on_stage1=None):
         """FeatureNet for every (reference, source) pair in ONE batched pass: V copies of the reference image (each
         conditioned on its pair's epipole — DynamicConv makes reference features pair specific, model.py:154-161)
         followed by the V source images.  Returns the runner's dict; rows [0,V) are the reference features (CHW), the
@@ -752,7 +768,8 @@ class CDSMVSNet(nn.Module):
             g = epi[v0:v0 + G]
             epipoles = torch.tensor([e[0] for e in g] + [e[1] for e in g], dtype=torch.float32)
             batch = torch.stack([ref_img] * len(g) + list(src_imgs[v0:v0 + G]))
-            parts.append((len(g), _FeatureRunner(self.feature)(batch, epipoles, T, n_chw=len(g), n_shared=len(g))))
+            parts.append((len(g), _FeatureRunner(self.feature)(batch, epipoles, T, n_chw=len(g), n_shared=len(g),
+                                                               on_stage1=on_stage1 if V <= G else None)))
         if len(parts) == 1:
             return parts[0][1]
         out = {}
@@ -806,10 +823,38 @@ class CDSMVSNet(nn.Module):
             views = self._my_views(N - 1)
             V = len(views)
             feats = None
-            if V:
-                feats = self.extract_features(ref_img, [_resize_nearest(imgs[b, v + 1], H, W) for v in views],
-                                              cams["stage3"][b, 0], [cams["stage3"][b, v + 1] for v in views], T)
+            early: Dict[str, object] = {}
             sh = self._view_shard
+            if V:
+                on_stage1 = None
+                if OVERLAP_STAGE1 and sh is None and V <= ops.MAX_IMAGES // 2 and not torch.cuda.is_current_stream_capturing():
+                    # stage 1 (quarter resolution: kernels that do not fill 256 CUs) runs on a side stream from the moment its
+                    # features exist, next to the finer FPN levels of FeatureNet on the main stream; joined before stage 2
+                    main = torch.cuda.current_stream(imgs.device)
+                    side = _side_stream(imgs.device)
+
+                    def on_stage1(name, f, b=b, views=views, V=V):
+                        if name == "stage2" and not OVERLAP_STAGE2:
+                            return
+                        s_ = int(name[-1]) - 1
+                        side.wait_stream(main)
+                        with torch.cuda.stream(side):
+                            scale = int(self.stage_infos[name]["scale"])
+                            if s_ == 0:
+                                hyp_ = ops.depth_planes(self.ndepths[0], H // scale, W // scale, float(dv[b, 0]), float(dv[b, -1]), imgs.device)
+                            else:
+                                hyp_ = ops.depth_hypotheses(early["stage1"][0], self.ndepths[s_], H, W, scale,
+                                                            float(self.depth_interals_ratio[s_] * (dv[b, 1] - dv[b, 0])), float(dv[b, 0]), float(dv[b, -1]))
+                            ref, src, nc_sum, nc_abs = f
+                            mats = geometry.warp_matrices(cams[name][b])[views].contiguous()
+                            early[name] = self._run_stage(ref, src, nc_abs[:V].contiguous(), ops.pair_mean(nc_sum, V), mats, hyp_, s_, N - 1)
+                feats = self.extract_features(ref_img, [_resize_nearest(imgs[b, v + 1], H, W) for v in views],
+                                              cams["stage3"][b, 0], [cams["stage3"][b, v + 1] for v in views], T, on_stage1=on_stage1)
+                if early:
+                    torch.cuda.current_stream(imgs.device).wait_stream(side)
+                    for st_out in early.values():
+                        for t in st_out:
+                            t.record_stream(torch.cuda.current_stream(imgs.device))
             if sh is not None and sh.exchange == "slab":
                 # pixel-slab sharding: FeatureNet stays sharded by view; every rank then needs every view's maps for its rows
                 C_s = self.feature.out_channels
@@ -827,6 +872,10 @@ class CDSMVSNet(nn.Module):
                 scale = int(self.stage_infos[name]["scale"])
                 h, w = H // scale, W // scale
                 D = self.ndepths[s]
+                if name in early:
+                    depth, conf, nc = early[name]
+                    out_b[name] = {"depth": depth, "photometric_confidence": conf, "norm_curv": nc.unsqueeze(0)}
+                    continue
                 if depth is None:
                     hyp = ops.depth_planes(D, h, w, float(dmin), float(dmax), imgs.device)
                 else:
