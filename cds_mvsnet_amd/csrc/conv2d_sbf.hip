@@ -113,8 +113,16 @@ __global__ __launch_bounds__(256, 2) void dynconv_branches_sbf_kernel(const floa
   for (int rd = 0; rd < rounds; ++rd) {
     if (rd) __syncthreads();
     // ---- stage 8 channels: unit = (row, x-quad): 8 float4 (one per channel), normalise-on-load, split, 4 positions ----
-    // (mode 2 is always 3x3: only the rows of a 1-pixel halo are staged)
-    constexpr int ROW0 = MODE == 2 ? R - 1 : 0, ROWS = MODE == 2 ? TY + 2 : IY;
+    // only the rows the largest kernel of this DynamicConv reads are staged (mode 2 is always 3x3): a (1, 3) layer stages 10 of the
+    // 14 rows, a (3, 5) layer 12 - the load + normalise + 3-way split of a row is what these layers cost
+#ifdef CDS_DYNCONV_FULL_HALO
+    const int rmax = R;
+#else
+    int rmax = 0;
+#pragma unroll
+    for (int b = 0; b < NBR; ++b) rmax = max(rmax, (br.k[b] - 1) >> 1);
+#endif
+    const int ROW0 = MODE == 2 ? R - 1 : R - rmax, ROWS = MODE == 2 ? TY + 2 : TY + 2 * rmax;
     for (int u = tid; u < ROWS * (IXP / 4); u += 256) {
       const int row = ROW0 + u / (IXP / 4), q = u - (row - ROW0) * (IXP / 4);
       const int gy = oy0 - R + row, gx = ox0 - 4 + 4 * q;
