@@ -293,3 +293,28 @@ def test_side_stream_weight_gradients_give_the_same_step():
     for n in res[False][1]:
         a, b = res[True][1][n].double(), res[False][1][n].double()
         assert (a - b).abs().max().item() <= 1e-5 * max(b.abs().max().item(), 1e-6), n     # gradients differ by the order of atomics only
+
+
+def test_zero_arena_exhaustion_falls_back_to_torch_zeros():
+    """_scratch.zeros hands out slices of ONE zero-filled arena per step; a step that needs more than the arena holds must fall back to
+    torch.zeros and give the same step."""
+    from cds_mvsnet_amd import CDSMVSNet, seeded_init_, train as T, _scratch
+    from test_train_harness import _train_sample
+    dev = torch.device("cuda:0")
+    sample = _train_sample(dev)
+    res = {}
+    old = _scratch.ARENA_BYTES
+    try:
+        for nbytes in (old, 4096):
+            _scratch.ARENA_BYTES = nbytes
+            model = seeded_init_(CDSMVSNet(refine=False, ndepths=(48, 32, 8), depth_interals_ratio=(4.0, 2.0, 1.0)), 7).to(dev)
+            opt = T.make_optimizer(model, lr=1e-3)
+            loss = T.train_step(model, opt, sample, temperature=0.1, reducer=T.GradAllReducer(model.parameters()))[0]
+            torch.cuda.synchronize()
+            res[nbytes] = (loss, {n: p.detach().clone() for n, p in model.named_parameters()})
+    finally:
+        _scratch.ARENA_BYTES = old
+    assert abs(res[4096][0] - res[old][0]) <= 1e-6 * abs(res[old][0])
+    for n in res[old][1]:
+        a, b = res[4096][1][n].double(), res[old][1][n].double()
+        assert (a - b).abs().max().item() <= 1e-5 * max(b.abs().max().item(), 1e-6), n
