@@ -65,9 +65,12 @@ def test_instnorm_act_backward(act):
 @pytest.mark.parametrize("cin,cout,ks,bias,groups,T,train", [(8, 8, (3, 5, 7), False, 2, 0.5, True), (3, 8, (3, 7, 11), False, 1, 0.05, True),
                                                            (16, 16, (3, 5), False, 2, 0.1, True), (32, 32, (1, 3), True, 4, 0.05, True),
                                                            (8, 8, (1, 3), True, 1, 0.3, False)])
-def test_dynamic_conv_forward_backward(cin, cout, ks, bias, groups, T, train):
+@pytest.mark.parametrize("sbf", [False, True])
+def test_dynamic_conv_forward_backward(cin, cout, ks, bias, groups, T, train, sbf, monkeypatch):
     from cds_mvsnet_amd import train2d_ops as t2, training
     from cds_mvsnet_amd.model import DynamicConv
+    # sbf: the split-bf16 all-branches forward kernel (large batches) instead of the direct kernels (where the shape supports it)
+    monkeypatch.setattr(t2, "SBF_MIN_PIXELS", 0 if sbf else 1 << 60)
     torch.manual_seed(cin + len(ks))
     dev = torch.device("cuda:0")
     N, H, W = 4, 24, 36
