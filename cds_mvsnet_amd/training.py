@@ -10,6 +10,7 @@ sampling grid has no gradient, the entropy input of the visibility CNN is detach
 """
 from __future__ import annotations
 
+import contextlib
 import os
 from typing import Dict, List, Optional, Tuple
 
@@ -302,6 +303,17 @@ def stage_forward_train(stage_net, features, cams: Tensor, depth_values: Tensor,
     return {"depth": depth, "photometric_confidence": conf, "feat_distance": _stack(fds), "norm_curv": nc_mean}
 
 
+STAGE_STREAMS = os.environ.get("CDS_TRAIN_STAGE_STREAMS", "0") == "1"   # experiment: one stream per cascade stage (see forward_train)
+_STAGE_STREAMS: Dict[Tuple[int, int], "torch.cuda.Stream"] = {}
+
+
+def _stage_stream(dev, s: int) -> "torch.cuda.Stream":
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), s)
+    if key not in _STAGE_STREAMS:
+        _STAGE_STREAMS[key] = torch.cuda.Stream(device=dev)
+    return _STAGE_STREAMS[key]
+
+
 _PAIR_ORDER: Dict[Tuple[int, str], Tensor] = {}
 
 
@@ -352,31 +364,59 @@ def forward_train(model, imgs: Tensor, proj_matrices: Dict[str, Tensor], depth_v
     outputs: Dict[str, object] = {}
     depth = None
     dint_all = (dv[:, 1] - dv[:, 0])
+    # One stream per stage (CDS_TRAIN_STAGE_STREAMS=1, experiment): the forward stays serial (a stage's hypotheses need the previous
+    # stage's depth) but depth is DETACHED between stages, so the three backward chains are independent and autograd runs each on the
+    # stream of its forward - next to each other.  Every tensor that crosses streams is recorded on the other stream (caching allocator).
+    use_streams = STAGE_STREAMS and BATCH_FEATURES and _hip2d(imgs)
+    main = torch.cuda.current_stream(dev) if use_streams else None
+    prev_stream = None
     for s in range(model.num_stage):
         name = f"stage{s + 1}"
         scale = int(model.stage_infos[name]["scale"])
         h, w = H // scale, W // scale
         D = model.ndepths[s]
-        hyps = []
-        for b in range(B):
-            dmin, dmax = float(dv[b, 0]), float(dv[b, -1])
-            if depth is None:
-                hyps.append(ops.depth_planes(D, h, w, dmin, dmax, dev))
-            else:
-                hyps.append(ops.depth_hypotheses(depth[b].detach().contiguous(), D, H, W, scale,
-                                                 float(model.depth_interals_ratio[s] * dint_all[b]), dmin, dmax))
-        features = stacked_feats[name] if BATCH_FEATURES else [{"ref": feats[v][0][name], "src": feats[v][1][name]} for v in range(V)]
-        hyp_b = torch.stack(hyps)
-        st = stage_forward_train(model.stage_net, features, cams[name], hyp_b, model.cost_regularization[s], s,
-                                 gt_depth=gt_depths[name] if gt_depths is not None else None)
-        depth = st["depth"]
-        if gt_depths is not None:                                            # model.py:202-207
-            gt_s = gt_depths[name].unsqueeze(1)
-            di_stage = dint_all.to(dev).view(B, 1, 1, 1) * float(scale)
-            target = ((hyp_b - gt_s).abs() / di_stage < 0.5 / float(scale)).float()
-            st["feat_target"] = torch.cat((target, torch.ones_like(gt_s)), dim=1)
+        st_s = None
+        if use_streams:
+            st_s = _stage_stream(dev, s)
+            st_s.wait_stream(main)                                           # FeatureNet outputs, the zero arena
+            if prev_stream is not None:
+                st_s.wait_stream(prev_stream)                                # the previous stage's depth
+        with (torch.cuda.stream(st_s) if use_streams else contextlib.nullcontext()):
+            hyps = []
+            for b in range(B):
+                dmin, dmax = float(dv[b, 0]), float(dv[b, -1])
+                if depth is None:
+                    hyps.append(ops.depth_planes(D, h, w, dmin, dmax, dev))
+                else:
+                    hyps.append(ops.depth_hypotheses(depth[b].detach().contiguous(), D, H, W, scale,
+                                                     float(model.depth_interals_ratio[s] * dint_all[b]), dmin, dmax))
+            features = stacked_feats[name] if BATCH_FEATURES else [{"ref": feats[v][0][name], "src": feats[v][1][name]} for v in range(V)]
+            hyp_b = torch.stack(hyps)
+            if use_streams:
+                for t in (features.fea, features.nc_sum, features.nc):
+                    t.record_stream(st_s)
+                if gt_depths is not None:
+                    gt_depths[name].record_stream(st_s)
+                if depth is not None:
+                    depth.record_stream(st_s)
+            st = stage_forward_train(model.stage_net, features, cams[name], hyp_b, model.cost_regularization[s], s,
+                                     gt_depth=gt_depths[name] if gt_depths is not None else None)
+            depth = st["depth"]
+            if gt_depths is not None:                                            # model.py:202-207
+                gt_s = gt_depths[name].unsqueeze(1)
+                di_stage = dint_all.to(dev).view(B, 1, 1, 1) * float(scale)
+                target = ((hyp_b - gt_s).abs() / di_stage < 0.5 / float(scale)).float()
+                st["feat_target"] = torch.cat((target, torch.ones_like(gt_s)), dim=1)
+            if use_streams:
+                for t in st.values():
+                    if isinstance(t, torch.Tensor):
+                        t.record_stream(main)
+        prev_stream = st_s
         outputs[name] = st
         outputs.update(st)
+    if use_streams:
+        for s in range(model.num_stage):
+            main.wait_stream(_stage_stream(dev, s))
     if model.refine:
         dvd = depth_values.float()
         dint = (dvd[:, 1] - dvd[:, 0]).view(B, 1, 1)
