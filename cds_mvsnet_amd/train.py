@@ -140,7 +140,8 @@ def train_step(model: torch.nn.Module, optimizer: torch.optim.Optimizer, sample:
                bf16: bool = False) -> Tuple[float, float]:
     """One optimisation step on ``sample`` = {imgs, proj_matrices, depth_values, depth: {stageK}, mask: {stageK}}
     (already on the model's device).  Returns (loss, depth_loss) as Python floats."""
-    model.train()
+    if not model.training:                                   # walking ~1 400 modules costs 1 ms of a CPU-bound 28 ms step
+        model.train()
     optimizer.zero_grad(set_to_none=True)
     dv = sample["depth_values"]
     interval = dv[:, 1] - dv[:, 0]
