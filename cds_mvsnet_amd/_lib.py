@@ -43,16 +43,12 @@ SIGNATURES = {
     "cds_volume_normalize_f32": [P, P, I, I, I, P],
     "cds_volume_normalize_cl_f32": [P, P, I, I, I, P],
     "cds_softargmin_conf_f32": [P, P, P, P, P, I, I, I, I, P],
-    "cds_softargmin_conf_p3_f32": [P, P, P, P, P, I, I, I, I, P],
-    "cds_deconv3d_prob_sbf_f32": [P, P, P, P, P, P, I, I, I, P],
     "cds_depth_hypotheses_f32": [P, P, I, I, I, I, I, I, F, F, F, P],
     "cds_depth_planes_f32": [P, I, I, I, F, F, P],
     "cds_conv3d_k3_f32": [P, P, P, P, P, I, I, I, I, I, I, I, P],
     "cds_conv3d_k3_cl_f32": [P, P, P, P, P, I, I, I, I, I, I, P],
     "cds_conv3d_sbf_f32": [P, P, P, P, P, I, I, I, I, I, I, I, P],
     "cds_deconv3d_sbf_f32": [P, P, P, P, P, I, I, I, I, I, I, I, P],
-    "cds_conv3d_prob_sbf_f32": [P, P, P, I, I, I, P],
-    "cds_conv3d_prob_cl8_f32": [P, P, P, I, I, I, P],
     "cds_deconv3d_k3s2_f32": [P, P, P, P, P, I, I, I, I, I, I, P],
     "cds_conv2d_f32": [P, P, P, P, I, I, I, I, I, I, I, I, I, P],
     "cds_conv2d_affine_f32": [P, P, P, P, P, I, I, I, I, I, I, I, I, I, P],

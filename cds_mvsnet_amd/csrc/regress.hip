@@ -21,19 +21,6 @@ __device__ __forceinline__ float cds_slice_max(float v) {
   return v;
 }
 
-// P3: `pre` holds the three in-plane maps P_kz [3][D][hw] of the prob layer written by the fused conv11 + prob kernel
-// (csrc/conv3d_sbf.hip: deconv_prob_kernel); the logit of plane d is P_0[d - 1] + P_1[d] + P_2[d + 1] (zero outside [0, D)).
-template <bool P3>
-__device__ __forceinline__ float cds_logit(const float* __restrict__ pre, int d, int D, size_t hw, size_t p) {
-  if (!P3) return pre[(size_t)d * hw + p];
-  const size_t vol = (size_t)D * hw;
-  float v = pre[vol + (size_t)d * hw + p];
-  if (d > 0) v = pre[(size_t)(d - 1) * hw + p] + v;            // (P_0 + P_1) + P_2: the order the planar prob kernel's kz loop adds in
-  if (d + 1 < D) v = v + pre[2 * vol + (size_t)(d + 1) * hw + p];
-  return v;
-}
-
-template <bool P3>
 __global__ __launch_bounds__(256) void softargmin_conf_kernel(const float* __restrict__ pre,
                                                               const float* __restrict__ hyp, float* __restrict__ depth,
                                                               float* __restrict__ conf, float* __restrict__ prob, int D,
@@ -51,7 +38,7 @@ __global__ __launch_bounds__(256) void softargmin_conf_kernel(const float* __res
   // volume is read once instead of twice; the four slices of a pixel are merged with their own rescale factors
   float m = -INFINITY, Z = 0.f, Sd = 0.f, Si = 0.f;
   for (int d = d0; d < d1; ++d) {
-    const float x = cds_logit<P3>(pre, d, D, (size_t)hw, p);
+    const float x = pre[(size_t)d * hw + p];
     const float hv = hyp_pp ? hyp[(size_t)d * hw + p] : hyp[d];
     if (x > m) {                      // also taken on the first plane (m = -inf: the sums are still zero)
       const float sc = expf(m - x);   // exp(-inf) = 0
@@ -79,7 +66,7 @@ __global__ __launch_bounds__(256) void softargmin_conf_kernel(const float* __res
   int i = (int)(Si / Z);  // trunc == floor, the value is >= 0
   i = max(0, min(D - 1, i));
   int j = i - 1 + slice;
-  float pj = (j >= 0 && j < D) ? expf(cds_logit<P3>(pre, j, D, (size_t)hw, p) - m) / Z : 0.f;
+  float pj = (j >= 0 && j < D) ? expf(pre[(size_t)j * hw + p] - m) / Z : 0.f;
   float c = cds_slice_sum(pj);
 
   if (live && slice == 0) {
@@ -87,7 +74,7 @@ __global__ __launch_bounds__(256) void softargmin_conf_kernel(const float* __res
     conf[p] = c;
   }
   if (prob != nullptr && live) {
-    for (int d = d0; d < d1; ++d) prob[(size_t)d * hw + p] = expf(cds_logit<P3>(pre, d, D, (size_t)hw, p) - m) * inv;
+    for (int d = d0; d < d1; ++d) prob[(size_t)d * hw + p] = expf(pre[(size_t)d * hw + p] - m) * inv;
   }
 }
 
@@ -166,17 +153,8 @@ extern "C" int cds_softargmin_conf_f32(const float* prob_pre, const float* hyp, 
                                        int D, int h, int w, int hyp_per_pixel, void* stream) {
   if (!prob_pre || !hyp || !depth || !conf || D < 1 || h < 1 || w < 1) return CDS_EINVAL;
   int hw = h * w;
-  hipLaunchKernelGGL(softargmin_conf_kernel<false>, dim3(cds_ceil_div(hw, 64)), dim3(256), 0, (hipStream_t)stream, prob_pre,
+  hipLaunchKernelGGL(softargmin_conf_kernel, dim3(cds_ceil_div(hw, 64)), dim3(256), 0, (hipStream_t)stream, prob_pre,
                      hyp, depth, conf, prob, D, hw, hyp_per_pixel);
-  return cds_launch_status();
-}
-
-extern "C" int cds_softargmin_conf_p3_f32(const float* p3, const float* hyp, float* depth, float* conf, float* prob, int D, int h,
-                                          int w, int hyp_per_pixel, void* stream) {
-  if (!p3 || !hyp || !depth || !conf || D < 1 || h < 1 || w < 1) return CDS_EINVAL;
-  int hw = h * w;
-  hipLaunchKernelGGL(softargmin_conf_kernel<true>, dim3(cds_ceil_div(hw, 64)), dim3(256), 0, (hipStream_t)stream, p3, hyp, depth,
-                     conf, prob, D, hw, hyp_per_pixel);
   return cds_launch_status();
 }
 

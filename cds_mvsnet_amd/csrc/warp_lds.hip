@@ -36,10 +36,6 @@ namespace {
 constexpr int C8 = 8;
 constexpr int TW = CDS_K3_TW, TH = CDS_K3_TH;  // reference-pixel tile of a workgroup (TW*TH = 256)
 constexpr int BOX_CAP = CDS_K3_BOX;   // texels per view box (x 32 B; 4 views + scratch must fit the LDS budget)
-#ifndef CDS_K3_BOX6
-#define CDS_K3_BOX6 392
-#endif
-constexpr int BOX_CAP6 = CDS_K3_BOX6; // box budget per view with 5 / 6 resident views (6 x 2 x 392 x 16 B = 75 KB: two workgroups per CU)
 constexpr int DC = CDS_K3_DC;         // depth planes per staged chunk
 #ifndef CDS_K1_DC
 #define CDS_K1_DC 64
@@ -581,11 +577,7 @@ __global__ __launch_bounds__(256, CDS_K3_MINW) void warp_aggregate_lds_kernel(
         }
       }
 #endif
-#ifdef CDS_EXP_NOSTORE
-      if (active && acc[0][0].x == 123456.0f) {
-#else
       if (active) {
-#endif
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
           if (cl) {
@@ -792,16 +784,10 @@ bool cds_warp_aggregate_lds_launch(const float* ref, const float* src, const flo
   if ((C != 8 && C != 16 && C != 32) || V < 1 || V > CDS_MAX_VIEWS || !hyp_pp || w < 2 || hs < 2 || h < 1 || y_off < 0 ||
       y_off + h > hs || (size_t)D * h * w * 4 >= ((size_t)1 << 32))
     return false;
-  // 5 / 6 source views (BASELINE config 4, N = 7) CAN run in one pass with a smaller box budget per view (CAP6 texels: 6 views = 75 KB,
-  // still two workgroups per CU; a footprint that does not fit halves its chunk).  Measured at the config-4 stage shapes with the
-  // cascade's real hypothesis ranges (7 views, same box, one pass vs two launches with a re-read of the partial volume): 960x528 D=32 C=16
-  // 1.78 vs 1.58 ms; 1920x1056 D=8 C=8 2.16 vs 0.99 ms; 480x264 D=48 C=32 2.68 vs 1.44 ms -- the smaller boxes overflow, the 6-view
-  // kernel spills in its plane loop, and the volume it saves re-reading is cheap.  (A first A/B with narrower ranges had the 16-channel
-  // stage at 1.12 vs 1.52 ms and shipped a heuristic for a few hours; the cascade bench caught it: 28.7 -> 30.0 ms at config 4.)
-  // Two launches stay the rule; CDS_K3_SPLIT_VIEWS=0 selects the single pass for experiments.
-  static const int split_env = []() { const char* e = getenv("CDS_K3_SPLIT_VIEWS"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
-  const bool one_pass = V <= 6 && split_env == 0;
-  if (V > 4 && !one_pass) {
+  // 5 / 6 source views (BASELINE config 4, N = 7) in ONE pass with smaller boxes was built and measured in round 3 at the config-4
+  // stage shapes with the cascade's real hypothesis ranges: slower than two launches at every stage (1.78 vs 1.58, 2.16 vs 0.99,
+  // 2.68 vs 1.44 ms: the smaller boxes overflow, the 6-view kernel spills; profiles/r03_costreg_experiments.md section 4) and removed.
+  if (V > 4) {
     // more views than fit the LDS budget: two launches over halves of the view list; the second adds to the first's
     // partial sums (and normalises).  Costs one extra read of the volume, still far cheaper than L1 gathers.
     const int v1 = (V + 1) / 2;
@@ -850,9 +836,7 @@ bool cds_warp_aggregate_lds_launch(const float* ref, const float* src, const flo
     case 1: LAUNCH(1, BOX_CAP); break;
     case 2: LAUNCH(2, BOX_CAP); break;
     case 3: LAUNCH(3, BOX_CAP); break;
-    case 4: LAUNCH(4, BOX_CAP); break;
-    case 5: LAUNCH(5, BOX_CAP6); break;
-    default: LAUNCH(6, BOX_CAP6); break;
+    default: LAUNCH(4, BOX_CAP); break;
   }
 #undef LAUNCH4
 #undef LAUNCH3

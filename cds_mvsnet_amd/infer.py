@@ -56,14 +56,15 @@ class _placeholder_pickle:
     """A ``pickle_module`` for ``torch.load`` whose unpickler resolves ONLY an allowlist of globals (the tensor / storage
     rebuild helpers, ``torch.Size`` / ``dtype`` / ``device``, ``OrderedDict``, numpy array reconstruction, a few builtin
     containers) and replaces every other global by :class:`_Opaque` instead of importing it: ``torch.hub.load``,
-    ``torch.jit.load`` and the like are NOT resolvable through it."""
+    ``torch.jit.load`` and the like are NOT resolvable through it -- nor is ``torch.storage._load_from_bytes``, which is a plain
+    ``torch.load(..., weights_only=False)`` with the default pickle module in disguise (zip-format state dicts never reference it)."""
     import pickle as _pickle
     __name__ = "cds_mvsnet_amd.infer._placeholder_pickle"
 
     class Unpickler(_pickle.Unpickler):
         def find_class(self, module, name):
             if (module, name) in _SAFE_GLOBALS or (module == "torch" and name in _SAFE_TORCH_ATTRS) \
-                    or (module == "torch.storage" and name in ("TypedStorage", "UntypedStorage", "_load_from_bytes")) \
+                    or (module == "torch.storage" and name in ("TypedStorage", "UntypedStorage")) \
                     or (module == "builtins" and name in _SAFE_BUILTINS):
                 return super().find_class(module, name)
             return _Opaque

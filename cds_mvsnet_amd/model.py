@@ -30,11 +30,6 @@ BN_EPS = 1e-5
 # split-bf16 matrix-core kernels (fp32-class error, channels-last volumes)
 USE_SPLIT_BF16 = os.environ.get("CDS_CONV_EXACT", "0") != "1"
 USE_FUSED_BLEND = os.environ.get("CDS_FUSED_BLEND", "1") != "0"   # A/B knob: 0 = DynamicConv branches and blend as two kernels
-# conv11 + prob fused (csrc/conv3d_sbf.hip: deconv_prob_kernel; parity-tested, the 2 GB 8-channel tensor is never written) is OFF by
-# default: at M1 it measures 3.5 ms + 0.27 ms of soft-argmin against 1.16 + 0.67 + 0.12 ms for the three separate kernels
-# (profiles/r03_costreg_experiments.md section 5).  CDS_FUSED_PROB=1 selects it.
-USE_FUSED_PROB = os.environ.get("CDS_FUSED_PROB", "0") == "1"
-USE_PROB_MFMA = os.environ.get("CDS_PROB_MFMA", "0") == "1"
 # stage 1 on a side stream next to FeatureNet's finer levels (CDS_OVERLAP_STAGE1=0: one stream): 1600x1184 19.04 -> 18.72 ms, 640x512 4.67 -> 4.48
 OVERLAP_STAGE1 = os.environ.get("CDS_OVERLAP_STAGE1", "1") != "0"
 OVERLAP_STAGE2 = os.environ.get("CDS_OVERLAP_STAGE2", "0") == "1"   # A/B knob: stage 2 as well (next to the full-resolution FPN level)
@@ -245,8 +240,6 @@ class CostRegNet(_PackedHolder):
                     out[name + ".ws"] = ops.split_pack_conv3d_pair(unit.conv.weight.detach() * scale.view(-1, 1, 1, 1, 1))
                 else:
                     out[name + ".ws"] = ops.split_pack_conv3d(unit.conv.weight.detach() * scale.view(-1, 1, 1, 1, 1))
-            out["prob.wt"] = ops.pack_prob_cl(self.prob.weight)
-            out["prob.ws"] = ops.split_pack_prob_toeplitz(self.prob.weight)      # A operand of the fused conv11 + prob kernel
         return out
 
     def split_bf16_supported(self) -> bool:
@@ -260,7 +253,7 @@ class CostRegNet(_PackedHolder):
         planar form the exact-fp32 kernels (one fmaf chain per output)."""
         if self.training:
             # training / autograd path (SURVEY §8(f)-2): HIP forward + backward kernels behind autograd Functions
-            from . import training                                      # honours the CDS_TRAIN_HIP A/B knob, validates the dims
+            from . import training                                      # validates the dims
             v = volume.permute(3, 0, 1, 2) if channels_last else volume
             return training.cost_regularization(self, v.unsqueeze(0).contiguous())[0, 0]
         D, h, w = volume.shape[:3] if channels_last else volume.shape[1:]
@@ -276,41 +269,10 @@ class CostRegNet(_PackedHolder):
 
     def regress(self, volume_cl: Tensor, hyp: Tensor) -> Tuple[Tensor, Tensor]:
         """volume [D,h,w,C] channels-last + hypotheses [D,h,w] -> (depth [h,w], confidence [h,w]): CostRegNet followed by the
-        soft-argmin (models/model.py:83-92).  With the split-bf16 kernels the last transposed convolution is fused with the
-        prob layer (csrc/conv3d_sbf.hip: deconv_prob_kernel): the 8-channel full-resolution tensor is never written, the three
-        in-plane maps of the prob layer go straight to the soft-argmin, which adds the z-shifted planes as it reads them.
-        Opt-in (CDS_FUSED_PROB=1): the fused kernel is correct but slower than the separate kernels so far."""
-        D, h, w = volume_cl.shape[:3]
-        if D % 8 or h % 8 or w % 8:
-            raise ValueError(f"CostRegNet needs D,h,w divisible by 8, got {(D, h, w)}")
+        soft-argmin (models/model.py:83-92)."""
         if self.training:
             raise RuntimeError("CostRegNet.regress is the inference path")
-        p = self._packed.get(self, self._pack)
-        if not (USE_FUSED_PROB and "prob.ws" in p):
-            return ops.softargmin_conf(self.forward(volume_cl, channels_last=True), hyp)
-        with ops.prof("costreg"):
-            x, c0 = self._run_cl_trunk(volume_cl, p)
-            p3 = ops.deconv3d_prob_sbf(x, p["conv11.ws"], p["conv11.b"], c0, p["prob.ws"])
-            del x, c0
-        return ops.softargmin_conf_p3(p3, hyp)
-
-    @staticmethod
-    def _run_cl_trunk(v: Tensor, p: Dict[str, Tensor]) -> Tuple[Tensor, Tensor]:
-        """conv0 .. conv9 on the split-bf16 kernels: returns (conv9's output [D/2,h/2,w/2,16], conv0's output = conv11's skip)."""
-        c0 = ops.conv3d_sbf(v, p["conv0.ws"], p["conv0.b"], 8, stride=ops.SBF_PAIR)
-        c1 = ops.conv3d_sbf(c0, p["conv1.ws"], p["conv1.b"], 16, stride=2)
-        c2 = ops.conv3d_sbf(c1, p["conv2.ws"], p["conv2.b"], 16)
-        del c1
-        c3 = ops.conv3d_sbf(c2, p["conv3.ws"], p["conv3.b"], 32, stride=2)
-        c4 = ops.conv3d_sbf(c3, p["conv4.ws"], p["conv4.b"], 32)
-        del c3
-        c5 = ops.conv3d_sbf(c4, p["conv5.ws"], p["conv5.b"], 64, stride=2)
-        x = ops.conv3d_sbf(c5, p["conv6.ws"], p["conv6.b"], 64)
-        del c5
-        x = ops.deconv3d_sbf(x, p["conv7.ws"], p["conv7.b"], 32, skip=c4)
-        del c4
-        x = ops.deconv3d_sbf(x, p["conv9.ws"], p["conv9.b"], 16, skip=c2)
-        return x, c0
+        return ops.softargmin_conf(self.forward(volume_cl, channels_last=True), hyp)
 
     @staticmethod
     def _run_cl(v: Tensor, p: Dict[str, Tensor]) -> Tensor:
@@ -328,11 +290,6 @@ class CostRegNet(_PackedHolder):
         del c4
         x = ops.deconv3d_sbf(x, p["conv9.ws"], p["conv9.b"], 16, skip=c2)
         del c2
-        if USE_PROB_MFMA and "prob.ws" in p and v.shape[2] % 4 == 0:
-            # the prob layer on the matrix cores too (z-marching split-bf16 kernel on conv11's channels-last output)
-            x = ops.deconv3d_sbf(x, p["conv11.ws"], p["conv11.b"], 8, skip=c0)
-            del c0
-            return ops.conv3d_prob_sbf(x, p["prob.ws"])
         x = ops.deconv3d_sbf(x, p["conv11.ws"], p["conv11.b"], 8, skip=c0, out_planar=True)   # the VALU prob kernel reads planar
         del c0
         return ops.conv3d_k3(x, p["prob.w"], None, relu=False)[0]
@@ -389,28 +346,11 @@ class Refinement(_PackedHolder):
         out["res.w"] = _pack2d(self.res.weight.detach())
         return out
 
-    @staticmethod
-    def _cbr(unit: ConvBn2d, x: Tensor) -> Tensor:
-        return F.relu(unit.bn(unit.conv(x)))
-
-    def _forward_autograd(self, img: Tensor, depth0: Tensor, dmin: Tensor, dmax: Tensor) -> Tensor:
-        B = dmin.shape[0]
-        lo, hi = dmin.view(B, 1, 1, 1), dmax.view(B, 1, 1, 1)
-        d = (depth0 - lo) / (hi - lo) * 10
-        f_img = self._cbr(self.conv0, img)
-        f_d = F.relu(self.bn(self.deconv(self._cbr(self.conv2, self._cbr(self.conv1, d)))))
-        res = self.res(self._cbr(self.conv3, torch.cat((f_d, f_img), dim=1)))
-        d = (F.interpolate(d, scale_factor=2, mode="bilinear", align_corners=True) + res) / 10
-        return d * (hi - lo) + lo
-
     def forward(self, img: Tensor, depth0: Tensor, dmin: Tensor, dmax: Tensor) -> Tensor:
         """img [B,3,H,W], depth0 [B,1,H/2,W/2], dmin/dmax [B] -> refined depth [B,1,H,W]."""
         if self.training:
             from . import training
-            if training.USE_HIP_TRAIN2D and img.is_cuda:                      # HIP forward / backward kernels (train2d_ops.py)
-                from . import train2d_ops
-                return train2d_ops.refinement(self, img, depth0, dmin, dmax)
-            return self._forward_autograd(img, depth0, dmin, dmax)
+            return training._refinement(self, img, depth0, dmin, dmax)         # HIP forward / backward kernels (train2d_ops.py)
         p = self._packed.get(self, self._pack)
         B, _, H, W = img.shape
         h, w = depth0.shape[-2:]
@@ -667,7 +607,7 @@ class StageNet(_PackedHolder):
         cl = isinstance(cost_regularization, CostRegNet) and cost_regularization.split_bf16_supported()
         volume, _, _, _ = self.aggregate(ref_chw, src_hwc, ref_nc, mats, hyp, stage_idx, channels_last=cl)
         if cl:
-            depth, conf = cost_regularization.regress(volume, hyp)       # conv11 + prob fused, soft-argmin on the three maps
+            depth, conf = cost_regularization.regress(volume, hyp)
         else:
             depth, conf = ops.softargmin_conf(cost_regularization(volume), hyp)
         del volume

@@ -295,23 +295,6 @@ def softargmin_conf(prob_pre: Tensor, hyp: Tensor, want_prob: bool = False):
     return (depth, conf, prob) if want_prob else (depth, conf)
 
 
-def softargmin_conf_p3(p3: Tensor, hyp: Tensor):
-    """K5 on the three in-plane maps of the fused conv11 + prob kernel: p3 [3,D,h,w] (logit of plane d = P_0[d-1] + P_1[d] +
-    P_2[d+1]) -> depth [h,w], confidence [h,w]."""
-    if p3.dim() != 4 or p3.shape[0] != 3:
-        raise ValueError("softargmin_conf_p3: expected [3,D,h,w]")
-    _, D, h, w = p3.shape
-    D2, pp = _hyp_args(hyp, D, h, w)
-    if D2 != D:
-        raise ValueError("softargmin_conf_p3: hypotheses / volume depth mismatch")
-    depth = torch.empty((h, w), dtype=torch.float32, device=p3.device)
-    conf = torch.empty_like(depth)
-    with prof("softargmin_conf"):
-        check(_lib.load().cds_softargmin_conf_p3_f32(_dev(p3, "p3"), _dev(hyp, "hyp"), depth.data_ptr(), conf.data_ptr(), None,
-                                                     D, h, w, pp, _stream(depth)), "cds_softargmin_conf_p3_f32")
-    return depth, conf
-
-
 def depth_hypotheses(prev_depth: Tensor, D: int, H: int, W: int, scale: int, interval: float, dmin: float,
                      dmax: float) -> Tensor:
     """K6.  prev_depth [hp,wp] -> hypotheses [D,H/scale,W/scale]."""
@@ -506,71 +489,6 @@ def conv3d_sbf(x_cl: Tensor, wsplit: Tensor, bias: Optional[Tensor], cout: int, 
     check(_lib.load().cds_conv3d_sbf_f32(_dev(x_cl, "x"), wsplit.data_ptr(), _dev(bias, "bias") if bias is not None else None,
                                          _dev(skip, "skip") if skip is not None else None, out.data_ptr(), Cin, cout,
                                          D, H, W, stride, ACT_RELU if relu else ACT_NONE, _stream(x_cl)), "cds_conv3d_sbf_f32")
-    return out
-
-
-def pack_prob_cl(w: Tensor) -> Tensor:
-    """prob.weight [1,8,3,3,3] -> fp32 [ky][kx][kz][ci] for cds_conv3d_prob_cl8_f32."""
-    if tuple(w.shape) != (1, 8, 3, 3, 3):
-        raise ValueError("pack_prob_cl: expected a [1,8,3,3,3] weight")
-    return w.detach().float()[0].permute(2, 3, 1, 0).contiguous()        # [ci,kz,ky,kx] -> [ky,kx,kz,ci]
-
-
-def split_pack_prob_toeplitz(w: Tensor) -> Tensor:
-    """prob.weight [1,8,3,3,3] -> the A operand of the P phase of cds_deconv3d_prob_sbf_f32: matrix rows i = 4 kz + xo (x offset
-    0..3 inside a quad of outputs; rows 12..15 zero), K = 5 steps x 4 in-plane positions s = 4 t + g = (ky, dx) = (s // 6, s % 6)
-    x 8 channels; entry = w[c][kz][ky][dx - xo] (zero unless 0 <= dx - xo <= 2).  int16 [5][3][64][8] (exact 3-way bf16 split)."""
-    if tuple(w.shape) != (1, 8, 3, 3, 3):
-        raise ValueError("split_pack_prob_toeplitz: expected a [1,8,3,3,3] weight")
-    wf = w.detach().float()[0]                                   # [c][kz][ky][kx]
-    a = torch.zeros((5, 4, 16, 8), dtype=torch.float32, device=w.device)     # [t][g][row][c]
-    for s_ in range(18):
-        t, g = divmod(s_, 4)
-        ky, dx = divmod(s_, 6)
-        for kz in range(3):
-            for xo in range(4):
-                kx = dx - xo
-                if 0 <= kx <= 2:
-                    a[t, g, 4 * kz + xo] = wf[:, kz, ky, kx]
-    return _split3(a.reshape(5, 64, 8))
-
-
-def deconv3d_prob_sbf(x_cl: Tensor, wsplit: Tensor, bias: Optional[Tensor], skip_cl: Tensor, prob_split: Tensor) -> Tensor:
-    """conv11 + prob fused: x_cl [Da,Ha,Wa,16], skip_cl [2Da,2Ha,2Wa,8] (conv0's output) -> the prob layer's three in-plane maps
-    [3,2Da,2Ha,2Wa] (see softargmin_conf_p3).  The 8-channel full-resolution tensor never reaches HBM."""
-    Da, Ha, Wa, Cin = x_cl.shape
-    if Cin != 16 or tuple(skip_cl.shape) != (2 * Da, 2 * Ha, 2 * Wa, 8) or Wa % 2:
-        raise ValueError("deconv3d_prob_sbf: x_cl [Da,Ha,Wa,16] (Wa even), skip_cl [2Da,2Ha,2Wa,8]")
-    for t, nm in ((wsplit, "wsplit"), (prob_split, "prob_split")):
-        if t.dtype != torch.int16 or not t.is_cuda or not t.is_contiguous():
-            raise ValueError(f"deconv3d_prob_sbf: {nm} must be a contiguous int16 device tensor")
-    out = torch.empty((3, 2 * Da, 2 * Ha, 2 * Wa), dtype=torch.float32, device=x_cl.device)
-    check(_lib.load().cds_deconv3d_prob_sbf_f32(_dev(x_cl, "x"), wsplit.data_ptr(), _dev(bias, "bias") if bias is not None else None,
-                                                _dev(skip_cl, "skip"), prob_split.data_ptr(), out.data_ptr(), Da, Ha, Wa,
-                                                _stream(x_cl)), "cds_deconv3d_prob_sbf_f32")
-    return out
-
-
-def conv3d_prob_sbf(x_cl: Tensor, prob_split: Tensor) -> Tensor:
-    """Conv3d(8 -> 1, k3, p1) on the matrix cores (split-bf16): x_cl [D,H,W,8] channels-last -> [D,H,W]; prob_split =
-    split_pack_prob_toeplitz(prob.weight).  W % 4 == 0."""
-    D, H, W, C = x_cl.shape
-    if C != 8 or W % 4 or prob_split.dtype != torch.int16 or not prob_split.is_cuda or not prob_split.is_contiguous():
-        raise ValueError("conv3d_prob_sbf: x_cl [D,H,W % 4 == 0,8], prob_split = a contiguous int16 device tensor")
-    out = torch.empty((D, H, W), dtype=torch.float32, device=x_cl.device)
-    check(_lib.load().cds_conv3d_prob_sbf_f32(_dev(x_cl, "x"), prob_split.data_ptr(), out.data_ptr(), D, H, W, _stream(x_cl)),
-          "cds_conv3d_prob_sbf_f32")
-    return out
-
-
-def conv3d_prob_cl8(x_cl: Tensor, wtap: Tensor) -> Tensor:
-    """Conv3d(8 -> 1, k3, p1) on a channels-last volume: x_cl [D,H,W,8] -> [D,H,W]."""
-    D, H, W, C = x_cl.shape
-    if C != 8 or tuple(wtap.shape) != (3, 3, 3, 8):
-        raise ValueError("conv3d_prob_cl8: x_cl [D,H,W,8], wtap [3,3,3,8]")
-    out = torch.empty((D, H, W), dtype=torch.float32, device=x_cl.device)
-    check(_lib.load().cds_conv3d_prob_cl8_f32(_dev(x_cl, "x"), _dev(wtap, "weight_tap"), out.data_ptr(), D, H, W, _stream(x_cl)),
-          "cds_conv3d_prob_cl8_f32")
     return out
 
 

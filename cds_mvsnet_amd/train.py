@@ -8,16 +8,17 @@
   (981 622 parameters = 3.9 MB -> one bucket, one RCCL all-reduce per step: the exchange is latency-bound on xGMI, so
   fewer/larger messages, not NCCL-style 25 MB overlap buckets), divided by the world size and unpacked.  BatchNorm
   statistics stay per replica like ``nn.DataParallel``.
-* :func:`train_step` — forward (optionally under bf16 autocast for the PyTorch-op convolution stacks; the HIP
-  warp/aggregate Function, the soft-argmin and the loss stay fp32), ``final_loss``, backward, gradient exchange,
-  optimizer step (trainer.py:69-82).
+* :func:`train_step` — forward, ``final_loss``, backward, gradient exchange, optimizer step (trainer.py:69-82), all fp32.
 
-bf16 note: the reference trains in fp32 and has no AMP; BASELINE config 5 asks for bf16.  Autocast covers conv / matmul
-ops only, InstanceNorm/BatchNorm statistics and softmax run in fp32 through autocast's own promotion rules.
+Precision: the reference trains in fp32 and has no AMP.  BASELINE config 5 is labelled bf16; every training kernel here is fp32 (the
+rounds-2/3 experiment, ``torch.autocast(bf16)`` around fp32 kernels, only added casts and was slower, so it was removed): config 5 runs
+fp32.  A bf16 policy would mean bf16 STORAGE of the 2D activations with fp32 accumulation inside the kernels; it is not built.
 """
 from __future__ import annotations
 
+import bisect
 import contextlib
+import weakref
 import os
 from typing import Dict, Iterable, List, Optional, Sequence, Tuple
 
@@ -136,8 +137,7 @@ class GradAllReducer:
 
 
 def train_step(model: torch.nn.Module, optimizer: torch.optim.Optimizer, sample: Dict[str, object], temperature: float,
-               dlossw: Sequence[float] = (0.5, 1.0, 2.0), reducer: Optional[GradAllReducer] = None,
-               bf16: bool = False) -> Tuple[float, float]:
+               dlossw: Sequence[float] = (0.5, 1.0, 2.0), reducer: Optional[GradAllReducer] = None) -> Tuple[float, float]:
     """One optimisation step on ``sample`` = {imgs, proj_matrices, depth_values, depth: {stageK}, mask: {stageK}}
     (already on the model's device).  Returns (loss, depth_loss) as Python floats."""
     if not model.training:                                   # walking ~1 400 modules costs 1 ms of a CPU-bound 28 ms step
@@ -145,18 +145,50 @@ def train_step(model: torch.nn.Module, optimizer: torch.optim.Optimizer, sample:
     optimizer.zero_grad(set_to_none=True)
     dv = sample["depth_values"]
     interval = dv[:, 1] - dv[:, 0]
-    ctx = torch.autocast("cuda", dtype=torch.bfloat16) if bf16 else contextlib.nullcontext()
-    with ctx:
-        outputs = model(sample["imgs"], sample["proj_matrices"], dv, gt_depths=sample["depth"], temperature=temperature)
+    outputs = model(sample["imgs"], sample["proj_matrices"], dv, gt_depths=sample["depth"], temperature=temperature)
     outputs = _to_float(outputs)
     loss, depth_loss = final_loss(outputs, sample["depth"], sample["mask"], dlossw=list(dlossw), depth_interval=interval)
     # weight gradients on a side stream, joined before anything reads .grad (CDS_TRAIN_SIDE_STREAM=0: everything on one stream)
-    with _scratch.side_stream_weight_gradients(loss.device, SIDE_STREAM_WGRAD):
-        loss.backward()
+    _backward(model, loss)
     if reducer is not None:
         reducer.reduce()
     optimizer.step()
     return float(loss.detach()), float(depth_loss.detach())
+
+
+_SIDE_VERDICT: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()   # model -> (step structure key, side stream is sound)
+
+
+def _backward(model: torch.nn.Module, loss: torch.Tensor) -> None:
+    """loss.backward() with the weight-gradient kernels on a side stream when that is SOUND for this model (see _scratch.py): the first
+    backward of a model runs on one stream and audits that every buffer a weight-gradient kernel filled ended up as the storage of a
+    parameter's `.grad` (so AccumulateGrad launched nothing on it: one gradient per parameter, handed over untouched).  A parameter
+    that is used twice (CDS_TRAIN_BATCH_FEATURES=0 runs FeatureNet 2 V times on shared weights) fails the audit and keeps the single
+    stream: `grad += dw` on the main stream would race with the kernel still writing `dw`."""
+    from . import training
+    dev = loss.device
+    if not (SIDE_STREAM_WGRAD and dev.type == "cuda"):
+        loss.backward()
+        return
+    key = (training.BATCH_FEATURES,)
+    verdict = _SIDE_VERDICT.get(model)
+    if verdict is None or verdict[0] != key:
+        _scratch.audit_begin(dev)
+        try:
+            loss.backward()
+        finally:
+            filled = _scratch.audit_end(dev)
+        starts = sorted(p.grad.data_ptr() for p in model.parameters() if p.grad is not None)
+        ok = bool(filled)
+        for ptr, nbytes in filled:
+            i = bisect.bisect_left(starts, ptr)
+            if i >= len(starts) or starts[i] >= ptr + nbytes:
+                ok = False
+                break
+        _SIDE_VERDICT[model] = (key, ok)
+        return
+    with _scratch.side_stream_weight_gradients(dev, verdict[1]):
+        loss.backward()
 
 
 def _to_float(x):

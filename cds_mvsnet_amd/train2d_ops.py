@@ -70,6 +70,7 @@ def conv2d_wgrad(g: Tensor, x: Tensor, k: int, stride: int, pad: int) -> Tensor:
     if Nx != N:
         raise ValueError("conv2d_wgrad: batch mismatch")
     dw = _scratch.zeros((Co, Cin, k, k), torch.float32, g.device)
+    _scratch.audit_note(dw)
     side = _scratch.side_stream(g.device)
     if side is None:
         check(_lib.load().cds_conv2d_wgrad_f32(_p(g), _p(x), dw.data_ptr(), N, Co, Cin, Ho, Wo, H, W, k, stride, pad, ops._stream(g)),

@@ -33,6 +33,7 @@ def conv3d_wgrad(g: Tensor, xin: Tensor, stride: int) -> Tensor:
     if Bx != B:
         raise ValueError("conv3d_wgrad: batch mismatch")
     dw = _scratch.zeros((Ca, Cb, 3, 3, 3), torch.float32, g.device)
+    _scratch.audit_note(dw)
     side = _scratch.side_stream(g.device)
     if side is None:
         check(_lib.load().cds_conv3d_wgrad_f32(_dev(g), _dev(xin), dw.data_ptr(), B, Ca, Cb, Do, Ho, Wo, Di, Hi, Wi, stride,

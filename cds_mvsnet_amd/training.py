@@ -4,8 +4,8 @@ SURVEY §8(f)-2.  Every stack runs on the hand-written HIP kernels in BOTH direc
 aggregation (``ops.WarpAggregate``: K3 forward, scatter-add backward), CostRegNet with batch-statistics BatchNorm (``train_ops.py``),
 and the 2D stacks - FeatureNet / DynamicConv, visibility CNN, Refinement, soft-argmin (``train2d_ops.py``); the no-gradient pieces
 (K1 entropy, hypothesis generation, confidence) use the inference kernels.  The parameter-holder modules are the inference ones, so
-``state_dict`` / optimisers / checkpoints are unchanged.  The torch-op forms of the 2D stacks below (``_dynamic_conv`` ...) are the
-CPU / ``CDS_TRAIN_HIP2D=0`` path and the float64 reference of tests/test_train2d_gpu.py.  Gradient topology follows the reference: the
+``state_dict`` / optimisers / checkpoints are unchanged.  There is no other backend: CPU tensors raise (the torch-op restatement that
+serves as the float64 reference of the gradient tests is test infrastructure, tests/torch_training_ref.py).  Gradient topology follows the reference: the
 sampling grid has no gradient, the entropy input of the visibility CNN is detached, depth is detached between stages.
 """
 from __future__ import annotations
@@ -22,81 +22,39 @@ from . import _scratch, geometry, ops
 Tensor = torch.Tensor
 
 
-def _att_weights_grouped(seq, curvs: Tensor, groups: int) -> Tensor:
-    """``DynamicConv.att_weights`` (1x1 conv -> BatchNorm2d -> ReLU -> 1x1 conv, dynamic_conv.py:88-91) on a batch that
-    stacks ``groups`` separate calls of the reference: the BatchNorm statistics are taken per group of N / groups samples
-    (what each of those calls would have seen) and the running statistics receive the groups' updates in call order."""
-    conv_a, bn, _, conv_b = seq[0], seq[1], seq[2], seq[3]
-    # statistics and normalisation in fp32 also under bf16 autocast, like nn.BatchNorm2d (the groups == 1 path)
-    h = conv_a(curvs)
-    act_dtype = h.dtype
-    if h.dtype in (torch.bfloat16, torch.float16):
-        h = h.float()
-    N, C, H, W = h.shape
-    hg = h.view(groups, N // groups, C, H, W)
-    mean = hg.mean(dim=(1, 3, 4))                                            # [G,C]
-    var = hg.var(dim=(1, 3, 4), unbiased=False)
-    y = (hg - mean.view(groups, 1, C, 1, 1)) * torch.rsqrt(var.view(groups, 1, C, 1, 1) + bn.eps)
-    y = y * bn.weight.view(1, 1, C, 1, 1).to(y.dtype) + bn.bias.view(1, 1, C, 1, 1).to(y.dtype)
-    if bn.training and bn.track_running_stats:
-        with torch.no_grad():
-            m = bn.momentum if bn.momentum is not None else 0.1
-            n = (N // groups) * H * W
-            rdt = bn.running_mean.dtype
-            wts = m * (1.0 - m) ** torch.arange(groups - 1, -1, -1, device=h.device, dtype=rdt)   # call g, then g+1, ...
-            bn.running_mean.mul_((1.0 - m) ** groups).add_((wts.view(-1, 1) * mean.detach().to(rdt)).sum(dim=0))
-            bn.running_var.mul_((1.0 - m) ** groups).add_((wts.view(-1, 1) * (var.detach().to(rdt) * (n / max(n - 1, 1)))).sum(dim=0))
-            bn.num_batches_tracked += groups
-    return conv_b(F.relu(y.view(N, C, H, W)).to(act_dtype))
+def _need_hip(x: Tensor) -> None:
+    if not x.is_cuda:
+        raise RuntimeError("the training step runs on the HIP kernels only: CPU tensors are not supported (the torch-op restatement "
+                           "used as the float64 reference of the gradient tests lives in tests/torch_training_ref.py)")
 
 
-def _dynamic_conv(dc, x: Tensor, epi: Tensor, T: float, groups: int = 1) -> Tuple[Tensor, Tensor]:
-    """models/dynamic_conv.py:97-122 with torch ops.  x [N,Cin,H,W]; epi [N,2] on x's device.  groups > 1: the batch stacks
-    that many separate calls of the reference (see ``_att_weights_grouped``)."""
-    N, _, H, W = x.shape
-    ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float32, device=x.device),
-                            torch.arange(W, dtype=torch.float32, device=x.device), indexing="ij")
-    u = xs.view(1, 1, H, W) - epi[:, 0].view(N, 1, 1, 1)
-    v = ys.view(1, 1, H, W) - epi[:, 1].view(N, 1, 1, 1)
-    nrm = torch.sqrt(u ** 2 + v ** 2)
-    u, v = u / (nrm + 1e-6), v / (nrm + 1e-6)
-    basis = torch.cat((u ** 2, 2 * u * v, v ** 2), dim=1)
-    curvs, res = [], []
-    for att, conv in zip(dc.att_convs, dc.convs):
-        curvs.append((att(x) * basis).sum(dim=1, keepdim=True))
-        res.append(conv(x).unsqueeze(1))
-    curvs = torch.cat(curvs, dim=1)
-    aw = dc.att_weights(curvs) if (groups == 1 or not dc.att_weights[1].training) else _att_weights_grouped(dc.att_weights, curvs, groups)
-    wts = F.softmax(aw / T, dim=1)
-    return (torch.cat(res, dim=1) * wts.unsqueeze(2)).sum(dim=1), (curvs * wts).sum(dim=1, keepdim=True)
-
-
-def _hip2d(x: Tensor) -> bool:
-    return USE_HIP_TRAIN2D and x.is_cuda
+def _stacked_operands() -> bool:
+    """The K1 / K3 operands and the visibility CNN's input are read straight from the stacked FeatureNet outputs, and the V
+    visibility calls of a stage run as ONE grouped call.  (Patched to False by tests/torch_training_ref.py, whose per-call torch
+    reference follows the reference's own call structure.)"""
+    return True
 
 
 def _dyn(dc, x: Tensor, epi: Tensor, T: float, groups: int = 1) -> Tuple[Tensor, Tensor]:
-    """One DynamicConv: the HIP forward / backward kernels (train2d_ops.dynamic_conv) or, with CDS_TRAIN_HIP2D=0 / on the CPU, torch ops."""
-    if _hip2d(x):
-        from . import train2d_ops
-        return train2d_ops.dynamic_conv(dc, x, epi, T, groups)
-    return _dynamic_conv(dc, x, epi, T, groups)
+    """One DynamicConv (models/dynamic_conv.py:97-122) on the HIP forward / backward kernels.  groups > 1: the batch stacks that many
+    separate calls of the reference; the BatchNorm2d of the attention MLP takes its statistics per group."""
+    _need_hip(x)
+    from . import train2d_ops
+    return train2d_ops.dynamic_conv(dc, x, epi, T, groups)
 
 
 def _in_act(y: Tensor, tanh: bool = False) -> Tensor:
     """InstanceNorm2d + LeakyReLU(0.1) (module.py:66-69) or + tanh (module.py:223)."""
-    if _hip2d(y):
-        from . import train2d_ops
-        return train2d_ops.InstNormAct.apply(y, ops.ACT_TANH if tanh else ops.ACT_LEAKY01)
-    return torch.tanh(F.instance_norm(y)) if tanh else F.leaky_relu(F.instance_norm(y), 0.1)
+    _need_hip(y)
+    from . import train2d_ops
+    return train2d_ops.InstNormAct.apply(y, ops.ACT_TANH if tanh else ops.ACT_LEAKY01)
 
 
 def _conv(conv, x: Tensor) -> Tensor:
-    """A plain nn.Conv2d holder (3x3 stride 1 | 2, 1x1) on the HIP training kernels, or torch."""
-    if _hip2d(x):
-        from . import train2d_ops
-        return train2d_ops.Conv2d.apply(x, conv.weight, conv.bias, conv.stride[0], conv.padding[0])
-    return conv(x)
+    """A plain nn.Conv2d holder (3x3 stride 1 | 2, 1x1) on the HIP training kernels."""
+    _need_hip(x)
+    from . import train2d_ops
+    return train2d_ops.Conv2d.apply(x, conv.weight, conv.bias, conv.stride[0], conv.padding[0])
 
 
 def _unit(unit, x: Tensor, epi: Optional[Tensor], T: float, groups: int = 1):
@@ -132,40 +90,35 @@ def feature_net(net, x: Tensor, epi: Tensor, T: float, groups: int = 1) -> Dict[
     return out
 
 
-def _cbr3(unit, x: Tensor) -> Tensor:
-    return F.relu(unit.bn(unit.conv(x)))
-
-
 BATCH_FEATURES = os.environ.get("CDS_TRAIN_BATCH_FEATURES", "1") != "0"   # 0 = one FeatureNet call per image of every pair, as the reference
-USE_HIP_TRAIN = os.environ.get("CDS_TRAIN_HIP", "1") != "0"   # A/B knob: 0 = PyTorch-ROCm (MIOpen) autograd ops for CostRegNet
-USE_HIP_TRAIN2D = os.environ.get("CDS_TRAIN_HIP2D", "1") != "0"   # A/B knob: 0 = PyTorch-ROCm autograd ops for the 2D stacks
 
 
 def cost_regularization(cr, x: Tensor) -> Tensor:
-    """models/module.py:305-315 (BatchNorm in the module's current mode).  x [B,C,D,h,w] -> [B,1,D,h,w].
-    Default: the hand-written HIP training ops (train_ops.py: convolution forward / data gradient / weight gradient and
-    fused BatchNorm(train) + ReLU + skip kernels); CDS_TRAIN_HIP=0 keeps the stock PyTorch-ROCm autograd ops."""
-    if USE_HIP_TRAIN and x.is_cuda:
-        from . import train_ops
-        return train_ops.cost_regularization(cr, x)
-    c0 = _cbr3(cr.conv0, x)
-    c2 = _cbr3(cr.conv2, _cbr3(cr.conv1, c0))
-    c4 = _cbr3(cr.conv4, _cbr3(cr.conv3, c2))
-    y = _cbr3(cr.conv6, _cbr3(cr.conv5, c4))
-    y = c4 + _cbr3(cr.conv7, y)
-    y = c2 + _cbr3(cr.conv9, y)
-    y = c0 + _cbr3(cr.conv11, y)
-    return cr.prob(y)
+    """models/module.py:305-315 with BatchNorm in batch-statistics mode.  x [B,C,D,h,w] -> [B,1,D,h,w] on the hand-written HIP
+    training ops (train_ops.py: convolution forward / data gradient / weight gradient and fused BatchNorm(train) + ReLU + skip)."""
+    _need_hip(x)
+    from . import train_ops
+    return train_ops.cost_regularization(cr, x)
+
+
+def _softargmin(prob_pre: Tensor, hyp: Tensor) -> Tensor:
+    """softmax over D + depth regression (models/module.py:373-379), HIP forward / backward."""
+    _need_hip(prob_pre)
+    from . import train2d_ops
+    return train2d_ops.SoftArgmin.apply(prob_pre, hyp)
+
+
+def _refinement(net, img: Tensor, depth0: Tensor, dmin: Tensor, dmax: Tensor) -> Tensor:
+    """Refinement (models/module.py:318-370) in training mode, HIP forward / backward."""
+    _need_hip(img)
+    from . import train2d_ops
+    return train2d_ops.refinement(net, img, depth0, dmin, dmax)
 
 
 def _cbr2(unit, x: Tensor, groups: int = 1) -> Tensor:
-    """ConvBn2d holder: Conv2d 3x3 -> BatchNorm2d (module mode) -> ReLU."""
-    if _hip2d(x):
-        from . import train2d_ops
-        return train2d_ops.bn_relu2d(unit.bn, _conv(unit.conv, x), True, groups)
-    if groups > 1:
-        raise ValueError("grouped BatchNorm calls need the HIP training ops")
-    return F.relu(unit.bn(unit.conv(x)))
+    """ConvBn2d holder: Conv2d 3x3 -> BatchNorm2d (module mode) -> ReLU.  groups > 1: the batch stacks that many calls."""
+    from . import train2d_ops
+    return train2d_ops.bn_relu2d(unit.bn, _conv(unit.conv, x), True, groups)
 
 
 def _visibility(seq, x: Tensor, groups: int = 1) -> Tensor:
@@ -242,9 +195,9 @@ def stage_forward_train(stage_net, features, cams: Tensor, depth_values: Tensor,
     features = list over source views of {'ref': (fea [B,C,h,w], nc_sum [B,1,h,w], nc [B,1,h,w]), 'src': (fea, nc_sum, _)};
     cams [B,N,2,4,4] (host); depth_values [B,D,h,w].  Returns depth / photometric_confidence / feat_distance / norm_curv.
     K1 (detached, model.py:49), hypotheses and confidence run on the HIP kernels without gradient; K3 forward / backward and
-    CostRegNet forward / backward on the HIP kernels with gradient; the visibility CNN on PyTorch-ROCm autograd ops."""
+    CostRegNet, the visibility CNN and the soft-argmin forward / backward on the HIP kernels with gradient."""
     stacked = features if isinstance(features, StackedFeatures) else None
-    if stacked is not None and not _hip2d(stacked.fea):
+    if stacked is not None and not _stacked_operands():
         features, stacked = stacked.as_list(), None
     V = len(features)
     B = depth_values.shape[0]
@@ -266,7 +219,7 @@ def stage_forward_train(stage_net, features, cams: Tensor, depth_values: Tensor,
     with torch.no_grad():                                               # K1, detached input (model.py:49)
         ent = torch.stack([ops.warp_entropy(ref[b].detach().contiguous(), src[b].detach(), mats[b], hyps[b])
                            for b in range(B)])                           # [B,V,h,w]
-    if _hip2d(ent) and V > 1:
+    if _stacked_operands() and V > 1:
         # the V calls of model.py:51 as ONE call on the views stacked along the batch axis (BatchNorm statistics per view)
         nc_ref = nc6[:, 0] if stacked is not None else torch.stack([features[v]["ref"][2].float()[:, 0] for v in range(V)])   # [V,B,h,w]
         x = torch.stack((ent.transpose(0, 1), nc_ref), dim=2).reshape(V * B, 2, ent.shape[-2], ent.shape[-1])
@@ -293,11 +246,7 @@ def stage_forward_train(stage_net, features, cams: Tensor, depth_values: Tensor,
         nc_mean = sum((features[v]["ref"][1] + features[v]["src"][1]) / 2 for v in range(V)) / V   # [B,1,h,w]
     hyp_b = _stack(hyps)
     prob_pre = cost_regularization(cost_reg, _stack(vols)).squeeze(1).float()
-    if _hip2d(prob_pre):
-        from . import train2d_ops
-        depth = train2d_ops.SoftArgmin.apply(prob_pre, hyp_b)
-    else:
-        depth = torch.sum(F.softmax(prob_pre, dim=1) * hyp_b, dim=1)
+    depth = _softargmin(prob_pre, hyp_b)
     with torch.no_grad():
         conf = torch.stack([ops.softargmin_conf(prob_pre[b].detach().contiguous(), hyp_b[b])[1] for b in range(B)])
     return {"depth": depth, "photometric_confidence": conf, "feat_distance": _stack(fds), "norm_curv": nc_mean}
@@ -367,7 +316,7 @@ def forward_train(model, imgs: Tensor, proj_matrices: Dict[str, Tensor], depth_v
     # One stream per stage (CDS_TRAIN_STAGE_STREAMS=1, experiment): the forward stays serial (a stage's hypotheses need the previous
     # stage's depth) but depth is DETACHED between stages, so the three backward chains are independent and autograd runs each on the
     # stream of its forward - next to each other.  Every tensor that crosses streams is recorded on the other stream (caching allocator).
-    use_streams = STAGE_STREAMS and BATCH_FEATURES and _hip2d(imgs)
+    use_streams = STAGE_STREAMS and BATCH_FEATURES and _stacked_operands()
     main = torch.cuda.current_stream(dev) if use_streams else None
     prev_stream = None
     for s in range(model.num_stage):

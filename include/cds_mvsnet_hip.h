@@ -139,11 +139,6 @@ int cds_volume_normalize_cl_f32(float* volume, const float* vis_sum, int C, int 
  */
 int cds_softargmin_conf_f32(const float* prob_pre, const float* hyp, float* depth, float* conf,
                             float* prob, int D, int h, int w, int hyp_per_pixel, void* stream);
-/* K5 on the three in-plane maps P_kz [3][D][h][w] of the fused conv11 + prob kernel (cds_deconv3d_prob_sbf_f32): the logit of
- * plane d is P_0[d-1] + P_1[d] + P_2[d+1].  Everything else as cds_softargmin_conf_f32. */
-int cds_softargmin_conf_p3_f32(const float* p3, const float* hyp, float* depth, float* conf, float* prob,
-                               int D, int h, int w, int hyp_per_pixel, void* stream);
-
 
 /*
  * K6 (module.py:394-439 + model.py:176-193): per-pixel hypotheses of a cascade stage.
@@ -199,27 +194,6 @@ int cds_conv3d_sbf_f32(const float* x, const void* weight_split, const float* bi
  * out_planar != 0: the output is written [Cout][2D][2H][2W] (for a planar consumer: conv11 -> prob); skip stays channels-last. */
 int cds_deconv3d_sbf_f32(const float* x, const void* weight_split, const float* bias, const float* skip, float* out,
                          int Cin, int Cout, int D, int H, int W, int act, int out_planar, void* stream);
-/* The prob layer alone on the matrix cores (split-bf16 arithmetic): x [D][H][W][8] channels-last -> out [D][H][W]; prob_split =
- * the Toeplitz layout of prob.weight (ops.split_pack_prob_toeplitz).  The layer is separable along z (prob[z] = P_0[z-1] + P_1[z] +
- * P_2[z+1], P_kz the in-plane 3x3 8 -> 1 convolution): a workgroup marches along z, every plane goes through LDS once, the three
- * z-taps meet in registers.  W % 4 == 0.  (models/module.py:303,315) */
-int cds_conv3d_prob_sbf_f32(const float* x, const void* prob_split, float* out, int D, int H, int W, void* stream);
-
-/*
- * conv11 (ConvTranspose3d 16 -> 8 + BN + ReLU + skip, models/module.py:299-301,313) FUSED with the in-plane part of the prob layer
- * (Conv3d 8 -> 1, module.py:303,314): the 8-channel full-resolution tensor is never written.
- *   x [Da][Ha][Wa][16] channels-last, skip = conv0's output [2Da][2Ha][2Wa][8], weight_split = conv11's split-bf16 weights
- *   (BN folded), bias [8], prob_split = the prob weights in Toeplitz split-bf16 form (ops.split_pack_prob_toeplitz),
- *   out_p3 [3][2Da][2Ha][2Wa]: P_kz[z][y][x] = sum_{ky,kx,c} w[c][kz][ky][kx] y[c][z][y+ky-1][x+kx-1]; Wa must be even.
- */
-int cds_deconv3d_prob_sbf_f32(const float* x, const void* weight_split, const float* bias, const float* skip,
-                              const void* prob_split, float* out_p3, int Da, int Ha, int Wa, void* stream);
-
-
-/* CostRegNet's last layer (Conv3d 8 -> 1, k3 p1, no bias / BatchNorm / ReLU; models/module.py:303) on a channels-last
- * input: x [D][H][W][8] -> out [D][H][W] (the planar logits cds_softargmin_conf_f32 reads).  Plain fp32 FMAs.
- * weight_tap: fp32 [3 ky][3 kx][3 kz][8 ci]. */
-int cds_conv3d_prob_cl8_f32(const float* x, const float* weight_tap, float* out, int D, int H, int W, void* stream);
 
 /*
  * K4 (module.py:125-160): ConvTranspose3d k=3, stride 2, padding 1, output_padding 1 (doubles

@@ -1,6 +1,6 @@
 """Time K1 / K3 alone with HIP events (A/B of kernel variants through env knobs).
 Usage: time_warp.py [h w D C [lo hi]]   (default: the M1 shape; lo/hi = hypothesis range, narrow for cascade stages 2/3)
-Env: NVIEWS (default 5), EXACT=0|1 (sample-position mode), CL=1 (channels-last volume), CDS_K3_SPLIT_VIEWS=1 (two launches for 5/6 views)."""
+Env: NVIEWS (default 5), EXACT=0|1 (sample-position mode), CL=1 (channels-last volume)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -463,29 +463,6 @@ def test_warp_paths_agree_lds_vs_direct(dev, ops):
     assert (outs[0][1] - outs[1][1]).abs().max() < 2e-6
 
 
-def test_k3_single_pass_six_views_equals_two_launches(dev, ops):
-    """The experiment form of K3 for 5 / 6 views (CDS_K3_SPLIT_VIEWS=0: all views resident with 392-texel boxes, one pass) against the
-    shipped two-launch form: same arithmetic per view, the sums differ by fp32 re-association only."""
-    import os, subprocess, sys
-    code = ("import torch,sys; sys.path.insert(0,'.'); from cds_mvsnet_amd import ops, synth, geometry;"
-            "dev=torch.device('cuda:0'); V,C,D,h,w=6,16,20,48,136;"
-            "f=synth.make_pair_features(V,C,h,w,seed=9,sharp=True); cams=synth.stage_cameras(V+1,h,w,seed=8);"
-            "hyp=synth.make_hypotheses(D,h,w,seed=7)[0].to(dev);"
-            "ref=torch.stack([x['ref'][0][0] for x in f]).to(dev).contiguous();"
-            "src=torch.stack([ops.chw_to_hwc(x['src'][0][0].to(dev).contiguous()) for x in f]);"
-            "vis=torch.rand(V,h,w,generator=torch.Generator().manual_seed(3)).to(dev);"
-            "m=geometry.warp_matrices(cams[0]); v,s=ops.warp_aggregate(ref,src,vis,m,hyp,channels_last=True);"
-            "torch.save((v.cpu(),s.cpu()), sys.argv[1])")
-    outs = []
-    for flag in ("0", "1"):
-        path = f"/tmp/cds_split_{flag}.pt"
-        env = dict(os.environ, CDS_K3_SPLIT_VIEWS=flag)
-        subprocess.run([sys.executable, "-c", code, path], check=True, env=env, cwd=os.path.dirname(os.path.dirname(__file__)))
-        outs.append(torch.load(path))
-    assert (outs[0][0] - outs[1][0]).abs().max() < 2e-6
-    assert torch.equal(outs[0][1], outs[1][1])
-
-
 def test_per_plane_hypotheses_equal_broadcast(dev, ops):
     feats, cams, hyp, ref, src, mats, _ = _random_stage(ops, dev, 2, 8, 6, 16, 40, seed=77)
     planes = torch.linspace(430, 890, 6, device=dev)
@@ -934,18 +911,6 @@ def test_deconv3d_split_bf16_is_fp32_class(cin, cout, D, H, W, dev, ops):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("D,H,W", [(9, 7, 70), (4, 4, 64), (6, 9, 131)])
-def test_prob_layer_channels_last(D, H, W, dev, ops):
-    """CostRegNet's last layer (Conv3d 8 -> 1, module.py:303) on a channels-last input against PyTorch fp32."""
-    g = torch.Generator().manual_seed(D * 100 + W)
-    x = torch.randn(8, D, H, W, generator=g)
-    w = torch.randn(1, 8, 3, 3, 3, generator=g) / 216 ** 0.5
-    want = F.conv3d(x.unsqueeze(0), w, padding=1)[0, 0]
-    got = ops.conv3d_prob_cl8(x.permute(1, 2, 3, 0).contiguous().to(dev), ops.pack_prob_cl(w).to(dev)).cpu()
-    assert (got - want).abs().max() < 2e-6 * max(1.0, want.abs().max().item())
-
-
-@pytest.mark.gpu
 @pytest.mark.parametrize("cin,cout,ks,N,H,W,bias", [(8, 8, (3, 5, 7), 2, 21, 44, False), (16, 16, (3, 5), 1, 16, 36, False),
                                                    (32, 32, (1, 3), 2, 9, 20, True), (16, 16, (1, 3), 1, 12, 32, True),
                                                    (8, 8, (1, 3), 3, 8, 64, True)])
@@ -1004,100 +969,3 @@ def test_dynconv_fused_equals_branches_then_blend(cin, cout, ks, N, H, W, bias, 
         assert torch.equal(o1, o2) and torch.equal(n1, n2)
         assert torch.allclose(s1, s2, rtol=1e-12, atol=1e-9)
         assert torch.allclose(a1, a2, rtol=1e-6, atol=1e-7)
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("N,H,W", [(4, 20, 36), (1, 8, 32), (3, 13, 100)])
-def test_visibility_layers_split_bf16(N, H, W, dev, ops):
-    """cds_conv2d_k3_relu_sbf_f32 (visibility CNN layers 2 / 3 + head, model.py:14, split-bf16 on the bf16 matrix cores) against
-    float64 and the fp32-MFMA kernel it replaces (cds_conv2d_k3_c16_f32): fp32-class, with and without the fused 1x1 head."""
-    g = torch.Generator().manual_seed(N * 100 + W)
-    x = torch.randn(N, 16, H, W, generator=g).clamp_min(0)
-    w = torch.randn(16, 16, 3, 3, generator=g) / 12.0
-    b = torch.randn(16, generator=g) * 0.2
-    hw, hb = torch.randn(16, generator=g) * 0.3, torch.randn(1, generator=g)
-    y64 = F.conv2d(x.double(), w.double(), b.double(), padding=1).clamp_min(0)
-    ws = ops.split_pack_dynconv([w.to(dev)])
-    wcl = w.permute(2, 3, 0, 1).reshape(9, 16, 16).contiguous().to(dev)
-    got = ops.conv2d_k3_relu_sbf(x.to(dev), ws, b.to(dev)).cpu()
-    old = ops.conv2d_k3_c16(x.to(dev), wcl, b.to(dev)).cpu()
-    e_new, e_old = (got.double() - y64).abs().max().item(), (old.double() - y64).abs().max().item()
-    ulp = y64.abs().max().item() * 2.0 ** -23
-    assert e_new <= 1.5 * e_old + ulp, (e_new, e_old)
-    h64 = torch.sigmoid((y64 * hw.double().view(1, 16, 1, 1)).sum(1) + hb.double())
-    goth = ops.conv2d_k3_relu_sbf(x.to(dev), ws, b.to(dev), head_w=hw.to(dev), head_b=hb.to(dev)).cpu()
-    oldh = ops.conv2d_k3_c16(x.to(dev), wcl, b.to(dev), head_w=hw.to(dev), head_b=hb.to(dev)).cpu()
-    assert (goth.double() - h64).abs().max().item() <= 1.5 * (oldh.double() - h64).abs().max().item() + 2.0 ** -23
-
-
-@pytest.mark.parametrize("V,C,D,h,w,y0,y1", [(4, 8, 40, 64, 136, 16, 40), (2, 16, 9, 40, 72, 0, 8), (3, 32, 12, 32, 48, 24, 32),
-                                            (6, 16, 20, 48, 64, 8, 48), (1, 8, 70, 24, 200, 8, 24)])
-def test_warp_row_windows_equal_full_grid_rows(V, C, D, h, w, y0, y1, dev, ops):
-    """Row-window forms of K1 / K3 (pixel-slab sharding): reference-side tensors restricted to rows [y0, y1), source maps whole.
-    The window's entropy and volume must equal the same rows of the full-grid call BIT FOR BIT (positions come from the global
-    pixel row), planar and channels-last, both position modes."""
-    feats, cams, hyp, ref, src, mats, hyp_d = _random_stage(ops, dev, V, C, D, h, w, seed=60 + V)
-    vis = (torch.rand(V, h, w, generator=torch.Generator().manual_seed(4)) * 0.8 + 0.1).to(dev)
-    for exact in (True, False):
-        ent_full = ops.warp_entropy(ref, src, mats, hyp_d, exact=exact)
-        ref_w, hyp_w, vis_w = ref[:, :, y0:y1].contiguous(), hyp_d[:, y0:y1].contiguous(), vis[:, y0:y1].contiguous()
-        ent_w = ops.warp_entropy(ref_w, src, mats, hyp_w, exact=exact, window=(h, y0))
-        assert torch.equal(ent_w, ent_full[:, y0:y1])
-        for cl in (False, True):
-            vol_full, vs_full = ops.warp_aggregate(ref, src, vis, mats, hyp_d, channels_last=cl, exact=exact)
-            vol_w, vs_w = ops.warp_aggregate(ref_w, src, vis_w, mats, hyp_w, channels_last=cl, exact=exact, window=(h, y0))
-            assert torch.equal(vs_w, vs_full[y0:y1])
-            assert torch.equal(vol_w, vol_full[:, y0:y1] if cl else vol_full[:, :, y0:y1])
-
-
-@pytest.mark.parametrize("Da,Ha,Wa", [(2, 4, 16), (3, 8, 24), (4, 12, 40), (1, 4, 18), (5, 20, 64)])
-def test_fused_conv11_prob_equals_two_kernels(Da, Ha, Wa, dev, ops):
-    """cds_deconv3d_prob_sbf_f32 (conv11 + in-plane prob, y never written) against the two shipped kernels (transposed convolution
-    + skip -> planar y -> prob) and against a float64 reference: logits P_0[d-1] + P_1[d] + P_2[d+1] and the soft-argmin on the
-    three maps.  Odd tile counts, a width that is not a multiple of 32, a single cell plane."""
-    g = torch.Generator().manual_seed(100 + Wa)
-    x = torch.randn(Da, Ha, Wa, 16, generator=g).to(dev)
-    skip = torch.randn(2 * Da, 2 * Ha, 2 * Wa, 8, generator=g).to(dev)
-    w = (torch.randn(16, 8, 3, 3, 3, generator=g) / (27 * 16 / 8) ** 0.5).to(dev)
-    b = torch.randn(8, generator=g).to(dev)
-    wp = (torch.randn(1, 8, 3, 3, 3, generator=g) / 216 ** 0.5).to(dev)
-    ws, pws = ops.split_pack_deconv3d(w), ops.split_pack_prob_toeplitz(wp)
-    p3 = ops.deconv3d_prob_sbf(x, ws, b, skip, pws)
-    D = 2 * Da
-    got = p3[1].clone()
-    got[1:] += p3[0][:-1]
-    got[:-1] += p3[2][1:]
-    # the shipped two-kernel path
-    y = ops.deconv3d_sbf(x, ws, b, 8, skip=skip, out_planar=True)
-    want = ops.conv3d_k3(y, wp.permute(1, 2, 3, 4, 0).reshape(8, 27, 1).contiguous(), None, relu=False)[0]
-    # float64 reference
-    xd = x.double().permute(3, 0, 1, 2)[None].cpu()
-    yd = torch.relu(F.conv_transpose3d(xd, w.double().cpu(), b.double().cpu(), stride=2, padding=1, output_padding=1))
-    yd = yd + skip.double().permute(3, 0, 1, 2)[None].cpu()
-    ref = F.conv3d(yd, wp.double().cpu(), padding=1)[0, 0]
-    scale = ref.abs().max().item()
-    e_fused, e_two = (got.double().cpu() - ref).abs().max().item(), (want.double().cpu() - ref).abs().max().item()
-    assert e_fused <= max(2.0 * e_two, 2e-6 * scale), (e_fused, e_two, scale)      # fp32-class, like the two-kernel path
-    assert (got - want).abs().max().item() < 1e-5 * max(1.0, scale)
-    hyp = (400.0 + 500.0 * torch.rand(D, 2 * Ha, 2 * Wa, generator=g)).to(dev)
-    d_f, c_f = ops.softargmin_conf_p3(p3, hyp)
-    d_t, c_t = ops.softargmin_conf(want, hyp)
-    assert (d_f - d_t).abs().max() < 2e-3 and (c_f - c_t).abs().mean() < 1e-4
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("D,H,W", [(8, 24, 40), (20, 72, 100), (50, 64, 36), (3, 8, 4), (96, 40, 64)])
-def test_prob_layer_on_the_matrix_cores_is_fp32_class(D, H, W):
-    """cds_conv3d_prob_sbf_f32 (the prob layer alone, z-marching split-bf16 matrix-core kernel) against float64 Conv3d(8 -> 1, k3, p1)
-    (models/module.py:303,315): fp32-class accuracy like every split-bf16 layer, ragged tiles, chunk borders, zero padding."""
-    import torch.nn.functional as F
-    from cds_mvsnet_amd import ops
-    torch.manual_seed(D + W)
-    dev = torch.device("cuda:0")
-    x = torch.randn(D, H, W, 8, dtype=torch.float64) * 2.0
-    x[:, :, :, 3] *= 1e-3                                      # a channel of small magnitudes (exercises the lower split terms)
-    w = torch.randn(1, 8, 3, 3, 3, dtype=torch.float64) * 0.3
-    ref = F.conv3d(x.permute(3, 0, 1, 2).unsqueeze(0), w, padding=1)[0, 0]
-    out = ops.conv3d_prob_sbf(x.float().to(dev).contiguous(), ops.split_pack_prob_toeplitz(w.float().to(dev)))
-    err = (out.double().cpu() - ref).abs().max().item()
-    assert err <= 2e-6 * ref.abs().max().item(), (err, ref.abs().max().item())

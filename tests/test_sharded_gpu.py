@@ -201,7 +201,7 @@ def test_packed_weights_follow_parameter_updates():
 
 def test_config5_training_step_768x576():
     """BASELINE config 5: BlendedMVS training shape 768x576, N=5, refine=True (configs/config_blended.json), one
-    optimisation step in fp32 and under bf16 autocast: finite losses that agree, every layer updated."""
+    optimisation step (fp32 kernels; two fresh models): finite losses that agree, every layer updated."""
     import numpy as np
     from cds_mvsnet_amd import CDSMVSNet, seeded_init_, synth, train as T
     import torch.nn.functional as F
@@ -218,16 +218,15 @@ def test_config5_training_step_768x576():
         mask[s] = (torch.rand(B, H // sc, W // sc, generator=g) > 0.15).float().to(dev)
     sample = {"imgs": imgs, "proj_matrices": cams, "depth_values": dv, "depth": gt, "mask": mask}
     losses = {}
-    for bf16 in (False, True):
+    for rep in (0, 1):
         model = seeded_init_(CDSMVSNet(refine=True, ndepths=(48, 32, 8), depth_interals_ratio=(4.0, 1.5, 0.75)), 7).to(dev)
         opt = T.make_optimizer(model, lr=1e-3)
         before = {n: p.detach().clone() for n, p in model.named_parameters()}
-        l0, d0 = T.train_step(model, opt, sample, temperature=0.1, reducer=T.GradAllReducer(model.parameters(), module=model),
-                              bf16=bf16)
+        l0, d0 = T.train_step(model, opt, sample, temperature=0.1, reducer=T.GradAllReducer(model.parameters(), module=model))
         assert np.isfinite(l0) and np.isfinite(d0) and d0 > 0
         moved = sum(1 for n, p in model.named_parameters() if not torch.equal(p.detach(), before[n]))
         assert moved > 0.9 * len(before)
-        losses[bf16] = l0
+        losses[rep] = l0
         del model, opt
         torch.cuda.empty_cache()
-    assert abs(losses[True] - losses[False]) < 0.05 * abs(losses[False]), losses
+    assert abs(losses[1] - losses[0]) <= 1e-4 * abs(losses[0]), losses

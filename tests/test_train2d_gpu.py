@@ -1,11 +1,14 @@
 """HIP forward / backward of the 2D training stacks (csrc/train2d.hip, train2d_ops.py) against float64 torch autograd of the same
-expressions (training.py's torch functions = models/dynamic_conv.py:97-122, models/module.py:28-71,373-379 restated with torch ops).
+expressions (tests/torch_training_ref.py = models/dynamic_conv.py:97-122, models/module.py:28-71,373-379 restated with torch ops).
 Tolerance: 5e-4 of the largest reference magnitude per tensor (fp32 kernels, fp64 reference)."""
+import contextlib
 import copy
 
 import pytest
 import torch
 import torch.nn.functional as F
+
+import torch_training_ref as TR
 
 pytestmark = pytest.mark.gpu
 
@@ -86,7 +89,7 @@ def test_dynamic_conv_forward_backward(cin, cout, ks, bias, groups, T, train, sb
     x = torch.randn(N, cin, H, W, dtype=torch.float64)
     epi = torch.tensor([[5.5, -3.0], [100.0, 40.0], [-20.0, 10.0], [18.2, 12.7]], dtype=torch.float64)
     xr = x.clone().requires_grad_(True)
-    yr, ncr = training._dynamic_conv(ref, xr, epi, T, groups)
+    yr, ncr = TR.dynamic_conv(ref, xr, epi, T, groups)
     gy, gn = torch.randn_like(yr), torch.randn_like(ncr)
     (yr * gy).sum().add((ncr * gn).sum()).backward()
     xg = x.float().to(dev).requires_grad_(True)
@@ -142,19 +145,16 @@ def test_full_training_forward_equals_torch_2d_stacks(refine, B):
     gt["stage4"] = F.interpolate(base.unsqueeze(1), (Hm, Wm) if refine else (H, W), mode="nearest")[:, 0].contiguous().to(dev)
     mask["stage4"] = torch.ones_like(gt["stage4"])
     res = {}
-    old = training.USE_HIP_TRAIN2D
-    try:
+    if True:
         for hip in (False, True):
-            training.USE_HIP_TRAIN2D = hip
             model = seeded_init_(CDSMVSNet(refine=refine, ndepths=(48, 32, 8), depth_interals_ratio=(4.0, 2.0, 1.0)), 7).to(dev)
             model.train()
-            out = model(imgs, cams, dv, gt_depths=gt, temperature=0.1)
-            loss, _ = losses.final_loss(out, gt, mask, depth_interval=dv[:, 1] - dv[:, 0], dlossw=[0.5, 1.0, 2.0])
-            loss.backward()
+            with (contextlib.nullcontext() if hip else TR.torch_layers(two_d=True, three_d=False)):
+                out = model(imgs, cams, dv, gt_depths=gt, temperature=0.1)
+                loss, _ = losses.final_loss(out, gt, mask, depth_interval=dv[:, 1] - dv[:, 0], dlossw=[0.5, 1.0, 2.0])
+                loss.backward()
             res[hip] = (loss.detach(), out["refined_depth"].detach(), {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None},
                         {n: b.detach().clone() for n, b in model.named_buffers()})
-    finally:
-        training.USE_HIP_TRAIN2D = old
     _close(res[True][0], res[False][0], "loss", rel=1e-4)
     _close(res[True][1], res[False][1], "refined_depth", rel=1e-4)
     assert set(res[True][2]) == set(res[False][2])
@@ -199,7 +199,7 @@ def test_refinement_forward_backward():
     img = torch.rand(B, 3, H, W, dtype=torch.float64)
     d0 = 500.0 + 100.0 * torch.rand(B, 1, H // 2, W // 2, dtype=torch.float64)
     dmin, dmax = torch.tensor([425.0, 430.0], dtype=torch.float64), torch.tensor([905.0, 900.0], dtype=torch.float64)
-    yr = ref._forward_autograd(img, d0, dmin, dmax)
+    yr = TR.refinement(ref, img, d0, dmin, dmax)
     g = torch.randn_like(yr)
     yr.backward(g)
     y = t2.refinement(hip, img.float().to(dev), d0.float().to(dev), dmin.float().to(dev), dmax.float().to(dev))
@@ -223,7 +223,7 @@ def test_visibility_cnn_forward_backward():
     hip = copy.deepcopy(seq).to(dev)
     x = torch.randn(2, 2, 24, 40, dtype=torch.float64)
     xr = x.clone().requires_grad_(True)
-    yr = training._visibility(ref, xr)
+    yr = TR.visibility(ref, xr)
     g = torch.randn_like(yr)
     yr.backward(g)
     xg = x.float().to(dev).requires_grad_(True)

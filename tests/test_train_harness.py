@@ -1,5 +1,5 @@
 """Training-loop pieces: schedules, optimiser set-up, the flat-bucket gradient all-reduce on gloo
-(world size 2, CPU) and one optimisation step on the GPU in fp32 and under bf16 autocast."""
+(world size 2, CPU) and one optimisation step on the GPU (fp32: the training kernels are fp32, see train.py)."""
 import os
 import socket
 
@@ -104,22 +104,53 @@ def _train_sample(dev, B=1, N=3, H=64, W=96):
 
 
 @pytest.mark.gpu
-def test_train_step_fp32_and_bf16():
+def test_train_step_fp32():
+    """Three optimisation steps from the same weights with the weight-gradient side stream allowed and forbidden: step 1 audits a
+    single-stream backward (train._backward), steps 2 and 3 run the weight gradients on the side stream when the audit allows it;
+    the loss of step 3 depends on the gradients of both kinds of step and must agree with the single-stream run."""
     from cds_mvsnet_amd import CDSMVSNet, seeded_init_
     dev = torch.device("cuda")
     sample = _train_sample(dev)
     losses = {}
-    for bf16 in (False, True):
+    old = T.SIDE_STREAM_WGRAD
+    try:
+        for side in (False, True):
+            T.SIDE_STREAM_WGRAD = side
+            model = seeded_init_(CDSMVSNet(refine=False, ndepths=(48, 32, 8), depth_interals_ratio=(4.0, 2.0, 1.0)), 7).to(dev)
+            opt = T.make_optimizer(model, lr=1e-3)
+            before = {n: p.detach().clone() for n, p in model.named_parameters()}
+            ls = [T.train_step(model, opt, sample, temperature=0.1, reducer=T.GradAllReducer(model.parameters())) for _ in range(3)]
+            assert all(np.isfinite(l) and np.isfinite(d) and d > 0 for l, d in ls)
+            moved = sum(1 for n, p in model.named_parameters() if not torch.equal(p.detach(), before[n]))
+            assert moved > 0.9 * len(before)                 # every layer is trained (weight decay touches all of them)
+            losses[side] = ls
+            if side:
+                assert T._SIDE_VERDICT[model][1] is True      # one gradient per parameter, handed over untouched: the side stream is sound
+    finally:
+        T.SIDE_STREAM_WGRAD = old
+    assert abs(losses[True][0][0] - losses[False][0][0]) <= 1e-5 * abs(losses[False][0][0])
+    assert abs(losses[True][2][0] - losses[False][2][0]) <= 2e-3 * abs(losses[False][2][0]), losses
+
+
+@pytest.mark.gpu
+def test_side_stream_is_refused_when_parameters_are_used_twice():
+    """with CDS_TRAIN_BATCH_FEATURES=0 FeatureNet runs 2 V times on shared weights, AccumulateGrad then launches
+    `grad += dw` on the main stream while a side-stream kernel may still be writing `dw`.  The audit of the first backward must see
+    that (a weight-gradient buffer that did not become a parameter's .grad storage) and keep the single stream."""
+    from cds_mvsnet_amd import CDSMVSNet, seeded_init_, training
+    dev = torch.device("cuda")
+    sample = _train_sample(dev)
+    old = training.BATCH_FEATURES
+    try:
+        training.BATCH_FEATURES = False
         model = seeded_init_(CDSMVSNet(refine=False, ndepths=(48, 32, 8), depth_interals_ratio=(4.0, 2.0, 1.0)), 7).to(dev)
         opt = T.make_optimizer(model, lr=1e-3)
-        before = {n: p.detach().clone() for n, p in model.named_parameters()}
-        l0, d0 = T.train_step(model, opt, sample, temperature=0.1, reducer=T.GradAllReducer(model.parameters()), bf16=bf16)
-        assert np.isfinite(l0) and np.isfinite(d0) and d0 > 0
-        moved = sum(1 for n, p in model.named_parameters() if not torch.equal(p.detach(), before[n]))
-        assert moved > 0.9 * len(before)                 # every layer is trained (weight decay touches all of them)
-        losses[bf16] = (l0, d0)
-    # bf16 autocast only changes the convolution stacks' arithmetic: same loss to a few per cent
-    assert abs(losses[True][0] - losses[False][0]) < 0.05 * abs(losses[False][0])
+        for _ in range(2):
+            l, d = T.train_step(model, opt, sample, temperature=0.1)
+            assert np.isfinite(l)
+        assert T._SIDE_VERDICT[model] == ((False,), False)
+    finally:
+        training.BATCH_FEATURES = old
 
 
 @pytest.mark.gpu
@@ -137,12 +168,8 @@ def test_costreg_training_kernels_vs_torch_autograd(C, B, D, h, w):
     x = torch.randn(B, C, D, h, w, generator=g)
     gout = torch.randn(B, 1, D, h, w, generator=g)
     xr = x.double().requires_grad_(True)
-    old = training.USE_HIP_TRAIN
-    training.USE_HIP_TRAIN = False
-    try:
-        yr = training.cost_regularization(ref, xr)            # stock PyTorch ops, float64, CPU
-    finally:
-        training.USE_HIP_TRAIN = old
+    import torch_training_ref as TR
+    yr = TR.cost_regularization(ref, xr)                      # stock PyTorch ops, float64, CPU (test infrastructure)
     yr.backward(gout.double())
     net = net.to(dev)
     xg = x.to(dev).requires_grad_(True)
@@ -195,26 +222,28 @@ def test_stacked_feature_net_calls_equal_separate_calls():
     """training.forward_train runs FeatureNet ONCE on the 2 V B images of all pairs (launch-bound step) where the reference
     makes 2 V calls (models/model.py:154-161).  The only cross-sample operation in FeatureNet is the BatchNorm2d inside every
     DynamicConv's attention MLP (dynamic_conv.py:88-91): stacked, its statistics must be taken per original call and the
-    running statistics must receive the calls' updates in order.  CPU, torch ops: features, gradients and running statistics
+    running statistics must receive the calls' updates in order.  CPU, torch ops (tests/torch_training_ref.py): features, gradients and running statistics
     of the stacked call against the separate calls."""
     import copy
     from cds_mvsnet_amd import CDSMVSNet, seeded_init_
     from cds_mvsnet_amd.training import feature_net
+    import torch_training_ref as TR
     a = seeded_init_(CDSMVSNet(refine=False), 7).double().train()       # float64: the comparison is about semantics
     b = copy.deepcopy(a)
     g = torch.Generator().manual_seed(3)
     x = torch.rand(6, 3, 48, 64, generator=g).double()
     e = torch.rand(6, 2, generator=g).double() * 80
-    fa = feature_net(a.feature, x, e, 0.1, groups=3)
-    sum(fa[k][0].square().sum() + fa[k][1].sum() for k in fa).backward()
-    loss_b = 0
-    for i in range(3):
-        fb = feature_net(b.feature, x[2 * i:2 * i + 2], e[2 * i:2 * i + 2], 0.1)
-        for k in fa:
-            for q in range(3):
-                assert (fa[k][q][2 * i:2 * i + 2] - fb[k][q]).abs().max() < 1e-9, (k, q)
-        loss_b = loss_b + sum(fb[k][0].square().sum() + fb[k][1].sum() for k in fb)
-    loss_b.backward()
+    with TR.torch_layers():                                             # float64 on the CPU: the torch restatement of the layers
+        fa = feature_net(a.feature, x, e, 0.1, groups=3)
+        sum(fa[k][0].square().sum() + fa[k][1].sum() for k in fa).backward()
+        loss_b = 0
+        for i in range(3):
+            fb = feature_net(b.feature, x[2 * i:2 * i + 2], e[2 * i:2 * i + 2], 0.1)
+            for k in fa:
+                for q in range(3):
+                    assert (fa[k][q][2 * i:2 * i + 2] - fb[k][q]).abs().max() < 1e-9, (k, q)
+            loss_b = loss_b + sum(fb[k][0].square().sum() + fb[k][1].sum() for k in fb)
+        loss_b.backward()
     for (n, pa), (_, pb) in zip(a.feature.named_parameters(), b.feature.named_parameters()):
         assert (pa.grad - pb.grad).abs().max() <= 1e-8 * max(pb.grad.abs().max().item(), 1e-3), n
     for (n, ba), (_, bb) in zip(a.feature.named_buffers(), b.feature.named_buffers()):
