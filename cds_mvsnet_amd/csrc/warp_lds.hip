@@ -204,15 +204,6 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ v2f splat2(float a) { return (v2f){a, a}; }
 
-// a / b for two planes at once: v_rcp + one Newton step for the reciprocal, then two Markstein corrections of the
-// quotient (correctly rounded for operands in the normal range; the pole z -> 0 yields inf/NaN like IEEE division).
-__device__ __forceinline__ v2f div2_refine(v2f a, v2f b, v2f y) {
-  v2f q = a * y;
-  v2f r = fma2(-b, q, a);
-  q = fma2(r, y, q);
-  r = fma2(-b, q, a);
-  return fma2(r, y, q);
-}
 // a / c for a constant c with rc = RN(1/c): one correction gives the correctly rounded quotient.
 __device__ __forceinline__ v2f div2_const(v2f a, float c, float rc) {
   v2f q = a * rc;
@@ -225,11 +216,12 @@ struct Geo {       // per launch constants
   float half_w, half_h, rhw, rhh;
 };
 
-// Sample positions of two consecutive planes.  FAST = false: the reference's fp32 operation order (= cds_taps: correctly
-// rounded divisions by z + 1e-6 and by (w-1)/2, ATen's normalise / de-normalise round trip; 33 packed instructions per plane
-// pair and view, sample positions bit-identical to F.grid_sample's).  FAST = true (the default of the product path, flag
-// CDS_WARP_FAST_POSITIONS): sample at (u, v) = p.xy * v_rcp(z) directly, 13 instructions; positions move by <= ~1e-4 px
-// (volume max-abs 4e-6 against a tolerance of 1e-5, depth mean-L1 unchanged: profiles/r02_relaxed_positions_ab.md).
+// Sample positions of two consecutive planes.  FAST = false (the DEFAULT of the product path, ops.WARP_EXACT): the reference's fp32
+// operation order (= cds_taps: correctly rounded divisions by z + 1e-6 and by (w-1)/2, ATen's normalise / de-normalise round trip;
+// sample positions bit-identical to F.grid_sample's).  FAST = true (per-call flag CDS_WARP_FAST_POSITIONS, opt-in): sample at
+// (u, v) = p.xy * v_rcp(z) directly; positions then differ by up to ~1e-4 px at w = 640, which moves the volume of sharp feature
+// maps by 8.4e-5 against the oracle - 8x the 1e-5 parity tolerance (test_fast_positions_leave_the_parity_tolerance_at_full_width;
+// exact mode 1.2e-7) - while the depth mean-L1 is unaffected.
 template <bool FAST>
 __device__ __forceinline__ void positions2(const float r[3], const float* __restrict__ t, v2f d, const Geo& g, v2f& ix,
                                            v2f& iy) {
@@ -247,11 +239,13 @@ __device__ __forceinline__ void positions2(const float r[3], const float* __rest
   }
   const v2f e = fma2(-z, y0, splat2(1.0f));
   const v2f y = fma2(e, y0, y0);
-  // u = px / z and v = py / z (div2_refine), written interleaved: two independent dependency chains
-  v2f qu = px * y, qv = py * y;
-  v2f ru = fma2(-z, qu, px), rv = fma2(-z, qv, py);
-  qu = fma2(ru, y, qu); qv = fma2(rv, y, qv);
-  ru = fma2(-z, qu, px); rv = fma2(-z, qv, py);
+  // u = px / z and v = py / z, written interleaved: two independent dependency chains.  y is the Newton-refined reciprocal
+  // (correctly rounded for all but ~1e-6 of the operands), so ONE Markstein correction of the quotient yields the correctly
+  // rounded result: 0 mismatches against IEEE division over 12 M random operand pairs incl. +-1 ulp errors of v_rcp_f32
+  // (profiles/r04_experiments.md; the bit-equality tests against F.grid_sample's positions are unchanged).  Round 3 spent a
+  // second correction: 4 more packed instructions per view and plane pair, K3 0.947 -> 0.929 ms, K1 0.790 -> 0.770 ms without it.
+  const v2f qu = px * y, qv = py * y;
+  const v2f ru = fma2(-z, qu, px), rv = fma2(-z, qv, py);
   const v2f u = fma2(ru, y, qu), v = fma2(rv, y, qv);
   // g = u / half - 1 (div2_const), interleaved as well
   v2f qx = u * g.rhw, qy = v * g.rhh;

@@ -43,9 +43,11 @@ extern "C" {
 #define CDS_AGG_CHANNELS_LAST 4 /* volume laid out [D][h][w][C] (a voxel's channels contiguous: one 32-byte store per 8 channels) */
 /*
  * Sample-position arithmetic of the LDS-staged K1 / K3 kernels (flag of cds_warp_aggregate_f32 and cds_warp_entropy_flags_f32).
- * Absent: the reference's fp32 operation order (true divisions, ATen's normalise / de-normalise round trip): positions
- * bit-identical to F.grid_sample's.  Set: (u, v) = p.xy * rcp(p.z + 1e-6) directly; positions move by <= ~1e-4 px, the volume by
- * <= 4e-6 (tolerance 1e-5), the depth mean-L1 not at all (profiles/r02_relaxed_positions_ab.md); 9 % faster.  The direct
+ * Absent (what the product path passes by default): the reference's fp32 operation order (correctly rounded divisions, ATen's
+ * normalise / de-normalise round trip): sample positions bit-identical to F.grid_sample's.  Set (opt-in): (u, v) = p.xy *
+ * rcp(p.z + 1e-6) directly, 5-11 % faster; the positions then differ by up to ~1e-4 px at w = 640 and the volume of sharp
+ * feature maps moves by up to 8.4e-5 against the reference - OUTSIDE the 1e-5 parity tolerance (exact mode: 1.2e-7); the depth
+ * mean-L1 is unaffected (tests/test_hip_parity.py::test_fast_positions_leave_the_parity_tolerance_at_full_width).  The direct
  * (non-LDS) fallback kernels always use the reference order.
  */
 #define CDS_AGG_FAST_POSITIONS 8
