@@ -312,6 +312,13 @@ static bool cds_warp_args_ok(int V, int C, int D, int h, int w) {
   return V >= 1 && V <= CDS_MAX_VIEWS && (C == 8 || C == 16 || C == 32) && D >= 1 && h >= 1 && w >= 1;
 }
 
+// Shapes the LDS-staged row-window kernels cover (the conditions cds_warp_*_lds_launch rejects, checked BEFORE anything is launched:
+// the window entry points have no direct-kernel fallback and must not leave side effects behind an error return).
+static bool cds_warp_window_ok(int V, int C, int D, int h, int w, int hs, int y_off) {
+  return cds_warp_args_ok(V, C, D, h, w) && w >= 2 && hs >= 2 && hs >= h && y_off >= 0 && y_off + h <= hs &&
+         (size_t)D * h * w * 4 < ((size_t)1 << 32);
+}
+
 static void cds_fill_mats(WarpMats& wm, const float* mats_host, int V) {
   for (int v = 0; v < CDS_MAX_VIEWS; ++v)
     for (int i = 0; i < 12; ++i) wm.m[v][i] = v < V ? mats_host[v * 12 + i] : 0.f;
@@ -387,9 +394,7 @@ extern "C" int cds_warp_entropy_flags_f32(const float* ref_chw, const float* src
 extern "C" int cds_warp_entropy_window_f32(const float* ref_chw, const float* src_hwc, const float* mats_host, const float* hyp,
                                            float* entropy, int V, int C, int D, int h, int w, int hs, int y_off, int flags,
                                            void* stream) {
-  if (!ref_chw || !src_hwc || !mats_host || !hyp || !entropy || V < 1 || V > CDS_MAX_VIEWS || D < 1 || h < 1 || hs < h || y_off < 0 ||
-      y_off + h > hs)
-    return CDS_EINVAL;
+  if (!ref_chw || !src_hwc || !mats_host || !hyp || !entropy || !cds_warp_window_ok(V, C, D, h, w, hs, y_off)) return CDS_EINVAL;
   WarpMats wm;
   cds_fill_mats(wm, mats_host, V);
   if (!cds_warp_entropy_lds_launch(ref_chw, src_hwc, wm, hyp, entropy, V, C, D, h, w, 1, (flags & CDS_WARP_FAST_POSITIONS) != 0,
@@ -401,8 +406,7 @@ extern "C" int cds_warp_entropy_window_f32(const float* ref_chw, const float* sr
 extern "C" int cds_warp_aggregate_window_f32(const float* ref_chw, const float* src_hwc, const float* vis_w, const float* mats_host,
                                              const float* hyp, float* volume, float* vis_sum, int V, int C, int D, int h, int w,
                                              int hs, int y_off, int flags, void* stream) {
-  if (!ref_chw || !src_hwc || !vis_w || !mats_host || !hyp || !volume || !vis_sum || V < 1 || V > CDS_MAX_VIEWS || D < 1 || h < 1 ||
-      hs < h || y_off < 0 || y_off + h > hs)
+  if (!ref_chw || !src_hwc || !vis_w || !mats_host || !hyp || !volume || !vis_sum || !cds_warp_window_ok(V, C, D, h, w, hs, y_off))
     return CDS_EINVAL;
   WarpMats wm;
   cds_fill_mats(wm, mats_host, V);

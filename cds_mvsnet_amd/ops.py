@@ -134,6 +134,13 @@ def _pos_flag(exact: Optional[bool]) -> int:
     return 0 if (WARP_EXACT if exact is None else exact) else AGG_FAST_POSITIONS
 
 
+def _window_shape_ok(C: int, D: int, h: int, w: int, hs: int) -> None:
+    """The row-window kernels are the LDS-staged ones only (no direct-kernel fallback): name the shape instead of a bare EINVAL."""
+    if C not in (8, 16, 32) or w < 2 or hs < 2 or D * h * w * 4 >= 1 << 32:
+        raise ValueError(f"row-window K1 / K3 (the pixel-slab shard) cover C in (8, 16, 32), w >= 2, a grid of >= 2 rows and D*h*w < 2^30 "
+                         f"voxels per window; got C={C}, D={D}, window {h}x{w} of {hs} rows - use exchange='allreduce' for this stage")
+
+
 def _window_args(window: Optional[Tuple[int, int]], h: int) -> Tuple[int, int]:
     """window = (hs, y_off): the reference-side tensors cover rows [y_off, y_off + h) of an hs-row image grid."""
     if window is None:
@@ -156,6 +163,8 @@ def warp_entropy(ref_chw: Tensor, src_hwc: Tensor, mats: Tensor, hyp: Tensor, ex
     D, pp = _hyp_args(hyp, None, h, w)
     if window is not None and not pp:
         raise ValueError("warp_entropy: a row window needs per-pixel hypotheses [D,h,w]")
+    if window is not None:
+        _window_shape_ok(C, D, h, w, hs)
     ent = torch.empty((V, h, w), dtype=torch.float32, device=ref_chw.device)
     lib = _lib.load()
     with prof("warp_entropy"):
@@ -188,6 +197,8 @@ def warp_aggregate(ref_chw: Tensor, src_hwc: Tensor, vis_w: Tensor, mats: Tensor
     D, pp = _hyp_args(hyp, None, h, w)
     if window is not None and not pp:
         raise ValueError("warp_aggregate: a row window needs per-pixel hypotheses [D,h,w]")
+    if window is not None:
+        _window_shape_ok(C, D, h, w, hs)
     dev = ref_chw.device
     vshape = (D, h, w, C) if channels_last else (C, D, h, w)
     if volume is None:

@@ -230,3 +230,29 @@ def test_config5_training_step_768x576():
         del model, opt
         torch.cuda.empty_cache()
     assert abs(losses[1] - losses[0]) <= 1e-4 * abs(losses[0]), losses
+
+
+def test_bench_two_ranks_dry_run_on_one_device(tmp_path):
+    """the WHOLE N > 1 bench path - torch.distributed.run with two ranks, the timed replicas, and the `viewshard`
+    measurements of all three exchanges (all-reduce, reduce_scatter, slab: slab-parallel CostRegNet with its 11 halo exchanges per
+    stage) incl. the self-check - executed every round as a dry run: both ranks on cuda:0, gloo instead of RCCL."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = _free_port()
+    env = dict(os.environ, CDS_BENCH_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--dist-backend", "gloo", "--no-extras", "--no-pmc", "--cpu-sample", "0.1"]
+    res = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=1500)
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["value"] > 0
+    vs = line["viewshard"]
+    assert vs["ranks"] == 2 and vs["backend"] == "gloo"
+    for mode in ("reduce_scatter", "slab"):
+        assert "error" not in vs[mode], vs[mode]
+        assert vs[mode]["stage"]["halo_exchanges_per_depth_map"] == 11
+        assert vs[mode]["stage"]["ms_per_depth_map"] > 0 and vs[mode]["cascade"]["ms_per_depth_map"] > 0
+    assert vs["stage"]["ms_per_depth_map"] > 0 and vs["cascade"]["exchanges_per_depth_map"] == 3
