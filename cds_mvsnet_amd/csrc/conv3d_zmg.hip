@@ -36,12 +36,12 @@ struct ZG {
   static constexpr bool PAIR = PAIR_, DEINT = PAIR_ || S_ == 2;
   static constexpr int CW = CW_, PW = 4, THREADS = (CW + PW) * 64;
   static constexpr int KSPL = RD, MBS = MB;                       // wave = (round, cout block, row part)
-  static_assert(CW % (KSPL * MBS) == 0 && (KSPL == 1 || KSPL == 2), "consumer waves");
+  static_assert(CW % (KSPL * MBS) == 0 && (KSPL == 1 || KSPL == 2 || KSPL == 4), "consumer waves");
   static constexpr int PARTS = CW / (KSPL * MBS);
   static constexpr int ROWS = TYO / PARTS;                        // output rows per consumer wave
   static constexpr int XT = TXO / (PAIR ? 32 : 16);
   static constexpr int NTW = ROWS * XT * G;                       // N-tiles per consumer wave and stage
-  static_assert(TYO % PARTS == 0 && NTW % NG == 0 && (KSPL == 1 || NTW % 2 == 0), "tile split");
+  static_assert(TYO % PARTS == 0 && NTW % NG == 0 && (KSPL != 2 || NTW % 2 == 0), "tile split");
   static constexpr int KW = PAIR ? 4 : 3, KS = (9 * KW + 3) / 4;  // 7 K-steps of 4 taps (27 + 1 zero) | 9 of (kz, ky) x 4 x'
   static constexpr int IX = (TXO - 1) * S + 3, IY = (TYO - 1) * S + 3;
   static constexpr int IXH = DEINT ? (IX + 1) / 2 : 0;            // x parities de-interleaved (stride 2, pair columns)
@@ -50,7 +50,11 @@ struct ZG {
   static constexpr int NINIT = 3 - S;                             // planes below the first stage's new ones
   static constexpr int NRES = S * (G - 1) + 3, NNEW = S * G, R = NRES + NNEW;
   static constexpr int RINGB = R * PLANEB;
-  static constexpr int XCH1 = KSPL == 2 ? CW * (NTW / 2) * 1024 : 0;  // one exchange buffer: every wave sends NTW / 2 N-tiles
+  // one exchange buffer.  K split in two: every wave sends NTW / 2 N-tiles to its partner.  In four (the 32 -> 8 pair layer: the
+  // ring leaves no room for more than three output rows per stage): a slot per (N-tile, source round); N-tile n is finalised by the
+  // wave of round n % 4, which adds the four partial sums in the order of the rounds.
+  static constexpr int XCH1 = KSPL == 2 ? CW * (NTW / 2) * 1024 : (KSPL == 4 ? CW * NTW * 1024 : 0);
+  static constexpr int NFIN = KSPL == 4 ? (NTW + 3) / 4 : 1;          // N-tiles a wave finalises (K split in four)
   // tap of (K-step t, lane group gg): PAIR: (kz, ky) row t, x' = 0, 2, 1, 3 (the two groups of an LDS service group read the same
   // parity plane one position apart); else tap 4 t + gg, tap 27 = zero weights -> any resident position
   static constexpr int tap_of(int t, int gg) {
@@ -231,7 +235,19 @@ __global__ __launch_bounds__(Cfg::THREADS, 1) void conv3d_zmg_kernel(const float
   unsigned char* xch = lds + Cfg::RINGB;                 // [buffer][sender wave][N-tile of its partner's half][lane] x 16 B
   constexpr int NH = NTW / 2;
   f32x4 acc[NTW];
-  f32x4 keep[Cfg::KSPL == 2 ? NH : 1];                  // this wave's partial sums of the half it finalises, across the barrier
+  f32x4 keep[Cfg::KSPL == 2 ? NH : Cfg::NFIN];          // this wave's partial sums of the N-tiles it finalises, across the barrier
+  // K split in four: N-tile n known only at run time (n = 4 j + k)
+  auto store_tile_rt = [&](int n, int st, const f32x4& a) {
+    const int i = n % G, rx = n / G, xt = rx % Cfg::XT, r = rx / Cfg::XT;
+    if (z0 + st * G + i >= z1 || oy0 + r >= Ho) return;            // wave-uniform
+    if (!(ox0 + xt * XW < Wo && co < Cout)) return;
+    float4 o = make_float4(a.x + bv.x, a.y + bv.y, a.z + bv.z, a.w + bv.w);
+    if (act == CDS_ACT_RELU) {
+      o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
+    }
+    sbf_store4(obase + ((size_t)((size_t)(st * G + i) * Ho + r) * Wo + xt * XW) * Cout, o);
+  };
+  const int xgrp = (wave / Cfg::KSPL) * NTW;            // first exchange slot row of this wave's (cout block, row part)
   // finish stage sp: bias / ReLU / store of this wave's outputs.  K split: N-tiles [k NH, (k + 1) NH) = round 0's partial sum +
   // round 1's (the partner's half arrived through exchange buffer sp & 1 before the stage barrier)
   auto finish = [&](int sp) {
@@ -241,6 +257,17 @@ __global__ __launch_bounds__(Cfg::THREADS, 1) void conv3d_zmg_kernel(const float
       for (int m = 0; m < NH; ++m) {
         const f32x4 o = *reinterpret_cast<const f32x4*>(src + m * 1024);
         store_tile(k * NH + m, sp, k == 0 ? keep[m] + o : o + keep[m]);
+      }
+    } else if (Cfg::KSPL == 4) {
+#pragma unroll
+      for (int jf = 0; jf < Cfg::NFIN; ++jf) {
+        const int n = jf * 4 + k;
+        if (n >= NTW) continue;                                      // wave-uniform
+        const unsigned char* src = xch + (sp & 1) * Cfg::XCH1 + ((xgrp + n) * 4) * 1024 + lane * 16;
+        f32x4 total = k == 0 ? keep[jf] : *reinterpret_cast<const f32x4*>(src);
+#pragma unroll
+        for (int kk = 1; kk < 4; ++kk) total = total + (kk == k ? keep[jf] : *reinterpret_cast<const f32x4*>(src + kk * 1024));
+        store_tile_rt(n, sp, total);
       }
     } else {
 #pragma unroll
@@ -323,12 +350,20 @@ __global__ __launch_bounds__(Cfg::THREADS, 1) void conv3d_zmg_kernel(const float
         *reinterpret_cast<f32x4*>(dst + m * 1024) = acc[(k ^ 1) * NH + m];
         keep[m] = acc[k * NH + m];
       }
+    } else if (Cfg::KSPL == 4) {
+      if (st > 0) finish(st - 1);
+      unsigned char* dst = xch + (st & 1) * Cfg::XCH1 + (xgrp * 4 + k) * 1024 + lane * 16;
+#pragma unroll
+      for (int n = 0; n < NTW; ++n) {
+        if ((n & 3) == k) keep[n >> 2] = acc[n];                     // wave-uniform
+        else *reinterpret_cast<f32x4*>(dst + n * 4096) = acc[n];
+      }
     } else if (!late) {
       finish(st);
     }
     __syncthreads();                                   // #(st + 1)
   }
-  if (Cfg::KSPL == 2 || late) finish(nstages - 1);
+  if (Cfg::KSPL >= 2 || late) finish(nstages - 1);
 }
 
 // z segments per column: enough workgroups for the 256 CUs (one workgroup per CU: the ring takes most of the LDS) with full
@@ -376,6 +411,7 @@ int cds_conv3d_zmg_dispatch(const float* x, const void* wsp, const float* bias, 
   if (pair) {
     if (Cin == 8) return launch_zmg<ZG<1, 1, 1, true, 32, 8, 3, 1, 8>>(x, wsp, bias, out, Cout, D, H, W, act, st);
     if (Cin == 16) return launch_zmg<ZG<1, 2, 1, true, 32, 8, 1, 4>>(x, wsp, bias, out, Cout, D, H, W, act, st);
+    if (Cin == 32) return launch_zmg<ZG<1, 4, 1, true, 32, 3, 1, 3>>(x, wsp, bias, out, Cout, D, H, W, act, st);
     return CDS_ZMG_UNSUPPORTED;
   }
   if (stride == 1) {

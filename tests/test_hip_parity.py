@@ -840,7 +840,10 @@ def test_full_forward_view_counts(dev, seeded_state, N):
                                                   (32, 32, 1, 5, 9, 20), (64, 64, 1, 4, 6, 16), (8, 4, 1, 7, 8, 44),
                                                   (8, 16, 2, 9, 17, 35), (16, 32, 2, 8, 16, 32), (32, 64, 2, 6, 9, 21),
                                                   (8, 16, 2, 16, 32, 64), (8, 8, 101, 9, 13, 40), (8, 8, 101, 50, 9, 70), (16, 8, 101, 5, 8, 33),
-                                                  (32, 8, 101, 8, 16, 64)])
+                                                  (32, 8, 101, 8, 16, 64),
+                                                  # ragged volumes over several columns / z segments of the z-marching kernels (conv3d_zmg.hip)
+                                                  (32, 8, 101, 20, 23, 100), (16, 8, 101, 17, 29, 70), (16, 16, 1, 21, 27, 70),
+                                                  (8, 16, 2, 21, 37, 131), (16, 32, 2, 19, 31, 67), (8, 8, 101, 23, 19, 67)])
 def test_conv3d_split_bf16_is_fp32_class(cin, cout, stride, D, H, W, dev, ops):
     """csrc/conv3d_sbf.hip: 3 x 3 x 3 convolution with every fp32 operand split exactly into three bf16 terms and six
     error-compensated partial products on the bf16 matrix cores (fp32 accumulate).  The claim is fp32-CLASS accuracy,
