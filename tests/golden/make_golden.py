@@ -247,6 +247,13 @@ def g6_forward():
         save(f"g6_forward_{tag}", **arrays)
 
 
+G7_FULL_GRADIENTS = ("feature.conv01.conv.att_convs.1.weight", "feature.conv01.conv.convs.2.weight",
+                     "feature.conv10.conv.att_weights.0.weight", "feature.conv10.conv.att_weights.3.weight",
+                     "feature.conv01.conv.att_weights.1.weight", "feature.out1.convs.1.weight",
+                     "cost_regularization.0.conv4.conv.weight", "cost_regularization.0.conv4.bn.weight",
+                     "stage_net.vis.1.0.conv.weight")
+
+
 def g7_training_step():
     """Reference training step on CPU (model.train(), gt depths, final_loss, backward): loss and per-parameter gradient
     norms.  B = 2 so every BatchNorm sees real batch statistics."""
@@ -279,6 +286,12 @@ def g7_training_step():
               "stage3_depth": out["stage3"]["depth"].detach(), "stage1_feat_distance_mean": out["stage1"]["feat_distance"].detach().mean(),
               "grad_prob3": model.cost_regularization[2].prob.weight.grad.clone(),
               "grad_vis0": model.stage_net.vis[0][3].weight.grad.clone()}
+    # full gradient tensors of one parameter of every kind of layer the step trains (norms alone do not pin a
+    # gradient's direction): a DynamicConv curvature branch, a feature branch, the attention MLP's two 1x1 layers and its BatchNorm2d,
+    # a CostRegNet convolution and its BatchNorm3d
+    params = dict(model.named_parameters())
+    for n in G7_FULL_GRADIENTS:
+        arrays["fullgrad:" + n] = params[n].grad.clone()
     for k, v in cams.items():
         arrays["cam_" + k] = v
     for s in gt:

@@ -593,6 +593,19 @@ def test_training_step_matches_reference(dev):
         assert rel[n] < 0.08 or abs(got[n] - want[n]) < 5e-4, (n, got[n], want[n])
     assert sorted(rel.values())[len(rel) // 2] < 2e-3          # median parameter: 0.2 %
     assert (model.cost_regularization[2].prob.weight.grad.cpu() - g["grad_prob3"]).abs().max() < 2e-3 * g["grad_prob3"].abs().max()
+    # full gradient TENSORS of one parameter per kind of layer (captured from the reference's step): direction, not only norm.
+    # fp32 against fp32 through a cascade whose hypothesis ranges switch discretely: the cosine is the robust measure; the
+    # element-wise bound is relative to the tensor's largest entry
+    params = dict(model.named_parameters())
+    full = [k for k in g if k.startswith("fullgrad:")]
+    assert len(full) >= 8
+    for key in full:
+        want_g = g[key].double()
+        got_g = params[key[len("fullgrad:"):]].grad.detach().cpu().double()
+        assert got_g.shape == want_g.shape, key
+        cos = float((got_g * want_g).sum() / (got_g.norm() * want_g.norm() + 1e-30))
+        err = float((got_g - want_g).abs().max() / (want_g.abs().max() + 1e-30))
+        assert cos > 0.999 and err < 0.05, (key, cos, err)
     # BatchNorm running statistics were updated by the step (training-mode BN, momentum 0.1)
     assert model.cost_regularization[0].conv0.bn.num_batches_tracked.item() == 101
 
