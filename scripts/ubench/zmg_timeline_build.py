@@ -42,9 +42,9 @@ rep('''      if (st + 2 < nstages) {
       __syncthreads();                                 // #(st + 2)''')
 # consumer stamps: wave 0 (early) and wave 4 of CW = 8 (late)
 rep('    if (late && st > 0) finish(st - 1);', '    const int cwv = wave == 0 ? 0 : 1; const bool cst = wave == 0 || (Cfg::CW == 8 && wave == 4);\n    if (cst) STAMP(cwv, 0);\n    if (late && st > 0) finish(st - 1);')
-rep('    load_b(0, 0);\n#pragma unroll\n    for (int t = 0; t < NTW; ++t) acc[t]', '    load_b(0, 0);\n    if (cst) STAMP(cwv, 1);\n#pragma unroll\n    for (int t = 0; t < NTW; ++t) acc[t]')
-rep('    if (Cfg::KSPL == 2) {\n      if (!late && st > 0) finish(st - 1);', '    if (cst) STAMP(cwv, 2);\n    if (Cfg::KSPL == 2) {\n      if (!late && st > 0) finish(st - 1);')
-rep('    __syncthreads();                                   // #(st + 1)\n  }\n  if (Cfg::KSPL == 2 || late)', '    if (cst) STAMP(cwv, 3);\n    __syncthreads();                                   // #(st + 1)\n  }\n  if (Cfg::KSPL == 2 || late)')
+rep('    __builtin_amdgcn_s_setprio(0);\n#pragma unroll\n    for (int t = 0; t < NTW; ++t) acc[t]', '    __builtin_amdgcn_s_setprio(0);\n    if (cst) STAMP(cwv, 1);\n#pragma unroll\n    for (int t = 0; t < NTW; ++t) acc[t]')
+rep('    __builtin_amdgcn_s_setprio(CDS_ZMG_CPRIO);\n    if (Cfg::KSPL == 2) {', '    __builtin_amdgcn_s_setprio(CDS_ZMG_CPRIO);\n    if (cst) STAMP(cwv, 2);\n    if (Cfg::KSPL == 2) {')
+rep('    __syncthreads();                                   // #(st + 1)\n  }\n  if (Cfg::KSPL >= 2 || late)', '    if (cst) STAMP(cwv, 3);\n    __syncthreads();                                   // #(st + 1)\n  }\n  if (Cfg::KSPL >= 2 || late)')
 s += '''
 extern "C" int cds_zmg_probe_dump(long long* host, int n) {
   return -(int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_dbg), sizeof(long long) * n, 0, hipMemcpyDeviceToHost);

@@ -1,5 +1,5 @@
 """Run one layer through the timeline probe library and print per-stage phase durations (cycles) of workgroup 300.
-usage: CDS_MVSNET_LIB=.../libcdsmvs_hip.probe_timeline.so CDS_ZMG=2 CDS_ZMG_CW=8 python scripts/ubench/zmg_timeline_run.py conv0"""
+usage: CDS_MVSNET_LIB=.../libcdsmvs_hip.probe_timeline.so python scripts/ubench/zmg_timeline_run.py conv0"""
 import os, sys, ctypes, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from cds_mvsnet_amd import ops, _lib
