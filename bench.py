@@ -433,6 +433,9 @@ def main():
     ap.add_argument("--cpu-sample", type=float, default=1.0,
                     help="linear window fraction for the CPU baseline (1 = the full workload once; 0 = skip)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) in production; gloo only for single-GPU dry runs")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise torch.distributed and run the view-shard side measurements also with ONE rank (the RCCL dry run a "
+                         "one-GPU box allows: communicator, device collectives and the nccl branches of every exchange)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -447,13 +450,20 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
+        if world == 1:
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
+            os.environ.setdefault("MASTER_PORT", "29531")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # a bounded collective timeout: a rank that dies inside an exchange must not leave the others hanging until the driver's limit
+        import datetime
+        tmo = datetime.timedelta(minutes=10)
         if args.dist_backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, timeout=tmo)
         else:
-            dist.init_process_group(args.dist_backend)
+            dist.init_process_group(args.dist_backend, timeout=tmo)
 
     from cds_mvsnet_amd import CDSMVSNet, ops, seeded_init_, synth
     kind = "stage" if args.workload in WORKLOADS else ("cascade" if args.workload in CASCADES else "train")
@@ -607,9 +617,13 @@ def main():
     if world == 1 and args.streams == 1 and args.workload == "M1" and not args.no_extras:
         others = other_workloads(model, dev)
     vs = None
-    if world > 1 and kind != "train" and not args.no_viewshard:
+    if (world > 1 or args.force_dist) and kind != "train" and not args.no_viewshard:
         model._view_shard = None
-        vs = measure_viewshard(model, dev, dist, rank, world, args.exchange)
+        try:
+            vs = measure_viewshard(model, dev, dist, rank, world, args.exchange)
+        except Exception as e:       # noqa: BLE001  (the side measurement must not take the timed headline line down with it)
+            model._view_shard = None
+            vs = {"error": f"{type(e).__name__}: {str(e)[:400]}", "ranks": world, "backend": dist.get_backend()}
     if rank == 0:
         cpu = None
         if world == 1 and args.cpu_sample > 0 and kind == "stage":

@@ -53,13 +53,20 @@ def _unsharded_volume(model, dfe, cams, hyp, stage):
     return vol
 
 
-def test_shard_views_world1_equals_unsharded():
+@pytest.mark.parametrize("backend", ["gloo", "nccl"])
+def test_shard_views_world1_equals_unsharded(backend):
+    """backend "nccl" = RCCL with a one-rank communicator: the only RCCL execution a one-GPU box allows (two ranks on one device are
+    refused as duplicate GPUs).  It runs the library, the device all-reduce and the nccl branches of the exchanges (no staging through
+    the host, the communication stream of HaloComm) at least once per round; the N > 1 traffic itself needs a node."""
     from cds_mvsnet_amd import distributed as cdist
     dev = torch.device("cuda:0")
     torch.cuda.set_device(dev)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(_free_port())
-    dist.init_process_group("gloo", rank=0, world_size=1)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    else:
+        dist.init_process_group("gloo", rank=0, world_size=1)
     try:
         model = _model(dev)
         imgs, cams, dv = _inputs(4, 128, 160, 3, dev)
@@ -256,3 +263,26 @@ def test_bench_two_ranks_dry_run_on_one_device(tmp_path):
         assert vs[mode]["stage"]["halo_exchanges_per_depth_map"] == 11
         assert vs[mode]["stage"]["ms_per_depth_map"] > 0 and vs[mode]["cascade"]["ms_per_depth_map"] > 0
     assert vs["stage"]["ms_per_depth_map"] > 0 and vs["cascade"]["exchanges_per_depth_map"] == 3
+
+
+def test_bench_one_rank_over_rccl(tmp_path):
+    """`bench.py --force-dist`: the view-shard side measurements (all three exchanges, stage + cascade) with a ONE-rank RCCL communicator -
+    every nccl branch of the bench and of the exchanges runs on the device at least once per round (the self-check must pass:
+    ranks == N, backend nccl)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--force-dist", "--no-extras",
+           "--no-pmc", "--cpu-sample", "0"]
+    res = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=1500)
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+    vs = line["viewshard"]
+    assert "error" not in vs, vs
+    assert vs["backend"] == "nccl" and vs["ranks"] == 1 and all(vs["self_check"].values())
+    for mode in ("reduce_scatter", "slab"):
+        assert "error" not in vs[mode], vs[mode]
+    assert vs["stage"]["ms_per_depth_map"] > 0
