@@ -440,148 +440,6 @@ __global__ __launch_bounds__(256) void conv3d_k3_pipe_kernel(const float* __rest
   }
 }
 
-template <int LX, int LY, int LZ, int CO, int CI_CHUNK>
-struct DPipeCfg {
-  static constexpr int IY = LY + 1, IZ = LZ + 1;
-  static constexpr int IXP = (LX + 1 + 3) & ~3;
-  static constexpr int Q = IXP / 4;
-  static constexpr int NS = IZ * IY * Q;
-  static constexpr int TILE = NS * 4;
-  static constexpr int NSLOT = (CI_CHUNK * NS + 255) / 256;
-};
-
-template <int LX, int LY, int LZ, int CO, int CI_CHUNK>
-__global__ __launch_bounds__(256) void deconv3d_k3s2_pipe_kernel(const float* __restrict__ x,
-                                                                 const float* __restrict__ wpk,
-                                                                 const float* __restrict__ bias,
-                                                                 const float* __restrict__ skip, float* __restrict__ out,
-                                                                 int Cin, int Cout, int D, int H, int W, int act,
-                                                                 int tiles_x, int tiles_y, int tiles_z, int ntiles) {
-  using Cfg = DPipeCfg<LX, LY, LZ, CO, CI_CHUNK>;
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int co_blocks = Cout / CO;
-  int lin = cds_xcd_remap(blockIdx.x, ntiles * co_blocks);
-  const int cob = lin % co_blocks;
-  int tile = lin / co_blocks;
-  const int tx_i = tile % tiles_x;
-  tile /= tiles_x;
-  const int ty_i = tile % tiles_y;
-  const int tz_i = tile / tiles_y;
-  const int co0 = cob * CO;
-  const int tid = threadIdx.x;
-  const int lx = tid % LX, ly = (tid / LX) % LY, lz = tid / (LX * LY);
-  const int ax0 = tx_i * LX, ay0 = ty_i * LY, az0 = tz_i * LZ;
-  const size_t plane = (size_t)H * W, vol = (size_t)D * plane;
-
-  int goff[Cfg::NSLOT];
-#pragma unroll
-  for (int j = 0; j < Cfg::NSLOT; ++j) {
-    const int s = tid + 256 * j;
-    const int ci = s / Cfg::NS;
-    int r = s - ci * Cfg::NS;
-    const int row = r / Cfg::Q, c4 = r - row * Cfg::Q;
-    const int rz = row / Cfg::IY, ry = row - rz * Cfg::IY;
-    const int gz = az0 + rz, gy = ay0 + ry, gx = ax0 + 4 * c4;
-    const bool ok = (s < CI_CHUNK * Cfg::NS) && gz < D && gy < H && gx + 3 < W;
-    goff[j] = ok ? (int)((size_t)ci * vol + (size_t)gz * plane + (size_t)gy * W + gx) : -1;
-  }
-  float4 pre[Cfg::NSLOT];
-  auto issue = [&](int ci0) {
-    const float* __restrict__ xb = x + (size_t)ci0 * vol;
-#pragma unroll
-    for (int j = 0; j < Cfg::NSLOT; ++j) {
-      const int s = tid + 256 * j;
-      const int ci = s / Cfg::NS;
-      // branch-free: always load (from element 0 when the slot is outside); masked when written to LDS
-      const bool ok = goff[j] >= 0 && ci0 + ci < Cin;
-      pre[j] = *reinterpret_cast<const float4*>(ok ? xb + goff[j] : x);
-    }
-  };
-
-  float acc[8][CO];
-#pragma unroll
-  for (int q = 0; q < 8; ++q)
-#pragma unroll
-    for (int c = 0; c < CO; ++c) acc[q][c] = 0.f;
-
-  issue(0);
-  for (int ci0 = 0; ci0 < Cin; ci0 += CI_CHUNK) {
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < Cfg::NSLOT; ++j) {
-      const int s = tid + 256 * j;
-      const bool ok = goff[j] >= 0 && ci0 + s / Cfg::NS < Cin;
-      if (s < CI_CHUNK * Cfg::NS)
-        *reinterpret_cast<float4*>(lds + 4 * s) = ok ? pre[j] : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    __syncthreads();
-    if (ci0 + CI_CHUNK < Cin) issue(ci0 + CI_CHUNK);
-    const int cmax = min(CI_CHUNK, Cin - ci0);
-#pragma unroll 1
-    for (int ci = 0; ci < cmax; ++ci) {
-      const float* __restrict__ wc = wpk + ((size_t)(ci0 + ci) * 27) * Cout + co0;
-      const float* t = lds + ci * Cfg::TILE + (lz * Cfg::IY + ly) * Cfg::IXP + lx;
-      float in[2][2][2];
-#pragma unroll
-      for (int dz = 0; dz < 2; ++dz)
-#pragma unroll
-        for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-          for (int dx = 0; dx < 2; ++dx) in[dz][dy][dx] = t[(dz * Cfg::IY + dy) * Cfg::IXP + dx];
-#pragma unroll
-      for (int pz = 0; pz < 2; ++pz)
-#pragma unroll
-        for (int py = 0; py < 2; ++py)
-#pragma unroll
-          for (int px = 0; px < 2; ++px) {
-            const int q = (pz * 2 + py) * 2 + px;
-#pragma unroll
-            for (int sz = 0; sz <= pz; ++sz)
-#pragma unroll
-              for (int sy = 0; sy <= py; ++sy)
-#pragma unroll
-                for (int sx = 0; sx <= px; ++sx) {
-                  const int iz = pz ? 1 - sz : 0, kz = pz ? 2 * sz : 1;
-                  const int iy = py ? 1 - sy : 0, ky = py ? 2 * sy : 1;
-                  const int ix = px ? 1 - sx : 0, kx = px ? 2 * sx : 1;
-                  const float v = in[iz][iy][ix];
-#pragma unroll
-                  for (int c = 0; c < CO; ++c)
-                    acc[q][c] = fmaf(v, wc[((kz * 3 + ky) * 3 + kx) * Cout + c], acc[q][c]);
-                }
-          }
-    }
-  }
-
-  const int az = az0 + lz, ay = ay0 + ly, ax = ax0 + lx;
-  if (az >= D || ay >= H || ax >= W) return;
-  const int Do = 2 * D, Ho = 2 * H, Wo = 2 * W;
-  const size_t oplane = (size_t)Ho * Wo, ovol = (size_t)Do * oplane;
-#pragma unroll
-  for (int c = 0; c < CO; ++c) {
-    const float b = bias ? bias[co0 + c] : 0.f;
-#pragma unroll
-    for (int pz = 0; pz < 2; ++pz)
-#pragma unroll
-      for (int py = 0; py < 2; ++py) {
-        const size_t base = (size_t)(co0 + c) * ovol + (size_t)(2 * az + pz) * oplane + (size_t)(2 * ay + py) * Wo + 2 * ax;
-        float2 v;
-        v.x = acc[(pz * 2 + py) * 2 + 0][c] + b;
-        v.y = acc[(pz * 2 + py) * 2 + 1][c] + b;
-        if (act == CDS_ACT_RELU) {
-          v.x = fmaxf(v.x, 0.f);
-          v.y = fmaxf(v.y, 0.f);
-        }
-        if (skip) {
-          const float2 s = *reinterpret_cast<const float2*>(skip + base);
-          v.x = s.x + v.x;
-          v.y = s.y + v.y;
-        }
-        *reinterpret_cast<float2*>(out + base) = v;
-      }
-  }
-}
-
 template <int S, int LX, int LY, int LZ, int PX, int PZ, int CO, int CI_CHUNK>
 int launch_conv_pipe(const float* x, const float* w, const float* b, const float* skip, float* out, int Cin, int Cout,
                      int D, int H, int W, int act, hipStream_t st) {
@@ -597,25 +455,6 @@ int launch_conv_pipe(const float* x, const float* w, const float* b, const float
   return cds_launch_status();
 }
 
-template <int LX, int LY, int LZ, int CO, int CI_CHUNK>
-int launch_deconv_pipe(const float* x, const float* w, const float* b, const float* skip, float* out, int Cin, int Cout,
-                       int D, int H, int W, int act, hipStream_t st) {
-  using Cfg = DPipeCfg<LX, LY, LZ, CO, CI_CHUNK>;
-  const int tx = cds_ceil_div(W, LX), ty = cds_ceil_div(H, LY), tz = cds_ceil_div(D, LZ);
-  const int ntiles = tx * ty * tz;
-  const size_t lds_bytes = (size_t)Cfg::TILE * CI_CHUNK * sizeof(float);
-  auto kern = deconv3d_k3s2_pipe_kernel<LX, LY, LZ, CO, CI_CHUNK>;
-  hipLaunchKernelGGL(kern, dim3(ntiles * (Cout / CO)), dim3(256), lds_bytes, st, x, w, b, skip, out, Cin, Cout, D, H, W,
-                     act, tx, ty, tz, ntiles);
-  return cds_launch_status();
-}
-
-// ---------------------------------------------------------------------------------------------
-// transposed conv v2 (wide volumes): a workgroup owns 64x4x4 input cells and ONE (z,y) output parity class
-// (pz,py); a thread owns 4 x-adjacent cells and produces their 8 x-adjacent outputs (both x parities) x 8 channels
-// (64 accumulators).  Every weight fetched through the scalar cache is now used by 4 cells (the v1 kernel used each
-// weight once per thread and was bound by scalar-load issue: 4 packed FMAs per s_load instead of 16).
-// ---------------------------------------------------------------------------------------------
 template <int CO, int CI_CHUNK>
 struct D2Cfg {
   static constexpr int LX = 16, LY = 4, LZ = 4, PC = 4;   // PC cells per thread
@@ -946,7 +785,6 @@ extern "C" int cds_conv3d_k3_f32(const float* x, const float* weight, const floa
   const bool wide = Wo >= 48;
   // total elements must fit the 32-bit staging offsets of the pipe kernels
   const bool pipe_ok = (W % 4 == 0) && Wo >= 32 && ((size_t)Cin * D * H * W < (size_t)0x7fffffff);
-  static const int pz_knob = []() { const char* e = getenv("CDS_CONV_PZ"); return e ? atoi(e) : 0; }();  // A/B knob
   static const bool no_mfma = []() { const char* e = getenv("CDS_CONV_NO_MFMA"); return e && e[0] == '1'; }();
   if (!no_mfma) {
     int rc = 0;
@@ -954,21 +792,15 @@ extern "C" int cds_conv3d_k3_f32(const float* x, const float* weight, const floa
   }
   if (pipe_ok && Cout % 8 == 0) {
     if (stride == 1) {
-      if (pz_knob == 2) return launch_conv_pipe<1, 16, 4, 4, 4, 2, 8, 2>(x, weight, bias, skip, out, Cin, Cout, D, H, W, act, st);
       // one input channel per staged chunk (10 KB of LDS, fewer staging registers -> more resident waves): conv0 at M1
-      // 2810 us with 4 channels per chunk, 2610 with 2, 2370 with 1
-      if (pz_knob == 6) return launch_conv_pipe<1, 16, 4, 4, 4, 2, 8, 1>(x, weight, bias, skip, out, Cin, Cout, D, H, W, act, st);
-      if (pz_knob == 4) return launch_conv_pipe<1, 16, 4, 4, 4, 1, 8, 4>(x, weight, bias, skip, out, Cin, Cout, D, H, W, act, st);
-      if (pz_knob == 5) return launch_conv_pipe<1, 16, 4, 4, 4, 1, 8, 2>(x, weight, bias, skip, out, Cin, Cout, D, H, W, act, st);
+      // 2810 us with 4 channels per chunk, 2610 with 2, 2370 with 1 (round-1 A/B; the other blockings were removed in round 4)
       return launch_conv_pipe<1, 16, 4, 4, 4, 1, 8, 1>(x, weight, bias, skip, out, Cin, Cout, D, H, W, act, st);
     }
     return launch_conv_pipe<2, 16, 4, 4, 2, 1, 8, 2>(x, weight, bias, skip, out, Cin, Cout, D, H, W, act, st);
   }
   if (pipe_ok && Cout == 1 && stride == 1) {
     // Cout = 1 (prob): 4 z-outputs per thread so every LDS row read feeds up to 3 outputs (LDS-bound otherwise)
-    if (pz_knob == 1) return launch_conv_pipe<1, 16, 4, 4, 4, 1, 1, 4>(x, weight, bias, skip, out, Cin, Cout, D, H, W, act, st);
     // one input channel per staged chunk: 31 KB of LDS -> 5 workgroups per CU (2 with two channels); 898 -> 627 us at M1
-    if (pz_knob == 3) return launch_conv_pipe<1, 16, 4, 4, 4, 4, 1, 2>(x, weight, bias, skip, out, Cin, Cout, D, H, W, act, st);
     return launch_conv_pipe<1, 16, 4, 4, 4, 4, 1, 1>(x, weight, bias, skip, out, Cin, Cout, D, H, W, act, st);
   }
   if (Cout == 1) {
@@ -995,13 +827,7 @@ extern "C" int cds_deconv3d_k3s2_f32(const float* x, const float* weight, const 
     if (!no_mfma && cds_deconv3d_mfma_launch(x, weight, bias, skip, out, Cin, Cout, D, H, W, act, st, &rc)) return rc;
   }
   if ((W % 4 == 0) && W >= 32 && ((size_t)Cin * D * H * W < (size_t)0x7fffffff)) {
-    static const bool v1 = []() { const char* e = getenv("CDS_DECONV_V1"); return e && e[0] == '1'; }();  // A/B knob
-    if (v1) return launch_deconv_pipe<64, 2, 2, 8, 8>(x, weight, bias, skip, out, Cin, Cout, D, H, W, act, st);
-    static const bool v2 = []() { const char* e = getenv("CDS_DECONV_V2"); return e && e[0] == '1'; }();          // A/B knobs
-    static const int v3pc = []() { const char* e = getenv("CDS_DECONV_V3_PC"); return e ? atoi(e) : 4; }();
-    if (!v2 && Cout == 8 && Cin <= D3_MAX_CIN)
-      return v3pc == 4 ? launch_deconv_v3<4>(x, weight, bias, skip, out, Cin, Cout, D, H, W, act, st)
-                       : launch_deconv_v3<2>(x, weight, bias, skip, out, Cin, Cout, D, H, W, act, st);
+    if (Cout == 8 && Cin <= D3_MAX_CIN) return launch_deconv_v3<4>(x, weight, bias, skip, out, Cin, Cout, D, H, W, act, st);
     return launch_deconv_v2<8, 4>(x, weight, bias, skip, out, Cin, Cout, D, H, W, act, st);
   }
   return W >= 48 ? launch_deconv<64, 2, 2, 8, 8>(x, weight, bias, skip, out, Cin, Cout, D, H, W, act, st)

@@ -707,33 +707,30 @@ bool cds_conv3d_mfma_launch(const float* x, const float* w, const float* b, cons
     else *rc = launch_mfma<2, 0, true>(x, w, b, skip, out, Cin, Cout, D, H, W, act, st);
     return true;
   }
-  static const int s2var = []() { const char* e = getenv("CDS_MFMA_S2VAR"); return e ? atoi(e) : 1; }();   // A/B knob
   if (stride == 1) *rc = launch_mfma<1, 0>(x, w, b, skip, out, Cin, Cout, D, H, W, act, st);
-  else if (s2var && Wo >= 256 && Wo % 64 == 0) *rc = launch_mfma<2, 1>(x, w, b, skip, out, Cin, Cout, D, H, W, act, st);
+  else if (Wo >= 256 && Wo % 64 == 0) *rc = launch_mfma<2, 1>(x, w, b, skip, out, Cin, Cout, D, H, W, act, st);
   else *rc = launch_mfma<2, 0>(x, w, b, skip, out, Cin, Cout, D, H, W, act, st);
   return true;
 }
 
 bool cds_deconv3d_mfma_launch(const float* x, const float* w, const float* b, const float* skip, float* out, int Cin,
                               int Cout, int D, int H, int W, int act, hipStream_t st, int* rc) {
-  // Cout % 16 != 0 (conv11, 16 -> 8): the (cout, parity) MFMA variant below is correct but measured slower than the
-  // packed-VALU v2 kernel on this memory-bound layer (2.2 vs 1.5 ms at M1), so it is only used when CDS_DECONV_MFMA8=1.
-  static const bool mfma8 = []() { const char* e = getenv("CDS_DECONV_MFMA8"); return e && e[0] == '1'; }();
-  if ((Cout % 8) || (Cout % 16 && !mfma8) || (Cin % 4) || (W % 2) || (W % 4 && Cout % 16) || W < 8 ||
+  // Cout % 16 != 0 (conv11, 16 -> 8) stays on the packed-VALU kernels: a (cout, parity) MFMA variant measured slower on this
+  // memory-bound layer (2.2 vs 1.5 ms at M1, round 1) and was removed in round 4
+  if ((Cout % 16) || (Cin % 4) || (W % 2) || W < 8 ||
       (size_t)Cin * D * H * W >= (size_t)0x7fffffff)
     return false;
   using Cfg = MDCfg;
   const int tx = cds_ceil_div(W, Cfg::CX), ty = cds_ceil_div(H, Cfg::CY), tz = cds_ceil_div(D, Cfg::CZ);
   const int ntiles = tx * ty * tz;
   const size_t lds_bytes = (size_t)Cfg::SLAB * Cfg::CI_CHUNK * sizeof(float);
-  static const bool split = []() { const char* e = getenv("CDS_DECONV_MFMA_SPLIT"); return e && e[0] == '1'; }();   // A/B knob
   using C4 = MD4Cfg;
   const int tx4 = cds_ceil_div(W, C4::CX), ty4 = cds_ceil_div(H, C4::CY);
   const int nt4 = tx4 * ty4 * D;
   // all four parity classes per workgroup (the input tile is staged once, not four times): 64->32 at 80x64x24 399 -> 339 us,
   // 32->16 at 160x128x48 695 -> 635 us; levels too small to give every CU a workgroup keep the one-class-per-workgroup kernel
   // (50x37x6: 63 vs 81 us)
-  if (Cout % 16 == 0 && !split && (long)nt4 * (Cout / 16) >= 256) {
+  if ((long)nt4 * (Cout / 16) >= 256) {
     const size_t lds4 = (size_t)C4::SLAB * C4::CI_CHUNK * sizeof(float);
     if (W % 4)
       hipLaunchKernelGGL(deconv3d_k3s2_mfma4_kernel<true>, dim3(nt4 * (Cout / 16)), dim3(256), lds4, st, x, w, b, skip, out, Cin,
@@ -747,11 +744,8 @@ bool cds_deconv3d_mfma_launch(const float* x, const float* w, const float* b, co
   if (W % 4)
     hipLaunchKernelGGL((deconv3d_k3s2_mfma_kernel<16, true>), dim3(ntiles * (Cout / 16) * 4), dim3(256), lds_bytes, st, x, w, b,
                        skip, out, Cin, Cout, D, H, W, act, tx, ty, tz, ntiles);
-  else if (Cout % 16 == 0)
-    hipLaunchKernelGGL(deconv3d_k3s2_mfma_kernel<16>, dim3(ntiles * (Cout / 16) * 4), dim3(256), lds_bytes, st, x, w, b,
-                       skip, out, Cin, Cout, D, H, W, act, tx, ty, tz, ntiles);
   else
-    hipLaunchKernelGGL(deconv3d_k3s2_mfma_kernel<8>, dim3(ntiles * (Cout / 8) * 4), dim3(256), lds_bytes, st, x, w, b,
+    hipLaunchKernelGGL(deconv3d_k3s2_mfma_kernel<16>, dim3(ntiles * (Cout / 16) * 4), dim3(256), lds_bytes, st, x, w, b,
                        skip, out, Cin, Cout, D, H, W, act, tx, ty, tz, ntiles);
   *rc = cds_launch_status();
   return true;
