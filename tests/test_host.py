@@ -149,3 +149,23 @@ def test_split_bf16_packers_reconstruct_the_weights_exactly():
     x = torch.tensor([1.0, 1 + 2 ** -23, 3.1415927, -1e-30, 6.5e37, 2 ** -120, 0.0]).reshape(1, 1, 7).expand(1, 64, 7)
     x = torch.cat((x, torch.zeros(1, 64, 1)), dim=-1).contiguous()
     assert torch.equal(_unsplit(ops._split3(x)), x)
+
+
+def test_restricted_unpickler_does_not_resolve_load_from_bytes():
+    """`torch.storage._load_from_bytes` is a full `torch.load(..., weights_only=False)` in disguise; the allowlisted
+    unpickler of infer.load_checkpoint must turn it (like every other non-tensor global) into an inert placeholder."""
+    import io
+    import pickle
+    from cds_mvsnet_amd.infer import _Opaque, _placeholder_pickle
+    up = _placeholder_pickle.Unpickler(io.BytesIO(b""))
+    assert up.find_class("torch.storage", "_load_from_bytes") is _Opaque
+    assert up.find_class("os", "system") is _Opaque
+    assert up.find_class("torch.hub", "load") is _Opaque
+    assert up.find_class("collections", "OrderedDict") is __import__("collections").OrderedDict
+    # a pickle stream that tries to CALL it only builds a placeholder
+    class Evil:
+        def __reduce__(self):
+            import torch.storage
+            return (torch.storage._load_from_bytes, (b"not a checkpoint",))
+    obj = _placeholder_pickle.load(io.BytesIO(pickle.dumps(Evil())))
+    assert isinstance(obj, _Opaque)
