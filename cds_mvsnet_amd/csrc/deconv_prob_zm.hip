@@ -1,0 +1,334 @@
+// K4 tail, fused: conv11 (ConvTranspose3d 16 -> 8, k3 s2 p1 op1, BN folded, ReLU; models/module.py:125-160) + the conv0
+// residual (models/module.py:498 `x = conv0 + self.conv11(x)`) + prob (Conv3d 8 -> 1, k3 p1, no bias; module.py:499), as ONE
+// z-marching kernel: the full-resolution 8-channel volume between the two layers (2 x 2.0 GB of HBM traffic at 640x512x192)
+// never leaves the CU.
+//
+// A workgroup owns a column of 30 x 6 input cells (60 x 12 output voxels) and walks it along z.  Per cell plane a it computes
+// the transposed convolution on 32 x 8 cells (one cell of halo on every side: the prob convolution needs its neighbours' y)
+// in split-bf16 arithmetic on the matrix cores, in two half-steps: output plane 2a (z parity 0: kernel tap kz = 1 of cell
+// plane a) and output plane 2a + 1 (taps kz = 2 of plane a and kz = 0 of plane a + 1).  The consumer waves (one per cell row,
+// two 16-cell N-tiles, rows of the matrix tile = (x parity, cout) as in deconv3d_sbf_ws_kernel) add bias, ReLU and the
+// residual and write the finished plane as fp32 into an LDS double buffer; everything outside the volume is written as 0 (the
+// zero padding of prob).  Four more waves - one per SIMD - (a) stage the next input cell plane (exact three-way bf16 split
+// in registers, two plane slots in LDS) and (b) run the prob convolution on the plane finished in the half-step before, on the
+// VALU in packed fp32 (v_pk_fma_f32: two input channels per instruction, two partial sums per output that are added at the
+// end): a lane owns one x column and three output rows, reads the 5 x 3 x 8-channel window of the new plane once and
+// scatters it into the accumulators of output planes q - 1, q, q + 1 (kz = 2, 1, 0); plane q - 1 is complete after that and
+// is stored.  One workgroup barrier per half-step.
+//
+// Operand sharing: the classes (z parity, y parity) of one half-step read the same input cells with different weights, so
+// their B operands are loaded once: 3 operand reads per 8-channel round instead of the 5 of deconv3d_sbf_ws_kernel
+//   half 1 (pz = 0): B1 = cells (dy, dx) in {0,1}^2 of plane a      -> A[0] (py = 0: dy = 1 slots are zero), A[1] (py = 1)
+//   half 2 (pz = 1): B2 = cells (dz, dx) at dy = 0, B3 = at dy = 1  -> A[2] (py = 0) on B2; A[3] on B2 and A[4] on B3 (py = 1)
+// with K-slot g = lane >> 4 of a 32-deep K-step = the cell offset, its 8 values = the 8 channels of the round.
+#include "sbf_common.hpp"
+
+namespace {
+
+struct DPZ {
+  static constexpr int CXC = 32, CYC = 8;            // computed cells per plane (halo included); one consumer wave per cell row
+  static constexpr int CXR = CXC - 2, CYR = CYC - 2;  // owned cells
+  static constexpr int NT = CXC / 16;
+  static constexpr int IY = CYC + 1, IX = CXC + 1, IXP = 34;
+  static constexpr int ROUNDS = 2;                   // Cin = 16
+  static constexpr int ROUNDB = IY * IXP * POSB;
+  static constexpr int SLOTB = ROUNDS * ROUNDB;      // one input cell plane: [round][row][col][term][8] bf16
+  static constexpr int NA = 5;
+  static constexpr int WB = ROUNDS * NA * 3 * 1024;  // split weights: [round][operand][term][lane] x 16 B
+  static constexpr int YX = 2 * CXC, YY = 2 * CYC;
+  static constexpr int YHALFB = YX * 16, YROWB = 2 * YHALFB;   // y plane: [row][channel half][x][4] fp32
+  static constexpr int YB = YY * YROWB;
+  static constexpr int CW = CYC, PW = 4, THREADS = (CW + PW) * 64;
+  static constexpr int LDS = WB + 2 * SLOTB + 2 * YB;
+  static constexpr int PR = 3;                       // output rows per prob lane: PW * PR = 2 * CYR
+  static constexpr int NITEM = IY * IX * ROUNDS;     // (cell, round) staging items of one plane
+  static constexpr int IPT = (NITEM + PW * 64 - 1) / (PW * 64);
+};
+static_assert(DPZ::PW * DPZ::PR == 2 * DPZ::CYR, "prob rows");
+static_assert(DPZ::LDS <= 160 * 1024, "LDS budget");
+
+__device__ __forceinline__ f32x2 dpz_fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+
+__global__ __launch_bounds__(DPZ::THREADS, 3) void deconv_prob_zm_kernel(
+    const float* __restrict__ x, const uint4* __restrict__ wsp, const float* __restrict__ bias, const float* __restrict__ skip,
+    const float* __restrict__ pw, float* __restrict__ out, int D, int H, int W, int tiles_x, int ncols, int seg_len) {
+  using C = DPZ;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  unsigned char* const inring = lds + C::WB;
+  unsigned char* const ybuf = inring + 2 * C::SLOTB;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wg = cds_xcd_remap(blockIdx.x, gridDim.x);
+  const int col = wg % ncols, seg = wg / ncols;
+  const int tx_i = col % tiles_x, ty_i = col / tiles_x;
+  const int a0 = seg * seg_len, a1 = min(D, a0 + seg_len);
+  if (a0 >= a1) return;
+  const int X0 = tx_i * C::CXR - 1, Y0 = ty_i * C::CYR - 1;     // first computed cell
+  const int Do = 2 * D, Ho = 2 * H, Wo = 2 * W;
+  const int qs = a0 > 0 ? 2 * a0 - 1 : 0;                        // first y plane this segment needs
+  const int qe = min(Do - 1, 2 * a1);                            // last one
+  const int te = 2 * a1 + 1;                                     // last half-step
+  {
+    uint4* wdst = reinterpret_cast<uint4*>(lds);
+    for (int i = tid; i < C::WB / 16; i += C::THREADS) wdst[i] = wsp[i];
+  }
+
+  if (wave >= C::CW) {
+    // ====================== producer / prob waves ======================
+    __builtin_amdgcn_s_setprio(2);
+    const int ptid = tid - C::CW * 64;
+    // ---- staging of input cell planes ----
+    int s_src[C::IPT], s_dst[C::IPT];
+#pragma unroll
+    for (int h = 0; h < C::IPT; ++h) {
+      const int it = h * C::PW * 64 + ptid;
+      const int rd = it & 1, p = it >> 1;
+      const int row = p / C::IX, c = p - row * C::IX;
+      const int gy = Y0 + row, gx = X0 + c;
+      const bool ok = it < C::NITEM && gy >= 0 && gy < H && gx >= 0 && gx < W;
+      s_src[h] = ok ? ((gy * W + gx) * 16 + rd * 8) : -1;
+      s_dst[h] = it < C::NITEM ? rd * C::ROUNDB + (row * C::IXP + c) * POSB : -1;
+    }
+    float4 va[C::IPT], vb[C::IPT];
+    auto issue = [&](int plane) {
+      const bool pok = plane < D;
+      const float* __restrict__ xp = x + (size_t)min(plane, D - 1) * H * W * 16;
+#pragma unroll
+      for (int h = 0; h < C::IPT; ++h) {
+        const bool ok = pok && s_src[h] >= 0;
+        const float* src = xp + (ok ? s_src[h] : 0);
+        const float4 a = *reinterpret_cast<const float4*>(src), b = *reinterpret_cast<const float4*>(src + 4);
+        va[h] = ok ? a : make_float4(0.f, 0.f, 0.f, 0.f);
+        vb[h] = ok ? b : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    };
+    auto deposit = [&](int plane) {
+      unsigned char* base = inring + (plane & 1) * C::SLOTB;
+#pragma unroll
+      for (int h = 0; h < C::IPT; ++h)
+        if (s_dst[h] >= 0) split_store8(base + s_dst[h], va[h], vb[h]);
+    };
+    // ---- prob: lane = x column c of the owned 60, wave = 3 output rows ----
+    const int c = ptid & 63, rg = ptid >> 6;
+    const int ox = tx_i * 2 * C::CXR + c;
+    const int oy0 = ty_i * 2 * C::CYR + C::PR * rg;
+    const bool lane_ok = c < 2 * C::CXR && ox < Wo;
+    const int yoff = (C::PR * rg + 1) * C::YROWB + (c + 1) * 16;    // window origin: local row 3 rg + 1, local x c + 1
+    f32x2 A[3][C::PR];
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+      for (int r = 0; r < C::PR; ++r) A[s][r] = (f32x2){0.f, 0.f};
+    const f32x4* __restrict__ pw4 = reinterpret_cast<const f32x4*>(pw);   // [ky][dx][half][kz] x 4 channels
+    auto process = [&](int q) {
+      const unsigned char* yb = ybuf + (q & 1) * C::YB + yoff;
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          f32x4 d[C::PR + 2];
+#pragma unroll
+          for (int rho = 0; rho < C::PR + 2; ++rho)
+            d[rho] = *reinterpret_cast<const f32x4*>(yb + rho * C::YROWB + hh * C::YHALFB + dx * 16);
+#pragma unroll
+          for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kz = 0; kz < 3; ++kz) {
+              const f32x4 wv = pw4[((ky * 3 + dx) * 2 + hh) * 3 + kz];
+              const f32x2 wl = {wv.x, wv.y}, wh = {wv.z, wv.w};
+#pragma unroll
+              for (int r = 0; r < C::PR; ++r) {
+                const f32x4 dv = d[r + ky];
+                A[2 - kz][r] = dpz_fma2((f32x2){dv.x, dv.y}, wl, A[2 - kz][r]);
+                A[2 - kz][r] = dpz_fma2((f32x2){dv.z, dv.w}, wh, A[2 - kz][r]);
+              }
+            }
+        }
+    };
+    // prologue: the input planes of the first half-step
+    const int ap = qs >> 1;
+    issue(ap);
+    deposit(ap);
+    if (qs & 1) {
+      issue(ap + 1);
+      deposit(ap + 1);
+    }
+    int nextp = (qs & 1) ? ap + 2 : ap + 1;     // deposited during the next even half-step
+    issue(nextp);
+    __syncthreads();                            // #0
+    for (int t = qs; t <= te; ++t) {
+      if (!(t & 1)) {
+        deposit(nextp);                         // plane (t / 2) + 1 for the half-step after this one
+        ++nextp;
+        issue(nextp);
+      }
+      const int q = t - 1;
+      if (q >= qs && q <= qe) process(q);
+      const int o = t - 2;
+      if (o >= 2 * a0 && o < 2 * a1 && lane_ok) {
+        float* po = out + ((size_t)o * Ho + oy0) * Wo + ox;
+#pragma unroll
+        for (int r = 0; r < C::PR; ++r)
+          if (oy0 + r < Ho) po[(size_t)r * Wo] = A[0][r].x + A[0][r].y;
+      }
+#pragma unroll
+      for (int r = 0; r < C::PR; ++r) {
+        A[0][r] = A[1][r];
+        A[1][r] = A[2][r];
+        A[2][r] = (f32x2){0.f, 0.f};
+      }
+      __syncthreads();
+    }
+    return;
+  }
+
+  // ============================== consumers ==============================
+  const int j = lane & 15, g = lane >> 4;
+  const int px = g >> 1, co = 4 * (g & 1);
+  const float4 bv = *reinterpret_cast<const float4*>(bias + co);
+  const unsigned char* const wl = lds + lane * 16;
+  // B operand offsets inside a plane slot (round 0, N-tile 0)
+  const int b_h1 = ((wave + (g >> 1)) * C::IXP + j + (g & 1)) * POSB;
+  const int b_h2a = (wave * C::IXP + j + (g & 1)) * POSB;
+  const int b_h2b = b_h2a + C::IXP * POSB;
+  // output voxels of this lane: x = 2 (X0 + 16 q + j) + px, y = 2 (Y0 + wave) + py
+  int sk_off[2][C::NT];      // residual element offsets inside a z plane, -1 outside the volume
+#pragma unroll
+  for (int py = 0; py < 2; ++py)
+#pragma unroll
+    for (int q = 0; q < C::NT; ++q) {
+      const int xv = 2 * (X0 + 16 * q + j) + px, yv = 2 * (Y0 + wave) + py;
+      sk_off[py][q] = (xv >= 0 && xv < Wo && yv >= 0 && yv < Ho) ? (yv * Wo + xv) * 8 + co : -1;
+    }
+  const int y_off = (2 * wave) * C::YROWB + (g & 1) * C::YHALFB + (2 * j + px) * 16;   // + py * YROWB + q * 32 * 16
+  const size_t zstride = (size_t)Ho * Wo * 8;
+  float4 sk0[2][C::NT], sk1[2][C::NT];    // [py][q] of the even / odd half-steps
+  auto load_skip = [&](float4 (&sk)[2][C::NT], int t) {
+    if (t > qe) return;
+    const float* __restrict__ sp = skip + (size_t)t * zstride;
+#pragma unroll
+    for (int py = 0; py < 2; ++py)
+#pragma unroll
+      for (int q = 0; q < C::NT; ++q) {
+        const int o = sk_off[py][q];
+        const float4 v = *reinterpret_cast<const float4*>(sp + max(o, 0));
+        sk[py][q] = o >= 0 ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+  };
+  auto load_a = [&](BV (&wa)[3], int rd, int k) {
+    const unsigned char* p = wl + (rd * C::NA + k) * 3 * 1024;
+    wa[0].u = *reinterpret_cast<const uint4*>(p);
+    wa[1].u = *reinterpret_cast<const uint4*>(p + 1024);
+    wa[2].u = *reinterpret_cast<const uint4*>(p + 2048);
+  };
+  auto load_b = [&](BV (&bd)[C::NT][3], const unsigned char* p) {
+#pragma unroll
+    for (int q = 0; q < C::NT; ++q) {
+      bd[q][0].u = *reinterpret_cast<const uint4*>(p + q * 16 * POSB);
+      bd[q][1].u = *reinterpret_cast<const uint4*>(p + q * 16 * POSB + 16);
+      bd[q][2].u = *reinterpret_cast<const uint4*>(p + q * 16 * POSB + 32);
+    }
+  };
+  f32x4 acc[2][C::NT];
+  auto epilogue = [&](const float4 (&sk)[2][C::NT], int par) {
+    unsigned char* yb = ybuf + par * C::YB + y_off;
+#pragma unroll
+    for (int py = 0; py < 2; ++py)
+#pragma unroll
+      for (int q = 0; q < C::NT; ++q) {
+        const f32x4 a = acc[py][q];
+        const float4 s4 = sk[py][q];
+        float4 o = make_float4(s4.x + fmaxf(a.x + bv.x, 0.f), s4.y + fmaxf(a.y + bv.y, 0.f), s4.z + fmaxf(a.z + bv.z, 0.f),
+                               s4.w + fmaxf(a.w + bv.w, 0.f));
+        if (sk_off[py][q] < 0) o = make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(yb + py * C::YROWB + q * 32 * 16) = o;
+      }
+  };
+  if (qs & 1) load_skip(sk1, qs); else load_skip(sk0, qs);
+  __syncthreads();                                // #0
+  for (int t = qs; t <= te; ++t) {
+    if (t <= qe) {
+      const int a = t >> 1;
+      const unsigned char* cur = inring + (a & 1) * C::SLOTB;
+#pragma unroll
+      for (int py = 0; py < 2; ++py)
+#pragma unroll
+        for (int q = 0; q < C::NT; ++q) acc[py][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (!(t & 1)) {
+        // ---- z parity 0: plane 2 a from cell plane a ----
+        load_skip(sk1, t + 1);
+        BV w0[3], w1[3], b0[C::NT][3], b1[C::NT][3];
+        load_b(b0, cur + b_h1);
+        load_a(w0, 0, 0);
+        load_a(w1, 0, 1);
+        load_b(b1, cur + C::ROUNDB + b_h1);
+        __builtin_amdgcn_sched_barrier(0);
+        SBF_TERMS(acc[0], 0, C::NT, w0, b0);
+        load_a(w0, 1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        SBF_TERMS(acc[1], 0, C::NT, w1, b0);
+        load_a(w1, 1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        SBF_TERMS(acc[0], 0, C::NT, w0, b1);
+        SBF_TERMS(acc[1], 0, C::NT, w1, b1);
+        epilogue(sk0, 0);
+      } else {
+        // ---- z parity 1: plane 2 a + 1 from cell planes a (kz = 2) and a + 1 (kz = 0) ----
+        load_skip(sk0, t + 1);
+        const unsigned char* oth = inring + ((a + 1) & 1) * C::SLOTB;
+        const unsigned char* bz = (g >> 1) ? oth : cur;
+        BV w0[3], w1[3], b0[C::NT][3], b1[C::NT][3];
+#pragma unroll
+        for (int rd = 0; rd < C::ROUNDS; ++rd) {
+          load_b(b0, bz + rd * C::ROUNDB + b_h2a);
+          load_a(w0, rd, 2);
+          load_a(w1, rd, 3);
+          load_b(b1, bz + rd * C::ROUNDB + b_h2b);
+          __builtin_amdgcn_sched_barrier(0);
+          SBF_TERMS(acc[0], 0, C::NT, w0, b0);
+          load_a(w0, rd, 4);
+          __builtin_amdgcn_sched_barrier(0);
+          SBF_TERMS(acc[1], 0, C::NT, w1, b0);
+          SBF_TERMS(acc[1], 0, C::NT, w0, b1);
+        }
+        epilogue(sk1, 1);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+}  // namespace
+
+// conv11 + residual + prob in one launch.  x [D][H][W][16] channels-last input cells, skip [2D][2H][2W][8] channels-last (conv0's
+// output), weight_split from ops.split_pack_deconv_prob (int16 [2][5][3][64][8]), bias [8] (BN shift), prob_table from
+// ops.pack_prob_table (float [3 ky][3 kx][2 halves][3 kz][4]); out [2D][2H][2W] fp32.
+extern "C" int cds_deconv_prob_zm_f32(const float* x, const void* weight_split, const float* bias, const float* skip,
+                                      const float* prob_table, float* out, int D, int H, int W, void* stream) {
+  if (!x || !weight_split || !bias || !skip || !prob_table || !out || D < 1 || H < 1 || W < 1) return CDS_EINVAL;
+  if ((long)2 * H * 2 * W * 8 >= (1l << 31) || (long)H * W * 16 >= (1l << 31)) return CDS_EINVAL;   // in-plane offsets are 32-bit
+  using C = DPZ;
+  hipStream_t st = (hipStream_t)stream;
+  const int tiles_x = cds_ceil_div(W, C::CXR), tiles_y = cds_ceil_div(H, C::CYR);
+  const int ncols = tiles_x * tiles_y;
+  // z segments: whole rounds of the 256 single-resident workgroups, each segment pays ~1.5 extra half-steps of priming
+  const char* nseg_e = getenv("CDS_DPZ_NSEG");   // A/B and test knob, read per launch
+  const int nseg_env = nseg_e ? atoi(nseg_e) : 0;
+  int best = 1;
+  double best_cost = 1e30;
+  for (int n = 1; n <= min(D, 16); ++n) {
+    const int len = cds_ceil_div(D, n);
+    const int n_eff = cds_ceil_div(D, len);
+    const double cost = (double)cds_ceil_div(ncols * n_eff, 256) * (2.0 * len + 3.0);
+    if (cost < best_cost - 1e-9) { best_cost = cost; best = n; }
+  }
+  if (nseg_env > 0) best = min(nseg_env, D);
+  const int seg_len = cds_ceil_div(D, best);
+  const int nseg = cds_ceil_div(D, seg_len);
+  static std::atomic<unsigned long long> lds_ok{0};
+  if (int e_lds = cds_allow_lds(reinterpret_cast<const void*>(deconv_prob_zm_kernel), 160 * 1024, lds_ok)) return e_lds;
+  hipLaunchKernelGGL(deconv_prob_zm_kernel, dim3(ncols * nseg), dim3(C::THREADS), C::LDS, st, x,
+                     reinterpret_cast<const uint4*>(weight_split), bias, skip, prob_table, out, D, H, W, tiles_x, ncols, seg_len);
+  return cds_launch_status();
+}

@@ -234,6 +234,10 @@ class CostRegNet(_PackedHolder):
             for name in ("conv0", "conv1", "conv2", "conv3", "conv4", "conv5", "conv6", "conv7", "conv9", "conv11"):
                 unit = getattr(self, name)
                 scale, _ = _bn_fold(unit.bn)
+                if name == "conv11":    # fused with the residual and prob (csrc/deconv_prob_zm.hip); the slab-parallel form
+                    # (slab.py) exchanges halo rows between the two layers and keeps the separate kernels (".ws" below)
+                    out[name + ".wz"] = ops.split_pack_deconv_prob(unit.conv.weight.detach() * scale.view(1, -1, 1, 1, 1))
+                    out["prob.tab"] = ops.pack_prob_table(self.prob.weight)
                 if unit.transposed:
                     out[name + ".ws"] = ops.split_pack_deconv3d(unit.conv.weight.detach() * scale.view(1, -1, 1, 1, 1))
                 elif name == "conv0":   # Cout = 8, stride 1: voxel-pair columns (no matrix row multiplies padding)
@@ -290,9 +294,8 @@ class CostRegNet(_PackedHolder):
         del c4
         x = ops.deconv3d_sbf(x, p["conv9.ws"], p["conv9.b"], 16, skip=c2)
         del c2
-        x = ops.deconv3d_sbf(x, p["conv11.ws"], p["conv11.b"], 8, skip=c0, out_planar=True)   # the VALU prob kernel reads planar
-        del c0
-        return ops.conv3d_k3(x, p["prob.w"], None, relu=False)[0]
+        # conv11 + the conv0 residual + prob: one z-marching kernel, the 8-channel volume between them never reaches HBM
+        return ops.deconv_prob_zm(x, p["conv11.wz"], p["conv11.b"], c0, p["prob.tab"])
 
     @staticmethod
     def _run(volume: Tensor, p: Dict[str, Tensor]) -> Tensor:

@@ -464,6 +464,56 @@ def deconv3d_sbf(x_cl: Tensor, wsplit: Tensor, bias: Optional[Tensor], cout: int
     return out
 
 
+def split_pack_deconv_prob(w: Tensor) -> Tensor:
+    """Pack the (BN-folded) conv11 weight [16,8,3,3,3] for cds_deconv_prob_zm_f32: five matrix operands per 8-channel round,
+    rows = (x parity, cout), K slot g = a cell offset (csrc/deconv_prob_zm.hip).  Output parity 0 of an axis takes kernel tap
+    1 of cell a; parity 1 takes tap 2 of cell a and tap 0 of cell a + 1.  int16 [2][5][3][64][8]."""
+    if tuple(w.shape) != (16, 8, 3, 3, 3):
+        raise ValueError("split_pack_deconv_prob: ConvTranspose3d weight [16,8,3,3,3]")
+    wf = w.detach().float().reshape(2, 8, 8, 3, 3, 3)                               # [rd][j][co][kz][ky][kx]
+    a = torch.zeros((2, 5, 4, 16, 8), dtype=torch.float32, device=w.device)         # [rd][operand][g][row][j]
+    # operand -> per slot group (g >> 1) the (kz, ky) it multiplies, or None; g & 1 = dx
+    ops_tab = [
+        [(1, 1), None],          # plane 2a,     y parity 0: slots (dy, dx); dy = 1 unused
+        [(1, 2), (1, 0)],        # plane 2a,     y parity 1: dy = 0 -> ky 2, dy = 1 -> ky 0
+        [(2, 1), (0, 1)],        # plane 2a + 1, y parity 0: slots (dz, dx) at dy = 0: dz = 0 -> kz 2, dz = 1 -> kz 0
+        [(2, 2), (0, 2)],        # plane 2a + 1, y parity 1, dy = 0 (ky 2)
+        [(2, 0), (0, 0)],        # plane 2a + 1, y parity 1, dy = 1 (ky 0)
+    ]
+    for k, groups in enumerate(ops_tab):
+        for hi, kk in enumerate(groups):
+            if kk is None:
+                continue
+            kz, ky = kk
+            a[:, k, 2 * hi, 0:8] = wf[:, :, :, kz, ky, 1].permute(0, 2, 1)          # dx = 0, px = 0: tap 1 of cell a
+            a[:, k, 2 * hi, 8:16] = wf[:, :, :, kz, ky, 2].permute(0, 2, 1)         # dx = 0, px = 1: tap 2 of cell a
+            a[:, k, 2 * hi + 1, 8:16] = wf[:, :, :, kz, ky, 0].permute(0, 2, 1)     # dx = 1, px = 1: tap 0 of cell a + 1
+    return _split3(a.reshape(2, 5, 64, 8))
+
+
+def pack_prob_table(w: Tensor) -> Tensor:
+    """prob weight [1,8,3,3,3] -> float [3 ky][3 kx][2 channel halves][3 kz][4] for cds_deconv_prob_zm_f32."""
+    if tuple(w.shape) != (1, 8, 3, 3, 3):
+        raise ValueError("pack_prob_table: Conv3d weight [1,8,3,3,3]")
+    return w.detach().float()[0].reshape(2, 4, 3, 3, 3).permute(3, 4, 0, 2, 1).contiguous()   # [h][i][kz][ky][kx] -> [ky][kx][h][kz][i]
+
+
+def deconv_prob_zm(x_cl: Tensor, wsplit: Tensor, bias: Tensor, skip: Tensor, prob_table: Tensor) -> Tensor:
+    """conv11 + residual + prob in one launch: x_cl [D,H,W,16], skip [2D,2H,2W,8] channels-last -> [2D,2H,2W]."""
+    D, H, W, Cin = x_cl.shape
+    if Cin != 16 or tuple(skip.shape) != (2 * D, 2 * H, 2 * W, 8):
+        raise ValueError("deconv_prob_zm: x [D,H,W,16] and skip [2D,2H,2W,8]")
+    if wsplit.dtype != torch.int16 or not wsplit.is_cuda or not wsplit.is_contiguous() or wsplit.numel() != 2 * 5 * 3 * 64 * 8:
+        raise ValueError("deconv_prob_zm: wsplit must be the contiguous int16 device tensor from split_pack_deconv_prob")
+    if prob_table.numel() != 216 or bias.numel() != 8:
+        raise ValueError("deconv_prob_zm: prob_table from pack_prob_table, bias [8]")
+    out = torch.empty((2 * D, 2 * H, 2 * W), dtype=torch.float32, device=x_cl.device)
+    check(_lib.load().cds_deconv_prob_zm_f32(_dev(x_cl, "x"), wsplit.data_ptr(), _dev(bias, "bias"), _dev(skip, "skip"),
+                                             _dev(prob_table, "prob_table"), out.data_ptr(), D, H, W, _stream(x_cl)),
+          "cds_deconv_prob_zm_f32")
+    return out
+
+
 SBF_PAIR = 101   # CDS_SBF_PAIR: stride code of the pair-packed stride-1, Cout = 8 form
 
 

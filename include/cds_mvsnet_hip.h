@@ -197,6 +197,16 @@ int cds_conv3d_sbf_f32(const float* x, const void* weight_split, const float* bi
 int cds_deconv3d_sbf_f32(const float* x, const void* weight_split, const float* bias, const float* skip, float* out,
                          int Cin, int Cout, int D, int H, int W, int act, int out_planar, void* stream);
 
+/* The tail of CostRegNet in one launch: conv11 = ConvTranspose3d(16 -> 8, k3 s2 p1 op1) + BatchNorm3d(eval, folded) + ReLU
+ * (models/module.py:125-160, :495), the residual `conv0 + conv11(x)` (:498) and prob = Conv3d(8 -> 1, k3, p1, bias=False)
+ * (:499).  x [D][H][W][16] channels-last input cells, skip [2D][2H][2W][8] channels-last, out [2D][2H][2W] fp32.  The 8-channel
+ * full-resolution volume between the two layers stays in LDS (z-marching workgroups, csrc/deconv_prob_zm.hip); the transposed
+ * convolution runs in split-bf16 arithmetic on the matrix cores, prob in packed fp32 on the VALU.
+ * weight_split from ops.split_pack_deconv_prob (int16 [2][5][3][64][8]), bias [8], prob_table from ops.pack_prob_table
+ * (float [3 ky][3 kx][2][3 kz][4]). */
+int cds_deconv_prob_zm_f32(const float* x, const void* weight_split, const float* bias, const float* skip,
+                           const float* prob_table, float* out, int D, int H, int W, void* stream);
+
 /*
  * K4 (module.py:125-160): ConvTranspose3d k=3, stride 2, padding 1, output_padding 1 (doubles
  * D,H,W) + bias + activation + residual.

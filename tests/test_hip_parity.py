@@ -927,6 +927,45 @@ def test_deconv3d_split_bf16_is_fp32_class(cin, cout, D, H, W, dev, ops):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("D,H,W,nseg", [(1, 1, 1, 0), (2, 3, 5, 0), (3, 7, 31, 1), (4, 6, 30, 0), (5, 13, 61, 2), (9, 12, 64, 4),
+                                        (7, 20, 33, 1), (6, 40, 95, 0)])
+def test_conv11_residual_prob_fused(D, H, W, nseg, dev, ops, monkeypatch):
+    """csrc/deconv_prob_zm.hip: conv11 (ConvTranspose3d 16 -> 8 + folded BN + ReLU), the conv0 residual and prob (Conv3d
+    8 -> 1) in one z-marching launch (models/module.py:125-160, :495-499) against a float64 restatement: fp32-class (no worse
+    than 1.5x the two separate fp32 layers of PyTorch), on ragged volumes that exercise the 30 x 6-cell column tiling (partial
+    tiles, one-cell volumes, exact multiples) and the z segmentation (segment seams; nseg = 0: the launcher's own choice,
+    which cuts small volumes into one-plane segments)."""
+    if nseg:
+        monkeypatch.setenv("CDS_DPZ_NSEG", str(nseg))
+    else:
+        monkeypatch.delenv("CDS_DPZ_NSEG", raising=False)
+    g = torch.Generator().manual_seed(D * 1000 + H * 10 + W)
+    x = torch.randn(16, D, H, W, generator=g) * torch.exp(0.5 * torch.randn(16, 1, 1, 1, generator=g))
+    skip = torch.randn(8, 2 * D, 2 * H, 2 * W, generator=g)
+    w11 = torch.randn(16, 8, 3, 3, 3, generator=g) / (27 * 2) ** 0.5
+    b11 = torch.randn(8, generator=g)
+    wp = torch.randn(1, 8, 3, 3, 3, generator=g) / 27 ** 0.5
+    y64 = F.conv_transpose3d(x.double()[None], w11.double(), b11.double(), stride=2, padding=1, output_padding=1).clamp_min(0) \
+        + skip.double()[None]
+    want64 = F.conv3d(y64, wp.double(), padding=1)[0, 0]
+    y32 = F.conv_transpose3d(x[None], w11, b11, stride=2, padding=1, output_padding=1).clamp_min(0) + skip[None]
+    want32 = F.conv3d(y32, wp, padding=1)[0, 0]
+    got = ops.deconv_prob_zm(x.permute(1, 2, 3, 0).contiguous().to(dev), ops.split_pack_deconv_prob(w11.to(dev)), b11.to(dev),
+                             skip.permute(1, 2, 3, 0).contiguous().to(dev), ops.pack_prob_table(wp.to(dev))).cpu()
+    assert got.shape == want32.shape
+    err = (got.double() - want64).abs().max().item()
+    err32 = (want32.double() - want64).abs().max().item()
+    ulp = want64.abs().max().item() * 2.0 ** -23
+    print(f"conv11+prob fused D{D} H{H} W{W}: max err vs float64 {err:.2e} (torch fp32: {err32:.2e})")
+    assert err <= 1.5 * err32 + 2 * ulp, (err, err32)
+    # and equal to the two separate product kernels to fp32 rounding (different summation order in prob)
+    ysep = ops.deconv3d_sbf(x.permute(1, 2, 3, 0).contiguous().to(dev), ops.split_pack_deconv3d(w11.to(dev)), b11.to(dev), 8,
+                            skip=skip.permute(1, 2, 3, 0).contiguous().to(dev), out_planar=True)
+    sep = ops.conv3d_k3(ysep, wp.permute(1, 2, 3, 4, 0).reshape(8, 27, 1).contiguous().to(dev), None, relu=False)[0].cpu()
+    assert (got - sep).abs().max().item() <= 16 * ulp + 1e-6
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("cin,cout,ks,N,H,W,bias", [(8, 8, (3, 5, 7), 2, 21, 44, False), (16, 16, (3, 5), 1, 16, 36, False),
                                                    (32, 32, (1, 3), 2, 9, 20, True), (16, 16, (1, 3), 1, 12, 32, True),
                                                    (8, 8, (1, 3), 3, 8, 64, True)])
