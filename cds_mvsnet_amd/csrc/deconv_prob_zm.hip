@@ -11,10 +11,11 @@
 // residual and write the finished plane as fp32 into an LDS double buffer; everything outside the volume is written as 0 (the
 // zero padding of prob).  Four more waves - one per SIMD - (a) stage the next input cell plane (exact three-way bf16 split
 // in registers, two plane slots in LDS) and (b) run the prob convolution on the plane finished in the half-step before, on the
-// VALU in packed fp32 (v_pk_fma_f32: two input channels per instruction, two partial sums per output that are added at the
-// end): a lane owns one x column and three output rows, reads the 5 x 3 x 8-channel window of the new plane once and
-// scatters it into the accumulators of output planes q - 1, q, q + 1 (kz = 2, 1, 0); plane q - 1 is complete after that and
-// is stored.  One workgroup barrier per half-step.
+// VALU in fp32 (plain v_fmac_f32 with the weight as a scalar operand): a lane owns one x column and three output rows, reads
+// the 5 x 3 x 8-channel window of the new plane once and scatters it into the accumulators of output planes q - 1, q, q + 1
+// (kz = 2, 1, 0); plane q - 1 is complete after that and is stored.  One workgroup barrier per half-step.
+// Measured (profiles/r04_deconv_prob.md): 1120 us at 640x512x192 against 1656-1700 us for the two separate kernels; the prob
+// waves are the critical path (648 FMAs per half-step and wave at ~6.8 cycles each beside the consumers' MFMAs).
 //
 // Operand sharing: the classes (z parity, y parity) of one half-step read the same input cells with different weights, so
 // their B operands are loaded once: 3 operand reads per 8-channel round instead of the 5 of deconv3d_sbf_ws_kernel
@@ -47,7 +48,13 @@ struct DPZ {
 static_assert(DPZ::PW * DPZ::PR == 2 * DPZ::CYR, "prob rows");
 static_assert(DPZ::LDS <= 160 * 1024, "LDS budget");
 
-__device__ __forceinline__ f32x2 dpz_fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+// One v_fma_f32 with the (wave-uniform) weight as a scalar operand.  Written as an instruction because the compiler otherwise
+// pairs adjacent channels into v_pk_fma_f32, and a packed fp32 instruction issued beside another wave's MFMAs costs far more
+// than the two plain ones it replaces (measured here: 12-15 cycles per v_pk_fma_f32 in the prob waves).
+__device__ __forceinline__ float dpz_fma(float d, float w, float acc) {
+  asm("v_fmac_f32 %0, %1, %2" : "+v"(acc) : "s"(w), "v"(d));
+  return acc;
+}
 
 __global__ __launch_bounds__(DPZ::THREADS, 3) void deconv_prob_zm_kernel(
     const float* __restrict__ x, const uint4* __restrict__ wsp, const float* __restrict__ bias, const float* __restrict__ skip,
@@ -115,36 +122,64 @@ __global__ __launch_bounds__(DPZ::THREADS, 3) void deconv_prob_zm_kernel(
     const int oy0 = ty_i * 2 * C::CYR + C::PR * rg;
     const bool lane_ok = c < 2 * C::CXR && ox < Wo;
     const int yoff = (C::PR * rg + 1) * C::YROWB + (c + 1) * 16;    // window origin: local row 3 rg + 1, local x c + 1
-    f32x2 A[3][C::PR];
+    float A[3][C::PR];
 #pragma unroll
     for (int s = 0; s < 3; ++s)
 #pragma unroll
-      for (int r = 0; r < C::PR; ++r) A[s][r] = (f32x2){0.f, 0.f};
-    const f32x4* __restrict__ pw4 = reinterpret_cast<const f32x4*>(pw);   // [ky][dx][half][kz] x 4 channels
+      for (int r = 0; r < C::PR; ++r) A[s][r] = 0.f;
+    // Six batches b = (dx, channel half) of 5 window rows x 4 channels and their 9 (ky, kz) x 4 weights.  The weights come
+    // through the scalar cache into SGPRs; scalar and LDS loads share lgkmcnt and return out of order with respect to each
+    // other, so every wait on either is a wait for ALL of both: the loads of batch b + 1 are therefore issued right AFTER the
+    // one wait of batch b and have its ~430 cycles of FMAs to land, instead of being waited for the moment they were issued.
+    const f32x4* __restrict__ pw4 = reinterpret_cast<const f32x4*>(pw);   // [dx][half][ky][kz] x 4 channels
+    auto load_d = [&](f32x4 (&d)[C::PR + 2], const unsigned char* yb, int b) {
+#pragma unroll
+      for (int rho = 0; rho < C::PR + 2; ++rho)
+        d[rho] = *reinterpret_cast<const f32x4*>(yb + rho * C::YROWB + (b & 1) * C::YHALFB + (b >> 1) * 16);
+    };
+    auto load_w = [&](f32x4 (&w)[9], int b) {
+#pragma unroll
+      for (int k = 0; k < 9; ++k) w[k] = pw4[b * 9 + k];
+    };
+    auto compute = [&](const f32x4 (&d)[C::PR + 2], const f32x4 (&w)[9]) {
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kz = 0; kz < 3; ++kz) {
+          const f32x4 wv = w[ky * 3 + kz];
+#pragma unroll
+          for (int r = 0; r < C::PR; ++r) {
+            const f32x4 dv = d[r + ky];
+            float acc = A[2 - kz][r];
+            acc = dpz_fma(dv.x, wv.x, acc);
+            acc = dpz_fma(dv.y, wv.y, acc);
+            acc = dpz_fma(dv.z, wv.z, acc);
+            acc = dpz_fma(dv.w, wv.w, acc);
+            A[2 - kz][r] = acc;
+          }
+        }
+    };
+    f32x4 wq0[9], wq1[9];
+    load_w(wq0, 0);                                  // batch 0 of the first plane; re-requested at the end of every plane
     auto process = [&](int q) {
       const unsigned char* yb = ybuf + (q & 1) * C::YB + yoff;
-#pragma unroll
-      for (int dx = 0; dx < 3; ++dx)
-#pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-          f32x4 d[C::PR + 2];
-#pragma unroll
-          for (int rho = 0; rho < C::PR + 2; ++rho)
-            d[rho] = *reinterpret_cast<const f32x4*>(yb + rho * C::YROWB + hh * C::YHALFB + dx * 16);
-#pragma unroll
-          for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-            for (int kz = 0; kz < 3; ++kz) {
-              const f32x4 wv = pw4[((ky * 3 + dx) * 2 + hh) * 3 + kz];
-              const f32x2 wl = {wv.x, wv.y}, wh = {wv.z, wv.w};
-#pragma unroll
-              for (int r = 0; r < C::PR; ++r) {
-                const f32x4 dv = d[r + ky];
-                A[2 - kz][r] = dpz_fma2((f32x2){dv.x, dv.y}, wl, A[2 - kz][r]);
-                A[2 - kz][r] = dpz_fma2((f32x2){dv.z, dv.w}, wh, A[2 - kz][r]);
-              }
-            }
-        }
+      f32x4 d0[C::PR + 2], d1[C::PR + 2];
+      load_d(d0, yb, 0);
+#define DPZ_BATCH(B, DC, WC, DN, WN)                                   \
+      __builtin_amdgcn_s_waitcnt(0xC07F); /* lgkmcnt(0): batch B */    \
+      __builtin_amdgcn_sched_barrier(0);                               \
+      load_w(WN, ((B) + 1) % 6);                                       \
+      if ((B) + 1 < 6) load_d(DN, yb, (B) + 1);                        \
+      __builtin_amdgcn_sched_barrier(0);                               \
+      compute(DC, WC);                                                 \
+      __builtin_amdgcn_sched_barrier(0);
+      DPZ_BATCH(0, d0, wq0, d1, wq1)
+      DPZ_BATCH(1, d1, wq1, d0, wq0)
+      DPZ_BATCH(2, d0, wq0, d1, wq1)
+      DPZ_BATCH(3, d1, wq1, d0, wq0)
+      DPZ_BATCH(4, d0, wq0, d1, wq1)
+      DPZ_BATCH(5, d1, wq1, d0, wq0)
+#undef DPZ_BATCH
     };
     // prologue: the input planes of the first half-step
     const int ap = qs >> 1;
@@ -158,25 +193,27 @@ __global__ __launch_bounds__(DPZ::THREADS, 3) void deconv_prob_zm_kernel(
     issue(nextp);
     __syncthreads();                            // #0
     for (int t = qs; t <= te; ++t) {
+      const int q = t - 1;
+      if (q >= qs && q <= qe) process(q);
       if (!(t & 1)) {
-        deposit(nextp);                         // plane (t / 2) + 1 for the half-step after this one
+        // plane (t / 2) + 1 for the half-step after this one.  After the arithmetic: the wait for the loads (issued a step
+        // ago) also covers the stores of the half-step before (vmcnt counts both, in order), which have had the time to land
+        deposit(nextp);
         ++nextp;
         issue(nextp);
       }
-      const int q = t - 1;
-      if (q >= qs && q <= qe) process(q);
       const int o = t - 2;
       if (o >= 2 * a0 && o < 2 * a1 && lane_ok) {
         float* po = out + ((size_t)o * Ho + oy0) * Wo + ox;
 #pragma unroll
         for (int r = 0; r < C::PR; ++r)
-          if (oy0 + r < Ho) po[(size_t)r * Wo] = A[0][r].x + A[0][r].y;
+          if (oy0 + r < Ho) po[(size_t)r * Wo] = A[0][r];
       }
 #pragma unroll
       for (int r = 0; r < C::PR; ++r) {
         A[0][r] = A[1][r];
         A[1][r] = A[2][r];
-        A[2][r] = (f32x2){0.f, 0.f};
+        A[2][r] = 0.f;
       }
       __syncthreads();
     }
@@ -201,6 +238,7 @@ __global__ __launch_bounds__(DPZ::THREADS, 3) void deconv_prob_zm_kernel(
       const int xv = 2 * (X0 + 16 * q + j) + px, yv = 2 * (Y0 + wave) + py;
       sk_off[py][q] = (xv >= 0 && xv < Wo && yv >= 0 && yv < Ho) ? (yv * Wo + xv) * 8 + co : -1;
     }
+  const bool border = X0 < 0 || X0 + C::CXC > W || Y0 < 0 || Y0 + C::CYC > H;   // workgroup-uniform: only then is y masked
   const int y_off = (2 * wave) * C::YROWB + (g & 1) * C::YHALFB + (2 * j + px) * 16;   // + py * YROWB + q * 32 * 16
   const size_t zstride = (size_t)Ho * Wo * 8;
   float4 sk0[2][C::NT], sk1[2][C::NT];    // [py][q] of the even / odd half-steps
@@ -239,9 +277,8 @@ __global__ __launch_bounds__(DPZ::THREADS, 3) void deconv_prob_zm_kernel(
       for (int q = 0; q < C::NT; ++q) {
         const f32x4 a = acc[py][q];
         const float4 s4 = sk[py][q];
-        float4 o = make_float4(s4.x + fmaxf(a.x + bv.x, 0.f), s4.y + fmaxf(a.y + bv.y, 0.f), s4.z + fmaxf(a.z + bv.z, 0.f),
-                               s4.w + fmaxf(a.w + bv.w, 0.f));
-        if (sk_off[py][q] < 0) o = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 o = make_float4(s4.x + fmaxf(a.x, 0.f), s4.y + fmaxf(a.y, 0.f), s4.z + fmaxf(a.z, 0.f), s4.w + fmaxf(a.w, 0.f));
+        if (border && sk_off[py][q] < 0) o = make_float4(0.f, 0.f, 0.f, 0.f);
         *reinterpret_cast<float4*>(yb + py * C::YROWB + q * 32 * 16) = o;
       }
   };
@@ -254,7 +291,7 @@ __global__ __launch_bounds__(DPZ::THREADS, 3) void deconv_prob_zm_kernel(
 #pragma unroll
       for (int py = 0; py < 2; ++py)
 #pragma unroll
-        for (int q = 0; q < C::NT; ++q) acc[py][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int q = 0; q < C::NT; ++q) acc[py][q] = (f32x4){bv.x, bv.y, bv.z, bv.w};   // the BN shift rides in the accumulator
       if (!(t & 1)) {
         // ---- z parity 0: plane 2 a from cell plane a ----
         load_skip(sk1, t + 1);
@@ -303,7 +340,7 @@ __global__ __launch_bounds__(DPZ::THREADS, 3) void deconv_prob_zm_kernel(
 
 // conv11 + residual + prob in one launch.  x [D][H][W][16] channels-last input cells, skip [2D][2H][2W][8] channels-last (conv0's
 // output), weight_split from ops.split_pack_deconv_prob (int16 [2][5][3][64][8]), bias [8] (BN shift), prob_table from
-// ops.pack_prob_table (float [3 ky][3 kx][2 halves][3 kz][4]); out [2D][2H][2W] fp32.
+// ops.pack_prob_table (float [3 kx][2 halves][3 ky][3 kz][4]); out [2D][2H][2W] fp32.
 extern "C" int cds_deconv_prob_zm_f32(const float* x, const void* weight_split, const float* bias, const float* skip,
                                       const float* prob_table, float* out, int D, int H, int W, void* stream) {
   if (!x || !weight_split || !bias || !skip || !prob_table || !out || D < 1 || H < 1 || W < 1) return CDS_EINVAL;

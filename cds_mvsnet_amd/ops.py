@@ -492,10 +492,10 @@ def split_pack_deconv_prob(w: Tensor) -> Tensor:
 
 
 def pack_prob_table(w: Tensor) -> Tensor:
-    """prob weight [1,8,3,3,3] -> float [3 ky][3 kx][2 channel halves][3 kz][4] for cds_deconv_prob_zm_f32."""
+    """prob weight [1,8,3,3,3] -> float [3 kx][2 channel halves][3 ky][3 kz][4] for cds_deconv_prob_zm_f32."""
     if tuple(w.shape) != (1, 8, 3, 3, 3):
         raise ValueError("pack_prob_table: Conv3d weight [1,8,3,3,3]")
-    return w.detach().float()[0].reshape(2, 4, 3, 3, 3).permute(3, 4, 0, 2, 1).contiguous()   # [h][i][kz][ky][kx] -> [ky][kx][h][kz][i]
+    return w.detach().float()[0].reshape(2, 4, 3, 3, 3).permute(4, 0, 3, 2, 1).contiguous()   # [h][i][kz][ky][kx] -> [kx][h][ky][kz][i]
 
 
 def deconv_prob_zm(x_cl: Tensor, wsplit: Tensor, bias: Tensor, skip: Tensor, prob_table: Tensor) -> Tensor:

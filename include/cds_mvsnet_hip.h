@@ -203,7 +203,7 @@ int cds_deconv3d_sbf_f32(const float* x, const void* weight_split, const float* 
  * full-resolution volume between the two layers stays in LDS (z-marching workgroups, csrc/deconv_prob_zm.hip); the transposed
  * convolution runs in split-bf16 arithmetic on the matrix cores, prob in packed fp32 on the VALU.
  * weight_split from ops.split_pack_deconv_prob (int16 [2][5][3][64][8]), bias [8], prob_table from ops.pack_prob_table
- * (float [3 ky][3 kx][2][3 kz][4]). */
+ * (float [3 kx][2][3 ky][3 kz][4]). */
 int cds_deconv_prob_zm_f32(const float* x, const void* weight_split, const float* bias, const float* skip,
                            const float* prob_table, float* out, int D, int H, int W, void* stream);
 
