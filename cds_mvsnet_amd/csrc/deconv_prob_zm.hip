@@ -122,6 +122,9 @@ __global__ __launch_bounds__(DPZ::THREADS, 3) void deconv_prob_zm_kernel(
     const int oy0 = ty_i * 2 * C::CYR + C::PR * rg;
     const bool lane_ok = c < 2 * C::CXR && ox < Wo;
     const int yoff = (C::PR * rg + 1) * C::YROWB + (c + 1) * 16;    // window origin: local row 3 rg + 1, local x c + 1
+    int st_off[C::PR];                                              // element offsets of this lane's outputs inside a plane
+#pragma unroll
+    for (int r = 0; r < C::PR; ++r) st_off[r] = (lane_ok && oy0 + r < Ho) ? (oy0 + r) * Wo + ox : -1;
     float A[3][C::PR];
 #pragma unroll
     for (int s = 0; s < 3; ++s)
@@ -203,11 +206,11 @@ __global__ __launch_bounds__(DPZ::THREADS, 3) void deconv_prob_zm_kernel(
         issue(nextp);
       }
       const int o = t - 2;
-      if (o >= 2 * a0 && o < 2 * a1 && lane_ok) {
-        float* po = out + ((size_t)o * Ho + oy0) * Wo + ox;
+      if (o >= 2 * a0 && o < 2 * a1) {
+        float* po = out + (size_t)o * Ho * Wo;     // wave-uniform plane base + per-lane 32-bit offsets
 #pragma unroll
         for (int r = 0; r < C::PR; ++r)
-          if (oy0 + r < Ho) po[(size_t)r * Wo] = A[0][r];
+          if (st_off[r] >= 0) po[st_off[r]] = A[0][r];
       }
 #pragma unroll
       for (int r = 0; r < C::PR; ++r) {
