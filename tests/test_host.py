@@ -151,6 +151,45 @@ def test_split_bf16_packers_reconstruct_the_weights_exactly():
     assert torch.equal(_unsplit(ops._split3(x)), x)
 
 
+def test_fused_conv11_prob_operands_compute_the_reference_layers():
+    """Host side of csrc/deconv_prob_zm.hip: the five matrix operands per round from ops.split_pack_deconv_prob, multiplied the way
+    the kernel's K-steps read the input cells (half-step 1: slots (dy, dx) of cell plane a; half-step 2: slots (dz, dx) at dy = 0 and
+    at dy = 1; rows = (x parity, cout)), reproduce ConvTranspose3d(16 -> 8, k3 s2 p1 op1) of the reference (models/module.py:125-160),
+    and the prob table of ops.pack_prob_table read as [kx][half][ky][kz][4] reproduces Conv3d(8 -> 1, k3, p1) (module.py:499)."""
+    import torch.nn.functional as F
+    from cds_mvsnet_amd import ops
+    g = torch.Generator().manual_seed(3)
+    D, H, W = 2, 3, 4
+    x = torch.randn(16, D, H, W, generator=g).double()
+    w = torch.randn(16, 8, 3, 3, 3, generator=g)
+    a = _unsplit(ops.split_pack_deconv_prob(w)).double()           # [rd][operand][64 = 16 g + row][8 ci]
+    assert a.shape == (2, 5, 64, 8)
+    xp = F.pad(x, (0, 1, 0, 1, 0, 1))                              # cells beyond the volume are zero
+    def cells(dz, dy, dx):                                         # [16][D][H][W]: cell (a + dz, y + dy, x + dx)
+        return xp[:, dz:dz + D, dy:dy + H, dx:dx + W]
+    out = torch.zeros(8, 2 * D, 2 * H, 2 * W, dtype=torch.float64)
+    # (operand, [slot g -> (dz, dy, dx)], z parity, y parity)
+    plan = [(0, lambda gg: (0, gg >> 1, gg & 1), 0, 0), (1, lambda gg: (0, gg >> 1, gg & 1), 0, 1),
+            (2, lambda gg: (gg >> 1, 0, gg & 1), 1, 0), (3, lambda gg: (gg >> 1, 0, gg & 1), 1, 1),
+            (4, lambda gg: (gg >> 1, 1, gg & 1), 1, 1)]
+    for k, slot, pz, py in plan:
+        for rd in range(2):
+            for gg in range(4):
+                b = cells(*slot(gg))[8 * rd:8 * rd + 8]                         # [8 ci][D][H][W]
+                rows = a[rd, k, 16 * gg:16 * gg + 16]                           # [16 rows = 8 px + co][8 ci]
+                r = torch.einsum("ic,cdhw->idhw", rows, b)                      # [16][D][H][W]
+                for px in range(2):
+                    out[:, pz::2, py::2, px::2] += r[8 * px:8 * px + 8]
+    want = F.conv_transpose3d(x[None], w.double(), stride=2, padding=1, output_padding=1)[0]
+    assert (out - want).abs().max().item() < 1e-12
+    # prob table
+    wp = torch.randn(1, 8, 3, 3, 3, generator=g)
+    tab = ops.pack_prob_table(wp)
+    assert tab.shape == (3, 2, 3, 3, 4)
+    for kx, hh, ky, kz, i in ((0, 0, 0, 0, 0), (2, 1, 1, 0, 3), (1, 0, 2, 2, 1), (2, 1, 2, 1, 2)):
+        assert tab[kx, hh, ky, kz, i] == wp[0, 4 * hh + i, kz, ky, kx]
+
+
 def test_restricted_unpickler_does_not_resolve_load_from_bytes():
     """`torch.storage._load_from_bytes` is a full `torch.load(..., weights_only=False)` in disguise; the allowlisted
     unpickler of infer.load_checkpoint must turn it (like every other non-tensor global) into an inert placeholder."""
