@@ -238,6 +238,8 @@ class CostRegNet(_PackedHolder):
                     # (slab.py) exchanges halo rows between the two layers and keeps the separate kernels (".ws" below)
                     out[name + ".wz"] = ops.split_pack_deconv_prob(unit.conv.weight.detach() * scale.view(1, -1, 1, 1, 1))
                     out["prob.tab"] = ops.pack_prob_table(self.prob.weight)
+                if name == "conv9":     # 32 -> 16: z-marching class-per-wave kernel (csrc/deconv3d_zm.hip); ".ws" stays for slab.py
+                    out[name + ".wc"] = ops.split_pack_deconv_cls(unit.conv.weight.detach() * scale.view(1, -1, 1, 1, 1))
                 if unit.transposed:
                     out[name + ".ws"] = ops.split_pack_deconv3d(unit.conv.weight.detach() * scale.view(1, -1, 1, 1, 1))
                 elif name == "conv0":   # Cout = 8, stride 1: voxel-pair columns (no matrix row multiplies padding)
@@ -292,7 +294,7 @@ class CostRegNet(_PackedHolder):
         del c5
         x = ops.deconv3d_sbf(x, p["conv7.ws"], p["conv7.b"], 32, skip=c4)
         del c4
-        x = ops.deconv3d_sbf(x, p["conv9.ws"], p["conv9.b"], 16, skip=c2)
+        x = ops.deconv3d_zm(x, p["conv9.wc"], p["conv9.b"], skip=c2)
         del c2
         # conv11 + the conv0 residual + prob: one z-marching kernel, the 8-channel volume between them never reaches HBM
         return ops.deconv_prob_zm(x, p["conv11.wz"], p["conv11.b"], c0, p["prob.tab"])

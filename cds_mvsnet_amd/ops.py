@@ -464,6 +464,42 @@ def deconv3d_sbf(x_cl: Tensor, wsplit: Tensor, bias: Optional[Tensor], cout: int
     return out
 
 
+def split_pack_deconv_cls(w: Tensor) -> Tensor:
+    """Pack a (BN-folded) ConvTranspose3d weight [32,16,3,3,3] for cds_deconv3d_zm_f32: per output parity class c = 4 pz + 2 py + px
+    and 8-channel round two matrix operands (cell offset dz = 0 | 1), rows = couts, K slot g = (dy, dx) = (g >> 1, g & 1); a slot the
+    class does not reach (d > parity on an axis) is zero.  Per axis: parity 0 takes kernel tap 1 of cell a; parity 1 takes tap 2 of
+    cell a and tap 0 of cell a + 1.  int16 [8][4][2][3][64][8]."""
+    if tuple(w.shape) != (32, 16, 3, 3, 3):
+        raise ValueError("split_pack_deconv_cls: ConvTranspose3d weight [32,16,3,3,3]")
+    wf = w.detach().float().reshape(4, 8, 16, 3, 3, 3)                              # [rd][j][co][kz][ky][kx]
+    a = torch.zeros((8, 4, 2, 4, 16, 8), dtype=torch.float32, device=w.device)      # [class][rd][dz][g][co][j]
+    tap = lambda par, d: (1 if d == 0 else None) if par == 0 else (2 if d == 0 else 0)
+    for c in range(8):
+        pz, py, px = c >> 2, (c >> 1) & 1, c & 1
+        for dz in range(2):
+            for g in range(4):
+                kz, ky, kx = tap(pz, dz), tap(py, g >> 1), tap(px, g & 1)
+                if kz is None or ky is None or kx is None:
+                    continue
+                a[c, :, dz, g] = wf[:, :, :, kz, ky, kx].permute(0, 2, 1)
+    return _split3(a.reshape(8, 4, 2, 64, 8))
+
+
+def deconv3d_zm(x_cl: Tensor, wcls: Tensor, bias: Optional[Tensor], relu: bool = True, skip: Optional[Tensor] = None) -> Tensor:
+    """ConvTranspose3d 32 -> 16 (k3 s2 p1 op1) in split-bf16 arithmetic on the z-marching class-per-wave kernel, channels-last:
+    x_cl [D,H,W,32] -> [2D,2H,2W,16]."""
+    D, H, W, Cin = x_cl.shape
+    out = torch.empty((2 * D, 2 * H, 2 * W, 16), dtype=torch.float32, device=x_cl.device)
+    if skip is not None and tuple(skip.shape) != tuple(out.shape):
+        raise ValueError("deconv3d_zm: residual shape mismatch")
+    if wcls.dtype != torch.int16 or not wcls.is_cuda or not wcls.is_contiguous() or wcls.numel() != 8 * 4 * 2 * 3 * 64 * 8:
+        raise ValueError("deconv3d_zm: wcls must be the contiguous int16 device tensor from split_pack_deconv_cls")
+    check(_lib.load().cds_deconv3d_zm_f32(_dev(x_cl, "x"), wcls.data_ptr(), _dev(bias, "bias") if bias is not None else None,
+                                          _dev(skip, "skip") if skip is not None else None, out.data_ptr(), Cin, 16, D, H, W,
+                                          ACT_RELU if relu else ACT_NONE, _stream(x_cl)), "cds_deconv3d_zm_f32")
+    return out
+
+
 def split_pack_deconv_prob(w: Tensor) -> Tensor:
     """Pack the (BN-folded) conv11 weight [16,8,3,3,3] for cds_deconv_prob_zm_f32: five matrix operands per 8-channel round,
     rows = (x parity, cout), K slot g = a cell offset (csrc/deconv_prob_zm.hip).  Output parity 0 of an axis takes kernel tap

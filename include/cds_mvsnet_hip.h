@@ -197,6 +197,14 @@ int cds_conv3d_sbf_f32(const float* x, const void* weight_split, const float* bi
 int cds_deconv3d_sbf_f32(const float* x, const void* weight_split, const float* bias, const float* skip, float* out,
                          int Cin, int Cout, int D, int H, int W, int act, int out_planar, void* stream);
 
+/* ConvTranspose3d(32 -> 16, k3 s2 p1 op1) + folded BN shift + ReLU + residual (conv9 of CostRegNet: models/module.py:125-160, :496)
+ * as a z-marching kernel with one consumer wave per output parity class and that class's weights resident in registers
+ * (csrc/deconv3d_zm.hip).  Same arithmetic (split-bf16) and tensors as cds_deconv3d_sbf_f32: x [D][H][W][32] channels-last ->
+ * out [2D][2H][2W][16], skip like out or NULL; weight_cls from ops.split_pack_deconv_cls (int16 [8][4][2][3][64][8]).
+ * Cin == 32 and Cout == 16 only (CDS_EINVAL otherwise). */
+int cds_deconv3d_zm_f32(const float* x, const void* weight_cls, const float* bias, const float* skip, float* out,
+                        int Cin, int Cout, int D, int H, int W, int act, void* stream);
+
 /* The tail of CostRegNet in one launch: conv11 = ConvTranspose3d(16 -> 8, k3 s2 p1 op1) + BatchNorm3d(eval, folded) + ReLU
  * (models/module.py:125-160, :495), the residual `conv0 + conv11(x)` (:498) and prob = Conv3d(8 -> 1, k3, p1, bias=False)
  * (:499).  x [D][H][W][16] channels-last input cells, skip [2D][2H][2W][8] channels-last, out [2D][2H][2W] fp32.  The 8-channel

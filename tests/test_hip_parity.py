@@ -927,6 +927,39 @@ def test_deconv3d_split_bf16_is_fp32_class(cin, cout, D, H, W, dev, ops):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("D,H,W,nseg", [(1, 1, 1, 0), (2, 3, 5, 0), (3, 8, 16, 1), (4, 9, 17, 2), (5, 13, 33, 0), (7, 24, 47, 3), (6, 5, 70, 1)])
+def test_conv9_class_per_wave_z_march(D, H, W, nseg, dev, ops, monkeypatch):
+    """csrc/deconv3d_zm.hip: ConvTranspose3d 32 -> 16 (k3 s2 p1 op1) + shift + ReLU + residual as a z-marching kernel with one wave
+    per output parity class (models/module.py:125-160) against float64: same acceptance as the tiled split-bf16 kernel (no worse
+    than 1.5x PyTorch's fp32 layer), on volumes that exercise partial 16 x 8-cell columns and the z segmentation; and without the
+    residual / activation."""
+    if nseg:
+        monkeypatch.setenv("CDS_DZM_NSEG", str(nseg))
+    else:
+        monkeypatch.delenv("CDS_DZM_NSEG", raising=False)
+    g = torch.Generator().manual_seed(D * 100 + W)
+    x = torch.randn(32, D, H, W, generator=g) * torch.exp(0.5 * torch.randn(32, 1, 1, 1, generator=g))
+    w = torch.randn(32, 16, 3, 3, 3, generator=g) / (27 * 4) ** 0.5
+    b = torch.randn(16, generator=g)
+    skip = torch.randn(16, 2 * D, 2 * H, 2 * W, generator=g)
+    want64 = F.conv_transpose3d(x.double()[None], w.double(), b.double(), stride=2, padding=1, output_padding=1)[0]
+    want32 = F.conv_transpose3d(x[None], w, b, stride=2, padding=1, output_padding=1)[0]
+    wc = ops.split_pack_deconv_cls(w.to(dev))
+    x_cl = x.permute(1, 2, 3, 0).contiguous().to(dev)
+    got = ops.deconv3d_zm(x_cl, wc, b.to(dev), relu=False).cpu().permute(3, 0, 1, 2)
+    err = (got.double() - want64).abs().max().item()
+    err32 = (want32.double() - want64).abs().max().item()
+    ulp = want64.abs().max().item() * 2.0 ** -23
+    print(f"conv9 z-march D{D} H{H} W{W}: max err vs float64 {err:.2e} (torch fp32 {err32:.2e})")
+    assert err <= 1.5 * err32 + ulp, (err, err32)
+    got2 = ops.deconv3d_zm(x_cl, wc, b.to(dev), relu=True, skip=skip.permute(1, 2, 3, 0).contiguous().to(dev)).cpu().permute(3, 0, 1, 2)
+    assert (got2.double() - (skip.double() + want64.clamp_min(0))).abs().max().item() <= 1.5 * err32 + 2 * ulp
+    tiled = ops.deconv3d_sbf(x_cl, ops.split_pack_deconv3d(w.to(dev)), b.to(dev), 16, relu=True,
+                             skip=skip.permute(1, 2, 3, 0).contiguous().to(dev)).cpu().permute(3, 0, 1, 2)
+    assert (got2 - tiled).abs().max().item() <= 8 * ulp + 1e-6
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("D,H,W,nseg", [(1, 1, 1, 0), (2, 3, 5, 0), (3, 7, 31, 1), (4, 6, 30, 0), (5, 13, 61, 2), (9, 12, 64, 4),
                                         (7, 20, 33, 1), (6, 40, 95, 0)])
 def test_conv11_residual_prob_fused(D, H, W, nseg, dev, ops, monkeypatch):
