@@ -50,7 +50,7 @@ __global__ __launch_bounds__((DZC<ROUNDS>::THREADS), 3) void deconv3d_zm_kernel(
 
   if (wave >= C::CW) {
     // ============================== producers ==============================
-    __builtin_amdgcn_s_setprio(3);
+    __builtin_amdgcn_s_setprio(3);               // A/B at M1: producers at 0 / 1 / 3: 355 / 351 / 345 us
     const int ptid = tid - C::CW * 64;
     int s_src[C::IPT], s_dst[C::IPT];
 #pragma unroll
@@ -98,6 +98,7 @@ __global__ __launch_bounds__((DZC<ROUNDS>::THREADS), 3) void deconv3d_zm_kernel(
 
   // ============================== consumers: wave = parity class ==============================
   const int pz = wave >> 2, py = (wave >> 1) & 1, px = wave & 1;
+  if (pz) __builtin_amdgcn_s_setprio(1);         // twice the matrix work of its pz = 0 SIMD neighbour: 345 -> 329 us at M1
   const int j = lane & 15, g = lane >> 4;
   BV wlo[ROUNDS][3], whi[ROUNDS][3];                  // this class's weights: K-step at dz = 0 and (pz = 1) at dz = 1
   {
