@@ -48,7 +48,25 @@ for name, cin, cout, D, H, W in (("conv7", 64, 32, 24, 64, 80), ("conv9", 32, 16
     d = (ops.deconv3d_k3s2(x, wpk, b, skip=skip) - (got if cout == 8 else got.permute(3, 0, 1, 2))).abs().max().item()
     fl = 2.0 * 27 * cin * cout * D * H * W
     by = 4.0 * (x.numel() + 2 * skip.numel())
-    print(f"{name}: fp32 kernel {t32:8.1f} us ({fl / t32 / 1e6:6.1f} TF)   split-bf16 {tsb:8.1f} us ({fl / tsb / 1e6:6.1f} TF-equivalent, {by / tsb / 1e6:5.2f} TB/s compulsory)   max |diff| {d:.2e}")
+    tail = ""
+    if (cin, cout) == (32, 16):     # the z-marching class-per-wave kernel CostRegNet runs conv9 on (csrc/deconv3d_zm.hip)
+        wc = ops.split_pack_deconv_cls(w)
+        tzm = t(lambda: ops.deconv3d_zm(x_cl, wc, b, skip=skip_cl))
+        dz = (ops.deconv3d_zm(x_cl, wc, b, skip=skip_cl) - got).abs().max().item()
+        tail = f"   z-march {tzm:8.1f} us ({by / tzm / 1e6:5.2f} TB/s compulsory, max |diff to tiled| {dz:.2e})"
+    print(f"{name}: fp32 kernel {t32:8.1f} us ({fl / t32 / 1e6:6.1f} TF)   split-bf16 {tsb:8.1f} us ({fl / tsb / 1e6:6.1f} TF-equivalent, {by / tsb / 1e6:5.2f} TB/s compulsory)   max |diff| {d:.2e}{tail}")
+if not sel or "tail" in sel:
+    # conv11 + conv0 residual + prob in one launch (csrc/deconv_prob_zm.hip) against the two kernels timed above / below
+    D, H, W = 96, 256, 320
+    x_cl = torch.randn(D, H, W, 16, device=dev)
+    skip_cl = torch.randn(2 * D, 2 * H, 2 * W, 8, device=dev)
+    w11 = torch.randn(16, 8, 3, 3, 3, device=dev) / 54 ** 0.5
+    b11 = torch.randn(8, device=dev)
+    wp = torch.randn(1, 8, 3, 3, 3, device=dev) / 216 ** 0.5
+    wz, tab = ops.split_pack_deconv_prob(w11), ops.pack_prob_table(wp)
+    tf = t(lambda: ops.deconv_prob_zm(x_cl, wz, b11, skip_cl, tab))
+    by = 4.0 * (x_cl.numel() + skip_cl.numel() + 8 * D * H * W)
+    print(f"conv11 + residual + prob fused: {tf:8.1f} us ({by / tf / 1e6:5.2f} TB/s compulsory)")
 if not sel or "prob" in sel:
     x = torch.randn(8, 192, 512, 640, device=dev)
     w = torch.randn(1, 8, 3, 3, 3, device=dev) / 216 ** 0.5
