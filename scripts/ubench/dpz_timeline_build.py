@@ -62,6 +62,19 @@ tag = "dpz_timeline"
 if "nomfma" in sys.argv:
     rep('#include "sbf_common.hpp"', '#include "sbf_common.hpp"\n#undef SBF_MFMA\n#define SBF_MFMA(acc, a, b) asm volatile("" : "+v"(acc) : "v"((a).v), "v"((b).v))')
     tag += "_nomfma"
+if "pk" in sys.argv:           # A/B: packed FMAs over channel pairs (two partial sums per output) instead of the plain ones
+    rep('    float A[3][C::PR];', '    f32x2 A[3][C::PR];')
+    rep('      for (int r = 0; r < C::PR; ++r) A[s][r] = 0.f;', '      for (int r = 0; r < C::PR; ++r) A[s][r] = (f32x2){0.f, 0.f};')
+    rep('''            float acc = A[2 - kz][r];
+            acc = dpz_fma(dv.x, wv.x, acc);
+            acc = dpz_fma(dv.y, wv.y, acc);
+            acc = dpz_fma(dv.z, wv.z, acc);
+            acc = dpz_fma(dv.w, wv.w, acc);
+            A[2 - kz][r] = acc;''', '''            A[2 - kz][r] = __builtin_elementwise_fma((f32x2){dv.x, dv.y}, (f32x2){wv.x, wv.y}, A[2 - kz][r]);
+            A[2 - kz][r] = __builtin_elementwise_fma((f32x2){dv.z, dv.w}, (f32x2){wv.z, wv.w}, A[2 - kz][r]);''')
+    rep('          if (st_off[r] >= 0) po[st_off[r]] = A[0][r];', '          if (st_off[r] >= 0) po[st_off[r]] = A[0][r].x + A[0][r].y;')
+    rep('        A[2][r] = 0.f;', '        A[2][r] = (f32x2){0.f, 0.f};')
+    tag += "_pk"
 if "noconsumer" in sys.argv:   # consumers only keep the barriers
     rep('    if (t <= qe) {\n      const int a = t >> 1;', '    if (t < 0) {\n      const int a = t >> 1;')
     tag += "_noconsumer"
