@@ -76,11 +76,9 @@ SIGNATURES = {
     "cds_deconv2d_k3s2_f32": [P, P, P, P, I, I, I, I, I, P],
     "cds_refine_finish_f32": [P, P, P, I, I, F, F, P],
     "cds_bn3d_stats_f32": [P, P, I, I, L, P],
-    "cds_bn3d_apply_f32": [P, P, P, P, P, I, I, L, I, P],
+    "cds_bn3d_norm_f32": [P, P, P, P, DB, DB, F, P, P, P, P, P, P, P, P, I, I, L, I, P],
     "cds_bn3d_bwd_reduce_f32": [P, P, P, P, P, I, I, L, I, P],
-    "cds_bn3d_bwd_apply_f32": [P, P, P, P, P, P, P, I, I, L, I, P],
-    "cds_bn3d_finalize_f32": [P, P, P, DB, DB, F, P, P, P, P, P, P, I, P],
-    "cds_bn3d_bwd_finalize_f32": [P, P, P, P, DB, P, P, P, P, I, P],
+    "cds_bn3d_bwd_norm_f32": [P, P, P, P, P, P, P, DB, P, P, P, I, I, L, I, P],
     "cds_conv3d_wgrad_f32": [P, P, P, I, I, I, I, I, I, I, I, I, I, P],
     "cds_conv2d_wgrad_f32": [P, P, P, I, I, I, I, I, I, I, I, I, I, P],
     "cds_conv2d_dgrad_s2_f32": [P, P, P, I, I, I, I, I, I, I, P],

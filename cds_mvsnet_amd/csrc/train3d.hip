@@ -4,9 +4,9 @@
 // convolution with the same weights and vice versa; a stride-1 convolution's is the convolution with flipped, transposed
 // weights).  New here:
 //   cds_bn3d_stats_f32        per-channel sum / sum of squares over (batch, voxels), fp64 accumulation
-//   cds_bn3d_apply_f32        y -> relu(y * scale[c] + shift[c]) (+ residual): BatchNorm(train) + ReLU + U-Net skip, fused
+//   cds_bn3d_norm_f32         per-channel step + y -> relu(y * scale[c] + shift[c]) (+ residual): BatchNorm(train) + ReLU + U-Net skip, fused
 //   cds_bn3d_bwd_reduce_f32   sum g and sum g*y per channel, g = dout * [relu argument > 0]
-//   cds_bn3d_bwd_apply_f32    dy = g * scale[c] + y * k1[c] + k0[c]   (the BatchNorm backward in closed form)
+//   cds_bn3d_bwd_norm_f32     dgamma, dbeta, dy = g * scale[c] + y * k1[c] + k0[c]   (the BatchNorm backward in closed form)
 //   cds_conv3d_wgrad_f32      dw[a][b][tap] = sum_o g[a][o] * xin[b][S*o - 1 + tap]   (conv: g = dy, xin = x, S = stride;
 //                             transposed conv: g = x, xin = dy, S = 2: the same sum with the roles swapped)
 // Layouts: activations [B][C][D][H][W] fp32 planar (PyTorch's), statistics fp64 [C].
@@ -43,13 +43,36 @@ __global__ __launch_bounds__(256) void bn3d_stats_kernel(const float* __restrict
   }
 }
 
-// out = relu(y * scale[c] + shift[c]) (+ skip).  grid (chunks, C, B)
-__global__ __launch_bounds__(256) void bn3d_apply_kernel(const float* __restrict__ y, const float* __restrict__ scale,
-                                                         const float* __restrict__ shift, const float* __restrict__ skip,
-                                                         float* __restrict__ out, int C, size_t V, int relu) {
+// BatchNorm (training) normalisation pass: every workgroup redoes the per-channel step from the fp64 sums (sum y, sum y^2) of the
+// statistics pass - mean, biased variance, scale = gamma invstd, shift = beta - mean scale: a dozen fp64 operations - and applies
+// out = relu(y * scale[c] + shift[c]) (+ skip); the first workgroup of a channel also writes scale / shift / mean / invstd for the
+// backward and updates the running statistics.  (The per-channel step used to be its own one-workgroup launch between the two passes:
+// 2 x 44 launches of a launch-bound training step.)  grid (chunks, C, B)
+__global__ __launch_bounds__(256) void bn3d_norm_kernel(const float* __restrict__ y, const double* __restrict__ sums,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta, double n,
+                                                        double eps, float momentum, float* __restrict__ running_mean,
+                                                        float* __restrict__ running_var, const float* __restrict__ skip,
+                                                        float* __restrict__ out, float* __restrict__ scale_out,
+                                                        float* __restrict__ shift_out, double* __restrict__ mean_out,
+                                                        double* __restrict__ invstd_out, int C, size_t V, int relu) {
   const int c = blockIdx.y, b = blockIdx.z;
+  const double mean = sums[2 * c] / n;
+  double var = sums[2 * c + 1] / n - mean * mean;                  // biased, like F.batch_norm in training
+  var = var < 0.0 ? 0.0 : var;
+  const double invstd = 1.0 / sqrt(var + eps);
+  const double gm = (double)gamma[c];
+  const float sc = (float)(gm * invstd), sh = (float)((double)beta[c] - mean * gm * invstd);
+  if (blockIdx.x == 0 && b == 0 && threadIdx.x == 0) {
+    scale_out[c] = sc;
+    shift_out[c] = sh;
+    mean_out[c] = mean;
+    invstd_out[c] = invstd;
+    if (running_mean) {
+      running_mean[c] = running_mean[c] * (1.0f - momentum) + momentum * (float)mean;
+      running_var[c] = running_var[c] * (1.0f - momentum) + momentum * (float)(var * (n / (n > 1.0 ? n - 1.0 : 1.0)));
+    }
+  }
   const size_t base = ((size_t)b * C + c) * V;
-  const float sc = scale[c], sh = shift[c];
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < V; i += (size_t)gridDim.x * 256) {
     float v = fmaf(y[base + i], sc, sh);
     if (relu) v = fmaxf(v, 0.f);
@@ -83,14 +106,25 @@ __global__ __launch_bounds__(256) void bn3d_bwd_reduce_kernel(const float* __res
   }
 }
 
-// dy = g * scale[c] + y * k1[c] + k0[c]
-__global__ __launch_bounds__(256) void bn3d_bwd_apply_kernel(const float* __restrict__ dout, const float* __restrict__ y,
-                                                             const float* __restrict__ scale, const float* __restrict__ shift,
-                                                             const float* __restrict__ k1, const float* __restrict__ k0,
-                                                             float* __restrict__ dy, int C, size_t V, int relu) {
+// BatchNorm backward, second pass: from the fp64 sums (sum g, sum g y) of the reduction pass every workgroup derives dgamma, dbeta
+// and the (k1, k0) of dy = g scale[c] + y k1[c] + k0[c] itself; the first workgroup of a channel writes dgamma / dbeta.
+__global__ __launch_bounds__(256) void bn3d_bwd_norm_kernel(const float* __restrict__ dout, const float* __restrict__ y,
+                                                            const float* __restrict__ scale, const float* __restrict__ shift,
+                                                            const double* __restrict__ sums, const double* __restrict__ mean,
+                                                            const double* __restrict__ invstd, double n, float* __restrict__ dy,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta, int C, size_t V,
+                                                            int relu) {
   const int c = blockIdx.y, b = blockIdx.z;
   const size_t base = ((size_t)b * C + c) * V;
-  const float sc = scale[c], sh = shift[c], a1 = k1[c], a0 = k0[c];
+  const float sc = scale[c], sh = shift[c];
+  const double db = sums[2 * c];
+  const double dg = invstd[c] * (sums[2 * c + 1] - mean[c] * sums[2 * c]);      // sum g * xhat
+  const double scd = (double)sc;
+  const float a1 = (float)(-scd * dg * invstd[c] / n), a0 = (float)(-scd * db / n + scd * dg * invstd[c] * mean[c] / n);
+  if (blockIdx.x == 0 && b == 0 && threadIdx.x == 0) {
+    dgamma[c] = (float)dg;
+    dbeta[c] = (float)db;
+  }
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < V; i += (size_t)gridDim.x * 256) {
     const float yv = y[base + i];
     const float g = (!relu || fmaf(yv, sc, sh) > 0.f) ? dout[base + i] : 0.f;
@@ -260,45 +294,6 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_mfma_kernel(const float* __r
   }
 }
 
-// The per-channel arithmetic between the reduction and the apply kernels (it was ~20 tiny ATen launches per layer and direction
-// in a launch-bound training step).  sums[c] = (sum y, sum y^2) in fp64.
-__global__ void bn3d_finalize_kernel(const double* __restrict__ sums, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                     double n, double eps, float momentum, float* __restrict__ running_mean,
-                                     float* __restrict__ running_var, float* __restrict__ scale, float* __restrict__ shift,
-                                     double* __restrict__ mean_out, double* __restrict__ invstd_out, int C) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  const double mean = sums[2 * c] / n;
-  double var = sums[2 * c + 1] / n - mean * mean;                  // biased, like F.batch_norm in training
-  var = var < 0.0 ? 0.0 : var;
-  const double invstd = 1.0 / sqrt(var + eps);
-  const double gm = (double)gamma[c];
-  scale[c] = (float)(gm * invstd);
-  shift[c] = (float)((double)beta[c] - mean * gm * invstd);
-  mean_out[c] = mean;
-  invstd_out[c] = invstd;
-  if (running_mean) {
-    running_mean[c] = running_mean[c] * (1.0f - momentum) + momentum * (float)mean;
-    running_var[c] = running_var[c] * (1.0f - momentum) + momentum * (float)(var * (n / (n > 1.0 ? n - 1.0 : 1.0)));
-  }
-}
-
-// sums[c] = (sum g, sum g * y_bn_input) from cds_bn3d_bwd_reduce_f32 -> dgamma, dbeta and the (k1, k0) of dy = g scale + y k1 + k0
-__global__ void bn3d_bwd_finalize_kernel(const double* __restrict__ sums, const double* __restrict__ mean,
-                                         const double* __restrict__ invstd, const float* __restrict__ scale, double n,
-                                         float* __restrict__ k1, float* __restrict__ k0, float* __restrict__ dgamma,
-                                         float* __restrict__ dbeta, int C) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  const double db = sums[2 * c];
-  const double dg = invstd[c] * (sums[2 * c + 1] - mean[c] * sums[2 * c]);      // sum g * xhat
-  const double sc = (double)scale[c];
-  k1[c] = (float)(-sc * dg * invstd[c] / n);
-  k0[c] = (float)(-sc * db / n + sc * dg * invstd[c] * mean[c] / n);
-  dgamma[c] = (float)dg;
-  dbeta[c] = (float)db;
-}
-
 inline dim3 ew_grid(size_t V, int C, int B) {
   size_t chunks = (V + 256 * 8 - 1) / (256 * 8);
   if (chunks > 512) chunks = 512;
@@ -314,11 +309,14 @@ extern "C" int cds_bn3d_stats_f32(const float* x, double* sums, int B, int C, lo
   return cds_launch_status();
 }
 
-extern "C" int cds_bn3d_apply_f32(const float* y, const float* scale, const float* shift, const float* skip, float* out, int B,
-                                  int C, long long V, int relu, void* stream) {
-  if (!y || !scale || !shift || !out || B < 1 || C < 1 || V < 1) return CDS_EINVAL;
-  hipLaunchKernelGGL(bn3d_apply_kernel, ew_grid((size_t)V, C, B), dim3(256), 0, (hipStream_t)stream, y, scale, shift, skip, out, C,
-                     (size_t)V, relu);
+extern "C" int cds_bn3d_norm_f32(const float* y, const double* sums, const float* gamma, const float* beta, double n, double eps,
+                                 float momentum, float* running_mean, float* running_var, const float* skip, float* out, float* scale,
+                                 float* shift, double* mean, double* invstd, int B, int C, long long V, int relu, void* stream) {
+  if (!y || !sums || !gamma || !beta || !out || !scale || !shift || !mean || !invstd || B < 1 || C < 1 || V < 1 || n < 1.0 ||
+      (running_mean != nullptr) != (running_var != nullptr))
+    return CDS_EINVAL;
+  hipLaunchKernelGGL(bn3d_norm_kernel, ew_grid((size_t)V, C, B), dim3(256), 0, (hipStream_t)stream, y, sums, gamma, beta, n, eps,
+                     momentum, running_mean, running_var, skip, out, scale, shift, mean, invstd, C, (size_t)V, relu);
   return cds_launch_status();
 }
 
@@ -330,11 +328,13 @@ extern "C" int cds_bn3d_bwd_reduce_f32(const float* dout, const float* y, const 
   return cds_launch_status();
 }
 
-extern "C" int cds_bn3d_bwd_apply_f32(const float* dout, const float* y, const float* scale, const float* shift, const float* k1,
-                                      const float* k0, float* dy, int B, int C, long long V, int relu, void* stream) {
-  if (!dout || !y || !scale || !shift || !k1 || !k0 || !dy || B < 1 || C < 1 || V < 1) return CDS_EINVAL;
-  hipLaunchKernelGGL(bn3d_bwd_apply_kernel, ew_grid((size_t)V, C, B), dim3(256), 0, (hipStream_t)stream, dout, y, scale, shift, k1,
-                     k0, dy, C, (size_t)V, relu);
+extern "C" int cds_bn3d_bwd_norm_f32(const float* dout, const float* y, const float* scale, const float* shift, const double* sums,
+                                     const double* mean, const double* invstd, double n, float* dy, float* dgamma, float* dbeta, int B,
+                                     int C, long long V, int relu, void* stream) {
+  if (!dout || !y || !scale || !shift || !sums || !mean || !invstd || !dy || !dgamma || !dbeta || B < 1 || C < 1 || V < 1 || n < 1.0)
+    return CDS_EINVAL;
+  hipLaunchKernelGGL(bn3d_bwd_norm_kernel, ew_grid((size_t)V, C, B), dim3(256), 0, (hipStream_t)stream, dout, y, scale, shift, sums,
+                     mean, invstd, n, dy, dgamma, dbeta, C, (size_t)V, relu);
   return cds_launch_status();
 }
 
@@ -371,23 +371,3 @@ extern "C" int cds_conv3d_wgrad_f32(const float* g, const float* xin, float* dw,
   return cds_launch_status();
 }
 
-// BatchNorm3d (training) between the statistics pass and the apply pass, one launch: scale / shift of y -> y * scale + shift,
-// the saved (mean, invstd) in fp64 for the backward, and the running-statistics update (running_* may be NULL).
-extern "C" int cds_bn3d_finalize_f32(const double* sums, const float* gamma, const float* beta, double n, double eps, float momentum,
-                                     float* running_mean, float* running_var, float* scale, float* shift, double* mean,
-                                     double* invstd, int C, void* stream) {
-  if (!sums || !gamma || !beta || !scale || !shift || !mean || !invstd || C < 1 || n < 1.0 || (running_mean != nullptr) != (running_var != nullptr))
-    return CDS_EINVAL;
-  hipLaunchKernelGGL(bn3d_finalize_kernel, dim3(cds_ceil_div(C, 64)), dim3(64), 0, (hipStream_t)stream, sums, gamma, beta, n, eps,
-                     momentum, running_mean, running_var, scale, shift, mean, invstd, C);
-  return cds_launch_status();
-}
-
-// The backward's per-channel step: (sum g, sum g y) -> dgamma, dbeta, and k1 / k0 for cds_bn3d_bwd_apply_f32.
-extern "C" int cds_bn3d_bwd_finalize_f32(const double* sums, const double* mean, const double* invstd, const float* scale, double n,
-                                         float* k1, float* k0, float* dgamma, float* dbeta, int C, void* stream) {
-  if (!sums || !mean || !invstd || !scale || !k1 || !k0 || !dgamma || !dbeta || C < 1 || n < 1.0) return CDS_EINVAL;
-  hipLaunchKernelGGL(bn3d_bwd_finalize_kernel, dim3(cds_ceil_div(C, 64)), dim3(64), 0, (hipStream_t)stream, sums, mean, invstd, scale,
-                     n, k1, k0, dgamma, dbeta, C);
-  return cds_launch_status();
-}

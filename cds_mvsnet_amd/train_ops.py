@@ -6,7 +6,7 @@ models/module.py:80-160 Conv3d / Deconv3d + BatchNorm3d(train) + ReLU, :305-315 
   of a stride-2 convolution is the transposed convolution with the same weights and vice versa, a stride-1 convolution's is
   the convolution with flipped, transposed weights), weight gradient on ``cds_conv3d_wgrad_f32``.
 * :class:`BnRelu3d` — BatchNorm3d with batch statistics + ReLU + optional residual, fused forward (``cds_bn3d_stats_f32`` ->
-  ``cds_bn3d_apply_f32``) and closed-form backward (``cds_bn3d_bwd_reduce_f32`` -> ``cds_bn3d_bwd_apply_f32``); running
+  ``cds_bn3d_norm_f32``) and closed-form backward (``cds_bn3d_bwd_reduce_f32`` -> ``cds_bn3d_bwd_norm_f32``); running
   statistics are updated like ``nn.BatchNorm3d`` (momentum 0.1, unbiased variance).
 
 All kernels are fp32; under bf16 autocast the Functions cast their inputs up (the reference trains in fp32)."""
@@ -120,21 +120,20 @@ class BnRelu3d(torch.autograd.Function):
         lib = _lib.load()
         sums = _scratch.zeros((C, 2), torch.float64, y.device)
         check(lib.cds_bn3d_stats_f32(_dev(y), sums.data_ptr(), B, C, V, ops._stream(y)), "cds_bn3d_stats_f32")
-        # per-channel step in ONE launch (fp64): scale / shift, the saved mean / invstd, the running-statistics update
-        scale = torch.empty((C,), dtype=torch.float32, device=y.device)
-        shift = torch.empty_like(scale)
-        mean = torch.empty((C,), dtype=torch.float64, device=y.device)
-        invstd = torch.empty_like(mean)
+        # statistics pass, then ONE launch for the per-channel step (fp64: scale / shift, the saved mean / invstd, the
+        # running-statistics update) + normalisation + ReLU + residual
+        ss = torch.empty((2, C), dtype=torch.float32, device=y.device)
+        mi = torch.empty((2, C), dtype=torch.float64, device=y.device)
+        scale, shift, mean, invstd = ss[0], ss[1], mi[0], mi[1]
         g32, b32 = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
         track = running_mean is not None
-        check(lib.cds_bn3d_finalize_f32(sums.data_ptr(), _dev(g32), _dev(b32), float(n), float(eps), float(momentum),
-                                        _dev(running_mean) if track else None, _dev(running_var) if track else None,
-                                        scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), invstd.data_ptr(), C, ops._stream(y)),
-              "cds_bn3d_finalize_f32")
         out = torch.empty_like(y)
         skip_c = skip.contiguous() if skip is not None else None
-        check(lib.cds_bn3d_apply_f32(_dev(y), _dev(scale), _dev(shift), _dev(skip_c) if skip_c is not None else None,
-                                     out.data_ptr(), B, C, V, 1 if relu else 0, ops._stream(y)), "cds_bn3d_apply_f32")
+        check(lib.cds_bn3d_norm_f32(_dev(y), sums.data_ptr(), _dev(g32), _dev(b32), float(n), float(eps), float(momentum),
+                                    _dev(running_mean) if track else None, _dev(running_var) if track else None,
+                                    _dev(skip_c) if skip_c is not None else None, out.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                                    mean.data_ptr(), invstd.data_ptr(), B, C, V, 1 if relu else 0, ops._stream(y)),
+              "cds_bn3d_norm_f32")
         ctx.save_for_backward(y, scale, shift, mean, invstd, gamma)
         ctx.relu, ctx.has_skip, ctx.n = relu, skip is not None, n
         return out
@@ -149,16 +148,14 @@ class BnRelu3d(torch.autograd.Function):
         n = ctx.n
         lib = _lib.load()
         sums = _scratch.zeros((C, 2), torch.float64, y.device)
-        check(lib.cds_bn3d_bwd_reduce_f32(_dev(dout), _dev(y), _dev(scale), _dev(shift), sums.data_ptr(), B, C, V,
+        check(lib.cds_bn3d_bwd_reduce_f32(_dev(dout), _dev(y), scale.data_ptr(), shift.data_ptr(), sums.data_ptr(), B, C, V,
                                           1 if ctx.relu else 0, ops._stream(y)), "cds_bn3d_bwd_reduce_f32")
-        k1 = torch.empty((C,), dtype=torch.float32, device=y.device)
-        k0, dgamma, dbeta = torch.empty_like(k1), torch.empty_like(k1), torch.empty_like(k1)
-        check(lib.cds_bn3d_bwd_finalize_f32(sums.data_ptr(), mean.data_ptr(), invstd.data_ptr(), _dev(scale), float(n), k1.data_ptr(),
-                                            k0.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), C, ops._stream(y)),
-              "cds_bn3d_bwd_finalize_f32")
+        gb = torch.empty((2, C), dtype=torch.float32, device=y.device)
+        dgamma, dbeta = gb[0], gb[1]
         dy = torch.empty_like(y)
-        check(lib.cds_bn3d_bwd_apply_f32(_dev(dout), _dev(y), _dev(scale), _dev(shift), _dev(k1), _dev(k0), dy.data_ptr(), B, C,
-                                         V, 1 if ctx.relu else 0, ops._stream(y)), "cds_bn3d_bwd_apply_f32")
+        check(lib.cds_bn3d_bwd_norm_f32(_dev(dout), _dev(y), scale.data_ptr(), shift.data_ptr(), sums.data_ptr(), mean.data_ptr(),
+                                        invstd.data_ptr(), float(n), dy.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), B, C, V,
+                                        1 if ctx.relu else 0, ops._stream(y)), "cds_bn3d_bwd_norm_f32")
         return (dy, dgamma.to(gamma.dtype), dbeta.to(gamma.dtype), dout if ctx.has_skip else None,
                 None, None, None, None, None)
 

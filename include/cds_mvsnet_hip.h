@@ -405,31 +405,27 @@ int cds_refine_finish_f32(const float* d_norm, const float* res, float* out, int
  * Activations [B][C][D][H][W] fp32 (V = D*H*W), statistics fp64.  Forward convolutions and data gradients use
  * cds_conv3d_k3_f32 / cds_deconv3d_k3s2_f32 (a convolution's data gradient is the transposed convolution and vice versa).
  *   cds_bn3d_stats_f32:       sums[c] = (sum x, sum x^2) over batch and voxels, ADDED onto sums [C][2] (zero it first)
- *   cds_bn3d_apply_f32:       out = relu?(y * scale[c] + shift[c]) (+ skip)            BatchNorm(train) + ReLU + U-Net skip
+ *   cds_bn3d_norm_f32:        the per-channel step of nn.BatchNorm3d in training mode from those sums (fp64: mean, biased variance,
+ *                             scale = gamma / sqrt(var + eps), shift = beta - mean scale; n = elements per channel) done by every
+ *                             workgroup, then out = relu?(y * scale[c] + shift[c]) (+ skip): BatchNorm(train) + ReLU + U-Net skip in
+ *                             one launch.  Writes scale / shift [C] floats and mean / invstd [C] doubles for the backward and updates
+ *                             running_mean / running_var in place with `momentum` (unbiased variance; both may be NULL)
  *   cds_bn3d_bwd_reduce_f32:  sums[c] += (sum g, sum g*y), g = dout * [relu ? y*scale+shift > 0 : 1]
- *   cds_bn3d_bwd_apply_f32:   dy = g * scale[c] + y * k1[c] + k0[c]                    BatchNorm backward in closed form
+ *   cds_bn3d_bwd_norm_f32:    dgamma, dbeta [C] and dy = g * scale[c] + y * k1[c] + k0[c] (the BatchNorm backward in closed form; k1,
+ *                             k0 derived from the sums of cds_bn3d_bwd_reduce_f32 by every workgroup) in one launch
  *   cds_conv3d_wgrad_f32:     dw[a][b][tap] += sum_{batch, o} g[a][o] * xin[b][stride * o - 1 + tap]   (k3, pad 1)
  *                             Conv3d: g = dy, xin = x -> dw [Cout][Cin][27]; ConvTranspose3d: g = x, xin = dy, stride 2 ->
  *                             dw [Cin][Cout][27] (PyTorch's layouts).  dw is accumulated onto: zero it first.
  */
 int cds_bn3d_stats_f32(const float* x, double* sums, int B, int C, long long V, void* stream);
-int cds_bn3d_apply_f32(const float* y, const float* scale, const float* shift, const float* skip, float* out, int B, int C,
-                       long long V, int relu, void* stream);
+int cds_bn3d_norm_f32(const float* y, const double* sums, const float* gamma, const float* beta, double n, double eps, float momentum,
+                      float* running_mean, float* running_var, const float* skip, float* out, float* scale, float* shift, double* mean,
+                      double* invstd, int B, int C, long long V, int relu, void* stream);
 int cds_bn3d_bwd_reduce_f32(const float* dout, const float* y, const float* scale, const float* shift, double* sums, int B,
                             int C, long long V, int relu, void* stream);
-int cds_bn3d_bwd_apply_f32(const float* dout, const float* y, const float* scale, const float* shift, const float* k1,
-                           const float* k0, float* dy, int B, int C, long long V, int relu, void* stream);
-
-/* The per-channel arithmetic of BatchNorm3d (training) between those passes, one launch each (fp64 like the statistics):
- * forward: sums [C][2] = (sum y, sum y^2), n = elements per channel -> scale / shift for cds_bn3d_apply_f32, the saved mean / invstd
- * [C] doubles, and running_mean / running_var updated in place with `momentum` (unbiased variance; both may be NULL);
- * backward: sums [C][2] from cds_bn3d_bwd_reduce_f32 -> dgamma, dbeta [C] and k1 / k0 [C] for cds_bn3d_bwd_apply_f32
- * (models/module.py:80-160 in training mode: nn.BatchNorm3d). */
-int cds_bn3d_finalize_f32(const double* sums, const float* gamma, const float* beta, double n, double eps, float momentum,
-                          float* running_mean, float* running_var, float* scale, float* shift, double* mean, double* invstd,
-                          int C, void* stream);
-int cds_bn3d_bwd_finalize_f32(const double* sums, const double* mean, const double* invstd, const float* scale, double n,
-                              float* k1, float* k0, float* dgamma, float* dbeta, int C, void* stream);
+int cds_bn3d_bwd_norm_f32(const float* dout, const float* y, const float* scale, const float* shift, const double* sums,
+                          const double* mean, const double* invstd, double n, float* dy, float* dgamma, float* dbeta, int B, int C,
+                          long long V, int relu, void* stream);
 int cds_conv3d_wgrad_f32(const float* g, const float* xin, float* dw, int B, int Ca, int Cb, int Do, int Ho, int Wo, int Di,
                          int Hi, int Wi, int stride, void* stream);
 
