@@ -5,6 +5,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <atomic>
 
@@ -26,6 +27,12 @@ static inline int cds_launch_status() {
 }
 
 static inline int cds_ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// A/B and test knobs are read PER LAUNCH (a getenv is ~100 ns next to a ~5 us launch): a test that sets one after the first
+// call gets the new value.  cds_env_is(name, c): the variable is set and starts with c; cds_env_int: its integer value or dflt.
+static inline bool cds_env_is(const char* name, char c) { const char* e = getenv(name); return e && e[0] == c; }
+static inline bool cds_env_set(const char* name) { return getenv(name) != nullptr; }
+static inline int cds_env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
 
 // Opt a kernel into more than 64 KB of dynamic LDS once per DEVICE (function attributes are per device: one process may
 // drive several, e.g. nn.DataParallel replicas; `mask` is a per-kernel static).

@@ -351,7 +351,7 @@ int launch_conv2d_n(const float* x, const float* aff, const float* w, const floa
   const int co_groups = CoutP / (CO * NCB);
   const size_t lds_bytes = (K == 1 && S == 1) ? 0 : (size_t)Cfg::TILE * CI_CHUNK * sizeof(float);
   if constexpr (K >= 3 && K <= 5) {   // 7x7 / 11x11 amortise their staging already (80+ TF); measured slower here
-    static const bool pipe = []() { const char* e = getenv("CDS_CONV2D_PIPE"); return !(e && e[0] == '0'); }();   // A/B knob
+    const bool pipe = !cds_env_is("CDS_CONV2D_PIPE", '0');   // A/B knob
     if (pipe && W % 4 == 0 && pad == (K - 1) / 2) {
       using PCfg = C2PipeCfg<K, S, PX, CI_CHUNK>;
       auto pk = conv2d_pipe_kernel<K, S, PX, CI_CHUNK, NCB, CWE>;
@@ -366,17 +366,15 @@ int launch_conv2d_n(const float* x, const float* aff, const float* w, const floa
   return cds_launch_status();
 }
 
-// CDS_CONV2D_WIDE (A/B knob): 0 = one 8-wide block per workgroup everywhere.  Default: all output-channel blocks of a
-// layer from one staged tile where a variant exists (cascade forward 640x512: 11.0 -> 9.8 ms, 1600x1184: 46.9 -> 41.4 ms).
+// All output-channel blocks of a layer from one staged tile where a variant exists (against one 8-wide block per workgroup:
+// cascade forward 640x512 11.0 -> 9.8 ms, 1600x1184 46.9 -> 41.4 ms; the A/B knob is closed).
 template <int K, int S, int CI_CHUNK>
 int launch_conv2d(const float* x, const float* aff, const float* w, const float* b, float* out, int N, int Cin, int Cout,
                   int H, int W, int pad, int act, hipStream_t st) {
-  static const int wide = []() { const char* e = getenv("CDS_CONV2D_WIDE"); return e ? atoi(e) : -1; }();
   const int blocks = (Cout + CO - 1) / CO;
   constexpr int PXW = (S == 2) ? 2 : 4;
-  const bool use_wide = wide != 0;
-  if (use_wide) {
-    static const bool exact = []() { const char* e = getenv("CDS_CONV2D_EXACT"); return !(e && e[0] == '0'); }();
+  {
+    const bool exact = !cds_env_is("CDS_CONV2D_EXACT", '0');
     if (exact && S == 1) {   // DynamicConv branch widths: one workgroup owns every output channel, no padded columns
       if (Cout == 11) return launch_conv2d_n<K, S, PXW, CI_CHUNK, 2, 11>(x, aff, w, b, out, N, Cin, Cout, H, W, pad, act, st);
       if constexpr (K <= 5) {

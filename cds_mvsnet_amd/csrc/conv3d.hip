@@ -785,7 +785,7 @@ extern "C" int cds_conv3d_k3_f32(const float* x, const float* weight, const floa
   const bool wide = Wo >= 48;
   // total elements must fit the 32-bit staging offsets of the pipe kernels
   const bool pipe_ok = (W % 4 == 0) && Wo >= 32 && ((size_t)Cin * D * H * W < (size_t)0x7fffffff);
-  static const bool no_mfma = []() { const char* e = getenv("CDS_CONV_NO_MFMA"); return e && e[0] == '1'; }();
+  const bool no_mfma = cds_env_is("CDS_CONV_NO_MFMA", '1');
   if (!no_mfma) {
     int rc = 0;
     if (cds_conv3d_mfma_launch(x, weight, bias, skip, out, Cin, Cout, D, H, W, stride, act, st, &rc)) return rc;
@@ -822,7 +822,7 @@ extern "C" int cds_deconv3d_k3s2_f32(const float* x, const float* weight, const 
   if (!x || !weight || !out || Cin < 1 || Cout < 1 || (Cout % 8) || D < 1 || H < 1 || W < 1) return CDS_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   {
-    static const bool no_mfma = []() { const char* e = getenv("CDS_CONV_NO_MFMA"); return e && e[0] == '1'; }();
+    const bool no_mfma = cds_env_is("CDS_CONV_NO_MFMA", '1');
     int rc = 0;
     if (!no_mfma && cds_deconv3d_mfma_launch(x, weight, bias, skip, out, Cin, Cout, D, H, W, act, st, &rc)) return rc;
   }

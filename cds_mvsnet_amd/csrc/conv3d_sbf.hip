@@ -340,8 +340,7 @@ int launch_fwd(const float* x, const void* wsp, const float* b, const float* ski
   const int ntiles = tx * ty * tz;
   // tiles per workgroup: enough workgroups for ~6 rounds of one per CU (two where the LDS allows), at most 32 tiles each
   // (a sweep of 4 / 8 / 16 / 32 / 64 at M1 moves single layers by a few percent either way: conv4 likes 8-16, conv6 likes 1)
-  static const int tpw_env = []() { const char* e = getenv("CDS_SBF_TPW"); return e ? atoi(e) : 0; }();   // A/B knob
-  int tpw = tpw_env > 0 ? tpw_env : max(1, min(32, ntiles / (256 * 6)));
+  int tpw = max(1, min(32, ntiles / (256 * 6)));
   const int nwg = cds_ceil_div(ntiles, tpw);
   auto kern = conv3d_sbf_kernel<S, MB, TX, TZ, PAIR, WRES_>;
   constexpr int lds_bytes = 2 * Cfg::LDSB;
@@ -592,8 +591,7 @@ int launch_deconv(const float* x, const void* wsp, const float* b, const float* 
   using Cfg = DCfg;
   const int tx = cds_ceil_div(W, Cfg::CX), ty = cds_ceil_div(H, Cfg::CY);
   const int ntiles = tx * ty * D;
-  static const int tpw_env = []() { const char* e = getenv("CDS_SBF_TPW"); return e ? atoi(e) : 0; }();   // A/B knob
-  int tpw = tpw_env > 0 ? tpw_env : max(1, min(16, ntiles / (256 * 2 * 8)));
+  int tpw = max(1, min(16, ntiles / (256 * 2 * 8)));
   const int nwg = cds_ceil_div(ntiles, tpw);
   hipLaunchKernelGGL((deconv3d_sbf_kernel<MERGE, MB>), dim3(nwg), dim3(256), Cfg::LDSB, st, x, reinterpret_cast<const uint4*>(wsp),
                      b, skip, out, Cin, Cout, D, H, W, act, out_planar, tx, ty, ntiles, tpw);
@@ -829,8 +827,7 @@ int launch_deconv_ws_t(const float* x, const void* wsp, const float* b, const fl
   using Cfg = DWSCfg<CYT>;
   const int tx = cds_ceil_div(W, Cfg::CX), ty = cds_ceil_div(H, Cfg::CY);
   const int ntiles = tx * ty * D;
-  static const int tpw_env = []() { const char* e = getenv("CDS_SBF_TPW"); return e ? atoi(e) : 0; }();   // A/B knob
-  int tpw = tpw_env > 0 ? tpw_env : max(1, min(16, ntiles / (256 * (CYT == 8 ? 1 : 2) * 8)));
+  int tpw = max(1, min(16, ntiles / (256 * (CYT == 8 ? 1 : 2) * 8)));
   const int nwg = cds_ceil_div(ntiles, tpw);
   const int lds_bytes = (Cin >> 3) * DTab<true>::NKS * 3 * 1024 + 2 * Cfg::LDSB;
   static std::atomic<unsigned long long> lds_ok{0};
@@ -842,8 +839,7 @@ int launch_deconv_ws_t(const float* x, const void* wsp, const float* b, const fl
 
 int launch_deconv_ws(const float* x, const void* wsp, const float* b, const float* skip, float* out, int Cin, int Cout, int D, int H,
                      int W, int act, int out_planar, hipStream_t st) {
-  static const int cyt_env = []() { const char* e = getenv("CDS_DWS_CYT"); return e ? atoi(e) : 0; }();   // A/B knob: 4 | 8
-  const bool big = cyt_env ? cyt_env == 8 : (H >= 16 && (long)cds_ceil_div(W, 32) * cds_ceil_div(H, 8) * D >= 2 * 256);
+  const bool big = (H >= 16 && (long)cds_ceil_div(W, 32) * cds_ceil_div(H, 8) * D >= 2 * 256);
   if (big) return launch_deconv_ws_t<8>(x, wsp, b, skip, out, Cin, Cout, D, H, W, act, out_planar, st);
   return launch_deconv_ws_t<4>(x, wsp, b, skip, out, Cin, Cout, D, H, W, act, out_planar, st);
 }
@@ -857,6 +853,7 @@ extern "C" int cds_conv3d_sbf_f32(const float* x, const void* weight_split, cons
   if (!x || !weight_split || !out || Cin < 8 || (Cin % 8) || Cout < 4 || (Cout % 4) || Cout > 64 || D < 1 || H < 1 || W < 1 ||
       (stride != 1 && stride != 2 && stride != CDS_SBF_PAIR))
     return CDS_EINVAL;
+  if (stride == CDS_SBF_PAIR && Cout != 8) return CDS_EINVAL;   // pair-packed weights exist for Cout == 8 only
   hipStream_t st = (hipStream_t)stream;
   const int mb = (Cout + 15) / 16;
   if (!skip) {   // z-marching kernels (conv3d_zmg.hip) where they cover the shape
@@ -889,8 +886,7 @@ extern "C" int cds_deconv3d_sbf_f32(const float* x, const void* weight_split, co
   if (!x || !weight_split || !out || Cin < 8 || (Cin % 8) || D < 1 || H < 1 || W < 1) return CDS_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   if (Cout == 8) {
-    static const bool old = getenv("CDS_DECONV_OLD") != nullptr;   // A/B knob
-    if (Cin <= 32 && !old) return launch_deconv_ws(x, weight_split, bias, skip, out, Cin, Cout, D, H, W, act, out_planar, st);
+    if (Cin <= 32) return launch_deconv_ws(x, weight_split, bias, skip, out, Cin, Cout, D, H, W, act, out_planar, st);
     return launch_deconv<true, 1>(x, weight_split, bias, skip, out, Cin, Cout, D, H, W, act, out_planar, st);
   }
   if (Cout == 16) return launch_deconv<false, 1>(x, weight_split, bias, skip, out, Cin, Cout, D, H, W, act, out_planar, st);

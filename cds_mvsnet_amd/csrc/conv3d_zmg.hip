@@ -369,7 +369,7 @@ __global__ __launch_bounds__(Cfg::THREADS, 1) void conv3d_zmg_kernel(const float
 // z segments per column: enough workgroups for the 256 CUs (one workgroup per CU: the ring takes most of the LDS) with full
 // rounds of them, against the two or three stage times a segment spends filling its pipeline.
 inline int zmg_pick_nseg(int cols, int Do, int G) {
-  static const int nseg_env = []() { const char* e = getenv("CDS_ZMG_NSEG"); return e ? atoi(e) : 0; }();   // A/B knob
+  const int nseg_env = cds_env_int("CDS_ZMG_NSEG", 0);   // A/B knob
   if (nseg_env > 0) return nseg_env;
   const int stages = cds_ceil_div(Do, G);
   int best = 1;
@@ -405,7 +405,7 @@ int launch_zmg(const float* x, const void* wsp, const float* b, float* out, int 
 // pair != 0: Cout == 8 with the pair-packed weights (ops.split_pack_conv3d_pair), stride 1.
 int cds_conv3d_zmg_dispatch(const float* x, const void* wsp, const float* bias, float* out, int Cin, int Cout, int D, int H, int W,
                             int stride, int pair, int act, hipStream_t st) {
-  static const bool off = []() { const char* e = getenv("CDS_ZMG"); return e && e[0] == '0'; }();   // A/B knob: 0 = tiled kernels only
+  const bool off = cds_env_is("CDS_ZMG", '0');   // A/B knob: 0 = tiled kernels only
   if (off) return CDS_ZMG_UNSUPPORTED;
   // Consumer waves per SIMD as measured at the M1 / cascade shapes (profiles/r04_zmarch.md): two for everything but the 16 -> 8 pair layer
   if (pair) {

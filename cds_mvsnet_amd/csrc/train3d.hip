@@ -347,7 +347,7 @@ extern "C" int cds_conv3d_wgrad_f32(const float* g, const float* xin, float* dw,
   const int ntiles = tx * ty * tz;
   int per = cds_ceil_div(ntiles * B, 1024);      // ~1024 tile groups: a handful of atomics per output, enough workgroups
   if (per < 1) per = 1;
-  static const bool valu = getenv("CDS_WGRAD_VALU") != nullptr;   // A/B knob: the VALU kernel
+  const bool valu = cds_env_set("CDS_WGRAD_VALU");   // A/B knob: the VALU kernel
   if (!valu) {
     const dim3 gm(cds_ceil_div(ntiles * B, per), cds_ceil_div(Ca, 16), cds_ceil_div(Cb, 8));
     if (stride == 1) {

@@ -301,11 +301,7 @@ bool cds_warp_entropy_lds_launch(const float* ref, const float* src, const WarpM
                                  float* entropy, int V, int C, int D, int h, int w, int hyp_pp, bool fast, hipStream_t st, int hs = 0,
                                  int y_off = 0);
 static bool cds_use_lds_path() {
-  static const bool on = []() {
-    const char* e = getenv("CDS_WARP_DIRECT");  // CDS_WARP_DIRECT=1 forces the direct (L1 gather) kernels
-    return !(e && e[0] == '1');
-  }();
-  return on;
+  return !cds_env_is("CDS_WARP_DIRECT", '1');   // CDS_WARP_DIRECT=1 forces the direct (L1 gather) kernels
 }
 
 static bool cds_warp_args_ok(int V, int C, int D, int h, int w) {

@@ -317,7 +317,7 @@ extern "C" int cds_warp_aggregate_bwd_f32(const float* ref_chw, const float* src
   const int tiles_x = cds_ceil_div(w, CDS_TILE_X), tiles_y = cds_ceil_div(h, CDS_TILE_Y);
   const int ntiles = tiles_x * tiles_y;
   const int base = ntiles * V * (C / 8);
-  static const bool direct = getenv("CDS_K3BWD_DIRECT") != nullptr;   // A/B knob: the direct-scatter kernel
+  const bool direct = cds_env_set("CDS_K3BWD_DIRECT");   // A/B knob: the direct-scatter kernel
   if (!direct) {
     // LDS-privatised scatter: segments only until ~1024 workgroups (every segment pays one box flush), >= 8 planes each
     int nseg = 1;

@@ -9,8 +9,8 @@ checkpoints load unchanged (387 entries, e.g. ``feature.conv00.conv.att_convs.0.
 (:class:`_Packed`) and handed to the C ABI through :mod:`cds_mvsnet_amd.ops`.
 
 Scope: inference (``model.eval()``) runs entirely on the HIP kernels.  ``model.train()`` dispatches to
-``training.forward_train`` (first step): the fused warp-aggregate has hand-written forward AND
-backward kernels, the convolution stacks use stock PyTorch-ROCm autograd ops for now.
+``training.forward_train``: every stack has hand-written HIP forward AND backward kernels behind
+``torch.autograd.Function``s (train_ops.py, train2d_ops.py); CUDA (ROCm) tensors only, CPU tensors raise.
 """
 from __future__ import annotations
 
@@ -209,7 +209,15 @@ class CostRegNet(_PackedHolder):
         self.conv9 = ConvBn3d(4 * b, 2 * b, transposed=True)
         self.conv11 = ConvBn3d(2 * b, b, transposed=True)
         self.prob = nn.Conv3d(b, 1, 3, stride=1, padding=1, bias=False)
+        self._slab_operands = False     # slab.py: also pack the tiled operands of conv9 / conv11 (want_slab_operands())
         self._init_packed()
+
+    def want_slab_operands(self) -> None:
+        """The slab-parallel form (slab.py) exchanges halo rows between conv11 and prob and keeps the tiled transposed kernels
+        for conv9 / conv11: pack their operands too (every other model skips them)."""
+        if not self._slab_operands:
+            self._slab_operands = True
+            self._packed.invalidate()
 
     def _pack(self) -> Dict[str, Tensor]:
         out: Dict[str, Tensor] = {}
@@ -241,6 +249,8 @@ class CostRegNet(_PackedHolder):
                 if name == "conv9":     # 32 -> 16: z-marching class-per-wave kernel (csrc/deconv3d_zm.hip); ".ws" stays for slab.py
                     out[name + ".wc"] = ops.split_pack_deconv_cls(unit.conv.weight.detach() * scale.view(1, -1, 1, 1, 1))
                 if unit.transposed:
+                    if name != "conv7" and not self._slab_operands:
+                        continue        # conv9 / conv11 run their z-marching forms; the tiled operands are slab.py's
                     out[name + ".ws"] = ops.split_pack_deconv3d(unit.conv.weight.detach() * scale.view(1, -1, 1, 1, 1))
                 elif name == "conv0":   # Cout = 8, stride 1: voxel-pair columns (no matrix row multiplies padding)
                     out[name + ".ws"] = ops.split_pack_conv3d_pair(unit.conv.weight.detach() * scale.view(-1, 1, 1, 1, 1))
@@ -324,7 +334,7 @@ class Refinement(_PackedHolder):
     """2x depth up-sampling with image guidance (module.py:318-370).  Eval mode runs on the HIP
     kernels (3x3 Conv+BN+ReLU units on cds_conv2d_f32 with the BatchNorm folded in, the transposed conv, the depth
     pre-scale and the bilinear-upsample + residual epilogue in refine.hip); training mode runs the HIP forward /
-    backward training ops (train2d_ops.refinement; torch autograd ops with CDS_TRAIN_HIP2D=0 or on the CPU)."""
+    backward training ops (train2d_ops.refinement; device tensors only)."""
 
     def __init__(self):
         super().__init__()
@@ -751,7 +761,7 @@ class CDSMVSNet(nn.Module):
         if H % 32 or W % 32:
             raise ValueError("internal resolution must be a multiple of 32 (three stride-2 levels at 1/4 scale)")
         if self.training:
-            from .training import forward_train   # autograd path: HIP warp-aggregate fwd/bwd + torch conv stacks
+            from .training import forward_train   # autograd path: HIP forward / backward kernels for every stack
             return forward_train(self, imgs.float(), proj_matrices, depth_values, gt_depths, temperature)
         T = float(temperature)
         keys = list(proj_matrices.keys())

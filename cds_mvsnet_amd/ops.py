@@ -583,6 +583,13 @@ def conv3d_sbf(x_cl: Tensor, wsplit: Tensor, bias: Optional[Tensor], cout: int, 
         raise ValueError("conv3d_sbf: residual shape mismatch")
     if wsplit.dtype != torch.int16 or not wsplit.is_cuda or not wsplit.is_contiguous():
         raise ValueError("conv3d_sbf: wsplit must be the contiguous int16 device tensor from split_pack_conv3d")
+    if stride == SBF_PAIR and cout != 8:
+        raise ValueError("conv3d_sbf: the pair-packed form (stride=SBF_PAIR) exists for cout == 8 only")
+    ksteps = 9 if stride == SBF_PAIR else 7                     # split_pack_conv3d_pair / split_pack_conv3d
+    want = (Cin // 8) * ksteps * ((cout + 15) // 16) * 3 * 64 * 8
+    if Cin % 8 or wsplit.numel() != want:
+        raise ValueError(f"conv3d_sbf: wsplit has {wsplit.numel()} entries, the packer gives {want} for Cin={Cin}, cout={cout}, "
+                         f"stride code {stride}")
     check(_lib.load().cds_conv3d_sbf_f32(_dev(x_cl, "x"), wsplit.data_ptr(), _dev(bias, "bias") if bias is not None else None,
                                          _dev(skip, "skip") if skip is not None else None, out.data_ptr(), Cin, cout,
                                          D, H, W, stride, ACT_RELU if relu else ACT_NONE, _stream(x_cl)), "cds_conv3d_sbf_f32")

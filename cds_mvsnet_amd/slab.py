@@ -243,6 +243,7 @@ class HipCostRegLayers:
         self.ops = ops
         if not cost_reg.split_bf16_supported():
             raise RuntimeError("slab-parallel CostRegNet needs the split-bf16 kernels (base channels 8, CDS_CONV_EXACT unset)")
+        cost_reg.want_slab_operands()
         self.p = cost_reg._packed.get(cost_reg, cost_reg._pack)
         self.cout = {name: getattr(cost_reg, name).conv.out_channels for name in
                      ("conv0", "conv1", "conv2", "conv3", "conv4", "conv5", "conv6", "conv7", "conv9", "conv11")}

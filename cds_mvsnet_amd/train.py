@@ -162,7 +162,8 @@ _SIDE_VERDICT: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()   # mod
 def _backward(model: torch.nn.Module, loss: torch.Tensor) -> None:
     """loss.backward() with the weight-gradient kernels on a side stream when that is SOUND for this model (see _scratch.py): the first
     backward of a model runs on one stream and audits that every buffer a weight-gradient kernel filled ended up as the storage of a
-    parameter's `.grad` (so AccumulateGrad launched nothing on it: one gradient per parameter, handed over untouched).  A parameter
+    parameter's `.grad` - all of its bytes - and that every parameter accumulated exactly one gradient in the backward (so
+    AccumulateGrad launched nothing on a buffer: one gradient per parameter, handed over untouched).  A parameter
     that is used twice (CDS_TRAIN_BATCH_FEATURES=0 runs FeatureNet 2 V times on shared weights) fails the audit and keeps the single
     stream: `grad += dw` on the main stream would race with the kernel still writing `dw`."""
     from . import training
@@ -170,19 +171,33 @@ def _backward(model: torch.nn.Module, loss: torch.Tensor) -> None:
     if not (SIDE_STREAM_WGRAD and dev.type == "cuda"):
         loss.backward()
         return
-    key = (training.BATCH_FEATURES,)
+    params = [p for p in model.parameters() if p.requires_grad]
+    key = (training.BATCH_FEATURES, tuple(id(p) for p in params))      # re-audit when the trainable set changes
     verdict = _SIDE_VERDICT.get(model)
     if verdict is None or verdict[0] != key:
+        # the audit: (1) every parameter's gradient is accumulated exactly ONCE in this backward (a second contribution - from any op,
+        # not only from a weight-gradient kernel - would be `grad += X` on the main stream while the side-stream kernel still writes the
+        # buffer); (2) the gradients found inside a buffer a weight-gradient kernel filled cover ALL of its bytes (a DynamicConv's dw is
+        # split into two parameters' gradients: both must have taken their part, untouched)
+        counts: dict = {}
+        hooks = [p.register_post_accumulate_grad_hook(lambda q: counts.__setitem__(id(q), counts.get(id(q), 0) + 1)) for p in params]
         _scratch.audit_begin(dev)
         try:
             loss.backward()
         finally:
             filled = _scratch.audit_end(dev)
-        starts = sorted(p.grad.data_ptr() for p in model.parameters() if p.grad is not None)
-        ok = bool(filled)
+            for h in hooks:
+                h.remove()
+        grads = sorted((p.grad.data_ptr(), p.grad.numel() * p.grad.element_size()) for p in params if p.grad is not None)
+        starts = [g[0] for g in grads]
+        ok = bool(filled) and all(c == 1 for c in counts.values())
         for ptr, nbytes in filled:
             i = bisect.bisect_left(starts, ptr)
-            if i >= len(starts) or starts[i] >= ptr + nbytes:
+            covered = 0
+            while i < len(grads) and grads[i][0] < ptr + nbytes:
+                covered += grads[i][1]
+                i += 1
+            if covered != nbytes:
                 ok = False
                 break
         _SIDE_VERDICT[model] = (key, ok)

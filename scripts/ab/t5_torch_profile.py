@@ -13,10 +13,10 @@ sample = bench.train_sample(H, W, n_views, refine, dev, seed=21)
 opt = T.make_optimizer(model)
 reducer = T.GradAllReducer(model.parameters(), module=model)
 for _ in range(3):
-    T.train_step(model, opt, sample, temperature=0.1, reducer=reducer, bf16=False)
+    T.train_step(model, opt, sample, temperature=0.1, reducer=reducer)
 torch.cuda.synchronize()
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
-    T.train_step(model, opt, sample, temperature=0.1, reducer=reducer, bf16=False)
+    T.train_step(model, opt, sample, temperature=0.1, reducer=reducer)
     torch.cuda.synchronize()
 import collections
 ks = prof.key_averages(group_by_stack_n=12)

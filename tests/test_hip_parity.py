@@ -1059,3 +1059,48 @@ def test_dynconv_fused_equals_branches_then_blend(cin, cout, ks, N, H, W, bias, 
         assert torch.equal(o1, o2) and torch.equal(n1, n2)
         assert torch.allclose(s1, s2, rtol=1e-12, atol=1e-9)
         assert torch.allclose(a1, a2, rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,H,W", [(4, 20, 36), (1, 8, 32), (3, 13, 100)])
+def test_visibility_layers_split_bf16(N, H, W, dev, ops):
+    """cds_conv2d_k3_relu_sbf_f32 (visibility CNN layers 2 / 3 + head, model.py:14, split-bf16 on the bf16 matrix cores) against
+    float64 and the fp32-MFMA kernel it replaces (cds_conv2d_k3_c16_f32): fp32-class, with and without the fused 1x1 head."""
+    g = torch.Generator().manual_seed(N * 100 + W)
+    x = torch.randn(N, 16, H, W, generator=g).clamp_min(0)
+    w = torch.randn(16, 16, 3, 3, generator=g) / 12.0
+    b = torch.randn(16, generator=g) * 0.2
+    hw, hb = torch.randn(16, generator=g) * 0.3, torch.randn(1, generator=g)
+    y64 = F.conv2d(x.double(), w.double(), b.double(), padding=1).clamp_min(0)
+    ws = ops.split_pack_dynconv([w.to(dev)])
+    wcl = w.permute(2, 3, 0, 1).reshape(9, 16, 16).contiguous().to(dev)
+    got = ops.conv2d_k3_relu_sbf(x.to(dev), ws, b.to(dev)).cpu()
+    old = ops.conv2d_k3_c16(x.to(dev), wcl, b.to(dev)).cpu()
+    e_new, e_old = (got.double() - y64).abs().max().item(), (old.double() - y64).abs().max().item()
+    ulp = y64.abs().max().item() * 2.0 ** -23
+    assert e_new <= 1.5 * e_old + ulp, (e_new, e_old)
+    h64 = torch.sigmoid((y64 * hw.double().view(1, 16, 1, 1)).sum(1) + hb.double())
+    goth = ops.conv2d_k3_relu_sbf(x.to(dev), ws, b.to(dev), head_w=hw.to(dev), head_b=hb.to(dev)).cpu()
+    oldh = ops.conv2d_k3_c16(x.to(dev), wcl, b.to(dev), head_w=hw.to(dev), head_b=hb.to(dev)).cpu()
+    assert (goth.double() - h64).abs().max().item() <= 1.5 * (oldh.double() - h64).abs().max().item() + 2.0 ** -23
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("V,C,D,h,w,y0,y1", [(4, 8, 40, 64, 136, 16, 40), (2, 16, 9, 40, 72, 0, 8), (3, 32, 12, 32, 48, 24, 32),
+                                            (6, 16, 20, 48, 64, 8, 48), (1, 8, 70, 24, 200, 8, 24)])
+def test_warp_row_windows_equal_full_grid_rows(V, C, D, h, w, y0, y1, dev, ops):
+    """Row-window forms of K1 / K3 (pixel-slab sharding, exchange='slab'): reference-side tensors restricted to rows [y0, y1),
+    source maps whole.  The window's entropy and volume must equal the same rows of the full-grid call BIT FOR BIT (positions come
+    from the global pixel row), planar and channels-last, both position modes."""
+    feats, cams, hyp, ref, src, mats, hyp_d = _random_stage(ops, dev, V, C, D, h, w, seed=60 + V)
+    vis = (torch.rand(V, h, w, generator=torch.Generator().manual_seed(4)) * 0.8 + 0.1).to(dev)
+    for exact in (True, False):
+        ent_full = ops.warp_entropy(ref, src, mats, hyp_d, exact=exact)
+        ref_w, hyp_w, vis_w = ref[:, :, y0:y1].contiguous(), hyp_d[:, y0:y1].contiguous(), vis[:, y0:y1].contiguous()
+        ent_w = ops.warp_entropy(ref_w, src, mats, hyp_w, exact=exact, window=(h, y0))
+        assert torch.equal(ent_w, ent_full[:, y0:y1])
+        for cl in (False, True):
+            vol_full, vs_full = ops.warp_aggregate(ref, src, vis, mats, hyp_d, channels_last=cl, exact=exact)
+            vol_w, vs_w = ops.warp_aggregate(ref_w, src, vis_w, mats, hyp_w, channels_last=cl, exact=exact, window=(h, y0))
+            assert torch.equal(vs_w, vs_full[y0:y1])
+            assert torch.equal(vol_w, vol_full[:, y0:y1] if cl else vol_full[:, :, y0:y1])

@@ -160,7 +160,7 @@ def test_full_training_forward_equals_torch_2d_stacks(refine, B):
     assert set(res[True][2]) == set(res[False][2])
     # fp32 against fp32 through 30 layers with discrete switches (hypothesis ranges follow the previous stage's depth, ReLU / softmax(./T)
     # kinks, BatchNorm over a few hundred values in the coarse 3D layers): scaling the images by (1 + 1e-6) moves single gradients of the
-    # torch path by 2-3 % (57 % in stage 3's conv6) and the whole gradient's cosine to 0.99999 (scripts/ab/train2d_e2e.py).  The tight
+    # torch path by 2-3 % (57 % in stage 3's conv6) and the whole gradient's cosine to 0.99999 (round-3 A/B script, removed with the torch training path).  The tight
     # checks are the per-op tests above (float64 reference); this one catches a wrong or missing gradient path.
     names = list(res[False][2])
     va = torch.cat([res[True][2][n].double().flatten() for n in names])
