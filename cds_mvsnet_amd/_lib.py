@@ -69,6 +69,16 @@ SIGNATURES = {
     "cds_instnorm_reduce_f32": [P, I, P, P, I, I, I, I, F, P],
     "cds_instnorm_apply_f32": [P, P, P, I, I, I, I, I, I, P],
     "cds_instnorm_act_f32": [P, P, P, I, I, I, I, I, I, P],
+    "cds_dynconv_cl_parts": [I, I],
+    "cds_dynconv_cl_f32": [P, P, P, P, P, P, P, P, F, P, P, P, I, I, I, I, P, I, P],
+    "cds_blend_cl_parts": [I, I],
+    "cds_dynconv_blend_cl_f32": [P, P, P, P, P, F, P, P, P, I, I, I, I, I, I, P],
+    "cds_conv2d_k3s2_cl_f32": [P, P, P, P, I, I, I, I, I, P],
+    "cds_fpn_cl_parts": [I, I],
+    "cds_conv2d_fpn_cl_f32": [P, P, P, P, P, P, P, I, I, I, I, I, I, P],
+    "cds_instnorm_stats_cl_parts": [I, I],
+    "cds_instnorm_stats_cl_f32": [P, P, I, I, I, I, P],
+    "cds_instnorm_apply_cl_f32": [P, P, P, P, I, I, I, I, I, I, I, P],
     "cds_curvature_stats_f32": [P, P, P, P, P, I, P],
     "cds_pair_mean_f32": [P, P, I, I, P],
     "cds_view_mean_f32": [P, P, I, I, P],

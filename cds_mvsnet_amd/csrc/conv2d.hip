@@ -19,6 +19,7 @@
 #include <stdlib.h>
 
 #include "cds_common.hpp"
+#include "feat_common.hpp"
 
 #ifndef CDS_C2_CHUNK3
 #define CDS_C2_CHUNK3 4     // input channels per staged chunk of the 3x3 layers (A/B: 2 / 4 / 8)
@@ -394,26 +395,6 @@ int launch_conv2d(const float* x, const float* aff, const float* w, const float*
   return launch_conv2d_n<K, S, PXW, CI_CHUNK, 1>(x, aff, w, b, out, N, Cin, Cout, H, W, pad, act, st);
 }
 
-// fp64 sum over the 64 lanes of a wave without the LDS crossbar: four DPP steps inside each row of 16 lanes, then the
-// four row totals through v_readlane.
-template <int CTRL>
-__device__ __forceinline__ double dpp_f64(double v) {
-  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, true);
-  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, true);
-  return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double readlane_f64(double v, int lane) {
-  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane),
-                          __builtin_amdgcn_readlane(__double2loint(v), lane));
-}
-__device__ __forceinline__ double wave_sum_f64(double v) {
-  v += dpp_f64<0xB1>(v);    // quad_perm [1,0,3,2]
-  v += dpp_f64<0x4E>(v);    // quad_perm [2,3,0,1]
-  v += dpp_f64<0x141>(v);   // row_half_mirror
-  v += dpp_f64<0x140>(v);   // row_mirror
-  return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
-}
-
 // ---------------------------------------------------------------------------------------------
 // FPN lateral (module.py:253-254,260-261): 1x1 convolution over cat(nearest2x(coarse), skip) without building either
 // the up-sampled tensor or the concatenation.  coarse [N][Ca][H/2][W/2], skip [N][Cb][H][W], weights packed
@@ -526,61 +507,6 @@ __global__ __launch_bounds__(256) void fpn_lateral_kernel(const float* __restric
 // DynamicConv epilogue.  `branch` holds, for each kernel size k, the Cout conv responses followed
 // by the 3 curvature responses: [K][Cout+3][H][W].
 // ---------------------------------------------------------------------------------------------
-struct EpiBatch {
-  float x[CDS_MAX_IMAGES], y[CDS_MAX_IMAGES];
-};
-
-// Per-pixel part of the epilogue: epipolar projection of the K curvature responses, 1x1 MLP, softmax(./T).
-// Returns the blend weights in logit[] and the weighted curvature.
-template <int K>
-__device__ __forceinline__ float blend_weights(const float* __restrict__ branch, size_t bstride, int Cout, int hw, int p,
-                                               int W, float epi_x, float epi_y, const float* __restrict__ w1,
-                                               const float* __restrict__ b1, const float* __restrict__ w2,
-                                               float temperature, float logit[K]) {
-  const int y = p / W, x = p % W;
-  float u = (float)x - epi_x, v = (float)y - epi_y;
-  const float nrm = sqrtf(u * u + v * v);
-  u = u / (nrm + 1e-6f);
-  v = v / (nrm + 1e-6f);
-  const float b0 = u * u, b1v = 2.0f * u * v, b2 = v * v;
-  float curv[K];
-#pragma unroll
-  for (int k = 0; k < K; ++k) {
-    const float* a = branch + k * bstride + (size_t)Cout * hw + p;
-    curv[k] = a[0] * b0 + a[hw] * b1v + a[2 * (size_t)hw] * b2;
-  }
-  float hid[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    float s = 0.f;
-#pragma unroll
-    for (int k = 0; k < K; ++k) s = fmaf(w1[j * K + k], curv[k], s);
-    hid[j] = fmaxf(s + b1[j], 0.f);
-  }
-  float mx = -INFINITY;
-#pragma unroll
-  for (int k = 0; k < K; ++k) {
-    float s = 0.f;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) s = fmaf(w2[k * 4 + j], hid[j], s);
-    logit[k] = s / temperature;
-    mx = fmaxf(mx, logit[k]);
-  }
-  float den = 0.f;
-#pragma unroll
-  for (int k = 0; k < K; ++k) {
-    logit[k] = expf(logit[k] - mx);
-    den += logit[k];
-  }
-  float nc = 0.f;
-#pragma unroll
-  for (int k = 0; k < K; ++k) {
-    logit[k] = logit[k] / den;
-    nc = nc + curv[k] * logit[k];
-  }
-  return nc;
-}
-
 // branch: [K][N][Cout+3][H][W]; out: [N][Cout][H][W]; norm_curv: [N][H][W]; image n = blockIdx.y
 template <int K>
 __global__ __launch_bounds__(256) void dynconv_blend_kernel(const float* __restrict__ branch,

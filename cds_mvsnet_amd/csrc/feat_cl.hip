@@ -1,0 +1,725 @@
+// FeatureNet on CHANNELS-LAST activations (round 5; models/module.py:234-267, models/dynamic_conv.py:97-122).
+//
+// Every FeatureNet activation is [N][H][W][C] fp32: a pixel's channels are contiguous (32 / 64 / 128-byte texels for C = 8 / 16 /
+// 32), a staged tile row is ONE contiguous, 32-byte aligned run of (tile width + 2 halo) * C floats instead of C row segments of
+// 160 bytes from C channel planes (what the planar kernels of conv2d_sbf.hip waited for: memory-system throughput on short
+// segments, profiles/r04_experiments.md).  K1 / K3 gather source features channels-last already, so the stage outputs need no
+// transposition pass.
+//
+//   cds_dynconv_cl_f32        one DynamicConv in one kernel: all branch convolutions (conv_k and the 3 curvature channels att_k
+//                             of every kernel size k) as implicit GEMMs on the bf16 matrix cores in split-bf16 arithmetic
+//                             (sbf_common.hpp: 3 bf16 terms per fp32 operand, 6 partial products, fp32 accumulate) + the blend
+//                             epilogue (epipolar projection, 1x1 MLP, softmax(./T), blend) on the accumulators + the InstanceNorm
+//                             records of the result.  TRANSPOSED GEMM: D[cout][pixel] += W[cout][k] X[k][pixel], so a lane ends
+//                             with 4 consecutive output channels of ONE pixel = one 16-byte channels-last store, and the three
+//                             curvature responses of a pixel sit in ONE lane (no LDS round trip for the epilogue).
+//   cds_dynconv_blend_cl_f32  the same epilogue over a planar branch tensor (conv00: 3 input channels, VALU branch kernels),
+//                             channels-last output
+//   cds_conv2d_k3s2_cl_f32    the two down-sampling units (3x3, stride 2, pad 1), VALU, texel loads straight from global memory
+//   cds_conv2d_fpn_cl_f32     FPN lateral: 1x1 convolution over cat(nearest2x(coarse), skip), neither materialised
+//   cds_instnorm_stats_cl_f32 / cds_instnorm_apply_cl_f32   InstanceNorm statistics records / normalise + activation, with the
+//                             reference-view rows also written planar [C][h][w] (what K1 / K3 read per reference pixel)
+// Normalise-on-load everywhere: a layer output travels as (raw, affine [N][C][3] = 1/std, -mean/std, leaky slope).
+#include "sbf_common.hpp"
+#include "feat_common.hpp"
+
+namespace {
+
+constexpr int TX = 32, TY = 8;   // output tile of a workgroup: wave w owns rows 2w, 2w + 1 = four 16-pixel MFMA column tiles
+
+struct DynEpi {
+  const float* w1;      // [4][K]
+  const float* b1;      // [4]
+  const float* w2;      // [K][4]
+  float* out;           // [N][H][W][C]
+  float* norm_curv;     // [N][H][W]
+  double* partial;      // [N][tiles][C][2]
+  float temperature;
+  float ex[CDS_MAX_IMAGES], ey[CDS_MAX_IMAGES];
+};
+
+constexpr int cmax(int a, int b) { return a > b ? a : b; }
+constexpr int nks_of(int k) { return (k * k + 3) / 4; }
+
+template <int CIN, int K0, int K1, int K2>
+struct DCfg {
+  static constexpr int NBR = K2 > 0 ? 3 : 2;
+  static constexpr int R = (cmax(K0, cmax(K1, K2)) - 1) / 2;
+  static constexpr int IXP = TX + 2 * R, IY = TY + 2 * R, NPOS = IXP * IY;
+  static constexpr int ROUNDS = CIN / 8, PLANE = NPOS * POSB;
+  static constexpr int CO3 = CIN + 3, NBLK = (CO3 + 15) / 16;
+  static constexpr int NCB = CIN >= 16 ? CIN / 16 : 1;        // blocks that hold output channels
+  static constexpr int C4 = CIN / 4;                           // float4 chunks per texel
+  static constexpr int NCH = NPOS * C4, NIT = (NCH + 255) / 256, PSTEP = 256 / C4;
+  static constexpr int NKS = nks_of(K0) + nks_of(K1) + (K2 > 0 ? nks_of(K2) : 0);
+  static constexpr int GC = CIN == 8 ? 2 : 0, MBC = CIN / 16;  // lane group / block that hold the curvature rows Cout .. Cout + 2
+  static constexpr int LDSB = cmax(ROUNDS * PLANE, 4 * CIN * 2 * 8);
+};
+
+// sum over the 16 lanes of a DPP row, fp64 (all lanes end up with the total)
+__device__ __forceinline__ double row16_sum_f64(double v) {
+  v += dpp_f64<0xB1>(v);
+  v += dpp_f64<0x4E>(v);
+  v += dpp_f64<0x141>(v);
+  v += dpp_f64<0x140>(v);
+  return v;
+}
+
+template <int CIN, int K0, int K1, int K2>
+__global__ __launch_bounds__(256, 2) void dynconv_cl_kernel(const float* __restrict__ x, const float* __restrict__ affine,
+                                                            const uint4* __restrict__ wsp, const float* __restrict__ bias,
+                                                            DynEpi ep, int N, int H, int W, int tiles_x, int tiles_y) {
+  using C = DCfg<CIN, K0, K1, K2>;
+  constexpr int NBR = C::NBR, NBLK = C::NBLK, R = C::R, IXP = C::IXP;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  int lin = cds_xcd_remap(blockIdx.x, tiles_x * tiles_y * N);
+  const int tx_i = lin % tiles_x;
+  lin /= tiles_x;
+  const int ty_i = lin % tiles_y, img = lin / tiles_y;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = lane & 15, g = lane >> 4;
+  const int ox0 = tx_i * TX, oy0 = ty_i * TY;
+
+  // ---- stage the (TY + 2R) x (TX + 2R) texel tile, all channels: thread = float4 chunk of the tile's contiguous rows, so the
+  // 64 lanes of a load instruction read 1 KB of consecutive bytes.  A thread's channel quad is the same in every iteration
+  // (256 % C4 == 0): its 12 normalise-on-load constants are loaded once.  Exact 3-way bf16 split in registers. ----
+  {
+    const int c4 = tid % C::C4;
+    float al[4], be[4], sl[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      al[j] = 1.f; be[j] = 0.f; sl[j] = 1.f;
+    }
+    if (affine) {
+      const float* __restrict__ af = affine + ((size_t)img * CIN + c4 * 4) * 3;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        al[j] = af[3 * j]; be[j] = af[3 * j + 1]; sl[j] = af[3 * j + 2];
+      }
+    }
+    float4 v[C::NIT];
+    unsigned okmask = 0;
+#pragma unroll
+    for (int i = 0; i < C::NIT; ++i) {
+      const int pos = tid / C::C4 + i * C::PSTEP;
+      const int row = pos / IXP, col = pos - row * IXP;
+      const int gy = oy0 - R + row, gx = ox0 - R + col;
+      const bool ok = pos < C::NPOS && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+      v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ok) {
+        v[i] = *reinterpret_cast<const float4*>(x + (((size_t)img * H + gy) * W + gx) * CIN + c4 * 4);
+        okmask |= 1u << i;
+      }
+    }
+    unsigned char* dst0 = lds + (c4 >> 1) * C::PLANE + (c4 & 1) * 8;
+#pragma unroll
+    for (int i = 0; i < C::NIT; ++i) {
+      const int pos = tid / C::C4 + i * C::PSTEP;
+      if (pos >= C::NPOS) break;
+      float4 t = v[i];
+      if (okmask & (1u << i)) {            // zero padding follows the normalisation: out-of-image texels stay zero
+        float a;
+        a = fmaf(t.x, al[0], be[0]); t.x = a > 0.f ? a : a * sl[0];
+        a = fmaf(t.y, al[1], be[1]); t.y = a > 0.f ? a : a * sl[1];
+        a = fmaf(t.z, al[2], be[2]); t.z = a > 0.f ? a : a * sl[2];
+        a = fmaf(t.w, al[3], be[3]); t.w = a > 0.f ? a : a * sl[3];
+      }
+      uint32_t h0, m0, l0, h1, m1, l1;
+      split2(t.x, t.y, h0, m0, l0);
+      split2(t.z, t.w, h1, m1, l1);
+      unsigned char* d = dst0 + pos * POSB;
+      *reinterpret_cast<uint2*>(d) = make_uint2(h0, h1);
+      *reinterpret_cast<uint2*>(d + 16) = make_uint2(m0, m1);
+      *reinterpret_cast<uint2*>(d + 32) = make_uint2(l0, l1);
+    }
+  }
+  __syncthreads();
+
+  f32x4 acc[NBR][NBLK][4];       // [branch][16-row block][column tile: (row 0 | 1 of the wave) x (x-run 0 | 1)]
+#pragma unroll
+  for (int b = 0; b < NBR; ++b)
+#pragma unroll
+    for (int mb = 0; mb < NBLK; ++mb)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[b][mb][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // B operand (data): lane (n, g) supplies the 8 channels of tap 4 t + g for pixel n of the column tile = one ds_read_b128 per term
+  const int a_base = ((wave * 2) * IXP + n) * POSB;
+  const uint4* __restrict__ wl = wsp + lane;
+  constexpr int KS[3] = {K0, K1, K2 > 0 ? K2 : 1};
+#pragma unroll 1
+  for (int rd = 0; rd < C::ROUNDS; ++rd) {
+    const uint4* __restrict__ wr = wl + (size_t)rd * C::NKS * NBLK * 3 * 64;
+    const unsigned char* __restrict__ lp = lds + rd * C::PLANE + a_base;
+    int ks0 = 0;
+#pragma unroll
+    for (int b = 0; b < NBR; ++b) {
+      const int k = KS[b], kk = k * k, rk = (k - 1) >> 1, nks = (kk + 3) >> 2;
+      const uint4* __restrict__ wb = wr + (size_t)ks0 * NBLK * 3 * 64;
+#pragma unroll 1
+      for (int t = 0; t < nks; ++t) {
+        int tap = 4 * t + g;
+        if (tap >= kk) tap = kk - 1;                    // padded tap: zero weights, any in-tile data
+        const int ky = tap / k, kx = tap - ky * k;
+        const unsigned char* ap = lp + ((ky + R - rk) * IXP + (kx + R - rk)) * POSB;
+        BV wv[NBLK][3];
+#pragma unroll
+        for (int mb = 0; mb < NBLK; ++mb) {
+          const uint4* p = wb + (size_t)((t * NBLK + mb) * 3) * 64;
+          wv[mb][0].u = p[0];
+          wv[mb][1].u = p[64];
+          wv[mb][2].u = p[128];
+        }
+        BV xv[4][3];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const unsigned char* a = ap + ((q >> 1) * IXP + (q & 1) * 16) * POSB;
+          xv[q][0].u = *reinterpret_cast<const uint4*>(a);
+          xv[q][1].u = *reinterpret_cast<const uint4*>(a + 16);
+          xv[q][2].u = *reinterpret_cast<const uint4*>(a + 32);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mb = 0; mb < NBLK; ++mb) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) SBF_MFMA(acc[b][mb][q], wv[mb][0], xv[q][2]);    // order 2^-16 terms first
+#pragma unroll
+          for (int q = 0; q < 4; ++q) SBF_MFMA(acc[b][mb][q], wv[mb][1], xv[q][1]);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) SBF_MFMA(acc[b][mb][q], wv[mb][2], xv[q][0]);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) SBF_MFMA(acc[b][mb][q], wv[mb][0], xv[q][1]);    // 2^-8
+#pragma unroll
+          for (int q = 0; q < 4; ++q) SBF_MFMA(acc[b][mb][q], wv[mb][1], xv[q][0]);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) SBF_MFMA(acc[b][mb][q], wv[mb][0], xv[q][0]);    // leading term
+        }
+      }
+      ks0 += nks;
+    }
+  }
+
+  // ---- epilogue.  Accumulator layout: lane (n, g) holds rows 16 mb + 4 g + 0..3 of pixel n of column tile q.  Rows < Cout are
+  // the branch responses, rows Cout .. Cout + 2 the curvature responses: they sit in the lanes of group GC of block MBC, which
+  // compute the blend weights of their pixel; the other three lanes of the pixel fetch them with one cross-lane read each. ----
+  constexpr int NCB = C::NCB;
+  const bool chan_lane = 4 * g < (CIN < 16 ? CIN : 16);       // this lane's four rows of a channel block are output channels
+  float bch[NBR][NCB][4], bcu[NBR][3];
+#pragma unroll
+  for (int b = 0; b < NBR; ++b) {
+#pragma unroll
+    for (int mb = 0; mb < NCB; ++mb)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bch[b][mb][j] = (bias && chan_lane) ? bias[b * C::CO3 + mb * 16 + 4 * g + j] : 0.f;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) bcu[b][j] = bias ? bias[b * C::CO3 + CIN + j] : 0.f;
+  }
+  double ds[NCB][4], dq[NCB][4];
+#pragma unroll
+  for (int mb = 0; mb < NCB; ++mb)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ds[mb][j] = dq[mb][j] = 0.0;
+
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int oy = oy0 + wave * 2 + (q >> 1), ox = ox0 + (q & 1) * 16 + n;
+    const bool inb = oy < H && ox < W;
+    float att[NBR][3], wts[NBR];
+#pragma unroll
+    for (int b = 0; b < NBR; ++b) {
+      const f32x4 a = acc[b][C::MBC][q];
+      att[b][0] = a.x + bcu[b][0];
+      att[b][1] = a.y + bcu[b][1];
+      att[b][2] = a.z + bcu[b][2];
+    }
+    const float nc = blend_from_att<NBR>(att, ox, oy, ep.ex[img], ep.ey[img], ep.w1, ep.b1, ep.w2, ep.temperature, wts);
+    if (g == C::GC && inb) ep.norm_curv[((size_t)img * H + oy) * W + ox] = nc;
+#pragma unroll
+    for (int b = 0; b < NBR; ++b) wts[b] = __shfl(wts[b], (C::GC << 4) | n);
+#pragma unroll
+    for (int mb = 0; mb < NCB; ++mb) {
+      float o[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float sacc = 0.f;
+#pragma unroll
+        for (int b = 0; b < NBR; ++b) {
+          const f32x4 a = acc[b][mb][q];
+          const float av = (j == 0 ? a.x : j == 1 ? a.y : j == 2 ? a.z : a.w) + bch[b][mb][j];
+          sacc = sacc + av * wts[b];
+        }
+        o[j] = sacc;
+      }
+      if (chan_lane && inb) {
+        *reinterpret_cast<float4*>(ep.out + (((size_t)img * H + oy) * W + ox) * CIN + mb * 16 + 4 * g) =
+            make_float4(o[0], o[1], o[2], o[3]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const double dv = (double)o[j];
+          ds[mb][j] += dv;
+          dq[mb][j] += dv * dv;
+        }
+      }
+    }
+  }
+  // InstanceNorm records of the output (fp64 sums of the rounded fp32 values = what a statistics pass would read back): the 16
+  // pixels of a lane row by DPP, the four waves through LDS in a fixed order, one record per (tile, channel): bit-reproducible
+  __syncthreads();                                            // every wave is done with the staged tile
+  double* red = reinterpret_cast<double*>(lds);               // [wave][CIN][2]
+#pragma unroll
+  for (int mb = 0; mb < NCB; ++mb)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const double s = row16_sum_f64(ds[mb][j]), s2 = row16_sum_f64(dq[mb][j]);
+      if (n == 0 && chan_lane) {
+        red[(wave * CIN + mb * 16 + 4 * g + j) * 2] = s;
+        red[(wave * CIN + mb * 16 + 4 * g + j) * 2 + 1] = s2;
+      }
+    }
+  __syncthreads();
+  if (tid < CIN) {
+    const int parts = tiles_x * tiles_y;
+    double* rec = ep.partial + (((size_t)img * parts + (size_t)(ty_i * tiles_x + tx_i)) * CIN + tid) * 2;
+    rec[0] = (red[tid * 2] + red[(CIN + tid) * 2]) + (red[(2 * CIN + tid) * 2] + red[(3 * CIN + tid) * 2]);
+    rec[1] = (red[tid * 2 + 1] + red[(CIN + tid) * 2 + 1]) + (red[(2 * CIN + tid) * 2 + 1] + red[(3 * CIN + tid) * 2 + 1]);
+  }
+}
+
+template <int CIN, int K0, int K1, int K2>
+int launch_dynconv_cl(const float* x, const float* aff, const void* wsp, const float* bias, const DynEpi& ep, int N, int H, int W,
+                      hipStream_t st) {
+  using C = DCfg<CIN, K0, K1, K2>;
+  const int tx = cds_ceil_div(W, TX), ty = cds_ceil_div(H, TY);
+  auto kern = dynconv_cl_kernel<CIN, K0, K1, K2>;
+  if (C::LDSB > 64 * 1024) {
+    static std::atomic<unsigned long long> lds_ok{0};   // per instantiation
+    if (int e = cds_allow_lds(reinterpret_cast<const void*>(kern), C::LDSB, lds_ok)) return e;
+  }
+  hipLaunchKernelGGL(kern, dim3(tx * ty * N), dim3(256), (size_t)C::LDSB, st, x, aff, reinterpret_cast<const uint4*>(wsp), bias, ep, N,
+                     H, W, tx, ty);
+  return cds_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// DynamicConv epilogue over a PLANAR branch tensor [K][slots][Cout + 3][H][W] (conv00: the VALU branch kernels of conv2d.hip),
+// channels-last output [N][H][W][8] + InstanceNorm records; the first n_shared images share branch slot 0.
+// ---------------------------------------------------------------------------------------------------------------------------
+constexpr int BCL_PXT = 4;
+template <int K>
+__global__ __launch_bounds__(256) void dynconv_blend_cl_kernel(const float* __restrict__ branch, const float* __restrict__ w1,
+                                                               const float* __restrict__ b1, const float* __restrict__ w2,
+                                                               EpiBatch epi, float temperature, float* __restrict__ out,
+                                                               float* __restrict__ norm_curv, double* __restrict__ partial, int N,
+                                                               int H, int W, int n_shared) {
+  constexpr int PXT = BCL_PXT, Cout = 8;
+  const int hw = H * W;
+  const int n = blockIdx.y;
+  const int slot = n < n_shared ? 0 : n - n_shared + 1;
+  const int nslots = N - n_shared + 1;
+  branch += (size_t)slot * (Cout + 3) * hw;
+  out += (size_t)n * Cout * hw;
+  const size_t bstride = (size_t)nslots * (Cout + 3) * hw;
+  const int base = blockIdx.x * (256 * PXT) + threadIdx.x;
+  double ds[Cout], dq[Cout];
+#pragma unroll
+  for (int c = 0; c < Cout; ++c) ds[c] = dq[c] = 0.0;
+#pragma unroll
+  for (int j = 0; j < PXT; ++j) {
+    const int p = base + 256 * j;
+    if (p >= hw) continue;
+    float lg[K];
+    norm_curv[(size_t)n * hw + p] = blend_weights<K>(branch, bstride, Cout, hw, p, W, epi.x[n], epi.y[n], w1, b1, w2, temperature, lg);
+    float o[Cout];
+#pragma unroll
+    for (int c = 0; c < Cout; ++c) {
+      float s = 0.f;
+#pragma unroll
+      for (int k = 0; k < K; ++k) s = s + branch[k * bstride + (size_t)c * hw + p] * lg[k];
+      o[c] = s;
+      const double v = (double)s;
+      ds[c] += v;
+      dq[c] += v * v;
+    }
+    float4* o4 = reinterpret_cast<float4*>(out + (size_t)p * Cout);
+    o4[0] = make_float4(o[0], o[1], o[2], o[3]);
+    o4[1] = make_float4(o[4], o[5], o[6], o[7]);
+  }
+  const int wave = threadIdx.x >> 6;
+  const int parts = 4 * gridDim.x;
+  double* rec = partial + (((size_t)n * parts + blockIdx.x * 4 + wave) * Cout) * 2;
+#pragma unroll
+  for (int c = 0; c < Cout; ++c) {
+    const double s = wave_sum_f64(ds[c]), s2 = wave_sum_f64(dq[c]);
+    if ((threadIdx.x & 63) == 0) {
+      rec[2 * c] = s;
+      rec[2 * c + 1] = s2;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// 3x3, stride 2, pad 1 convolution CIN -> COUT (downsample1 8 -> 16, downsample2 16 -> 32; module.py:236,240), channels-last in
+// and out, normalise-on-load.  One thread per output pixel: nine texel loads straight from global memory (neighbouring lanes
+// share 1/3 of them through L1), COUT accumulators, wave-uniform weights [tap][cin][cout] through the scalar cache.
+// ---------------------------------------------------------------------------------------------------------------------------
+template <int CIN, int COUT>
+__global__ __launch_bounds__(256) void conv2d_k3s2_cl_kernel(const float* __restrict__ x, const float* __restrict__ affine,
+                                                             const float* __restrict__ wpk, float* __restrict__ out, int H, int W,
+                                                             int Ho, int Wo) {
+  const int n = blockIdx.y;
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= Ho * Wo) return;
+  const int oy = p / Wo, ox = p - oy * Wo;
+  const float* __restrict__ aff = affine ? affine + (size_t)n * CIN * 3 : nullptr;
+  const float* __restrict__ xn = x + (size_t)n * H * W * CIN;
+  float acc[COUT];
+#pragma unroll
+  for (int c = 0; c < COUT; ++c) acc[c] = 0.f;
+#pragma unroll 1
+  for (int tap = 0; tap < 9; ++tap) {
+    const int ky = tap / 3, kx = tap - ky * 3;
+    const int gy = 2 * oy - 1 + ky, gx = 2 * ox - 1 + kx;
+    const bool ok = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+    const float4* __restrict__ src = reinterpret_cast<const float4*>(xn + ((size_t)(ok ? gy : 0) * W + (ok ? gx : 0)) * CIN);
+    const float* __restrict__ wt = wpk + tap * CIN * COUT;
+#pragma unroll 1
+    for (int c4 = 0; c4 < CIN / 4; ++c4) {                    // runtime loop: 4 x COUT wave-uniform weights in flight, no SGPR spills
+      const float4 v4 = src[c4];
+      float v[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int ci = c4 * 4 + j;
+        float t = v[j];
+        if (aff) {
+          t = t * aff[3 * ci] + aff[3 * ci + 1];
+          t = t > 0.f ? t : t * aff[3 * ci + 2];
+        }
+        t = ok ? t : 0.f;                                     // zero padding follows the normalisation
+        const float* __restrict__ wc = wt + ci * COUT;
+#pragma unroll
+        for (int c = 0; c < COUT; ++c) acc[c] = fmaf(t, wc[c], acc[c]);
+      }
+    }
+  }
+  float4* o4 = reinterpret_cast<float4*>(out + ((size_t)n * Ho * Wo + p) * COUT);
+#pragma unroll
+  for (int c = 0; c < COUT; c += 4) o4[c >> 2] = make_float4(acc[c], acc[c + 1], acc[c + 2], acc[c + 3]);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// FPN lateral (module.py:253-254,260-261): 1x1 convolution over cat(nearest2x(coarse), skip), channels-last, neither tensor
+// materialised; each source has its own optional normalise-on-load table.  Thread = PXT pixels, 256 apart (consecutive lanes read
+// consecutive texels); COUT accumulators; weights [Ca + Cb][COUT] through the scalar cache.
+// InstanceNorm records of the output: fp64 sums per thread over its PXT pixels, one wave reduction per channel.
+// ---------------------------------------------------------------------------------------------------------------------------
+constexpr int FPN_PXT = 4;
+template <int CA, int CB, int COUT>
+__global__ __launch_bounds__(256) void fpn_lateral_cl_kernel(const float* __restrict__ xa, const float* __restrict__ affa,
+                                                             const float* __restrict__ xb, const float* __restrict__ affb,
+                                                             const float* __restrict__ wpk, float* __restrict__ out,
+                                                             double* __restrict__ partial, int H, int W) {
+  const int n = blockIdx.y;
+  const int hw = H * W, Hc = H >> 1, Wc = W >> 1;
+  const float* __restrict__ fa = affa ? affa + (size_t)n * CA * 3 : nullptr;
+  const float* __restrict__ fb = affb ? affb + (size_t)n * CB * 3 : nullptr;
+  xa += (size_t)n * Hc * Wc * CA;
+  xb += (size_t)n * hw * CB;
+  out += (size_t)n * hw * COUT;
+  double ds[COUT], dq[COUT];
+#pragma unroll
+  for (int c = 0; c < COUT; ++c) ds[c] = dq[c] = 0.0;
+  const int base = blockIdx.x * (256 * FPN_PXT) + threadIdx.x;
+#pragma unroll 1
+  for (int jp = 0; jp < FPN_PXT; ++jp) {
+    const int p = base + 256 * jp;
+    if (p >= hw) break;
+    const int oy = p / W, ox = p - oy * W;
+    float acc[COUT];
+#pragma unroll
+    for (int c = 0; c < COUT; ++c) acc[c] = 0.f;
+    int zero = 0;
+    asm volatile("" : "+s"(zero));                             // opaque 0: the weights are re-read per pixel through the scalar cache
+    const float* __restrict__ wp = wpk + zero;                 // instead of being hoisted out of the loop into 768 (spilled) SGPRs
+    const float4* __restrict__ sa = reinterpret_cast<const float4*>(xa + ((size_t)(oy >> 1) * Wc + (ox >> 1)) * CA);
+#pragma unroll 1
+    for (int c4 = 0; c4 < CA / 4; ++c4) {
+      const float4 v4 = sa[c4];
+      float v[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int ci = c4 * 4 + j;
+        float t = v[j];
+        if (fa) {
+          t = t * fa[3 * ci] + fa[3 * ci + 1];
+          t = t > 0.f ? t : t * fa[3 * ci + 2];
+        }
+        const float* __restrict__ wc = wp + ci * COUT;
+#pragma unroll
+        for (int c = 0; c < COUT; ++c) acc[c] = fmaf(t, wc[c], acc[c]);
+      }
+    }
+    const float4* __restrict__ sb = reinterpret_cast<const float4*>(xb + (size_t)p * CB);
+#pragma unroll 1
+    for (int c4 = 0; c4 < CB / 4; ++c4) {
+      const float4 v4 = sb[c4];
+      float v[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int ci = c4 * 4 + j;
+        float t = v[j];
+        if (fb) {
+          t = t * fb[3 * ci] + fb[3 * ci + 1];
+          t = t > 0.f ? t : t * fb[3 * ci + 2];
+        }
+        const float* __restrict__ wc = wp + (CA + ci) * COUT;
+#pragma unroll
+        for (int c = 0; c < COUT; ++c) acc[c] = fmaf(t, wc[c], acc[c]);
+      }
+    }
+    float4* o4 = reinterpret_cast<float4*>(out + (size_t)p * COUT);
+#pragma unroll
+    for (int c = 0; c < COUT; c += 4) o4[c >> 2] = make_float4(acc[c], acc[c + 1], acc[c + 2], acc[c + 3]);
+    if (partial) {
+#pragma unroll
+      for (int c = 0; c < COUT; ++c) {
+        const double dv = (double)acc[c];
+        ds[c] += dv;
+        dq[c] += dv * dv;
+      }
+    }
+  }
+  if (partial) {
+    const int wave = threadIdx.x >> 6;
+    double* rec = partial + (((size_t)n * (4 * gridDim.x) + blockIdx.x * 4 + wave) * COUT) * 2;
+#pragma unroll
+    for (int c = 0; c < COUT; ++c) {
+      const double s = wave_sum_f64(ds[c]), s2 = wave_sum_f64(dq[c]);
+      if ((threadIdx.x & 63) == 0) {
+        rec[2 * c] = s;
+        rec[2 * c + 1] = s2;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// InstanceNorm records of a channels-last tensor [N][hw][C]: thread = float4 chunk of the image's contiguous bytes, so its channel
+// quad is fixed (grid stride % (C / 4) == 0): 8 fp64 sums in registers; lanes with the same quad are combined by cross-lane adds,
+// waves through LDS; one record per (workgroup, channel).  partial [N][gridDim.x][C][2].
+// ---------------------------------------------------------------------------------------------------------------------------
+template <int CT>
+__global__ __launch_bounds__(256) void instnorm_stats_cl_kernel(const float* __restrict__ x, double* __restrict__ partial, int hw) {
+  constexpr int C4 = CT / 4;
+  __shared__ double red[4][CT][2];
+  const int n = blockIdx.y;
+  const float4* __restrict__ x4 = reinterpret_cast<const float4*>(x + (size_t)n * hw * CT);
+  const size_t total = (size_t)hw * C4;
+  double s[4] = {0.0, 0.0, 0.0, 0.0}, q[4] = {0.0, 0.0, 0.0, 0.0};
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const float4 v = x4[i];
+    const double a = v.x, b = v.y, c = v.z, d = v.w;
+    s[0] += a; q[0] += a * a;
+    s[1] += b; q[1] += b * b;
+    s[2] += c; q[2] += c * c;
+    s[3] += d; q[3] += d * d;
+  }
+  // lanes l and l' hold the same channel quad iff l % C4 == l' % C4: fold the 64 lanes down to C4 (xor offsets 32 .. C4)
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+#pragma unroll
+    for (int o = 32; o >= C4; o >>= 1) {
+      s[j] += __shfl_xor(s[j], o);
+      q[j] += __shfl_xor(q[j], o);
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane < C4) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      red[wave][lane * 4 + j][0] = s[j];
+      red[wave][lane * 4 + j][1] = q[j];
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < CT) {
+    const int c = threadIdx.x;
+    double* rec = partial + (((size_t)n * gridDim.x + blockIdx.x) * CT + c) * 2;
+    rec[0] = (red[0][c][0] + red[1][c][0]) + (red[2][c][0] + red[3][c][0]);
+    rec[1] = (red[0][c][1] + red[1][c][1]) + (red[2][c][1] + red[3][c][1]);
+  }
+}
+
+// InstanceNorm + activation of a channels-last tensor for given statistics: out_cl [N - cl_from][hw][CT] for the images
+// n >= cl_from (may be NULL) and out_chw [n_chw][CT][hw] for the first n_chw images (the reference-view feature maps K1 / K3 read per
+// pixel and channel plane).
+template <int CT>
+__global__ __launch_bounds__(256) void instnorm_apply_cl_kernel(const float* __restrict__ x, const double* __restrict__ stats,
+                                                                float* __restrict__ out_cl, float* __restrict__ out_chw, int hw,
+                                                                int act, int n_chw, int cl_from) {
+  __shared__ float ab[2][CT];
+  const int n = blockIdx.y;
+  stats += (size_t)n * 2 * CT;
+  if ((int)threadIdx.x < CT) {
+    const int c = threadIdx.x;
+    const double mean = stats[2 * c] / hw;
+    double var = stats[2 * c + 1] / hw - mean * mean;
+    var = var < 0.0 ? 0.0 : var;
+    const float invstd = (float)(1.0 / sqrt(var + 1e-5));
+    ab[0][c] = invstd;
+    ab[1][c] = -(float)mean * invstd;
+  }
+  __syncthreads();
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  const bool want_cl = out_cl && n >= cl_from;
+  if (p >= hw || (!want_cl && n >= n_chw)) return;
+  const float4* __restrict__ src = reinterpret_cast<const float4*>(x + ((size_t)n * hw + p) * CT);
+  float v[CT];
+#pragma unroll
+  for (int c4 = 0; c4 < CT / 4; ++c4) {
+    const float4 t = src[c4];
+    v[4 * c4] = t.x; v[4 * c4 + 1] = t.y; v[4 * c4 + 2] = t.z; v[4 * c4 + 3] = t.w;
+  }
+#pragma unroll
+  for (int c = 0; c < CT; ++c) v[c] = cds_apply_act(v[c] * ab[0][c] + ab[1][c], act);
+  if (want_cl) {
+    float4* o4 = reinterpret_cast<float4*>(out_cl + ((size_t)(n - cl_from) * hw + p) * CT);
+#pragma unroll
+    for (int c = 0; c < CT; c += 4) o4[c >> 2] = make_float4(v[c], v[c + 1], v[c + 2], v[c + 3]);
+  }
+  if (n < n_chw) {
+    float* o = out_chw + (size_t)n * CT * hw + p;
+#pragma unroll
+    for (int c = 0; c < CT; ++c) o[(size_t)c * hw] = v[c];
+  }
+}
+
+}  // namespace
+
+// Records per image that cds_dynconv_cl_f32 leaves for cds_instnorm_reduce_f32: one per 32 x 8 tile.
+extern "C" int cds_dynconv_cl_parts(int H, int W) { return cds_ceil_div(W, TX) * cds_ceil_div(H, TY); }
+
+// One DynamicConv (dynamic_conv.py:97-122) on channels-last activations in ONE kernel.  x [N][H][W][C] (+ in_affine [N][C][3] or
+// NULL), weight_split from ops.split_pack_dynconv (the packing of cds_dynconv_branches_sbf_f32), bias [nb][C + 3] or NULL,
+// w1 [4][nb], b1 [4], w2 [nb][4] the attention MLP with its BatchNorm folded in, epipoles_host [N][2] (pixels at this resolution)
+// -> out [N][H][W][C] (before its InstanceNorm), norm_curv [N][H][W], partial [N][parts][C][2] doubles with
+// parts = cds_dynconv_cl_parts(H, W) (reduce with cds_instnorm_reduce_f32).  (C, ksizes) in {(8, 3-5-7), (8, 1-3), (16, 3-5),
+// (16, 1-3), (32, 1-3)}: the DynamicConv layers of FeatureNet with Cin == Cout; N <= CDS_MAX_IMAGES; CDS_EINVAL otherwise.
+extern "C" int cds_dynconv_cl_f32(const float* x, const float* in_affine, const void* weight_split, const float* bias,
+                                  const float* w1, const float* b1, const float* w2, const float* epipoles_host, float temperature,
+                                  float* out, float* norm_curv, double* partial, int N, int C, int H, int W, const int* ksizes, int nb,
+                                  void* stream) {
+  if (!x || !weight_split || !w1 || !b1 || !w2 || !epipoles_host || !out || !norm_curv || !partial || !ksizes || N < 1 ||
+      N > CDS_MAX_IMAGES || H < 1 || W < 1 || nb < 2 || nb > 3)
+    return CDS_EINVAL;
+  DynEpi ep;
+  ep.w1 = w1; ep.b1 = b1; ep.w2 = w2; ep.out = out; ep.norm_curv = norm_curv; ep.partial = partial; ep.temperature = temperature;
+  for (int n = 0; n < CDS_MAX_IMAGES; ++n) {
+    ep.ex[n] = n < N ? epipoles_host[2 * n] : 0.f;
+    ep.ey[n] = n < N ? epipoles_host[2 * n + 1] : 0.f;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const int k0 = ksizes[0], k1 = ksizes[1], k2 = nb == 3 ? ksizes[2] : 0;
+  if (C == 8 && k0 == 3 && k1 == 5 && k2 == 7) return launch_dynconv_cl<8, 3, 5, 7>(x, in_affine, weight_split, bias, ep, N, H, W, st);
+  if (C == 8 && k0 == 1 && k1 == 3 && k2 == 0) return launch_dynconv_cl<8, 1, 3, 0>(x, in_affine, weight_split, bias, ep, N, H, W, st);
+  if (C == 16 && k0 == 3 && k1 == 5 && k2 == 0) return launch_dynconv_cl<16, 3, 5, 0>(x, in_affine, weight_split, bias, ep, N, H, W, st);
+  if (C == 16 && k0 == 1 && k1 == 3 && k2 == 0) return launch_dynconv_cl<16, 1, 3, 0>(x, in_affine, weight_split, bias, ep, N, H, W, st);
+  if (C == 32 && k0 == 1 && k1 == 3 && k2 == 0) return launch_dynconv_cl<32, 1, 3, 0>(x, in_affine, weight_split, bias, ep, N, H, W, st);
+  return CDS_EINVAL;
+}
+
+extern "C" int cds_blend_cl_parts(int H, int W) { return 4 * cds_ceil_div(H * W, 256 * BCL_PXT); }
+
+// The DynamicConv epilogue of cds_dynconv_blend_stats_f32 with a channels-last result: branches [K][N - n_shared + 1][8 + 3][H][W]
+// planar (the first n_shared images share slot 0) -> out [N][H][W][8], norm_curv [N][H][W], partial [N][cds_blend_cl_parts][8][2].
+extern "C" int cds_dynconv_blend_cl_f32(const float* branches, const float* w1, const float* b1, const float* w2,
+                                        const float* epipoles_host, float temperature, float* out, float* norm_curv, double* partial,
+                                        int N, int K, int Cout, int H, int W, int n_shared, void* stream) {
+  if (!branches || !w1 || !b1 || !w2 || !epipoles_host || !out || !norm_curv || !partial || N < 1 || N > CDS_MAX_IMAGES || K != 3 ||
+      Cout != 8 || H < 1 || W < 1 || n_shared < 1 || n_shared > N)
+    return CDS_EINVAL;
+  EpiBatch epi;
+  for (int n = 0; n < CDS_MAX_IMAGES; ++n) {
+    epi.x[n] = n < N ? epipoles_host[2 * n] : 0.f;
+    epi.y[n] = n < N ? epipoles_host[2 * n + 1] : 0.f;
+  }
+  const dim3 grid(cds_ceil_div(H * W, 256 * BCL_PXT), N);
+  hipLaunchKernelGGL(dynconv_blend_cl_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, branches, w1, b1, w2, epi, temperature, out,
+                     norm_curv, partial, N, H, W, n_shared);
+  return cds_launch_status();
+}
+
+// 3x3 stride-2 pad-1 convolution on channels-last activations (downsample1 / downsample2): x [N][H][W][Cin] (+ in_affine) ->
+// out [N][Ho][Wo][Cout], Ho = (H - 1) / 2 + 1; weight [9][Cin][Cout] (tap = ky * 3 + kx; cout fastest), no bias.
+// (Cin, Cout) in {(8, 16), (16, 32)}.
+extern "C" int cds_conv2d_k3s2_cl_f32(const float* x, const float* in_affine, const float* weight, float* out, int N, int Cin,
+                                      int Cout, int H, int W, void* stream) {
+  if (!x || !weight || !out || N < 1 || H < 1 || W < 1) return CDS_EINVAL;
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  const dim3 grid(cds_ceil_div(Ho * Wo, 256), N);
+  hipStream_t st = (hipStream_t)stream;
+  if (Cin == 8 && Cout == 16)
+    hipLaunchKernelGGL((conv2d_k3s2_cl_kernel<8, 16>), grid, dim3(256), 0, st, x, in_affine, weight, out, H, W, Ho, Wo);
+  else if (Cin == 16 && Cout == 32)
+    hipLaunchKernelGGL((conv2d_k3s2_cl_kernel<16, 32>), grid, dim3(256), 0, st, x, in_affine, weight, out, H, W, Ho, Wo);
+  else
+    return CDS_EINVAL;
+  return cds_launch_status();
+}
+
+extern "C" int cds_fpn_cl_parts(int H, int W) { return 4 * cds_ceil_div(H * W, 256 * FPN_PXT); }
+
+// FPN lateral on channels-last activations: out [N][H][W][Cout] = 1x1 conv of cat(nearest2x(coarse [N][H/2][W/2][Ca]), skip
+// [N][H][W][Cb]); weight [Ca + Cb][Cout] (coarse channels first); affine tables [N][Ca][3] / [N][Cb][3] or NULL; partial NULL or
+// [N][cds_fpn_cl_parts(H, W)][Cout][2] doubles (InstanceNorm records of `out`).  (Ca, Cb, Cout) in {(32, 16, 16), (16, 8, 8)}.
+extern "C" int cds_conv2d_fpn_cl_f32(const float* coarse, const float* coarse_affine, const float* skip, const float* skip_affine,
+                                     const float* weight, float* out, double* partial, int N, int Ca, int Cb, int Cout, int H, int W,
+                                     void* stream) {
+  if (!coarse || !skip || !weight || !out || N < 1 || H < 2 || W < 2 || (H & 1) || (W & 1)) return CDS_EINVAL;
+  const dim3 grid(cds_ceil_div(H * W, 256 * FPN_PXT), N);
+  hipStream_t st = (hipStream_t)stream;
+  if (Ca == 32 && Cb == 16 && Cout == 16)
+    hipLaunchKernelGGL((fpn_lateral_cl_kernel<32, 16, 16>), grid, dim3(256), 0, st, coarse, coarse_affine, skip, skip_affine, weight, out,
+                       partial, H, W);
+  else if (Ca == 16 && Cb == 8 && Cout == 8)
+    hipLaunchKernelGGL((fpn_lateral_cl_kernel<16, 8, 8>), grid, dim3(256), 0, st, coarse, coarse_affine, skip, skip_affine, weight, out,
+                       partial, H, W);
+  else
+    return CDS_EINVAL;
+  return cds_launch_status();
+}
+
+extern "C" int cds_instnorm_stats_cl_parts(int H, int W) {
+  const int wg = cds_ceil_div(H * W, 256 * 8);
+  return wg < 1 ? 1 : (wg > 512 ? 512 : wg);
+}
+
+// InstanceNorm records of x [N][H][W][C] (C in {8, 16, 32}): partial [N][cds_instnorm_stats_cl_parts(H, W)][C][2] doubles; reduce
+// with cds_instnorm_reduce_f32.
+extern "C" int cds_instnorm_stats_cl_f32(const float* x, double* partial, int N, int C, int H, int W, void* stream) {
+  if (!x || !partial || N < 1 || H < 1 || W < 1) return CDS_EINVAL;
+  const dim3 grid(cds_instnorm_stats_cl_parts(H, W), N);
+  hipStream_t st = (hipStream_t)stream;
+  if (C == 8) hipLaunchKernelGGL(instnorm_stats_cl_kernel<8>, grid, dim3(256), 0, st, x, partial, H * W);
+  else if (C == 16) hipLaunchKernelGGL(instnorm_stats_cl_kernel<16>, grid, dim3(256), 0, st, x, partial, H * W);
+  else if (C == 32) hipLaunchKernelGGL(instnorm_stats_cl_kernel<32>, grid, dim3(256), 0, st, x, partial, H * W);
+  else return CDS_EINVAL;
+  return cds_launch_status();
+}
+
+// InstanceNorm + activation for given statistics [N][C][2] doubles (sum, sum of squares) on x [N][H][W][C]: the images n >= cl_from
+// channels-last into out_cl [N - cl_from][H][W][C] (or NULL), the first n_chw images planar into out_chw [n_chw][C][H][W] (or NULL
+// with n_chw = 0).  C in {8, 16, 32}.
+extern "C" int cds_instnorm_apply_cl_f32(const float* x, const double* stats, float* out_cl, float* out_chw, int N, int C, int H, int W,
+                                         int act, int n_chw, int cl_from, void* stream) {
+  if (!x || !stats || N < 1 || H < 1 || W < 1 || n_chw < 0 || n_chw > N || (n_chw > 0 && !out_chw) || (!out_cl && n_chw < 1) ||
+      cl_from < 0 || (out_cl && cl_from >= N))
+    return CDS_EINVAL;
+  const dim3 grid(cds_ceil_div(H * W, 256), N);
+  hipStream_t st = (hipStream_t)stream;
+  if (C == 8) hipLaunchKernelGGL(instnorm_apply_cl_kernel<8>, grid, dim3(256), 0, st, x, stats, out_cl, out_chw, H * W, act, n_chw, cl_from);
+  else if (C == 16) hipLaunchKernelGGL(instnorm_apply_cl_kernel<16>, grid, dim3(256), 0, st, x, stats, out_cl, out_chw, H * W, act, n_chw, cl_from);
+  else if (C == 32) hipLaunchKernelGGL(instnorm_apply_cl_kernel<32>, grid, dim3(256), 0, st, x, stats, out_cl, out_chw, H * W, act, n_chw, cl_from);
+  else return CDS_EINVAL;
+  return cds_launch_status();
+}

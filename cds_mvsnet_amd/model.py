@@ -33,6 +33,8 @@ USE_FUSED_BLEND = os.environ.get("CDS_FUSED_BLEND", "1") != "0"   # A/B knob: 0 
 # stage 1 on a side stream next to FeatureNet's finer levels (CDS_OVERLAP_STAGE1=0: one stream): 1600x1184 19.04 -> 18.72 ms, 640x512 4.67 -> 4.48
 OVERLAP_STAGE1 = os.environ.get("CDS_OVERLAP_STAGE1", "1") != "0"
 OVERLAP_STAGE2 = os.environ.get("CDS_OVERLAP_STAGE2", "0") == "1"   # A/B knob: stage 2 as well (next to the full-resolution FPN level)
+# FeatureNet on channels-last activations (csrc/feat_cl.hip, round 5); CDS_FEAT_CL=0: the planar kernels of rounds 1-4
+USE_FEAT_CL = os.environ.get("CDS_FEAT_CL", "1") != "0"
 _SIDE_STREAMS: Dict[int, "torch.cuda.Stream"] = {}
 
 
@@ -456,6 +458,13 @@ class _FeatureRunner:
             dyn(name, getattr(net, name))
         for name in ("downsample1", "downsample2", "inner1", "inner2"):
             out[f"{name}.w"] = _pack2d(getattr(net, name).conv.weight.detach())
+        # channels-last kernels (feat_cl.hip): [tap][cin][cout] for the stride-2 units, [cin][cout] for the FPN laterals
+        for name in ("downsample1", "downsample2"):
+            w = getattr(net, name).conv.weight.detach()
+            out[f"{name}.w9"] = w.permute(2, 3, 1, 0).reshape(9, w.shape[1], w.shape[0]).contiguous()
+        for name in ("inner1", "inner2"):
+            w = getattr(net, name).conv.weight.detach()
+            out[f"{name}.wt"] = w.reshape(w.shape[0], w.shape[1]).t().contiguous()
         return out
 
     # A layer output travels as (raw, affine): the un-normalised convolution result plus the [N,C,3] table
@@ -529,6 +538,8 @@ class _FeatureRunner:
         e0 = epipoles.float().contiguous()
         e1 = (e0 / 2).contiguous()
         e2 = (e0 / 4).contiguous()
+        if USE_FEAT_CL and net.conv00.conv.out_c == 8 and all(f"{nm}.ws" in p for nm in self._CL_LAYERS):
+            return self._call_cl(p, imgs, e0, e1, e2, T, n_chw, n_shared, on_stage1)
         # conv00 sees the raw images: with n_shared copies of the reference image its branch convolutions (3x3, 7x7,
         # 11x11) run once for all of them; from conv01 on the inputs differ (the blend depends on the epipole)
         c00, a00, n00 = self._dyn_unit(p, "conv00", imgs, e0, T, n_shared)
@@ -558,6 +569,64 @@ class _FeatureRunner:
         x, ax = self._lateral_unit(p, "inner2", o2n, None, c01, a01)      # o2n is materialised (tanh features)
         o3, n02, s3, _ = self._dynamic(p, "out3", net.out3, x, e0, T, aff=ax)
         out["stage3"] = self._final(o3, s3, n_chw) + ops.curvature_stats(n00, n01, n02)
+        return out
+
+
+    _CL_LAYERS = ("conv01", "conv10", "conv11", "conv20", "conv21", "out1", "out2", "out3")
+
+    def _call_cl(self, p, imgs: Tensor, e0: Tensor, e1: Tensor, e2: Tensor, T: float, n_chw: int, n_shared: int, on_stage1):
+        """The same network on CHANNELS-LAST activations [N,h,w,C] (csrc/feat_cl.hip): staged tile rows are contiguous runs, the
+        DynamicConv kernel stores 16-byte channel quads, the stage outputs leave channels-last for the source views (what K1 / K3
+        gather) and planar for the reference views in the same pass - no transposition kernels."""
+        net = self.net
+        N, _, H, W = imgs.shape
+
+        def dyn(name: str, dc: DynamicConv, x: Tensor, epi: Tensor, aff: Optional[Tensor]):
+            return ops.dynconv_cl(x, p[f"{name}.ws"], p.get(f"{name}.bs"), dc.size_kernels, p[f"{name}.m1"], p[f"{name}.mb"],
+                                  p[f"{name}.m2"], epi, T, 0.1, in_affine=aff)
+
+        def down(name: str, x: Tensor, aff: Tensor):
+            y = ops.conv2d_k3s2_cl(x, p[f"{name}.w9"], getattr(net, name).conv.out_channels, aff)
+            return y, ops.instnorm_stats_cl(y, 0.1)[1]
+
+        # conv00 (3 input channels, 11 x 11): VALU branch kernels on the planar images, once for the n_shared reference copies;
+        # its blend writes channels-last
+        dc = net.conv00.conv
+        xs = imgs[n_shared - 1:] if n_shared > 1 else imgs
+        branches = torch.empty((len(dc.size_kernels), xs.shape[0], dc.out_c + 3, H, W), dtype=torch.float32, device=imgs.device)
+        for i, k in enumerate(dc.size_kernels):
+            ops.conv2d(xs, p[f"conv00.w{i}"], p.get(f"conv00.b{i}"), dc.out_c + 3, k, 1, (k - 1) // 2, ACT_NONE, out=branches[i])
+        c00, n00, _, a00 = ops.dynconv_blend_cl(branches, p["conv00.m1"], p["conv00.mb"], p["conv00.m2"], e0, T, n_shared, 0.1)
+        del branches
+        c01, n01, _, a01 = dyn("conv01", net.conv01.conv, c00, e0, a00)
+        del c00
+        d0, ad0 = down("downsample1", c01, a01)
+        c10, n10, _, a10 = dyn("conv10", net.conv10.conv, d0, e1, ad0)
+        c11, n11, _, a11 = dyn("conv11", net.conv11.conv, c10, e1, a10)
+        del d0, c10
+        d1, ad1 = down("downsample2", c11, a11)
+        c20, n20, _, a20 = dyn("conv20", net.conv20.conv, d1, e2, ad1)
+        c21, n21, _, a21 = dyn("conv21", net.conv21.conv, c20, e2, a20)
+        del d1, c20
+
+        out = {}
+        o1, n22, s1, _ = dyn("out1", net.out1, c21, e2, a21)
+        hwc, chw = ops.instnorm_apply_cl(o1, s1, ACT_TANH, n_chw, cl_from=n_chw)
+        out["stage1"] = (chw, hwc) + ops.curvature_stats(n20, n21, n22)
+        if on_stage1 is not None:
+            on_stage1("stage1", out["stage1"])
+
+        x, ax = ops.conv2d_fpn_cl(c21, c11, p["inner1.wt"], net.inner1.conv.out_channels, a21, a11, 0.1)
+        o2, n12, s2, _ = dyn("out2", net.out2, x, e1, ax)
+        o2n, chw = ops.instnorm_apply_cl(o2, s2, ACT_TANH, n_chw, cl_from=0)       # all images channels-last: inner2 reads them
+        out["stage2"] = (chw, o2n[n_chw:] if n_chw < N else None) + ops.curvature_stats(n10, n11, n12)
+        if on_stage1 is not None:
+            on_stage1("stage2", out["stage2"])
+
+        x, ax = ops.conv2d_fpn_cl(o2n, c01, p["inner2.wt"], net.inner2.conv.out_channels, None, a01, 0.1)
+        o3, n02, s3, _ = dyn("out3", net.out3, x, e0, ax)
+        hwc, chw = ops.instnorm_apply_cl(o3, s3, ACT_TANH, n_chw, cl_from=n_chw)
+        out["stage3"] = (chw, hwc) + ops.curvature_stats(n00, n01, n02)
         return out
 
 

@@ -871,6 +871,143 @@ def instnorm_act(x: Tensor, act: int, out_hwc: bool = False) -> Tensor:
     return out
 
 
+# ------------------------------------------------------------------------------------------------
+# FeatureNet on channels-last activations (csrc/feat_cl.hip): x_cl [N,H,W,C]
+# ------------------------------------------------------------------------------------------------
+def _reduce_records(partial: Tensor, N: int, C: int, H: int, W: int, slope: float):
+    """partial [N,parts,C,2] float64 -> (stats [N,C,2] float64, affine [N,C,3]) in a fixed summation order."""
+    stats = torch.empty((N, C, 2), dtype=torch.float64, device=partial.device)
+    affine = torch.empty((N, C, 3), dtype=torch.float32, device=partial.device)
+    check(_lib.load().cds_instnorm_reduce_f32(partial.data_ptr(), partial.shape[1], stats.data_ptr(), affine.data_ptr(), N, C, H, W,
+                                              float(slope), _stream(partial)), "cds_instnorm_reduce_f32")
+    return stats, affine
+
+
+DYNCONV_CL_SHAPES = ((8, (3, 5, 7)), (8, (1, 3)), (16, (3, 5)), (16, (1, 3)), (32, (1, 3)))
+
+
+def dynconv_cl(x_cl: Tensor, wsplit: Tensor, bias: Optional[Tensor], ksizes, w1: Tensor, b1: Tensor, w2: Tensor, epipoles: Tensor,
+               temperature: float, stats_slope: float = 0.1, in_affine: Optional[Tensor] = None):
+    """One DynamicConv (Cin == Cout == C) on channels-last activations in one kernel: x_cl [N,H,W,C] (+ its pending affine [N,C,3])
+    -> (out_cl [N,H,W,C] before its InstanceNorm, norm_curv [N,H,W], stats [N,C,2] float64, affine [N,C,3])."""
+    N, H, W, C = x_cl.shape
+    K = len(ksizes)
+    if (C, tuple(int(k) for k in ksizes)) not in DYNCONV_CL_SHAPES:
+        raise ValueError(f"dynconv_cl: (C, kernel sizes) = ({C}, {tuple(ksizes)}) not in {DYNCONV_CL_SHAPES}")
+    if in_affine is not None and tuple(in_affine.shape) != (N, C, 3):
+        raise ValueError(f"dynconv_cl: in_affine must be [{N},{C},3]")
+    if bias is not None and tuple(bias.shape) != (K, C + 3):
+        raise ValueError("dynconv_cl: bias must be [K, C + 3]")
+    if tuple(epipoles.shape) != (N, 2):
+        raise ValueError("dynconv_cl: epipoles must be [N,2]")
+    nks = sum((int(k) * int(k) + 3) // 4 for k in ksizes)
+    if wsplit.dtype != torch.int16 or not wsplit.is_cuda or wsplit.numel() != (C // 8) * nks * ((C + 3 + 15) // 16) * 3 * 64 * 8:
+        raise ValueError("dynconv_cl: wsplit must be split_pack_dynconv's int16 device tensor for these kernel sizes")
+    dev = x_cl.device
+    lib = _lib.load()
+    out = torch.empty((N, H, W, C), dtype=torch.float32, device=dev)
+    nc = torch.empty((N, H, W), dtype=torch.float32, device=dev)
+    partial = torch.empty((N, lib.cds_dynconv_cl_parts(H, W), C, 2), dtype=torch.float64, device=dev)
+    import ctypes
+    ks = (ctypes.c_int * K)(*[int(k) for k in ksizes])
+    check(lib.cds_dynconv_cl_f32(_dev(x_cl, "x"), _dev(in_affine, "in_affine") if in_affine is not None else None, wsplit.data_ptr(),
+                                 _dev(bias, "bias") if bias is not None else None, _dev(w1, "w1"), _dev(b1, "b1"), _dev(w2, "w2"),
+                                 _host(epipoles, "epipoles"), float(temperature), out.data_ptr(), nc.data_ptr(), partial.data_ptr(),
+                                 N, C, H, W, ks, K, _stream(x_cl)), "cds_dynconv_cl_f32")
+    stats, affine = _reduce_records(partial, N, C, H, W, stats_slope)
+    return out, nc, stats, affine
+
+
+def dynconv_blend_cl(branches: Tensor, w1: Tensor, b1: Tensor, w2: Tensor, epipoles: Tensor, temperature: float, n_shared: int = 1,
+                     stats_slope: float = 0.1):
+    """DynamicConv epilogue over a PLANAR branch tensor [3,N - n_shared + 1,8 + 3,H,W] (conv00) with a channels-last result:
+    -> (out_cl [N,H,W,8], norm_curv [N,H,W], stats [N,8,2] float64, affine [N,8,3])."""
+    K, nslots, C3, H, W = branches.shape
+    N = nslots + n_shared - 1
+    cout = C3 - 3
+    if tuple(epipoles.shape) != (N, 2) or n_shared < 1:
+        raise ValueError("dynconv_blend_cl: epipoles must be [N,2]")
+    dev = branches.device
+    lib = _lib.load()
+    out = torch.empty((N, H, W, cout), dtype=torch.float32, device=dev)
+    nc = torch.empty((N, H, W), dtype=torch.float32, device=dev)
+    partial = torch.empty((N, lib.cds_blend_cl_parts(H, W), cout, 2), dtype=torch.float64, device=dev)
+    check(lib.cds_dynconv_blend_cl_f32(_dev(branches, "branches"), _dev(w1, "w1"), _dev(b1, "b1"), _dev(w2, "w2"),
+                                       _host(epipoles, "epipoles"), float(temperature), out.data_ptr(), nc.data_ptr(),
+                                       partial.data_ptr(), N, K, cout, H, W, n_shared, _stream(out)), "cds_dynconv_blend_cl_f32")
+    stats, affine = _reduce_records(partial, N, cout, H, W, stats_slope)
+    return out, nc, stats, affine
+
+
+def instnorm_stats_cl(x_cl: Tensor, slope: float = 0.1):
+    """InstanceNorm statistics of x_cl [N,H,W,C] -> (stats [N,C,2] float64, affine [N,C,3] = (1/std, -mean/std, slope))."""
+    N, H, W, C = x_cl.shape
+    lib = _lib.load()
+    partial = torch.empty((N, lib.cds_instnorm_stats_cl_parts(H, W), C, 2), dtype=torch.float64, device=x_cl.device)
+    check(lib.cds_instnorm_stats_cl_f32(_dev(x_cl, "x"), partial.data_ptr(), N, C, H, W, _stream(x_cl)), "cds_instnorm_stats_cl_f32")
+    return _reduce_records(partial, N, C, H, W, slope)
+
+
+def conv2d_k3s2_cl(x_cl: Tensor, w9: Tensor, cout: int, in_affine: Optional[Tensor] = None) -> Tensor:
+    """3x3, stride 2, pad 1, no bias on channels-last activations: x_cl [N,H,W,Cin] (+ pending affine), w9 [9,Cin,cout] ->
+    [N,Ho,Wo,cout]."""
+    N, H, W, Cin = x_cl.shape
+    if tuple(w9.shape) != (9, Cin, cout):
+        raise ValueError(f"conv2d_k3s2_cl: weight must be [9,{Cin},{cout}], got {tuple(w9.shape)}")
+    if in_affine is not None and tuple(in_affine.shape) != (N, Cin, 3):
+        raise ValueError(f"conv2d_k3s2_cl: in_affine must be [{N},{Cin},3]")
+    out = torch.empty((N, (H - 1) // 2 + 1, (W - 1) // 2 + 1, cout), dtype=torch.float32, device=x_cl.device)
+    check(_lib.load().cds_conv2d_k3s2_cl_f32(_dev(x_cl, "x"), _dev(in_affine, "in_affine") if in_affine is not None else None,
+                                             _dev(w9, "weight"), out.data_ptr(), N, Cin, cout, H, W, _stream(x_cl)),
+          "cds_conv2d_k3s2_cl_f32")
+    return out
+
+
+def conv2d_fpn_cl(coarse_cl: Tensor, skip_cl: Tensor, w: Tensor, cout: int, coarse_affine: Optional[Tensor] = None,
+                  skip_affine: Optional[Tensor] = None, stats_slope: Optional[float] = 0.1):
+    """FPN lateral on channels-last activations: coarse_cl [N,H/2,W/2,Ca], skip_cl [N,H,W,Cb], w [Ca+Cb,cout] ->
+    out_cl [N,H,W,cout], or (out_cl, affine [N,cout,3]) with stats_slope."""
+    N, hc, wc, Ca = coarse_cl.shape
+    Nb, H, W, Cb = skip_cl.shape
+    if Nb != N or H != 2 * hc or W != 2 * wc:
+        raise ValueError(f"conv2d_fpn_cl: skip {tuple(skip_cl.shape)} is not twice coarse {tuple(coarse_cl.shape)}")
+    if tuple(w.shape) != (Ca + Cb, cout):
+        raise ValueError(f"conv2d_fpn_cl: weight must be [{Ca + Cb},{cout}], got {tuple(w.shape)}")
+    for a, c, nm in ((coarse_affine, Ca, "coarse_affine"), (skip_affine, Cb, "skip_affine")):
+        if a is not None and tuple(a.shape) != (N, c, 3):
+            raise ValueError(f"conv2d_fpn_cl: {nm} must be [{N},{c},3], got {tuple(a.shape)}")
+    dev = skip_cl.device
+    lib = _lib.load()
+    out = torch.empty((N, H, W, cout), dtype=torch.float32, device=dev)
+    partial = (torch.empty((N, lib.cds_fpn_cl_parts(H, W), cout, 2), dtype=torch.float64, device=dev)
+               if stats_slope is not None else None)
+    check(lib.cds_conv2d_fpn_cl_f32(_dev(coarse_cl, "coarse"), _dev(coarse_affine, "coarse_affine") if coarse_affine is not None else None,
+                                    _dev(skip_cl, "skip"), _dev(skip_affine, "skip_affine") if skip_affine is not None else None,
+                                    _dev(w, "weight"), out.data_ptr(), partial.data_ptr() if partial is not None else None,
+                                    N, Ca, Cb, cout, H, W, _stream(skip_cl)), "cds_conv2d_fpn_cl_f32")
+    if stats_slope is None:
+        return out
+    return out, _reduce_records(partial, N, cout, H, W, stats_slope)[1]
+
+
+def instnorm_apply_cl(x_cl: Tensor, stats: Tensor, act: int, n_chw: int = 0, cl_from: Optional[int] = 0):
+    """InstanceNorm + activation of x_cl [N,H,W,C] for given statistics [N,C,2] float64 -> (out_cl [N - cl_from,H,W,C] for the images
+    n >= cl_from, or None with cl_from=None; out_chw [n_chw,C,H,W] for the first n_chw images, or None)."""
+    N, H, W, C = x_cl.shape
+    if stats.dtype != torch.float64 or tuple(stats.shape) != (N, C, 2):
+        raise ValueError(f"instnorm_apply_cl: stats must be float64 [{N},{C},2]")
+    want_cl = cl_from is not None and cl_from < N
+    if not want_cl and n_chw < 1:
+        raise ValueError("instnorm_apply_cl: nothing to write")
+    dev = x_cl.device
+    out_cl = torch.empty((N - cl_from, H, W, C), dtype=torch.float32, device=dev) if want_cl else None
+    out_chw = torch.empty((n_chw, C, H, W), dtype=torch.float32, device=dev) if n_chw > 0 else None
+    check(_lib.load().cds_instnorm_apply_cl_f32(_dev(x_cl, "x"), _dev64(stats, "stats"), out_cl.data_ptr() if want_cl else None,
+                                                out_chw.data_ptr() if n_chw > 0 else None, N, C, H, W, act, n_chw,
+                                                cl_from if want_cl else 0, _stream(x_cl)), "cds_instnorm_apply_cl_f32")
+    return out_cl, out_chw
+
+
 def depth_fusion(ref_depth: Tensor, ref_conf: Tensor, src_depths: Tensor, src_confs: Tensor, cams: Tensor,
                  prob_thresh, dist_thresh: float, depth_thresh: float, view_thresh: float,
                  want_view_masks: bool = False):

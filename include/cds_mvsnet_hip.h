@@ -363,6 +363,52 @@ int cds_instnorm_affine_f32(const float* x, float* affine, float* stats, int N, 
                             void* stream);
 
 /*
+ * FeatureNet on CHANNELS-LAST activations (csrc/feat_cl.hip, round 5; models/module.py:234-267, models/dynamic_conv.py:97-122).
+ * Every activation is [N][H][W][C] fp32 (a pixel's channels contiguous); normalise-on-load tables [N][C][3] as above; InstanceNorm
+ * records [N][parts][C][2] doubles (sum, sum of squares per record) reduced by cds_instnorm_reduce_f32.  The inference runner
+ * (cds_mvsnet_amd.model._FeatureRunner) uses these; the planar entry points above remain for the training path and the
+ * visibility CNN.
+ *
+ * cds_dynconv_cl_f32: one DynamicConv (dynamic_conv.py:97-122) in ONE kernel - all branch convolutions on the bf16 matrix cores in
+ *   split-bf16 arithmetic as a transposed implicit GEMM (rows = output channels, columns = pixels) + the blend epilogue on the
+ *   accumulators + the InstanceNorm records of the result.
+ *     x [N][H][W][C], in_affine [N][C][3] or NULL, weight_split = ops.split_pack_dynconv (as cds_dynconv_branches_sbf_f32),
+ *     bias [nb][C + 3] or NULL, w1 [4][nb], b1 [4], w2 [nb][4], epipoles_host [N][2] (pixels at this resolution)
+ *     out [N][H][W][C] (before its InstanceNorm), norm_curv [N][H][W], partial [N][cds_dynconv_cl_parts(H, W)][C][2]
+ *   (C, ksizes) in {(8, 3-5-7), (8, 1-3), (16, 3-5), (16, 1-3), (32, 1-3)}, Cin == Cout == C, N <= CDS_MAX_IMAGES.
+ * cds_dynconv_blend_cl_f32: the epilogue alone over a PLANAR branch tensor [3][N - n_shared + 1][8 + 3][H][W] (conv00: 3 input
+ *   channels, the VALU branch kernels; the first n_shared images share slot 0) -> out [N][H][W][8], norm_curv, partial
+ *   [N][cds_blend_cl_parts(H, W)][8][2].
+ * cds_conv2d_k3s2_cl_f32: 3x3, stride 2, pad 1, no bias (downsample1 / downsample2): x [N][H][W][Cin] -> out [N][Ho][Wo][Cout],
+ *   weight [9][Cin][Cout] (tap = ky * 3 + kx, cout fastest); (Cin, Cout) in {(8, 16), (16, 32)}.
+ * cds_conv2d_fpn_cl_f32: FPN lateral, 1x1 convolution of cat(nearest2x(coarse [N][H/2][W/2][Ca]), skip [N][H][W][Cb]) ->
+ *   out [N][H][W][Cout]; weight [Ca + Cb][Cout]; partial NULL or [N][cds_fpn_cl_parts(H, W)][Cout][2];
+ *   (Ca, Cb, Cout) in {(32, 16, 16), (16, 8, 8)}.
+ * cds_instnorm_stats_cl_f32: records of x [N][H][W][C] -> partial [N][cds_instnorm_stats_cl_parts(H, W)][C][2]; C in {8, 16, 32}.
+ * cds_instnorm_apply_cl_f32: InstanceNorm + activation for given statistics [N][C][2] doubles: the images n >= cl_from channels-last
+ *   into out_cl [N - cl_from][H][W][C] (or NULL), the first n_chw images planar into out_chw [n_chw][C][H][W] (the reference-view
+ *   feature maps K1 / K3 read).
+ */
+int cds_dynconv_cl_parts(int H, int W);
+int cds_dynconv_cl_f32(const float* x, const float* in_affine, const void* weight_split, const float* bias, const float* w1,
+                       const float* b1, const float* w2, const float* epipoles_host, float temperature, float* out,
+                       float* norm_curv, double* partial, int N, int C, int H, int W, const int* ksizes, int nb, void* stream);
+int cds_blend_cl_parts(int H, int W);
+int cds_dynconv_blend_cl_f32(const float* branches, const float* w1, const float* b1, const float* w2, const float* epipoles_host,
+                             float temperature, float* out, float* norm_curv, double* partial, int N, int K, int Cout, int H, int W,
+                             int n_shared, void* stream);
+int cds_conv2d_k3s2_cl_f32(const float* x, const float* in_affine, const float* weight, float* out, int N, int Cin, int Cout, int H,
+                           int W, void* stream);
+int cds_fpn_cl_parts(int H, int W);
+int cds_conv2d_fpn_cl_f32(const float* coarse, const float* coarse_affine, const float* skip, const float* skip_affine,
+                          const float* weight, float* out, double* partial, int N, int Ca, int Cb, int Cout, int H, int W,
+                          void* stream);
+int cds_instnorm_stats_cl_parts(int H, int W);
+int cds_instnorm_stats_cl_f32(const float* x, double* partial, int N, int C, int H, int W, void* stream);
+int cds_instnorm_apply_cl_f32(const float* x, const double* stats, float* out_cl, float* out_chw, int N, int C, int H, int W, int act,
+                              int n_chw, int cl_from, void* stream);
+
+/*
  * Depth-map filtering + fusion (fusion.py:7-114, test.py:334-351).  Per reference pixel and source
  * view: re-projection through the source depth map, pixel-distance / relative-depth / in-range tests, average fusion.
  *   ref_depth [h][w]; ref_conf [3][h][w]; src_depths [V][h][w]; src_confs [V][3][h][w] (probability filter

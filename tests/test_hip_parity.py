@@ -275,9 +275,14 @@ def test_dynconv_and_epipoles(dev, ops, seeded_state):
         assert (nc[1] - nc[0]).abs().max() > 1e-4
 
 
-def test_featurenet(dev, seeded_state):
+@pytest.mark.parametrize("layout", ["channels_last", "planar"])
+def test_featurenet(layout, dev, seeded_state, monkeypatch):
+    """FeatureNet against the reference golden G5 and the float64 envelope G9, on the channels-last kernels (feat_cl.hip, the
+    default since round 5) and on the planar kernels of rounds 1-4 (CDS_FEAT_CL=0)."""
     from cds_mvsnet_amd import FeatureNet, seeded_init_
+    import cds_mvsnet_amd.model as cm
     from cds_mvsnet_amd.model import _FeatureRunner
+    monkeypatch.setattr(cm, "USE_FEAT_CL", layout == "channels_last")
     g = load_golden("g5_featurenet")
     net = FeatureNet(8)
     seeded_init_(net, 7)
