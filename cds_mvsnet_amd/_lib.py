@@ -69,6 +69,7 @@ SIGNATURES = {
     "cds_instnorm_reduce_f32": [P, I, P, P, I, I, I, I, F, P],
     "cds_instnorm_apply_f32": [P, P, P, I, I, I, I, I, I, P],
     "cds_instnorm_act_f32": [P, P, P, I, I, I, I, I, I, P],
+    "cds_debug_poison_lds": [ctypes.c_uint],
     "cds_dynconv_cl_parts": [I, I],
     "cds_dynconv_cl_f32": [P, P, P, P, P, P, P, P, F, P, P, P, I, I, I, I, P, I, P],
     "cds_blend_cl_parts": [I, I],

@@ -21,8 +21,13 @@ int cds_conv3d_zmg_dispatch(const float* x, const void* wsp, const float* bias, 
 // native 4-float vector (volatile-loadable, unlike HIP's float4 struct): pins a 16-byte LDS read
 using cds_f4 = float __attribute__((ext_vector_type(4)));
 
+extern "C" int cds_debug_poison_lds(unsigned pattern);   // lib.hip
+
 static inline int cds_launch_status() {
   hipError_t e = hipGetLastError();
+  if (const char* p = getenv("CDS_DEBUG_POISON_LDS")) {    // debug aid, see lib.hip: the next kernel starts on poisoned LDS
+    if (e == hipSuccess) (void)cds_debug_poison_lds((unsigned)strtoul(p, nullptr, 16));
+  }
   return e == hipSuccess ? 0 : -(int)e;
 }
 

@@ -17,6 +17,7 @@
 #include <stdlib.h>
 
 #include "cds_common.hpp"
+#include "feat_common.hpp"
 
 namespace {
 
@@ -260,45 +261,14 @@ __global__ __launch_bounds__(256, 2) void dynconv_branches_sbf_kernel(const floa
     {
       const int wp = wave * 64 + (m >> 2) * 16 + g * 4 + (m & 3);
       const int px = ox0 + ((m >> 2) & 1) * 16 + g * 4 + (m & 3), py = oy0 + wave * 2 + (m >> 3);
-      float u = (float)px - bl.ex[img], v = (float)py - bl.ey[img];
-      const float nrm = sqrtf(u * u + v * v);
-      u = u / (nrm + 1e-6f);
-      v = v / (nrm + 1e-6f);
-      const float b0 = u * u, b1v = 2.0f * u * v, b2 = v * v;
-      float curv[NBR];
+      float att[NBR][3], logit[NBR];
 #pragma unroll
       for (int b = 0; b < NBR; ++b)
-        curv[b] = attL[(b * 3) * 256 + wp] * b0 + attL[(b * 3 + 1) * 256 + wp] * b1v + attL[(b * 3 + 2) * 256 + wp] * b2;
-      float hid[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float sacc = 0.f;
+        for (int j = 0; j < 3; ++j) att[b][j] = attL[(b * 3 + j) * 256 + wp];
+      const float nc = blend_from_att<NBR>(att, px, py, bl.ex[img], bl.ey[img], bl.w1, bl.b1, bl.w2, bl.temperature, logit);
 #pragma unroll
-        for (int b = 0; b < NBR; ++b) sacc = fmaf(bl.w1[j * NBR + b], curv[b], sacc);
-        hid[j] = fmaxf(sacc + bl.b1[j], 0.f);
-      }
-      float logit[NBR], mx = -INFINITY;
-#pragma unroll
-      for (int b = 0; b < NBR; ++b) {
-        float sacc = 0.f;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) sacc = fmaf(bl.w2[b * 4 + j], hid[j], sacc);
-        logit[b] = sacc / bl.temperature;
-        mx = fmaxf(mx, logit[b]);
-      }
-      float den = 0.f;
-#pragma unroll
-      for (int b = 0; b < NBR; ++b) {
-        logit[b] = expf(logit[b] - mx);
-        den += logit[b];
-      }
-      float nc = 0.f;
-#pragma unroll
-      for (int b = 0; b < NBR; ++b) {
-        logit[b] = logit[b] / den;
-        nc = nc + curv[b] * logit[b];
-        wL[b * 256 + wp] = logit[b];
-      }
+      for (int b = 0; b < NBR; ++b) wL[b * 256 + wp] = logit[b];
       if (px < W && py < H) bl.norm_curv[(size_t)img * plane + (size_t)py * W + px] = nc;
     }
     float4 wq[NBR][4];

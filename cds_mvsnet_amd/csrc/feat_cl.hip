@@ -10,9 +10,9 @@
 //                             of every kernel size k) as implicit GEMMs on the bf16 matrix cores in split-bf16 arithmetic
 //                             (sbf_common.hpp: 3 bf16 terms per fp32 operand, 6 partial products, fp32 accumulate) + the blend
 //                             epilogue (epipolar projection, 1x1 MLP, softmax(./T), blend) on the accumulators + the InstanceNorm
-//                             records of the result.  TRANSPOSED GEMM: D[cout][pixel] += W[cout][k] X[k][pixel], so a lane ends
-//                             with 4 consecutive output channels of ONE pixel = one 16-byte channels-last store, and the three
-//                             curvature responses of a pixel sit in ONE lane (no LDS round trip for the epilogue).
+//                             records of the result; the K-loop and epilogue of the planar kernel (conv2d_sbf.hip), the blended
+//                             16 x 16 tiles transposed through LDS for 16-byte channels-last stores (why not the transposed GEMM:
+//                             see the kernel's comment - it corrupts other waves).
 //   cds_dynconv_blend_cl_f32  the same epilogue over a planar branch tensor (conv00: 3 input channels, VALU branch kernels),
 //                             channels-last output
 //   cds_conv2d_k3s2_cl_f32    the two down-sampling units (3x3, stride 2, pad 1), VALU, texel loads straight from global memory
@@ -52,25 +52,34 @@ struct DCfg {
   static constexpr int C4 = CIN / 4;                           // float4 chunks per texel
   static constexpr int NCH = NPOS * C4, NIT = (NCH + 255) / 256, PSTEP = 256 / C4;
   static constexpr int NKS = nks_of(K0) + nks_of(K1) + (K2 > 0 ? nks_of(K2) : 0);
-  static constexpr int GC = CIN == 8 ? 2 : 0, MBC = CIN / 16;  // lane group / block that hold the curvature rows Cout .. Cout + 2
-  static constexpr int LDSB = cmax(ROUNDS * PLANE, 4 * CIN * 2 * 8);
+  // epilogue areas (they reuse the staged tile): curvature responses [b][j][256 px] and blend weights [b][256 px] floats, then the
+  // transposition tiles [wave][q][block][16 px][TP] floats and the statistics [wave][NBLK * 16][2] doubles
+  static constexpr int TP = 20;                                // row pitch of a transposition tile: conflict-free writes and 16-byte reads
+  static constexpr int ATTB = NBR * 3 * 256 * 4, WLB = NBR * 256 * 4;
+  static constexpr int TRB = 4 * 4 * NCB * 16 * TP * 4;
+  static constexpr int REDB = 4 * NBLK * 16 * 2 * 8;
+  static constexpr int LDSB = cmax(ROUNDS * PLANE, cmax(ATTB + WLB, TRB) + REDB);
 };
 
-// sum over the 16 lanes of a DPP row, fp64 (all lanes end up with the total)
-__device__ __forceinline__ double row16_sum_f64(double v) {
-  v += dpp_f64<0xB1>(v);
-  v += dpp_f64<0x4E>(v);
-  v += dpp_f64<0x141>(v);
-  v += dpp_f64<0x140>(v);
-  return v;
-}
-
+// One DynamicConv on channels-last activations.  Staging: channels-last (contiguous tile rows).  K-loop: exactly the planar kernel's
+// (conv2d_sbf.hip): A operand = data from LDS (rows = 16 pixels of an x-run), B operand = weights (columns = output channels), so a
+// lane ends with ONE output channel of 4 consecutive pixels.  Epilogue: the planar kernel's (curvature columns and per-pixel blend
+// weights through LDS, statistics per channel column) - then each wave transposes its blended 16 x 16 tiles through LDS so that a lane
+// stores 4 consecutive channels of one pixel (16 bytes, channels-last).
+//
+// Why not the transposed GEMM (rows = output channels, weights as the A operand), which needs no transposition and keeps a pixel's three
+// curvature responses in one lane?  It was built first and is ~5 % faster - and it CORRUPTS OTHER WAVES: with the weights (loaded from
+// global memory) as SrcA and the LDS-loaded data as SrcB of v_mfma_f32_16x16x32_bf16, waves of ANY kernel sharing the CU (other
+// waves of this kernel, K1 on another stream) occasionally get wrong values in lanes 48-63 (about one 16-pixel tile in 10^4); with the
+// two source operands exchanged - nothing else changed - the effect is gone.  Measured by an aggressor / victim experiment and bisected to
+// the K-loop (profiles/r05_experiments.md, scripts/ab/r05_aggressor.py); operand data, zero padding, wait states after the MFMAs and the
+// distance to the next loads make no difference.  The operand roles below are the ones that have been bit-stable for three rounds.
 template <int CIN, int K0, int K1, int K2>
 __global__ __launch_bounds__(256, 2) void dynconv_cl_kernel(const float* __restrict__ x, const float* __restrict__ affine,
                                                             const uint4* __restrict__ wsp, const float* __restrict__ bias,
                                                             DynEpi ep, int N, int H, int W, int tiles_x, int tiles_y) {
   using C = DCfg<CIN, K0, K1, K2>;
-  constexpr int NBR = C::NBR, NBLK = C::NBLK, R = C::R, IXP = C::IXP;
+  constexpr int NBR = C::NBR, NBLK = C::NBLK, NCB = C::NCB, R = C::R, IXP = C::IXP, Cout = CIN, Co3 = C::CO3;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   int lin = cds_xcd_remap(blockIdx.x, tiles_x * tiles_y * N);
   const int tx_i = lin % tiles_x;
@@ -78,7 +87,7 @@ __global__ __launch_bounds__(256, 2) void dynconv_cl_kernel(const float* __restr
   const int ty_i = lin % tiles_y, img = lin / tiles_y;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int n = lane & 15, g = lane >> 4;
+  const int m = lane & 15, g = lane >> 4;
   const int ox0 = tx_i * TX, oy0 = ty_i * TY;
 
   // ---- stage the (TY + 2R) x (TX + 2R) texel tile, all channels: thread = float4 chunk of the tile's contiguous rows, so the
@@ -136,16 +145,16 @@ __global__ __launch_bounds__(256, 2) void dynconv_cl_kernel(const float* __restr
   }
   __syncthreads();
 
-  f32x4 acc[NBR][NBLK][4];       // [branch][16-row block][column tile: (row 0 | 1 of the wave) x (x-run 0 | 1)]
+  f32x4 acc[NBR][NBLK][4];       // M-tiles: (row 0 | 1 of the wave) x (x-run 0 | 1)
 #pragma unroll
   for (int b = 0; b < NBR; ++b)
 #pragma unroll
-    for (int mb = 0; mb < NBLK; ++mb)
+    for (int nb = 0; nb < NBLK; ++nb)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) acc[b][mb][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int q = 0; q < 4; ++q) acc[b][nb][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  // B operand (data): lane (n, g) supplies the 8 channels of tap 4 t + g for pixel n of the column tile = one ds_read_b128 per term
-  const int a_base = ((wave * 2) * IXP + n) * POSB;
+  // A operand (data): lane (m, g) supplies the 8 channels of tap 4 t + g for pixel m of the x-run = one ds_read_b128 per term
+  const int a_base = ((wave * 2) * IXP + m) * POSB;
   const uint4* __restrict__ wl = wsp + lane;
   constexpr int KS[3] = {K0, K1, K2 > 0 ? K2 : 1};
 #pragma unroll 1
@@ -163,126 +172,154 @@ __global__ __launch_bounds__(256, 2) void dynconv_cl_kernel(const float* __restr
         if (tap >= kk) tap = kk - 1;                    // padded tap: zero weights, any in-tile data
         const int ky = tap / k, kx = tap - ky * k;
         const unsigned char* ap = lp + ((ky + R - rk) * IXP + (kx + R - rk)) * POSB;
-        BV wv[NBLK][3];
+        BV wh[NBLK], wm[NBLK], wlo[NBLK];
 #pragma unroll
-        for (int mb = 0; mb < NBLK; ++mb) {
-          const uint4* p = wb + (size_t)((t * NBLK + mb) * 3) * 64;
-          wv[mb][0].u = p[0];
-          wv[mb][1].u = p[64];
-          wv[mb][2].u = p[128];
+        for (int nb = 0; nb < NBLK; ++nb) {
+          const uint4* p = wb + (size_t)((t * NBLK + nb) * 3) * 64;
+          wh[nb].u = p[0];
+          wm[nb].u = p[64];
+          wlo[nb].u = p[128];
         }
-        BV xv[4][3];
+        BV ah[4], am[4], al[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const unsigned char* a = ap + ((q >> 1) * IXP + (q & 1) * 16) * POSB;
-          xv[q][0].u = *reinterpret_cast<const uint4*>(a);
-          xv[q][1].u = *reinterpret_cast<const uint4*>(a + 16);
-          xv[q][2].u = *reinterpret_cast<const uint4*>(a + 32);
+          ah[q].u = *reinterpret_cast<const uint4*>(a);
+          am[q].u = *reinterpret_cast<const uint4*>(a + 16);
+          al[q].u = *reinterpret_cast<const uint4*>(a + 32);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int mb = 0; mb < NBLK; ++mb) {
+        for (int nb = 0; nb < NBLK; ++nb) {
 #pragma unroll
-          for (int q = 0; q < 4; ++q) SBF_MFMA(acc[b][mb][q], wv[mb][0], xv[q][2]);    // order 2^-16 terms first
+          for (int q = 0; q < 4; ++q) SBF_MFMA(acc[b][nb][q], al[q], wh[nb]);    // order 2^-16 terms first
 #pragma unroll
-          for (int q = 0; q < 4; ++q) SBF_MFMA(acc[b][mb][q], wv[mb][1], xv[q][1]);
+          for (int q = 0; q < 4; ++q) SBF_MFMA(acc[b][nb][q], am[q], wm[nb]);
 #pragma unroll
-          for (int q = 0; q < 4; ++q) SBF_MFMA(acc[b][mb][q], wv[mb][2], xv[q][0]);
+          for (int q = 0; q < 4; ++q) SBF_MFMA(acc[b][nb][q], ah[q], wlo[nb]);
 #pragma unroll
-          for (int q = 0; q < 4; ++q) SBF_MFMA(acc[b][mb][q], wv[mb][0], xv[q][1]);    // 2^-8
+          for (int q = 0; q < 4; ++q) SBF_MFMA(acc[b][nb][q], am[q], wh[nb]);    // 2^-8
 #pragma unroll
-          for (int q = 0; q < 4; ++q) SBF_MFMA(acc[b][mb][q], wv[mb][1], xv[q][0]);
+          for (int q = 0; q < 4; ++q) SBF_MFMA(acc[b][nb][q], ah[q], wm[nb]);
 #pragma unroll
-          for (int q = 0; q < 4; ++q) SBF_MFMA(acc[b][mb][q], wv[mb][0], xv[q][0]);    // leading term
+          for (int q = 0; q < 4; ++q) SBF_MFMA(acc[b][nb][q], ah[q], wh[nb]);    // leading term
         }
       }
       ks0 += nks;
     }
   }
 
-  // ---- epilogue.  Accumulator layout: lane (n, g) holds rows 16 mb + 4 g + 0..3 of pixel n of column tile q.  Rows < Cout are
-  // the branch responses, rows Cout .. Cout + 2 the curvature responses: they sit in the lanes of group GC of block MBC, which
-  // compute the blend weights of their pixel; the other three lanes of the pixel fetch them with one cross-lane read each. ----
-  constexpr int NCB = C::NCB;
-  const bool chan_lane = 4 * g < (CIN < 16 ? CIN : 16);       // this lane's four rows of a channel block are output channels
-  float bch[NBR][NCB][4], bcu[NBR][3];
+  // ---- epilogue (the planar kernel's).  Accumulator layout: lane (m, g) holds column 16 nb + m of pixels x = (q & 1) 16 + 4 g + i,
+  // y = 2 wave + (q >> 1).  (1) the lanes of the three curvature columns leave them in LDS; (2) lane m of a 16-lane group owns pixel
+  // (q, i) = (m >> 2, m & 3) of its group: projection, MLP, softmax -> K weights into LDS, norm_curv to memory; (3) every lane reads the
+  // weights of its 16 pixels and blends its column; (4) the blended 16 x 16 tiles are transposed through LDS: a lane stores 4
+  // consecutive channels of one pixel.  InstanceNorm records per (wave, channel) as the planar kernel leaves them. ----
+  float* attL = reinterpret_cast<float*>(lds);                 // [b][j][256 pixels of the tile]
+  float* wL = attL + NBR * 3 * 256;                            // [b][256]
+  __syncthreads();                                             // every wave is done with the staged input tile
 #pragma unroll
-  for (int b = 0; b < NBR; ++b) {
-#pragma unroll
-    for (int mb = 0; mb < NCB; ++mb)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) bch[b][mb][j] = (bias && chan_lane) ? bias[b * C::CO3 + mb * 16 + 4 * g + j] : 0.f;
-#pragma unroll
-    for (int j = 0; j < 3; ++j) bcu[b][j] = bias ? bias[b * C::CO3 + CIN + j] : 0.f;
-  }
-  double ds[NCB][4], dq[NCB][4];
-#pragma unroll
-  for (int mb = 0; mb < NCB; ++mb)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) ds[mb][j] = dq[mb][j] = 0.0;
-
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int oy = oy0 + wave * 2 + (q >> 1), ox = ox0 + (q & 1) * 16 + n;
-    const bool inb = oy < H && ox < W;
-    float att[NBR][3], wts[NBR];
+  for (int nb = 0; nb < NBLK; ++nb) {
+    const int jj = nb * 16 + m - Cout;
+    if (jj < 0 || jj > 2) continue;
 #pragma unroll
     for (int b = 0; b < NBR; ++b) {
-      const f32x4 a = acc[b][C::MBC][q];
-      att[b][0] = a.x + bcu[b][0];
-      att[b][1] = a.y + bcu[b][1];
-      att[b][2] = a.z + bcu[b][2];
+      const float bv = bias ? bias[b * Co3 + nb * 16 + m] : 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 a = acc[b][nb][q];
+        *reinterpret_cast<float4*>(attL + (b * 3 + jj) * 256 + wave * 64 + q * 16 + g * 4) =
+            make_float4(a.x + bv, a.y + bv, a.z + bv, a.w + bv);
+      }
     }
-    const float nc = blend_from_att<NBR>(att, ox, oy, ep.ex[img], ep.ey[img], ep.w1, ep.b1, ep.w2, ep.temperature, wts);
-    if (g == C::GC && inb) ep.norm_curv[((size_t)img * H + oy) * W + ox] = nc;
+  }
+  __syncthreads();
+  {
+    const int wp = wave * 64 + (m >> 2) * 16 + g * 4 + (m & 3);
+    const int px = ox0 + ((m >> 2) & 1) * 16 + g * 4 + (m & 3), py = oy0 + wave * 2 + (m >> 3);
+    float att[NBR][3], logit[NBR];
 #pragma unroll
-    for (int b = 0; b < NBR; ++b) wts[b] = __shfl(wts[b], (C::GC << 4) | n);
+    for (int b = 0; b < NBR; ++b)
 #pragma unroll
-    for (int mb = 0; mb < NCB; ++mb) {
+      for (int j = 0; j < 3; ++j) att[b][j] = attL[(b * 3 + j) * 256 + wp];
+    const float nc = blend_from_att<NBR>(att, px, py, ep.ex[img], ep.ey[img], ep.w1, ep.b1, ep.w2, ep.temperature, logit);
+#pragma unroll
+    for (int b = 0; b < NBR; ++b) wL[b * 256 + wp] = logit[b];
+    if (px < W && py < H) ep.norm_curv[((size_t)img * H + py) * W + px] = nc;
+  }
+  __syncthreads();
+  float4 wq[NBR][4];
+#pragma unroll
+  for (int b = 0; b < NBR; ++b)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) wq[b][q] = *reinterpret_cast<const float4*>(wL + b * 256 + wave * 64 + q * 16 + g * 4);
+  __syncthreads();                                             // the weights are in registers: the area becomes the transposition tiles
+  constexpr int AREA = cmax(C::ATTB + C::WLB, C::TRB);
+  float* trL = reinterpret_cast<float*>(lds) + wave * (4 * NCB * 16 * C::TP);    // [q][block][16 pixels][TP]
+  double* red = reinterpret_cast<double*>(lds + AREA);         // [wave][NBLK * 16][2]: the four waves' sums of a tile, added below
+#pragma unroll
+  for (int nb = 0; nb < NCB; ++nb) {
+    const int co = nb * 16 + m;
+    const bool col = co < Cout;
+    float bvb[NBR];
+#pragma unroll
+    for (int b = 0; b < NBR; ++b) bvb[b] = (bias && col) ? bias[b * Co3 + co] : 0.f;
+    double ds = 0.0, dq = 0.0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int oy = oy0 + wave * 2 + (q >> 1), ox = ox0 + (q & 1) * 16 + g * 4;
       float o[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int i = 0; i < 4; ++i) {
         float sacc = 0.f;
 #pragma unroll
         for (int b = 0; b < NBR; ++b) {
-          const f32x4 a = acc[b][mb][q];
-          const float av = (j == 0 ? a.x : j == 1 ? a.y : j == 2 ? a.z : a.w) + bch[b][mb][j];
-          sacc = sacc + av * wts[b];
+          const f32x4 a = acc[b][nb][q];
+          const float av = (i == 0 ? a.x : i == 1 ? a.y : i == 2 ? a.z : a.w) + bvb[b];
+          const float wv = i == 0 ? wq[b][q].x : i == 1 ? wq[b][q].y : i == 2 ? wq[b][q].z : wq[b][q].w;
+          sacc = sacc + av * wv;
         }
-        o[j] = sacc;
+        o[i] = sacc;
+        trL[((q * NCB + nb) * 16 + g * 4 + i) * C::TP + m] = sacc;      // pixel row 4 g + i, channel column m
       }
-      if (chan_lane && inb) {
-        *reinterpret_cast<float4*>(ep.out + (((size_t)img * H + oy) * W + ox) * CIN + mb * 16 + 4 * g) =
-            make_float4(o[0], o[1], o[2], o[3]);
+      if (col && oy < H) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const double dv = (double)o[j];
-          ds[mb][j] += dv;
-          dq[mb][j] += dv * dv;
-        }
+        for (int i = 0; i < 4; ++i)
+          if (ox + i < W) {
+            const double dv = (double)o[i];
+            ds += dv;
+            dq += dv * dv;
+          }
       }
+    }
+    // the wave's 64 pixels of this channel: lanes (m, g = 0..3)
+    ds += __shfl_xor(ds, 16);
+    dq += __shfl_xor(dq, 16);
+    ds += __shfl_xor(ds, 32);
+    dq += __shfl_xor(dq, 32);
+    if (g == 0) {
+      red[(wave * NBLK * 16 + co) * 2] = ds;
+      red[(wave * NBLK * 16 + co) * 2 + 1] = dq;
     }
   }
-  // InstanceNorm records of the output (fp64 sums of the rounded fp32 values = what a statistics pass would read back): the 16
-  // pixels of a lane row by DPP, the four waves through LDS in a fixed order, one record per (tile, channel): bit-reproducible
-  __syncthreads();                                            // every wave is done with the staged tile
-  double* red = reinterpret_cast<double*>(lds);               // [wave][CIN][2]
-#pragma unroll
-  for (int mb = 0; mb < NCB; ++mb)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const double s = row16_sum_f64(ds[mb][j]), s2 = row16_sum_f64(dq[mb][j]);
-      if (n == 0 && chan_lane) {
-        red[(wave * CIN + mb * 16 + 4 * g + j) * 2] = s;
-        red[(wave * CIN + mb * 16 + 4 * g + j) * 2 + 1] = s2;
-      }
-    }
   __syncthreads();
-  if (tid < CIN) {
+  // channels-last store: lane (m, g) takes pixel m of each x-run and channels 4 g .. 4 g + 3 of each block: 16 bytes
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int oy = oy0 + wave * 2 + (q >> 1), ox = ox0 + (q & 1) * 16 + m;
+    if (oy >= H || ox >= W) continue;
+    float* __restrict__ op = ep.out + (((size_t)img * H + oy) * W + ox) * CIN;
+#pragma unroll
+    for (int nb = 0; nb < NCB; ++nb) {
+      if (nb * 16 + 4 * g < Cout)
+        *reinterpret_cast<float4*>(op + nb * 16 + 4 * g) = *reinterpret_cast<const float4*>(trL + ((q * NCB + nb) * 16 + m) * C::TP + 4 * g);
+    }
+  }
+  // one record per (tile, channel): the four waves in a fixed order
+  if (tid < NBLK * 16 && tid < Cout) {
     const int parts = tiles_x * tiles_y;
-    double* rec = ep.partial + (((size_t)img * parts + (size_t)(ty_i * tiles_x + tx_i)) * CIN + tid) * 2;
-    rec[0] = (red[tid * 2] + red[(CIN + tid) * 2]) + (red[(2 * CIN + tid) * 2] + red[(3 * CIN + tid) * 2]);
-    rec[1] = (red[tid * 2 + 1] + red[(CIN + tid) * 2 + 1]) + (red[(2 * CIN + tid) * 2 + 1] + red[(3 * CIN + tid) * 2 + 1]);
+    double* rec = ep.partial + (((size_t)img * parts + (size_t)(ty_i * tiles_x + tx_i)) * Cout + tid) * 2;
+    rec[0] = (red[tid * 2] + red[(NBLK * 16 + tid) * 2]) + (red[(2 * NBLK * 16 + tid) * 2] + red[(3 * NBLK * 16 + tid) * 2]);
+    rec[1] = (red[tid * 2 + 1] + red[(NBLK * 16 + tid) * 2 + 1]) + (red[(2 * NBLK * 16 + tid) * 2 + 1] + red[(3 * NBLK * 16 + tid) * 2 + 1]);
   }
 }
 
@@ -360,132 +397,166 @@ __global__ __launch_bounds__(256) void dynconv_blend_cl_kernel(const float* __re
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // 3x3, stride 2, pad 1 convolution CIN -> COUT (downsample1 8 -> 16, downsample2 16 -> 32; module.py:236,240), channels-last in
-// and out, normalise-on-load.  One thread per output pixel: nine texel loads straight from global memory (neighbouring lanes
-// share 1/3 of them through L1), COUT accumulators, wave-uniform weights [tap][cin][cout] through the scalar cache.
+// and out, normalise-on-load.  Thread = TWO x-adjacent output pixels: per tap the two texels (columns kx and kx + 2 of the shared
+// 3 x 5 window) are loaded straight from global memory (consecutive lanes read consecutive texel pairs; the overlaps are L1 hits)
+// and every wave-uniform weight (scalar cache, [tap][cin][cout]) feeds two multiply-adds.  At most 64 weights are in flight (SGPRs).
+// Summation order per output: taps outer, input channels inner (fp32 fmaf chain).
 // ---------------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float affine_leaky(float v, const float* __restrict__ aff, int ci) {
+  const float t = v * aff[3 * ci] + aff[3 * ci + 1];
+  return t > 0.f ? t : t * aff[3 * ci + 2];
+}
+
 template <int CIN, int COUT>
 __global__ __launch_bounds__(256) void conv2d_k3s2_cl_kernel(const float* __restrict__ x, const float* __restrict__ affine,
                                                              const float* __restrict__ wpk, float* __restrict__ out, int H, int W,
                                                              int Ho, int Wo) {
+  constexpr int CSTEP = COUT >= 32 ? 2 : 4;                   // input channels per weight batch: CSTEP * COUT <= 64 SGPRs
   const int n = blockIdx.y;
-  const int p = blockIdx.x * 256 + threadIdx.x;
-  if (p >= Ho * Wo) return;
-  const int oy = p / Wo, ox = p - oy * Wo;
+  const int Wp = (Wo + 1) >> 1;                               // output pixel pairs per row
+  const int pp = blockIdx.x * 256 + threadIdx.x;
+  if (pp >= Ho * Wp) return;
+  const int oy = pp / Wp, ox = (pp - oy * Wp) * 2;
+  const bool has2 = ox + 1 < Wo;
   const float* __restrict__ aff = affine ? affine + (size_t)n * CIN * 3 : nullptr;
   const float* __restrict__ xn = x + (size_t)n * H * W * CIN;
-  float acc[COUT];
+  float acc0[COUT], acc1[COUT];
 #pragma unroll
-  for (int c = 0; c < COUT; ++c) acc[c] = 0.f;
+  for (int c = 0; c < COUT; ++c) acc0[c] = acc1[c] = 0.f;
 #pragma unroll 1
   for (int tap = 0; tap < 9; ++tap) {
     const int ky = tap / 3, kx = tap - ky * 3;
-    const int gy = 2 * oy - 1 + ky, gx = 2 * ox - 1 + kx;
-    const bool ok = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
-    const float4* __restrict__ src = reinterpret_cast<const float4*>(xn + ((size_t)(ok ? gy : 0) * W + (ok ? gx : 0)) * CIN);
+    const int gy = 2 * oy - 1 + ky, gxa = 2 * ox - 1 + kx, gxb = gxa + 2;
+    const bool oky = (unsigned)gy < (unsigned)H;
+    const bool oka = oky && (unsigned)gxa < (unsigned)W, okb = oky && has2 && (unsigned)gxb < (unsigned)W;
+    const float4* __restrict__ sa = reinterpret_cast<const float4*>(xn + ((size_t)(oka ? gy : 0) * W + (oka ? gxa : 0)) * CIN);
+    const float4* __restrict__ sb = reinterpret_cast<const float4*>(xn + ((size_t)(okb ? gy : 0) * W + (okb ? gxb : 0)) * CIN);
     const float* __restrict__ wt = wpk + tap * CIN * COUT;
 #pragma unroll 1
-    for (int c4 = 0; c4 < CIN / 4; ++c4) {                    // runtime loop: 4 x COUT wave-uniform weights in flight, no SGPR spills
-      const float4 v4 = src[c4];
-      float v[4] = {v4.x, v4.y, v4.z, v4.w};
+    for (int c4 = 0; c4 < CIN / 4; ++c4) {
+      const float4 a4 = sa[c4], b4 = sb[c4];
+      const float va[4] = {a4.x, a4.y, a4.z, a4.w}, vb[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll 1
+      for (int h = 0; h < 4 / CSTEP; ++h) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int ci = c4 * 4 + j;
-        float t = v[j];
-        if (aff) {
-          t = t * aff[3 * ci] + aff[3 * ci + 1];
-          t = t > 0.f ? t : t * aff[3 * ci + 2];
+        for (int j = 0; j < CSTEP; ++j) {
+          const int ci = c4 * 4 + h * CSTEP + j;
+          float ta = CSTEP == 4 ? va[j] : (h ? va[2 + j] : va[j]);
+          float tb = CSTEP == 4 ? vb[j] : (h ? vb[2 + j] : vb[j]);
+          if (aff) {
+            ta = affine_leaky(ta, aff, ci);
+            tb = affine_leaky(tb, aff, ci);
+          }
+          ta = oka ? ta : 0.f;                                 // zero padding follows the normalisation
+          tb = okb ? tb : 0.f;
+          const float* __restrict__ wc = wt + ci * COUT;
+#pragma unroll
+          for (int c = 0; c < COUT; ++c) {
+            const float wv = wc[c];
+            acc0[c] = fmaf(ta, wv, acc0[c]);
+            acc1[c] = fmaf(tb, wv, acc1[c]);
+          }
         }
-        t = ok ? t : 0.f;                                     // zero padding follows the normalisation
-        const float* __restrict__ wc = wt + ci * COUT;
-#pragma unroll
-        for (int c = 0; c < COUT; ++c) acc[c] = fmaf(t, wc[c], acc[c]);
       }
     }
   }
-  float4* o4 = reinterpret_cast<float4*>(out + ((size_t)n * Ho * Wo + p) * COUT);
+  float4* o4 = reinterpret_cast<float4*>(out + (((size_t)n * Ho + oy) * Wo + ox) * COUT);
 #pragma unroll
-  for (int c = 0; c < COUT; c += 4) o4[c >> 2] = make_float4(acc[c], acc[c + 1], acc[c + 2], acc[c + 3]);
+  for (int c = 0; c < COUT; c += 4) o4[c >> 2] = make_float4(acc0[c], acc0[c + 1], acc0[c + 2], acc0[c + 3]);
+  if (has2) {
+#pragma unroll
+    for (int c = 0; c < COUT; c += 4) o4[(COUT + c) >> 2] = make_float4(acc1[c], acc1[c + 1], acc1[c + 2], acc1[c + 3]);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // FPN lateral (module.py:253-254,260-261): 1x1 convolution over cat(nearest2x(coarse), skip), channels-last, neither tensor
-// materialised; each source has its own optional normalise-on-load table.  Thread = PXT pixels, 256 apart (consecutive lanes read
-// consecutive texels); COUT accumulators; weights [Ca + Cb][COUT] through the scalar cache.
-// InstanceNorm records of the output: fp64 sums per thread over its PXT pixels, one wave reduction per channel.
+// materialised; each source has its own optional normalise-on-load table.  Thread = one 2 x 2 block of output pixels = ONE coarse
+// texel: the coarse half of the fmaf chain (the first Ca channels of the concatenation) is the same for the four pixels and is
+// computed once; the skip half continues it per pixel - the chain order of conv2d_kernel<1,...> on the materialised concatenation,
+// bit-identical results.  A row of the block is two adjacent texels = 2 Cb contiguous floats per lane, consecutive lanes consecutive
+// blocks; every wave-uniform weight ([Ca + Cb][COUT], scalar cache) of the skip half feeds two multiply-adds.  InstanceNorm records:
+// fp64 sums per thread over its FPN_NB blocks, one wave reduction per channel at the end.
 // ---------------------------------------------------------------------------------------------------------------------------
-constexpr int FPN_PXT = 4;
+constexpr int FPN_NB = 2;
 template <int CA, int CB, int COUT>
 __global__ __launch_bounds__(256) void fpn_lateral_cl_kernel(const float* __restrict__ xa, const float* __restrict__ affa,
                                                              const float* __restrict__ xb, const float* __restrict__ affb,
                                                              const float* __restrict__ wpk, float* __restrict__ out,
                                                              double* __restrict__ partial, int H, int W) {
   const int n = blockIdx.y;
-  const int hw = H * W, Hc = H >> 1, Wc = W >> 1;
+  const int Hc = H >> 1, Wc = W >> 1, nblk = Hc * Wc;
   const float* __restrict__ fa = affa ? affa + (size_t)n * CA * 3 : nullptr;
   const float* __restrict__ fb = affb ? affb + (size_t)n * CB * 3 : nullptr;
-  xa += (size_t)n * Hc * Wc * CA;
-  xb += (size_t)n * hw * CB;
-  out += (size_t)n * hw * COUT;
+  xa += (size_t)n * nblk * CA;
+  xb += (size_t)n * H * W * CB;
+  out += (size_t)n * H * W * COUT;
   double ds[COUT], dq[COUT];
 #pragma unroll
   for (int c = 0; c < COUT; ++c) ds[c] = dq[c] = 0.0;
-  const int base = blockIdx.x * (256 * FPN_PXT) + threadIdx.x;
 #pragma unroll 1
-  for (int jp = 0; jp < FPN_PXT; ++jp) {
-    const int p = base + 256 * jp;
-    if (p >= hw) break;
-    const int oy = p / W, ox = p - oy * W;
-    float acc[COUT];
-#pragma unroll
-    for (int c = 0; c < COUT; ++c) acc[c] = 0.f;
+  for (int it = 0; it < FPN_NB; ++it) {
+    const int bi = (blockIdx.x * FPN_NB + it) * 256 + threadIdx.x;
+    if (bi >= nblk) break;
+    const int by = bi / Wc, bx = bi - by * Wc;
     int zero = 0;
-    asm volatile("" : "+s"(zero));                             // opaque 0: the weights are re-read per pixel through the scalar cache
-    const float* __restrict__ wp = wpk + zero;                 // instead of being hoisted out of the loop into 768 (spilled) SGPRs
-    const float4* __restrict__ sa = reinterpret_cast<const float4*>(xa + ((size_t)(oy >> 1) * Wc + (ox >> 1)) * CA);
+    asm volatile("" : "+s"(zero));                             // opaque 0: the weights are re-read per block through the scalar cache
+    const float* __restrict__ wp = wpk + zero;                 // instead of being hoisted out of the loop into hundreds of (spilled) SGPRs
+    float base[COUT];
+#pragma unroll
+    for (int c = 0; c < COUT; ++c) base[c] = 0.f;
+    const float4* __restrict__ sa = reinterpret_cast<const float4*>(xa + (size_t)bi * CA);
 #pragma unroll 1
     for (int c4 = 0; c4 < CA / 4; ++c4) {
       const float4 v4 = sa[c4];
-      float v[4] = {v4.x, v4.y, v4.z, v4.w};
+      const float v[4] = {v4.x, v4.y, v4.z, v4.w};
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int ci = c4 * 4 + j;
-        float t = v[j];
-        if (fa) {
-          t = t * fa[3 * ci] + fa[3 * ci + 1];
-          t = t > 0.f ? t : t * fa[3 * ci + 2];
-        }
+        const float t = fa ? affine_leaky(v[j], fa, ci) : v[j];
         const float* __restrict__ wc = wp + ci * COUT;
 #pragma unroll
-        for (int c = 0; c < COUT; ++c) acc[c] = fmaf(t, wc[c], acc[c]);
+        for (int c = 0; c < COUT; ++c) base[c] = fmaf(t, wc[c], base[c]);
       }
     }
-    const float4* __restrict__ sb = reinterpret_cast<const float4*>(xb + (size_t)p * CB);
 #pragma unroll 1
-    for (int c4 = 0; c4 < CB / 4; ++c4) {
-      const float4 v4 = sb[c4];
-      float v[4] = {v4.x, v4.y, v4.z, v4.w};
+    for (int r = 0; r < 2; ++r) {
+      const size_t p = (size_t)(2 * by + r) * W + 2 * bx;      // pixels p, p + 1
+      float acc0[COUT], acc1[COUT];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int ci = c4 * 4 + j;
-        float t = v[j];
-        if (fb) {
-          t = t * fb[3 * ci] + fb[3 * ci + 1];
-          t = t > 0.f ? t : t * fb[3 * ci + 2];
+      for (int c = 0; c < COUT; ++c) acc0[c] = acc1[c] = base[c];
+      const float4* __restrict__ sb = reinterpret_cast<const float4*>(xb + p * CB);
+#pragma unroll 1
+      for (int c4 = 0; c4 < CB / 4; ++c4) {
+        const float4 a4 = sb[c4], b4 = sb[CB / 4 + c4];
+        const float va[4] = {a4.x, a4.y, a4.z, a4.w}, vb[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int ci = c4 * 4 + j;
+          const float ta = fb ? affine_leaky(va[j], fb, ci) : va[j];
+          const float tb = fb ? affine_leaky(vb[j], fb, ci) : vb[j];
+          const float* __restrict__ wc = wp + (CA + ci) * COUT;
+#pragma unroll
+          for (int c = 0; c < COUT; ++c) {
+            const float wv = wc[c];
+            acc0[c] = fmaf(ta, wv, acc0[c]);
+            acc1[c] = fmaf(tb, wv, acc1[c]);
+          }
         }
-        const float* __restrict__ wc = wp + (CA + ci) * COUT;
-#pragma unroll
-        for (int c = 0; c < COUT; ++c) acc[c] = fmaf(t, wc[c], acc[c]);
       }
-    }
-    float4* o4 = reinterpret_cast<float4*>(out + (size_t)p * COUT);
+      float4* o4 = reinterpret_cast<float4*>(out + p * COUT);
 #pragma unroll
-    for (int c = 0; c < COUT; c += 4) o4[c >> 2] = make_float4(acc[c], acc[c + 1], acc[c + 2], acc[c + 3]);
-    if (partial) {
+      for (int c = 0; c < COUT; c += 4) {
+        o4[c >> 2] = make_float4(acc0[c], acc0[c + 1], acc0[c + 2], acc0[c + 3]);
+        o4[(COUT + c) >> 2] = make_float4(acc1[c], acc1[c + 1], acc1[c + 2], acc1[c + 3]);
+      }
+      if (partial) {
 #pragma unroll
-      for (int c = 0; c < COUT; ++c) {
-        const double dv = (double)acc[c];
-        ds[c] += dv;
-        dq[c] += dv * dv;
+        for (int c = 0; c < COUT; ++c) {
+          const double d0 = (double)acc0[c], d1 = (double)acc1[c];
+          ds[c] += d0 + d1;
+          dq[c] += d0 * d0 + d1 * d1;
+        }
       }
     }
   }
@@ -656,7 +727,7 @@ extern "C" int cds_conv2d_k3s2_cl_f32(const float* x, const float* in_affine, co
                                       int Cout, int H, int W, void* stream) {
   if (!x || !weight || !out || N < 1 || H < 1 || W < 1) return CDS_EINVAL;
   const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
-  const dim3 grid(cds_ceil_div(Ho * Wo, 256), N);
+  const dim3 grid(cds_ceil_div(Ho * ((Wo + 1) / 2), 256), N);
   hipStream_t st = (hipStream_t)stream;
   if (Cin == 8 && Cout == 16)
     hipLaunchKernelGGL((conv2d_k3s2_cl_kernel<8, 16>), grid, dim3(256), 0, st, x, in_affine, weight, out, H, W, Ho, Wo);
@@ -667,7 +738,7 @@ extern "C" int cds_conv2d_k3s2_cl_f32(const float* x, const float* in_affine, co
   return cds_launch_status();
 }
 
-extern "C" int cds_fpn_cl_parts(int H, int W) { return 4 * cds_ceil_div(H * W, 256 * FPN_PXT); }
+extern "C" int cds_fpn_cl_parts(int H, int W) { return 4 * cds_ceil_div((H / 2) * (W / 2), 256 * FPN_NB); }
 
 // FPN lateral on channels-last activations: out [N][H][W][Cout] = 1x1 conv of cat(nearest2x(coarse [N][H/2][W/2][Ca]), skip
 // [N][H][W][Cb]); weight [Ca + Cb][Cout] (coarse channels first); affine tables [N][Ca][3] / [N][Cb][3] or NULL; partial NULL or
@@ -676,7 +747,7 @@ extern "C" int cds_conv2d_fpn_cl_f32(const float* coarse, const float* coarse_af
                                      const float* weight, float* out, double* partial, int N, int Ca, int Cb, int Cout, int H, int W,
                                      void* stream) {
   if (!coarse || !skip || !weight || !out || N < 1 || H < 2 || W < 2 || (H & 1) || (W & 1)) return CDS_EINVAL;
-  const dim3 grid(cds_ceil_div(H * W, 256 * FPN_PXT), N);
+  const dim3 grid(cds_ceil_div((H / 2) * (W / 2), 256 * FPN_NB), N);
   hipStream_t st = (hipStream_t)stream;
   if (Ca == 32 && Cb == 16 && Cout == 16)
     hipLaunchKernelGGL((fpn_lateral_cl_kernel<32, 16, 16>), grid, dim3(256), 0, st, coarse, coarse_affine, skip, skip_affine, weight, out,
@@ -723,3 +794,4 @@ extern "C" int cds_instnorm_apply_cl_f32(const float* x, const double* stats, fl
   else return CDS_EINVAL;
   return cds_launch_status();
 }
+

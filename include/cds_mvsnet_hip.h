@@ -389,6 +389,10 @@ int cds_instnorm_affine_f32(const float* x, float* affine, float* stats, int N, 
  *   into out_cl [N - cl_from][H][W][C] (or NULL), the first n_chw images planar into out_chw [n_chw][C][H][W] (the reference-view
  *   feature maps K1 / K3 read).
  */
+/* Debug aid: synchronise the device and fill the LDS of every CU with `pattern` (see csrc/lib.hip; CDS_DEBUG_POISON_LDS=<hex> makes
+ * every entry point do this after its launch). */
+int cds_debug_poison_lds(unsigned pattern);
+
 int cds_dynconv_cl_parts(int H, int W);
 int cds_dynconv_cl_f32(const float* x, const float* in_affine, const void* weight_split, const float* bias, const float* w1,
                        const float* b1, const float* w2, const float* epipoles_host, float temperature, float* out,

@@ -1,0 +1,100 @@
+"""Which kernel, running on another stream, perturbs K1 (warp_entropy)?  Victim on stream A, aggressor on stream B, the victim's
+output compared bit for bit with its output in isolation."""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from cds_mvsnet_amd import ops, synth, geometry
+from cds_mvsnet_amd.model import _pack2d
+dev = torch.device("cuda")
+if os.environ.get("AGGR_FILL_TAPS"):
+    # experiment: the padded taps (beyond k^2) of the weight operand are 1.0 in every row instead of 0 (the kernel variant zeroes the data)
+    def _pack_taps(ws):
+        Co3, Cin = ws[0].shape[:2]
+        rounds, nblk = Cin // 8, (Co3 + 15) // 16
+        parts = []
+        for w in ws:
+            k = w.shape[-1]
+            nks = (k * k + 3) // 4
+            taps = torch.ones((nblk * 16, rounds, nks * 4, 8), dtype=torch.float32, device=w.device)
+            taps[:, :, :k * k] = 0.0
+            taps[:Co3, :, :k * k] = w.detach().float().reshape(Co3, rounds, 8, k * k).permute(0, 1, 3, 2)
+            if os.environ["AGGR_FILL_TAPS"] == "rows":
+                taps[Co3:, :, :k * k] = taps[:1, :, :k * k]
+            parts.append(taps.reshape(nblk, 16, rounds, nks, 4, 8).permute(2, 3, 0, 4, 1, 5).reshape(rounds, nks, nblk, 64, 8))
+        return ops._split3(torch.cat(parts, dim=1))
+    ops.split_pack_dynconv = _pack_taps
+if os.environ.get("AGGR_FILL_PAD"):
+    # experiment: no all-zero rows in the weight (A) operand: the padded output channels repeat channel 0
+    _orig_pack = ops.split_pack_dynconv
+    def _pack_filled(ws):
+        Co3 = ws[0].shape[0]
+        pad = (-Co3) % 16
+        mode = os.environ["AGGR_FILL_PAD"]
+        if mode == "rows":
+            ws2 = [torch.cat([w] + [w[:1]] * pad, 0) for w in ws]
+        else:   # "quad": only make the LAST row of the block nonzero (does one nonzero row per 4-row group suffice?)
+            ws2 = [torch.cat([w, torch.zeros_like(w[:1]).repeat(pad - 1, 1, 1, 1), w[:1]], 0) if pad > 1 else torch.cat([w, w[:1]], 0) for w in ws]
+        out = _orig_pack(ws2)
+        return out
+    ops.split_pack_dynconv = _pack_filled
+g = torch.Generator().manual_seed(0)
+# victim: stage-1 K1 of the 1600x1184 cascade
+V, C, D, h, w = 4, 32, 48, 296, 400
+feats = synth.make_pair_features(V, C, h, w, seed=1)
+cams = synth.stage_cameras(V + 1, h, w, seed=0)
+hyp = synth.make_hypotheses(D, h, w, seed=1)[0].to(dev).contiguous()
+ref = torch.stack([f["ref"][0][0] for f in feats]).to(dev).contiguous()
+src = torch.stack([ops.chw_to_hwc(f["src"][0][0].to(dev).contiguous()) for f in feats])
+mats = geometry.warp_matrices(cams[0])
+victim = lambda: ops.warp_entropy(ref, src, mats, hyp)
+want = victim().clone()
+torch.cuda.synchronize()
+
+def dyn_setup(c, ks, N, H, W, cl):
+    K, co3 = len(ks), c + 3
+    x = torch.randn(N, c, H, W, generator=g).to(dev)
+    xcl = x.permute(0, 2, 3, 1).contiguous()
+    aff = torch.stack((0.5 + torch.rand(N, c, generator=g), 0.3 * torch.randn(N, c, generator=g), torch.full((N, c), 0.1)), -1).to(dev).contiguous()
+    wsp = ops.split_pack_dynconv([(torch.randn(co3, c, k, k, generator=g) / (c * k * k) ** 0.5).to(dev) for k in ks])
+    w1, b1, w2 = torch.randn(4, K, generator=g).to(dev), torch.randn(4, generator=g).to(dev), torch.randn(K, 4, generator=g).to(dev)
+    epi = torch.tensor([[W * 0.3 + 5.0 * n, -H * 1.7 - n] for n in range(N)], dtype=torch.float32)
+    if cl:
+        return lambda: ops.dynconv_cl(xcl, wsp, None, ks, w1, b1, w2, epi, 0.01, 0.1, in_affine=aff)
+    return lambda: ops.dynconv_fused_sbf(x, wsp, None, c, ks, w1, b1, w2, epi, 0.01, 0.1, in_affine=aff)
+
+N = 8
+aggr = {}
+for name, c, ks, H, W in (("conv01", 8, (3, 5, 7), 592, 800), ("conv10", 16, (3, 5), 592, 800), ("conv20", 32, (1, 3), 296, 400), ("out2", 16, (1, 3), 592, 800),
+                          ("out3", 8, (1, 3), 592, 800)):
+    aggr["cl " + name] = dyn_setup(c, ks, N, H, W, True)
+    aggr["planar " + name] = dyn_setup(c, ks, N, H, W, False)
+xa, xb = torch.randn(N, 296, 400, 32, generator=g).to(dev), torch.randn(N, 592, 800, 16, generator=g).to(dev)
+wt = torch.randn(48, 16, generator=g).to(dev)
+aggr["cl fpn inner1"] = lambda: ops.conv2d_fpn_cl(xa, xb, wt, 16, None, None, 0.1)
+w9 = torch.randn(9, 16, 32, generator=g).to(dev)
+aggr["cl downsample2"] = lambda: ops.conv2d_k3s2_cl(xb, w9, 32, None)
+aggr["cl instnorm stats"] = lambda: ops.instnorm_stats_cl(xb, 0.1)
+st = ops.instnorm_stats_cl(xb, 0.1)[0]
+aggr["cl instnorm apply"] = lambda: ops.instnorm_apply_cl(xb, st, ops.ACT_TANH, 4, cl_from=4)
+aggr["victim itself"] = victim
+big = torch.randn(64 * 1024 * 1024, device=dev)
+aggr["torch copy 256 MB"] = lambda: big.clone()
+sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+only = os.environ.get("AGGR_ONLY")
+for name, fn in aggr.items():
+    if only and not name.startswith(only):
+        continue
+    fn(); torch.cuda.synchronize()
+    bad = tot = 0
+    for rep in range(3):
+        with torch.cuda.stream(sb):
+            for _ in range(6):
+                fn()
+        outs = []
+        with torch.cuda.stream(sa):
+            for _ in range(12):
+                outs.append(victim())
+        torch.cuda.synchronize()
+        for o in outs:
+            tot += 1
+            bad += int(not torch.equal(o, want))
+    print(f"aggressor {name:22s}: victim outputs differing from isolation: {bad} / {tot}")

@@ -31,9 +31,9 @@ def _affine(N, C, g):
                                              (8, (1, 3), 1, 8, 64, True), (16, (3, 5), 1, 40, 100, False), (16, (1, 3), 2, 17, 33, True),
                                              (32, (1, 3), 1, 24, 70, True), (8, (3, 5, 7), 1, 5, 7, False)])
 def test_dynconv_cl_equals_planar_fused(c, ks, N, H, W, bias, dev, ops):
-    """cds_dynconv_cl_f32 against cds_dynconv_fused_sbf_f32 (planar, W % 4 == 0) or branches + blend (any W): the same split-bf16
-    products accumulated in the same order with the operand roles swapped, the same epilogue arithmetic (feat_common.hpp): blended
-    output and norm-curvature agree to a few ulp (bit-identical in practice), the InstanceNorm statistics to fp64 regrouping.
+    """cds_dynconv_cl_f32 against cds_dynconv_fused_sbf_f32 (planar, W % 4 == 0) or branches + blend (any W): the same K-loop and
+    epilogue arithmetic (feat_common.hpp) on another activation layout: blended output and norm-curvature bit-identical, the
+    InstanceNorm statistics to fp64 regrouping.
     Partial tiles, widths that are not multiples of 4, tiles smaller than the halo, several images, both temperatures."""
     g = torch.Generator().manual_seed(c * 3 + len(ks) + H)
     K = len(ks)
@@ -177,3 +177,31 @@ def test_feature_runner_layouts_agree(dev, ops, monkeypatch):
             assert a[j].shape == b[j].shape, (s, j, a[j].shape, b[j].shape)
             err = (a[j] - b[j]).abs()
             assert err.mean().item() < 2e-6 and err.max().item() < 2e-3, (s, j, err.mean().item(), err.max().item())
+
+
+@pytest.mark.parametrize("c,ks,N,H,W", [(8, (1, 3), 8, 592, 800), (8, (3, 5, 7), 8, 296, 400), (16, (3, 5), 8, 296, 400), (16, (1, 3), 8, 296, 400),
+                                        (32, (1, 3), 8, 296, 400)])
+def test_dynconv_cl_is_bit_stable_at_scale(c, ks, N, H, W, dev, ops):
+    """Thousands of workgroups (several per CU, in different phases: MFMA K-loops beside epilogues), four repetitions, every output
+    bit compared with the unfused planar path (branches kernel + blend kernel).  Round 5: the first form of this kernel (transposed
+    GEMM, weights from global loads as the MFMA's A operand) produced wrong values in lanes 48-63 for about one 16-pixel tile in 10^4
+    - in its own waves and in OTHER kernels sharing the CU - only at this scale, differently in every run; small-shape tests never
+    saw it (profiles/r05_experiments.md)."""
+    g = torch.Generator().manual_seed(c + len(ks))
+    K, co3 = len(ks), c + 3
+    x = torch.randn(N, c, H, W, generator=g).to(dev)
+    xcl = _cl(x)
+    aff = _affine(N, c, g).to(dev)
+    wsp = ops.split_pack_dynconv([(torch.randn(co3, c, k, k, generator=g) / (c * k * k) ** 0.5).to(dev) for k in ks])
+    w1, b1, w2 = torch.randn(4, K, generator=g).to(dev), torch.randn(4, generator=g).to(dev), torch.randn(K, 4, generator=g).to(dev)
+    epi = torch.tensor([[W * 0.3 + 5.0 * n, -H * 1.7 - n] for n in range(N)], dtype=torch.float32)
+    for T in (1.0, 0.01):
+        br = ops.dynconv_branches_sbf(x, wsp, None, co3, ks, in_affine=aff)
+        o2, n2, _, _ = ops.dynconv_blend(br, w1, b1, w2, epi, T, 1, stats_slope=0.1)
+        del br
+        for rep in range(4):
+            o1, n1, _, _ = ops.dynconv_cl(xcl, wsp, None, ks, w1, b1, w2, epi, T, 0.1, in_affine=aff)
+            bad = int((o1.permute(0, 3, 1, 2) != o2).sum()), int((n1 != n2).sum())
+            assert bad == (0, 0), (T, rep, bad)
+        o3, n3, _, _ = ops.dynconv_fused_sbf(x, wsp, None, c, ks, w1, b1, w2, epi, T, 0.1, in_affine=aff)
+        assert torch.equal(o3, o2) and torch.equal(n3, n2)          # the planar fused kernel as well

@@ -208,3 +208,4 @@ def test_restricted_unpickler_does_not_resolve_load_from_bytes():
             return (torch.storage._load_from_bytes, (b"not a checkpoint",))
     obj = _placeholder_pickle.load(io.BytesIO(pickle.dumps(Evil())))
     assert isinstance(obj, _Opaque)
+

@@ -148,7 +148,8 @@ def test_side_stream_is_refused_when_parameters_are_used_twice():
         for _ in range(2):
             l, d = T.train_step(model, opt, sample, temperature=0.1)
             assert np.isfinite(l)
-        assert T._SIDE_VERDICT[model] == ((False,), False)
+        key, sound = T._SIDE_VERDICT[model]
+        assert key[0] is False and sound is False
     finally:
         training.BATCH_FEATURES = old
 
