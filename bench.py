@@ -178,6 +178,7 @@ def other_workloads(model, dev):
             # best of three 3-iteration batches: the first passes at a new size occasionally pay for allocator growth
             out[key] = min(timeit(lambda: model(imgs, pm, dv, temperature=0.01), n=3, warm=2 if r == 0 else 0) for r in range(3))
             del imgs
+        k3 = k3_stage_rooflines(model, dev)
     # BASELINE configs[4] on one GPU: the BlendedMVS training step (768x576, N=5, refine, fp32: forward + final_loss + backward +
     # SGD; the weight-gradient side stream is audited on the first step) -- the driver-timed figure of SURVEY 8(f)-2
     from cds_mvsnet_amd import CDSMVSNet, seeded_init_, train as T
@@ -188,7 +189,52 @@ def other_workloads(model, dev):
     out["T5_train_step_768x576_N5_fp32_ms"] = min(timeit(lambda: T.train_step(tmodel, opt, sample, temperature=0.1), n=5, warm=3 if r == 0 else 0)
                                                  for r in range(2))
     del tmodel, opt, sample
-    return {k: round(v, 3) for k, v in out.items()}
+    res = {k: round(v, 3) for k, v in out.items()}
+    res["M3_K3_roofline_by_stage"] = k3
+    return res
+
+
+def k3_stage_rooflines(model, dev, H=1184, W=1600, n_views=5):
+    """`roofline` objects of the fused warp + aggregation kernel (K3) at the three stage shapes of the BASELINE config-3
+    cascade (C = 32 / 16 / 8: 1.94 ms of an 18 ms forward), with the cascade's own hypothesis ranges (stage 1: the 48 planes of the
+    whole depth range; stages 2 / 3: 32 / 8 planes at 1.5 / 0.75 intervals around a smooth depth map).  HIP events on the launch stream,
+    median of 7 launches after 2 warm-ups; algorithmic bytes per SURVEY 8(d)."""
+    import statistics
+    from cds_mvsnet_amd import geometry, ops, synth
+    out = {}
+    V = n_views - 1
+    g = torch.Generator().manual_seed(5)
+    for s, (sc, D, C, ratio) in enumerate(zip((4, 2, 1), NDEPTHS, STAGE_C, RATIOS)):
+        h, w = H // sc, W // sc
+        feats = synth.make_pair_features(V, C, h, w, seed=11 + s)
+        cams = synth.stage_cameras(n_views, h, w, seed=s)
+        if s == 0:
+            hyp = torch.linspace(425.0, 902.5, D).view(D, 1, 1).expand(D, h, w).contiguous()
+        else:
+            base = 600.0 + 120.0 * torch.nn.functional.interpolate(torch.rand(1, 1, 6, 8, generator=g), (h, w), mode="bicubic",
+                                                                   align_corners=False)[0, 0]
+            hyp = (base.unsqueeze(0) + (torch.arange(D, dtype=torch.float32).view(D, 1, 1) - (D - 1) // 2) * (ratio * 2.5)).contiguous()
+        ref = torch.stack([f["ref"][0][0] for f in feats]).to(dev).contiguous()
+        src = torch.stack([ops.chw_to_hwc(f["src"][0][0].to(dev).contiguous()) for f in feats])
+        vis = (torch.rand(V, h, w, generator=g) * 0.9 + 0.05).to(dev)
+        mats, hyp_d = geometry.warp_matrices(cams[0]), hyp.to(dev)
+        ts = []
+        for i in range(9):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            vol, _ = ops.warp_aggregate(ref, src, vis, mats, hyp_d, channels_last=True)
+            b.record()
+            b.synchronize()
+            if i >= 2:
+                ts.append(a.elapsed_time(b))
+            del vol
+        ms = statistics.median(ts)
+        b_alg = algorithmic_bytes(h, w, D, C, n_views)
+        out[f"stage{s + 1}"] = {"shape": f"{w}x{h}, D={D}, C={C}, N={n_views}", "kernel_ms": round(ms, 4), "algorithmic_bytes": b_alg,
+                               "bound": "hbm", "achieved": round(b_alg / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                               "frac": round(b_alg / (ms * 1e-3) / HBM_PEAK, 4)}
+        del ref, src, vis, hyp_d
+    return out
 
 
 def cpu_baseline(model_cpu, name, budget_frac, seed=0, gpu_depth=None):
@@ -323,28 +369,37 @@ def measure_viewshard(model, dev, dist, rank, world, exchange, stage_name="M1", 
     workload through `ViewShardedStage`, (ii) the BASELINE config-4 cascade through `shard_views(model)`.  Same
     bracket as the headline: barrier + synchronize on both sides, max over ranks."""
     from cds_mvsnet_amd import distributed as cdist, ops, synth
+    import datetime
+    # the side measurement runs in its OWN communicator with a short collective timeout: a rank that fails alone inside one of the modes
+    # (never run on RCCL hardware so far) leaves the others stuck for two minutes, not for the ten of the default group
+    grp = dist.new_group(ranks=list(range(dist.get_world_size())), timeout=datetime.timedelta(minutes=2))
 
     def timed(fn, n, warm):
         for _ in range(warm):
             fn()
         ops.PROFILE.clear()
+        ops.PROFILE_HOST_MS.clear()
         ops.PROFILE_ON = True
-        dist.barrier(); torch.cuda.synchronize()
+        dist.barrier(group=grp); torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(n):
             fn()
-        dist.barrier(); torch.cuda.synchronize()
+        dist.barrier(group=grp); torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         ops.PROFILE_ON = False
         t = torch.tensor([dt], device=dev if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=grp)
         kern = {k: sum(a.elapsed_time(b) for a, b in v) / n for k, v in ops.PROFILE.items() if v}
+        for k, v in ops.PROFILE_HOST_MS.items():          # host-timed sections (gloo dry run of the halo exchange)
+            kern.setdefault(k, sum(v) / n)
+        kern["_halo_exchanges_timed"] = (len(ops.PROFILE.get("halo_exchange", ())) or len(ops.PROFILE_HOST_MS.get("halo_exchange", ()))) / n
         return float(t.item()) / n * 1e3, kern
 
     out = {"ranks": dist.get_world_size(), "backend": dist.get_backend(), "exchange": exchange,
            "NCCL_ALGO": os.environ.get("NCCL_ALGO"), "NCCL_PROTO": os.environ.get("NCCL_PROTO"),
            "collective": "one fp32 SUM all-reduce of volume_sum ++ vis_sum ++ nc_sum per stage (models/model.py:57-60,74)"}
     # self-check of the first RCCL run: one rank per GPU in ONE communicator, and that communicator is RCCL
+    assert dist.get_world_size() == world, f"communicator of {dist.get_world_size()} ranks on a --gpus {world} run"
     out["self_check"] = {"ranks_equal_n_gpus": dist.get_world_size() == world, "backend_is_nccl": dist.get_backend() == "nccl"}
     if dev.type == "cuda" and torch.cuda.device_count() >= world and not all(out["self_check"].values()):
         raise RuntimeError(f"viewshard self-check failed: {out['self_check']} (ranks {dist.get_world_size()}, N {world}, "
@@ -362,7 +417,7 @@ def measure_viewshard(model, dev, dist, rank, world, exchange, stage_name="M1", 
             stage = {8: 2, 16: 1, 32: 0}[C]
             _, cams, hyp, dfe = make_workload(stage_name, 0, dev)
             hyp_d = hyp.to(dev)
-            runner = cdist.ViewShardedStage(model, dist.group.WORLD, exchange=exch)
+            runner = cdist.ViewShardedStage(model, grp, exchange=exch)
             ms, kern = timed(lambda: runner(dfe, cams, hyp_d, D, stage), 5, 2)
             nbytes = 4 * cdist.ViewShard.flat_size(C, D, h, w)
             res["stage"] = {"workload": f"{stage_name}: {w}x{h}, D={D}, C={C}, N={n_views}", "ms_per_depth_map": ms,
@@ -371,7 +426,9 @@ def measure_viewshard(model, dev, dist, rank, world, exchange, stage_name="M1", 
                             "exchange_ms": kern.get(key), "local_source_views": len(runner.shard.local_views(n_views - 1)),
                             "halo_exchanges_per_depth_map": runner.shard.halo_exchanges // max(1, runner.shard.exchanges),
                             "halo_bytes_sent_per_rank": runner.shard.halo_bytes // max(1, runner.shard.exchanges),
-                            "kernel_ms": {k: round(v, 4) for k, v in sorted(kern.items())}}
+                            "halo_exchange_us_measured": (1e3 * kern["halo_exchange"] / kern["_halo_exchanges_timed"]
+                                                          if kern.get("halo_exchange") and kern.get("_halo_exchanges_timed") else None),
+                            "kernel_ms": {k: round(v, 4) for k, v in sorted(kern.items()) if not k.startswith("_")}}
             if key == "allreduce" and kern.get("allreduce"):
                 res["stage"]["allreduce_busbw_GBps"] = 2.0 * (world - 1) / world * nbytes / (kern["allreduce"] * 1e-3) / 1e9
             del dfe, hyp_d, runner
@@ -379,7 +436,7 @@ def measure_viewshard(model, dev, dist, rank, world, exchange, stage_name="M1", 
             imgs = synth.make_images(nv, H, W, seed=0).to(dev)
             pm = synth.make_cameras(nv, H, W, refine=False, seed=0)
             dv = synth.make_depth_values()
-            sh = cdist.shard_views(model, dist.group.WORLD, exchange=exch)
+            sh = cdist.shard_views(model, grp, exchange=exch)
             try:
                 ms, kern = timed(lambda: model(imgs, pm, dv, temperature=0.01), 3, 2)
             finally:
@@ -389,7 +446,9 @@ def measure_viewshard(model, dev, dist, rank, world, exchange, stage_name="M1", 
             res["cascade"] = {"workload": f"{cascade_name}: cascade {W}x{H}, N={nv}, D={NDEPTHS}", "ms_per_depth_map": ms,
                               "depth_maps_per_s": 1e3 / ms, "volume_bytes": bytes_per_map, "exchanges_per_depth_map": 3,
                               "exchange_ms": kern.get(key), "local_source_views": len(sh.local_views(nv - 1)),
-                              "kernel_ms": {k: round(v, 4) for k, v in sorted(kern.items())}}
+                              "halo_exchange_us_measured": (1e3 * kern["halo_exchange"] / kern["_halo_exchanges_timed"]
+                                                            if kern.get("halo_exchange") and kern.get("_halo_exchanges_timed") else None),
+                              "kernel_ms": {k: round(v, 4) for k, v in sorted(kern.items()) if not k.startswith("_")}}
             if key == "allreduce" and kern.get("allreduce"):
                 res["cascade"]["allreduce_busbw_GBps"] = 2.0 * (world - 1) / world * bytes_per_map / (kern["allreduce"] * 1e-3) / 1e9
         return res
@@ -411,7 +470,36 @@ def measure_viewshard(model, dev, dist, rank, world, exchange, stage_name="M1", 
     # pixel slabs: no volume on any link (view-sharded FeatureNet + all-gather of the feature maps, then all views for own rows)
     out["slab"] = guarded("slab", "all-gather of the per-view feature maps (cascade only), 11 one-row halo exchanges per stage, gather of "
                           "3 h w floats; no cost volume crosses a link")
+    # the RCCL algorithm / protocol actually in force: what the environment pins, else RCCL's own choice (NCCL_DEBUG=INFO prints it per
+    # communicator; the bench does not parse logs)
+    out["rccl"] = {"NCCL_ALGO": os.environ.get("NCCL_ALGO") or "unset (RCCL chooses per message size)",
+                   "NCCL_PROTO": os.environ.get("NCCL_PROTO") or "unset", "NCCL_DEBUG": os.environ.get("NCCL_DEBUG") or "unset",
+                   "version": out.get("rccl_version")}
     return out
+
+
+def strong_scaling_summary(vs):
+    """Top-level view of the north-star measurement: ms per depth map of ONE depth map sharded over the ranks, per
+    exchange mode, for the single-stage M1 workload and the config-4 cascade - next to the `replicas` headline, so that the first
+    N-GPU run explains itself.  Keys exist on every N > 1 line (None where a mode failed; its error is in `viewshard`)."""
+    def pick(obj, part):
+        try:
+            return round(float(obj[part]["ms_per_depth_map"]), 4)
+        except Exception:      # noqa: BLE001
+            return None
+    def halo(obj, part):
+        try:
+            v = obj[part]["halo_exchange_us_measured"]
+            return None if v is None else round(float(v), 2)
+        except Exception:      # noqa: BLE001
+            return None
+    s = {"ranks": vs.get("ranks"), "backend": vs.get("backend"), "rccl": vs.get("rccl"),
+         "stage_M1_ms_per_depth_map": {"allreduce": pick(vs, "stage"), "reduce_scatter": pick(vs.get("reduce_scatter", {}), "stage"),
+                                       "slab": pick(vs.get("slab", {}), "stage")},
+         "cascade_M4_ms_per_depth_map": {"allreduce": pick(vs, "cascade"), "reduce_scatter": pick(vs.get("reduce_scatter", {}), "cascade"),
+                                         "slab": pick(vs.get("slab", {}), "cascade")},
+         "halo_exchange_us_measured": {"reduce_scatter": halo(vs.get("reduce_scatter", {}), "stage"), "slab": halo(vs.get("slab", {}), "stage")}}
+    return s
 
 
 def main():
@@ -650,6 +738,7 @@ def main():
             line["other_workloads"] = others
         if vs is not None:
             line["viewshard"] = vs
+            line["strong_scaling"] = strong_scaling_summary(vs)
         print(json.dumps(line))
     if dist is not None:
         dist.barrier()

@@ -41,17 +41,20 @@ struct DynEpi {
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
 constexpr int nks_of(int k) { return (k * k + 3) / 4; }
 
-template <int CIN, int K0, int K1, int K2>
+// MODE 1: one DynamicConv (NBR kernel sizes, CIN + 3 columns each, blend epilogue); MODE 2: ONE 3 x 3 convolution CIN -> 16 with bias +
+// ReLU, optionally followed by a 1x1 head 16 -> 1 + sigmoid (the visibility CNN's layers 2 / 3, models/model.py:14)
+template <int CIN, int K0, int K1, int K2, int MODE = 1>
 struct DCfg {
-  static constexpr int NBR = K2 > 0 ? 3 : 2;
+  static constexpr int NBR = MODE == 2 ? 1 : (K2 > 0 ? 3 : 2);
   static constexpr int R = (cmax(K0, cmax(K1, K2)) - 1) / 2;
   static constexpr int IXP = TX + 2 * R, IY = TY + 2 * R, NPOS = IXP * IY;
   static constexpr int ROUNDS = CIN / 8, PLANE = NPOS * POSB;
-  static constexpr int CO3 = CIN + 3, NBLK = (CO3 + 15) / 16;
-  static constexpr int NCB = CIN >= 16 ? CIN / 16 : 1;        // blocks that hold output channels
+  static constexpr int COUT = MODE == 2 ? 16 : CIN;
+  static constexpr int CO3 = MODE == 2 ? 16 : CIN + 3, NBLK = (CO3 + 15) / 16;
+  static constexpr int NCB = COUT >= 16 ? COUT / 16 : 1;      // blocks that hold output channels
   static constexpr int C4 = CIN / 4;                           // float4 chunks per texel
   static constexpr int NCH = NPOS * C4, NIT = (NCH + 255) / 256, PSTEP = 256 / C4;
-  static constexpr int NKS = nks_of(K0) + nks_of(K1) + (K2 > 0 ? nks_of(K2) : 0);
+  static constexpr int NKS = nks_of(K0) + (K1 > 0 ? nks_of(K1) : 0) + (K2 > 0 ? nks_of(K2) : 0);
   // epilogue areas (they reuse the staged tile): curvature responses [b][j][256 px] and blend weights [b][256 px] floats, then the
   // transposition tiles [wave][q][block][16 px][TP] floats and the statistics [wave][NBLK * 16][2] doubles
   static constexpr int TP = 20;                                // row pitch of a transposition tile: conflict-free writes and 16-byte reads
@@ -74,12 +77,21 @@ struct DCfg {
 // two source operands exchanged - nothing else changed - the effect is gone.  Measured by an aggressor / victim experiment and bisected to
 // the K-loop (profiles/r05_experiments.md, scripts/ab/r05_aggressor.py); operand data, zero padding, wait states after the MFMAs and the
 // distance to the next loads make no difference.  The operand roles below are the ones that have been bit-stable for three rounds.
-template <int CIN, int K0, int K1, int K2>
+// sum over the 16 lanes of a DPP row (all lanes end up with the total)
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+  v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
+  v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x141, 0xf, 0xf, true));  // row_half_mirror
+  v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x140, 0xf, 0xf, true));  // row_mirror
+  return v;
+}
+
+template <int CIN, int K0, int K1, int K2, int MODE>
 __global__ __launch_bounds__(256, 2) void dynconv_cl_kernel(const float* __restrict__ x, const float* __restrict__ affine,
                                                             const uint4* __restrict__ wsp, const float* __restrict__ bias,
                                                             DynEpi ep, int N, int H, int W, int tiles_x, int tiles_y) {
-  using C = DCfg<CIN, K0, K1, K2>;
-  constexpr int NBR = C::NBR, NBLK = C::NBLK, NCB = C::NCB, R = C::R, IXP = C::IXP, Cout = CIN, Co3 = C::CO3;
+  using C = DCfg<CIN, K0, K1, K2, MODE>;
+  constexpr int NBR = C::NBR, NBLK = C::NBLK, NCB = C::NCB, R = C::R, IXP = C::IXP, Cout = C::COUT, Co3 = C::CO3;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   int lin = cds_xcd_remap(blockIdx.x, tiles_x * tiles_y * N);
   const int tx_i = lin % tiles_x;
@@ -156,7 +168,7 @@ __global__ __launch_bounds__(256, 2) void dynconv_cl_kernel(const float* __restr
   // A operand (data): lane (m, g) supplies the 8 channels of tap 4 t + g for pixel m of the x-run = one ds_read_b128 per term
   const int a_base = ((wave * 2) * IXP + m) * POSB;
   const uint4* __restrict__ wl = wsp + lane;
-  constexpr int KS[3] = {K0, K1, K2 > 0 ? K2 : 1};
+  constexpr int KS[3] = {K0, K1 > 0 ? K1 : 1, K2 > 0 ? K2 : 1};
 #pragma unroll 1
   for (int rd = 0; rd < C::ROUNDS; ++rd) {
     const uint4* __restrict__ wr = wl + (size_t)rd * C::NKS * NBLK * 3 * 64;
@@ -209,6 +221,51 @@ __global__ __launch_bounds__(256, 2) void dynconv_cl_kernel(const float* __restr
     }
   }
 
+  if constexpr (MODE == 2) {
+    // visibility-CNN layer: ReLU(conv + folded BatchNorm); with a head (ep.w1 = head weights [16], ep.b1 = head bias [1]) the 1x1
+    // convolution 16 -> 1 + sigmoid follows and the result is one value per pixel, ep.out [N][H][W]; else ep.out [N][H][W][16]
+    const float bv = bias ? bias[m] : 0.f;
+    const bool head = ep.w1 != nullptr;
+    if (head) {
+      const float hw_n = ep.w1[m], hb = ep.b1[0];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int oy = oy0 + wave * 2 + (q >> 1), ox = ox0 + (q & 1) * 16 + g * 4;
+        const f32x4 a = acc[0][0][q];
+        float v[4] = {fmaxf(a.x + bv, 0.f), fmaxf(a.y + bv, 0.f), fmaxf(a.z + bv, 0.f), fmaxf(a.w + bv, 0.f)};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float sacc = row16_sum(v[i] * hw_n) + hb;
+          v[i] = 1.0f / (1.0f + expf(-sacc));
+        }
+        if (m == 0 && oy < H) {
+          float* __restrict__ o = ep.out + ((size_t)img * H + oy) * W + ox;
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (ox + i < W) o[i] = v[i];
+        }
+      }
+      return;
+    }
+    __syncthreads();                                           // every wave is done with the staged input tile
+    float* trL = reinterpret_cast<float*>(lds) + wave * (4 * 16 * C::TP);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 a = acc[0][0][q];
+      const float v[4] = {fmaxf(a.x + bv, 0.f), fmaxf(a.y + bv, 0.f), fmaxf(a.z + bv, 0.f), fmaxf(a.w + bv, 0.f)};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) trL[(q * 16 + g * 4 + i) * C::TP + m] = v[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int oy = oy0 + wave * 2 + (q >> 1), ox = ox0 + (q & 1) * 16 + m;
+      if (oy < H && ox < W)
+        *reinterpret_cast<float4*>(ep.out + (((size_t)img * H + oy) * W + ox) * 16 + 4 * g) =
+            *reinterpret_cast<const float4*>(trL + (q * 16 + m) * C::TP + 4 * g);
+    }
+    return;
+  }
   // ---- epilogue (the planar kernel's).  Accumulator layout: lane (m, g) holds column 16 nb + m of pixels x = (q & 1) 16 + 4 g + i,
   // y = 2 wave + (q >> 1).  (1) the lanes of the three curvature columns leave them in LDS; (2) lane m of a 16-lane group owns pixel
   // (q, i) = (m >> 2, m & 3) of its group: projection, MLP, softmax -> K weights into LDS, norm_curv to memory; (3) every lane reads the
@@ -323,12 +380,12 @@ __global__ __launch_bounds__(256, 2) void dynconv_cl_kernel(const float* __restr
   }
 }
 
-template <int CIN, int K0, int K1, int K2>
+template <int CIN, int K0, int K1, int K2, int MODE = 1>
 int launch_dynconv_cl(const float* x, const float* aff, const void* wsp, const float* bias, const DynEpi& ep, int N, int H, int W,
                       hipStream_t st) {
-  using C = DCfg<CIN, K0, K1, K2>;
+  using C = DCfg<CIN, K0, K1, K2, MODE>;
   const int tx = cds_ceil_div(W, TX), ty = cds_ceil_div(H, TY);
-  auto kern = dynconv_cl_kernel<CIN, K0, K1, K2>;
+  auto kern = dynconv_cl_kernel<CIN, K0, K1, K2, MODE>;
   if (C::LDSB > 64 * 1024) {
     static std::atomic<unsigned long long> lds_ok{0};   // per instantiation
     if (int e = cds_allow_lds(reinterpret_cast<const void*>(kern), C::LDSB, lds_ok)) return e;
@@ -407,11 +464,26 @@ __device__ __forceinline__ float affine_leaky(float v, const float* __restrict__
   return t > 0.f ? t : t * aff[3 * ci + 2];
 }
 
+// opaque zero (asm volatile): pointer arithmetic with it cannot be hoisted above this point, so the scalar weight loads of one group
+// of input channels are issued here and not all at once (hundreds of SGPRs: spills)
+__device__ __forceinline__ int opaque_zero() {
+  int z = 0;
+  asm volatile("" : "+s"(z));
+  return z;
+}
+// the same, ordered AFTER the computation of `dep` (a data dependency the scheduler must respect): the loads behind it cannot be
+// clustered with those of the previous channel group
+__device__ __forceinline__ int opaque_zero_after(float dep) {
+  int z = 0;
+  asm volatile("" : "+s"(z) : "v"(dep));
+  return z;
+}
+
 template <int CIN, int COUT>
 __global__ __launch_bounds__(256) void conv2d_k3s2_cl_kernel(const float* __restrict__ x, const float* __restrict__ affine,
                                                              const float* __restrict__ wpk, float* __restrict__ out, int H, int W,
                                                              int Ho, int Wo) {
-  constexpr int CSTEP = COUT >= 32 ? 2 : 4;                   // input channels per weight batch: CSTEP * COUT <= 64 SGPRs
+  constexpr int C4 = CIN / 4;
   const int n = blockIdx.y;
   const int Wp = (Wo + 1) >> 1;                               // output pixel pairs per row
   const int pp = blockIdx.x * 256 + threadIdx.x;
@@ -423,38 +495,56 @@ __global__ __launch_bounds__(256) void conv2d_k3s2_cl_kernel(const float* __rest
   float acc0[COUT], acc1[COUT];
 #pragma unroll
   for (int c = 0; c < COUT; ++c) acc0[c] = acc1[c] = 0.f;
+  // one input row of the 3 x 5 window at a time: its five texels are requested together (5 C4 16-byte loads in flight per thread),
+  // then consumed: column kx feeds the first pixel, column kx + 2 the second
 #pragma unroll 1
-  for (int tap = 0; tap < 9; ++tap) {
-    const int ky = tap / 3, kx = tap - ky * 3;
-    const int gy = 2 * oy - 1 + ky, gxa = 2 * ox - 1 + kx, gxb = gxa + 2;
+  for (int ky = 0; ky < 3; ++ky) {
+    const int gy = 2 * oy - 1 + ky;
     const bool oky = (unsigned)gy < (unsigned)H;
-    const bool oka = oky && (unsigned)gxa < (unsigned)W, okb = oky && has2 && (unsigned)gxb < (unsigned)W;
-    const float4* __restrict__ sa = reinterpret_cast<const float4*>(xn + ((size_t)(oka ? gy : 0) * W + (oka ? gxa : 0)) * CIN);
-    const float4* __restrict__ sb = reinterpret_cast<const float4*>(xn + ((size_t)(okb ? gy : 0) * W + (okb ? gxb : 0)) * CIN);
-    const float* __restrict__ wt = wpk + tap * CIN * COUT;
-#pragma unroll 1
-    for (int c4 = 0; c4 < CIN / 4; ++c4) {
-      const float4 a4 = sa[c4], b4 = sb[c4];
-      const float va[4] = {a4.x, a4.y, a4.z, a4.w}, vb[4] = {b4.x, b4.y, b4.z, b4.w};
-#pragma unroll 1
-      for (int h = 0; h < 4 / CSTEP; ++h) {
+    float4 t[5][C4];
+    bool okc[5];
 #pragma unroll
-        for (int j = 0; j < CSTEP; ++j) {
-          const int ci = c4 * 4 + h * CSTEP + j;
-          float ta = CSTEP == 4 ? va[j] : (h ? va[2 + j] : va[j]);
-          float tb = CSTEP == 4 ? vb[j] : (h ? vb[2 + j] : vb[j]);
-          if (aff) {
-            ta = affine_leaky(ta, aff, ci);
-            tb = affine_leaky(tb, aff, ci);
-          }
-          ta = oka ? ta : 0.f;                                 // zero padding follows the normalisation
-          tb = okb ? tb : 0.f;
-          const float* __restrict__ wc = wt + ci * COUT;
+    for (int cx = 0; cx < 5; ++cx) {
+      const int gx = 2 * ox - 1 + cx;
+      okc[cx] = oky && (unsigned)gx < (unsigned)W && (cx < 3 || has2);
+      const float4* __restrict__ sp = reinterpret_cast<const float4*>(xn + ((size_t)(okc[cx] ? gy : 0) * W + (okc[cx] ? gx : 0)) * CIN);
+#pragma unroll
+      for (int c4 = 0; c4 < C4; ++c4) t[cx][c4] = sp[c4];
+    }
+    if (aff) {                                                // normalise-on-load; zero padding follows the normalisation
+#pragma unroll
+      for (int c4 = 0; c4 < C4; ++c4) {
+        const float* __restrict__ af = aff + opaque_zero() + c4 * 12;
+#pragma unroll
+        for (int cx = 0; cx < 5; ++cx) {
+          t[cx][c4].x = affine_leaky(t[cx][c4].x, af, 0);
+          t[cx][c4].y = affine_leaky(t[cx][c4].y, af, 1);
+          t[cx][c4].z = affine_leaky(t[cx][c4].z, af, 2);
+          t[cx][c4].w = affine_leaky(t[cx][c4].w, af, 3);
+        }
+      }
+    }
+#pragma unroll
+    for (int cx = 0; cx < 5; ++cx)
+      if (!okc[cx]) {
+#pragma unroll
+        for (int c4 = 0; c4 < C4; ++c4) t[cx][c4] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+#pragma unroll
+      for (int c4 = 0; c4 < C4; ++c4) {
+        const float* __restrict__ wt = wpk + opaque_zero() + ((ky * 3 + kx) * CIN + c4 * 4) * COUT;
+        const float va[4] = {t[kx][c4].x, t[kx][c4].y, t[kx][c4].z, t[kx][c4].w};
+        const float vb[4] = {t[kx + 2][c4].x, t[kx + 2][c4].y, t[kx + 2][c4].z, t[kx + 2][c4].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (COUT >= 32 && j == 2) wt += opaque_zero();     // at most 2 x 32 weights in flight for the wide layer
 #pragma unroll
           for (int c = 0; c < COUT; ++c) {
-            const float wv = wc[c];
-            acc0[c] = fmaf(ta, wv, acc0[c]);
-            acc1[c] = fmaf(tb, wv, acc1[c]);
+            const float wv = wt[j * COUT + c];
+            acc0[c] = fmaf(va[j], wv, acc0[c]);
+            acc1[c] = fmaf(vb[j], wv, acc1[c]);
           }
         }
       }
@@ -474,20 +564,21 @@ __global__ __launch_bounds__(256) void conv2d_k3s2_cl_kernel(const float* __rest
 // materialised; each source has its own optional normalise-on-load table.  Thread = one 2 x 2 block of output pixels = ONE coarse
 // texel: the coarse half of the fmaf chain (the first Ca channels of the concatenation) is the same for the four pixels and is
 // computed once; the skip half continues it per pixel - the chain order of conv2d_kernel<1,...> on the materialised concatenation,
-// bit-identical results.  A row of the block is two adjacent texels = 2 Cb contiguous floats per lane, consecutive lanes consecutive
-// blocks; every wave-uniform weight ([Ca + Cb][COUT], scalar cache) of the skip half feeds two multiply-adds.  InstanceNorm records:
-// fp64 sums per thread over its FPN_NB blocks, one wave reduction per channel at the end.
+// bit-identical results.  ALL texels of a block (one coarse, four skip: 2 rows of 2 Cb contiguous floats) are requested before the
+// first multiply (Ca / 4 + Cb 16-byte loads in flight per thread: the kernel is memory-bound); every wave-uniform weight
+// ([Ca + Cb][COUT], scalar cache) of the skip half feeds four multiply-adds.  InstanceNorm records: fp64 sums per thread over its
+// FPN_NB blocks, one wave reduction per channel at the end.
 // ---------------------------------------------------------------------------------------------------------------------------
 constexpr int FPN_NB = 2;
-template <int CA, int CB, int COUT>
+template <int CA, int CB, int COUT, bool HAS_A, bool HAS_B>
 __global__ __launch_bounds__(256) void fpn_lateral_cl_kernel(const float* __restrict__ xa, const float* __restrict__ affa,
                                                              const float* __restrict__ xb, const float* __restrict__ affb,
                                                              const float* __restrict__ wpk, float* __restrict__ out,
                                                              double* __restrict__ partial, int H, int W) {
   const int n = blockIdx.y;
   const int Hc = H >> 1, Wc = W >> 1, nblk = Hc * Wc;
-  const float* __restrict__ fa = affa ? affa + (size_t)n * CA * 3 : nullptr;
-  const float* __restrict__ fb = affb ? affb + (size_t)n * CB * 3 : nullptr;
+  const float* __restrict__ fa = affa + (HAS_A ? (size_t)n * CA * 3 : 0);     // compile-time switches: no per-element pointer tests
+  const float* __restrict__ fb = affb + (HAS_B ? (size_t)n * CB * 3 : 0);
   xa += (size_t)n * nblk * CA;
   xb += (size_t)n * H * W * CB;
   out += (size_t)n * H * W * COUT;
@@ -499,64 +590,99 @@ __global__ __launch_bounds__(256) void fpn_lateral_cl_kernel(const float* __rest
     const int bi = (blockIdx.x * FPN_NB + it) * 256 + threadIdx.x;
     if (bi >= nblk) break;
     const int by = bi / Wc, bx = bi - by * Wc;
-    int zero = 0;
-    asm volatile("" : "+s"(zero));                             // opaque 0: the weights are re-read per block through the scalar cache
-    const float* __restrict__ wp = wpk + zero;                 // instead of being hoisted out of the loop into hundreds of (spilled) SGPRs
+    const size_t p0 = (size_t)(2 * by) * W + 2 * bx;           // pixels p0, p0 + 1 and p0 + W, p0 + W + 1
+    float4 ta[CA / 4], tb[2][2 * CB / 4];
+    {
+      const float4* __restrict__ sa = reinterpret_cast<const float4*>(xa + (size_t)bi * CA);
+#pragma unroll
+      for (int c4 = 0; c4 < CA / 4; ++c4) ta[c4] = sa[c4];
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const float4* __restrict__ sb = reinterpret_cast<const float4*>(xb + (p0 + (size_t)r * W) * CB);
+#pragma unroll
+        for (int c4 = 0; c4 < 2 * CB / 4; ++c4) tb[r][c4] = sb[c4];
+      }
+    }
+    // normalise-on-load of every texel first (12 wave-uniform constants per channel quad at a time), then the multiply-adds see
+    // plain values and only the weights travel through scalar registers
+    if (HAS_A) {
+#pragma unroll
+      for (int c4 = 0; c4 < CA / 4; ++c4) {
+        const float* __restrict__ af = fa + opaque_zero_after(ta[c4 ? c4 - 1 : 0].x) + c4 * 12;
+        ta[c4].x = affine_leaky(ta[c4].x, af, 0);
+        ta[c4].y = affine_leaky(ta[c4].y, af, 1);
+        ta[c4].z = affine_leaky(ta[c4].z, af, 2);
+        ta[c4].w = affine_leaky(ta[c4].w, af, 3);
+      }
+    }
+    if (HAS_B) {
+#pragma unroll
+      for (int c4 = 0; c4 < CB / 4; ++c4) {
+        const float* __restrict__ af = fb + opaque_zero_after(tb[0][c4 ? c4 - 1 : 0].x) + c4 * 12;
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+          for (int sx = 0; sx < 2; ++sx) {
+            float4& t4 = tb[r][sx * (CB / 4) + c4];
+            t4.x = affine_leaky(t4.x, af, 0);
+            t4.y = affine_leaky(t4.y, af, 1);
+            t4.z = affine_leaky(t4.z, af, 2);
+            t4.w = affine_leaky(t4.w, af, 3);
+          }
+      }
+    }
     float base[COUT];
 #pragma unroll
     for (int c = 0; c < COUT; ++c) base[c] = 0.f;
-    const float4* __restrict__ sa = reinterpret_cast<const float4*>(xa + (size_t)bi * CA);
-#pragma unroll 1
+#pragma unroll
     for (int c4 = 0; c4 < CA / 4; ++c4) {
-      const float4 v4 = sa[c4];
-      const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+      const float* __restrict__ wc = wpk + opaque_zero_after(base[0]) + c4 * 4 * COUT;
+      const float v[4] = {ta[c4].x, ta[c4].y, ta[c4].z, ta[c4].w};
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const int ci = c4 * 4 + j;
-        const float t = fa ? affine_leaky(v[j], fa, ci) : v[j];
-        const float* __restrict__ wc = wp + ci * COUT;
 #pragma unroll
-        for (int c = 0; c < COUT; ++c) base[c] = fmaf(t, wc[c], base[c]);
+        for (int c = 0; c < COUT; ++c) base[c] = fmaf(v[j], wc[j * COUT + c], base[c]);
       }
     }
-#pragma unroll 1
-    for (int r = 0; r < 2; ++r) {
-      const size_t p = (size_t)(2 * by + r) * W + 2 * bx;      // pixels p, p + 1
-      float acc0[COUT], acc1[COUT];
+    float acc[4][COUT];                                        // pixel 2 r + s of the block
 #pragma unroll
-      for (int c = 0; c < COUT; ++c) acc0[c] = acc1[c] = base[c];
-      const float4* __restrict__ sb = reinterpret_cast<const float4*>(xb + p * CB);
-#pragma unroll 1
-      for (int c4 = 0; c4 < CB / 4; ++c4) {
-        const float4 a4 = sb[c4], b4 = sb[CB / 4 + c4];
-        const float va[4] = {a4.x, a4.y, a4.z, a4.w}, vb[4] = {b4.x, b4.y, b4.z, b4.w};
+    for (int q = 0; q < 4; ++q)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int ci = c4 * 4 + j;
-          const float ta = fb ? affine_leaky(va[j], fb, ci) : va[j];
-          const float tb = fb ? affine_leaky(vb[j], fb, ci) : vb[j];
-          const float* __restrict__ wc = wp + (CA + ci) * COUT;
+      for (int c = 0; c < COUT; ++c) acc[q][c] = base[c];
 #pragma unroll
-          for (int c = 0; c < COUT; ++c) {
-            const float wv = wc[c];
-            acc0[c] = fmaf(ta, wv, acc0[c]);
-            acc1[c] = fmaf(tb, wv, acc1[c]);
-          }
-        }
+    for (int c4 = 0; c4 < CB / 4; ++c4) {
+      const float* __restrict__ wc = wpk + opaque_zero_after(acc[0][0]) + (CA + c4 * 4) * COUT;
+      float v[4][4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 t4 = tb[q >> 1][(q & 1) * (CB / 4) + c4];
+        v[q][0] = t4.x; v[q][1] = t4.y; v[q][2] = t4.z; v[q][3] = t4.w;
       }
-      float4* o4 = reinterpret_cast<float4*>(out + p * COUT);
 #pragma unroll
-      for (int c = 0; c < COUT; c += 4) {
-        o4[c >> 2] = make_float4(acc0[c], acc0[c + 1], acc0[c + 2], acc0[c + 3]);
-        o4[(COUT + c) >> 2] = make_float4(acc1[c], acc1[c + 1], acc1[c + 2], acc1[c + 3]);
-      }
-      if (partial) {
+      for (int j = 0; j < 4; ++j) {
 #pragma unroll
         for (int c = 0; c < COUT; ++c) {
-          const double d0 = (double)acc0[c], d1 = (double)acc1[c];
-          ds[c] += d0 + d1;
-          dq[c] += d0 * d0 + d1 * d1;
+          const float wv = wc[j * COUT + c];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc[q][c] = fmaf(v[q][j], wv, acc[q][c]);
         }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      float4* o4 = reinterpret_cast<float4*>(out + (p0 + (size_t)r * W) * COUT);
+#pragma unroll
+      for (int c = 0; c < COUT; c += 4) {
+        o4[c >> 2] = make_float4(acc[2 * r][c], acc[2 * r][c + 1], acc[2 * r][c + 2], acc[2 * r][c + 3]);
+        o4[(COUT + c) >> 2] = make_float4(acc[2 * r + 1][c], acc[2 * r + 1][c + 1], acc[2 * r + 1][c + 2], acc[2 * r + 1][c + 3]);
+      }
+    }
+    if (partial) {
+#pragma unroll
+      for (int c = 0; c < COUT; ++c) {
+        const double d0 = (double)acc[0][c], d1 = (double)acc[1][c], d2 = (double)acc[2][c], d3 = (double)acc[3][c];
+        ds[c] += (d0 + d1) + (d2 + d3);
+        dq[c] += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
       }
     }
   }
@@ -665,7 +791,67 @@ __global__ __launch_bounds__(256) void instnorm_apply_cl_kernel(const float* __r
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Visibility CNN, layer 1 (models/model.py:14,51): cat(entropy, ref_nc) -> 3x3 convolution 2 -> 16 (BatchNorm folded) + ReLU, straight
+// from the two maps [V][h][w] to the channels-last activation [V][h][w][16] the matrix-core layers 2 / 3 stage from.  Memory-bound
+// (8 bytes in, 64 bytes out per pixel): one thread per pixel, the 2 x 9 taps through L1, wave-uniform weights [2][9][16].
+// ---------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void vis_layer1_cl_kernel(const float* __restrict__ ent, const float* __restrict__ nc,
+                                                            const float* __restrict__ wpk, const float* __restrict__ bias,
+                                                            float* __restrict__ out, int H, int W) {
+  const int n = blockIdx.y;
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= H * W) return;
+  const int y = p / W, x = p - y * W;
+  float acc[16];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) acc[c] = 0.f;
+#pragma unroll
+  for (int ci = 0; ci < 2; ++ci) {
+    const float* __restrict__ src = (ci ? nc : ent) + (size_t)n * H * W;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int gy = y - 1 + ky, gx = x - 1 + kx;
+        const float v = ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) ? src[(size_t)gy * W + gx] : 0.f;
+        const float* __restrict__ wc = wpk + (ci * 9 + ky * 3 + kx) * 16;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) acc[c] = fmaf(v, wc[c], acc[c]);
+      }
+  }
+  float4* o4 = reinterpret_cast<float4*>(out + ((size_t)n * H * W + p) * 16);
+#pragma unroll
+  for (int c = 0; c < 16; c += 4)
+    o4[c >> 2] = make_float4(fmaxf(acc[c] + bias[c], 0.f), fmaxf(acc[c + 1] + bias[c + 1], 0.f), fmaxf(acc[c + 2] + bias[c + 2], 0.f),
+                             fmaxf(acc[c + 3] + bias[c + 3], 0.f));
+}
+
 }  // namespace
+
+// Visibility CNN on channels-last activations (models/model.py:14,51).
+// cds_vis_layer1_cl_f32: entropy, ref_nc [V][h][w] -> ReLU(conv3x3(cat) + bias) as [V][h][w][16]; weight packed [2][9][16] (cout fastest),
+//   bias [16] (BatchNorm folded by the caller).
+// cds_conv2d_k3_relu_cl_f32: 3x3, 16 -> 16, bias + ReLU in split-bf16 arithmetic on the matrix cores (layers 2 / 3); x [N][H][W][16],
+//   weight_split = ops.split_pack_dynconv([w]) with w [16][16][3][3], bias [16]; head_w [16] / head_b [1] or both NULL:
+//   out [N][H][W][16], or with the head sigmoid(head_b + sum_c head_w[c] relu(..)[c]) as [N][H][W].
+extern "C" int cds_vis_layer1_cl_f32(const float* entropy, const float* ref_nc, const float* weight, const float* bias, float* out, int V,
+                                     int H, int W, void* stream) {
+  if (!entropy || !ref_nc || !weight || !bias || !out || V < 1 || H < 1 || W < 1) return CDS_EINVAL;
+  hipLaunchKernelGGL(vis_layer1_cl_kernel, dim3(cds_ceil_div(H * W, 256), V), dim3(256), 0, (hipStream_t)stream, entropy, ref_nc, weight,
+                     bias, out, H, W);
+  return cds_launch_status();
+}
+
+extern "C" int cds_conv2d_k3_relu_cl_f32(const float* x, const void* weight_split, const float* bias, const float* head_w,
+                                         const float* head_b, float* out, int N, int Cin, int H, int W, void* stream) {
+  if (!x || !weight_split || !out || N < 1 || Cin != 16 || H < 1 || W < 1 || (head_w != nullptr) != (head_b != nullptr)) return CDS_EINVAL;
+  DynEpi ep{};
+  ep.w1 = head_w;
+  ep.b1 = head_b;
+  ep.out = out;
+  return launch_dynconv_cl<16, 3, 0, 0, 2>(x, nullptr, weight_split, bias, ep, N, H, W, (hipStream_t)stream);
+}
 
 // Records per image that cds_dynconv_cl_f32 leaves for cds_instnorm_reduce_f32: one per 32 x 8 tile.
 extern "C" int cds_dynconv_cl_parts(int H, int W) { return cds_ceil_div(W, TX) * cds_ceil_div(H, TY); }
@@ -749,14 +935,21 @@ extern "C" int cds_conv2d_fpn_cl_f32(const float* coarse, const float* coarse_af
   if (!coarse || !skip || !weight || !out || N < 1 || H < 2 || W < 2 || (H & 1) || (W & 1)) return CDS_EINVAL;
   const dim3 grid(cds_ceil_div((H / 2) * (W / 2), 256 * FPN_NB), N);
   hipStream_t st = (hipStream_t)stream;
-  if (Ca == 32 && Cb == 16 && Cout == 16)
-    hipLaunchKernelGGL((fpn_lateral_cl_kernel<32, 16, 16>), grid, dim3(256), 0, st, coarse, coarse_affine, skip, skip_affine, weight, out,
-                       partial, H, W);
-  else if (Ca == 16 && Cb == 8 && Cout == 8)
-    hipLaunchKernelGGL((fpn_lateral_cl_kernel<16, 8, 8>), grid, dim3(256), 0, st, coarse, coarse_affine, skip, skip_affine, weight, out,
-                       partial, H, W);
-  else
-    return CDS_EINVAL;
+#define FPN_LAUNCH(CA_, CB_, CO_, HA_, HB_)                                                                                       \
+  hipLaunchKernelGGL((fpn_lateral_cl_kernel<CA_, CB_, CO_, HA_, HB_>), grid, dim3(256), 0, st, coarse, coarse_affine, skip, skip_affine, \
+                     weight, out, partial, H, W)
+#define FPN_PICK(CA_, CB_, CO_)                                  \
+  do {                                                           \
+    if (coarse_affine && skip_affine) FPN_LAUNCH(CA_, CB_, CO_, true, true);     \
+    else if (coarse_affine) FPN_LAUNCH(CA_, CB_, CO_, true, false);              \
+    else if (skip_affine) FPN_LAUNCH(CA_, CB_, CO_, false, true);                \
+    else FPN_LAUNCH(CA_, CB_, CO_, false, false);                                \
+  } while (0)
+  if (Ca == 32 && Cb == 16 && Cout == 16) FPN_PICK(32, 16, 16);
+  else if (Ca == 16 && Cb == 8 && Cout == 8) FPN_PICK(16, 8, 8);
+  else return CDS_EINVAL;
+#undef FPN_PICK
+#undef FPN_LAUNCH
   return cds_launch_status();
 }
 

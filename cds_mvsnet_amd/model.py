@@ -662,6 +662,11 @@ class StageNet(_PackedHolder):
         p = self._packed.get(self, self._pack)
         s = stage_idx
         with ops.prof("visibility_cnn"):
+            if USE_FEAT_CL and f"{s}.ws1" in p and ops.USE_CONV2D_SBF:
+                # channels-last activations (csrc/feat_cl.hip): layer 1 straight from the two maps, layers 2 / 3 on the matrix cores
+                x = ops.vis_layer1_cl(entropy.contiguous(), ref_nc.contiguous(), p[f"{s}.w0"], p[f"{s}.b0"])
+                x = ops.conv2d_k3_relu_cl(x, p[f"{s}.ws1"], p[f"{s}.b1"])
+                return ops.conv2d_k3_relu_cl(x, p[f"{s}.ws2"], p[f"{s}.b2"], head_w=p[f"{s}.hw"], head_b=p[f"{s}.b3"])
             x = torch.stack((entropy, ref_nc), dim=1)
             x = ops.conv2d(x, p[f"{s}.w0"], p[f"{s}.b0"], 16, 3, 1, 1, ACT_RELU)
             if f"{s}.ws1" in p and ops.USE_CONV2D_SBF and x.shape[-1] % 4 == 0:

@@ -22,6 +22,7 @@ Tensor = torch.Tensor
 # events are recorded asynchronously, nothing synchronises here).
 PROFILE_ON = False
 PROFILE: dict = {}
+PROFILE_HOST_MS: dict = {}     # host-timed sections (gloo dry runs of the communication paths): name -> [ms, ...]
 
 
 class prof:
@@ -1006,6 +1007,38 @@ def instnorm_apply_cl(x_cl: Tensor, stats: Tensor, act: int, n_chw: int = 0, cl_
                                                 out_chw.data_ptr() if n_chw > 0 else None, N, C, H, W, act, n_chw,
                                                 cl_from if want_cl else 0, _stream(x_cl)), "cds_instnorm_apply_cl_f32")
     return out_cl, out_chw
+
+
+def vis_layer1_cl(entropy: Tensor, ref_nc: Tensor, wpk: Tensor, bias: Tensor) -> Tensor:
+    """Visibility CNN layer 1 (model.py:14,51): entropy, ref_nc [V,h,w] -> ReLU(conv3x3(cat) + bias) channels-last [V,h,w,16].
+    wpk packed [2,9,16] (BatchNorm folded), bias [16]."""
+    V, h, w = entropy.shape
+    if tuple(ref_nc.shape) != (V, h, w) or tuple(wpk.shape) != (2, 9, 16) or bias.numel() != 16:
+        raise ValueError(f"vis_layer1_cl: need entropy / ref_nc [V,h,w], weight [2,9,16], bias [16]; got {tuple(entropy.shape)}, "
+                         f"{tuple(ref_nc.shape)}, {tuple(wpk.shape)}")
+    out = torch.empty((V, h, w, 16), dtype=torch.float32, device=entropy.device)
+    check(_lib.load().cds_vis_layer1_cl_f32(_dev(entropy, "entropy"), _dev(ref_nc, "ref_nc"), _dev(wpk, "weight"), _dev(bias, "bias"),
+                                            out.data_ptr(), V, h, w, _stream(entropy)), "cds_vis_layer1_cl_f32")
+    return out
+
+
+def conv2d_k3_relu_cl(x_cl: Tensor, wsplit: Tensor, bias: Optional[Tensor], head_w: Optional[Tensor] = None,
+                      head_b: Optional[Tensor] = None) -> Tensor:
+    """3x3, pad 1, 16 -> 16 channels + bias + ReLU on channels-last activations in split-bf16 arithmetic on the matrix cores
+    (visibility CNN layers 2 / 3); x_cl [N,H,W,16] -> [N,H,W,16], or with head_w [16] / head_b [1] the 1x1 head + sigmoid: [N,H,W]."""
+    N, H, W, C = x_cl.shape
+    if C != 16:
+        raise ValueError(f"conv2d_k3_relu_cl: need [N,H,W,16], got {tuple(x_cl.shape)}")
+    if (head_w is None) != (head_b is None) or (head_w is not None and (head_w.numel() != 16 or head_b.numel() != 1)):
+        raise ValueError("conv2d_k3_relu_cl: head_w [16] and head_b [1] go together")
+    if wsplit.dtype != torch.int16 or wsplit.numel() != 2 * 3 * 1 * 3 * 64 * 8:
+        raise ValueError("conv2d_k3_relu_cl: wsplit must be split_pack_dynconv([w]) of a [16,16,3,3] weight")
+    out = torch.empty((N, H, W) if head_w is not None else (N, H, W, 16), dtype=torch.float32, device=x_cl.device)
+    check(_lib.load().cds_conv2d_k3_relu_cl_f32(_dev(x_cl, "x"), wsplit.data_ptr(), _dev(bias, "bias") if bias is not None else None,
+                                                _dev(head_w, "head_w") if head_w is not None else None,
+                                                _dev(head_b, "head_b") if head_b is not None else None,
+                                                out.data_ptr(), N, C, H, W, _stream(x_cl)), "cds_conv2d_k3_relu_cl_f32")
+    return out
 
 
 def depth_fusion(ref_depth: Tensor, ref_conf: Tensor, src_depths: Tensor, src_confs: Tensor, cams: Tensor,

@@ -116,6 +116,15 @@ class HaloComm:
             side.wait_stream(main)                                   # the producing layer
         ctx = torch.cuda.stream(side) if nccl else contextlib.nullcontext()
         recv_top = recv_bot = None
+        from . import ops as _ops
+        t_host = ev0 = None
+        if _ops.PROFILE_ON:                                          # bench.py: measured us per exchange (events on the communication stream)
+            if nccl:
+                ev0 = torch.cuda.Event(enable_timing=True)
+                ev0.record(side)
+            else:
+                import time as _time
+                t_host = _time.perf_counter()
         with ctx:
             ops_ = []
 
@@ -149,9 +158,14 @@ class HaloComm:
                     recv_top = self._row(own, row_dim, "recv_top_dev", False).copy_(recv_top)
                 if recv_bot is not None:
                     recv_bot = self._row(own, row_dim, "recv_bot_dev", False).copy_(recv_bot)
+        if t_host is not None:
+            import time as _time
+            _ops.PROFILE_HOST_MS.setdefault("halo_exchange", []).append((_time.perf_counter() - t_host) * 1e3)
         if nccl:
-            ev = torch.cuda.Event()
+            ev = torch.cuda.Event(enable_timing=ev0 is not None)
             ev.record(side)
+            if ev0 is not None:
+                _ops.PROFILE.setdefault("halo_exchange", []).append((ev0, ev))
             main.wait_event(ev)                                      # the consuming layer waits for the rows, the host does not
             for t in (recv_top, recv_bot):
                 if t is not None:

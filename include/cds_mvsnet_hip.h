@@ -407,6 +407,14 @@ int cds_fpn_cl_parts(int H, int W);
 int cds_conv2d_fpn_cl_f32(const float* coarse, const float* coarse_affine, const float* skip, const float* skip_affine,
                           const float* weight, float* out, double* partial, int N, int Ca, int Cb, int Cout, int H, int W,
                           void* stream);
+/* Visibility CNN on channels-last activations (models/model.py:14,51; csrc/feat_cl.hip): layer 1 from the two maps
+ * (entropy, ref_nc [V][h][w]; weight packed [2][9][16], bias [16], BatchNorm folded) to [V][h][w][16]; layers 2 / 3 (3x3, 16 -> 16,
+ * bias + ReLU, split-bf16 on the matrix cores; weight_split = ops.split_pack_dynconv([w]); with head_w [16] / head_b [1] the 1x1 head
+ * + sigmoid follows and out is [N][H][W], else [N][H][W][16]). */
+int cds_vis_layer1_cl_f32(const float* entropy, const float* ref_nc, const float* weight, const float* bias, float* out, int V, int H,
+                          int W, void* stream);
+int cds_conv2d_k3_relu_cl_f32(const float* x, const void* weight_split, const float* bias, const float* head_w, const float* head_b,
+                              float* out, int N, int Cin, int H, int W, void* stream);
 int cds_instnorm_stats_cl_parts(int H, int W);
 int cds_instnorm_stats_cl_f32(const float* x, double* partial, int N, int C, int H, int W, void* stream);
 int cds_instnorm_apply_cl_f32(const float* x, const double* stats, float* out_cl, float* out_chw, int N, int C, int H, int W, int act,

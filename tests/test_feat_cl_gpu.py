@@ -205,3 +205,36 @@ def test_dynconv_cl_is_bit_stable_at_scale(c, ks, N, H, W, dev, ops):
             assert bad == (0, 0), (T, rep, bad)
         o3, n3, _, _ = ops.dynconv_fused_sbf(x, wsp, None, c, ks, w1, b1, w2, epi, T, 0.1, in_affine=aff)
         assert torch.equal(o3, o2) and torch.equal(n3, n2)          # the planar fused kernel as well
+
+
+@pytest.mark.parametrize("V,H,W", [(4, 20, 36), (1, 8, 33), (3, 13, 100), (6, 37, 50)])
+def test_visibility_layers_channels_last(V, H, W, dev, ops):
+    """cds_vis_layer1_cl_f32 and cds_conv2d_k3_relu_cl_f32 (the visibility CNN on channels-last activations) against float64 and the
+    planar kernels they replace: layer 1 (exact fp32 fmaf chains) to round-off, the matrix-core layers fp32-class, with and without the
+    fused head; widths that are not multiples of 4, partial tiles."""
+    import torch.nn.functional as F
+    from cds_mvsnet_amd.model import _pack2d
+    g = torch.Generator().manual_seed(V * 100 + W)
+    ent, nc = torch.rand(V, H, W, generator=g) * 3.0, torch.rand(V, H, W, generator=g)
+    w0, b0 = torch.randn(16, 2, 3, 3, generator=g) / 4.0, torch.randn(16, generator=g) * 0.2
+    y0 = F.conv2d(torch.stack((ent, nc), 1).double(), w0.double(), b0.double(), padding=1).clamp_min(0)
+    x1 = ops.vis_layer1_cl(ent.to(dev), nc.to(dev), _pack2d(w0.to(dev)), b0.to(dev))
+    assert (x1.permute(0, 3, 1, 2).cpu().double() - y0).abs().max().item() <= 1e-5 * max(1.0, y0.abs().max().item())
+    w, b = torch.randn(16, 16, 3, 3, generator=g) / 12.0, torch.randn(16, generator=g) * 0.2
+    hw, hb = torch.randn(16, generator=g) * 0.3, torch.randn(1, generator=g)
+    xin = x1.permute(0, 3, 1, 2).cpu()
+    y64 = F.conv2d(xin.double(), w.double(), b.double(), padding=1).clamp_min(0)
+    ws = ops.split_pack_dynconv([w.to(dev)])
+    got = ops.conv2d_k3_relu_cl(x1, ws, b.to(dev))
+    ref32 = F.conv2d(xin, w, b, padding=1).clamp_min(0)
+    e_new, e_ref = (got.permute(0, 3, 1, 2).cpu().double() - y64).abs().max().item(), (ref32.double() - y64).abs().max().item()
+    assert e_new <= 1.5 * e_ref + y64.abs().max().item() * 2.0 ** -23, (e_new, e_ref)
+    h64 = torch.sigmoid((y64 * hw.double().view(1, 16, 1, 1)).sum(1) + hb.double())
+    goth = ops.conv2d_k3_relu_cl(x1, ws, b.to(dev), head_w=hw.to(dev), head_b=hb.to(dev))
+    assert tuple(goth.shape) == (V, H, W)
+    assert (goth.cpu().double() - h64).abs().max().item() <= 2e-6
+    if W % 4 == 0:      # the planar matrix-core kernel: same K-loop -> bit-identical
+        old = ops.conv2d_k3_relu_sbf(xin.to(dev).contiguous(), ws, b.to(dev))
+        assert torch.equal(got.permute(0, 3, 1, 2), old)
+        oldh = ops.conv2d_k3_relu_sbf(xin.to(dev).contiguous(), ws, b.to(dev), head_w=hw.to(dev), head_b=hb.to(dev))
+        assert torch.equal(goth, oldh)

@@ -373,6 +373,41 @@ def test_oracle_parity_midsize(dev, ops, seeded_state):
     assert (out["photometric_confidence"].cpu() - ref_out["photometric_confidence"]).abs().mean() < 1e-3
 
 
+@pytest.mark.parametrize("name,h,w,D,C,N", [("M1b", 128, 160, 192, 32, 5), ("M1 crop", 256, 320, 192, 8, 5)])
+def test_oracle_parity_large_depth_range(name, h, w, D, C, N, dev, ops, seeded_state):
+    """the D = 192 single-stage workloads against the CPU oracle under an assertion (until round 5 only bench.py's
+    cpu_baseline compared them): M1b (BASELINE config 2 read as the 160x128, C = 32 grid) at full size, and a 320x256 window of M1
+    (640x512, C = 8) - the same D = 192 chunking of K1 / K3 (48-plane LDS chunks, CDS_K3_NSEG depth segments) and the same
+    CostRegNet kernels as the full size at a quarter of the oracle's run time.  Tolerances are SURVEY 8(c)'s: aggregated volume
+    <= 1e-5 abs, depth mean-L1 <= 1e-3, confidence mean <= 1e-3."""
+    from cds_mvsnet_amd import synth
+    from oracle import cds_oracle as O
+    model = seeded_state(False)
+    sd = model.state_dict()
+    stage = {8: 2, 16: 1, 32: 0}[C]
+    feats = synth.make_pair_features(N - 1, C, h, w, seed=31)
+    cams = synth.stage_cameras(N, h, w, seed=32)
+    hyp = synth.make_hypotheses(D, h, w, seed=33)
+    torch.set_num_threads(min(os.cpu_count() or 1, 64))
+    with torch.no_grad():
+        want = O.stage_forward(feats, cams, hyp, sd, stage, exact=False)
+    model = model.to(dev)
+    dfe = [{k: tuple(t.to(dev) if t is not None else None for t in f[k]) for k in ("ref", "src")} for f in feats]
+    with torch.no_grad():
+        out = model.stage_net(dfe, cams, depth_values=hyp.to(dev), num_depth=D, cost_regularization=model.cost_regularization[stage],
+                              stage_idx=stage)
+        # the aggregated volume itself (K1 -> visibility CNN -> K3), planar
+        from cds_mvsnet_amd import geometry
+        ref = torch.stack([f["ref"][0][0] for f in feats]).to(dev).contiguous()
+        src = torch.stack([ops.chw_to_hwc(f["src"][0][0].to(dev).contiguous()) for f in feats])
+        ref_nc = torch.stack([f["ref"][2][0, 0] for f in feats]).to(dev).contiguous()
+        vol, _, _, _ = model.stage_net.aggregate(ref, src, ref_nc, geometry.warp_matrices(cams[0]), hyp[0].to(dev).contiguous(), stage)
+    assert (vol.cpu() - want["_volume_mean"][0]).abs().max().item() <= 1e-5, name
+    assert (out["depth"].cpu() - want["depth"]).abs().mean().item() <= 1e-3, name
+    assert (out["photometric_confidence"].cpu() - want["photometric_confidence"]).abs().mean().item() <= 1e-3, name
+    assert (out["norm_curv"].cpu() - want["norm_curv"]).abs().max().item() <= 1e-6, name
+
+
 def test_cpu_tensors_fail_loudly(ops):
     with pytest.raises(RuntimeError):
         ops.chw_to_hwc(torch.zeros(8, 4, 4))
@@ -661,11 +696,13 @@ def test_conv3d_channels_last_mfma_vs_torch(dev, ops):
         assert (out - want).abs().max() < 2e-5 * max(1.0, ref.abs().max().item()), (cin, cout, D, H, W)
 
 
-@pytest.mark.parametrize("H,W,N,refine", [(1184, 1600, 5, False), (1056, 1920, 7, False), (1152, 1536, 5, True)])
+@pytest.mark.parametrize("H,W,N,refine", [(1184, 1600, 5, False), (1056, 1920, 7, False), (1152, 1536, 5, True),
+                                          (512, 640, 3, False), (512, 640, 5, False)])
 def test_full_size_cascade_configs(H, W, N, refine):
-    """BASELINE configs 3 / 4 / 3alt at full size through size-independent properties (the CPU oracle needs minutes
-    there): finite outputs, depths inside the hypothesis range, confidences in [0,1], output shapes, run-to-run agreement
-    (InstanceNorm statistics use atomics, so not bit-identical) and view-order covariance of the stage-1 depth."""
+    """BASELINE configs 3 / 4 / 3alt, config 1's shape (640x512, N=3) and M2 (640x512, N=5) at full size through size-independent
+    properties (the CPU oracle needs minutes there): finite outputs, depths inside the hypothesis range, confidences in [0,1],
+    output shapes, run-to-run agreement (two forwards with stage 1 on its side stream next to FeatureNet: this is the test that caught
+    a kernel corrupting its stream neighbours in round 5) and view-order covariance of the stage-1 depth."""
     from cds_mvsnet_amd import CDSMVSNet, seeded_init_, synth
     dev = torch.device("cuda")
     model = seeded_init_(CDSMVSNet(refine=refine, depth_interals_ratio=(4.0, 1.5, 0.75)), 0).eval().to(dev)

@@ -263,6 +263,13 @@ def test_bench_two_ranks_dry_run_on_one_device(tmp_path):
         assert vs[mode]["stage"]["halo_exchanges_per_depth_map"] == 11
         assert vs[mode]["stage"]["ms_per_depth_map"] > 0 and vs[mode]["cascade"]["ms_per_depth_map"] > 0
     assert vs["stage"]["ms_per_depth_map"] > 0 and vs["cascade"]["exchanges_per_depth_map"] == 3
+    # the first node run explains itself - the north-star strong-scaling figures at top level, per exchange mode, with the
+    # measured time of a halo exchange and the RCCL settings in force
+    ss = line["strong_scaling"]
+    assert ss["ranks"] == 2 and set(ss["rccl"]) >= {"NCCL_ALGO", "NCCL_PROTO", "version"}
+    for key in ("stage_M1_ms_per_depth_map", "cascade_M4_ms_per_depth_map"):
+        assert set(ss[key]) == {"allreduce", "reduce_scatter", "slab"} and all(v is not None and v > 0 for v in ss[key].values()), ss
+    assert all(v is not None and v > 0 for v in ss["halo_exchange_us_measured"].values()), ss
 
 
 def test_bench_one_rank_over_rccl(tmp_path):
