@@ -58,10 +58,10 @@ struct DCfg {
   // epilogue areas (they reuse the staged tile): curvature responses [b][j][256 px] and blend weights [b][256 px] floats, then the
   // transposition tiles [wave][q][block][16 px][TP] floats and the statistics [wave][NBLK * 16][2] doubles
   static constexpr int TP = 20;                                // row pitch of a transposition tile: conflict-free writes and 16-byte reads
-  static constexpr int ATTB = NBR * 3 * 256 * 4, WLB = NBR * 256 * 4;
+  static constexpr int WREG = cmax(NBR * 4 * 64 * 4, 4 * NCB * 16 * TP * 4);   // per-wave epilogue region: curvature + weights | tiles
   static constexpr int TRB = 4 * 4 * NCB * 16 * TP * 4;
   static constexpr int REDB = 4 * NBLK * 16 * 2 * 8;
-  static constexpr int LDSB = cmax(ROUNDS * PLANE, cmax(ATTB + WLB, TRB) + REDB);
+  static constexpr int LDSB = cmax(ROUNDS * PLANE, 4 * WREG + REDB);
 };
 
 // One DynamicConv on channels-last activations.  Staging: channels-last (contiguous tile rows).  K-loop: exactly the planar kernel's
@@ -77,6 +77,135 @@ struct DCfg {
 // two source operands exchanged - nothing else changed - the effect is gone.  Measured by an aggressor / victim experiment and bisected to
 // the K-loop (profiles/r05_experiments.md, scripts/ab/r05_aggressor.py); operand data, zero padding, wait states after the MFMAs and the
 // distance to the next loads make no difference.  The operand roles below are the ones that have been bit-stable for three rounds.
+// The DynamicConv epilogue on the accumulators of one 32 x 8 tile (the planar kernel's, conv2d_sbf.hip MODE 1).  Accumulator layout: lane
+// (m, g) holds column 16 nb + m of pixels x = (q & 1) 16 + 4 g + i, y = 2 wave + (q >> 1).  (1) the lanes of the three curvature columns
+// leave them in LDS; (2) lane m of a 16-lane group owns pixel (q, i) = (m >> 2, m & 3) of its group: projection, MLP, softmax -> K weights
+// into LDS, norm_curv to memory; (3) every lane reads the weights of its 16 pixels and blends its column; (4) the blended 16 x 16 tiles are
+// transposed through LDS: a lane stores 4 consecutive channels of one pixel (16 bytes, channels-last).  InstanceNorm records per (wave,
+// channel) as the planar kernel leaves them.  `img` = the OUTPUT image (its epipole, its rows of out / norm_curv / partial): conv00 calls
+// this once per reference copy on the same accumulators.  Starts with a workgroup barrier (the LDS areas alias the staged tile).
+// order this wave's LDS writes before its later LDS reads for the compiler (the LDS executes one wave's instructions in order)
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <class C>
+__device__ __forceinline__ void dyn_epilogue(f32x4 (&acc)[C::NBR][C::NBLK][4], unsigned char* lds, const float* __restrict__ bias,
+                                             const DynEpi& ep, int img, int H, int W, int ox0, int oy0, int wave, int m, int g, int tid,
+                                             int tile, int parts) {
+  constexpr int NBR = C::NBR, NBLK = C::NBLK, NCB = C::NCB, Cout = C::COUT, Co3 = C::CO3, CIN = C::COUT;
+  // every exchange below stays inside ONE wave (a wave blends the 64 pixels it convolved): each wave has its own LDS region and orders
+  // its writes and reads with wave-level fences; only the tile hand-over and the four waves' statistics need workgroup barriers
+  float* attL = reinterpret_cast<float*>(lds + wave * C::WREG);    // [b][j][64 pixels of the wave]
+  float* wL = attL + NBR * 3 * 64;                                 // [b][64]
+  __syncthreads();                                             // every wave is done with the staged input tile
+#pragma unroll
+  for (int nb = 0; nb < NBLK; ++nb) {
+    const int jj = nb * 16 + m - Cout;
+    if (jj < 0 || jj > 2) continue;
+#pragma unroll
+    for (int b = 0; b < NBR; ++b) {
+      const float bv = bias ? bias[b * Co3 + nb * 16 + m] : 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 a = acc[b][nb][q];
+        *reinterpret_cast<float4*>(attL + (b * 3 + jj) * 64 + q * 16 + g * 4) =
+            make_float4(a.x + bv, a.y + bv, a.z + bv, a.w + bv);
+      }
+    }
+  }
+  wave_lds_fence();
+  {
+    const int wp = (m >> 2) * 16 + g * 4 + (m & 3);
+    const int px = ox0 + ((m >> 2) & 1) * 16 + g * 4 + (m & 3), py = oy0 + wave * 2 + (m >> 3);
+    float att[NBR][3], logit[NBR];
+#pragma unroll
+    for (int b = 0; b < NBR; ++b)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) att[b][j] = attL[(b * 3 + j) * 64 + wp];
+    const float nc = blend_from_att<NBR>(att, px, py, ep.ex[img], ep.ey[img], ep.w1, ep.b1, ep.w2, ep.temperature, logit);
+#pragma unroll
+    for (int b = 0; b < NBR; ++b) wL[b * 64 + wp] = logit[b];
+    if (px < W && py < H) ep.norm_curv[((size_t)img * H + py) * W + px] = nc;
+  }
+  wave_lds_fence();
+  float4 wq[NBR][4];
+#pragma unroll
+  for (int b = 0; b < NBR; ++b)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) wq[b][q] = *reinterpret_cast<const float4*>(wL + b * 64 + q * 16 + g * 4);
+  wave_lds_fence();                                            // the weights are in registers: the wave's region becomes its transposition tiles
+  float* trL = reinterpret_cast<float*>(lds + wave * C::WREG);                  // [q][block][16 pixels][TP]
+  double* red = reinterpret_cast<double*>(lds + 4 * C::WREG);  // [wave][NBLK * 16][2]: the four waves' sums of a tile, added below
+#pragma unroll
+  for (int nb = 0; nb < NCB; ++nb) {
+    const int co = nb * 16 + m;
+    const bool col = co < Cout;
+    float bvb[NBR];
+#pragma unroll
+    for (int b = 0; b < NBR; ++b) bvb[b] = (bias && col) ? bias[b * Co3 + co] : 0.f;
+    double ds = 0.0, dq = 0.0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int oy = oy0 + wave * 2 + (q >> 1), ox = ox0 + (q & 1) * 16 + g * 4;
+      float o[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float sacc = 0.f;
+#pragma unroll
+        for (int b = 0; b < NBR; ++b) {
+          const f32x4 a = acc[b][nb][q];
+          const float av = (i == 0 ? a.x : i == 1 ? a.y : i == 2 ? a.z : a.w) + bvb[b];
+          const float wv = i == 0 ? wq[b][q].x : i == 1 ? wq[b][q].y : i == 2 ? wq[b][q].z : wq[b][q].w;
+          sacc = sacc + av * wv;
+        }
+        o[i] = sacc;
+        trL[((q * NCB + nb) * 16 + g * 4 + i) * C::TP + m] = sacc;      // pixel row 4 g + i, channel column m
+      }
+      if (col && oy < H) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (ox + i < W) {
+            const double dv = (double)o[i];
+            ds += dv;
+            dq += dv * dv;
+          }
+      }
+    }
+    // the wave's 64 pixels of this channel: lanes (m, g = 0..3)
+    ds += __shfl_xor(ds, 16);
+    dq += __shfl_xor(dq, 16);
+    ds += __shfl_xor(ds, 32);
+    dq += __shfl_xor(dq, 32);
+    if (g == 0) {
+      red[(wave * NBLK * 16 + co) * 2] = ds;
+      red[(wave * NBLK * 16 + co) * 2 + 1] = dq;
+    }
+  }
+  wave_lds_fence();
+  // channels-last store: lane (m, g) takes pixel m of each x-run and channels 4 g .. 4 g + 3 of each block: 16 bytes
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int oy = oy0 + wave * 2 + (q >> 1), ox = ox0 + (q & 1) * 16 + m;
+    if (oy >= H || ox >= W) continue;
+    float* __restrict__ op = ep.out + (((size_t)img * H + oy) * W + ox) * CIN;
+#pragma unroll
+    for (int nb = 0; nb < NCB; ++nb) {
+      if (nb * 16 + 4 * g < Cout)
+        *reinterpret_cast<float4*>(op + nb * 16 + 4 * g) = *reinterpret_cast<const float4*>(trL + ((q * NCB + nb) * 16 + m) * C::TP + 4 * g);
+    }
+  }
+  __syncthreads();
+  // one record per (tile, channel): the four waves in a fixed order
+  if (tid < NBLK * 16 && tid < Cout) {
+    double* rec = ep.partial + (((size_t)img * parts + (size_t)tile) * Cout + tid) * 2;
+    rec[0] = (red[tid * 2] + red[(NBLK * 16 + tid) * 2]) + (red[(2 * NBLK * 16 + tid) * 2] + red[(3 * NBLK * 16 + tid) * 2]);
+    rec[1] = (red[tid * 2 + 1] + red[(NBLK * 16 + tid) * 2 + 1]) + (red[(2 * NBLK * 16 + tid) * 2 + 1] + red[(3 * NBLK * 16 + tid) * 2 + 1]);
+  }
+}
+
 // sum over the 16 lanes of a DPP row (all lanes end up with the total)
 __device__ __forceinline__ float row16_sum(float v) {
   v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
@@ -91,7 +220,7 @@ __global__ __launch_bounds__(256, 2) void dynconv_cl_kernel(const float* __restr
                                                             const uint4* __restrict__ wsp, const float* __restrict__ bias,
                                                             DynEpi ep, int N, int H, int W, int tiles_x, int tiles_y) {
   using C = DCfg<CIN, K0, K1, K2, MODE>;
-  constexpr int NBR = C::NBR, NBLK = C::NBLK, NCB = C::NCB, R = C::R, IXP = C::IXP, Cout = C::COUT, Co3 = C::CO3;
+  constexpr int NBR = C::NBR, NBLK = C::NBLK, R = C::R, IXP = C::IXP;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   int lin = cds_xcd_remap(blockIdx.x, tiles_x * tiles_y * N);
   const int tx_i = lin % tiles_x;
@@ -266,118 +395,147 @@ __global__ __launch_bounds__(256, 2) void dynconv_cl_kernel(const float* __restr
     }
     return;
   }
-  // ---- epilogue (the planar kernel's).  Accumulator layout: lane (m, g) holds column 16 nb + m of pixels x = (q & 1) 16 + 4 g + i,
-  // y = 2 wave + (q >> 1).  (1) the lanes of the three curvature columns leave them in LDS; (2) lane m of a 16-lane group owns pixel
-  // (q, i) = (m >> 2, m & 3) of its group: projection, MLP, softmax -> K weights into LDS, norm_curv to memory; (3) every lane reads the
-  // weights of its 16 pixels and blends its column; (4) the blended 16 x 16 tiles are transposed through LDS: a lane stores 4
-  // consecutive channels of one pixel.  InstanceNorm records per (wave, channel) as the planar kernel leaves them. ----
-  float* attL = reinterpret_cast<float*>(lds);                 // [b][j][256 pixels of the tile]
-  float* wL = attL + NBR * 3 * 256;                            // [b][256]
-  __syncthreads();                                             // every wave is done with the staged input tile
+  dyn_epilogue<C>(acc, lds, bias, ep, img, H, W, ox0, oy0, wave, m, g, tid, ty_i * tiles_x + tx_i, tiles_x * tiles_y);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// conv00 (module.py:209: DynamicConv 3 -> 8, kernel sizes 3 / 7 / 11) on the matrix cores.  Three input channels would leave 5/8 of a
+// K-step's 4 taps x 8 channels padding; here a K-step is 8 x-adjacent tap PAIRS... 4 k-groups x (2 taps x 4 channels, the 4th zero):
+// k = 3 / 7 / 11 take 2 + 7 + 17 = 26 K-steps (the 8-channel scheme: 41).  The image planes [S][3][H][W] are staged once per tile as
+// [term][row][x][4 ch] bf16 (8 bytes per position and term: a tap pair = 16 contiguous bytes = one LDS read per term), the A operand
+// of lane (m, g) is pixel m of its x-run at the pair 4 t + g; weights from ops.split_pack_conv00.  Same operand roles, accumulator
+// layout and epilogue as dynconv_cl_kernel.  An image SLOT is convolved once and blended for every output image that shows it: the
+// V copies of the reference image of a FeatureNet batch share slot 0, each with its own epipole.
+// ---------------------------------------------------------------------------------------------------------------------------
+struct C00 {
+  static constexpr int NBR = 3, NBLK = 1, NCB = 1, COUT = 8, CO3 = 11, TP = 20;
+  static constexpr int R = 5, HL = 8;                          // halo rows / staged halo columns (16-byte aligned image rows)
+  static constexpr int IXP = TX + 2 * HL, IY = TY + 2 * R, NPOS = IXP * IY, PLANE = NPOS * 8;
+  static constexpr int WREG = cmax(NBR * 4 * 64 * 4, 4 * NCB * 16 * TP * 4);
+  static constexpr int REDB = 4 * NBLK * 16 * 2 * 8;
+  static constexpr int LDSB = cmax(3 * PLANE, 4 * WREG + REDB);
+  static constexpr int KS[3] = {3, 7, 11};
+  static constexpr int pairs(int k) { return (k + 1) / 2; }
+  static constexpr int nks(int k) { return (k * pairs(k) + 3) / 4; }
+};
+
+__global__ __launch_bounds__(256, 2) void conv00_cl_kernel(const float* __restrict__ x, const uint4* __restrict__ wsp,
+                                                           const float* __restrict__ bias, DynEpi ep, int S, int n_shared, int H, int W,
+                                                           int tiles_x, int tiles_y) {
+  using C = C00;
+  constexpr int NBR = C::NBR, IXP = C::IXP, R = C::R, HL = C::HL;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  int lin = cds_xcd_remap(blockIdx.x, tiles_x * tiles_y * S);
+  const int tx_i = lin % tiles_x;
+  lin /= tiles_x;
+  const int ty_i = lin % tiles_y, slot = lin / tiles_y;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m = lane & 15, g = lane >> 4;
+  const int ox0 = tx_i * TX, oy0 = ty_i * TY;
+  const size_t plane = (size_t)H * W;
+
+  // ---- stage: unit = (row, x-quad): three 16-byte loads (one per colour plane), four positions of 4 channels (the 4th zero),
+  // exact 3-way bf16 split, per term four positions = 32 contiguous bytes ----
+  if (tid < C::IY * (IXP / 4)) {
+    const int row = tid / (IXP / 4), q4 = tid - row * (IXP / 4);
+    const int gy = oy0 - R + row, gx = ox0 - HL + 4 * q4;
+    float4 v[3];
 #pragma unroll
-  for (int nb = 0; nb < NBLK; ++nb) {
-    const int jj = nb * 16 + m - Cout;
-    if (jj < 0 || jj > 2) continue;
-#pragma unroll
-    for (int b = 0; b < NBR; ++b) {
-      const float bv = bias ? bias[b * Co3 + nb * 16 + m] : 0.f;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const f32x4 a = acc[b][nb][q];
-        *reinterpret_cast<float4*>(attL + (b * 3 + jj) * 256 + wave * 64 + q * 16 + g * 4) =
-            make_float4(a.x + bv, a.y + bv, a.z + bv, a.w + bv);
+    for (int c = 0; c < 3; ++c) {
+      v[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if ((unsigned)gy < (unsigned)H) {
+        const float* __restrict__ src = x + ((size_t)slot * 3 + c) * plane + (size_t)gy * W;
+        if (gx >= 0 && gx + 3 < W && (W & 3) == 0) {
+          v[c] = *reinterpret_cast<const float4*>(src + gx);
+        } else {
+          if ((unsigned)gx < (unsigned)W) v[c].x = src[gx];
+          if ((unsigned)(gx + 1) < (unsigned)W) v[c].y = src[gx + 1];
+          if ((unsigned)(gx + 2) < (unsigned)W) v[c].z = src[gx + 2];
+          if ((unsigned)(gx + 3) < (unsigned)W) v[c].w = src[gx + 3];
+        }
       }
     }
+    uint32_t h[4][2], md[4][2], lo[4][2];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const float c0 = p == 0 ? v[0].x : p == 1 ? v[0].y : p == 2 ? v[0].z : v[0].w;
+      const float c1 = p == 0 ? v[1].x : p == 1 ? v[1].y : p == 2 ? v[1].z : v[1].w;
+      const float c2 = p == 0 ? v[2].x : p == 1 ? v[2].y : p == 2 ? v[2].z : v[2].w;
+      split2(c0, c1, h[p][0], md[p][0], lo[p][0]);
+      split2(c2, 0.f, h[p][1], md[p][1], lo[p][1]);
+    }
+    unsigned char* d = lds + (row * IXP + 4 * q4) * 8;
+    uint4* d4;
+    d4 = reinterpret_cast<uint4*>(d);
+    d4[0] = make_uint4(h[0][0], h[0][1], h[1][0], h[1][1]);
+    d4[1] = make_uint4(h[2][0], h[2][1], h[3][0], h[3][1]);
+    d4 = reinterpret_cast<uint4*>(d + C::PLANE);
+    d4[0] = make_uint4(md[0][0], md[0][1], md[1][0], md[1][1]);
+    d4[1] = make_uint4(md[2][0], md[2][1], md[3][0], md[3][1]);
+    d4 = reinterpret_cast<uint4*>(d + 2 * C::PLANE);
+    d4[0] = make_uint4(lo[0][0], lo[0][1], lo[1][0], lo[1][1]);
+    d4[1] = make_uint4(lo[2][0], lo[2][1], lo[3][0], lo[3][1]);
   }
   __syncthreads();
-  {
-    const int wp = wave * 64 + (m >> 2) * 16 + g * 4 + (m & 3);
-    const int px = ox0 + ((m >> 2) & 1) * 16 + g * 4 + (m & 3), py = oy0 + wave * 2 + (m >> 3);
-    float att[NBR][3], logit[NBR];
-#pragma unroll
-    for (int b = 0; b < NBR; ++b)
-#pragma unroll
-      for (int j = 0; j < 3; ++j) att[b][j] = attL[(b * 3 + j) * 256 + wp];
-    const float nc = blend_from_att<NBR>(att, px, py, ep.ex[img], ep.ey[img], ep.w1, ep.b1, ep.w2, ep.temperature, logit);
-#pragma unroll
-    for (int b = 0; b < NBR; ++b) wL[b * 256 + wp] = logit[b];
-    if (px < W && py < H) ep.norm_curv[((size_t)img * H + py) * W + px] = nc;
-  }
-  __syncthreads();
-  float4 wq[NBR][4];
+
+  f32x4 acc[NBR][1][4];
 #pragma unroll
   for (int b = 0; b < NBR; ++b)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) wq[b][q] = *reinterpret_cast<const float4*>(wL + b * 256 + wave * 64 + q * 16 + g * 4);
-  __syncthreads();                                             // the weights are in registers: the area becomes the transposition tiles
-  constexpr int AREA = cmax(C::ATTB + C::WLB, C::TRB);
-  float* trL = reinterpret_cast<float*>(lds) + wave * (4 * NCB * 16 * C::TP);    // [q][block][16 pixels][TP]
-  double* red = reinterpret_cast<double*>(lds + AREA);         // [wave][NBLK * 16][2]: the four waves' sums of a tile, added below
+    for (int q = 0; q < 4; ++q) acc[b][0][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const uint4* __restrict__ wl = wsp + lane;
+  int ks0 = 0;
 #pragma unroll
-  for (int nb = 0; nb < NCB; ++nb) {
-    const int co = nb * 16 + m;
-    const bool col = co < Cout;
-    float bvb[NBR];
-#pragma unroll
-    for (int b = 0; b < NBR; ++b) bvb[b] = (bias && col) ? bias[b * Co3 + co] : 0.f;
-    double ds = 0.0, dq = 0.0;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int oy = oy0 + wave * 2 + (q >> 1), ox = ox0 + (q & 1) * 16 + g * 4;
-      float o[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        float sacc = 0.f;
-#pragma unroll
-        for (int b = 0; b < NBR; ++b) {
-          const f32x4 a = acc[b][nb][q];
-          const float av = (i == 0 ? a.x : i == 1 ? a.y : i == 2 ? a.z : a.w) + bvb[b];
-          const float wv = i == 0 ? wq[b][q].x : i == 1 ? wq[b][q].y : i == 2 ? wq[b][q].z : wq[b][q].w;
-          sacc = sacc + av * wv;
-        }
-        o[i] = sacc;
-        trL[((q * NCB + nb) * 16 + g * 4 + i) * C::TP + m] = sacc;      // pixel row 4 g + i, channel column m
+  for (int b = 0; b < NBR; ++b) {
+    const int k = C::KS[b], rk = (k - 1) >> 1, np = C::pairs(k), npairs = k * np, nks = C::nks(k);
+    const uint4* __restrict__ wb = wl + (size_t)ks0 * 3 * 64;
+#pragma unroll 1
+    for (int t = 0; t < nks; ++t) {
+      int pi = 4 * t + g;
+      if (pi >= npairs) pi = npairs - 1;                        // padded pair: zero weights, any in-tile data
+      const int ky = pi / np, kxp = pi - ky * np;
+      // pixel (row 2 wave + (q >> 1), x-run (q & 1)) x m: first tap of the pair at staged column HL + x - rk + 2 kxp
+      const unsigned char* ap = lds + (((wave * 2 + ky + R - rk) * IXP) + (HL - rk + 2 * kxp + m)) * 8;
+      BV wh, wm, wlo;
+      {
+        const uint4* p = wb + (size_t)(t * 3) * 64;
+        wh.u = p[0];
+        wm.u = p[64];
+        wlo.u = p[128];
       }
-      if (col && oy < H) {
+      BV ah[4], am[4], al[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-          if (ox + i < W) {
-            const double dv = (double)o[i];
-            ds += dv;
-            dq += dv * dv;
-          }
+      for (int q = 0; q < 4; ++q) {
+        const unsigned char* a = ap + ((q >> 1) * IXP + (q & 1) * 16) * 8;
+        const uint2 h0 = *reinterpret_cast<const uint2*>(a), h1 = *reinterpret_cast<const uint2*>(a + 8);
+        const uint2 m0 = *reinterpret_cast<const uint2*>(a + C::PLANE), m1 = *reinterpret_cast<const uint2*>(a + C::PLANE + 8);
+        const uint2 l0 = *reinterpret_cast<const uint2*>(a + 2 * C::PLANE), l1 = *reinterpret_cast<const uint2*>(a + 2 * C::PLANE + 8);
+        ah[q].u = make_uint4(h0.x, h0.y, h1.x, h1.y);
+        am[q].u = make_uint4(m0.x, m0.y, m1.x, m1.y);
+        al[q].u = make_uint4(l0.x, l0.y, l1.x, l1.y);
       }
-    }
-    // the wave's 64 pixels of this channel: lanes (m, g = 0..3)
-    ds += __shfl_xor(ds, 16);
-    dq += __shfl_xor(dq, 16);
-    ds += __shfl_xor(ds, 32);
-    dq += __shfl_xor(dq, 32);
-    if (g == 0) {
-      red[(wave * NBLK * 16 + co) * 2] = ds;
-      red[(wave * NBLK * 16 + co) * 2 + 1] = dq;
-    }
-  }
-  __syncthreads();
-  // channels-last store: lane (m, g) takes pixel m of each x-run and channels 4 g .. 4 g + 3 of each block: 16 bytes
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int oy = oy0 + wave * 2 + (q >> 1), ox = ox0 + (q & 1) * 16 + m;
-    if (oy >= H || ox >= W) continue;
-    float* __restrict__ op = ep.out + (((size_t)img * H + oy) * W + ox) * CIN;
+      for (int q = 0; q < 4; ++q) SBF_MFMA(acc[b][0][q], al[q], wh);    // order 2^-16 terms first
 #pragma unroll
-    for (int nb = 0; nb < NCB; ++nb) {
-      if (nb * 16 + 4 * g < Cout)
-        *reinterpret_cast<float4*>(op + nb * 16 + 4 * g) = *reinterpret_cast<const float4*>(trL + ((q * NCB + nb) * 16 + m) * C::TP + 4 * g);
+      for (int q = 0; q < 4; ++q) SBF_MFMA(acc[b][0][q], am[q], wm);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) SBF_MFMA(acc[b][0][q], ah[q], wlo);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) SBF_MFMA(acc[b][0][q], am[q], wh);    // 2^-8
+#pragma unroll
+      for (int q = 0; q < 4; ++q) SBF_MFMA(acc[b][0][q], ah[q], wm);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) SBF_MFMA(acc[b][0][q], ah[q], wh);    // leading term
     }
+    ks0 += nks;
   }
-  // one record per (tile, channel): the four waves in a fixed order
-  if (tid < NBLK * 16 && tid < Cout) {
-    const int parts = tiles_x * tiles_y;
-    double* rec = ep.partial + (((size_t)img * parts + (size_t)(ty_i * tiles_x + tx_i)) * Cout + tid) * 2;
-    rec[0] = (red[tid * 2] + red[(NBLK * 16 + tid) * 2]) + (red[(2 * NBLK * 16 + tid) * 2] + red[(3 * NBLK * 16 + tid) * 2]);
-    rec[1] = (red[tid * 2 + 1] + red[(NBLK * 16 + tid) * 2 + 1]) + (red[(2 * NBLK * 16 + tid) * 2 + 1] + red[(3 * NBLK * 16 + tid) * 2 + 1]);
-  }
+  // output images of this slot: the n_shared reference copies for slot 0, one image otherwise
+  const int first = slot == 0 ? 0 : slot + n_shared - 1, count = slot == 0 ? n_shared : 1;
+  for (int i = 0; i < count; ++i)
+    dyn_epilogue<C>(acc, lds, bias, ep, first + i, H, W, ox0, oy0, wave, m, g, tid, ty_i * tiles_x + tx_i, tiles_x * tiles_y);
 }
 
 template <int CIN, int K0, int K1, int K2, int MODE = 1>
@@ -883,6 +1041,30 @@ extern "C" int cds_dynconv_cl_f32(const float* x, const float* in_affine, const 
   if (C == 16 && k0 == 1 && k1 == 3 && k2 == 0) return launch_dynconv_cl<16, 1, 3, 0>(x, in_affine, weight_split, bias, ep, N, H, W, st);
   if (C == 32 && k0 == 1 && k1 == 3 && k2 == 0) return launch_dynconv_cl<32, 1, 3, 0>(x, in_affine, weight_split, bias, ep, N, H, W, st);
   return CDS_EINVAL;
+}
+
+// conv00 of FeatureNet (DynamicConv 3 -> 8, kernel sizes 3 / 7 / 11) in ONE kernel on the matrix cores, channels-last result.
+// x [S][3][H][W] planar images, S = N - n_shared + 1 slots: slot 0 is shown by the first n_shared output images (the reference copies of a
+// FeatureNet batch, each with its own epipole), slot s > 0 by image n_shared - 1 + s.  weight_split = ops.split_pack_conv00, bias
+// [3][11] or NULL; w1 [4][3], b1 [4], w2 [3][4] the attention MLP; epipoles_host [N][2] -> out [N][H][W][8], norm_curv [N][H][W],
+// partial [N][cds_dynconv_cl_parts(H, W)][8][2] doubles.
+extern "C" int cds_conv00_cl_f32(const float* x, const void* weight_split, const float* bias, const float* w1, const float* b1,
+                                 const float* w2, const float* epipoles_host, float temperature, float* out, float* norm_curv,
+                                 double* partial, int N, int n_shared, int H, int W, void* stream) {
+  if (!x || !weight_split || !w1 || !b1 || !w2 || !epipoles_host || !out || !norm_curv || !partial || N < 1 || N > CDS_MAX_IMAGES ||
+      n_shared < 1 || n_shared > N || H < 1 || W < 1)
+    return CDS_EINVAL;
+  DynEpi ep;
+  ep.w1 = w1; ep.b1 = b1; ep.w2 = w2; ep.out = out; ep.norm_curv = norm_curv; ep.partial = partial; ep.temperature = temperature;
+  for (int n = 0; n < CDS_MAX_IMAGES; ++n) {
+    ep.ex[n] = n < N ? epipoles_host[2 * n] : 0.f;
+    ep.ey[n] = n < N ? epipoles_host[2 * n + 1] : 0.f;
+  }
+  const int S = N - n_shared + 1;
+  const int tx = cds_ceil_div(W, TX), ty = cds_ceil_div(H, TY);
+  hipLaunchKernelGGL(conv00_cl_kernel, dim3(tx * ty * S), dim3(256), (size_t)C00::LDSB, (hipStream_t)stream, x,
+                     reinterpret_cast<const uint4*>(weight_split), bias, ep, S, n_shared, H, W, tx, ty);
+  return cds_launch_status();
 }
 
 extern "C" int cds_blend_cl_parts(int H, int W) { return 4 * cds_ceil_div(H * W, 256 * BCL_PXT); }

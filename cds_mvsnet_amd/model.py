@@ -35,6 +35,7 @@ OVERLAP_STAGE1 = os.environ.get("CDS_OVERLAP_STAGE1", "1") != "0"
 OVERLAP_STAGE2 = os.environ.get("CDS_OVERLAP_STAGE2", "0") == "1"   # A/B knob: stage 2 as well (next to the full-resolution FPN level)
 # FeatureNet on channels-last activations (csrc/feat_cl.hip, round 5); CDS_FEAT_CL=0: the planar kernels of rounds 1-4
 USE_FEAT_CL = os.environ.get("CDS_FEAT_CL", "1") != "0"
+USE_CONV00_MFMA = os.environ.get("CDS_CONV00_MFMA", "1") != "0"   # A/B knob: 0 = conv00's branches on the VALU kernels + blend kernel
 _SIDE_STREAMS: Dict[int, "torch.cuda.Stream"] = {}
 
 
@@ -446,6 +447,12 @@ class _FeatureRunner:
                                                             for i in range(len(dc.size_kernels))])
                 if dc.convs[0].bias is not None:
                     out[f"{name}.bs"] = torch.stack([out[f"{name}.b{i}"] for i in range(len(dc.size_kernels))]).contiguous()
+            if name == "conv00" and USE_SPLIT_BF16 and ops.USE_CONV2D_SBF and dc.size_kernels == (3, 7, 11) and dc.att_convs[0].weight.is_cuda:
+                # conv00 on the matrix cores (csrc/feat_cl.hip: tap-pair K-steps for the 3-channel input)
+                out[f"{name}.ws00"] = ops.split_pack_conv00([torch.cat((dc.convs[i].weight.detach(), dc.att_convs[i].weight.detach()), dim=0)
+                                                             for i in range(3)])
+                if dc.convs[0].bias is not None:
+                    out[f"{name}.bs"] = torch.stack([out[f"{name}.b{i}"] for i in range(3)]).contiguous()
             scale, shift = _bn_fold(dc.att_weights[1])
             nk = len(dc.size_kernels)
             out[f"{name}.m1"] = (dc.att_weights[0].weight.detach().reshape(4, nk) * scale.view(4, 1)).contiguous()
@@ -580,6 +587,25 @@ class _FeatureRunner:
         gather) and planar for the reference views in the same pass - no transposition kernels."""
         net = self.net
         N, _, H, W = imgs.shape
+        # conv00 (3 input channels, kernel sizes 3 / 7 / 11) sees the raw planar images; the n_shared reference copies are convolved
+        # once and blended per copy (its own epipole).  Default: one matrix-core kernel (tap-pair K-steps); CDS_CONV00_MFMA=0: the
+        # VALU branch kernels + a blend kernel that writes channels-last
+        dc = net.conv00.conv
+        xs = imgs[n_shared - 1:] if n_shared > 1 else imgs
+        if "conv00.ws00" in p and USE_CONV00_MFMA:
+            c00, n00, _, a00 = ops.conv00_cl(xs.contiguous(), p["conv00.ws00"], p.get("conv00.bs"), p["conv00.m1"], p["conv00.mb"],
+                                             p["conv00.m2"], e0, T, n_shared, 0.1)
+            return self._after_conv00(p, c00, n00, a00, e0, e1, e2, T, n_chw, on_stage1)
+        branches = torch.empty((len(dc.size_kernels), xs.shape[0], dc.out_c + 3, H, W), dtype=torch.float32, device=imgs.device)
+        for i, k in enumerate(dc.size_kernels):
+            ops.conv2d(xs, p[f"conv00.w{i}"], p.get(f"conv00.b{i}"), dc.out_c + 3, k, 1, (k - 1) // 2, ACT_NONE, out=branches[i])
+        c00, n00, _, a00 = ops.dynconv_blend_cl(branches, p["conv00.m1"], p["conv00.mb"], p["conv00.m2"], e0, T, n_shared, 0.1)
+        del branches
+        return self._after_conv00(p, c00, n00, a00, e0, e1, e2, T, n_chw, on_stage1)
+
+    def _after_conv00(self, p, c00: Tensor, n00: Tensor, a00: Tensor, e0: Tensor, e1: Tensor, e2: Tensor, T: float, n_chw: int, on_stage1):
+        net = self.net
+        N = c00.shape[0]
 
         def dyn(name: str, dc: DynamicConv, x: Tensor, epi: Tensor, aff: Optional[Tensor]):
             return ops.dynconv_cl(x, p[f"{name}.ws"], p.get(f"{name}.bs"), dc.size_kernels, p[f"{name}.m1"], p[f"{name}.mb"],
@@ -589,15 +615,6 @@ class _FeatureRunner:
             y = ops.conv2d_k3s2_cl(x, p[f"{name}.w9"], getattr(net, name).conv.out_channels, aff)
             return y, ops.instnorm_stats_cl(y, 0.1)[1]
 
-        # conv00 (3 input channels, 11 x 11): VALU branch kernels on the planar images, once for the n_shared reference copies;
-        # its blend writes channels-last
-        dc = net.conv00.conv
-        xs = imgs[n_shared - 1:] if n_shared > 1 else imgs
-        branches = torch.empty((len(dc.size_kernels), xs.shape[0], dc.out_c + 3, H, W), dtype=torch.float32, device=imgs.device)
-        for i, k in enumerate(dc.size_kernels):
-            ops.conv2d(xs, p[f"conv00.w{i}"], p.get(f"conv00.b{i}"), dc.out_c + 3, k, 1, (k - 1) // 2, ACT_NONE, out=branches[i])
-        c00, n00, _, a00 = ops.dynconv_blend_cl(branches, p["conv00.m1"], p["conv00.mb"], p["conv00.m2"], e0, T, n_shared, 0.1)
-        del branches
         c01, n01, _, a01 = dyn("conv01", net.conv01.conv, c00, e0, a00)
         del c00
         d0, ad0 = down("downsample1", c01, a01)

@@ -714,6 +714,51 @@ def split_pack_dynconv(ws) -> Tensor:
     return _split3(torch.cat(parts, dim=1))
 
 
+def split_pack_conv00(ws) -> Tensor:
+    """Pack the branch weights of conv00 (DynamicConv 3 -> 8: ws = [Co3 = 11, 3, k, k] for k = 3, 7, 11: convs[k] and att_convs[k]
+    concatenated) for cds_conv00_cl_f32: a K-step is 4 x-adjacent tap PAIRS x (2 taps x 4 channels, the 4th zero).  int16
+    [sum_k ceil(k ceil(k/2) / 4) = 26][3][64][8]; lane l = 16 g + n multiplies output channel n by the pair 4 t + g = (ky, kxp), values
+    (kx = 2 kxp: c0 c1 c2 0, kx = 2 kxp + 1: c0 c1 c2 0); pairs beyond k ceil(k/2), kx = k and channels beyond Co3 are zero."""
+    parts = []
+    for w in ws:
+        co3, cin, k, _ = w.shape
+        if cin != 3 or co3 > 16:
+            raise ValueError("split_pack_conv00: weights must be [<=16, 3, k, k]")
+        np_ = (k + 1) // 2
+        npairs, nks = k * np_, (k * np_ + 3) // 4
+        wp = torch.zeros((co3, 3, k, 2 * np_), dtype=torch.float32, device=w.device)
+        wp[..., :k] = w.detach().float()
+        t = torch.zeros((16, nks * 4, 2, 4), dtype=torch.float32, device=w.device)                  # [col][pair][tap of the pair][ch]
+        t[:co3, :npairs, :, :3] = wp.reshape(co3, 3, k, np_, 2).permute(0, 2, 3, 4, 1).reshape(co3, npairs, 2, 3)
+        parts.append(t.reshape(16, nks, 4, 8).permute(1, 2, 0, 3).reshape(nks, 64, 8))              # [t][16 g + n][8]
+    return _split3(torch.cat(parts, dim=0))
+
+
+def conv00_cl(imgs: Tensor, wsplit: Tensor, bias: Optional[Tensor], w1: Tensor, b1: Tensor, w2: Tensor, epipoles: Tensor,
+              temperature: float, n_shared: int = 1, stats_slope: float = 0.1):
+    """conv00 of FeatureNet in one kernel on the matrix cores.  imgs [S,3,H,W] planar (S = N - n_shared + 1 slots: slot 0 is shown by
+    the first n_shared of the N output images), epipoles CPU [N,2] -> (out_cl [N,H,W,8], norm_curv [N,H,W], stats [N,8,2] float64,
+    affine [N,8,3])."""
+    S, C, H, W = imgs.shape
+    N = S + n_shared - 1
+    if C != 3 or tuple(epipoles.shape) != (N, 2) or n_shared < 1:
+        raise ValueError(f"conv00_cl: need imgs [S,3,H,W] and epipoles [S + n_shared - 1, 2], got {tuple(imgs.shape)}, {tuple(epipoles.shape)}")
+    if wsplit.dtype != torch.int16 or wsplit.numel() != 26 * 3 * 64 * 8:
+        raise ValueError("conv00_cl: wsplit must come from split_pack_conv00 (kernel sizes 3, 7, 11)")
+    if bias is not None and tuple(bias.shape) != (3, 11):
+        raise ValueError("conv00_cl: bias must be [3, 11]")
+    dev = imgs.device
+    lib = _lib.load()
+    out = torch.empty((N, H, W, 8), dtype=torch.float32, device=dev)
+    nc = torch.empty((N, H, W), dtype=torch.float32, device=dev)
+    partial = torch.empty((N, lib.cds_dynconv_cl_parts(H, W), 8, 2), dtype=torch.float64, device=dev)
+    check(lib.cds_conv00_cl_f32(_dev(imgs, "imgs"), wsplit.data_ptr(), _dev(bias, "bias") if bias is not None else None, _dev(w1, "w1"),
+                                _dev(b1, "b1"), _dev(w2, "w2"), _host(epipoles, "epipoles"), float(temperature), out.data_ptr(),
+                                nc.data_ptr(), partial.data_ptr(), N, n_shared, H, W, _stream(imgs)), "cds_conv00_cl_f32")
+    stats, affine = _reduce_records(partial, N, 8, H, W, stats_slope)
+    return out, nc, stats, affine
+
+
 def dynconv_branches_sbf(x: Tensor, wsplit: Tensor, bias: Optional[Tensor], co3: int, ksizes, out: Optional[Tensor] = None,
                          in_affine: Optional[Tensor] = None) -> Tensor:
     """All branch convolutions of a DynamicConv on the matrix cores: x [N,Cin,H,W] -> branches [K,N,co3,H,W]."""

@@ -397,6 +397,13 @@ int cds_dynconv_cl_parts(int H, int W);
 int cds_dynconv_cl_f32(const float* x, const float* in_affine, const void* weight_split, const float* bias, const float* w1,
                        const float* b1, const float* w2, const float* epipoles_host, float temperature, float* out,
                        float* norm_curv, double* partial, int N, int C, int H, int W, const int* ksizes, int nb, void* stream);
+/* conv00 of FeatureNet (module.py:209: DynamicConv 3 -> 8, kernel sizes 3 / 7 / 11) in ONE kernel on the matrix cores: x [S][3][H][W]
+ * planar images in S = N - n_shared + 1 slots (slot 0 is shown by the first n_shared output images, each with its own epipole),
+ * weight_split = ops.split_pack_conv00, bias [3][11] or NULL -> out [N][H][W][8], norm_curv [N][H][W],
+ * partial [N][cds_dynconv_cl_parts(H, W)][8][2] doubles. */
+int cds_conv00_cl_f32(const float* x, const void* weight_split, const float* bias, const float* w1, const float* b1, const float* w2,
+                      const float* epipoles_host, float temperature, float* out, float* norm_curv, double* partial, int N, int n_shared,
+                      int H, int W, void* stream);
 int cds_blend_cl_parts(int H, int W);
 int cds_dynconv_blend_cl_f32(const float* branches, const float* w1, const float* b1, const float* w2, const float* epipoles_host,
                              float temperature, float* out, float* norm_curv, double* partial, int N, int K, int Cout, int H, int W,

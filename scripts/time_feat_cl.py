@@ -35,6 +35,24 @@ for name, c, ks, H, W in (("conv01", 8, (3, 5, 7), 1184, 1600), ("conv10", 16, (
     floor = mfma * 16 / (1024 * 2.1e9) * 1e6                        # us at 16 cycles per MFMA and SIMD, 2.1 GHz
     print(f"{name}: planar fused {tp:8.1f} us   channels-last {tc:8.1f} us   (matrix-pipe floor {floor:6.1f} us = {floor / tc * 100:4.1f} %)   "
           f"max |diff| {(o1 - o2).abs().max().item():.2e} equal {torch.equal(o1, o2)}")
+if not only or "conv00" in only:
+    H, W, V = 1184, 1600, 4
+    imgs = torch.rand(1 + V, 3, H, W, generator=g).to(dev)
+    ks = (3, 7, 11)
+    ws = [torch.cat((torch.randn(8, 3, k, k, generator=g) / (3 * k * k) ** 0.5, torch.randn(3, 3, k, k, generator=g) * 0.1)).to(dev) for k in ks]
+    w1, b1, w2 = torch.randn(4, 3, generator=g).to(dev), torch.randn(4, generator=g).to(dev), torch.randn(3, 4, generator=g).to(dev)
+    epi = torch.tensor([[W * 0.3 + 5.0 * n, -H * 1.7 - n] for n in range(2 * V)], dtype=torch.float32)
+    wpk = [_pack2d(w) for w in ws]
+    wsp = ops.split_pack_conv00(ws)
+    def valu():
+        br = torch.empty((3, 1 + V, 11, H, W), device=dev)
+        for i, k in enumerate(ks):
+            ops.conv2d(imgs, wpk[i], None, 11, k, 1, (k - 1) // 2, ops.ACT_NONE, out=br[i])
+        return ops.dynconv_blend_cl(br, w1, b1, w2, epi, 0.01, V, 0.1)
+    mfma = 26 * 6 * ((1 + V) * H * W / 16)
+    floor = mfma * 16 / (1024 * 2.1e9) * 1e6
+    tm = t(lambda: ops.conv00_cl(imgs, wsp, None, w1, b1, w2, epi, 0.01, V, 0.1))
+    print(f"conv00 (5 slots -> 8 images): VALU branches + blend {t(valu):8.1f} us   matrix cores {tm:8.1f} us   (matrix-pipe floor {floor:6.1f} us = {floor / tm * 100:4.1f} %)")
 if not only or "small" in only:
     # the small layers: downsample1 / 2, inner1 / 2, the tanh outputs
     for name, cin, cout, H, W in (("downsample1", 8, 16, 1184, 1600), ("downsample2", 16, 32, 592, 800)):

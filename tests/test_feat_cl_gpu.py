@@ -156,8 +156,9 @@ def test_instnorm_apply_cl(C, N, H, W, n_chw, dev, ops):
 
 def test_feature_runner_layouts_agree(dev, ops, monkeypatch):
     """The whole FeatureNet on channels-last activations against the planar runner of rounds 1-4 on the same weights and images
-    (three pairs: shared reference copies, CHW + HWC outputs, partial tiles at every level): features to 5e-5 at T = 0.01 (the
-    two paths differ by fp32 summation order in conv00's successors, amplified by softmax(./T)), curvature maps alike."""
+    (three pairs: shared reference copies, CHW + HWC outputs, partial tiles at every level): mean difference <= 1e-5 at T = 0.01 (the
+    two paths differ by conv00's arithmetic - split-bf16 matrix cores vs fp32 fmaf chains - and by fp32 summation order in the VALU
+    layers, amplified by softmax(./T)), curvature maps alike."""
     import cds_mvsnet_amd.model as cm
     from cds_mvsnet_amd import FeatureNet, seeded_init_
     net = seeded_init_(FeatureNet(8), 7).to(dev).eval()
@@ -176,7 +177,7 @@ def test_feature_runner_layouts_agree(dev, ops, monkeypatch):
         for j in range(4):
             assert a[j].shape == b[j].shape, (s, j, a[j].shape, b[j].shape)
             err = (a[j] - b[j]).abs()
-            assert err.mean().item() < 2e-6 and err.max().item() < 2e-3, (s, j, err.mean().item(), err.max().item())
+            assert err.mean().item() < 1e-5 and err.max().item() < 2e-3, (s, j, err.mean().item(), err.max().item())
 
 
 @pytest.mark.parametrize("c,ks,N,H,W", [(8, (1, 3), 8, 592, 800), (8, (3, 5, 7), 8, 296, 400), (16, (3, 5), 8, 296, 400), (16, (1, 3), 8, 296, 400),
@@ -238,3 +239,42 @@ def test_visibility_layers_channels_last(V, H, W, dev, ops):
         assert torch.equal(got.permute(0, 3, 1, 2), old)
         oldh = ops.conv2d_k3_relu_sbf(xin.to(dev).contiguous(), ws, b.to(dev), head_w=hw.to(dev), head_b=hb.to(dev))
         assert torch.equal(goth, oldh)
+
+
+@pytest.mark.parametrize("N,n_shared,H,W", [(4, 2, 24, 40), (1, 1, 9, 13), (5, 3, 16, 100), (3, 1, 40, 70), (8, 4, 64, 96)])
+def test_conv00_on_matrix_cores(N, n_shared, H, W, dev, ops):
+    """cds_conv00_cl_f32 (conv00: 3 -> 8 + 3, kernel sizes 3 / 7 / 11, tap-pair K-steps on the matrix cores, blend fused, shared
+    reference slots) against the exact-fp32 VALU branch kernels + blend kernel it replaces and against float64: fp32-class
+    (error vs float64 <= 1.5x the VALU kernels'), blended output / curvature within the softmax(./T) amplification of that round-off;
+    partial tiles, widths that are not multiples of 4, several slots."""
+    import torch.nn.functional as F
+    from cds_mvsnet_amd.model import _pack2d
+    g = torch.Generator().manual_seed(N * 10 + W)
+    S = N - n_shared + 1
+    imgs = torch.rand(S, 3, H, W, generator=g)
+    ks = (3, 7, 11)
+    ws = [torch.cat((torch.randn(8, 3, k, k, generator=g) / (3 * k * k) ** 0.5, torch.randn(3, 3, k, k, generator=g) * 0.1)) for k in ks]
+    w1, b1, w2 = torch.randn(4, 3, generator=g).to(dev), torch.randn(4, generator=g).to(dev), torch.randn(3, 4, generator=g).to(dev)
+    epi = torch.tensor([[W * 0.4 + 3.0 * n, H * 2.1 + n] for n in range(N)], dtype=torch.float32)
+    br = torch.empty((3, S, 11, H, W), device=dev)
+    for i, k in enumerate(ks):
+        ops.conv2d(imgs.to(dev), _pack2d(ws[i].to(dev)), None, 11, k, 1, (k - 1) // 2, ops.ACT_NONE, out=br[i])
+    wsp = ops.split_pack_conv00([w.to(dev) for w in ws])
+    # branch responses themselves: T -> infinity makes the blend the plain mean of the three branches
+    for T in (1e9, 1.0, 0.01):
+        o2, n2, s2, a2 = ops.dynconv_blend_cl(br, w1, b1, w2, epi, T, n_shared, 0.1)
+        o1, n1, s1, a1 = ops.conv00_cl(imgs.to(dev), wsp, None, w1, b1, w2, epi, T, n_shared, 0.1)
+        assert o1.shape == o2.shape == (N, H, W, 8)
+        tol = 3e-6 if T >= 1.0 else 3e-4
+        assert (o1 - o2).abs().max().item() <= tol * max(1.0, o2.abs().max().item()), (T, (o1 - o2).abs().max().item())
+        assert (n1 - n2).abs().max().item() <= tol * max(1.0, n2.abs().max().item()), (T, (n1 - n2).abs().max().item())
+        if T >= 1.0:
+            assert torch.allclose(a1, a2, rtol=2e-4, atol=2e-5)
+    # float64: the mean-of-branches output (T = 1e9) against F.conv2d
+    want = sum(F.conv2d(imgs.double(), w[:8].double(), padding=(k - 1) // 2) for w, k in zip(ws, ks)) / 3.0
+    o1 = ops.conv00_cl(imgs.to(dev), wsp, None, w1, b1, w2, epi, 1e9, n_shared, 0.1)[0].permute(0, 3, 1, 2).cpu().double()
+    o2 = ops.dynconv_blend_cl(br, w1, b1, w2, epi, 1e9, n_shared, 0.1)[0].permute(0, 3, 1, 2).cpu().double()
+    slot = [0] * n_shared + list(range(1, S))
+    e1 = max((o1[n] - want[slot[n]]).abs().max().item() for n in range(N))
+    e2 = max((o2[n] - want[slot[n]]).abs().max().item() for n in range(N))
+    assert e1 <= 1.5 * e2 + want.abs().max().item() * 2.0 ** -22, (e1, e2)
