@@ -103,6 +103,11 @@ SIGNATURES = {
     "cds_pack_conv2d_f32": [P, P, P, P, I, I, I, I, P],
     "cds_pack_conv3d_f32": [P, P, P, I, I, I, P],
     "cds_softargmin_bwd_f32": [P, P, P, P, I, I, I, I, P],
+    "cds_loss_records": [ctypes.c_longlong],
+    "cds_loss_stage_f32": [P, P, P, P, P, P, P, I, I, I, P, P, P],
+    "cds_loss_final_f32": [P, P, P, P, P, P, I, P, P, P, P],
+    "cds_loss_stage_bwd_f32": [P, P, P, P, P, P, P, P, F, I, I, I, P, P, P, P],
+    "cds_feat_target_f32": [P, P, P, F, F, I, I, I, P, P],
     "cds_depth_fusion_f32": [P, P, P, P, P, P, P, P, P, I, I, I, P, F, F, F, P],
 }
 

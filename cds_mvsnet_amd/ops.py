@@ -1170,3 +1170,16 @@ def view_mean(x: Tensor) -> Tensor:
     out = torch.empty(tuple(x.shape[1:]), dtype=torch.float32, device=x.device)
     check(_lib.load().cds_view_mean_f32(_dev(x, "x"), out.data_ptr(), x.shape[0], out.numel(), _stream(x)), "cds_view_mean_f32")
     return out
+
+
+def feat_target(hyp: Tensor, gt: Tensor, interval: Tensor, scale: float, thresh: float) -> Tensor:
+    """Targets of the feature-distance loss (models/model.py:202-207): hyp [B,D,h,w], gt [B,h,w], interval [B] (device) ->
+    [B,D+1,h,w] = |hyp - gt| / (interval x scale) < thresh, last plane 1."""
+    B, D, h, w = hyp.shape
+    hyp, gt, interval = hyp.detach().float().contiguous(), gt.detach().float().contiguous(), interval.detach().float().contiguous()
+    if tuple(gt.shape) != (B, h, w) or interval.numel() != B:
+        raise ValueError(f"feat_target: gt {tuple(gt.shape)} / interval {tuple(interval.shape)} do not match hyp {tuple(hyp.shape)}")
+    out = torch.empty((B, D + 1, h, w), dtype=torch.float32, device=hyp.device)
+    check(_lib.load().cds_feat_target_f32(hyp.data_ptr(), gt.data_ptr(), interval.data_ptr(), float(scale), float(thresh), B, D, h * w,
+                                          out.data_ptr(), _stream(hyp)), "cds_feat_target_f32")
+    return out

@@ -313,6 +313,7 @@ def forward_train(model, imgs: Tensor, proj_matrices: Dict[str, Tensor], depth_v
     outputs: Dict[str, object] = {}
     depth = None
     dint_all = (dv[:, 1] - dv[:, 0])
+    dint_dev = dint_all.to(dev) if gt_depths is not None else None
     # One stream per stage (CDS_TRAIN_STAGE_STREAMS=1, experiment): the forward stays serial (a stage's hypotheses need the previous
     # stage's depth) but depth is DETACHED between stages, so the three backward chains are independent and autograd runs each on the
     # stream of its forward - next to each other.  Every tensor that crosses streams is recorded on the other stream (caching allocator).
@@ -352,10 +353,7 @@ def forward_train(model, imgs: Tensor, proj_matrices: Dict[str, Tensor], depth_v
                                      gt_depth=gt_depths[name] if gt_depths is not None else None)
             depth = st["depth"]
             if gt_depths is not None:                                            # model.py:202-207
-                gt_s = gt_depths[name].unsqueeze(1)
-                di_stage = dint_all.to(dev).view(B, 1, 1, 1) * float(scale)
-                target = ((hyp_b - gt_s).abs() / di_stage < 0.5 / float(scale)).float()
-                st["feat_target"] = torch.cat((target, torch.ones_like(gt_s)), dim=1)
+                st["feat_target"] = ops.feat_target(hyp_b, gt_depths[name], dint_dev, float(scale), 0.5 / float(scale))
             if use_streams:
                 for t in st.values():
                     if isinstance(t, torch.Tensor):

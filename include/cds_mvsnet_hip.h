@@ -541,6 +541,26 @@ int cds_pack_conv3d_f32(const float* w, float* fwd, float* dgrad, int A, int B, 
 int cds_softargmin_bwd_f32(const float* prob_pre, const float* hyp, const float* gdepth, float* gpre, int D, int h, int w,
                            int hyp_per_pixel, void* stream);
 
+/* final_loss on the device (reference: models/losses.py:6-48; replaces ~90 ATen launches forward and ~150 backward per step) and the
+ * feature-distance targets (models/model.py:202-207).  Sums in fp64 through per-workgroup records reduced in a fixed order.
+ *   cds_loss_records(n):       records a pass over n elements writes (recA: x 4 doubles over B h w pixels; recB: x 1 over B Dp h w).
+ *   cds_loss_stage_f32:        passes over one stage: depth, gt, mask [B][hw] (mask > 0.5 selects), norm_curv [B][hw] or NULL, dist / target
+ *                              [B][Dp][hw] or both NULL (no feature term: the refined-depth stage), interval [B] on the DEVICE.
+ *   cds_loss_final_f32:        total = sum_s weight_s (depth_s + 5 feature_s + 0.1 curvature_s), depth_loss of the last stage (device
+ *                              scalars) and scalars [n_stages][4] doubles for the backward; host arrays of n_stages <= 4 entries.
+ *   cds_loss_stage_bwd_f32:    gdepth [B][hw], gnc [B][hw] or NULL, gdist [B][Dp][hw] or NULL from the device scalar gtotal.
+ *   cds_feat_target_f32:       target [B][D+1][hw] = |hyp - gt| / (di[b] scale) < thresh (planes < D), 1 (plane D); di [B] on the DEVICE. */
+int cds_loss_records(long long elements);
+int cds_loss_stage_f32(const float* depth, const float* gt, const float* mask, const float* norm_curv, const float* dist,
+                       const float* target, const float* interval, int B, int hw, int Dp, double* recA, double* recB, void* stream);
+int cds_loss_final_f32(const double* const* recA, const double* const* recB, const long long* pixels, const int* Dp, const float* weight,
+                       const int* has_curv, int n_stages, float* total, float* depth_loss, double* scalars, void* stream);
+int cds_loss_stage_bwd_f32(const float* depth, const float* gt, const float* mask, const float* dist, const float* target,
+                           const float* interval, const float* gtotal, const double* scalars, float weight, int B, int hw, int Dp,
+                           float* gdepth, float* gnc, float* gdist, void* stream);
+int cds_feat_target_f32(const float* hyp, const float* gt, const float* di, float scale, float thresh, int B, int D, int hw,
+                        float* target, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

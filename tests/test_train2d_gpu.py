@@ -321,3 +321,80 @@ def test_zero_arena_exhaustion_falls_back_to_torch_zeros():
     for n in res[old][1]:
         a, b = res[4096][1][n].double(), res[old][1][n].double()
         assert (a - b).abs().max().item() <= 1e-5 * max(b.abs().max().item(), 1e-6), n
+
+
+def _loss_case(B, sizes, refined, weights, seed, empty_mask_rows=False):
+    g = torch.Generator().manual_seed(seed)
+    dev = torch.device("cuda:0")
+    interval = (2.0 + torch.rand(B, generator=g)).to(dev)
+    inputs, gt, mask = {}, {}, {}
+    for i, (h, w, D) in enumerate(sizes):
+        key = f"stage{i + 1}"
+        gt[key] = (600 + 100 * torch.rand(B, h, w, generator=g)).to(dev)
+        m = (torch.rand(B, h, w, generator=g) > 0.3).float()
+        if empty_mask_rows:
+            m[:, : h // 2] = 0
+        mask[key] = m.to(dev)
+        target = (torch.rand(B, D + 1, h, w, generator=g) < 0.1).float()
+        target[:, -1] = 1
+        inputs[key] = {"depth": (gt[key] + 6 * torch.randn(B, h, w, generator=g).to(dev)).requires_grad_(),
+                       "norm_curv": torch.rand(B, 1, h, w, generator=g).to(dev).requires_grad_(),
+                       "feat_distance": (3 * torch.randn(B, D + 1, h, w, generator=g)).to(dev).requires_grad_(),
+                       "feat_target": target.to(dev)}
+    if refined:
+        h, w, _ = sizes[-1]
+        gt["stage4"] = (600 + 100 * torch.rand(B, 2 * h, 2 * w, generator=g)).to(dev)
+        mask["stage4"] = (torch.rand(B, 2 * h, 2 * w, generator=g) > 0.2).float().to(dev)
+        inputs["refined_depth"] = (gt["stage4"] + 3 * torch.randn(B, 2 * h, 2 * w, generator=g).to(dev)).requires_grad_()
+    return inputs, gt, mask, interval, weights
+
+
+@pytest.mark.parametrize("B,sizes,refined,weights", [(1, ((9, 12, 6), (18, 24, 4), (36, 48, 2)), True, [0.5, 1.0, 2.0]),
+                                                     (2, ((17, 23, 48), (34, 46, 32), (68, 92, 8)), False, None),
+                                                     (1, ((72, 96, 48), (144, 192, 32), (288, 384, 8)), True, [0.5, 1.0, 2.0])])
+def test_fused_final_loss_equals_aten(B, sizes, refined, weights):
+    """csrc/loss.hip (models/losses.py:6-48 in 8 + 4 launches) against the ATen formulation the golden vectors G11 pin to the reference:
+    loss / depth loss to 2e-6 relative (fp64 sums against fp32 tree sums), every input gradient to 1e-5 of its largest magnitude."""
+    from cds_mvsnet_amd import losses
+    inputs, gt, mask, interval, w = _loss_case(B, sizes, refined, weights, 3)
+    kw = {"depth_interval": interval}
+    if w is not None:
+        kw["dlossw"] = w
+    leaves = [t for st in inputs.values() for t in (st.values() if isinstance(st, dict) else [st]) if t.requires_grad]
+    ref, ref_dl = losses.final_loss_aten(inputs, gt, mask, **kw)
+    g_ref = torch.autograd.grad(ref, leaves)
+    got, got_dl = losses.final_loss(inputs, gt, mask, **kw)
+    assert got.grad_fn is not None and type(got.grad_fn).__name__.startswith("_FusedLoss")
+    g_got = torch.autograd.grad(got * 1.0, leaves)
+    assert abs(got.item() - ref.item()) <= 2e-6 * abs(ref.item()), (got.item(), ref.item())
+    assert abs(got_dl.item() - ref_dl.item()) <= 2e-6 * abs(ref_dl.item())
+    for i, (a, b) in enumerate(zip(g_got, g_ref)):
+        _close(a, b, f"gradient {i}", rel=1e-5)
+    again, _ = losses.final_loss(inputs, gt, mask, **kw)
+    assert again.item() == got.item()                                  # fixed summation order
+
+
+def test_fused_final_loss_half_empty_mask_and_feature_less_stage():
+    from cds_mvsnet_amd import losses
+    inputs, gt, mask, interval, _ = _loss_case(2, ((10, 14, 5), (20, 28, 3), (40, 56, 2)), True, None, 8, empty_mask_rows=True)
+    for key in ("stage1", "stage2", "stage3"):                         # eval-style outputs: no feature-distance volume
+        del inputs[key]["feat_distance"], inputs[key]["feat_target"]
+    leaves = [inputs[k]["depth"] for k in ("stage1", "stage2", "stage3")] + [inputs[k]["norm_curv"] for k in ("stage1", "stage2", "stage3")]
+    ref, _ = losses.final_loss_aten(inputs, gt, mask, depth_interval=interval)
+    got, _ = losses.final_loss(inputs, gt, mask, depth_interval=interval)
+    assert abs(got.item() - ref.item()) <= 2e-6 * abs(ref.item())
+    for a, b in zip(torch.autograd.grad(got, leaves), torch.autograd.grad(ref, leaves)):
+        _close(a, b, "gradient", rel=1e-5)
+
+
+def test_feat_target_kernel():
+    from cds_mvsnet_amd import ops
+    g = torch.Generator().manual_seed(2)
+    B, D, h, w, scale = 2, 7, 13, 22, 2.0
+    dev = torch.device("cuda:0")
+    gt = (600 + 50 * torch.rand(B, h, w, generator=g)).to(dev)
+    hyp = (gt.unsqueeze(1) + 3 * torch.randn(B, D, h, w, generator=g).to(dev)).contiguous()
+    di = torch.tensor([2.5, 3.1], device=dev)
+    ref = torch.cat((((hyp - gt.unsqueeze(1)).abs() / (di.view(B, 1, 1, 1) * scale) < 0.5 / scale).float(), torch.ones(B, 1, h, w, device=dev)), 1)
+    got = ops.feat_target(hyp, gt, di, scale, 0.5 / scale)
+    assert torch.equal(got, ref) and 0 < ref[:, :-1].mean().item() < 1
