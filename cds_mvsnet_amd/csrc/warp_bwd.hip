@@ -117,11 +117,19 @@ __global__ __launch_bounds__(256) void warp_aggregate_bwd_kernel(const float* __
 // The same gradients with the scatter into grad_src privatised in LDS.  The samples of a (tile, view, depth segment) land in a
 // bounded box of source texels (the warp is a homography: neighbouring pixels and planes map to neighbouring texels), so the
 // workgroup first finds that box (a cheap pass over the sample positions), accumulates the 4 x 8 tap contributions of every
-// sample with LDS atomics into [box texel][8 channels], and then adds the box to grad_src with ONE coalesced pass of global
+// sample with LDS atomics into [8 channels][box texel], and then adds the box to grad_src with ONE coalesced pass of global
 // atomics (box-size many, on consecutive addresses) instead of 32 scattered ones per pixel and cell change.  Boxes that do
 // not fit (BWD_BOX texels) fall back to the direct scatter above, decided per workgroup.
+//
+// The LDS accumulators are 64-bit FIXED POINT, not fp32: ds_add_f32 retires ~0.35 lanes per clock and CU on gfx950 whatever the
+// address pattern (85 % of this kernel's time when the box was fp32: profiles/r05_k3_bwd.md), ds_add_u64 is ~30 x faster.  The first
+// pass also finds M = max |g ref vis| over the workgroup's samples; a contribution coef x weight (<= M in magnitude, product taken in
+// fp64 = exact) is scaled by 2^E with M 2^E < 2^45, rounded to an integer and added: 2^16 contributions cannot overflow 63 bits, the
+// rounding is 2^-45 of M per contribution (fp32 atomics: 2^-24 of the running sum), and integer addition is associative, so the box
+// is independent of the order the lanes arrive in.  Non-finite M (a NaN / inf in the gradient) takes the fp32 direct scatter, which
+// propagates it.
 #ifndef CDS_K3BWD_BOX
-#define CDS_K3BWD_BOX 1536   // texels: 48 KB of LDS -> three workgroups per CU (build with a tiny value to force the fallback path)
+#define CDS_K3BWD_BOX 1024   // texels: 64 KB of LDS -> two workgroups per CU (build with a tiny value to force the fallback path)
 #endif
 constexpr int BWD_BOX = CDS_K3BWD_BOX;
 
@@ -175,8 +183,10 @@ __global__ __launch_bounds__(256) void warp_aggregate_bwd_box_kernel(const float
                                                                      int C, int D, int h, int w, int hyp_pp, int tiles_x,
                                                                      int ntiles, int nseg, int seg_planes) {
   constexpr int CG = 8;
-  __shared__ float box[BWD_BOX * CG];
+  constexpr int BOXP = BWD_BOX + 1;                         // channel-planar [c][texel]: the lanes of one ds_add (neighbouring pixels) hit neighbouring words
+  __shared__ long long box[BOXP * CG];
   __shared__ int lim[4];                                   // xmin, ymin, xmax, ymax of the touched texels
+  __shared__ unsigned mbits;                               // bits of M = max |g ref vis| (non-negative floats order like their bit patterns; NaN on top)
   const int ngroups = C / CG;
   int lin = cds_xcd_remap(blockIdx.x, ntiles * V * ngroups * nseg);
   const int seg = lin % nseg;
@@ -200,14 +210,20 @@ __global__ __launch_bounds__(256) void warp_aggregate_bwd_box_kernel(const float
   float r[3];
   cds_row_terms(m, (float)x, (float)y, r);
   const int d_lo = seg * seg_planes, d_hi = min(D, d_lo + seg_planes);
+  const float vw = live ? vis[(size_t)v * hw + pix] : 0.f;
+  float rf[CG];
+#pragma unroll
+  for (int c = 0; c < CG; ++c) rf[c] = live ? ref[((size_t)v * C + c0 + c) * hw + pix] : 0.f;
 
-  // ---- pass 1: the box ----
+  // ---- pass 1: the box and the magnitude bound ----
   if (threadIdx.x == 0) {
     lim[0] = 1 << 30; lim[1] = 1 << 30; lim[2] = -(1 << 30); lim[3] = -(1 << 30);
+    mbits = 0u;
   }
   __syncthreads();
   {
     int xmin = 1 << 30, ymin = 1 << 30, xmax = -(1 << 30), ymax = -(1 << 30);
+    float mx = 0.f;
     if (live)
       for (int d = d_lo; d < d_hi; ++d) {
         const float dv = hyp_pp ? hyp[(size_t)d * hw + pix] : hyp[d];
@@ -215,37 +231,49 @@ __global__ __launch_bounds__(256) void warp_aggregate_bwd_box_kernel(const float
         if (tp.any) {
           xmin = min(xmin, max(tp.x0, 0)); ymin = min(ymin, max(tp.y0, 0));
           xmax = max(xmax, min(tp.x0 + 1, w - 1)); ymax = max(ymax, min(tp.y0 + 1, h - 1));
+#pragma unroll
+          for (int c = 0; c < CG; ++c) {
+            const float a = fabsf(gvol[((size_t)(c0 + c) * D + d) * hw + pix] * rf[c] * vw);
+            mx = (a > mx || a != a) ? a : mx;               // a NaN sticks
+          }
         }
       }
+    unsigned mb = __float_as_uint(mx) & 0x7fffffffu;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
       xmin = min(xmin, __shfl_xor(xmin, o)); ymin = min(ymin, __shfl_xor(ymin, o));
       xmax = max(xmax, __shfl_xor(xmax, o)); ymax = max(ymax, __shfl_xor(ymax, o));
+      mb = max(mb, (unsigned)__shfl_xor((int)mb, o));
     }
     if ((threadIdx.x & 63) == 0) {
       atomicMin(&lim[0], xmin); atomicMin(&lim[1], ymin); atomicMax(&lim[2], xmax); atomicMax(&lim[3], ymax);
+      atomicMax(&mbits, mb);
     }
   }
   __syncthreads();
   const int bx0 = lim[0], by0 = lim[1];
   const int bw = lim[2] - lim[0] + 1, bh = lim[3] - lim[1] + 1;
   const bool empty = bw <= 0 || bh <= 0;
-  const bool boxed = !empty && bw * bh <= BWD_BOX;          // (workgroup-uniform)
+  const int ef = (int)(mbits >> 23);                        // M < 2^(ef - 126)
+  const bool boxed = !empty && bw * bh <= BWD_BOX && ef != 255;   // (workgroup-uniform)
+  const bool scatter = mbits != 0u;                         // M == 0: every contribution to grad_src is zero
+  // contributions per box cell <= 256 pixels x planes of the segment (one tap of a sample per cell): 2^16 up to 256 planes
+  int extra = 0;
+  while ((256 << extra) < d_hi - d_lo) ++extra;
+  const int E = 45 - extra - (ef - 126);
+  const double scale = __longlong_as_double((long long)(E + 1023) << 52), inv_scale = __longlong_as_double((long long)(1023 - E) << 52);
   if (boxed) {
-    for (int i = threadIdx.x; i < bw * bh * CG; i += 256) box[i] = 0.f;
+    for (int i = threadIdx.x; i < bw * bh * CG; i += 256) box[(i % CG) * BOXP + i / CG] = 0;
     __syncthreads();
   }
 
   // ---- pass 2 ----
+  constexpr double MAGIC = 6755399441055744.0;              // 1.5 x 2^52: (x + MAGIC) holds round(x) in its low mantissa bits, |x| < 2^51
   float gv = 0.f;
   float gr[CG];
 #pragma unroll
   for (int c = 0; c < CG; ++c) gr[c] = 0.f;
   if (live && !empty) {
-    const float vw = vis[(size_t)v * hw + pix];
-    float rf[CG];
-#pragma unroll
-    for (int c = 0; c < CG; ++c) rf[c] = ref[((size_t)v * C + c0 + c) * hw + pix];
     for (int d = d_lo; d < d_hi; ++d) {
       const float dv = hyp_pp ? hyp[(size_t)d * hw + pix] : hyp[d];
       const TapsXY tp = cds_taps_xy(r, m + 9, dv, h, w, half_w, half_h);
@@ -271,14 +299,27 @@ __global__ __launch_bounds__(256) void warp_aggregate_bwd_box_kernel(const float
         gv = fmaf(g[c] * rf[c], wv[c], gv);
         coef[c] = g[c] * rf[c] * vw;
       }
+      if (!scatter) continue;
+      if (boxed) {
+        double cd[CG];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        if (off[t] < 0) continue;
-        if (boxed) {
-          float* dst = box + (((tp.y0 + (t >> 1) - by0) * bw + (tp.x0 + (t & 1) - bx0)) * CG);
+        for (int c = 0; c < CG; ++c) cd[c] = (double)coef[c];
 #pragma unroll
-          for (int c = 0; c < CG; ++c) atomicAdd(dst + c, coef[c] * tp.wt[t]);      // ds_add_f32
-        } else {
+        for (int t = 0; t < 4; ++t) {
+          if (off[t] < 0) continue;
+          const double wd = (double)tp.wt[t] * scale;
+          unsigned long long* dst =
+              reinterpret_cast<unsigned long long*>(box) + ((tp.y0 + (t >> 1) - by0) * bw + (tp.x0 + (t & 1) - bx0));
+#pragma unroll
+          for (int c = 0; c < CG; ++c) {
+            const long long q = __double_as_longlong(fma(cd[c], wd, MAGIC)) - __double_as_longlong(MAGIC);
+            atomicAdd(dst + c * BOXP, (unsigned long long)q);                            // ds_add_u64
+          }
+        }
+      } else {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          if (off[t] < 0) continue;
           float* dst = gsrcv + (size_t)off[t] * C + c0;
 #pragma unroll
           for (int c = 0; c < CG; ++c) atomicAdd(dst + c, coef[c] * tp.wt[t]);
@@ -289,14 +330,14 @@ __global__ __launch_bounds__(256) void warp_aggregate_bwd_box_kernel(const float
     for (int c = 0; c < CG; ++c) atomicAdd(&gref[((size_t)v * C + c0 + c) * hw + pix], gr[c] * vw);
     atomicAdd(&gvis[(size_t)v * hw + pix], gv);
   }
-  if (boxed) {
+  if (boxed && scatter) {
     __syncthreads();
     for (int i = threadIdx.x; i < bw * bh * CG; i += 256) {
-      const float val = box[i];
-      if (val != 0.f) {
-        const int t = i / CG, c = i - t * CG;
+      const int t = i / CG, c = i - t * CG;
+      const long long q = box[c * BOXP + t];
+      if (q != 0) {
         const int by = t / bw, bxx = t - by * bw;
-        atomicAdd(&gsrcv[((size_t)(by0 + by) * w + bx0 + bxx) * C + c0 + c], val);
+        atomicAdd(&gsrcv[((size_t)(by0 + by) * w + bx0 + bxx) * C + c0 + c], (float)((double)q * inv_scale));
       }
     }
   }

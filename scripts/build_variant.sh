@@ -10,7 +10,7 @@ mkdir -p $out/obj_$tag
 cd $root/cds_mvsnet_amd/csrc
 objs=""
 # ONLY="feat_cl conv2d" scripts/build_variant.sh tag -D...: recompile only those sources with the flags, link the tree's other objects
-for f in lib warp warp_lds warp_bwd regress conv3d conv3d_mfma conv3d_sbf conv3d_zmg deconv_prob_zm deconv3d_zm conv2d conv2d_mfma conv2d_sbf feat_cl fusion refine train3d train2d; do
+for f in lib warp warp_lds warp_bwd regress conv3d conv3d_mfma conv3d_sbf conv3d_zmg deconv_prob_zm deconv3d_zm conv2d conv2d_mfma conv2d_sbf feat_cl fusion refine train3d train2d loss; do
   if [ -n "$ONLY" ] && ! echo " $ONLY " | grep -q " $f "; then objs="$objs $root/cds_mvsnet_amd/csrc/$f.o"; continue; fi
   extra=""; if [ "$f" = feat_cl ] || [ "$f" = conv2d_sbf ]; then extra="-fno-slp-vectorize"; fi   # as in the Makefile
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-function $extra "$@" -c $f.hip -o $out/obj_$tag/$f.o &

@@ -107,15 +107,18 @@ def _train_sample(dev, B=1, N=3, H=64, W=96):
 def test_train_step_fp32():
     """Three optimisation steps from the same weights with the weight-gradient side stream allowed and forbidden: step 1 audits a
     single-stream backward (train._backward), steps 2 and 3 run the weight gradients on the side stream when the audit allows it;
-    the loss of step 3 depends on the gradients of both kinds of step and must agree with the single-stream run."""
+    the loss of step 3 depends on the gradients of both kinds of step and must agree with the single-stream run as well as two
+    single-stream runs agree with each other: the fp32 atomics of the K3 / weight-gradient kernels make the gradients of a step differ
+    from run to run in the last bits, and two Adam updates at lr 1e-3 turn that into 1e-3 .. 4e-3 of the step-3 loss
+    (scripts/ab/r05_side_stream_diag.py: six trials, single-stream runs 88.34 .. 88.60), so a fixed bound is a coin flip."""
     from cds_mvsnet_amd import CDSMVSNet, seeded_init_
     dev = torch.device("cuda")
     sample = _train_sample(dev)
     losses = {}
     old = T.SIDE_STREAM_WGRAD
     try:
-        for side in (False, True):
-            T.SIDE_STREAM_WGRAD = side
+        for side in (False, "again", True):
+            T.SIDE_STREAM_WGRAD = side is True
             model = seeded_init_(CDSMVSNet(refine=False, ndepths=(48, 32, 8), depth_interals_ratio=(4.0, 2.0, 1.0)), 7).to(dev)
             opt = T.make_optimizer(model, lr=1e-3)
             before = {n: p.detach().clone() for n, p in model.named_parameters()}
@@ -124,12 +127,14 @@ def test_train_step_fp32():
             moved = sum(1 for n, p in model.named_parameters() if not torch.equal(p.detach(), before[n]))
             assert moved > 0.9 * len(before)                 # every layer is trained (weight decay touches all of them)
             losses[side] = ls
-            if side:
+            if side is True:
                 assert T._SIDE_VERDICT[model][1] is True      # one gradient per parameter, handed over untouched: the side stream is sound
     finally:
         T.SIDE_STREAM_WGRAD = old
     assert abs(losses[True][0][0] - losses[False][0][0]) <= 1e-5 * abs(losses[False][0][0])
-    assert abs(losses[True][2][0] - losses[False][2][0]) <= 2e-3 * abs(losses[False][2][0]), losses
+    assert abs(losses[True][1][0] - losses[False][1][0]) <= 1e-5 * abs(losses[False][1][0])
+    noise = abs(losses["again"][2][0] - losses[False][2][0])
+    assert abs(losses[True][2][0] - losses[False][2][0]) <= max(3 * noise, 5e-3 * abs(losses[False][2][0])), losses
 
 
 @pytest.mark.gpu
