@@ -40,6 +40,8 @@ SIGNATURES = {
     "cds_warp_entropy_window_f32": [P, P, P, P, P, I, I, I, I, I, I, I, I, P],
     "cds_warp_aggregate_window_f32": [P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, P],
     "cds_warp_aggregate_bwd_f32": [P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, P],
+    "cds_volume_finish_f32": [P, P, P, I, I, I, I, P, P, P],
+    "cds_volume_finish_bwd_f32": [P, P, P, P, P, I, I, I, I, P, P, P, P, P],
     "cds_volume_normalize_f32": [P, P, I, I, I, P],
     "cds_volume_normalize_cl_f32": [P, P, I, I, I, P],
     "cds_softargmin_conf_f32": [P, P, P, P, P, I, I, I, I, P],
@@ -84,6 +86,7 @@ SIGNATURES = {
     "cds_instnorm_stats_cl_f32": [P, P, I, I, I, I, P],
     "cds_instnorm_apply_cl_f32": [P, P, P, P, I, I, I, I, I, I, I, P],
     "cds_curvature_stats_f32": [P, P, P, P, P, I, P],
+    "cds_curvature_stats_bwd_f32": [P, P, P, P, P, P, P, P, I, P],
     "cds_pair_mean_f32": [P, P, I, I, P],
     "cds_view_mean_f32": [P, P, I, I, P],
     "cds_depth_affine_f32": [P, P, I, F, F, P],
@@ -103,6 +106,7 @@ SIGNATURES = {
     "cds_pack_conv2d_f32": [P, P, P, P, I, I, I, I, P],
     "cds_pack_conv3d_f32": [P, P, P, I, I, I, P],
     "cds_softargmin_bwd_f32": [P, P, P, P, I, I, I, I, P],
+    "cds_dynconv_bwd_finish_f32": [P, P, I, I, P, P],
     "cds_loss_records": [ctypes.c_longlong],
     "cds_loss_stage_f32": [P, P, P, P, P, P, P, I, I, I, P, P, P],
     "cds_loss_final_f32": [P, P, P, P, P, P, I, P, P, P, P],

@@ -737,6 +737,20 @@ __global__ __launch_bounds__(256) void curvature_stats_kernel(const float* __res
   nc_abs[i] = fabsf(vc);
 }
 
+// backward of curvature_stats_kernel: ga = (g_sum / 3) 2 a, ..., gc += g_abs sgn(c); g_sum / g_abs may be NULL (no gradient)
+__global__ __launch_bounds__(256) void curvature_stats_bwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                                  const float* __restrict__ c, const float* __restrict__ g_sum,
+                                                                  const float* __restrict__ g_abs, float* __restrict__ ga,
+                                                                  float* __restrict__ gb, float* __restrict__ gc, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float gs = g_sum ? g_sum[i] / 3.0f : 0.f;
+  const float vc = c[i];
+  ga[i] = gs * (2.0f * a[i]);
+  gb[i] = gs * (2.0f * b[i]);
+  gc[i] = gs * (2.0f * vc) + (g_abs ? g_abs[i] * (vc > 0.f ? 1.f : (vc < 0.f ? -1.f : 0.f)) : 0.f);
+}
+
 // out[v][i] = (x[v][i] + x[V+v][i]) / 2: per pair (ref_nc_sum + src_nc_sum) / 2 (model.py:59)
 __global__ __launch_bounds__(256) void pair_mean_kernel(const float* __restrict__ x, float* __restrict__ out, int V, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -772,6 +786,14 @@ extern "C" int cds_curvature_stats_f32(const float* a, const float* b, const flo
   if (!a || !b || !c || !nc_sum || !nc_abs || n < 1) return CDS_EINVAL;
   hipLaunchKernelGGL(curvature_stats_kernel, dim3(cds_ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, a, b, c,
                      nc_sum, nc_abs, n);
+  return cds_launch_status();
+}
+
+extern "C" int cds_curvature_stats_bwd_f32(const float* a, const float* b, const float* c, const float* g_sum, const float* g_abs,
+                                           float* ga, float* gb, float* gc, int n, void* stream) {
+  if (!a || !b || !c || !ga || !gb || !gc || n < 1) return CDS_EINVAL;
+  hipLaunchKernelGGL(curvature_stats_bwd_kernel, dim3(cds_ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, a, b, c, g_sum, g_abs,
+                     ga, gb, gc, n);
   return cds_launch_status();
 }
 

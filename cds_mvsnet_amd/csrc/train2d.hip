@@ -736,6 +736,30 @@ extern "C" int cds_dynconv_blend_bwd_f32(const float* branches, const float* epi
   return blend_dispatch_k(K, 3, a, nullptr, nullptr, gy, gnc, sums, count, use_batch, gbr, dw1, st);
 }
 
+namespace {
+__global__ void dynconv_bwd_finish_kernel(const double* __restrict__ sums, const double* __restrict__ dw1, int G, int K,
+                                          float* __restrict__ out) {
+  const int i = threadIdx.x;
+  if (i < 2 * HID) {                                        // dbeta_j (i < 4), dgamma_j: the groups in a fixed order
+    double s = 0.0;
+    for (int g = 0; g < G; ++g) s += sums[g * 2 * HID + i];
+    out[i] = (float)s;
+  } else if (i < 2 * HID + K * HID) {
+    out[i] = (float)sums[G * 2 * HID + (i - 2 * HID)];      // dw2 [K][4]
+  } else if (i < 2 * HID + 2 * K * HID) {
+    out[i] = (float)dw1[i - 2 * HID - K * HID];             // dw1 [4][K]
+  }
+}
+}  // namespace
+
+// The small gradients of a DynamicConv's attention MLP from the fp64 accumulators of cds_dynconv_blend_bwd_f32 in one launch:
+// out = [dbeta (4) | dgamma (4) | dw2 [K][4] | dw1 [4][K]] floats.
+extern "C" int cds_dynconv_bwd_finish_f32(const double* sums, const double* dw1, int G, int K, float* out, void* stream) {
+  if (!sums || !dw1 || !out || G < 1 || K < 1 || K > 3) return CDS_EINVAL;
+  hipLaunchKernelGGL(dynconv_bwd_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sums, dw1, G, K, out);
+  return cds_launch_status();
+}
+
 // gpre [D][h][w] = d (sum_d softmax(prob_pre)_d hyp_d) / d prob_pre * gdepth [h][w]
 extern "C" int cds_softargmin_bwd_f32(const float* prob_pre, const float* hyp, const float* gdepth, float* gpre, int D, int h, int w,
                                       int hyp_per_pixel, void* stream) {

@@ -380,3 +380,103 @@ extern "C" int cds_warp_aggregate_bwd_f32(const float* ref_chw, const float* src
                      ntiles, nseg, seg_planes);
   return cds_launch_status();
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// The training step's epilogue of K3 (models/model.py:56-78): cost volume = sum / (sum_v vis + 1e-6), feature distance
+// fd[d] = (sum_c volume_sum[c][d]) / (sum_v vis + 1e-6) and, with the ground-truth plane, fd[D] from gt_sum; one launch forward,
+// two backward (the reduction over planes of d(denominator) goes through per-plane partial sums: no atomics, fixed order).
+// ---------------------------------------------------------------------------------------------------------------------------
+namespace {
+
+__device__ __forceinline__ float vis_denominator(const float* __restrict__ vis, int V, size_t hw, size_t p) {
+  float s = vis[p];
+  for (int v = 1; v < V; ++v) s += vis[(size_t)v * hw + p];
+  return s + 1e-6f;
+}
+
+__global__ __launch_bounds__(256) void volume_finish_kernel(const float* __restrict__ vsum, const float* __restrict__ gtsum,
+                                                            const float* __restrict__ vis, int V, int C, int D, int hw,
+                                                            float* __restrict__ vol, float* __restrict__ fd) {
+  const int p = blockIdx.x * 256 + threadIdx.x, d = blockIdx.y;
+  if (p >= hw) return;
+  const float den = vis_denominator(vis, V, hw, p);
+  float s = 0.f;
+  for (int c = 0; c < C; ++c) {
+    const size_t i = ((size_t)c * D + d) * hw + p;
+    const float x = vsum[i];
+    vol[i] = x / den;
+    s = c ? s + x : x;
+  }
+  fd[(size_t)d * hw + p] = s / den;
+  if (gtsum && d == 0) {
+    float g = gtsum[p];
+    for (int c = 1; c < C; ++c) g += gtsum[(size_t)c * hw + p];
+    fd[(size_t)D * hw + p] = g / den;
+  }
+}
+
+__global__ __launch_bounds__(256) void volume_finish_bwd_kernel(const float* __restrict__ gvol, const float* __restrict__ gfd,
+                                                                const float* __restrict__ vsum, const float* __restrict__ vis, int V,
+                                                                int C, int D, int hw, float* __restrict__ gvsum,
+                                                                float* __restrict__ part) {
+  const int p = blockIdx.x * 256 + threadIdx.x, d = blockIdx.y;
+  if (p >= hw) return;
+  const float den = vis_denominator(vis, V, hw, p);
+  const float gf = gfd ? gfd[(size_t)d * hw + p] : 0.f;
+  float acc = 0.f;
+  for (int c = 0; c < C; ++c) {
+    const size_t i = ((size_t)c * D + d) * hw + p;
+    const float g = (gvol ? gvol[i] : 0.f) + gf;
+    gvsum[i] = g / den;
+    acc = fmaf(g, vsum[i], acc);
+  }
+  part[(size_t)d * hw + p] = acc;
+}
+
+__global__ __launch_bounds__(256) void volume_finish_bwd_vis_kernel(const float* __restrict__ part, const float* __restrict__ gfd,
+                                                                    const float* __restrict__ gtsum, const float* __restrict__ vis, int V,
+                                                                    int C, int D, int hw, float* __restrict__ ggt,
+                                                                    float* __restrict__ gvis) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= hw) return;
+  const float den = vis_denominator(vis, V, hw, p);
+  float tot = 0.f;
+  for (int d = 0; d < D; ++d) tot += part[(size_t)d * hw + p];
+  if (gtsum) {
+    const float gf = gfd ? gfd[(size_t)D * hw + p] : 0.f;
+    for (int c = 0; c < C; ++c) {
+      ggt[(size_t)c * hw + p] = gf / den;
+      tot = fmaf(gf, gtsum[(size_t)c * hw + p], tot);
+    }
+  }
+  const float gden = -tot / (den * den);
+  for (int v = 0; v < V; ++v) gvis[(size_t)v * hw + p] = gden;
+}
+
+}  // namespace
+
+// volume_sum [C][D][hw] (un-normalised K3), gt_sum [C][hw] (K3 at the ground-truth depth) or NULL, vis [V][hw] ->
+// volume [C][D][hw], feat_distance [D (+ 1 with gt_sum)][hw].
+extern "C" int cds_volume_finish_f32(const float* volume_sum, const float* gt_sum, const float* vis, int V, int C, int D, int hw,
+                                     float* volume, float* feat_distance, void* stream) {
+  if (!volume_sum || !vis || !volume || !feat_distance || V < 1 || C < 1 || D < 1 || D > 65535 || hw < 1) return CDS_EINVAL;
+  hipLaunchKernelGGL(volume_finish_kernel, dim3(cds_ceil_div(hw, 256), D), dim3(256), 0, (hipStream_t)stream, volume_sum, gt_sum, vis, V,
+                     C, D, hw, volume, feat_distance);
+  return cds_launch_status();
+}
+
+// Its backward.  g_volume [C][D][hw] / g_feat_distance [D (+ 1)][hw] (either may be NULL: no gradient) -> g_volume_sum [C][D][hw],
+// g_gt_sum [C][hw] (with gt_sum), g_vis [V][hw]; scratch: D x hw floats.
+extern "C" int cds_volume_finish_bwd_f32(const float* g_volume, const float* g_feat_distance, const float* volume_sum, const float* gt_sum,
+                                         const float* vis, int V, int C, int D, int hw, float* g_volume_sum, float* g_gt_sum, float* g_vis,
+                                         float* scratch, void* stream) {
+  if (!volume_sum || !vis || !g_volume_sum || !g_vis || !scratch || (gt_sum != nullptr) != (g_gt_sum != nullptr) || V < 1 || C < 1 ||
+      D < 1 || D > 65535 || hw < 1)
+    return CDS_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(volume_finish_bwd_kernel, dim3(cds_ceil_div(hw, 256), D), dim3(256), 0, st, g_volume, g_feat_distance, volume_sum,
+                     vis, V, C, D, hw, g_volume_sum, scratch);
+  hipLaunchKernelGGL(volume_finish_bwd_vis_kernel, dim3(cds_ceil_div(hw, 256)), dim3(256), 0, st, scratch, g_feat_distance, gt_sum, vis, V,
+                     C, D, hw, g_gt_sum, g_vis);
+  return cds_launch_status();
+}

@@ -242,9 +242,11 @@ def warp_aggregate_bwd(ref_chw: Tensor, src_hwc: Tensor, vis_w: Tensor, mats: Te
         raise ValueError(f"warp_aggregate_bwd: grad_volume must be {(C, D, h, w)}, got {tuple(grad_volume.shape)}")
     if tuple(src_hwc.shape) != (V, h, w, C) or tuple(mats.shape) != (V, 12) or tuple(vis_w.shape) != (V, h, w):
         raise ValueError("warp_aggregate_bwd: inconsistent shapes")
-    g_ref = torch.zeros_like(ref_chw)      # the kernel accumulates partial sums (channel groups x depth segments) with atomics
-    g_src = torch.zeros_like(src_hwc)
-    g_vis = torch.zeros_like(vis_w)
+    # the kernel accumulates partial sums (channel groups x depth segments) with atomics: ONE zero fill for the three gradients
+    flat = torch.zeros((ref_chw.numel() + src_hwc.numel() + vis_w.numel(),), dtype=torch.float32, device=ref_chw.device)
+    g_ref = flat[:ref_chw.numel()].view_as(ref_chw)
+    g_src = flat[ref_chw.numel():ref_chw.numel() + src_hwc.numel()].view_as(src_hwc)
+    g_vis = flat[ref_chw.numel() + src_hwc.numel():].view_as(vis_w)
     lib = _lib.load()
     # every gradient is per view: groups of MAX_VIEWS views are independent launches (like the forward's chunks)
     for v0 in range(0, V, MAX_VIEWS):
@@ -276,6 +278,46 @@ class WarpAggregate(torch.autograd.Function):
         ref_chw, src_hwc, vis_w, hyp = ctx.saved_tensors
         g_ref, g_src, g_vis = warp_aggregate_bwd(ref_chw, src_hwc, vis_w, ctx.mats, hyp, grad_volume.contiguous())
         return g_ref, g_src, g_vis, None, None
+
+
+class VolumeFinish(torch.autograd.Function):
+    """(volume, feat_distance) of the training step from the un-normalised K3 outputs (models/model.py:56-78): volume_sum [C,D,h,w],
+    gt_sum [C,1,h,w] or None, vis [V,h,w] -> volume_sum / (sum_v vis + 1e-6) and [D (+1),h,w] = channel sums / the same denominator.
+    One launch forward, two backward (8 + ~15 ATen launches otherwise)."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, volume_sum, gt_sum, vis):
+        volume_sum, vis = volume_sum.contiguous(), vis.contiguous()
+        gt_sum = gt_sum.contiguous() if gt_sum is not None else None
+        C, D, h, w = volume_sum.shape
+        V = vis.shape[0]
+        if tuple(vis.shape) != (V, h, w) or (gt_sum is not None and tuple(gt_sum.shape) != (C, 1, h, w)):
+            raise ValueError("VolumeFinish: inconsistent shapes")
+        vol = torch.empty_like(volume_sum)
+        fd = torch.empty((D + (1 if gt_sum is not None else 0), h, w), dtype=torch.float32, device=vol.device)
+        check(_lib.load().cds_volume_finish_f32(_dev(volume_sum, "volume_sum"), gt_sum.data_ptr() if gt_sum is not None else None,
+                                                _dev(vis, "vis"), V, C, D, h * w, vol.data_ptr(), fd.data_ptr(), _stream(vol)),
+              "cds_volume_finish_f32")
+        ctx.save_for_backward(volume_sum, gt_sum, vis)
+        return vol, fd
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, g_vol, g_fd):
+        volume_sum, gt_sum, vis = ctx.saved_tensors
+        C, D, h, w = volume_sum.shape
+        V = vis.shape[0]
+        g_vol = g_vol.contiguous().float() if g_vol is not None else None
+        g_fd = g_fd.contiguous().float() if g_fd is not None else None
+        g_vs = torch.empty_like(volume_sum)
+        g_gt = torch.empty_like(gt_sum) if gt_sum is not None else None
+        g_vis = torch.empty_like(vis)
+        scratch = torch.empty((D, h, w), dtype=torch.float32, device=vis.device)
+        p = lambda t: t.data_ptr() if t is not None else None                                       # noqa: E731
+        check(_lib.load().cds_volume_finish_bwd_f32(p(g_vol), p(g_fd), p(volume_sum), p(gt_sum), p(vis), V, C, D, h * w, p(g_vs), p(g_gt),
+                                                    p(g_vis), p(scratch), _stream(vis)), "cds_volume_finish_bwd_f32")
+        return g_vs, g_gt, g_vis
 
 
 def volume_normalize_(volume: Tensor, vis_sum: Tensor, channels_last: bool = False) -> Tensor:

@@ -257,10 +257,11 @@ class _DynConvFn(torch.autograd.Function):
                                             _p(beta.detach().contiguous()), _p(mean), _p(rstd), T, _p(gy), _p(gnc), gbr.data_ptr(),
                                             sums.data_ptr(), dw1.data_ptr(), N, G, K, cout, H, W, 1 if use_batch else 0, 1, st),
               "cds_dynconv_blend_bwd_f32")
-        grp = sums[:G * 8].view(G, 2, 4).sum(dim=0)
-        g_beta, g_gamma = grp[0].float(), grp[1].float()
-        g_w2 = sums[G * 8:].view(K, 4).float().view_as(w2)
-        g_w1 = dw1.float().view_as(w1)
+        small = torch.empty((8 + 8 * K,), dtype=torch.float32, device=dev)
+        check(lib.cds_dynconv_bwd_finish_f32(_p64(sums), _p64(dw1), G, K, small.data_ptr(), st), "cds_dynconv_bwd_finish_f32")
+        g_beta, g_gamma = small[:4], small[4:8]
+        g_w2 = small[8:8 + 4 * K].view_as(w2)
+        g_w1 = small[8 + 4 * K:].view_as(w1)
         dx = None
         g_convs: List[Optional[Tensor]] = []
         g_atts: List[Optional[Tensor]] = []
@@ -294,6 +295,29 @@ def conv_in_act(conv, x: Tensor, act: int = ACT_LEAKY01) -> Tensor:
     """Plain ConvUnit (module.py:28-71): Conv2d (no bias) -> InstanceNorm2d -> LeakyReLU(0.1)."""
     y = Conv2d.apply(x, conv.weight, conv.bias, conv.stride[0], conv.padding[0])
     return InstNormAct.apply(y, act)
+
+
+class CurvatureStats(torch.autograd.Function):
+    """((a^2 + b^2) + c^2) / 3 and |c| of the three norm-curvature maps of a FeatureNet level (module.py:250-251,257-258,264-265):
+    one launch forward, one backward (14 ATen launches as `(a ** 2 + b ** 2 + c ** 2) / 3, c.abs()`)."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, a, b, c):
+        a, b, c = a.contiguous(), b.contiguous(), c.contiguous()
+        ctx.save_for_backward(a, b, c)
+        return ops.curvature_stats(a, b, c)
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, g_sum, g_abs):
+        a, b, c = ctx.saved_tensors
+        ga, gb, gc = torch.empty_like(a), torch.empty_like(b), torch.empty_like(c)
+        gs = g_sum.contiguous().float() if g_sum is not None else None
+        gm = g_abs.contiguous().float() if g_abs is not None else None
+        check(_lib.load().cds_curvature_stats_bwd_f32(_p(a), _p(b), _p(c), _p(gs), _p(gm), ga.data_ptr(), gb.data_ptr(), gc.data_ptr(),
+                                                      a.numel(), ops._stream(a)), "cds_curvature_stats_bwd_f32")
+        return ga, gb, gc
 
 
 class SoftArgmin(torch.autograd.Function):

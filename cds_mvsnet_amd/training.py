@@ -64,6 +64,13 @@ def _unit(unit, x: Tensor, epi: Optional[Tensor], T: float, groups: int = 1):
     return _in_act(_conv(unit.conv, x))
 
 
+def _curv(a: Tensor, b: Tensor, c: Tensor) -> Tuple[Tensor, Tensor]:
+    """((a^2 + b^2) + c^2) / 3 and |c| (module.py:250-251), HIP forward / backward."""
+    _need_hip(a)
+    from . import train2d_ops
+    return train2d_ops.CurvatureStats.apply(a, b, c)
+
+
 def feature_net(net, x: Tensor, epi: Tensor, T: float, groups: int = 1) -> Dict[str, Tuple[Tensor, Tensor, Tensor]]:
     """models/module.py:234-267.  x [N,3,H,W], epi [N,2] -> {'stageK': (fea, nc_sum, |nc|)} batched over N.  groups > 1: x stacks
     that many separate calls of the reference (the only cross-sample operation in FeatureNet is the BatchNorm2d inside each
@@ -79,14 +86,14 @@ def feature_net(net, x: Tensor, epi: Tensor, T: float, groups: int = 1) -> Dict[
     c21, n21 = _unit(net.conv21, c20, e2, T, groups)
     out = {}
     o1, n22 = _dyn(net.out1, c21, e2, T, groups)
-    out["stage1"] = (_in_act(o1, tanh=True), (n20 ** 2 + n21 ** 2 + n22 ** 2) / 3, n22.abs())
+    out["stage1"] = (_in_act(o1, tanh=True), *_curv(n20, n21, n22))
     t = _unit(net.inner1, torch.cat((F.interpolate(c21, scale_factor=2, mode="nearest"), c11), dim=1), None, T)
     o2, n12 = _dyn(net.out2, t, e1, T, groups)
     o2 = _in_act(o2, tanh=True)
-    out["stage2"] = (o2, (n10 ** 2 + n11 ** 2 + n12 ** 2) / 3, n12.abs())
+    out["stage2"] = (o2, *_curv(n10, n11, n12))
     t = _unit(net.inner2, torch.cat((F.interpolate(o2, scale_factor=2, mode="nearest"), c01), dim=1), None, T)
     o3, n02 = _dyn(net.out3, t, e0, T, groups)
-    out["stage3"] = (_in_act(o3, tanh=True), (n00 ** 2 + n01 ** 2 + n02 ** 2) / 3, n02.abs())
+    out["stage3"] = (_in_act(o3, tanh=True), *_curv(n00, n01, n02))
     return out
 
 
@@ -233,12 +240,12 @@ def stage_forward_train(stage_net, features, cams: Tensor, depth_values: Tensor,
     for b in range(B):
         vis_b = torch.stack([vis[v][b] for v in range(V)]).float()       # [V,h,w]
         vol_sum = ops.WarpAggregate.apply(ref[b], src[b], vis_b, mats[b], hyps[b])       # K3 fwd / bwd kernels
-        denom = (vis_b.sum(dim=0) + 1e-6).unsqueeze(0)
-        vols.append(vol_sum / denom.unsqueeze(0))                        # model.py:74
-        fd = vol_sum.sum(dim=0) / denom                                  # sum_v sim_v * vis_v / vis_sum (model.py:56,75)
+        gt_sum = None
         if gt_depth is not None:                                         # model.py:63-69,76-78
             gt_sum = ops.WarpAggregate.apply(ref[b], src[b], vis_b, mats[b], gt_depth[b:b + 1].float().contiguous())
-            fd = torch.cat((fd, gt_sum.sum(dim=0) / denom), dim=0)
+        # volume / (sum_v vis + 1e-6) (model.py:74) and the feature distances sum_v sim_v vis_v / vis_sum (model.py:56,75-78): one launch
+        vol, fd = ops.VolumeFinish.apply(vol_sum, gt_sum, vis_b)
+        vols.append(vol)
         fds.append(fd)
     if stacked is not None:                                                                         # sum_v ((ref + src) / 2) / V
         nc_mean = stacked.nc_sum.view(V, 2, B, *stacked.nc_sum.shape[1:]).mean(dim=(0, 1))         # [B,1,h,w]

@@ -125,6 +125,14 @@ int cds_warp_aggregate_bwd_f32(const float* ref_chw, const float* src_hwc, const
                                const float* mats_host, const float* hyp, const float* grad_volume,
                                float* grad_ref, float* grad_src_hwc, float* grad_vis, int V, int C, int D,
                                int h, int w, int hyp_per_pixel, void* stream);
+/* The training step's epilogue of K3 (models/model.py:56-78) in one launch, and its backward in two: volume = volume_sum /
+ * (sum_v vis + 1e-6), feat_distance[d] = sum_c volume_sum[c][d] / (sum_v vis + 1e-6), plane D from gt_sum [C][hw] (K3 at the
+ * ground-truth depth) when given.  Backward: g_volume / g_feat_distance may be NULL (no gradient); scratch D x hw floats. */
+int cds_volume_finish_f32(const float* volume_sum, const float* gt_sum, const float* vis, int V, int C, int D, int hw, float* volume,
+                          float* feat_distance, void* stream);
+int cds_volume_finish_bwd_f32(const float* g_volume, const float* g_feat_distance, const float* volume_sum, const float* gt_sum,
+                              const float* vis, int V, int C, int D, int hw, float* g_volume_sum, float* g_gt_sum, float* g_vis,
+                              float* scratch, void* stream);
 
 /* volume[c][d][p] /= (vis_sum[p] + 1e-6)  (model.py:74) — the finalisation after a view-shard
  * all-reduce of partial sums. */
@@ -446,6 +454,9 @@ int cds_depth_fusion_f32(const float* ref_depth, const float* ref_conf, const fl
  */
 int cds_curvature_stats_f32(const float* a, const float* b, const float* c, float* nc_sum, float* nc_abs, int n,
                             void* stream);
+/* Its backward (training): ga = (g_sum / 3) 2 a, gb likewise, gc = (g_sum / 3) 2 c + g_abs sgn(c); g_sum / g_abs may be NULL. */
+int cds_curvature_stats_bwd_f32(const float* a, const float* b, const float* c, const float* g_sum, const float* g_abs, float* ga,
+                                float* gb, float* gc, int n, void* stream);
 /* out[v][i] = (x[v][i] + x[V+v][i]) / 2 for v < V (model.py:59); x [2V][n] */
 int cds_pair_mean_f32(const float* x, float* out, int V, int n, void* stream);
 /* out[i] = (sum over v of x[v][i]) / V (model.py:60,79); x [V][n] */
@@ -540,6 +551,9 @@ int cds_pack_conv2d_f32(const float* wa, const float* wb, float* fwd, float* dgr
 int cds_pack_conv3d_f32(const float* w, float* fwd, float* dgrad, int A, int B, int mode, void* stream);
 int cds_softargmin_bwd_f32(const float* prob_pre, const float* hyp, const float* gdepth, float* gpre, int D, int h, int w,
                            int hyp_per_pixel, void* stream);
+/* The attention-MLP gradients of a DynamicConv from cds_dynconv_blend_bwd_f32's fp64 accumulators, one launch:
+ * out = [dbeta (4) | dgamma (4) | dw2 [K][4] | dw1 [4][K]] floats (the groups summed in a fixed order). */
+int cds_dynconv_bwd_finish_f32(const double* sums, const double* dw1, int G, int K, float* out, void* stream);
 
 /* final_loss on the device (reference: models/losses.py:6-48; replaces ~90 ATen launches forward and ~150 backward per step) and the
  * feature-distance targets (models/model.py:202-207).  Sums in fp64 through per-workgroup records reduced in a fixed order.

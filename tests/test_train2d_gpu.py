@@ -398,3 +398,53 @@ def test_feat_target_kernel():
     ref = torch.cat((((hyp - gt.unsqueeze(1)).abs() / (di.view(B, 1, 1, 1) * scale) < 0.5 / scale).float(), torch.ones(B, 1, h, w, device=dev)), 1)
     got = ops.feat_target(hyp, gt, di, scale, 0.5 / scale)
     assert torch.equal(got, ref) and 0 < ref[:, :-1].mean().item() < 1
+
+
+@pytest.mark.parametrize("with_gt", [True, False])
+def test_volume_finish_forward_backward(with_gt):
+    """ops.VolumeFinish (models/model.py:56-78: volume / (sum_v vis + 1e-6) and the feature distances) against the ATen expressions it
+    replaces, float64 autograd."""
+    from cds_mvsnet_amd import ops
+    g = torch.Generator().manual_seed(4)
+    dev = torch.device("cuda:0")
+    V, C, D, h, w = 3, 8, 5, 11, 19
+    vs = torch.randn(C, D, h, w, generator=g).to(dev).requires_grad_()
+    gt = torch.randn(C, 1, h, w, generator=g).to(dev).requires_grad_() if with_gt else None
+    vis = (0.05 + torch.rand(V, h, w, generator=g)).to(dev).requires_grad_()
+    vol, fd = ops.VolumeFinish.apply(vs, gt, vis)
+    wv, wf = torch.randn(vol.shape, generator=g).to(dev), torch.randn(fd.shape, generator=g).to(dev)
+    leaves = [vs, vis] + ([gt] if with_gt else [])
+    got = torch.autograd.grad((vol * wv).sum() + (fd * wf).sum(), leaves)
+    vs64, vis64 = vs.detach().double().requires_grad_(), vis.detach().double().requires_grad_()
+    gt64 = gt.detach().double().requires_grad_() if with_gt else None
+    denom = (vis64.sum(dim=0) + 1e-6).unsqueeze(0)
+    vol_ref = vs64 / denom.unsqueeze(0)
+    fd_ref = vs64.sum(dim=0) / denom
+    if with_gt:
+        fd_ref = torch.cat((fd_ref, gt64.sum(dim=0) / denom), dim=0)
+    ref = torch.autograd.grad((vol_ref * wv.double()).sum() + (fd_ref * wf.double()).sum(), [vs64, vis64] + ([gt64] if with_gt else []))
+    _close(vol, vol_ref, "volume", rel=2e-6)
+    _close(fd, fd_ref, "feat_distance", rel=2e-6)
+    for a, b, n in zip(got, ref, ("g_volume_sum", "g_vis", "g_gt_sum")):
+        _close(a, b, n, rel=1e-5)
+    only_vol = torch.autograd.grad((ops.VolumeFinish.apply(vs, gt, vis)[0] * wv).sum(), [vs, vis])     # feat_distance unused: NULL gradient
+    ref_only = torch.autograd.grad(((vs64 / (vis64.sum(dim=0) + 1e-6)) * wv.double()).sum(), [vs64, vis64])
+    for a, b in zip(only_vol, ref_only):
+        _close(a, b, "volume-only gradient", rel=1e-5)
+
+
+def test_curvature_stats_backward():
+    from cds_mvsnet_amd import train2d_ops
+    g = torch.Generator().manual_seed(6)
+    dev = torch.device("cuda:0")
+    a, b, c = (torch.randn(3, 1, 9, 14, generator=g).to(dev).requires_grad_() for _ in range(3))
+    s, m = train2d_ops.CurvatureStats.apply(a, b, c)
+    ws, wm = torch.randn(s.shape, generator=g).to(dev), torch.randn(m.shape, generator=g).to(dev)
+    got = torch.autograd.grad((s * ws).sum() + (m * wm).sum(), [a, b, c])
+    a64, b64, c64 = (t.detach().double().requires_grad_() for t in (a, b, c))
+    s_ref, m_ref = (a64 ** 2 + b64 ** 2 + c64 ** 2) / 3, c64.abs()
+    ref = torch.autograd.grad((s_ref * ws.double()).sum() + (m_ref * wm.double()).sum(), [a64, b64, c64])
+    _close(s, s_ref, "nc_sum", rel=2e-6)
+    assert torch.equal(m.double(), m_ref.detach().float().double())
+    for x, y in zip(got, ref):
+        _close(x, y, "gradient", rel=2e-6)

@@ -138,6 +138,7 @@ def torch_layers(two_d: bool = True, three_d: bool = True):
             swap("_dyn", dynamic_conv)
             swap("_in_act", in_act)
             swap("_conv", conv)
+            swap("_curv", lambda a, b, c: ((a ** 2 + b ** 2 + c ** 2) / 3, c.abs()))      # module.py:250-251
             swap("_cbr2", cbr2)
             swap("_softargmin", softargmin)
             swap("_refinement", refinement)
