@@ -107,6 +107,7 @@ SIGNATURES = {
     "cds_pack_conv3d_f32": [P, P, P, I, I, I, P],
     "cds_softargmin_bwd_f32": [P, P, P, P, I, I, I, I, P],
     "cds_dynconv_bwd_finish_f32": [P, P, I, I, P, P],
+    "cds_bn_running_update_f32": [P, P, P, F, I, I, P, P, P],
     "cds_loss_records": [ctypes.c_longlong],
     "cds_loss_stage_f32": [P, P, P, P, P, P, P, I, I, I, P, P, P],
     "cds_loss_final_f32": [P, P, P, P, P, P, I, P, P, P, P],

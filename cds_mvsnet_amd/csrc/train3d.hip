@@ -371,3 +371,27 @@ extern "C" int cds_conv3d_wgrad_f32(const float* g, const float* xin, float* dw,
   return cds_launch_status();
 }
 
+
+// Running statistics of a BatchNorm whose call stacked G groups (train2d_ops.bn_relu2d): r = keep r + sum_g wts[g] stat[g][c] for the mean
+// and the variance in one launch (the groups in call order; wts[g] = m (1 - m)^(G-1-g), keep = (1 - m)^G).
+namespace {
+__global__ void bn_running_update_kernel(const float* __restrict__ tm, const float* __restrict__ tv, const float* __restrict__ wts,
+                                         float keep, int G, int C, float* __restrict__ rmean, float* __restrict__ rvar) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 2 * C) return;
+  const int c = i < C ? i : i - C;
+  const float* __restrict__ st = i < C ? tm : tv;
+  float* __restrict__ r = i < C ? rmean : rvar;
+  float acc = 0.f;
+  for (int g = 0; g < G; ++g) acc = fmaf(wts[g], st[g * C + c], acc);
+  r[c] = keep * r[c] + acc;
+}
+}  // namespace
+
+extern "C" int cds_bn_running_update_f32(const float* batch_mean, const float* batch_var, const float* group_weights, float keep, int G,
+                                         int C, float* running_mean, float* running_var, void* stream) {
+  if (!batch_mean || !batch_var || !group_weights || !running_mean || !running_var || G < 1 || C < 1) return CDS_EINVAL;
+  hipLaunchKernelGGL(bn_running_update_kernel, dim3(cds_ceil_div(2 * C, 128)), dim3(128), 0, (hipStream_t)stream, batch_mean, batch_var,
+                     group_weights, keep, G, C, running_mean, running_var);
+  return cds_launch_status();
+}

@@ -98,6 +98,19 @@ def _c16(w: Tensor, stride: int, pad: int, width: int) -> bool:
     return tuple(w.shape) == (16, 16, 3, 3) and stride == 1 and pad == 1 and width % 4 == 0 and ops.USE_CONV2D_MFMA
 
 
+_C16_DGRAD_INDEX: dict = {}
+
+
+def _c16_dgrad_index(device) -> Tensor:
+    """Gather index of the data-gradient operand of the 16 -> 16 3x3 matrix-core kernel: [tap][ci][co] = w[co][ci][2-ky][2-kx] in ONE
+    launch (flip + permute + contiguous were two)."""
+    key = str(device)
+    if key not in _C16_DGRAD_INDEX:
+        t, ci, co = torch.meshgrid(torch.arange(9), torch.arange(16), torch.arange(16), indexing="ij")
+        _C16_DGRAD_INDEX[key] = (co * 144 + ci * 9 + (8 - t)).reshape(-1).to(device)
+    return _C16_DGRAD_INDEX[key]
+
+
 class Conv2d(torch.autograd.Function):
     """y = conv2d(x, weight [Cout,Cin,k,k], bias | None; stride 1 with k in (1,3,5,7,11), or k 3 stride 2 pad 1)."""
 
@@ -129,7 +142,7 @@ class Conv2d(torch.autograd.Function):
                 if 2 * ctx.pad != k - 1:
                     raise ValueError("train2d_ops.Conv2d: the stride-1 data gradient needs 'same' padding")
                 if _c16(w, 1, ctx.pad, dy.shape[-1]):
-                    dx = ops.conv2d_k3_c16(dy, w.flip(2, 3).permute(2, 3, 1, 0).reshape(9, 16, 16).contiguous(), None, ACT_NONE)
+                    dx = ops.conv2d_k3_c16(dy, w.reshape(-1).index_select(0, _c16_dgrad_index(w.device)).view(9, 16, 16), None, ACT_NONE)
                 else:
                     dx = ops.conv2d(dy, pack_conv2d(w, None, fwd=False, dgrad=True)[1], None, w.shape[1], k, 1, ctx.pad)
             else:
@@ -378,8 +391,13 @@ def bn_relu2d(bn, y: Tensor, relu: bool = True, groups: int = 1) -> Tensor:
                     m = float(bn.momentum)
                     wts = _group_weights(m, groups, y.device)
                     keep = (1.0 - m) ** groups
-                    torch.addmv(bn.running_mean, tm.t(), wts, beta=keep, out=bn.running_mean)      # one launch per statistic
-                    torch.addmv(bn.running_var, tv.t(), wts, beta=keep, out=bn.running_var)
+                    if bn.running_mean.dtype == torch.float32 and bn.running_mean.is_contiguous() and bn.running_var.is_contiguous():
+                        check(_lib.load().cds_bn_running_update_f32(tm.data_ptr(), tv.data_ptr(), wts.data_ptr(), float(keep), groups, C,
+                                                                    bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
+                                                                    ops._stream(y)), "cds_bn_running_update_f32")   # both statistics: one launch
+                    else:
+                        torch.addmv(bn.running_mean, tm.t(), wts, beta=keep, out=bn.running_mean)
+                        torch.addmv(bn.running_var, tv.t(), wts, beta=keep, out=bn.running_var)
                     _scratch.bump(bn.num_batches_tracked, groups)
                 else:
                     for g in range(groups):

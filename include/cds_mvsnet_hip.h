@@ -575,6 +575,11 @@ int cds_loss_stage_bwd_f32(const float* depth, const float* gt, const float* mas
 int cds_feat_target_f32(const float* hyp, const float* gt, const float* di, float scale, float thresh, int B, int D, int hw,
                         float* target, void* stream);
 
+/* Running statistics of a BatchNorm call that stacked G groups: r = keep r + sum_g group_weights[g] stat[g][c] for the mean and the
+ * variance in one launch; batch_mean / batch_var [G][C], group_weights [G] on the device. */
+int cds_bn_running_update_f32(const float* batch_mean, const float* batch_var, const float* group_weights, float keep, int G, int C,
+                              float* running_mean, float* running_var, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
