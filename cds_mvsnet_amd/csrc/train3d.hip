@@ -212,6 +212,23 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_kernel(const float* __restri
   }
 }
 
+typedef float wg_f32x4 __attribute__((ext_vector_type(4)));
+
+// The K-steps of one staged tile for a wave that owns NQ column blocks (branch-free: NQ is a template parameter).
+template <typename Cfg, int S, int NQ>
+__device__ __forceinline__ void wgrad3d_ksteps(const float* __restrict__ lg, const float* __restrict__ lx, int j, int kq, const int* colofs,
+                                               wg_f32x4* acc) {
+#pragma unroll 4
+  for (int ks = 0; ks < Cfg::NO / 4; ++ks) {
+    const int p = 4 * ks + kq;                         // this lane's voxel of the K-step
+    const int px = p % Cfg::OX, py = (p / Cfg::OX) % Cfg::OY, pz = p / (Cfg::OX * Cfg::OY);
+    const int base = ((pz * S) * Cfg::IY + py * S) * Cfg::IX + px * S;
+    const float av = lg[j * Cfg::GS + p];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, lx[base + colofs[q]], acc[q], 0, 0, 0);
+  }
+}
+
 // The same sums on the fp32 matrix pipe (v_mfma_f32_16x16x4_f32: exact fp32 products, fp32 accumulation):
 //   D[a][n] += A[a][k] B[k][n],  a = 16 channels of g, n = (b, tap) column (8 b-channels x 27 taps = 216 of 224), k = voxel.
 // A lane reads ONE float of g and one float of the xin tile per MFMA (the VALU kernel above read 8 per 7 FMAs and was
@@ -266,18 +283,13 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_mfma_kernel(const float* __r
       lx[i] = ok ? xin[((size_t)bi * Cb + b0 + ch) * vi + ((size_t)iz * Hi + iy) * Wi + ix] : 0.f;
     }
     __syncthreads();
-#pragma unroll 4
-    for (int ks = 0; ks < Cfg::NO / 4; ++ks) {
-      const int p = 4 * ks + kq;                       // this lane's voxel of the K-step
-      const int px = p % Cfg::OX, py = (p / Cfg::OX) % Cfg::OY, pz = p / (Cfg::OX * Cfg::OY);
-      const int base = ((pz * S) * Cfg::IY + py * S) * Cfg::IX + px * S;
-      const float av = lg[j * Cfg::GS + p];
-#pragma unroll
-      for (int q = 0; q < QW; ++q) {
-        if (wave + 4 * q >= NBLK) continue;            // (wave-uniform)
-        acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, lx[base + colofs[q]], acc[q], 0, 0, 0);
-      }
-    }
+    // waves 0 / 1 own four column blocks, waves 2 / 3 three: decided ONCE per tile.  With the test inside the K loop the compiler
+    // wrapped every MFMA in a branch and copied the accumulators in and out of the AGPRs around it (s_nop + v_accvgpr_read after
+    // each MFMA: the matrix pipe ran at 14 %)
+    if (wave + 4 * (QW - 1) < NBLK)
+      wgrad3d_ksteps<Cfg, S, QW>(lg, lx, j, kq, colofs, acc);
+    else
+      wgrad3d_ksteps<Cfg, S, QW - 1>(lg, lx, j, kq, colofs, acc);
   }
   // D: lane holds rows a = 4 kq + 0..3 of column n = 16 (wave + 4 q) + j
 #pragma unroll
