@@ -75,24 +75,56 @@ __global__ __launch_bounds__(256) void conv2d_wgrad_mfma_kernel(const float* __r
 #pragma unroll
   for (int q = 0; q < Cfg::NBLK; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const int t0 = blockIdx.x * tiles_per_wg, t1 = min(ntiles * N, t0 + tiles_per_wg);
-  for (int tile = t0; tile < t1; ++tile) {
+  // Staging through registers (see conv3d_wgrad_mfma_kernel): per-thread element offsets computed once, all loads of a tile issued back
+  // to back from clamped addresses, and the loads of tile t + 1 in flight during the K-steps of tile t.  The guarded scalar loop this
+  // replaces compiled to one load + s_waitcnt vmcnt(0) per element: 80 % of the kernel's time.
+  constexpr int NG = 16 * Cfg::NO / 256, NX = (CB * Cfg::NI + 255) / 256;
+  float rg[NG], rx[NX];
+  int relx[NX], pkx[NX];
+  const int gpx = tid % Cfg::OX, gpy = tid / Cfg::OX;      // NO == 256: element e of the g tile is channel e, pixel tid
+  static_assert(Cfg::NO == 256, "the g tile is one pixel per thread and channel");
+#pragma unroll
+  for (int e = 0; e < NX; ++e) {
+    const int i = tid + 256 * e;
+    const int ch = i / Cfg::NI, p = i - ch * Cfg::NI;
+    const int px = p % Cfg::IX, py = p / Cfg::IX;
+    relx[e] = ch * (int)pi + py * W + px;
+    pkx[e] = (i < CB * Cfg::NI && b0 + ch < Cin) ? (px | (py << 16)) : -1;
+  }
+  auto fetch = [&](int tile) {
     const int n = tile / ntiles;
     const int r = tile - n * ntiles;
     const int ox0 = (r % tiles_x) * Cfg::OX, oy0 = (r / tiles_x) * Cfg::OY;
-    __syncthreads();
-    for (int i = tid; i < 16 * Cfg::NO; i += 256) {
-      const int ch = i / Cfg::NO, p = i - ch * Cfg::NO;
-      const int ox = ox0 + p % Cfg::OX, oy = oy0 + p / Cfg::OX;
-      const bool ok = a0 + ch < Co && ox < Wo && oy < Ho;
-      lg[ch * Cfg::GS + p] = ok ? g[((size_t)n * Co + a0 + ch) * po + (size_t)oy * Wo + ox] : 0.f;
+    const bool gok = ox0 + gpx < Wo && oy0 + gpy < Ho;
+    const float* __restrict__ gt = g + ((size_t)n * Co + a0) * po + (size_t)(oy0 + gpy) * Wo + ox0 + gpx;
+#pragma unroll
+    for (int e = 0; e < NG; ++e) {
+      const bool ok = gok && a0 + e < Co;
+      const float v = *(ok ? gt + (size_t)e * po : g);
+      rg[e] = ok ? v : 0.f;
     }
-    for (int i = tid; i < CB * Cfg::NI; i += 256) {
-      const int ch = i / Cfg::NI, p = i - ch * Cfg::NI;
-      const int ix = ox0 * S - pad + p % Cfg::IX, iy = oy0 * S - pad + p / Cfg::IX;
-      const bool ok = b0 + ch < Cin && (unsigned)ix < (unsigned)W && (unsigned)iy < (unsigned)H;
-      lx[i] = ok ? xin[((size_t)n * Cin + b0 + ch) * pi + (size_t)iy * W + ix] : 0.f;
+    const int ix0 = ox0 * S - pad, iy0 = oy0 * S - pad;
+    const long long xbase = (long long)(((size_t)n * Cin + b0) * pi) + (long long)iy0 * W + ix0;
+#pragma unroll
+    for (int e = 0; e < NX; ++e) {
+      const int pk = pkx[e];
+      const bool ok = pk >= 0 && (unsigned)(ix0 + (pk & 0xffff)) < (unsigned)W && (unsigned)(iy0 + (pk >> 16)) < (unsigned)H;
+      const float v = xin[ok ? xbase + relx[e] : 0];
+      rx[e] = ok ? v : 0.f;
+    }
+  };
+  if (t0 < t1) fetch(t0);
+  for (int tile = t0; tile < t1; ++tile) {
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < NG; ++e) lg[e * Cfg::GS + tid] = rg[e];
+#pragma unroll
+    for (int e = 0; e < NX; ++e) {
+      const int i = tid + 256 * e;
+      if (i < CB * Cfg::NI) lx[i] = rx[e];
     }
     __syncthreads();
+    if (tile + 1 < t1) fetch(tile + 1);
     const int pw = wave * (Cfg::NO / 4);
 #pragma unroll 2
     for (int ks = 0; ks < Cfg::NO / 16; ++ks) {
@@ -133,7 +165,7 @@ int launch_wgrad2d(const float* g, const float* xin, float* dw, int N, int Co, i
   const int tx = cds_ceil_div(Wo, Cfg::OX), ty = cds_ceil_div(Ho, Cfg::OY);
   const int ntiles = tx * ty;
   const int ab = cds_ceil_div(Co, 16) * cds_ceil_div(Cin, CB);
-  int per = cds_ceil_div(ntiles * N * ab, 1024);         // ~1024 workgroups in all
+  int per = cds_ceil_div(ntiles * N * ab, cds_env_int("CDS_WG2_WGS", 512));         // ~512 workgroups in all: each ends with one atomic per weight of its block
   if (per < 1) per = 1;
   const dim3 grid(cds_ceil_div(ntiles * N, per), cds_ceil_div(Co, 16), cds_ceil_div(Cin, CB));
   const int ldsb = Cfg::LDS_FLOATS * (int)sizeof(float);

@@ -260,29 +260,71 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_mfma_kernel(const float* __r
 #pragma unroll
   for (int q = 0; q < QW; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const int t0 = blockIdx.x * tiles_per_wg, t1 = min(ntiles * B, t0 + tiles_per_wg);
-  for (int tile = t0; tile < t1; ++tile) {
+  // Staging through registers: all loads of a tile are issued back to back (unconditional loads from clamped addresses, zeros selected
+  // afterwards: a guarded load inside a loop compiled to ONE load per iteration followed by s_waitcnt vmcnt(0), ~20 serial round trips
+  // per tile), and the loads of tile t + 1 are issued before the K-steps of tile t.
+  constexpr int NG = (16 * Cfg::NO + 255) / 256, NX = (8 * Cfg::NI + 255) / 256;
+  float rg[NG], rx[NX];
+  // per element of this thread, fixed for all tiles: offset from the tile's origin and (x, y, z) inside the tile for the bounds tests
+  // (the div / mod chains per element and tile were ~1 200 VALU instructions per thread and tile: more than the K-steps' matrix time)
+  int relg[NG], pkg[NG], relx[NX], pkx[NX];
+#pragma unroll
+  for (int e = 0; e < NG; ++e) {
+    const int i = tid + 256 * e;
+    const int ch = i / Cfg::NO, p = i - ch * Cfg::NO;
+    const int px = p % Cfg::OX, py = (p / Cfg::OX) % Cfg::OY, pz = p / (Cfg::OX * Cfg::OY);
+    relg[e] = ch * (int)vo + (pz * Ho + py) * Wo + px;
+    pkg[e] = (i < 16 * Cfg::NO && a0 + ch < Ca) ? (px | (py << 8) | (pz << 16)) : -1;
+  }
+#pragma unroll
+  for (int e = 0; e < NX; ++e) {
+    const int i = tid + 256 * e;
+    const int ch = i / Cfg::NI, p = i - ch * Cfg::NI;
+    const int px = p % Cfg::IX, py = (p / Cfg::IX) % Cfg::IY, pz = p / (Cfg::IX * Cfg::IY);
+    relx[e] = ch * (int)vi + (pz * Hi + py) * Wi + px;
+    pkx[e] = (i < 8 * Cfg::NI && b0 + ch < Cb) ? (px | (py << 8) | (pz << 16)) : -1;
+  }
+  auto fetch = [&](int tile) {
     const int bi = tile / ntiles;
     int r = tile - bi * ntiles;
     const int tx_i = r % tiles_x;
     r /= tiles_x;
     const int ty_i = r % tiles_y, tz_i = r / tiles_y;
     const int ox0 = tx_i * Cfg::OX, oy0 = ty_i * Cfg::OY, oz0 = tz_i * Cfg::OZ;
-    __syncthreads();
-    for (int i = tid; i < 16 * Cfg::NO; i += 256) {
-      const int ch = i / Cfg::NO, p = i - ch * Cfg::NO;
-      const int px = p % Cfg::OX, py = (p / Cfg::OX) % Cfg::OY, pz = p / (Cfg::OX * Cfg::OY);
-      const int ox = ox0 + px, oy = oy0 + py, oz = oz0 + pz;
-      const bool ok = a0 + ch < Ca && ox < Wo && oy < Ho && oz < Do;
-      lg[ch * Cfg::GS + p] = ok ? g[((size_t)bi * Ca + a0 + ch) * vo + ((size_t)oz * Ho + oy) * Wo + ox] : 0.f;
+    const float* __restrict__ gt = g + ((size_t)bi * Ca + a0) * vo + ((size_t)oz0 * Ho + oy0) * Wo + ox0;
+    const int ix0 = ox0 * S - 1, iy0 = oy0 * S - 1, iz0 = oz0 * S - 1;
+    const long long xbase = (long long)(((size_t)bi * Cb + b0) * vi) + ((long long)iz0 * Hi + iy0) * Wi + ix0;
+#pragma unroll
+    for (int e = 0; e < NG; ++e) {
+      const int pk = pkg[e];
+      const bool ok = pk >= 0 && ox0 + (pk & 255) < Wo && oy0 + ((pk >> 8) & 255) < Ho && oz0 + (pk >> 16) < Do;
+      const float v = gt[ok ? relg[e] : 0];
+      rg[e] = ok ? v : 0.f;
     }
-    for (int i = tid; i < 8 * Cfg::NI; i += 256) {
-      const int ch = i / Cfg::NI, p = i - ch * Cfg::NI;
-      const int px = p % Cfg::IX, py = (p / Cfg::IX) % Cfg::IY, pz = p / (Cfg::IX * Cfg::IY);
-      const int ix = ox0 * S - 1 + px, iy = oy0 * S - 1 + py, iz = oz0 * S - 1 + pz;
-      const bool ok = b0 + ch < Cb && (unsigned)ix < (unsigned)Wi && (unsigned)iy < (unsigned)Hi && (unsigned)iz < (unsigned)Di;
-      lx[i] = ok ? xin[((size_t)bi * Cb + b0 + ch) * vi + ((size_t)iz * Hi + iy) * Wi + ix] : 0.f;
+#pragma unroll
+    for (int e = 0; e < NX; ++e) {
+      const int pk = pkx[e];
+      const bool ok = pk >= 0 && (unsigned)(ix0 + (pk & 255)) < (unsigned)Wi && (unsigned)(iy0 + ((pk >> 8) & 255)) < (unsigned)Hi &&
+                      (unsigned)(iz0 + (pk >> 16)) < (unsigned)Di;
+      const float v = xin[ok ? xbase + relx[e] : 0];
+      rx[e] = ok ? v : 0.f;
+    }
+  };
+  if (t0 < t1) fetch(t0);
+  for (int tile = t0; tile < t1; ++tile) {
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < NG; ++e) {
+      const int i = tid + 256 * e;
+      if (i < 16 * Cfg::NO) lg[(i / Cfg::NO) * Cfg::GS + i % Cfg::NO] = rg[e];
+    }
+#pragma unroll
+    for (int e = 0; e < NX; ++e) {
+      const int i = tid + 256 * e;
+      if (i < 8 * Cfg::NI) lx[i] = rx[e];
     }
     __syncthreads();
+    if (tile + 1 < t1) fetch(tile + 1);
     // waves 0 / 1 own four column blocks, waves 2 / 3 three: decided ONCE per tile.  With the test inside the K loop the compiler
     // wrapped every MFMA in a branch and copied the accumulators in and out of the AGPRs around it (s_nop + v_accvgpr_read after
     // each MFMA: the matrix pipe ran at 14 %)
@@ -357,7 +399,9 @@ extern "C" int cds_conv3d_wgrad_f32(const float* g, const float* xin, float* dw,
   if (!g || !xin || !dw || B < 1 || Ca < 1 || Cb < 1 || Do < 1 || Ho < 1 || Wo < 1 || (stride != 1 && stride != 2)) return CDS_EINVAL;
   const int tx = cds_ceil_div(Wo, 8), ty = cds_ceil_div(Ho, 4), tz = cds_ceil_div(Do, 4);
   const int ntiles = tx * ty * tz;
-  int per = cds_ceil_div(ntiles * B, 1024);      // ~1024 tile groups: a handful of atomics per output, enough workgroups
+  // tiles per workgroup: every workgroup ends with one atomic per weight of its (16 x 8-channel) block, all workgroups on the same few
+  // thousand addresses (a quarter of the kernel's time at ~1024 tile groups per channel block), so aim at CDS_WG3_WGS workgroups in ALL
+  int per = cds_ceil_div(ntiles * B * cds_ceil_div(Ca, 16) * cds_ceil_div(Cb, 8), cds_env_int("CDS_WG3_WGS", 512));
   if (per < 1) per = 1;
   const bool valu = cds_env_set("CDS_WGRAD_VALU");   // A/B knob: the VALU kernel
   if (!valu) {
