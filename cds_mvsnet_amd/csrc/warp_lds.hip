@@ -177,27 +177,37 @@ __device__ __forceinline__ void reduce_boxes(const int cx0[NV], const int cy0[NV
   }
 }
 
-// Cooperative copy of one box into its two LDS planes, zero outside the image.  Each wave takes rows wave, wave+4, ...
+// Cooperative copy of one box into its two LDS planes, zero outside the image.
 // srcv points at the first of the 8 channels staged; cs = channels per texel of the source image (8, 16 or 32).
+// All loads of a thread are issued back to back from clamped addresses (zeros selected afterwards) and land in LDS together: the
+// row / lane loops with a guarded load this replaces compiled to ONE global_load_dwordx4 + s_waitcnt vmcnt(0) per iteration, ~10 serial
+// memory round trips per wave, view and chunk (scripts/isa_scan.py; profiles/r05_k3_staging.md).
 template <int CAP>
 __device__ __forceinline__ void stage_box(const float* __restrict__ srcv, int cs, int h, int w, const Box& b,
                                           float4* __restrict__ dst) {
   if (!b.staged) return;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  constexpr int KMAX = (2 * CAP + 255) / 256;
   const int n4 = 2 * b.bw;  // float4 per row
-  for (int row = wave; row < b.bh; row += 4) {
-    const int gy = b.y0 + row;
-    const bool row_ok = (unsigned)gy < (unsigned)h;
-    const float* __restrict__ g = srcv + ((ptrdiff_t)(row_ok ? gy : 0) * w + b.x0) * cs;
-    float4* lo = dst + row * b.bw;
-    float4* hi = dst + CAP + row * b.bw;
-    for (int i = lane; i < n4; i += 64) {
-      const bool ok = row_ok && (unsigned)(b.x0 + (i >> 1)) < (unsigned)w;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (ok) v = *reinterpret_cast<const float4*>(g + (ptrdiff_t)(i >> 1) * cs + (i & 1) * 4);
-      ((i & 1) ? hi : lo)[i >> 1] = v;
-    }
+  const int total = b.bh * n4;
+  const float rn4 = 1.0f / (float)n4;
+  float4 val[KMAX];
+  int slot[KMAX];
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k) {
+    const int idx = (int)threadIdx.x + 256 * k;
+    const int row = (int)(((float)idx + 0.5f) * rn4);       // idx / n4 (exact: idx < 2^12, the quotient is >= 0.5 / n4 from an integer)
+    const int col = idx - row * n4;
+    const int gy = b.y0 + row, gx = b.x0 + (col >> 1);
+    const bool in = idx < total;
+    const bool ok = in && (unsigned)gy < (unsigned)h && (unsigned)gx < (unsigned)w;
+    const ptrdiff_t off = ok ? ((ptrdiff_t)gy * w + gx) * cs + (col & 1) * 4 : 0;
+    const float4 v = *reinterpret_cast<const float4*>(srcv + off);
+    val[k] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+    slot[k] = in ? ((col & 1) ? CAP : 0) + row * b.bw + (col >> 1) : -1;
   }
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k)
+    if (slot[k] >= 0) dst[slot[k]] = val[k];
 }
 
 typedef float v2f __attribute__((ext_vector_type(2)));
