@@ -37,20 +37,33 @@ __global__ __launch_bounds__(256) void softargmin_conf_kernel(const float* __res
   // one pass over the logits (online softmax: the running maximum rescales the partial sums when it moves), so the
   // volume is read once instead of twice; the four slices of a pixel are merged with their own rescale factors
   float m = -INFINITY, Z = 0.f, Sd = 0.f, Si = 0.f;
-  for (int d = d0; d < d1; ++d) {
-    const float x = pre[(size_t)d * hw + p];
-    const float hv = hyp_pp ? hyp[(size_t)d * hw + p] : hyp[d];
-    if (x > m) {                      // also taken on the first plane (m = -inf: the sums are still zero)
-      const float sc = expf(m - x);   // exp(-inf) = 0
-      Z *= sc;
-      Sd *= sc;
-      Si *= sc;
-      m = x;
+  // eight planes per round: their loads are issued together (clamped plane index), the arithmetic runs in plane order as before
+  // (one load + s_waitcnt vmcnt(0) per plane made the 48-plane walk a chain of memory round trips)
+  for (int db = d0; db < d1; db += 8) {
+    float xs[8], hs[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int d = min(db + k, d1 - 1);
+      xs[k] = pre[(size_t)d * hw + p];
+      hs[k] = hyp_pp ? hyp[(size_t)d * hw + p] : hyp[d];
     }
-    const float e = expf(x - m);
-    Z += e;
-    Sd = fmaf(e, hv, Sd);
-    Si = fmaf(e, (float)d, Si);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int d = db + k;
+      if (d >= d1) break;
+      const float x = xs[k], hv = hs[k];
+      if (x > m) {                      // also taken on the first plane (m = -inf: the sums are still zero)
+        const float sc = expf(m - x);   // exp(-inf) = 0
+        Z *= sc;
+        Sd *= sc;
+        Si *= sc;
+        m = x;
+      }
+      const float e = expf(x - m);
+      Z += e;
+      Sd = fmaf(e, hv, Sd);
+      Si = fmaf(e, (float)d, Si);
+    }
   }
   {
     const float M = cds_slice_max(m);

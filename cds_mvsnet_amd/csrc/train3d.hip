@@ -23,14 +23,36 @@ __device__ __forceinline__ double wave_sum(double v) {
 }
 
 // grid (chunks, C, B); sums [C][2] fp64 (zeroed by the caller)
+// V a multiple of 4 and every pointer 16-byte aligned: the elementwise / reduction loops below run on float4
+__device__ __forceinline__ bool bn_vec4(size_t V, const void* a, const void* b = nullptr, const void* c = nullptr, const void* d = nullptr) {
+  return ((V & 3) | ((uintptr_t)a & 15) | ((uintptr_t)b & 15) | ((uintptr_t)c & 15) | ((uintptr_t)d & 15)) == 0;
+}
+
 __global__ __launch_bounds__(256) void bn3d_stats_kernel(const float* __restrict__ x, double* __restrict__ sums, int C, size_t V) {
   const int c = blockIdx.y, b = blockIdx.z;
   const float* __restrict__ p = x + ((size_t)b * C + c) * V;
   double s = 0.0, q = 0.0;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < V; i += (size_t)gridDim.x * 256) {
-    const double v = p[i];
-    s += v;
-    q += v * v;
+  if (bn_vec4(V, p)) {               // 16-byte loads, two in flight per thread (the scalar loop is one 4-byte load per memory round trip)
+    const float4* __restrict__ p4 = reinterpret_cast<const float4*>(p);
+    const size_t V4 = V >> 2, step = (size_t)gridDim.x * 256;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + step < V4; i += 2 * step) {
+      const float4 a = p4[i], b4 = p4[i + step];
+      s += ((double)a.x + (double)a.y) + ((double)a.z + (double)a.w) + ((double)b4.x + (double)b4.y) + ((double)b4.z + (double)b4.w);
+      q += ((double)a.x * a.x + (double)a.y * a.y) + ((double)a.z * a.z + (double)a.w * a.w) + ((double)b4.x * b4.x + (double)b4.y * b4.y) +
+           ((double)b4.z * b4.z + (double)b4.w * b4.w);
+    }
+    if (i < V4) {
+      const float4 a = p4[i];
+      s += ((double)a.x + (double)a.y) + ((double)a.z + (double)a.w);
+      q += ((double)a.x * a.x + (double)a.y * a.y) + ((double)a.z * a.z + (double)a.w * a.w);
+    }
+  } else {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < V; i += (size_t)gridDim.x * 256) {
+      const double v = p[i];
+      s += v;
+      q += v * v;
+    }
   }
   __shared__ double red[2][4];
   s = wave_sum(s);
@@ -73,6 +95,22 @@ __global__ __launch_bounds__(256) void bn3d_norm_kernel(const float* __restrict_
     }
   }
   const size_t base = ((size_t)b * C + c) * V;
+  if (bn_vec4(V, y + base, out + base, skip ? skip + base : nullptr)) {
+    const float4* __restrict__ y4 = reinterpret_cast<const float4*>(y + base);
+    const float4* __restrict__ k4 = skip ? reinterpret_cast<const float4*>(skip + base) : nullptr;
+    float4* __restrict__ o4 = reinterpret_cast<float4*>(out + base);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < (V >> 2); i += (size_t)gridDim.x * 256) {
+      const float4 a = y4[i];
+      float4 v = make_float4(fmaf(a.x, sc, sh), fmaf(a.y, sc, sh), fmaf(a.z, sc, sh), fmaf(a.w, sc, sh));
+      if (relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+      if (k4) {
+        const float4 k = k4[i];
+        v = make_float4(k.x + v.x, k.y + v.y, k.z + v.z, k.w + v.w);
+      }
+      o4[i] = v;
+    }
+    return;
+  }
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < V; i += (size_t)gridDim.x * 256) {
     float v = fmaf(y[base + i], sc, sh);
     if (relu) v = fmaxf(v, 0.f);
@@ -89,11 +127,23 @@ __global__ __launch_bounds__(256) void bn3d_bwd_reduce_kernel(const float* __res
   const size_t base = ((size_t)b * C + c) * V;
   const float sc = scale[c], sh = shift[c];
   double s = 0.0, q = 0.0;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < V; i += (size_t)gridDim.x * 256) {
-    const float yv = y[base + i];
-    const float g = (!relu || fmaf(yv, sc, sh) > 0.f) ? dout[base + i] : 0.f;
-    s += (double)g;
-    q += (double)g * (double)yv;
+  if (bn_vec4(V, y + base, dout + base)) {
+    const float4* __restrict__ y4 = reinterpret_cast<const float4*>(y + base);
+    const float4* __restrict__ d4 = reinterpret_cast<const float4*>(dout + base);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < (V >> 2); i += (size_t)gridDim.x * 256) {
+      const float4 yv = y4[i], dv = d4[i];
+      const float g0 = (!relu || fmaf(yv.x, sc, sh) > 0.f) ? dv.x : 0.f, g1 = (!relu || fmaf(yv.y, sc, sh) > 0.f) ? dv.y : 0.f;
+      const float g2 = (!relu || fmaf(yv.z, sc, sh) > 0.f) ? dv.z : 0.f, g3 = (!relu || fmaf(yv.w, sc, sh) > 0.f) ? dv.w : 0.f;
+      s += ((double)g0 + (double)g1) + ((double)g2 + (double)g3);
+      q += ((double)g0 * (double)yv.x + (double)g1 * (double)yv.y) + ((double)g2 * (double)yv.z + (double)g3 * (double)yv.w);
+    }
+  } else {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < V; i += (size_t)gridDim.x * 256) {
+      const float yv = y[base + i];
+      const float g = (!relu || fmaf(yv, sc, sh) > 0.f) ? dout[base + i] : 0.f;
+      s += (double)g;
+      q += (double)g * (double)yv;
+    }
   }
   __shared__ double red[2][4];
   s = wave_sum(s);
@@ -124,6 +174,19 @@ __global__ __launch_bounds__(256) void bn3d_bwd_norm_kernel(const float* __restr
   if (blockIdx.x == 0 && b == 0 && threadIdx.x == 0) {
     dgamma[c] = (float)dg;
     dbeta[c] = (float)db;
+  }
+  if (bn_vec4(V, y + base, dout + base, dy + base)) {
+    const float4* __restrict__ y4 = reinterpret_cast<const float4*>(y + base);
+    const float4* __restrict__ d4 = reinterpret_cast<const float4*>(dout + base);
+    float4* __restrict__ o4 = reinterpret_cast<float4*>(dy + base);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < (V >> 2); i += (size_t)gridDim.x * 256) {
+      const float4 yv = y4[i], dv = d4[i];
+      const float g0 = (!relu || fmaf(yv.x, sc, sh) > 0.f) ? dv.x : 0.f, g1 = (!relu || fmaf(yv.y, sc, sh) > 0.f) ? dv.y : 0.f;
+      const float g2 = (!relu || fmaf(yv.z, sc, sh) > 0.f) ? dv.z : 0.f, g3 = (!relu || fmaf(yv.w, sc, sh) > 0.f) ? dv.w : 0.f;
+      o4[i] = make_float4(fmaf(g0, sc, fmaf(yv.x, a1, a0)), fmaf(g1, sc, fmaf(yv.y, a1, a0)), fmaf(g2, sc, fmaf(yv.z, a1, a0)),
+                          fmaf(g3, sc, fmaf(yv.w, a1, a0)));
+    }
+    return;
   }
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < V; i += (size_t)gridDim.x * 256) {
     const float yv = y[base + i];
