@@ -489,6 +489,7 @@ __global__ __launch_bounds__(256, CDS_K3_MINW) void warp_aggregate_lds_kernel(
     v2f dnext;
     dnext.x = *reinterpret_cast<const float*>(hyp_b + boff);
     dnext.y = *reinterpret_cast<const float*>(hyp_b + min(boff + bstep, blast));
+    asm volatile("" ::"v"(dnext.x), "v"(dnext.y));   // delivered before the loop: the loop head then joins two states without pending loads
     for (int d = d0; d < d1; d += 2, boff += 2u * bstep) {
       const bool two = d + 1 < d1;
       const v2f dv = dnext;
@@ -581,6 +582,11 @@ __global__ __launch_bounds__(256, CDS_K3_MINW) void warp_aggregate_lds_kernel(
         }
       }
 #endif
+      // Take delivery of the next pair's hypotheses HERE, before this pair's stores are issued.  gfx9 counts loads and stores in one
+      // vmcnt and they complete out of order with respect to each other, so a wait for a load with younger stores in flight has to be
+      // vmcnt(0): left at its first use (the top of the next iteration) it drained the stores just issued, every iteration.  At this
+      // point only the previous iteration's stores are outstanding and they have had a whole iteration to complete.
+      asm volatile("" ::"v"(dnext.x), "v"(dnext.y));
       if (active) {
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
