@@ -294,6 +294,19 @@ __global__ __launch_bounds__((FCfg<S, MB, TX_, TZ_, PAIR, WRES_>::THREADS)) void
         }
       }
       if (rd + 1 == rounds) {
+        // Take delivery of the next stage's first weights (requested at K-steps 1 and L - 1 above) BEFORE the epilogue stores are
+        // issued: gfx9 has ONE vmcnt for loads and stores and they complete out of order with respect to each other, so the compiler
+        // turns a wait for a load that has younger stores in flight into vmcnt(0) - the first MFMAs of the next stage then waited for
+        // every store of this epilogue to be acknowledged (round 5, scripts/isa_scan.py; the same fix as in K3's plane loop).
+        if (Cfg::WDB && !Cfg::WRES) {
+#pragma unroll
+          for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int tm = 0; tm < 3; ++tm) {
+              asm volatile("" ::"v"(w0[mb][tm].u.x), "v"(w0[mb][tm].u.y), "v"(w0[mb][tm].u.z), "v"(w0[mb][tm].u.w));
+              asm volatile("" ::"v"(wa[1][mb][tm].u.x), "v"(wa[1][mb][tm].u.y), "v"(wa[1][mb][tm].u.z), "v"(wa[1][mb][tm].u.w));
+            }
+        }
         // ---- epilogue: lane -> voxel j of the run, couts 16 mb + 4 g + 0..3: one 16-byte channels-last store ----
         SBF_TILE(tile, tx_i, ty_i, tz_i);
         const int ox0 = tx_i * Cfg::TX, oy = ty_i * Cfg::TY + wy, oz0 = tz_i * Cfg::TZ;
@@ -541,6 +554,15 @@ __global__ __launch_bounds__(256, (MERGE ? CDS_DECONV_SBF_MINW : (MB == 1 ? CDS_
 
     // ---- epilogue ----
     if (ay < H) {
+      // Two passes: first every output value is finished in its accumulator registers (bias, ReLU, + skip: all skip loads of the tile
+      // in flight together), then all stores are issued.  One pass interleaved load - store - load: on gfx9's single vmcnt every skip
+      // wait then drained the store before it (73 full drains per tile in the 64 -> 32 layer, scripts/isa_scan.py).
+      float4 bvr[MB];
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) {
+        const int co = MERGE ? 4 * (g & 1) : mb * 16 + 4 * g;
+        bvr[mb] = bias ? *reinterpret_cast<const float4*>(bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
 #pragma unroll
       for (int c = 0; c < Tab::NCLS; ++c) {
         const int pz = MERGE ? (c >> 1) : (c >> 2), py = MERGE ? (c & 1) : ((c >> 1) & 1);
@@ -549,7 +571,7 @@ __global__ __launch_bounds__(256, (MERGE ? CDS_DECONV_SBF_MINW : (MB == 1 ? CDS_
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) {
           const int co = MERGE ? 4 * (g & 1) : mb * 16 + 4 * g;
-          const float4 bv = bias ? *reinterpret_cast<const float4*>(bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+          const float4 bv = bvr[mb];
 #pragma unroll
           for (int q = 0; q < Cfg::NT; ++q) {
             const int ax = tx_i * Cfg::CX + q * 16 + j;
@@ -564,6 +586,25 @@ __global__ __launch_bounds__(256, (MERGE ? CDS_DECONV_SBF_MINW : (MB == 1 ? CDS_
               const float4 s4 = SKIP_PF ? skv[SKIP_PF ? c : 0][q] : *reinterpret_cast<const float4*>(skip + base);
               o.x = s4.x + o.x; o.y = s4.y + o.y; o.z = s4.z + o.z; o.w = s4.w + o.w;
             }
+            acc[c][mb][q] = (f32x4){o.x, o.y, o.z, o.w};
+          }
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < Tab::NCLS; ++c) {
+        const int pz = MERGE ? (c >> 1) : (c >> 2), py = MERGE ? (c & 1) : ((c >> 1) & 1);
+        const int px = MERGE ? (g >> 1) : (c & 1);
+        const size_t rowbase = ((size_t)(2 * az + pz) * Ho + (2 * ay + py)) * Wo;
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+          const int co = MERGE ? 4 * (g & 1) : mb * 16 + 4 * g;
+#pragma unroll
+          for (int q = 0; q < Cfg::NT; ++q) {
+            const int ax = tx_i * Cfg::CX + q * 16 + j;
+            if (ax >= W) continue;
+            const size_t base = (rowbase + 2 * ax + px) * Cout + co;
+            const f32x4 a = acc[c][mb][q];
+            const float4 o = make_float4(a.x, a.y, a.z, a.w);
             if (out_planar) {
               // [Cout][2D][2H][2W] for a planar consumer (the prob layer): per component the lanes of a store cover runs of
               // 32 consecutive x (both x parities of 16 cells) -> whole 128-byte segments

@@ -125,6 +125,7 @@ __global__ __launch_bounds__((DZC<ROUNDS>::THREADS), 3) void deconv3d_zm_kernel(
     float4 skn = make_float4(0.f, 0.f, 0.f, 0.f);
     auto row_off = [&](int n) { return ((size_t)(2 * (Y0 + n) + py) * Wo + xv) * Cout + 4 * g; };
     if (skip && x_ok) skn = *reinterpret_cast<const float4*>(skip + zbase + row_off(0));
+    asm volatile("" ::"v"(skn.x), "v"(skn.y), "v"(skn.z), "v"(skn.w));   // (the row loop's head then joins two states without pending loads)
     for (int n = 0; n < nrows; ++n) {
       const float4 sk = skn;
       if (skip && x_ok && n + 1 < nrows) skn = *reinterpret_cast<const float4*>(skip + zbase + row_off(n + 1));
@@ -146,6 +147,9 @@ __global__ __launch_bounds__((DZC<ROUNDS>::THREADS), 3) void deconv3d_zm_kernel(
           SBF_TERMS(acc, 0, 1, whi[rd], c);
         }
       }
+      // the next row's residual is taken delivery of BEFORE this row's store is issued (gfx9: one vmcnt for loads and stores, out of
+      // order with respect to each other -> a wait for a load with a younger store in flight is a full drain)
+      asm volatile("" ::"v"(skn.x), "v"(skn.y), "v"(skn.z), "v"(skn.w));
       if (x_ok) {
         const f32x4 r = acc[0];
         float4 o = make_float4(r.x, r.y, r.z, r.w);
