@@ -250,9 +250,11 @@ __device__ __forceinline__ void positions2(const float r[3], const float* __rest
   const v2f e = fma2(-z, y0, splat2(1.0f));
   const v2f y = fma2(e, y0, y0);
   // u = px / z and v = py / z, written interleaved: two independent dependency chains.  y is the Newton-refined reciprocal
-  // (correctly rounded for all but ~1e-6 of the operands), so ONE Markstein correction of the quotient yields the correctly
-  // rounded result: 0 mismatches against IEEE division over 12 M random operand pairs incl. +-1 ulp errors of v_rcp_f32
-  // (profiles/r04_experiments.md; the bit-equality tests against F.grid_sample's positions are unchanged).  Round 3 spent a
+  // (correctly rounded for all but ~1e-6 of the operands), followed by ONE Markstein correction of the quotient.  That is only
+  // GUARANTEED to be the correctly rounded quotient when y = RN(1/z); for the rare mis-rounded y it is an empirical statement: 0
+  // mismatches against IEEE division over 12 M random operand pairs incl. +-1 ulp errors of v_rcp_f32 (profiles/r04_experiments.md;
+  // the bit-equality tests against F.grid_sample's positions are unchanged).  A miss would be one ulp of a position (6e-8 relative):
+  // it changes a sample only if it flips floor() exactly at a texel boundary, by a weight of that size.  Round 3 spent a
   // second correction: 4 more packed instructions per view and plane pair, K3 0.947 -> 0.929 ms, K1 0.790 -> 0.770 ms without it.
   const v2f qu = px * y, qv = py * y;
   const v2f ru = fma2(-z, qu, px), rv = fma2(-z, qv, py);

@@ -1,10 +1,17 @@
 #!/bin/bash
-# round 5: the profile set committed under profiles/r05_* (kernel stats, MFMA utilisation, HBM traffic, cascade breakdown, bench line)
+# round 5: the profile set committed under profiles/r05_* (kernel stats, MFMA utilisation, HBM traffic, cascade breakdown, T5 breakdown, bench line)
 R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=$(pwd)
 O=$R/gpurun_out; mkdir -p $O/r05
 cd $R
 scripts/profile_round.sh r05 > /dev/null 2>&1
 TOPN=40 scripts/profile_m3.sh r05 > /dev/null 2>&1
-cp $O/r05_kernel_stats.md $O/r05_pmc_mfma.txt $O/pmc_traffic.md $O/pmc_traffic.json $O/r05_m3_breakdown.txt $O/r05_m3_pmc_mfma.txt $O/r05/ 2>/dev/null
+TOPN=45 scripts/profile_t5.sh r05 > /dev/null 2>&1
+cp $O/r05_kernel_stats.md $O/r05_pmc_mfma.txt $O/pmc_traffic.md $O/pmc_traffic.json $O/r05_m3_breakdown.txt $O/r05_m3_pmc_mfma.txt $O/r05_t5_breakdown.txt $O/r05/ 2>/dev/null
 python bench.py > $O/r05/bench_b.json 2> $O/r05/bench_b.err
-tail -c 3000 $O/r05/bench_b.json
+python - <<'PY'
+import json
+d=json.loads([l for l in open('gpurun_out/r05/bench_b.json') if l.startswith('{')][-1])
+print('value',d['value'],'ms',d['ms_per_step'],'frac',d['roofline']['frac'],'traffic',d['roofline']['traffic'],'kernel_ms',d['kernel_ms'])
+print({k:v for k,v in d['other_workloads'].items() if not isinstance(v,dict)})
+print({k:v['frac'] for k,v in d['other_workloads']['M3_K3_roofline_by_stage'].items()})
+PY
