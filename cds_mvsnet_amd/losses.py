@@ -3,7 +3,7 @@ binary cross-entropy on the feature-distance volume, curvature regulariser; smoo
 
 Device tensors run the HIP kernels of csrc/loss.hip behind ONE autograd node (8 launches forward, 4 backward at three stages + the
 refined depth; the ATen formulation below is ~90 + ~150 launches of a launch-bound step); CPU tensors - the golden-vector check of the
-formula against the reference's values (tests/test_oracle_golden.py, G11) - run the same formula in ATen."""
+formula against the reference's values (golden set G11 under tests/) - run the same formula in ATen."""
 from __future__ import annotations
 
 import ctypes
