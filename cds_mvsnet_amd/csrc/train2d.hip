@@ -447,6 +447,7 @@ __global__ __launch_bounds__(256) void dynconv_blend_train_kernel(BlendArgs a, f
     for (int k = 0; k < K; ++k) nc = nc + s.curv[k] * s.wts[k];
     norm_curv[(size_t)n * hw + p] = nc;
     const float* __restrict__ res = a.branch + (size_t)n * (a.Cout + 3) * hw + p;
+#pragma unroll 4                                   // Cout is a multiple of 8: four channels of loads in flight
     for (int c = 0; c < a.Cout; ++c) {
       float v = 0.f;
 #pragma unroll
@@ -466,6 +467,7 @@ __device__ __forceinline__ void pixel_backward(const BlendArgs& a, int n, int p,
   float g_w[K];
 #pragma unroll
   for (int k = 0; k < K; ++k) g_w[k] = gnc * s.curv[k];
+#pragma unroll 4                                   // Cout is a multiple of 8: four channels of loads in flight
   for (int c = 0; c < a.Cout; ++c) {
     const float gv = gy[((size_t)n * a.Cout + c) * hw + p];
 #pragma unroll
@@ -555,6 +557,7 @@ __global__ __launch_bounds__(256) void dynconv_blend_bwd_apply_kernel(BlendArgs 
       }
     }
     float* __restrict__ o = gbr + (size_t)n * (a.Cout + 3) * hw + p;
+#pragma unroll 4                                   // Cout is a multiple of 8: four channels of loads in flight
     for (int c = 0; c < a.Cout; ++c) {
       const float gv = gy[((size_t)n * a.Cout + c) * hw + p];
 #pragma unroll
