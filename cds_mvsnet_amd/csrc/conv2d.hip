@@ -604,6 +604,7 @@ __global__ __launch_bounds__(256) void instnorm_stats_kernel(const float* __rest
   const int c = blockIdx.x / blocks_per_c, b = blockIdx.x % blocks_per_c;
   const float* __restrict__ xc = x + (size_t)c * hw;
   double s = 0.0, q = 0.0;
+#pragma unroll 4
   for (int i = b * 256 + threadIdx.x; i < hw; i += blocks_per_c * 256) {
     double v = (double)xc[i];
     s += v;

@@ -871,6 +871,7 @@ __global__ __launch_bounds__(256) void instnorm_stats_cl_kernel(const float* __r
   const float4* __restrict__ x4 = reinterpret_cast<const float4*>(x + (size_t)n * hw * CT);
   const size_t total = (size_t)hw * C4;
   double s[4] = {0.0, 0.0, 0.0, 0.0}, q[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
     const float4 v = x4[i];
     const double a = v.x, b = v.y, c = v.z, d = v.w;

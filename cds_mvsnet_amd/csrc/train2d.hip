@@ -247,6 +247,7 @@ __global__ __launch_bounds__(256) void instnorm_bwd_reduce_kernel(const float* _
   const float* __restrict__ yc = y + (size_t)c * hw;
   const float* __restrict__ gc = gz + (size_t)c * hw;
   double s0 = 0.0, s1 = 0.0;
+#pragma unroll 4
   for (int i = b * 256 + threadIdx.x; i < hw; i += blocks_per_c * 256) {
     const float xh = (yc[i] - mean) * rstd;
     const float gh = gc[i] * act_grad(xh, act);
@@ -581,14 +582,17 @@ __global__ __launch_bounds__(256) void softargmin_bwd_kernel(const float* __rest
   const int p = blockIdx.x * 256 + threadIdx.x;
   if (p >= hw) return;
   float mx = -INFINITY;
+#pragma unroll 8
   for (int d = 0; d < D; ++d) mx = fmaxf(mx, pre[(size_t)d * hw + p]);
   float den = 0.f, num = 0.f;
+#pragma unroll 8
   for (int d = 0; d < D; ++d) {
     const float e = expf(pre[(size_t)d * hw + p] - mx);
     den += e;
     num = fmaf(e, hyp_per_pixel ? hyp[(size_t)d * hw + p] : hyp[d], num);
   }
   const float depth = num / den, gd = gdepth[p];
+#pragma unroll 8
   for (int d = 0; d < D; ++d) {
     const float pd = expf(pre[(size_t)d * hw + p] - mx) / den;
     gpre[(size_t)d * hw + p] = pd * ((hyp_per_pixel ? hyp[(size_t)d * hw + p] : hyp[d]) - depth) * gd;

@@ -401,6 +401,7 @@ __global__ __launch_bounds__(256) void volume_finish_kernel(const float* __restr
   if (p >= hw) return;
   const float den = vis_denominator(vis, V, hw, p);
   float s = 0.f;
+#pragma unroll 4
   for (int c = 0; c < C; ++c) {
     const size_t i = ((size_t)c * D + d) * hw + p;
     const float x = vsum[i];
@@ -424,6 +425,7 @@ __global__ __launch_bounds__(256) void volume_finish_bwd_kernel(const float* __r
   const float den = vis_denominator(vis, V, hw, p);
   const float gf = gfd ? gfd[(size_t)d * hw + p] : 0.f;
   float acc = 0.f;
+#pragma unroll 4
   for (int c = 0; c < C; ++c) {
     const size_t i = ((size_t)c * D + d) * hw + p;
     const float g = (gvol ? gvol[i] : 0.f) + gf;
@@ -441,6 +443,7 @@ __global__ __launch_bounds__(256) void volume_finish_bwd_vis_kernel(const float*
   if (p >= hw) return;
   const float den = vis_denominator(vis, V, hw, p);
   float tot = 0.f;
+#pragma unroll 4
   for (int d = 0; d < D; ++d) tot += part[(size_t)d * hw + p];
   if (gtsum) {
     const float gf = gfd ? gfd[(size_t)D * hw + p] : 0.f;
