@@ -119,11 +119,14 @@ def other_workloads(model, dev):
     out = {}
 
     def timeit(fn, n=5, warm=2):
-        for _ in range(warm):
-            fn()
-        torch.cuda.synchronize()
         gc.collect()
         gc.disable()          # a generation-2 collection inside a 20-100 ms timed batch showed up as 3x outliers
+        # at least one untimed call AFTER the collection, then synchronise and start the clock at once: the collection pause (tens of ms
+        # of an idle GPU) used to sit between the warm-up and the timed batch, and the first timed forward then ran at ramping clocks
+        # (scripts/ab/r05_fwd_n.py: 18.3 ms for one forward after an idle gap against 15.2 ms per forward in a batch of ten)
+        for _ in range(max(warm, 1)):
+            fn()
+        torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(n):
             fn()
@@ -628,12 +631,12 @@ def main():
 
     grad_ctx = torch.enable_grad() if kind == "train" else torch.no_grad()
     with grad_ctx:
-        for _ in range(args.warmup):
+        gc.collect()
+        gc.disable()          # no cyclic-GC pause inside the timed region (the steps allocate no reference cycles); collected BEFORE the
+        for _ in range(args.warmup):      # warm-up so that no idle gap sits between the warm-up steps and the timed ones
             out = step()
         ops.PROFILE.clear()
         ops.PROFILE_ON = args.streams == 1
-        gc.collect()
-        gc.disable()          # no cyclic-GC pause inside the timed region (the steps allocate no reference cycles)
         barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
