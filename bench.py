@@ -191,6 +191,10 @@ def other_workloads(model, dev):
     opt = T.make_optimizer(tmodel)
     out["T5_train_step_768x576_N5_fp32_ms"] = min(timeit(lambda: T.train_step(tmodel, opt, sample, temperature=0.1), n=5, warm=3 if r == 0 else 0)
                                                  for r in range(2))
+    # the same step under the bf16-storage / f32-accumulate policy of the FeatureNet activations (config 5's "bf16" label; train.py)
+    out["T5_train_step_768x576_N5_bf16storage_ms"] = min(
+        timeit(lambda: T.train_step(tmodel, opt, sample, temperature=0.1, activation_storage="bf16"), n=5, warm=3 if r == 0 else 0)
+        for r in range(2))
     del tmodel, opt, sample
     res = {k: round(v, 3) for k, v in out.items()}
     res["M3_K3_roofline_by_stage"] = k3
@@ -515,6 +519,8 @@ def main():
     ap.add_argument("--exchange", default="allreduce", choices=["allreduce", "p2p", "reduce_scatter", "slab"],
                     help="viewshard exchange: one RCCL all-reduce; reduce-scatter + all-gather as direct P2P sends; or "
                          "reduce_scatter = rows of the sum per rank + slab-parallel CostRegNet (the form that scales)")
+    ap.add_argument("--train-act-storage", default="f32", choices=["f32", "bf16"],
+                    help="--workload T5: storage of the FeatureNet activations between the passes (bf16 = bf16 storage / f32 accumulate)")
     ap.add_argument("--no-extras", action="store_true", help="skip the M1b / M2 / M3 / M4 side measurements")
     ap.add_argument("--no-pmc", action="store_true", help="do not re-measure roofline.traffic with rocprofv3 in this run")
     ap.add_argument("--no-viewshard", action="store_true", help="N > 1: skip the north-star view-shard measurement")
@@ -605,12 +611,13 @@ def main():
         opt = T.make_optimizer(model)
         reducer = T.GradAllReducer(model.parameters(), module=model)       # broadcasts rank 0's weights when world > 1
         workload_desc = (f"{args.workload}: BlendedMVS-shaped training step {W}x{H}, N={n_views}, refine={refine}, "
-                         + "fp32 (every training kernel is fp32; see cds_mvsnet_amd/train.py), "
+                         + ("fp32 (the reference's precision; see cds_mvsnet_amd/train.py), " if args.train_act_storage == "f32" else
+                            "bf16 storage of the FeatureNet activations / f32 accumulate (cds_mvsnet_amd/train.py), ")
                          + "SGD, flat-bucket gradient all-reduce")
         metric, unit = f"training samples/sec ({W}x{H} N={n_views} step: forward + loss + backward + all-reduce + SGD)", "samples/s"
         b_alg = None
         def step():
-            l, _ = T.train_step(model, opt, sample, temperature=0.1, reducer=reducer)
+            l, _ = T.train_step(model, opt, sample, temperature=0.1, reducer=reducer, activation_storage=args.train_act_storage)
             return {"depth": torch.tensor([l])}
 
     if args.streams > 1:   # independent pipelines on separate streams: memory-bound and issue-bound kernels overlap
@@ -724,7 +731,8 @@ def main():
             "value": value, "unit": unit, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "strong" if viewshard_timed else "weak",
-            "vs_baseline": None, "dtype": "f32",
+            "vs_baseline": None,
+            "dtype": "bf16-storage/f32-accumulate" if (args.workload in TRAIN and args.train_act_storage == "bf16") else "f32",
             "data": "synthetic (seeded features/cameras/hypotheses, seeded random weights)",
             "config": {"workload": workload_desc,
                        "parallelism": (args.parallelism if kind != "train" else "data-parallel") if world > 1 else "single",

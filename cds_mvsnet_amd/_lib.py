@@ -103,6 +103,13 @@ SIGNATURES = {
     "cds_dynconv_bn_stats_f32": [P, P, P, P, P, P, P, P, I, I, I, I, I, I, F, F, I, I, P],
     "cds_dynconv_blend_train_f32": [P, P, P, P, P, P, P, P, F, P, P, I, I, I, I, I, I, P],
     "cds_dynconv_blend_bwd_f32": [P, P, P, P, P, P, P, P, F, P, P, P, P, P, I, I, I, I, I, I, I, I, P],
+    "cds_f32_to_bf16": [P, P, L, P],
+    "cds_instnorm_act_b16_f32": [P, P, P, P, P, I, I, I, I, I, I, P],
+    "cds_conv2d_wgrad_xb16_f32": [P, P, P, I, I, I, I, I, I, I, I, I, I, P],
+    "cds_instnorm_bwd_yb16_f32": [P, P, P, P, P, P, I, I, I, I, I, I, P],
+    "cds_dynconv_bn_stats_b16_f32": [P, P, P, P, P, P, P, P, I, I, I, I, I, I, F, F, I, I, P],
+    "cds_dynconv_blend_train_b16_f32": [P, P, P, P, P, P, P, P, F, P, P, I, I, I, I, I, I, P],
+    "cds_dynconv_blend_bwd_b16_f32": [P, P, P, P, P, P, P, P, F, P, P, P, P, P, I, I, I, I, I, I, I, I, P],
     "cds_pack_conv2d_f32": [P, P, P, P, I, I, I, I, P],
     "cds_pack_conv3d_f32": [P, P, P, I, I, I, P],
     "cds_softargmin_bwd_f32": [P, P, P, P, I, I, I, I, P],

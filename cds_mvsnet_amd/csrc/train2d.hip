@@ -25,6 +25,19 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// bf16 STORAGE of the 2D activations (the "bf16-storage / f32-accumulate" policy of the training step): tensors that live from the forward to
+// the backward pass (layer inputs, DynamicConv branch responses, pre-normalisation maps) are raw bfloat16; every kernel widens on load
+// and accumulates in fp32 / fp64 exactly as on the fp32 path.  Rounding is round-to-nearest-even (what torch's .bfloat16() does).
+typedef unsigned short b16;
+__device__ __forceinline__ float ldf(const float* __restrict__ p, size_t i) { return p[i]; }
+__device__ __forceinline__ float ldf(const b16* __restrict__ p, size_t i) { return __uint_as_float((unsigned)p[i] << 16); }
+__device__ __forceinline__ b16 f2b(float f) {
+  unsigned u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (b16)((u >> 16) | 0x40u);   // NaN stays NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (b16)(u >> 16);
+}
+
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -51,8 +64,8 @@ struct W2Cfg {
   static constexpr int LDS_FLOATS = LDS_IN > LDS_RED ? LDS_IN : LDS_RED;
 };
 
-template <int K, int S, int CB>
-__global__ __launch_bounds__(256) void conv2d_wgrad_mfma_kernel(const float* __restrict__ g, const float* __restrict__ xin,
+template <int K, int S, int CB, typename TX>
+__global__ __launch_bounds__(256) void conv2d_wgrad_mfma_kernel(const float* __restrict__ g, const TX* __restrict__ xin,
                                                                 float* __restrict__ dw, int N, int Co, int Cin, int Ho, int Wo,
                                                                 int H, int W, int pad, int tiles_x, int ntiles, int tiles_per_wg) {
   using Cfg = W2Cfg<K, S, CB>;
@@ -109,7 +122,7 @@ __global__ __launch_bounds__(256) void conv2d_wgrad_mfma_kernel(const float* __r
     for (int e = 0; e < NX; ++e) {
       const int pk = pkx[e];
       const bool ok = pk >= 0 && (unsigned)(ix0 + (pk & 0xffff)) < (unsigned)W && (unsigned)(iy0 + (pk >> 16)) < (unsigned)H;
-      const float v = xin[ok ? xbase + relx[e] : 0];
+      const float v = ldf(xin, (size_t)(ok ? xbase + relx[e] : 0));
       rx[e] = ok ? v : 0.f;
     }
   };
@@ -158,8 +171,8 @@ __global__ __launch_bounds__(256) void conv2d_wgrad_mfma_kernel(const float* __r
   }
 }
 
-template <int K, int S, int CB>
-int launch_wgrad2d(const float* g, const float* xin, float* dw, int N, int Co, int Cin, int Ho, int Wo, int H, int W, int pad,
+template <int K, int S, int CB, typename TX>
+int launch_wgrad2d(const float* g, const TX* xin, float* dw, int N, int Co, int Cin, int Ho, int Wo, int H, int W, int pad,
                    hipStream_t st) {
   using Cfg = W2Cfg<K, S, CB>;
   const int tx = cds_ceil_div(Wo, Cfg::OX), ty = cds_ceil_div(Ho, Cfg::OY);
@@ -171,8 +184,8 @@ int launch_wgrad2d(const float* g, const float* xin, float* dw, int N, int Co, i
   const int ldsb = Cfg::LDS_FLOATS * (int)sizeof(float);
   static std::atomic<unsigned long long> ok{0};
   if (ldsb > 64 * 1024)
-    if (int e = cds_allow_lds((const void*)conv2d_wgrad_mfma_kernel<K, S, CB>, ldsb, ok)) return e;
-  hipLaunchKernelGGL((conv2d_wgrad_mfma_kernel<K, S, CB>), grid, dim3(256), ldsb, st, g, xin, dw, N, Co, Cin, Ho, Wo, H, W, pad, tx,
+    if (int e = cds_allow_lds((const void*)conv2d_wgrad_mfma_kernel<K, S, CB, TX>, ldsb, ok)) return e;
+  hipLaunchKernelGGL((conv2d_wgrad_mfma_kernel<K, S, CB, TX>), grid, dim3(256), ldsb, st, g, xin, dw, N, Co, Cin, Ho, Wo, H, W, pad, tx,
                      ntiles, per);
   return cds_launch_status();
 }
@@ -238,19 +251,20 @@ __device__ __forceinline__ float act_grad(float xhat, int act) {
   return 1.f;
 }
 
-__global__ __launch_bounds__(256) void instnorm_bwd_reduce_kernel(const float* __restrict__ gz, const float* __restrict__ y,
+template <typename TY>
+__global__ __launch_bounds__(256) void instnorm_bwd_reduce_kernel(const float* __restrict__ gz, const TY* __restrict__ y,
                                                                   const double* __restrict__ stats, double* __restrict__ sums,
-                                                                  int hw, int act, int blocks_per_c) {
+                                                                  int hw, int act, int blocks_per_c, const b16* __restrict__ zs) {
   const int c = blockIdx.x / blocks_per_c, b = blockIdx.x % blocks_per_c;   // c = image * C + channel
   float mean, rstd;
   in_stats(stats + 2 * c, hw, mean, rstd);
-  const float* __restrict__ yc = y + (size_t)c * hw;
+  const TY* __restrict__ yc = y + (size_t)c * hw;
   const float* __restrict__ gc = gz + (size_t)c * hw;
   double s0 = 0.0, s1 = 0.0;
 #pragma unroll 4
   for (int i = b * 256 + threadIdx.x; i < hw; i += blocks_per_c * 256) {
-    const float xh = (yc[i] - mean) * rstd;
-    const float gh = gc[i] * act_grad(xh, act);
+    const float xh = (ldf(yc, i) - mean) * rstd;
+    const float gh = gc[i] * (zs ? ((zs[(size_t)c * hw + i] & 0x8000u) ? 0.1f : 1.f) : act_grad(xh, act));
     s0 += (double)gh;
     s1 += (double)gh * (double)xh;
   }
@@ -268,17 +282,18 @@ __global__ __launch_bounds__(256) void instnorm_bwd_reduce_kernel(const float* _
   }
 }
 
-__global__ __launch_bounds__(256) void instnorm_bwd_apply_kernel(const float* __restrict__ gz, const float* __restrict__ y,
+template <typename TY>
+__global__ __launch_bounds__(256) void instnorm_bwd_apply_kernel(const float* __restrict__ gz, const TY* __restrict__ y,
                                                                  const double* __restrict__ stats, const double* __restrict__ sums,
-                                                                 float* __restrict__ gy, int hw, int act) {
+                                                                 float* __restrict__ gy, int hw, int act, const b16* __restrict__ zs) {
   const int c = blockIdx.y;
   float mean, rstd;
   in_stats(stats + 2 * c, hw, mean, rstd);
   const float m0 = (float)(sums[2 * c] / hw), m1 = (float)(sums[2 * c + 1] / hw);
   const size_t o = (size_t)c * hw;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < hw; i += gridDim.x * 256) {
-    const float xh = (y[o + i] - mean) * rstd;
-    const float gh = gz[o + i] * act_grad(xh, act);
+    const float xh = (ldf(y, o + i) - mean) * rstd;
+    const float gh = gz[o + i] * (zs ? ((zs[o + i] & 0x8000u) ? 0.1f : 1.f) : act_grad(xh, act));
     gy[o + i] = rstd * (gh - m0 - xh * m1);
   }
 }
@@ -297,8 +312,9 @@ __global__ __launch_bounds__(256) void instnorm_bwd_apply_kernel(const float* __
 constexpr int HID = 4;                 // hidden width of the attention MLP (dynamic_conv.py:84)
 constexpr int TPX = 8;                 // pixels per thread of the epilogue kernels
 
-struct BlendArgs {
-  const float* branch;                 // [K][N][Cout + 3][hw]
+template <typename TB>
+struct BlendArgsT {
+  const TB* branch;                    // [K][N][Cout + 3][hw], fp32 or raw bf16
   const float* epi;                    // [N][2] device
   const float* w1;                     // [HID][K]
   const float* w2;                     // [K][HID]
@@ -315,8 +331,8 @@ struct PixelState {
   float basis[3], curv[K], hhat[HID], r[HID], wts[K];
 };
 
-template <int K>
-__device__ __forceinline__ void pixel_basis_curv(const BlendArgs& a, int n, int p, PixelState<K>& s) {
+template <int K, typename TB>
+__device__ __forceinline__ void pixel_basis_curv(const BlendArgsT<TB>& a, int n, int p, PixelState<K>& s) {
   const int hw = a.H * a.W;
   const int y = p / a.W, x = p - y * a.W;
   float u = (float)x - a.epi[2 * n], v = (float)y - a.epi[2 * n + 1];
@@ -329,13 +345,13 @@ __device__ __forceinline__ void pixel_basis_curv(const BlendArgs& a, int n, int 
   const size_t bstride = (size_t)a.N * (a.Cout + 3) * hw;
 #pragma unroll
   for (int k = 0; k < K; ++k) {
-    const float* c = a.branch + k * bstride + ((size_t)n * (a.Cout + 3) + a.Cout) * hw + p;
-    s.curv[k] = c[0] * s.basis[0] + c[hw] * s.basis[1] + c[2 * (size_t)hw] * s.basis[2];
+    const TB* c = a.branch + k * bstride + ((size_t)n * (a.Cout + 3) + a.Cout) * hw + p;
+    s.curv[k] = ldf(c, 0) * s.basis[0] + ldf(c, hw) * s.basis[1] + ldf(c, 2 * (size_t)hw) * s.basis[2];
   }
 }
 
-template <int K>
-__device__ __forceinline__ void pixel_weights(const BlendArgs& a, int g, PixelState<K>& s) {
+template <int K, typename TB>
+__device__ __forceinline__ void pixel_weights(const BlendArgsT<TB>& a, int g, PixelState<K>& s) {
 #pragma unroll
   for (int j = 0; j < HID; ++j) {
     float h = 0.f;
@@ -377,8 +393,8 @@ __device__ __forceinline__ void block_atomic_sum(double (&v)[NV], double* __rest
 }
 
 // mom [G][K + K (K + 1) / 2] fp64 (zeroed): sums of curv_k, then of curv_k curv_l (k <= l, row-major upper triangle)
-template <int K>
-__global__ __launch_bounds__(256) void dynconv_moments_kernel(BlendArgs a, double* __restrict__ mom) {
+template <int K, typename TB>
+__global__ __launch_bounds__(256) void dynconv_moments_kernel(BlendArgsT<TB> a, double* __restrict__ mom) {
   constexpr int NM = K + K * (K + 1) / 2;
   const int hw = a.H * a.W, n = blockIdx.y, g = n / (a.N / a.G);
   double acc[NM];
@@ -388,7 +404,7 @@ __global__ __launch_bounds__(256) void dynconv_moments_kernel(BlendArgs a, doubl
     const int p = (blockIdx.x * TPX + t) * 256 + threadIdx.x;
     if (p >= hw) break;
     PixelState<K> s;
-    pixel_basis_curv<K>(a, n, p, s);
+    pixel_basis_curv<K, TB>(a, n, p, s);
     int i = K;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
@@ -433,38 +449,38 @@ __global__ void dynconv_bn_fold_kernel(const double* __restrict__ mom, const flo
 }
 
 // out [N][Cout][hw], norm_curv [N][hw]
-template <int K>
-__global__ __launch_bounds__(256) void dynconv_blend_train_kernel(BlendArgs a, float* __restrict__ out, float* __restrict__ norm_curv) {
+template <int K, typename TB>
+__global__ __launch_bounds__(256) void dynconv_blend_train_kernel(BlendArgsT<TB> a, float* __restrict__ out, float* __restrict__ norm_curv) {
   const int hw = a.H * a.W, n = blockIdx.y, g = n / (a.N / a.G);
   const size_t bstride = (size_t)a.N * (a.Cout + 3) * hw;
   for (int t = 0; t < TPX; ++t) {
     const int p = (blockIdx.x * TPX + t) * 256 + threadIdx.x;
     if (p >= hw) break;
     PixelState<K> s;
-    pixel_basis_curv<K>(a, n, p, s);
-    pixel_weights<K>(a, g, s);
+    pixel_basis_curv<K, TB>(a, n, p, s);
+    pixel_weights<K, TB>(a, g, s);
     float nc = 0.f;
 #pragma unroll
     for (int k = 0; k < K; ++k) nc = nc + s.curv[k] * s.wts[k];
     norm_curv[(size_t)n * hw + p] = nc;
-    const float* __restrict__ res = a.branch + (size_t)n * (a.Cout + 3) * hw + p;
+    const TB* __restrict__ res = a.branch + (size_t)n * (a.Cout + 3) * hw + p;
 #pragma unroll 4                                   // Cout is a multiple of 8: four channels of loads in flight
     for (int c = 0; c < a.Cout; ++c) {
       float v = 0.f;
 #pragma unroll
-      for (int k = 0; k < K; ++k) v = v + res[k * bstride + (size_t)c * hw] * s.wts[k];
+      for (int k = 0; k < K; ++k) v = v + ldf(res, k * bstride + (size_t)c * hw) * s.wts[k];
       out[((size_t)n * a.Cout + c) * hw + p] = v;
     }
   }
 }
 
 // The per-pixel backward up to the BatchNorm: g_aw, g_hbn (already masked by the ReLU).
-template <int K>
-__device__ __forceinline__ void pixel_backward(const BlendArgs& a, int n, int p, const PixelState<K>& s, const float* __restrict__ gy,
+template <int K, typename TB>
+__device__ __forceinline__ void pixel_backward(const BlendArgsT<TB>& a, int n, int p, const PixelState<K>& s, const float* __restrict__ gy,
                                                float gnc, float (&g_aw)[K], float (&g_hbn)[HID]) {
   const int hw = a.H * a.W;
   const size_t bstride = (size_t)a.N * (a.Cout + 3) * hw;
-  const float* __restrict__ res = a.branch + (size_t)n * (a.Cout + 3) * hw + p;
+  const TB* __restrict__ res = a.branch + (size_t)n * (a.Cout + 3) * hw + p;
   float g_w[K];
 #pragma unroll
   for (int k = 0; k < K; ++k) g_w[k] = gnc * s.curv[k];
@@ -472,7 +488,7 @@ __device__ __forceinline__ void pixel_backward(const BlendArgs& a, int n, int p,
   for (int c = 0; c < a.Cout; ++c) {
     const float gv = gy[((size_t)n * a.Cout + c) * hw + p];
 #pragma unroll
-    for (int k = 0; k < K; ++k) g_w[k] = fmaf(gv, res[k * bstride + (size_t)c * hw], g_w[k]);
+    for (int k = 0; k < K; ++k) g_w[k] = fmaf(gv, ldf(res, k * bstride + (size_t)c * hw), g_w[k]);
   }
   float dot = 0.f;
 #pragma unroll
@@ -489,8 +505,8 @@ __device__ __forceinline__ void pixel_backward(const BlendArgs& a, int n, int p,
 }
 
 // Pass 1.  sums (fp64, zeroed): [G][2 HID] = per group (sum g_hbn_j, sum g_hbn_j hhat_j), then dW2 [K][HID] over all images.
-template <int K>
-__global__ __launch_bounds__(256) void dynconv_blend_bwd_reduce_kernel(BlendArgs a, const float* __restrict__ gy,
+template <int K, typename TB>
+__global__ __launch_bounds__(256) void dynconv_blend_bwd_reduce_kernel(BlendArgsT<TB> a, const float* __restrict__ gy,
                                                                       const float* __restrict__ gnc, double* __restrict__ sums) {
   const int hw = a.H * a.W, n = blockIdx.y, g = n / (a.N / a.G);
   double acc[2 * HID], accw[K * HID];
@@ -502,10 +518,10 @@ __global__ __launch_bounds__(256) void dynconv_blend_bwd_reduce_kernel(BlendArgs
     const int p = (blockIdx.x * TPX + t) * 256 + threadIdx.x;
     if (p >= hw) break;
     PixelState<K> s;
-    pixel_basis_curv<K>(a, n, p, s);
-    pixel_weights<K>(a, g, s);
+    pixel_basis_curv<K, TB>(a, n, p, s);
+    pixel_weights<K, TB>(a, g, s);
     float g_aw[K], g_hbn[HID];
-    pixel_backward<K>(a, n, p, s, gy, gnc ? gnc[(size_t)n * hw + p] : 0.f, g_aw, g_hbn);
+    pixel_backward<K, TB>(a, n, p, s, gy, gnc ? gnc[(size_t)n * hw + p] : 0.f, g_aw, g_hbn);
 #pragma unroll
     for (int j = 0; j < HID; ++j) {
       acc[j] += (double)g_hbn[j];
@@ -520,8 +536,8 @@ __global__ __launch_bounds__(256) void dynconv_blend_bwd_reduce_kernel(BlendArgs
 }
 
 // Pass 2.  gbr [K][N][Cout + 3][hw] (overwritten); dw1 [HID][K] fp64 (zeroed).  use_batch = 0: BatchNorm in eval mode.
-template <int K>
-__global__ __launch_bounds__(256) void dynconv_blend_bwd_apply_kernel(BlendArgs a, const float* __restrict__ gy,
+template <int K, typename TB>
+__global__ __launch_bounds__(256) void dynconv_blend_bwd_apply_kernel(BlendArgsT<TB> a, const float* __restrict__ gy,
                                                                      const float* __restrict__ gnc, const double* __restrict__ sums,
                                                                      double count, int use_batch, float* __restrict__ gbr,
                                                                      double* __restrict__ dw1) {
@@ -540,11 +556,11 @@ __global__ __launch_bounds__(256) void dynconv_blend_bwd_apply_kernel(BlendArgs 
     const int p = (blockIdx.x * TPX + t) * 256 + threadIdx.x;
     if (p >= hw) break;
     PixelState<K> s;
-    pixel_basis_curv<K>(a, n, p, s);
-    pixel_weights<K>(a, g, s);
+    pixel_basis_curv<K, TB>(a, n, p, s);
+    pixel_weights<K, TB>(a, g, s);
     float g_aw[K], g_hbn[HID];
     const float gn = gnc ? gnc[(size_t)n * hw + p] : 0.f;
-    pixel_backward<K>(a, n, p, s, gy, gn, g_aw, g_hbn);
+    pixel_backward<K, TB>(a, n, p, s, gy, gn, g_aw, g_hbn);
     float g_curv[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) g_curv[k] = gn * s.wts[k];
@@ -642,23 +658,24 @@ __global__ void pack_conv3d_kernel(const float* __restrict__ w, float* __restric
   }
 }
 
-template <int K>
-int blend_dispatch(int what, const BlendArgs& a, float* out, float* nc, const float* gy, const float* gnc, double* sums, double count,
+template <int K, typename TB>
+int blend_dispatch(int what, const BlendArgsT<TB>& a, float* out, float* nc, const float* gy, const float* gnc, double* sums, double count,
                    int use_batch, float* gbr, double* dw1, hipStream_t st) {
   const dim3 grid(cds_ceil_div(a.H * a.W, 256 * TPX), a.N), block(256);
   switch (what) {
-    case 0: hipLaunchKernelGGL(dynconv_moments_kernel<K>, grid, block, 0, st, a, sums); break;
-    case 1: hipLaunchKernelGGL(dynconv_blend_train_kernel<K>, grid, block, 0, st, a, out, nc); break;
-    case 2: hipLaunchKernelGGL(dynconv_blend_bwd_reduce_kernel<K>, grid, block, 0, st, a, gy, gnc, sums); break;
-    default: hipLaunchKernelGGL(dynconv_blend_bwd_apply_kernel<K>, grid, block, 0, st, a, gy, gnc, sums, count, use_batch, gbr, dw1);
+    case 0: hipLaunchKernelGGL((dynconv_moments_kernel<K, TB>), grid, block, 0, st, a, sums); break;
+    case 1: hipLaunchKernelGGL((dynconv_blend_train_kernel<K, TB>), grid, block, 0, st, a, out, nc); break;
+    case 2: hipLaunchKernelGGL((dynconv_blend_bwd_reduce_kernel<K, TB>), grid, block, 0, st, a, gy, gnc, sums); break;
+    default: hipLaunchKernelGGL((dynconv_blend_bwd_apply_kernel<K, TB>), grid, block, 0, st, a, gy, gnc, sums, count, use_batch, gbr, dw1);
   }
   return cds_launch_status();
 }
 
-int blend_dispatch_k(int K, int what, const BlendArgs& a, float* out, float* nc, const float* gy, const float* gnc, double* sums,
+template <typename TB>
+int blend_dispatch_k(int K, int what, const BlendArgsT<TB>& a, float* out, float* nc, const float* gy, const float* gnc, double* sums,
                      double count, int use_batch, float* gbr, double* dw1, hipStream_t st) {
-  if (K == 2) return blend_dispatch<2>(what, a, out, nc, gy, gnc, sums, count, use_batch, gbr, dw1, st);
-  if (K == 3) return blend_dispatch<3>(what, a, out, nc, gy, gnc, sums, count, use_batch, gbr, dw1, st);
+  if (K == 2) return blend_dispatch<2, TB>(what, a, out, nc, gy, gnc, sums, count, use_batch, gbr, dw1, st);
+  if (K == 3) return blend_dispatch<3, TB>(what, a, out, nc, gy, gnc, sums, count, use_batch, gbr, dw1, st);
   return CDS_EINVAL;
 }
 
@@ -666,8 +683,9 @@ int blend_dispatch_k(int K, int what, const BlendArgs& a, float* out, float* nc,
 
 // dw [Co][Cin][k][k] is ACCUMULATED onto (zero it first).  g [N][Co][Ho][Wo], x [N][Cin][H][W]; k in {1,3,5,7,11} with stride 1, or
 // k = 3 with stride 2.
-extern "C" int cds_conv2d_wgrad_f32(const float* g, const float* x, float* dw, int N, int Co, int Cin, int Ho, int Wo, int H, int W,
-                                    int k, int stride, int pad, void* stream) {
+template <typename TX>
+static int wgrad2d_entry(const float* g, const TX* x, float* dw, int N, int Co, int Cin, int Ho, int Wo, int H, int W, int k, int stride,
+                         int pad, void* stream) {
   if (!g || !x || !dw || N < 1 || Co < 1 || Cin < 1 || Ho < 1 || Wo < 1 || H < 1 || W < 1 || pad < 0) return CDS_EINVAL;
   if (Ho != (H + 2 * pad - k) / stride + 1 || Wo != (W + 2 * pad - k) / stride + 1) return CDS_EINVAL;
   hipStream_t st = (hipStream_t)stream;
@@ -684,6 +702,17 @@ extern "C" int cds_conv2d_wgrad_f32(const float* g, const float* x, float* dw, i
   }
   if (stride == 2 && k == 3) return launch_wgrad2d<3, 2, 8>(g, x, dw, N, Co, Cin, Ho, Wo, H, W, pad, st);
   return CDS_EINVAL;
+}
+
+extern "C" int cds_conv2d_wgrad_f32(const float* g, const float* x, float* dw, int N, int Co, int Cin, int Ho, int Wo, int H, int W,
+                                    int k, int stride, int pad, void* stream) {
+  return wgrad2d_entry<float>(g, x, dw, N, Co, Cin, Ho, Wo, H, W, k, stride, pad, stream);
+}
+
+// The same with the layer input x stored as raw bfloat16 (widened on load, fp32 matrix pipe, fp32 accumulation).
+extern "C" int cds_conv2d_wgrad_xb16_f32(const float* g, const unsigned short* x, float* dw, int N, int Co, int Cin, int Ho, int Wo, int H,
+                                         int W, int k, int stride, int pad, void* stream) {
+  return wgrad2d_entry<b16>(g, x, dw, N, Co, Cin, Ho, Wo, H, W, k, stride, pad, stream);
 }
 
 // gx [N][Cin][H][W] (overwritten) for conv 3x3 stride 2 pad 1 with weight w [Co][Cin][3][3]; g [N][Co][Ho][Wo], Cin % 8 == 0.
@@ -704,33 +733,49 @@ extern "C" int cds_conv2d_dgrad_s2_f32(const float* g, const float* w, float* gx
 
 // InstanceNorm2d(eps 1e-5, no affine) + activation backward.  gz, y, gy [N][C][H][W]; stats [N][C][2] fp64 (sum, sum of squares of y:
 // what cds_instnorm_act_f32 leaves); sums [N][C][2] fp64 scratch (zeroed here unless scratch_zeroed says the caller did).  act: CDS_ACT_LEAKY01 | CDS_ACT_TANH | CDS_ACT_NONE.
-extern "C" int cds_instnorm_bwd_f32(const float* gz, const float* y, const double* stats, double* sums, float* gy, int N, int C, int H,
-                                    int W, int act, int scratch_zeroed, void* stream) {
+template <typename TY>
+static int instnorm_bwd_entry(const float* gz, const TY* y, const b16* zs, const double* stats, double* sums, float* gy, int N, int C, int H,
+                              int W, int act, int scratch_zeroed, void* stream) {
   if (!gz || !y || !stats || !sums || !gy || N < 1 || C < 1 || H < 1 || W < 1) return CDS_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const int hw = H * W;
   if (!scratch_zeroed && hipMemsetAsync(sums, 0, sizeof(double) * 2 * N * C, st) != hipSuccess) return cds_launch_status();
   int bpc = cds_ceil_div(hw, 256 * 16);
   if (bpc > 64) bpc = 64;
-  hipLaunchKernelGGL(instnorm_bwd_reduce_kernel, dim3(N * C * bpc), dim3(256), 0, st, gz, y, stats, sums, hw, act, bpc);
+  hipLaunchKernelGGL(instnorm_bwd_reduce_kernel<TY>, dim3(N * C * bpc), dim3(256), 0, st, gz, y, stats, sums, hw, act, bpc, zs);
   int gx = cds_ceil_div(hw, 256 * 4);
   if (gx > 256) gx = 256;
-  hipLaunchKernelGGL(instnorm_bwd_apply_kernel, dim3(gx, N * C), dim3(256), 0, st, gz, y, stats, sums, gy, hw, act);
+  hipLaunchKernelGGL(instnorm_bwd_apply_kernel<TY>, dim3(gx, N * C), dim3(256), 0, st, gz, y, stats, sums, gy, hw, act, zs);
   return cds_launch_status();
+}
+
+extern "C" int cds_instnorm_bwd_f32(const float* gz, const float* y, const double* stats, double* sums, float* gy, int N, int C, int H,
+                                    int W, int act, int scratch_zeroed, void* stream) {
+  return instnorm_bwd_entry<float>(gz, y, nullptr, stats, sums, gy, N, C, H, W, act, scratch_zeroed, stream);
+}
+
+// The same with the pre-normalisation map y stored as raw bfloat16 (what cds_instnorm_act_b16_f32 left).  z16 (optional, LeakyReLU
+// only): the stored OUTPUT of the forward; its sign bit is the LeakyReLU decision the forward took (xhat rebuilt from the rounded y can
+// fall on the other side of zero: a gradient factor of 0.1 instead of 1 on ~0.3 % of the elements).
+extern "C" int cds_instnorm_bwd_yb16_f32(const float* gz, const unsigned short* y, const unsigned short* z16, const double* stats,
+                                         double* sums, float* gy, int N, int C, int H, int W, int act, int scratch_zeroed, void* stream) {
+  if (z16 && act != CDS_ACT_LEAKY01) return CDS_EINVAL;
+  return instnorm_bwd_entry<b16>(gz, y, z16, stats, sums, gy, N, C, H, W, act, scratch_zeroed, stream);
 }
 
 // ---- DynamicConv epilogue, training mode --------------------------------------------------------------------------------------
 // Statistics of the attention MLP's BatchNorm2d for G groups of N / G images.  branches [K][N][Cout+3][H][W], epipoles DEVICE [N][2],
 // w1 [4][K].  mom: fp64 scratch [G][K + K(K+1)/2] (overwritten).  Leaves mean / rstd [G][4] (batch statistics if use_batch, else the
 // running ones) and, if use_batch and running_mean != NULL, updates the running statistics group after group (momentum as given).
-extern "C" int cds_dynconv_bn_stats_f32(const float* branches, const float* epipoles, const float* w1, double* mom, float* mean,
-                                        float* rstd, float* running_mean, float* running_var, int N, int G, int K, int Cout, int H,
-                                        int W, float eps, float momentum, int use_batch, int scratch_zeroed, void* stream) {
+template <typename TB>
+static int bn_stats_entry(const TB* branches, const float* epipoles, const float* w1, double* mom, float* mean, float* rstd,
+                          float* running_mean, float* running_var, int N, int G, int K, int Cout, int H, int W, float eps, float momentum,
+                          int use_batch, int scratch_zeroed, void* stream) {
   if (!branches || !epipoles || !w1 || !mom || !mean || !rstd || N < 1 || G < 1 || (N % G) || Cout < 1 || H < 1 || W < 1 || (K != 2 && K != 3))
     return CDS_EINVAL;
   if (!use_batch && (!running_mean || !running_var)) return CDS_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  BlendArgs a{branches, epipoles, w1, nullptr, nullptr, nullptr, nullptr, nullptr, N, G, Cout, H, W, 1.f};
+  BlendArgsT<TB> a{branches, epipoles, w1, nullptr, nullptr, nullptr, nullptr, nullptr, N, G, Cout, H, W, 1.f};
   const int NM = K + K * (K + 1) / 2;
   if (use_batch) {
     if (!scratch_zeroed && hipMemsetAsync(mom, 0, sizeof(double) * G * NM, st) != hipSuccess) return cds_launch_status();
@@ -742,30 +787,63 @@ extern "C" int cds_dynconv_bn_stats_f32(const float* branches, const float* epip
   return cds_launch_status();
 }
 
+extern "C" int cds_dynconv_bn_stats_f32(const float* branches, const float* epipoles, const float* w1, double* mom, float* mean,
+                                        float* rstd, float* running_mean, float* running_var, int N, int G, int K, int Cout, int H,
+                                        int W, float eps, float momentum, int use_batch, int scratch_zeroed, void* stream) {
+  return bn_stats_entry<float>(branches, epipoles, w1, mom, mean, rstd, running_mean, running_var, N, G, K, Cout, H, W, eps, momentum,
+                               use_batch, scratch_zeroed, stream);
+}
+
+// The three DynamicConv epilogue entries with the branch tensor stored as raw bfloat16 (cds_f32_to_bf16 of the convolution responses).
+extern "C" int cds_dynconv_bn_stats_b16_f32(const unsigned short* branches, const float* epipoles, const float* w1, double* mom,
+                                            float* mean, float* rstd, float* running_mean, float* running_var, int N, int G, int K,
+                                            int Cout, int H, int W, float eps, float momentum, int use_batch, int scratch_zeroed,
+                                            void* stream) {
+  return bn_stats_entry<b16>(branches, epipoles, w1, mom, mean, rstd, running_mean, running_var, N, G, K, Cout, H, W, eps, momentum,
+                             use_batch, scratch_zeroed, stream);
+}
+
 // out [N][Cout][H][W], norm_curv [N][H][W] from the branches and the statistics of cds_dynconv_bn_stats_f32.
+template <typename TB>
+static int blend_train_entry(const TB* branches, const float* epipoles, const float* w1, const float* w2, const float* gamma,
+                             const float* beta, const float* mean, const float* rstd, float temperature, float* out, float* norm_curv,
+                             int N, int G, int K, int Cout, int H, int W, void* stream) {
+  if (!branches || !epipoles || !w1 || !w2 || !gamma || !beta || !mean || !rstd || !out || !norm_curv || N < 1 || G < 1 || (N % G) ||
+      Cout < 1 || H < 1 || W < 1 || !(temperature > 0.f))
+    return CDS_EINVAL;
+  BlendArgsT<TB> a{branches, epipoles, w1, w2, gamma, beta, mean, rstd, N, G, Cout, H, W, 1.0f / temperature};
+  return blend_dispatch_k(K, 1, a, out, norm_curv, nullptr, nullptr, nullptr, 0.0, 1, nullptr, nullptr, (hipStream_t)stream);
+}
+
 extern "C" int cds_dynconv_blend_train_f32(const float* branches, const float* epipoles, const float* w1, const float* w2,
                                            const float* gamma, const float* beta, const float* mean, const float* rstd,
                                            float temperature, float* out, float* norm_curv, int N, int G, int K, int Cout, int H, int W,
                                            void* stream) {
-  if (!branches || !epipoles || !w1 || !w2 || !gamma || !beta || !mean || !rstd || !out || !norm_curv || N < 1 || G < 1 || (N % G) ||
-      Cout < 1 || H < 1 || W < 1 || !(temperature > 0.f))
-    return CDS_EINVAL;
-  BlendArgs a{branches, epipoles, w1, w2, gamma, beta, mean, rstd, N, G, Cout, H, W, 1.0f / temperature};
-  return blend_dispatch_k(K, 1, a, out, norm_curv, nullptr, nullptr, nullptr, 0.0, 1, nullptr, nullptr, (hipStream_t)stream);
+  return blend_train_entry<float>(branches, epipoles, w1, w2, gamma, beta, mean, rstd, temperature, out, norm_curv, N, G, K, Cout, H, W,
+                                  stream);
+}
+
+extern "C" int cds_dynconv_blend_train_b16_f32(const unsigned short* branches, const float* epipoles, const float* w1, const float* w2,
+                                               const float* gamma, const float* beta, const float* mean, const float* rstd,
+                                               float temperature, float* out, float* norm_curv, int N, int G, int K, int Cout, int H,
+                                               int W, void* stream) {
+  return blend_train_entry<b16>(branches, epipoles, w1, w2, gamma, beta, mean, rstd, temperature, out, norm_curv, N, G, K, Cout, H, W,
+                                stream);
 }
 
 // Backward of cds_dynconv_blend_train_f32 (+ the BatchNorm, batch statistics if use_batch).  gy [N][Cout][H][W], gnc [N][H][W] or NULL.
 // Leaves gbr [K][N][Cout+3][H][W] (gradient of the branch tensor) and, in fp64, sums [G][8] scratch followed by dw2 [K][4], and
 // dw1 [4][K]; dgamma_j = sum_g sums[g][4 + j], dbeta_j = sum_g sums[g][j].  sums: G * 8 + K * 4 doubles, dw1: 4 K doubles.
-extern "C" int cds_dynconv_blend_bwd_f32(const float* branches, const float* epipoles, const float* w1, const float* w2,
-                                         const float* gamma, const float* beta, const float* mean, const float* rstd,
-                                         float temperature, const float* gy, const float* gnc, float* gbr, double* sums, double* dw1,
-                                         int N, int G, int K, int Cout, int H, int W, int use_batch, int scratch_zeroed, void* stream) {
+template <typename TB>
+static int blend_bwd_entry(const TB* branches, const float* epipoles, const float* w1, const float* w2, const float* gamma,
+                           const float* beta, const float* mean, const float* rstd, float temperature, const float* gy, const float* gnc,
+                           float* gbr, double* sums, double* dw1, int N, int G, int K, int Cout, int H, int W, int use_batch,
+                           int scratch_zeroed, void* stream) {
   if (!branches || !epipoles || !w1 || !w2 || !gamma || !beta || !mean || !rstd || !gy || !gbr || !sums || !dw1 || N < 1 || G < 1 ||
       (N % G) || Cout < 1 || H < 1 || W < 1 || !(temperature > 0.f))
     return CDS_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  BlendArgs a{branches, epipoles, w1, w2, gamma, beta, mean, rstd, N, G, Cout, H, W, 1.0f / temperature};
+  BlendArgsT<TB> a{branches, epipoles, w1, w2, gamma, beta, mean, rstd, N, G, Cout, H, W, 1.0f / temperature};
   if (!scratch_zeroed) {
     if (hipMemsetAsync(sums, 0, sizeof(double) * (G * 2 * HID + K * HID), st) != hipSuccess) return cds_launch_status();
     if (hipMemsetAsync(dw1, 0, sizeof(double) * HID * K, st) != hipSuccess) return cds_launch_status();
@@ -773,6 +851,23 @@ extern "C" int cds_dynconv_blend_bwd_f32(const float* branches, const float* epi
   const double count = (double)(N / G) * H * W;
   if (int e = blend_dispatch_k(K, 2, a, nullptr, nullptr, gy, gnc, sums, count, use_batch, nullptr, nullptr, st)) return e;
   return blend_dispatch_k(K, 3, a, nullptr, nullptr, gy, gnc, sums, count, use_batch, gbr, dw1, st);
+}
+
+extern "C" int cds_dynconv_blend_bwd_f32(const float* branches, const float* epipoles, const float* w1, const float* w2,
+                                         const float* gamma, const float* beta, const float* mean, const float* rstd,
+                                         float temperature, const float* gy, const float* gnc, float* gbr, double* sums, double* dw1,
+                                         int N, int G, int K, int Cout, int H, int W, int use_batch, int scratch_zeroed, void* stream) {
+  return blend_bwd_entry<float>(branches, epipoles, w1, w2, gamma, beta, mean, rstd, temperature, gy, gnc, gbr, sums, dw1, N, G, K, Cout,
+                                H, W, use_batch, scratch_zeroed, stream);
+}
+
+extern "C" int cds_dynconv_blend_bwd_b16_f32(const unsigned short* branches, const float* epipoles, const float* w1, const float* w2,
+                                             const float* gamma, const float* beta, const float* mean, const float* rstd,
+                                             float temperature, const float* gy, const float* gnc, float* gbr, double* sums,
+                                             double* dw1, int N, int G, int K, int Cout, int H, int W, int use_batch,
+                                             int scratch_zeroed, void* stream) {
+  return blend_bwd_entry<b16>(branches, epipoles, w1, w2, gamma, beta, mean, rstd, temperature, gy, gnc, gbr, sums, dw1, N, G, K, Cout, H,
+                              W, use_batch, scratch_zeroed, stream);
 }
 
 namespace {
@@ -825,5 +920,109 @@ extern "C" int cds_pack_conv3d_f32(const float* w, float* fwd, float* dgrad, int
   const int n = A * B * 27;
   hipLaunchKernelGGL(pack_conv3d_kernel, dim3(cds_ceil_div(n, 256) > 128 ? 128 : cds_ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, w,
                      fwd, dgrad, A, B, mode);
+  return cds_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// bf16 storage of the 2D activations: the forward-side kernels of the policy (the backward-side ones are the *_b16 / *_xb16 / *_yb16
+// entries above).  Rounding happens ONCE, where a tensor is stored.  Two forms: the default rounds only what is KEPT for the backward
+// (the forward pass continues on the unrounded fp32 transients: loss and depth maps are those of the fp32 step); `strict` also feeds the
+// forward with the stored values (statistics of y16, out32 = widened out16), so both passes see one and the same activation.
+// ---------------------------------------------------------------------------------------------------------------------------
+namespace {
+
+__global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restrict__ src, b16* __restrict__ dst, size_t n4, size_t n) {
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+    const float4 v = reinterpret_cast<const float4*>(src)[i];
+    const unsigned lo = (unsigned)f2b(v.x) | ((unsigned)f2b(v.y) << 16), hi = (unsigned)f2b(v.z) | ((unsigned)f2b(v.w) << 16);
+    reinterpret_cast<uint2*>(dst)[i] = make_uint2(lo, hi);
+  }
+  if (blockIdx.x == 0)
+    for (size_t i = 4 * n4 + threadIdx.x; i < n; i += 256) dst[i] = f2b(src[i]);
+}
+
+// Pass 1 of InstanceNorm on a bf16-stored map: y16 = bf16(y) is written, the fp64 (sum, sum of squares) are those of y (strict: of y16).
+__global__ __launch_bounds__(256) void instnorm_stats_store_b16_kernel(const float* __restrict__ y, b16* __restrict__ y16,
+                                                                       double* __restrict__ stats, int hw, int blocks_per_c, int strict) {
+  const int c = blockIdx.x / blocks_per_c, b = blockIdx.x % blocks_per_c;
+  const float* __restrict__ yc = y + (size_t)c * hw;
+  b16* __restrict__ oc = y16 + (size_t)c * hw;
+  double s = 0.0, q = 0.0;
+#pragma unroll 4
+  for (int i = b * 256 + threadIdx.x; i < hw; i += blocks_per_c * 256) {
+    const float yv = yc[i];
+    const b16 h = f2b(yv);
+    oc[i] = h;
+    const double v = (double)(strict ? __uint_as_float((unsigned)h << 16) : yv);
+    s += v;
+    q += v * v;
+  }
+  s = wave_sum_d(s);
+  q = wave_sum_d(q);
+  __shared__ double red[2][4];
+  if ((threadIdx.x & 63) == 0) {
+    red[0][threadIdx.x >> 6] = s;
+    red[1][threadIdx.x >> 6] = q;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(&stats[2 * c + 0], red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+    atomicAdd(&stats[2 * c + 1], red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+  }
+}
+
+// Pass 2: z = act(y * alpha + beta) (the expression of instnorm_apply_kernel; strict: of y16).  out16 != NULL: z is stored as bf16 and
+// out32 (the transient fp32 copy the next layer's forward kernel reads) receives z, or under strict the widened stored value;
+// out16 == NULL: out32 = z in fp32 (the tanh stage outputs, which leave the 2D stack for the cost volume).
+__global__ __launch_bounds__(256) void instnorm_apply_b16_kernel(const float* __restrict__ y, const b16* __restrict__ y16,
+                                                                 const double* __restrict__ stats, float* __restrict__ out32,
+                                                                 b16* __restrict__ out16, int hw, int act, int strict) {
+  const int c = blockIdx.y;
+  const double mean = stats[2 * c] / hw;
+  double var = stats[2 * c + 1] / hw - mean * mean;
+  var = var < 0.0 ? 0.0 : var;
+  const float al = (float)(1.0 / sqrt(var + 1e-5));
+  const float be = -(float)mean * al;
+  const size_t o = (size_t)c * hw;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < hw; i += gridDim.x * 256) {
+    float z = cds_apply_act((strict ? ldf(y16, o + i) : y[o + i]) * al + be, act);
+    if (out16) {
+      const b16 h = f2b(z);
+      out16[o + i] = h;
+      if (strict) z = __uint_as_float((unsigned)h << 16);
+    }
+    out32[o + i] = z;
+  }
+}
+
+}  // namespace
+
+// dst[i] = bfloat16(src[i]) (round to nearest even), n elements; src 16-byte aligned.
+extern "C" int cds_f32_to_bf16(const float* src, unsigned short* dst, long long n, void* stream) {
+  if (!src || !dst || n < 1) return CDS_EINVAL;
+  const size_t n4 = (size_t)n / 4;
+  size_t blocks = (n4 + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, dst, n4, (size_t)n);
+  return cds_launch_status();
+}
+
+// InstanceNorm2d (eps 1e-5, no affine) + activation with bf16 storage: y [N][C][H][W] fp32 (the transient convolution output) ->
+// y16 (its stored form, what cds_instnorm_bwd_yb16_f32 reads), stats [N][C][2] fp64, out32 / out16 as described at
+// instnorm_apply_b16_kernel (out16 may be NULL); strict as described above.
+extern "C" int cds_instnorm_act_b16_f32(const float* y, unsigned short* y16, float* out32, unsigned short* out16, double* stats, int N,
+                                        int C, int H, int W, int act, int strict, void* stream) {
+  if (!y || !y16 || !out32 || !stats || N < 1 || C < 1 || H < 1 || W < 1) return CDS_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int hw = H * W;
+  if (hipMemsetAsync(stats, 0, sizeof(double) * 2 * N * C, st) != hipSuccess) return cds_launch_status();
+  int bpc = cds_ceil_div(hw, 256 * 16);
+  if (bpc < 1) bpc = 1;
+  hipLaunchKernelGGL(instnorm_stats_store_b16_kernel, dim3(N * C * bpc), dim3(256), 0, st, y, y16, stats, hw, bpc, strict);
+  int gx = cds_ceil_div(hw, 256 * 4);
+  if (gx > 256) gx = 256;
+  hipLaunchKernelGGL(instnorm_apply_b16_kernel, dim3(gx, N * C), dim3(256), 0, st, y, y16, stats, out32, out16, hw, act, strict);
   return cds_launch_status();
 }

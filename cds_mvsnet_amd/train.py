@@ -10,9 +10,13 @@
   statistics stay per replica like ``nn.DataParallel``.
 * :func:`train_step` — forward, ``final_loss``, backward, gradient exchange, optimizer step (trainer.py:69-82), all fp32.
 
-Precision: the reference trains in fp32 and has no AMP.  BASELINE config 5 is labelled bf16; every training kernel here is fp32 (the
-rounds-2/3 experiment, ``torch.autocast(bf16)`` around fp32 kernels, only added casts and was slower, so it was removed): config 5 runs
-fp32.  A bf16 policy would mean bf16 STORAGE of the 2D activations with fp32 accumulation inside the kernels; it is not built.
+Precision: the reference trains in fp32 and has no AMP; fp32 is the default here.  BASELINE config 5 is labelled bf16:
+``train_step(..., activation_storage="bf16")`` (or ``CDS_TRAIN_ACT_STORAGE=bf16``) selects bf16 STORAGE / fp32 ACCUMULATE for the
+FeatureNet activations - the layer inputs, the DynamicConv branch responses and the pre-normalisation maps are kept as bfloat16 from
+the forward to the backward pass, the kernels widen on load and accumulate in fp32 / fp64 (``train2d_ops.activation_storage``,
+csrc/train2d.hip).  Weights, gradients, statistics, the cost-volume path (K1 / K3 / CostRegNet / soft-argmin) and the loss stay
+fp32.  Acceptance against the reference's own step G7 (tests/test_train_bf16_gpu.py): loss within 1e-2 relative, cosine >= 0.99 on the
+nine full gradient tensors.  (The rounds-2/3 experiment, ``torch.autocast(bf16)`` around fp32 kernels, only added casts and was removed.)
 """
 from __future__ import annotations
 
@@ -137,15 +141,19 @@ class GradAllReducer:
 
 
 def train_step(model: torch.nn.Module, optimizer: torch.optim.Optimizer, sample: Dict[str, object], temperature: float,
-               dlossw: Sequence[float] = (0.5, 1.0, 2.0), reducer: Optional[GradAllReducer] = None) -> Tuple[float, float]:
+               dlossw: Sequence[float] = (0.5, 1.0, 2.0), reducer: Optional[GradAllReducer] = None,
+               activation_storage: Optional[str] = None) -> Tuple[float, float]:
     """One optimisation step on ``sample`` = {imgs, proj_matrices, depth_values, depth: {stageK}, mask: {stageK}}
-    (already on the model's device).  Returns (loss, depth_loss) as Python floats."""
+    (already on the model's device).  Returns (loss, depth_loss) as Python floats.  activation_storage: None = the process default
+    (fp32 unless CDS_TRAIN_ACT_STORAGE=bf16), "f32" or "bf16" (module docstring)."""
     if not model.training:                                   # walking ~1 400 modules costs 1 ms of a CPU-bound 28 ms step
         model.train()
     optimizer.zero_grad(set_to_none=True)
     dv = sample["depth_values"]
     interval = dv[:, 1] - dv[:, 0]
-    outputs = model(sample["imgs"], sample["proj_matrices"], dv, gt_depths=sample["depth"], temperature=temperature)
+    from . import train2d_ops
+    with (train2d_ops.activation_storage(activation_storage) if activation_storage is not None else contextlib.nullcontext()):
+        outputs = model(sample["imgs"], sample["proj_matrices"], dv, gt_depths=sample["depth"], temperature=temperature)
     outputs = _to_float(outputs)
     loss, depth_loss = final_loss(outputs, sample["depth"], sample["mask"], dlossw=list(dlossw), depth_interval=interval)
     # weight gradients on a side stream, joined before anything reads .grad (CDS_TRAIN_SIDE_STREAM=0: everything on one stream)

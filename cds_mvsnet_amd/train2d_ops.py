@@ -21,6 +21,99 @@ from ._lib import ACT_ACCUM, ACT_LEAKY01, ACT_NONE, ACT_TANH, check
 
 Tensor = torch.Tensor
 
+# ---- activation storage policy ---------------------------------------------------------------------------------------------------
+# "f32" (default: what the reference trains in, trainer/trainer.py:69-82) or "bf16" = bf16 STORAGE / fp32 ACCUMULATE for the FeatureNet
+# activations (BASELINE config 5's label): every tensor of the 2D stack that lives from the forward to the backward pass - the layer
+# inputs (InstanceNorm + LeakyReLU outputs), the DynamicConv branch responses [K,N,Cout+3,H,W] and the pre-normalisation maps - is a
+# bfloat16 tensor, rounded once where it is produced; the backward kernels widen on load and accumulate in fp32 / fp64 as on the fp32
+# path (csrc/train2d.hip: cds_instnorm_act_b16_f32, cds_f32_to_bf16, the *_b16 / *_xb16 / *_yb16 entries).  Between a producer and its
+# consumer in the FORWARD pass the activation travels as a transient fp32 tensor (freed as soon as its consumers ran):
+#   "bf16"          the transient is the unrounded value: the forward pass - loss, depth maps - is that of the fp32 step, the gradients
+#                   differ by one bf16 rounding of each stored operand (the shipped policy; acceptance tests/test_train_bf16_gpu.py);
+#   "bf16-forward"  the transient is the widened STORED value, so both passes see one and the same activation.  Kept as the stricter
+#                   form: through nine DynamicConvs (InstanceNorm, LeakyReLU, softmax(. / T)) and a cascade whose hypothesis ranges
+#                   switch discretely, 2^-9 of rounding per activation moves single gradient tensors of the randomly initialised G7
+#                   step to cosines of 0.76-0.98 against fp32 (loss within 2e-3) - measured, and the reason it is not the default.
+# Gradients, weights, statistics, the stage outputs (tanh features -> cost volume), the visibility CNN and Refinement (a few maps of
+# 1-16 channels) stay fp32.
+_STORAGE = {"dtype": torch.float32, "strict": False}
+
+
+def set_activation_storage(kind) -> None:
+    if kind in ("bf16", torch.bfloat16):
+        _STORAGE["dtype"], _STORAGE["strict"] = torch.bfloat16, False
+    elif kind == "bf16-forward":
+        _STORAGE["dtype"], _STORAGE["strict"] = torch.bfloat16, True
+    elif kind in ("f32", "fp32", torch.float32):
+        _STORAGE["dtype"], _STORAGE["strict"] = torch.float32, False
+    else:
+        raise ValueError(f"activation storage {kind!r}: expected 'f32', 'bf16' or 'bf16-forward'")
+
+
+set_activation_storage(__import__("os").environ.get("CDS_TRAIN_ACT_STORAGE", "f32").lower())
+
+
+def activation_storage_dtype() -> torch.dtype:
+    return _STORAGE["dtype"]
+
+
+class activation_storage:
+    """``with activation_storage("bf16"): loss = model(...); loss.backward()`` - the policy applies to the forward passes run inside."""
+
+    def __init__(self, kind):
+        self.kind = kind
+
+    def __enter__(self):
+        self.prev = dict(_STORAGE)
+        set_activation_storage(self.kind)
+        return self
+
+    def __exit__(self, *exc):
+        _STORAGE.update(self.prev)
+        return False
+
+
+def stored(x: Tensor) -> Optional[Tensor]:
+    """The bf16-stored twin of an activation produced under the bf16 policy (None on the fp32 path)."""
+    return getattr(x, "_cds_b16", None)
+
+
+def with_store(x: Tensor, x16: Optional[Tensor]) -> Tensor:
+    if x16 is not None:
+        x._cds_b16 = x16
+    return x
+
+
+def cat_stored(parts: Sequence[Tensor]) -> Tensor:
+    """torch.cat(parts, dim=1) that keeps the stored twins together (the FPN laterals concatenate two stored activations)."""
+    out = torch.cat(tuple(parts), dim=1)
+    tw = [stored(t) for t in parts]
+    if any(t is not None for t in tw):       # a part without a twin (a tanh stage output, kept fp32 for the cost volume) is rounded here
+        out._cds_b16 = torch.cat([t if t is not None else to_bf16(p.detach()) for t, p in zip(tw, parts)], dim=1)
+    return out
+
+
+def upsample2_stored(x: Tensor) -> Tensor:
+    out = F.interpolate(x, scale_factor=2, mode="nearest")
+    if stored(x) is not None:
+        out._cds_b16 = F.interpolate(stored(x), scale_factor=2, mode="nearest")
+    return out
+
+
+def _p16(t: Tensor) -> int:
+    if not (t.is_cuda and t.dtype == torch.bfloat16 and t.is_contiguous()):
+        raise ValueError("expected a contiguous bfloat16 device tensor")
+    return t.data_ptr()
+
+
+def to_bf16(x: Tensor) -> Tensor:
+    """bfloat16(x) (round to nearest even) on the HIP conversion kernel."""
+    x = x.contiguous()
+    out = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    check(_lib.load().cds_f32_to_bf16(_p(x), out.data_ptr(), x.numel(), ops._stream(x)), "cds_f32_to_bf16")
+    return out
+
+
 _KS_DIRECT = (1, 3, 5, 7, 11)
 SBF_MIN_PIXELS = 4 << 20      # DynamicConv forward: images x pixels from which the split-bf16 matrix-core branch kernel pays for its packing
 
@@ -72,13 +165,15 @@ def conv2d_wgrad(g: Tensor, x: Tensor, k: int, stride: int, pad: int) -> Tensor:
     dw = _scratch.zeros((Co, Cin, k, k), torch.float32, g.device)
     _scratch.audit_note(dw)
     side = _scratch.side_stream(g.device)
+    if x.dtype == torch.bfloat16:                                # the layer input in its stored form (bf16 policy)
+        fn, px, what = _lib.load().cds_conv2d_wgrad_xb16_f32, _p16(x), "cds_conv2d_wgrad_xb16_f32"
+    else:
+        fn, px, what = _lib.load().cds_conv2d_wgrad_f32, _p(x), "cds_conv2d_wgrad_f32"
     if side is None:
-        check(_lib.load().cds_conv2d_wgrad_f32(_p(g), _p(x), dw.data_ptr(), N, Co, Cin, Ho, Wo, H, W, k, stride, pad, ops._stream(g)),
-              "cds_conv2d_wgrad_f32")
+        check(fn(_p(g), px, dw.data_ptr(), N, Co, Cin, Ho, Wo, H, W, k, stride, pad, ops._stream(g)), what)
         return dw
     with torch.cuda.stream(side):                                # a leaf of the backward pass: overlaps with the data-gradient chain
-        check(_lib.load().cds_conv2d_wgrad_f32(_p(g), _p(x), dw.data_ptr(), N, Co, Cin, Ho, Wo, H, W, k, stride, pad, side.cuda_stream),
-              "cds_conv2d_wgrad_f32")
+        check(fn(_p(g), px, dw.data_ptr(), N, Co, Cin, Ho, Wo, H, W, k, stride, pad, side.cuda_stream), what)
     g.record_stream(side)
     x.record_stream(side)
     return dw
@@ -116,12 +211,12 @@ class Conv2d(torch.autograd.Function):
 
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
-    def forward(ctx, x, weight, bias, stride: int, pad: int):
+    def forward(ctx, x, weight, bias, stride: int, pad: int, x16=None):
         x = x.contiguous()
         k = weight.shape[-1]
         if k not in _KS_DIRECT or (stride == 2 and (k != 3 or pad != 1)) or stride not in (1, 2):
             raise ValueError(f"train2d_ops.Conv2d: unsupported kernel {k} / stride {stride} / pad {pad}")
-        ctx.save_for_backward(x, weight)
+        ctx.save_for_backward(x16 if x16 is not None else x, weight)    # bf16 policy: the stored twin is what lives until the backward
         ctx.stride, ctx.pad, ctx.has_bias = stride, pad, bias is not None
         if _c16(weight, stride, pad, x.shape[-1]):               # 16 -> 16, 3x3: the fp32 matrix-core kernel of the visibility CNN
             return ops.conv2d_k3_c16(x, weight.detach().permute(2, 3, 0, 1).reshape(9, 16, 16).contiguous(),
@@ -151,7 +246,7 @@ class Conv2d(torch.autograd.Function):
             dw = conv2d_wgrad(dy, x, k, ctx.stride, ctx.pad)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = dy.sum(dim=(0, 2, 3))
-        return dx, dw, db, None, None
+        return dx, dw, db, None, None, None
 
 
 class InstNormAct(torch.autograd.Function):
@@ -183,6 +278,48 @@ class InstNormAct(torch.autograd.Function):
         return gy, None
 
 
+class InstNormActB16(torch.autograd.Function):
+    """InstNormAct under the bf16 storage policy: y (the transient fp32 convolution output) -> (z32, z16).  y16 = bfloat16(y) is what is
+    kept for the backward; z16 = bfloat16(z) is the stored activation and z32 the transient for the next forward kernel (z itself, or
+    under strict the widened z16 with the statistics taken from y16).  act = tanh (the stage outputs): z16 is empty, z32 unrounded."""
+
+    @staticmethod
+    def forward(ctx, y, act: int, strict: bool):
+        y = y.contiguous()
+        N, C, H, W = y.shape
+        y16 = torch.empty(y.shape, dtype=torch.bfloat16, device=y.device)
+        z32 = torch.empty_like(y)
+        keep = act != ACT_TANH
+        z16 = torch.empty(y.shape if keep else (0,), dtype=torch.bfloat16, device=y.device)
+        stats = torch.empty((N, C, 2), dtype=torch.float64, device=y.device)
+        check(_lib.load().cds_instnorm_act_b16_f32(_p(y), y16.data_ptr(), z32.data_ptr(), z16.data_ptr() if keep else None,
+                                                   stats.data_ptr(), N, C, H, W, act, 1 if strict else 0, ops._stream(y)),
+              "cds_instnorm_act_b16_f32")
+        ctx.save_for_backward(y16, stats, z16)                    # z16: the tensor the consumer keeps anyway; here for its sign bits
+        ctx.act = act
+        ctx.mark_non_differentiable(z16)
+        return z32, z16
+
+    @staticmethod
+    def backward(ctx, gz, _g16):
+        y16, stats, z16 = ctx.saved_tensors
+        gz = gz.contiguous().float()
+        N, C, H, W = y16.shape
+        gy = torch.empty(y16.shape, dtype=torch.float32, device=y16.device)
+        sums = _scratch.zeros((N, C, 2), torch.float64, y16.device)
+        check(_lib.load().cds_instnorm_bwd_yb16_f32(_p(gz), _p16(y16), _p16(z16) if z16.numel() else None, _p64(stats), _p64(sums), gy.data_ptr(), N, C, H, W, ctx.act, 1,
+                                                    ops._stream(gz)), "cds_instnorm_bwd_yb16_f32")
+        return gy, None, None
+
+
+def instnorm_act(y: Tensor, act: int) -> Tensor:
+    """act(InstanceNorm2d(y)) in the current storage policy; under "bf16" the result carries its stored twin (``stored(out)``)."""
+    if _STORAGE["dtype"] is torch.bfloat16:
+        z32, z16 = InstNormActB16.apply(y, act, _STORAGE["strict"])
+        return with_store(z32, z16 if z16.numel() else None)
+    return InstNormAct.apply(y, act)
+
+
 class _DynConvFn(torch.autograd.Function):
     """One DynamicConv (dynamic_conv.py:97-122): (x, epipoles) -> (y [N,Cout,H,W], norm_curv [N,1,H,W]).
     Tensor arguments after the fixed ones: K convolution weights, K attention-convolution weights, K biases (or none), then
@@ -190,7 +327,7 @@ class _DynConvFn(torch.autograd.Function):
 
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
-    def forward(ctx, x, epi, T: float, groups: int, bn, ksizes: Tuple[int, ...], has_bias: bool, *params):
+    def forward(ctx, x, epi, T: float, groups: int, bn, ksizes: Tuple[int, ...], has_bias: bool, x16, *params):
         K = len(ksizes)
         x = x.contiguous()
         N, Cin, H, W = x.shape
@@ -228,7 +365,15 @@ class _DynConvFn(torch.autograd.Function):
         mom = _scratch.zeros((G, K + K * (K + 1) // 2), torch.float64, dev)
         track = use_batch and bn.training and bn.track_running_stats
         momentum = bn.momentum if bn.momentum is not None else 0.1
-        check(lib.cds_dynconv_bn_stats_f32(_p(branches), _p(epi), _p(w1m), mom.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+        keep16 = _STORAGE["dtype"] is torch.bfloat16             # the branch responses are STORED as bf16 ...
+        b16 = keep16 and _STORAGE["strict"]                       # ... and (strict) the epilogue reads the stored form
+        if b16:
+            br32, branches = branches, to_bf16(branches)
+            del br32
+        f_stats = lib.cds_dynconv_bn_stats_b16_f32 if b16 else lib.cds_dynconv_bn_stats_f32
+        f_blend = lib.cds_dynconv_blend_train_b16_f32 if b16 else lib.cds_dynconv_blend_train_f32
+        pbr = _p16(branches) if b16 else _p(branches)
+        check(f_stats(pbr, _p(epi), _p(w1m), mom.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
                                            bn.running_mean.data_ptr() if (track or not use_batch) else None,
                                            bn.running_var.data_ptr() if (track or not use_batch) else None,
                                            N, G, K, cout, H, W, float(bn.eps), float(momentum), 1 if use_batch else 0, 1, st),
@@ -238,9 +383,11 @@ class _DynConvFn(torch.autograd.Function):
         y = torch.empty((N, cout, H, W), dtype=torch.float32, device=dev)
         nc = torch.empty((N, 1, H, W), dtype=torch.float32, device=dev)
         gm, bt = gamma.detach().contiguous(), beta.detach().contiguous()
-        check(lib.cds_dynconv_blend_train_f32(_p(branches), _p(epi), _p(w1m), _p(w2m), _p(gm), _p(bt), _p(mean), _p(rstd), float(T),
-                                              y.data_ptr(), nc.data_ptr(), N, G, K, cout, H, W, st), "cds_dynconv_blend_train_f32")
-        ctx.save_for_backward(x, epi, branches, mean, rstd, *params)
+        check(f_blend(pbr, _p(epi), _p(w1m), _p(w2m), _p(gm), _p(bt), _p(mean), _p(rstd), float(T),
+                      y.data_ptr(), nc.data_ptr(), N, G, K, cout, H, W, st), "cds_dynconv_blend_train_f32")
+        if keep16 and not b16:
+            branches = to_bf16(branches)
+        ctx.save_for_backward(x16 if x16 is not None else x, epi, branches, mean, rstd, *params)
         ctx.dgrad_packs = [pk[1] for pk in packs]
         ctx.cfg = (float(T), G, tuple(ksizes), has_bias, use_batch)
         return y, nc
@@ -263,12 +410,14 @@ class _DynConvFn(torch.autograd.Function):
         gnc = gnc.contiguous().float() if gnc is not None else None
         w1m = w1.detach().reshape(4, K).contiguous()
         w2m = w2.detach().reshape(K, 4).contiguous()
-        gbr = torch.empty_like(branches)
+        gbr = torch.empty(branches.shape, dtype=torch.float32, device=dev)
         sums = _scratch.zeros((G * 8 + K * 4,), torch.float64, dev)
         dw1 = _scratch.zeros((4, K), torch.float64, dev)
-        check(lib.cds_dynconv_blend_bwd_f32(_p(branches), _p(epi), _p(w1m), _p(w2m), _p(gamma.detach().contiguous()),
-                                            _p(beta.detach().contiguous()), _p(mean), _p(rstd), T, _p(gy), _p(gnc), gbr.data_ptr(),
-                                            sums.data_ptr(), dw1.data_ptr(), N, G, K, cout, H, W, 1 if use_batch else 0, 1, st),
+        b16 = branches.dtype == torch.bfloat16
+        f_bwd = lib.cds_dynconv_blend_bwd_b16_f32 if b16 else lib.cds_dynconv_blend_bwd_f32
+        check(f_bwd(_p16(branches) if b16 else _p(branches), _p(epi), _p(w1m), _p(w2m), _p(gamma.detach().contiguous()),
+                    _p(beta.detach().contiguous()), _p(mean), _p(rstd), T, _p(gy), _p(gnc), gbr.data_ptr(),
+                    sums.data_ptr(), dw1.data_ptr(), N, G, K, cout, H, W, 1 if use_batch else 0, 1, st),
               "cds_dynconv_blend_bwd_f32")
         small = torch.empty((8 + 8 * K,), dtype=torch.float32, device=dev)
         check(lib.cds_dynconv_bwd_finish_f32(_p64(sums), _p64(dw1), G, K, small.data_ptr(), st), "cds_dynconv_bwd_finish_f32")
@@ -282,14 +431,14 @@ class _DynConvFn(torch.autograd.Function):
         for i, k in enumerate(ksizes):
             if ctx.needs_input_grad[0]:
                 if dx is None:
-                    dx = torch.empty_like(x)
+                    dx = torch.empty(x.shape, dtype=torch.float32, device=dev)
                 ops.conv2d(gbr[i], ctx.dgrad_packs[i], None, Cin, k, 1, (k - 1) // 2, act=ACT_NONE if i == 0 else ACT_ACCUM, out=dx)
             dw = conv2d_wgrad(gbr[i], x, k, 1, (k - 1) // 2)
             g_convs.append(dw[:cout])
             g_atts.append(dw[cout:])
             if has_bias:
                 g_bias.append(gbr[i][:, :cout].sum(dim=(0, 2, 3)))
-        return (dx, None, None, None, None, None, None, *g_convs, *g_atts, *g_bias, g_w1, g_gamma, g_beta, g_w2)
+        return (dx, None, None, None, None, None, None, None, *g_convs, *g_atts, *g_bias, g_w1, g_gamma, g_beta, g_w2)
 
 
 def dynamic_conv(dc, x: Tensor, epi: Tensor, T: float, groups: int = 1) -> Tuple[Tensor, Tensor]:
@@ -301,13 +450,13 @@ def dynamic_conv(dc, x: Tensor, epi: Tensor, T: float, groups: int = 1) -> Tuple
     if has_bias:
         params += [c.bias for c in dc.convs]
     params += [dc.att_weights[0].weight, dc.att_weights[1].weight, dc.att_weights[1].bias, dc.att_weights[3].weight]
-    return _DynConvFn.apply(x, epi, float(T), int(groups), dc.att_weights[1], tuple(dc.size_kernels), has_bias, *params)
+    return _DynConvFn.apply(x, epi, float(T), int(groups), dc.att_weights[1], tuple(dc.size_kernels), has_bias, stored(x), *params)
 
 
 def conv_in_act(conv, x: Tensor, act: int = ACT_LEAKY01) -> Tensor:
     """Plain ConvUnit (module.py:28-71): Conv2d (no bias) -> InstanceNorm2d -> LeakyReLU(0.1)."""
-    y = Conv2d.apply(x, conv.weight, conv.bias, conv.stride[0], conv.padding[0])
-    return InstNormAct.apply(y, act)
+    y = Conv2d.apply(x, conv.weight, conv.bias, conv.stride[0], conv.padding[0], stored(x))
+    return instnorm_act(y, act)
 
 
 class CurvatureStats(torch.autograd.Function):

@@ -47,14 +47,21 @@ def _in_act(y: Tensor, tanh: bool = False) -> Tensor:
     """InstanceNorm2d + LeakyReLU(0.1) (module.py:66-69) or + tanh (module.py:223)."""
     _need_hip(y)
     from . import train2d_ops
-    return train2d_ops.InstNormAct.apply(y, ops.ACT_TANH if tanh else ops.ACT_LEAKY01)
+    return train2d_ops.instnorm_act(y, ops.ACT_TANH if tanh else ops.ACT_LEAKY01)
 
 
 def _conv(conv, x: Tensor) -> Tensor:
     """A plain nn.Conv2d holder (3x3 stride 1 | 2, 1x1) on the HIP training kernels."""
     _need_hip(x)
     from . import train2d_ops
-    return train2d_ops.Conv2d.apply(x, conv.weight, conv.bias, conv.stride[0], conv.padding[0])
+    return train2d_ops.Conv2d.apply(x, conv.weight, conv.bias, conv.stride[0], conv.padding[0], train2d_ops.stored(x))
+
+
+def _cat_up(coarse: Tensor, skip: Tensor) -> Tensor:
+    """cat(nearest2x(coarse), skip) of an FPN lateral (module.py:253-254,260-261); under the bf16 storage policy the stored twins
+    (train2d_ops.stored) are concatenated alongside, so the lateral's weight gradient reads bf16."""
+    from . import train2d_ops
+    return train2d_ops.cat_stored((train2d_ops.upsample2_stored(coarse), skip))
 
 
 def _unit(unit, x: Tensor, epi: Optional[Tensor], T: float, groups: int = 1):
@@ -87,11 +94,11 @@ def feature_net(net, x: Tensor, epi: Tensor, T: float, groups: int = 1) -> Dict[
     out = {}
     o1, n22 = _dyn(net.out1, c21, e2, T, groups)
     out["stage1"] = (_in_act(o1, tanh=True), *_curv(n20, n21, n22))
-    t = _unit(net.inner1, torch.cat((F.interpolate(c21, scale_factor=2, mode="nearest"), c11), dim=1), None, T)
+    t = _unit(net.inner1, _cat_up(c21, c11), None, T)
     o2, n12 = _dyn(net.out2, t, e1, T, groups)
     o2 = _in_act(o2, tanh=True)
     out["stage2"] = (o2, *_curv(n10, n11, n12))
-    t = _unit(net.inner2, torch.cat((F.interpolate(o2, scale_factor=2, mode="nearest"), c01), dim=1), None, T)
+    t = _unit(net.inner2, _cat_up(o2, c01), None, T)
     o3, n02 = _dyn(net.out3, t, e0, T, groups)
     out["stage3"] = (_in_act(o3, tanh=True), *_curv(n00, n01, n02))
     return out

@@ -542,6 +542,35 @@ int cds_dynconv_blend_bwd_f32(const float* branches, const float* epipoles, cons
                               const float* beta, const float* mean, const float* rstd, float temperature, const float* gy,
                               const float* gnc, float* gbr, double* sums, double* dw1, int N, int G, int K, int Cout, int H, int W,
                               int use_batch, int scratch_zeroed, void* stream);
+/* bf16 STORAGE of the 2D activations with fp32 accumulation (BASELINE config 5 is labelled bf16; the reference itself trains in fp32,
+ * trainer/trainer.py:69-82, so this is an opt-in policy of the training step, train2d_ops.activation_storage("bf16")).  Tensors that
+ * live from the forward to the backward pass - layer inputs, DynamicConv branch responses, pre-normalisation maps - are raw bfloat16
+ * (unsigned short, round to nearest even); every kernel widens on load and accumulates as its fp32 twin does.
+ *   cds_f32_to_bf16:             dst = bfloat16(src), n elements.
+ *   cds_instnorm_act_b16_f32:    InstanceNorm2d + activation of cds_instnorm_act_f32 that also STORES: y16 = bfloat16(y) (kept for the
+ *                                backward), z = act((y - mean) rstd) as out32 (the transient the next layer's forward kernel reads)
+ *                                and out16 = bfloat16(z) (kept); out16 == NULL: no stored output.  strict != 0: the forward continues on
+ *                                the stored values too (statistics of y16, out32 = widened out16).
+ *   *_xb16 / *_yb16 / *_b16:     the fp32 entry of the same name with that operand read from its bf16-stored form.
+ *                                cds_instnorm_bwd_yb16_f32 also takes the stored LeakyReLU output z16 (or NULL): its sign bit is the
+ *                                gate the forward took. */
+int cds_f32_to_bf16(const float* src, unsigned short* dst, long long n, void* stream);
+int cds_instnorm_act_b16_f32(const float* y, unsigned short* y16, float* out32, unsigned short* out16, double* stats, int N, int C,
+                             int H, int W, int act, int strict, void* stream);
+int cds_conv2d_wgrad_xb16_f32(const float* g, const unsigned short* x, float* dw, int N, int Co, int Cin, int Ho, int Wo, int H, int W,
+                              int k, int stride, int pad, void* stream);
+int cds_instnorm_bwd_yb16_f32(const float* gz, const unsigned short* y, const unsigned short* z16, const double* stats, double* sums,
+                              float* gy, int N, int C, int H, int W, int act, int scratch_zeroed, void* stream);
+int cds_dynconv_bn_stats_b16_f32(const unsigned short* branches, const float* epipoles, const float* w1, double* mom, float* mean,
+                                 float* rstd, float* running_mean, float* running_var, int N, int G, int K, int Cout, int H, int W,
+                                 float eps, float momentum, int use_batch, int scratch_zeroed, void* stream);
+int cds_dynconv_blend_train_b16_f32(const unsigned short* branches, const float* epipoles, const float* w1, const float* w2,
+                                    const float* gamma, const float* beta, const float* mean, const float* rstd, float temperature,
+                                    float* out, float* norm_curv, int N, int G, int K, int Cout, int H, int W, void* stream);
+int cds_dynconv_blend_bwd_b16_f32(const unsigned short* branches, const float* epipoles, const float* w1, const float* w2,
+                                  const float* gamma, const float* beta, const float* mean, const float* rstd, float temperature,
+                                  const float* gy, const float* gnc, float* gbr, double* sums, double* dw1, int N, int G, int K,
+                                  int Cout, int H, int W, int use_batch, int scratch_zeroed, void* stream);
 /* The weight layouts of cds_conv2d_f32 in one launch: fwd [Cin][k k][CoP] (forward) and / or dgrad [Ca+Cb][k k][CiP] (stride-1 data
  * gradient: taps flipped, channels swapped) from wa [Ca][Cin][k][k] and, optionally, wb [Cb][Cin][k][k] stacked behind it. */
 int cds_pack_conv2d_f32(const float* wa, const float* wb, float* fwd, float* dgrad, int Ca, int Cb, int Cin, int k, void* stream);

@@ -18,6 +18,15 @@ import torch.nn.functional as F
 
 Tensor = torch.Tensor
 
+# Emulation of the product's bf16-storage policy (train2d_ops.activation_storage("bf16")) with torch ops: the tensors the policy stores
+# as bfloat16 are rounded where they are produced, with a straight-through gradient (the kernels differentiate the widened values).
+BF16_STORAGE = False
+
+
+def _rb(x: Tensor) -> Tensor:
+    return x + (x.float().bfloat16().to(x.dtype) - x).detach() if BF16_STORAGE else x
+
+
 
 def att_weights_grouped(seq, curvs: Tensor, groups: int) -> Tensor:
     """``DynamicConv.att_weights`` (1x1 conv -> BatchNorm2d -> ReLU -> 1x1 conv, dynamic_conv.py:88-91) on a batch that
@@ -59,8 +68,8 @@ def dynamic_conv(dc, x: Tensor, epi: Tensor, T: float, groups: int = 1) -> Tuple
     basis = torch.cat((u ** 2, 2 * u * v, v ** 2), dim=1)
     curvs, res = [], []
     for att, conv in zip(dc.att_convs, dc.convs):
-        curvs.append((att(x) * basis).sum(dim=1, keepdim=True))
-        res.append(conv(x).unsqueeze(1))
+        curvs.append((_rb(att(x)) * basis).sum(dim=1, keepdim=True))
+        res.append(_rb(conv(x)).unsqueeze(1))
     curvs = torch.cat(curvs, dim=1)
     aw = dc.att_weights(curvs) if (groups == 1 or not dc.att_weights[1].training) else att_weights_grouped(dc.att_weights, curvs, groups)
     wts = F.softmax(aw / T, dim=1)
@@ -69,7 +78,8 @@ def dynamic_conv(dc, x: Tensor, epi: Tensor, T: float, groups: int = 1) -> Tuple
 
 def in_act(y: Tensor, tanh: bool = False) -> Tensor:
     """InstanceNorm2d + LeakyReLU(0.1) (module.py:66-69) or + tanh (module.py:223)."""
-    return torch.tanh(F.instance_norm(y)) if tanh else F.leaky_relu(F.instance_norm(y), 0.1)
+    y = _rb(y)
+    return torch.tanh(F.instance_norm(y)) if tanh else _rb(F.leaky_relu(F.instance_norm(y), 0.1))
 
 
 def conv(conv_mod, x: Tensor) -> Tensor:
