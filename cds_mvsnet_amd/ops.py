@@ -46,6 +46,10 @@ class prof:
         return False
 
 
+# the current device index without torch.cuda.current_device()'s lazy-init bookkeeping (~1 000 calls per training step)
+_current_device = getattr(torch._C, "_cuda_getDevice", None) or torch.cuda.current_device
+
+
 def _dev(t: Tensor, name: str) -> int:
     if not isinstance(t, torch.Tensor):
         raise TypeError(f"{name}: expected a tensor")
@@ -55,7 +59,7 @@ def _dev(t: Tensor, name: str) -> int:
         raise TypeError(f"{name}: expected float32, got {t.dtype}")
     if not t.is_contiguous():
         raise ValueError(f"{name}: tensor must be contiguous")
-    if t.device.index != torch.cuda.current_device():
+    if t.device.index != _current_device():
         raise RuntimeError(f"{name}: tensor on {t.device} but the current device is cuda:{torch.cuda.current_device()} "
                            "(the launch goes to the current device; use `with torch.cuda.device(t.device):`)")
     return t.data_ptr()

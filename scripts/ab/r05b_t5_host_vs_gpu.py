@@ -34,3 +34,16 @@ for _ in range(N):
     for k, v in (("fwd", t1 - t0), ("loss", t2 - t1), ("bwd", t3 - t2), ("opt", t4 - t3), ("total", t5 - t0)):
         acc[k] += v * 1e3 / N
 print("host enqueue ms per step:", {k: round(v, 2) for k, v in acc.items()}, "| host sum", round(sum(v for k, v in acc.items() if k != "total"), 2))
+
+if os.environ.get("T5_CPROFILE"):
+    import cProfile, pstats
+    pr = cProfile.Profile()
+    torch.cuda.synchronize()
+    pr.enable()
+    for _ in range(4):
+        T.train_step(model, opt, sample, temperature=0.1)
+    torch.cuda.synchronize()
+    pr.disable()
+    st = pstats.Stats(pr)
+    st.sort_stats("tottime").print_stats(45)
+    st.sort_stats("cumulative").print_stats(60)
