@@ -43,7 +43,8 @@ struct DPZ {
   static constexpr int LDS = WB + 2 * SLOTB + 2 * YB;
   static constexpr int PR = 3;                       // output rows per prob lane: PW * PR = 2 * CYR
   static constexpr int NITEM = IY * IX * ROUNDS;     // (cell, round) staging items of one plane
-  static constexpr int IPT = (NITEM + PW * 64 - 1) / (PW * 64);
+  static constexpr int IPT = (NITEM + PW * 64 - 1) / (PW * 64);      // per producer thread (prologue of a segment)
+  static constexpr int IPC = (NITEM + CW * 64 - 1) / (CW * 64);      // per consumer thread (inside the march)
 };
 static_assert(DPZ::PW * DPZ::PR == 2 * DPZ::CYR, "prob rows");
 static_assert(DPZ::LDS <= 160 * 1024, "LDS budget");
@@ -192,19 +193,11 @@ __global__ __launch_bounds__(DPZ::THREADS, 3) void deconv_prob_zm_kernel(
       issue(ap + 1);
       deposit(ap + 1);
     }
-    int nextp = (qs & 1) ? ap + 2 : ap + 1;     // deposited during the next even half-step
-    issue(nextp);
+    // (inside the march the CONSUMERS stage: plane t / 2 + 1 during every even half-step t, see there)
     __syncthreads();                            // #0
     for (int t = qs; t <= te; ++t) {
       const int q = t - 1;
       if (q >= qs && q <= qe) process(q);
-      if (!(t & 1)) {
-        // plane (t / 2) + 1 for the half-step after this one.  After the arithmetic: the wait for the loads (issued a step
-        // ago) also covers the stores of the half-step before (vmcnt counts both, in order), which have had the time to land
-        deposit(nextp);
-        ++nextp;
-        issue(nextp);
-      }
       const int o = t - 2;
       if (o >= 2 * a0 && o < 2 * a1) {
         float* po = out + (size_t)o * Ho * Wo;     // wave-uniform plane base + per-lane 32-bit offsets
@@ -285,6 +278,21 @@ __global__ __launch_bounds__(DPZ::THREADS, 3) void deconv_prob_zm_kernel(
         *reinterpret_cast<float4*>(yb + py * C::YROWB + q * 32 * 16) = o;
       }
   };
+  // ---- input staging inside the march: plane t / 2 + 1 is loaded at the start of every EVEN half-step t (its slot held plane
+  // t / 2 - 1, which nobody reads after the barrier before) and split + stored after the half-step's epilogue, in the ~2000 cycles
+  // the consumers used to spend at that barrier waiting for the prob waves.  (The prob waves did this until round 5: 1600-1700
+  // cycles of every even half-step on the kernel's critical chain; probe without any staging: 975 vs 1170 us.) ----
+  int c_src[C::IPC], c_dst[C::IPC];
+#pragma unroll
+  for (int h = 0; h < C::IPC; ++h) {
+    const int it = h * C::CW * 64 + tid;
+    const int rd = it & 1, p = it >> 1;
+    const int row = p / C::IX, c = p - row * C::IX;
+    const int gy = Y0 + row, gx = X0 + c;
+    const bool ok = it < C::NITEM && gy >= 0 && gy < H && gx >= 0 && gx < W;
+    c_src[h] = ok ? ((gy * W + gx) * 16 + rd * 8) : -1;
+    c_dst[h] = it < C::NITEM ? rd * C::ROUNDB + (row * C::IXP + c) * POSB : -1;
+  }
   if (qs & 1) load_skip(sk1, qs); else load_skip(sk0, qs);
   __syncthreads();                                // #0
   for (int t = qs; t <= te; ++t) {
@@ -297,6 +305,20 @@ __global__ __launch_bounds__(DPZ::THREADS, 3) void deconv_prob_zm_kernel(
         for (int q = 0; q < C::NT; ++q) acc[py][q] = (f32x4){bv.x, bv.y, bv.z, bv.w};   // the BN shift rides in the accumulator
       if (!(t & 1)) {
         // ---- z parity 0: plane 2 a from cell plane a ----
+        float4 va[C::IPC], vb[C::IPC];
+        {
+          const int plane = a + 1;
+          const bool pok = plane < D;
+          const float* __restrict__ xp = x + (size_t)min(plane, D - 1) * H * W * 16;
+#pragma unroll
+          for (int h = 0; h < C::IPC; ++h) {
+            const bool ok = pok && c_src[h] >= 0;
+            const float* src = xp + (ok ? c_src[h] : 0);
+            const float4 la = *reinterpret_cast<const float4*>(src), lb = *reinterpret_cast<const float4*>(src + 4);
+            va[h] = ok ? la : make_float4(0.f, 0.f, 0.f, 0.f);
+            vb[h] = ok ? lb : make_float4(0.f, 0.f, 0.f, 0.f);
+          }
+        }
         load_skip(sk1, t + 1);
         BV w0[3], w1[3], b0[C::NT][3], b1[C::NT][3];
         load_b(b0, cur + b_h1);
@@ -313,6 +335,12 @@ __global__ __launch_bounds__(DPZ::THREADS, 3) void deconv_prob_zm_kernel(
         SBF_TERMS(acc[0], 0, C::NT, w0, b1);
         SBF_TERMS(acc[1], 0, C::NT, w1, b1);
         epilogue(sk0, 0);
+        {
+          unsigned char* base = inring + ((a + 1) & 1) * C::SLOTB;
+#pragma unroll
+          for (int h = 0; h < C::IPC; ++h)
+            if (c_dst[h] >= 0) split_store8(base + c_dst[h], va[h], vb[h]);
+        }
       } else {
         // ---- z parity 1: plane 2 a + 1 from cell planes a (kz = 2) and a + 1 (kz = 0) ----
         load_skip(sk0, t + 1);

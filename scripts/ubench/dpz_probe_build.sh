@@ -1,7 +1,7 @@
 #!/bin/bash
 # Probe builds of the fused conv11 + prob kernel (csrc/deconv_prob_zm.hip): a patched COPY of the source is compiled and linked
 # with the product objects into cds_mvsnet_amd/_variants/libcdsmvs_hip.dpz_<tag>.so; the product source holds no probe code.
-#   dpz_probe_build.sh noprob|nomfma|noskip|nostore|nosplit|prio0|prio3|base [extra hipcc flags]
+#   dpz_probe_build.sh noprob|nomfma|noskip|nostore|nosplit|nostage|prio0|prio3|base [extra hipcc flags]
 set -e
 tag=$1; shift
 root=$(cd "$(dirname "$0")/../.." && pwd)
@@ -19,6 +19,8 @@ case $tag in
     sed -i 's|    float4 va\[C::IPT\], vb\[C::IPT\];|    float4 va[C::IPT], vb[C::IPT], vc[C::IPT];|' $tmp
     sed -i 's|        vb\[h\] = ok ? b : make_float4(0.f, 0.f, 0.f, 0.f);|        vb[h] = ok ? b : make_float4(0.f, 0.f, 0.f, 0.f); { const float4 c = *reinterpret_cast<const float4*>(src + (s_src[h] >= 16 ? -8 : 0)); vc[h] = ok ? c : make_float4(0.f, 0.f, 0.f, 0.f); }|' $tmp
     sed -i 's|        if (s_dst\[h\] >= 0) split_store8(base + s_dst\[h\], va\[h\], vb\[h\]);|        if (s_dst[h] >= 0) { float4* d4 = reinterpret_cast<float4*>(base + s_dst[h]); d4[0] = va[h]; d4[1] = vb[h]; d4[2] = vc[h]; }|' $tmp ;;
+  nostage) # upper bound for moving the input staging off the prob waves: no loads, no split, no LDS stores inside the march
+    sed -i 's|^        deposit(nextp);|        /* probe: no staging */|; s|^        issue(nextp);|        /* probe */|' $tmp ;;
   prio0) sed -i 's|__builtin_amdgcn_s_setprio(2);|__builtin_amdgcn_s_setprio(0);|' $tmp ;;
   prio3) sed -i 's|__builtin_amdgcn_s_setprio(2);|__builtin_amdgcn_s_setprio(3);|' $tmp ;;
   *) echo "unknown probe $tag"; exit 1 ;;
