@@ -20,12 +20,10 @@ rep('''      const int q = t - 1;
       const int q = t - 1;
       if (q >= qs && q <= qe) process(q);
       if (wave == C::CW) STAMP(2, 1);''')
-rep('''        issue(nextp);
-      }
-      const int o = t - 2;''', '''        issue(nextp);
-      }
-      if (wave == C::CW) STAMP(2, 2);
-      const int o = t - 2;''')
+rep('''      const int o = t - 2;
+      if (o >= 2 * a0''', '''      if (wave == C::CW) STAMP(2, 2);           // (no staging in the prob waves since round 5)
+      const int o = t - 2;
+      if (o >= 2 * a0''')
 rep('''        A[2][r] = 0.f;
       }
       __syncthreads();''', '''        A[2][r] = 0.f;
@@ -49,6 +47,10 @@ rep('''        SBF_TERMS(acc[1], 0, C::NT, w1, b1);
         epilogue(sk0, 0);''', '''        SBF_TERMS(acc[1], 0, C::NT, w1, b1);
         if (cst) STAMP(cwv, 2);
         epilogue(sk0, 0);
+        __builtin_amdgcn_s_waitcnt(0xC07F); if (cst) STAMP(cwv, 4);''')
+rep('''            if (c_dst[h] >= 0) split_store8(base + c_dst[h], va[h], vb[h]);
+        }''', '''            if (c_dst[h] >= 0) split_store8(base + c_dst[h], va[h], vb[h]);
+        }
         __builtin_amdgcn_s_waitcnt(0xC07F); if (cst) STAMP(cwv, 3);''')
 rep('''          SBF_TERMS(acc[1], 0, C::NT, w0, b1);
         }

@@ -26,6 +26,8 @@ print(" t | consumer 0: operands mfma epilogue (barrier wait) | consumer 7: oper
 for t in range(2, min(ns - 1, 44)):
     e, l, p = a[0], a[1], a[2]
     per = p[0, t + 1] - p[0, t]
+    # even half-steps: the consumers' third phase = epilogue + input staging (stamp 4 separates them)
+    stg = f" [stg {e[3,t]-e[4,t]:5d} {l[3,t]-l[4,t]:5d}]" if (e[4, t] > e[2, t] and e[4, t] <= e[3, t]) else ""
     print(f"{t:3d} | {e[1,t]-e[0,t]:6d} {e[2,t]-e[1,t]:6d} {e[3,t]-e[2,t]:6d} ({e[0,t+1]-e[3,t]:6d}) | "
           f"{l[1,t]-l[0,t]:6d} {l[2,t]-l[1,t]:6d} {l[3,t]-l[2,t]:6d} ({l[0,t+1]-l[3,t]:6d}) | "
           f"{p[1,t]-p[0,t]:6d} {p[2,t]-p[1,t]:6d} {p[3,t]-p[2,t]:6d} ({p[0,t+1]-p[3,t]:6d}) | {per:6d}")
