@@ -18,5 +18,9 @@ build() {  # name, sed expression
 build krep2 's/^    for \(int ss = 0; ss < NS; \+\+ss\) \{/    for (int rep_ = 0; rep_ < 2; ++rep_) for (int ss = 0; ss < NS; ++ss) {/' &
 build nostore 's/^    sbf_store4\(obase/    if (o.x == 1234.5f) sbf_store4(obase/' &
 build noload 's/const float\* __restrict__ src = ok \? x \+ \(\(long long\)z \* plane_elems \+ s_off\[h\]\) : g_zmg_zeros;/const float* __restrict__ src = g_zmg_zeros;/' &
+# halfstage: the producers load, split and store only every second item of a stage (upper bound for handing part of the staging to the
+# consumer waves, which wait 500-2000 cycles per stage at the barrier); nostage: none inside the march
+build halfstage 's/^      for \(int h = 0; h < PPT; \+\+h\) \{$/      for (int h = 0; h < PPT; h += 2) {/' &
+build nostage 's/^      for \(int h = 0; h < PPT; \+\+h\) \{$/      for (int h = 0; h < 0; ++h) {/' &
 wait
 ls -la $out/*probe*
