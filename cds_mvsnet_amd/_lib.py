@@ -82,7 +82,6 @@ SIGNATURES = {
     "cds_conv2d_fpn_cl_f32": [P, P, P, P, P, P, P, I, I, I, I, I, I, P],
     "cds_vis_layer1_cl_f32": [P, P, P, P, P, I, I, I, P],
     "cds_conv2d_k3_relu_cl_f32": [P, P, P, P, P, P, I, I, I, I, P],
-    "cds_vis23_cl_f32": [P, P, P, P, P, P, P, P, I, I, I, P],
     "cds_instnorm_stats_cl_parts": [I, I],
     "cds_instnorm_stats_cl_f32": [P, P, I, I, I, I, P],
     "cds_instnorm_apply_cl_f32": [P, P, P, P, I, I, I, I, I, I, I, P],

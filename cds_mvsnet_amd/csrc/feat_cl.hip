@@ -554,237 +554,6 @@ int launch_dynconv_cl(const float* x, const float* aff, const void* wsp, const f
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
-// Visibility CNN layers 2 + 3 + head in ONE kernel (models/model.py:14: ConvBnReLU 16 -> 16, ConvBnReLU 16 -> 16, Conv2d 16 -> 1 +
-// sigmoid; BatchNorm folded).  The two MODE 2 launches of dynconv_cl_kernel it replaces write and re-read the 16-channel map between
-// the layers (2 x 64 B per pixel and view at 3 TB/s).  Here a workgroup stages the layer-1 output on its 32 x 8 tile + a TWO-texel
-// halo, runs layer 2 on the tile + ONE texel of halo (34 x 10 positions as 22 M-tiles of 16 consecutive positions: 1.38 x the
-// interior's matrix work), writes ReLU(layer 2) - zero outside the image, the zero padding layer 3 sees - straight into the LDS
-// operand format of layer 3 ([position][term][8 channels] bf16, the same exact three-way split the staging of a separate layer-3
-// launch would apply to the same fp32 values), and runs layer 3 + head on the interior.  Every accumulator sees the K-steps and the
-// six partial products in the order of the separate kernels: results are bit-identical to the two launches.
-// ---------------------------------------------------------------------------------------------------------------------------
-struct V23 {
-  static constexpr int R1X = TX + 4, R1Y = TY + 4, NP1 = R1X * R1Y;      // staged input region
-  static constexpr int R2X = TX + 2, R2Y = TY + 2, NP2 = R2X * R2Y;      // layer-2 output region
-  static constexpr int PLANE1 = NP1 * POSB, PLANE2 = NP2 * POSB;          // one 8-channel round of a region
-  static constexpr int NT2 = (NP2 + 15) / 16, TPW = (NT2 + 3) / 4;        // M-tiles of layer 2, per wave
-  static constexpr int HALF = TPW / 2;                                    // operand registers: TPW / 2 tiles at a time
-  static constexpr int LDSB = 2 * PLANE1 + 2 * PLANE2;
-  static constexpr int NIT = (NP1 * 4 + 255) / 256;
-};
-static_assert(V23::TPW % 2 == 0, "layer-2 tiles are processed in two halves");
-
-__global__ __launch_bounds__(256, 2) void vis23_cl_kernel(const float* __restrict__ x, const uint4* __restrict__ w2sp,
-                                                          const float* __restrict__ b2, const uint4* __restrict__ w3sp,
-                                                          const float* __restrict__ b3, const float* __restrict__ head_w,
-                                                          const float* __restrict__ head_b, float* __restrict__ out, int N, int H,
-                                                          int W, int tiles_x, int tiles_y) {
-  using C = V23;
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  unsigned char* const ldsA = lds;
-  unsigned char* const ldsB = lds + 2 * C::PLANE1;
-  int lin = cds_xcd_remap(blockIdx.x, tiles_x * tiles_y * N);
-  const int tx_i = lin % tiles_x;
-  lin /= tiles_x;
-  const int ty_i = lin % tiles_y, img = lin / tiles_y;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int m = lane & 15, g = lane >> 4;
-  const int ox0 = tx_i * TX, oy0 = ty_i * TY;
-
-  // ---- stage the layer-1 output (ReLU already applied by its producer) on the (TY + 4) x (TX + 4) region, zero outside the image ----
-  {
-    const int c4 = tid & 3;
-    float4 v[C::NIT];
-#pragma unroll
-    for (int i = 0; i < C::NIT; ++i) {
-      const int pos = (tid >> 2) + i * 64;
-      const int row = pos / C::R1X, col = pos - row * C::R1X;
-      const int gy = oy0 - 2 + row, gx = ox0 - 2 + col;
-      const bool ok = pos < C::NP1 && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
-      const float4 t = *reinterpret_cast<const float4*>(x + (ok ? (((size_t)img * H + gy) * W + gx) * 16 + c4 * 4 : 0));
-      v[i] = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    unsigned char* dst0 = ldsA + (c4 >> 1) * C::PLANE1 + (c4 & 1) * 8;
-#pragma unroll
-    for (int i = 0; i < C::NIT; ++i) {
-      const int pos = (tid >> 2) + i * 64;
-      if (pos >= C::NP1) break;
-      uint32_t h0, m0, l0, h1, m1, l1;
-      split2(v[i].x, v[i].y, h0, m0, l0);
-      split2(v[i].z, v[i].w, h1, m1, l1);
-      unsigned char* d = dst0 + pos * POSB;
-      *reinterpret_cast<uint2*>(d) = make_uint2(h0, h1);
-      *reinterpret_cast<uint2*>(d + 16) = make_uint2(m0, m1);
-      *reinterpret_cast<uint2*>(d + 32) = make_uint2(l0, l1);
-    }
-  }
-  __syncthreads();
-
-  // ---- layer 2 on the 34 x 10 region: M-tile (wave + 4 i) = region positions 16 tile .. 16 tile + 15; lane (m, g) supplies the 8
-  // channels of tap 4 t + g for position m of the tile.  Tiles past the region (two of 24) run on clamped positions and are dropped. ----
-  f32x4 acc2[C::TPW];
-  int ab2[C::TPW];
-#pragma unroll
-  for (int i = 0; i < C::TPW; ++i) {
-    acc2[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int p = min((wave + 4 * i) * 16 + m, C::NP2 - 1);
-    const int r2 = p / C::R2X, c2 = p - r2 * C::R2X;
-    ab2[i] = (r2 * C::R1X + c2) * POSB;
-  }
-  {
-    const uint4* __restrict__ wl = w2sp + lane;
-#pragma unroll 1
-    for (int rd = 0; rd < 2; ++rd) {
-#pragma unroll 1
-      for (int t = 0; t < 3; ++t) {
-        int tap = 4 * t + g;
-        if (tap > 8) tap = 8;                           // padded taps: zero weights, any in-region data
-        const int ky = tap / 3, kx = tap - 3 * ky;
-        const unsigned char* ap = ldsA + rd * C::PLANE1 + (ky * C::R1X + kx) * POSB;
-        const uint4* wp = wl + (size_t)((rd * 3 + t) * 3) * 64;
-        BV wh, wm, wlo;
-        wh.u = wp[0];
-        wm.u = wp[64];
-        wlo.u = wp[128];
-#pragma unroll
-        for (int hf = 0; hf < 2; ++hf) {
-          BV ah[C::HALF], am[C::HALF], al[C::HALF];
-#pragma unroll
-          for (int q = 0; q < C::HALF; ++q) {
-            const unsigned char* a = ap + ab2[hf * C::HALF + q];
-            ah[q].u = *reinterpret_cast<const uint4*>(a);
-            am[q].u = *reinterpret_cast<const uint4*>(a + 16);
-            al[q].u = *reinterpret_cast<const uint4*>(a + 32);
-          }
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int q = 0; q < C::HALF; ++q) SBF_MFMA(acc2[hf * C::HALF + q], al[q], wh);     // the product order of dynconv_cl_kernel
-#pragma unroll
-          for (int q = 0; q < C::HALF; ++q) SBF_MFMA(acc2[hf * C::HALF + q], am[q], wm);
-#pragma unroll
-          for (int q = 0; q < C::HALF; ++q) SBF_MFMA(acc2[hf * C::HALF + q], ah[q], wlo);
-#pragma unroll
-          for (int q = 0; q < C::HALF; ++q) SBF_MFMA(acc2[hf * C::HALF + q], am[q], wh);
-#pragma unroll
-          for (int q = 0; q < C::HALF; ++q) SBF_MFMA(acc2[hf * C::HALF + q], ah[q], wm);
-#pragma unroll
-          for (int q = 0; q < C::HALF; ++q) SBF_MFMA(acc2[hf * C::HALF + q], ah[q], wh);
-        }
-      }
-    }
-  }
-  // ---- ReLU(layer 2 + bias) -> region B in layer 3's operand format.  Lane (m, g) holds channel m of positions 16 tile + 4 g + k; the
-  // lanes m, m ^ 1 exchange values so that each splits channel PAIRS (even lane: k = 0, 1; odd lane: k = 2, 3) and stores 4-byte words ----
-  {
-    const float bv = b2 ? b2[m] : 0.f;
-    const int ch0 = m & ~1;
-    unsigned char* const dstc = ldsB + (ch0 >> 3) * C::PLANE2 + (ch0 & 7) * 2;
-#pragma unroll
-    for (int i = 0; i < C::TPW; ++i) {
-      const int tile = wave + 4 * i;
-      const f32x4 a = acc2[i];
-      // value k of this lane: channel m of position 16 tile + 4 g + k (zero outside the image: layer 3's zero padding)
-      auto val = [&](float acc_k, int k, int& pidx) -> float {
-        const int p = tile * 16 + 4 * g + k;
-        const int r2 = p / C::R2X, c2 = p - r2 * C::R2X;
-        const int gy = oy0 - 1 + r2, gx = ox0 - 1 + c2;
-        pidx = p < C::NP2 ? p : -1;
-        return ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) ? fmaxf(acc_k + bv, 0.f) : 0.f;
-      };
-      int p0, p1, p2, p3;
-      const float v0 = val(a.x, 0, p0), v1 = val(a.y, 1, p1), v2 = val(a.z, 2, p2), v3 = val(a.w, 3, p3);
-      auto xchg = [](float t) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(t), 0xB1, 0xf, 0xf, true)); };   // lane m ^ 1
-      const float q0 = xchg(v0), q1 = xchg(v1), q2 = xchg(v2), q3 = xchg(v3);
-      const bool odd = m & 1;
-      // even lane: positions k = 0, 1 with (own, partner) = channels (m, m + 1); odd lane: k = 2, 3 with (partner, own) = (m - 1, m)
-      const float loA = odd ? q2 : v0, hiA = odd ? v2 : q0, loB = odd ? q3 : v1, hiB = odd ? v3 : q1;
-      const int pA = odd ? p2 : p0, pB = odd ? p3 : p1;
-      uint32_t hh, mm, ll;
-      split2(loA, hiA, hh, mm, ll);
-      if (pA >= 0) {
-        unsigned char* d = dstc + pA * POSB;
-        *reinterpret_cast<uint32_t*>(d) = hh;
-        *reinterpret_cast<uint32_t*>(d + 16) = mm;
-        *reinterpret_cast<uint32_t*>(d + 32) = ll;
-      }
-      split2(loB, hiB, hh, mm, ll);
-      if (pB >= 0) {
-        unsigned char* d = dstc + pB * POSB;
-        *reinterpret_cast<uint32_t*>(d) = hh;
-        *reinterpret_cast<uint32_t*>(d + 16) = mm;
-        *reinterpret_cast<uint32_t*>(d + 32) = ll;
-      }
-    }
-  }
-  __syncthreads();
-
-  // ---- layer 3 on the interior (the K-loop of dynconv_cl_kernel MODE 2 over region B) + head ----
-  f32x4 acc3[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) acc3[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  {
-    const int a_base = ((wave * 2) * C::R2X + m) * POSB;
-    const uint4* __restrict__ wl = w3sp + lane;
-#pragma unroll 1
-    for (int rd = 0; rd < 2; ++rd) {
-#pragma unroll 1
-      for (int t = 0; t < 3; ++t) {
-        int tap = 4 * t + g;
-        if (tap > 8) tap = 8;
-        const int ky = tap / 3, kx = tap - 3 * ky;
-        const unsigned char* ap = ldsB + rd * C::PLANE2 + a_base + (ky * C::R2X + kx) * POSB;
-        const uint4* wp = wl + (size_t)((rd * 3 + t) * 3) * 64;
-        BV wh, wm, wlo;
-        wh.u = wp[0];
-        wm.u = wp[64];
-        wlo.u = wp[128];
-        BV ah[4], am[4], al[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const unsigned char* a = ap + ((q >> 1) * C::R2X + (q & 1) * 16) * POSB;
-          ah[q].u = *reinterpret_cast<const uint4*>(a);
-          am[q].u = *reinterpret_cast<const uint4*>(a + 16);
-          al[q].u = *reinterpret_cast<const uint4*>(a + 32);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) SBF_MFMA(acc3[q], al[q], wh);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) SBF_MFMA(acc3[q], am[q], wm);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) SBF_MFMA(acc3[q], ah[q], wlo);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) SBF_MFMA(acc3[q], am[q], wh);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) SBF_MFMA(acc3[q], ah[q], wm);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) SBF_MFMA(acc3[q], ah[q], wh);
-      }
-    }
-  }
-  const float bv3 = b3 ? b3[m] : 0.f;
-  const float hw_n = head_w[m], hb = head_b[0];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int oy = oy0 + wave * 2 + (q >> 1), ox = ox0 + (q & 1) * 16 + g * 4;
-    const f32x4 a = acc3[q];
-    float v[4] = {fmaxf(a.x + bv3, 0.f), fmaxf(a.y + bv3, 0.f), fmaxf(a.z + bv3, 0.f), fmaxf(a.w + bv3, 0.f)};
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const float sacc = row16_sum(v[i] * hw_n) + hb;
-      v[i] = 1.0f / (1.0f + expf(-sacc));
-    }
-    if (m == 0 && oy < H) {
-      float* __restrict__ o = out + ((size_t)img * H + oy) * W + ox;
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-        if (ox + i < W) o[i] = v[i];
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------------------------------
 // DynamicConv epilogue over a PLANAR branch tensor [K][slots][Cout + 3][H][W] (conv00: the VALU branch kernels of conv2d.hip),
 // channels-last output [N][H][W][8] + InstanceNorm records; the first n_shared images share branch slot 0.
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -1241,21 +1010,6 @@ extern "C" int cds_conv2d_k3_relu_cl_f32(const float* x, const void* weight_spli
   ep.b1 = head_b;
   ep.out = out;
   return launch_dynconv_cl<16, 3, 0, 0, 2>(x, nullptr, weight_split, bias, ep, N, H, W, (hipStream_t)stream);
-}
-
-// Visibility CNN layers 2 + 3 + head in one launch (vis23_cl_kernel): x [N][H][W][16] (layer-1 output, ReLU applied), w2 / w3 =
-// ops.split_pack_dynconv([w]) of the two [16][16][3][3] weights, b2 / b3 [16] (folded BatchNorm shifts) or NULL, head_w [16], head_b [1]
-// -> out [N][H][W] = sigmoid(head).  Bit-identical to two cds_conv2d_k3_relu_cl_f32 launches.
-extern "C" int cds_vis23_cl_f32(const float* x, const void* w2_split, const float* b2, const void* w3_split, const float* b3,
-                                const float* head_w, const float* head_b, float* out, int N, int H, int W, void* stream) {
-  if (!x || !w2_split || !w3_split || !head_w || !head_b || !out || N < 1 || H < 1 || W < 1) return CDS_EINVAL;
-  const int tx = cds_ceil_div(W, TX), ty = cds_ceil_div(H, TY);
-  static std::atomic<unsigned long long> lds_ok{0};
-  if (int e = cds_allow_lds(reinterpret_cast<const void*>(vis23_cl_kernel), V23::LDSB, lds_ok)) return e;
-  hipLaunchKernelGGL(vis23_cl_kernel, dim3(tx * ty * N), dim3(256), (size_t)V23::LDSB, (hipStream_t)stream, x,
-                     reinterpret_cast<const uint4*>(w2_split), b2, reinterpret_cast<const uint4*>(w3_split), b3, head_w, head_b, out, N,
-                     H, W, tx, ty);
-  return cds_launch_status();
 }
 
 // Records per image that cds_dynconv_cl_f32 leaves for cds_instnorm_reduce_f32: one per 32 x 8 tile.

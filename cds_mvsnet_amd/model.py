@@ -32,7 +32,6 @@ USE_SPLIT_BF16 = os.environ.get("CDS_CONV_EXACT", "0") != "1"
 USE_FUSED_BLEND = os.environ.get("CDS_FUSED_BLEND", "1") != "0"   # A/B knob: 0 = DynamicConv branches and blend as two kernels
 # stage 1 on a side stream next to FeatureNet's finer levels (CDS_OVERLAP_STAGE1=0: one stream): 1600x1184 19.04 -> 18.72 ms, 640x512 4.67 -> 4.48
 OVERLAP_STAGE1 = os.environ.get("CDS_OVERLAP_STAGE1", "1") != "0"
-USE_VIS_FUSED = os.environ.get("CDS_VIS_FUSED", "0") == "1"      # A/B knob: visibility CNN layers 2 + 3 + head as one kernel (vis23_cl_kernel)
 OVERLAP_STAGE2 = os.environ.get("CDS_OVERLAP_STAGE2", "0") == "1"   # A/B knob: stage 2 as well (next to the full-resolution FPN level)
 # FeatureNet on channels-last activations (csrc/feat_cl.hip, round 5); CDS_FEAT_CL=0: the planar kernels of rounds 1-4
 USE_FEAT_CL = os.environ.get("CDS_FEAT_CL", "1") != "0"
@@ -683,8 +682,6 @@ class StageNet(_PackedHolder):
             if USE_FEAT_CL and f"{s}.ws1" in p and ops.USE_CONV2D_SBF:
                 # channels-last activations (csrc/feat_cl.hip): layer 1 straight from the two maps, layers 2 / 3 on the matrix cores
                 x = ops.vis_layer1_cl(entropy.contiguous(), ref_nc.contiguous(), p[f"{s}.w0"], p[f"{s}.b0"])
-                if USE_VIS_FUSED:                                        # layers 2 + 3 + head in one launch, same values
-                    return ops.vis23_cl(x, p[f"{s}.ws1"], p[f"{s}.b1"], p[f"{s}.ws2"], p[f"{s}.b2"], p[f"{s}.hw"], p[f"{s}.b3"])
                 x = ops.conv2d_k3_relu_cl(x, p[f"{s}.ws1"], p[f"{s}.b1"])
                 return ops.conv2d_k3_relu_cl(x, p[f"{s}.ws2"], p[f"{s}.b2"], head_w=p[f"{s}.hw"], head_b=p[f"{s}.b3"])
             x = torch.stack((entropy, ref_nc), dim=1)

@@ -1132,25 +1132,6 @@ def conv2d_k3_relu_cl(x_cl: Tensor, wsplit: Tensor, bias: Optional[Tensor], head
     return out
 
 
-def vis23_cl(x_cl: Tensor, w2split: Tensor, b2: Optional[Tensor], w3split: Tensor, b3: Optional[Tensor], head_w: Tensor,
-             head_b: Tensor) -> Tensor:
-    """Visibility CNN layers 2 + 3 + head in one launch (csrc/feat_cl.hip vis23_cl_kernel; models/model.py:14): x_cl [N,H,W,16] ->
-    [N,H,W].  Bit-identical to conv2d_k3_relu_cl(conv2d_k3_relu_cl(x, w2, b2), w3, b3, head_w, head_b)."""
-    N, H, W, C = x_cl.shape
-    if C != 16:
-        raise ValueError(f"vis23_cl: need [N,H,W,16], got {tuple(x_cl.shape)}")
-    for w in (w2split, w3split):
-        if w.dtype != torch.int16 or w.numel() != 2 * 3 * 1 * 3 * 64 * 8:
-            raise ValueError("vis23_cl: the weights must be split_pack_dynconv([w]) of [16,16,3,3] tensors")
-    if head_w.numel() != 16 or head_b.numel() != 1:
-        raise ValueError("vis23_cl: head_w [16], head_b [1]")
-    out = torch.empty((N, H, W), dtype=torch.float32, device=x_cl.device)
-    check(_lib.load().cds_vis23_cl_f32(_dev(x_cl, "x"), w2split.data_ptr(), _dev(b2, "b2") if b2 is not None else None, w3split.data_ptr(),
-                                       _dev(b3, "b3") if b3 is not None else None, _dev(head_w, "head_w"), _dev(head_b, "head_b"),
-                                       out.data_ptr(), N, H, W, _stream(x_cl)), "cds_vis23_cl_f32")
-    return out
-
-
 def depth_fusion(ref_depth: Tensor, ref_conf: Tensor, src_depths: Tensor, src_confs: Tensor, cams: Tensor,
                  prob_thresh, dist_thresh: float, depth_thresh: float, view_thresh: float,
                  want_view_masks: bool = False):

@@ -430,12 +430,6 @@ int cds_vis_layer1_cl_f32(const float* entropy, const float* ref_nc, const float
                           int W, void* stream);
 int cds_conv2d_k3_relu_cl_f32(const float* x, const void* weight_split, const float* bias, const float* head_w, const float* head_b,
                               float* out, int N, int Cin, int H, int W, void* stream);
-/* Visibility CNN layers 2 + 3 + head in ONE launch (models/model.py:14): x [N][H][W][16] = the layer-1 output, w2_split / w3_split =
- * the split-bf16 packing of the two [16][16][3][3] weights (as for cds_conv2d_k3_relu_cl_f32), b2 / b3 [16] or NULL, head_w [16],
- * head_b [1] -> out [N][H][W] = sigmoid(head(ReLU(conv3(ReLU(conv2(x)))))).  The 16-channel map between the layers stays in LDS;
- * bit-identical to two cds_conv2d_k3_relu_cl_f32 launches. */
-int cds_vis23_cl_f32(const float* x, const void* w2_split, const float* b2, const void* w3_split, const float* b3, const float* head_w,
-                     const float* head_b, float* out, int N, int H, int W, void* stream);
 int cds_instnorm_stats_cl_parts(int H, int W);
 int cds_instnorm_stats_cl_f32(const float* x, double* partial, int N, int C, int H, int W, void* stream);
 int cds_instnorm_apply_cl_f32(const float* x, const double* stats, float* out_cl, float* out_chw, int N, int C, int H, int W, int act,

@@ -241,29 +241,6 @@ def test_visibility_layers_channels_last(V, H, W, dev, ops):
         assert torch.equal(goth, oldh)
 
 
-@pytest.mark.parametrize("V,H,W", [(1, 8, 32), (2, 9, 33), (4, 24, 40), (3, 7, 13), (1, 1, 1), (2, 40, 100), (4, 128, 160), (6, 66, 97)])
-def test_visibility_layers_2_3_fused(V, H, W, dev, ops):
-    """cds_vis23_cl_f32 (layers 2 + 3 + head of the visibility CNN in one launch, the 16-channel map between them kept in LDS in layer
-    3's operand format) == two cds_conv2d_k3_relu_cl_f32 launches, bit for bit: exact tiles, partial tiles, one-pixel maps, image
-    borders inside the two-texel halo; and against float64."""
-    import torch.nn.functional as F
-    g = torch.Generator().manual_seed(V * 1000 + H * 7 + W)
-    x = torch.rand(V, H, W, 16, generator=g).clamp_min(0.2) * (torch.rand(V, H, W, 16, generator=g) > 0.3)      # a ReLU output
-    w2, b2 = torch.randn(16, 16, 3, 3, generator=g) / 12.0, torch.randn(16, generator=g) * 0.2
-    w3, b3 = torch.randn(16, 16, 3, 3, generator=g) / 12.0, torch.randn(16, generator=g) * 0.2
-    hw, hb = torch.randn(16, generator=g) * 0.3, torch.randn(1, generator=g)
-    xs = x.to(dev).contiguous()
-    ws2, ws3 = ops.split_pack_dynconv([w2.to(dev)]), ops.split_pack_dynconv([w3.to(dev)])
-    two = ops.conv2d_k3_relu_cl(ops.conv2d_k3_relu_cl(xs, ws2, b2.to(dev)), ws3, b3.to(dev), head_w=hw.to(dev), head_b=hb.to(dev))
-    one = ops.vis23_cl(xs, ws2, b2.to(dev), ws3, b3.to(dev), hw.to(dev), hb.to(dev))
-    assert tuple(one.shape) == (V, H, W)
-    assert torch.equal(one, two), (one - two).abs().max().item()
-    xin = x.permute(0, 3, 1, 2).double()
-    y = F.conv2d(F.conv2d(xin, w2.double(), b2.double(), padding=1).clamp_min(0), w3.double(), b3.double(), padding=1).clamp_min(0)
-    h64 = torch.sigmoid((y * hw.double().view(1, 16, 1, 1)).sum(1) + hb.double())
-    assert (one.cpu().double() - h64).abs().max().item() <= 3e-6
-
-
 @pytest.mark.parametrize("N,n_shared,H,W", [(4, 2, 24, 40), (1, 1, 9, 13), (5, 3, 16, 100), (3, 1, 40, 70), (8, 4, 64, 96)])
 def test_conv00_on_matrix_cores(N, n_shared, H, W, dev, ops):
     """cds_conv00_cl_f32 (conv00: 3 -> 8 + 3, kernel sizes 3 / 7 / 11, tap-pair K-steps on the matrix cores, blend fused, shared
