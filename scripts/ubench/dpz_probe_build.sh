@@ -1,7 +1,7 @@
 #!/bin/bash
 # Probe builds of the fused conv11 + prob kernel (csrc/deconv_prob_zm.hip): a patched COPY of the source is compiled and linked
 # with the product objects into cds_mvsnet_amd/_variants/libcdsmvs_hip.dpz_<tag>.so; the product source holds no probe code.
-#   dpz_probe_build.sh noprob|nomfma|noskip|nostore|nosplit|nostage|prio0|prio3|base [extra hipcc flags]
+#   dpz_probe_build.sh noprob|nomfma|noskip|nostore|nostage|prio0|prio3|base [extra hipcc flags]
 set -e
 tag=$1; shift
 root=$(cd "$(dirname "$0")/../.." && pwd)
@@ -15,12 +15,10 @@ case $tag in
   nomfma) sed -i 's|#include "sbf_common.hpp"|#include "sbf_common.hpp"\n#undef SBF_MFMA\n#define SBF_MFMA(acc, a, b) asm volatile("" : "+v"(acc) : "v"((a).v), "v"((b).v))|' $tmp ;;
   noskip) sed -i 's|    if (t > qe) return;|    if (t >= 0) { for (int py = 0; py < 2; ++py) for (int q = 0; q < C::NT; ++q) sk[py][q] = make_float4(0.f, 0.f, 0.f, 0.f); return; }|' $tmp ;;
   nostore) sed -i 's|if (o >= 2 \* a0 \&\& o < 2 \* a1 \&\& lane_ok) {|if (o >= 2 * a0 \&\& o < 2 * a1 \&\& lane_ok \&\& A[0][0].x == 123.456f) {|' $tmp ;;
-  nosplit) # upper bound for "conv9 writes the split format": the staging copies 48 B per item (three 16-byte loads, three LDS stores), no VALU
-    sed -i 's|    float4 va\[C::IPT\], vb\[C::IPT\];|    float4 va[C::IPT], vb[C::IPT], vc[C::IPT];|' $tmp
-    sed -i 's|        vb\[h\] = ok ? b : make_float4(0.f, 0.f, 0.f, 0.f);|        vb[h] = ok ? b : make_float4(0.f, 0.f, 0.f, 0.f); { const float4 c = *reinterpret_cast<const float4*>(src + (s_src[h] >= 16 ? -8 : 0)); vc[h] = ok ? c : make_float4(0.f, 0.f, 0.f, 0.f); }|' $tmp
-    sed -i 's|        if (s_dst\[h\] >= 0) split_store8(base + s_dst\[h\], va\[h\], vb\[h\]);|        if (s_dst[h] >= 0) { float4* d4 = reinterpret_cast<float4*>(base + s_dst[h]); d4[0] = va[h]; d4[1] = vb[h]; d4[2] = vc[h]; }|' $tmp ;;
-  nostage) # upper bound for moving the input staging off the prob waves: no loads, no split, no LDS stores inside the march
-    sed -i 's|^        deposit(nextp);|        /* probe: no staging */|; s|^        issue(nextp);|        /* probe */|' $tmp ;;
+  nostage) # no input staging inside the march (the consumers' loads, split and LDS stores compiled out): upper bound for removing it from
+           # the kernel altogether.  (Round 5 ran this probe - and `nosplit`, an unsplit 48-byte copy - against the tree in which the PROB
+           # waves still staged: 975 / 1 350 us against 1 180, profiles/r05_costreg_tail_closure.md; that tree is the parent of commit a1b02ac.)
+    sed -i 's|^            if (c_dst\[h\] >= 0) split_store8(base + c_dst\[h\], va\[h\], vb\[h\]);|            ; /* probe: no staging */|' $tmp ;;
   prio0) sed -i 's|__builtin_amdgcn_s_setprio(2);|__builtin_amdgcn_s_setprio(0);|' $tmp ;;
   prio3) sed -i 's|__builtin_amdgcn_s_setprio(2);|__builtin_amdgcn_s_setprio(3);|' $tmp ;;
   *) echo "unknown probe $tag"; exit 1 ;;
