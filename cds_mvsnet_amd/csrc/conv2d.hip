@@ -525,7 +525,7 @@ __global__ __launch_bounds__(256) void dynconv_blend_kernel(const float* __restr
   out += (size_t)n * Cout * hw;
   const size_t bstride = (size_t)nslots * (Cout + 3) * hw;  // stride between kernel sizes
   float logit[K];
-  norm_curv[(size_t)n * hw + p] = blend_weights<K>(branch, bstride, Cout, hw, p, W, epi.x[n], epi.y[n], w1, b1, w2,
+  norm_curv[(size_t)n * hw + p] = blend_weights<K>(branch, bstride, Cout, hw, p, W, epi.x(n), epi.y(n), w1, b1, w2,
                                                    temperature, logit);
   for (int c = 0; c < Cout; ++c) {
     float s = 0.f;
@@ -566,7 +566,7 @@ __global__ __launch_bounds__(256) void dynconv_blend_stats_kernel(const float* _
     const int p = base + 256 * j;
     ok[j] = p < hw;
     px[j] = ok[j] ? p : hw - 1;
-    const float nc = blend_weights<K>(branch, bstride, Cout, hw, px[j], W, epi.x[n], epi.y[n], w1, b1, w2, temperature, lg[j]);
+    const float nc = blend_weights<K>(branch, bstride, Cout, hw, px[j], W, epi.x(n), epi.y(n), w1, b1, w2, temperature, lg[j]);
     if (ok[j]) norm_curv[(size_t)n * hw + p] = nc;
   }
   const int wave = threadIdx.x >> 6;
@@ -844,17 +844,13 @@ extern "C" int cds_conv2d_f32(const float* x, const float* weight, const float* 
 }
 
 extern "C" int cds_dynconv_blend_shared_f32(const float* branches, const float* w1, const float* b1, const float* w2,
-                                            const float* epipoles_host, float temperature, float* out, float* norm_curv,
+                                            const float* epipoles, float temperature, float* out, float* norm_curv,
                                             int N, int K, int Cout, int H, int W, int n_shared, void* stream) {
-  if (!branches || !w1 || !b1 || !w2 || !epipoles_host || !out || !norm_curv || N < 1 || N > CDS_MAX_IMAGES ||
+  if (!branches || !w1 || !b1 || !w2 || !epipoles || !out || !norm_curv || N < 1 || N > CDS_MAX_IMAGES ||
       Cout < 1 || H < 1 || W < 1 || n_shared < 1 || n_shared > N)
     return CDS_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  EpiBatch epi;
-  for (int n = 0; n < CDS_MAX_IMAGES; ++n) {
-    epi.x[n] = n < N ? epipoles_host[2 * n] : 0.f;
-    epi.y[n] = n < N ? epipoles_host[2 * n + 1] : 0.f;
-  }
+  const EpiBatch epi{epipoles};
   dim3 grid(cds_ceil_div(H * W, 256), N), block(256);
   if (K == 2)
     hipLaunchKernelGGL(dynconv_blend_kernel<2>, grid, block, 0, st, branches, w1, b1, w2, epi, temperature, out,
@@ -870,18 +866,14 @@ extern "C" int cds_dynconv_blend_shared_f32(const float* branches, const float* 
 extern "C" int cds_blend_stats_parts(int H, int W) { return 4 * cds_ceil_div(H * W, 256 * BLEND_PXT); }
 
 extern "C" int cds_dynconv_blend_stats_f32(const float* branches, const float* w1, const float* b1, const float* w2,
-                                           const float* epipoles_host, float temperature, float* out, float* norm_curv,
+                                           const float* epipoles, float temperature, float* out, float* norm_curv,
                                            float* partial, int N, int K, int Cout, int H, int W, int n_shared,
                                            void* stream) {
-  if (!branches || !w1 || !b1 || !w2 || !epipoles_host || !out || !norm_curv || !partial || N < 1 || N > CDS_MAX_IMAGES ||
+  if (!branches || !w1 || !b1 || !w2 || !epipoles || !out || !norm_curv || !partial || N < 1 || N > CDS_MAX_IMAGES ||
       Cout < 1 || H < 1 || W < 1 || n_shared < 1 || n_shared > N)
     return CDS_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  EpiBatch epi;
-  for (int n = 0; n < CDS_MAX_IMAGES; ++n) {
-    epi.x[n] = n < N ? epipoles_host[2 * n] : 0.f;
-    epi.y[n] = n < N ? epipoles_host[2 * n + 1] : 0.f;
-  }
+  const EpiBatch epi{epipoles};
   dim3 grid(cds_ceil_div(H * W, 256 * BLEND_PXT), N), block(256);
   double* dpart = reinterpret_cast<double*>(partial);
   if (K == 2)
@@ -920,9 +912,9 @@ extern "C" int cds_instnorm_apply_f32(const float* x, const float* stats, float*
 }
 
 extern "C" int cds_dynconv_blend_f32(const float* branches, const float* w1, const float* b1, const float* w2,
-                                     const float* epipoles_host, float temperature, float* out, float* norm_curv, int N,
+                                     const float* epipoles, float temperature, float* out, float* norm_curv, int N,
                                      int K, int Cout, int H, int W, void* stream) {
-  return cds_dynconv_blend_shared_f32(branches, w1, b1, w2, epipoles_host, temperature, out, norm_curv, N, K, Cout, H, W, 1,
+  return cds_dynconv_blend_shared_f32(branches, w1, b1, w2, epipoles, temperature, out, norm_curv, N, K, Cout, H, W, 1,
                                       stream);
 }
 

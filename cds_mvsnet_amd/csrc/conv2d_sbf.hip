@@ -78,7 +78,7 @@ struct Blend {
   float* norm_curv;     // [N][H][W]
   double* partial;      // [N][parts = tiles][Cout][2]
   float temperature;
-  float ex[CDS_MAX_IMAGES], ey[CDS_MAX_IMAGES];
+  const float* epi;     // [N][2] DEVICE: epipoles in pixels of this resolution (feat_common.hpp)
 };
 
 // NBR branches, NBLK 16-cout blocks (Cout + 3 <= 16 NBLK)
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(256, 2) void dynconv_branches_sbf_kernel(const floa
       for (int b = 0; b < NBR; ++b)
 #pragma unroll
         for (int j = 0; j < 3; ++j) att[b][j] = attL[(b * 3 + j) * 256 + wp];
-      const float nc = blend_from_att<NBR>(att, px, py, bl.ex[img], bl.ey[img], bl.w1, bl.b1, bl.w2, bl.temperature, logit);
+      const float nc = blend_from_att<NBR>(att, px, py, bl.epi[2 * img], bl.epi[2 * img + 1], bl.w1, bl.b1, bl.w2, bl.temperature, logit);
 #pragma unroll
       for (int b = 0; b < NBR; ++b) wL[b * 256 + wp] = logit[b];
       if (px < W && py < H) bl.norm_curv[(size_t)img * plane + (size_t)py * W + px] = nc;
@@ -400,13 +400,13 @@ extern "C" int cds_dynconv_fused_parts(int H, int W) { return cds_ceil_div(W, TX
 // epilogue of cds_dynconv_blend_stats_f32 applied to the accumulators.  out [N][Cout][H][W] (before its InstanceNorm),
 // norm_curv [N][H][W], partial: 8-byte aligned scratch of 2 * N * parts * Cout doubles, parts = cds_dynconv_fused_parts(H, W)
 // (reduce with cds_instnorm_reduce_f32).  w1 [4][K], b1 [4], w2 [K][4]: the attention MLP with its BatchNorm folded in;
-// epipoles_host [N][2] pixels at this resolution.  Same shape limits as cds_dynconv_branches_sbf_f32; N <= CDS_MAX_IMAGES.
+// epipoles [N][2] pixels at this resolution.  Same shape limits as cds_dynconv_branches_sbf_f32; N <= CDS_MAX_IMAGES.
 extern "C" int cds_dynconv_fused_sbf_f32(const float* x, const float* in_affine, const void* weight_split, const float* bias,
-                                         const float* w1, const float* b1, const float* w2, const float* epipoles_host,
+                                         const float* w1, const float* b1, const float* w2, const float* epipoles,
                                          float temperature, float* out, float* norm_curv, double* partial, int N, int Cin,
                                          int Cout, int H, int W, const int* ksizes, int nb, void* stream) {
   const int Co3 = Cout + 3;
-  if (!x || !weight_split || !w1 || !b1 || !w2 || !epipoles_host || !out || !norm_curv || !partial || !ksizes || N < 1 ||
+  if (!x || !weight_split || !w1 || !b1 || !w2 || !epipoles || !out || !norm_curv || !partial || !ksizes || N < 1 ||
       N > CDS_MAX_IMAGES || Cin < 8 || (Cin % 8) || Cout < 1 || Co3 > 48 || (Cout % 16) + 2 > 15 || H < 1 || W < 4 || (W % 4) ||
       nb < 2 || nb > MAXB)
     return CDS_EINVAL;
@@ -424,10 +424,7 @@ extern "C" int cds_dynconv_fused_sbf_f32(const float* x, const float* in_affine,
   br.nks = ks;
   Blend bl;
   bl.w1 = w1; bl.b1 = b1; bl.w2 = w2; bl.out = out; bl.norm_curv = norm_curv; bl.partial = partial; bl.temperature = temperature;
-  for (int n = 0; n < CDS_MAX_IMAGES; ++n) {
-    bl.ex[n] = n < N ? epipoles_host[2 * n] : 0.f;
-    bl.ey[n] = n < N ? epipoles_host[2 * n + 1] : 0.f;
-  }
+  bl.epi = epipoles;
   const int nblk = (Co3 + 15) / 16;
   const int tx = cds_ceil_div(W, TX), ty = cds_ceil_div(H, TY);
   const dim3 grid(tx * ty * N), block(256);

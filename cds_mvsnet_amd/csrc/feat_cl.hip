@@ -35,7 +35,7 @@ struct DynEpi {
   float* norm_curv;     // [N][H][W]
   double* partial;      // [N][tiles][C][2]
   float temperature;
-  float ex[CDS_MAX_IMAGES], ey[CDS_MAX_IMAGES];
+  const float* epi;     // [N][2] DEVICE: epipoles in pixels of this resolution (feat_common.hpp)
 };
 
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
@@ -125,7 +125,7 @@ __device__ __forceinline__ void dyn_epilogue(f32x4 (&acc)[C::NBR][C::NBLK][4], u
     for (int b = 0; b < NBR; ++b)
 #pragma unroll
       for (int j = 0; j < 3; ++j) att[b][j] = attL[(b * 3 + j) * 64 + wp];
-    const float nc = blend_from_att<NBR>(att, px, py, ep.ex[img], ep.ey[img], ep.w1, ep.b1, ep.w2, ep.temperature, logit);
+    const float nc = blend_from_att<NBR>(att, px, py, ep.epi[2 * img], ep.epi[2 * img + 1], ep.w1, ep.b1, ep.w2, ep.temperature, logit);
 #pragma unroll
     for (int b = 0; b < NBR; ++b) wL[b * 64 + wp] = logit[b];
     if (px < W && py < H) ep.norm_curv[((size_t)img * H + py) * W + px] = nc;
@@ -581,7 +581,7 @@ __global__ __launch_bounds__(256) void dynconv_blend_cl_kernel(const float* __re
     const int p = base + 256 * j;
     if (p >= hw) continue;
     float lg[K];
-    norm_curv[(size_t)n * hw + p] = blend_weights<K>(branch, bstride, Cout, hw, p, W, epi.x[n], epi.y[n], w1, b1, w2, temperature, lg);
+    norm_curv[(size_t)n * hw + p] = blend_weights<K>(branch, bstride, Cout, hw, p, W, epi.x(n), epi.y(n), w1, b1, w2, temperature, lg);
     float o[Cout];
 #pragma unroll
     for (int c = 0; c < Cout; ++c) {
@@ -1017,23 +1017,20 @@ extern "C" int cds_dynconv_cl_parts(int H, int W) { return cds_ceil_div(W, TX) *
 
 // One DynamicConv (dynamic_conv.py:97-122) on channels-last activations in ONE kernel.  x [N][H][W][C] (+ in_affine [N][C][3] or
 // NULL), weight_split from ops.split_pack_dynconv (the packing of cds_dynconv_branches_sbf_f32), bias [nb][C + 3] or NULL,
-// w1 [4][nb], b1 [4], w2 [nb][4] the attention MLP with its BatchNorm folded in, epipoles_host [N][2] (pixels at this resolution)
+// w1 [4][nb], b1 [4], w2 [nb][4] the attention MLP with its BatchNorm folded in, epipoles [N][2] (pixels at this resolution)
 // -> out [N][H][W][C] (before its InstanceNorm), norm_curv [N][H][W], partial [N][parts][C][2] doubles with
 // parts = cds_dynconv_cl_parts(H, W) (reduce with cds_instnorm_reduce_f32).  (C, ksizes) in {(8, 3-5-7), (8, 1-3), (16, 3-5),
 // (16, 1-3), (32, 1-3)}: the DynamicConv layers of FeatureNet with Cin == Cout; N <= CDS_MAX_IMAGES; CDS_EINVAL otherwise.
 extern "C" int cds_dynconv_cl_f32(const float* x, const float* in_affine, const void* weight_split, const float* bias,
-                                  const float* w1, const float* b1, const float* w2, const float* epipoles_host, float temperature,
+                                  const float* w1, const float* b1, const float* w2, const float* epipoles, float temperature,
                                   float* out, float* norm_curv, double* partial, int N, int C, int H, int W, const int* ksizes, int nb,
                                   void* stream) {
-  if (!x || !weight_split || !w1 || !b1 || !w2 || !epipoles_host || !out || !norm_curv || !partial || !ksizes || N < 1 ||
+  if (!x || !weight_split || !w1 || !b1 || !w2 || !epipoles || !out || !norm_curv || !partial || !ksizes || N < 1 ||
       N > CDS_MAX_IMAGES || H < 1 || W < 1 || nb < 2 || nb > 3)
     return CDS_EINVAL;
   DynEpi ep;
   ep.w1 = w1; ep.b1 = b1; ep.w2 = w2; ep.out = out; ep.norm_curv = norm_curv; ep.partial = partial; ep.temperature = temperature;
-  for (int n = 0; n < CDS_MAX_IMAGES; ++n) {
-    ep.ex[n] = n < N ? epipoles_host[2 * n] : 0.f;
-    ep.ey[n] = n < N ? epipoles_host[2 * n + 1] : 0.f;
-  }
+  ep.epi = epipoles;
   hipStream_t st = (hipStream_t)stream;
   const int k0 = ksizes[0], k1 = ksizes[1], k2 = nb == 3 ? ksizes[2] : 0;
   if (C == 8 && k0 == 3 && k1 == 5 && k2 == 7) return launch_dynconv_cl<8, 3, 5, 7>(x, in_affine, weight_split, bias, ep, N, H, W, st);
@@ -1047,20 +1044,17 @@ extern "C" int cds_dynconv_cl_f32(const float* x, const float* in_affine, const 
 // conv00 of FeatureNet (DynamicConv 3 -> 8, kernel sizes 3 / 7 / 11) in ONE kernel on the matrix cores, channels-last result.
 // x [S][3][H][W] planar images, S = N - n_shared + 1 slots: slot 0 is shown by the first n_shared output images (the reference copies of a
 // FeatureNet batch, each with its own epipole), slot s > 0 by image n_shared - 1 + s.  weight_split = ops.split_pack_conv00, bias
-// [3][11] or NULL; w1 [4][3], b1 [4], w2 [3][4] the attention MLP; epipoles_host [N][2] -> out [N][H][W][8], norm_curv [N][H][W],
+// [3][11] or NULL; w1 [4][3], b1 [4], w2 [3][4] the attention MLP; epipoles [N][2] -> out [N][H][W][8], norm_curv [N][H][W],
 // partial [N][cds_dynconv_cl_parts(H, W)][8][2] doubles.
 extern "C" int cds_conv00_cl_f32(const float* x, const void* weight_split, const float* bias, const float* w1, const float* b1,
-                                 const float* w2, const float* epipoles_host, float temperature, float* out, float* norm_curv,
+                                 const float* w2, const float* epipoles, float temperature, float* out, float* norm_curv,
                                  double* partial, int N, int n_shared, int H, int W, void* stream) {
-  if (!x || !weight_split || !w1 || !b1 || !w2 || !epipoles_host || !out || !norm_curv || !partial || N < 1 || N > CDS_MAX_IMAGES ||
+  if (!x || !weight_split || !w1 || !b1 || !w2 || !epipoles || !out || !norm_curv || !partial || N < 1 || N > CDS_MAX_IMAGES ||
       n_shared < 1 || n_shared > N || H < 1 || W < 1)
     return CDS_EINVAL;
   DynEpi ep;
   ep.w1 = w1; ep.b1 = b1; ep.w2 = w2; ep.out = out; ep.norm_curv = norm_curv; ep.partial = partial; ep.temperature = temperature;
-  for (int n = 0; n < CDS_MAX_IMAGES; ++n) {
-    ep.ex[n] = n < N ? epipoles_host[2 * n] : 0.f;
-    ep.ey[n] = n < N ? epipoles_host[2 * n + 1] : 0.f;
-  }
+  ep.epi = epipoles;
   const int S = N - n_shared + 1;
   const int tx = cds_ceil_div(W, TX), ty = cds_ceil_div(H, TY);
   hipLaunchKernelGGL(conv00_cl_kernel, dim3(tx * ty * S), dim3(256), (size_t)C00::LDSB, (hipStream_t)stream, x,
@@ -1073,16 +1067,12 @@ extern "C" int cds_blend_cl_parts(int H, int W) { return 4 * cds_ceil_div(H * W,
 // The DynamicConv epilogue of cds_dynconv_blend_stats_f32 with a channels-last result: branches [K][N - n_shared + 1][8 + 3][H][W]
 // planar (the first n_shared images share slot 0) -> out [N][H][W][8], norm_curv [N][H][W], partial [N][cds_blend_cl_parts][8][2].
 extern "C" int cds_dynconv_blend_cl_f32(const float* branches, const float* w1, const float* b1, const float* w2,
-                                        const float* epipoles_host, float temperature, float* out, float* norm_curv, double* partial,
+                                        const float* epipoles, float temperature, float* out, float* norm_curv, double* partial,
                                         int N, int K, int Cout, int H, int W, int n_shared, void* stream) {
-  if (!branches || !w1 || !b1 || !w2 || !epipoles_host || !out || !norm_curv || !partial || N < 1 || N > CDS_MAX_IMAGES || K != 3 ||
+  if (!branches || !w1 || !b1 || !w2 || !epipoles || !out || !norm_curv || !partial || N < 1 || N > CDS_MAX_IMAGES || K != 3 ||
       Cout != 8 || H < 1 || W < 1 || n_shared < 1 || n_shared > N)
     return CDS_EINVAL;
-  EpiBatch epi;
-  for (int n = 0; n < CDS_MAX_IMAGES; ++n) {
-    epi.x[n] = n < N ? epipoles_host[2 * n] : 0.f;
-    epi.y[n] = n < N ? epipoles_host[2 * n + 1] : 0.f;
-  }
+  const EpiBatch epi{epipoles};
   const dim3 grid(cds_ceil_div(H * W, 256 * BCL_PXT), N);
   hipLaunchKernelGGL(dynconv_blend_cl_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, branches, w1, b1, w2, epi, temperature, out,
                      norm_curv, partial, N, H, W, n_shared);

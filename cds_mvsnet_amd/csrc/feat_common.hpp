@@ -25,8 +25,13 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
   return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
 }
 
+// Epipoles of the images of a call: DEVICE [N][2] (x, y in pixels of the layer's resolution), part of the call's geometry block like the
+// homographies (warp_common.hpp): by-value kernel arguments until round 5, device data since, so that a captured graph can be replayed
+// with new cameras.
 struct EpiBatch {
-  float x[CDS_MAX_IMAGES], y[CDS_MAX_IMAGES];
+  const float* p;
+  __device__ __forceinline__ float x(int n) const { return p[2 * n]; }
+  __device__ __forceinline__ float y(int n) const { return p[2 * n + 1]; }
 };
 
 // Per-pixel part of the DynamicConv epilogue (dynamic_conv.py:100-121) from the K x 3 curvature responses att[k][0..2] of pixel

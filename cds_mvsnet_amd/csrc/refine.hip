@@ -1,7 +1,8 @@
 // Refinement network pieces that are not plain 3x3 convolutions (module.py:318-370):
-//   cds_depth_affine_f32     d = (depth - lo) / (hi - lo) * 10                       (module.py:353-355)
+//   cds_depth_affine_f32     d = (depth / ival - lo) / (hi - lo) * 10,  lo = depth_min / ival, hi = depth_max / ival   (model.py:213-216, module.py:353-355)
 //   cds_deconv2d_k3s2_f32    ConvTranspose2d k3 s2 p1 op1 + folded BN + activation    (module.py:331-335,359)
-//   cds_refine_finish_f32    ((bilinear x2, align_corners=True)(d) + res) / 10 * (hi - lo) + lo   (module.py:366-368)
+//   cds_refine_finish_f32    (((bilinear x2, align_corners=True)(d) + res) / 10 * (hi - lo) + lo) * ival   (module.py:366-368, model.py:218)
+// (depth_min, depth_max, ival) are DEVICE scalars of the call's geometry block; ival = 1 gives the network of module.py on its own)
 // The 3x3 Conv+BN+ReLU units run on cds_conv2d_f32 (conv2d.hip).  All of it is a few hundred microseconds of
 // HBM-bound work at 640x512; the kernels are written for clarity, one thread per input cell / output pixel.
 #include "cds_common.hpp"
@@ -9,9 +10,13 @@
 namespace {
 
 __global__ __launch_bounds__(256) void depth_affine_kernel(const float* __restrict__ x, float* __restrict__ out, int n,
-                                                           float lo, float hi) {
+                                                           const float* __restrict__ range_d) {
+  // range_d = (depth_min, depth_max, depth_interval) in DEVICE memory (the call's geometry block): models/model.py:213-216 divides the
+  // depth and both limits by the interval (true divisions), module.py:353-355 normalises
+  const float ival = range_d[2];
+  const float lo = range_d[0] / ival, hi = range_d[1] / ival;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) out[i] = (x[i] - lo) / (hi - lo) * 10.0f;
+  if (i < n) out[i] = (x[i] / ival - lo) / (hi - lo) * 10.0f;
 }
 
 // thread = one input cell (y, x) -> the 2x2 output block (2y.., 2x..) for CO output channels.
@@ -67,7 +72,10 @@ __global__ __launch_bounds__(256) void deconv2d_k3s2_kernel(const float* __restr
 
 // bilinear x2 with align_corners=True: src = dst * (in - 1) / (out - 1); ATen's order l0*v0 + l1*v1 per axis
 __global__ __launch_bounds__(256) void refine_finish_kernel(const float* __restrict__ d, const float* __restrict__ res,
-                                                            float* __restrict__ out, int h, int w, float lo, float hi) {
+                                                            float* __restrict__ out, int h, int w,
+                                                            const float* __restrict__ range_d) {
+  const float ival = range_d[2];
+  const float lo = range_d[0] / ival, hi = range_d[1] / ival;
   const int H = 2 * h, W = 2 * w;
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= H * W) return;
@@ -83,15 +91,15 @@ __global__ __launch_bounds__(256) void refine_finish_kernel(const float* __restr
   const float bot = lx0 * d[y1 * w + x0] + lx1 * d[y1 * w + x1];
   const float up = ly0 * top + ly1 * bot;
   const float v = (up + res[p]) / 10.0f;
-  out[p] = v * (hi - lo) + lo;
+  out[p] = (v * (hi - lo) + lo) * ival;     // module.py:368, then models/model.py:218
 }
 
 }  // namespace
 
-extern "C" int cds_depth_affine_f32(const float* depth, float* out, int n, float lo, float hi, void* stream) {
-  if (!depth || !out || n < 1) return CDS_EINVAL;
-  hipLaunchKernelGGL(depth_affine_kernel, dim3(cds_ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, depth, out, n, lo,
-                     hi);
+extern "C" int cds_depth_affine_f32(const float* depth, float* out, int n, const float* depth_range, void* stream) {
+  if (!depth || !out || !depth_range || n < 1) return CDS_EINVAL;
+  hipLaunchKernelGGL(depth_affine_kernel, dim3(cds_ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, depth, out, n,
+                     depth_range);
   return cds_launch_status();
 }
 
@@ -103,10 +111,10 @@ extern "C" int cds_deconv2d_k3s2_f32(const float* x, const float* weight, const 
   return cds_launch_status();
 }
 
-extern "C" int cds_refine_finish_f32(const float* d_norm, const float* res, float* out, int h, int w, float lo, float hi,
+extern "C" int cds_refine_finish_f32(const float* d_norm, const float* res, float* out, int h, int w, const float* depth_range,
                                      void* stream) {
-  if (!d_norm || !res || !out || h < 1 || w < 1) return CDS_EINVAL;
+  if (!d_norm || !res || !out || !depth_range || h < 1 || w < 1) return CDS_EINVAL;
   hipLaunchKernelGGL(refine_finish_kernel, dim3(cds_ceil_div(4 * h * w, 256)), dim3(256), 0, (hipStream_t)stream, d_norm,
-                     res, out, h, w, lo, hi);
+                     res, out, h, w, depth_range);
   return cds_launch_status();
 }

@@ -128,9 +128,11 @@ __device__ __forceinline__ float cds_clamped_sample(float first, float k, float 
 
 __global__ __launch_bounds__(256) void depth_hypotheses_kernel(const float* __restrict__ prev, float* __restrict__ out,
                                                                int D, int hp, int wp, int H, int W, int h, int w,
-                                                               float interval, float dmin, float dmax) {
+                                                               const float* __restrict__ interval_d,
+                                                               const float* __restrict__ range_d) {
   int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= h * w) return;
+  const float interval = interval_d[0], dmin = range_d[0], dmax = range_d[1];   // the call's geometry block (device scalars)
   int y = p / w, x = p % w;
   const float up_sy = (float)hp / (float)H, up_sx = (float)wp / (float)W;
   const float dn_sy = (float)H / (float)h, dn_sx = (float)W / (float)w;
@@ -154,7 +156,9 @@ __global__ __launch_bounds__(256) void depth_hypotheses_kernel(const float* __re
   }
 }
 
-__global__ void depth_planes_kernel(float* __restrict__ out, int D, size_t hw, float lo, float step) {
+__global__ void depth_planes_kernel(float* __restrict__ out, int D, size_t hw, const float* __restrict__ range_d) {
+  const float lo = range_d[0];
+  const float step = (range_d[1] - lo) / (float)(D - 1);
   size_t n = (size_t)D * hw;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     float k = (float)(i / hw);
@@ -172,21 +176,20 @@ extern "C" int cds_softargmin_conf_f32(const float* prob_pre, const float* hyp, 
 }
 
 extern "C" int cds_depth_hypotheses_f32(const float* prev_depth, float* out, int D, int hp, int wp, int H, int W,
-                                        int scale, float interval, float dmin, float dmax, void* stream) {
-  if (!prev_depth || !out || D < 1 || hp < 1 || wp < 1 || H < 1 || W < 1 || scale < 1 || (H % scale) || (W % scale))
+                                        int scale, const float* interval, const float* depth_range, void* stream) {
+  if (!prev_depth || !out || !interval || !depth_range || D < 1 || hp < 1 || wp < 1 || H < 1 || W < 1 || scale < 1 || (H % scale) || (W % scale))
     return CDS_EINVAL;
   int h = H / scale, w = W / scale;
   hipLaunchKernelGGL(depth_hypotheses_kernel, dim3(cds_ceil_div(h * w, 256)), dim3(256), 0, (hipStream_t)stream,
-                     prev_depth, out, D, hp, wp, H, W, h, w, interval, dmin, dmax);
+                     prev_depth, out, D, hp, wp, H, W, h, w, interval, depth_range);
   return cds_launch_status();
 }
 
-extern "C" int cds_depth_planes_f32(float* out, int D, int h, int w, float lo, float hi, void* stream) {
-  if (!out || D < 2 || h < 1 || w < 1) return CDS_EINVAL;
-  float step = (hi - lo) / (float)(D - 1);
+extern "C" int cds_depth_planes_f32(float* out, int D, int h, int w, const float* depth_range, void* stream) {
+  if (!out || !depth_range || D < 2 || h < 1 || w < 1) return CDS_EINVAL;
   size_t n = (size_t)D * h * w;
   int grid = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
-  hipLaunchKernelGGL(depth_planes_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, out, D, (size_t)h * w, lo,
-                     step);
+  hipLaunchKernelGGL(depth_planes_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, out, D, (size_t)h * w,
+                     depth_range);
   return cds_launch_status();
 }

@@ -16,7 +16,7 @@
 // plain warp  -> out [C][D][h][w]
 // ---------------------------------------------------------------------------------------------
 template <int C>
-__global__ __launch_bounds__(256) void warp_kernel(const float* __restrict__ src, WarpMats mats,
+__global__ __launch_bounds__(256) void warp_kernel(const float* __restrict__ src, const float* __restrict__ mats_d,
                                                    const float* __restrict__ hyp, float* __restrict__ out,
                                                    int D, int h, int w, int hyp_pp, int tiles_x,
                                                    int ntiles) {
@@ -25,6 +25,7 @@ __global__ __launch_bounds__(256) void warp_kernel(const float* __restrict__ src
   int x = tx * CDS_TILE_X + (threadIdx.x & 63);
   int y = ty * CDS_TILE_Y + (threadIdx.x >> 6);
   if (x >= w || y >= h) return;
+  const MatRegs<1> mats(mats_d);
   const float half_w = (float)((w - 1) / 2.0), half_h = (float)((h - 1) / 2.0);
   float r[3];
   cds_row_terms(mats.m[0], (float)x, (float)y, r);
@@ -55,7 +56,7 @@ __global__ __launch_bounds__(256) void warp_kernel(const float* __restrict__ src
 // (small images: 4x the workgroups, 1/4 of the serial plane loop).
 template <int C, int DS>
 __global__ __launch_bounds__(256) void warp_entropy_kernel(const float* __restrict__ ref,
-                                                           const float* __restrict__ src, WarpMats mats,
+                                                           const float* __restrict__ src, const float* __restrict__ mats_d,
                                                            const float* __restrict__ hyp,
                                                            float* __restrict__ entropy, int V, int D, int h,
                                                            int w, int hyp_pp, int tiles_x, int ntiles) {
@@ -79,12 +80,13 @@ __global__ __launch_bounds__(256) void warp_entropy_kernel(const float* __restri
   float rf[C];
 #pragma unroll
   for (int c = 0; c < C; ++c) rf[c] = ref[((size_t)v * C + c) * hw + pix];
+  const MatRegs<1> mats(mats_d + v * 12);
   float r[3];
-  cds_row_terms(mats.m[v], (float)x, (float)y, r);
+  cds_row_terms(mats.m[0], (float)x, (float)y, r);
   float m = -INFINITY, Z = 0.f, T = 0.f;
   for (int d = slice; d < D; d += DS) {
     float dv = hyp_pp ? hyp[d * hw + pix] : hyp[d];
-    Taps tp = cds_taps(r, mats.m[v] + 9, dv, h, w, half_w, half_h);
+    Taps tp = cds_taps(r, mats.m[0] + 9, dv, h, w, half_w, half_h);
     float s = 0.f;
     // ATen's outer-dim sum: sequential inside 16-row levels, then level sums added.
 #pragma unroll
@@ -149,10 +151,11 @@ __global__ __launch_bounds__(256) void warp_entropy_kernel(const float* __restri
 // ---------------------------------------------------------------------------------------------
 template <int VMAX>
 __global__ __launch_bounds__(256) void warp_aggregate_kernel(
-    const float* __restrict__ ref, const float* __restrict__ src, const float* __restrict__ vis, WarpMats mats,
+    const float* __restrict__ ref, const float* __restrict__ src, const float* __restrict__ vis, const float* __restrict__ mats_d,
     const float* __restrict__ hyp, float* __restrict__ volume, const float* __restrict__ vis_sum, int V, int C,
     int D, int h, int w, int hyp_pp, int flags, int tiles_x, int ntiles, int nseg, int seg_planes) {
   constexpr int CG = 8;
+  const MatRegs<VMAX> mats(mats_d, V);
   const int ngroups = C / CG;
   // depth segment fastest, then channel group: the blocks of one pixel tile run together (same features in L2).
   // Small images (cascade stage 1: 160x128) would otherwise give 1-2 workgroups per CU looping over all planes.
@@ -294,10 +297,10 @@ __global__ void chw_to_hwc_kernel(const float* __restrict__ src, float* __restri
 // host entry points
 // ---------------------------------------------------------------------------------------------
 // LDS-staged fast paths (warp_lds.hip); return false when the shape is not covered.
-bool cds_warp_aggregate_lds_launch(const float* ref, const float* src, const float* vis, const WarpMats& wm,
+bool cds_warp_aggregate_lds_launch(const float* ref, const float* src, const float* vis, const float* wm,
                                    const float* hyp, float* volume, const float* vis_sum, int V, int C, int D, int h,
                                    int w, int hyp_pp, int flags, hipStream_t st, int hs = 0, int y_off = 0);
-bool cds_warp_entropy_lds_launch(const float* ref, const float* src, const WarpMats& wm, const float* hyp,
+bool cds_warp_entropy_lds_launch(const float* ref, const float* src, const float* wm, const float* hyp,
                                  float* entropy, int V, int C, int D, int h, int w, int hyp_pp, bool fast, hipStream_t st, int hs = 0,
                                  int y_off = 0);
 static bool cds_use_lds_path() {
@@ -315,11 +318,6 @@ static bool cds_warp_window_ok(int V, int C, int D, int h, int w, int hs, int y_
          (size_t)D * h * w * 4 < ((size_t)1 << 32);
 }
 
-static void cds_fill_mats(WarpMats& wm, const float* mats_host, int V) {
-  for (int v = 0; v < CDS_MAX_VIEWS; ++v)
-    for (int i = 0; i < 12; ++i) wm.m[v][i] = v < V ? mats_host[v * 12 + i] : 0.f;
-}
-
 extern "C" int cds_chw_to_hwc_f32(const float* src_chw, float* dst_hwc, int C, int h, int w, void* stream) {
   if (!src_chw || !dst_hwc || C < 4 || (C % 4) || h < 1 || w < 1) return CDS_EINVAL;
   int hw = h * w;
@@ -328,11 +326,10 @@ extern "C" int cds_chw_to_hwc_f32(const float* src_chw, float* dst_hwc, int C, i
   return cds_launch_status();
 }
 
-extern "C" int cds_homo_warp_f32(const float* src_hwc, const float* mat_host, const float* hyp, float* out, int C,
+extern "C" int cds_homo_warp_f32(const float* src_hwc, const float* mat, const float* hyp, float* out, int C,
                                  int D, int h, int w, int hyp_per_pixel, void* stream) {
-  if (!src_hwc || !mat_host || !hyp || !out || !cds_warp_args_ok(1, C, D, h, w)) return CDS_EINVAL;
-  WarpMats wm;
-  cds_fill_mats(wm, mat_host, 1);
+  if (!src_hwc || !mat || !hyp || !out || !cds_warp_args_ok(1, C, D, h, w)) return CDS_EINVAL;
+  const float* wm = mat;
   int tiles_x = cds_ceil_div(w, CDS_TILE_X), tiles_y = cds_ceil_div(h, CDS_TILE_Y);
   int ntiles = tiles_x * tiles_y;
   hipStream_t st = (hipStream_t)stream;
@@ -346,18 +343,17 @@ extern "C" int cds_homo_warp_f32(const float* src_hwc, const float* mat_host, co
   return cds_launch_status();
 }
 
-extern "C" int cds_warp_entropy_f32(const float* ref_chw, const float* src_hwc, const float* mats_host,
+extern "C" int cds_warp_entropy_f32(const float* ref_chw, const float* src_hwc, const float* mats,
                                     const float* hyp, float* entropy, int V, int C, int D, int h, int w,
                                     int hyp_per_pixel, void* stream) {
-  return cds_warp_entropy_flags_f32(ref_chw, src_hwc, mats_host, hyp, entropy, V, C, D, h, w, hyp_per_pixel, 0, stream);
+  return cds_warp_entropy_flags_f32(ref_chw, src_hwc, mats, hyp, entropy, V, C, D, h, w, hyp_per_pixel, 0, stream);
 }
 
-extern "C" int cds_warp_entropy_flags_f32(const float* ref_chw, const float* src_hwc, const float* mats_host,
+extern "C" int cds_warp_entropy_flags_f32(const float* ref_chw, const float* src_hwc, const float* mats,
                                           const float* hyp, float* entropy, int V, int C, int D, int h, int w,
                                           int hyp_per_pixel, int flags, void* stream) {
-  if (!ref_chw || !src_hwc || !mats_host || !hyp || !entropy || !cds_warp_args_ok(V, C, D, h, w)) return CDS_EINVAL;
-  WarpMats wm;
-  cds_fill_mats(wm, mats_host, V);
+  if (!ref_chw || !src_hwc || !mats || !hyp || !entropy || !cds_warp_args_ok(V, C, D, h, w)) return CDS_EINVAL;
+  const float* wm = mats;
   int tiles_x = cds_ceil_div(w, CDS_TILE_X), tiles_y = cds_ceil_div(h, CDS_TILE_Y);
   int ntiles = tiles_x * tiles_y;
   hipStream_t st = (hipStream_t)stream;
@@ -387,25 +383,23 @@ extern "C" int cds_warp_entropy_flags_f32(const float* ref_chw, const float* src
 // weights, entropy / volume outputs) cover rows [y_off, y_off + h) of the hs x w image grid, the source maps the whole grid.
 // Sample positions are computed from the GLOBAL pixel row, so the window of a result is bit-identical to the same rows of the
 // full-grid call.  LDS-staged kernels only (per-pixel hypotheses, C in {8, 16, 32}): anything else is CDS_EINVAL.
-extern "C" int cds_warp_entropy_window_f32(const float* ref_chw, const float* src_hwc, const float* mats_host, const float* hyp,
+extern "C" int cds_warp_entropy_window_f32(const float* ref_chw, const float* src_hwc, const float* mats, const float* hyp,
                                            float* entropy, int V, int C, int D, int h, int w, int hs, int y_off, int flags,
                                            void* stream) {
-  if (!ref_chw || !src_hwc || !mats_host || !hyp || !entropy || !cds_warp_window_ok(V, C, D, h, w, hs, y_off)) return CDS_EINVAL;
-  WarpMats wm;
-  cds_fill_mats(wm, mats_host, V);
+  if (!ref_chw || !src_hwc || !mats || !hyp || !entropy || !cds_warp_window_ok(V, C, D, h, w, hs, y_off)) return CDS_EINVAL;
+  const float* wm = mats;
   if (!cds_warp_entropy_lds_launch(ref_chw, src_hwc, wm, hyp, entropy, V, C, D, h, w, 1, (flags & CDS_WARP_FAST_POSITIONS) != 0,
                                    (hipStream_t)stream, hs, y_off))
     return CDS_EINVAL;
   return cds_launch_status();
 }
 
-extern "C" int cds_warp_aggregate_window_f32(const float* ref_chw, const float* src_hwc, const float* vis_w, const float* mats_host,
+extern "C" int cds_warp_aggregate_window_f32(const float* ref_chw, const float* src_hwc, const float* vis_w, const float* mats,
                                              const float* hyp, float* volume, float* vis_sum, int V, int C, int D, int h, int w,
                                              int hs, int y_off, int flags, void* stream) {
-  if (!ref_chw || !src_hwc || !vis_w || !mats_host || !hyp || !volume || !vis_sum || !cds_warp_window_ok(V, C, D, h, w, hs, y_off))
+  if (!ref_chw || !src_hwc || !vis_w || !mats || !hyp || !volume || !vis_sum || !cds_warp_window_ok(V, C, D, h, w, hs, y_off))
     return CDS_EINVAL;
-  WarpMats wm;
-  cds_fill_mats(wm, mats_host, V);
+  const float* wm = mats;
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(vis_sum_kernel, dim3(cds_ceil_div(h * w, 256)), dim3(256), 0, st, vis_w, vis_sum, V, h * w,
                      flags & CDS_AGG_ACCUMULATE);
@@ -415,12 +409,11 @@ extern "C" int cds_warp_aggregate_window_f32(const float* ref_chw, const float* 
 }
 
 extern "C" int cds_warp_aggregate_f32(const float* ref_chw, const float* src_hwc, const float* vis_w,
-                                      const float* mats_host, const float* hyp, float* volume, float* vis_sum, int V,
+                                      const float* mats, const float* hyp, float* volume, float* vis_sum, int V,
                                       int C, int D, int h, int w, int hyp_per_pixel, int flags, void* stream) {
-  if (!ref_chw || !src_hwc || !vis_w || !mats_host || !hyp || !volume || !vis_sum || !cds_warp_args_ok(V, C, D, h, w))
+  if (!ref_chw || !src_hwc || !vis_w || !mats || !hyp || !volume || !vis_sum || !cds_warp_args_ok(V, C, D, h, w))
     return CDS_EINVAL;
-  WarpMats wm;
-  cds_fill_mats(wm, mats_host, V);
+  const float* wm = mats;
   int tiles_x = cds_ceil_div(w, CDS_TILE_X), tiles_y = cds_ceil_div(h, CDS_TILE_Y);
   int ntiles = tiles_x * tiles_y;
   int ngroups = C / 8;

@@ -13,7 +13,7 @@ namespace {
 
 __global__ __launch_bounds__(256) void warp_aggregate_bwd_kernel(const float* __restrict__ ref,
                                                                  const float* __restrict__ src,
-                                                                 const float* __restrict__ vis, WarpMats mats,
+                                                                 const float* __restrict__ vis, const float* __restrict__ mats_d,
                                                                  const float* __restrict__ hyp,
                                                                  const float* __restrict__ gvol, float* __restrict__ gref,
                                                                  float* __restrict__ gsrc, float* __restrict__ gvis, int V,
@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void warp_aggregate_bwd_kernel(const float* __
   float* __restrict__ gsrcv = gsrc + (size_t)v * hw * C;
   float m[12];
 #pragma unroll
-  for (int i = 0; i < 12; ++i) m[i] = mats.m[v][i];
+  for (int i = 0; i < 12; ++i) m[i] = mats_d[v * 12 + i];
   float r[3];
   cds_row_terms(m, (float)x, (float)y, r);
   const float vw = vis[(size_t)v * hw + pix];
@@ -129,7 +129,8 @@ __global__ __launch_bounds__(256) void warp_aggregate_bwd_kernel(const float* __
 // is independent of the order the lanes arrive in.  Non-finite M (a NaN / inf in the gradient) takes the fp32 direct scatter, which
 // propagates it.
 #ifndef CDS_K3BWD_BOX
-#define CDS_K3BWD_BOX 1024   // texels: 64 KB of LDS -> two workgroups per CU (build with a tiny value to force the fallback path)
+#define CDS_K3BWD_BOX 1024   // texels: (1024 + 1) x 8 channels x 8 B = 65 600 B of LDS (+ 20 B of limits) -> two workgroups per gfx950 CU (160 KB);
+                             // over the 64 KB of gfx942 / gfx90a on purpose - this library is gfx950-only (static_assert below).  Build with a tiny value to force the fallback path
 #endif
 constexpr int BWD_BOX = CDS_K3BWD_BOX;
 
@@ -176,7 +177,7 @@ __device__ __forceinline__ TapsXY cds_taps_xy(const float r[3], const float* __r
 }
 
 __global__ __launch_bounds__(256) void warp_aggregate_bwd_box_kernel(const float* __restrict__ ref, const float* __restrict__ src,
-                                                                     const float* __restrict__ vis, WarpMats mats,
+                                                                     const float* __restrict__ vis, const float* __restrict__ mats_d,
                                                                      const float* __restrict__ hyp,
                                                                      const float* __restrict__ gvol, float* __restrict__ gref,
                                                                      float* __restrict__ gsrc, float* __restrict__ gvis, int V,
@@ -185,6 +186,7 @@ __global__ __launch_bounds__(256) void warp_aggregate_bwd_box_kernel(const float
   constexpr int CG = 8;
   constexpr int BOXP = BWD_BOX + 1;                         // channel-planar [c][texel]: the lanes of one ds_add (neighbouring pixels) hit neighbouring words
   __shared__ long long box[BOXP * CG];
+  static_assert((size_t)BOXP * CG * 8 + 32 <= 80 * 1024, "K3 backward box: two workgroups must fit the 160 KB LDS of a gfx950 CU");
   __shared__ int lim[4];                                   // xmin, ymin, xmax, ymax of the touched texels
   __shared__ unsigned mbits;                               // bits of M = max |g ref vis| (non-negative floats order like their bit patterns; NaN on top)
   const int ngroups = C / CG;
@@ -206,7 +208,7 @@ __global__ __launch_bounds__(256) void warp_aggregate_bwd_box_kernel(const float
   float* __restrict__ gsrcv = gsrc + (size_t)v * hw * C;
   float m[12];
 #pragma unroll
-  for (int i = 0; i < 12; ++i) m[i] = mats.m[v][i];
+  for (int i = 0; i < 12; ++i) m[i] = mats_d[v * 12 + i];
   float r[3];
   cds_row_terms(m, (float)x, (float)y, r);
   const int d_lo = seg * seg_planes, d_hi = min(D, d_lo + seg_planes);
@@ -346,15 +348,13 @@ __global__ __launch_bounds__(256) void warp_aggregate_bwd_box_kernel(const float
 }  // namespace
 
 extern "C" int cds_warp_aggregate_bwd_f32(const float* ref_chw, const float* src_hwc, const float* vis_w,
-                                          const float* mats_host, const float* hyp, const float* grad_volume,
+                                          const float* mats, const float* hyp, const float* grad_volume,
                                           float* grad_ref, float* grad_src_hwc, float* grad_vis, int V, int C, int D, int h,
                                           int w, int hyp_per_pixel, void* stream) {
-  if (!ref_chw || !src_hwc || !vis_w || !mats_host || !hyp || !grad_volume || !grad_ref || !grad_src_hwc || !grad_vis ||
+  if (!ref_chw || !src_hwc || !vis_w || !mats || !hyp || !grad_volume || !grad_ref || !grad_src_hwc || !grad_vis ||
       V < 1 || V > CDS_MAX_VIEWS || (C != 8 && C != 16 && C != 32) || D < 1 || h < 1 || w < 1)
     return CDS_EINVAL;
-  WarpMats wm;
-  for (int v = 0; v < CDS_MAX_VIEWS; ++v)
-    for (int i = 0; i < 12; ++i) wm.m[v][i] = v < V ? mats_host[v * 12 + i] : 0.f;
+  const float* wm = mats;
   const int tiles_x = cds_ceil_div(w, CDS_TILE_X), tiles_y = cds_ceil_div(h, CDS_TILE_Y);
   const int ntiles = tiles_x * tiles_y;
   const int base = ntiles * V * (C / 8);

@@ -2,8 +2,20 @@
 #pragma once
 #include "cds_common.hpp"
 
-struct WarpMats {
-  float m[CDS_MAX_VIEWS][12];
+// The homographies of a call live in DEVICE memory: mats_d = [V][12] floats (rows of (P_src P_ref^-1)[:3,:3], then its [:3,3]), part of the
+// call's geometry block (cds_mvsnet_amd/geometry.py: one small host -> device copy per forward).  They were by-value kernel
+// arguments until round 5; as device data a captured hipGraph of the forward / the training step is re-targeted at new cameras by
+// rewriting the block before the replay.  The values are wave-uniform: the loads are scalar (s_load) and what a
+// kernel keeps of them stays in SGPRs.
+template <int NV>
+struct MatRegs {
+  float m[NV][12];
+  __device__ __forceinline__ explicit MatRegs(const float* __restrict__ mats_d, int V = NV) {
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+#pragma unroll
+      for (int i = 0; i < 12; ++i) m[v][i] = v < V ? mats_d[v * 12 + i] : 0.f;
+  }
 };
 
 struct Taps {

@@ -384,13 +384,14 @@ __device__ __forceinline__ void plane_weights(v2f ix, v2f iy, v2f& x0f, v2f& y0f
 // ---------------------------------------------------------------------------------------------
 template <int VMAX, bool ACCUMULATE, bool NORMALIZE, bool FAST, int CAP>
 __global__ __launch_bounds__(256, CDS_K3_MINW) void warp_aggregate_lds_kernel(
-    const float* __restrict__ ref, const float* __restrict__ src, const float* __restrict__ vis, WarpMats mats,
+    const float* __restrict__ ref, const float* __restrict__ src, const float* __restrict__ vis, const float* __restrict__ mats_d,
     const float* __restrict__ hyp, float* __restrict__ volume, const float* __restrict__ vis_sum, int C, int D, int h,
     int w, float rhw, float rhh, int flags, int tiles_x, int ntiles, int nseg, int seg_planes, int hs, int y_off) {
   // h x w: the reference-side grid of this call (features, hypotheses, weights, volume); it is the window of rows
   // [y_off, y_off + h) of the full image grid hs x w that the SOURCE feature maps cover (hs == h, y_off == 0: the whole grid)
   extern __shared__ __attribute__((aligned(16))) cds_f4 lds4[];  // VMAX * 2*CAP float4, then int red[4*VMAX*4], int boxes[VMAX*4]
   int* red = reinterpret_cast<int*>(lds4 + VMAX * 2 * CAP);
+  const MatRegs<VMAX> mats(mats_d);
 
   // depth segment is the fastest-varying index: the nseg blocks of a tile run together and share its features in L2
   // then the group of 8 channels (C = 16 / 32: one workgroup per group; the groups of a tile run together, so the
@@ -653,7 +654,7 @@ __device__ __forceinline__ void online_entropy_update(float s, float& mx, float&
 // 79 KB, two workgroups per CU at C = 32).  A box that does not fit halves its chunk, as in K3.
 template <int NG, int CAP, int DCK, bool FAST>
 __global__ __launch_bounds__(256, (NG == 4 ? 2 : CDS_K1_MINW)) void warp_entropy_lds_kernel(
-    const float* __restrict__ ref, const float* __restrict__ src, WarpMats mats, const float* __restrict__ hyp,
+    const float* __restrict__ ref, const float* __restrict__ src, const float* __restrict__ mats_d, const float* __restrict__ hyp,
     float* __restrict__ entropy, int V, int D, int h, int w, float rhw, float rhh, int tiles_x, int ntiles, int hs, int y_off) {
   // h x w = rows [y_off, y_off + h) of the full hs x w grid of the source maps (see warp_aggregate_lds_kernel)
   constexpr int C = NG * C8;
@@ -676,7 +677,7 @@ __global__ __launch_bounds__(256, (NG == 4 ? 2 : CDS_K1_MINW)) void warp_entropy
   const float* __restrict__ srcv = src + (size_t)v * hs * w * C;
   float m[12];
 #pragma unroll
-  for (int i = 0; i < 12; ++i) m[i] = mats.m[v][i];
+  for (int i = 0; i < 12; ++i) m[i] = mats_d[v * 12 + i];
   v2f rf[NG][4];
 #pragma unroll
   for (int q = 0; q < NG; ++q)
@@ -789,7 +790,7 @@ __global__ __launch_bounds__(256, (NG == 4 ? 2 : CDS_K1_MINW)) void warp_entropy
 }  // namespace
 
 // Launchers used by the extern "C" entry points in warp.hip.  Return false if the shape is not covered.
-bool cds_warp_aggregate_lds_launch(const float* ref, const float* src, const float* vis, const WarpMats& wm,
+bool cds_warp_aggregate_lds_launch(const float* ref, const float* src, const float* vis, const float* wm,
                                    const float* hyp, float* volume, const float* vis_sum, int V, int C, int D, int h,
                                    int w, int hyp_pp, int flags, hipStream_t st, int hs, int y_off) {
   if (hs <= 0) { hs = h; y_off = 0; }      // whole grid
@@ -804,9 +805,7 @@ bool cds_warp_aggregate_lds_launch(const float* ref, const float* src, const flo
     // partial sums (and normalises).  Costs one extra read of the volume, still far cheaper than L1 gathers.
     const int v1 = (V + 1) / 2;
     const size_t hw = (size_t)h * w, hws = (size_t)hs * w;
-    WarpMats wm2;
-    for (int v = 0; v < CDS_MAX_VIEWS; ++v)
-      for (int i = 0; i < 12; ++i) wm2.m[v][i] = (v + v1 < CDS_MAX_VIEWS) ? wm.m[v + v1][i] : 0.f;
+    const float* wm2 = wm + (size_t)v1 * 12;
     const int keep = flags & (CDS_AGG_CHANNELS_LAST | CDS_AGG_FAST_POSITIONS);
     return cds_warp_aggregate_lds_launch(ref, src, vis, wm, hyp, volume, vis_sum, v1, C, D, h, w, hyp_pp,
                                          (flags & CDS_AGG_ACCUMULATE) | keep, st, hs, y_off) &&
@@ -856,7 +855,7 @@ bool cds_warp_aggregate_lds_launch(const float* ref, const float* src, const flo
   return true;
 }
 
-bool cds_warp_entropy_lds_launch(const float* ref, const float* src, const WarpMats& wm, const float* hyp,
+bool cds_warp_entropy_lds_launch(const float* ref, const float* src, const float* wm, const float* hyp,
                                  float* entropy, int V, int C, int D, int h, int w, int hyp_pp, bool fast, hipStream_t st, int hs,
                                  int y_off) {
   if (hs <= 0) { hs = h; y_off = 0; }

@@ -29,9 +29,16 @@ class _FusedLoss(torch.autograd.Function):
         from . import _lib, ops
         from ._lib import check
         lib = _lib.load()
-        dev = interval.device
-        st = ops._stream(interval)
-        interval = interval.detach().float().contiguous()
+        dev = tensors[0].device
+        st = ops._stream(tensors[0])
+        interval = interval.detach().float().contiguous().reshape(-1)
+        B0 = tensors[0].shape[0]
+        if interval.numel() == 1 and B0 > 1:
+            interval = interval.expand(B0).contiguous()      # a scalar interval broadcasts, as in final_loss_aten
+        if interval.numel() != B0 or interval.device != tensors[0].device:
+            # the kernels read interval[b] for b < B on the depth's device: anything else is an out-of-bounds / wrong-device read
+            raise ValueError(f"final_loss: depth_interval must hold one value per batch item on the depth's device "
+                             f"(got {interval.numel()} values on {interval.device} for a batch of {B0} on {tensors[0].device})")
         stages, k = [], 0
         for has_nc, has_feat in layout:
             depth, gt, mask = (t.detach().float().contiguous() for t in tensors[k:k + 3])

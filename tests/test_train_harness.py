@@ -103,38 +103,87 @@ def _train_sample(dev, B=1, N=3, H=64, W=96):
     return {"imgs": imgs, "proj_matrices": cams, "depth_values": dv, "depth": gt, "mask": mask}
 
 
+def _backward_gradients(model, sample, side, passes=2):
+    """`passes` forward + backward passes on FIXED weights (no optimiser step); the gradients of the last one.  With the side stream
+    allowed the first backward of a model is the single-stream audit (train._backward), the second runs the weight-gradient kernels
+    on the side stream; the single-stream runs make the same two passes so both see the same allocator history."""
+    from cds_mvsnet_amd.losses import final_loss
+    T.SIDE_STREAM_WGRAD = side
+    dv = sample["depth_values"]
+    model.train()
+    loss = None
+    for _ in range(passes):
+        model.zero_grad(set_to_none=True)
+        out = model(sample["imgs"], sample["proj_matrices"], dv, gt_depths=sample["depth"], temperature=0.1)
+        loss, _d = final_loss(out, sample["depth"], sample["mask"], dlossw=[0.5, 1.0, 2.0], depth_interval=dv[:, 1] - dv[:, 0])
+        T._backward(model, loss)
+    torch.cuda.synchronize()
+    return float(loss.detach()), {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+
+
+def _gradient_gap(a, b):
+    """(worst max|a-b| / max|b| over the parameters, its name)."""
+    worst = (0.0, "")
+    for n in b:
+        gap = float((a[n] - b[n]).abs().max() / (b[n].abs().max() + 1e-30))
+        if not np.isfinite(gap) or gap > worst[0]:
+            worst = (gap, n)
+    return worst
+
+
+@pytest.mark.gpu
+def test_side_stream_gradients_equal_single_stream_gradients():
+    """The weight-gradient side stream (on by default, train.SIDE_STREAM_WGRAD) against the single stream on ONE backward pass from
+    identical weights, every parameter gradient tensor by tensor - the well-conditioned form of the question "is the side stream
+    sound" (the round-5 form compared the loss after three SGD steps at lr 1e-3, a divergent regime - the losses rose 85.5 -> 89.0 -
+    in which last-bit gradient noise is amplified ~1e4 x and no bound separates a race from chaos).
+    The fp32 atomics of the K3 backward and weight-gradient kernels make two single-stream runs differ in the last bits: that
+    off-vs-off figure is the noise floor, the on-vs-off gap must stay within 3 x of it (and under 1e-4 of the tensor's largest
+    entry: a kernel reading a half-written buffer moves a gradient by O(1) of its magnitude, not by 1e-5).  Repeated with a used
+    allocator and back to back so that a race has several chances to show."""
+    from cds_mvsnet_amd import CDSMVSNet, seeded_init_, _scratch
+    dev = torch.device("cuda")
+    sample = _train_sample(dev)
+    old = T.SIDE_STREAM_WGRAD
+    junk = [torch.randn(1 << (10 + i % 12), device=dev) for i in range(200)]      # a used allocator: freed blocks get recycled
+    del junk[::2]
+    try:
+        model = seeded_init_(CDSMVSNet(refine=False, ndepths=(48, 32, 8), depth_interals_ratio=(4.0, 2.0, 1.0)), 7).to(dev)
+        for trial in range(3):
+            l_off, g_off = _backward_gradients(model, sample, False)
+            l_off2, g_off2 = _backward_gradients(model, sample, False)
+            l_on, g_on = _backward_gradients(model, sample, True)
+            key, sound = T._SIDE_VERDICT[model]
+            assert sound is True                              # one gradient per parameter, handed over untouched: the audit passed
+            assert _scratch._dev_state(dev).side is not None   # ... and the second pass did launch on the side stream
+            assert set(g_on) == set(g_off) and len(g_on) > 200      # 212 trainable tensors (the 387 state-dict entries include buffers)
+            assert l_on == pytest.approx(l_off, rel=1e-6) and l_off2 == pytest.approx(l_off, rel=1e-6)     # the same forward
+            noise, n_noise = _gradient_gap(g_off2, g_off)
+            gap, n_gap = _gradient_gap(g_on, g_off)
+            print(f"[side stream] trial {trial}: on-vs-off {gap:.2e} ({n_gap}); off-vs-off {noise:.2e} ({n_noise}); loss {l_off:.6f}")
+            assert np.isfinite(gap) and gap <= max(3.0 * noise, 2e-6) and gap <= 1e-4, \
+                f"trial {trial}: side stream vs single stream {gap:.2e} ({n_gap}); single vs single {noise:.2e} ({n_noise})"
+    finally:
+        T.SIDE_STREAM_WGRAD = old
+
+
 @pytest.mark.gpu
 def test_train_step_fp32():
-    """Three optimisation steps from the same weights with the weight-gradient side stream allowed and forbidden: step 1 audits a
-    single-stream backward (train._backward), steps 2 and 3 run the weight gradients on the side stream when the audit allows it;
-    the loss of step 3 depends on the gradients of both kinds of step and must agree with the single-stream run as well as two
-    single-stream runs agree with each other: the fp32 atomics of the K3 / weight-gradient kernels make the gradients of a step differ
-    from run to run in the last bits, and two Adam updates at lr 1e-3 turn that into 1e-3 .. 4e-3 of the step-3 loss
-    (scripts/ab/r05_side_stream_diag.py: six trials, single-stream runs 88.34 .. 88.60), so a fixed bound is a coin flip."""
+    """Four optimisation steps (trainer/trainer.py:69-82) at the configuration's own learning rate (configs/config_blended.json:
+    SGD, lr 1e-4, weight decay 0.01) with the side stream as configured: every loss finite, every layer trained, and the loss does not
+    rise over the steps (same batch: plain gradient descent at a stable step size).  Smoke only - what the side stream does to the
+    gradients is test_side_stream_gradients_equal_single_stream_gradients' business."""
     from cds_mvsnet_amd import CDSMVSNet, seeded_init_
     dev = torch.device("cuda")
     sample = _train_sample(dev)
-    losses = {}
-    old = T.SIDE_STREAM_WGRAD
-    try:
-        for side in (False, "again", True):
-            T.SIDE_STREAM_WGRAD = side is True
-            model = seeded_init_(CDSMVSNet(refine=False, ndepths=(48, 32, 8), depth_interals_ratio=(4.0, 2.0, 1.0)), 7).to(dev)
-            opt = T.make_optimizer(model, lr=1e-3)
-            before = {n: p.detach().clone() for n, p in model.named_parameters()}
-            ls = [T.train_step(model, opt, sample, temperature=0.1, reducer=T.GradAllReducer(model.parameters())) for _ in range(3)]
-            assert all(np.isfinite(l) and np.isfinite(d) and d > 0 for l, d in ls)
-            moved = sum(1 for n, p in model.named_parameters() if not torch.equal(p.detach(), before[n]))
-            assert moved > 0.9 * len(before)                 # every layer is trained (weight decay touches all of them)
-            losses[side] = ls
-            if side is True:
-                assert T._SIDE_VERDICT[model][1] is True      # one gradient per parameter, handed over untouched: the side stream is sound
-    finally:
-        T.SIDE_STREAM_WGRAD = old
-    assert abs(losses[True][0][0] - losses[False][0][0]) <= 1e-5 * abs(losses[False][0][0])
-    assert abs(losses[True][1][0] - losses[False][1][0]) <= 1e-5 * abs(losses[False][1][0])
-    noise = abs(losses["again"][2][0] - losses[False][2][0])
-    assert abs(losses[True][2][0] - losses[False][2][0]) <= max(3 * noise, 5e-3 * abs(losses[False][2][0])), losses
+    model = seeded_init_(CDSMVSNet(refine=False, ndepths=(48, 32, 8), depth_interals_ratio=(4.0, 2.0, 1.0)), 7).to(dev)
+    opt = T.make_optimizer(model)                            # SGD(lr 1e-4, weight_decay 0.01)
+    before = {n: p.detach().clone() for n, p in model.named_parameters()}
+    ls = [T.train_step(model, opt, sample, temperature=0.1, reducer=T.GradAllReducer(model.parameters())) for _ in range(4)]
+    assert all(np.isfinite(l) and np.isfinite(d) and d > 0 for l, d in ls), ls
+    moved = sum(1 for n, p in model.named_parameters() if not torch.equal(p.detach(), before[n]))
+    assert moved > 0.9 * len(before)                         # every layer is trained (weight decay touches all of them)
+    assert ls[-1][0] <= ls[0][0] * (1 + 1e-4), ls            # no rise
 
 
 @pytest.mark.gpu
