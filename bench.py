@@ -224,7 +224,7 @@ def k3_stage_rooflines(model, dev, H=1184, W=1600, n_views=5):
         ref = torch.stack([f["ref"][0][0] for f in feats]).to(dev).contiguous()
         src = torch.stack([ops.chw_to_hwc(f["src"][0][0].to(dev).contiguous()) for f in feats])
         vis = (torch.rand(V, h, w, generator=g) * 0.9 + 0.05).to(dev)
-        mats, hyp_d = geometry.warp_matrices(cams[0]), hyp.to(dev)
+        mats, hyp_d = ops.geo(geometry.warp_matrices(cams[0]), dev, "mats"), hyp.to(dev)   # homographies are device data (geometry block)
         ts = []
         for i in range(9):
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -45,8 +45,8 @@ SIGNATURES = {
     "cds_volume_normalize_f32": [P, P, I, I, I, P],
     "cds_volume_normalize_cl_f32": [P, P, I, I, I, P],
     "cds_softargmin_conf_f32": [P, P, P, P, P, I, I, I, I, P],
-    "cds_depth_hypotheses_f32": [P, P, I, I, I, I, I, I, F, F, F, P],
-    "cds_depth_planes_f32": [P, I, I, I, F, F, P],
+    "cds_depth_hypotheses_f32": [P, P, I, I, I, I, I, I, P, P, P],
+    "cds_depth_planes_f32": [P, I, I, I, P, P],
     "cds_conv3d_k3_f32": [P, P, P, P, P, I, I, I, I, I, I, I, P],
     "cds_conv3d_k3_cl_f32": [P, P, P, P, P, I, I, I, I, I, I, P],
     "cds_conv3d_sbf_f32": [P, P, P, P, P, I, I, I, I, I, I, I, P],
@@ -89,9 +89,9 @@ SIGNATURES = {
     "cds_curvature_stats_bwd_f32": [P, P, P, P, P, P, P, P, I, P],
     "cds_pair_mean_f32": [P, P, I, I, P],
     "cds_view_mean_f32": [P, P, I, I, P],
-    "cds_depth_affine_f32": [P, P, I, F, F, P],
+    "cds_depth_affine_f32": [P, P, I, P, P],
     "cds_deconv2d_k3s2_f32": [P, P, P, P, I, I, I, I, I, P],
-    "cds_refine_finish_f32": [P, P, P, I, I, F, F, P],
+    "cds_refine_finish_f32": [P, P, P, I, I, P, P],
     "cds_bn3d_stats_f32": [P, P, I, I, L, P],
     "cds_bn3d_norm_f32": [P, P, P, P, DB, DB, F, P, P, P, P, P, P, P, P, I, I, L, I, P],
     "cds_bn3d_bwd_reduce_f32": [P, P, P, P, P, I, I, L, I, P],

@@ -373,7 +373,7 @@ class ViewShardedStage:
             src = torch.stack([ops.chw_to_hwc(features[v]["src"][0][0].contiguous()) for v in mine])
             ref_nc = torch.stack([features[v]["ref"][2][0, 0] for v in mine]).contiguous()
             nc_sums = torch.stack([(features[v]["ref"][1][0, 0] + features[v]["src"][1][0, 0]) / 2 for v in mine])
-            mats = geometry.warp_matrices(cams[0])[mine].contiguous()
+            mats = ops.geo(geometry.warp_matrices(cams[0])[mine].contiguous(), ref.device, "mats")   # one upload for K1 and K3
         else:
             ref = src = ref_nc = nc_sums = mats = None
         depth, conf, nc = sh.run_stage(self.model, ref, src, ref_nc, nc_sums, mats, hyp, stage_idx, V, C=C)

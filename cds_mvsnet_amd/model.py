@@ -15,6 +15,7 @@ Scope: inference (``model.eval()``) runs entirely on the HIP kernel
 from __future__ import annotations
 
 import os
+import weakref
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -36,7 +37,11 @@ OVERLAP_STAGE2 = os.environ.get("CDS_OVERLAP_STAGE2", "0") == "1"   # A/B knob: 
 # FeatureNet on channels-last activations (csrc/feat_cl.hip, round 5); CDS_FEAT_CL=0: the planar kernels of rounds 1-4
 USE_FEAT_CL = os.environ.get("CDS_FEAT_CL", "1") != "0"
 USE_CONV00_MFMA = os.environ.get("CDS_CONV00_MFMA", "1") != "0"   # A/B knob: 0 = conv00's branches on the VALU kernels + blend kernel
+# the stage-1 side stream inside a stream capture (fork / join become graph edges); CDS_OVERLAP_IN_CAPTURE=0: captured forwards are one chain
+OVERLAP_IN_CAPTURE = os.environ.get("CDS_OVERLAP_IN_CAPTURE", "1") != "0"
 _SIDE_STREAMS: Dict[int, "torch.cuda.Stream"] = {}
+USE_GRAPHS_DEFAULT = os.environ.get("CDS_GRAPH", "0") == "1"       # eval forwards of every model through graphed.CapturedForward
+_GRAPH_RUNNERS: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()   # model -> its CapturedForward (CDSMVSNet.use_graphs)
 
 
 def _side_stream(device) -> "torch.cuda.Stream":
@@ -364,8 +369,11 @@ class Refinement(_PackedHolder):
         out["res.w"] = _pack2d(self.res.weight.detach())
         return out
 
-    def forward(self, img: Tensor, depth0: Tensor, dmin: Tensor, dmax: Tensor) -> Tensor:
-        """img [B,3,H,W], depth0 [B,1,H/2,W/2], dmin/dmax [B] -> refined depth [B,1,H,W]."""
+    def forward(self, img: Tensor, depth0: Tensor, dmin, dmax=None) -> Tensor:
+        """img [B,3,H,W], depth0 [B,1,H/2,W/2], dmin / dmax [B] -> refined depth [B,1,H,W]  (the reference's signature, module.py:344).
+        Internal form (CDSMVSNet.forward_device): dmin = a list of B device triples (depth_min, depth_max, interval) of the geometry
+        block and dmax None - depth0 is then the depth in depth units and the interval scaling of models/model.py:213-218 happens
+        inside the first and last kernel."""
         if self.training:
             from . import training
             return training._refinement(self, img, depth0, dmin, dmax)         # HIP forward / backward kernels (train2d_ops.py)
@@ -374,12 +382,15 @@ class Refinement(_PackedHolder):
         h, w = depth0.shape[-2:]
         if (2 * h, 2 * w) != (H, W):
             raise ValueError(f"Refinement: image {(H, W)} must be twice the depth map {(h, w)}")
-        lo_hi = torch.stack((dmin.float(), dmax.float()), 1).cpu()            # scalars for the launches
+        if dmax is None:
+            ranges = list(dmin)
+        else:
+            lo_hi = _to_host([torch.stack((dmin.float(), dmax.float()), 1)])[0]   # reference signature: host scalars, uploaded
+            ranges = [ops.geo([float(lo_hi[b, 0]), float(lo_hi[b, 1]), 1.0], img.device, "depth_range") for b in range(B)]
         outs = []
         with ops.prof("refinement"):
             for b in range(B):
-                lo, hi = float(lo_hi[b, 0]), float(lo_hi[b, 1])
-                d = ops.depth_affine(depth0[b, 0].contiguous(), lo, hi)                              # [h,w]
+                d = ops.depth_affine(depth0[b, 0].contiguous(), ranges[b])                           # [h,w]
                 cat = torch.empty((1, 16, H, W), dtype=torch.float32, device=img.device)            # deconv | conv0
                 ops.conv2d(img[b:b + 1].contiguous(), p["conv0.w"], p["conv0.b"], 8, 3, 1, 1, ACT_RELU, out=cat[0, 8:])
                 x = ops.conv2d(d.view(1, 1, h, w), p["conv1.w"], p["conv1.b"], 8, 3, 1, 1, ACT_RELU)
@@ -387,7 +398,7 @@ class Refinement(_PackedHolder):
                 ops.deconv2d_k3s2(x[0], p["deconv.w"], p["deconv.b"], ACT_RELU, out=cat[0, :8])
                 x = ops.conv2d(cat, p["conv3.w"], p["conv3.b"], 8, 3, 1, 1, ACT_RELU)
                 res = ops.conv2d(x, p["res.w"], None, 1, 3, 1, 1, ACT_NONE)
-                outs.append(ops.refine_finish(d, res[0, 0], lo, hi))
+                outs.append(ops.refine_finish(d, res[0, 0], ranges[b]))
         return torch.stack(outs).unsqueeze(1)
 
 
@@ -530,7 +541,8 @@ class _FeatureRunner:
         return chw, hwc
 
     def __call__(self, imgs: Tensor, epipoles: Tensor, T: float, n_chw: Optional[int] = None, n_shared: int = 1, on_stage1=None):
-        """imgs [N,3,H,W], epipoles CPU [N,2] (one epipole per image, full-resolution pixels).
+        """imgs [N,3,H,W]; epipoles: one per image in pixels - a CPU tensor [N,2] at full resolution, or the three device tensors [N,2]
+        of the geometry block at full / half / quarter resolution.
         Returns {'stageK': (fea_chw [n_chw,C,h,w] | None, fea_hwc [N-n_chw,h,w,C] | None, nc_sum [N,h,w], |nc| [N,h,w])}."""
         net = self.net
         if net.training:
@@ -542,9 +554,11 @@ class _FeatureRunner:
         if N > ops.MAX_IMAGES:
             raise ValueError(f"at most {ops.MAX_IMAGES} images per FeatureNet batch")
         p = net._packed.get(net, self._pack)
-        e0 = epipoles.float().contiguous()
-        e1 = (e0 / 2).contiguous()
-        e2 = (e0 / 4).contiguous()
+        if isinstance(epipoles, (tuple, list)):
+            e0, e1, e2 = epipoles                 # device slices of the call's geometry block (CDSMVSNet.geometry_block)
+        else:                                     # direct callers: CPU [N,2] at full resolution, uploaded here
+            e0 = epipoles.detach().float().cpu().contiguous()
+            e0, e1, e2 = (ops.geo(e, imgs.device, "epipoles") for e in (e0, e0 / 2, e0 / 4))
         if USE_FEAT_CL and net.conv00.conv.out_c == 8 and all(f"{nm}.ws" in p for nm in self._CL_LAYERS):
             return self._call_cl(p, imgs, e0, e1, e2, T, n_chw, n_shared, on_stage1)
         # conv00 sees the raw images: with n_shared copies of the reference image its branch convolutions (3x3, 7x7,
@@ -746,6 +760,10 @@ class StageNet(_PackedHolder):
         cams = _to_host([proj_matrices])[0]
         V = len(features)
         depths, confs, ncs = [], [], []
+        geo = geometry.GeoBlock()                  # the homographies of the call: one asynchronous upload, read by K1 and K3
+        for b in range(B):
+            geo.add(f"b{b}.mats", geometry.warp_matrices(cams[b]))
+        geo.upload(depth_values.device)
         for b in range(B):
             ref = torch.stack([f["ref"][0][b] for f in features]).contiguous()
             C, h, w = ref.shape[1:]
@@ -759,8 +777,7 @@ class StageNet(_PackedHolder):
             if hyp.dim() == 1:
                 h, w = ref.shape[-2:]
                 hyp = hyp.view(-1, 1, 1).expand(-1, h, w)
-            d, c, n = self.run_single(ref, src, ref_nc, nc_sums, geometry.warp_matrices(cams[b]), hyp.contiguous(),
-                                      cost_regularization, stage_idx)
+            d, c, n = self.run_single(ref, src, ref_nc, nc_sums, geo[f"b{b}.mats"], hyp.contiguous(), cost_regularization, stage_idx)
             depths.append(d)
             confs.append(c)
             ncs.append(n.unsqueeze(0))
@@ -798,24 +815,21 @@ class CDSMVSNet(nn.Module):
         self._view_shard = None
 
     # -- helpers -----------------------------------------------------------------------------
-    def extract_features(self, ref_img: Tensor, src_imgs: List[Tensor], cam_ref: Tensor, cam_srcs: List[Tensor], T: float,
-                         on_stage1=None):
+    def extract_features(self, ref_img: Tensor, src_imgs: List[Tensor], epi_groups, T: float, on_stage1=None):
         """FeatureNet for every (reference, source) pair in ONE batched pass: V copies of the reference image (each
         conditioned on its pair's epipole — DynamicConv makes reference features pair specific, model.py:154-161)
-        followed by the V source images.  Returns the runner's dict; rows [0,V) are the reference features (CHW), the
-        source features come back channels-last."""
+        followed by the V source images.  epi_groups: per group of at most MAX_IMAGES / 2 pairs the epipoles of its images
+        ([reference copies ..., sources ...]) at the three FeatureNet resolutions as device tensors [2 g, 2] (slices of the call's
+        geometry block, :meth:`geometry_block`).  Returns the runner's dict; rows [0,V) are the reference features (CHW), the source
+        features come back channels-last."""
         V = len(src_imgs)
-        epi = []
-        for cam_src in cam_srcs:
-            epi.append(geometry.pair_epipoles(cam_ref, cam_src))
         G = ops.MAX_IMAGES // 2   # pairs per batched pass (2 images per pair); more views run in groups
         parts = []
-        for v0 in range(0, V, G):
-            g = epi[v0:v0 + G]
-            epipoles = torch.tensor([e[0] for e in g] + [e[1] for e in g], dtype=torch.float32)
-            batch = torch.stack([ref_img] * len(g) + list(src_imgs[v0:v0 + G]))
-            parts.append((len(g), _FeatureRunner(self.feature)(batch, epipoles, T, n_chw=len(g), n_shared=len(g),
-                                                               on_stage1=on_stage1 if V <= G else None)))
+        for gi, v0 in enumerate(range(0, V, G)):
+            n = min(G, V - v0)
+            batch = torch.stack([ref_img] * n + list(src_imgs[v0:v0 + G]))
+            parts.append((n, _FeatureRunner(self.feature)(batch, epi_groups[gi], T, n_chw=n, n_shared=n,
+                                                          on_stage1=on_stage1 if V <= G else None)))
         if len(parts) == 1:
             return parts[0][1]
         out = {}
@@ -837,10 +851,28 @@ class CDSMVSNet(nn.Module):
             if isinstance(m, _PackedHolder):
                 m.repack()
 
+    def use_graphs(self, on: bool = True, check_weights: bool = True) -> "CDSMVSNet":
+        """Route eval-mode ``forward`` calls through a hipGraph replay (graphed.CapturedForward: one capture per image shape /
+        view count / temperature, replayed with this call's cameras through the geometry block; outputs are copies, as from the eager
+        path).  Off by default; ``CDS_GRAPH=1`` in the environment turns it on for every model.  Training mode, view-sharded
+        models and nn.DataParallel replicas always run eagerly."""
+        if on:
+            from .graphed import CapturedForward
+            _GRAPH_RUNNERS[self] = CapturedForward(self, check_weights=check_weights)
+        else:
+            _GRAPH_RUNNERS.pop(self, None)
+        return self
+
     def forward(self, imgs, proj_matrices, depth_values, gt_depths=None, temperature=0.001):
         if not imgs.is_cuda:
             raise RuntimeError("cds_mvsnet_amd.CDSMVSNet runs on a ROCm device only (no CPU fallback); "
                                "move the model and inputs with .cuda()")
+        if not self.training and gt_depths is None and self._view_shard is None and not getattr(self, "_is_replica", False):
+            runner = _GRAPH_RUNNERS.get(self)
+            if runner is None and USE_GRAPHS_DEFAULT:
+                runner = self.use_graphs(True) and _GRAPH_RUNNERS[self]
+            if runner is not None:
+                return runner(imgs, proj_matrices, depth_values, temperature=temperature, clone=True)
         # the kernels are launched on the CURRENT device's stream: make the inputs' device current for the whole call
         # (nn.DataParallel replicas, models on cuda:k in a process whose current device is another one)
         with torch.cuda.device(imgs.device):
@@ -854,16 +886,54 @@ class CDSMVSNet(nn.Module):
         if self.training:
             from .training import forward_train   # autograd path: HIP forward / backward kernels for every stack
             return forward_train(self, imgs.float(), proj_matrices, depth_values, gt_depths, temperature)
-        T = float(temperature)
+        # host part: camera algebra -> the geometry block, one asynchronous copy; device part: launches only (capturable)
+        geo = self.geometry_block(proj_matrices, depth_values, N).upload(imgs.device)
+        return self.forward_device(imgs, geo, float(temperature))
+
+    def geometry_block(self, proj_matrices, depth_values, N: int) -> "geometry.GeoBlock":
+        """The HOST side of an inference forward: everything the reference derives from the cameras and the depth range inside its
+        forward (projection composition + relative homographies per stage, models/model.py:40-43, warping.py:80-82; epipoles of every
+        pair at the three FeatureNet resolutions, dynamic_conv.py:19-47, model.py:156-158, module.py:239,242; depth range and the
+        stages' hypothesis spacings, model.py:165-175), packed into a :class:`geometry.GeoBlock`.  CPU inputs are used as they are;
+        device inputs are read back (`_to_host`)."""
         keys = list(proj_matrices.keys())
         host = _to_host([depth_values] + [proj_matrices[k] for k in keys])
         dv, cams = host[0], dict(zip(keys, host[1:]))
+        geo = geometry.GeoBlock()
+        views = self._my_views(N - 1)
+        sh = self._view_shard
+        mat_views = list(range(N - 1)) if (sh is not None and sh.exchange == "slab") else views   # slab: every rank warps every view
+        G = ops.MAX_IMAGES // 2
+        for b in range(dv.shape[0]):
+            dint = dv[b, 1] - dv[b, 0]
+            geo.add(f"b{b}.range", [float(dv[b, 0]), float(dv[b, -1]), float(dint)])          # depth_min, depth_max, interval
+            for s in range(self.num_stage):
+                geo.add(f"b{b}.interval{s}", [float(self.depth_interals_ratio[s] * dint)])    # model.py:174
+            if views:
+                e_ref, e_src = geometry.pairs_epipoles(cams["stage3"][b])       # [N-1,2] each, every pair in one batched pass
+            for gi, v0 in enumerate(range(0, len(views), G)):
+                g = views[v0:v0 + G]
+                e0 = torch.cat((e_ref[g], e_src[g]))                              # [reference copies ..., sources ...]
+                geo.add(f"b{b}.epi{gi}.0", e0)               # full resolution; halved / quartered for the coarser levels
+                geo.add(f"b{b}.epi{gi}.1", e0 / 2)
+                geo.add(f"b{b}.epi{gi}.2", e0 / 4)
+            if mat_views:
+                for s in range(self.num_stage):
+                    name = f"stage{s + 1}"
+                    geo.add(f"b{b}.mats.{name}", geometry.warp_matrices(cams[name][b])[mat_views].contiguous())
+        return geo
+
+    def forward_device(self, imgs: Tensor, geo: "geometry.GeoBlock", T: float):
+        """The DEVICE side of an inference forward: kernel launches only - no host readback, no host-side camera algebra, every
+        per-call number read from `geo`'s device block.  This is the function a hipGraph capture records (graphed.py)."""
+        B, N, _, Him, Wim = imgs.shape
+        H, W = (Him // 2, Wim // 2) if self.refine else (Him, Wim)
         imgs = imgs.float()
+        capturing = torch.cuda.is_current_stream_capturing()
 
         per_b: List[Dict[str, object]] = []
         for b in range(B):
-            dmin, dmax = dv[b, 0], dv[b, -1]
-            dint = dv[b, 1] - dv[b, 0]
+            rng = geo[f"b{b}.range"]
             # ---- features, one FeatureNet pass per image of every (ref, src) pair ----
             ref_img = _resize_nearest(imgs[b, 0], H, W)
             views = self._my_views(N - 1)
@@ -873,13 +943,13 @@ class CDSMVSNet(nn.Module):
             sh = self._view_shard
             if V:
                 on_stage1 = None
-                if OVERLAP_STAGE1 and sh is None and V <= ops.MAX_IMAGES // 2 and not torch.cuda.is_current_stream_capturing():
+                if OVERLAP_STAGE1 and sh is None and V <= ops.MAX_IMAGES // 2 and (not capturing or OVERLAP_IN_CAPTURE):
                     # stage 1 (quarter resolution: kernels that do not fill 256 CUs) runs on a side stream from the moment its
                     # features exist, next to the finer FPN levels of FeatureNet on the main stream; joined before stage 2
                     main = torch.cuda.current_stream(imgs.device)
                     side = _side_stream(imgs.device)
 
-                    def on_stage1(name, f, b=b, views=views, V=V):
+                    def on_stage1(name, f, b=b, V=V, rng=rng):
                         if name == "stage2" and not OVERLAP_STAGE2:
                             return
                         s_ = int(name[-1]) - 1
@@ -887,15 +957,16 @@ class CDSMVSNet(nn.Module):
                         with torch.cuda.stream(side):
                             scale = int(self.stage_infos[name]["scale"])
                             if s_ == 0:
-                                hyp_ = ops.depth_planes(self.ndepths[0], H // scale, W // scale, float(dv[b, 0]), float(dv[b, -1]), imgs.device)
+                                hyp_ = ops.depth_planes(self.ndepths[0], H // scale, W // scale, rng, None, imgs.device)
                             else:
-                                hyp_ = ops.depth_hypotheses(early["stage1"][0], self.ndepths[s_], H, W, scale,
-                                                            float(self.depth_interals_ratio[s_] * (dv[b, 1] - dv[b, 0])), float(dv[b, 0]), float(dv[b, -1]))
+                                hyp_ = ops.depth_hypotheses(early["stage1"][0], self.ndepths[s_], H, W, scale, geo[f"b{b}.interval{s_}"], rng)
                             ref, src, nc_sum, nc_abs = f
-                            mats = geometry.warp_matrices(cams[name][b])[views].contiguous()
-                            early[name] = self._run_stage(ref, src, nc_abs[:V].contiguous(), ops.pair_mean(nc_sum, V), mats, hyp_, s_, N - 1)
-                feats = self.extract_features(ref_img, [_resize_nearest(imgs[b, v + 1], H, W) for v in views],
-                                              cams["stage3"][b, 0], [cams["stage3"][b, v + 1] for v in views], T, on_stage1=on_stage1)
+                            early[name] = self._run_stage(ref, src, nc_abs[:V].contiguous(), ops.pair_mean(nc_sum, V),
+                                                          geo[f"b{b}.mats.{name}"], hyp_, s_, N - 1)
+                G = ops.MAX_IMAGES // 2
+                epi_groups = [tuple(geo[f"b{b}.epi{gi}.{k}"] for k in range(3)) for gi in range((V + G - 1) // G)]
+                feats = self.extract_features(ref_img, [_resize_nearest(imgs[b, v + 1], H, W) for v in views], epi_groups, T,
+                                              on_stage1=on_stage1)
                 if early:
                     torch.cuda.current_stream(imgs.device).wait_stream(side)
                     for st_out in early.values():
@@ -923,15 +994,14 @@ class CDSMVSNet(nn.Module):
                     out_b[name] = {"depth": depth, "photometric_confidence": conf, "norm_curv": nc.unsqueeze(0)}
                     continue
                 if depth is None:
-                    hyp = ops.depth_planes(D, h, w, float(dmin), float(dmax), imgs.device)
+                    hyp = ops.depth_planes(D, h, w, rng, None, imgs.device)
                 else:
-                    interval = float(self.depth_interals_ratio[s] * dint)
-                    hyp = ops.depth_hypotheses(depth, D, H, W, scale, interval, float(dmin), float(dmax))
+                    hyp = ops.depth_hypotheses(depth, D, H, W, scale, geo[f"b{b}.interval{s}"], rng)
                 if V:
                     ref, src, nc_sum, nc_abs = feats[name]
                     ref_nc = nc_abs[:V].contiguous()
                     nc_sums = ops.pair_mean(nc_sum, V)
-                    mats = geometry.warp_matrices(cams[name][b])[views].contiguous()
+                    mats = geo[f"b{b}.mats.{name}"]
                 else:  # a view-shard rank without a source view of its own (more GPUs than views)
                     ref = src = ref_nc = nc_sums = mats = None
                 depth, conf, nc = self._run_stage(ref, src, ref_nc, nc_sums, mats, hyp, s, N - 1)
@@ -947,10 +1017,10 @@ class CDSMVSNet(nn.Module):
             outputs.update(st)
         depth = outputs["depth"]
         if self.refine:
-            dint_h = dv[:, 1] - dv[:, 0]                                   # host copies: no readback / upload here
-            cur = torch.stack([depth[b] / float(dint_h[b]) for b in range(B)])
-            refined = self.refine_network(imgs[:, 0], cur.unsqueeze(1), dv[:, 0] / dint_h, dv[:, -1] / dint_h)
-            outputs["refined_depth"] = torch.stack([refined[b, 0] * float(dint_h[b]) for b in range(B)])
+            # models/model.py:213-218: depth and limits in interval units in, refined depth times the interval out - the divisions and the
+            # product are inside the first / last Refinement kernel (device scalars of the geometry block)
+            refined = self.refine_network(imgs[:, 0], depth.unsqueeze(1), [geo[f"b{b}.range"] for b in range(B)], None)
+            outputs["refined_depth"] = refined[:, 0]
         else:
             outputs["refined_depth"] = depth
         return outputs

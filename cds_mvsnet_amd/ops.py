@@ -77,6 +77,23 @@ def _host(t: Tensor, name: str) -> int:
     return t.data_ptr()
 
 
+def geo(t, device, name: str = "geometry") -> Tensor:
+    """Per-call GEOMETRY operand (homographies [V,12], epipoles [N,2], depth-range scalars) as the float32 DEVICE tensor the kernels
+    read.  Since round 6 these are device data, not by-value kernel arguments: the model writes all of a forward's geometry into one
+    block with one host -> device copy (geometry.GeoBlock) and hands out slices of it, and a captured hipGraph is replayed for new
+    cameras by rewriting that block.  Direct callers (tests, scripts) may still pass a CPU tensor or a list of Python floats: it is
+    uploaded here through pinned memory (asynchronous, the host does not wait for the stream) - which a stream capture must not
+    contain (the captured copy would replay stale host bytes), hence the error there."""
+    if isinstance(t, torch.Tensor) and t.is_cuda:
+        return t
+    if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+        raise RuntimeError(f"{name}: host-side geometry inside a stream capture - build a geometry.GeoBlock before capturing and "
+                           "pass its device slices")
+    if not isinstance(t, torch.Tensor):
+        t = torch.tensor([float(v) for v in t], dtype=torch.float32)
+    return t.detach().to(dtype=torch.float32).contiguous().pin_memory().to(device=device, non_blocking=True)
+
+
 # the raw hipStream_t of the current stream without building a torch.cuda.Stream object (5 us -> 0.5 us per launch: the training step is
 # CPU-bound at ~1 500 launches)
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None) or (lambda idx: torch.cuda.current_stream(idx).cuda_stream)
@@ -118,11 +135,12 @@ def _hyp_args(hyp: Tensor, D_expected: Optional[int], h: int, w: int) -> Tuple[i
 
 
 def homo_warp(src_hwc: Tensor, mat: Tensor, hyp: Tensor) -> Tensor:
-    """models/utils/warping.py:69-104 for one view.  src_hwc [h,w,C], mat CPU [12] -> [C,D,h,w]."""
+    """models/utils/warping.py:69-104 for one view.  src_hwc [h,w,C], mat [12] (device; a CPU tensor is uploaded) -> [C,D,h,w]."""
     h, w, C = src_hwc.shape
+    mat = geo(mat, src_hwc.device, "mat")
     D, pp = _hyp_args(hyp, None, h, w)
     out = torch.empty((C, D, h, w), dtype=torch.float32, device=src_hwc.device)
-    check(_lib.load().cds_homo_warp_f32(_dev(src_hwc, "src_hwc"), _host(mat, "mat"), _dev(hyp, "hyp"), out.data_ptr(),
+    check(_lib.load().cds_homo_warp_f32(_dev(src_hwc, "src_hwc"), _dev(mat, "mat"), _dev(hyp, "hyp"), out.data_ptr(),
                                         C, D, h, w, pp, _stream(out)), "cds_homo_warp_f32")
     return out
 
@@ -158,13 +176,14 @@ def _window_args(window: Optional[Tuple[int, int]], h: int) -> Tuple[int, int]:
 
 def warp_entropy(ref_chw: Tensor, src_hwc: Tensor, mats: Tensor, hyp: Tensor, exact: Optional[bool] = None,
                  window: Optional[Tuple[int, int]] = None) -> Tensor:
-    """K1.  ref_chw [V,C,h,w], src_hwc [V,h,w,C], mats CPU [V,12], hyp [D,h,w]|[D] -> entropy [V,h,w].
+    """K1.  ref_chw [V,C,h,w], src_hwc [V,h,w,C], mats [V,12] (device slice of the geometry block; a CPU tensor is uploaded), hyp [D,h,w]|[D] -> entropy [V,h,w].
     exact: sample-position arithmetic (None = the module default ``WARP_EXACT``).
     window = (hs, y_off): ref_chw / hyp / the result cover rows [y_off, y_off + h) of the grid, src_hwc is [V,hs,w,C]."""
     V, C, h, w = ref_chw.shape
     hs, y_off = _window_args(window, h)
     if tuple(src_hwc.shape) != (V, hs, w, C) or tuple(mats.shape) != (V, 12):
         raise ValueError("warp_entropy: inconsistent shapes")
+    mats = geo(mats, ref_chw.device, "mats")
     D, pp = _hyp_args(hyp, None, h, w)
     if window is not None and not pp:
         raise ValueError("warp_entropy: a row window needs per-pixel hypotheses [D,h,w]")
@@ -177,12 +196,12 @@ def warp_entropy(ref_chw: Tensor, src_hwc: Tensor, mats: Tensor, hyp: Tensor, ex
             v1 = min(V, v0 + MAX_VIEWS)
             if window is not None:
                 check(lib.cds_warp_entropy_window_f32(_dev(ref_chw[v0:v1], "ref"), _dev(src_hwc[v0:v1], "src"),
-                                                      _host(mats[v0:v1], "mats"), _dev(hyp, "hyp"), ent[v0:v1].data_ptr(),
+                                                      _dev(mats[v0:v1], "mats"), _dev(hyp, "hyp"), ent[v0:v1].data_ptr(),
                                                       v1 - v0, C, D, h, w, hs, y_off, _pos_flag(exact), _stream(ent)),
                       "cds_warp_entropy_window_f32")
                 continue
             check(lib.cds_warp_entropy_flags_f32(_dev(ref_chw[v0:v1], "ref"), _dev(src_hwc[v0:v1], "src"),
-                                                 _host(mats[v0:v1], "mats"), _dev(hyp, "hyp"), ent[v0:v1].data_ptr(),
+                                                 _dev(mats[v0:v1], "mats"), _dev(hyp, "hyp"), ent[v0:v1].data_ptr(),
                                                  v1 - v0, C, D, h, w, pp, _pos_flag(exact), _stream(ent)),
                   "cds_warp_entropy_flags_f32")
     return ent
@@ -199,6 +218,7 @@ def warp_aggregate(ref_chw: Tensor, src_hwc: Tensor, vis_w: Tensor, mats: Tensor
     hs, y_off = _window_args(window, h)          # window: see warp_entropy
     if tuple(src_hwc.shape) != (V, hs, w, C) or tuple(mats.shape) != (V, 12) or tuple(vis_w.shape) != (V, h, w):
         raise ValueError("warp_aggregate: inconsistent shapes")
+    mats = geo(mats, ref_chw.device, "mats")
     D, pp = _hyp_args(hyp, None, h, w)
     if window is not None and not pp:
         raise ValueError("warp_aggregate: a row window needs per-pixel hypotheses [D,h,w]")
@@ -226,12 +246,12 @@ def warp_aggregate(ref_chw: Tensor, src_hwc: Tensor, vis_w: Tensor, mats: Tensor
                 flags |= AGG_NORMALIZE
             if window is not None:
                 check(lib.cds_warp_aggregate_window_f32(_dev(ref_chw[v0:v1], "ref"), _dev(src_hwc[v0:v1], "src"),
-                                                        _dev(vis_w[v0:v1], "vis"), _host(mats[v0:v1], "mats"), _dev(hyp, "hyp"),
+                                                        _dev(vis_w[v0:v1], "vis"), _dev(mats[v0:v1], "mats"), _dev(hyp, "hyp"),
                                                         _dev(volume, "volume"), _dev(vis_sum, "vis_sum"), v1 - v0, C, D, h, w,
                                                         hs, y_off, flags, _stream(volume)), "cds_warp_aggregate_window_f32")
                 continue
             check(lib.cds_warp_aggregate_f32(_dev(ref_chw[v0:v1], "ref"), _dev(src_hwc[v0:v1], "src"),
-                                             _dev(vis_w[v0:v1], "vis"), _host(mats[v0:v1], "mats"), _dev(hyp, "hyp"),
+                                             _dev(vis_w[v0:v1], "vis"), _dev(mats[v0:v1], "mats"), _dev(hyp, "hyp"),
                                              _dev(volume, "volume"), _dev(vis_sum, "vis_sum"), v1 - v0, C, D, h, w, pp,
                                              flags, _stream(volume)), "cds_warp_aggregate_f32")
     return volume, vis_sum
@@ -246,6 +266,7 @@ def warp_aggregate_bwd(ref_chw: Tensor, src_hwc: Tensor, vis_w: Tensor, mats: Te
         raise ValueError(f"warp_aggregate_bwd: grad_volume must be {(C, D, h, w)}, got {tuple(grad_volume.shape)}")
     if tuple(src_hwc.shape) != (V, h, w, C) or tuple(mats.shape) != (V, 12) or tuple(vis_w.shape) != (V, h, w):
         raise ValueError("warp_aggregate_bwd: inconsistent shapes")
+    mats = geo(mats, ref_chw.device, "mats")
     # the kernel accumulates partial sums (channel groups x depth segments) with atomics: ONE zero fill for the three gradients
     flat = torch.zeros((ref_chw.numel() + src_hwc.numel() + vis_w.numel(),), dtype=torch.float32, device=ref_chw.device)
     g_ref = flat[:ref_chw.numel()].view_as(ref_chw)
@@ -256,7 +277,7 @@ def warp_aggregate_bwd(ref_chw: Tensor, src_hwc: Tensor, vis_w: Tensor, mats: Te
     for v0 in range(0, V, MAX_VIEWS):
         v1 = min(V, v0 + MAX_VIEWS)
         check(lib.cds_warp_aggregate_bwd_f32(_dev(ref_chw[v0:v1], "ref"), _dev(src_hwc[v0:v1], "src"),
-                                             _dev(vis_w[v0:v1], "vis"), _host(mats[v0:v1], "mats"), _dev(hyp, "hyp"),
+                                             _dev(vis_w[v0:v1], "vis"), _dev(mats[v0:v1], "mats"), _dev(hyp, "hyp"),
                                              _dev(grad_volume, "grad_volume"), g_ref[v0:v1].data_ptr(),
                                              g_src[v0:v1].data_ptr(), g_vis[v0:v1].data_ptr(), v1 - v0, C, D, h, w, pp,
                                              _stream(g_ref)), "cds_warp_aggregate_bwd_f32")
@@ -353,20 +374,34 @@ def softargmin_conf(prob_pre: Tensor, hyp: Tensor, want_prob: bool = False):
     return (depth, conf, prob) if want_prob else (depth, conf)
 
 
-def depth_hypotheses(prev_depth: Tensor, D: int, H: int, W: int, scale: int, interval: float, dmin: float,
-                     dmax: float) -> Tensor:
-    """K6.  prev_depth [hp,wp] -> hypotheses [D,H/scale,W/scale]."""
+def depth_hypotheses(prev_depth: Tensor, D: int, H: int, W: int, scale: int, interval, dmin, dmax=None) -> Tensor:
+    """K6.  prev_depth [hp,wp] -> hypotheses [D,H/scale,W/scale].  interval: the stage's hypothesis spacing, dmin / dmax: the clamp
+    range - device scalars of the geometry block (interval = a 1-element device tensor, dmin = a 2-element device tensor (dmin, dmax),
+    dmax None) or Python floats (uploaded)."""
     hp, wp = prev_depth.shape
-    out = torch.empty((D, H // scale, W // scale), dtype=torch.float32, device=prev_depth.device)
+    dev = prev_depth.device
+    out = torch.empty((D, H // scale, W // scale), dtype=torch.float32, device=dev)
+    if dmax is None:
+        ival, rng = geo(interval, dev, "interval"), geo(dmin, dev, "depth_range")
+    else:
+        ival = geo([interval, dmin, dmax], dev, "interval")
+        rng = ival[1:]
+    if ival.numel() < 1 or rng.numel() < 2:
+        raise ValueError("depth_hypotheses: interval needs 1 value, the depth range 2")
     check(_lib.load().cds_depth_hypotheses_f32(_dev(prev_depth, "prev_depth"), out.data_ptr(), D, hp, wp, H, W, scale,
-                                               float(interval), float(dmin), float(dmax), _stream(out)),
+                                               _dev(ival, "interval"), _dev(rng, "depth_range"), _stream(out)),
           "cds_depth_hypotheses_f32")
     return out
 
 
-def depth_planes(D: int, h: int, w: int, lo: float, hi: float, device) -> Tensor:
+def depth_planes(D: int, h: int, w: int, lo, hi, device) -> Tensor:
+    """First-stage planes lo + k (hi - lo) / (D - 1).  lo = a 2-element device tensor (lo, hi) of the geometry block with hi None,
+    or two Python floats (uploaded)."""
     out = torch.empty((D, h, w), dtype=torch.float32, device=device)
-    check(_lib.load().cds_depth_planes_f32(out.data_ptr(), D, h, w, float(lo), float(hi), _stream(out)),
+    rng = geo(lo if hi is None else [lo, hi], out.device, "depth_range")
+    if rng.numel() < 2:
+        raise ValueError("depth_planes: the depth range needs 2 values")
+    check(_lib.load().cds_depth_planes_f32(out.data_ptr(), D, h, w, _dev(rng, "depth_range"), _stream(out)),
           "cds_depth_planes_f32")
     return out
 
@@ -783,7 +818,7 @@ def split_pack_conv00(ws) -> Tensor:
 def conv00_cl(imgs: Tensor, wsplit: Tensor, bias: Optional[Tensor], w1: Tensor, b1: Tensor, w2: Tensor, epipoles: Tensor,
               temperature: float, n_shared: int = 1, stats_slope: float = 0.1):
     """conv00 of FeatureNet in one kernel on the matrix cores.  imgs [S,3,H,W] planar (S = N - n_shared + 1 slots: slot 0 is shown by
-    the first n_shared of the N output images), epipoles CPU [N,2] -> (out_cl [N,H,W,8], norm_curv [N,H,W], stats [N,8,2] float64,
+    the first n_shared of the N output images), epipoles [N,2] (device) -> (out_cl [N,H,W,8], norm_curv [N,H,W], stats [N,8,2] float64,
     affine [N,8,3])."""
     S, C, H, W = imgs.shape
     N = S + n_shared - 1
@@ -794,12 +829,13 @@ def conv00_cl(imgs: Tensor, wsplit: Tensor, bias: Optional[Tensor], w1: Tensor, 
     if bias is not None and tuple(bias.shape) != (3, 11):
         raise ValueError("conv00_cl: bias must be [3, 11]")
     dev = imgs.device
+    epipoles = geo(epipoles, dev, "epipoles")          # device slice of the geometry block (a CPU tensor is uploaded)
     lib = _lib.load()
     out = torch.empty((N, H, W, 8), dtype=torch.float32, device=dev)
     nc = torch.empty((N, H, W), dtype=torch.float32, device=dev)
     partial = torch.empty((N, lib.cds_dynconv_cl_parts(H, W), 8, 2), dtype=torch.float64, device=dev)
     check(lib.cds_conv00_cl_f32(_dev(imgs, "imgs"), wsplit.data_ptr(), _dev(bias, "bias") if bias is not None else None, _dev(w1, "w1"),
-                                _dev(b1, "b1"), _dev(w2, "w2"), _host(epipoles, "epipoles"), float(temperature), out.data_ptr(),
+                                _dev(b1, "b1"), _dev(w2, "w2"), _dev(epipoles, "epipoles"), float(temperature), out.data_ptr(),
                                 nc.data_ptr(), partial.data_ptr(), N, n_shared, H, W, _stream(imgs)), "cds_conv00_cl_f32")
     stats, affine = _reduce_records(partial, N, 8, H, W, stats_slope)
     return out, nc, stats, affine
@@ -841,6 +877,7 @@ def dynconv_fused_sbf(x: Tensor, wsplit: Tensor, bias: Optional[Tensor], cout: i
     if tuple(epipoles.shape) != (N, 2):
         raise ValueError("dynconv_fused_sbf: epipoles must be [N,2]")
     dev = x.device
+    epipoles = geo(epipoles, dev, "epipoles")          # device slice of the geometry block (a CPU tensor is uploaded)
     lib = _lib.load()
     out = torch.empty((N, cout, H, W), dtype=torch.float32, device=dev)
     nc = torch.empty((N, H, W), dtype=torch.float32, device=dev)
@@ -852,7 +889,7 @@ def dynconv_fused_sbf(x: Tensor, wsplit: Tensor, bias: Optional[Tensor], cout: i
     ks = (ctypes.c_int * K)(*[int(k) for k in ksizes])
     check(lib.cds_dynconv_fused_sbf_f32(_dev(x, "x"), _dev(in_affine, "in_affine") if in_affine is not None else None,
                                         wsplit.data_ptr(), _dev(bias, "bias") if bias is not None else None, _dev(w1, "w1"),
-                                        _dev(b1, "b1"), _dev(w2, "w2"), _host(epipoles, "epipoles"), float(temperature),
+                                        _dev(b1, "b1"), _dev(w2, "w2"), _dev(epipoles, "epipoles"), float(temperature),
                                         out.data_ptr(), nc.data_ptr(), partial.data_ptr(), N, Cin, cout, H, W, ks, K, _stream(x)),
           "cds_dynconv_fused_sbf_f32")
     check(lib.cds_instnorm_reduce_f32(partial.data_ptr(), parts, stats.data_ptr(), affine.data_ptr(), N, cout, H, W,
@@ -908,8 +945,8 @@ def instnorm_affine(x: Tensor, slope: float = 0.1) -> Tensor:
 
 def dynconv_blend(branches: Tensor, w1: Tensor, b1: Tensor, w2: Tensor, epipoles: Tensor,
                   temperature: float, n_shared: int = 1, stats_slope: Optional[float] = None):
-    """K7 epilogue.  branches [K,N - n_shared + 1,Cout+3,H,W] (the first n_shared images share slot 0), epipoles CPU
-    [N,2] -> (out [N,Cout,H,W], norm_curv [N,H,W]).
+    """K7 epilogue.  branches [K,N - n_shared + 1,Cout+3,H,W] (the first n_shared images share slot 0), epipoles
+    [N,2] (device) -> (out [N,Cout,H,W], norm_curv [N,H,W]).
     stats_slope given: the kernel also leaves the InstanceNorm statistics of `out` (no second pass over it) and the call
     returns (out, norm_curv, stats [N,Cout,2] float64 = (sum, sum of squares), affine [N,Cout,3]) - affine as from
     instnorm_affine(out, stats_slope), stats for instnorm_apply."""
@@ -919,12 +956,13 @@ def dynconv_blend(branches: Tensor, w1: Tensor, b1: Tensor, w2: Tensor, epipoles
     if tuple(epipoles.shape) != (N, 2) or n_shared < 1:
         raise ValueError("dynconv_blend: epipoles must be [N,2]")
     dev = branches.device
+    epipoles = geo(epipoles, dev, "epipoles")          # device slice of the geometry block (a CPU tensor is uploaded)
     out = torch.empty((N, cout, H, W), dtype=torch.float32, device=dev)
     nc = torch.empty((N, H, W), dtype=torch.float32, device=dev)
     lib = _lib.load()
     if stats_slope is None:
         check(lib.cds_dynconv_blend_shared_f32(_dev(branches, "branches"), _dev(w1, "w1"), _dev(b1, "b1"), _dev(w2, "w2"),
-                                               _host(epipoles, "epipoles"), float(temperature), out.data_ptr(),
+                                               _dev(epipoles, "epipoles"), float(temperature), out.data_ptr(),
                                                nc.data_ptr(), N, K, cout, H, W, n_shared, _stream(out)),
               "cds_dynconv_blend_shared_f32")
         return out, nc
@@ -933,7 +971,7 @@ def dynconv_blend(branches: Tensor, w1: Tensor, b1: Tensor, w2: Tensor, epipoles
     stats = torch.empty((N, cout, 2), dtype=torch.float64, device=dev)
     affine = torch.empty((N, cout, 3), dtype=torch.float32, device=dev)
     check(lib.cds_dynconv_blend_stats_f32(_dev(branches, "branches"), _dev(w1, "w1"), _dev(b1, "b1"), _dev(w2, "w2"),
-                                          _host(epipoles, "epipoles"), float(temperature), out.data_ptr(), nc.data_ptr(),
+                                          _dev(epipoles, "epipoles"), float(temperature), out.data_ptr(), nc.data_ptr(),
                                           partial.data_ptr(), N, K, cout, H, W, n_shared, _stream(out)),
           "cds_dynconv_blend_stats_f32")
     check(lib.cds_instnorm_reduce_f32(partial.data_ptr(), parts, stats.data_ptr(), affine.data_ptr(), N, cout, H, W,
@@ -996,6 +1034,7 @@ def dynconv_cl(x_cl: Tensor, wsplit: Tensor, bias: Optional[Tensor], ksizes, w1:
     if wsplit.dtype != torch.int16 or not wsplit.is_cuda or wsplit.numel() != (C // 8) * nks * ((C + 3 + 15) // 16) * 3 * 64 * 8:
         raise ValueError("dynconv_cl: wsplit must be split_pack_dynconv's int16 device tensor for these kernel sizes")
     dev = x_cl.device
+    epipoles = geo(epipoles, dev, "epipoles")          # device slice of the geometry block (a CPU tensor is uploaded)
     lib = _lib.load()
     out = torch.empty((N, H, W, C), dtype=torch.float32, device=dev)
     nc = torch.empty((N, H, W), dtype=torch.float32, device=dev)
@@ -1004,7 +1043,7 @@ def dynconv_cl(x_cl: Tensor, wsplit: Tensor, bias: Optional[Tensor], ksizes, w1:
     ks = (ctypes.c_int * K)(*[int(k) for k in ksizes])
     check(lib.cds_dynconv_cl_f32(_dev(x_cl, "x"), _dev(in_affine, "in_affine") if in_affine is not None else None, wsplit.data_ptr(),
                                  _dev(bias, "bias") if bias is not None else None, _dev(w1, "w1"), _dev(b1, "b1"), _dev(w2, "w2"),
-                                 _host(epipoles, "epipoles"), float(temperature), out.data_ptr(), nc.data_ptr(), partial.data_ptr(),
+                                 _dev(epipoles, "epipoles"), float(temperature), out.data_ptr(), nc.data_ptr(), partial.data_ptr(),
                                  N, C, H, W, ks, K, _stream(x_cl)), "cds_dynconv_cl_f32")
     stats, affine = _reduce_records(partial, N, C, H, W, stats_slope)
     return out, nc, stats, affine
@@ -1020,12 +1059,13 @@ def dynconv_blend_cl(branches: Tensor, w1: Tensor, b1: Tensor, w2: Tensor, epipo
     if tuple(epipoles.shape) != (N, 2) or n_shared < 1:
         raise ValueError("dynconv_blend_cl: epipoles must be [N,2]")
     dev = branches.device
+    epipoles = geo(epipoles, dev, "epipoles")          # device slice of the geometry block (a CPU tensor is uploaded)
     lib = _lib.load()
     out = torch.empty((N, H, W, cout), dtype=torch.float32, device=dev)
     nc = torch.empty((N, H, W), dtype=torch.float32, device=dev)
     partial = torch.empty((N, lib.cds_blend_cl_parts(H, W), cout, 2), dtype=torch.float64, device=dev)
     check(lib.cds_dynconv_blend_cl_f32(_dev(branches, "branches"), _dev(w1, "w1"), _dev(b1, "b1"), _dev(w2, "w2"),
-                                       _host(epipoles, "epipoles"), float(temperature), out.data_ptr(), nc.data_ptr(),
+                                       _dev(epipoles, "epipoles"), float(temperature), out.data_ptr(), nc.data_ptr(),
                                        partial.data_ptr(), N, K, cout, H, W, n_shared, _stream(out)), "cds_dynconv_blend_cl_f32")
     stats, affine = _reduce_records(partial, N, cout, H, W, stats_slope)
     return out, nc, stats, affine
@@ -1159,10 +1199,21 @@ def depth_fusion(ref_depth: Tensor, ref_conf: Tensor, src_depths: Tensor, src_co
     return fused, mask, points, vm
 
 
-def depth_affine(depth: Tensor, lo: float, hi: float) -> Tensor:
-    """(depth - lo) / (hi - lo) * 10   (Refinement pre-scale, module.py:353-355)."""
+def _refine_range(lo, hi, device) -> Tensor:
+    """(depth_min, depth_max, interval) of the Refinement kernels: a 3-element device tensor (geometry block) with hi None, or two
+    Python floats = limits that are already in interval units (interval 1: module.py's network on its own)."""
+    rng = geo(lo if hi is None else [lo, hi, 1.0], device, "depth_range")
+    if rng.numel() < 3:
+        raise ValueError("Refinement depth range: (depth_min, depth_max, interval) needs 3 values")
+    return rng
+
+
+def depth_affine(depth: Tensor, lo, hi=None) -> Tensor:
+    """(depth / ival - lo') / (hi' - lo') * 10 with lo' = lo / ival, hi' = hi / ival (models/model.py:213-216 + the Refinement pre-scale,
+    module.py:353-355).  (lo, hi, ival): see _refine_range."""
     out = torch.empty_like(depth)
-    check(_lib.load().cds_depth_affine_f32(_dev(depth, "depth"), out.data_ptr(), depth.numel(), float(lo), float(hi),
+    rng = _refine_range(lo, hi, depth.device)
+    check(_lib.load().cds_depth_affine_f32(_dev(depth, "depth"), out.data_ptr(), depth.numel(), _dev(rng, "depth_range"),
                                            _stream(depth)), "cds_depth_affine_f32")
     return out
 
@@ -1181,14 +1232,16 @@ def deconv2d_k3s2(x: Tensor, wpk: Tensor, bias: Optional[Tensor], act: int = ACT
     return out
 
 
-def refine_finish(d_norm: Tensor, res: Tensor, lo: float, hi: float) -> Tensor:
-    """((bilinear x2, align_corners=True)(d_norm [h,w]) + res [2h,2w]) / 10 * (hi - lo) + lo   (module.py:366-368)."""
+def refine_finish(d_norm: Tensor, res: Tensor, lo, hi=None) -> Tensor:
+    """(((bilinear x2, align_corners=True)(d_norm [h,w]) + res [2h,2w]) / 10 * (hi' - lo') + lo') * ival   (module.py:366-368,
+    models/model.py:218).  (lo, hi, ival): see _refine_range."""
     h, w = d_norm.shape
     if tuple(res.shape) != (2 * h, 2 * w):
         raise ValueError("refine_finish: res must be [2h,2w]")
     out = torch.empty_like(res)
-    check(_lib.load().cds_refine_finish_f32(_dev(d_norm, "d_norm"), _dev(res, "res"), out.data_ptr(), h, w, float(lo),
-                                            float(hi), _stream(res)), "cds_refine_finish_f32")
+    rng = _refine_range(lo, hi, res.device)
+    check(_lib.load().cds_refine_finish_f32(_dev(d_norm, "d_norm"), _dev(res, "res"), out.data_ptr(), h, w, _dev(rng, "depth_range"),
+                                            _stream(res)), "cds_refine_finish_f32")
     return out
 
 

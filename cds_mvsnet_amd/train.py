@@ -146,22 +146,32 @@ def train_step(model: torch.nn.Module, optimizer: torch.optim.Optimizer, sample:
     """One optimisation step on ``sample`` = {imgs, proj_matrices, depth_values, depth: {stageK}, mask: {stageK}}
     (already on the model's device).  Returns (loss, depth_loss) as Python floats.  activation_storage: None = the process default
     (fp32 unless CDS_TRAIN_ACT_STORAGE=bf16), "f32" or "bf16" (module docstring)."""
+    loss, depth_loss = _step_tensors(model, optimizer, sample, temperature, dlossw, reducer, activation_storage)
+    return float(loss), float(depth_loss)
+
+
+def _step_tensors(model, optimizer, sample, temperature, dlossw, reducer, activation_storage, geo=None, update: bool = True):
+    """train_step without the host read of the loss: returns the two 0-dim device tensors.  geo: the step's geometry block
+    (training.train_geometry, uploaded); None = built from the sample here.  update=False stops after the backward pass."""
+    from . import train2d_ops, training
     if not model.training:                                   # walking ~1 400 modules costs 1 ms of a CPU-bound 28 ms step
         model.train()
     optimizer.zero_grad(set_to_none=True)
-    dv = sample["depth_values"]
-    interval = dv[:, 1] - dv[:, 0]
-    from . import train2d_ops
+    imgs = sample["imgs"]
+    if geo is None:
+        geo = training.train_geometry(model, sample["proj_matrices"], sample["depth_values"], imgs.shape[1]).upload(imgs.device)
     with (train2d_ops.activation_storage(activation_storage) if activation_storage is not None else contextlib.nullcontext()):
-        outputs = model(sample["imgs"], sample["proj_matrices"], dv, gt_depths=sample["depth"], temperature=temperature)
+        with torch.cuda.device(imgs.device):
+            outputs = training.forward_train(model, imgs.float(), None, None, sample["depth"], temperature, geo=geo)
     outputs = _to_float(outputs)
-    loss, depth_loss = final_loss(outputs, sample["depth"], sample["mask"], dlossw=list(dlossw), depth_interval=interval)
+    loss, depth_loss = final_loss(outputs, sample["depth"], sample["mask"], dlossw=list(dlossw), depth_interval=geo["dint"])
     # weight gradients on a side stream, joined before anything reads .grad (CDS_TRAIN_SIDE_STREAM=0: everything on one stream)
     _backward(model, loss)
-    if reducer is not None:
-        reducer.reduce()
-    optimizer.step()
-    return float(loss.detach()), float(depth_loss.detach())
+    if update:
+        if reducer is not None:
+            reducer.reduce()
+        optimizer.step()
+    return loss.detach(), depth_loss.detach()
 
 
 _SIDE_VERDICT: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()   # model -> (step structure key, side stream is sound)
@@ -229,3 +239,112 @@ def _to_float(x):
     if isinstance(x, dict):
         return {k: _to_float(v) for k, v in x.items()}
     return x
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# the training step as a hipGraph
+# ---------------------------------------------------------------------------------------------------------------------------------------
+class CapturedTrainStep:
+    """``train_step`` captured into a hipGraph and replayed.  An eager step is ~1 000 kernel launches behind ~140
+    autograd nodes: ~21 ms of Python / ctypes / autograd-engine time for a step whose kernels finish 0.35 ms after the last launch
+     - and the loss read at its end keeps the host from running ahead.  Everything per-sample that the kernels
+    need as NUMBERS (epipoles, homographies, depth range, spacings) is device data in the step's geometry block
+    (training.train_geometry), so forward + loss + backward (+ the SGD update when there is one rank) are recorded ONCE per
+    ``(sample shapes, temperature, learning rate, weight decay, storage policy)`` key and replayed with
+
+        the sample copied into the graph's static input tensors, the geometry block rewritten, one hipGraphLaunch;
+        with several ranks: the flat-bucket gradient all-reduce and the optimizer step, eagerly, after the replay.
+
+    The first ``eager_steps`` calls of a key run ``train_step``'s eager path (real steps on real samples: they are also the side-stream
+    audit of ``_backward`` and the allocator / LDS-attribute warm-up a capture must not contain).  Returns the step's loss and depth
+    loss as 0-dim DEVICE tensors that the next call overwrites (static graph outputs): read them with ``float()`` when a number is
+    wanted - reading every step synchronises the host with the GPU, reading every n-th lets the host prepare the next samples'
+    geometry while the GPU trains.  A change of the learning rate (StepLR) or the temperature (trainer.py:45-49) is a new key: one
+    capture per epoch boundary.  Parity: ``tests/test_graphed_gpu.py`` - captured and eager steps from the same weights give equal
+    losses and the same updated weights up to the fp32 atomics noise of the gradients."""
+
+    def __init__(self, model: torch.nn.Module, optimizer: torch.optim.Optimizer, reducer: Optional[GradAllReducer] = None,
+                 dlossw: Sequence[float] = (0.5, 1.0, 2.0), activation_storage: Optional[str] = None, eager_steps: int = 2,
+                 max_graphs: int = 2):
+        self.model, self.optimizer, self.reducer = model, optimizer, reducer
+        self.dlossw, self.activation_storage = tuple(dlossw), activation_storage
+        # the first backward of a model is the single-stream audit of `_backward`: with eager_steps = 0 and a model that has not run a
+        # backward yet, that audit happens inside the capture and the graph keeps the weight gradients on one stream
+        self.eager_steps = max(0, int(eager_steps))
+        self.max_graphs = max_graphs
+        self._entries: Dict[tuple, dict] = {}
+        self._stream: Optional["torch.cuda.Stream"] = None
+        self.captures = 0
+
+    def _multi_rank(self) -> bool:
+        return self.reducer is not None and self.reducer.world_size() > 1
+
+    @staticmethod
+    def _sample_tensors(sample) -> List[Tuple[str, Tensor]]:
+        out = [("imgs", sample["imgs"])]
+        for grp in ("depth", "mask"):
+            out += [(f"{grp}.{k}", sample[grp][k]) for k in sorted(sample[grp])]
+        return out
+
+    def _key(self, sample, temperature: float, geo) -> tuple:
+        groups = tuple((g["lr"], g["weight_decay"], g.get("momentum", 0)) for g in self.optimizer.param_groups)
+        shapes = tuple((n, tuple(t.shape), t.dtype) for n, t in self._sample_tensors(sample))
+        return (shapes, float(temperature), groups, geo.layout(), self.activation_storage, self._multi_rank())
+
+    def _capture(self, sample, temperature: float, geo) -> dict:
+        dev = sample["imgs"].device
+        e: dict = {"static": {}, "block": torch.empty((geo.numel(),), dtype=torch.float32, device=dev)}
+        seen: Dict[int, Tensor] = {}
+        for name, t in self._sample_tensors(sample):        # tensors that alias in the sample (stage4 = stage3) alias in the copy
+            e["static"][name] = seen.setdefault(t.data_ptr(), t.detach().clone())
+        st_sample = {"imgs": e["static"]["imgs"],
+                     "depth": {k: e["static"][f"depth.{k}"] for k in sample["depth"]},
+                     "mask": {k: e["static"][f"mask.{k}"] for k in sample["mask"]}}
+        if self._stream is None:
+            self._stream = torch.cuda.Stream(device=dev)
+        st, cur = self._stream, torch.cuda.current_stream(dev)
+        geo.upload(dev, into=e["block"])
+        st.wait_stream(cur)
+        self.optimizer.zero_grad(set_to_none=True)           # the captured backward allocates the gradients from the graph's pool
+        e["graph"] = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(st):
+            with torch.cuda.graph(e["graph"], stream=st):
+                e["loss"], e["depth_loss"] = _step_tensors(self.model, self.optimizer, st_sample, temperature, self.dlossw, None,
+                                                           self.activation_storage, geo=geo.bind(e["block"]),
+                                                           update=not self._multi_rank())
+        cur.wait_stream(st)
+        self.captures += 1
+        e["calls"] = 0
+        e["grads"] = [(p, p.grad) for p in self.model.parameters() if p.grad is not None]   # this graph's gradient tensors (its pool)
+        return e
+
+    def __call__(self, sample: Dict[str, object], temperature: float) -> Tuple[Tensor, Tensor]:
+        from . import training
+        imgs = sample["imgs"]
+        with torch.cuda.device(imgs.device):
+            geo = training.train_geometry(self.model, sample["proj_matrices"], sample["depth_values"], imgs.shape[1])
+            key = self._key(sample, temperature, geo)
+            e = self._entries.get(key)
+            if e is None:
+                e = self._entries[key] = {"eager": 0}
+                while len(self._entries) > self.max_graphs:
+                    self._entries.pop(next(iter(self._entries)))
+            if "graph" not in e:
+                if e["eager"] < self.eager_steps:            # real steps, eagerly: audit + warm-up
+                    e["eager"] += 1
+                    return _step_tensors(self.model, self.optimizer, sample, temperature, self.dlossw, self.reducer,
+                                         self.activation_storage, geo=geo.upload(imgs.device))
+                e.update(self._capture(sample, temperature, geo))
+            for name, t in self._sample_tensors(sample):
+                dst = e["static"][name]
+                if dst.data_ptr() != t.data_ptr():
+                    dst.copy_(t, non_blocking=True)
+            geo.upload(imgs.device, into=e["block"])
+            e["graph"].replay()
+            e["calls"] += 1
+            for p, g in e["grads"]:                          # `.grad` shows THIS graph's gradients (another key's capture may have re-bound it)
+                p.grad = g
+            if self._multi_rank():
+                self.reducer.reduce()
+                self.optimizer.step()
+        return e["loss"], e["depth_loss"]

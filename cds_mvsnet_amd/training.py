@@ -203,11 +203,12 @@ def _stack(ts: List[Tensor]) -> Tensor:
     return ts[0].unsqueeze(0) if len(ts) == 1 else torch.stack(ts)
 
 
-def stage_forward_train(stage_net, features, cams: Tensor, depth_values: Tensor, cost_reg, stage_idx: int,
-                        gt_depth: Optional[Tensor] = None) -> Dict[str, Tensor]:
+def stage_forward_train(stage_net, features, cams: Optional[Tensor], depth_values: Tensor, cost_reg, stage_idx: int,
+                        gt_depth: Optional[Tensor] = None, mats: Optional[List[Tensor]] = None) -> Dict[str, Tensor]:
     """``StageNet.forward`` in training mode (models/model.py:16-94 with ``self.training``), reference argument layout:
     features = list over source views of {'ref': (fea [B,C,h,w], nc_sum [B,1,h,w], nc [B,1,h,w]), 'src': (fea, nc_sum, _)};
-    cams [B,N,2,4,4] (host); depth_values [B,D,h,w].  Returns depth / photometric_confidence / feat_distance / norm_curv.
+    cams [B,N,2,4,4] (host) - or `mats`, the per-item homographies [V,12] as device slices of the step's geometry block (cams then
+    unused); depth_values [B,D,h,w].  Returns depth / photometric_confidence / feat_distance / norm_curv.
     K1 (detached, model.py:49), hypotheses and confidence run on the HIP kernels without gradient; K3 forward / backward and
     CostRegNet, the visibility CNN and the soft-argmin forward / backward on the HIP kernels with gradient."""
     stacked = features if isinstance(features, StackedFeatures) else None
@@ -219,8 +220,9 @@ def stage_forward_train(stage_net, features, cams: Tensor, depth_values: Tensor,
         if gt_depth.shape[1] != 1:
             raise ValueError(f"gt_depth must be [B,h,w] or [B,1,h,w], got {tuple(gt_depth.shape)}")
         gt_depth = gt_depth[:, 0]
-    cams = cams.detach().float().cpu()
-    mats = [geometry.warp_matrices(cams[b]) for b in range(B)]
+    if mats is None:                                                     # reference signature: cameras in, one upload per batch item
+        cams = cams.detach().float().cpu()
+        mats = [ops.geo(geometry.warp_matrices(cams[b]), depth_values.device, "mats") for b in range(B)]
     hyps = [depth_values[b].detach().float().contiguous() for b in range(B)]
     # .float(): under bf16 autocast the convolution stacks hand over bf16 activations; the HIP kernels are fp32
     if stacked is not None:
@@ -288,29 +290,59 @@ def _pair_order(V: int, dev) -> Tensor:
     return _PAIR_ORDER[key]
 
 
-def forward_train(model, imgs: Tensor, proj_matrices: Dict[str, Tensor], depth_values: Tensor,
-                  gt_depths: Optional[Dict[str, Tensor]], temperature: float):
+def train_geometry(model, proj_matrices: Dict[str, Tensor], depth_values: Tensor, N: int) -> "geometry.GeoBlock":
+    """The HOST side of a training forward (the counterpart of CDSMVSNet.geometry_block): epipoles of every pair and batch item in
+    the orders FeatureNet's calls want them, homographies per stage and item, depth range / interval / per-stage spacing - one
+    geometry block, uploaded with one asynchronous copy; `forward_train(..., geo=)` then only launches kernels, which is what the
+    captured training step (train.CapturedTrainStep) records.  Device inputs are read back here (a synchronisation: keep the cameras
+    and depth values on the host, as the data loader delivers them, to let the host run ahead of the GPU)."""
+    from .model import _to_host
+    keys = list(proj_matrices.keys())
+    host = _to_host([depth_values] + [proj_matrices[k] for k in keys])
+    dv, cams = host[0], dict(zip(keys, host[1:]))
+    B, V = dv.shape[0], N - 1
+    geo = geometry.GeoBlock()
+    epi = [geometry.pairs_epipoles(cams["stage3"][b]) for b in range(B)]            # per item: ([V,2] in the reference, [V,2] in the sources)
+    # one stacked FeatureNet call: images ordered (pair v: reference, source) x batch (forward_train, BATCH_FEATURES)
+    geo.add("epi.all", torch.stack([epi[b][k][v] for v in range(V) for k in (0, 1) for b in range(B)]))
+    for v in range(V):                                                                # the reference's 2 V separate calls
+        geo.add(f"epi.ref{v}", torch.stack([epi[b][0][v] for b in range(B)]))
+        geo.add(f"epi.src{v}", torch.stack([epi[b][1][v] for b in range(B)]))
+    dint = dv[:, 1] - dv[:, 0]
+    geo.add("dmin", dv[:, 0])
+    geo.add("dmax", dv[:, -1])
+    geo.add("dint", dint)
+    for b in range(B):
+        geo.add(f"b{b}.range", [float(dv[b, 0]), float(dv[b, -1]), float(dint[b])])
+        for s in range(model.num_stage):
+            geo.add(f"b{b}.interval{s}", [float(model.depth_interals_ratio[s] * dint[b])])
+            geo.add(f"b{b}.mats.stage{s + 1}", geometry.warp_matrices(cams[f"stage{s + 1}"][b]))
+    return geo
+
+
+def forward_train(model, imgs: Tensor, proj_matrices: Optional[Dict[str, Tensor]], depth_values: Optional[Tensor],
+                  gt_depths: Optional[Dict[str, Tensor]], temperature: float, geo: Optional["geometry.GeoBlock"] = None):
     """CDSMVSNet.forward in training mode.  Same inputs / outputs as the reference (adds 'feat_distance' and
     'feat_target' per stage).  Module calls are grouped exactly like the reference's (FeatureNet once per image of
     every pair over the batch, the visibility CNN once per source view over the batch, CostRegNet once per stage over the
-    batch) so the batch statistics of every BatchNorm layer are taken over the same sets."""
+    batch) so the batch statistics of every BatchNorm layer are taken over the same sets.
+    geo: the step's geometry block (:func:`train_geometry`, uploaded); None = built from proj_matrices / depth_values here."""
     B, N, _, Him, Wim = imgs.shape
     H, W = (Him // 2, Wim // 2) if model.refine else (Him, Wim)
     T = float(temperature)
     dev = imgs.device
+    if geo is None:
+        geo = train_geometry(model, proj_matrices, depth_values, N).upload(dev)
     _scratch.begin_step(dev)                                             # zero arena + deferred counters of this step's HIP training ops
-    dv = depth_values.detach().float().cpu()
-    cams = {k: v.detach().float().cpu() for k, v in proj_matrices.items()}
     V = N - 1
     # model.py:154-161 calls FeatureNet once per image of every pair.  Its InstanceNorms are per sample and the BatchNorm2d of
     # each DynamicConv's attention MLP is evaluated per group of B samples (_att_weights_grouped), so the 2 V calls are ONE call
     # on the 2 V B images stacked along the batch axis: same values, an eighth of the kernel launches and of the per-parameter
     # gradient accumulations (the step is launch-bound).
-    epi = [[geometry.pair_epipoles(cams["stage3"][b, 0], cams["stage3"][b, v + 1]) for b in range(B)] for v in range(V)]
     feats = []
     if BATCH_FEATURES:
         # one call on the 2 V B images, stacked in the reference's call order (ref of pair 0, src of pair 0, ref of pair 1, ...)
-        e_all = torch.tensor([epi[v][b][k] for v in range(V) for k in (0, 1) for b in range(B)], dtype=torch.float32, device=dev)
+        e_all = geo["epi.all"]
         # all N views resized in one call, then gathered in the reference's call order (ref, src_1, ref, src_2, ...)
         small = imgs if (Him, Wim) == (H, W) else F.interpolate(imgs.reshape(B * N, 3, Him, Wim), (H, W)).view(B, N, 3, H, W)
         order = _pair_order(V, dev)
@@ -320,14 +352,12 @@ def forward_train(model, imgs: Tensor, proj_matrices: Dict[str, Tensor], depth_v
     else:
         ref_img = F.interpolate(imgs[:, 0], (H, W))
         for v in range(V):
-            e_ref = torch.tensor([e[0] for e in epi[v]], dtype=torch.float32, device=dev)
-            e_src = torch.tensor([e[1] for e in epi[v]], dtype=torch.float32, device=dev)
+            e_ref, e_src = geo[f"epi.ref{v}"], geo[f"epi.src{v}"]
             feats.append((feature_net(model.feature, ref_img, e_ref, T),
                           feature_net(model.feature, F.interpolate(imgs[:, v + 1], (H, W)), e_src, T)))
     outputs: Dict[str, object] = {}
     depth = None
-    dint_all = (dv[:, 1] - dv[:, 0])
-    dint_dev = dint_all.to(dev) if gt_depths is not None else None
+    dint_dev = geo["dint"]
     # One stream per stage (CDS_TRAIN_STAGE_STREAMS=1, experiment): the forward stays serial (a stage's hypotheses need the previous
     # stage's depth) but depth is DETACHED between stages, so the three backward chains are independent and autograd runs each on the
     # stream of its forward - next to each other.  Every tensor that crosses streams is recorded on the other stream (caching allocator).
@@ -348,12 +378,11 @@ def forward_train(model, imgs: Tensor, proj_matrices: Dict[str, Tensor], depth_v
         with (torch.cuda.stream(st_s) if use_streams else contextlib.nullcontext()):
             hyps = []
             for b in range(B):
-                dmin, dmax = float(dv[b, 0]), float(dv[b, -1])
                 if depth is None:
-                    hyps.append(ops.depth_planes(D, h, w, dmin, dmax, dev))
+                    hyps.append(ops.depth_planes(D, h, w, geo[f"b{b}.range"], None, dev))
                 else:
-                    hyps.append(ops.depth_hypotheses(depth[b].detach().contiguous(), D, H, W, scale,
-                                                     float(model.depth_interals_ratio[s] * dint_all[b]), dmin, dmax))
+                    hyps.append(ops.depth_hypotheses(depth[b].detach().contiguous(), D, H, W, scale, geo[f"b{b}.interval{s}"],
+                                                     geo[f"b{b}.range"]))
             features = stacked_feats[name] if BATCH_FEATURES else [{"ref": feats[v][0][name], "src": feats[v][1][name]} for v in range(V)]
             hyp_b = torch.stack(hyps)
             if use_streams:
@@ -363,8 +392,9 @@ def forward_train(model, imgs: Tensor, proj_matrices: Dict[str, Tensor], depth_v
                     gt_depths[name].record_stream(st_s)
                 if depth is not None:
                     depth.record_stream(st_s)
-            st = stage_forward_train(model.stage_net, features, cams[name], hyp_b, model.cost_regularization[s], s,
-                                     gt_depth=gt_depths[name] if gt_depths is not None else None)
+            st = stage_forward_train(model.stage_net, features, None, hyp_b, model.cost_regularization[s], s,
+                                     gt_depth=gt_depths[name] if gt_depths is not None else None,
+                                     mats=[geo[f"b{b}.mats.{name}"] for b in range(B)])
             depth = st["depth"]
             if gt_depths is not None:                                            # model.py:202-207
                 st["feat_target"] = ops.feat_target(hyp_b, gt_depths[name], dint_dev, float(scale), 0.5 / float(scale))
@@ -379,10 +409,8 @@ def forward_train(model, imgs: Tensor, proj_matrices: Dict[str, Tensor], depth_v
         for s in range(model.num_stage):
             main.wait_stream(_stage_stream(dev, s))
     if model.refine:
-        dvd = depth_values.float()
-        dint = (dvd[:, 1] - dvd[:, 0]).view(B, 1, 1)
-        refined = model.refine_network(imgs[:, 0], (depth.detach() / dint).unsqueeze(1), dvd[:, 0] / dint[:, 0, 0],
-                                       dvd[:, -1] / dint[:, 0, 0])
+        dint = dint_dev.view(B, 1, 1)
+        refined = model.refine_network(imgs[:, 0], (depth.detach() / dint).unsqueeze(1), geo["dmin"] / dint_dev, geo["dmax"] / dint_dev)
         outputs["refined_depth"] = refined.squeeze(1) * dint
     else:
         outputs["refined_depth"] = depth

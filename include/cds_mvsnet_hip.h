@@ -8,7 +8,11 @@
  * the reference lines it replaces.
  *
  * Conventions
- *   - every pointer is a DEVICE pointer to contiguous fp32 unless the name ends in _host;
+ *   - every pointer is a DEVICE pointer to contiguous fp32 unless the name ends in _host.  Since round 6 that includes the
+ *     per-call GEOMETRY: homographies (`mats`), epipoles and the depth-range scalars are device data - slices of one small
+ *     "geometry block" the host writes with a single host -> device copy per forward (cds_mvsnet_amd/geometry.py) - and no
+ *     longer by-value arguments, so that a captured hipGraph of the forward / training step is replayed for new cameras by
+ *     rewriting that block;
  *   - the caller owns all memory; nothing is allocated, freed or synchronised inside;
  *   - `stream` is a hipStream_t (NULL = default stream); calls are re-entrant across streams;
  *   - return value: 0 on success, a negative hipError_t on a launch failure,
@@ -62,11 +66,11 @@ int cds_chw_to_hwc_f32(const float* src_chw, float* dst_hwc, int C, int h, int w
 /*
  * homo_warping_3D (models/utils/warping.py:69-104): bilinear, zero padding, align_corners=True.
  *   src_hwc   [h][w][C]   source feature map, channels-last
- *   mat_host  12 floats   rows of (P_src * P_ref^-1)[:3,:3] then its [:3,3] (warping.py:80-82)
+ *   mat       12 floats   rows of (P_src * P_ref^-1)[:3,:3] then its [:3,3] (warping.py:80-82); DEVICE memory
  *   hyp       [D][h][w] if hyp_per_pixel else [D]
  *   out       [C][D][h][w]
  */
-int cds_homo_warp_f32(const float* src_hwc, const float* mat_host, const float* hyp, float* out,
+int cds_homo_warp_f32(const float* src_hwc, const float* mat, const float* hyp, float* out,
                       int C, int D, int h, int w, int hyp_per_pixel, void* stream);
 
 /*
@@ -75,14 +79,14 @@ int cds_homo_warp_f32(const float* src_hwc, const float* mat_host, const float* 
  * warped volume.
  *   ref_chw   [V][C][h][w]  per-pair reference features
  *   src_hwc   [V][h][w][C]  source features, channels-last
- *   mats_host [V][12]
+ *   mats      [V][12]       homographies as above, DEVICE memory (geometry block)
  *   entropy   [V][h][w]
  */
-int cds_warp_entropy_f32(const float* ref_chw, const float* src_hwc, const float* mats_host,
+int cds_warp_entropy_f32(const float* ref_chw, const float* src_hwc, const float* mats,
                          const float* hyp, float* entropy, int V, int C, int D, int h, int w,
                          int hyp_per_pixel, void* stream);
 /* the same with flags: CDS_WARP_FAST_POSITIONS (cds_warp_entropy_f32 == flags 0) */
-int cds_warp_entropy_flags_f32(const float* ref_chw, const float* src_hwc, const float* mats_host,
+int cds_warp_entropy_flags_f32(const float* ref_chw, const float* src_hwc, const float* mats,
                                const float* hyp, float* entropy, int V, int C, int D, int h, int w,
                                int hyp_per_pixel, int flags, void* stream);
 
@@ -96,7 +100,7 @@ int cds_warp_entropy_flags_f32(const float* ref_chw, const float* src_hwc, const
  * V <= CDS_MAX_VIEWS per call.
  */
 int cds_warp_aggregate_f32(const float* ref_chw, const float* src_hwc, const float* vis_w,
-                           const float* mats_host, const float* hyp, float* volume, float* vis_sum,
+                           const float* mats, const float* hyp, float* volume, float* vis_sum,
                            int V, int C, int D, int h, int w, int hyp_per_pixel, int flags,
                            void* stream);
 
@@ -107,9 +111,9 @@ int cds_warp_aggregate_f32(const float* ref_chw, const float* src_hwc, const flo
  * y_off + y: a window's result equals the same rows of the full-grid call bit for bit.  flags as in the full-grid calls.
  * Returns CDS_EINVAL for shapes outside the LDS-staged kernels (C not in {8, 16, 32}, w < 2).
  */
-int cds_warp_entropy_window_f32(const float* ref_chw, const float* src_hwc, const float* mats_host, const float* hyp,
+int cds_warp_entropy_window_f32(const float* ref_chw, const float* src_hwc, const float* mats, const float* hyp,
                                 float* entropy, int V, int C, int D, int h, int w, int hs, int y_off, int flags, void* stream);
-int cds_warp_aggregate_window_f32(const float* ref_chw, const float* src_hwc, const float* vis_w, const float* mats_host,
+int cds_warp_aggregate_window_f32(const float* ref_chw, const float* src_hwc, const float* vis_w, const float* mats,
                                   const float* hyp, float* volume, float* vis_sum, int V, int C, int D, int h, int w, int hs,
                                   int y_off, int flags, void* stream);
 
@@ -122,7 +126,7 @@ int cds_warp_aggregate_window_f32(const float* ref_chw, const float* src_hwc, co
  * The sampling grid has no gradient (built under no_grad, warping.py:79): nothing flows to hypotheses / cameras.
  */
 int cds_warp_aggregate_bwd_f32(const float* ref_chw, const float* src_hwc, const float* vis_w,
-                               const float* mats_host, const float* hyp, const float* grad_volume,
+                               const float* mats, const float* hyp, const float* grad_volume,
                                float* grad_ref, float* grad_src_hwc, float* grad_vis, int V, int C, int D,
                                int h, int w, int hyp_per_pixel, void* stream);
 /* The training step's epilogue of K3 (models/model.py:56-78) in one launch, and its backward in two: volume = volume_sum /
@@ -156,12 +160,14 @@ int cds_softargmin_conf_f32(const float* prob_pre, const float* hyp, float* dept
  *                        upsampled to H x W, sampled at  up - ((D-1)/2)*interval + k*interval,
  *                        clamped to [dmin,dmax] and resized trilinearly to [D][H/scale][W/scale].
  *   out        [D][H/scale][W/scale]
+ *   interval   1 float, DEVICE: the stage's hypothesis spacing (ratio x depth interval)
+ *   depth_range 2 floats, DEVICE: (dmin, dmax)
  */
 int cds_depth_hypotheses_f32(const float* prev_depth, float* out, int D, int hp, int wp, int H, int W,
-                             int scale, float interval, float dmin, float dmax, void* stream);
+                             int scale, const float* interval, const float* depth_range, void* stream);
 
-/* First-stage planes: out[k][y][x] = lo + k*((hi-lo)/(D-1))  (module.py:425-433). */
-int cds_depth_planes_f32(float* out, int D, int h, int w, float lo, float hi, void* stream);
+/* First-stage planes: out[k][y][x] = lo + k*((hi-lo)/(D-1))  (module.py:425-433); depth_range = (lo, hi), DEVICE. */
+int cds_depth_planes_f32(float* out, int D, int h, int w, const float* depth_range, void* stream);
 
 /*
  * K4 (module.py:80-116,270-315): 3x3x3 convolution, padding 1, stride 1 or 2, with fused
@@ -282,10 +288,10 @@ int cds_dynconv_branches_sbf_f32(const float* x, const float* in_affine, const v
  *   out [N][Cout][H][W] (before its InstanceNorm), norm_curv [N][H][W]
  *   partial: 8-byte aligned scratch of 2 * N * parts * Cout doubles, parts = cds_dynconv_fused_parts(H, W); reduce with
  *            cds_instnorm_reduce_f32
- *   w1 [4][K], b1 [4], w2 [K][4]: the attention MLP with its BatchNorm folded in; epipoles_host [N][2] (pixels, this resolution)
+ *   w1 [4][K], b1 [4], w2 [K][4]: the attention MLP with its BatchNorm folded in; epipoles [N][2] (DEVICE) (pixels, this resolution)
  * K in {2, 3}, kernel sizes in {1, 3, 5, 7}, Cin % 8 == 0, Cout + 3 <= 48, Cout % 16 <= 13, W % 4 == 0, N <= CDS_MAX_IMAGES. */
 int cds_dynconv_fused_sbf_f32(const float* x, const float* in_affine, const void* weight_split, const float* bias,
-                              const float* w1, const float* b1, const float* w2, const float* epipoles_host,
+                              const float* w1, const float* b1, const float* w2, const float* epipoles,
                               float temperature, float* out, float* norm_curv, double* partial, int N, int Cin, int Cout,
                               int H, int W, const int* ksizes, int nb, void* stream);
 int cds_dynconv_fused_parts(int H, int W);
@@ -320,11 +326,11 @@ int cds_conv2d_fpn_f32(const float* coarse, const float* coarse_affine, const fl
  *   branches [K][N][Cout+3][H][W]  per kernel size: the Cout responses of convs[k] followed by the 3 responses of
  *                                  att_convs[k] (one batched cds_conv2d_f32 per size)
  *   w1 [4][K], b1 [4] (BN folded), w2 [K][4]   (device pointers); K in {2,3}
- *   epipoles_host [N][2]           (x, y) in pixels of this resolution; N <= CDS_MAX_IMAGES
+ *   epipoles [N][2] (DEVICE)           (x, y) in pixels of this resolution; N <= CDS_MAX_IMAGES
  *   out [N][Cout][H][W]; norm_curv [N][H][W]
  */
 int cds_dynconv_blend_f32(const float* branches, const float* w1, const float* b1, const float* w2,
-                          const float* epipoles_host, float temperature, float* out, float* norm_curv,
+                          const float* epipoles, float temperature, float* out, float* norm_curv,
                           int N, int K, int Cout, int H, int W, void* stream);
 /*
  * Same, when the first n_shared images of the batch are copies of ONE image (the reference image of every pair,
@@ -333,7 +339,7 @@ int cds_dynconv_blend_f32(const float* branches, const float* w1, const float* b
  *   branches [K][N - n_shared + 1][Cout+3][H][W]: slot 0 = the shared image, slot n - n_shared + 1 = image n >= n_shared
  */
 int cds_dynconv_blend_shared_f32(const float* branches, const float* w1, const float* b1, const float* w2,
-                                 const float* epipoles_host, float temperature, float* out, float* norm_curv, int N,
+                                 const float* epipoles, float temperature, float* out, float* norm_curv, int N,
                                  int K, int Cout, int H, int W, int n_shared, void* stream);
 
 /*
@@ -348,7 +354,7 @@ int cds_dynconv_blend_shared_f32(const float* branches, const float* w1, const f
  */
 int cds_blend_stats_parts(int H, int W);
 int cds_dynconv_blend_stats_f32(const float* branches, const float* w1, const float* b1, const float* w2,
-                                const float* epipoles_host, float temperature, float* out, float* norm_curv,
+                                const float* epipoles, float temperature, float* out, float* norm_curv,
                                 float* partial, int N, int K, int Cout, int H, int W, int n_shared, void* stream);
 int cds_instnorm_reduce_f32(const float* partial, int parts, float* stats, float* affine, int N, int C, int H, int W,
                             float slope, void* stream);
@@ -381,7 +387,7 @@ int cds_instnorm_affine_f32(const float* x, float* affine, float* stats, int N, 
  *   split-bf16 arithmetic as a transposed implicit GEMM (rows = output channels, columns = pixels) + the blend epilogue on the
  *   accumulators + the InstanceNorm records of the result.
  *     x [N][H][W][C], in_affine [N][C][3] or NULL, weight_split = ops.split_pack_dynconv (as cds_dynconv_branches_sbf_f32),
- *     bias [nb][C + 3] or NULL, w1 [4][nb], b1 [4], w2 [nb][4], epipoles_host [N][2] (pixels at this resolution)
+ *     bias [nb][C + 3] or NULL, w1 [4][nb], b1 [4], w2 [nb][4], epipoles [N][2] (DEVICE) (pixels at this resolution)
  *     out [N][H][W][C] (before its InstanceNorm), norm_curv [N][H][W], partial [N][cds_dynconv_cl_parts(H, W)][C][2]
  *   (C, ksizes) in {(8, 3-5-7), (8, 1-3), (16, 3-5), (16, 1-3), (32, 1-3)}, Cin == Cout == C, N <= CDS_MAX_IMAGES.
  * cds_dynconv_blend_cl_f32: the epilogue alone over a PLANAR branch tensor [3][N - n_shared + 1][8 + 3][H][W] (conv00: 3 input
@@ -403,17 +409,17 @@ int cds_debug_poison_lds(unsigned pattern);
 
 int cds_dynconv_cl_parts(int H, int W);
 int cds_dynconv_cl_f32(const float* x, const float* in_affine, const void* weight_split, const float* bias, const float* w1,
-                       const float* b1, const float* w2, const float* epipoles_host, float temperature, float* out,
+                       const float* b1, const float* w2, const float* epipoles, float temperature, float* out,
                        float* norm_curv, double* partial, int N, int C, int H, int W, const int* ksizes, int nb, void* stream);
 /* conv00 of FeatureNet (module.py:209: DynamicConv 3 -> 8, kernel sizes 3 / 7 / 11) in ONE kernel on the matrix cores: x [S][3][H][W]
  * planar images in S = N - n_shared + 1 slots (slot 0 is shown by the first n_shared output images, each with its own epipole),
  * weight_split = ops.split_pack_conv00, bias [3][11] or NULL -> out [N][H][W][8], norm_curv [N][H][W],
  * partial [N][cds_dynconv_cl_parts(H, W)][8][2] doubles. */
 int cds_conv00_cl_f32(const float* x, const void* weight_split, const float* bias, const float* w1, const float* b1, const float* w2,
-                      const float* epipoles_host, float temperature, float* out, float* norm_curv, double* partial, int N, int n_shared,
+                      const float* epipoles, float temperature, float* out, float* norm_curv, double* partial, int N, int n_shared,
                       int H, int W, void* stream);
 int cds_blend_cl_parts(int H, int W);
-int cds_dynconv_blend_cl_f32(const float* branches, const float* w1, const float* b1, const float* w2, const float* epipoles_host,
+int cds_dynconv_blend_cl_f32(const float* branches, const float* w1, const float* b1, const float* w2, const float* epipoles,
                              float temperature, float* out, float* norm_curv, double* partial, int N, int K, int Cout, int H, int W,
                              int n_shared, void* stream);
 int cds_conv2d_k3s2_cl_f32(const float* x, const float* in_affine, const float* weight, float* out, int N, int Cin, int Cout, int H,
@@ -464,16 +470,20 @@ int cds_view_mean_f32(const float* x, float* out, int V, int n, void* stream);
 
 /*
  * Refinement network (module.py:318-370) pieces besides its 3x3 Conv+BN+ReLU units (those run on cds_conv2d_f32):
- *   cds_depth_affine_f32   out[i] = (depth[i] - lo) / (hi - lo) * 10                      (module.py:353-355)
+ *   depth_range            3 floats, DEVICE (geometry block): (depth_min, depth_max, ival).  models/model.py:213-216 divides the depth
+ *                          and both limits by the depth interval before the network and multiplies the result by it (:218): that is
+ *                          folded into the two kernels - lo = depth_min / ival, hi = depth_max / ival (true divisions, as the
+ *                          reference's tensor ops); ival = 1 gives module.py's network on its own
+ *   cds_depth_affine_f32   out[i] = (depth[i] / ival - lo) / (hi - lo) * 10               (module.py:353-355)
  *   cds_deconv2d_k3s2_f32  ConvTranspose2d k=3, stride 2, padding 1, output_padding 1 (+ bias + activation);
  *                          x [Cin][H][W] -> out [Cout][2H][2W]; weight PACKED [Cin][9][Cout] = PyTorch's
  *                          [Cin][Cout][3][3] permuted (0,2,3,1) (BatchNorm folded in by the caller); Cout = 8
- *   cds_refine_finish_f32  out = ((bilinear x2, align_corners=True)(d_norm [h][w]) + res [2h][2w]) / 10 * (hi - lo) + lo
+ *   cds_refine_finish_f32  out = (((bilinear x2, align_corners=True)(d_norm [h][w]) + res [2h][2w]) / 10 * (hi - lo) + lo) * ival
  */
-int cds_depth_affine_f32(const float* depth, float* out, int n, float lo, float hi, void* stream);
+int cds_depth_affine_f32(const float* depth, float* out, int n, const float* depth_range, void* stream);
 int cds_deconv2d_k3s2_f32(const float* x, const float* weight, const float* bias, float* out, int Cin, int Cout,
                           int H, int W, int act, void* stream);
-int cds_refine_finish_f32(const float* d_norm, const float* res, float* out, int h, int w, float lo, float hi,
+int cds_refine_finish_f32(const float* d_norm, const float* res, float* out, int h, int w, const float* depth_range,
                           void* stream);
 
 /*

@@ -11,7 +11,7 @@ hyp = synth.make_hypotheses(D, h, w, seed=1)[0].to(dev)
 ref = torch.stack([f["ref"][0][0] for f in feats]).to(dev).contiguous()
 src = torch.stack([ops.chw_to_hwc(f["src"][0][0].to(dev).contiguous()) for f in feats])
 vis = torch.rand(N - 1, h, w, device=dev)
-mats = geometry.warp_matrices(cams[0])
+mats = ops.geo(geometry.warp_matrices(cams[0]), "cuda", "mats")   # device data since round 6 (geometry block)
 vol = torch.empty(D, h, w, C, device=dev); vs = torch.empty(h, w, device=dev)   # channels-last: what the model runs
 for _ in range(3):
     ops.warp_aggregate(ref, src, vis, mats, hyp, volume=vol, vis_sum=vs, channels_last=True)      # B_alg = 2 354 053 120 B

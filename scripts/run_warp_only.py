@@ -13,7 +13,7 @@ hyp = synth.make_hypotheses(D, h, w, seed=1)[0].to(dev)
 ref = torch.stack([f["ref"][0][0] for f in feats]).to(dev).contiguous()
 src = torch.stack([ops.chw_to_hwc(f["src"][0][0].to(dev).contiguous()) for f in feats])
 vis = torch.rand(N - 1, h, w, device=dev)
-mats = geometry.warp_matrices(cams[0])
+mats = ops.geo(geometry.warp_matrices(cams[0]), "cuda", "mats")   # device data since round 6 (geometry block)
 for i in range(3):
     ent = ops.warp_entropy(ref, src, mats, hyp)
     vol, vs = ops.warp_aggregate(ref, src, vis, mats, hyp)

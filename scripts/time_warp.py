@@ -18,7 +18,7 @@ hyp = synth.make_hypotheses(D, h, w, seed=1, **rng)[0].to(dev)
 ref = torch.stack([f["ref"][0][0] for f in feats]).to(dev).contiguous()
 src = torch.stack([ops.chw_to_hwc(f["src"][0][0].to(dev).contiguous()) for f in feats])
 vis = torch.rand(N - 1, h, w, device=dev)
-mats = geometry.warp_matrices(cams[0])
+mats = ops.geo(geometry.warp_matrices(cams[0]), "cuda", "mats")   # device data since round 6 (geometry block)
 vol = torch.empty((D, h, w, C) if CL else (C, D, h, w), device=dev); vs = torch.empty(h, w, device=dev)
 def timeit(fn, n=10):
     for _ in range(3): fn()

@@ -1,0 +1,172 @@
+"""hipGraph replay of the inference forward (cds_mvsnet_amd/graphed.py) against the eager forward - the parity reference of the
+captured path: same kernels in the same order on the same numbers, so the outputs must be EQUAL, bit for bit,
+also when the replay runs with other cameras / depth ranges than the capture saw (the geometry block is the only thing that changes)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _scene(N, H, W, refine, seed, dev, on_device=False):
+    from cds_mvsnet_amd import synth
+    imgs = synth.make_images(N, H, W, seed=seed).to(dev)
+    cams = synth.make_cameras(N, H, W, refine=refine, seed=seed)
+    dv = synth.make_depth_values()
+    if seed % 2:                                   # another depth range as well: every scalar of the block changes between scenes
+        dv = dv * 1.25 + 10.0
+    if on_device:
+        cams, dv = {k: v.to(dev) for k, v in cams.items()}, dv.to(dev)
+    return imgs, cams, dv
+
+
+def _flat(out):
+    items = []
+    for k in sorted(out):
+        v = out[k]
+        if isinstance(v, dict):
+            items += [(f"{k}.{kk}", v[kk]) for kk in sorted(v)]
+        else:
+            items.append((k, v))
+    return items
+
+
+def _assert_equal(a, b, what):
+    fa, fb = _flat(a), _flat(b)
+    assert [k for k, _ in fa] == [k for k, _ in fb]
+    for (k, x), (_, y) in zip(fa, fb):
+        assert x.shape == y.shape, (what, k)
+        assert torch.equal(x, y), (what, k, float((x - y).abs().max()))
+
+
+@pytest.mark.parametrize("H,W,N,refine", [(128, 160, 3, False), (128, 192, 3, True), (256, 320, 5, False), (512, 640, 5, False)])
+def test_captured_forward_equals_eager(H, W, N, refine):
+    from cds_mvsnet_amd import CDSMVSNet, seeded_init_
+    from cds_mvsnet_amd.graphed import CapturedForward
+    dev = torch.device("cuda")
+    model = seeded_init_(CDSMVSNet(refine=refine, depth_interals_ratio=(4.0, 1.5, 0.75)), 0).eval().to(dev)
+    runner = CapturedForward(model)
+    scenes = [_scene(N, H, W, refine, 4 + i, dev, on_device=(i == 2)) for i in range(3)]
+    with torch.no_grad():
+        eager = [model(*s, temperature=0.01) for s in scenes]
+        again = model(*scenes[0], temperature=0.01)
+    _assert_equal(again, eager[0], "eager vs eager")        # the inference kernels are deterministic: equality is the right bar
+    # capture on scene 0, replay on 0, 1, 2 (other images, cameras, depth range; scene 2 hands the cameras over as device tensors), then 0 again
+    for i in (0, 1, 2, 0):
+        got = runner(*scenes[i], temperature=0.01, clone=True)
+        _assert_equal(got, eager[i], f"captured vs eager, scene {i}")
+    assert runner.captures == 1
+    # another temperature is another key (the softmax temperature is a by-value kernel argument)
+    with torch.no_grad():
+        want = model(*scenes[1], temperature=0.1)
+    _assert_equal(runner(*scenes[1], temperature=0.1, clone=True), want, "captured vs eager, T = 0.1")
+    assert runner.captures == 2
+
+
+def test_use_graphs_keeps_the_module_surface_and_follows_the_weights():
+    """model.use_graphs(): `model(imgs, proj_matrices, depth_values, temperature=...)` unchanged (models/model.py:140), outputs are
+    copies (a second call does not overwrite the first call's tensors), and a weight update re-captures."""
+    from cds_mvsnet_amd import CDSMVSNet, seeded_init_
+    from cds_mvsnet_amd import model as M
+    dev = torch.device("cuda")
+    N, H, W = 3, 128, 160
+    model = seeded_init_(CDSMVSNet(refine=False, depth_interals_ratio=(4.0, 1.5, 0.75)), 0).eval().to(dev)
+    s0, s1 = _scene(N, H, W, False, 4, dev), _scene(N, H, W, False, 5, dev)
+    with torch.no_grad():
+        e0, e1 = model(*s0, temperature=0.01), model(*s1, temperature=0.01)
+    model.use_graphs(True)
+    runner = M._GRAPH_RUNNERS[model]
+    g0 = model(*s0, temperature=0.01)
+    g1 = model(*s1, temperature=0.01)
+    _assert_equal(g0, e0, "graph 0")
+    _assert_equal(g1, e1, "graph 1")
+    assert runner.captures == 1 and g0["depth"].data_ptr() != g1["depth"].data_ptr()
+    # new weights: the packed tables are rebuilt, the graph must not keep running the old ones
+    seeded_init_(model, 1)
+    model.load_state_dict({k: v.clone() for k, v in model.state_dict().items()})
+    g2 = model(*s0, temperature=0.01)
+    model.use_graphs(False)
+    with torch.no_grad():
+        e2 = model(*s0, temperature=0.01)
+    _assert_equal(g2, e2, "after a weight update")
+    assert runner.captures == 2 and not torch.equal(g2["depth"], e0["depth"])
+    # training mode runs eagerly, whatever the switch says
+    model.use_graphs(True)
+    assert model.train().training and M._GRAPH_RUNNERS[model].captures == 0
+
+
+def test_host_geometry_inside_a_capture_is_refused():
+    from cds_mvsnet_amd import ops
+    dev = torch.device("cuda")
+    g = torch.cuda.CUDAGraph()
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        with pytest.raises(RuntimeError, match="GeoBlock"):
+            with torch.cuda.graph(g, stream=st):
+                ops.depth_planes(8, 8, 8, 425.0, 900.0, dev)
+
+
+def _train_scene(seed, dev, N=3, H=64, W=96):
+    import torch.nn.functional as F
+    from cds_mvsnet_amd import synth
+    imgs = synth.make_images(N, H, W, seed=seed).to(dev)
+    cams = synth.make_cameras(N, H, W, refine=False, seed=seed)               # cameras / depth values stay on the host (data loader)
+    dv = synth.make_depth_values() * (1.0 + 0.1 * (seed % 3))
+    g = torch.Generator().manual_seed(seed)
+    base = 600.0 + 120.0 * F.interpolate(torch.rand(1, 1, 4, 6, generator=g), (H, W), mode="bicubic", align_corners=False)[:, 0]
+    gt, mask = {}, {}
+    for s, sc in (("stage1", 4), ("stage2", 2), ("stage3", 1)):
+        gt[s] = F.interpolate(base.unsqueeze(1), (H // sc, W // sc), mode="nearest")[:, 0].contiguous().to(dev)
+        mask[s] = (torch.rand(1, H // sc, W // sc, generator=g) > 0.15).float().to(dev)
+    gt["stage4"], mask["stage4"] = gt["stage3"], mask["stage3"]
+    return {"imgs": imgs, "proj_matrices": cams, "depth_values": dv, "depth": gt, "mask": mask}
+
+
+def test_captured_train_step_equals_eager_steps():
+    """train.CapturedTrainStep (forward + loss + backward + SGD as one hipGraph, replayed with each sample's geometry block) against
+    train.train_step, compared the well-conditioned way: ONE step each from identical weights.  Both launch the same kernels, so the
+    loss (a forward quantity) agrees to float rounding of the reductions and the weight UPDATE to the fp32-atomics noise of the
+    gradients (~5e-6 of a gradient's largest entry, test_train_harness.py).  The second step runs on another scene - images, cameras,
+    depth range and ground truth the capture never saw - and a changed learning rate re-captures."""
+    import numpy as np
+    from cds_mvsnet_amd import CDSMVSNet, seeded_init_, train as T
+    dev = torch.device("cuda")
+    scenes = [_train_scene(31, dev), _train_scene(32, dev)]
+
+    def fresh():
+        m = seeded_init_(CDSMVSNet(refine=False, ndepths=(48, 32, 8), depth_interals_ratio=(4.0, 2.0, 1.0)), 7).to(dev)
+        o = T.make_optimizer(m)
+        T._step_tensors(m, o, scenes[0], 0.1, (0.5, 1.0, 2.0), None, None, update=False)    # the audit backward; weights untouched
+        return m, o, {n: p.detach().clone() for n, p in m.named_parameters()}
+
+    m_e, o_e, w0 = fresh()
+    m_c, o_c, w0c = fresh()
+    assert all(torch.equal(w0[n], w0c[n]) for n in w0)
+    step = T.CapturedTrainStep(m_c, o_c, reducer=T.GradAllReducer(m_c.parameters()), eager_steps=0)
+    for k, sc in enumerate(scenes):
+        before = {n: p.detach().clone() for n, p in m_e.named_parameters()}
+        le, de = T.train_step(m_e, o_e, sc, temperature=0.1, reducer=T.GradAllReducer(m_e.parameters()))
+        lc, dc = (float(v) for v in step(sc, 0.1))
+        assert np.isfinite(lc) and lc == pytest.approx(le, rel=2e-6 if k == 0 else 1e-4), (k, lc, le)
+        assert dc == pytest.approx(de, rel=1e-4, abs=1e-6), (k, dc, de)
+        if k > 0:
+            continue      # the second step starts from weights that differ by the first step's noise; gradients behind discrete choices
+                          # (hypothesis clamps, bilinear cells: stage-3 CostRegNet, DynamicConv attention) amplify it to tens of
+                          # percent of a tiny update - the tight bound is the first step's, from identical weights
+        for (n, p), (_, q) in zip(m_c.named_parameters(), m_e.named_parameters()):
+            upd = float((q.detach() - before[n]).abs().max())
+            gap = float((p.detach() - q.detach()).abs().max())            # gradient noise x lr, plus the rounding of w - lr (g + wd w)
+            assert gap <= 5e-5 * upd + 2.5e-7 * float(q.detach().abs().max()) + 1e-9, (k, n, gap, upd)
+    assert step.captures == 1
+    for (n, p), (_, q) in zip(m_c.named_buffers(), m_e.named_buffers()):          # BatchNorm running statistics and step counters
+        if p.dtype.is_floating_point:
+            assert (p - q).abs().max() <= 1e-5 * max(1.0, float(q.abs().max())), n
+        else:
+            assert torch.equal(p, q), n
+    # a new learning rate (StepLR) is a new key: its own graph, and `.grad` afterwards shows that graph's gradients
+    for g in o_c.param_groups:
+        g["lr"] = 5e-5
+    for sc in scenes:
+        l, _ = step(sc, 0.1)
+        assert np.isfinite(float(l))
+    assert step.captures == 2
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m_c.parameters() if p.requires_grad)

@@ -138,8 +138,9 @@ def test_side_stream_gradients_equal_single_stream_gradients():
     sound" (the round-5 form compared the loss after three SGD steps at lr 1e-3, a divergent regime - the losses rose 85.5 -> 89.0 -
     in which last-bit gradient noise is amplified ~1e4 x and no bound separates a race from chaos).
     The fp32 atomics of the K3 backward and weight-gradient kernels make two single-stream runs differ in the last bits: that
-    off-vs-off figure is the noise floor, the on-vs-off gap must stay within 3 x of it (and under 1e-4 of the tensor's largest
-    entry: a kernel reading a half-written buffer moves a gradient by O(1) of its magnitude, not by 1e-5).  Repeated with a used
+    off-vs-off figure is the noise floor (4e-6 .. 8e-6 over many runs, two draws of the same distribution: the bound is 3 x that figure
+    with a floor of 3e-5, and 1e-4 of the tensor's largest entry in any case: a kernel reading a half-written buffer moves a gradient
+    by O(1) of its magnitude, not by 1e-5).  Repeated with a used
     allocator and back to back so that a race has several chances to show."""
     from cds_mvsnet_amd import CDSMVSNet, seeded_init_, _scratch
     dev = torch.device("cuda")
@@ -161,7 +162,7 @@ def test_side_stream_gradients_equal_single_stream_gradients():
             noise, n_noise = _gradient_gap(g_off2, g_off)
             gap, n_gap = _gradient_gap(g_on, g_off)
             print(f"[side stream] trial {trial}: on-vs-off {gap:.2e} ({n_gap}); off-vs-off {noise:.2e} ({n_noise}); loss {l_off:.6f}")
-            assert np.isfinite(gap) and gap <= max(3.0 * noise, 2e-6) and gap <= 1e-4, \
+            assert np.isfinite(gap) and gap <= max(3.0 * noise, 3e-5) and gap <= 1e-4, \
                 f"trial {trial}: side stream vs single stream {gap:.2e} ({n_gap}); single vs single {noise:.2e} ({n_noise})"
     finally:
         T.SIDE_STREAM_WGRAD = old
