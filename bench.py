@@ -30,6 +30,7 @@ import json
 import os
 import sys
 import time
+import statistics
 
 import torch
 
@@ -172,7 +173,23 @@ def other_workloads(model, dev):
         imgs = synth.make_images(5, 512, 640, seed=0).to(dev)
         pm = synth.make_cameras(5, 512, 640, refine=False, seed=0)
         dv = synth.make_depth_values()
+        from cds_mvsnet_amd.graphed import CapturedForward
+        runner = CapturedForward(model)            # hipGraph replay of the same forward (graphed.py; torch.equal to eager under -m gpu)
+
+        def single(fn, n=5):
+            """one forward issued to an idle GPU (host camera algebra + enqueue + execution), median of n"""
+            ts = []
+            for _ in range(n):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                fn()
+                torch.cuda.synchronize()
+                ts.append((time.perf_counter() - t0) * 1e3)
+            return statistics.median(ts)
         out["M2_cascade_forward_640x512_N5_ms"] = timeit(lambda: model(imgs, pm, dv, temperature=0.01))
+        out["M2_cascade_forward_640x512_N5_graph_ms"] = timeit(lambda: runner(imgs, pm, dv, temperature=0.01))
+        out["M2_single_forward_after_sync_eager_ms"] = single(lambda: model(imgs, pm, dv, temperature=0.01))
+        out["M2_single_forward_after_sync_graph_ms"] = single(lambda: runner(imgs, pm, dv, temperature=0.01))
         # BASELINE configs[2] / [3] on one GPU: the DTU and Tanks&Temples image sizes through the full cascade
         for key, (hh, ww, nn) in {"M3_cascade_forward_1600x1184_N5_ms": (1184, 1600, 5),
                                   "M4_cascade_forward_1920x1056_N7_ms": (1056, 1920, 7)}.items():
@@ -180,7 +197,13 @@ def other_workloads(model, dev):
             pm = synth.make_cameras(nn, hh, ww, refine=False, seed=0)
             # best of three 3-iteration batches: the first passes at a new size occasionally pay for allocator growth
             out[key] = min(timeit(lambda: model(imgs, pm, dv, temperature=0.01), n=3, warm=2 if r == 0 else 0) for r in range(3))
+            out[key.replace("_ms", "_graph_ms")] = min(timeit(lambda: runner(imgs, pm, dv, temperature=0.01), n=3, warm=2 if r == 0 else 0)
+                                                       for r in range(3))
+            if key.startswith("M3"):
+                out["M3_single_forward_after_sync_eager_ms"] = single(lambda: model(imgs, pm, dv, temperature=0.01))
+                out["M3_single_forward_after_sync_graph_ms"] = single(lambda: runner(imgs, pm, dv, temperature=0.01))
             del imgs
+        del runner
         k3 = k3_stage_rooflines(model, dev)
     # BASELINE configs[4] on one GPU: the BlendedMVS training step (768x576, N=5, refine, fp32: forward + final_loss + backward +
     # SGD; the weight-gradient side stream is audited on the first step) -- the driver-timed figure of SURVEY 8(f)-2
@@ -195,7 +218,17 @@ def other_workloads(model, dev):
     out["T5_train_step_768x576_N5_bf16storage_ms"] = min(
         timeit(lambda: T.train_step(tmodel, opt, sample, temperature=0.1, activation_storage="bf16"), n=5, warm=3 if r == 0 else 0)
         for r in range(2))
-    del tmodel, opt, sample
+    # the same fp32 step as ONE hipGraph (train.CapturedTrainStep: forward + loss + backward + SGD recorded once, replayed with the
+    # sample's geometry block); the loss is read every step, like train_step does
+    tmodel = seeded_init_(CDSMVSNet(refine=refine5, ndepths=NDEPTHS, depth_interals_ratio=RATIOS), 0).to(dev)
+    opt = T.make_optimizer(tmodel)
+    cstep = T.CapturedTrainStep(tmodel, opt)
+    out["T5_train_step_768x576_N5_fp32_graph_ms"] = min(timeit(lambda: float(cstep(sample, 0.1)[0]), n=5, warm=4 if r == 0 else 0) for r in range(2))
+    # ... and with the loss read once per five steps and the cameras on the host (as a data loader delivers them): the host prepares the
+    # next step's geometry while the GPU trains
+    hsample = dict(sample, proj_matrices={k: v.cpu() for k, v in sample["proj_matrices"].items()}, depth_values=sample["depth_values"].cpu())
+    out["T5_train_step_768x576_N5_fp32_graph_deferred_loss_ms"] = min(timeit(lambda: cstep(hsample, 0.1), n=5, warm=1) for r in range(2))
+    del tmodel, opt, sample, cstep, hsample
     res = {k: round(v, 3) for k, v in out.items()}
     res["M3_K3_roofline_by_stage"] = k3
     return res
@@ -279,7 +312,8 @@ def cpu_baseline(model_cpu, name, budget_frac, seed=0, gpu_depth=None):
     what = "full size" if frac == 1.0 else f"window {ws}x{hs} of {w}x{h} ({frac:.4f} of the pixels, linear extrapolation)"
     out = {"value": frac / dt, "unit": "depth-maps/s", "cores": cores, "kind": "port",
            "sample": f"{name} {what}, D={D}, C={C}, N={n_views}, one run ({dt:.2f} s) after a small warm-up of the torch-CPU "
-                     f"oracle (F.grid_sample path)", "run_seconds": [round(t, 2) for t in times]}
+                     f"oracle (F.grid_sample path); runs: 1 (a stated baseline, not a statistic)", "runs": len(times),
+           "run_seconds": [round(t, 2) for t in times]}
     if gpu_depth is not None and frac == 1.0:
         dcpu = ref["depth"].reshape(h, w).float()
         dgpu = gpu_depth.reshape(h, w).float().cpu()

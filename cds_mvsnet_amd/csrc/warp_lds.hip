@@ -33,6 +33,9 @@ namespace {
 #define CDS_K3_DC 48
 #define CDS_K3_MINW 2
 #endif
+#ifndef CDS_PROBE_K3
+#define CDS_PROBE_K3 0
+#endif
 constexpr int C8 = 8;
 constexpr int TW = CDS_K3_TW, TH = CDS_K3_TH;  // reference-pixel tile of a workgroup (TW*TH = 256)
 constexpr int BOX_CAP = CDS_K3_BOX;   // texels per view box (x 32 B; 4 views + scratch must fit the LDS budget)
@@ -495,7 +498,11 @@ __global__ __launch_bounds__(256, CDS_K3_MINW) void warp_aggregate_lds_kernel(
     asm volatile("" ::"v"(dnext.x), "v"(dnext.y));   // delivered before the loop: the loop head then joins two states without pending loads
     for (int d = d0; d < d1; d += 2, boff += 2u * bstep) {
       const bool two = d + 1 < d1;
+#ifdef CDS_PROBE_K3_POS
+      const v2f dv = dnext * 0.0f + 600.0f;      // probe: loop-invariant positions
+#else
       const v2f dv = dnext;
+#endif
       dnext.x = *reinterpret_cast<const float*>(hyp_b + min(boff + 2u * bstep, blast));
       dnext.y = *reinterpret_cast<const float*>(hyp_b + min(boff + 3u * bstep, blast));
       v2f acc[2][4];
@@ -536,8 +543,19 @@ __global__ __launch_bounds__(256, CDS_K3_MINW) void warp_aggregate_lds_kernel(
           ok &= cell_addr_fast<CAP, false>(x0f.y, y0f.y, wf, hf, fb[v], lv, p0[1], p1[1]);
         };
         prep(0, wt[0]);
+        // Probe builds (wrong results, right timing; scripts/ab/r06_k3_probe.sh, profiles/r06_k3_probe.md): CDS_PROBE_K3 = 1: the
+        // second plane of a pair reuses the first plane's taps (half the ds_reads: what tap reuse along depth could save at best);
+        // 2: no ds_read in the plane loop at all (the VALU-only floor of the loop); CDS_PROBE_K3_POS: (nearly) loop-invariant
+        // sample positions (the position arithmetic may be hoisted: the LDS-read side on its own).
+#if CDS_PROBE_K3 == 2
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { tc[k][q].lo = (cds_f4){rv[0][0].x, rv[0][1].x, rv[0][2].x, rv[0][3].x}; tc[k][q].hi = tc[k][q].lo * dv.x; }
+#else
         load_cell<CAP>(p0[0], p1[0], tc[0]);
-        load_cell<CAP>(p0[1], p1[1], tc[1]);
+        if (CDS_PROBE_K3 != 1) load_cell<CAP>(p0[1], p1[1], tc[1]);
+#endif
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int v = 0; v < VMAX; ++v) {
@@ -549,10 +567,10 @@ __global__ __launch_bounds__(256, CDS_K3_MINW) void warp_aggregate_lds_kernel(
             const float wgt[4] = {k ? wt[cur][0].y : wt[cur][0].x, k ? wt[cur][1].y : wt[cur][1].x,
                                   k ? wt[cur][2].y : wt[cur][2].x, k ? wt[cur][3].y : wt[cur][3].x};
             v2f o[4];
-            interp8(tc[k], wgt, o);
+            interp8(tc[CDS_PROBE_K3 == 1 ? 0 : k], wgt, o);
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[k][j] = fma2(rv[v][j], o[j], acc[k][j]);
-            if (v + 1 < VMAX) load_cell<CAP>(p0[k], p1[k], tc[k]);
+            if (v + 1 < VMAX && CDS_PROBE_K3 != 2 && !(CDS_PROBE_K3 == 1 && k == 1)) load_cell<CAP>(p0[k], p1[k], tc[k]);
             __builtin_amdgcn_sched_barrier(0);
           }
         }

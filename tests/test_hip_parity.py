@@ -373,13 +373,16 @@ def test_oracle_parity_midsize(dev, ops, seeded_state):
     assert (out["photometric_confidence"].cpu() - ref_out["photometric_confidence"]).abs().mean() < 1e-3
 
 
-@pytest.mark.parametrize("name,h,w,D,C,N", [("M1b", 128, 160, 192, 32, 5), ("M1 crop", 256, 320, 192, 8, 5)])
+@pytest.mark.parametrize("name,h,w,D,C,N", [("M1b", 128, 160, 192, 32, 5), ("M1 crop", 256, 320, 192, 8, 5),
+                                            ("M1 full size (the headline workload: 640x512, D=192, C=8, N=5)", 512, 640, 192, 8, 5)])
 def test_oracle_parity_large_depth_range(name, h, w, D, C, N, dev, ops, seeded_state):
     """the D = 192 single-stage workloads against the CPU oracle under an assertion (until round 5 only bench.py's
     cpu_baseline compared them): M1b (BASELINE config 2 read as the 160x128, C = 32 grid) at full size, and a 320x256 window of M1
     (640x512, C = 8) - the same D = 192 chunking of K1 / K3 (48-plane LDS chunks, CDS_K3_NSEG depth segments) and the same
-    CostRegNet kernels as the full size at a quarter of the oracle's run time.  Tolerances are SURVEY 8(c)'s: aggregated volume
-    <= 1e-5 abs, depth mean-L1 <= 1e-3, confidence mean <= 1e-3."""
+    CostRegNet kernels as the full size at a quarter of the oracle's run time - and, since round 6, M1 itself at full
+    size: the workload bench.py's headline number is quoted on is under an assertion, not only under bench.py's `abs_depth_l1_vs_gpu`
+    (~20 s and ~20 GB of the oracle on the box's host cores).  Tolerances are SURVEY 8(c)'s: aggregated volume <= 1e-5 abs, depth
+    mean-L1 <= 1e-3, confidence mean <= 1e-3."""
     from cds_mvsnet_amd import synth
     from oracle import cds_oracle as O
     model = seeded_state(False)
