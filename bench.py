@@ -188,6 +188,20 @@ def other_workloads(model, dev):
             return statistics.median(ts)
         out["M2_cascade_forward_640x512_N5_ms"] = timeit(lambda: model(imgs, pm, dv, temperature=0.01))
         out["M2_cascade_forward_640x512_N5_graph_ms"] = timeit(lambda: runner(imgs, pm, dv, temperature=0.01))
+        # two depth maps in flight: two replayed graphs (own static buffers) on two streams - the 640x512 kernels do not fill 256 CUs, and
+        # with ~0.7 ms of host work per replay (eager: ~2.3 ms of enqueue per forward) the host keeps both streams fed
+        runner2 = CapturedForward(model)
+        lanes2 = [torch.cuda.Stream(device=dev) for _ in range(2)]
+
+        def two_maps():
+            for st_, r_ in zip(lanes2, (runner, runner2)):
+                st_.wait_stream(torch.cuda.current_stream(dev))
+                with torch.cuda.stream(st_):
+                    r_(imgs, pm, dv, temperature=0.01)
+            for st_ in lanes2:
+                torch.cuda.current_stream(dev).wait_stream(st_)
+        out["M2_two_graph_streams_ms_per_depth_map"] = timeit(two_maps) / 2
+        del runner2
         out["M2_single_forward_after_sync_eager_ms"] = single(lambda: model(imgs, pm, dv, temperature=0.01))
         out["M2_single_forward_after_sync_graph_ms"] = single(lambda: runner(imgs, pm, dv, temperature=0.01))
         # BASELINE configs[2] / [3] on one GPU: the DTU and Tanks&Temples image sizes through the full cascade
