@@ -16,7 +16,8 @@
 // conv3d_zmg.hip: the z-marching split-bf16 kernels behind cds_conv3d_sbf_f32; CDS_ZMG_UNSUPPORTED = shape stays on the tiled kernels
 #define CDS_ZMG_UNSUPPORTED 1
 int cds_conv3d_zmg_dispatch(const float* x, const void* wsp, const float* bias, float* out, int Cin, int Cout, int D, int H, int W,
-                            int stride, int pair, int act, hipStream_t st);
+                            int stride, int pair, int act, hipStream_t st, const float* in_bound = nullptr, float w_inv = 1.f,
+                            float* out_bound = nullptr);
 
 // native 4-float vector (volatile-loadable, unlike HIP's float4 struct): pins a 16-byte LDS read
 using cds_f4 = float __attribute__((ext_vector_type(4)));

@@ -919,6 +919,22 @@ extern "C" int cds_conv3d_sbf_f32(const float* x, const void* weight_split, cons
   return CDS_EINVAL;
 }
 
+// The same convolution in SPLIT-F16 arithmetic (sbf_common.hpp: two fp16 terms per operand, three products per K-step, fp32-class
+// error at half the matrix-pipe work) for the shapes the z-marching kernels cover (CDS_EINVAL otherwise: the caller stays on
+// cds_conv3d_sbf_f32).  weight_split: the split-bf16 layouts with fp16 terms (hi, lo, unused) of w * w_scale (ops.split_pack_conv3d*(...,
+// f16=True)); w_inv_scale = 1 / w_scale (a power of two); in_bound: DEVICE scalar >= max |x| (the producer's out_bound, or any upper
+// bound); out_bound: DEVICE scalar that receives max |out| by atomic maximum (zero it first) or NULL.
+extern "C" int cds_conv3d_sf16_f32(const float* x, const void* weight_split, const float* bias, float* out, int Cin, int Cout, int D, int H,
+                                   int W, int stride, int act, const float* in_bound, float w_inv_scale, float* out_bound, void* stream) {
+  if (!x || !weight_split || !out || !in_bound || Cin < 8 || (Cin % 8) || Cout < 4 || (Cout % 4) || Cout > 64 || D < 1 || H < 1 || W < 1 ||
+      (stride != 1 && stride != 2 && stride != CDS_SBF_PAIR) || !(w_inv_scale > 0.f))
+    return CDS_EINVAL;
+  if (stride == CDS_SBF_PAIR && Cout != 8) return CDS_EINVAL;
+  const int r = cds_conv3d_zmg_dispatch(x, weight_split, bias, out, Cin, Cout, D, H, W, stride == CDS_SBF_PAIR ? 1 : stride,
+                                        stride == CDS_SBF_PAIR, act, (hipStream_t)stream, in_bound, w_inv_scale, out_bound);
+  return r == CDS_ZMG_UNSUPPORTED ? CDS_EINVAL : r;
+}
+
 // ConvTranspose3d k3 s2 p1 op1 (+bias +ReLU +residual) in split-bf16 arithmetic on channels-last volumes.  x [D][H][W][Cin]
 // -> out [2D][2H][2W][Cout]; weight_split from ops.split_pack_deconv3d (class / K-step tables: DTab above).  Cout == 8 or
 // Cout in {16, 32}; Cin % 8 == 0.

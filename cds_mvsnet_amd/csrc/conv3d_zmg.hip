@@ -30,9 +30,13 @@ __device__ __attribute__((aligned(32))) float g_zmg_zeros[8];   // what an out-o
 // CW_ = 4: one consumer wave per SIMD (256-register budget); CW_ = 8: two per SIMD, 12 waves per workgroup, 168 registers: one
 // MFMA-issuing wave per SIMD sustains one v_mfma_f32_16x16x32_bf16 per 10.0 ns, two sustain one per 8.1 ns (scripts/ubench), and the
 // second wave's K-loop covers the first one's exchange / epilogue / barrier time.
-template <int S_, int RD_, int MB_, bool PAIR_, int TXO_, int TYO_, int G_, int NG_, int CW_ = 4>
+// F16_: split-f16 arithmetic (two fp16 terms per operand, three products per K-step, tensor scales from device bounds: sbf_common.hpp)
+// instead of split-bf16 (three bf16 terms, six products); same staging geometry, term 2 of a position / weight vector unused.
+template <int S_, int RD_, int MB_, bool PAIR_, int TXO_, int TYO_, int G_, int NG_, int CW_ = 4, bool F16_ = false>
 struct ZG {
   static constexpr int S = S_, RD = RD_, MB = MB_, TXO = TXO_, TYO = TYO_, G = G_, NG = NG_;
+  static constexpr bool F16 = F16_;
+  static constexpr int NT = F16_ ? 2 : 3;                          // terms per operand
   static constexpr bool PAIR = PAIR_, DEINT = PAIR_ || S_ == 2;
   static constexpr int CW = CW_, PW = 4, THREADS = (CW + PW) * 64;
   static constexpr int KSPL = RD, MBS = MB;                       // wave = (round, cout block, row part)
@@ -76,9 +80,15 @@ template <class Cfg>
 __global__ __launch_bounds__(Cfg::THREADS, 1) void conv3d_zmg_kernel(const float* __restrict__ x, const uint4* __restrict__ wsp,
                                                                   const float* __restrict__ bias, float* __restrict__ out, int Cout,
                                                                   int D, int H, int W, int Do, int Ho, int Wo, int act,
-                                                                  int tiles_x, int tiles_y, int zseg) {
+                                                                  int tiles_x, int tiles_y, int zseg,
+                                                                  const float* __restrict__ in_bound, float w_inv,
+                                                                  float* __restrict__ out_bound) {
   constexpr int S = Cfg::S, RD = Cfg::RD, G = Cfg::G, R = Cfg::R, Cin = 8 * RD, KS = Cfg::KS, NTW = Cfg::NTW, NG = Cfg::NG;
-  constexpr bool PAIR = Cfg::PAIR;
+  constexpr bool PAIR = Cfg::PAIR, F16 = Cfg::F16;
+  constexpr int NT = Cfg::NT;
+  // split-f16: the input's scale from the bound its producer left, and what the accumulators are multiplied by at the end (exact)
+  const float xs = F16 ? sf16_scale(in_bound[0]) : 1.0f;
+  const float out_mul = F16 ? w_inv / xs : 1.0f;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -145,7 +155,8 @@ __global__ __launch_bounds__(Cfg::THREADS, 1) void conv3d_zmg_kernel(const float
         if (h + 1 == PPT && s_pl[h] < 0) continue;                 // only the last item of a thread can be missing
         int slot = slot0 + (s_pl[h] < 0 ? 0 : s_pl[h]);
         slot = slot >= R ? slot - R : slot;
-        split_store8(lds + slot * Cfg::PLANEB + s_dst[h], va[set][h], vb[set][h]);
+        if (F16) split_store8_f16(lds + slot * Cfg::PLANEB + s_dst[h], va[set][h], vb[set][h], xs);
+        else split_store8(lds + slot * Cfg::PLANEB + s_dst[h], va[set][h], vb[set][h]);
       }
     };
     // the NINIT lowest planes of the segment: loaded, split and stored directly
@@ -157,8 +168,12 @@ __global__ __launch_bounds__(Cfg::THREADS, 1) void conv3d_zmg_kernel(const float
       const int gz = zin0 + pl, gy = gy0 + row, gx = gx0 + c;
       const bool ok = c < Cfg::IX && (unsigned)gz < (unsigned)D && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
       const float* __restrict__ src = ok ? x + (((long long)gz * H + gy) * W + gx) * Cin + rd * 8 : g_zmg_zeros;
-      split_store8(lds + pl * Cfg::PLANEB + rd * Cfg::SLICEB + (row * Cfg::IXP + q) * POSB, *reinterpret_cast<const float4*>(src),
-                   *reinterpret_cast<const float4*>(src + 4));
+      if (F16)
+        split_store8_f16(lds + pl * Cfg::PLANEB + rd * Cfg::SLICEB + (row * Cfg::IXP + q) * POSB, *reinterpret_cast<const float4*>(src),
+                         *reinterpret_cast<const float4*>(src + 4), xs);
+      else
+        split_store8(lds + pl * Cfg::PLANEB + rd * Cfg::SLICEB + (row * Cfg::IXP + q) * POSB, *reinterpret_cast<const float4*>(src),
+                     *reinterpret_cast<const float4*>(src + 4));
     }
     issue(0, 0);
     if (nstages > 1) issue(1, 1);
@@ -201,17 +216,17 @@ __global__ __launch_bounds__(Cfg::THREADS, 1) void conv3d_zmg_kernel(const float
   const int lane_base = k * Cfg::SLICEB + (part * Cfg::ROWS * S * Cfg::IXP + j) * POSB +
                         (PAIR ? (((g & 1) * 2 + (g >> 1)) & 1) * Cfg::IXH * POSB + ((((g & 1) * 2 + (g >> 1))) >> 1) * POSB : 0);
   // this wave's weights: [round k][K-step][cout block mbi][term][lane]
-  BV wres[KS][3];
+  BV wres[KS][NT];
   {
     const uint4* __restrict__ wl = wsp + lane;
 #pragma unroll
     for (int t = 0; t < KS; ++t) {
       const size_t o = (size_t)(((k * KS + t) * Cfg::MB + mbi) * 3) * 64;
-      wres[t][0].u = wl[o];
-      wres[t][1].u = wl[o + 64];
-      wres[t][2].u = wl[o + 128];
+#pragma unroll
+      for (int tm = 0; tm < NT; ++tm) wres[t][tm].u = wl[o + 64 * tm];
     }
   }
+  float amax = 0.f;                                    // running maximum of the magnitudes this lane stores (split-f16: the output's bound)
   const int co = PAIR ? 4 * (g & 1) : mbi * 16 + 4 * g;
   const float4 bv = (bias && co < Cout) ? *reinterpret_cast<const float4*>(bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
   // N-tile n of this wave = (row r, x run xt, plane i): n = (r XT + xt) G + i
@@ -226,10 +241,12 @@ __global__ __launch_bounds__(Cfg::THREADS, 1) void conv3d_zmg_kernel(const float
     const int i = n % G, rx = n / G, xt = rx % Cfg::XT, r = rx / Cfg::XT;
     if (z0 + st * G + i >= z1 || oy0 + r >= Ho) return;            // wave-uniform
     if (!lane_ok[xt]) return;
-    float4 o = make_float4(a.x + bv.x, a.y + bv.y, a.z + bv.z, a.w + bv.w);
+    float4 o = F16 ? make_float4(a.x * out_mul + bv.x, a.y * out_mul + bv.y, a.z * out_mul + bv.z, a.w * out_mul + bv.w)
+                   : make_float4(a.x + bv.x, a.y + bv.y, a.z + bv.z, a.w + bv.w);
     if (act == CDS_ACT_RELU) {
       o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
     }
+    if (F16) amax = fmaxf(fmaxf(amax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
     sbf_store4(obase + ((size_t)((size_t)(st * G + i) * Ho + r) * Wo + xt * XW) * Cout, o);
   };
   unsigned char* xch = lds + Cfg::RINGB;                 // [buffer][sender wave][N-tile of its partner's half][lane] x 16 B
@@ -241,10 +258,12 @@ __global__ __launch_bounds__(Cfg::THREADS, 1) void conv3d_zmg_kernel(const float
     const int i = n % G, rx = n / G, xt = rx % Cfg::XT, r = rx / Cfg::XT;
     if (z0 + st * G + i >= z1 || oy0 + r >= Ho) return;            // wave-uniform
     if (!(ox0 + xt * XW < Wo && co < Cout)) return;
-    float4 o = make_float4(a.x + bv.x, a.y + bv.y, a.z + bv.z, a.w + bv.w);
+    float4 o = F16 ? make_float4(a.x * out_mul + bv.x, a.y * out_mul + bv.y, a.z * out_mul + bv.z, a.w * out_mul + bv.w)
+                   : make_float4(a.x + bv.x, a.y + bv.y, a.z + bv.z, a.w + bv.w);
     if (act == CDS_ACT_RELU) {
       o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
     }
+    if (F16) amax = fmaxf(fmaxf(amax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
     sbf_store4(obase + ((size_t)((size_t)(st * G + i) * Ho + r) * Wo + xt * XW) * Cout, o);
   };
   const int xgrp = (wave / Cfg::KSPL) * NTW;            // first exchange slot row of this wave's (cout block, row part)
@@ -305,7 +324,7 @@ __global__ __launch_bounds__(Cfg::THREADS, 1) void conv3d_zmg_kernel(const float
       }
     }
     constexpr int NGRP = NTW / NG, NS = KS * NGRP;
-    BV bd[2][NG][3];
+    BV bd[2][NG][NT];
     auto load_b = [&](int buf, int ss) {
       const int t = ss / NGRP, grp = ss % NGRP;
 #pragma unroll
@@ -316,7 +335,7 @@ __global__ __launch_bounds__(Cfg::THREADS, 1) void conv3d_zmg_kernel(const float
                                  (r * S * Cfg::IXP + xt * 16) * POSB;
         bd[buf][q][0].u = *reinterpret_cast<const uint4*>(b);
         bd[buf][q][1].u = *reinterpret_cast<const uint4*>(b + 16);
-        bd[buf][q][2].u = *reinterpret_cast<const uint4*>(b + 32);
+        if (!F16) bd[buf][q][NT - 1].u = *reinterpret_cast<const uint4*>(b + 32);
       }
     };
     load_b(0, 0);
@@ -334,11 +353,15 @@ __global__ __launch_bounds__(Cfg::THREADS, 1) void conv3d_zmg_kernel(const float
 #ifndef CDS_ZMG_LAZYWAIT
       // ONE wait for all operands of this step (they were requested a whole step ago) instead of the compiler's lgkmcnt waits
       // BETWEEN the dependent MFMAs: an issue slot between two MFMAs on the same accumulator costs ~40 cycles of matrix pipe
-      if (ss + 1 < NS) __builtin_amdgcn_s_waitcnt(0xC07F | ((3 * NG) << 8));    // lgkmcnt(3 NG): the next step's requests stay in flight
+      if (ss + 1 < NS) __builtin_amdgcn_s_waitcnt(0xC07F | ((NT * NG) << 8));   // lgkmcnt(NT NG): the next step's requests stay in flight
       else __builtin_amdgcn_s_waitcnt(0xC07F);
       __builtin_amdgcn_sched_barrier(0);
 #endif
-      SBF_TERMS(acc, grp * NG, NG, wres[t], bd[db]);
+      if constexpr (F16) {
+        SF16_TERMS(acc, grp * NG, NG, wres[t], bd[db]);
+      } else {
+        SBF_TERMS(acc, grp * NG, NG, wres[t], bd[db]);
+      }
     }
     __builtin_amdgcn_s_setprio(CDS_ZMG_CPRIO);
     if (Cfg::KSPL == 2) {
@@ -364,6 +387,7 @@ __global__ __launch_bounds__(Cfg::THREADS, 1) void conv3d_zmg_kernel(const float
     __syncthreads();                                   // #(st + 1)
   }
   if (Cfg::KSPL >= 2 || late) finish(nstages - 1);
+  if (F16) sf16_publish_bound(amax, out_bound);       // this wave's largest stored magnitude -> the bound the next layer scales by
 }
 
 // z segments per column: enough workgroups for the 256 CUs (one workgroup per CU: the ring takes most of the LDS) with full
@@ -384,7 +408,8 @@ inline int zmg_pick_nseg(int cols, int Do, int G) {
 }
 
 template <class Cfg>
-int launch_zmg(const float* x, const void* wsp, const float* b, float* out, int Cout, int D, int H, int W, int act, hipStream_t st) {
+int launch_zmg(const float* x, const void* wsp, const float* b, float* out, int Cout, int D, int H, int W, int act, hipStream_t st,
+               const float* in_bound = nullptr, float w_inv = 1.f, float* out_bound = nullptr) {
   constexpr int S = Cfg::S;
   const int Do = (D - 1) / S + 1, Ho = (H - 1) / S + 1, Wo = (W - 1) / S + 1;
   const int tx = cds_ceil_div(Wo, Cfg::TXO), ty = cds_ceil_div(Ho, Cfg::TYO);
@@ -395,7 +420,7 @@ int launch_zmg(const float* x, const void* wsp, const float* b, float* out, int 
   static std::atomic<unsigned long long> lds_ok{0};     // per instantiation
   if (int e_lds = cds_allow_lds(reinterpret_cast<const void*>(kern), Cfg::LDSB, lds_ok)) return e_lds;
   hipLaunchKernelGGL(kern, dim3(tx * ty * nseg), dim3(Cfg::THREADS), Cfg::LDSB, st, x, reinterpret_cast<const uint4*>(wsp), b, out,
-                     Cout, D, H, W, Do, Ho, Wo, act, tx, ty, zseg);
+                     Cout, D, H, W, Do, Ho, Wo, act, tx, ty, zseg, in_bound, w_inv, out_bound);
   return cds_launch_status();
 }
 
@@ -404,7 +429,22 @@ int launch_zmg(const float* x, const void* wsp, const float* b, float* out, int 
 // Dispatch for cds_conv3d_sbf_f32 (conv3d_sbf.hip): returns CDS_ZMG_UNSUPPORTED when the shape stays on the tiled kernels.
 // pair != 0: Cout == 8 with the pair-packed weights (ops.split_pack_conv3d_pair), stride 1.
 int cds_conv3d_zmg_dispatch(const float* x, const void* wsp, const float* bias, float* out, int Cin, int Cout, int D, int H, int W,
-                            int stride, int pair, int act, hipStream_t st) {
+                            int stride, int pair, int act, hipStream_t st, const float* in_bound, float w_inv, float* out_bound) {
+  if (in_bound) {   // split-f16 arithmetic: the same six shapes, scales from device bounds (cds_conv3d_sf16_f32)
+    if (pair) {
+      if (Cin == 8) return launch_zmg<ZG<1, 1, 1, true, 32, 8, 3, 1, 8, true>>(x, wsp, bias, out, Cout, D, H, W, act, st, in_bound, w_inv, out_bound);
+      if (Cin == 16) return launch_zmg<ZG<1, 2, 1, true, 32, 8, 1, 4, 4, true>>(x, wsp, bias, out, Cout, D, H, W, act, st, in_bound, w_inv, out_bound);
+      if (Cin == 32) return launch_zmg<ZG<1, 4, 1, true, 32, 3, 1, 3, 4, true>>(x, wsp, bias, out, Cout, D, H, W, act, st, in_bound, w_inv, out_bound);
+      return CDS_ZMG_UNSUPPORTED;
+    }
+    if (stride == 1 && Cin == 16 && Cout == 16)
+      return launch_zmg<ZG<1, 2, 1, false, 32, 8, 1, 1, 8, true>>(x, wsp, bias, out, Cout, D, H, W, act, st, in_bound, w_inv, out_bound);
+    if (stride == 2 && Cin == 8 && Cout == 16)
+      return launch_zmg<ZG<2, 1, 1, false, 16, 8, 1, 1, 8, true>>(x, wsp, bias, out, Cout, D, H, W, act, st, in_bound, w_inv, out_bound);
+    if (stride == 2 && Cin == 16 && Cout == 32)
+      return launch_zmg<ZG<2, 2, 2, false, 16, 4, 1, 1, 8, true>>(x, wsp, bias, out, Cout, D, H, W, act, st, in_bound, w_inv, out_bound);
+    return CDS_ZMG_UNSUPPORTED;
+  }
   const bool off = cds_env_is("CDS_ZMG", '0');   // A/B knob: 0 = tiled kernels only
   if (off) return CDS_ZMG_UNSUPPORTED;
   // Consumer waves per SIMD as measured at the M1 / cascade shapes (profiles/r04_zmarch.md): two for everything but the 16 -> 8 pair layer

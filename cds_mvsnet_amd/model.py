@@ -44,6 +44,17 @@ USE_GRAPHS_DEFAULT = os.environ.get("CDS_GRAPH", "0") == "1"       # eval forwar
 _GRAPH_RUNNERS: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()   # model -> its CapturedForward (CDSMVSNet.use_graphs)
 
 
+_UNIT_BOUNDS: Dict[int, Tensor] = {}
+
+
+def _unit_bound(device) -> Tensor:
+    """A device scalar 1.0 (the bound of |tanh features| products), one per device."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    if idx not in _UNIT_BOUNDS:
+        _UNIT_BOUNDS[idx] = torch.ones((1,), dtype=torch.float32, device=device)
+    return _UNIT_BOUNDS[idx]
+
+
 def _side_stream(device) -> "torch.cuda.Stream":
     idx = device.index if device.index is not None else torch.cuda.current_device()
     if idx not in _SIDE_STREAMS:
@@ -264,6 +275,12 @@ class CostRegNet(_PackedHolder):
                     out[name + ".ws"] = ops.split_pack_conv3d_pair(unit.conv.weight.detach() * scale.view(-1, 1, 1, 1, 1))
                 else:
                     out[name + ".ws"] = ops.split_pack_conv3d(unit.conv.weight.detach() * scale.view(-1, 1, 1, 1, 1))
+                # split-f16 operands (two fp16 terms of w x a power-of-two scale, + 1 / scale) of the layers that have the kernel
+                if not unit.transposed:
+                    wf = unit.conv.weight.detach() * scale.view(-1, 1, 1, 1, 1)
+                    code = ops.SBF_PAIR if name == "conv0" else unit.stride
+                    if ops.conv3d_sf16_supported(wf.shape[1], wf.shape[0], code):
+                        out[name + ".wh"], out[name + ".whs"] = (ops.split_pack_conv3d_pair if name == "conv0" else ops.split_pack_conv3d)(wf, f16=True)
         return out
 
     def split_bf16_supported(self) -> bool:
@@ -271,10 +288,13 @@ class CostRegNet(_PackedHolder):
         return (USE_SPLIT_BF16 and self.conv0.conv.out_channels == 8 and self.conv0.conv.in_channels % 8 == 0
                 and self.conv0.conv.weight.is_cuda)
 
-    def forward(self, volume: Tensor, channels_last: bool = False) -> Tensor:
+    def forward(self, volume: Tensor, channels_last: bool = False, bound: Optional[Tensor] = None) -> Tensor:
         """volume [C,D,h,w] (one batch item; [D,h,w,C] with channels_last) -> [D,h,w].  D, h, w must be multiples of 8.
         The channels-last form runs the split-bf16 matrix-core kernels (fp32-class arithmetic, csrc/conv3d_sbf.hip), the
-        planar form the exact-fp32 kernels (one fmaf chain per output)."""
+        planar form the exact-fp32 kernels (one fmaf chain per output).
+        bound: a 1-element device tensor >= max |volume| (channels-last form): conv0 - conv3 then run in split-f16 arithmetic (half
+        the matrix-pipe work at fp32-class error, csrc/sbf_common.hpp), each layer scaling its input by the bound its producer
+        measured; None: split-bf16 throughout."""
         if self.training:
             # training / autograd path (SURVEY §8(f)-2): HIP forward + backward kernels behind autograd Functions
             from . import training                                      # validates the dims
@@ -288,23 +308,34 @@ class CostRegNet(_PackedHolder):
             if channels_last:
                 if "conv0.ws" not in p:
                     raise RuntimeError("CostRegNet: channels-last input needs the split-bf16 kernels (CDS_CONV_EXACT=1 disables them)")
-                return self._run_cl(volume, p)
+                return self._run_cl(volume, p, bound)
             return self._run(volume, p)
 
-    def regress(self, volume_cl: Tensor, hyp: Tensor) -> Tuple[Tensor, Tensor]:
+    def regress(self, volume_cl: Tensor, hyp: Tensor, bound: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
         """volume [D,h,w,C] channels-last + hypotheses [D,h,w] -> (depth [h,w], confidence [h,w]): CostRegNet followed by the
-        soft-argmin (models/model.py:83-92)."""
+        soft-argmin (models/model.py:83-92).  bound: see forward()."""
         if self.training:
             raise RuntimeError("CostRegNet.regress is the inference path")
-        return ops.softargmin_conf(self.forward(volume_cl, channels_last=True), hyp)
+        return ops.softargmin_conf(self.forward(volume_cl, channels_last=True, bound=bound), hyp)
 
     @staticmethod
-    def _run_cl(v: Tensor, p: Dict[str, Tensor]) -> Tensor:
-        c0 = ops.conv3d_sbf(v, p["conv0.ws"], p["conv0.b"], 8, stride=ops.SBF_PAIR)
-        c1 = ops.conv3d_sbf(c0, p["conv1.ws"], p["conv1.b"], 16, stride=2)
-        c2 = ops.conv3d_sbf(c1, p["conv2.ws"], p["conv2.b"], 16)
-        del c1
-        c3 = ops.conv3d_sbf(c2, p["conv3.ws"], p["conv3.b"], 32, stride=2)
+    def _run_cl(v: Tensor, p: Dict[str, Tensor], bound: Optional[Tensor] = None) -> Tensor:
+        if bound is not None and all(f"conv{i}.wh" in p for i in range(4)) and ops.USE_SPLIT_F16:
+            # conv0 - conv3 in split-f16: every layer leaves max |output| in its slot of `bnd` (zeroed once), the next one scales by it
+            bnd = torch.zeros((4,), dtype=torch.float32, device=v.device)
+            c0 = ops.conv3d_sbf(v, p["conv0.wh"], p["conv0.b"], 8, stride=ops.SBF_PAIR, in_bound=bound, w_inv_scale=p["conv0.whs"],
+                                out_bound=bnd[0:1])
+            c1 = ops.conv3d_sbf(c0, p["conv1.wh"], p["conv1.b"], 16, stride=2, in_bound=bnd[0:1], w_inv_scale=p["conv1.whs"],
+                                out_bound=bnd[1:2])
+            c2 = ops.conv3d_sbf(c1, p["conv2.wh"], p["conv2.b"], 16, in_bound=bnd[1:2], w_inv_scale=p["conv2.whs"], out_bound=bnd[2:3])
+            del c1
+            c3 = ops.conv3d_sbf(c2, p["conv3.wh"], p["conv3.b"], 32, stride=2, in_bound=bnd[2:3], w_inv_scale=p["conv3.whs"])
+        else:
+            c0 = ops.conv3d_sbf(v, p["conv0.ws"], p["conv0.b"], 8, stride=ops.SBF_PAIR)
+            c1 = ops.conv3d_sbf(c0, p["conv1.ws"], p["conv1.b"], 16, stride=2)
+            c2 = ops.conv3d_sbf(c1, p["conv2.ws"], p["conv2.b"], 16)
+            del c1
+            c3 = ops.conv3d_sbf(c2, p["conv3.ws"], p["conv3.b"], 32, stride=2)
         c4 = ops.conv3d_sbf(c3, p["conv4.ws"], p["conv4.b"], 32)
         del c3
         c5 = ops.conv3d_sbf(c4, p["conv5.ws"], p["conv5.b"], 64, stride=2)
@@ -721,13 +752,17 @@ class StageNet(_PackedHolder):
         volume, vis_sum = ops.warp_aggregate(ref_chw, src_hwc, vis, mats, hyp, normalize=normalize, channels_last=channels_last)
         return volume, vis_sum, ent, vis
 
-    def run_single(self, ref_chw, src_hwc, ref_nc, nc_sums, mats, hyp, cost_regularization, stage_idx):
+    def run_single(self, ref_chw, src_hwc, ref_nc, nc_sums, mats, hyp, cost_regularization, stage_idx, vol_bound=None):
         """One batch item.  ref_chw [V,C,h,w], src_hwc [V,h,w,C], ref_nc [V,h,w], nc_sums [V,h,w] (already
-        (ref+src)/2 per view), hyp [D,h,w]."""
+        (ref+src)/2 per view), hyp [D,h,w].  vol_bound: a 1-element device tensor >= max |volume| for CostRegNet's split-f16 layers
+        (the model passes 1: its features are tanh outputs); None = max |ref| x max |src|, which bounds the normalised volume - a
+        visibility-weighted average of ref x (bilinear, zero-padded samples of src) - for any features."""
         cl = isinstance(cost_regularization, CostRegNet) and cost_regularization.split_bf16_supported()
         volume, _, _, _ = self.aggregate(ref_chw, src_hwc, ref_nc, mats, hyp, stage_idx, channels_last=cl)
         if cl:
-            depth, conf = cost_regularization.regress(volume, hyp)
+            if vol_bound is None and ops.USE_SPLIT_F16:
+                vol_bound = (ref_chw.abs().amax() * src_hwc.abs().amax()).reshape(1)
+            depth, conf = cost_regularization.regress(volume, hyp, bound=vol_bound)
         else:
             depth, conf = ops.softargmin_conf(cost_regularization(volume), hyp)
         del volume
@@ -1033,7 +1068,9 @@ class CDSMVSNet(nn.Module):
     def _run_stage(self, ref, src, ref_nc, nc_sums, mats, hyp, s, V_total):
         sh = self._view_shard
         if sh is None:
-            return self.stage_net.run_single(ref, src, ref_nc, nc_sums, mats, hyp, self.cost_regularization[s], s)
+            # FeatureNet's stage outputs are tanh outputs: |feature| < 1, so 1 bounds the normalised volume (no reduction launches)
+            return self.stage_net.run_single(ref, src, ref_nc, nc_sums, mats, hyp, self.cost_regularization[s], s,
+                                             vol_bound=_unit_bound(ref.device))
         return sh.run_stage(self, ref, src, ref_nc, nc_sums, mats, hyp, s, V_total, C=self.feature.out_channels[s])
 
 

@@ -450,7 +450,7 @@ def conv3d_k3(x: Tensor, wpk: Tensor, bias: Optional[Tensor], stride: int = 1, r
     return out
 
 
-def split_pack_conv3d(w: Tensor) -> Tensor:
+def split_pack_conv3d(w: Tensor, f16: bool = False):
     """Pack a (BN-folded) Conv3d weight [Cout,Cin,3,3,3] for cds_conv3d_sbf_f32: every weight is split exactly into
     three bf16 terms (hi = RN(w), mid = RN(w - hi), lo = w - hi - mid) and laid out as the A operands of
     v_mfma_f32_16x16x32_bf16: int16 [Cin/8][7 ksteps][ceil(Cout/16)][3][64 lanes][8].  Lane l = 16 g + i multiplies output
@@ -463,7 +463,21 @@ def split_pack_conv3d(w: Tensor) -> Tensor:
     taps[:Cout, :, :27] = w.detach().float().reshape(Cout, rounds, 8, 27).permute(0, 1, 3, 2)
     # -> [rd][t][mb][g][i][j] -> lanes l = 16 g + i
     a = taps.reshape(mbl, 16, rounds, 7, 4, 8).permute(2, 3, 0, 4, 1, 5).reshape(rounds, 7, mbl, 64, 8)
-    return _split3(a)                                                                            # [rd][t][mb][3][64][8]
+    return _split2_f16(a) if f16 else _split3(a)                                                 # [rd][t][mb][3][64][8] (f16: + 1 / scale)
+
+
+def _split2_f16(a: Tensor) -> Tuple[Tensor, float]:
+    """Split-f16 form of a weight operand [...,64,8] (csrc/sbf_common.hpp): two fp16 terms of a * s for the power of two s that puts
+    max |a| into (2^14, 2^15] -> (int16 [...,3,64,8] = (hi, lo, unused), 1 / s).  The third slot keeps the split-bf16 geometry."""
+    import math
+    m = float(a.abs().max())
+    e = math.frexp(m)[1] if (m > 0.0 and math.isfinite(m)) else 15
+    e = max(-100, min(100, e))
+    s = 2.0 ** (15 - e)
+    v = a * s
+    hi = v.to(torch.float16)
+    lo = (v - hi.float()).to(torch.float16)
+    return torch.stack((hi, lo, torch.zeros_like(hi)), dim=-3).contiguous().view(torch.int16), 1.0 / s
 
 
 def _split3(a: Tensor) -> Tensor:
@@ -633,9 +647,12 @@ def deconv_prob_zm(x_cl: Tensor, wsplit: Tensor, bias: Tensor, skip: Tensor, pro
 
 
 SBF_PAIR = 101   # CDS_SBF_PAIR: stride code of the pair-packed stride-1, Cout = 8 form
+# split-f16 arithmetic (two fp16 terms, three products: half the matrix-pipe work of split-bf16 at fp32-class error) for the layers that
+# have it (round 6: conv0 - conv3 of CostRegNet); CDS_SPLIT_F16=0: split-bf16 everywhere (A/B, and the arithmetic of rounds 2-5)
+USE_SPLIT_F16 = os.environ.get("CDS_SPLIT_F16", "1") != "0"
 
 
-def split_pack_conv3d_pair(w: Tensor) -> Tensor:
+def split_pack_conv3d_pair(w: Tensor, f16: bool = False):
     """Pair packing of a (BN-folded) Conv3d weight [8,Cin,3,3,3] for cds_conv3d_sbf_f32(stride=CDS_SBF_PAIR): an MFMA column
     is the voxel pair (2 j, 2 j + 1), row i = 8 p + co is output channel co of voxel 2 j + p, and the K window is 3 x 3 x 4
     taps (x' = 0..3 relative to the pair): row (p, co) multiplies w[co][ci][kz][ky][x' - p], or 0 outside 0..2.
@@ -650,13 +667,22 @@ def split_pack_conv3d_pair(w: Tensor) -> Tensor:
         taps[p_, :, :, :, :, p_:p_ + 3] = wf.permute(0, 1, 3, 4, 5, 2)
     taps = taps[:, :, :, :, :, [0, 2, 1, 3]]          # lane group g multiplies x' = (0, 2, 1, 3)[g] (LDS bank pairing)
     a = taps.reshape(16, rounds, 9, 4, 8).permute(1, 2, 3, 0, 4).reshape(rounds, 9, 1, 64, 8)   # [rd][t][mb][16 g + i][j]
-    return _split3(a)
+    return _split2_f16(a) if f16 else _split3(a)
+
+
+def conv3d_sf16_supported(cin: int, cout: int, stride: int) -> bool:
+    """Shapes of the split-f16 z-marching kernels (cds_conv3d_sf16_f32)."""
+    return USE_SPLIT_F16 and (cin, cout, stride) in ((8, 8, SBF_PAIR), (16, 8, SBF_PAIR), (32, 8, SBF_PAIR), (16, 16, 1), (8, 16, 2), (16, 32, 2))
 
 
 def conv3d_sbf(x_cl: Tensor, wsplit: Tensor, bias: Optional[Tensor], cout: int, stride: int = 1, relu: bool = True,
-               skip: Optional[Tensor] = None) -> Tensor:
+               skip: Optional[Tensor] = None, in_bound: Optional[Tensor] = None, w_inv_scale: float = 1.0,
+               out_bound: Optional[Tensor] = None) -> Tensor:
     """K4 in split-bf16 arithmetic (fp32-class error on the bf16 matrix cores) on channels-last volumes.
-    x_cl [D,H,W,Cin] fp32, wsplit from split_pack_conv3d -> [Do,Ho,Wo,cout]."""
+    x_cl [D,H,W,Cin] fp32, wsplit from split_pack_conv3d -> [Do,Ho,Wo,cout].
+    in_bound given: SPLIT-F16 arithmetic instead (cds_conv3d_sf16_f32; conv3d_sf16_supported shapes): wsplit / w_inv_scale from the
+    packers with f16=True, in_bound a 1-element device tensor >= max |x_cl|, out_bound a ZEROED 1-element device tensor that receives
+    max |out| (the next layer's in_bound) or None."""
     D, H, W, Cin = x_cl.shape
     sg = 1 if stride == SBF_PAIR else stride        # geometric stride (SBF_PAIR: stride 1, pair-packed weights)
     Do, Ho, Wo = (D - 1) // sg + 1, (H - 1) // sg + 1, (W - 1) // sg + 1
@@ -672,6 +698,15 @@ def conv3d_sbf(x_cl: Tensor, wsplit: Tensor, bias: Optional[Tensor], cout: int, 
     if Cin % 8 or wsplit.numel() != want:
         raise ValueError(f"conv3d_sbf: wsplit has {wsplit.numel()} entries, the packer gives {want} for Cin={Cin}, cout={cout}, "
                          f"stride code {stride}")
+    if in_bound is not None:
+        if skip is not None or not conv3d_sf16_supported(Cin, cout, stride):
+            raise ValueError(f"conv3d_sbf: no split-f16 kernel for Cin={Cin}, cout={cout}, stride code {stride}, skip={skip is not None}")
+        check(_lib.load().cds_conv3d_sf16_f32(_dev(x_cl, "x"), wsplit.data_ptr(), _dev(bias, "bias") if bias is not None else None,
+                                              out.data_ptr(), Cin, cout, D, H, W, stride, ACT_RELU if relu else ACT_NONE,
+                                              _dev(in_bound, "in_bound"), float(w_inv_scale),
+                                              _dev(out_bound, "out_bound") if out_bound is not None else None, _stream(x_cl)),
+              "cds_conv3d_sf16_f32")
+        return out
     check(_lib.load().cds_conv3d_sbf_f32(_dev(x_cl, "x"), wsplit.data_ptr(), _dev(bias, "bias") if bias is not None else None,
                                          _dev(skip, "skip") if skip is not None else None, out.data_ptr(), Cin, cout,
                                          D, H, W, stride, ACT_RELU if relu else ACT_NONE, _stream(x_cl)), "cds_conv3d_sbf_f32")

@@ -203,6 +203,17 @@ int cds_conv3d_k3_cl_f32(const float* x, const float* weight_cl, const float* bi
 #define CDS_SBF_PAIR 101
 int cds_conv3d_sbf_f32(const float* x, const void* weight_split, const float* bias, const float* skip, float* out,
                        int Cin, int Cout, int D, int H, int W, int stride, int act, void* stream);
+/* The same convolution in SPLIT-F16 arithmetic: every fp32 operand as TWO fp16 terms of (operand x a power-of-two tensor scale), three
+ * partial products per K-step on v_mfma_f32_16x16x32_f16, fp32 accumulate, exact rescaling in the epilogue - fp32-class error (the
+ * representation error is ~0.3x the rounding error of an fp32 convolution) at half the matrix-pipe work of split-bf16.  Shapes: those
+ * of the z-marching kernels (Cin, Cout, stride) in {(8 | 16 | 32, 8, PAIR), (16, 16, 1), (8, 16, 2), (16, 32, 2)}; CDS_EINVAL otherwise.
+ *   weight_split  the split-bf16 layout with fp16 terms (hi, lo, unused) of weight * w_scale (ops.split_pack_conv3d / _pair (f16=True))
+ *   w_inv_scale   1 / w_scale, a power of two
+ *   in_bound      DEVICE scalar >= max |x| (the producing kernel's out_bound, or any upper bound: it fixes the input's scale)
+ *   out_bound     DEVICE scalar that receives max |out| by an atomic maximum (zero it before the call), or NULL */
+int cds_conv3d_sf16_f32(const float* x, const void* weight_split, const float* bias, float* out, int Cin, int Cout, int D, int H, int W,
+                        int stride, int act, const float* in_bound, float w_inv_scale, float* out_bound, void* stream);
+
 
 /* ConvTranspose3d k3 s2 p1 op1 (+bias +ReLU +residual) in the same split-bf16 arithmetic, channels-last: x [D][H][W][Cin]
  * -> out [2D][2H][2W][Cout].  Replaces models/module.py:125-160 (Deconv3d + BatchNorm3d(eval, folded) + ReLU + the U-Net

@@ -35,10 +35,18 @@ for name in (sys.argv[1:] or list(SH)):
         f.in_numel = n
         return f
     with torch.no_grad():
-        c0 = run("conv0", mk(lambda: ops.conv3d_sbf(v, p["conv0.ws"], p["conv0.b"], 8, stride=ops.SBF_PAIR), v.numel()), C, 8, D * h * w)
-        c1 = run("conv1", mk(lambda: ops.conv3d_sbf(c0, p["conv1.ws"], p["conv1.b"], 16, stride=2), c0.numel()), 8, 16, D * h * w // 8)
-        c2 = run("conv2", mk(lambda: ops.conv3d_sbf(c1, p["conv2.ws"], p["conv2.b"], 16), c1.numel()), 16, 16, D * h * w // 8)
-        c3 = run("conv3", mk(lambda: ops.conv3d_sbf(c2, p["conv3.ws"], p["conv3.b"], 32, stride=2), c2.numel()), 16, 32, D * h * w // 64)
+        if ops.USE_SPLIT_F16 and "conv0.wh" in p:      # conv0 - conv3 in split-f16 (CDS_SPLIT_F16=0: split-bf16)
+            bnd = torch.zeros(4, device=dev); vb = v.abs().amax().reshape(1)
+            def z(i): bnd[i:i + 1].zero_(); return bnd[i:i + 1]
+            c0 = run("conv0 h", mk(lambda: ops.conv3d_sbf(v, p["conv0.wh"], p["conv0.b"], 8, stride=ops.SBF_PAIR, in_bound=vb, w_inv_scale=p["conv0.whs"], out_bound=bnd[0:1]), v.numel()), C, 8, D * h * w)
+            c1 = run("conv1 h", mk(lambda: ops.conv3d_sbf(c0, p["conv1.wh"], p["conv1.b"], 16, stride=2, in_bound=bnd[0:1], w_inv_scale=p["conv1.whs"], out_bound=bnd[1:2]), c0.numel()), 8, 16, D * h * w // 8)
+            c2 = run("conv2 h", mk(lambda: ops.conv3d_sbf(c1, p["conv2.wh"], p["conv2.b"], 16, in_bound=bnd[1:2], w_inv_scale=p["conv2.whs"], out_bound=bnd[2:3]), c1.numel()), 16, 16, D * h * w // 8)
+            c3 = run("conv3 h", mk(lambda: ops.conv3d_sbf(c2, p["conv3.wh"], p["conv3.b"], 32, stride=2, in_bound=bnd[2:3], w_inv_scale=p["conv3.whs"]), c2.numel()), 16, 32, D * h * w // 64)
+        else:
+            c0 = run("conv0", mk(lambda: ops.conv3d_sbf(v, p["conv0.ws"], p["conv0.b"], 8, stride=ops.SBF_PAIR), v.numel()), C, 8, D * h * w)
+            c1 = run("conv1", mk(lambda: ops.conv3d_sbf(c0, p["conv1.ws"], p["conv1.b"], 16, stride=2), c0.numel()), 8, 16, D * h * w // 8)
+            c2 = run("conv2", mk(lambda: ops.conv3d_sbf(c1, p["conv2.ws"], p["conv2.b"], 16), c1.numel()), 16, 16, D * h * w // 8)
+            c3 = run("conv3", mk(lambda: ops.conv3d_sbf(c2, p["conv3.ws"], p["conv3.b"], 32, stride=2), c2.numel()), 16, 32, D * h * w // 64)
         c4 = run("conv4", mk(lambda: ops.conv3d_sbf(c3, p["conv4.ws"], p["conv4.b"], 32), c3.numel()), 32, 32, D * h * w // 64)
         c5 = run("conv5", mk(lambda: ops.conv3d_sbf(c4, p["conv5.ws"], p["conv5.b"], 64, stride=2), c4.numel()), 32, 64, D * h * w // 512)
         c6 = run("conv6", mk(lambda: ops.conv3d_sbf(c5, p["conv6.ws"], p["conv6.b"], 64), c5.numel()), 64, 64, D * h * w // 512)

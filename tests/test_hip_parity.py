@@ -134,7 +134,13 @@ def test_costreg(tag, C, dev):
     err_cl = (out_cl - g["cost_reg"]).abs().max()
     assert err_cl < 1e-4, err_cl
     assert (out_cl - out).abs().max() < 2e-5
-    print(f"CostRegNet {tag}: max |HIP - reference| exact-fp32 {err:.2e}, split-bf16 {err_cl:.2e}")
+    # ... and with conv0 - conv3 in split-f16 (what the model runs since round 6: a bound of the volume's magnitudes is handed in)
+    vol_cl = g["volume"].permute(1, 2, 3, 0).contiguous().to(dev)
+    out_h = net(vol_cl, channels_last=True, bound=vol_cl.abs().amax().reshape(1)).cpu()
+    err_h = (out_h - g["cost_reg"]).abs().max()
+    assert err_h < 1e-4, err_h
+    assert (out_h - out).abs().max() < 2e-5 and not torch.equal(out_h, out_cl)      # (not equal: the split-f16 layers really ran)
+    print(f"CostRegNet {tag}: max |HIP - reference| exact-fp32 {err:.2e}, split-bf16 {err_cl:.2e}, split-f16 conv0-3 {err_h:.2e}")
 
 
 def test_conv3d_layers_vs_torch(dev, ops):
@@ -936,6 +942,50 @@ def test_conv3d_split_bf16_is_fp32_class(cin, cout, stride, D, H, W, dev, ops):
                           skip=skip.permute(1, 2, 3, 0).contiguous().to(dev)).cpu().permute(3, 0, 1, 2)
     want2 = skip.double() + want64.clamp_min(0)
     assert (got2.double() - want2).abs().max().item() <= 1.5 * err_f32 + 2 * ulp
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("loose", [1.0, 6.5])
+@pytest.mark.parametrize("cin,cout,stride,D,H,W", [(8, 8, 101, 9, 13, 40), (8, 8, 101, 50, 9, 70), (16, 8, 101, 5, 8, 33), (32, 8, 101, 8, 16, 64),
+                                                  (32, 8, 101, 20, 23, 100), (16, 8, 101, 17, 29, 70), (16, 16, 1, 6, 10, 36),
+                                                  (16, 16, 1, 21, 27, 70), (8, 16, 2, 9, 17, 35), (8, 16, 2, 21, 37, 131),
+                                                  (16, 32, 2, 8, 16, 32), (16, 32, 2, 19, 31, 67)])
+def test_conv3d_split_f16_is_fp32_class(cin, cout, stride, D, H, W, loose, dev, ops):
+    """Round 6: the z-marching kernels in SPLIT-F16 arithmetic (csrc/sbf_common.hpp: two fp16 terms of operand x power-of-two tensor
+    scale, three products per K-step instead of split-bf16's six, exact rescaling) - the same claim and the same bar as
+    test_conv3d_split_bf16_is_fp32_class: against a float64 convolution no worse than 1.5x a plain fp32 evaluation (+ one ulp of
+    the result scale), on the same inputs (uneven channel scales: magnitudes spread over ~3 decades inside one tensor scale).
+    `loose`: the input bound handed to the kernel is that many times the true maximum (any upper bound is valid: it only moves the
+    tensor scale - here across a power of two).  The kernel's out_bound must be the exact maximum magnitude of what it stored."""
+    g = torch.Generator().manual_seed(cin * 100 + cout)
+    x = torch.randn(cin, D, H, W, generator=g) * torch.exp(torch.randn(cin, 1, 1, 1, generator=g))     # uneven channel scales
+    w = torch.randn(cout, cin, 3, 3, 3, generator=g) / (27 * cin) ** 0.5
+    b = torch.randn(cout, generator=g)
+    pair = stride == ops.SBF_PAIR
+    code, stride = stride, (1 if pair else stride)
+    assert ops.conv3d_sf16_supported(cin, cout, code)
+    want64 = F.conv3d(x.double().unsqueeze(0), w.double(), b.double(), padding=1, stride=stride)[0]
+    want32 = F.conv3d(x.unsqueeze(0), w, b, padding=1, stride=stride)[0]
+    wh, w_inv = (ops.split_pack_conv3d_pair if pair else ops.split_pack_conv3d)(w.to(dev), f16=True)
+    x_cl = x.permute(1, 2, 3, 0).contiguous().to(dev)
+    in_bound = (x_cl.abs().amax() * loose).reshape(1)
+    for relu in (False, True):
+        out_bound = torch.zeros(1, device=dev)
+        got = ops.conv3d_sbf(x_cl, wh, b.to(dev), cout, stride=code, relu=relu, in_bound=in_bound, w_inv_scale=w_inv, out_bound=out_bound)
+        assert float(out_bound) == float(got.abs().max()), (relu, float(out_bound), float(got.abs().max()))
+        got = got.cpu().permute(3, 0, 1, 2)
+        ref64 = want64.clamp_min(0) if relu else want64
+        wpk = w.permute(1, 2, 3, 4, 0).reshape(cin, 27, cout).contiguous().to(dev)
+        chain32 = ops.conv3d_k3(x.to(dev), wpk, b.to(dev), stride=stride, relu=False).cpu()
+        err = (got.double() - ref64).abs().max().item()
+        err_f32 = max((want32.double() - want64).abs().max().item(), (chain32.double() - want64).abs().max().item())
+        ulp = want64.abs().max().item() * 2.0 ** -23
+        if not relu:
+            ws = ops.split_pack_conv3d_pair(w.to(dev)) if pair else ops.split_pack_conv3d(w.to(dev))
+            sbf = ops.conv3d_sbf(x_cl, ws, b.to(dev), cout, stride=code, relu=False).cpu().permute(3, 0, 1, 2)
+            print(f"conv3d {cin}->{cout} s{stride} bound x{loose}: max err vs float64: split-f16 {err:.2e}, split-bf16 "
+                  f"{(sbf.double() - want64).abs().max().item():.2e}, fp32 {err_f32:.2e}")
+        assert err <= 1.5 * err_f32 + ulp, (relu, err, err_f32)
 
 
 @pytest.mark.gpu
