@@ -87,13 +87,19 @@ struct FCfg {
 // loads -> exact bf16 split in registers -> LDS writes), double-buffered LDS tile, ONE workgroup barrier per stage.  The
 // producers run a stage ahead in LDS and another one ahead in registers, so the matrix pipe never waits for staging: with
 // the staging in the same waves as the MFMAs, the two workgroups of a CU fell into lock-step and the pipe idled half the time.
-template <int S, int MB, int TX_, int TZ_, bool PAIR = false, bool WRES_ = false>
+// F16: split-f16 arithmetic (sbf_common.hpp: two fp16 terms, three products per K-step, tensor scales from device bounds) - same tile
+// geometry and weight layout, term 2 unused.
+template <int S, int MB, int TX_, int TZ_, bool PAIR = false, bool WRES_ = false, bool F16 = false>
 __global__ __launch_bounds__((FCfg<S, MB, TX_, TZ_, PAIR, WRES_>::THREADS)) void conv3d_sbf_kernel(const float* __restrict__ x, const uint4* __restrict__ wsp,
                                                             const float* __restrict__ bias, const float* __restrict__ skip,
                                                             float* __restrict__ out, int Cin, int Cout, int D, int H, int W,
                                                             int Do, int Ho, int Wo, int act, int tiles_x, int tiles_y,
-                                                            int ntiles, int tpw) {
+                                                            int ntiles, int tpw, const float* __restrict__ in_bound, float w_inv,
+                                                            float* __restrict__ out_bound) {
   using Cfg = FCfg<S, MB, TX_, TZ_, PAIR, WRES_>;
+  constexpr int NT = F16 ? 2 : 3;                       // terms per operand
+  const float xs = F16 ? sf16_scale(in_bound[0]) : 1.0f;
+  const float out_mul = F16 ? w_inv / xs : 1.0f;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -143,7 +149,10 @@ __global__ __launch_bounds__((FCfg<S, MB, TX_, TZ_, PAIR, WRES_>::THREADS)) void
       unsigned char* base = lds + buf * Cfg::LDSB;
 #pragma unroll
       for (int h = 0; h < PPT; ++h)
-        if (s_rel[h] >= 0) split_store8(base + s_dst[h], va[set][h], vb[set][h]);
+        if (s_rel[h] >= 0) {
+          if (F16) split_store8_f16(base + s_dst[h], va[set][h], vb[set][h], xs);
+          else split_store8(base + s_dst[h], va[set][h], vb[set][h]);
+        }
     };
     // Stage s travels in register set s % NSETS and lands in LDS buffer s & 1; its loads are issued NSETS stages before it is
     // split and written.  (NSETS = 4 measured no faster than 2 on any layer: the staging loads are not latency-bound.)
@@ -197,7 +206,7 @@ __global__ __launch_bounds__((FCfg<S, MB, TX_, TZ_, PAIR, WRES_>::THREADS)) void
       const uint4* p = wrp + (size_t)((t * MB + mb) * 3) * 64;
       wa[buf][mb][0].u = p[0];
       wa[buf][mb][1].u = p[64];
-      wa[buf][mb][2].u = p[128];
+      if (!F16) wa[buf][mb][2].u = p[128];
     }
   };
   // WDB (streamed weights, double-buffered): K-step 0 of a stage multiplies from its own registers w0, requested during the
@@ -209,7 +218,7 @@ __global__ __launch_bounds__((FCfg<S, MB, TX_, TZ_, PAIR, WRES_>::THREADS)) void
     for (int mb = 0; mb < MB; ++mb) {
       w0[mb][0].u = wrp[(size_t)(mb * 3) * 64];
       w0[mb][1].u = wrp[(size_t)(mb * 3 + 1) * 64];
-      w0[mb][2].u = wrp[(size_t)(mb * 3 + 2) * 64];
+      if (!F16) w0[mb][2].u = wrp[(size_t)(mb * 3 + 2) * 64];
     }
   };
   // WRES: every K-step's weights are loaded ONCE.  The consumer waves then issue no vector-memory loads in the stage loop,
@@ -220,7 +229,7 @@ __global__ __launch_bounds__((FCfg<S, MB, TX_, TZ_, PAIR, WRES_>::THREADS)) void
     for (int t = 0; t < Cfg::KSTEPS; ++t) {
       wres[t][0].u = wl[(size_t)(t * 3) * 64];
       wres[t][1].u = wl[(size_t)(t * 3 + 1) * 64];
-      wres[t][2].u = wl[(size_t)(t * 3 + 2) * 64];
+      if (!F16) wres[t][2].u = wl[(size_t)(t * 3 + 2) * 64];
     }
   } else if (Cfg::WDB) {
     load_w0(wl);                                       // first stage: K-steps 0 and 1 requested before the barrier
@@ -234,6 +243,7 @@ __global__ __launch_bounds__((FCfg<S, MB, TX_, TZ_, PAIR, WRES_>::THREADS)) void
     const int co = PAIR ? 4 * (g & 1) : mb * 16 + 4 * g;
     bvr[mb] = (bias && co < Cout) ? *reinterpret_cast<const float4*>(bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
+  float amax = 0.f;                                    // split-f16: running maximum of the magnitudes this lane stores
   __syncthreads();                                     // #0
   int st = 0;
   for (int tile = tile0; tile < tile1; ++tile) {
@@ -258,7 +268,7 @@ __global__ __launch_bounds__((FCfg<S, MB, TX_, TZ_, PAIR, WRES_>::THREADS)) void
           const unsigned char* b = bp + ((tz * S * Cfg::IY) * Cfg::IXP + txr * 16) * POSB;
           bd[buf][q][0].u = *reinterpret_cast<const uint4*>(b);
           bd[buf][q][1].u = *reinterpret_cast<const uint4*>(b + 16);
-          bd[buf][q][2].u = *reinterpret_cast<const uint4*>(b + 32);
+          if (!F16) bd[buf][q][2].u = *reinterpret_cast<const uint4*>(b + 32);
         }
       };
       load_b(0, 0, 0);                                 // (the K-step-0 weights were requested before the stage barrier)
@@ -284,12 +294,22 @@ __global__ __launch_bounds__((FCfg<S, MB, TX_, TZ_, PAIR, WRES_>::THREADS)) void
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) {
-          if (Cfg::WRES) {
-            SBF_TERMS(acc[mb], t0, Cfg::NG, wres[t], bd[db]);
-          } else if (Cfg::WDB && t == 0) {
-            SBF_TERMS(acc[mb], t0, Cfg::NG, w0[mb], bd[db]);
+          if constexpr (F16) {
+            if (Cfg::WRES) {
+              SF16_TERMS(acc[mb], t0, Cfg::NG, wres[t], bd[db]);
+            } else if (Cfg::WDB && t == 0) {
+              SF16_TERMS(acc[mb], t0, Cfg::NG, w0[mb], bd[db]);
+            } else {
+              SF16_TERMS(acc[mb], t0, Cfg::NG, wa[wb][mb], bd[db]);
+            }
           } else {
-            SBF_TERMS(acc[mb], t0, Cfg::NG, wa[wb][mb], bd[db]);
+            if (Cfg::WRES) {
+              SBF_TERMS(acc[mb], t0, Cfg::NG, wres[t], bd[db]);
+            } else if (Cfg::WDB && t == 0) {
+              SBF_TERMS(acc[mb], t0, Cfg::NG, w0[mb], bd[db]);
+            } else {
+              SBF_TERMS(acc[mb], t0, Cfg::NG, wa[wb][mb], bd[db]);
+            }
           }
         }
       }
@@ -302,7 +322,7 @@ __global__ __launch_bounds__((FCfg<S, MB, TX_, TZ_, PAIR, WRES_>::THREADS)) void
 #pragma unroll
           for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-            for (int tm = 0; tm < 3; ++tm) {
+            for (int tm = 0; tm < NT; ++tm) {
               asm volatile("" ::"v"(w0[mb][tm].u.x), "v"(w0[mb][tm].u.y), "v"(w0[mb][tm].u.z), "v"(w0[mb][tm].u.w));
               asm volatile("" ::"v"(wa[1][mb][tm].u.x), "v"(wa[1][mb][tm].u.y), "v"(wa[1][mb][tm].u.z), "v"(wa[1][mb][tm].u.w));
             }
@@ -322,7 +342,9 @@ __global__ __launch_bounds__((FCfg<S, MB, TX_, TZ_, PAIR, WRES_>::THREADS)) void
               const int oz = oz0 + tz, ox = PAIR ? ox0 + txr * 32 + 2 * j + (g >> 1) : ox0 + txr * 16 + j;
               if (oz >= Do || ox >= Wo) continue;
               const size_t base = ((size_t)((size_t)oz * Ho + oy) * Wo + ox) * Cout + co;
-              float4 o = make_float4(acc[mb][tl].x + bv.x, acc[mb][tl].y + bv.y, acc[mb][tl].z + bv.z, acc[mb][tl].w + bv.w);
+              float4 o = F16 ? make_float4(acc[mb][tl].x * out_mul + bv.x, acc[mb][tl].y * out_mul + bv.y, acc[mb][tl].z * out_mul + bv.z,
+                                           acc[mb][tl].w * out_mul + bv.w)
+                             : make_float4(acc[mb][tl].x + bv.x, acc[mb][tl].y + bv.y, acc[mb][tl].z + bv.z, acc[mb][tl].w + bv.w);
               if (act == CDS_ACT_RELU) {
                 o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
               }
@@ -330,6 +352,7 @@ __global__ __launch_bounds__((FCfg<S, MB, TX_, TZ_, PAIR, WRES_>::THREADS)) void
                 const float4 s4 = *reinterpret_cast<const float4*>(skip + base);
                 o.x = s4.x + o.x; o.y = s4.y + o.y; o.z = s4.z + o.z; o.w = s4.w + o.w;
               }
+              if (F16) amax = fmaxf(fmaxf(amax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
               sbf_store4(out + base, o);
             }
           }
@@ -340,11 +363,12 @@ __global__ __launch_bounds__((FCfg<S, MB, TX_, TZ_, PAIR, WRES_>::THREADS)) void
       __syncthreads();                                 // #(st + 1)
     }
   }
+  if (F16) sf16_publish_bound(amax, out_bound);
 }
 
-template <int S, int MB, int TX, int TZ, bool PAIR = false, bool WRES_ = false>
+template <int S, int MB, int TX, int TZ, bool PAIR = false, bool WRES_ = false, bool F16 = false>
 int launch_fwd(const float* x, const void* wsp, const float* b, const float* skip, float* out, int Cin, int Cout, int D, int H,
-               int W, int act, hipStream_t st) {
+               int W, int act, hipStream_t st, const float* in_bound = nullptr, float w_inv = 1.f, float* out_bound = nullptr) {
   using Cfg = FCfg<S, MB, TX, TZ, PAIR, WRES_>;
   static_assert(Cfg::KSTEPS % 2 == 1, "the weight ring assumes an even last K-step");
   static_assert(2 * Cfg::LDSB <= 160 * 1024, "two LDS tile buffers above 160 KB");
@@ -355,14 +379,14 @@ int launch_fwd(const float* x, const void* wsp, const float* b, const float* ski
   // (a sweep of 4 / 8 / 16 / 32 / 64 at M1 moves single layers by a few percent either way: conv4 likes 8-16, conv6 likes 1)
   int tpw = max(1, min(32, ntiles / (256 * 6)));
   const int nwg = cds_ceil_div(ntiles, tpw);
-  auto kern = conv3d_sbf_kernel<S, MB, TX, TZ, PAIR, WRES_>;
+  auto kern = conv3d_sbf_kernel<S, MB, TX, TZ, PAIR, WRES_, F16>;
   constexpr int lds_bytes = 2 * Cfg::LDSB;
   if (lds_bytes > 64 * 1024) {
     static std::atomic<unsigned long long> lds_ok{0};   // per instantiation
     if (int e_lds = cds_allow_lds(reinterpret_cast<const void*>(kern), lds_bytes, lds_ok)) return e_lds;
   }
   hipLaunchKernelGGL(kern, dim3(nwg), dim3(Cfg::THREADS), lds_bytes, st, x, reinterpret_cast<const uint4*>(wsp), b, skip, out, Cin,
-                     Cout, D, H, W, Do, Ho, Wo, act, tx, ty, ntiles, tpw);
+                     Cout, D, H, W, Do, Ho, Wo, act, tx, ty, ntiles, tpw, in_bound, w_inv, out_bound);
   return cds_launch_status();
 }
 
@@ -930,9 +954,16 @@ extern "C" int cds_conv3d_sf16_f32(const float* x, const void* weight_split, con
       (stride != 1 && stride != 2 && stride != CDS_SBF_PAIR) || !(w_inv_scale > 0.f))
     return CDS_EINVAL;
   if (stride == CDS_SBF_PAIR && Cout != 8) return CDS_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
   const int r = cds_conv3d_zmg_dispatch(x, weight_split, bias, out, Cin, Cout, D, H, W, stride == CDS_SBF_PAIR ? 1 : stride,
-                                        stride == CDS_SBF_PAIR, act, (hipStream_t)stream, in_bound, w_inv_scale, out_bound);
-  return r == CDS_ZMG_UNSUPPORTED ? CDS_EINVAL : r;
+                                        stride == CDS_SBF_PAIR, act, st, in_bound, w_inv_scale, out_bound);
+  if (r != CDS_ZMG_UNSUPPORTED) return r;
+  // the tiled kernels in split-f16: the deep layers (conv4 32 -> 32, conv5 32 -> 64 stride 2, conv6 64 -> 64)
+  const int mb = (Cout + 15) / 16;
+  if (stride == 1 && mb == 2) return launch_fwd<1, 2, 32, 2, false, false, true>(x, weight_split, bias, nullptr, out, Cin, Cout, D, H, W, act, st, in_bound, w_inv_scale, out_bound);
+  if (stride == 1 && mb == 4) return launch_fwd<1, 4, 32, 2, false, false, true>(x, weight_split, bias, nullptr, out, Cin, Cout, D, H, W, act, st, in_bound, w_inv_scale, out_bound);
+  if (stride == 2 && mb == 4) return launch_fwd<2, 4, 16, 2, false, false, true>(x, weight_split, bias, nullptr, out, Cin, Cout, D, H, W, act, st, in_bound, w_inv_scale, out_bound);
+  return CDS_EINVAL;
 }
 
 // ConvTranspose3d k3 s2 p1 op1 (+bias +ReLU +residual) in split-bf16 arithmetic on channels-last volumes.  x [D][H][W][Cin]

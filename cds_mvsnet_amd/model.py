@@ -320,27 +320,35 @@ class CostRegNet(_PackedHolder):
 
     @staticmethod
     def _run_cl(v: Tensor, p: Dict[str, Tensor], bound: Optional[Tensor] = None) -> Tensor:
-        if bound is not None and all(f"conv{i}.wh" in p for i in range(4)) and ops.USE_SPLIT_F16:
-            # conv0 - conv3 in split-f16: every layer leaves max |output| in its slot of `bnd` (zeroed once), the next one scales by it
-            bnd = torch.zeros((4,), dtype=torch.float32, device=v.device)
+        f16 = bound is not None and all(f"conv{i}.wh" in p for i in range(7)) and ops.USE_SPLIT_F16
+        if f16:
+            # conv0 - conv6 in split-f16: every layer leaves max |output| in its slot of `bnd` (zeroed once), the next one scales by it
+            bnd = torch.zeros((8,), dtype=torch.float32, device=v.device)
             c0 = ops.conv3d_sbf(v, p["conv0.wh"], p["conv0.b"], 8, stride=ops.SBF_PAIR, in_bound=bound, w_inv_scale=p["conv0.whs"],
                                 out_bound=bnd[0:1])
             c1 = ops.conv3d_sbf(c0, p["conv1.wh"], p["conv1.b"], 16, stride=2, in_bound=bnd[0:1], w_inv_scale=p["conv1.whs"],
                                 out_bound=bnd[1:2])
             c2 = ops.conv3d_sbf(c1, p["conv2.wh"], p["conv2.b"], 16, in_bound=bnd[1:2], w_inv_scale=p["conv2.whs"], out_bound=bnd[2:3])
             del c1
-            c3 = ops.conv3d_sbf(c2, p["conv3.wh"], p["conv3.b"], 32, stride=2, in_bound=bnd[2:3], w_inv_scale=p["conv3.whs"])
+            c3 = ops.conv3d_sbf(c2, p["conv3.wh"], p["conv3.b"], 32, stride=2, in_bound=bnd[2:3], w_inv_scale=p["conv3.whs"],
+                                out_bound=bnd[3:4])
+            c4 = ops.conv3d_sbf(c3, p["conv4.wh"], p["conv4.b"], 32, in_bound=bnd[3:4], w_inv_scale=p["conv4.whs"], out_bound=bnd[4:5])
+            del c3
+            c5 = ops.conv3d_sbf(c4, p["conv5.wh"], p["conv5.b"], 64, stride=2, in_bound=bnd[4:5], w_inv_scale=p["conv5.whs"],
+                                out_bound=bnd[5:6])
+            x = ops.conv3d_sbf(c5, p["conv6.wh"], p["conv6.b"], 64, in_bound=bnd[5:6], w_inv_scale=p["conv6.whs"])
+            del c5
         else:
             c0 = ops.conv3d_sbf(v, p["conv0.ws"], p["conv0.b"], 8, stride=ops.SBF_PAIR)
             c1 = ops.conv3d_sbf(c0, p["conv1.ws"], p["conv1.b"], 16, stride=2)
             c2 = ops.conv3d_sbf(c1, p["conv2.ws"], p["conv2.b"], 16)
             del c1
             c3 = ops.conv3d_sbf(c2, p["conv3.ws"], p["conv3.b"], 32, stride=2)
-        c4 = ops.conv3d_sbf(c3, p["conv4.ws"], p["conv4.b"], 32)
-        del c3
-        c5 = ops.conv3d_sbf(c4, p["conv5.ws"], p["conv5.b"], 64, stride=2)
-        x = ops.conv3d_sbf(c5, p["conv6.ws"], p["conv6.b"], 64)
-        del c5
+            c4 = ops.conv3d_sbf(c3, p["conv4.ws"], p["conv4.b"], 32)
+            del c3
+            c5 = ops.conv3d_sbf(c4, p["conv5.ws"], p["conv5.b"], 64, stride=2)
+            x = ops.conv3d_sbf(c5, p["conv6.ws"], p["conv6.b"], 64)
+            del c5
         x = ops.deconv3d_sbf(x, p["conv7.ws"], p["conv7.b"], 32, skip=c4)
         del c4
         x = ops.deconv3d_zm(x, p["conv9.wc"], p["conv9.b"], skip=c2)

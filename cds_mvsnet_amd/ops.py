@@ -672,7 +672,8 @@ def split_pack_conv3d_pair(w: Tensor, f16: bool = False):
 
 def conv3d_sf16_supported(cin: int, cout: int, stride: int) -> bool:
     """Shapes of the split-f16 z-marching kernels (cds_conv3d_sf16_f32)."""
-    return USE_SPLIT_F16 and (cin, cout, stride) in ((8, 8, SBF_PAIR), (16, 8, SBF_PAIR), (32, 8, SBF_PAIR), (16, 16, 1), (8, 16, 2), (16, 32, 2))
+    return USE_SPLIT_F16 and (cin, cout, stride) in ((8, 8, SBF_PAIR), (16, 8, SBF_PAIR), (32, 8, SBF_PAIR), (16, 16, 1), (8, 16, 2), (16, 32, 2),
+                                                     (32, 32, 1), (32, 64, 2), (64, 64, 1))      # z-marching kernels | tiled kernels
 
 
 def conv3d_sbf(x_cl: Tensor, wsplit: Tensor, bias: Optional[Tensor], cout: int, stride: int = 1, relu: bool = True,

@@ -42,12 +42,15 @@ for name in (sys.argv[1:] or list(SH)):
             c1 = run("conv1 h", mk(lambda: ops.conv3d_sbf(c0, p["conv1.wh"], p["conv1.b"], 16, stride=2, in_bound=bnd[0:1], w_inv_scale=p["conv1.whs"], out_bound=bnd[1:2]), c0.numel()), 8, 16, D * h * w // 8)
             c2 = run("conv2 h", mk(lambda: ops.conv3d_sbf(c1, p["conv2.wh"], p["conv2.b"], 16, in_bound=bnd[1:2], w_inv_scale=p["conv2.whs"], out_bound=bnd[2:3]), c1.numel()), 16, 16, D * h * w // 8)
             c3 = run("conv3 h", mk(lambda: ops.conv3d_sbf(c2, p["conv3.wh"], p["conv3.b"], 32, stride=2, in_bound=bnd[2:3], w_inv_scale=p["conv3.whs"]), c2.numel()), 16, 32, D * h * w // 64)
+            c4 = run("conv4 h", mk(lambda: ops.conv3d_sbf(c3, p["conv4.wh"], p["conv4.b"], 32, in_bound=vb * 0 + 1e3, w_inv_scale=p["conv4.whs"], out_bound=bnd[3:4]), c3.numel()), 32, 32, D * h * w // 64)
+            c5 = run("conv5 h", mk(lambda: ops.conv3d_sbf(c4, p["conv5.wh"], p["conv5.b"], 64, stride=2, in_bound=vb * 0 + 1e3, w_inv_scale=p["conv5.whs"]), c4.numel()), 32, 64, D * h * w // 512)
+            c6 = run("conv6 h", mk(lambda: ops.conv3d_sbf(c5, p["conv6.wh"], p["conv6.b"], 64, in_bound=vb * 0 + 1e3, w_inv_scale=p["conv6.whs"]), c5.numel()), 64, 64, D * h * w // 512)
         else:
             c0 = run("conv0", mk(lambda: ops.conv3d_sbf(v, p["conv0.ws"], p["conv0.b"], 8, stride=ops.SBF_PAIR), v.numel()), C, 8, D * h * w)
             c1 = run("conv1", mk(lambda: ops.conv3d_sbf(c0, p["conv1.ws"], p["conv1.b"], 16, stride=2), c0.numel()), 8, 16, D * h * w // 8)
             c2 = run("conv2", mk(lambda: ops.conv3d_sbf(c1, p["conv2.ws"], p["conv2.b"], 16), c1.numel()), 16, 16, D * h * w // 8)
             c3 = run("conv3", mk(lambda: ops.conv3d_sbf(c2, p["conv3.ws"], p["conv3.b"], 32, stride=2), c2.numel()), 16, 32, D * h * w // 64)
-        c4 = run("conv4", mk(lambda: ops.conv3d_sbf(c3, p["conv4.ws"], p["conv4.b"], 32), c3.numel()), 32, 32, D * h * w // 64)
+        c4 = c4 if "c4" in dir() and False else run("conv4", mk(lambda: ops.conv3d_sbf(c3, p["conv4.ws"], p["conv4.b"], 32), c3.numel()), 32, 32, D * h * w // 64)
         c5 = run("conv5", mk(lambda: ops.conv3d_sbf(c4, p["conv5.ws"], p["conv5.b"], 64, stride=2), c4.numel()), 32, 64, D * h * w // 512)
         c6 = run("conv6", mk(lambda: ops.conv3d_sbf(c5, p["conv6.ws"], p["conv6.b"], 64), c5.numel()), 64, 64, D * h * w // 512)
         x7 = run("conv7", mk(lambda: ops.deconv3d_sbf(c6, p["conv7.ws"], p["conv7.b"], 32, skip=c4), c6.numel() + c4.numel()), 64, 32, D * h * w // 512)

@@ -949,7 +949,10 @@ def test_conv3d_split_bf16_is_fp32_class(cin, cout, stride, D, H, W, dev, ops):
 @pytest.mark.parametrize("cin,cout,stride,D,H,W", [(8, 8, 101, 9, 13, 40), (8, 8, 101, 50, 9, 70), (16, 8, 101, 5, 8, 33), (32, 8, 101, 8, 16, 64),
                                                   (32, 8, 101, 20, 23, 100), (16, 8, 101, 17, 29, 70), (16, 16, 1, 6, 10, 36),
                                                   (16, 16, 1, 21, 27, 70), (8, 16, 2, 9, 17, 35), (8, 16, 2, 21, 37, 131),
-                                                  (16, 32, 2, 8, 16, 32), (16, 32, 2, 19, 31, 67)])
+                                                  (16, 32, 2, 8, 16, 32), (16, 32, 2, 19, 31, 67),
+                                                  # the tiled kernels (deep layers): conv4 / conv5 / conv6
+                                                  (32, 32, 1, 5, 9, 20), (32, 32, 1, 9, 13, 70), (64, 64, 1, 4, 6, 16), (64, 64, 1, 6, 11, 37),
+                                                  (32, 64, 2, 6, 9, 21), (32, 64, 2, 11, 18, 45)])
 def test_conv3d_split_f16_is_fp32_class(cin, cout, stride, D, H, W, loose, dev, ops):
     """Round 6: the z-marching kernels in SPLIT-F16 arithmetic (csrc/sbf_common.hpp: two fp16 terms of operand x power-of-two tensor
     scale, three products per K-step instead of split-bf16's six, exact rescaling) - the same claim and the same bar as
