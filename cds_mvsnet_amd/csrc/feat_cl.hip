@@ -36,6 +36,7 @@ struct DynEpi {
   double* partial;      // [N][tiles][C][2]
   float temperature;
   const float* epi;     // [N][2] DEVICE: epipoles in pixels of this resolution (feat_common.hpp)
+  float xs, omul;       // split-f16 kernels: power-of-two scale of the (normalised) input, accumulator multiplier 1 / (xs w_scale)
 };
 
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
@@ -215,7 +216,11 @@ __device__ __forceinline__ float row16_sum(float v) {
   return v;
 }
 
-template <int CIN, int K0, int K1, int K2, int MODE>
+// F16: split-f16 arithmetic (sbf_common.hpp: two fp16 terms of value x power-of-two scale, three products per K-step instead of six).
+// The input scale needs no measured bound here: a DynamicConv's input is InstanceNorm-ed on load, and n samples normalised by their own
+// mean and standard deviation are bounded by sqrt(n - 1) (Samuelson), LeakyReLU only shrinks; a bound that loose (~100x the real
+// maximum) moves the absolute error floor of the low term to B 2^-40 = 1e-9 of a unit-scale activation - far below an fp32 ulp.
+template <int CIN, int K0, int K1, int K2, int MODE, bool F16 = false>
 __global__ __launch_bounds__(256, 2) void dynconv_cl_kernel(const float* __restrict__ x, const float* __restrict__ affine,
                                                             const uint4* __restrict__ wsp, const float* __restrict__ bias,
                                                             DynEpi ep, int N, int H, int W, int tiles_x, int tiles_y) {
@@ -276,12 +281,17 @@ __global__ __launch_bounds__(256, 2) void dynconv_cl_kernel(const float* __restr
         a = fmaf(t.w, al[3], be[3]); t.w = a > 0.f ? a : a * sl[3];
       }
       uint32_t h0, m0, l0, h1, m1, l1;
-      split2(t.x, t.y, h0, m0, l0);
-      split2(t.z, t.w, h1, m1, l1);
       unsigned char* d = dst0 + pos * POSB;
+      if (F16) {
+        split2_f16(t.x, t.y, ep.xs, h0, m0);
+        split2_f16(t.z, t.w, ep.xs, h1, m1);
+      } else {
+        split2(t.x, t.y, h0, m0, l0);
+        split2(t.z, t.w, h1, m1, l1);
+        *reinterpret_cast<uint2*>(d + 32) = make_uint2(l0, l1);
+      }
       *reinterpret_cast<uint2*>(d) = make_uint2(h0, h1);
       *reinterpret_cast<uint2*>(d + 16) = make_uint2(m0, m1);
-      *reinterpret_cast<uint2*>(d + 32) = make_uint2(l0, l1);
     }
   }
   __syncthreads();
@@ -319,7 +329,7 @@ __global__ __launch_bounds__(256, 2) void dynconv_cl_kernel(const float* __restr
           const uint4* p = wb + (size_t)((t * NBLK + nb) * 3) * 64;
           wh[nb].u = p[0];
           wm[nb].u = p[64];
-          wlo[nb].u = p[128];
+          if (!F16) wlo[nb].u = p[128];
         }
         BV ah[4], am[4], al[4];
 #pragma unroll
@@ -327,9 +337,21 @@ __global__ __launch_bounds__(256, 2) void dynconv_cl_kernel(const float* __restr
           const unsigned char* a = ap + ((q >> 1) * IXP + (q & 1) * 16) * POSB;
           ah[q].u = *reinterpret_cast<const uint4*>(a);
           am[q].u = *reinterpret_cast<const uint4*>(a + 16);
-          al[q].u = *reinterpret_cast<const uint4*>(a + 32);
+          if (!F16) al[q].u = *reinterpret_cast<const uint4*>(a + 32);
         }
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (F16) {
+#pragma unroll
+          for (int nb = 0; nb < NBLK; ++nb) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) SF16_MFMA(acc[b][nb][q], am[q], wh[nb]);   // lo x hi
+#pragma unroll
+            for (int q = 0; q < 4; ++q) SF16_MFMA(acc[b][nb][q], ah[q], wm[nb]);   // hi x lo
+#pragma unroll
+            for (int q = 0; q < 4; ++q) SF16_MFMA(acc[b][nb][q], ah[q], wh[nb]);   // hi x hi
+          }
+          continue;
+        }
 #pragma unroll
         for (int nb = 0; nb < NBLK; ++nb) {
 #pragma unroll
@@ -350,6 +372,14 @@ __global__ __launch_bounds__(256, 2) void dynconv_cl_kernel(const float* __restr
     }
   }
 
+  if constexpr (F16) {         // back to the convolution's scale (exact: powers of two)
+#pragma unroll
+    for (int b = 0; b < NBR; ++b)
+#pragma unroll
+      for (int nb = 0; nb < NBLK; ++nb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[b][nb][q] = acc[b][nb][q] * ep.omul;
+  }
   if constexpr (MODE == 2) {
     // visibility-CNN layer: ReLU(conv + folded BatchNorm); with a head (ep.w1 = head weights [16], ep.b1 = head bias [1]) the 1x1
     // convolution 16 -> 1 + sigmoid follows and the result is one value per pixel, ep.out [N][H][W]; else ep.out [N][H][W][16]
@@ -538,12 +568,12 @@ __global__ __launch_bounds__(256, 2) void conv00_cl_kernel(const float* __restri
     dyn_epilogue<C>(acc, lds, bias, ep, first + i, H, W, ox0, oy0, wave, m, g, tid, ty_i * tiles_x + tx_i, tiles_x * tiles_y);
 }
 
-template <int CIN, int K0, int K1, int K2, int MODE = 1>
+template <int CIN, int K0, int K1, int K2, int MODE = 1, bool F16 = false>
 int launch_dynconv_cl(const float* x, const float* aff, const void* wsp, const float* bias, const DynEpi& ep, int N, int H, int W,
                       hipStream_t st) {
   using C = DCfg<CIN, K0, K1, K2, MODE>;
   const int tx = cds_ceil_div(W, TX), ty = cds_ceil_div(H, TY);
-  auto kern = dynconv_cl_kernel<CIN, K0, K1, K2, MODE>;
+  auto kern = dynconv_cl_kernel<CIN, K0, K1, K2, MODE, F16>;
   if (C::LDSB > 64 * 1024) {
     static std::atomic<unsigned long long> lds_ok{0};   // per instantiation
     if (int e = cds_allow_lds(reinterpret_cast<const void*>(kern), C::LDSB, lds_ok)) return e;
@@ -1028,7 +1058,7 @@ extern "C" int cds_dynconv_cl_f32(const float* x, const float* in_affine, const 
   if (!x || !weight_split || !w1 || !b1 || !w2 || !epipoles || !out || !norm_curv || !partial || !ksizes || N < 1 ||
       N > CDS_MAX_IMAGES || H < 1 || W < 1 || nb < 2 || nb > 3)
     return CDS_EINVAL;
-  DynEpi ep;
+  DynEpi ep{};
   ep.w1 = w1; ep.b1 = b1; ep.w2 = w2; ep.out = out; ep.norm_curv = norm_curv; ep.partial = partial; ep.temperature = temperature;
   ep.epi = epipoles;
   hipStream_t st = (hipStream_t)stream;
@@ -1038,6 +1068,34 @@ extern "C" int cds_dynconv_cl_f32(const float* x, const float* in_affine, const 
   if (C == 16 && k0 == 3 && k1 == 5 && k2 == 0) return launch_dynconv_cl<16, 3, 5, 0>(x, in_affine, weight_split, bias, ep, N, H, W, st);
   if (C == 16 && k0 == 1 && k1 == 3 && k2 == 0) return launch_dynconv_cl<16, 1, 3, 0>(x, in_affine, weight_split, bias, ep, N, H, W, st);
   if (C == 32 && k0 == 1 && k1 == 3 && k2 == 0) return launch_dynconv_cl<32, 1, 3, 0>(x, in_affine, weight_split, bias, ep, N, H, W, st);
+  return CDS_EINVAL;
+}
+
+// The same DynamicConv in SPLIT-F16 arithmetic (sbf_common.hpp; half the matrix-pipe work, fp32-class error).  weight_split: the same
+// layout with fp16 terms (hi, lo, unused) of weight x w_scale (ops.split_pack_dynconv(..., f16=True)), w_inv_scale = 1 / w_scale;
+// x_bound >= max |input after its affine + LeakyReLU| (a host number: sqrt(H W) bounds any InstanceNorm-ed map; 1 a tanh output).
+extern "C" int cds_dynconv_cl_sf16_f32(const float* x, const float* in_affine, const void* weight_split, const float* bias,
+                                       const float* w1, const float* b1, const float* w2, const float* epipoles, float temperature,
+                                       float* out, float* norm_curv, double* partial, int N, int C, int H, int W, const int* ksizes,
+                                       int nb, float x_bound, float w_inv_scale, void* stream) {
+  if (!x || !weight_split || !w1 || !b1 || !w2 || !epipoles || !out || !norm_curv || !partial || !ksizes || N < 1 ||
+      N > CDS_MAX_IMAGES || H < 1 || W < 1 || nb < 2 || nb > 3 || !(x_bound > 0.f) || !(w_inv_scale > 0.f))
+    return CDS_EINVAL;
+  DynEpi ep{};
+  ep.w1 = w1; ep.b1 = b1; ep.w2 = w2; ep.out = out; ep.norm_curv = norm_curv; ep.partial = partial; ep.temperature = temperature;
+  ep.epi = epipoles;
+  int e = 0;
+  (void)frexpf(x_bound, &e);                           // x_bound = m 2^e, m in [0.5, 1): x_bound xs <= 2^15
+  e = e > 100 ? 100 : (e < -100 ? -100 : e);
+  ep.xs = ldexpf(1.0f, 15 - e);
+  ep.omul = w_inv_scale / ep.xs;
+  hipStream_t st = (hipStream_t)stream;
+  const int k0 = ksizes[0], k1 = ksizes[1], k2 = nb == 3 ? ksizes[2] : 0;
+  if (C == 8 && k0 == 3 && k1 == 5 && k2 == 7) return launch_dynconv_cl<8, 3, 5, 7, 1, true>(x, in_affine, weight_split, bias, ep, N, H, W, st);
+  if (C == 8 && k0 == 1 && k1 == 3 && k2 == 0) return launch_dynconv_cl<8, 1, 3, 0, 1, true>(x, in_affine, weight_split, bias, ep, N, H, W, st);
+  if (C == 16 && k0 == 3 && k1 == 5 && k2 == 0) return launch_dynconv_cl<16, 3, 5, 0, 1, true>(x, in_affine, weight_split, bias, ep, N, H, W, st);
+  if (C == 16 && k0 == 1 && k1 == 3 && k2 == 0) return launch_dynconv_cl<16, 1, 3, 0, 1, true>(x, in_affine, weight_split, bias, ep, N, H, W, st);
+  if (C == 32 && k0 == 1 && k1 == 3 && k2 == 0) return launch_dynconv_cl<32, 1, 3, 0, 1, true>(x, in_affine, weight_split, bias, ep, N, H, W, st);
   return CDS_EINVAL;
 }
 
@@ -1052,7 +1110,7 @@ extern "C" int cds_conv00_cl_f32(const float* x, const void* weight_split, const
   if (!x || !weight_split || !w1 || !b1 || !w2 || !epipoles || !out || !norm_curv || !partial || N < 1 || N > CDS_MAX_IMAGES ||
       n_shared < 1 || n_shared > N || H < 1 || W < 1)
     return CDS_EINVAL;
-  DynEpi ep;
+  DynEpi ep{};
   ep.w1 = w1; ep.b1 = b1; ep.w2 = w2; ep.out = out; ep.norm_curv = norm_curv; ep.partial = partial; ep.temperature = temperature;
   ep.epi = epipoles;
   const int S = N - n_shared + 1;

@@ -495,6 +495,11 @@ class _FeatureRunner:
             if ops.dynconv_sbf_supported(dc.in_c, dc.out_c + 3, dc.size_kernels, 4, fused=USE_FUSED_BLEND) and dc.att_convs[0].weight.is_cuda:
                 out[f"{name}.ws"] = ops.split_pack_dynconv([torch.cat((dc.convs[i].weight.detach(), dc.att_convs[i].weight.detach()), dim=0)
                                                             for i in range(len(dc.size_kernels))])
+                if ops.USE_SPLIT_F16 and (dc.in_c, tuple(dc.size_kernels)) in ops.DYNCONV_CL_SHAPES:
+                    # split-f16 operands of the channels-last kernel (two fp16 terms of w x a power-of-two scale, + 1 / scale)
+                    out[f"{name}.wh"], out[f"{name}.whs"] = ops.split_pack_dynconv(
+                        [torch.cat((dc.convs[i].weight.detach(), dc.att_convs[i].weight.detach()), dim=0) for i in range(len(dc.size_kernels))],
+                        f16=True)
                 if dc.convs[0].bias is not None:
                     out[f"{name}.bs"] = torch.stack([out[f"{name}.b{i}"] for i in range(len(dc.size_kernels))]).contiguous()
             if name == "conv00" and USE_SPLIT_BF16 and ops.USE_CONV2D_SBF and dc.size_kernels == (3, 7, 11) and dc.att_convs[0].weight.is_cuda:
@@ -661,6 +666,11 @@ class _FeatureRunner:
         N = c00.shape[0]
 
         def dyn(name: str, dc: DynamicConv, x: Tensor, epi: Tensor, aff: Optional[Tensor]):
+            if ops.USE_SPLIT_F16 and f"{name}.wh" in p and aff is not None:
+                # split-f16: the input is InstanceNorm-ed on load, so sqrt(h w) bounds it (Samuelson's inequality; LeakyReLU shrinks)
+                return ops.dynconv_cl(x, p[f"{name}.wh"], p.get(f"{name}.bs"), dc.size_kernels, p[f"{name}.m1"], p[f"{name}.mb"],
+                                      p[f"{name}.m2"], epi, T, 0.1, in_affine=aff, x_bound=float(x.shape[1] * x.shape[2]) ** 0.5,
+                                      w_inv_scale=p[f"{name}.whs"])
             return ops.dynconv_cl(x, p[f"{name}.ws"], p.get(f"{name}.bs"), dc.size_kernels, p[f"{name}.m1"], p[f"{name}.mb"],
                                   p[f"{name}.m2"], epi, T, 0.1, in_affine=aff)
 

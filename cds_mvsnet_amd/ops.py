@@ -813,7 +813,7 @@ def dynconv_sbf_supported(Cin: int, co3: int, ksizes, W: int, fused: bool = Fals
             and (nb, nblk) in ((3, 1), (3, 2), (2, 1), (2, 2), (2, 3)))
 
 
-def split_pack_dynconv(ws) -> Tensor:
+def split_pack_dynconv(ws, f16: bool = False):
     """Pack the branch weights of one DynamicConv for cds_dynconv_branches_sbf_f32.  ws: list over kernel sizes of
     [Co3,Cin,k,k] (convs[k] and att_convs[k] concatenated).  int16 [Cin/8][nks][nblk][3][64][8]; within a round branch b
     owns K-steps ks0_b .. ks0_b + ceil(k_b^2 / 4); lane l = 16 g + n multiplies output channel 16 nb + n by tap 4 t + g
@@ -828,7 +828,8 @@ def split_pack_dynconv(ws) -> Tensor:
         taps[:Co3, :, :k * k] = w.detach().float().reshape(Co3, rounds, 8, k * k).permute(0, 1, 3, 2)
         # -> [rd][t][nb][g][n][j]
         parts.append(taps.reshape(nblk, 16, rounds, nks, 4, 8).permute(2, 3, 0, 4, 1, 5).reshape(rounds, nks, nblk, 64, 8))
-    return _split3(torch.cat(parts, dim=1))
+    a = torch.cat(parts, dim=1)
+    return _split2_f16(a) if f16 else _split3(a)      # f16: (tensor, 1 / weight scale) for cds_dynconv_cl_sf16_f32
 
 
 def split_pack_conv00(ws) -> Tensor:
@@ -1053,9 +1054,12 @@ DYNCONV_CL_SHAPES = ((8, (3, 5, 7)), (8, (1, 3)), (16, (3, 5)), (16, (1, 3)), (3
 
 
 def dynconv_cl(x_cl: Tensor, wsplit: Tensor, bias: Optional[Tensor], ksizes, w1: Tensor, b1: Tensor, w2: Tensor, epipoles: Tensor,
-               temperature: float, stats_slope: float = 0.1, in_affine: Optional[Tensor] = None):
+               temperature: float, stats_slope: float = 0.1, in_affine: Optional[Tensor] = None, x_bound: Optional[float] = None,
+               w_inv_scale: float = 1.0):
     """One DynamicConv (Cin == Cout == C) on channels-last activations in one kernel: x_cl [N,H,W,C] (+ its pending affine [N,C,3])
-    -> (out_cl [N,H,W,C] before its InstanceNorm, norm_curv [N,H,W], stats [N,C,2] float64, affine [N,C,3])."""
+    -> (out_cl [N,H,W,C] before its InstanceNorm, norm_curv [N,H,W], stats [N,C,2] float64, affine [N,C,3]).
+    x_bound given: SPLIT-F16 arithmetic (cds_dynconv_cl_sf16_f32): wsplit / w_inv_scale from split_pack_dynconv(..., f16=True), x_bound a
+    number >= max |input after its affine| (sqrt(H W) for an InstanceNorm-ed input)."""
     N, H, W, C = x_cl.shape
     K = len(ksizes)
     if (C, tuple(int(k) for k in ksizes)) not in DYNCONV_CL_SHAPES:
@@ -1077,10 +1081,16 @@ def dynconv_cl(x_cl: Tensor, wsplit: Tensor, bias: Optional[Tensor], ksizes, w1:
     partial = torch.empty((N, lib.cds_dynconv_cl_parts(H, W), C, 2), dtype=torch.float64, device=dev)
     import ctypes
     ks = (ctypes.c_int * K)(*[int(k) for k in ksizes])
-    check(lib.cds_dynconv_cl_f32(_dev(x_cl, "x"), _dev(in_affine, "in_affine") if in_affine is not None else None, wsplit.data_ptr(),
-                                 _dev(bias, "bias") if bias is not None else None, _dev(w1, "w1"), _dev(b1, "b1"), _dev(w2, "w2"),
-                                 _dev(epipoles, "epipoles"), float(temperature), out.data_ptr(), nc.data_ptr(), partial.data_ptr(),
-                                 N, C, H, W, ks, K, _stream(x_cl)), "cds_dynconv_cl_f32")
+    if x_bound is not None:
+        check(lib.cds_dynconv_cl_sf16_f32(_dev(x_cl, "x"), _dev(in_affine, "in_affine") if in_affine is not None else None, wsplit.data_ptr(),
+                                          _dev(bias, "bias") if bias is not None else None, _dev(w1, "w1"), _dev(b1, "b1"), _dev(w2, "w2"),
+                                          _dev(epipoles, "epipoles"), float(temperature), out.data_ptr(), nc.data_ptr(), partial.data_ptr(),
+                                          N, C, H, W, ks, K, float(x_bound), float(w_inv_scale), _stream(x_cl)), "cds_dynconv_cl_sf16_f32")
+    else:
+        check(lib.cds_dynconv_cl_f32(_dev(x_cl, "x"), _dev(in_affine, "in_affine") if in_affine is not None else None, wsplit.data_ptr(),
+                                     _dev(bias, "bias") if bias is not None else None, _dev(w1, "w1"), _dev(b1, "b1"), _dev(w2, "w2"),
+                                     _dev(epipoles, "epipoles"), float(temperature), out.data_ptr(), nc.data_ptr(), partial.data_ptr(),
+                                     N, C, H, W, ks, K, _stream(x_cl)), "cds_dynconv_cl_f32")
     stats, affine = _reduce_records(partial, N, C, H, W, stats_slope)
     return out, nc, stats, affine
 

@@ -422,6 +422,14 @@ int cds_dynconv_cl_parts(int H, int W);
 int cds_dynconv_cl_f32(const float* x, const float* in_affine, const void* weight_split, const float* bias, const float* w1,
                        const float* b1, const float* w2, const float* epipoles, float temperature, float* out,
                        float* norm_curv, double* partial, int N, int C, int H, int W, const int* ksizes, int nb, void* stream);
+/* The same DynamicConv in SPLIT-F16 arithmetic (two fp16 terms of value x power-of-two scale, three products per K-step; see
+ * cds_conv3d_sf16_f32): weight_split from ops.split_pack_dynconv(..., f16=True), w_inv_scale = 1 / its weight scale; x_bound = a HOST
+ * number >= max |input after its affine + LeakyReLU| (sqrt(H W) bounds any InstanceNorm-ed map: Samuelson's inequality). */
+int cds_dynconv_cl_sf16_f32(const float* x, const float* in_affine, const void* weight_split, const float* bias, const float* w1,
+                            const float* b1, const float* w2, const float* epipoles, float temperature, float* out, float* norm_curv,
+                            double* partial, int N, int C, int H, int W, const int* ksizes, int nb, float x_bound, float w_inv_scale,
+                            void* stream);
+
 /* conv00 of FeatureNet (module.py:209: DynamicConv 3 -> 8, kernel sizes 3 / 7 / 11) in ONE kernel on the matrix cores: x [S][3][H][W]
  * planar images in S = N - n_shared + 1 slots (slot 0 is shown by the first n_shared output images, each with its own epipole),
  * weight_split = ops.split_pack_conv00, bias [3][11] or NULL -> out [N][H][W][8], norm_curv [N][H][W],

@@ -67,6 +67,27 @@ for name, c, ks, H, W in (("conv01", 8, (3, 5, 7), 592, 800), ("conv10", 16, (3,
                           ("out3", 8, (1, 3), 592, 800)):
     aggr["cl " + name] = dyn_setup(c, ks, N, H, W, True)
     aggr["planar " + name] = dyn_setup(c, ks, N, H, W, False)
+# round 6: the split-f16 kernels (v_mfma_f32_16x16x32_f16, same operand roles as their split-bf16 forms) as aggressors
+def dyn_f16_setup(c, ks, N, H, W):
+    K, co3 = len(ks), c + 3
+    xcl = torch.randn(N, H, W, c, generator=g).to(dev)
+    aff = torch.stack((0.5 + torch.rand(N, c, generator=g), 0.3 * torch.randn(N, c, generator=g), torch.full((N, c), 0.1)), -1).to(dev).contiguous()
+    wh, winv = ops.split_pack_dynconv([(torch.randn(co3, c, k, k, generator=g) / (c * k * k) ** 0.5).to(dev) for k in ks], f16=True)
+    w1, b1, w2 = torch.randn(4, K, generator=g).to(dev), torch.randn(4, generator=g).to(dev), torch.randn(K, 4, generator=g).to(dev)
+    epi = torch.tensor([[W * 0.3 + 5.0 * n, -H * 1.7 - n] for n in range(N)], dtype=torch.float32)
+    return lambda: ops.dynconv_cl(xcl, wh, None, ks, w1, b1, w2, epi, 0.01, 0.1, in_affine=aff, x_bound=(H * W) ** 0.5, w_inv_scale=winv)
+for name, c, ks, H, W in (("conv01", 8, (3, 5, 7), 592, 800), ("conv10", 16, (3, 5), 592, 800), ("conv20", 32, (1, 3), 296, 400)):
+    aggr["f16 cl " + name] = dyn_f16_setup(c, ks, N, H, W)
+def conv3d_f16_setup(cin, cout, code, D, H, W):
+    x = torch.randn(D, H, W, cin, generator=g).to(dev)
+    w = (torch.randn(cout, cin, 3, 3, 3, generator=g) / (27 * cin) ** 0.5).to(dev)
+    wh, winv = (ops.split_pack_conv3d_pair if code == ops.SBF_PAIR else ops.split_pack_conv3d)(w, f16=True)
+    b = torch.randn(cout, generator=g).to(dev)
+    bound = x.abs().amax().reshape(1)
+    return lambda: ops.conv3d_sbf(x, wh, b, cout, stride=code, in_bound=bound, w_inv_scale=winv)
+aggr["f16 conv3d 8->8 pair"] = conv3d_f16_setup(8, 8, ops.SBF_PAIR, 48, 296, 400)
+aggr["f16 conv3d 16->16"] = conv3d_f16_setup(16, 16, 1, 24, 148, 200)
+aggr["f16 conv3d 32->32"] = conv3d_f16_setup(32, 32, 1, 24, 148, 200)
 xa, xb = torch.randn(N, 296, 400, 32, generator=g).to(dev), torch.randn(N, 592, 800, 16, generator=g).to(dev)
 wt = torch.randn(48, 16, generator=g).to(dev)
 aggr["cl fpn inner1"] = lambda: ops.conv2d_fpn_cl(xa, xb, wt, 16, None, None, 0.1)
