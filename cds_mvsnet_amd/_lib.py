@@ -77,6 +77,7 @@ SIGNATURES = {
     "cds_dynconv_cl_f32": [P, P, P, P, P, P, P, P, F, P, P, P, I, I, I, I, P, I, P],
     "cds_dynconv_cl_sf16_f32": [P, P, P, P, P, P, P, P, F, P, P, P, I, I, I, I, P, I, F, F, P],
     "cds_conv00_cl_f32": [P, P, P, P, P, P, P, F, P, P, P, I, I, I, I, P],
+    "cds_conv00_cl_sf16_f32": [P, P, P, P, P, P, P, F, P, P, P, I, I, I, I, P, F, P],
     "cds_blend_cl_parts": [I, I],
     "cds_dynconv_blend_cl_f32": [P, P, P, P, P, F, P, P, P, I, I, I, I, I, I, P],
     "cds_conv2d_k3s2_cl_f32": [P, P, P, P, I, I, I, I, I, P],

@@ -449,10 +449,12 @@ struct C00 {
   static constexpr int nks(int k) { return (k * pairs(k) + 3) / 4; }
 };
 
+template <bool F16>      // split-f16 arithmetic: the images' scale from a device bound (in_bound >= max |x|), weights x w_scale
 __global__ __launch_bounds__(256, 2) void conv00_cl_kernel(const float* __restrict__ x, const uint4* __restrict__ wsp,
                                                            const float* __restrict__ bias, DynEpi ep, int S, int n_shared, int H, int W,
-                                                           int tiles_x, int tiles_y) {
+                                                           int tiles_x, int tiles_y, const float* __restrict__ in_bound, float w_inv) {
   using C = C00;
+  const float xs = F16 ? sf16_scale(in_bound[0]) : 1.0f;
   constexpr int NBR = C::NBR, IXP = C::IXP, R = C::R, HL = C::HL;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   int lin = cds_xcd_remap(blockIdx.x, tiles_x * tiles_y * S);
@@ -492,8 +494,13 @@ __global__ __launch_bounds__(256, 2) void conv00_cl_kernel(const float* __restri
       const float c0 = p == 0 ? v[0].x : p == 1 ? v[0].y : p == 2 ? v[0].z : v[0].w;
       const float c1 = p == 0 ? v[1].x : p == 1 ? v[1].y : p == 2 ? v[1].z : v[1].w;
       const float c2 = p == 0 ? v[2].x : p == 1 ? v[2].y : p == 2 ? v[2].z : v[2].w;
-      split2(c0, c1, h[p][0], md[p][0], lo[p][0]);
-      split2(c2, 0.f, h[p][1], md[p][1], lo[p][1]);
+      if (F16) {
+        split2_f16(c0, c1, xs, h[p][0], md[p][0]);
+        split2_f16(c2, 0.f, xs, h[p][1], md[p][1]);
+      } else {
+        split2(c0, c1, h[p][0], md[p][0], lo[p][0]);
+        split2(c2, 0.f, h[p][1], md[p][1], lo[p][1]);
+      }
     }
     unsigned char* d = lds + (row * IXP + 4 * q4) * 8;
     uint4* d4;
@@ -503,9 +510,11 @@ __global__ __launch_bounds__(256, 2) void conv00_cl_kernel(const float* __restri
     d4 = reinterpret_cast<uint4*>(d + C::PLANE);
     d4[0] = make_uint4(md[0][0], md[0][1], md[1][0], md[1][1]);
     d4[1] = make_uint4(md[2][0], md[2][1], md[3][0], md[3][1]);
-    d4 = reinterpret_cast<uint4*>(d + 2 * C::PLANE);
-    d4[0] = make_uint4(lo[0][0], lo[0][1], lo[1][0], lo[1][1]);
-    d4[1] = make_uint4(lo[2][0], lo[2][1], lo[3][0], lo[3][1]);
+    if (!F16) {
+      d4 = reinterpret_cast<uint4*>(d + 2 * C::PLANE);
+      d4[0] = make_uint4(lo[0][0], lo[0][1], lo[1][0], lo[1][1]);
+      d4[1] = make_uint4(lo[2][0], lo[2][1], lo[3][0], lo[3][1]);
+    }
   }
   __syncthreads();
 
@@ -533,7 +542,7 @@ __global__ __launch_bounds__(256, 2) void conv00_cl_kernel(const float* __restri
         const uint4* p = wb + (size_t)(t * 3) * 64;
         wh.u = p[0];
         wm.u = p[64];
-        wlo.u = p[128];
+        if (!F16) wlo.u = p[128];
       }
       BV ah[4], am[4], al[4];
 #pragma unroll
@@ -541,12 +550,23 @@ __global__ __launch_bounds__(256, 2) void conv00_cl_kernel(const float* __restri
         const unsigned char* a = ap + ((q >> 1) * IXP + (q & 1) * 16) * 8;
         const uint2 h0 = *reinterpret_cast<const uint2*>(a), h1 = *reinterpret_cast<const uint2*>(a + 8);
         const uint2 m0 = *reinterpret_cast<const uint2*>(a + C::PLANE), m1 = *reinterpret_cast<const uint2*>(a + C::PLANE + 8);
-        const uint2 l0 = *reinterpret_cast<const uint2*>(a + 2 * C::PLANE), l1 = *reinterpret_cast<const uint2*>(a + 2 * C::PLANE + 8);
         ah[q].u = make_uint4(h0.x, h0.y, h1.x, h1.y);
         am[q].u = make_uint4(m0.x, m0.y, m1.x, m1.y);
-        al[q].u = make_uint4(l0.x, l0.y, l1.x, l1.y);
+        if (!F16) {
+          const uint2 l0 = *reinterpret_cast<const uint2*>(a + 2 * C::PLANE), l1 = *reinterpret_cast<const uint2*>(a + 2 * C::PLANE + 8);
+          al[q].u = make_uint4(l0.x, l0.y, l1.x, l1.y);
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
+      if constexpr (F16) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) SF16_MFMA(acc[b][0][q], am[q], wh);   // lo x hi
+#pragma unroll
+        for (int q = 0; q < 4; ++q) SF16_MFMA(acc[b][0][q], ah[q], wm);   // hi x lo
+#pragma unroll
+        for (int q = 0; q < 4; ++q) SF16_MFMA(acc[b][0][q], ah[q], wh);   // hi x hi
+        continue;
+      }
 #pragma unroll
       for (int q = 0; q < 4; ++q) SBF_MFMA(acc[b][0][q], al[q], wh);    // order 2^-16 terms first
 #pragma unroll
@@ -561,6 +581,13 @@ __global__ __launch_bounds__(256, 2) void conv00_cl_kernel(const float* __restri
       for (int q = 0; q < 4; ++q) SBF_MFMA(acc[b][0][q], ah[q], wh);    // leading term
     }
     ks0 += nks;
+  }
+  if constexpr (F16) {
+    const float omul = w_inv / xs;                              // exact: powers of two
+#pragma unroll
+    for (int b = 0; b < NBR; ++b)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[b][0][q] = acc[b][0][q] * omul;
   }
   // output images of this slot: the n_shared reference copies for slot 0, one image otherwise
   const int first = slot == 0 ? 0 : slot + n_shared - 1, count = slot == 0 ? n_shared : 1;
@@ -1104,9 +1131,9 @@ extern "C" int cds_dynconv_cl_sf16_f32(const float* x, const float* in_affine, c
 // FeatureNet batch, each with its own epipole), slot s > 0 by image n_shared - 1 + s.  weight_split = ops.split_pack_conv00, bias
 // [3][11] or NULL; w1 [4][3], b1 [4], w2 [3][4] the attention MLP; epipoles [N][2] -> out [N][H][W][8], norm_curv [N][H][W],
 // partial [N][cds_dynconv_cl_parts(H, W)][8][2] doubles.
-extern "C" int cds_conv00_cl_f32(const float* x, const void* weight_split, const float* bias, const float* w1, const float* b1,
-                                 const float* w2, const float* epipoles, float temperature, float* out, float* norm_curv,
-                                 double* partial, int N, int n_shared, int H, int W, void* stream) {
+static int conv00_entry(const float* x, const void* weight_split, const float* bias, const float* w1, const float* b1, const float* w2,
+                        const float* epipoles, float temperature, float* out, float* norm_curv, double* partial, int N, int n_shared,
+                        int H, int W, const float* in_bound, float w_inv_scale, void* stream) {
   if (!x || !weight_split || !w1 || !b1 || !w2 || !epipoles || !out || !norm_curv || !partial || N < 1 || N > CDS_MAX_IMAGES ||
       n_shared < 1 || n_shared > N || H < 1 || W < 1)
     return CDS_EINVAL;
@@ -1115,9 +1142,31 @@ extern "C" int cds_conv00_cl_f32(const float* x, const void* weight_split, const
   ep.epi = epipoles;
   const int S = N - n_shared + 1;
   const int tx = cds_ceil_div(W, TX), ty = cds_ceil_div(H, TY);
-  hipLaunchKernelGGL(conv00_cl_kernel, dim3(tx * ty * S), dim3(256), (size_t)C00::LDSB, (hipStream_t)stream, x,
-                     reinterpret_cast<const uint4*>(weight_split), bias, ep, S, n_shared, H, W, tx, ty);
+  if (in_bound)
+    hipLaunchKernelGGL(conv00_cl_kernel<true>, dim3(tx * ty * S), dim3(256), (size_t)C00::LDSB, (hipStream_t)stream, x,
+                       reinterpret_cast<const uint4*>(weight_split), bias, ep, S, n_shared, H, W, tx, ty, in_bound, w_inv_scale);
+  else
+    hipLaunchKernelGGL(conv00_cl_kernel<false>, dim3(tx * ty * S), dim3(256), (size_t)C00::LDSB, (hipStream_t)stream, x,
+                       reinterpret_cast<const uint4*>(weight_split), bias, ep, S, n_shared, H, W, tx, ty, nullptr, 1.0f);
   return cds_launch_status();
+}
+
+extern "C" int cds_conv00_cl_f32(const float* x, const void* weight_split, const float* bias, const float* w1, const float* b1,
+                                 const float* w2, const float* epipoles, float temperature, float* out, float* norm_curv,
+                                 double* partial, int N, int n_shared, int H, int W, void* stream) {
+  return conv00_entry(x, weight_split, bias, w1, b1, w2, epipoles, temperature, out, norm_curv, partial, N, n_shared, H, W, nullptr, 1.0f,
+                      stream);
+}
+
+// conv00 in SPLIT-F16 arithmetic: weight_split from ops.split_pack_conv00(..., f16=True), w_inv_scale = 1 / its weight scale; in_bound: a
+// DEVICE scalar >= max |x| (the images: e.g. their amax; it fixes their scale).
+extern "C" int cds_conv00_cl_sf16_f32(const float* x, const void* weight_split, const float* bias, const float* w1, const float* b1,
+                                      const float* w2, const float* epipoles, float temperature, float* out, float* norm_curv,
+                                      double* partial, int N, int n_shared, int H, int W, const float* in_bound, float w_inv_scale,
+                                      void* stream) {
+  if (!in_bound || !(w_inv_scale > 0.f)) return CDS_EINVAL;
+  return conv00_entry(x, weight_split, bias, w1, b1, w2, epipoles, temperature, out, norm_curv, partial, N, n_shared, H, W, in_bound,
+                      w_inv_scale, stream);
 }
 
 extern "C" int cds_blend_cl_parts(int H, int W) { return 4 * cds_ceil_div(H * W, 256 * BCL_PXT); }

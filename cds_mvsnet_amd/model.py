@@ -506,6 +506,9 @@ class _FeatureRunner:
                 # conv00 on the matrix cores (csrc/feat_cl.hip: tap-pair K-steps for the 3-channel input)
                 out[f"{name}.ws00"] = ops.split_pack_conv00([torch.cat((dc.convs[i].weight.detach(), dc.att_convs[i].weight.detach()), dim=0)
                                                              for i in range(3)])
+                if ops.USE_SPLIT_F16:
+                    out[f"{name}.wh00"], out[f"{name}.whs00"] = ops.split_pack_conv00(
+                        [torch.cat((dc.convs[i].weight.detach(), dc.att_convs[i].weight.detach()), dim=0) for i in range(3)], f16=True)
                 if dc.convs[0].bias is not None:
                     out[f"{name}.bs"] = torch.stack([out[f"{name}.b{i}"] for i in range(3)]).contiguous()
             scale, shift = _bn_fold(dc.att_weights[1])
@@ -651,6 +654,11 @@ class _FeatureRunner:
         dc = net.conv00.conv
         xs = imgs[n_shared - 1:] if n_shared > 1 else imgs
         if "conv00.ws00" in p and USE_CONV00_MFMA:
+            if ops.USE_SPLIT_F16 and "conv00.wh00" in p:      # split-f16: the images' scale from their largest magnitude (one small reduction)
+                xs = xs.contiguous()
+                c00, n00, _, a00 = ops.conv00_cl(xs, p["conv00.wh00"], p.get("conv00.bs"), p["conv00.m1"], p["conv00.mb"], p["conv00.m2"],
+                                                 e0, T, n_shared, 0.1, in_bound=xs.abs().amax().reshape(1), w_inv_scale=p["conv00.whs00"])
+                return self._after_conv00(p, c00, n00, a00, e0, e1, e2, T, n_chw, on_stage1)
             c00, n00, _, a00 = ops.conv00_cl(xs.contiguous(), p["conv00.ws00"], p.get("conv00.bs"), p["conv00.m1"], p["conv00.mb"],
                                              p["conv00.m2"], e0, T, n_shared, 0.1)
             return self._after_conv00(p, c00, n00, a00, e0, e1, e2, T, n_chw, on_stage1)

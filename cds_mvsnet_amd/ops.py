@@ -832,7 +832,7 @@ def split_pack_dynconv(ws, f16: bool = False):
     return _split2_f16(a) if f16 else _split3(a)      # f16: (tensor, 1 / weight scale) for cds_dynconv_cl_sf16_f32
 
 
-def split_pack_conv00(ws) -> Tensor:
+def split_pack_conv00(ws, f16: bool = False):
     """Pack the branch weights of conv00 (DynamicConv 3 -> 8: ws = [Co3 = 11, 3, k, k] for k = 3, 7, 11: convs[k] and att_convs[k]
     concatenated) for cds_conv00_cl_f32: a K-step is 4 x-adjacent tap PAIRS x (2 taps x 4 channels, the 4th zero).  int16
     [sum_k ceil(k ceil(k/2) / 4) = 26][3][64][8]; lane l = 16 g + n multiplies output channel n by the pair 4 t + g = (ky, kxp), values
@@ -849,14 +849,17 @@ def split_pack_conv00(ws) -> Tensor:
         t = torch.zeros((16, nks * 4, 2, 4), dtype=torch.float32, device=w.device)                  # [col][pair][tap of the pair][ch]
         t[:co3, :npairs, :, :3] = wp.reshape(co3, 3, k, np_, 2).permute(0, 2, 3, 4, 1).reshape(co3, npairs, 2, 3)
         parts.append(t.reshape(16, nks, 4, 8).permute(1, 2, 0, 3).reshape(nks, 64, 8))              # [t][16 g + n][8]
-    return _split3(torch.cat(parts, dim=0))
+    a = torch.cat(parts, dim=0)
+    return _split2_f16(a) if f16 else _split3(a)      # f16: (tensor, 1 / weight scale) for cds_conv00_cl_sf16_f32
 
 
 def conv00_cl(imgs: Tensor, wsplit: Tensor, bias: Optional[Tensor], w1: Tensor, b1: Tensor, w2: Tensor, epipoles: Tensor,
-              temperature: float, n_shared: int = 1, stats_slope: float = 0.1):
+              temperature: float, n_shared: int = 1, stats_slope: float = 0.1, in_bound: Optional[Tensor] = None,
+              w_inv_scale: float = 1.0):
     """conv00 of FeatureNet in one kernel on the matrix cores.  imgs [S,3,H,W] planar (S = N - n_shared + 1 slots: slot 0 is shown by
     the first n_shared of the N output images), epipoles [N,2] (device) -> (out_cl [N,H,W,8], norm_curv [N,H,W], stats [N,8,2] float64,
-    affine [N,8,3])."""
+    affine [N,8,3]).  in_bound (1-element device tensor >= max |imgs|) given: split-f16 arithmetic, wsplit / w_inv_scale from
+    split_pack_conv00(..., f16=True)."""
     S, C, H, W = imgs.shape
     N = S + n_shared - 1
     if C != 3 or tuple(epipoles.shape) != (N, 2) or n_shared < 1:
@@ -871,9 +874,15 @@ def conv00_cl(imgs: Tensor, wsplit: Tensor, bias: Optional[Tensor], w1: Tensor, 
     out = torch.empty((N, H, W, 8), dtype=torch.float32, device=dev)
     nc = torch.empty((N, H, W), dtype=torch.float32, device=dev)
     partial = torch.empty((N, lib.cds_dynconv_cl_parts(H, W), 8, 2), dtype=torch.float64, device=dev)
-    check(lib.cds_conv00_cl_f32(_dev(imgs, "imgs"), wsplit.data_ptr(), _dev(bias, "bias") if bias is not None else None, _dev(w1, "w1"),
-                                _dev(b1, "b1"), _dev(w2, "w2"), _dev(epipoles, "epipoles"), float(temperature), out.data_ptr(),
-                                nc.data_ptr(), partial.data_ptr(), N, n_shared, H, W, _stream(imgs)), "cds_conv00_cl_f32")
+    if in_bound is not None:
+        check(lib.cds_conv00_cl_sf16_f32(_dev(imgs, "imgs"), wsplit.data_ptr(), _dev(bias, "bias") if bias is not None else None,
+                                         _dev(w1, "w1"), _dev(b1, "b1"), _dev(w2, "w2"), _dev(epipoles, "epipoles"), float(temperature),
+                                         out.data_ptr(), nc.data_ptr(), partial.data_ptr(), N, n_shared, H, W, _dev(in_bound, "in_bound"),
+                                         float(w_inv_scale), _stream(imgs)), "cds_conv00_cl_sf16_f32")
+    else:
+        check(lib.cds_conv00_cl_f32(_dev(imgs, "imgs"), wsplit.data_ptr(), _dev(bias, "bias") if bias is not None else None, _dev(w1, "w1"),
+                                    _dev(b1, "b1"), _dev(w2, "w2"), _dev(epipoles, "epipoles"), float(temperature), out.data_ptr(),
+                                    nc.data_ptr(), partial.data_ptr(), N, n_shared, H, W, _stream(imgs)), "cds_conv00_cl_f32")
     stats, affine = _reduce_records(partial, N, 8, H, W, stats_slope)
     return out, nc, stats, affine
 

@@ -437,6 +437,12 @@ int cds_dynconv_cl_sf16_f32(const float* x, const float* in_affine, const void* 
 int cds_conv00_cl_f32(const float* x, const void* weight_split, const float* bias, const float* w1, const float* b1, const float* w2,
                       const float* epipoles, float temperature, float* out, float* norm_curv, double* partial, int N, int n_shared,
                       int H, int W, void* stream);
+/* conv00 in SPLIT-F16 arithmetic (see cds_conv3d_sf16_f32): weight_split from ops.split_pack_conv00(..., f16=True), w_inv_scale = 1 / its
+ * weight scale, in_bound a DEVICE scalar >= max |x| (e.g. the images' amax). */
+int cds_conv00_cl_sf16_f32(const float* x, const void* weight_split, const float* bias, const float* w1, const float* b1, const float* w2,
+                           const float* epipoles, float temperature, float* out, float* norm_curv, double* partial, int N, int n_shared,
+                           int H, int W, const float* in_bound, float w_inv_scale, void* stream);
+
 int cds_blend_cl_parts(int H, int W);
 int cds_dynconv_blend_cl_f32(const float* branches, const float* w1, const float* b1, const float* w2, const float* epipoles,
                              float temperature, float* out, float* norm_curv, double* partial, int N, int K, int Cout, int H, int W,
