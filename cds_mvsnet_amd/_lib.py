@@ -52,6 +52,8 @@ SIGNATURES = {
     "cds_conv3d_sbf_f32": [P, P, P, P, P, I, I, I, I, I, I, I, P],
     "cds_conv3d_sf16_f32": [P, P, P, P, I, I, I, I, I, I, I, P, F, P, P],
     "cds_deconv3d_sbf_f32": [P, P, P, P, P, I, I, I, I, I, I, I, P],
+    "cds_deconv3d_sf16_f32": [P, P, P, P, P, I, I, I, I, I, I, P, F, P, P],
+    "cds_deconv3d_zm_sf16_f32": [P, P, P, P, P, I, I, I, I, I, I, P, F, P, P],
     "cds_deconv_prob_zm_f32": [P, P, P, P, P, P, I, I, I, P],
     "cds_deconv3d_zm_f32": [P, P, P, P, P, I, I, I, I, I, I, P],
     "cds_deconv3d_k3s2_f32": [P, P, P, P, P, I, I, I, I, I, I, P],

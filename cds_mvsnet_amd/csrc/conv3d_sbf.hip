@@ -432,7 +432,7 @@ struct DCfg {
 #ifndef CDS_DECONV_SBF_MINW
 #define CDS_DECONV_SBF_MINW 2   // minimum waves per SIMD of the Cout = 8 (memory-bound) variant: A/B build knob
 #endif
-template <bool MERGE, int MB>
+template <bool MERGE, int MB, bool F16 = false>     // F16: split-f16 arithmetic (sbf_common.hpp), scales from device bounds
 #ifndef CDS_DECONV_NM_MINW
 #define CDS_DECONV_NM_MINW 2   // waves per SIMD of the Cout = 16 / 32 variants (A/B build knob)
 #endif
@@ -440,9 +440,13 @@ __global__ __launch_bounds__(256, (MERGE ? CDS_DECONV_SBF_MINW : (MB == 1 ? CDS_
                                                               const float* __restrict__ bias, const float* __restrict__ skip,
                                                               float* __restrict__ out, int Cin, int Cout, int D, int H, int W,
                                                               int act, int out_planar, int tiles_x, int tiles_y, int ntiles,
-                                                              int tpw) {
+                                                              int tpw, const float* __restrict__ in_bound, float w_inv,
+                                                              float* __restrict__ out_bound) {
   using Cfg = DCfg;
   using Tab = DTab<MERGE>;
+  const float xs = F16 ? sf16_scale(in_bound[0]) : 1.0f;
+  const float out_mul = F16 ? w_inv / xs : 1.0f;
+  float amax = 0.f;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -495,7 +499,10 @@ __global__ __launch_bounds__(256, (MERGE ? CDS_DECONV_SBF_MINW : (MB == 1 ? CDS_
   auto deposit = [&]() {
 #pragma unroll
     for (int h = 0; h < PPT; ++h)
-      if (s_rel[h] >= 0) split_store8(lds + s_dst[h], va[h], vb[h]);
+      if (s_rel[h] >= 0) {
+        if (F16) split_store8_f16(lds + s_dst[h], va[h], vb[h], xs);
+        else split_store8(lds + s_dst[h], va[h], vb[h]);
+      }
   };
 
   f32x4 acc[Tab::NCLS][MB][Cfg::NT];
@@ -545,7 +552,7 @@ __global__ __launch_bounds__(256, (MERGE ? CDS_DECONV_SBF_MINW : (MB == 1 ? CDS_
           const uint4* p = wr + (size_t)((ks * MB + mb) * 3) * 64;
           wa[buf][mb][0].u = p[0];
           wa[buf][mb][1].u = p[64];
-          wa[buf][mb][2].u = p[128];
+          if (!F16) wa[buf][mb][2].u = p[128];
         }
       };
       auto load_b = [&](int buf, int ks) {
@@ -555,7 +562,7 @@ __global__ __launch_bounds__(256, (MERGE ? CDS_DECONV_SBF_MINW : (MB == 1 ? CDS_
           const unsigned char* b = bp + q * 16 * POSB;
           bd[buf][q][0].u = *reinterpret_cast<const uint4*>(b);
           bd[buf][q][1].u = *reinterpret_cast<const uint4*>(b + 16);
-          bd[buf][q][2].u = *reinterpret_cast<const uint4*>(b + 32);
+          if (!F16) bd[buf][q][2].u = *reinterpret_cast<const uint4*>(b + 32);
         }
       };
       load_w(0, 0);
@@ -571,7 +578,11 @@ __global__ __launch_bounds__(256, (MERGE ? CDS_DECONV_SBF_MINW : (MB == 1 ? CDS_
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) {
-          SBF_TERMS(acc[c][mb], 0, Cfg::NT, wa[wcur][mb], bd[cur]);
+          if constexpr (F16) {
+            SF16_TERMS(acc[c][mb], 0, Cfg::NT, wa[wcur][mb], bd[cur]);
+          } else {
+            SBF_TERMS(acc[c][mb], 0, Cfg::NT, wa[wcur][mb], bd[cur]);
+          }
         }
       }
     }
@@ -602,7 +613,8 @@ __global__ __launch_bounds__(256, (MERGE ? CDS_DECONV_SBF_MINW : (MB == 1 ? CDS_
             if (ax >= W) continue;
             const size_t base = (rowbase + 2 * ax + px) * Cout + co;
             const f32x4 a = acc[c][mb][q];
-            float4 o = make_float4(a.x + bv.x, a.y + bv.y, a.z + bv.z, a.w + bv.w);
+            float4 o = F16 ? make_float4(a.x * out_mul + bv.x, a.y * out_mul + bv.y, a.z * out_mul + bv.z, a.w * out_mul + bv.w)
+                           : make_float4(a.x + bv.x, a.y + bv.y, a.z + bv.z, a.w + bv.w);
             if (act == CDS_ACT_RELU) {
               o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
             }
@@ -610,6 +622,7 @@ __global__ __launch_bounds__(256, (MERGE ? CDS_DECONV_SBF_MINW : (MB == 1 ? CDS_
               const float4 s4 = SKIP_PF ? skv[SKIP_PF ? c : 0][q] : *reinterpret_cast<const float4*>(skip + base);
               o.x = s4.x + o.x; o.y = s4.y + o.y; o.z = s4.z + o.z; o.w = s4.w + o.w;
             }
+            if (F16) amax = fmaxf(fmaxf(amax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
             acc[c][mb][q] = (f32x4){o.x, o.y, o.z, o.w};
           }
         }
@@ -648,18 +661,20 @@ __global__ __launch_bounds__(256, (MERGE ? CDS_DECONV_SBF_MINW : (MB == 1 ? CDS_
       }
     }
   }
+  if (F16) sf16_publish_bound(amax, out_bound);
 }
 
-template <bool MERGE, int MB>
+template <bool MERGE, int MB, bool F16 = false>
 int launch_deconv(const float* x, const void* wsp, const float* b, const float* skip, float* out, int Cin, int Cout, int D, int H,
-                  int W, int act, int out_planar, hipStream_t st) {
+                  int W, int act, int out_planar, hipStream_t st, const float* in_bound = nullptr, float w_inv = 1.f,
+                  float* out_bound = nullptr) {
   using Cfg = DCfg;
   const int tx = cds_ceil_div(W, Cfg::CX), ty = cds_ceil_div(H, Cfg::CY);
   const int ntiles = tx * ty * D;
   int tpw = max(1, min(16, ntiles / (256 * 2 * 8)));
   const int nwg = cds_ceil_div(ntiles, tpw);
-  hipLaunchKernelGGL((deconv3d_sbf_kernel<MERGE, MB>), dim3(nwg), dim3(256), Cfg::LDSB, st, x, reinterpret_cast<const uint4*>(wsp),
-                     b, skip, out, Cin, Cout, D, H, W, act, out_planar, tx, ty, ntiles, tpw);
+  hipLaunchKernelGGL((deconv3d_sbf_kernel<MERGE, MB, F16>), dim3(nwg), dim3(256), Cfg::LDSB, st, x, reinterpret_cast<const uint4*>(wsp),
+                     b, skip, out, Cin, Cout, D, H, W, act, out_planar, tx, ty, ntiles, tpw, in_bound, w_inv, out_bound);
   return cds_launch_status();
 }
 
@@ -964,6 +979,17 @@ extern "C" int cds_conv3d_sf16_f32(const float* x, const void* weight_split, con
   if (stride == 1 && mb == 4) return launch_fwd<1, 4, 32, 2, false, false, true>(x, weight_split, bias, nullptr, out, Cin, Cout, D, H, W, act, st, in_bound, w_inv_scale, out_bound);
   if (stride == 2 && mb == 4) return launch_fwd<2, 4, 16, 2, false, false, true>(x, weight_split, bias, nullptr, out, Cin, Cout, D, H, W, act, st, in_bound, w_inv_scale, out_bound);
   return CDS_EINVAL;
+}
+
+// The transposed convolution to Cout = 32 (conv7 of CostRegNet) in SPLIT-F16 arithmetic: weight_split from
+// ops.split_pack_deconv3d(..., f16=True), w_inv_scale = 1 / its weight scale, in_bound / out_bound as in cds_conv3d_sf16_f32.
+extern "C" int cds_deconv3d_sf16_f32(const float* x, const void* weight_split, const float* bias, const float* skip, float* out, int Cin,
+                                     int Cout, int D, int H, int W, int act, const float* in_bound, float w_inv_scale, float* out_bound,
+                                     void* stream) {
+  if (!x || !weight_split || !out || !in_bound || Cin < 8 || (Cin % 8) || Cout != 32 || D < 1 || H < 1 || W < 1 || !(w_inv_scale > 0.f))
+    return CDS_EINVAL;
+  return launch_deconv<false, 2, true>(x, weight_split, bias, skip, out, Cin, Cout, D, H, W, act, 0, (hipStream_t)stream, in_bound,
+                                       w_inv_scale, out_bound);
 }
 
 // ConvTranspose3d k3 s2 p1 op1 (+bias +ReLU +residual) in split-bf16 arithmetic on channels-last volumes.  x [D][H][W][Cin]

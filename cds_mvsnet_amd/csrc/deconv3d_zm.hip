@@ -30,11 +30,16 @@ struct DZC {
   static constexpr int IPT = (NITEM + PW * 64 - 1) / (PW * 64);
 };
 
-template <int ROUNDS>
+// F16: split-f16 arithmetic (sbf_common.hpp): two fp16 terms, three products per K-step, tensor scales from device bounds.
+template <int ROUNDS, bool F16>
 __global__ __launch_bounds__((DZC<ROUNDS>::THREADS), 3) void deconv3d_zm_kernel(
     const float* __restrict__ x, const uint4* __restrict__ wcls, const float* __restrict__ bias, const float* __restrict__ skip,
-    float* __restrict__ out, int D, int H, int W, int tiles_x, int ncols, int seg_len, int act) {
+    float* __restrict__ out, int D, int H, int W, int tiles_x, int ncols, int seg_len, int act, const float* __restrict__ in_bound,
+    float w_inv, float* __restrict__ out_bound) {
   using C = DZC<ROUNDS>;
+  constexpr int NT = F16 ? 2 : 3;
+  const float xs = F16 ? sf16_scale(in_bound[0]) : 1.0f;
+  const float out_mul = F16 ? w_inv / xs : 1.0f;
   constexpr int Cin = 8 * ROUNDS, Cout = 16;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int tid = threadIdx.x;
@@ -80,7 +85,10 @@ __global__ __launch_bounds__((DZC<ROUNDS>::THREADS), 3) void deconv3d_zm_kernel(
       unsigned char* base = lds + (plane % C::NSLOT) * C::SLOTB;
 #pragma unroll
       for (int h = 0; h < C::IPT; ++h)
-        if (s_dst[h] >= 0) split_store8(base + s_dst[h], va[h], vb[h]);
+        if (s_dst[h] >= 0) {
+          if (F16) split_store8_f16(base + s_dst[h], va[h], vb[h], xs);
+          else split_store8(base + s_dst[h], va[h], vb[h]);
+        }
     };
     issue(a0);
     deposit(a0);
@@ -106,7 +114,7 @@ __global__ __launch_bounds__((DZC<ROUNDS>::THREADS), 3) void deconv3d_zm_kernel(
 #pragma unroll
     for (int rd = 0; rd < ROUNDS; ++rd)
 #pragma unroll
-      for (int k = 0; k < 3; ++k) {
+      for (int k = 0; k < NT; ++k) {
         wlo[rd][k].u = wp[((rd * 2 + 0) * 3 + k) * 64];
         whi[rd][k].u = wp[((rd * 2 + 1) * 3 + k) * 64];
       }
@@ -116,6 +124,7 @@ __global__ __launch_bounds__((DZC<ROUNDS>::THREADS), 3) void deconv3d_zm_kernel(
   const int xv = 2 * (X0 + j) + px;
   const bool x_ok = X0 + j < W;
   const size_t zstride = (size_t)Ho * Wo * Cout;
+  float amax = 0.f;                                   // split-f16: running maximum of the magnitudes this lane stores
   __syncthreads();                                    // #0
   for (int a = a0; a < a1; ++a) {
     const unsigned char* lo = lds + (a % C::NSLOT) * C::SLOTB + b_off;
@@ -129,7 +138,7 @@ __global__ __launch_bounds__((DZC<ROUNDS>::THREADS), 3) void deconv3d_zm_kernel(
     for (int n = 0; n < nrows; ++n) {
       const float4 sk = skn;
       if (skip && x_ok && n + 1 < nrows) skn = *reinterpret_cast<const float4*>(skip + zbase + row_off(n + 1));
-      f32x4 acc[1] = {(f32x4){bv.x, bv.y, bv.z, bv.w}};
+      f32x4 acc[1] = {F16 ? (f32x4){0.f, 0.f, 0.f, 0.f} : (f32x4){bv.x, bv.y, bv.z, bv.w}};
       const unsigned char* lo_n = lo + n * C::IXP * POSB;
       const unsigned char* hi_n = hi + n * C::IXP * POSB;
 #pragma unroll
@@ -137,14 +146,22 @@ __global__ __launch_bounds__((DZC<ROUNDS>::THREADS), 3) void deconv3d_zm_kernel(
         BV b[1][3];
         b[0][0].u = *reinterpret_cast<const uint4*>(lo_n + rd * C::ROUNDB);
         b[0][1].u = *reinterpret_cast<const uint4*>(lo_n + rd * C::ROUNDB + 16);
-        b[0][2].u = *reinterpret_cast<const uint4*>(lo_n + rd * C::ROUNDB + 32);
-        SBF_TERMS(acc, 0, 1, wlo[rd], b);
+        if constexpr (F16) {
+          SF16_TERMS(acc, 0, 1, wlo[rd], b);
+        } else {
+          b[0][2].u = *reinterpret_cast<const uint4*>(lo_n + rd * C::ROUNDB + 32);
+          SBF_TERMS(acc, 0, 1, wlo[rd], b);
+        }
         if (pz) {
           BV c[1][3];
           c[0][0].u = *reinterpret_cast<const uint4*>(hi_n + rd * C::ROUNDB);
           c[0][1].u = *reinterpret_cast<const uint4*>(hi_n + rd * C::ROUNDB + 16);
-          c[0][2].u = *reinterpret_cast<const uint4*>(hi_n + rd * C::ROUNDB + 32);
-          SBF_TERMS(acc, 0, 1, whi[rd], c);
+          if constexpr (F16) {
+            SF16_TERMS(acc, 0, 1, whi[rd], c);
+          } else {
+            c[0][2].u = *reinterpret_cast<const uint4*>(hi_n + rd * C::ROUNDB + 32);
+            SBF_TERMS(acc, 0, 1, whi[rd], c);
+          }
         }
       }
       // the next row's residual is taken delivery of BEFORE this row's store is issued (gfx9: one vmcnt for loads and stores, out of
@@ -152,22 +169,25 @@ __global__ __launch_bounds__((DZC<ROUNDS>::THREADS), 3) void deconv3d_zm_kernel(
       asm volatile("" ::"v"(skn.x), "v"(skn.y), "v"(skn.z), "v"(skn.w));
       if (x_ok) {
         const f32x4 r = acc[0];
-        float4 o = make_float4(r.x, r.y, r.z, r.w);
+        float4 o = F16 ? make_float4(r.x * out_mul + bv.x, r.y * out_mul + bv.y, r.z * out_mul + bv.z, r.w * out_mul + bv.w)
+                       : make_float4(r.x, r.y, r.z, r.w);
         if (act == CDS_ACT_RELU) o = make_float4(fmaxf(o.x, 0.f), fmaxf(o.y, 0.f), fmaxf(o.z, 0.f), fmaxf(o.w, 0.f));
         if (skip) o = make_float4(sk.x + o.x, sk.y + o.y, sk.z + o.z, sk.w + o.w);
+        if (F16) amax = fmaxf(fmaxf(amax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
         sbf_store4(out + zbase + row_off(n), o);
       }
     }
     __syncthreads();
   }
+  if (F16) sf16_publish_bound(amax, out_bound);
 }
 
 }  // namespace
 
 // ConvTranspose3d k3 s2 p1 op1 (+bias +ReLU +residual) 32 -> 16 in split-bf16 arithmetic, channels-last: x [D][H][W][32] ->
 // out [2D][2H][2W][16]; weight_cls from ops.split_pack_deconv_cls (int16 [8 classes][4 rounds][2][3][64][8]).
-extern "C" int cds_deconv3d_zm_f32(const float* x, const void* weight_cls, const float* bias, const float* skip, float* out,
-                                   int Cin, int Cout, int D, int H, int W, int act, void* stream) {
+static int dzm_entry(const float* x, const void* weight_cls, const float* bias, const float* skip, float* out, int Cin, int Cout, int D,
+                     int H, int W, int act, const float* in_bound, float w_inv, float* out_bound, void* stream) {
   if (!x || !weight_cls || !out || Cin != 32 || Cout != 16 || D < 1 || H < 1 || W < 1) return CDS_EINVAL;
   if ((long)2 * H * 2 * W * Cout >= (1l << 31) || (long)H * W * Cin >= (1l << 31)) return CDS_EINVAL;   // in-plane offsets are 32-bit
   using C = DZC<4>;
@@ -186,9 +206,32 @@ extern "C" int cds_deconv3d_zm_f32(const float* x, const void* weight_cls, const
   if (nseg_e && atoi(nseg_e) > 0) best = min(atoi(nseg_e), D);
   const int seg_len = cds_ceil_div(D, best);
   const int nseg = cds_ceil_div(D, seg_len);
+  if (in_bound) {
+    static std::atomic<unsigned long long> lds_ok_h{0};
+    if (int e_lds = cds_allow_lds(reinterpret_cast<const void*>(deconv3d_zm_kernel<4, true>), 160 * 1024, lds_ok_h)) return e_lds;
+    hipLaunchKernelGGL((deconv3d_zm_kernel<4, true>), dim3(ncols * nseg), dim3(C::THREADS), C::LDS, st, x,
+                       reinterpret_cast<const uint4*>(weight_cls), bias, skip, out, D, H, W, tiles_x, ncols, seg_len, act, in_bound, w_inv,
+                       out_bound);
+    return cds_launch_status();
+  }
   static std::atomic<unsigned long long> lds_ok{0};
-  if (int e_lds = cds_allow_lds(reinterpret_cast<const void*>(deconv3d_zm_kernel<4>), 160 * 1024, lds_ok)) return e_lds;
-  hipLaunchKernelGGL(deconv3d_zm_kernel<4>, dim3(ncols * nseg), dim3(C::THREADS), C::LDS, st, x,
-                     reinterpret_cast<const uint4*>(weight_cls), bias, skip, out, D, H, W, tiles_x, ncols, seg_len, act);
+  if (int e_lds = cds_allow_lds(reinterpret_cast<const void*>(deconv3d_zm_kernel<4, false>), 160 * 1024, lds_ok)) return e_lds;
+  hipLaunchKernelGGL((deconv3d_zm_kernel<4, false>), dim3(ncols * nseg), dim3(C::THREADS), C::LDS, st, x,
+                     reinterpret_cast<const uint4*>(weight_cls), bias, skip, out, D, H, W, tiles_x, ncols, seg_len, act, nullptr, 1.0f,
+                     nullptr);
   return cds_launch_status();
+}
+
+extern "C" int cds_deconv3d_zm_f32(const float* x, const void* weight_cls, const float* bias, const float* skip, float* out,
+                                   int Cin, int Cout, int D, int H, int W, int act, void* stream) {
+  return dzm_entry(x, weight_cls, bias, skip, out, Cin, Cout, D, H, W, act, nullptr, 1.0f, nullptr, stream);
+}
+
+// The same layer in SPLIT-F16 arithmetic (sbf_common.hpp): weight_cls from ops.split_pack_deconv_cls(..., f16=True), w_inv_scale = 1 / its
+// weight scale, in_bound a DEVICE scalar >= max |x|, out_bound a zeroed DEVICE scalar that receives max |out| (or NULL).
+extern "C" int cds_deconv3d_zm_sf16_f32(const float* x, const void* weight_cls, const float* bias, const float* skip, float* out,
+                                        int Cin, int Cout, int D, int H, int W, int act, const float* in_bound, float w_inv_scale,
+                                        float* out_bound, void* stream) {
+  if (!in_bound || !(w_inv_scale > 0.f)) return CDS_EINVAL;
+  return dzm_entry(x, weight_cls, bias, skip, out, Cin, Cout, D, H, W, act, in_bound, w_inv_scale, out_bound, stream);
 }

@@ -267,6 +267,10 @@ class CostRegNet(_PackedHolder):
                     out["prob.tab"] = ops.pack_prob_table(self.prob.weight)
                 if name == "conv9":     # 32 -> 16: z-marching class-per-wave kernel (csrc/deconv3d_zm.hip); ".ws" stays for slab.py
                     out[name + ".wc"] = ops.split_pack_deconv_cls(unit.conv.weight.detach() * scale.view(1, -1, 1, 1, 1))
+                    if ops.USE_SPLIT_F16:
+                        out[name + ".wh"], out[name + ".whs"] = ops.split_pack_deconv_cls(unit.conv.weight.detach() * scale.view(1, -1, 1, 1, 1), f16=True)
+                if name == "conv7" and ops.USE_SPLIT_F16:
+                    out[name + ".wh"], out[name + ".whs"] = ops.split_pack_deconv3d(unit.conv.weight.detach() * scale.view(1, -1, 1, 1, 1), f16=True)
                 if unit.transposed:
                     if name != "conv7" and not self._slab_operands:
                         continue        # conv9 / conv11 run their z-marching forms; the tiled operands are slab.py's
@@ -320,7 +324,7 @@ class CostRegNet(_PackedHolder):
 
     @staticmethod
     def _run_cl(v: Tensor, p: Dict[str, Tensor], bound: Optional[Tensor] = None) -> Tensor:
-        f16 = bound is not None and all(f"conv{i}.wh" in p for i in range(7)) and ops.USE_SPLIT_F16
+        f16 = bound is not None and all(f"conv{i}.wh" in p for i in (0, 1, 2, 3, 4, 5, 6, 7, 9)) and ops.USE_SPLIT_F16
         if f16:
             # conv0 - conv6 in split-f16: every layer leaves max |output| in its slot of `bnd` (zeroed once), the next one scales by it
             bnd = torch.zeros((8,), dtype=torch.float32, device=v.device)
@@ -336,8 +340,14 @@ class CostRegNet(_PackedHolder):
             del c3
             c5 = ops.conv3d_sbf(c4, p["conv5.wh"], p["conv5.b"], 64, stride=2, in_bound=bnd[4:5], w_inv_scale=p["conv5.whs"],
                                 out_bound=bnd[5:6])
-            x = ops.conv3d_sbf(c5, p["conv6.wh"], p["conv6.b"], 64, in_bound=bnd[5:6], w_inv_scale=p["conv6.whs"])
+            x = ops.conv3d_sbf(c5, p["conv6.wh"], p["conv6.b"], 64, in_bound=bnd[5:6], w_inv_scale=p["conv6.whs"], out_bound=bnd[6:7])
             del c5
+            x = ops.deconv3d_sbf(x, p["conv7.wh"], p["conv7.b"], 32, skip=c4, in_bound=bnd[6:7], w_inv_scale=p["conv7.whs"],
+                                 out_bound=bnd[7:8])
+            del c4
+            x = ops.deconv3d_zm(x, p["conv9.wh"], p["conv9.b"], skip=c2, in_bound=bnd[7:8], w_inv_scale=p["conv9.whs"])
+            del c2
+            return ops.deconv_prob_zm(x, p["conv11.wz"], p["conv11.b"], c0, p["prob.tab"])
         else:
             c0 = ops.conv3d_sbf(v, p["conv0.ws"], p["conv0.b"], 8, stride=ops.SBF_PAIR)
             c1 = ops.conv3d_sbf(c0, p["conv1.ws"], p["conv1.b"], 16, stride=2)

@@ -510,7 +510,7 @@ def _deconv_tables(merge: bool):
     return classes, ksteps, taps
 
 
-def split_pack_deconv3d(w: Tensor) -> Tensor:
+def split_pack_deconv3d(w: Tensor, f16: bool = False):
     """Pack a (BN-folded) ConvTranspose3d weight [Cin,Cout,3,3,3] for cds_deconv3d_sbf_f32 (Cout == 8: the two x parities
     share an MFMA, rows = (px, cout); Cout in {16, 32}: rows = couts).  int16 [Cin/8][nks][mb][3][64][8]."""
     Cin, Cout = w.shape[:2]
@@ -539,11 +539,13 @@ def split_pack_deconv3d(w: Tensor) -> Tensor:
                 kx = xs[0]
                 for mb in range(mbl):
                     a[:, ks, mb, gg] = wf[:, :, mb * 16:(mb + 1) * 16, kz, ky, kx].permute(0, 2, 1)
-    return _split3(a.reshape(rounds, len(ksteps), mbl, 64, 8))
+    a = a.reshape(rounds, len(ksteps), mbl, 64, 8)
+    return _split2_f16(a) if f16 else _split3(a)      # f16: (tensor, 1 / weight scale) for cds_deconv3d_sf16_f32
 
 
 def deconv3d_sbf(x_cl: Tensor, wsplit: Tensor, bias: Optional[Tensor], cout: int, relu: bool = True,
-                 skip: Optional[Tensor] = None, out_planar: bool = False) -> Tensor:
+                 skip: Optional[Tensor] = None, out_planar: bool = False, in_bound: Optional[Tensor] = None, w_inv_scale: float = 1.0,
+                 out_bound: Optional[Tensor] = None) -> Tensor:
     """ConvTranspose3d k3 s2 p1 op1 in split-bf16 arithmetic, channels-last: x_cl [D,H,W,Cin] -> [2D,2H,2W,cout]
     (or planar [cout,2D,2H,2W] with out_planar; the residual `skip` is channels-last either way)."""
     D, H, W, Cin = x_cl.shape
@@ -553,6 +555,15 @@ def deconv3d_sbf(x_cl: Tensor, wsplit: Tensor, bias: Optional[Tensor], cout: int
         raise ValueError("deconv3d_sbf: residual shape mismatch")
     if wsplit.dtype != torch.int16 or not wsplit.is_cuda or not wsplit.is_contiguous():
         raise ValueError("deconv3d_sbf: wsplit must be the contiguous int16 device tensor from split_pack_deconv3d")
+    if in_bound is not None:       # split-f16 arithmetic (cout == 32: conv7 of CostRegNet); operands from split_pack_deconv3d(..., f16=True)
+        if cout != 32 or out_planar:
+            raise ValueError("deconv3d_sbf: the split-f16 form exists for cout == 32, channels-last output")
+        check(_lib.load().cds_deconv3d_sf16_f32(_dev(x_cl, "x"), wsplit.data_ptr(), _dev(bias, "bias") if bias is not None else None,
+                                                _dev(skip, "skip") if skip is not None else None, out.data_ptr(), Cin, cout, D, H, W,
+                                                ACT_RELU if relu else ACT_NONE, _dev(in_bound, "in_bound"), float(w_inv_scale),
+                                                _dev(out_bound, "out_bound") if out_bound is not None else None, _stream(x_cl)),
+              "cds_deconv3d_sf16_f32")
+        return out
     check(_lib.load().cds_deconv3d_sbf_f32(_dev(x_cl, "x"), wsplit.data_ptr(), _dev(bias, "bias") if bias is not None else None,
                                            _dev(skip, "skip") if skip is not None else None, out.data_ptr(), Cin, cout,
                                            D, H, W, ACT_RELU if relu else ACT_NONE, 1 if out_planar else 0, _stream(x_cl)),
@@ -560,7 +571,7 @@ def deconv3d_sbf(x_cl: Tensor, wsplit: Tensor, bias: Optional[Tensor], cout: int
     return out
 
 
-def split_pack_deconv_cls(w: Tensor) -> Tensor:
+def split_pack_deconv_cls(w: Tensor, f16: bool = False):
     """Pack a (BN-folded) ConvTranspose3d weight [32,16,3,3,3] for cds_deconv3d_zm_f32: per output parity class c = 4 pz + 2 py + px
     and 8-channel round two matrix operands (cell offset dz = 0 | 1), rows = couts, K slot g = (dy, dx) = (g >> 1, g & 1); a slot the
     class does not reach (d > parity on an axis) is zero.  Per axis: parity 0 takes kernel tap 1 of cell a; parity 1 takes tap 2 of
@@ -578,18 +589,28 @@ def split_pack_deconv_cls(w: Tensor) -> Tensor:
                 if kz is None or ky is None or kx is None:
                     continue
                 a[c, :, dz, g] = wf[:, :, :, kz, ky, kx].permute(0, 2, 1)
-    return _split3(a.reshape(8, 4, 2, 64, 8))
+    a = a.reshape(8, 4, 2, 64, 8)
+    return _split2_f16(a) if f16 else _split3(a)      # f16: (tensor, 1 / weight scale) for cds_deconv3d_zm_sf16_f32
 
 
-def deconv3d_zm(x_cl: Tensor, wcls: Tensor, bias: Optional[Tensor], relu: bool = True, skip: Optional[Tensor] = None) -> Tensor:
+def deconv3d_zm(x_cl: Tensor, wcls: Tensor, bias: Optional[Tensor], relu: bool = True, skip: Optional[Tensor] = None,
+                in_bound: Optional[Tensor] = None, w_inv_scale: float = 1.0, out_bound: Optional[Tensor] = None) -> Tensor:
     """ConvTranspose3d 32 -> 16 (k3 s2 p1 op1) in split-bf16 arithmetic on the z-marching class-per-wave kernel, channels-last:
-    x_cl [D,H,W,32] -> [2D,2H,2W,16]."""
+    x_cl [D,H,W,32] -> [2D,2H,2W,16].  in_bound given: split-f16 arithmetic (wcls / w_inv_scale from split_pack_deconv_cls(..., f16=True);
+    bounds as in conv3d_sbf)."""
     D, H, W, Cin = x_cl.shape
     out = torch.empty((2 * D, 2 * H, 2 * W, 16), dtype=torch.float32, device=x_cl.device)
     if skip is not None and tuple(skip.shape) != tuple(out.shape):
         raise ValueError("deconv3d_zm: residual shape mismatch")
     if wcls.dtype != torch.int16 or not wcls.is_cuda or not wcls.is_contiguous() or wcls.numel() != 8 * 4 * 2 * 3 * 64 * 8:
         raise ValueError("deconv3d_zm: wcls must be the contiguous int16 device tensor from split_pack_deconv_cls")
+    if in_bound is not None:
+        check(_lib.load().cds_deconv3d_zm_sf16_f32(_dev(x_cl, "x"), wcls.data_ptr(), _dev(bias, "bias") if bias is not None else None,
+                                                   _dev(skip, "skip") if skip is not None else None, out.data_ptr(), Cin, 16, D, H, W,
+                                                   ACT_RELU if relu else ACT_NONE, _dev(in_bound, "in_bound"), float(w_inv_scale),
+                                                   _dev(out_bound, "out_bound") if out_bound is not None else None, _stream(x_cl)),
+              "cds_deconv3d_zm_sf16_f32")
+        return out
     check(_lib.load().cds_deconv3d_zm_f32(_dev(x_cl, "x"), wcls.data_ptr(), _dev(bias, "bias") if bias is not None else None,
                                           _dev(skip, "skip") if skip is not None else None, out.data_ptr(), Cin, 16, D, H, W,
                                           ACT_RELU if relu else ACT_NONE, _stream(x_cl)), "cds_deconv3d_zm_f32")

@@ -229,6 +229,13 @@ int cds_deconv3d_sbf_f32(const float* x, const void* weight_split, const float* 
  * Cin == 32 and Cout == 16 only (CDS_EINVAL otherwise). */
 int cds_deconv3d_zm_f32(const float* x, const void* weight_cls, const float* bias, const float* skip, float* out,
                         int Cin, int Cout, int D, int H, int W, int act, void* stream);
+/* conv7 (Cout = 32) and conv9 (32 -> 16, z-marching) in SPLIT-F16 arithmetic (see cds_conv3d_sf16_f32 for the operands: weights from the
+ * packers with f16=True, w_inv_scale, in_bound / out_bound device scalars). */
+int cds_deconv3d_sf16_f32(const float* x, const void* weight_split, const float* bias, const float* skip, float* out, int Cin, int Cout,
+                          int D, int H, int W, int act, const float* in_bound, float w_inv_scale, float* out_bound, void* stream);
+int cds_deconv3d_zm_sf16_f32(const float* x, const void* weight_cls, const float* bias, const float* skip, float* out, int Cin, int Cout,
+                             int D, int H, int W, int act, const float* in_bound, float w_inv_scale, float* out_bound, void* stream);
+
 
 /* The tail of CostRegNet in one launch: conv11 = ConvTranspose3d(16 -> 8, k3 s2 p1 op1) + BatchNorm3d(eval, folded) + ReLU
  * (models/module.py:125-160, :495), the residual `conv0 + conv11(x)` (:498) and prob = Conv3d(8 -> 1, k3, p1, bias=False)

@@ -992,6 +992,45 @@ def test_conv3d_split_f16_is_fp32_class(cin, cout, stride, D, H, W, loose, dev, 
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("cin,cout,D,H,W", [(64, 32, 2, 5, 18), (64, 32, 5, 9, 37), (32, 16, 3, 6, 20), (32, 16, 7, 13, 37)])
+def test_deconv3d_split_f16_is_fp32_class(cin, cout, D, H, W, dev, ops):
+    """conv7 (64 -> 32, tiled transposed kernel) and conv9 (32 -> 16, z-marching class-per-wave kernel) in split-f16 arithmetic against
+    float64: the bar of test_deconv3d_split_bf16_is_fp32_class (no worse than 1.5x a plain fp32 evaluation), with ReLU + residual, and the
+    kernel's out_bound = the largest magnitude it stored."""
+    g = torch.Generator().manual_seed(cin * 10 + cout)
+    x = torch.randn(cin, D, H, W, generator=g) * torch.exp(torch.randn(cin, 1, 1, 1, generator=g))
+    w = torch.randn(cin, cout, 3, 3, 3, generator=g) / (27 * cin / 8) ** 0.5
+    b = torch.randn(cout, generator=g)
+    want64 = F.conv_transpose3d(x.double().unsqueeze(0), w.double(), b.double(), stride=2, padding=1, output_padding=1)[0]
+    want32 = F.conv_transpose3d(x.unsqueeze(0), w, b, stride=2, padding=1, output_padding=1)[0]
+    skip = torch.randn(want32.shape, generator=g)
+    x_cl = x.permute(1, 2, 3, 0).contiguous().to(dev)
+    skip_cl = skip.permute(1, 2, 3, 0).contiguous().to(dev)
+    in_bound = x_cl.abs().amax().reshape(1)
+    wpk = w.permute(0, 2, 3, 4, 1).reshape(cin, 27, cout).contiguous().to(dev)
+    chain32 = ops.deconv3d_k3s2(x.to(dev), wpk, b.to(dev), relu=False).cpu()
+    err_f32 = max((want32.double() - want64).abs().max().item(), (chain32.double() - want64).abs().max().item())
+    ulp = want64.abs().max().item() * 2.0 ** -23
+    if cout == 32:
+        wh, winv = ops.split_pack_deconv3d(w.to(dev), f16=True)
+        run = lambda **kw: ops.deconv3d_sbf(x_cl, wh, b.to(dev), cout, in_bound=in_bound, w_inv_scale=winv, **kw)
+    else:
+        wh, winv = ops.split_pack_deconv_cls(w.to(dev), f16=True)
+        run = lambda **kw: ops.deconv3d_zm(x_cl, wh, b.to(dev), in_bound=in_bound, w_inv_scale=winv, **kw)
+    ob = torch.zeros(1, device=dev)
+    got = run(relu=False, out_bound=ob)
+    assert float(ob) == float(got.abs().max())
+    err = (got.cpu().permute(3, 0, 1, 2).double() - want64).abs().max().item()
+    print(f"deconv3d {cin}->{cout}: max err vs float64: split-f16 {err:.2e}, fp32 {err_f32:.2e}")
+    assert err <= 1.5 * err_f32 + ulp, (err, err_f32)
+    ob.zero_()
+    got2 = run(relu=True, skip=skip_cl, out_bound=ob)
+    assert float(ob) == float(got2.abs().max())
+    want2 = skip.double() + want64.clamp_min(0)
+    assert (got2.cpu().permute(3, 0, 1, 2).double() - want2).abs().max().item() <= 1.5 * err_f32 + 2 * ulp
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("cin,cout,D,H,W", [(16, 8, 5, 7, 37), (16, 8, 4, 8, 32), (32, 16, 3, 6, 20), (64, 32, 2, 5, 18),
                                             (8, 8, 3, 4, 16)])
 def test_deconv3d_split_bf16_is_fp32_class(cin, cout, D, H, W, dev, ops):
