@@ -55,6 +55,7 @@ SIGNATURES = {
     "cds_deconv3d_sf16_f32": [P, P, P, P, P, I, I, I, I, I, I, P, F, P, P],
     "cds_deconv3d_zm_sf16_f32": [P, P, P, P, P, I, I, I, I, I, I, P, F, P, P],
     "cds_deconv_prob_zm_f32": [P, P, P, P, P, P, I, I, I, P],
+    "cds_deconv_prob_zm_sf16_f32": [P, P, P, P, P, P, I, I, I, P, F, P],
     "cds_deconv3d_zm_f32": [P, P, P, P, P, I, I, I, I, I, I, P],
     "cds_deconv3d_k3s2_f32": [P, P, P, P, P, I, I, I, I, I, I, P],
     "cds_conv2d_f32": [P, P, P, P, I, I, I, I, I, I, I, I, I, P],

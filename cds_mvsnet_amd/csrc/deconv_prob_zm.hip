@@ -57,10 +57,21 @@ __device__ __forceinline__ float dpz_fma(float d, float w, float acc) {
   return acc;
 }
 
+// F16: the transposed convolution in split-f16 arithmetic (sbf_common.hpp): two fp16 terms of x x (scale from the device bound in_bound),
+// three products per K-step, exact rescaling before the BN shift; prob (VALU, fp32) is unchanged.
+#define DPZ_TERMS(ACC, W, X)                                  \
+  do {                                                        \
+    if constexpr (F16) { SF16_TERMS(ACC, 0, C::NT, W, X); }   \
+    else { SBF_TERMS(ACC, 0, C::NT, W, X); }                  \
+  } while (0)
+template <bool F16>
 __global__ __launch_bounds__(DPZ::THREADS, 3) void deconv_prob_zm_kernel(
     const float* __restrict__ x, const uint4* __restrict__ wsp, const float* __restrict__ bias, const float* __restrict__ skip,
-    const float* __restrict__ pw, float* __restrict__ out, int D, int H, int W, int tiles_x, int ncols, int seg_len) {
+    const float* __restrict__ pw, float* __restrict__ out, int D, int H, int W, int tiles_x, int ncols, int seg_len,
+    const float* __restrict__ in_bound, float w_inv) {
   using C = DPZ;
+  const float xs = F16 ? sf16_scale(in_bound[0]) : 1.0f;
+  const float out_mul = F16 ? w_inv / xs : 1.0f;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   unsigned char* const inring = lds + C::WB;
   unsigned char* const ybuf = inring + 2 * C::SLOTB;
@@ -115,7 +126,10 @@ __global__ __launch_bounds__(DPZ::THREADS, 3) void deconv_prob_zm_kernel(
       unsigned char* base = inring + (plane & 1) * C::SLOTB;
 #pragma unroll
       for (int h = 0; h < C::IPT; ++h)
-        if (s_dst[h] >= 0) split_store8(base + s_dst[h], va[h], vb[h]);
+        if (s_dst[h] >= 0) {
+          if (F16) split_store8_f16(base + s_dst[h], va[h], vb[h], xs);
+          else split_store8(base + s_dst[h], va[h], vb[h]);
+        }
     };
     // ---- prob: lane = x column c of the owned 60, wave = 3 output rows ----
     const int c = ptid & 63, rg = ptid >> 6;
@@ -254,14 +268,14 @@ __global__ __launch_bounds__(DPZ::THREADS, 3) void deconv_prob_zm_kernel(
     const unsigned char* p = wl + (rd * C::NA + k) * 3 * 1024;
     wa[0].u = *reinterpret_cast<const uint4*>(p);
     wa[1].u = *reinterpret_cast<const uint4*>(p + 1024);
-    wa[2].u = *reinterpret_cast<const uint4*>(p + 2048);
+    if (!F16) wa[2].u = *reinterpret_cast<const uint4*>(p + 2048);
   };
   auto load_b = [&](BV (&bd)[C::NT][3], const unsigned char* p) {
 #pragma unroll
     for (int q = 0; q < C::NT; ++q) {
       bd[q][0].u = *reinterpret_cast<const uint4*>(p + q * 16 * POSB);
       bd[q][1].u = *reinterpret_cast<const uint4*>(p + q * 16 * POSB + 16);
-      bd[q][2].u = *reinterpret_cast<const uint4*>(p + q * 16 * POSB + 32);
+      if (!F16) bd[q][2].u = *reinterpret_cast<const uint4*>(p + q * 16 * POSB + 32);
     }
   };
   f32x4 acc[2][C::NT];
@@ -271,7 +285,8 @@ __global__ __launch_bounds__(DPZ::THREADS, 3) void deconv_prob_zm_kernel(
     for (int py = 0; py < 2; ++py)
 #pragma unroll
       for (int q = 0; q < C::NT; ++q) {
-        const f32x4 a = acc[py][q];
+        f32x4 a = acc[py][q];
+        if (F16) a = a * out_mul + (f32x4){bv.x, bv.y, bv.z, bv.w};      // split-f16: back to the layer's scale, then the BN shift
         const float4 s4 = sk[py][q];
         float4 o = make_float4(s4.x + fmaxf(a.x, 0.f), s4.y + fmaxf(a.y, 0.f), s4.z + fmaxf(a.z, 0.f), s4.w + fmaxf(a.w, 0.f));
         if (border && sk_off[py][q] < 0) o = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -302,7 +317,8 @@ __global__ __launch_bounds__(DPZ::THREADS, 3) void deconv_prob_zm_kernel(
 #pragma unroll
       for (int py = 0; py < 2; ++py)
 #pragma unroll
-        for (int q = 0; q < C::NT; ++q) acc[py][q] = (f32x4){bv.x, bv.y, bv.z, bv.w};   // the BN shift rides in the accumulator
+        for (int q = 0; q < C::NT; ++q)      // the BN shift rides in the accumulator (split-f16: added after the rescaling)
+          acc[py][q] = F16 ? (f32x4){0.f, 0.f, 0.f, 0.f} : (f32x4){bv.x, bv.y, bv.z, bv.w};
       if (!(t & 1)) {
         // ---- z parity 0: plane 2 a from cell plane a ----
         float4 va[C::IPC], vb[C::IPC];
@@ -326,20 +342,23 @@ __global__ __launch_bounds__(DPZ::THREADS, 3) void deconv_prob_zm_kernel(
         load_a(w1, 0, 1);
         load_b(b1, cur + C::ROUNDB + b_h1);
         __builtin_amdgcn_sched_barrier(0);
-        SBF_TERMS(acc[0], 0, C::NT, w0, b0);
+        DPZ_TERMS(acc[0], w0, b0);
         load_a(w0, 1, 0);
         __builtin_amdgcn_sched_barrier(0);
-        SBF_TERMS(acc[1], 0, C::NT, w1, b0);
+        DPZ_TERMS(acc[1], w1, b0);
         load_a(w1, 1, 1);
         __builtin_amdgcn_sched_barrier(0);
-        SBF_TERMS(acc[0], 0, C::NT, w0, b1);
-        SBF_TERMS(acc[1], 0, C::NT, w1, b1);
+        DPZ_TERMS(acc[0], w0, b1);
+        DPZ_TERMS(acc[1], w1, b1);
         epilogue(sk0, 0);
         {
           unsigned char* base = inring + ((a + 1) & 1) * C::SLOTB;
 #pragma unroll
           for (int h = 0; h < C::IPC; ++h)
-            if (c_dst[h] >= 0) split_store8(base + c_dst[h], va[h], vb[h]);
+            if (c_dst[h] >= 0) {
+              if (F16) split_store8_f16(base + c_dst[h], va[h], vb[h], xs);
+              else split_store8(base + c_dst[h], va[h], vb[h]);
+            }
         }
       } else {
         // ---- z parity 1: plane 2 a + 1 from cell planes a (kz = 2) and a + 1 (kz = 0) ----
@@ -354,11 +373,11 @@ __global__ __launch_bounds__(DPZ::THREADS, 3) void deconv_prob_zm_kernel(
           load_a(w1, rd, 3);
           load_b(b1, bz + rd * C::ROUNDB + b_h2b);
           __builtin_amdgcn_sched_barrier(0);
-          SBF_TERMS(acc[0], 0, C::NT, w0, b0);
+          DPZ_TERMS(acc[0], w0, b0);
           load_a(w0, rd, 4);
           __builtin_amdgcn_sched_barrier(0);
-          SBF_TERMS(acc[1], 0, C::NT, w1, b0);
-          SBF_TERMS(acc[1], 0, C::NT, w0, b1);
+          DPZ_TERMS(acc[1], w1, b0);
+          DPZ_TERMS(acc[1], w0, b1);
         }
         epilogue(sk1, 1);
       }
@@ -372,8 +391,8 @@ __global__ __launch_bounds__(DPZ::THREADS, 3) void deconv_prob_zm_kernel(
 // conv11 + residual + prob in one launch.  x [D][H][W][16] channels-last input cells, skip [2D][2H][2W][8] channels-last (conv0's
 // output), weight_split from ops.split_pack_deconv_prob (int16 [2][5][3][64][8]), bias [8] (BN shift), prob_table from
 // ops.pack_prob_table (float [3 kx][2 halves][3 ky][3 kz][4]); out [2D][2H][2W] fp32.
-extern "C" int cds_deconv_prob_zm_f32(const float* x, const void* weight_split, const float* bias, const float* skip,
-                                      const float* prob_table, float* out, int D, int H, int W, void* stream) {
+static int dpz_entry(const float* x, const void* weight_split, const float* bias, const float* skip, const float* prob_table, float* out,
+                     int D, int H, int W, const float* in_bound, float w_inv, void* stream) {
   if (!x || !weight_split || !bias || !skip || !prob_table || !out || D < 1 || H < 1 || W < 1) return CDS_EINVAL;
   if ((long)2 * H * 2 * W * 8 >= (1l << 31) || (long)H * W * 16 >= (1l << 31)) return CDS_EINVAL;   // in-plane offsets are 32-bit
   using C = DPZ;
@@ -394,9 +413,31 @@ extern "C" int cds_deconv_prob_zm_f32(const float* x, const void* weight_split, 
   if (nseg_env > 0) best = min(nseg_env, D);
   const int seg_len = cds_ceil_div(D, best);
   const int nseg = cds_ceil_div(D, seg_len);
+  if (in_bound) {
+    static std::atomic<unsigned long long> lds_ok_h{0};
+    if (int e_lds = cds_allow_lds(reinterpret_cast<const void*>(deconv_prob_zm_kernel<true>), 160 * 1024, lds_ok_h)) return e_lds;
+    hipLaunchKernelGGL(deconv_prob_zm_kernel<true>, dim3(ncols * nseg), dim3(C::THREADS), C::LDS, st, x,
+                       reinterpret_cast<const uint4*>(weight_split), bias, skip, prob_table, out, D, H, W, tiles_x, ncols, seg_len, in_bound,
+                       w_inv);
+    return cds_launch_status();
+  }
   static std::atomic<unsigned long long> lds_ok{0};
-  if (int e_lds = cds_allow_lds(reinterpret_cast<const void*>(deconv_prob_zm_kernel), 160 * 1024, lds_ok)) return e_lds;
-  hipLaunchKernelGGL(deconv_prob_zm_kernel, dim3(ncols * nseg), dim3(C::THREADS), C::LDS, st, x,
-                     reinterpret_cast<const uint4*>(weight_split), bias, skip, prob_table, out, D, H, W, tiles_x, ncols, seg_len);
+  if (int e_lds = cds_allow_lds(reinterpret_cast<const void*>(deconv_prob_zm_kernel<false>), 160 * 1024, lds_ok)) return e_lds;
+  hipLaunchKernelGGL(deconv_prob_zm_kernel<false>, dim3(ncols * nseg), dim3(C::THREADS), C::LDS, st, x,
+                     reinterpret_cast<const uint4*>(weight_split), bias, skip, prob_table, out, D, H, W, tiles_x, ncols, seg_len, nullptr, 1.0f);
   return cds_launch_status();
+}
+
+extern "C" int cds_deconv_prob_zm_f32(const float* x, const void* weight_split, const float* bias, const float* skip,
+                                      const float* prob_table, float* out, int D, int H, int W, void* stream) {
+  return dpz_entry(x, weight_split, bias, skip, prob_table, out, D, H, W, nullptr, 1.0f, stream);
+}
+
+// The same fused tail with the transposed convolution in SPLIT-F16 arithmetic: weight_split from ops.split_pack_deconv_prob(..., f16=True),
+// w_inv_scale = 1 / its weight scale, in_bound a DEVICE scalar >= max |x| (conv9's out_bound).
+extern "C" int cds_deconv_prob_zm_sf16_f32(const float* x, const void* weight_split, const float* bias, const float* skip,
+                                           const float* prob_table, float* out, int D, int H, int W, const float* in_bound,
+                                           float w_inv_scale, void* stream) {
+  if (!in_bound || !(w_inv_scale > 0.f)) return CDS_EINVAL;
+  return dpz_entry(x, weight_split, bias, skip, prob_table, out, D, H, W, in_bound, w_inv_scale, stream);
 }

@@ -265,6 +265,8 @@ class CostRegNet(_PackedHolder):
                     # (slab.py) exchanges halo rows between the two layers and keeps the separate kernels (".ws" below)
                     out[name + ".wz"] = ops.split_pack_deconv_prob(unit.conv.weight.detach() * scale.view(1, -1, 1, 1, 1))
                     out["prob.tab"] = ops.pack_prob_table(self.prob.weight)
+                    if ops.USE_SPLIT_F16:
+                        out[name + ".wh"], out[name + ".whs"] = ops.split_pack_deconv_prob(unit.conv.weight.detach() * scale.view(1, -1, 1, 1, 1), f16=True)
                 if name == "conv9":     # 32 -> 16: z-marching class-per-wave kernel (csrc/deconv3d_zm.hip); ".ws" stays for slab.py
                     out[name + ".wc"] = ops.split_pack_deconv_cls(unit.conv.weight.detach() * scale.view(1, -1, 1, 1, 1))
                     if ops.USE_SPLIT_F16:
@@ -324,10 +326,10 @@ class CostRegNet(_PackedHolder):
 
     @staticmethod
     def _run_cl(v: Tensor, p: Dict[str, Tensor], bound: Optional[Tensor] = None) -> Tensor:
-        f16 = bound is not None and all(f"conv{i}.wh" in p for i in (0, 1, 2, 3, 4, 5, 6, 7, 9)) and ops.USE_SPLIT_F16
+        f16 = bound is not None and all(f"conv{i}.wh" in p for i in (0, 1, 2, 3, 4, 5, 6, 7, 9, 11)) and ops.USE_SPLIT_F16
         if f16:
-            # conv0 - conv6 in split-f16: every layer leaves max |output| in its slot of `bnd` (zeroed once), the next one scales by it
-            bnd = torch.zeros((8,), dtype=torch.float32, device=v.device)
+            # the whole network in split-f16: every layer leaves max |output| in its slot of `bnd` (zeroed once), the next one scales by it
+            bnd = torch.zeros((16,), dtype=torch.float32, device=v.device)
             c0 = ops.conv3d_sbf(v, p["conv0.wh"], p["conv0.b"], 8, stride=ops.SBF_PAIR, in_bound=bound, w_inv_scale=p["conv0.whs"],
                                 out_bound=bnd[0:1])
             c1 = ops.conv3d_sbf(c0, p["conv1.wh"], p["conv1.b"], 16, stride=2, in_bound=bnd[0:1], w_inv_scale=p["conv1.whs"],
@@ -345,9 +347,9 @@ class CostRegNet(_PackedHolder):
             x = ops.deconv3d_sbf(x, p["conv7.wh"], p["conv7.b"], 32, skip=c4, in_bound=bnd[6:7], w_inv_scale=p["conv7.whs"],
                                  out_bound=bnd[7:8])
             del c4
-            x = ops.deconv3d_zm(x, p["conv9.wh"], p["conv9.b"], skip=c2, in_bound=bnd[7:8], w_inv_scale=p["conv9.whs"])
+            x = ops.deconv3d_zm(x, p["conv9.wh"], p["conv9.b"], skip=c2, in_bound=bnd[7:8], w_inv_scale=p["conv9.whs"], out_bound=bnd[8:9])
             del c2
-            return ops.deconv_prob_zm(x, p["conv11.wz"], p["conv11.b"], c0, p["prob.tab"])
+            return ops.deconv_prob_zm(x, p["conv11.wh"], p["conv11.b"], c0, p["prob.tab"], in_bound=bnd[8:9], w_inv_scale=p["conv11.whs"])
         else:
             c0 = ops.conv3d_sbf(v, p["conv0.ws"], p["conv0.b"], 8, stride=ops.SBF_PAIR)
             c1 = ops.conv3d_sbf(c0, p["conv1.ws"], p["conv1.b"], 16, stride=2)

@@ -617,7 +617,7 @@ def deconv3d_zm(x_cl: Tensor, wcls: Tensor, bias: Optional[Tensor], relu: bool =
     return out
 
 
-def split_pack_deconv_prob(w: Tensor) -> Tensor:
+def split_pack_deconv_prob(w: Tensor, f16: bool = False):
     """Pack the (BN-folded) conv11 weight [16,8,3,3,3] for cds_deconv_prob_zm_f32: five matrix operands per 8-channel round,
     rows = (x parity, cout), K slot g = a cell offset (csrc/deconv_prob_zm.hip).  Output parity 0 of an axis takes kernel tap
     1 of cell a; parity 1 takes tap 2 of cell a and tap 0 of cell a + 1.  int16 [2][5][3][64][8]."""
@@ -641,7 +641,8 @@ def split_pack_deconv_prob(w: Tensor) -> Tensor:
             a[:, k, 2 * hi, 0:8] = wf[:, :, :, kz, ky, 1].permute(0, 2, 1)          # dx = 0, px = 0: tap 1 of cell a
             a[:, k, 2 * hi, 8:16] = wf[:, :, :, kz, ky, 2].permute(0, 2, 1)         # dx = 0, px = 1: tap 2 of cell a
             a[:, k, 2 * hi + 1, 8:16] = wf[:, :, :, kz, ky, 0].permute(0, 2, 1)     # dx = 1, px = 1: tap 0 of cell a + 1
-    return _split3(a.reshape(2, 5, 64, 8))
+    a = a.reshape(2, 5, 64, 8)
+    return _split2_f16(a) if f16 else _split3(a)      # f16: (tensor, 1 / weight scale) for cds_deconv_prob_zm_sf16_f32
 
 
 def pack_prob_table(w: Tensor) -> Tensor:
@@ -651,8 +652,10 @@ def pack_prob_table(w: Tensor) -> Tensor:
     return w.detach().float()[0].reshape(2, 4, 3, 3, 3).permute(4, 0, 3, 2, 1).contiguous()   # [h][i][kz][ky][kx] -> [kx][h][ky][kz][i]
 
 
-def deconv_prob_zm(x_cl: Tensor, wsplit: Tensor, bias: Tensor, skip: Tensor, prob_table: Tensor) -> Tensor:
-    """conv11 + residual + prob in one launch: x_cl [D,H,W,16], skip [2D,2H,2W,8] channels-last -> [2D,2H,2W]."""
+def deconv_prob_zm(x_cl: Tensor, wsplit: Tensor, bias: Tensor, skip: Tensor, prob_table: Tensor, in_bound: Optional[Tensor] = None,
+                   w_inv_scale: float = 1.0) -> Tensor:
+    """conv11 + residual + prob in one launch: x_cl [D,H,W,16], skip [2D,2H,2W,8] channels-last -> [2D,2H,2W].  in_bound given: the
+    transposed convolution in split-f16 arithmetic (wsplit / w_inv_scale from split_pack_deconv_prob(..., f16=True))."""
     D, H, W, Cin = x_cl.shape
     if Cin != 16 or tuple(skip.shape) != (2 * D, 2 * H, 2 * W, 8):
         raise ValueError("deconv_prob_zm: x [D,H,W,16] and skip [2D,2H,2W,8]")
@@ -661,6 +664,11 @@ def deconv_prob_zm(x_cl: Tensor, wsplit: Tensor, bias: Tensor, skip: Tensor, pro
     if prob_table.numel() != 216 or bias.numel() != 8:
         raise ValueError("deconv_prob_zm: prob_table from pack_prob_table, bias [8]")
     out = torch.empty((2 * D, 2 * H, 2 * W), dtype=torch.float32, device=x_cl.device)
+    if in_bound is not None:
+        check(_lib.load().cds_deconv_prob_zm_sf16_f32(_dev(x_cl, "x"), wsplit.data_ptr(), _dev(bias, "bias"), _dev(skip, "skip"),
+                                                      _dev(prob_table, "prob_table"), out.data_ptr(), D, H, W, _dev(in_bound, "in_bound"),
+                                                      float(w_inv_scale), _stream(x_cl)), "cds_deconv_prob_zm_sf16_f32")
+        return out
     check(_lib.load().cds_deconv_prob_zm_f32(_dev(x_cl, "x"), wsplit.data_ptr(), _dev(bias, "bias"), _dev(skip, "skip"),
                                              _dev(prob_table, "prob_table"), out.data_ptr(), D, H, W, _stream(x_cl)),
           "cds_deconv_prob_zm_f32")

@@ -246,6 +246,11 @@ int cds_deconv3d_zm_sf16_f32(const float* x, const void* weight_cls, const float
  * (float [3 kx][2][3 ky][3 kz][4]). */
 int cds_deconv_prob_zm_f32(const float* x, const void* weight_split, const float* bias, const float* skip,
                            const float* prob_table, float* out, int D, int H, int W, void* stream);
+/* The fused tail with its transposed convolution in SPLIT-F16 arithmetic (weights from ops.split_pack_deconv_prob(..., f16=True);
+ * in_bound: DEVICE scalar >= max |x|, conv9's out_bound). */
+int cds_deconv_prob_zm_sf16_f32(const float* x, const void* weight_split, const float* bias, const float* skip, const float* prob_table,
+                                float* out, int D, int H, int W, const float* in_bound, float w_inv_scale, void* stream);
+
 
 /*
  * K4 (module.py:125-160): ConvTranspose3d k=3, stride 2, padding 1, output_padding 1 (doubles

@@ -1130,6 +1130,13 @@ def test_conv11_residual_prob_fused(D, H, W, nseg, dev, ops, monkeypatch):
     ulp = want64.abs().max().item() * 2.0 ** -23
     print(f"conv11+prob fused D{D} H{H} W{W}: max err vs float64 {err:.2e} (torch fp32: {err32:.2e})")
     assert err <= 1.5 * err32 + 2 * ulp, (err, err32)
+    # the same launch with the transposed convolution in split-f16 arithmetic (round 6): the same bar
+    x_cl = x.permute(1, 2, 3, 0).contiguous().to(dev)
+    wh, winv = ops.split_pack_deconv_prob(w11.to(dev), f16=True)
+    got_h = ops.deconv_prob_zm(x_cl, wh, b11.to(dev), skip.permute(1, 2, 3, 0).contiguous().to(dev), ops.pack_prob_table(wp.to(dev)),
+                               in_bound=x_cl.abs().amax().reshape(1), w_inv_scale=winv).cpu()
+    err_h = (got_h.double() - want64).abs().max().item()
+    assert err_h <= 1.5 * err32 + 2 * ulp, (err_h, err32)
     # and equal to the two separate product kernels to fp32 rounding (different summation order in prob)
     ysep = ops.deconv3d_sbf(x.permute(1, 2, 3, 0).contiguous().to(dev), ops.split_pack_deconv3d(w11.to(dev)), b11.to(dev), 8,
                             skip=skip.permute(1, 2, 3, 0).contiguous().to(dev), out_planar=True)
