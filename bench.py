@@ -748,12 +748,13 @@ def main():
         import cds_mvsnet_amd.model as cm
         tf = fl / (kern["costreg"] * 1e-3) / 1e12
         act = costreg_min_bytes(h, w, D, C)
+        # split-f16 (round 6): 3 fp16 MFMAs per fp32-equivalent product set -> 2.5 PFLOP/s / 3; split-bf16: 6 -> / 6; exact path: the fp32 pipes
+        nprod = 3.0 if ops.USE_SPLIT_F16 else 6.0
         extra["roofline_costreg"] = {
-            # split-bf16: 6 bf16 MFMAs per fp32-equivalent product set -> 2.5 PFLOP/s / 6; exact path: the fp32 pipes
-            "bound": "mfma bf16 / 6 (split-bf16) and hbm" if cm.USE_SPLIT_BF16 else "fp32",
+            "bound": (f"mfma {'f16 / 3 (split-f16)' if ops.USE_SPLIT_F16 else 'bf16 / 6 (split-bf16)'} and hbm") if cm.USE_SPLIT_BF16 else "fp32",
             "achieved": tf, "unit": "TFLOP/s (fp32-equivalent algorithmic flops)",
-            "peak": (2500.0 / 6.0) if cm.USE_SPLIT_BF16 else FP32_PEAK / 1e12,
-            "frac": tf / ((2500.0 / 6.0) if cm.USE_SPLIT_BF16 else FP32_PEAK / 1e12),
+            "peak": (2500.0 / nprod) if cm.USE_SPLIT_BF16 else FP32_PEAK / 1e12,
+            "frac": tf / ((2500.0 / nprod) if cm.USE_SPLIT_BF16 else FP32_PEAK / 1e12),
             "frac_of_fp32_peak": tf / (FP32_PEAK / 1e12), "kernel_ms": kern["costreg"], "flops": fl,
             "min_activation_bytes": act, "activation_gbs": act / (kern["costreg"] * 1e-3) / 1e9,
             "frac_of_hbm_peak": act / (kern["costreg"] * 1e-3) / HBM_PEAK}
@@ -785,9 +786,15 @@ def main():
             "config": {"workload": workload_desc,
                        "parallelism": (args.parallelism if kind != "train" else "data-parallel") if world > 1 else "single",
                        "depth_maps_per_step_per_gpu": args.streams, "depth_mean": depth_mean,
-                       "costreg_arithmetic": ("split-bf16: every fp32 operand split exactly into 3 bf16 terms, 6 error-compensated "
-                                              "partial products on v_mfma_f32_16x16x32_bf16, fp32 accumulate (error vs float64 <= the "
-                                              "exact-fp32 fmaf-chain kernels'; CDS_CONV_EXACT=1 selects those)"
+                       "costreg_arithmetic": (("split-f16: every fp32 operand as 2 fp16 terms of (operand x power-of-two tensor scale; the "
+                                               "scale from the producing kernel's measured max), 3 partial products on "
+                                               "v_mfma_f32_16x16x32_f16, fp32 accumulate, exact rescaling (22 of 24 significand bits per operand: "
+                                               "error vs float64 0.45-0.82x an fp32 convolution's own on every layer shape tested, "
+                                               "tests/test_hip_parity.py; CDS_SPLIT_F16=0: split-bf16, CDS_CONV_EXACT=1: exact fp32)"
+                                               if ops.USE_SPLIT_F16 else
+                                               "split-bf16: every fp32 operand split exactly into 3 bf16 terms, 6 error-compensated "
+                                               "partial products on v_mfma_f32_16x16x32_bf16, fp32 accumulate (error vs float64 <= the "
+                                               "exact-fp32 fmaf-chain kernels'; CDS_CONV_EXACT=1 selects those)")
                                               if __import__("cds_mvsnet_amd.model", fromlist=["x"]).USE_SPLIT_BF16
                                               else "exact fp32 (fmaf chains on the fp32 matrix / vector pipes)")},
             "roofline": roof, "cpu_baseline": cpu, "build": build_id(),
