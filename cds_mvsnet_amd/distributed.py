@@ -313,7 +313,11 @@ class ViewShard:
     # ---- one stage on this rank's views (GPU) --------------------------------------------------
     def run_stage(self, model, ref: Optional[Tensor], src: Optional[Tensor], ref_nc: Optional[Tensor],
                   nc_sums: Optional[Tensor], mats: Optional[Tensor], hyp: Tensor, stage_idx: int, n_src_total: int,
-                  C: Optional[int] = None):
+                  C: Optional[int] = None, vol_bound: Optional[Tensor] = None):
+        """vol_bound: a device scalar >= max |normalised volume| over ALL views of all ranks (the model passes 1: tanh features) - the
+        all-reduce / p2p exchanges then run CostRegNet in split-f16 arithmetic like the unsharded forward (same bound on every rank: same
+        result on every rank); None, and always for the row-slab forms (a rank's halo rows come from a neighbour whose maximum it does
+        not know): split-bf16."""
         D, h, w = hyp.shape
         if ref is not None:
             C = ref.shape[1]
@@ -340,7 +344,7 @@ class ViewShard:
         if self.keep_volume:
             self.last_volume = vol.permute(3, 0, 1, 2) if cl else vol
         if cl:
-            depth, conf = cr.regress(vol, hyp)
+            depth, conf = cr.regress(vol, hyp, bound=vol_bound)
         else:
             depth, conf = ops.softargmin_conf(cr(vol), hyp)
         return depth, conf, nc_sum / n_src_total

@@ -1109,7 +1109,8 @@ class CDSMVSNet(nn.Module):
             # FeatureNet's stage outputs are tanh outputs: |feature| < 1, so 1 bounds the normalised volume (no reduction launches)
             return self.stage_net.run_single(ref, src, ref_nc, nc_sums, mats, hyp, self.cost_regularization[s], s,
                                              vol_bound=_unit_bound(ref.device))
-        return sh.run_stage(self, ref, src, ref_nc, nc_sums, mats, hyp, s, V_total, C=self.feature.out_channels[s])
+        return sh.run_stage(self, ref, src, ref_nc, nc_sums, mats, hyp, s, V_total, C=self.feature.out_channels[s],
+                            vol_bound=_unit_bound(hyp.device))
 
 
 def _resize_nearest(img: Tensor, H: int, W: int) -> Tensor:
