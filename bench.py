@@ -242,7 +242,13 @@ def other_workloads(model, dev):
     # next step's geometry while the GPU trains
     hsample = dict(sample, proj_matrices={k: v.cpu() for k, v in sample["proj_matrices"].items()}, depth_values=sample["depth_values"].cpu())
     out["T5_train_step_768x576_N5_fp32_graph_deferred_loss_ms"] = min(timeit(lambda: cstep(hsample, 0.1), n=5, warm=1) for r in range(2))
-    del tmodel, opt, sample, cstep, hsample
+    # the bf16-storage policy under the same capture (GPU-bound there: fewer stored bytes can show)
+    tmodel2 = seeded_init_(CDSMVSNet(refine=refine5, ndepths=NDEPTHS, depth_interals_ratio=RATIOS), 0).to(dev)
+    opt2 = T.make_optimizer(tmodel2)
+    cstep2 = T.CapturedTrainStep(tmodel2, opt2, activation_storage="bf16")
+    out["T5_train_step_768x576_N5_bf16storage_graph_ms"] = min(timeit(lambda: float(cstep2(sample, 0.1)[0]), n=5, warm=4 if r == 0 else 0)
+                                                              for r in range(2))
+    del tmodel, opt, sample, cstep, hsample, tmodel2, opt2, cstep2
     res = {k: round(v, 3) for k, v in out.items()}
     res["M3_K3_roofline_by_stage"] = k3
     return res

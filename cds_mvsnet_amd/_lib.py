@@ -84,6 +84,7 @@ SIGNATURES = {
     "cds_blend_cl_parts": [I, I],
     "cds_dynconv_blend_cl_f32": [P, P, P, P, P, F, P, P, P, I, I, I, I, I, I, P],
     "cds_conv2d_k3s2_cl_f32": [P, P, P, P, I, I, I, I, I, P],
+    "cds_conv2d_k3s2_cl_sf16_f32": [P, P, P, P, I, I, I, I, I, F, F, P],
     "cds_fpn_cl_parts": [I, I],
     "cds_conv2d_fpn_cl_f32": [P, P, P, P, P, P, P, I, I, I, I, I, I, P],
     "cds_vis_layer1_cl_f32": [P, P, P, P, P, I, I, I, P],

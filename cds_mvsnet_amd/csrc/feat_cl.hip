@@ -1043,6 +1043,163 @@ __global__ __launch_bounds__(256) void vis_layer1_cl_kernel(const float* __restr
                              fmaxf(acc[c + 3] + bias[c + 3], 0.f));
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// The stride-2 units (downsample1 8 -> 16, downsample2 16 -> 32; module.py:213,217) on the MATRIX CORES in split-f16 arithmetic (round
+// 6; the VALU kernel above was 0.63 ms per 1600x1184 forward at 25 TFLOP/s).  A workgroup owns 32 x 4 OUTPUT pixels: wave = output row,
+// two 16-pixel x-runs per wave; it stages the 65 x 9 input texels (+ 1 pad column) of all channels once - normalise-on-load (the
+// producer's InstanceNorm + LeakyReLU), two fp16 terms of value x xs (xs from the bound sqrt(H W) of an InstanceNorm-ed map: host
+// number), 48-byte positions as everywhere (term slot 2 unused): the A operand of lane (m, g) is the input texel 2 (16 q + m) + kx of row
+// 2 wave + ky for tap 4 t + g - a 96-byte lane stride, conflict-free for the eight lanes an LDS cycle serves.  B = weights from
+// ops.split_pack_dynconv([w], f16=True) (tap-major K-steps: 3 per 8-channel round, 3 of 12 tap slots zero).  Epilogue: exact rescaling,
+// transposition through LDS, 16-byte channels-last stores (raw convolution result: its InstanceNorm statistics are the next launch's).
+// ---------------------------------------------------------------------------------------------------------------------------
+template <int CIN, int COUT>
+struct S2M {
+  static constexpr int TXO = 32, TYO = 4;
+  static constexpr int IX = 2 * TXO + 1, IY = 2 * TYO + 1, IXP = IX + 1, NPOS = IXP * IY;
+  static constexpr int ROUNDS = CIN / 8, NBLK = COUT / 16, C4 = CIN / 4;
+  static constexpr int PLANE = NPOS * POSB;
+  static constexpr int NCH = NPOS * C4, NIT = (NCH + 255) / 256, PSTEP = 256 / C4;
+  static constexpr int TP = 20;
+  static constexpr int TRB = 4 * 2 * NBLK * 16 * TP * 4;      // [wave][q][block][16 px][TP] floats
+  static constexpr int LDSB = cmax(ROUNDS * PLANE, TRB);
+};
+
+template <int CIN, int COUT>
+__global__ __launch_bounds__(256, 2) void conv2d_k3s2_mfma_cl_kernel(const float* __restrict__ x, const float* __restrict__ affine,
+                                                                     const uint4* __restrict__ wsp, float* __restrict__ out, int H, int W,
+                                                                     int Ho, int Wo, int tiles_x, int tiles_y, int N, float xs, float omul) {
+  using C = S2M<CIN, COUT>;
+  constexpr int IXP = C::IXP, NBLK = C::NBLK;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  int lin = cds_xcd_remap(blockIdx.x, tiles_x * tiles_y * N);
+  const int tx_i = lin % tiles_x;
+  lin /= tiles_x;
+  const int ty_i = lin % tiles_y, img = lin / tiles_y;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m = lane & 15, g = lane >> 4;
+  const int ox0 = tx_i * C::TXO, oy0 = ty_i * C::TYO;
+  const int ix0 = 2 * ox0 - 1, iy0 = 2 * oy0 - 1;             // input texel of staged position (0, 0)
+  {
+    const int c4 = tid % C::C4;
+    float al[4], be[4], sl[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      al[j] = 1.f; be[j] = 0.f; sl[j] = 1.f;
+    }
+    if (affine) {
+      const float* __restrict__ af = affine + ((size_t)img * CIN + c4 * 4) * 3;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        al[j] = af[3 * j]; be[j] = af[3 * j + 1]; sl[j] = af[3 * j + 2];
+      }
+    }
+    float4 v[C::NIT];
+    unsigned okmask = 0;
+#pragma unroll
+    for (int i = 0; i < C::NIT; ++i) {
+      const int pos = tid / C::C4 + i * C::PSTEP;
+      const int row = pos / IXP, col = pos - row * IXP;
+      const int gy = iy0 + row, gx = ix0 + col;
+      const bool ok = pos < C::NPOS && col < C::IX && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+      v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ok) {
+        v[i] = *reinterpret_cast<const float4*>(x + (((size_t)img * H + gy) * W + gx) * CIN + c4 * 4);
+        okmask |= 1u << i;
+      }
+    }
+    unsigned char* dst0 = lds + (c4 >> 1) * C::PLANE + (c4 & 1) * 8;
+#pragma unroll
+    for (int i = 0; i < C::NIT; ++i) {
+      const int pos = tid / C::C4 + i * C::PSTEP;
+      if (pos >= C::NPOS) break;
+      float4 t = v[i];
+      if (okmask & (1u << i)) {            // zero padding follows the normalisation
+        float a;
+        a = fmaf(t.x, al[0], be[0]); t.x = a > 0.f ? a : a * sl[0];
+        a = fmaf(t.y, al[1], be[1]); t.y = a > 0.f ? a : a * sl[1];
+        a = fmaf(t.z, al[2], be[2]); t.z = a > 0.f ? a : a * sl[2];
+        a = fmaf(t.w, al[3], be[3]); t.w = a > 0.f ? a : a * sl[3];
+      }
+      uint32_t h0, l0, h1, l1;
+      split2_f16(t.x, t.y, xs, h0, l0);
+      split2_f16(t.z, t.w, xs, h1, l1);
+      unsigned char* d = dst0 + pos * POSB;
+      *reinterpret_cast<uint2*>(d) = make_uint2(h0, h1);
+      *reinterpret_cast<uint2*>(d + 16) = make_uint2(l0, l1);
+    }
+  }
+  __syncthreads();
+
+  f32x4 acc[NBLK][2];
+#pragma unroll
+  for (int nb = 0; nb < NBLK; ++nb)
+#pragma unroll
+    for (int q = 0; q < 2; ++q) acc[nb][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const uint4* __restrict__ wl = wsp + lane;
+#pragma unroll
+  for (int rd = 0; rd < C::ROUNDS; ++rd) {
+    const uint4* __restrict__ wr = wl + (size_t)rd * 3 * NBLK * 3 * 64;
+    const unsigned char* __restrict__ lp = lds + rd * C::PLANE;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      int tap = 4 * t + g;
+      if (tap > 8) tap = 8;                               // padded tap slots carry zero weights: any staged position
+      const int ky = tap / 3, kx = tap - ky * 3;
+      const unsigned char* ap = lp + ((2 * wave + ky) * IXP + 2 * m + kx) * POSB;
+      BV wh[NBLK], wlo[NBLK], ah[2], alo[2];
+#pragma unroll
+      for (int nb = 0; nb < NBLK; ++nb) {
+        const uint4* p = wr + (size_t)((t * NBLK + nb) * 3) * 64;
+        wh[nb].u = p[0];
+        wlo[nb].u = p[64];
+      }
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const unsigned char* a = ap + q * 32 * POSB;
+        ah[q].u = *reinterpret_cast<const uint4*>(a);
+        alo[q].u = *reinterpret_cast<const uint4*>(a + 16);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int nb = 0; nb < NBLK; ++nb) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) SF16_MFMA(acc[nb][q], alo[q], wh[nb]);    // lo x hi
+#pragma unroll
+        for (int q = 0; q < 2; ++q) SF16_MFMA(acc[nb][q], ah[q], wlo[nb]);    // hi x lo
+#pragma unroll
+        for (int q = 0; q < 2; ++q) SF16_MFMA(acc[nb][q], ah[q], wh[nb]);     // hi x hi
+      }
+    }
+  }
+  __syncthreads();                                             // every wave is done with the staged tile: it becomes the transposition area
+  // lane (m, g) holds output channel 16 nb + m of pixels x = 16 q + 4 g + i: through LDS to 4 consecutive channels of one pixel per lane
+  float* trL = reinterpret_cast<float*>(lds) + wave * (2 * NBLK * 16 * C::TP);
+#pragma unroll
+  for (int nb = 0; nb < NBLK; ++nb)
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const f32x4 a = acc[nb][q] * omul;
+      const float v[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) trL[((q * NBLK + nb) * 16 + g * 4 + i) * C::TP + m] = v[i];
+    }
+  wave_lds_fence();
+  const int oy = oy0 + wave;
+  if (oy < Ho) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int ox = ox0 + q * 16 + m;
+      if (ox >= Wo) continue;
+      float* __restrict__ op = out + (((size_t)img * Ho + oy) * Wo + ox) * COUT;
+#pragma unroll
+      for (int nb = 0; nb < NBLK; ++nb)
+        *reinterpret_cast<float4*>(op + nb * 16 + 4 * g) = *reinterpret_cast<const float4*>(trL + ((q * NBLK + nb) * 16 + m) * C::TP + 4 * g);
+    }
+  }
+}
+
 }  // namespace
 
 // Visibility CNN on channels-last activations (models/model.py:14,51).
@@ -1201,6 +1358,34 @@ extern "C" int cds_conv2d_k3s2_cl_f32(const float* x, const float* in_affine, co
     hipLaunchKernelGGL((conv2d_k3s2_cl_kernel<16, 32>), grid, dim3(256), 0, st, x, in_affine, weight, out, H, W, Ho, Wo);
   else
     return CDS_EINVAL;
+  return cds_launch_status();
+}
+
+// The same layer on the matrix cores in split-f16 arithmetic: weight_split from ops.split_pack_dynconv([w [Cout,Cin,3,3]], f16=True),
+// w_inv_scale = 1 / its weight scale, x_bound a HOST number >= max |input after its affine + LeakyReLU| (sqrt(H W) for an InstanceNorm-ed map).
+extern "C" int cds_conv2d_k3s2_cl_sf16_f32(const float* x, const float* in_affine, const void* weight_split, float* out, int N, int Cin,
+                                           int Cout, int H, int W, float x_bound, float w_inv_scale, void* stream) {
+  if (!x || !weight_split || !out || N < 1 || H < 1 || W < 1 || !(x_bound > 0.f) || !(w_inv_scale > 0.f)) return CDS_EINVAL;
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  int e = 0;
+  (void)frexpf(x_bound, &e);
+  e = e > 100 ? 100 : (e < -100 ? -100 : e);
+  const float xs = ldexpf(1.0f, 15 - e), omul = w_inv_scale / xs;
+  hipStream_t st = (hipStream_t)stream;
+  const uint4* wsp = reinterpret_cast<const uint4*>(weight_split);
+  if (Cin == 8 && Cout == 16) {
+    using C = S2M<8, 16>;
+    const int tx = cds_ceil_div(Wo, C::TXO), ty = cds_ceil_div(Ho, C::TYO);
+    hipLaunchKernelGGL((conv2d_k3s2_mfma_cl_kernel<8, 16>), dim3(tx * ty * N), dim3(256), (size_t)C::LDSB, st, x, in_affine, wsp, out, H, W,
+                       Ho, Wo, tx, ty, N, xs, omul);
+  } else if (Cin == 16 && Cout == 32) {
+    using C = S2M<16, 32>;
+    const int tx = cds_ceil_div(Wo, C::TXO), ty = cds_ceil_div(Ho, C::TYO);
+    hipLaunchKernelGGL((conv2d_k3s2_mfma_cl_kernel<16, 32>), dim3(tx * ty * N), dim3(256), (size_t)C::LDSB, st, x, in_affine, wsp, out, H, W,
+                       Ho, Wo, tx, ty, N, xs, omul);
+  } else {
+    return CDS_EINVAL;
+  }
   return cds_launch_status();
 }
 

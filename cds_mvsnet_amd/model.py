@@ -539,6 +539,8 @@ class _FeatureRunner:
         for name in ("downsample1", "downsample2"):
             w = getattr(net, name).conv.weight.detach()
             out[f"{name}.w9"] = w.permute(2, 3, 1, 0).reshape(9, w.shape[1], w.shape[0]).contiguous()
+            if ops.USE_SPLIT_F16 and w.is_cuda and (w.shape[1], w.shape[0]) in ((8, 16), (16, 32)):
+                out[f"{name}.wh"], out[f"{name}.whs"] = ops.split_pack_dynconv([w], f16=True)      # the matrix-core form (split-f16)
         for name in ("inner1", "inner2"):
             w = getattr(net, name).conv.weight.detach()
             out[f"{name}.wt"] = w.reshape(w.shape[0], w.shape[1]).t().contiguous()
@@ -695,6 +697,10 @@ class _FeatureRunner:
                                   p[f"{name}.m2"], epi, T, 0.1, in_affine=aff)
 
         def down(name: str, x: Tensor, aff: Tensor):
+            if ops.USE_SPLIT_F16 and f"{name}.wh" in p and aff is not None:
+                y = ops.conv2d_k3s2_cl(x, None, getattr(net, name).conv.out_channels, aff, wsplit=p[f"{name}.wh"],
+                                       w_inv_scale=p[f"{name}.whs"], x_bound=float(x.shape[1] * x.shape[2]) ** 0.5)
+                return y, ops.instnorm_stats_cl(y, 0.1)[1]
             y = ops.conv2d_k3s2_cl(x, p[f"{name}.w9"], getattr(net, name).conv.out_channels, aff)
             return y, ops.instnorm_stats_cl(y, 0.1)[1]
 

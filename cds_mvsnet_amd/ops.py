@@ -1164,10 +1164,23 @@ def instnorm_stats_cl(x_cl: Tensor, slope: float = 0.1):
     return _reduce_records(partial, N, C, H, W, slope)
 
 
-def conv2d_k3s2_cl(x_cl: Tensor, w9: Tensor, cout: int, in_affine: Optional[Tensor] = None) -> Tensor:
+def conv2d_k3s2_cl(x_cl: Tensor, w9: Optional[Tensor], cout: int, in_affine: Optional[Tensor] = None, wsplit: Optional[Tensor] = None,
+                   w_inv_scale: float = 1.0, x_bound: Optional[float] = None) -> Tensor:
     """3x3, stride 2, pad 1, no bias on channels-last activations: x_cl [N,H,W,Cin] (+ pending affine), w9 [9,Cin,cout] ->
-    [N,Ho,Wo,cout]."""
+    [N,Ho,Wo,cout].  wsplit / w_inv_scale / x_bound given: the matrix-core kernel in split-f16 arithmetic (cds_conv2d_k3s2_cl_sf16_f32;
+    wsplit from split_pack_dynconv([w [cout,Cin,3,3]], f16=True), x_bound a number >= max |input after its affine|)."""
     N, H, W, Cin = x_cl.shape
+    if wsplit is not None:
+        if x_bound is None or (Cin, cout) not in ((8, 16), (16, 32)) or wsplit.dtype != torch.int16 or \
+                wsplit.numel() != (Cin // 8) * 3 * (cout // 16) * 3 * 64 * 8:
+            raise ValueError("conv2d_k3s2_cl: the split-f16 form needs x_bound, (Cin, cout) in ((8, 16), (16, 32)) and split_pack_dynconv's tensor")
+        if in_affine is not None and tuple(in_affine.shape) != (N, Cin, 3):
+            raise ValueError(f"conv2d_k3s2_cl: in_affine must be [{N},{Cin},3]")
+        out = torch.empty((N, (H - 1) // 2 + 1, (W - 1) // 2 + 1, cout), dtype=torch.float32, device=x_cl.device)
+        check(_lib.load().cds_conv2d_k3s2_cl_sf16_f32(_dev(x_cl, "x"), _dev(in_affine, "in_affine") if in_affine is not None else None,
+                                                      wsplit.data_ptr(), out.data_ptr(), N, Cin, cout, H, W, float(x_bound),
+                                                      float(w_inv_scale), _stream(x_cl)), "cds_conv2d_k3s2_cl_sf16_f32")
+        return out
     if tuple(w9.shape) != (9, Cin, cout):
         raise ValueError(f"conv2d_k3s2_cl: weight must be [9,{Cin},{cout}], got {tuple(w9.shape)}")
     if in_affine is not None and tuple(in_affine.shape) != (N, Cin, 3):

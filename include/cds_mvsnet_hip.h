@@ -461,6 +461,11 @@ int cds_dynconv_blend_cl_f32(const float* branches, const float* w1, const float
                              int n_shared, void* stream);
 int cds_conv2d_k3s2_cl_f32(const float* x, const float* in_affine, const float* weight, float* out, int N, int Cin, int Cout, int H,
                            int W, void* stream);
+/* The stride-2 units on the matrix cores in SPLIT-F16 arithmetic (round 6): weight_split from ops.split_pack_dynconv([w [Cout,Cin,3,3]],
+ * f16=True), w_inv_scale = 1 / its weight scale, x_bound a HOST number >= max |input after its affine + LeakyReLU|. */
+int cds_conv2d_k3s2_cl_sf16_f32(const float* x, const float* in_affine, const void* weight_split, float* out, int N, int Cin, int Cout,
+                                int H, int W, float x_bound, float w_inv_scale, void* stream);
+
 int cds_fpn_cl_parts(int H, int W);
 int cds_conv2d_fpn_cl_f32(const float* coarse, const float* coarse_affine, const float* skip, const float* skip_affine,
                           const float* weight, float* out, double* partial, int N, int Ca, int Cb, int Cout, int H, int W,

@@ -85,6 +85,13 @@ def conv3d_f16_setup(cin, cout, code, D, H, W):
     b = torch.randn(cout, generator=g).to(dev)
     bound = x.abs().amax().reshape(1)
     return lambda: ops.conv3d_sbf(x, wh, b, cout, stride=code, in_bound=bound, w_inv_scale=winv)
+def down_f16_setup(cin, cout, N, H, W):
+    xcl = torch.randn(N, H, W, cin, generator=g).to(dev)
+    aff = torch.stack((0.5 + torch.rand(N, cin, generator=g), 0.3 * torch.randn(N, cin, generator=g), torch.full((N, cin), 0.1)), -1).to(dev).contiguous()
+    wh, winv = ops.split_pack_dynconv([(torch.randn(cout, cin, 3, 3, generator=g) / (9 * cin) ** 0.5).to(dev)], f16=True)
+    return lambda: ops.conv2d_k3s2_cl(xcl, None, cout, aff, wsplit=wh, w_inv_scale=winv, x_bound=(H * W) ** 0.5)
+aggr["f16 cl downsample1"] = down_f16_setup(8, 16, N, 592, 800)
+aggr["f16 cl downsample2"] = down_f16_setup(16, 32, N, 296, 400)
 aggr["f16 conv3d 8->8 pair"] = conv3d_f16_setup(8, 8, ops.SBF_PAIR, 48, 296, 400)
 aggr["f16 conv3d 16->16"] = conv3d_f16_setup(16, 16, 1, 24, 148, 200)
 aggr["f16 conv3d 32->32"] = conv3d_f16_setup(32, 32, 1, 24, 148, 200)

@@ -85,7 +85,8 @@ def test_blend_cl_equals_planar_blend(N, n_shared, H, W, dev, ops):
         assert torch.allclose(s1, s2, rtol=1e-10, atol=1e-8) and torch.allclose(a1, a2, rtol=1e-5, atol=1e-6)
 
 
-@pytest.mark.parametrize("cin,cout,N,H,W", [(8, 16, 2, 20, 36), (16, 32, 3, 14, 22), (8, 16, 1, 7, 9), (16, 32, 1, 32, 64)])
+@pytest.mark.parametrize("cin,cout,N,H,W", [(8, 16, 2, 20, 36), (16, 32, 3, 14, 22), (8, 16, 1, 7, 9), (16, 32, 1, 32, 64), (8, 16, 2, 70, 133),
+                                            (16, 32, 2, 41, 67)])
 def test_downsample_cl_vs_planar(cin, cout, N, H, W, dev, ops):
     """cds_conv2d_k3s2_cl_f32 against cds_conv2d_affine_f32 (k 3, stride 2, pad 1) and float64; statistics pass against
     cds_instnorm_affine_f32."""
@@ -105,6 +106,14 @@ def test_downsample_cl_vs_planar(cin, cout, N, H, W, dev, ops):
     e_new = (new.permute(0, 3, 1, 2).cpu().double() - want).abs().max().item()
     e_old = (old.cpu().double() - want).abs().max().item()
     assert e_new <= 1.5 * e_old + want.abs().max().item() * 2.0 ** -22, (e_new, e_old)
+    # round 6: the same layer on the matrix cores in split-f16 arithmetic (what FeatureNet runs): fp32-class against float64, with the
+    # tight bound and with the loose one the model uses (sqrt(H W) of an InstanceNorm-ed map; here the input is not normalised: 8 x max)
+    wh, winv = ops.split_pack_dynconv([w.to(dev)], f16=True)
+    for bound in (float(xn.abs().max()), 8.0 * float(xn.abs().max())):
+        mf = ops.conv2d_k3s2_cl(_cl(x.to(dev)), None, cout, aff.to(dev), wsplit=wh, w_inv_scale=winv, x_bound=bound)
+        assert tuple(mf.shape) == tuple(new.shape)
+        e_mf = (mf.permute(0, 3, 1, 2).cpu().double() - want).abs().max().item()
+        assert e_mf <= 1.5 * e_old + want.abs().max().item() * 2.0 ** -22, (bound, e_mf, e_old)
     st, a_new = ops.instnorm_stats_cl(new, 0.1)
     a_old = ops.instnorm_affine(new.permute(0, 3, 1, 2).contiguous(), 0.1)
     assert torch.allclose(a_new, a_old, rtol=1e-5, atol=1e-6)
