@@ -95,7 +95,11 @@ __device__ __forceinline__ void wave_lds_fence() {
 template <class C>
 __device__ __forceinline__ void dyn_epilogue(f32x4 (&acc)[C::NBR][C::NBLK][4], unsigned char* lds, const float* __restrict__ bias,
                                              const DynEpi& ep, int img, int H, int W, int ox0, int oy0, int wave, int m, int g, int tid,
-                                             int tile, int parts) {
+                                             int tile, int parts, const float* mlp_w1, const float* mlp_b1, const float* mlp_w2,
+                                             float epi_x, float epi_y) {
+  // mlp_* / epi_*: the attention MLP and this image's epipole, handed in by the caller: conv00 runs this epilogue once per reference copy
+  // and keeps them in REGISTERS across the copies - read from memory inside, every later epilogue's loads were vector loads behind the
+  // previous one's output stores, and on gfx9's single vmcnt the wait for them drained those stores (round 6: ~4 000 cycles per epilogue)
   constexpr int NBR = C::NBR, NBLK = C::NBLK, NCB = C::NCB, Cout = C::COUT, Co3 = C::CO3, CIN = C::COUT;
   // every exchange below stays inside ONE wave (a wave blends the 64 pixels it convolved): each wave has its own LDS region and orders
   // its writes and reads with wave-level fences; only the tile hand-over and the four waves' statistics need workgroup barriers
@@ -126,10 +130,19 @@ __device__ __forceinline__ void dyn_epilogue(f32x4 (&acc)[C::NBR][C::NBLK][4], u
     for (int b = 0; b < NBR; ++b)
 #pragma unroll
       for (int j = 0; j < 3; ++j) att[b][j] = attL[(b * 3 + j) * 64 + wp];
-    const float nc = blend_from_att<NBR>(att, px, py, ep.epi[2 * img], ep.epi[2 * img + 1], ep.w1, ep.b1, ep.w2, ep.temperature, logit);
+#ifndef CDS_PROBE_EPI
+#define CDS_PROBE_EPI 0      // probe builds of the epilogue (wrong results, right timing): 1 = no fp64 statistics, 2 = no per-pixel blend weights
+#endif
+#if CDS_PROBE_EPI == 2
+    float nc = att[0][0];
+#pragma unroll
+    for (int b = 0; b < NBR; ++b) logit[b] = att[b][1];
+#else
+    const float nc = blend_from_att<NBR>(att, px, py, epi_x, epi_y, mlp_w1, mlp_b1, mlp_w2, ep.temperature, logit);
+#endif
 #pragma unroll
     for (int b = 0; b < NBR; ++b) wL[b * 64 + wp] = logit[b];
-    if (px < W && py < H) ep.norm_curv[((size_t)img * H + py) * W + px] = nc;
+    if (px < W && py < H && CDS_PROBE_EPI != 3) ep.norm_curv[((size_t)img * H + py) * W + px] = nc;
   }
   wave_lds_fence();
   float4 wq[NBR][4];
@@ -165,7 +178,7 @@ __device__ __forceinline__ void dyn_epilogue(f32x4 (&acc)[C::NBR][C::NBLK][4], u
         o[i] = sacc;
         trL[((q * NCB + nb) * 16 + g * 4 + i) * C::TP + m] = sacc;      // pixel row 4 g + i, channel column m
       }
-      if (col && oy < H) {
+      if (col && oy < H && CDS_PROBE_EPI != 1) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
           if (ox + i < W) {
@@ -190,7 +203,7 @@ __device__ __forceinline__ void dyn_epilogue(f32x4 (&acc)[C::NBR][C::NBLK][4], u
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int oy = oy0 + wave * 2 + (q >> 1), ox = ox0 + (q & 1) * 16 + m;
-    if (oy >= H || ox >= W) continue;
+    if (oy >= H || ox >= W || CDS_PROBE_EPI == 3) continue;
     float* __restrict__ op = ep.out + (((size_t)img * H + oy) * W + ox) * CIN;
 #pragma unroll
     for (int nb = 0; nb < NCB; ++nb) {
@@ -425,7 +438,8 @@ __global__ __launch_bounds__(256, 2) void dynconv_cl_kernel(const float* __restr
     }
     return;
   }
-  dyn_epilogue<C>(acc, lds, bias, ep, img, H, W, ox0, oy0, wave, m, g, tid, ty_i * tiles_x + tx_i, tiles_x * tiles_y);
+  dyn_epilogue<C>(acc, lds, bias, ep, img, H, W, ox0, oy0, wave, m, g, tid, ty_i * tiles_x + tx_i, tiles_x * tiles_y, ep.w1, ep.b1, ep.w2,
+                  ep.epi[2 * img], ep.epi[2 * img + 1]);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -449,6 +463,9 @@ struct C00 {
   static constexpr int nks(int k) { return (k * pairs(k) + 3) / 4; }
 };
 
+#ifndef CDS_PROBE_C00
+#define CDS_PROBE_C00 0      // probe builds (wrong results, right timing; profiles/r06_experiments.md): 1 = one epilogue per slot, 2 = no K-loop
+#endif
 template <bool F16>      // split-f16 arithmetic: the images' scale from a device bound (in_bound >= max |x|), weights x w_scale
 __global__ __launch_bounds__(256, 2) void conv00_cl_kernel(const float* __restrict__ x, const uint4* __restrict__ wsp,
                                                            const float* __restrict__ bias, DynEpi ep, int S, int n_shared, int H, int W,
@@ -531,7 +548,7 @@ __global__ __launch_bounds__(256, 2) void conv00_cl_kernel(const float* __restri
     const int k = C::KS[b], rk = (k - 1) >> 1, np = C::pairs(k), npairs = k * np, nks = C::nks(k);
     const uint4* __restrict__ wb = wl + (size_t)ks0 * 3 * 64;
 #pragma unroll 1
-    for (int t = 0; t < nks; ++t) {
+    for (int t = 0; t < (CDS_PROBE_C00 == 2 ? 1 : nks); ++t) {
       int pi = 4 * t + g;
       if (pi >= npairs) pi = npairs - 1;                        // padded pair: zero weights, any in-tile data
       const int ky = pi / np, kxp = pi - ky * np;
@@ -590,9 +607,24 @@ __global__ __launch_bounds__(256, 2) void conv00_cl_kernel(const float* __restri
       for (int q = 0; q < 4; ++q) acc[b][0][q] = acc[b][0][q] * omul;
   }
   // output images of this slot: the n_shared reference copies for slot 0, one image otherwise
-  const int first = slot == 0 ? 0 : slot + n_shared - 1, count = slot == 0 ? n_shared : 1;
-  for (int i = 0; i < count; ++i)
-    dyn_epilogue<C>(acc, lds, bias, ep, first + i, H, W, ox0, oy0, wave, m, g, tid, ty_i * tiles_x + tx_i, tiles_x * tiles_y);
+  const int first = slot == 0 ? 0 : slot + n_shared - 1, count = (slot == 0 && CDS_PROBE_C00 != 1) ? n_shared : 1;
+  // the attention MLP (28 floats) and the epipoles of this slot's output images: loaded ONCE, before the first epilogue's stores
+  float mw1[4 * NBR], mb1[4], mw2[NBR * 4];
+#pragma unroll
+  for (int q = 0; q < 4 * NBR; ++q) {
+    mw1[q] = ep.w1[q];
+    mw2[q] = ep.w2[q];
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) mb1[q] = ep.b1[q];
+  const int eimg = first + min(lane, count - 1);               // lane i holds the epipole of output image first + i (count <= 64)
+  const float exl = ep.epi[2 * eimg], eyl = ep.epi[2 * eimg + 1];
+  for (int i = 0; i < count; ++i) {
+    const float ex = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(exl), i));
+    const float ey = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(eyl), i));
+    dyn_epilogue<C>(acc, lds, bias, ep, first + i, H, W, ox0, oy0, wave, m, g, tid, ty_i * tiles_x + tx_i, tiles_x * tiles_y, mw1, mb1, mw2,
+                    ex, ey);
+  }
 }
 
 template <int CIN, int K0, int K1, int K2, int MODE = 1, bool F16 = false>
