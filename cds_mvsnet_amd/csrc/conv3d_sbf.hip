@@ -98,6 +98,10 @@ __global__ __launch_bounds__((FCfg<S, MB, TX_, TZ_, PAIR, WRES_>::THREADS)) void
                                                             float* __restrict__ out_bound) {
   using Cfg = FCfg<S, MB, TX_, TZ_, PAIR, WRES_>;
   constexpr int NT = F16 ? 2 : 3;                       // terms per operand
+  // cout split (round 6): gridDim.y workgroups share a tile, each computing MB of the layer's mbtot = MB gridDim.y 16-cout blocks.
+  // On the SMALL volumes of the cascade's deep layers a layer is a handful of tiles, each a serial chain of rounds x K-steps x MB
+  // MFMA groups (conv6 at 6 x 16 x 20 voxels: 52 us whatever the size): more, shorter workgroups.  gridDim.y == 1: as before.
+  const int mbtot = MB * (int)gridDim.y, mb0 = MB * (int)blockIdx.y;
   const float xs = F16 ? sf16_scale(in_bound[0]) : 1.0f;
   const float out_mul = F16 ? w_inv / xs : 1.0f;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -203,7 +207,7 @@ __global__ __launch_bounds__((FCfg<S, MB, TX_, TZ_, PAIR, WRES_>::THREADS)) void
   auto load_w_from = [&](const uint4* __restrict__ wrp, int buf, int t) {
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
-      const uint4* p = wrp + (size_t)((t * MB + mb) * 3) * 64;
+      const uint4* p = wrp + (size_t)((t * mbtot + mb0 + mb) * 3) * 64;
       wa[buf][mb][0].u = p[0];
       wa[buf][mb][1].u = p[64];
       if (!F16) wa[buf][mb][2].u = p[128];
@@ -216,9 +220,9 @@ __global__ __launch_bounds__((FCfg<S, MB, TX_, TZ_, PAIR, WRES_>::THREADS)) void
   auto load_w0 = [&](const uint4* __restrict__ wrp) {
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
-      w0[mb][0].u = wrp[(size_t)(mb * 3) * 64];
-      w0[mb][1].u = wrp[(size_t)(mb * 3 + 1) * 64];
-      if (!F16) w0[mb][2].u = wrp[(size_t)(mb * 3 + 2) * 64];
+      w0[mb][0].u = wrp[(size_t)((mb0 + mb) * 3) * 64];
+      w0[mb][1].u = wrp[(size_t)((mb0 + mb) * 3 + 1) * 64];
+      if (!F16) w0[mb][2].u = wrp[(size_t)((mb0 + mb) * 3 + 2) * 64];
     }
   };
   // WRES: every K-step's weights are loaded ONCE.  The consumer waves then issue no vector-memory loads in the stage loop,
@@ -240,7 +244,7 @@ __global__ __launch_bounds__((FCfg<S, MB, TX_, TZ_, PAIR, WRES_>::THREADS)) void
   float4 bvr[MB];                                      // bias of this lane's four couts per 16-cout block
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) {
-    const int co = PAIR ? 4 * (g & 1) : mb * 16 + 4 * g;
+    const int co = PAIR ? 4 * (g & 1) : (mb0 + mb) * 16 + 4 * g;
     bvr[mb] = (bias && co < Cout) ? *reinterpret_cast<const float4*>(bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
   float amax = 0.f;                                    // split-f16: running maximum of the magnitudes this lane stores
@@ -255,11 +259,11 @@ __global__ __launch_bounds__((FCfg<S, MB, TX_, TZ_, PAIR, WRES_>::THREADS)) void
       const unsigned char* tbuf = lds + (st & 1) * Cfg::LDSB;
       // Flat software pipeline over the NS = KSTEPS x (NT / NG) stages of the round: the operands of step s + 1 (data
       // from LDS; the weights of the next K-step from L1 / L2) are requested BEFORE the 6 NG MB MFMAs of step s.
-      const uint4* __restrict__ wr = wl + (size_t)rd * Cfg::KSTEPS * MB * 3 * 64;
+      const uint4* __restrict__ wr = wl + (size_t)rd * Cfg::KSTEPS * mbtot * 3 * 64;
       constexpr int NGRP = Cfg::NTW / Cfg::NG, NS = Cfg::KSTEPS * NGRP;
       BV bd[2][Cfg::NG][3];
       auto load_w = [&](int buf, int t) { load_w_from(wr, buf, t); };
-      const uint4* __restrict__ wnext = wl + (size_t)(rd + 1 < rounds ? rd + 1 : 0) * Cfg::KSTEPS * MB * 3 * 64;
+      const uint4* __restrict__ wnext = wl + (size_t)(rd + 1 < rounds ? rd + 1 : 0) * Cfg::KSTEPS * mbtot * 3 * 64;
       auto load_b = [&](int buf, int t, int grp) {
         const unsigned char* bp = tbuf + b_base + toff[t];
 #pragma unroll
@@ -333,7 +337,7 @@ __global__ __launch_bounds__((FCfg<S, MB, TX_, TZ_, PAIR, WRES_>::THREADS)) void
         if (oy < Ho) {
 #pragma unroll
           for (int mb = 0; mb < MB; ++mb) {
-            const int co = PAIR ? 4 * (g & 1) : mb * 16 + 4 * g;   // PAIR: rows = (x parity g >> 1, cout)
+            const int co = PAIR ? 4 * (g & 1) : (mb0 + mb) * 16 + 4 * g;   // PAIR: rows = (x parity g >> 1, cout)
             if (co >= Cout) continue;                          // Cout % 4 == 0 (host)
             const float4 bv = bvr[mb];
 #pragma unroll
@@ -368,7 +372,8 @@ __global__ __launch_bounds__((FCfg<S, MB, TX_, TZ_, PAIR, WRES_>::THREADS)) void
 
 template <int S, int MB, int TX, int TZ, bool PAIR = false, bool WRES_ = false, bool F16 = false>
 int launch_fwd(const float* x, const void* wsp, const float* b, const float* skip, float* out, int Cin, int Cout, int D, int H,
-               int W, int act, hipStream_t st, const float* in_bound = nullptr, float w_inv = 1.f, float* out_bound = nullptr) {
+               int W, int act, hipStream_t st, const float* in_bound = nullptr, float w_inv = 1.f, float* out_bound = nullptr,
+               int ysplit = 1) {
   using Cfg = FCfg<S, MB, TX, TZ, PAIR, WRES_>;
   static_assert(Cfg::KSTEPS % 2 == 1, "the weight ring assumes an even last K-step");
   static_assert(2 * Cfg::LDSB <= 160 * 1024, "two LDS tile buffers above 160 KB");
@@ -385,7 +390,7 @@ int launch_fwd(const float* x, const void* wsp, const float* b, const float* ski
     static std::atomic<unsigned long long> lds_ok{0};   // per instantiation
     if (int e_lds = cds_allow_lds(reinterpret_cast<const void*>(kern), lds_bytes, lds_ok)) return e_lds;
   }
-  hipLaunchKernelGGL(kern, dim3(nwg), dim3(Cfg::THREADS), lds_bytes, st, x, reinterpret_cast<const uint4*>(wsp), b, skip, out, Cin,
+  hipLaunchKernelGGL(kern, dim3(nwg, ysplit), dim3(Cfg::THREADS), lds_bytes, st, x, reinterpret_cast<const uint4*>(wsp), b, skip, out, Cin,
                      Cout, D, H, W, Do, Ho, Wo, act, tx, ty, ntiles, tpw, in_bound, w_inv, out_bound);
   return cds_launch_status();
 }
@@ -975,6 +980,14 @@ extern "C" int cds_conv3d_sf16_f32(const float* x, const void* weight_split, con
   if (r != CDS_ZMG_UNSUPPORTED) return r;
   // the tiled kernels in split-f16: the deep layers (conv4 32 -> 32, conv5 32 -> 64 stride 2, conv6 64 -> 64)
   const int mb = (Cout + 15) / 16;
+  // few tiles (the cascade stages' deep layers): one 16-cout block per workgroup, mb workgroups per tile (CDS_SBF_YSPLIT=0: never)
+  const int s_ = stride, Do = (D - 1) / s_ + 1, Ho = (H - 1) / s_ + 1, Wo = (W - 1) / s_ + 1;
+  const long tiles = (long)cds_ceil_div(Wo, s_ == 1 ? 32 : 16) * cds_ceil_div(Ho, 4) * cds_ceil_div(Do, 2);
+  const bool split = tiles <= cds_env_int("CDS_SBF_YSPLIT_TILES", 256) && !cds_env_is("CDS_SBF_YSPLIT", '0');
+  if (split && stride == 1 && (mb == 2 || mb == 4))
+    return launch_fwd<1, 1, 32, 2, false, false, true>(x, weight_split, bias, nullptr, out, Cin, Cout, D, H, W, act, st, in_bound, w_inv_scale, out_bound, mb);
+  if (split && stride == 2 && mb == 4)
+    return launch_fwd<2, 1, 16, 2, false, false, true>(x, weight_split, bias, nullptr, out, Cin, Cout, D, H, W, act, st, in_bound, w_inv_scale, out_bound, mb);
   if (stride == 1 && mb == 2) return launch_fwd<1, 2, 32, 2, false, false, true>(x, weight_split, bias, nullptr, out, Cin, Cout, D, H, W, act, st, in_bound, w_inv_scale, out_bound);
   if (stride == 1 && mb == 4) return launch_fwd<1, 4, 32, 2, false, false, true>(x, weight_split, bias, nullptr, out, Cin, Cout, D, H, W, act, st, in_bound, w_inv_scale, out_bound);
   if (stride == 2 && mb == 4) return launch_fwd<2, 4, 16, 2, false, false, true>(x, weight_split, bias, nullptr, out, Cin, Cout, D, H, W, act, st, in_bound, w_inv_scale, out_bound);
