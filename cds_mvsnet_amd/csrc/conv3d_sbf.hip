@@ -452,6 +452,7 @@ __global__ __launch_bounds__(256, (MERGE ? CDS_DECONV_SBF_MINW : (MB == 1 ? CDS_
   const float xs = F16 ? sf16_scale(in_bound[0]) : 1.0f;
   const float out_mul = F16 ? w_inv / xs : 1.0f;
   float amax = 0.f;
+  const int mbtot = MB * (int)gridDim.y, mb0 = MB * (int)blockIdx.y;   // cout split over gridDim.y workgroups per tile (see conv3d_sbf_kernel)
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -548,13 +549,13 @@ __global__ __launch_bounds__(256, (MERGE ? CDS_DECONV_SBF_MINW : (MB == 1 ? CDS_
         }
       }
       // K-steps of all classes, software-pipelined: the operands of K-step ks + 1 are requested before the MFMAs of ks
-      const uint4* __restrict__ wr = wl + (size_t)rd * Tab::NKS * MB * 3 * 64;
+      const uint4* __restrict__ wr = wl + (size_t)rd * Tab::NKS * mbtot * 3 * 64;
       BV wa[2][MB][3];
       BV bd[2][Cfg::NT][3];
       auto load_w = [&](int buf, int ks) {
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) {
-          const uint4* p = wr + (size_t)((ks * MB + mb) * 3) * 64;
+          const uint4* p = wr + (size_t)((ks * mbtot + mb0 + mb) * 3) * 64;
           wa[buf][mb][0].u = p[0];
           wa[buf][mb][1].u = p[64];
           if (!F16) wa[buf][mb][2].u = p[128];
@@ -600,7 +601,7 @@ __global__ __launch_bounds__(256, (MERGE ? CDS_DECONV_SBF_MINW : (MB == 1 ? CDS_
       float4 bvr[MB];
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb) {
-        const int co = MERGE ? 4 * (g & 1) : mb * 16 + 4 * g;
+        const int co = MERGE ? 4 * (g & 1) : (mb0 + mb) * 16 + 4 * g;
         bvr[mb] = bias ? *reinterpret_cast<const float4*>(bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
       }
 #pragma unroll
@@ -610,7 +611,7 @@ __global__ __launch_bounds__(256, (MERGE ? CDS_DECONV_SBF_MINW : (MB == 1 ? CDS_
         const size_t rowbase = ((size_t)(2 * az + pz) * Ho + (2 * ay + py)) * Wo;
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) {
-          const int co = MERGE ? 4 * (g & 1) : mb * 16 + 4 * g;
+          const int co = MERGE ? 4 * (g & 1) : (mb0 + mb) * 16 + 4 * g;
           const float4 bv = bvr[mb];
 #pragma unroll
           for (int q = 0; q < Cfg::NT; ++q) {
@@ -639,7 +640,7 @@ __global__ __launch_bounds__(256, (MERGE ? CDS_DECONV_SBF_MINW : (MB == 1 ? CDS_
         const size_t rowbase = ((size_t)(2 * az + pz) * Ho + (2 * ay + py)) * Wo;
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) {
-          const int co = MERGE ? 4 * (g & 1) : mb * 16 + 4 * g;
+          const int co = MERGE ? 4 * (g & 1) : (mb0 + mb) * 16 + 4 * g;
 #pragma unroll
           for (int q = 0; q < Cfg::NT; ++q) {
             const int ax = tx_i * Cfg::CX + q * 16 + j;
@@ -672,13 +673,13 @@ __global__ __launch_bounds__(256, (MERGE ? CDS_DECONV_SBF_MINW : (MB == 1 ? CDS_
 template <bool MERGE, int MB, bool F16 = false>
 int launch_deconv(const float* x, const void* wsp, const float* b, const float* skip, float* out, int Cin, int Cout, int D, int H,
                   int W, int act, int out_planar, hipStream_t st, const float* in_bound = nullptr, float w_inv = 1.f,
-                  float* out_bound = nullptr) {
+                  float* out_bound = nullptr, int ysplit = 1) {
   using Cfg = DCfg;
   const int tx = cds_ceil_div(W, Cfg::CX), ty = cds_ceil_div(H, Cfg::CY);
   const int ntiles = tx * ty * D;
   int tpw = max(1, min(16, ntiles / (256 * 2 * 8)));
   const int nwg = cds_ceil_div(ntiles, tpw);
-  hipLaunchKernelGGL((deconv3d_sbf_kernel<MERGE, MB, F16>), dim3(nwg), dim3(256), Cfg::LDSB, st, x, reinterpret_cast<const uint4*>(wsp),
+  hipLaunchKernelGGL((deconv3d_sbf_kernel<MERGE, MB, F16>), dim3(nwg, ysplit), dim3(256), Cfg::LDSB, st, x, reinterpret_cast<const uint4*>(wsp),
                      b, skip, out, Cin, Cout, D, H, W, act, out_planar, tx, ty, ntiles, tpw, in_bound, w_inv, out_bound);
   return cds_launch_status();
 }
@@ -1001,6 +1002,11 @@ extern "C" int cds_deconv3d_sf16_f32(const float* x, const void* weight_split, c
                                      void* stream) {
   if (!x || !weight_split || !out || !in_bound || Cin < 8 || (Cin % 8) || Cout != 32 || D < 1 || H < 1 || W < 1 || !(w_inv_scale > 0.f))
     return CDS_EINVAL;
+  // few tiles (the cascade stages): one 16-cout block per workgroup, two workgroups per tile
+  const long tiles = (long)cds_ceil_div(W, 32) * cds_ceil_div(H, 4) * D;
+  if (tiles <= cds_env_int("CDS_SBF_YSPLIT_TILES", 256) && !cds_env_is("CDS_SBF_YSPLIT", '0'))
+    return launch_deconv<false, 1, true>(x, weight_split, bias, skip, out, Cin, Cout, D, H, W, act, 0, (hipStream_t)stream, in_bound,
+                                         w_inv_scale, out_bound, 2);
   return launch_deconv<false, 2, true>(x, weight_split, bias, skip, out, Cin, Cout, D, H, W, act, 0, (hipStream_t)stream, in_bound,
                                        w_inv_scale, out_bound);
 }

@@ -53,6 +53,9 @@ for name in (sys.argv[1:] or list(SH)):
         c4 = c4 if "c4" in dir() and False else run("conv4", mk(lambda: ops.conv3d_sbf(c3, p["conv4.ws"], p["conv4.b"], 32), c3.numel()), 32, 32, D * h * w // 64)
         c5 = run("conv5", mk(lambda: ops.conv3d_sbf(c4, p["conv5.ws"], p["conv5.b"], 64, stride=2), c4.numel()), 32, 64, D * h * w // 512)
         c6 = run("conv6", mk(lambda: ops.conv3d_sbf(c5, p["conv6.ws"], p["conv6.b"], 64), c5.numel()), 64, 64, D * h * w // 512)
+        if ops.USE_SPLIT_F16 and "conv7.wh" in p:
+            b7 = c6.abs().amax().reshape(1)
+            run("conv7 h", mk(lambda: ops.deconv3d_sbf(c6, p["conv7.wh"], p["conv7.b"], 32, skip=c4, in_bound=b7, w_inv_scale=p["conv7.whs"]), c6.numel() + c4.numel()), 64, 32, D * h * w // 512)
         x7 = run("conv7", mk(lambda: ops.deconv3d_sbf(c6, p["conv7.ws"], p["conv7.b"], 32, skip=c4), c6.numel() + c4.numel()), 64, 32, D * h * w // 512)
         x9 = run("conv9", mk(lambda: ops.deconv3d_zm(x7, p["conv9.wc"], p["conv9.b"], skip=c2), x7.numel() + c2.numel()), 32, 16, D * h * w // 64)
         pr = run("tail", mk(lambda: ops.deconv_prob_zm(x9, p["conv11.wz"], p["conv11.b"], c0, p["prob.tab"]), x9.numel() + c0.numel()), 16, 8, D * h * w // 8)
