@@ -76,7 +76,8 @@ def dyn_f16_setup(c, ks, N, H, W):
     w1, b1, w2 = torch.randn(4, K, generator=g).to(dev), torch.randn(4, generator=g).to(dev), torch.randn(K, 4, generator=g).to(dev)
     epi = torch.tensor([[W * 0.3 + 5.0 * n, -H * 1.7 - n] for n in range(N)], dtype=torch.float32)
     return lambda: ops.dynconv_cl(xcl, wh, None, ks, w1, b1, w2, epi, 0.01, 0.1, in_affine=aff, x_bound=(H * W) ** 0.5, w_inv_scale=winv)
-for name, c, ks, H, W in (("conv01", 8, (3, 5, 7), 592, 800), ("conv10", 16, (3, 5), 592, 800), ("conv20", 32, (1, 3), 296, 400)):
+for name, c, ks, H, W in (("conv01", 8, (3, 5, 7), 592, 800), ("conv10", 16, (3, 5), 592, 800), ("conv20", 32, (1, 3), 296, 400),
+                          ("out2", 16, (1, 3), 592, 800), ("out3", 8, (1, 3), 592, 800)):
     aggr["f16 cl " + name] = dyn_f16_setup(c, ks, N, H, W)
 def conv3d_f16_setup(cin, cout, code, D, H, W):
     x = torch.randn(D, H, W, cin, generator=g).to(dev)
@@ -95,6 +96,19 @@ aggr["f16 cl downsample2"] = down_f16_setup(16, 32, N, 296, 400)
 aggr["f16 conv3d 8->8 pair"] = conv3d_f16_setup(8, 8, ops.SBF_PAIR, 48, 296, 400)
 aggr["f16 conv3d 16->16"] = conv3d_f16_setup(16, 16, 1, 24, 148, 200)
 aggr["f16 conv3d 32->32"] = conv3d_f16_setup(32, 32, 1, 24, 148, 200)
+# round 6: the weight-gradient kernels (fp32 matrix pipe, v_mfma_f32_16x16x4_f32): they run on the side stream of the training step
+from cds_mvsnet_amd import train_ops, train2d_ops
+def wgrad2d_setup(Co, Cin, H, W, k):
+    x, gg = torch.randn(8, Cin, H, W, generator=g).to(dev), torch.randn(8, Co, H, W, generator=g).to(dev)
+    return lambda: train2d_ops.conv2d_wgrad(gg, x, k, 1, (k - 1) // 2)
+def wgrad3d_setup(Ca, Cb, D, h, w, S):
+    x, gg = torch.randn(1, Cb, D, h, w, generator=g).to(dev), torch.randn(1, Ca, D // S, h // S, w // S, generator=g).to(dev)
+    return lambda: train_ops.conv3d_wgrad(gg, x, S)
+aggr["wgrad2d k3 16->19"] = wgrad2d_setup(19, 16, 144, 192, 3)
+aggr["wgrad2d k5 8->11"] = wgrad2d_setup(11, 8, 288, 384, 5)
+aggr["wgrad2d k7 8->11"] = wgrad2d_setup(11, 8, 288, 384, 7)
+aggr["wgrad3d s1 8->8"] = wgrad3d_setup(8, 8, 8, 288, 384, 1)
+aggr["wgrad3d s2 8->16"] = wgrad3d_setup(16, 8, 32, 144, 192, 2)
 xa, xb = torch.randn(N, 296, 400, 32, generator=g).to(dev), torch.randn(N, 592, 800, 16, generator=g).to(dev)
 wt = torch.randn(48, 16, generator=g).to(dev)
 aggr["cl fpn inner1"] = lambda: ops.conv2d_fpn_cl(xa, xb, wt, 16, None, None, 0.1)
@@ -112,10 +126,20 @@ for name, fn in aggr.items():
     if only and not name.startswith(only):
         continue
     fn(); torch.cuda.synchronize()
+    nag = 6
+    if os.environ.get("AGGR_COVER"):      # as many aggressor launches as cover the 12 victim launches in time
+        def _ms(f, n):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(n):
+                f()
+            e1.record(); torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / n
+        nag = max(6, min(2000, int(12 * _ms(victim, 6) / max(_ms(fn, 6), 1e-3)) + 1))
     bad = tot = 0
-    for rep in range(3):
+    for rep in range(int(os.environ.get("AGGR_REPS", "3"))):
         with torch.cuda.stream(sb):
-            for _ in range(6):
+            for _ in range(nag):
                 fn()
         outs = []
         with torch.cuda.stream(sa):
