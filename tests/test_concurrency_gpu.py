@@ -119,3 +119,37 @@ def test_dense_mfma_kernel_does_not_perturb_k1_k3(kind, which, victim, mfma_aggr
     fn, want = victim[which]
     bad, tot = _beside(fn, want, aggressor, n_victims=12)
     assert bad == 0, f"{bad} of {tot} {which} launches beside a dense {'bf16' if kind else 'f16'} MFMA kernel differ from {which} alone"
+
+
+@pytest.mark.parametrize("H,W,N", [(512, 640, 5), (1184, 1600, 5)])
+def test_forward_beside_dense_mfma_kernel_is_bit_identical(H, W, N, mfma_aggressor):
+    """Every kernel of the forward as the VICTIM: the whole cascade beside the synthetic matrix-core kernel must give, bit for bit, the
+    depth / confidence maps it gives alone (the forward is deterministic: no floating-point atomics on the inference path)."""
+    from cds_mvsnet_amd import CDSMVSNet, seeded_init_, synth
+    dev = torch.device("cuda")
+    model = seeded_init_(CDSMVSNet(refine=False, depth_interals_ratio=(4.0, 1.5, 0.75)), 0).eval().to(dev)
+    imgs = synth.make_images(N, H, W, seed=4).to(dev)
+    cams = {k: v.to(dev) for k, v in synth.make_cameras(N, H, W, refine=False, seed=4).items()}
+    dv = synth.make_depth_values().to(dev)
+    keys = [(s_, k) for s_ in ("stage1", "stage2", "stage3") for k in ("depth", "photometric_confidence")]
+    with torch.no_grad():
+        model(imgs, cams, dv, temperature=0.01)
+        alone = model(imgs, cams, dv, temperature=0.01)
+        again = model(imgs, cams, dv, temperature=0.01)
+    torch.cuda.synchronize()
+    for s_, k in keys:
+        assert torch.equal(alone[s_][k], again[s_][k]), f"the forward alone is not deterministic in {s_}.{k}"
+    out = torch.zeros(16, device=dev)
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    n_aggr = 4 if H < 1000 else 12                                      # ~1.5 ms per launch: covers the forward
+    for kind in (0, 1):
+        for rep in range(2):
+            with torch.cuda.stream(sb):
+                for _ in range(n_aggr):
+                    assert mfma_aggressor.mfma_aggressor(kind, out.data_ptr(), 2048, 400, 4, 0, 0, sb.cuda_stream) == 0
+            with torch.cuda.stream(sa), torch.no_grad():
+                got = model(imgs, cams, dv, temperature=0.01)
+            torch.cuda.synchronize()
+            for s_, k in keys:
+                n = int((got[s_][k] != alone[s_][k]).sum())
+                assert n == 0, f"{n} values of {s_}.{k} differ beside a dense {'bf16' if kind else 'f16'} MFMA kernel ({W}x{H}, run {rep})"
