@@ -25,6 +25,7 @@ reading ~390 tensor versions per call (~0.1 ms); ``check_weights=False`` skips t
 """
 from __future__ import annotations
 
+import weakref
 from typing import Dict, Optional, Tuple
 
 import torch
@@ -58,8 +59,10 @@ class CapturedForward:
     """Per-key hipGraphs of ``model.forward_device`` (module docstring).  One runner per model and device; not thread-safe (like the
     module it wraps: one forward at a time per instance)."""
 
-    def __init__(self, model, check_weights: bool = True, warmup: int = 2, max_graphs: int = 8):
-        self.model = model
+    def __init__(self, model, check_weights: bool = True, warmup: int = 2, max_graphs: int = 8, weak: bool = False):
+        # weak: the runner does not keep the model alive (CDSMVSNet.use_graphs registers runners in a WeakKeyDictionary keyed by the
+        # model: a strong reference from the value would pin every model - and the static pools of its graphs - for the process)
+        self._model_ref = weakref.ref(model) if weak else (lambda m=model: m)
         self.check_weights = check_weights
         self.warmup = max(1, int(warmup))
         self.max_graphs = max_graphs
@@ -67,13 +70,20 @@ class CapturedForward:
         self._stream: Optional["torch.cuda.Stream"] = None
         self.captures = 0
 
+    @property
+    def model(self):
+        m = self._model_ref()
+        if m is None:
+            raise RuntimeError("CapturedForward: the model of this runner was garbage-collected")
+        return m
+
     # ---- weights -------------------------------------------------------------------------------------------------------------------
     def _weights_signature(self) -> tuple:
         from .model import _PackedHolder
         sig = []
         for m in self.model.modules():
             if isinstance(m, _PackedHolder):
-                sig.append(tuple((t.data_ptr(), t._version) for t in m._packed._tensors(m)))
+                sig.append((m._packed.generation,) + tuple((t.data_ptr(), t._version) for t in m._packed._tensors(m)))
         return tuple(sig)
 
     # ---- capture -------------------------------------------------------------------------------------------------------------------

@@ -95,9 +95,11 @@ class _Packed:
 
     def __init__(self):
         self._entries: Dict[object, Tuple[tuple, Dict[str, Tensor]]] = {}
+        self.generation = 0       # bumped whenever packed tensors are dropped or rebuilt: a hipGraph holds their ADDRESSES (graphed.py)
 
     def invalidate(self) -> None:
         self._entries = {}
+        self.generation += 1
 
     @staticmethod
     def _tensors(owner: nn.Module) -> List[Tensor]:
@@ -115,6 +117,7 @@ class _Packed:
             with torch.no_grad():
                 hit = (sig, builder())
             self._entries[key] = hit
+            self.generation += 1
         return hit[1]
 
 
@@ -937,7 +940,7 @@ class CDSMVSNet(nn.Module):
         models and nn.DataParallel replicas always run eagerly."""
         if on:
             from .graphed import CapturedForward
-            _GRAPH_RUNNERS[self] = CapturedForward(self, check_weights=check_weights)
+            _GRAPH_RUNNERS[self] = CapturedForward(self, check_weights=check_weights, weak=True)
         else:
             _GRAPH_RUNNERS.pop(self, None)
         return self

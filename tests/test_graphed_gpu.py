@@ -89,6 +89,29 @@ def test_use_graphs_keeps_the_module_surface_and_follows_the_weights():
         e2 = model(*s0, temperature=0.01)
     _assert_equal(g2, e2, "after a weight update")
     assert runner.captures == 2 and not torch.equal(g2["depth"], e0["depth"])
+    # an edit through .data keeps pointer and version: the documented contract is repack() - which must reach the graph too (it holds
+    # the ADDRESSES of the packed tables that repack() drops)
+    model.use_graphs(True)
+    runner = M._GRAPH_RUNNERS[model]
+    g3 = model(*s0, temperature=0.01)
+    with torch.no_grad():
+        for p in model.cost_regularization.parameters():
+            p.data.mul_(0.5)
+    model.repack()
+    g4 = model(*s0, temperature=0.01)
+    model.use_graphs(False)
+    with torch.no_grad():
+        e4 = model(*s0, temperature=0.01)
+    _assert_equal(g4, e4, "after .data edit + repack()")
+    assert runner.captures == 2 and not torch.equal(g4["depth"], g3["depth"])
+    # a model that is dropped takes its runner (and the graphs' static pools) with it
+    import gc, weakref
+    m2 = seeded_init_(CDSMVSNet(refine=False, depth_interals_ratio=(4.0, 1.5, 0.75)), 2).eval().to(dev).use_graphs(True)
+    m2(*s0, temperature=0.01)
+    ref = weakref.ref(m2)
+    del m2
+    gc.collect()
+    assert ref() is None and all(k is not None for k in M._GRAPH_RUNNERS.keys())
     # training mode runs eagerly, whatever the switch says
     model.use_graphs(True)
     assert model.train().training and M._GRAPH_RUNNERS[model].captures == 0

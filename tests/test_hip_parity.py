@@ -139,7 +139,9 @@ def test_costreg(tag, C, dev):
     out_h = net(vol_cl, channels_last=True, bound=vol_cl.abs().amax().reshape(1)).cpu()
     err_h = (out_h - g["cost_reg"]).abs().max()
     assert err_h < 1e-4, err_h
-    assert (out_h - out).abs().max() < 2e-5 and not torch.equal(out_h, out_cl)      # (not equal: the split-f16 layers really ran)
+    from cds_mvsnet_amd import ops as _ops
+    assert (out_h - out).abs().max() < 2e-5
+    assert not torch.equal(out_h, out_cl) or not _ops.USE_SPLIT_F16         # (not equal: the split-f16 layers really ran)
     print(f"CostRegNet {tag}: max |HIP - reference| exact-fp32 {err:.2e}, split-bf16 {err_cl:.2e}, split-f16 conv0-3 {err_h:.2e}")
 
 
@@ -960,6 +962,8 @@ def test_conv3d_split_f16_is_fp32_class(cin, cout, stride, D, H, W, loose, dev, 
     the result scale), on the same inputs (uneven channel scales: magnitudes spread over ~3 decades inside one tensor scale).
     `loose`: the input bound handed to the kernel is that many times the true maximum (any upper bound is valid: it only moves the
     tensor scale - here across a power of two).  The kernel's out_bound must be the exact maximum magnitude of what it stored."""
+    if not ops.USE_SPLIT_F16:
+        pytest.skip("CDS_SPLIT_F16=0: the split-f16 convolution entry is switched off")
     g = torch.Generator().manual_seed(cin * 100 + cout)
     x = torch.randn(cin, D, H, W, generator=g) * torch.exp(torch.randn(cin, 1, 1, 1, generator=g))     # uneven channel scales
     w = torch.randn(cout, cin, 3, 3, 3, generator=g) / (27 * cin) ** 0.5
