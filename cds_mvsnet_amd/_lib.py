@@ -21,6 +21,7 @@ AGG_ACCUMULATE, AGG_NORMALIZE, AGG_CHANNELS_LAST, AGG_FAST_POSITIONS = 1, 2, 4, 
 WARP_FAST_POSITIONS = AGG_FAST_POSITIONS
 MAX_VIEWS = 8
 MAX_IMAGES = 16
+STAGE_STATE_WORDS = 2080
 EINVAL = -1000
 
 P = c_void_p
@@ -33,6 +34,7 @@ L = c_longlong
 SIGNATURES = {
     "cds_version": [],
     "cds_chw_to_hwc_f32": [P, P, I, I, I, P],
+    "cds_stage_inputs_f32": [P, P, P, P, P, P, P, P, P, P, I, I, I, I, P],
     "cds_homo_warp_f32": [P, P, P, P, I, I, I, I, I, P],
     "cds_warp_entropy_f32": [P, P, P, P, P, I, I, I, I, I, I, P],
     "cds_warp_entropy_flags_f32": [P, P, P, P, P, I, I, I, I, I, I, I, P],

@@ -294,6 +294,101 @@ __global__ void chw_to_hwc_kernel(const float* __restrict__ src, float* __restri
 }
 
 // ---------------------------------------------------------------------------------------------
+// The reference-signature boundary of one stage in ONE launch (models/model.py:16-40: `features` is a list over the source
+// views of {'ref': (fea, nc_sum, nc), 'src': (fea, nc_sum, _)}): stack the reference copies' features [V][C][h][w], transpose the
+// source features to the channels-last maps K1 / K3 gather from [V][h][w][C], stack the reference curvature maps, average the
+// per-pair curvature sums over the views (model.py:59-60, same operation order as pair_mean + view_mean), and leave
+// max |ref| x max |src| - the bound of the normalised volume CostRegNet's split-f16 layers scale by - in state[0].
+// Replaces 4 + V launches of the harness (cat, V transposes, 2 abs, 2 amax, mul) and their 4 extra passes over the features.
+// ---------------------------------------------------------------------------------------------
+struct StagePtrs {
+  const float* ref[CDS_MAX_VIEWS];
+  const float* src[CDS_MAX_VIEWS];
+  const float* ref_nc[CDS_MAX_VIEWS];
+  const float* ref_ncsum[CDS_MAX_VIEWS];
+  const float* src_ncsum[CDS_MAX_VIEWS];
+};
+
+__device__ __forceinline__ unsigned wave_umax(unsigned v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = max(v, (unsigned)__shfl_xor((int)v, o));
+  return v;
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void stage_inputs_kernel(StagePtrs ptrs, float* __restrict__ ref_out, float* __restrict__ src_out,
+                                                           float* __restrict__ ref_nc_out, float* __restrict__ nc_mean_out,
+                                                           unsigned* __restrict__ state, int V, int hw) {
+  const int v = blockIdx.y;
+  // |x| as an integer: the order of non-negative floats, with every NaN above +inf (a NaN feature makes the bound NaN, like amax)
+  unsigned mref = 0u, msrc = 0u;
+  const float* __restrict__ rf = ptrs.ref[v];
+  const float* __restrict__ sf = ptrs.src[v];
+  float* __restrict__ ro = ref_out + (size_t)v * C * hw;
+  // ~1024 workgroups walk the pixels with a grid stride and leave one pair of maxima each
+  for (int p = blockIdx.x * 256 + threadIdx.x; p < hw; p += gridDim.x * 256) {
+    float a[C], b[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {       // all loads first: 2 C independent coalesced plane reads in flight
+      a[c] = rf[(size_t)c * hw + p];
+      b[c] = sf[(size_t)c * hw + p];
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      ro[(size_t)c * hw + p] = a[c];
+      mref = max(mref, __float_as_uint(a[c]) & 0x7fffffffu);
+      msrc = max(msrc, __float_as_uint(b[c]) & 0x7fffffffu);
+    }
+    float* __restrict__ so = src_out + ((size_t)v * hw + p) * C;
+#pragma unroll
+    for (int c0 = 0; c0 < C; c0 += 4)
+      *reinterpret_cast<float4*>(so + c0) = make_float4(b[c0], b[c0 + 1], b[c0 + 2], b[c0 + 3]);
+    if (ref_nc_out) ref_nc_out[(size_t)v * hw + p] = ptrs.ref_nc[v][p];
+    if (nc_mean_out && v == 0) {
+      float s = (ptrs.ref_ncsum[0][p] + ptrs.src_ncsum[0][p]) / 2.0f;
+      for (int u = 1; u < V; ++u) s = s + (ptrs.ref_ncsum[u][p] + ptrs.src_ncsum[u][p]) / 2.0f;
+      nc_mean_out[p] = s / (float)V;
+    }
+  }
+  if (!state) return;
+  __shared__ unsigned red[2][4];
+  mref = wave_umax(mref);
+  msrc = wave_umax(msrc);
+  if ((threadIdx.x & 63) == 0) {
+    red[0][threadIdx.x >> 6] = mref;
+    red[1][threadIdx.x >> 6] = msrc;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    // one plain store per workgroup, merged by stage_bound_kernel: same-address device-scope atomics serialise at ~18 ns each on
+    // this part (one per wave of a one-pixel-per-thread grid: 46 000 of them, 0.85 ms at 640x512; one per workgroup of this grid
+    // with a completion counter: still ~0.1 ms)
+    const unsigned nb = gridDim.x * gridDim.y, b = blockIdx.y * gridDim.x + blockIdx.x;
+    state[1 + b] = max(max(red[0][0], red[0][1]), max(red[0][2], red[0][3]));
+    state[1 + nb + b] = max(max(red[1][0], red[1][1]), max(red[1][2], red[1][3]));
+  }
+}
+
+__global__ __launch_bounds__(256) void stage_bound_kernel(unsigned* __restrict__ state, int nb) {
+  unsigned mref = 0u, msrc = 0u;
+  for (int i = threadIdx.x; i < nb; i += 256) {
+    mref = max(mref, state[1 + i]);
+    msrc = max(msrc, state[1 + nb + i]);
+  }
+  __shared__ unsigned red[2][4];
+  mref = wave_umax(mref);
+  msrc = wave_umax(msrc);
+  if ((threadIdx.x & 63) == 0) {
+    red[0][threadIdx.x >> 6] = mref;
+    red[1][threadIdx.x >> 6] = msrc;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0)
+    reinterpret_cast<float*>(state)[0] = __uint_as_float(max(max(red[0][0], red[0][1]), max(red[0][2], red[0][3]))) *
+                                         __uint_as_float(max(max(red[1][0], red[1][1]), max(red[1][2], red[1][3])));
+}
+
+// ---------------------------------------------------------------------------------------------
 // host entry points
 // ---------------------------------------------------------------------------------------------
 // LDS-staged fast paths (warp_lds.hip); return false when the shape is not covered.
@@ -323,6 +418,40 @@ extern "C" int cds_chw_to_hwc_f32(const float* src_chw, float* dst_hwc, int C, i
   int hw = h * w;
   hipLaunchKernelGGL(chw_to_hwc_kernel, dim3(cds_ceil_div(hw, 256)), dim3(256), 0, (hipStream_t)stream, src_chw,
                      dst_hwc, C, hw);
+  return cds_launch_status();
+}
+
+extern "C" int cds_stage_inputs_f32(const float* const* ref_feas, const float* const* src_feas, const float* const* ref_nc,
+                                    const float* const* ref_ncsum, const float* const* src_ncsum, float* ref_chw_out,
+                                    float* src_hwc_out, float* ref_nc_out, float* nc_mean_out, float* state, int V, int C, int h,
+                                    int w, void* stream) {
+  if (!ref_feas || !src_feas || !ref_chw_out || !src_hwc_out || V < 1 || V > CDS_MAX_VIEWS || (C != 8 && C != 16 && C != 32) ||
+      h < 1 || w < 1 || (size_t)h * w > 0x7fffffffu / 32u)
+    return CDS_EINVAL;
+  if ((ref_nc_out && !ref_nc) || (nc_mean_out && (!ref_ncsum || !src_ncsum))) return CDS_EINVAL;
+  StagePtrs ptrs = {};
+  for (int v = 0; v < V; ++v) {
+    if (!ref_feas[v] || !src_feas[v]) return CDS_EINVAL;
+    ptrs.ref[v] = ref_feas[v];
+    ptrs.src[v] = src_feas[v];
+    if (ref_nc_out) { if (!ref_nc[v]) return CDS_EINVAL; ptrs.ref_nc[v] = ref_nc[v]; }
+    if (nc_mean_out) {
+      if (!ref_ncsum[v] || !src_ncsum[v]) return CDS_EINVAL;
+      ptrs.ref_ncsum[v] = ref_ncsum[v];
+      ptrs.src_ncsum[v] = src_ncsum[v];
+    }
+  }
+  const int hw = h * w;
+  const dim3 grid(min(cds_ceil_div(hw, 256), cds_ceil_div(1024, V)), V), block(256);   // <= ~1024 workgroups
+  hipStream_t st = (hipStream_t)stream;
+  unsigned* su = reinterpret_cast<unsigned*>(state);
+#define LAUNCH(CC) \
+  hipLaunchKernelGGL(stage_inputs_kernel<CC>, grid, block, 0, st, ptrs, ref_chw_out, src_hwc_out, ref_nc_out, nc_mean_out, su, V, hw)
+  if (C == 8) LAUNCH(8);
+  else if (C == 16) LAUNCH(16);
+  else LAUNCH(32);
+#undef LAUNCH
+  if (state) hipLaunchKernelGGL(stage_bound_kernel, dim3(1), block, 0, st, su, (int)(grid.x * grid.y));
   return cds_launch_status();
 }
 

@@ -799,7 +799,7 @@ class StageNet(_PackedHolder):
         volume, vis_sum = ops.warp_aggregate(ref_chw, src_hwc, vis, mats, hyp, normalize=normalize, channels_last=channels_last)
         return volume, vis_sum, ent, vis
 
-    def run_single(self, ref_chw, src_hwc, ref_nc, nc_sums, mats, hyp, cost_regularization, stage_idx, vol_bound=None):
+    def run_single(self, ref_chw, src_hwc, ref_nc, nc_sums, mats, hyp, cost_regularization, stage_idx, vol_bound=None, nc_mean=None):
         """One batch item.  ref_chw [V,C,h,w], src_hwc [V,h,w,C], ref_nc [V,h,w], nc_sums [V,h,w] (already
         (ref+src)/2 per view), hyp [D,h,w].  vol_bound: a 1-element device tensor >= max |volume| for CostRegNet's split-f16 layers
         (the model passes 1: its features are tanh outputs); None = max |ref| x max |src|, which bounds the normalised volume - a
@@ -813,7 +813,8 @@ class StageNet(_PackedHolder):
         else:
             depth, conf = ops.softargmin_conf(cost_regularization(volume), hyp)
         del volume
-        nc_mean = ops.view_mean(nc_sums.contiguous())
+        if nc_mean is None:        # (ops.stage_inputs has averaged the per-pair curvature sums already)
+            nc_mean = ops.view_mean(nc_sums.contiguous())
         return depth, conf, nc_mean
 
     def forward(self, features, proj_matrices, depth_values, num_depth, cost_regularization, prob_volume_init=None,
@@ -847,22 +848,34 @@ class StageNet(_PackedHolder):
             geo.add(f"b{b}.mats", geometry.warp_matrices(cams[b]))
         geo.upload(depth_values.device)
         for b in range(B):
-            ref = torch.stack([f["ref"][0][b] for f in features]).contiguous()
-            C, h, w = ref.shape[1:]
-            src = torch.empty((V, h, w, C), dtype=torch.float32, device=ref.device)
-            for v, f in enumerate(features):   # transposed straight into the stacked buffer (no second copy)
-                ops.chw_to_hwc(f["src"][0][b].contiguous(), out=src[v])
-            ref_nc = torch.stack([f["ref"][2][b, 0] for f in features]).contiguous()
-            nc_sums = ops.pair_mean(torch.stack([f["ref"][1][b, 0] for f in features] +
-                                                [f["src"][1][b, 0] for f in features]), V)
+            rf = [f["ref"][0][b] for f in features]
+            sf = [f["src"][0][b] for f in features]
+            maps = ([f["ref"][2][b, 0] for f in features], [f["ref"][1][b, 0] for f in features],
+                    [f["src"][1][b, 0] for f in features])
+            nc_mean = vol_bound = None
+            if V <= ops.MAX_VIEWS and ops.stage_inputs_supported(rf, sf, maps):
+                # the whole re-layout of the reference's feature dicts, the curvature mean and the volume bound in one launch
+                ref, src, ref_nc, nc_mean, vol_bound = ops.stage_inputs(rf, sf, *maps, want_bound=ops.USE_SPLIT_F16)
+                nc_sums = None
+            else:
+                ref = torch.stack(rf).contiguous()
+                C, h, w = ref.shape[1:]
+                src = torch.empty((V, h, w, C), dtype=torch.float32, device=ref.device)
+                for v in range(V):   # transposed straight into the stacked buffer (no second copy)
+                    ops.chw_to_hwc(sf[v].contiguous(), out=src[v])
+                ref_nc = torch.stack(maps[0]).contiguous()
+                nc_sums = ops.pair_mean(torch.stack(maps[1] + maps[2]), V)
             hyp = depth_values[b]
             if hyp.dim() == 1:
                 h, w = ref.shape[-2:]
                 hyp = hyp.view(-1, 1, 1).expand(-1, h, w)
-            d, c, n = self.run_single(ref, src, ref_nc, nc_sums, geo[f"b{b}.mats"], hyp.contiguous(), cost_regularization, stage_idx)
+            d, c, n = self.run_single(ref, src, ref_nc, nc_sums, geo[f"b{b}.mats"], hyp.contiguous(), cost_regularization, stage_idx,
+                                      vol_bound=vol_bound, nc_mean=nc_mean)
             depths.append(d)
             confs.append(c)
             ncs.append(n.unsqueeze(0))
+        if B == 1:      # a batch of one: views of the fresh outputs, no copy
+            return {"depth": depths[0].unsqueeze(0), "photometric_confidence": confs[0].unsqueeze(0), "norm_curv": ncs[0].unsqueeze(0)}
         return {"depth": torch.stack(depths), "photometric_confidence": torch.stack(confs),
                 "norm_curv": torch.stack(ncs)}
 

@@ -6,6 +6,7 @@ contiguous, ROCm-resident tensors and raises otherwise — there is no CPU path.
 """
 from __future__ import annotations
 
+import ctypes
 import os
 from typing import Optional, Tuple
 
@@ -124,6 +125,48 @@ def chw_to_hwc(x: Tensor, out: Optional[Tensor] = None) -> Tensor:
         raise ValueError(f"chw_to_hwc: out must be a contiguous float32 [{h},{w},{C}] tensor on {x.device}")
     check(_lib.load().cds_chw_to_hwc_f32(_dev(x, "x"), out.data_ptr(), C, h, w, _stream(x)), "cds_chw_to_hwc_f32")
     return out
+
+
+USE_STAGE_INPUTS = os.environ.get("CDS_STAGE_INPUTS", "1") != "0"     # A/B knob: 0 = the stack / transpose / amax launches
+
+
+def stage_inputs_supported(ref_feas, src_feas, maps=()) -> bool:
+    """Whether :func:`stage_inputs` covers these per-view tensors (contiguous fp32 maps on one CUDA device, C in 8 / 16 / 32)."""
+    V = len(ref_feas)
+    if not (USE_STAGE_INPUTS and 1 <= V <= MAX_VIEWS and len(src_feas) == V and all(len(m) == V for m in maps)):
+        return False
+    r0 = ref_feas[0]
+    if r0.dim() != 3 or r0.shape[0] not in (8, 16, 32) or not r0.is_cuda:
+        return False
+    ok = lambda t, shape: (t.is_cuda and t.device == r0.device and t.dtype == torch.float32 and t.is_contiguous()
+                           and tuple(t.shape) == shape)
+    return (all(ok(t, tuple(r0.shape)) for t in list(ref_feas) + list(src_feas))
+            and all(ok(t, tuple(r0.shape[1:])) for m in maps for t in m))
+
+
+def stage_inputs(ref_feas, src_feas, ref_nc=None, ref_ncsum=None, src_ncsum=None, want_bound: bool = True):
+    """The reference's per-view feature dicts (models/model.py:16-40) gathered for K1 / K3 in ONE launch (cds_stage_inputs_f32):
+    lists over the V source views of [C,h,w] reference-copy / source features (+ optionally the [h,w] curvature maps) ->
+    (ref_chw [V,C,h,w], src_hwc [V,h,w,C], ref_nc [V,h,w] | None, nc_mean [h,w] | None, bound [1] | None) where
+    bound = max |ref| * max |src| (what ``ref.abs().amax() * src.abs().amax()`` gives: the split-f16 CostRegNet's volume bound)."""
+    maps = [m for m in (ref_nc, ref_ncsum, src_ncsum) if m is not None]
+    if (ref_ncsum is None) != (src_ncsum is None) or not stage_inputs_supported(ref_feas, src_feas, maps):
+        raise ValueError("stage_inputs: V <= MAX_VIEWS contiguous float32 CUDA maps of one shape, C in (8, 16, 32)")
+    V = len(ref_feas)
+    C, h, w = ref_feas[0].shape
+    dev = ref_feas[0].device
+    arr = lambda ts: (ctypes.c_void_p * V)(*[t.data_ptr() for t in ts]) if ts is not None else None
+    ref = torch.empty((V, C, h, w), dtype=torch.float32, device=dev)
+    src = torch.empty((V, h, w, C), dtype=torch.float32, device=dev)
+    nc = torch.empty((V, h, w), dtype=torch.float32, device=dev) if ref_nc is not None else None
+    ncm = torch.empty((h, w), dtype=torch.float32, device=dev) if ref_ncsum is not None else None
+    state = torch.empty(_lib.STAGE_STATE_WORDS, dtype=torch.float32, device=dev) if want_bound else None
+    check(_lib.load().cds_stage_inputs_f32(arr(ref_feas), arr(src_feas), arr(ref_nc), arr(ref_ncsum), arr(src_ncsum), ref.data_ptr(),
+                                           src.data_ptr(), nc.data_ptr() if nc is not None else None,
+                                           ncm.data_ptr() if ncm is not None else None,
+                                           state.data_ptr() if state is not None else None, V, C, h, w, _stream(ref)),
+          "cds_stage_inputs_f32")
+    return ref, src, nc, ncm, (state[0:1] if state is not None else None)
 
 
 def _hyp_args(hyp: Tensor, D_expected: Optional[int], h: int, w: int) -> Tuple[int, int]:

@@ -32,6 +32,7 @@ extern "C" {
 #define CDS_EINVAL (-1000)
 #define CDS_MAX_VIEWS 8 /* source views per launch; more are handled by chunked calls */
 #define CDS_MAX_IMAGES 16 /* images per batched FeatureNet launch */
+#define CDS_STAGE_STATE_WORDS 2080 /* workspace of cds_stage_inputs_f32: 1 + 2 x (<= 1024 + CDS_MAX_VIEWS workgroups), rounded up */
 
 /* activation codes for the conv entry points */
 #define CDS_ACT_NONE 0
@@ -62,6 +63,24 @@ int cds_version(void);
 
 /* [C][h][w] -> [h][w][C] re-layout of one feature map (source maps are gathered channels-last). */
 int cds_chw_to_hwc_f32(const float* src_chw, float* dst_hwc, int C, int h, int w, void* stream);
+
+/*
+ * The reference-signature boundary of one stage in one launch.  models/model.py:16-40 hands StageNet.forward a list over the
+ * source views of {'ref': (fea, nc_sum, nc), 'src': (fea, nc_sum, _)}; this gathers it into the layouts K1 / K3 read:
+ *   ref_feas, src_feas      HOST arrays of V DEVICE pointers, each one [C][h][w] feature map (contiguous fp32)
+ *   ref_nc, ref_ncsum, src_ncsum   HOST arrays of V DEVICE pointers to [h][w] maps (model.py:51,59), or NULL with their outputs
+ *   ref_chw_out [V][C][h][w]   the stacked reference copies
+ *   src_hwc_out [V][h][w][C]   the source maps channels-last (cds_chw_to_hwc_f32 per view)
+ *   ref_nc_out  [V][h][w] | NULL;  nc_mean_out [h][w] | NULL = sum_v ((ref_ncsum[v] + src_ncsum[v]) / 2) / V in view order
+ *                              (= cds_pair_mean_f32 then cds_view_mean_f32, model.py:59-60)
+ *   state [CDS_STAGE_STATE_WORDS] | NULL   device workspace (no initialisation needed); on completion state[0] = max |ref| *
+ *                              max |src|: the bound of the normalised volume, the in_bound of cds_conv3d_sf16_f32's first layer
+ *                              (NaN if a feature is NaN); the rest holds the per-workgroup maxima a second tiny launch merges
+ * V <= CDS_MAX_VIEWS, C in {8, 16, 32}.
+ */
+int cds_stage_inputs_f32(const float* const* ref_feas, const float* const* src_feas, const float* const* ref_nc,
+                         const float* const* ref_ncsum, const float* const* src_ncsum, float* ref_chw_out, float* src_hwc_out,
+                         float* ref_nc_out, float* nc_mean_out, float* state, int V, int C, int h, int w, void* stream);
 
 /*
  * homo_warping_3D (models/utils/warping.py:69-104): bilinear, zero padding, align_corners=True.
