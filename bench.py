@@ -583,6 +583,9 @@ def main():
                          "per-kernel event timing and the roofline object need 1)")
     ap.add_argument("--cpu-sample", type=float, default=1.0,
                     help="linear window fraction for the CPU baseline (1 = the full workload once; 0 = skip)")
+    ap.add_argument("--viewshard-timeout", type=float, default=420.0,
+                    help="N > 1: seconds the view-shard side measurement may take before a watchdog prints the headline line without it "
+                         "and ends the process (below the process group's 10-minute timeout, which aborts without output)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) in production; gloo only for single-GPU dry runs")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed and run the view-shard side measurements also with ONE rank (the RCCL dry run a "
@@ -769,18 +772,7 @@ def main():
     others = None
     if world == 1 and args.streams == 1 and args.workload == "M1" and not args.no_extras:
         others = other_workloads(model, dev)
-    vs = None
-    if (world > 1 or args.force_dist) and kind != "train" and not args.no_viewshard:
-        model._view_shard = None
-        try:
-            vs = measure_viewshard(model, dev, dist, rank, world, args.exchange)
-        except Exception as e:       # noqa: BLE001  (the side measurement must not take the timed headline line down with it)
-            model._view_shard = None
-            vs = {"error": f"{type(e).__name__}: {str(e)[:400]}", "ranks": world, "backend": dist.get_backend()}
-    if rank == 0:
-        cpu = None
-        if world == 1 and args.cpu_sample > 0 and kind == "stage":
-            cpu = cpu_baseline(model_cpu, args.workload, args.cpu_sample, seed=seed, gpu_depth=out["depth"][0] if args.streams == 1 else None)
+    def make_line(vs, cpu):
         line = {
             "metric": metric,
             "value": value, "unit": unit, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -811,7 +803,46 @@ def main():
         if vs is not None:
             line["viewshard"] = vs
             line["strong_scaling"] = strong_scaling_summary(vs)
-        print(json.dumps(line))
+        return line
+
+    vs = None
+    if (world > 1 or args.force_dist) and kind != "train" and not args.no_viewshard:
+        # The view-shard side measurement is the first code of a node run that exchanges data over RCCL between kernels.  It must not
+        # take the timed headline down with it: an exception is recorded in the line; a HANG (ranks disagreeing about a collective) is
+        # cut by a watchdog on every rank that prints the headline line with the failure noted and ends the process before the
+        # process group's own timeout aborts it without output.
+        import threading
+        finished, emit_lock = threading.Event(), threading.Lock()
+
+        def watchdog():
+            if finished.wait(args.viewshard_timeout):
+                return
+            with emit_lock:
+                if finished.is_set():
+                    return
+                if rank == 0:
+                    print(json.dumps(make_line({"error": f"the view-shard side measurement did not finish within {args.viewshard_timeout:.0f} s "
+                                                         "and was abandoned (watchdog); the timed steps above are complete",
+                                                "ranks": world, "backend": args.dist_backend}, None)), flush=True)
+                sys.stdout.flush()
+                os._exit(0)
+
+        threading.Thread(target=watchdog, daemon=True).start()
+        model._view_shard = None
+        try:
+            if os.environ.get("CDS_BENCH_TEST_HANG") == "1":       # tests/test_sharded_gpu.py: the watchdog path itself
+                time.sleep(3600)
+            vs = measure_viewshard(model, dev, dist, rank, world, args.exchange)
+        except Exception as e:       # noqa: BLE001  (the side measurement must not take the timed headline line down with it)
+            model._view_shard = None
+            vs = {"error": f"{type(e).__name__}: {str(e)[:400]}", "ranks": world, "backend": dist.get_backend()}
+        with emit_lock:
+            finished.set()
+    if rank == 0:
+        cpu = None
+        if world == 1 and args.cpu_sample > 0 and kind == "stage":
+            cpu = cpu_baseline(model_cpu, args.workload, args.cpu_sample, seed=seed, gpu_depth=out["depth"][0] if args.streams == 1 else None)
+        print(json.dumps(make_line(vs, cpu)))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -297,3 +297,27 @@ def test_bench_one_rank_over_rccl(tmp_path):
     for mode in ("reduce_scatter", "slab"):
         assert "error" not in vs[mode], vs[mode]
     assert vs["stage"]["ms_per_depth_map"] > 0
+
+
+def test_bench_watchdog_cuts_a_hung_side_measurement(tmp_path):
+    """A view-shard side measurement that hangs (ranks disagreeing about a collective on the first node run) must not cost the timed
+    headline: the watchdog of `bench.py` prints the line with the failure noted and ends the process with exit code 0, well before the
+    process group's own timeout aborts it without output.  `CDS_BENCH_TEST_HANG=1` puts a sleep where the measurement would run."""
+    import json
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+               HSA_ENABLE_IPC_MODE_LEGACY="0", CDS_BENCH_TEST_HANG="1")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--force-dist", "--no-extras",
+           "--no-pmc", "--cpu-sample", "0", "--viewshard-timeout", "3"]
+    t0 = time.time()
+    res = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines
+    line = json.loads(lines[0])
+    assert line["value"] > 0 and line["n_gpus"] == 1 and line["roofline"] is not None
+    assert "watchdog" in line["viewshard"]["error"] and line["strong_scaling"]["stage_M1_ms_per_depth_map"]["allreduce"] is None
+    assert time.time() - t0 < 300
