@@ -306,18 +306,15 @@ def test_bench_watchdog_cuts_a_hung_side_measurement(tmp_path):
     import json
     import subprocess
     import sys
-    import time
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
                HSA_ENABLE_IPC_MODE_LEGACY="0", CDS_BENCH_TEST_HANG="1")
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--force-dist", "--no-extras",
            "--no-pmc", "--cpu-sample", "0", "--viewshard-timeout", "3"]
-    t0 = time.time()
-    res = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    res = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)     # (the sleep is an hour)
     assert res.returncode == 0, res.stderr[-2000:]
     lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, lines
     line = json.loads(lines[0])
     assert line["value"] > 0 and line["n_gpus"] == 1 and line["roofline"] is not None
     assert "watchdog" in line["viewshard"]["error"] and line["strong_scaling"]["stage_M1_ms_per_depth_map"]["allreduce"] is None
-    assert time.time() - t0 < 300
