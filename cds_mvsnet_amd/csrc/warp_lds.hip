@@ -15,6 +15,8 @@
 // Arithmetic and operation order are identical to warp.hip (same cds_taps / cds_interp).
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "warp_common.hpp"
 
 namespace {
@@ -114,17 +116,46 @@ __device__ __forceinline__ void cell_of(const float r[3], const float* __restric
 // so every plane of the chunk lands between the positions of these two (up to fp32 rounding and a projective pole
 // inside the interval, both caught by the fast path's acceptance test); first/last plane alone is not enough because
 // per-pixel hypotheses need not be monotone.
+template <int NMAX>
 __device__ __forceinline__ void chunk_depth_range(const float* __restrict__ hyp, unsigned hw, unsigned pix, int d0, int d1,
                                                   float& dlo, float& dhi) {
   dlo = INFINITY;
   dhi = -INFINITY;
   const float* p = hyp + (size_t)d0 * hw + pix;
+#ifdef CDS_RANGE_SERIAL   // the rolled loop of rounds 2-6 (A/B: scripts/ab/r06_k3_preamble_ab.sh)
 #pragma unroll 8
   for (int d = d0; d < d1; ++d, p += hw) {
     const float v = *p;
     dlo = fminf(dlo, v);
     dhi = fmaxf(dhi, v);
   }
+#else
+  // The planes of the chunk in flight together, 24 per batch (8 for a chunk of at most 8 planes: the D = 8 stage): plane indices are
+  // clamped to the chunk's last plane, so the loads are unconditional and a repeated plane changes neither extreme.  The rolled loop
+  // (eight loads, then a wait, per trip) was six serial memory round trips per workgroup and 48-plane chunk in front of the staging:
+  // K3 -3 % at M1, -3.4 / -1.3 / -2.7 % at the 1600x1184 cascade's stage shapes (profiles/r06_experiments.md).
+  const int nlast = d1 - d0 - 1;
+  auto batch = [&](int k0, auto nb) {
+    constexpr int NB = decltype(nb)::value;
+    float v[NB];
+#pragma unroll
+    for (int k = 0; k < NB; ++k) v[k] = p[(size_t)min(k0 + k, nlast) * hw];
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+      dlo = fminf(dlo, v[k]);
+      dhi = fmaxf(dhi, v[k]);
+    }
+  };
+  if (nlast < 8) {             // block-uniform
+    batch(0, std::integral_constant<int, 8>());
+    return;
+  }
+#pragma unroll
+  for (int k0 = 0; k0 < NMAX; k0 += 24) {
+    batch(k0, std::integral_constant<int, 24>());
+    if (k0 + 24 > nlast) break;   // block-uniform: the rest would repeat the last plane
+  }
+#endif
 }
 
 // Block-wide bounding boxes for NV views.  lo/hi: this thread's cells at the chunk's first and last plane.
@@ -464,7 +495,7 @@ __global__ __launch_bounds__(256, CDS_K3_MINW) void warp_aggregate_lds_kernel(
     for (;;) {
       int cx0[VMAX], cy0[VMAX], cx1[VMAX], cy1[VMAX];
       float dfirst, dlast;
-      chunk_depth_range(hyp, hw, pix, d0, d1, dfirst, dlast);
+      chunk_depth_range<DC>(hyp, hw, pix, d0, d1, dfirst, dlast);
 #pragma unroll
       for (int v = 0; v < VMAX; ++v) {
         cell_of(r[v], mats.m[v] + 9, dfirst, hs, w, g.half_w, g.half_h, cx0[v], cy0[v]);
@@ -719,7 +750,7 @@ __global__ __launch_bounds__(256, (NG == 4 ? 2 : CDS_K1_MINW)) void warp_entropy
     for (;;) {
       int cx0[1], cy0[1], cx1[1], cy1[1];
       float dlo, dhi;
-      chunk_depth_range(hyp, hw, pix, d0, d1, dlo, dhi);
+      chunk_depth_range<DCK>(hyp, hw, pix, d0, d1, dlo, dhi);
       cell_of(r, m + 9, dlo, hs, w, g.half_w, g.half_h, cx0[0], cy0[0]);
       cell_of(r, m + 9, dhi, hs, w, g.half_w, g.half_h, cx1[0], cy1[0]);
       __syncthreads();
