@@ -531,6 +531,34 @@ __global__ __launch_bounds__(256, CDS_K3_MINW) void warp_aggregate_lds_kernel(
     dnext.x = *reinterpret_cast<const float*>(hyp_b + boff);
     dnext.y = *reinterpret_cast<const float*>(hyp_b + min(boff + bstep, blast));
     asm volatile("" ::"v"(dnext.x), "v"(dnext.y));   // delivered before the loop: the loop head then joins two states without pending loads
+    // ACCUMULATE (the second launch of a view list longer than four: BASELINE config 4): the partial sums of a plane pair are read
+    // one iteration AHEAD, like the hypotheses.  Read at the top of their own iteration they were a full memory round trip in front
+    // of the first view's accumulation at two waves per SIMD (1920x1056, N = 7: the accumulating launch 1.76x the first one).
+    // Plane indices are clamped to the chunk's last plane: unconditional loads, the clamped repeats are never used.
+#ifndef CDS_K3_ACC_SERIAL
+    constexpr bool acc_ahead = ACCUMULATE;
+#else
+    constexpr bool acc_ahead = false;
+#endif
+    v2f accn[2][4];
+    auto load_partial = [&](int dp, v2f out[2][4]) {     // planes dp, dp + 1 (clamped) of this pixel
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const unsigned dk = (unsigned)min(dp + k, d1 - 1);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (cl) {
+            const float* pv = vol_cl + ((size_t)dk * hw + pix) * C + 2 * j;
+            out[k][j].x = pv[0];
+            out[k][j].y = pv[1];
+          } else {
+            out[k][j].x = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(volume + (size_t)(2 * j) * slab) + (dk * hw + pix) * 4u);
+            out[k][j].y = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(volume + (size_t)(2 * j + 1) * slab) + (dk * hw + pix) * 4u);
+          }
+        }
+      }
+    };
+    if (acc_ahead) load_partial(d0, accn);
     for (int d = d0; d < d1; d += 2, boff += 2u * bstep) {
       const bool two = d + 1 < d1;
 #ifdef CDS_PROBE_K3_POS
@@ -541,6 +569,16 @@ __global__ __launch_bounds__(256, CDS_K3_MINW) void warp_aggregate_lds_kernel(
       dnext.x = *reinterpret_cast<const float*>(hyp_b + min(boff + 2u * bstep, blast));
       dnext.y = *reinterpret_cast<const float*>(hyp_b + min(boff + 3u * bstep, blast));
       v2f acc[2][4];
+      if (acc_ahead) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            acc[k][j] = (k == 0 || two) ? accn[k][j] : splat2(0.f);
+            if (normalize) acc[k][j] = acc[k][j] * yden;  // partial sums of an earlier launch
+          }
+        load_partial(d + 2, accn);
+      }
       auto init_acc = [&]() {
 #pragma unroll
         for (int k = 0; k < 2; ++k)
@@ -560,7 +598,7 @@ __global__ __launch_bounds__(256, CDS_K3_MINW) void warp_aggregate_lds_kernel(
             }
           }
       };
-      init_acc();
+      if (!acc_ahead) init_acc();
       bool ok = all_staged;
       if (all_staged) {  // block-uniform
         // Software pipeline over the views: the LDS reads of view v+1 are issued while view v is interpolated, and
@@ -856,7 +894,8 @@ bool cds_warp_aggregate_lds_launch(const float* ref, const float* src, const flo
   if (V > 4) {
     // more views than fit the LDS budget: two launches over halves of the view list; the second adds to the first's
     // partial sums (and normalises).  Costs one extra read of the volume, still far cheaper than L1 gathers.
-    const int v1 = (V + 1) / 2;
+    int v1 = (V + 1) / 2;
+    if (const char* e = getenv("CDS_K3_SPLIT")) v1 = (atoi(e) >= 1 && atoi(e) <= 4 && atoi(e) < V && V - atoi(e) <= 4) ? atoi(e) : v1;   // A/B knob
     const size_t hw = (size_t)h * w, hws = (size_t)hs * w;
     const float* wm2 = wm + (size_t)v1 * 12;
     const int keep = flags & (CDS_AGG_CHANNELS_LAST | CDS_AGG_FAST_POSITIONS);
