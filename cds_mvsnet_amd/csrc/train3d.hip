@@ -411,9 +411,9 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_mfma_kernel(const float* __r
   }
 }
 
-inline dim3 ew_grid(size_t V, int C, int B) {
+inline dim3 ew_grid(size_t V, int C, int B, int cap = 512) {
   size_t chunks = (V + 256 * 8 - 1) / (256 * 8);
-  if (chunks > 512) chunks = 512;
+  if (chunks > (size_t)cap) chunks = cap;
   if (chunks < 1) chunks = 1;
   return dim3((unsigned)chunks, C, B);
 }
@@ -422,7 +422,7 @@ inline dim3 ew_grid(size_t V, int C, int B) {
 
 extern "C" int cds_bn3d_stats_f32(const float* x, double* sums, int B, int C, long long V, void* stream) {
   if (!x || !sums || B < 1 || C < 1 || V < 1) return CDS_EINVAL;
-  hipLaunchKernelGGL(bn3d_stats_kernel, ew_grid((size_t)V, C, B), dim3(256), 0, (hipStream_t)stream, x, sums, C, (size_t)V);
+  hipLaunchKernelGGL(bn3d_stats_kernel, ew_grid((size_t)V, C, B, cds_env_int("CDS_BN_RED_CHUNKS", 128)), dim3(256), 0, (hipStream_t)stream, x, sums, C, (size_t)V);
   return cds_launch_status();
 }
 
@@ -440,7 +440,7 @@ extern "C" int cds_bn3d_norm_f32(const float* y, const double* sums, const float
 extern "C" int cds_bn3d_bwd_reduce_f32(const float* dout, const float* y, const float* scale, const float* shift, double* sums,
                                        int B, int C, long long V, int relu, void* stream) {
   if (!dout || !y || !scale || !shift || !sums || B < 1 || C < 1 || V < 1) return CDS_EINVAL;
-  hipLaunchKernelGGL(bn3d_bwd_reduce_kernel, ew_grid((size_t)V, C, B), dim3(256), 0, (hipStream_t)stream, dout, y, scale, shift,
+  hipLaunchKernelGGL(bn3d_bwd_reduce_kernel, ew_grid((size_t)V, C, B, cds_env_int("CDS_BN_RED_CHUNKS", 128)), dim3(256), 0, (hipStream_t)stream, dout, y, scale, shift,
                      sums, C, (size_t)V, relu);
   return cds_launch_status();
 }
