@@ -467,6 +467,18 @@ def test_warp_kernels_vs_oracle_odd_shapes(V, C, D, h, w, exact, dev, ops):
     assert (vis_sum.cpu() - vis.sum(0)).abs().max() < 1e-6
 
 
+@pytest.mark.parametrize("V,C,D,h,w", [(6, 16, 49, 24, 72), (7, 8, 13, 12, 70), (5, 32, 7, 16, 40)])
+def test_warp_aggregate_two_launches_channels_last_equals_planar(V, C, D, h, w, dev, ops):
+    """More than four source views = two launches, the second one reading the first one's partial sums one plane pair ahead (round 6).
+    The channels-last volume (what CostRegNet's matrix-core kernels read; the layout of the cascade forward at N = 7) must be the planar
+    one bit for bit, also for an odd number of planes (a last pair with one plane) and chunks shorter than a pair's look-ahead."""
+    feats, cams, hyp, ref, src, mats, hyp_d = _random_stage(ops, dev, V, C, D, h, w, seed=70 + V)
+    vis = (torch.rand(V, h, w, generator=torch.Generator().manual_seed(3)) * 0.8 + 0.1).to(dev).contiguous()
+    planar, vs0 = ops.warp_aggregate(ref, src, vis, mats, hyp_d, exact=True)
+    cl, vs1 = ops.warp_aggregate(ref, src, vis, mats, hyp_d, exact=True, channels_last=True)
+    assert torch.equal(cl.permute(3, 0, 1, 2), planar) and torch.equal(vs0, vs1)
+
+
 def test_fast_positions_leave_the_parity_tolerance_at_full_width(dev, ops):
     """Why the reference-order positions are the default: at w = 640 the fast form p.xy * rcp(z) and the
     reference's normalise / de-normalise round trip place the samples up to ~1e-4 px apart; on sharp feature maps that moves
